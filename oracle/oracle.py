@@ -1,0 +1,261 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+numpy/ctypes front-end of the C restatement in ``sptk_oracle.c`` (the CPU restatement of
+the sp-nitech/diffsptk STFT -> mel-cepstrum / LPC path).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module.  The product package ``diffsptk_amd`` never does.
+
+Pinned against golden vectors generated from the reference itself
+(``tests/golden/make_golden.py``), see ``tests/test_oracle_golden.py``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsptk_oracle.so")
+_lib = None
+
+WINDOWS = {
+    "blackman": 0, "hamming": 1, "hanning": 2, "bartlett": 3, "trapezoidal": 4,
+    "rectangular": 5, "nuttall": 6, "povey": 7, "sine": 8, "vorbis": 9, "kbd": 10,
+}
+NORMS = {"none": 0, "power": 1, "magnitude": 2}
+PAD_MODES = {"constant": 0, "reflect": 1, "replicate": 2, "circular": 3}
+SPEC_FORMATS = {"db": 0, "log-magnitude": 1, "magnitude": 2, "power": 3, "complex": 4}
+FFTR_FORMATS = {"complex": 0, "real": 1, "imaginary": 2, "amplitude": 3, "power": 4}
+ACORR_FORMATS = {"naive": 0, "normalized": 1, "biased": 2, "unbiased": 3}
+
+
+def build(force: bool = False) -> str:
+    """Compile the C oracle (gcc) if needed and return the library path."""
+    src = [os.path.join(_HERE, f) for f in ("sptk_oracle.c", "sptk_oracle_impl.h")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libsptk_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _sfx(dtype) -> str:
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return "_f32"
+    if dtype == np.float64:
+        return "_f64"
+    raise TypeError(f"oracle supports float32/float64, got {dtype}")
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _real(dtype):
+    return C.c_float if np.dtype(dtype) == np.float32 else C.c_double
+
+
+def _code(table, key):
+    return key if isinstance(key, int) else table[key]
+
+
+def _as2d(x):
+    x = np.ascontiguousarray(x)
+    return x.reshape(-1, x.shape[-1]), x.shape[:-1]
+
+
+def num_frames(T: int, P: int) -> int:
+    return 0 if T <= 0 else (T - 1) // P + 1
+
+
+def window_table(L, window="blackman", norm="power", symmetric=True, dtype=np.float64):
+    w = np.empty(L, dtype=np.float64)
+    rc = lib().oracle_window_table(_code(WINDOWS, window), int(L), _code(NORMS, norm),
+                                   int(bool(symmetric)), _ptr(w))
+    if rc != 0:
+        raise ValueError("unsupported window configuration")
+    return w.astype(dtype)
+
+
+def frame(x, L, P, center=True, zmean=False, mode="constant"):
+    x2, lead = _as2d(x)
+    B, T = x2.shape
+    N = num_frames(T, P)
+    y = np.empty((B, N, L), dtype=x2.dtype)
+    fn = getattr(lib(), "oracle_frame" + _sfx(x2.dtype))
+    fn(_ptr(x2), C.c_long(B), C.c_long(T), int(L), int(P), int(center), int(zmean),
+       _code(PAD_MODES, mode), _ptr(y))
+    return y.reshape(*lead, N, L)
+
+
+def window(x, w, out_length=None):
+    x2, lead = _as2d(x)
+    F, L = x2.shape
+    L2 = L if out_length is None else out_length
+    w = np.ascontiguousarray(w, dtype=x2.dtype)
+    y = np.empty((F, L2), dtype=x2.dtype)
+    getattr(lib(), "oracle_window" + _sfx(x2.dtype))(_ptr(x2), C.c_long(F), L, _ptr(w), L2, _ptr(y))
+    return y.reshape(*lead, L2)
+
+
+def fftr(x, fft_length=None, out_format="complex"):
+    x2, lead = _as2d(x)
+    F, Lin = x2.shape
+    n = Lin if fft_length is None else fft_length
+    fmt = _code(FFTR_FORMATS, out_format)
+    K = n // 2 + 1
+    y = np.empty((F, K, 2) if fmt == 0 else (F, K), dtype=x2.dtype)
+    getattr(lib(), "oracle_fftr" + _sfx(x2.dtype))(_ptr(x2), C.c_long(F), min(Lin, n), n, fmt, _ptr(y))
+    if fmt == 0:
+        return (y[..., 0] + 1j * y[..., 1]).reshape(*lead, K)
+    return y.reshape(*lead, K)
+
+
+def spec(b=None, a=None, fft_length=512, eps=0.0, relative_floor=None, out_format="power"):
+    ref = b if b is not None else a
+    b2 = _as2d(np.asarray(b))[0] if b is not None else None
+    a2 = _as2d(np.asarray(a))[0] if a is not None else None
+    dt = np.asarray(ref).dtype
+    lead = np.asarray(ref).shape[:-1]
+    F = (b2 if b2 is not None else a2).shape[0]
+    K = fft_length // 2 + 1
+    y = np.empty((F, K), dtype=dt)
+    R = _real(dt)
+    getattr(lib(), "oracle_spec" + _sfx(dt))(
+        _ptr(b2), 0 if b2 is None else b2.shape[1], _ptr(a2), 0 if a2 is None else a2.shape[1],
+        C.c_long(F), int(fft_length), R(eps), int(relative_floor is not None),
+        R(0.0 if relative_floor is None else relative_floor), _code(SPEC_FORMATS, out_format), _ptr(y))
+    return y.reshape(*lead, K)
+
+
+def stft(x, frame_length, frame_period, fft_length, *, center=True, zmean=False,
+         mode="constant", window="blackman", norm="power", symmetric=True, eps=1e-9,
+         relative_floor=None, out_format="power"):
+    x2, lead = _as2d(x)
+    B, T = x2.shape
+    dt = x2.dtype
+    N = num_frames(T, frame_period)
+    K = fft_length // 2 + 1
+    fmt = _code(SPEC_FORMATS, out_format)
+    w = window_table(frame_length, window, norm, symmetric, dtype=dt)
+    y = np.empty((B, N, K, 2) if fmt == 4 else (B, N, K), dtype=dt)
+    R = _real(dt)
+    getattr(lib(), "oracle_stft" + _sfx(dt))(
+        _ptr(x2), C.c_long(B), C.c_long(T), int(frame_length), int(frame_period),
+        int(fft_length), _ptr(w), int(center), int(zmean), _code(PAD_MODES, mode), R(eps),
+        int(relative_floor is not None), R(0.0 if relative_floor is None else relative_floor),
+        fmt, _ptr(y))
+    if fmt == 4:
+        return (y[..., 0] + 1j * y[..., 1]).reshape(*lead, N, K)
+    return y.reshape(*lead, N, K)
+
+
+def freqt_matrix(in_order, out_order, alpha, dtype=np.float64):
+    At = np.empty((in_order + 1, out_order + 1), dtype=dtype)
+    getattr(lib(), "oracle_freqt_matrix" + _sfx(dtype))(int(in_order), int(out_order),
+                                                        C.c_double(alpha), _ptr(At))
+    return At
+
+
+def rfreqt_matrix(in_order, out_order, alpha, dtype=np.float64):
+    At = np.empty((in_order + 1, out_order + 1), dtype=dtype)
+    getattr(lib(), "oracle_rfreqt_matrix" + _sfx(dtype))(int(in_order), int(out_order),
+                                                         C.c_double(alpha), _ptr(At))
+    return At
+
+
+def freqt(c, out_order, alpha=0.0):
+    c2, lead = _as2d(c)
+    F, L1 = c2.shape
+    At = freqt_matrix(L1 - 1, out_order, alpha, dtype=c2.dtype)
+    out = np.empty((F, out_order + 1), dtype=c2.dtype)
+    getattr(lib(), "oracle_matmul" + _sfx(c2.dtype))(_ptr(c2), C.c_long(F), L1, _ptr(At),
+                                                     out_order + 1, _ptr(out))
+    return out.reshape(*lead, out_order + 1)
+
+
+def mcep(X, cep_order, alpha=0.0, n_iter=0, return_trace=False):
+    X2, lead = _as2d(X)
+    F, K = X2.shape
+    n = 2 * (K - 1)
+    dt = X2.dtype
+    mc = np.empty((F, cep_order + 1), dtype=dt)
+    trace = np.empty((n_iter + 1, F, cep_order + 1), dtype=dt) if return_trace else None
+    rc = getattr(lib(), "oracle_mcep" + _sfx(dt))(_ptr(X2), C.c_long(F), n, int(cep_order),
+                                                  C.c_double(alpha), int(n_iter), _ptr(mc), _ptr(trace))
+    if rc != 0:
+        raise np.linalg.LinAlgError("singular Toeplitz-plus-Hankel system")
+    mc = mc.reshape(*lead, cep_order + 1)
+    if return_trace:
+        return mc, trace.reshape(n_iter + 1, *lead, cep_order + 1)
+    return mc
+
+
+def acorr(x, acr_order, out_format="naive"):
+    x2, lead = _as2d(x)
+    F, L = x2.shape
+    r = np.empty((F, acr_order + 1), dtype=x2.dtype)
+    getattr(lib(), "oracle_acorr" + _sfx(x2.dtype))(_ptr(x2), C.c_long(F), L, int(acr_order),
+                                                    _code(ACORR_FORMATS, out_format), _ptr(r))
+    return r.reshape(*lead, acr_order + 1)
+
+
+def _default_eps(dtype, eps):
+    if eps is None:  # levdur.py:108-109
+        return 1e-5 if np.dtype(dtype) == np.float32 else 0.0
+    return eps
+
+
+def levdur(r, eps=None):
+    r2, lead = _as2d(r)
+    F, M1 = r2.shape
+    out = np.empty((F, M1), dtype=r2.dtype)
+    R = _real(r2.dtype)
+    rc = getattr(lib(), "oracle_levdur" + _sfx(r2.dtype))(_ptr(r2), C.c_long(F), M1 - 1,
+                                                          R(_default_eps(r2.dtype, eps)), _ptr(out))
+    if rc != 0:
+        raise np.linalg.LinAlgError("singular Yule-Walker system")
+    return out.reshape(*lead, M1)
+
+
+def lpc(x, lpc_order, eps=None):
+    x2, lead = _as2d(x)
+    F, L = x2.shape
+    out = np.empty((F, lpc_order + 1), dtype=x2.dtype)
+    R = _real(x2.dtype)
+    rc = getattr(lib(), "oracle_lpc" + _sfx(x2.dtype))(_ptr(x2), C.c_long(F), L, int(lpc_order),
+                                                       R(_default_eps(x2.dtype, eps)), _ptr(out))
+    if rc != 0:
+        raise np.linalg.LinAlgError("singular Yule-Walker system")
+    return out.reshape(*lead, lpc_order + 1)
+
+
+def stft_mcep(x, *, frame_length=400, frame_period=80, fft_length=512, cep_order=24,
+              alpha=0.42, n_iter=10, **stft_kw):
+    """The headline path: STFT power -> mel-cepstrum."""
+    return mcep(stft(x, frame_length, frame_period, fft_length, **stft_kw), cep_order, alpha, n_iter)
+
+
+def frame_window_lpc(x, *, frame_length=400, frame_period=80, lpc_order=24, eps=1e-5,
+                     window="blackman", norm="power"):
+    """The LPC branch: Frame -> Window -> LPC (README.md:198-201 of the reference)."""
+    fr = frame(x, frame_length, frame_period)
+    w = window_table(frame_length, window, norm, True, dtype=fr.dtype)
+    return lpc(window_apply(fr, w), lpc_order, eps)
+
+
+def window_apply(x, w):
+    return window(x, w, None)
