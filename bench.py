@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/sec of STFT -> mel-cepstrum (fl=400 fp=80 nfft=512 M=24,
+alpha=0.42, n_iter=10) on synthetic 16 kHz waveforms, one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]           (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over this rank's shard of utterances (inputs resident in
+HBM): fused STFT kernel -> mel-cepstral analysis kernel -> (N > 1) ONE all-gather of the
+(B, 200, 25) features over RCCL.  Weak scaling: 1024 utterances x 1 s per GPU, so N = 8 is
+BASELINE.json configs[4] (batch 8192 sharded 8x) and N = 1 is its per-GPU shard.
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying, besides the headline
+value, `roofline` for the dominant kernel (mel-cepstral analysis, fp32 MFMA/VALU bound),
+`roofline_stft` for the fused Frame+Window+rFFT stage (HBM bound) and `cpu_baseline`
+(the reference's op sequence with stock PyTorch CPU ops, oracle/torch_port.py, on a bounded
+sample; N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FL, FP, NFFT, M, ALPHA, N_ITER = 400, 80, 512, 24, 0.42, 10
+SAMPLES = 16000
+FRAMES_PER_UTT = (SAMPLES - 1) // FP + 1  # 200
+
+# algorithmic work per frame (DESIGN.md section "Kernels and rooflines")
+STFT_BYTES_PER_FRAME = FP * 4 + (NFFT // 2 + 1) * 4  # 320 B read + 1028 B written = 1348 B
+K, M1, M2 = NFFT // 2 + 1, M + 1, 2 * M + 1
+_SOLVE_MAC = M1 ** 3 // 3 + M1 * M1  # Cholesky-class elimination + substitutions
+MCEP_FLOP_PER_FRAME = 2 * (K * M1 + N_ITER * (M1 * K + K * M2 + _SOLVE_MAC)) + (N_ITER + 1) * K
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_PEAK_TFLOPS = 157.3    # fp32 MFMA dense peak = fp32 vector peak (same guide)
+
+
+def cpu_baseline(seconds_budget: float = 12.0):
+    """Reference CPU path (stock ATen ops, oracle/torch_port.py) on a bounded sample."""
+    from oracle import torch_port as TP
+
+    threads = torch.get_num_threads()
+    B = 32
+    x = torch.randn(B, SAMPLES, generator=torch.Generator().manual_seed(0))
+    tab = TP.McepTables(NFFT, M, ALPHA, torch.float32)
+    w = TP.window_table(FL, dtype=torch.float32)
+    times = []
+    with torch.no_grad():
+        TP.stft_mcep(x[:4], tab, FL, FP, N_ITER, w)  # warm-up
+        t_all = time.perf_counter()
+        while len(times) < 3 or (time.perf_counter() - t_all < seconds_budget and len(times) < 50):
+            t0 = time.perf_counter()
+            TP.stft_mcep(x, tab, FL, FP, N_ITER, w)
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {
+        "value": B * FRAMES_PER_UTT / med, "unit": "frames/s", "cores": threads, "kind": "port",
+        "sample": f"{B} utterances x 1 s (={B * FRAMES_PER_UTT} frames) STFT->mcep fwd, float32, "
+                  f"stock torch CPU ops (oracle/torch_port.py), median of {len(times)} runs",
+    }
+
+
+def c_oracle_baseline():
+    """The C restatement (oracle/sptk_oracle.c, OpenMP over frames in mcep) on a small sample."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    B = 8
+    x = np.random.default_rng(0).standard_normal((B, SAMPLES)).astype(np.float32)
+    O.stft_mcep(x[:1])
+    t0 = time.perf_counter()
+    O.stft_mcep(x)
+    dt = time.perf_counter() - t0
+    return {"value": B * FRAMES_PER_UTT / dt, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{B} utterances x 1 s, C oracle (naive mixed-radix FFT + LU), float32, single run"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="utterances per GPU (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--algo", choices=["auto", "generic", "tuned"], default="auto")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import diffsptk_amd as dsp
+    from diffsptk_amd import _lib, ops
+    from diffsptk_amd.dist import all_gather_features
+
+    algo = {"auto": _lib.ALGO_AUTO, "generic": _lib.ALGO_GENERIC, "tuned": _lib.ALGO_TUNED}[args.algo]
+    B = args.batch
+    x = torch.randn(B, SAMPLES, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
+    stft = dsp.STFT(FL, FP, NFFT, device=dev)
+    mcep = dsp.MelCepstralAnalysis(fft_length=NFFT, cep_order=M, alpha=ALPHA, n_iter=N_ITER, device=dev)
+
+    def step():
+        X = ops.StftFn.apply(x, stft.window, stft.twiddle, FL, FP, NFFT, True, False, "constant", 1e-9, None, 3, algo)
+        mc = ops.McepFn.apply(X, mcep.G, mcep.D, mcep.E, mcep.alpha_vector, NFFT, M, N_ITER, algo)
+        return all_gather_features(mc, B * world) if world > 1 else mc
+
+    kernels = {}
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            X = ops.StftFn.apply(x, stft.window, stft.twiddle, FL, FP, NFFT, True, False, "constant", 1e-9, None, 3, algo)
+            kernels["stft"] = _lib.last_kernel()
+            ops.McepFn.apply(X, mcep.G, mcep.D, mcep.E, mcep.alpha_vector, NFFT, M, N_ITER, algo)
+            kernels["mcep"] = _lib.last_kernel()
+            del X
+        for _ in range(args.warmup):
+            step()
+        # per-kernel HIP events on the launch stream (torch's current stream), inside the timed region
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            ev[i][0].record()
+            X = ops.StftFn.apply(x, stft.window, stft.twiddle, FL, FP, NFFT, True, False, "constant", 1e-9, None, 3, algo)
+            ev[i][1].record()
+            mc = ops.McepFn.apply(X, mcep.G, mcep.D, mcep.E, mcep.alpha_vector, NFFT, M, N_ITER, algo)
+            ev[i][2].record()
+            out = all_gather_features(mc, B * world) if world > 1 else mc
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    assert out.shape == (B * world, FRAMES_PER_UTT, M1) and bool(torch.isfinite(out).all())
+
+    frames_rank = B * FRAMES_PER_UTT
+    t_stft = statistics.mean(e[0].elapsed_time(e[1]) for e in ev) * 1e-3
+    t_mcep = statistics.mean(e[1].elapsed_time(e[2]) for e in ev) * 1e-3
+    if rank == 0:
+        res = {
+            "metric": "frames/sec STFT->mcep (fl=400 fp=80 nfft=512 M=24)",
+            "value": frames_rank * world * args.steps / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[4] per-GPU shard: STFT->mcep forward, {B} utterances x 1 s @ 16 kHz "
+                            f"per GPU ({frames_rank} frames), alpha={ALPHA} n_iter={N_ITER}; N=8 is the full "
+                            "8192-utterance batch; features all-gathered over RCCL when N>1",
+                "utterances_per_gpu": B, "global_batch": B * world, "frames_per_step": frames_rank * world,
+                "parallelism": f"dp{world}", "kernels": kernels,
+            },
+            "roofline": {
+                "kernel": kernels["mcep"], "bound": "mfma",
+                "achieved": MCEP_FLOP_PER_FRAME * frames_rank / t_mcep / 1e12,
+                "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": MCEP_FLOP_PER_FRAME * frames_rank / t_mcep / 1e12 / FP32_PEAK_TFLOPS,
+                "traffic": None, "avg_launch_ms": t_mcep * 1e3,
+                "flop_per_frame": MCEP_FLOP_PER_FRAME,
+                "note": "fp32 MFMA dense peak == fp32 vector peak (157.3 TFLOP/s); flops are the composed-matrix "
+                        "algorithm's (DESIGN.md), lower than the reference formulation's 0.71-0.75 MFLOP/frame",
+            },
+            "roofline_stft": {
+                "kernel": kernels["stft"], "bound": "hbm",
+                "achieved": STFT_BYTES_PER_FRAME * frames_rank / t_stft / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": STFT_BYTES_PER_FRAME * frames_rank / t_stft / 1e9 / HBM_PEAK_GBS,
+                "traffic": None, "avg_launch_ms": t_stft * 1e3, "bytes_per_frame": STFT_BYTES_PER_FRAME,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+            res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+            try:
+                res["cpu_baseline_c_oracle"] = c_oracle_baseline()
+            except Exception as e:  # the oracle is optional test infrastructure
+                res["cpu_baseline_c_oracle"] = {"error": str(e)}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

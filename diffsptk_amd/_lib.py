@@ -1,0 +1,134 @@
+"""Loader / builder of the C-ABI shared library (include/diffsptk_amd.h).
+
+The library is built IN-TREE by hipcc for gfx950 (``build()``; ``__graft_entry__.build()`` calls
+it) and loaded with ctypes.  There is no CPU fallback: if the library is missing, or no HIP
+device is visible, the ops raise -- they never silently compute elsewhere.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+CSRC = os.path.join(_PKG, "csrc")
+LIB_DIR = os.path.join(_PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libdiffsptk_amd.so")
+SOURCES = ("stft.hip", "mcep.hip", "mcep_mfma.hip", "lpc.hip")
+HIPCC_FLAGS = (
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+    "-mcode-object-version=5", "-Wno-unused-value", "-ffp-contract=on",
+)
+
+F32, F64 = 0, 1
+ALGO_AUTO, ALGO_GENERIC, ALGO_TUNED = 0, 1, 2
+
+_lib = None
+
+
+class BackendError(RuntimeError):
+    """The HIP library is missing, failed to load, or a call returned an error status."""
+
+
+def _sources():
+    files = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = files + [os.path.join(CSRC, "common.h"), os.path.join(_ROOT, "include", "diffsptk_amd.h")]
+    return files, deps
+
+
+def is_stale() -> bool:
+    _, deps = _sources()
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into one shared library (cross-compiles w/o GPU)."""
+    if not force and not is_stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise BackendError("hipcc not found: cannot build libdiffsptk_amd.so")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    files, _ = _sources()
+    tmp = LIB_PATH + ".tmp"
+    cmd = [hipcc, *HIPCC_FLAGS, "-o", tmp, *files]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise BackendError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, LIB_PATH)
+    global _lib
+    _lib = None
+    return LIB_PATH
+
+
+# name -> (restype, argtypes); mirrors include/diffsptk_amd.h
+_P, _I, _L, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+SIGNATURES = {
+    "dsa_version": (C.c_int, []),
+    "dsa_last_error": (C.c_char_p, []),
+    "dsa_device_count": (C.c_int, []),
+    "dsa_last_kernel": (C.c_char_p, []),
+    "dsa_num_frames": (C.c_int64, [_L, _I]),
+    "dsa_frame_fwd": (C.c_int, [_P, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dsa_frame_bwd": (C.c_int, [_P, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "dsa_window_fwd": (C.c_int, [_P, _L, _I, _P, _I, _I, _P, _P]),
+    "dsa_window_bwd": (C.c_int, [_P, _P, _L, _I, _P, _I, _I, _P, _P, _P]),
+    "dsa_fftr_fwd": (C.c_int, [_P, _L, _I, _I, _I, _P, _I, _P, _P]),
+    "dsa_fftr_bwd": (C.c_int, [_P, _P, _L, _I, _I, _I, _P, _I, _P, _P]),
+    "dsa_spec_fwd": (C.c_int, [_P, _I, _P, _I, _L, _I, _D, _I, _D, _I, _P, _I, _P, _P]),
+    "dsa_spec_bwd": (C.c_int, [_P, _P, _I, _P, _I, _L, _I, _D, _I, _D, _I, _P, _I, _P, _P, _P]),
+    "dsa_stft_fwd": (C.c_int, [_P, _L, _L, _I, _I, _I, _P, _P, _I, _I, _I, _D, _I, _D, _I, _I, _I, _P, _P]),
+    "dsa_stft_bwd": (C.c_int, [_P, _P, _L, _L, _I, _I, _I, _P, _P, _I, _I, _I, _D, _I, _D, _I, _I, _I, _P, _P, _P]),
+    "dsa_freqt_fwd": (C.c_int, [_P, _L, _I, _P, _I, _I, _P, _P]),
+    "dsa_freqt_bwd": (C.c_int, [_P, _L, _I, _P, _I, _I, _P, _P]),
+    "dsa_mcep_fwd": (C.c_int, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "dsa_mcep_bwd": (C.c_int, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "dsa_acorr_fwd": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P]),
+    "dsa_acorr_bwd": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, _P, _P]),
+    "dsa_levdur_fwd": (C.c_int, [_P, _L, _I, _D, _I, _P, _P]),
+    "dsa_levdur_bwd": (C.c_int, [_P, _P, _P, _L, _I, _D, _I, _P, _P]),
+    "dsa_lpc_fwd": (C.c_int, [_P, _L, _I, _I, _D, _I, _P, _P]),
+    "dsa_lpc_bwd": (C.c_int, [_P, _P, _P, _L, _I, _I, _D, _I, _P, _P]),
+    "dsa_frame_window_lpc_fwd": (C.c_int, [_P, _L, _L, _I, _I, _P, _I, _I, _I, _D, _I, _P, _P]),
+}
+
+
+def load():
+    """Load the library (after torch, so both share one HIP runtime) and bind signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  diffsptk_amd has no CPU fallback."
+        )
+    import torch  # noqa: F401  (loads torch's libamdhip64.so first: one runtime per process)
+
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise BackendError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().dsa_last_error().decode(errors="replace")
+        raise BackendError(f"{what or 'diffsptk_amd call'} failed (status {rc}): {msg}")
+
+
+def last_kernel() -> str:
+    return load().dsa_last_kernel().decode()

@@ -1,0 +1,143 @@
+// Shared host/device helpers for the diffsptk_amd HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/diffsptk_amd.h"
+
+#define DSA_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace dsa {
+
+// ---- per-thread error / dispatch record -------------------------------------------------
+inline char* err_buf()
+{
+    static thread_local char buf[512] = "";
+    return buf;
+}
+inline const char*& kernel_name()
+{
+    static thread_local const char* name = "";
+    return name;
+}
+inline int fail(int code, const char* fmt, const char* detail = "")
+{
+    snprintf(err_buf(), 512, fmt, detail);
+    return code;
+}
+inline int check_launch(const char* name)
+{
+    kernel_name() = name;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(err_buf(), 512, "%s: launch failed: %s", name, hipGetErrorString(e));
+        return DSA_ERR_LAUNCH;
+    }
+    return DSA_OK;
+}
+
+#define DSA_REQUIRE(cond, msg)                                              \
+    do {                                                                    \
+        if (!(cond)) return dsa::fail(DSA_ERR_INVALID_ARGUMENT, "%s", msg); \
+    } while (0)
+
+// ---- device helpers ------------------------------------------------------------------------
+// F.pad index semantics of Frame (frame.py:134-137).  i indexes the UN-padded signal of
+// length T; returns the source index, or -1 for a zero (constant mode).
+__device__ __forceinline__ long pad_src_index(long i, long T, int mode)
+{
+    if (i >= 0 && i < T) return i;
+    switch (mode) {
+    case DSA_PAD_REFLECT: {
+        if (T == 1) return 0;
+        long period = 2 * (T - 1);
+        long j = i % period;
+        if (j < 0) j += period;
+        return j < T ? j : period - j;
+    }
+    case DSA_PAD_REPLICATE: return i < 0 ? 0 : T - 1;
+    case DSA_PAD_CIRCULAR: {
+        long j = i % T;
+        if (j < 0) j += T;
+        return j;
+    }
+    default: return -1;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T load_padded(const T* __restrict__ x, long i, long len, int mode)
+{
+    long j = pad_src_index(i, len, mode);
+    return j < 0 ? T(0) : x[j];
+}
+
+// wave64 butterfly reductions
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T u = __shfl_xor(v, o, 64);
+        v = u > v ? u : v;
+    }
+    return v;
+}
+
+// block reductions through LDS scratch of >= blockDim.x/64 elements; result broadcast to all
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* scratch)
+{
+    v = wave_sum(v);
+    int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    T s = 0;
+    for (int i = 0; i < nw; ++i) s += scratch[i];
+    return s;
+}
+template <typename T>
+__device__ __forceinline__ T block_max(T v, T* scratch)
+{
+    v = wave_max(v);
+    int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    T s = scratch[0];
+    for (int i = 1; i < nw; ++i) s = scratch[i] > s ? scratch[i] : s;
+    return s;
+}
+
+__device__ __forceinline__ float dsa_log(float v) { return logf(v); }
+__device__ __forceinline__ double dsa_log(double v) { return log(v); }
+__device__ __forceinline__ float dsa_exp(float v) { return expf(v); }
+__device__ __forceinline__ double dsa_exp(double v) { return exp(v); }
+__device__ __forceinline__ float dsa_sqrt(float v) { return sqrtf(v); }
+__device__ __forceinline__ double dsa_sqrt(double v) { return sqrt(v); }
+__device__ __forceinline__ float dsa_log10(float v) { return log10f(v); }
+__device__ __forceinline__ double dsa_log10(double v) { return log10(v); }
+
+// spectrum formatter of spec.py:123-132 applied to s = |X|^2 + eps (already floored)
+template <typename T>
+__device__ __forceinline__ T spec_format(T s, int fmt)
+{
+    switch (fmt) {
+    case DSA_SPEC_DB: return T(10) * dsa_log10(s);
+    case DSA_SPEC_LOGMAG: return T(0.5) * dsa_log(s);
+    case DSA_SPEC_MAG: return dsa_sqrt(s);
+    default: return s;
+    }
+}
+
+}  // namespace dsa

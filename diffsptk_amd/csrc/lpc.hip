@@ -1,0 +1,442 @@
+// LPC branch (a11-a13) for gfx950: autocorrelation, Levinson-Durbin, LPC, and the fused
+// Frame -> Window -> LPC kernel.
+//
+// Reference: diffsptk/modules/acorr.py:110-120, levdur.py:113-127, lpc.py:137-139.
+//
+// MI355X-first restatement:
+//  * the reference obtains r[0..M] as irfft(|rfft(x, L+M)|^2)[:M+1]; with the transform length
+//    >= L+M there is no circular wrap, so this IS the direct lag sum r[m] = sum_l x[l] x[l+m],
+//    computed here straight from LDS-resident frames (float64 accumulation: products of float32
+//    samples are exact in float64);
+//  * the reference solves the Yule-Walker system (toeplitz(r[:M]) + eps I) a = -r[1:] by dense
+//    LU ("based on a simple matrix inversion", levdur.py:25); the same system is solved here by
+//    the Levinson-Durbin recursion on (r0 + eps, r1, ..., rM) in float64, one wave per frame.
+//    The gain keeps the reference's un-regularised r0 (levdur.py:124).
+// Both choices are at least as accurate as the reference's float32 path; parity is judged
+// against the float64 reference (tests/test_lpc_gpu.py states the tolerance).
+#include "common.h"
+
+namespace dsa {
+
+template <typename T>
+__device__ __forceinline__ T acorr_format(double r_m, double r_0, int m, int L, int fmt)
+{
+    switch (fmt) {  // acorr.py:94-107
+    case DSA_ACORR_NORMALIZED: return (T)(r_m / r_0);
+    case DSA_ACORR_BIASED: return (T)(r_m / (double)L);
+    case DSA_ACORR_UNBIASED: return (T)(r_m / (double)(L - m));
+    default: return (T)r_m;
+    }
+}
+
+// Autocorrelation._forward acorr.py:110-120.  One block (64..256 threads) per frame.
+// dynamic LDS: L elements of T.
+template <typename T>
+__global__ void acorr_fwd_kernel(const T* __restrict__ x, long F, int L, int M, int fmt,
+                                 T* __restrict__ r)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* xs = reinterpret_cast<T*>(smem_raw);
+    __shared__ double r0s;
+    long f = blockIdx.x;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) xs[l] = x[f * L + l];
+    __syncthreads();
+    // lag m handled by thread group; blockDim.x / 64 waves share the lags, each wave reduces
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    if (wave == 0) {
+        double acc = 0;
+        for (int l = lane; l < L; l += 64) acc += (double)xs[l] * (double)xs[l];
+        acc = wave_sum(acc);
+        if (lane == 0) r0s = acc;
+    }
+    __syncthreads();
+    for (int m = wave; m <= M; m += nw) {
+        double acc = 0;
+        for (int l = lane; l + m < L; l += 64) acc += (double)xs[l] * (double)xs[l + m];
+        acc = wave_sum(acc);
+        if (lane == 0) r[f * (M + 1) + m] = acorr_format<T>(acc, r0s, m, L, fmt);
+    }
+}
+
+// gx[l] = sum_m grr[m] (x[l+m] + x[l-m]), grr = cotangent of the raw lag sums
+template <typename T>
+__global__ void acorr_bwd_kernel(const T* __restrict__ gr, const T* __restrict__ x, long F, int L,
+                                 int M, int fmt, T* __restrict__ gx)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* xs = reinterpret_cast<T*>(smem_raw);
+    double* g = reinterpret_cast<double*>(smem_raw + (((size_t)L * sizeof(T) + 7) & ~(size_t)7));
+    __shared__ double red[8];
+    long f = blockIdx.x;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) xs[l] = x[f * L + l];
+    for (int m = threadIdx.x; m <= M; m += blockDim.x) {
+        double v = (double)gr[f * (M + 1) + m];
+        if (fmt == DSA_ACORR_BIASED) v /= (double)L;
+        else if (fmt == DSA_ACORR_UNBIASED) v /= (double)(L - m);
+        g[m] = v;
+    }
+    __syncthreads();
+    if (fmt == DSA_ACORR_NORMALIZED) {
+        // y_m = r_m / r_0:  rbar_m = ybar_m / r_0,  rbar_0 = (ybar_0 - sum_m ybar_m y_m) / r_0
+        // (wave 0 recomputes the raw lags it needs)
+        int lane = threadIdx.x & 63;
+        if (threadIdx.x < 64) {
+            double r0 = 0;
+            for (int l = lane; l < L; l += 64) r0 += (double)xs[l] * (double)xs[l];
+            r0 = wave_sum(r0);
+            double corr = 0;
+            for (int m = 1; m <= M; ++m) {
+                double acc = 0;
+                for (int l = lane; l + m < L; l += 64) acc += (double)xs[l] * (double)xs[l + m];
+                acc = wave_sum(acc);
+                corr += g[m] * acc / r0;
+            }
+            if (lane == 0) {
+                red[0] = r0;
+                red[1] = corr;
+            }
+        }
+        __syncthreads();
+        double r0 = red[0], corr = red[1];
+        __syncthreads();
+        for (int m = threadIdx.x; m <= M; m += blockDim.x) g[m] = (m == 0) ? (-corr) / r0 : g[m] / r0;
+        // note: ybar_0 multiplies d(r0/r0) = 0, so it drops out
+        __syncthreads();
+    }
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        double acc = 2.0 * g[0] * (double)xs[l];
+        for (int m = 1; m <= M; ++m) {
+            double v = 0;
+            if (l + m < L) v += (double)xs[l + m];
+            if (l - m >= 0) v += (double)xs[l - m];
+            acc += g[m] * v;
+        }
+        gx[f * L + l] = (T)acc;
+    }
+}
+
+// Levinson-Durbin on (r0 + eps, r1..rM) for M <= 63: one wave per frame, lane j owns a_j and
+// r_j in float64 registers, cross-lane traffic by shuffles only (no LDS, no barriers).
+// Writes out = [K, a1..aM] (levdur.py:121-126).
+template <typename T>
+__device__ __forceinline__ void levinson_wave_reg(double r_lane, int M, double eps, T* out)
+{
+    const int lane = threadIdx.x & 63;
+    const double r0 = __shfl(r_lane, 0, 64);
+    double a = 0.0;
+    double E = r0 + eps;
+    for (int m = 1; m <= M; ++m) {
+        const bool inner = lane >= 1 && lane < m;
+        double rmj = __shfl(r_lane, (m - lane) & 63, 64);  // r[m-j] on lane j
+        double acc = wave_sum(inner ? a * rmj : 0.0);
+        double k = -(__shfl(r_lane, m, 64) + acc) / E;
+        double amj = __shfl(a, (m - lane) & 63, 64);       // a[m-j] on lane j
+        if (inner) a += k * amj;
+        if (lane == m) a = k;
+        E *= (1.0 - k * k);
+    }
+    double s = wave_sum((lane >= 1 && lane <= M) ? r_lane * a : 0.0) + r0;  // un-regularised r0, levdur.py:124
+    if (lane == 0) out[0] = (T)sqrt(s);
+    if (lane >= 1 && lane <= M) out[lane] = (T)a;
+}
+
+// LevinsonDurbin._forward levdur.py:113-127; one wave per frame, 4 frames per block.
+template <typename T>
+__global__ void levdur_fwd_kernel(const T* __restrict__ r, long F, int M, double eps, T* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    long f = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (f >= F) return;
+    double r_lane = lane <= M ? (double)r[f * (M + 1) + lane] : 0.0;
+    levinson_wave_reg<T>(r_lane, M, eps, out + f * (M + 1));
+}
+
+// Orders above 63: the same recursion with a[] in LDS; block = one wave per frame.
+template <typename T>
+__global__ void levdur_fwd_lds_kernel(const T* __restrict__ r, long F, int M, double eps, T* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* rr = reinterpret_cast<double*>(smem_raw);
+    double* a = rr + (M + 1);
+    double* tmp = a + (M + 1);
+    const int lane = threadIdx.x;
+    long f = blockIdx.x;
+    for (int j = lane; j <= M; j += 64) {
+        rr[j] = (double)r[f * (M + 1) + j];
+        a[j] = 0;
+    }
+    __syncthreads();
+    double E = rr[0] + eps;
+    for (int m = 1; m <= M; ++m) {
+        double acc = 0;
+        for (int j = 1 + lane; j < m; j += 64) acc += a[j] * rr[m - j];
+        acc = wave_sum(acc);
+        double k = -(rr[m] + acc) / E;
+        for (int j = 1 + lane; j < m; j += 64) tmp[j] = a[j] + k * a[m - j];
+        __syncthreads();
+        for (int j = 1 + lane; j < m; j += 64) a[j] = tmp[j];
+        if (lane == 0) a[m] = k;
+        __syncthreads();
+        E *= (1.0 - k * k);
+    }
+    double s = 0;
+    for (int j = 1 + lane; j <= M; j += 64) s += rr[j] * a[j];
+    s = wave_sum(s) + rr[0];
+    if (lane == 0) out[f * (M + 1)] = (T)sqrt(s);
+    for (int j = 1 + lane; j <= M; j += 64) out[f * (M + 1) + j] = (T)a[j];
+}
+
+// Backward of levdur: out = [K, a], R a = -p, R = toeplitz(r[:M]) + eps I, p = r[1:],
+// K = sqrt(p.a + r0).  With cotangents (Kbar, abar):
+//   sbar = Kbar / (2K); abar += sbar p; pbar = sbar a; r0bar = sbar;
+//   v = R^{-1} abar (R symmetric); pbar -= v; Rbar = -v a^T; rbar[m] += sum_{|i-j|=m} Rbar_ij.
+// One block (64 threads) per frame, dense Gauss-Jordan in LDS (float64).
+template <typename T>
+__global__ void levdur_bwd_kernel(const T* __restrict__ gout, const T* __restrict__ r,
+                                  const T* __restrict__ out, long F, int M, double eps,
+                                  T* __restrict__ gr)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* rr = reinterpret_cast<double*>(smem_raw);  // M+1
+    double* a = rr + (M + 1);                          // M   (a[0..M-1] = a_1..a_M)
+    double* ab = a + M;                                // M
+    double* fac = ab + M;                              // M
+    double* aug = fac + M;                             // M * (M+1)
+    long f = blockIdx.x;
+    const int W = M + 1;
+    for (int j = threadIdx.x; j <= M; j += blockDim.x) rr[j] = (double)r[f * (M + 1) + j];
+    for (int j = threadIdx.x; j < M; j += blockDim.x) a[j] = (double)out[f * (M + 1) + 1 + j];
+    __syncthreads();
+    double K = (double)out[f * (M + 1)];
+    double sbar = (double)gout[f * (M + 1)] / (2.0 * K);
+    for (int j = threadIdx.x; j < M; j += blockDim.x) ab[j] = (double)gout[f * (M + 1) + 1 + j] + sbar * rr[j + 1];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < M * W; idx += blockDim.x) {
+        int i = idx / W, j = idx - i * W;
+        aug[idx] = j < M ? rr[i > j ? i - j : j - i] + (i == j ? eps : 0.0) : ab[i];
+    }
+    // Gauss-Jordan, no pivoting (R is symmetric positive definite)
+    for (int k = 0; k < M; ++k) {
+        __syncthreads();
+        double inv = 1.0 / aug[k * W + k];
+        for (int i = threadIdx.x; i < M; i += blockDim.x) fac[i] = (i == k) ? 0.0 : aug[i * W + k] * inv;
+        __syncthreads();
+        int ncol = W - (k + 1);
+        for (int idx = threadIdx.x; idx < M * ncol; idx += blockDim.x) {
+            int i = idx / ncol, jj = k + 1 + (idx - i * ncol);
+            if (i != k) aug[i * W + jj] -= fac[i] * aug[k * W + jj];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < M; i += blockDim.x) fac[i] = aug[i * W + M] / aug[i * W + i];  // v
+    __syncthreads();
+    for (int m = threadIdx.x; m <= M; m += blockDim.x) {
+        double acc = 0;
+        if (m < M) {  // Toeplitz scatter of Rbar = -v a^T onto r[0..M-1]
+            for (int i = 0; i + m < M; ++i) {
+                acc -= fac[i] * a[i + m];
+                if (m > 0) acc -= fac[i + m] * a[i];
+            }
+        }
+        if (m >= 1) acc += sbar * a[m - 1] - fac[m - 1];  // pbar
+        if (m == 0) acc += sbar;                          // r0 inside the gain
+        gr[f * (M + 1) + m] = (T)acc;
+    }
+}
+
+// Fused Frame -> Window -> autocorrelation -> Levinson (README.md:198-201 of the reference);
+// one wave per frame (M <= 63), blockDim/64 frames per block.  dynamic LDS: L elements per wave.
+template <typename T>
+__global__ void frame_window_lpc_kernel(const T* __restrict__ x, long Tlen, long N, long F, int L, int P,
+                                        int left, int mode, const T* __restrict__ w, int M, double eps,
+                                        T* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    T* xs = reinterpret_cast<T*>(smem_raw) + (size_t)wave * L;
+    long f = (long)blockIdx.x * nw + wave;
+    const bool active = f < F;
+    if (active) {
+        long b = f / N, n = f - b * N;
+        const T* xb = x + b * Tlen;
+        for (int l = lane; l < L; l += 64) xs[l] = load_padded(xb, n * P + l - left, Tlen, mode) * w[l];
+    }
+    __syncthreads();
+    if (!active) return;
+    double r_lane = 0.0;
+    for (int m = 0; m <= M; ++m) {
+        double acc = 0;
+        for (int l = lane; l + m < L; l += 64) acc += (double)xs[l] * (double)xs[l + m];
+        acc = wave_sum(acc);
+        if (lane == m) r_lane = acc;
+    }
+    levinson_wave_reg<T>(r_lane, M, eps, out + f * (M + 1));
+}
+
+template <typename T>
+static int acorr_fwd_impl(const void* x, int64_t F, int L, int M, int fmt, void* r, hipStream_t st)
+{
+    size_t lds = sizeof(T) * (size_t)L;
+    if (lds > 60 * 1024) return fail(DSA_ERR_UNSUPPORTED, "acorr: frame too long for LDS%s");
+    hipLaunchKernelGGL((acorr_fwd_kernel<T>), dim3((unsigned)F), dim3(256), lds, st, (const T*)x, (long)F, L,
+                       M, fmt, (T*)r);
+    return check_launch("acorr_fwd");
+}
+
+template <typename T>
+static int levdur_fwd_impl(const void* r, int64_t F, int M, double eps, void* out, hipStream_t st)
+{
+    if (M <= 63) {
+        hipLaunchKernelGGL((levdur_fwd_kernel<T>), dim3((unsigned)((F + 3) / 4)), dim3(256), 0, st, (const T*)r,
+                           (long)F, M, eps, (T*)out);
+        return check_launch("levdur_fwd");
+    }
+    size_t lds = sizeof(double) * 3 * (size_t)(M + 1);
+    if (lds > 60 * 1024) return fail(DSA_ERR_UNSUPPORTED, "levdur: order too large for LDS%s");
+    hipLaunchKernelGGL((levdur_fwd_lds_kernel<T>), dim3((unsigned)F), dim3(64), lds, st, (const T*)r, (long)F, M,
+                       eps, (T*)out);
+    return check_launch("levdur_fwd_lds");
+}
+
+template <typename T>
+static int acorr_bwd_impl(const void* gr, const void* x, int64_t F, int L, int M, int fmt, void* gx,
+                          hipStream_t st)
+{
+    size_t lds = (((size_t)L * sizeof(T) + 7) & ~(size_t)7) + sizeof(double) * (size_t)(M + 1);
+    if (lds > 60 * 1024) return fail(DSA_ERR_UNSUPPORTED, "acorr_bwd: frame too long for LDS%s");
+    hipLaunchKernelGGL((acorr_bwd_kernel<T>), dim3((unsigned)F), dim3(256), lds, st, (const T*)gr,
+                       (const T*)x, (long)F, L, M, fmt, (T*)gx);
+    return check_launch("acorr_bwd");
+}
+
+template <typename T>
+static int levdur_bwd_impl(const void* gout, const void* r, const void* out, int64_t F, int M, double eps,
+                           void* gr, hipStream_t st)
+{
+    size_t lds = sizeof(double) * ((size_t)(M + 1) + 3 * (size_t)M + (size_t)M * (M + 1));
+    if (lds > 60 * 1024) return fail(DSA_ERR_UNSUPPORTED, "levdur_bwd: order too large for LDS%s");
+    hipLaunchKernelGGL((levdur_bwd_kernel<T>), dim3((unsigned)F), dim3(64), lds, st, (const T*)gout,
+                       (const T*)r, (const T*)out, (long)F, M, eps, (T*)gr);
+    return check_launch("levdur_bwd");
+}
+
+}  // namespace dsa
+
+using namespace dsa;
+
+DSA_EXPORT int dsa_acorr_fwd(const void* x, int64_t F, int32_t L, int32_t M, int32_t out_format, int32_t dtype,
+                             void* r, void* stream)
+{
+    DSA_REQUIRE(L > 0 && M >= 0 && M < L && F >= 0, "acorr: acr_order must be less than frame_length");
+    DSA_REQUIRE(out_format >= 0 && out_format <= 3, "acorr: unknown out_format");
+    if (F == 0) return DSA_OK;
+    if (dtype == DSA_F32) return acorr_fwd_impl<float>(x, F, L, M, out_format, r, (hipStream_t)stream);
+    if (dtype == DSA_F64) return acorr_fwd_impl<double>(x, F, L, M, out_format, r, (hipStream_t)stream);
+    return fail(DSA_ERR_UNSUPPORTED, "acorr: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_acorr_bwd(const void* gr, const void* x, int64_t F, int32_t L, int32_t M, int32_t out_format,
+                             int32_t dtype, void* gx, void* stream)
+{
+    DSA_REQUIRE(L > 0 && M >= 0 && M < L && F >= 0, "acorr_bwd: acr_order must be less than frame_length");
+    if (F == 0) return DSA_OK;
+    if (dtype == DSA_F32) return acorr_bwd_impl<float>(gr, x, F, L, M, out_format, gx, (hipStream_t)stream);
+    if (dtype == DSA_F64) return acorr_bwd_impl<double>(gr, x, F, L, M, out_format, gx, (hipStream_t)stream);
+    return fail(DSA_ERR_UNSUPPORTED, "acorr_bwd: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_levdur_fwd(const void* r, int64_t F, int32_t M, double eps, int32_t dtype, void* out,
+                              void* stream)
+{
+    DSA_REQUIRE(M >= 0 && F >= 0 && eps >= 0, "levdur: lpc_order and eps must be non-negative");
+    if (F == 0) return DSA_OK;
+    if (dtype == DSA_F32) return levdur_fwd_impl<float>(r, F, M, eps, out, (hipStream_t)stream);
+    if (dtype == DSA_F64) return levdur_fwd_impl<double>(r, F, M, eps, out, (hipStream_t)stream);
+    return fail(DSA_ERR_UNSUPPORTED, "levdur: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_levdur_bwd(const void* gout, const void* r, const void* out, int64_t F, int32_t M, double eps,
+                              int32_t dtype, void* gr, void* stream)
+{
+    DSA_REQUIRE(M >= 0 && F >= 0, "levdur_bwd: lpc_order must be non-negative");
+    if (F == 0) return DSA_OK;
+    if (dtype == DSA_F32) return levdur_bwd_impl<float>(gout, r, out, F, M, eps, gr, (hipStream_t)stream);
+    if (dtype == DSA_F64) return levdur_bwd_impl<double>(gout, r, out, F, M, eps, gr, (hipStream_t)stream);
+    return fail(DSA_ERR_UNSUPPORTED, "levdur_bwd: unsupported dtype%s");
+}
+
+template <typename T>
+static int lpc_fwd_impl(const void* x, int64_t F, int L, int M, double eps, void* out, hipStream_t st)
+{
+    // a frame is its own one-frame "utterance": T = L, P = L, no padding, unit window not needed
+    T* r = nullptr;
+    if (hipMallocAsync((void**)&r, sizeof(T) * (size_t)F * (M + 1), st) != hipSuccess)
+        return fail(DSA_ERR_LAUNCH, "lpc: workspace allocation failed%s");
+    int rc = acorr_fwd_impl<T>(x, F, L, M, DSA_ACORR_NAIVE, r, st);
+    if (rc == DSA_OK) rc = levdur_fwd_impl<T>(r, F, M, eps, out, st);
+    hipFreeAsync(r, st);
+    return rc;
+}
+
+template <typename T>
+static int lpc_bwd_impl(const void* gout, const void* x, const void* out, int64_t F, int L, int M, double eps,
+                        void* gx, hipStream_t st)
+{
+    T *r = nullptr, *gr = nullptr;
+    size_t bytes = sizeof(T) * (size_t)F * (M + 1);
+    if (hipMallocAsync((void**)&r, bytes, st) != hipSuccess || hipMallocAsync((void**)&gr, bytes, st) != hipSuccess)
+        return fail(DSA_ERR_LAUNCH, "lpc_bwd: workspace allocation failed%s");
+    int rc = acorr_fwd_impl<T>(x, F, L, M, DSA_ACORR_NAIVE, r, st);
+    if (rc == DSA_OK) rc = levdur_bwd_impl<T>(gout, r, out, F, M, eps, gr, st);
+    if (rc == DSA_OK) rc = acorr_bwd_impl<T>(gr, x, F, L, M, DSA_ACORR_NAIVE, gx, st);
+    hipFreeAsync(r, st);
+    hipFreeAsync(gr, st);
+    return rc;
+}
+
+DSA_EXPORT int dsa_lpc_fwd(const void* x, int64_t F, int32_t L, int32_t M, double eps, int32_t dtype, void* out,
+                           void* stream)
+{
+    DSA_REQUIRE(L > 0 && M >= 0 && M < L && F >= 0 && eps >= 0, "lpc: lpc_order must be less than frame_length");
+    if (F == 0) return DSA_OK;
+    if (dtype == DSA_F32) return lpc_fwd_impl<float>(x, F, L, M, eps, out, (hipStream_t)stream);
+    if (dtype == DSA_F64) return lpc_fwd_impl<double>(x, F, L, M, eps, out, (hipStream_t)stream);
+    return fail(DSA_ERR_UNSUPPORTED, "lpc: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_lpc_bwd(const void* gout, const void* x, const void* out, int64_t F, int32_t L, int32_t M,
+                           double eps, int32_t dtype, void* gx, void* stream)
+{
+    DSA_REQUIRE(L > 0 && M >= 0 && M < L && F >= 0, "lpc_bwd: lpc_order must be less than frame_length");
+    if (F == 0) return DSA_OK;
+    if (dtype == DSA_F32) return lpc_bwd_impl<float>(gout, x, out, F, L, M, eps, gx, (hipStream_t)stream);
+    if (dtype == DSA_F64) return lpc_bwd_impl<double>(gout, x, out, F, L, M, eps, gx, (hipStream_t)stream);
+    return fail(DSA_ERR_UNSUPPORTED, "lpc_bwd: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, const void* w,
+                                        int32_t center, int32_t pad_mode, int32_t M, double eps, int32_t dtype,
+                                        void* out, void* stream)
+{
+    DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0 && M >= 0 && M < L && eps >= 0, "frame_window_lpc: invalid sizes");
+    DSA_REQUIRE(pad_mode >= 0 && pad_mode <= 3, "frame_window_lpc: unknown pad mode");
+    int64_t N = dsa_num_frames(T, P), F = B * N;
+    if (F == 0) return DSA_OK;
+    int left = center ? L / 2 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int nw = 4;
+    size_t esz = dtype == DSA_F32 ? 4 : 8;
+    size_t lds = (size_t)L * esz * nw;
+    if (M > 63) return fail(DSA_ERR_UNSUPPORTED, "frame_window_lpc: fused kernel supports lpc_order <= 63%s");
+    if (lds > 60 * 1024) return fail(DSA_ERR_UNSUPPORTED, "frame_window_lpc: frame too long for LDS%s");
+    unsigned grid = (unsigned)((F + nw - 1) / nw);
+    if (dtype == DSA_F32)
+        hipLaunchKernelGGL((frame_window_lpc_kernel<float>), dim3(grid), dim3(64 * nw), lds, st, (const float*)x,
+                           (long)T, (long)N, (long)F, L, P, left, pad_mode, (const float*)w, M, eps, (float*)out);
+    else if (dtype == DSA_F64)
+        hipLaunchKernelGGL((frame_window_lpc_kernel<double>), dim3(grid), dim3(64 * nw), lds, st, (const double*)x,
+                           (long)T, (long)N, (long)F, L, P, left, pad_mode, (const double*)w, M, eps, (double*)out);
+    else
+        return fail(DSA_ERR_UNSUPPORTED, "frame_window_lpc: unsupported dtype%s");
+    return check_launch("frame_window_lpc_fwd");
+}

@@ -1,0 +1,351 @@
+// Mel-cepstral analysis (a6-a10) for gfx950: FrequencyTransform matmul and the
+// MelCepstralAnalysis Newton iteration, forward and backward.
+//
+// Reference: diffsptk/modules/mcep.py:189-224, freqt.py:141-143, utils/private.py:291-302.
+//
+// MI355X-first restatement.  The reference runs, per Newton step, ifreqt (matmul) -> rfft ->
+// exp -> irfft -> rfreqt (matmul) -> build (F,25,25) Toeplitz + Hankel -> LU solve, each as a
+// separate ATen pass over HBM.  Every map except exp and the solve is LINEAR, so the host
+// composes them once per configuration in float64 (diffsptk_amd/utils/tables.py):
+//     G = irfft(.)[:H+1] with halved ends, then freqt          (H+1, M+1)
+//     D = ifreqt, then Re rfft(., nfft)                        (M+1, H+1)
+//     E = irfft(.)[:H+1], then rfreqt                          (H+1, 2M+1)
+// One step is then  d = mc D ; e = exp(log X - 2 d) ; rt = e E ;
+//                   mc += (T(rt[:M+1]) + H(rt))^{-1} (rt[:M+1] - alpha_vec)
+// with D/E/G of the SAME shapes as the reference's warping matrices -- the three FFTs per step
+// disappear and nothing but X (in) and mc (out) touches HBM.  T + H = 2 sum_w e(w) c(w) c(w)^T
+// is symmetric positive definite, so elimination needs no pivoting.
+//
+// Kernel families:
+//  * generic : one workgroup per frame, any (nfft, M), float32/float64, forward and backward.
+//  * tuned   : see mcep_mfma.hip (float32, f32 MFMA, 16 frames per wave).
+#include "common.h"
+
+namespace dsa {
+
+// out(F,L2) = c(F,L1) @ A(L1,L2): one thread per output element, A streamed from L2.
+template <typename T>
+__global__ void matmul_rows_kernel(const T* __restrict__ c, long F, int L1, const T* __restrict__ A,
+                                   int L2, T* __restrict__ out)
+{
+    extern __shared__ unsigned char smem_raw[];
+    T* cs = reinterpret_cast<T*>(smem_raw);
+    long f = blockIdx.x;
+    for (int j = threadIdx.x; j < L1; j += blockDim.x) cs[j] = c[f * L1 + j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < L2; i += blockDim.x) {
+        T s = 0;
+        for (int j = 0; j < L1; ++j) s += cs[j] * A[(long)j * L2 + i];
+        out[f * L2 + i] = s;
+    }
+}
+
+// gc(F,L1) = gout(F,L2) @ A^T
+template <typename T>
+__global__ void matmul_rows_t_kernel(const T* __restrict__ g, long F, int L1, const T* __restrict__ A,
+                                     int L2, T* __restrict__ gc)
+{
+    extern __shared__ unsigned char smem_raw[];
+    T* gs = reinterpret_cast<T*>(smem_raw);
+    long f = blockIdx.x;
+    for (int i = threadIdx.x; i < L2; i += blockDim.x) gs[i] = g[f * L2 + i];
+    __syncthreads();
+    for (int j = threadIdx.x; j < L1; j += blockDim.x) {
+        T s = 0;
+        for (int i = 0; i < L2; ++i) s += gs[i] * A[(long)j * L2 + i];
+        gc[f * L1 + j] = s;
+    }
+}
+
+// Reduce the (M1 x M1) symmetric positive definite system held in LDS as an augmented
+// row-major matrix Aug[M1][W] (W - M1 right-hand sides) to diagonal form by Gauss-Jordan
+// elimination without pivoting; afterwards x_c[i] = Aug[i][M1 + c] / Aug[i][i].
+// `fac` is M1 elements of scratch.  All threads of the block cooperate.
+template <typename T>
+__device__ void gauss_jordan(T* Aug, int M1, int W, T* fac)
+{
+    for (int k = 0; k < M1; ++k) {
+        __syncthreads();  // previous step's updates (incl. the new pivot) are visible
+        T inv = T(1) / Aug[k * W + k];
+        // factors first (column k is read by every update of this step)
+        for (int i = threadIdx.x; i < M1; i += blockDim.x)
+            fac[i] = (i == k) ? T(0) : Aug[i * W + k] * inv;
+        __syncthreads();
+        int ncol = W - (k + 1);
+        for (int idx = threadIdx.x; idx < M1 * ncol; idx += blockDim.x) {
+            int i = idx / ncol;
+            int jj = k + 1 + (idx - i * ncol);
+            if (i != k) Aug[i * W + jj] -= fac[i] * Aug[k * W + jj];
+        }
+    }
+    __syncthreads();
+}
+
+// LDS carve-up shared by the generic forward and backward kernels
+template <typename T>
+struct McepLds {
+    T *logx, *e, *mc, *rt, *aug, *sol, *aux1, *aux2;
+    __device__ McepLds(unsigned char* base, int K, int M1, int M2)
+    {
+        T* p = reinterpret_cast<T*>(base);
+        logx = p; p += K;
+        e = p; p += K;
+        aux1 = p; p += K;   // backward: gradient wrt log X
+        mc = p; p += M1;
+        sol = p; p += M1;
+        aux2 = p; p += M1;  // backward: running gradient wrt mc
+        rt = p; p += M2;
+        aug = p;            // M1 * (M1 + 2)
+    }
+    static size_t bytes(int K, int M1, int M2)
+    {
+        return sizeof(T) * ((size_t)3 * K + 3 * M1 + M2 + (size_t)M1 * (M1 + 2));
+    }
+};
+
+// one Newton step's forward quantities from mc (in LDS): e, rt, augmented system
+template <typename T>
+__device__ void newton_forward_parts(McepLds<T>& s, int K, int M1, int M2, int W,
+                                     const T* __restrict__ D, const T* __restrict__ E,
+                                     const T* __restrict__ av, const T* extra_rhs)
+{
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        T d = 0;
+        for (int m = 0; m < M1; ++m) d += s.mc[m] * D[(long)m * K + k];  // mcep.py:210-211
+        s.e[k] = dsa_exp(s.logx[k] - d - d);                            // mcep.py:212
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < M2; j += blockDim.x) {
+        T r = 0;
+        for (int k = 0; k < K; ++k) r += s.e[k] * E[(long)k * M2 + j];  // mcep.py:214-215
+        s.rt[j] = r;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < M1 * W; idx += blockDim.x) {
+        int i = idx / W, j = idx - i * W;
+        // R + Q (mcep.py:219-221) | right-hand side r - alpha_vector (mcep.py:216-217) | extra
+        s.aug[idx] = j < M1 ? s.rt[i > j ? i - j : j - i] + s.rt[i + j]
+                            : (j == M1 ? s.rt[i] - av[i] : extra_rhs[i]);
+    }
+    __syncthreads();
+}
+
+template <typename T>
+__global__ void mcep_generic_fwd_kernel(const T* __restrict__ X, long F, int K, int M1, int M2,
+                                        int n_iter, const T* __restrict__ G, const T* __restrict__ D,
+                                        const T* __restrict__ E, const T* __restrict__ av,
+                                        T* __restrict__ mc_out, T* __restrict__ hist)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    McepLds<T> s(smem_raw, K, M1, M2);
+    const long f = blockIdx.x;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) s.logx[k] = dsa_log(X[f * K + k]);  // :203
+    __syncthreads();
+    for (int m = threadIdx.x; m < M1; m += blockDim.x) {
+        T v = 0;
+        for (int k = 0; k < K; ++k) v += s.logx[k] * G[(long)k * M1 + m];  // :204-207
+        s.mc[m] = v;
+        if (hist) hist[f * M1 + m] = v;
+    }
+    __syncthreads();
+    for (int it = 0; it < n_iter; ++it) {
+        newton_forward_parts(s, K, M1, M2, M1 + 1, D, E, av, (const T*)nullptr);
+        gauss_jordan(s.aug, M1, M1 + 1, s.sol);
+        for (int m = threadIdx.x; m < M1; m += blockDim.x) {
+            T v = s.mc[m] + s.aug[m * (M1 + 1) + M1] / s.aug[m * (M1 + 1) + m];  // :221-222
+            s.mc[m] = v;
+            if (hist) hist[((long)(it + 1) * F + f) * M1 + m] = v;
+        }
+        __syncthreads();
+    }
+    for (int m = threadIdx.x; m < M1; m += blockDim.x) mc_out[f * M1 + m] = s.mc[m];
+}
+
+// Backward of the unrolled iteration.  For step k with saved mc_k and
+// g_k = mc_{k+1} - mc_k, cotangent mbar of mc_{k+1}:
+//   u = A^{-1} mbar (A symmetric);  Abar = -u g^T;  rtbar[m] = sum_{i+j=m} Abar_ij
+//   + [m<=M] (sum_{|i-j|=m} Abar_ij + u_m);  ebar = rtbar E^T;  zbar = ebar * e;
+//   logxbar += zbar;  mbar_k = mbar - 2 zbar D^T.
+// Finally logxbar += mbar_0 G^T and Xbar = logxbar / X.
+template <typename T>
+__global__ void mcep_generic_bwd_kernel(const T* __restrict__ gmc, const T* __restrict__ X,
+                                        const T* __restrict__ hist, long F, int K, int M1, int M2,
+                                        int n_iter, const T* __restrict__ G, const T* __restrict__ D,
+                                        const T* __restrict__ E, const T* __restrict__ av,
+                                        T* __restrict__ gX)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    McepLds<T> s(smem_raw, K, M1, M2);
+    T* lbar = s.aux1;
+    T* mbar = s.aux2;
+    const long f = blockIdx.x;
+    const int W = M1 + 2;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        s.logx[k] = dsa_log(X[f * K + k]);
+        lbar[k] = 0;
+    }
+    for (int m = threadIdx.x; m < M1; m += blockDim.x) mbar[m] = gmc[f * M1 + m];
+    __syncthreads();
+    for (int it = n_iter - 1; it >= 0; --it) {
+        for (int m = threadIdx.x; m < M1; m += blockDim.x) s.mc[m] = hist[((long)it * F + f) * M1 + m];
+        __syncthreads();
+        // two right-hand sides: b = r - alpha_vector (re-derives g = mc_{k+1} - mc_k without the
+        // cancellation of subtracting saved float32 iterates) and mbar
+        newton_forward_parts(s, K, M1, M2, W, D, E, av, (const T*)mbar);
+        gauss_jordan(s.aug, M1, W, s.sol);
+        for (int m = threadIdx.x; m < M1; m += blockDim.x) {
+            T dinv = T(1) / s.aug[m * W + m];
+            s.mc[m] = s.aug[m * W + M1] * dinv;       // g
+            s.sol[m] = s.aug[m * W + M1 + 1] * dinv;  // u
+        }
+        __syncthreads();
+        // rtbar (into s.rt)
+        for (int m = threadIdx.x; m < M2; m += blockDim.x) {
+            T acc = 0;
+            // Hankel part: i + j = m
+            int ilo = m - (M1 - 1) > 0 ? m - (M1 - 1) : 0;
+            int ihi = m < M1 - 1 ? m : M1 - 1;
+            for (int i = ilo; i <= ihi; ++i) acc -= s.sol[i] * s.mc[m - i];
+            if (m < M1) {
+                // Toeplitz part: |i - j| = m
+                for (int i = 0; i + m < M1; ++i) {
+                    acc -= s.sol[i] * s.mc[i + m];
+                    if (m > 0) acc -= s.sol[i + m] * s.mc[i];
+                }
+                acc += s.sol[m];  // through the right-hand side r - alpha_vector
+            }
+            s.rt[m] = acc;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            T eb = 0;
+            for (int j = 0; j < M2; ++j) eb += s.rt[j] * E[(long)k * M2 + j];
+            T zb = eb * s.e[k];
+            lbar[k] += zb;
+            s.e[k] = T(-2) * zb;  // dbar
+        }
+        __syncthreads();
+        for (int m = threadIdx.x; m < M1; m += blockDim.x) {
+            T acc = mbar[m];
+            for (int k = 0; k < K; ++k) acc += s.e[k] * D[(long)m * K + k];
+            mbar[m] = acc;
+        }
+        __syncthreads();
+    }
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        T acc = lbar[k];
+        for (int m = 0; m < M1; ++m) acc += mbar[m] * G[(long)k * M1 + m];
+        gX[f * K + k] = acc / X[f * K + k];
+    }
+}
+
+template <typename T>
+static int mcep_generic_fwd(const void* X, int64_t F, int nfft, int M, int n_iter, const void* G,
+                            const void* D, const void* E, const void* av, void* mc, void* hist,
+                            hipStream_t st)
+{
+    int K = nfft / 2 + 1, M1 = M + 1, M2 = 2 * M + 1;
+    size_t lds = McepLds<T>::bytes(K, M1, M2);
+    if (lds > 160 * 1024) return fail(DSA_ERR_UNSUPPORTED, "mcep: configuration exceeds LDS%s");
+    if (lds > 48 * 1024)
+        hipFuncSetAttribute((const void*)mcep_generic_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((mcep_generic_fwd_kernel<T>), dim3((unsigned)F), dim3(128), lds, st, (const T*)X,
+                       (long)F, K, M1, M2, n_iter, (const T*)G, (const T*)D, (const T*)E, (const T*)av,
+                       (T*)mc, (T*)hist);
+    return check_launch("mcep_generic_fwd");
+}
+
+template <typename T>
+static int mcep_generic_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int nfft, int M,
+                            int n_iter, const void* G, const void* D, const void* E, const void* av,
+                            void* gX, hipStream_t st)
+{
+    int K = nfft / 2 + 1, M1 = M + 1, M2 = 2 * M + 1;
+    size_t lds = McepLds<T>::bytes(K, M1, M2);
+    if (lds > 160 * 1024) return fail(DSA_ERR_UNSUPPORTED, "mcep: configuration exceeds LDS%s");
+    if (lds > 48 * 1024)
+        hipFuncSetAttribute((const void*)mcep_generic_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((mcep_generic_bwd_kernel<T>), dim3((unsigned)F), dim3(128), lds, st, (const T*)gmc,
+                       (const T*)X, (const T*)hist, (long)F, K, M1, M2, n_iter, (const T*)G, (const T*)D,
+                       (const T*)E, (const T*)av, (T*)gX);
+    return check_launch("mcep_generic_bwd");
+}
+
+// tuned kernels (mcep_mfma.hip)
+int mcep_mfma_supported(int nfft, int M, int dtype);
+int mcep_mfma_fwd(const void* X, int64_t F, int nfft, int M, int n_iter, const void* G, const void* D,
+                  const void* E, const void* av, void* mc, void* hist, hipStream_t st);
+
+}  // namespace dsa
+
+using namespace dsa;
+
+DSA_EXPORT int dsa_freqt_fwd(const void* c, int64_t F, int32_t L1, const void* A, int32_t L2, int32_t dtype,
+                             void* out, void* stream)
+{
+    DSA_REQUIRE(L1 > 0 && L2 > 0 && F >= 0, "freqt: sizes must be positive");
+    if (F == 0) return DSA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int threads = L2 >= 192 ? 256 : (L2 >= 96 ? 128 : 64);
+    if (dtype == DSA_F32)
+        hipLaunchKernelGGL((matmul_rows_kernel<float>), dim3((unsigned)F), dim3(threads), sizeof(float) * L1, st,
+                           (const float*)c, (long)F, L1, (const float*)A, L2, (float*)out);
+    else if (dtype == DSA_F64)
+        hipLaunchKernelGGL((matmul_rows_kernel<double>), dim3((unsigned)F), dim3(threads), sizeof(double) * L1, st,
+                           (const double*)c, (long)F, L1, (const double*)A, L2, (double*)out);
+    else
+        return fail(DSA_ERR_UNSUPPORTED, "freqt: unsupported dtype%s");
+    return check_launch("freqt_fwd");
+}
+
+DSA_EXPORT int dsa_freqt_bwd(const void* gout, int64_t F, int32_t L1, const void* A, int32_t L2, int32_t dtype,
+                             void* gc, void* stream)
+{
+    DSA_REQUIRE(L1 > 0 && L2 > 0 && F >= 0, "freqt_bwd: sizes must be positive");
+    if (F == 0) return DSA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int threads = L1 >= 192 ? 256 : (L1 >= 96 ? 128 : 64);
+    if (dtype == DSA_F32)
+        hipLaunchKernelGGL((matmul_rows_t_kernel<float>), dim3((unsigned)F), dim3(threads), sizeof(float) * L2, st,
+                           (const float*)gout, (long)F, L1, (const float*)A, L2, (float*)gc);
+    else if (dtype == DSA_F64)
+        hipLaunchKernelGGL((matmul_rows_t_kernel<double>), dim3((unsigned)F), dim3(threads), sizeof(double) * L2, st,
+                           (const double*)gout, (long)F, L1, (const double*)A, L2, (double*)gc);
+    else
+        return fail(DSA_ERR_UNSUPPORTED, "freqt_bwd: unsupported dtype%s");
+    return check_launch("freqt_bwd");
+}
+
+DSA_EXPORT int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, int32_t n_iter, const void* G,
+                            const void* D, const void* E, const void* alpha_vec, int32_t dtype, int32_t algo,
+                            void* mc, void* mc_hist, void* stream)
+{
+    DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "mcep: fft_length must be positive even");
+    DSA_REQUIRE(M >= 0 && 2 * M <= nfft, "mcep: cep_order must be in [0, fft_length/2]");
+    DSA_REQUIRE(n_iter >= 0 && F >= 0, "mcep: n_iter must be non-negative");
+    if (F == 0) return DSA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    bool tuned_ok = mcep_mfma_supported(nfft, M, dtype) != 0;
+    if (algo == DSA_ALGO_TUNED && !tuned_ok)
+        return fail(DSA_ERR_UNSUPPORTED, "mcep: tuned kernel needs float32, fft_length 512, cep_order <= 27%s");
+    if (tuned_ok && algo != DSA_ALGO_GENERIC)
+        return mcep_mfma_fwd(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);
+    if (dtype == DSA_F32) return mcep_generic_fwd<float>(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);
+    if (dtype == DSA_F64) return mcep_generic_fwd<double>(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);
+    return fail(DSA_ERR_UNSUPPORTED, "mcep: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist, int64_t F, int32_t nfft,
+                            int32_t M, int32_t n_iter, const void* G, const void* D, const void* E,
+                            const void* alpha_vec, int32_t dtype, int32_t algo, void* gX, void* stream)
+{
+    DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "mcep_bwd: fft_length must be positive even");
+    DSA_REQUIRE(M >= 0 && 2 * M <= nfft && n_iter >= 0 && F >= 0, "mcep_bwd: invalid sizes");
+    DSA_REQUIRE(mc_hist != nullptr, "mcep_bwd: the forward history is required");
+    if (F == 0) return DSA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    (void)algo;
+    if (dtype == DSA_F32) return mcep_generic_bwd<float>(gmc, X, mc_hist, F, nfft, M, n_iter, G, D, E, alpha_vec, gX, st);
+    if (dtype == DSA_F64) return mcep_generic_bwd<double>(gmc, X, mc_hist, F, nfft, M, n_iter, G, D, E, alpha_vec, gX, st);
+    return fail(DSA_ERR_UNSUPPORTED, "mcep_bwd: unsupported dtype%s");
+}

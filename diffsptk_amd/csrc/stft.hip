@@ -1,0 +1,998 @@
+// STFT family for gfx950: Frame (a1), Window (a2), fftr (a3), Spectrum (a4), fused STFT (a5).
+//
+// Two kernel families:
+//  * generic  -- any frame length / period / even fft length, float32 and float64, every
+//                option of the reference.  One workgroup per frame, direct DFT against a
+//                host-built twiddle table.  Correctness path for odd configurations and for
+//                float64 (gradcheck); never the fast path.
+//  * tuned    -- nfft = 512, float32: the BASELINE configuration.  One workgroup handles 16
+//                consecutive frames of one utterance: the waveform stretch they share is read
+//                from HBM once into LDS (frames overlap there, not in HBM), each frame is
+//                transformed by 16 lanes (4 frames per wave64) as a 256-point complex FFT =
+//                radix-16 in registers -> twiddle -> 16x16 transpose through LDS -> radix-16,
+//                and the real-FFT split + |.|^2 + eps + formatting is fused into the
+//                coalesced write of the (frames x 257) tile.
+//                Algorithmic HBM traffic: P*4 B read + 257*4 B written per frame.
+//
+// Reference semantics: diffsptk/modules/{frame,window,fftr,spec,stft}.py (cited per kernel).
+#include "common.h"
+
+namespace dsa {
+
+// =========================================================================== generic kernels
+
+// Frame._forward frame.py:120-141.  grid = F frames, any block size.
+template <typename T>
+__global__ void frame_fwd_kernel(const T* __restrict__ x, long Tlen, long N, int L, int P, int left,
+                                 int zmean, int mode, T* __restrict__ y)
+{
+    __shared__ T scratch[16];
+    long f = blockIdx.x;
+    long b = f / N, n = f - b * N;
+    const T* xb = x + b * Tlen;
+    T* row = y + f * L;
+    T acc = 0;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        T v = load_padded(xb, n * P + l - left, Tlen, mode);
+        row[l] = v;
+        acc += v;
+    }
+    if (zmean) {  // frame.py:139-140
+        T mean = block_sum(acc, scratch) / T(L);
+        for (int l = threadIdx.x; l < L; l += blockDim.x) row[l] -= mean;
+    }
+}
+
+// adjoint of Frame: gx[b,t] = sum over (n,l) whose source index is t of g'[b,n,l], where
+// g' = gy - mean_l(gy) if zmean.  Gather formulation (deterministic, no atomics) for constant
+// padding; the non-constant modes fold several padded positions onto one sample and use a
+// per-utterance serial-over-frames scatter within one block (deterministic as well).
+template <typename T>
+__global__ void frame_bwd_const_kernel(const T* __restrict__ gy, const T* __restrict__ gmean,
+                                       long Tlen, long N, int L, int P, int left,
+                                       T* __restrict__ gx)
+{
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long b = blockIdx.y;
+    if (t >= Tlen) return;
+    // frames n with 0 <= t + left - n*P < L
+    long p = t + left;
+    long n_hi = p / P;
+    if (n_hi > N - 1) n_hi = N - 1;
+    long n_lo = p - L + 1 <= 0 ? 0 : (p - L + P) / P;  // ceil((p-L+1)/P)
+    T acc = 0;
+    for (long n = n_lo; n <= n_hi; ++n) {
+        long l = p - n * P;
+        T g = gy[(b * N + n) * L + l];
+        if (gmean) g -= gmean[b * N + n];
+        acc += g;
+    }
+    gx[b * Tlen + t] = acc;
+}
+
+template <typename T>
+__global__ void row_mean_kernel(const T* __restrict__ g, int L, T* __restrict__ m)
+{
+    __shared__ T scratch[16];
+    long f = blockIdx.x;
+    T acc = 0;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) acc += g[f * L + l];
+    T s = block_sum(acc, scratch);
+    if (threadIdx.x == 0) m[f] = s / T(L);
+}
+
+// general-mode adjoint: one block per utterance, frames visited in order, each frame's L
+// contributions added by distinct threads (a frame never maps two l onto the same t unless
+// the padding folds, in which case the fold is resolved by a second serial pass) -- simple and
+// deterministic; only used for reflect/replicate/circular padding.
+template <typename T>
+__global__ void frame_bwd_general_kernel(const T* __restrict__ gy, const T* __restrict__ gmean,
+                                         long Tlen, long N, int L, int P, int left, int mode,
+                                         T* __restrict__ gx)
+{
+    long b = blockIdx.x;
+    T* gxb = gx + b * Tlen;
+    for (long t = threadIdx.x; t < Tlen; t += blockDim.x) gxb[t] = 0;
+    __syncthreads();
+    // interior (un-folded) part: gather
+    for (long t = threadIdx.x; t < Tlen; t += blockDim.x) {
+        long p = t + left;
+        long n_hi = p / P;
+        if (n_hi > N - 1) n_hi = N - 1;
+        long n_lo = p - L + 1 <= 0 ? 0 : (p - L + P) / P;
+        T acc = 0;
+        for (long n = n_lo; n <= n_hi; ++n) {
+            T g = gy[(b * N + n) * L + (p - n * P)];
+            if (gmean) g -= gmean[b * N + n];
+            acc += g;
+        }
+        gxb[t] = acc;
+    }
+    __syncthreads();
+    // folded part: padded positions i < 0 or i >= T, visited serially by thread 0
+    if (threadIdx.x == 0) {
+        for (long n = 0; n < N; ++n)
+            for (int l = 0; l < L; ++l) {
+                long i = n * P + l - left;
+                if (i >= 0 && i < Tlen) continue;
+                long j = pad_src_index(i, Tlen, mode);
+                if (j < 0) continue;
+                T g = gy[(b * N + n) * L + l];
+                if (gmean) g -= gmean[b * N + n];
+                gxb[j] += g;
+            }
+    }
+}
+
+// Window._forward window.py:185-193
+template <typename T>
+__global__ void window_fwd_kernel(const T* __restrict__ x, long F, int L, const T* __restrict__ w,
+                                  int L2, T* __restrict__ y)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = F * L2;
+    for (; i < total; i += (long)gridDim.x * blockDim.x) {
+        long f = i / L2;
+        int l = (int)(i - f * L2);
+        y[i] = l < L ? x[f * L + l] * w[l] : T(0);
+    }
+}
+
+template <typename T>
+__global__ void window_bwd_kernel(const T* __restrict__ gy, long F, int L, const T* __restrict__ w,
+                                  int L2, T* __restrict__ gx)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = F * L;
+    for (; i < total; i += (long)gridDim.x * blockDim.x) {
+        long f = i / L;
+        int l = (int)(i - f * L);
+        gx[i] = l < L2 ? gy[f * L2 + l] * w[l] : T(0);
+    }
+}
+
+// gw[l] = sum_f gy[f,l] * x[f,l]; one block per l, fixed summation order (deterministic)
+template <typename T>
+__global__ void window_gw_kernel(const T* __restrict__ gy, const T* __restrict__ x, long F, int L,
+                                 int L2, T* __restrict__ gw)
+{
+    __shared__ T scratch[16];
+    int l = blockIdx.x;
+    T acc = 0;
+    if (l < L2)
+        for (long f = threadIdx.x; f < F; f += blockDim.x) acc += gy[f * L2 + l] * x[f * L + l];
+    T s = block_sum(acc, scratch);
+    if (threadIdx.x == 0) gw[l] = s;
+}
+
+// Generic fused row transform: (optional framing) -> (optional zmean) -> (optional window) ->
+// direct DFT of length nfft -> formatter.  Covers fftr (fftr.py:136-151), the b-only branch of
+// Spectrum (spec.py:165-178) and STFT (stft.py:237-241) for any configuration.
+//   out_kind 0: fftr formats (DSA_FFTR_*), 1: spectrum formats (DSA_SPEC_*).
+// twiddle: (nfft, 2) = (cos, -sin)(2 pi m / nfft).
+// dynamic LDS: Lrow elements of T.
+template <typename T>
+__global__ void row_dft_kernel(const T* __restrict__ x, long Tlen, long N, int L, int P, int left,
+                               int mode, int zmean, const T* __restrict__ w, int nfft,
+                               const T* __restrict__ twiddle, int out_kind, int fmt, T eps,
+                               int use_floor, T floor_lin, T* __restrict__ y)
+{
+    extern __shared__ unsigned char smem_raw[];
+    T* xs = reinterpret_cast<T*>(smem_raw);
+    __shared__ T scratch[16];
+    long f = blockIdx.x;
+    long b = f / N, n = f - b * N;
+    const T* xb = x + b * Tlen;
+    T acc = 0;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        T v = load_padded(xb, n * P + l - left, Tlen, mode);
+        xs[l] = v;
+        acc += v;
+    }
+    T mean = 0;
+    if (zmean) mean = block_sum(acc, scratch) / T(L);
+    __syncthreads();
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        T v = xs[l] - mean;
+        xs[l] = w ? v * w[l] : v;
+    }
+    __syncthreads();
+    const int K = nfft / 2 + 1;
+    const int Lc = L < nfft ? L : nfft;  // rfft(x, n) crops when the row is longer than n
+    const bool complex_out = (out_kind == 0 && fmt == DSA_FFTR_COMPLEX) ||
+                             (out_kind == 1 && fmt == DSA_SPEC_COMPLEX);
+    T smax = 0;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        T re = 0, im = 0;
+        int idx = 0;
+        for (int l = 0; l < Lc; ++l) {
+            T c = twiddle[2 * idx], s = twiddle[2 * idx + 1];
+            re += xs[l] * c;
+            im += xs[l] * s;
+            idx += k;
+            if (idx >= nfft) idx -= nfft;
+        }
+        if (complex_out) {
+            y[(f * K + k) * 2] = re;
+            y[(f * K + k) * 2 + 1] = im;
+        } else if (out_kind == 0) {
+            T v;
+            switch (fmt) {
+            case DSA_FFTR_REAL: v = re; break;
+            case DSA_FFTR_IMAG: v = im; break;
+            case DSA_FFTR_AMPLITUDE: v = dsa_sqrt(re * re + im * im); break;
+            default: {
+                T a = dsa_sqrt(re * re + im * im);  // abs() then square(), fftr.py:119
+                v = a * a;
+            }
+            }
+            y[f * K + k] = v;
+        } else {
+            T a = dsa_sqrt(re * re + im * im);  // fftr amplitude (spec.py:139), then spec.py:173
+            T s = a * a + eps;
+            if (use_floor) {
+                y[f * K + k] = s;  // formatted after the row maximum is known
+                smax = s > smax ? s : smax;
+            } else {
+                y[f * K + k] = spec_format(s, fmt);
+            }
+        }
+    }
+    if (out_kind == 1 && use_floor && !complex_out) {  // spec.py:174-176
+        T m = block_max(smax, scratch);
+        __syncthreads();
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            T s = y[f * K + k];
+            T fl = m * floor_lin;
+            y[f * K + k] = spec_format(s > fl ? s : fl, fmt);
+        }
+    }
+}
+
+// Backward of row_dft_kernel.  Recomputes X (nothing but x is saved by the forward), forms the
+// complex cotangent C[k] = dL/dRe X + i dL/dIm X for the requested format, applies the adjoint
+// of the half-spectrum DFT  gxw[l] = sum_k Re(C[k] exp(+i theta k l)), then the adjoints of the
+// window multiply and of zmean.  Output: gframe (F, L) = cotangent of the framed samples (the
+// overlap-add into the waveform is done by frame_bwd); gwpart (F, L) = per-frame contribution
+// to the window gradient (NULL unless the window is learnable).
+// dynamic LDS: (L + 3K) elements of T.
+template <typename T>
+__global__ void row_dft_bwd_kernel(const T* __restrict__ x, long Tlen, long N, int L, int P, int left,
+                                   int mode, int zmean, const T* __restrict__ w, int nfft,
+                                   const T* __restrict__ twiddle, int out_kind, int fmt, T eps,
+                                   int use_floor, T floor_lin, const T* __restrict__ gy,
+                                   T* __restrict__ gframe, T* __restrict__ gwpart)
+{
+    extern __shared__ unsigned char smem_raw[];
+    T* xc = reinterpret_cast<T*>(smem_raw);
+    __shared__ T scratch[16];
+    const int K = nfft / 2 + 1;
+    const int Lc = L < nfft ? L : nfft;
+    T* Cre = xc + L;
+    T* Cim = Cre + K;
+    long f = blockIdx.x;
+    long b = f / N, n = f - b * N;
+    const T* xb = x + b * Tlen;
+    T acc = 0;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        T v = load_padded(xb, n * P + l - left, Tlen, mode);
+        xc[l] = v;
+        acc += v;
+    }
+    T mean = 0;
+    if (zmean) mean = block_sum(acc, scratch) / T(L);
+    __syncthreads();
+    for (int l = threadIdx.x; l < L; l += blockDim.x) xc[l] -= mean;
+    __syncthreads();
+    const bool complex_out = (out_kind == 0 && fmt == DSA_FFTR_COMPLEX) ||
+                             (out_kind == 1 && fmt == DSA_SPEC_COMPLEX);
+    T smax = 0;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        T re = 0, im = 0;
+        int idx = 0;
+        for (int l = 0; l < Lc; ++l) {
+            T xv = w ? xc[l] * w[l] : xc[l];
+            re += xv * twiddle[2 * idx];
+            im += xv * twiddle[2 * idx + 1];
+            idx += k;
+            if (idx >= nfft) idx -= nfft;
+        }
+        T cr, ci;
+        if (complex_out) {
+            cr = gy[(f * K + k) * 2];
+            ci = gy[(f * K + k) * 2 + 1];
+        } else if (out_kind == 0) {
+            T g = gy[f * K + k];
+            switch (fmt) {
+            case DSA_FFTR_REAL: cr = g; ci = 0; break;
+            case DSA_FFTR_IMAG: cr = 0; ci = g; break;
+            case DSA_FFTR_AMPLITUDE: {
+                T a = dsa_sqrt(re * re + im * im);
+                T sc = a > T(0) ? g / a : T(0);
+                cr = sc * re; ci = sc * im;
+                break;
+            }
+            default: cr = T(2) * g * re; ci = T(2) * g * im;
+            }
+        } else {
+            // keep (re, im) for now; the cotangent of s needs the row maximum when floored
+            cr = re; ci = im;
+            T sv = re * re + im * im + eps;
+            smax = sv > smax ? sv : smax;
+        }
+        Cre[k] = cr;
+        Cim[k] = ci;
+    }
+    if (out_kind == 1 && !complex_out) {
+        // cotangent of s = |X|^2 + eps through the formatter and the relative floor
+        // s' = max(s, m * floor), m = amax(s) (spec.py:173-177): floored bins pass their
+        // cotangent (times floor) to the arg-max bin.
+        T* gsarr = Cim + K;
+        T m = use_floor ? block_max(smax, scratch) : T(0);
+        T fl = m * floor_lin;
+        __syncthreads();
+        T lost = 0;
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            T re = Cre[k], im = Cim[k];
+            T sv = re * re + im * im + eps;
+            bool floored = use_floor && sv < fl;
+            T se = floored ? fl : sv;
+            T g = gy[f * K + k];
+            T gs;
+            switch (fmt) {
+            case DSA_SPEC_DB: gs = g * T(4.342944819032518) / se; break;  // 10 / ln 10
+            case DSA_SPEC_LOGMAG: gs = g * T(0.5) / se; break;
+            case DSA_SPEC_MAG: gs = g * T(0.5) / dsa_sqrt(se); break;
+            default: gs = g;
+            }
+            if (floored) {
+                lost += gs;
+                gs = 0;
+            }
+            gsarr[k] = gs;
+        }
+        T tot = use_floor ? block_sum(lost, scratch) * floor_lin : T(0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            T re = Cre[k], im = Cim[k];
+            T gs = gsarr[k];
+            if (use_floor && (re * re + im * im + eps) == m) gs += tot;
+            Cre[k] = T(2) * gs * re;
+            Cim[k] = T(2) * gs * im;
+        }
+    }
+    __syncthreads();
+    T gsum = 0;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        T g = 0;
+        if (l < Lc) {
+            int idx = 0;
+            for (int k = 0; k < K; ++k) {
+                g += Cre[k] * twiddle[2 * idx] + Cim[k] * twiddle[2 * idx + 1];
+                idx += l;
+                if (idx >= nfft) idx -= nfft;
+            }
+        }
+        if (gwpart) gwpart[f * L + l] = g * xc[l];
+        T gf = w ? g * w[l] : g;
+        gsum += gf;
+        gframe[f * L + l] = gf;
+    }
+    if (zmean) {
+        T gm = block_sum(gsum, scratch) / T(L);
+        for (int l = threadIdx.x; l < L; l += blockDim.x) gframe[f * L + l] -= gm;
+    }
+}
+
+// out[l] = sum_f part[f, l] in a fixed order (deterministic window gradient)
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ part, long F, int L, T* __restrict__ out)
+{
+    __shared__ T scratch[16];
+    int l = blockIdx.x;
+    T acc = 0;
+    for (long f = threadIdx.x; f < F; f += blockDim.x) acc += part[f * L + l];
+    T s = block_sum(acc, scratch);
+    if (threadIdx.x == 0) out[l] = s;
+}
+
+// Spectrum with a denominator (spec.py:160-171): combines |B| and |A| amplitude rows.
+// ab:(F,K) or NULL, aa:(F,K) or NULL (at least aa here), gain:(F) = a[:,0].
+template <typename T>
+__global__ void spec_ratio_kernel(const T* __restrict__ ab, const T* __restrict__ aa,
+                                  const T* __restrict__ a, int la, int K, T eps, int use_floor,
+                                  T floor_lin, int fmt, T* __restrict__ y)
+{
+    __shared__ T scratch[16];
+    long f = blockIdx.x;
+    T gain = a[f * la];
+    T smax = 0;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        T X = ab ? gain * (ab[f * K + k] / aa[f * K + k]) : gain / aa[f * K + k];
+        T s = X * X + eps;
+        smax = s > smax ? s : smax;
+        y[f * K + k] = use_floor ? s : spec_format(s, fmt);
+    }
+    if (use_floor) {
+        T m = block_max(smax, scratch);
+        __syncthreads();
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            T s = y[f * K + k];
+            T fl = m * floor_lin;
+            y[f * K + k] = spec_format(s > fl ? s : fl, fmt);
+        }
+    }
+}
+
+// remove_gain (utils/private.py:200-209): a1 = [1, a[1:]]
+template <typename T>
+__global__ void remove_gain_kernel(const T* __restrict__ a, long F, int la, T* __restrict__ a1)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F * la) return;
+    a1[i] = (i % la == 0) ? T(1) : a[i];
+}
+
+// =========================================================================== tuned rFFT-512 path
+
+struct cf {
+    float re, im;
+};
+__device__ __forceinline__ cf operator+(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cf operator-(cf a, cf b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cf cmul(cf a, cf b)
+{
+    return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+
+// 4-point DFT in place, forward (W4 = -i); INV conjugates the kernel.
+template <bool INV>
+__device__ __forceinline__ void dft4(cf& a0, cf& a1, cf& a2, cf& a3)
+{
+    cf s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+    a0 = s02 + s13;
+    a2 = s02 - s13;
+    if (!INV) {
+        a1 = {d02.re + d13.im, d02.im - d13.re};  // d02 - i d13
+        a3 = {d02.re - d13.im, d02.im + d13.re};  // d02 + i d13
+    } else {
+        a1 = {d02.re - d13.im, d02.im + d13.re};
+        a3 = {d02.re + d13.im, d02.im - d13.re};
+    }
+}
+
+// 16-point DFT in registers (radix 4 x 4).  Output order: X[k] sits in v[4*(k&3) + (k>>2)].
+template <bool INV>
+__device__ __forceinline__ void fft16(cf (&v)[16])
+{
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+    constexpr float sg = INV ? 1.f : -1.f;  // sign of the imaginary part of W16^e
+#pragma unroll
+    for (int n0 = 0; n0 < 4; ++n0) dft4<INV>(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);
+    // after the first pass v[n0 + 4q] = B[n0][q]; twiddle by W16^(n0*q)
+    v[1 + 4 * 1] = cmul(v[1 + 4 * 1], cf{C1, sg * S1});   // e = 1
+    v[1 + 4 * 2] = cmul(v[1 + 4 * 2], cf{R2, sg * R2});   // e = 2
+    v[1 + 4 * 3] = cmul(v[1 + 4 * 3], cf{S1, sg * C1});   // e = 3
+    v[2 + 4 * 1] = cmul(v[2 + 4 * 1], cf{R2, sg * R2});   // e = 2
+    v[2 + 4 * 2] = cf{-sg * v[2 + 4 * 2].im, sg * v[2 + 4 * 2].re};   // e = 4: (0, sg) * v
+    v[2 + 4 * 3] = cmul(v[2 + 4 * 3], cf{-R2, sg * R2});  // e = 6
+    v[3 + 4 * 1] = cmul(v[3 + 4 * 1], cf{S1, sg * C1});   // e = 3
+    v[3 + 4 * 2] = cmul(v[3 + 4 * 2], cf{-R2, sg * R2});  // e = 6
+    v[3 + 4 * 3] = cmul(v[3 + 4 * 3], cf{-C1, -sg * S1}); // e = 9
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dft4<INV>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+#define FFT16_OUT(k) (4 * ((k)&3) + ((k) >> 2))
+
+constexpr int kFPB = 16;        // frames per workgroup pass (4 waves x 4 frames)
+constexpr int kZStride = 272;   // complex elements per frame region: 16 x 17 (padded transpose)
+
+// ShortTimeFourierTransform._forward stft.py:237-241 for nfft = 512, float32.
+// dynamic LDS layout (bytes): in_buf[(kFPB-1)*P + 512 (+pad)] floats | zbuf[kFPB][272] cf |
+//                             tw[257] cf | fmax[kFPB] floats
+__global__ __launch_bounds__(256) void stft512_fwd_kernel(
+    const float* __restrict__ x, long Tlen, long N, int L, int P, int left, int mode, int zmean,
+    const float* __restrict__ w, const float* __restrict__ twiddle, float eps, int use_floor,
+    float floor_lin, int fmt, float* __restrict__ y, long total_chunks, int chunks_per_utt,
+    int in_floats)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* in_buf = reinterpret_cast<float*>(smem_raw);
+    cf* zbuf = reinterpret_cast<cf*>(in_buf + in_floats);
+    cf* tw = zbuf + kFPB * kZStride;
+    float* fmax = reinterpret_cast<float*>(tw + 257);
+
+    const int tid = threadIdx.x;
+    const int j = tid & 15;             // lane within the frame group
+    const int fl = tid >> 4;            // frame slot within the chunk (0..15)
+    const int span = (kFPB - 1) * P + 512;
+
+    // per-block constants: post-processing twiddles, per-lane window and W256^(j*k1)
+    for (int k = tid; k < 257; k += 256) tw[k] = cf{twiddle[2 * k], twiddle[2 * k + 1]};  // (cos,-sin)(2 pi k/512)
+    float wreg[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        int l = 2 * j + 32 * (r >> 1) + (r & 1);
+        wreg[r] = l < L ? w[l] : 0.f;
+    }
+    cf t256[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+        int m = 2 * j * k1;  // W256^(j k1) = W512^(2 j k1)
+        t256[k1] = cf{twiddle[2 * m], twiddle[2 * m + 1]};
+    }
+    const float inv_L = 1.f / (float)L;
+    const int K = 257;
+    const bool complex_out = fmt == DSA_SPEC_COMPLEX;
+
+    for (long c = blockIdx.x; c < total_chunks; c += gridDim.x) {
+        const long b = c / chunks_per_utt;
+        const long frame0 = (c - b * chunks_per_utt) * kFPB;
+        const int nvalid = (int)((N - frame0) < kFPB ? (N - frame0) : kFPB);
+        const float* xb = x + b * Tlen;
+        __syncthreads();  // previous chunk's output phase done with zbuf / in_buf
+        // ---- stage the shared waveform stretch (each sample read from HBM once) ----
+        {
+            const long g0 = frame0 * P - left;
+            const int need = (nvalid - 1) * P + L;  // samples any valid frame can touch
+            for (int s = tid; s < span; s += 256)
+                in_buf[s] = s < need ? load_padded(xb, g0 + s, Tlen, mode) : 0.f;
+        }
+        __syncthreads();
+        // ---- per frame: window, 256-point complex FFT (16 lanes x 16 points) ----
+        cf v[16];
+        {
+            const float* src = in_buf + fl * P + 2 * j;
+            float sum = 0.f;
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) {
+                int l = 2 * j + 32 * m1;
+                float a0 = src[32 * m1], a1 = src[32 * m1 + 1];
+                a0 = l < L ? a0 : 0.f;       // keep non-finite samples out of frames that do
+                a1 = l + 1 < L ? a1 : 0.f;   // not contain them (zero padding is exact)
+                v[m1] = cf{a0, a1};
+                sum += a0 + a1;
+            }
+            float mean = 0.f;
+            if (zmean) {  // frame.py:139-140: mean over the L samples of the frame
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+                mean = sum * inv_L;
+            }
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) {
+                int l = 2 * j + 32 * m1;
+                float a0 = l < L ? v[m1].re - mean : 0.f;
+                float a1 = l + 1 < L ? v[m1].im - mean : 0.f;
+                v[m1] = cf{a0 * wreg[2 * m1], a1 * wreg[2 * m1 + 1]};  // window.py:190
+            }
+        }
+        fft16<false>(v);
+        cf* zf = zbuf + fl * kZStride;
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1)  // twiddle, then transposed store [k1][j] (row stride 17)
+            zf[k1 * 17 + j] = cmul(v[FFT16_OUT(k1)], t256[k1]);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = zf[j * 17 + i];  // lane k1 = j reads A[i][k1]
+        __syncthreads();
+        fft16<false>(v);
+#pragma unroll
+        for (int k0 = 0; k0 < 16; ++k0) zf[j + 16 * k0] = v[FFT16_OUT(k0)];  // Z[k1 + 16 k0], natural order
+        __syncthreads();
+        // ---- optional relative floor: per-frame maximum of |X|^2 + eps (spec.py:174-176) ----
+        if (use_floor && !complex_out) {
+            float m = 0.f;
+            for (int k = j; k < K; k += 16) {
+                cf a = zf[k & 255], bq = zf[(256 - k) & 255];
+                cf e = {0.5f * (a.re + bq.re), 0.5f * (a.im - bq.im)};
+                cf o = {0.5f * (a.re - bq.re), 0.5f * (a.im + bq.im)};
+                cf t = tw[k];  // (cos, -sin)
+                float re = e.re + (t.re * o.im + t.im * o.re);
+                float im = e.im - (t.re * o.re - t.im * o.im);
+                float s = re * re + im * im + eps;
+                m = s > m ? s : m;
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                float u = __shfl_xor(m, o, 16);
+                m = u > m ? u : m;
+            }
+            if (j == 0) fmax[fl] = m;
+            __syncthreads();
+        }
+        // ---- real-FFT split + formatter fused into the coalesced write of the output tile ----
+        {
+            const long out0 = (b * N + frame0) * K;
+            const int total = nvalid * K;
+            for (int idx = tid; idx < total; idx += 256) {
+                int f = idx / K;
+                int k = idx - f * K;
+                const cf* z = zbuf + f * kZStride;
+                cf a = z[k & 255], bq = z[(256 - k) & 255];
+                // X[k] = E - i W O,  E = (a + conj(b))/2, O = (a - conj(b))/2, W = exp(-2 pi i k/512)
+                cf e = {0.5f * (a.re + bq.re), 0.5f * (a.im - bq.im)};
+                cf o = {0.5f * (a.re - bq.re), 0.5f * (a.im + bq.im)};
+                cf t = tw[k];
+                float re = e.re + (t.re * o.im + t.im * o.re);
+                float im = e.im - (t.re * o.re - t.im * o.im);
+                if (complex_out) {
+                    reinterpret_cast<float2*>(y)[out0 + idx] = make_float2(re, im);
+                } else {
+                    float s = re * re + im * im + eps;  // spec.py:173
+                    if (use_floor) {
+                        float flv = fmax[f] * floor_lin;
+                        s = s > flv ? s : flv;
+                    }
+                    y[out0 + idx] = spec_format(s, fmt);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host-side dispatch helpers
+template <typename T>
+static int launch_row_dft(const void* x, int64_t B, int64_t Tlen, int64_t N, int L, int P, int left,
+                          int mode, int zmean, const void* w, int nfft, const void* twiddle,
+                          int out_kind, int fmt, double eps, int use_floor, double floor_db,
+                          void* y, hipStream_t st)
+{
+    int64_t F = B * N;
+    if (F == 0) return DSA_OK;
+    T floor_lin = use_floor ? (T)pow(10.0, floor_db / 10.0) : T(0);
+    size_t lds = sizeof(T) * (size_t)L;
+    if (lds > 60 * 1024) return fail(DSA_ERR_UNSUPPORTED, "row_dft: frame too long for LDS%s");
+    int threads = nfft / 2 + 1 >= 192 ? 256 : (nfft / 2 + 1 >= 96 ? 128 : 64);
+    hipLaunchKernelGGL((row_dft_kernel<T>), dim3((unsigned)F), dim3(threads), lds, st, (const T*)x,
+                       (long)Tlen, (long)N, L, P, left, mode, zmean, (const T*)w, nfft,
+                       (const T*)twiddle, out_kind, fmt, (T)eps, use_floor, floor_lin, (T*)y);
+    return check_launch("row_dft_generic");
+}
+
+static int stft512_lds_bytes(int P, int* in_floats)
+{
+    int span = (kFPB - 1) * P + 512;
+    *in_floats = (span + 3) & ~3;
+    return *in_floats * 4 + kFPB * kZStride * 8 + 257 * 8 + kFPB * 4;
+}
+
+}  // namespace dsa
+
+using namespace dsa;
+
+// =========================================================================== C-ABI
+
+DSA_EXPORT int dsa_version(void) { return DSA_VERSION; }
+DSA_EXPORT const char* dsa_last_error(void) { return err_buf(); }
+DSA_EXPORT const char* dsa_last_kernel(void) { return kernel_name(); }
+DSA_EXPORT int dsa_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(DSA_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+DSA_EXPORT int64_t dsa_num_frames(int64_t T, int32_t P) { return (T <= 0 || P <= 0) ? 0 : (T - 1) / P + 1; }
+
+DSA_EXPORT int dsa_frame_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, int32_t center,
+                             int32_t zmean, int32_t pad_mode, int32_t dtype, void* y, void* stream)
+{
+    DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0, "frame: sizes must be positive");
+    DSA_REQUIRE(pad_mode >= 0 && pad_mode <= 3, "frame: unknown pad mode");
+    DSA_REQUIRE(pad_mode != DSA_PAD_REFLECT || (L / 2 < T && L - 1 < T) || T == 1,
+                "frame: reflect padding needs pad < input length");
+    int64_t N = dsa_num_frames(T, P), F = B * N;
+    if (F == 0) return DSA_OK;
+    int left = center ? L / 2 : 0;
+    int threads = L >= 192 ? 256 : (L >= 96 ? 128 : 64);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSA_F32)
+        hipLaunchKernelGGL((frame_fwd_kernel<float>), dim3((unsigned)F), dim3(threads), 0, st,
+                           (const float*)x, (long)T, (long)N, L, P, left, zmean, pad_mode, (float*)y);
+    else if (dtype == DSA_F64)
+        hipLaunchKernelGGL((frame_fwd_kernel<double>), dim3((unsigned)F), dim3(threads), 0, st,
+                           (const double*)x, (long)T, (long)N, L, P, left, zmean, pad_mode, (double*)y);
+    else
+        return fail(DSA_ERR_UNSUPPORTED, "frame: unsupported dtype%s");
+    return check_launch("frame_fwd");
+}
+
+template <typename T>
+static int frame_bwd_impl(const void* gy, int64_t B, int64_t Tlen, int L, int P, int center,
+                          int zmean, int pad_mode, void* gx, hipStream_t st)
+{
+    int64_t N = dsa_num_frames(Tlen, P), F = B * N;
+    int left = center ? L / 2 : 0;
+    T* gmean = nullptr;
+    if (zmean) {
+        // d/dx of (y - mean(y)) = g - mean(g): per-frame mean of the cotangent
+        if (hipMallocAsync((void**)&gmean, sizeof(T) * (size_t)F, st) != hipSuccess)
+            return fail(DSA_ERR_LAUNCH, "frame_bwd: workspace allocation failed%s");
+        hipLaunchKernelGGL((row_mean_kernel<T>), dim3((unsigned)F), dim3(64), 0, st, (const T*)gy, L, gmean);
+    }
+    if (pad_mode == DSA_PAD_CONSTANT) {
+        dim3 grid((unsigned)((Tlen + 255) / 256), (unsigned)B);
+        hipLaunchKernelGGL((frame_bwd_const_kernel<T>), grid, dim3(256), 0, st, (const T*)gy, gmean,
+                           (long)Tlen, (long)N, L, P, left, (T*)gx);
+    } else {
+        hipLaunchKernelGGL((frame_bwd_general_kernel<T>), dim3((unsigned)B), dim3(256), 0, st,
+                           (const T*)gy, gmean, (long)Tlen, (long)N, L, P, left, pad_mode, (T*)gx);
+    }
+    int rc = check_launch("frame_bwd");
+    if (gmean) hipFreeAsync(gmean, st);
+    return rc;
+}
+
+DSA_EXPORT int dsa_frame_bwd(const void* gy, int64_t B, int64_t T, int32_t L, int32_t P, int32_t center,
+                             int32_t zmean, int32_t pad_mode, int32_t dtype, void* gx, void* stream)
+{
+    DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0, "frame_bwd: sizes must be positive");
+    if (B == 0) return DSA_OK;
+    if (dtype == DSA_F32) return frame_bwd_impl<float>(gy, B, T, L, P, center, zmean, pad_mode, gx, (hipStream_t)stream);
+    if (dtype == DSA_F64) return frame_bwd_impl<double>(gy, B, T, L, P, center, zmean, pad_mode, gx, (hipStream_t)stream);
+    return fail(DSA_ERR_UNSUPPORTED, "frame_bwd: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_window_fwd(const void* x, int64_t F, int32_t L, const void* w, int32_t L2, int32_t dtype,
+                              void* y, void* stream)
+{
+    DSA_REQUIRE(L > 0 && L2 > 0 && F >= 0, "window: sizes must be positive");
+    if (F == 0) return DSA_OK;
+    int64_t total = F * L2;
+    unsigned grid = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSA_F32)
+        hipLaunchKernelGGL((window_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x,
+                           (long)F, L, (const float*)w, L2, (float*)y);
+    else if (dtype == DSA_F64)
+        hipLaunchKernelGGL((window_fwd_kernel<double>), dim3(grid), dim3(256), 0, st, (const double*)x,
+                           (long)F, L, (const double*)w, L2, (double*)y);
+    else
+        return fail(DSA_ERR_UNSUPPORTED, "window: unsupported dtype%s");
+    return check_launch("window_fwd");
+}
+
+DSA_EXPORT int dsa_window_bwd(const void* gy, const void* x, int64_t F, int32_t L, const void* w, int32_t L2,
+                              int32_t dtype, void* gx, void* gw, void* stream)
+{
+    DSA_REQUIRE(L > 0 && L2 > 0 && F >= 0, "window_bwd: sizes must be positive");
+    if (F == 0) return DSA_OK;
+    int64_t total = F * L;
+    unsigned grid = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSA_F32) {
+        hipLaunchKernelGGL((window_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)gy,
+                           (long)F, L, (const float*)w, L2, (float*)gx);
+        if (gw)
+            hipLaunchKernelGGL((window_gw_kernel<float>), dim3(L), dim3(256), 0, st, (const float*)gy,
+                               (const float*)x, (long)F, L, L2, (float*)gw);
+    } else if (dtype == DSA_F64) {
+        hipLaunchKernelGGL((window_bwd_kernel<double>), dim3(grid), dim3(256), 0, st, (const double*)gy,
+                           (long)F, L, (const double*)w, L2, (double*)gx);
+        if (gw)
+            hipLaunchKernelGGL((window_gw_kernel<double>), dim3(L), dim3(256), 0, st, (const double*)gy,
+                               (const double*)x, (long)F, L, L2, (double*)gw);
+    } else
+        return fail(DSA_ERR_UNSUPPORTED, "window_bwd: unsupported dtype%s");
+    return check_launch("window_bwd");
+}
+
+DSA_EXPORT int dsa_fftr_fwd(const void* x, int64_t F, int32_t len_in, int32_t nfft, int32_t out_format,
+                            const void* twiddle, int32_t dtype, void* y, void* stream)
+{
+    DSA_REQUIRE(len_in > 0 && nfft > 0 && nfft % 2 == 0, "fftr: fft_length must be positive even");
+    DSA_REQUIRE(out_format >= 0 && out_format <= 4, "fftr: unknown out_format");
+    hipStream_t st = (hipStream_t)stream;
+    // rows are "utterances" of len_in samples holding exactly one frame each
+    if (dtype == DSA_F32)
+        return launch_row_dft<float>(x, F, len_in, 1, len_in, len_in, 0, 0, 0, nullptr, nfft, twiddle, 0,
+                                     out_format, 0.0, 0, 0.0, y, st);
+    if (dtype == DSA_F64)
+        return launch_row_dft<double>(x, F, len_in, 1, len_in, len_in, 0, 0, 0, nullptr, nfft, twiddle, 0,
+                                      out_format, 0.0, 0, 0.0, y, st);
+    return fail(DSA_ERR_UNSUPPORTED, "fftr: unsupported dtype%s");
+}
+
+template <typename T>
+static int spec_fwd_impl(const void* b, int lb, const void* a, int la, int64_t F, int nfft, double eps,
+                         int use_floor, double floor_db, int fmt, const void* twiddle, void* y,
+                         hipStream_t st)
+{
+    if (!a)
+        return launch_row_dft<T>(b, F, lb, 1, lb, lb, 0, 0, 0, nullptr, nfft, twiddle, 1, fmt, eps,
+                                 use_floor, floor_db, y, st);
+    // denominator present: amplitude rows of b and of remove_gain(a), then the ratio kernel
+    const int K = nfft / 2 + 1;
+    T *amp_b = nullptr, *amp_a = nullptr, *a1 = nullptr;
+    size_t rows = sizeof(T) * (size_t)F * K;
+    if (hipMallocAsync((void**)&amp_a, rows, st) != hipSuccess ||
+        hipMallocAsync((void**)&a1, sizeof(T) * (size_t)F * la, st) != hipSuccess ||
+        (b && hipMallocAsync((void**)&amp_b, rows, st) != hipSuccess))
+        return fail(DSA_ERR_LAUNCH, "spec: workspace allocation failed%s");
+    int64_t tot = F * la;
+    hipLaunchKernelGGL((remove_gain_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
+                       (const T*)a, (long)F, la, a1);
+    int rc = launch_row_dft<T>(a1, F, la, 1, la, la, 0, 0, 0, nullptr, nfft, twiddle, 0, DSA_FFTR_AMPLITUDE,
+                               0.0, 0, 0.0, amp_a, st);
+    if (rc == DSA_OK && b)
+        rc = launch_row_dft<T>(b, F, lb, 1, lb, lb, 0, 0, 0, nullptr, nfft, twiddle, 0, DSA_FFTR_AMPLITUDE,
+                               0.0, 0, 0.0, amp_b, st);
+    if (rc == DSA_OK) {
+        T floor_lin = use_floor ? (T)pow(10.0, floor_db / 10.0) : T(0);
+        hipLaunchKernelGGL((spec_ratio_kernel<T>), dim3((unsigned)F), dim3(64), 0, st, (const T*)amp_b,
+                           (const T*)amp_a, (const T*)a, la, K, (T)eps, use_floor, floor_lin, fmt, (T*)y);
+        rc = check_launch("spec_ratio");
+    }
+    hipFreeAsync(amp_a, st);
+    hipFreeAsync(a1, st);
+    if (amp_b) hipFreeAsync(amp_b, st);
+    return rc;
+}
+
+DSA_EXPORT int dsa_spec_fwd(const void* b, int32_t lb, const void* a, int32_t la, int64_t F, int32_t nfft,
+                            double eps, int32_t use_floor, double relative_floor_db, int32_t out_format,
+                            const void* twiddle, int32_t dtype, void* y, void* stream)
+{
+    DSA_REQUIRE(b || a, "spec: either b or a must be specified");
+    DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "spec: fft_length must be positive even");
+    DSA_REQUIRE(out_format >= 0 && out_format <= 3, "spec: unknown out_format");
+    if (F == 0) return DSA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSA_F32)
+        return spec_fwd_impl<float>(b, lb, a, la, F, nfft, eps, use_floor, relative_floor_db, out_format, twiddle, y, st);
+    if (dtype == DSA_F64)
+        return spec_fwd_impl<double>(b, lb, a, la, F, nfft, eps, use_floor, relative_floor_db, out_format, twiddle, y, st);
+    return fail(DSA_ERR_UNSUPPORTED, "spec: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft,
+                            const void* w, const void* twiddle, int32_t center, int32_t zmean,
+                            int32_t pad_mode, double eps, int32_t use_floor, double relative_floor_db,
+                            int32_t out_format, int32_t dtype, int32_t algo, void* y, void* stream)
+{
+    DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0, "stft: sizes must be positive");
+    DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "stft: fft_length must be positive even");
+    DSA_REQUIRE(pad_mode >= 0 && pad_mode <= 3, "stft: unknown pad mode");
+    DSA_REQUIRE(out_format >= 0 && out_format <= 4, "stft: unknown out_format");
+    DSA_REQUIRE(pad_mode != DSA_PAD_REFLECT || (L / 2 < T && L - 1 < T) || T == 1,
+                "stft: reflect padding needs pad < input length");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t N = dsa_num_frames(T, P);
+    if (B * N == 0) return DSA_OK;
+    int left = center ? L / 2 : 0;
+    int in_floats = 0;
+    int lds = stft512_lds_bytes(P, &in_floats);
+    bool tuned_ok = dtype == DSA_F32 && nfft == 512 && L <= 512 && lds <= 160 * 1024;
+    if (algo == DSA_ALGO_TUNED && !tuned_ok)
+        return fail(DSA_ERR_UNSUPPORTED, "stft: tuned kernel needs float32, fft_length 512, frame_length <= 512%s");
+    if (tuned_ok && algo != DSA_ALGO_GENERIC) {
+        int chunks_per_utt = (int)((N + kFPB - 1) / kFPB);
+        long total_chunks = (long)B * chunks_per_utt;
+        if (lds > 48 * 1024)
+            hipFuncSetAttribute((const void*)stft512_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        int blocks_per_cu = 160 * 1024 / lds;
+        if (blocks_per_cu > 8) blocks_per_cu = 8;
+        if (blocks_per_cu < 1) blocks_per_cu = 1;
+        long grid = 256L * blocks_per_cu;
+        if (grid > total_chunks) grid = total_chunks;
+        float floor_lin = use_floor ? (float)pow(10.0, relative_floor_db / 10.0) : 0.f;
+        hipLaunchKernelGGL(stft512_fwd_kernel, dim3((unsigned)grid), dim3(256), lds, st, (const float*)x,
+                           (long)T, (long)N, L, P, left, pad_mode, zmean, (const float*)w,
+                           (const float*)twiddle, (float)eps, use_floor, floor_lin, out_format, (float*)y,
+                           total_chunks, chunks_per_utt, in_floats);
+        return check_launch("stft512_fwd");
+    }
+    if (dtype == DSA_F32)
+        return launch_row_dft<float>(x, B, T, N, L, P, left, pad_mode, zmean, w, nfft, twiddle, 1, out_format,
+                                     eps, use_floor, relative_floor_db, y, st);
+    if (dtype == DSA_F64)
+        return launch_row_dft<double>(x, B, T, N, L, P, left, pad_mode, zmean, w, nfft, twiddle, 1, out_format,
+                                      eps, use_floor, relative_floor_db, y, st);
+    return fail(DSA_ERR_UNSUPPORTED, "stft: unsupported dtype%s");
+}
+
+// --------------------------------------------------------------------------- backward entries
+namespace dsa {
+
+template <typename T>
+static int launch_row_dft_bwd(const void* x, int64_t B, int64_t Tlen, int64_t N, int L, int P, int left,
+                              int mode, int zmean, const void* w, int nfft, const void* twiddle,
+                              int out_kind, int fmt, double eps, int use_floor, double floor_db,
+                              const void* gy, void* gframe, void* gwpart, hipStream_t st)
+{
+    int64_t F = B * N;
+    if (F == 0) return DSA_OK;
+    T floor_lin = use_floor ? (T)pow(10.0, floor_db / 10.0) : T(0);
+    const int K = nfft / 2 + 1;
+    size_t lds = sizeof(T) * ((size_t)L + 3 * (size_t)K);
+    if (lds > 60 * 1024) return fail(DSA_ERR_UNSUPPORTED, "row_dft_bwd: frame too long for LDS%s");
+    hipLaunchKernelGGL((row_dft_bwd_kernel<T>), dim3((unsigned)F), dim3(256), lds, st, (const T*)x, (long)Tlen,
+                       (long)N, L, P, left, mode, zmean, (const T*)w, nfft, (const T*)twiddle, out_kind, fmt,
+                       (T)eps, use_floor, floor_lin, (const T*)gy, (T*)gframe, (T*)gwpart);
+    return check_launch("row_dft_bwd_generic");
+}
+
+template <typename T>
+static int stft_bwd_generic(const void* gy, const void* x, int64_t B, int64_t Tlen, int L, int P, int nfft,
+                            const void* w, const void* twiddle, int center, int zmean, int pad_mode,
+                            double eps, int use_floor, double floor_db, int fmt, void* gx, void* gw,
+                            hipStream_t st)
+{
+    int64_t N = dsa_num_frames(Tlen, P), F = B * N;
+    int left = center ? L / 2 : 0;
+    T *gframe = nullptr, *gwpart = nullptr;
+    size_t bytes = sizeof(T) * (size_t)F * L;
+    if (hipMallocAsync((void**)&gframe, bytes, st) != hipSuccess ||
+        (gw && hipMallocAsync((void**)&gwpart, bytes, st) != hipSuccess))
+        return fail(DSA_ERR_LAUNCH, "stft_bwd: workspace allocation failed%s");
+    int rc = launch_row_dft_bwd<T>(x, B, Tlen, N, L, P, left, pad_mode, zmean, w, nfft, twiddle, 1, fmt, eps,
+                                   use_floor, floor_db, gy, gframe, gwpart, st);
+    // overlap-add (zmean already folded into gframe)
+    if (rc == DSA_OK) rc = frame_bwd_impl<T>(gframe, B, Tlen, L, P, center, 0, pad_mode, gx, st);
+    if (rc == DSA_OK && gw) {
+        hipLaunchKernelGGL((colsum_kernel<T>), dim3(L), dim3(256), 0, st, (const T*)gwpart, (long)F, L, (T*)gw);
+        rc = check_launch("window_grad_colsum");
+    }
+    (void)hipFreeAsync(gframe, st);
+    if (gwpart) (void)hipFreeAsync(gwpart, st);
+    return rc;
+}
+
+}  // namespace dsa
+
+DSA_EXPORT int dsa_fftr_bwd(const void* gy, const void* x, int64_t F, int32_t len_in, int32_t nfft,
+                            int32_t out_format, const void* twiddle, int32_t dtype, void* gx, void* stream)
+{
+    DSA_REQUIRE(len_in > 0 && nfft > 0 && nfft % 2 == 0, "fftr_bwd: fft_length must be positive even");
+    DSA_REQUIRE(out_format >= 0 && out_format <= 4, "fftr_bwd: unknown out_format");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSA_F32)
+        return launch_row_dft_bwd<float>(x, F, len_in, 1, len_in, len_in, 0, 0, 0, nullptr, nfft, twiddle, 0,
+                                         out_format, 0.0, 0, 0.0, gy, gx, nullptr, st);
+    if (dtype == DSA_F64)
+        return launch_row_dft_bwd<double>(x, F, len_in, 1, len_in, len_in, 0, 0, 0, nullptr, nfft, twiddle, 0,
+                                          out_format, 0.0, 0, 0.0, gy, gx, nullptr, st);
+    return fail(DSA_ERR_UNSUPPORTED, "fftr_bwd: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_spec_bwd(const void* gy, const void* b, int32_t lb, const void* a, int32_t la, int64_t F,
+                            int32_t nfft, double eps, int32_t use_floor, double relative_floor_db,
+                            int32_t out_format, const void* twiddle, int32_t dtype, void* gb, void* ga,
+                            void* stream)
+{
+    DSA_REQUIRE(b || a, "spec_bwd: either b or a must be specified");
+    DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "spec_bwd: fft_length must be positive even");
+    if (a || ga)
+        return fail(DSA_ERR_UNSUPPORTED, "spec_bwd: the denominator (a) branch has no backward kernel yet%s");
+    (void)la;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSA_F32)
+        return launch_row_dft_bwd<float>(b, F, lb, 1, lb, lb, 0, 0, 0, nullptr, nfft, twiddle, 1, out_format, eps,
+                                         use_floor, relative_floor_db, gy, gb, nullptr, st);
+    if (dtype == DSA_F64)
+        return launch_row_dft_bwd<double>(b, F, lb, 1, lb, lb, 0, 0, 0, nullptr, nfft, twiddle, 1, out_format, eps,
+                                          use_floor, relative_floor_db, gy, gb, nullptr, st);
+    return fail(DSA_ERR_UNSUPPORTED, "spec_bwd: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_stft_bwd(const void* gy, const void* x, int64_t B, int64_t T, int32_t L, int32_t P,
+                            int32_t nfft, const void* w, const void* twiddle, int32_t center, int32_t zmean,
+                            int32_t pad_mode, double eps, int32_t use_floor, double relative_floor_db,
+                            int32_t out_format, int32_t dtype, int32_t algo, void* gx, void* gw, void* stream)
+{
+    DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0, "stft_bwd: sizes must be positive");
+    DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "stft_bwd: fft_length must be positive even");
+    DSA_REQUIRE(pad_mode >= 0 && pad_mode <= 3, "stft_bwd: unknown pad mode");
+    DSA_REQUIRE(out_format >= 0 && out_format <= 4, "stft_bwd: unknown out_format");
+    if (B == 0) return DSA_OK;
+    (void)algo;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSA_F32)
+        return stft_bwd_generic<float>(gy, x, B, T, L, P, nfft, w, twiddle, center, zmean, pad_mode, eps, use_floor,
+                                       relative_floor_db, out_format, gx, gw, st);
+    if (dtype == DSA_F64)
+        return stft_bwd_generic<double>(gy, x, B, T, L, P, nfft, w, twiddle, center, zmean, pad_mode, eps,
+                                        use_floor, relative_floor_db, out_format, gx, gw, st);
+    return fail(DSA_ERR_UNSUPPORTED, "stft_bwd: unsupported dtype%s");
+}

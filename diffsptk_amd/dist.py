@@ -1,0 +1,69 @@
+"""Data-parallel sharding of utterance batches across GPUs (one process per GPU).
+
+Every utterance -- in fact every frame -- of the analysis path is independent (frame.py:65-70,
+mcep.py:83-88 of the reference broadcast over leading dims), so the path shards by whole
+utterances with NO data-path collective; the only exchange is one all-gather of the final
+(B, N, M+1) feature tensor (RCCL over xGMI: torch.distributed backend "nccl").  The reference
+has no distributed code at all.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, world_size: int, rank: int) -> tuple[int, int]:
+    """Contiguous, balanced split of ``total`` utterances: the first ``total % world_size``
+    ranks get one extra.  Returns [lo, hi)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank must be in [0, world_size)")
+    base, extra = divmod(total, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_gather_features(local: torch.Tensor, total: int | None = None, group=None) -> torch.Tensor:
+    """Concatenate per-rank feature shards (B_r, ...) along dim 0 on every rank.
+
+    Equal shards use ONE ``all_gather_into_tensor`` (a single large collective: on the xGMI mesh
+    each rank's shard goes out over its 7 links at once); ragged shards are padded to the largest
+    shard for the same single collective and trimmed afterwards.
+    """
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    local = local.contiguous()
+    if total is None:
+        n = torch.tensor([local.size(0)], device=local.device, dtype=torch.int64)
+        dist.all_reduce(n, group=group)
+        total = int(n.item())
+    sizes = [shard_bounds(total, world, r) for r in range(world)]
+    counts = [hi - lo for lo, hi in sizes]
+    biggest = max(counts)
+    if local.size(0) != counts[dist.get_rank(group)]:
+        raise ValueError("local shard size does not match the contiguous balanced split")
+    if min(counts) == biggest:
+        out = local.new_empty((total, *local.shape[1:]))
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
+    padded = local.new_zeros((biggest, *local.shape[1:]))
+    padded[: local.size(0)] = local
+    buf = local.new_empty((world * biggest, *local.shape[1:]))
+    dist.all_gather_into_tensor(buf, padded, group=group)
+    return torch.cat([buf[r * biggest: r * biggest + c] for r, c in enumerate(counts)], dim=0)
+
+
+def analyze_sharded(x: torch.Tensor, compute: Callable[[torch.Tensor], torch.Tensor], gather: bool = True,
+                    group=None) -> torch.Tensor:
+    """Run ``compute`` (e.g. ``lambda w: mcep(stft(w))``) on this rank's contiguous shard of the
+    global batch ``x`` (B, T) and optionally all-gather the features."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return compute(x)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(x.size(0), world, rank)
+    local = compute(x[lo:hi])
+    return all_gather_features(local, x.size(0), group) if gather else local

@@ -1,0 +1,67 @@
+"""Functional API: one free function per module, each delegating to ``Module._func``
+(reference: diffsptk/functional.py:23,797,859,905,1659,1700,1956,2916,2963,3142)."""
+from __future__ import annotations
+
+from torch import Tensor
+
+from . import modules as nn
+
+
+def acorr(x: Tensor, acr_order: int, out_format: str | int = "naive") -> Tensor:
+    """Autocorrelation of framed waveforms x:(..., L) -> (..., M+1)."""
+    return nn.Autocorrelation._func(x, acr_order=acr_order, out_format=out_format)
+
+
+def fftr(x: Tensor, fft_length: int | None = None, out_format: str | int = "complex") -> Tensor:
+    """Real FFT x:(..., L) -> (..., fft_length/2+1)."""
+    return nn.RealValuedFastFourierTransform._func(x, fft_length=fft_length, out_format=out_format)
+
+
+def frame(x: Tensor, frame_length: int = 400, frame_period: int = 80, center: bool = True,
+          zmean: bool = False, mode: str = "constant") -> Tensor:
+    """Framing x:(..., T) -> (..., T/P, L)."""
+    return nn.Frame._func(x, frame_length, frame_period, center=center, zmean=zmean, mode=mode)
+
+
+def freqt(c: Tensor, out_order: int, alpha: float = 0) -> Tensor:
+    """Frequency transform c:(..., M1+1) -> (..., M2+1)."""
+    return nn.FrequencyTransform._func(c, out_order=out_order, alpha=alpha)
+
+
+def levdur(r: Tensor, eps: float | None = None) -> Tensor:
+    """Solve the Yule-Walker system r:(..., M+1) -> gain and LPC coefficients (..., M+1)."""
+    return nn.LevinsonDurbin._func(r, eps=eps)
+
+
+def lpc(x: Tensor, lpc_order: int, eps: float | None = None) -> Tensor:
+    """LPC analysis of framed waveforms x:(..., L) -> (..., M+1)."""
+    return nn.LinearPredictiveCodingAnalysis._func(x, lpc_order=lpc_order, eps=eps)
+
+
+def mcep(x: Tensor, cep_order: int, alpha: float = 0, n_iter: int = 0) -> Tensor:
+    """Mel-cepstral analysis of power spectra x:(..., L/2+1) -> (..., M+1)."""
+    return nn.MelCepstralAnalysis._func(x, cep_order=cep_order, alpha=alpha, n_iter=n_iter)
+
+
+def spec(b: Tensor | None = None, a: Tensor | None = None, *, fft_length: int = 512, eps: float = 0,
+         relative_floor: float | None = None, out_format: str | int = "power") -> Tensor:
+    """Spectrum of K B(z)/A(z): (..., M+1), (..., N+1) -> (..., L/2+1)."""
+    return nn.Spectrum._func(b, a, fft_length=fft_length, eps=eps, relative_floor=relative_floor,
+                             out_format=out_format)
+
+
+def stft(x: Tensor, *, frame_length: int = 400, frame_period: int = 80, fft_length: int = 512,
+         center: bool = True, zmean: bool = False, mode: str = "constant", window: str | int = "blackman",
+         norm: str | int = "power", symmetric: bool = True, eps: float = 1e-9,
+         relative_floor: float | None = None, out_format: str | int = "power") -> Tensor:
+    """Short-time Fourier transform x:(..., T) -> (..., T/P, N/2+1)."""
+    return nn.ShortTimeFourierTransform._func(
+        x, frame_length=frame_length, frame_period=frame_period, fft_length=fft_length, center=center,
+        zmean=zmean, mode=mode, window=window, norm=norm, symmetric=symmetric, eps=eps,
+        relative_floor=relative_floor, out_format=out_format)
+
+
+def window(x: Tensor, out_length: int | None = None, *, window: str | int = "blackman",
+           norm: str | int = "power", symmetric: bool = True) -> Tensor:
+    """Windowing x:(..., L1) -> (..., L2)."""
+    return nn.Window._func(x, out_length, window=window, norm=norm, symmetric=symmetric)

@@ -1,0 +1,61 @@
+"""get_alpha / read (diffsptk/utils/public.py:22-157), config-1 plumbing."""
+from __future__ import annotations
+
+import wave
+
+import numpy as np
+import torch
+
+_HTS_ALPHA = {8000: 0.31, 10000: 0.35, 12000: 0.37, 16000: 0.42, 22050: 0.45, 24000: 0.47,
+              32000: 0.50, 44100: 0.53, 48000: 0.55}
+
+
+def _auto_alpha(sample_rate: int, n_freq: int, n_alpha: int) -> float:
+    """Grid search for the all-pass coefficient whose phase response is closest (L2) to the
+    mel scale log(1 + f/1000) (public.py:74-96)."""
+    grid = np.arange(n_freq, dtype=np.float64) / (n_freq - 1)      # 0 .. 1 (Nyquist)
+    mel = np.log1p(grid * 0.5 * sample_rate / 1000.0)
+    mel *= np.pi / mel[-1]
+    omega = grid * np.pi
+    best, best_err = 0.0, np.inf
+    for a in np.linspace(0.0, 1.0, n_alpha, endpoint=False):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            warped = np.arctan((1 - a * a) * np.sin(omega) / ((1 + a * a) * np.cos(omega) - 2 * a))
+        warped = np.where(warped < 0, warped + np.pi, warped)
+        err = float(np.square(mel - warped).sum())
+        if err < best_err:
+            best, best_err = float(a), err
+    return best
+
+
+def get_alpha(sample_rate: int, mode: str = "hts", n_freq: int = 10, n_alpha: int = 100) -> float:
+    """Frequency-warping factor for a sample rate (public.py:22-104; 16 kHz -> 0.42)."""
+    if mode == "hts":
+        sr = int(sample_rate)
+        if sr not in _HTS_ALPHA:
+            raise ValueError(f"Unsupported sample rate: {sample_rate}. Please use mode='auto'.")
+        return _HTS_ALPHA[sr]
+    if mode == "auto":
+        return _auto_alpha(sample_rate, n_freq, n_alpha)
+    raise ValueError("Only hts and auto are supported.")
+
+
+def read(filename: str, device=None, dtype=None, channel_first: bool = True):
+    """Read a PCM wav file into a float tensor in [-1, 1) (stdlib ``wave``; the reference uses
+    soundfile, public.py:152-156, which scales int16 by 1/32768 as done here)."""
+    with wave.open(filename, "rb") as w:
+        nch, width, sr, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+        raw = w.readframes(n)
+    if width == 2:
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float64) / 32768.0
+    elif width == 4:
+        x = np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0
+    elif width == 1:
+        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float64) - 128.0) / 128.0
+    else:
+        raise ValueError(f"unsupported sample width: {width}")
+    x = x.reshape(-1, nch)
+    x = x[:, 0] if nch == 1 else (x.T if channel_first else x)
+    if dtype is None:
+        dtype = torch.get_default_dtype()
+    return torch.tensor(np.ascontiguousarray(x), device=device, dtype=dtype), sr

@@ -1,0 +1,179 @@
+/*
+ * diffsptk_amd -- C-ABI of the MI355X (gfx950) device backend for the STFT -> mel-cepstrum
+ * and LPC analysis hot path of sp-nitech/diffsptk (v4.0.0).
+ *
+ * The reference is a pure-Python library over PyTorch: it has NO FFI/plugin interface.  Its
+ * operator boundary is the static `_forward(x, **precomputed)` method of every module
+ * (diffsptk/modules/base.py:38-101).  Each entry point below is what a binding for one such
+ * `_forward` (and its autograd-derived backward) binds; the reference
+ * symbol it replaces is cited per function.  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HIP, same process / same HIP runtime as the caller)
+ *    unless the name ends in `_host`; the caller (PyTorch) allocates all buffers;
+ *  - tensors are dense row-major ("contiguous"); leading batch dims are flattened by the caller;
+ *  - `dtype`: DSA_F32 or DSA_F64 (the reference supports both; CI runs float64);
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous
+ *    on that stream, re-entrant, and keep no mutable global state;
+ *  - return value: DSA_OK (0) or a negative dsa_status; dsa_last_error() gives the message of
+ *    the last failure on the calling thread.  Nothing throws across the boundary.
+ *  - argument VALIDATION of user-facing options (ValueError text etc.) is done by the host
+ *    layer exactly like the reference's `_check`; the library re-checks only what would make a
+ *    launch unsafe.
+ */
+#ifndef DIFFSPTK_AMD_H
+#define DIFFSPTK_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSA_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+    DSA_OK = 0,
+    DSA_ERR_INVALID_ARGUMENT = -1,
+    DSA_ERR_UNSUPPORTED = -2,
+    DSA_ERR_LAUNCH = -3,
+    DSA_ERR_NO_DEVICE = -4
+} dsa_status;
+
+enum { DSA_F32 = 0, DSA_F64 = 1 };
+/* F.pad modes of Frame (frame.py:134-137) */
+enum { DSA_PAD_CONSTANT = 0, DSA_PAD_REFLECT = 1, DSA_PAD_REPLICATE = 2, DSA_PAD_CIRCULAR = 3 };
+/* fftr.py:110-121 */
+enum { DSA_FFTR_COMPLEX = 0, DSA_FFTR_REAL = 1, DSA_FFTR_IMAG = 2, DSA_FFTR_AMPLITUDE = 3, DSA_FFTR_POWER = 4 };
+/* spec.py:123-132 (+ complex pass-through of stft.py:211-222) */
+enum { DSA_SPEC_DB = 0, DSA_SPEC_LOGMAG = 1, DSA_SPEC_MAG = 2, DSA_SPEC_POWER = 3, DSA_SPEC_COMPLEX = 4 };
+/* acorr.py:94-107 */
+enum { DSA_ACORR_NAIVE = 0, DSA_ACORR_NORMALIZED = 1, DSA_ACORR_BIASED = 2, DSA_ACORR_UNBIASED = 3 };
+/* kernel selection: AUTO picks the tuned gfx950 kernel when the configuration allows it */
+enum { DSA_ALGO_AUTO = 0, DSA_ALGO_GENERIC = 1, DSA_ALGO_TUNED = 2 };
+
+int dsa_version(void);
+const char* dsa_last_error(void);
+/* number of visible HIP devices, or a negative dsa_status */
+int dsa_device_count(void);
+/* name of the kernel family the last call on this thread dispatched to (for tests/profiles) */
+const char* dsa_last_kernel(void);
+
+/* N = (T-1)/P + 1 frames for T >= 1 (frame.py:130-138: padded length is T + L - 1). */
+int64_t dsa_num_frames(int64_t T, int32_t P);
+
+/* ------------------------------------------------------------------ a1  Frame
+ * Frame._forward, diffsptk/modules/frame.py:120-141.
+ * x:(B,T) -> y:(B,N,L); bit-exact gather copy (zmean subtracts the frame mean). */
+int dsa_frame_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, int32_t center,
+                  int32_t zmean, int32_t pad_mode, int32_t dtype, void* y, void* stream);
+/* gy:(B,N,L) -> gx:(B,T): deterministic overlap-add (adjoint of pad + unfold + zmean). */
+int dsa_frame_bwd(const void* gy, int64_t B, int64_t T, int32_t L, int32_t P, int32_t center,
+                  int32_t zmean, int32_t pad_mode, int32_t dtype, void* gx, void* stream);
+
+/* ------------------------------------------------------------------ a2  Window
+ * Window._forward, window.py:185-193.  x:(F,L) * w:(L) -> y:(F,L2), zero padded (L2>=L) or
+ * cropped (L2<L, F.pad with a negative amount). */
+int dsa_window_fwd(const void* x, int64_t F, int32_t L, const void* w, int32_t L2, int32_t dtype,
+                   void* y, void* stream);
+/* gy:(F,L2) -> gx:(F,L) and, if gw != NULL, gw:(L) += sum_f gy*x (learnable window). */
+int dsa_window_bwd(const void* gy, const void* x, int64_t F, int32_t L, const void* w, int32_t L2,
+                   int32_t dtype, void* gx, void* gw, void* stream);
+
+/* ------------------------------------------------------------------ a3  fftr
+ * RealValuedFastFourierTransform._forward, fftr.py:136-151 (torch.fft.rfft + formatter).
+ * x:(F,len_in) zero-padded/cropped to nfft -> y:(F,nfft/2+1) real, or interleaved (re,im)
+ * pairs for DSA_FFTR_COMPLEX.  twiddle:(nfft,2) = (cos, -sin)(2 pi m / nfft), device. */
+int dsa_fftr_fwd(const void* x, int64_t F, int32_t len_in, int32_t nfft, int32_t out_format,
+                 const void* twiddle, int32_t dtype, void* y, void* stream);
+int dsa_fftr_bwd(const void* gy, const void* x, int64_t F, int32_t len_in, int32_t nfft,
+                 int32_t out_format, const void* twiddle, int32_t dtype, void* gx, void* stream);
+
+/* ------------------------------------------------------------------ a4  Spectrum
+ * Spectrum._forward, spec.py:152-178.  b:(F,lb) and/or a:(F,la) (either may be NULL, not both).
+ * y:(F,nfft/2+1) = format(max(|K B/A|^2 + eps, floor)). */
+int dsa_spec_fwd(const void* b, int32_t lb, const void* a, int32_t la, int64_t F, int32_t nfft,
+                 double eps, int32_t use_floor, double relative_floor_db, int32_t out_format,
+                 const void* twiddle, int32_t dtype, void* y, void* stream);
+int dsa_spec_bwd(const void* gy, const void* b, int32_t lb, const void* a, int32_t la, int64_t F,
+                 int32_t nfft, double eps, int32_t use_floor, double relative_floor_db,
+                 int32_t out_format, const void* twiddle, int32_t dtype, void* gb, void* ga,
+                 void* stream);
+
+/* ------------------------------------------------------------------ a5  STFT (fused a1+a2+a3+a4)
+ * ShortTimeFourierTransform._forward, stft.py:237-241 = spec(window(frame(x))).
+ * x:(B,T), w:(L) window table -> y:(B,N,nfft/2+1) (x2 interleaved for DSA_SPEC_COMPLEX).
+ * One kernel: each waveform sample is read from HBM once, frames overlap in LDS. */
+int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft,
+                 const void* w, const void* twiddle, int32_t center, int32_t zmean,
+                 int32_t pad_mode, double eps, int32_t use_floor, double relative_floor_db,
+                 int32_t out_format, int32_t dtype, int32_t algo, void* y, void* stream);
+/* gy like y -> gx:(B,T); if gw != NULL also gw:(L) (learnable window, stft.py:73-76). */
+int dsa_stft_bwd(const void* gy, const void* x, int64_t B, int64_t T, int32_t L, int32_t P,
+                 int32_t nfft, const void* w, const void* twiddle, int32_t center, int32_t zmean,
+                 int32_t pad_mode, double eps, int32_t use_floor, double relative_floor_db,
+                 int32_t out_format, int32_t dtype, int32_t algo, void* gx, void* gw, void* stream);
+
+/* ------------------------------------------------------------------ a6/a7  frequency transform
+ * FrequencyTransform._forward freqt.py:141-143 and CoefficientsFrequencyTransform._forward
+ * mcep.py:286-288: out:(F,L2) = c:(F,L1) @ A:(L1,L2).  (bwd: gc = gout @ A^T) */
+int dsa_freqt_fwd(const void* c, int64_t F, int32_t L1, const void* A, int32_t L2, int32_t dtype,
+                  void* out, void* stream);
+int dsa_freqt_bwd(const void* gout, int64_t F, int32_t L1, const void* A, int32_t L2,
+                  int32_t dtype, void* gc, void* stream);
+
+/* ------------------------------------------------------------------ a8-a10  mel-cepstral analysis
+ * MelCepstralAnalysis._forward, mcep.py:189-224 (incl. symmetric_toeplitz / hankel,
+ * utils/private.py:291-302, and the torch.linalg.solve call at mcep.py:221).
+ * X:(F,nfft/2+1) power spectrum -> mc:(F,M+1).  The host composes the reference's linear maps
+ * once per configuration (float64, then cast):
+ *   G:(H+1,M+1)  = irfft-with-halved-ends  o freqt          (mcep.py:204-207)
+ *   D:(M+1,H+1)  = ifreqt o Re(rfft(., nfft))               (mcep.py:210-211)
+ *   E:(H+1,2M+1) = irfft o rfreqt                           (mcep.py:214-215)
+ *   alpha_vec:(M+1) = (-alpha)^i                            (mcep.py:179-181)
+ * so that one Newton step is  d = mc D ; e = exp(log X - 2 d) ; rt = e E ;
+ * mc += solve(T(rt[:M+1]) + H(rt), rt[:M+1] - alpha_vec).
+ * mc_hist: NULL or (n_iter+1, F, M+1) receiving mc after 0..n_iter steps (saved for backward). */
+int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, int32_t n_iter, const void* G,
+                 const void* D, const void* E, const void* alpha_vec, int32_t dtype, int32_t algo,
+                 void* mc, void* mc_hist, void* stream);
+/* gradient of the UNROLLED n_iter-step iteration (what autograd gives the reference).
+ * gmc:(F,M+1), X, mc_hist as saved by the forward -> gX:(F,nfft/2+1). */
+int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist, int64_t F, int32_t nfft,
+                 int32_t M, int32_t n_iter, const void* G, const void* D, const void* E,
+                 const void* alpha_vec, int32_t dtype, int32_t algo, void* gX, void* stream);
+
+/* ------------------------------------------------------------------ a11  autocorrelation
+ * Autocorrelation._forward, acorr.py:110-120.  x:(F,L) -> r:(F,M+1).  Computed as direct lag
+ * sums (the reference's irfft(|rfft(x, L+M)|^2) is the same quantity: no circular wrap). */
+int dsa_acorr_fwd(const void* x, int64_t F, int32_t L, int32_t M, int32_t out_format, int32_t dtype,
+                  void* r, void* stream);
+int dsa_acorr_bwd(const void* gr, const void* x, int64_t F, int32_t L, int32_t M, int32_t out_format,
+                  int32_t dtype, void* gx, void* stream);
+
+/* ------------------------------------------------------------------ a12  Levinson-Durbin
+ * LevinsonDurbin._forward, levdur.py:113-127: a = solve(toeplitz(r[:M]) + eps I, -r[1:]),
+ * K = sqrt(sum r[1:] a + r[0]); out:(F,M+1) = [K, a].  Solved by the Levinson recursion on
+ * (r0+eps, r1..rM) (the same system; float64 accumulation inside). */
+int dsa_levdur_fwd(const void* r, int64_t F, int32_t M, double eps, int32_t dtype, void* out,
+                   void* stream);
+int dsa_levdur_bwd(const void* gout, const void* r, const void* out, int64_t F, int32_t M, double eps,
+                   int32_t dtype, void* gr, void* stream);
+
+/* ------------------------------------------------------------------ a13  LPC
+ * LinearPredictiveCodingAnalysis._forward, lpc.py:137-139 = levdur(acorr(x)); x:(F,L) frames. */
+int dsa_lpc_fwd(const void* x, int64_t F, int32_t L, int32_t M, double eps, int32_t dtype, void* out,
+                void* stream);
+int dsa_lpc_bwd(const void* gout, const void* x, const void* out, int64_t F, int32_t L, int32_t M,
+                double eps, int32_t dtype, void* gx, void* stream);
+/* Fused LPC branch of the README (README.md:198-201): LPC(Window(Frame(x))) in one kernel.
+ * x:(B,T), w:(L) -> out:(B,N,M+1). */
+int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P,
+                             const void* w, int32_t center, int32_t pad_mode, int32_t M, double eps,
+                             int32_t dtype, void* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFSPTK_AMD_H */

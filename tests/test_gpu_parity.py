@@ -1,0 +1,483 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI via
+the module / functional API, against (i) the committed golden vectors generated from the
+reference, (ii) the oracle on seeded inputs.
+
+Tolerances (stated once, used everywhere below):
+  float64   rtol 1e-5 / atol 1e-8 -- the reference's own criterion (tests/utils.py:66-72);
+            gradients 1e-6 relative to the largest gradient entry.
+  float32 spectra: |y - y64| <= 1e-4 |y64| + 2e-6 max_k y64[frame]   (bins far below the frame
+            maximum differ between ANY two float32 FFTs -- the reference's own float32 and
+            float64 outputs disagree by 1.9e-3 elementwise on data.wav).
+  float32 mel-cepstra: |mc - mc64| <= 1e-4 |mc64| + 2e-5        (reference f32 vs f64: 6e-6 abs).
+  float32 LPC: |a - a64| <= 1e-4 |a64| + 1e-4   (float64 recursion inside; the reference's own
+            float32 result is 8.8e-4 away from its float64 result).
+"""
+import numpy as np
+import pytest
+import torch
+
+import diffsptk_amd as dsp
+from conftest import wav_float
+from diffsptk_amd import _lib, functional as F, ops
+from oracle import oracle as O
+from oracle import torch_port as TP
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+F64 = dict(rtol=1e-5, atol=1e-8)
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def close(a, b, rtol, atol):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def spec_close(y, y64, rtol=1e-4, rel_rowmax=2e-6):
+    y, y64 = np.asarray(y, np.float64), np.asarray(y64, np.float64)
+    bound = rtol * np.abs(y64) + rel_rowmax * np.abs(y64).max(-1, keepdims=True)
+    bad = np.abs(y - y64) > bound
+    assert not bad.any(), f"{bad.sum()} bins out of tolerance, worst {np.abs(y - y64).max():.3e}"
+
+
+def test_device_and_library():
+    assert _lib.load().dsa_device_count() >= 1
+    assert torch.cuda.is_available()
+
+
+# ----------------------------------------------------------------------------- a1 Frame
+def test_frame_grid_bit_exact(golden):
+    g = golden("grids")
+    for dt in (torch.float64, torch.float32):
+        x = dev(g["frame_x"], dt)
+        for fl in range(1, 6):
+            for fp in range(1, 6):
+                for center in (True, False):
+                    y = host(dsp.Frame(fl, fp, center=center)(x))
+                    assert np.array_equal(y, g[f"frame_{fl}_{fp}_{int(center)}_0"].astype(y.dtype))
+                    yz = host(F.frame(x, fl, fp, center=center, zmean=True))
+                    close(yz, g[f"frame_{fl}_{fp}_{int(center)}_1"], 1e-5, 1e-6)
+
+
+def test_frame_pad_modes_bit_exact_and_backward(golden):
+    g = golden("grids")
+    x = dev(g["frame_modes_x"])
+    for mode in ("constant", "reflect", "replicate", "circular"):
+        for center in (True, False):
+            y = host(dsp.Frame(12, 5, center=center, mode=mode)(x))
+            assert np.array_equal(y, g[f"frame_mode_{mode}_{int(center)}"])
+            # adjoint vs autograd of the torch-op port
+            xg = x.clone().requires_grad_(True)
+            wts = torch.randn(y.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+            (dsp.Frame(12, 5, center=center, mode=mode, zmean=True)(xg) * wts.to(DEV)).sum().backward()
+            xc = x.cpu().clone().requires_grad_(True)
+            (TP.frame(xc, 12, 5, center, True, mode) * wts).sum().backward()
+            close(host(xg.grad), xc.grad.numpy(), 1e-9, 1e-12)
+
+
+def test_frame_big_matches_oracle():
+    x = torch.randn(3, 16000, generator=torch.Generator().manual_seed(0))
+    y = host(dsp.Frame(400, 80)(x.to(DEV)))
+    assert y.shape == (3, 200, 400)
+    assert np.array_equal(y, O.frame(x.numpy(), 400, 80))
+
+
+# ----------------------------------------------------------------------------- a2 Window
+def test_window_module_and_learnable(golden):
+    x = torch.randn(5, 8, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    for w in (0, 1, 2, 3, 4, 5, 6, "povey"):
+        for norm in (0, 1, 2):
+            y = host(dsp.Window(8, 10, window=w, norm=norm, dtype=torch.float64, device=DEV)(x.to(DEV)))
+            ref = O.window(x.numpy(), O.window_table(8, w, norm, True), 10)
+            close(y, ref, 1e-12, 1e-14)
+    m = dsp.Window(8, 10, learnable=True, dtype=torch.float64, device=DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    wts = torch.randn(5, 10, dtype=torch.float64, generator=torch.Generator().manual_seed(2))
+    (m(xg) * wts.to(DEV)).sum().backward()
+    wt = m.window.detach().cpu()
+    close(host(xg.grad), (wts[:, :8] * wt).numpy(), 1e-12, 1e-14)
+    close(host(m.window.grad), (wts[:, :8] * x).sum(0).numpy(), 1e-12, 1e-14)
+
+
+# ----------------------------------------------------------------------------- a3 fftr / a4 spec
+def test_fftr_formats(golden):
+    g = golden("grids")
+    x = dev(g["fftr_x"])
+    z = host(dsp.RealValuedFastFourierTransform(16, dtype=torch.float64, device=DEV)(x))
+    close(np.stack([z.real, z.imag], -1), g["fftr_0"], **F64)
+    for o in range(1, 5):
+        close(host(F.fftr(x, 16, o)), g[f"fftr_{o}"], **F64)
+    close(host(F.fftr(x[..., :12])), np.fft.rfft(g["fftr_x"][..., :12]), 1e-10, 1e-12)
+
+
+def test_spec_branches(golden):
+    g = golden("grids")
+    b, a = dev(g["spec_b"]), dev(g["spec_a"])
+    for o in range(4):
+        for rf in (None, -40):
+            sp = dsp.Spectrum(16, eps=0.01, relative_floor=rf, out_format=o)
+            close(host(sp(b, a)), g[f"spec_ba_{o}_{rf}"], **F64)
+            close(host(sp(b)), g[f"spec_b_{o}_{rf}"], **F64)
+    close(host(F.spec(b, fft_length=16)), g["spec_b_only"], **F64)
+    close(host(F.spec(None, a, fft_length=16)), g["spec_a_only"], **F64)
+
+
+def test_fftr_spec_backward_vs_autograd():
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 13, dtype=torch.float64, generator=gen)
+    for fmt in ("complex", "real", "imaginary", "amplitude", "power"):
+        xg = x.to(DEV).requires_grad_(True)
+        y = F.fftr(xg, 16, fmt)
+        wts = torch.randn(y.shape, dtype=y.dtype, generator=gen) if not y.is_complex() else \
+            torch.complex(torch.randn(y.shape, dtype=torch.float64, generator=gen),
+                          torch.randn(y.shape, dtype=torch.float64, generator=gen))
+        (y * wts.to(DEV)).sum().abs().backward() if y.is_complex() else (y * wts.to(DEV)).sum().backward()
+        xc = x.clone().requires_grad_(True)
+        z = torch.fft.rfft(xc, n=16)
+        yr = {"complex": z, "real": z.real, "imaginary": z.imag, "amplitude": z.abs(), "power": z.abs().square()}[fmt]
+        (yr * wts).sum().abs().backward() if yr.is_complex() else (yr * wts).sum().backward()
+        close(host(xg.grad), xc.grad.numpy(), 1e-9, 1e-11)
+    for o in ("db", "log-magnitude", "magnitude", "power"):
+        for rf in (None, -10):
+            xg = x.to(DEV).requires_grad_(True)
+            y = F.spec(xg, fft_length=16, eps=0.01, relative_floor=rf, out_format=o)
+            wts = torch.randn(y.shape, dtype=torch.float64, generator=gen)
+            (y * wts.to(DEV)).sum().backward()
+            xc = x.clone().requires_grad_(True)
+            s = torch.fft.rfft(xc, n=16).abs().square() + 0.01
+            if rf is not None:
+                s = torch.maximum(s, s.amax(-1, keepdim=True) * 10 ** (rf / 10))
+            yr = {"db": 10 * torch.log10(s), "log-magnitude": 0.5 * torch.log(s), "magnitude": s.sqrt(), "power": s}[o]
+            close(host(y), yr.detach().numpy(), 1e-9, 1e-11)
+            (yr * wts).sum().backward()
+            close(host(xg.grad), xc.grad.numpy(), 1e-8, 1e-10)
+
+
+# ----------------------------------------------------------------------------- a5 STFT
+def test_stft_small_generic_f64(golden):
+    g = golden("grids")
+    x = dev(g["stft_x"])
+    kw = dict(frame_length=12, frame_period=10, fft_length=16, window=1, norm=1, eps=1e-6)
+    close(host(dsp.STFT(**kw, dtype=torch.float64, device=DEV)(x)), g["stft_power"], **F64)
+    close(host(F.stft(x, **kw)), g["stft_power"], **F64)
+    z = host(F.stft(x, **kw, out_format="complex"))
+    close(np.stack([z.real, z.imag], -1), g["stft_complex"], **F64)
+    for o in ("db", "log-magnitude", "magnitude"):
+        close(host(F.stft(x, **kw, out_format=o)), g[f"stft_{o}"], **F64)
+    close(host(F.stft(x, **kw, relative_floor=-20)), g["stft_relfloor"], **F64)
+    close(host(F.stft(x, **kw, center=False, zmean=True, mode="reflect")), g["stft_zmean_nocenter_reflect"], **F64)
+    close(host(F.stft(dev(g["stft_odd_x"]), frame_length=9, frame_period=4, fft_length=20)), g["stft_odd"], **F64)
+
+
+@pytest.mark.parametrize("name,dt", [("f64", torch.float64), ("f32", torch.float32)])
+def test_stft_datawav_golden(golden, name, dt):
+    g = golden("datawav")
+    x = dev(wav_float(g["pcm"], np.float64), dt)
+    y = dsp.STFT(400, 80, 512, dtype=dt, device=DEV)(x)
+    assert _lib.last_kernel() == ("stft512_fwd" if dt == torch.float32 else "row_dft_generic")
+    assert y.shape == (240, 257)
+    if dt == torch.float64:
+        close(host(y), g["stft_power_f64"], **F64)
+    else:
+        spec_close(host(y), g["stft_power_f64"])
+        spec_close(host(y), g["stft_power_f32"])
+
+
+def test_stft_tuned_vs_generic_vs_oracle_options():
+    """Every option of the tuned kernel (float32, nfft 512) against the float64 oracle."""
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 2500, generator=gen)
+    xd = x.to(DEV)
+    x64 = x.double().numpy()
+    cases = [
+        dict(),
+        dict(center=False),
+        dict(zmean=True),
+        dict(mode="reflect"), dict(mode="replicate"), dict(mode="circular", center=False),
+        dict(window="hamming", norm="none"), dict(window="nuttall", norm="magnitude", symmetric=False),
+        dict(out_format="db"), dict(out_format="log-magnitude"), dict(out_format="magnitude"),
+        dict(relative_floor=-30), dict(relative_floor=-30, out_format="db"), dict(eps=0.0),
+    ]
+    for L, P in ((400, 80), (512, 128), (25, 10), (399, 77)):
+        for kw in cases:
+            y = F.stft(xd, frame_length=L, frame_period=P, fft_length=512, **kw)
+            assert _lib.last_kernel() == "stft512_fwd"
+            ref = O.stft(x64, L, P, 512, **kw)
+            if kw.get("out_format") in ("db", "log-magnitude"):
+                scale = 10 / np.log(10) if kw["out_format"] == "db" else 0.5
+                lin = O.stft(x64, L, P, 512, **{**kw, "out_format": "power"})
+                tol = scale * (1e-4 + 2e-6 * lin.max(-1, keepdims=True) / lin)
+                assert (np.abs(host(y) - ref) <= tol + 1e-6).all(), (L, P, kw)
+            elif kw.get("out_format") == "magnitude":
+                spec_close(host(y) ** 2, ref ** 2, 2e-4, 4e-6)
+            else:
+                spec_close(host(y), ref)
+        z = host(F.stft(xd, frame_length=L, frame_period=P, fft_length=512, out_format="complex"))
+        zr = O.stft(x64, L, P, 512, out_format="complex")
+        assert np.abs(z - zr).max() <= 2e-6 * np.abs(zr).max()
+    # generic float32 kernel agrees too (algo = generic through the raw op)
+    m = dsp.STFT(400, 80, 512, device=DEV)
+    yg = ops.StftFn.apply(xd, m.window, m.twiddle, 400, 80, 512, True, False, "constant", 1e-9, None, 3,
+                          _lib.ALGO_GENERIC)
+    assert _lib.last_kernel() == "row_dft_generic"
+    spec_close(host(yg), O.stft(x64, 400, 80, 512))
+
+
+def test_stft_config2_batch64(golden):
+    """BASELINE config 2: batch 64 x 1 s @ 16 kHz; full tensor vs the oracle + Parseval."""
+    x = torch.randn(64, 16000, generator=torch.Generator().manual_seed(0))
+    y = dsp.STFT(400, 80, 512, eps=0.0, device=DEV)(x.to(DEV))
+    assert y.shape == (64, 200, 257)
+    ref = O.stft(x.double().numpy(), 400, 80, 512, eps=0.0)
+    spec_close(host(y), ref)
+    # Parseval: sum over the full circle of |X|^2 = 512 * sum (x w)^2
+    w = O.window_table(400)
+    fr = O.frame(x.double().numpy(), 400, 80) * w
+    yd = host(y).astype(np.float64)
+    total = yd[..., 0] + yd[..., 256] + 2 * yd[..., 1:256].sum(-1)
+    close(total, 512 * (fr ** 2).sum(-1), 1e-5, 1e-9)
+
+
+def test_stft_ragged_and_edge_lengths():
+    gen = torch.Generator().manual_seed(7)
+    for T in (1, 79, 80, 81, 399, 400, 401, 1279, 1281, 5000):
+        x = torch.randn(2, T, generator=gen)
+        y = F.stft(x.to(DEV), frame_length=400, frame_period=80, fft_length=512)
+        assert y.shape == (2, (T - 1) // 80 + 1, 257)
+        spec_close(host(y), O.stft(x.double().numpy(), 400, 80, 512))
+    x = torch.randn(2, 3, 700, generator=gen)  # extra leading dims
+    y = F.stft(x.to(DEV), frame_length=400, frame_period=80, fft_length=512)
+    assert y.shape == (2, 3, 9, 257)
+    spec_close(host(y), O.stft(x.double().numpy(), 400, 80, 512))
+    x1 = torch.randn(900, generator=gen)  # 1-D input with non-constant padding (frame.py:134-135)
+    spec_close(host(F.stft(x1.to(DEV), mode="reflect")), O.stft(x1.double().numpy(), 400, 80, 512, mode="reflect"))
+
+
+def test_stft_nonfinite_sample_stays_in_its_frames():
+    x = torch.zeros(1, 4000)
+    x[0, 2000] = float("nan")
+    y = host(F.stft(x.to(DEV)))
+    bad = np.isnan(y).any(-1)[0]
+    ref = np.isnan(O.stft(x.double().numpy(), 400, 80, 512)).any(-1)[0]
+    assert np.array_equal(bad, ref)
+
+
+@pytest.mark.parametrize("name,dt", [("f64", torch.float64), ("f32", torch.float32)])
+def test_stft_backward_golden(golden, name, dt):
+    g = golden("randn")
+    x = dev(g["x"], dt).requires_grad_(True)
+    X = dsp.STFT(400, 80, 512, dtype=dt, device=DEV)(x)
+    torch.log(X).mean().backward()
+    ref = g["grad_logstft_mean_f64"]
+    scale = np.abs(ref).max()
+    tol = 1e-6 if dt == torch.float64 else 1e-3
+    assert np.abs(host(x.grad) - ref).max() < tol * scale
+
+
+def test_stft_backward_options_vs_autograd():
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 300, dtype=torch.float64, generator=gen)
+    for kw in (dict(), dict(center=False, zmean=True), dict(mode="reflect"), dict(out_format="db", relative_floor=-20),
+               dict(out_format="magnitude"), dict(out_format="complex")):
+        xg = x.to(DEV).requires_grad_(True)
+        m = dsp.STFT(48, 20, 64, learnable=["window"], dtype=torch.float64, device=DEV, **kw)
+        y = m(xg)
+        wts = torch.randn(y.shape, dtype=torch.float64, generator=gen)
+        loss = (y.real * wts.to(DEV)).sum() + ((y.imag * wts.to(DEV)).sum() * 0.5 if y.is_complex() else 0)
+        loss.backward()
+        # torch-op port with the same options
+        xc = x.clone().requires_grad_(True)
+        wc = m.window.detach().cpu().clone().requires_grad_(True)
+        fr = TP.frame(xc, 48, 20, kw.get("center", True), kw.get("zmean", False), kw.get("mode", "constant")) * wc
+        Z = torch.fft.rfft(torch.nn.functional.pad(fr, (0, 16)), n=64)
+        fmt = kw.get("out_format", "power")
+        if fmt == "complex":
+            yr = Z
+            lr = (yr.real * wts).sum() + (yr.imag * wts).sum() * 0.5
+        else:
+            s = Z.abs().square() + 1e-9
+            if "relative_floor" in kw:
+                s = torch.maximum(s, s.amax(-1, keepdim=True) * 10 ** (kw["relative_floor"] / 10))
+            yr = {"power": s, "db": 10 * torch.log10(s), "magnitude": s.sqrt()}[fmt]
+            lr = (yr * wts).sum()
+        close(host(y.real), yr.real.detach().numpy(), 1e-8, 1e-10)
+        lr.backward()
+        close(host(xg.grad), xc.grad.numpy(), 1e-7, 1e-9)
+        close(host(m.window.grad), wc.grad.numpy(), 1e-7, 1e-9)
+
+
+# ----------------------------------------------------------------------------- a6 freqt
+def test_freqt(golden):
+    g = golden("grids")
+    c = dev(g["freqt_c"]).requires_grad_(True)
+    m = dsp.FrequencyTransform(19, 29, 0.1, dtype=torch.float64, device=DEV)
+    y = m(c)
+    close(host(y), g["freqt_out"], **F64)
+    close(host(F.freqt(c, 29, 0.1)), g["freqt_out"], **F64)
+    wts = torch.randn(2, 30, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    (y * wts.to(DEV)).sum().backward()
+    close(host(c.grad), (wts @ m.A.cpu().T).numpy(), 1e-12, 1e-14)
+
+
+# ----------------------------------------------------------------------------- a8 mcep
+@pytest.mark.parametrize("M", [0, 7, 8, 16])
+@pytest.mark.parametrize("n_iter", [0, 3])
+def test_mcep_small_grid_f64(golden, M, n_iter):
+    g = golden("grids")
+    S = dev(g["mcep_S"])
+    m = dsp.MelCepstralAnalysis(fft_length=32, cep_order=M, alpha=0.1, n_iter=n_iter, dtype=torch.float64, device=DEV)
+    close(host(m(S)), g[f"mcep_{M}_{n_iter}"], **F64)
+    close(host(F.mcep(S, M, 0.1, n_iter)), g[f"mcep_{M}_{n_iter}"], **F64)
+
+
+@pytest.mark.parametrize("name,dt", [("f64", torch.float64), ("f32", torch.float32)])
+def test_mcep_datawav_golden_and_trace(golden, name, dt):
+    g = golden("datawav")
+    X = dev(g["stft_power_f64"], dt)
+    m = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, dtype=dt, device=DEV)
+    mc = host(m(X))
+    if dt == torch.float64:
+        close(mc, g["mcep_f64"], **F64)
+    else:
+        close(mc, g["mcep_f64"], 1e-4, 2e-5)
+        close(mc, g["mcep_f32"], 1e-4, 2e-5)
+    # Newton trace: mc after k = 0..10 iterations for 5 frames
+    Xt = X[torch.from_numpy(g["trace_frames"]).to(DEV)]
+    for k in (0, 1, 2, 5, 10):
+        mk = host(F.mcep(Xt, 24, 0.42, k))
+        tol = F64 if dt == torch.float64 else dict(rtol=1e-4, atol=2e-5)
+        close(mk, g["mcep_trace_f64"][k], **tol)
+
+
+@pytest.mark.parametrize("name,dt", [("f64", torch.float64), ("f32", torch.float32)])
+def test_stft_mcep_end_to_end_golden_with_gradient(golden, name, dt):
+    g = golden("randn")
+    x = dev(g["x"], dt).requires_grad_(True)
+    stft = dsp.STFT(400, 80, 512, dtype=dt, device=DEV)
+    mcep = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, dtype=dt, device=DEV)
+    mc = mcep(stft(x))
+    tol = F64 if dt == torch.float64 else dict(rtol=1e-4, atol=2e-5)
+    close(host(mc), g["mcep_f64"], **tol)
+    mc.mean().backward()
+    ref = g["grad_mcep_mean_f64"]
+    rel = 1e-6 if dt == torch.float64 else 2e-3
+    assert np.abs(host(x.grad) - ref).max() < rel * np.abs(ref).max()
+
+
+def test_mcep_backward_wrt_spectrum_golden(golden):
+    g = golden("randn")
+    for name, dt, rel in (("f64", torch.float64, 1e-6), ("f32", torch.float32, 2e-3)):
+        X = dev(g["stft_power_f64"], dt).requires_grad_(True)
+        m = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, dtype=dt, device=DEV)
+        wts = torch.linspace(-1, 1, 25, dtype=dt, device=DEV)
+        (m(X) * wts).sum().backward()
+        ref = g["grad_mcep_wsum_wrt_X_f64"]
+        # per-frame relative bound: the cotangent of tiny bins scales with 1/X
+        err = np.abs(host(X.grad) - ref) / np.abs(ref).max(-1, keepdims=True)
+        assert err.max() < rel
+
+
+def test_mcep_gradcheck_f64():
+    gen = torch.Generator().manual_seed(0)
+    X = (torch.randn(3, 17, dtype=torch.float64, generator=gen).square() + 0.1).to(DEV).requires_grad_(True)
+    m = dsp.MelCepstralAnalysis(fft_length=32, cep_order=6, alpha=0.3, n_iter=3, dtype=torch.float64, device=DEV)
+    assert torch.autograd.gradcheck(m, (X,), eps=1e-6, atol=1e-6, rtol=1e-4, nondet_tol=0.0)
+
+
+def test_stft_lpc_gradcheck_f64():
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 90, dtype=torch.float64, generator=gen).to(DEV).requires_grad_(True)
+    stft = dsp.STFT(24, 10, 32, dtype=torch.float64, device=DEV)
+    assert torch.autograd.gradcheck(lambda t: torch.log(stft(t)), (x,), eps=1e-6, atol=1e-6, rtol=1e-4)
+    fr, wn = dsp.Frame(24, 10), dsp.Window(24, dtype=torch.float64, device=DEV)
+    lpc = dsp.LPC(24, 6, eps=1e-5, dtype=torch.float64, device=DEV)
+    assert torch.autograd.gradcheck(lambda t: lpc(wn(fr(t))), (x,), eps=1e-6, atol=1e-6, rtol=1e-4)
+
+
+def test_mcep_full_size_properties():
+    """BASELINE config 3 size (256 x 1 s): sampled frames vs the oracle, permutation invariance,
+    Newton fixed point."""
+    x = torch.randn(256, 16000, generator=torch.Generator().manual_seed(0))
+    xd = x.to(DEV)
+    stft = dsp.STFT(400, 80, 512, device=DEV)
+    mcep = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, device=DEV)
+    X = stft(xd)
+    mc = mcep(X)
+    assert mc.shape == (256, 200, 25) and torch.isfinite(mc).all()
+    idx = torch.randperm(256, generator=torch.Generator().manual_seed(1))
+    mc_p = mcep(stft(xd[idx.to(DEV)]))
+    assert torch.equal(mc_p, mc[idx.to(DEV)])  # frames are independent: bitwise
+    sel = slice(0, 256, 37)
+    ref = O.mcep(O.stft(x[sel].double().numpy(), 400, 80, 512), 24, 0.42, 10)
+    close(host(mc[sel]), ref, 1e-4, 2e-5)
+    mc11 = F.mcep(X[:8], 24, 0.42, 11)  # one more step moves a converged solution by < 1e-4
+    assert float((mc11 - mc[:8]).abs().max()) < 1e-4
+
+
+# ----------------------------------------------------------------------------- a11-a13 LPC
+def test_acorr_levdur_lpc_small_f64(golden):
+    g = golden("grids")
+    xa = dev(g["acorr_x"])
+    for M in (12, 13):
+        for o in range(4):
+            close(host(dsp.Autocorrelation(14, M, o)(xa)), g[f"acorr_{M}_{o}"], **F64)
+            close(host(F.acorr(xa, M, o)), g[f"acorr_{M}_{o}"], **F64)
+    r = dev(g["levdur_r"])
+    close(host(dsp.LevinsonDurbin(30, eps=0.0, dtype=torch.float64)(r)), g["levdur_out_eps0"], 1e-5, 1e-7)
+    close(host(F.levdur(r, 1e-5)), g["levdur_out_eps1e-5"], 1e-5, 1e-7)
+    close(host(dsp.LPC(30, 14, eps=0.0, dtype=torch.float64)(dev(g["lpc_x"]))), g["lpc_out"], 1e-5, 1e-7)
+    close(host(F.lpc(dev(g["lpc_x"]), 14, 0.0)), g["lpc_out"], 1e-5, 1e-7)
+    # order above 63 takes the LDS kernel
+    x = torch.randn(3, 200, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    close(host(F.lpc(x.to(DEV), 70, 1e-6)), O.lpc(x.numpy(), 70, 1e-6), 1e-6, 1e-8)
+
+
+@pytest.mark.parametrize("name,dt", [("f64", torch.float64), ("f32", torch.float32)])
+def test_lpc_datawav_and_randn_golden(golden, name, dt):
+    g1, g2 = golden("datawav"), golden("randn")
+    tol = dict(rtol=1e-5, atol=1e-7) if dt == torch.float64 else dict(rtol=1e-4, atol=1e-4)
+    for x_np, ref, acr in ((wav_float(g1["pcm"], np.float64), g1["lpc_f64"], g1["acorr_f64"]),
+                           (g2["x"], g2["lpc_f64"], None)):
+        x = dev(x_np, dt)
+        xw = dsp.Window(400, dtype=dt, device=DEV)(dsp.Frame(400, 80)(x))
+        if acr is not None:
+            close(host(F.acorr(xw, 24)), acr, 1e-4, 1e-7)
+        a = dsp.LPC(400, 24, eps=1e-5, dtype=dt, device=DEV)(xw)
+        close(host(a), ref, **tol)
+        a2 = dsp.LevinsonDurbin(24, eps=1e-5, dtype=dt, device=DEV)(dsp.Autocorrelation(400, 24)(xw))
+        close(host(a2), host(a), 1e-6, 1e-7)
+        w = dsp.Window(400, dtype=dt, device=DEV).window
+        a3 = ops.frame_window_lpc(x, w, 400, 80, 24, 1e-5)  # fused kernel
+        close(host(a3), ref, **tol)
+
+
+def test_lpc_backward_golden(golden):
+    g = golden("randn")
+    for name, dt, rel in (("f64", torch.float64, 1e-6), ("f32", torch.float32, 1e-3)):
+        x = dev(g["x"], dt).requires_grad_(True)
+        a = dsp.LPC(400, 24, eps=1e-5, dtype=dt, device=DEV)(dsp.Window(400, dtype=dt, device=DEV)(dsp.Frame(400, 80)(x)))
+        wts = torch.linspace(-1, 1, 25, dtype=dt, device=DEV)
+        (a * wts).sum().backward()
+        ref = g["grad_lpc_wsum_f64"]
+        assert np.abs(host(x.grad) - ref).max() < rel * np.abs(ref).max()
+
+
+def test_lpc_config4_batch1024_sampled():
+    x = torch.randn(1024, 16000, generator=torch.Generator().manual_seed(0))
+    xd = x.to(DEV)
+    w = dsp.Window(400, device=DEV).window
+    a = ops.frame_window_lpc(xd, w, 400, 80, 24, 1e-5)
+    assert a.shape == (1024, 200, 25) and torch.isfinite(a).all()
+    sel = slice(0, 1024, 171)
+    close(host(a[sel]), O.frame_window_lpc(x[sel].double().numpy()), 1e-4, 1e-4)
+    a_mod = dsp.LPC(400, 24, eps=1e-5, device=DEV)(dsp.Window(400, device=DEV)(dsp.Frame(400, 80)(xd[:64])))
+    close(host(a_mod), host(a[:64]), 1e-6, 1e-6)

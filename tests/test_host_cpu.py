@@ -1,0 +1,179 @@
+"""CPU-only tests of the product's host side: tables vs reference-generated goldens, option
+validation (same ValueErrors as the reference), the C-ABI library (loads, exports every symbol
+the header declares) and the loud failure without a device."""
+import ctypes
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import diffsptk_amd as dsp
+from diffsptk_amd import _lib, functional as F
+from diffsptk_amd.utils import tables
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    _lib.build()
+
+
+def test_library_exports_every_header_symbol():
+    header = open(os.path.join(ROOT, "include", "diffsptk_amd.h")).read()
+    declared = set(re.findall(r"\b(dsa_[a-z0-9_]+)\s*\(", header))
+    declared -= {"dsa_status"}
+    assert len(declared) >= 26
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, f"declared in the header but not exported: {missing}"
+    assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
+    assert _lib.load().dsa_version() == 100
+    assert _lib.load().dsa_num_frames(16000, 80) == 200
+    assert _lib.load().dsa_num_frames(19200, 80) == 240
+
+
+def test_no_cpu_fallback():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dsp.STFT(400, 80, 512)(torch.zeros(800))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        F.lpc(torch.zeros(2, 400), 24)
+
+
+def test_window_tables_match_reference(golden):
+    g = golden("tables")
+    for w in list(range(7)) + ["povey", "sine", "vorbis", "kbd"]:
+        for norm in (0, 1, 2):
+            for sym in (True, False):
+                if w == "kbd" and not sym:
+                    continue
+                for L in (8, 10, 400):
+                    np.testing.assert_allclose(tables.window_table(L, w, norm, sym),
+                                               g[f"win_{w}_{norm}_{int(sym)}_{L}"], rtol=1e-10, atol=1e-13)
+    m = dsp.Window(400, 512)
+    # the reference builds this table IN float32 (window.py:138): agree to float32 rounding of cos()
+    np.testing.assert_allclose(m.window.numpy(), g["blackman400_power_f32"], rtol=1e-5, atol=1e-8)
+    assert m.state_dict() == {}  # buffers are non-persistent like the reference's (base.py:67)
+    assert isinstance(dsp.Window(8, learnable=True).window, torch.nn.Parameter)
+
+
+def test_warp_and_composed_matrices(golden):
+    g = golden("tables")
+    G, D, E, av, Af, Ai, Ar = tables.mcep_matrices(512, 24, 0.42)
+    for got, key in ((Af, "freqt_A"), (Ai, "ifreqt_A"), (Ar, "rfreqt_A"), (av, "alpha_vector")):
+        np.testing.assert_allclose(got, g[key], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(tables.freqt_matrix(19, 29, 0.1), g["freqt_19_29_0.1"], rtol=1e-12)
+    # the composed maps reproduce the reference's FFT chains (numpy evaluation of mcep.py:203-215)
+    X = golden("datawav")["stft_power_f64"][::40]
+    logx = np.log(X)
+    c = np.fft.irfft(logx)
+    c[:, 0] *= 0.5
+    c[:, 256] *= 0.5
+    mc0 = c[:, :257] @ Af
+    np.testing.assert_allclose(logx @ G, mc0, rtol=1e-10, atol=1e-12)
+    d = np.fft.rfft(mc0 @ Ai, n=512).real
+    np.testing.assert_allclose(mc0 @ D, d, rtol=1e-10, atol=1e-12)
+    e = np.exp(logx - 2 * d)
+    np.testing.assert_allclose(e @ E, np.fft.irfft(e)[:, :257] @ Ar, rtol=1e-10, atol=1e-12)
+    mod = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10)
+    assert mod.G.shape == (257, 25) and mod.D.shape == (25, 257) and mod.E.shape == (257, 49)
+    assert mod.state_dict() == {}
+
+
+@pytest.mark.parametrize("call,msg", [
+    (lambda: dsp.Frame(0, 1), "frame_length must be positive."),
+    (lambda: dsp.Frame(1, 0), "frame_period must be positive."),
+    (lambda: dsp.Window(0), "in_length must be positive."),
+    (lambda: dsp.Window(4, 0), "out_length must be positive."),
+    (lambda: dsp.Window(4, window="nope"), "window nope is not supported."),
+    (lambda: dsp.Window(4, norm=7), "norm 7 is not supported."),
+    (lambda: dsp.RealValuedFastFourierTransform(7), "fft_length must be positive even."),
+    (lambda: dsp.RealValuedFastFourierTransform(8, out_format="x"), "out_format x is not supported."),
+    (lambda: dsp.Spectrum(1), "fft_length must be greater than 1."),
+    (lambda: dsp.Spectrum(8, eps=-1), "eps must be non-negative."),
+    (lambda: dsp.Spectrum(8, relative_floor=1), "relative_floor must be negative."),
+    (lambda: dsp.STFT(4, 2, 8, learnable=["x"]), "An unsupported key is found in learnable."),
+    (lambda: dsp.STFT(4, 2, 8, learnable=1), "learnable must be boolean or list."),
+    (lambda: dsp.FrequencyTransform(-1, 2), "in_order must be non-negative."),
+    (lambda: dsp.FrequencyTransform(1, -2), "out_order must be non-negative."),
+    (lambda: dsp.FrequencyTransform(1, 2, 1.0), "alpha must be in (-1, 1)."),
+    (lambda: dsp.MelCepstralAnalysis(fft_length=1, cep_order=0), "fft_length must be greater than 1."),
+    (lambda: dsp.MelCepstralAnalysis(fft_length=8, cep_order=-1), "cep_order must be non-negative."),
+    (lambda: dsp.MelCepstralAnalysis(fft_length=8, cep_order=5), "cep_order must be less than or equal to fft_length // 2."),
+    (lambda: dsp.MelCepstralAnalysis(fft_length=8, cep_order=2, alpha=-1), "alpha must be in (-1, 1)."),
+    (lambda: dsp.MelCepstralAnalysis(fft_length=8, cep_order=2, n_iter=-1), "n_iter must be non-negative."),
+    (lambda: dsp.Autocorrelation(0, 0), "frame_length must be positive."),
+    (lambda: dsp.Autocorrelation(4, 4), "acr_order must be less than frame_length."),
+    (lambda: dsp.Autocorrelation(4, 2, "x"), "out_format x is not supported."),
+    (lambda: dsp.LevinsonDurbin(-1), "lpc_order must be non-negative."),
+    (lambda: dsp.LevinsonDurbin(2, eps=-1.0), "eps must be non-negative."),
+])
+def test_validation_messages_match_reference(call, msg):
+    with pytest.raises(ValueError) as e:
+        call()
+    assert str(e.value) == msg
+
+
+def test_forward_size_checks():
+    with pytest.raises(ValueError, match=r"Unexpected input length \(input 5 vs target 4\)\."):
+        dsp.Window(4)(torch.zeros(5))
+    with pytest.raises(ValueError, match=r"Unexpected dimension of spectrum \(input 4 vs target 5\)\."):
+        dsp.MelCepstralAnalysis(fft_length=8, cep_order=2)(torch.zeros(4))
+    with pytest.raises(ValueError, match=r"Unexpected dimension of cepstrum"):
+        dsp.FrequencyTransform(3, 4)(torch.zeros(3))
+    with pytest.raises(ValueError, match=r"Unexpected length of waveform"):
+        dsp.Autocorrelation(5, 2)(torch.zeros(4))
+    with pytest.raises(ValueError, match=r"Unexpected dimension of autocorrelation"):
+        dsp.LevinsonDurbin(2)(torch.zeros(4))
+
+
+def test_interface_contract():
+    """Same contract the reference pins by AST (tests/test_interface_consistency.py:153-207):
+    every functional delegates to Module._func, and every keyword-only name of _forward is
+    produced by _precompute."""
+    mods = [dsp.Frame, dsp.Window, dsp.RealValuedFastFourierTransform, dsp.Spectrum, dsp.STFT,
+            dsp.FrequencyTransform, dsp.MelCepstralAnalysis, dsp.Autocorrelation, dsp.LevinsonDurbin, dsp.LPC]
+    samples = {
+        dsp.Frame: dict(frame_length=4, frame_period=2),
+        dsp.Window: dict(in_length=4, out_length=8),
+        dsp.RealValuedFastFourierTransform: dict(fft_length=8),
+        dsp.Spectrum: dict(fft_length=8),
+        dsp.STFT: dict(frame_length=4, frame_period=2, fft_length=8),
+        dsp.FrequencyTransform: dict(in_order=3, out_order=4, alpha=0.1),
+        dsp.MelCepstralAnalysis: dict(fft_length=8, cep_order=2, alpha=0.1, n_iter=1),
+        dsp.Autocorrelation: dict(frame_length=5, acr_order=2),
+        dsp.LevinsonDurbin: dict(lpc_order=2),
+        dsp.LPC: dict(frame_length=5, lpc_order=2),
+    }
+    for M in mods:
+        for name in ("_func", "_check", "_precompute", "_forward"):
+            assert isinstance(inspect.getattr_static(M, name), staticmethod), (M, name)
+        m = M(**samples[M])
+        sig = inspect.signature(M._forward)
+        need = {k for k, p in sig.parameters.items() if p.kind is p.KEYWORD_ONLY and p.default is p.empty}
+        assert need <= set(m._state()), (M, need - set(m._state()))
+    for fn in (F.acorr, F.fftr, F.frame, F.freqt, F.levdur, F.lpc, F.mcep, F.spec, F.stft, F.window):
+        assert "._func(" in inspect.getsource(fn)
+    assert dsp.STFT is dsp.ShortTimeFourierTransform and dsp.LPC is dsp.LinearPredictiveCodingAnalysis
+
+
+def test_get_alpha_and_read(golden, tmp_path):
+    assert dsp.get_alpha(16000) == 0.42 and dsp.get_alpha(48000) == 0.55
+    assert dsp.get_alpha(16000, "auto") == pytest.approx(0.41) and dsp.get_alpha(8000, "auto") == pytest.approx(0.31)
+    with pytest.raises(ValueError):
+        dsp.get_alpha(12345)
+    import wave
+
+    pcm = golden("datawav")["pcm"]
+    p = str(tmp_path / "d.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(pcm.astype("<i2").tobytes())
+    x, sr = dsp.read(p)
+    assert sr == 16000 and x.shape == (19200,) and x.dtype == torch.float32
+    np.testing.assert_array_equal(x.numpy(), (pcm / 32768.0).astype(np.float32))
