@@ -327,7 +327,7 @@ DSA_EXPORT int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, i
     hipStream_t st = (hipStream_t)stream;
     bool tuned_ok = mcep_mfma_supported(nfft, M, dtype) != 0;
     if (algo == DSA_ALGO_TUNED && !tuned_ok)
-        return fail(DSA_ERR_UNSUPPORTED, "mcep: tuned kernel needs float32, fft_length 512, cep_order <= 27%s");
+        return fail(DSA_ERR_UNSUPPORTED, "mcep: tuned kernel needs float32, fft_length 512, cep_order 24%s");
     if (tuned_ok && algo != DSA_ALGO_GENERIC)
         return mcep_mfma_fwd(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);
     if (dtype == DSA_F32) return mcep_generic_fwd<float>(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);

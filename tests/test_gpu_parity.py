@@ -386,6 +386,31 @@ def test_mcep_backward_wrt_spectrum_golden(golden):
         assert err.max() < rel
 
 
+def test_mcep_tuned_vs_generic_and_history(golden):
+    g = golden("randn")
+    X = dev(g["stft_power_f32"])
+    m = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, device=DEV)
+    outs = {}
+    for name, algo in (("generic", _lib.ALGO_GENERIC), ("tuned", _lib.ALGO_TUNED)):
+        Xg = X.clone().requires_grad_(True)  # requires_grad => the Newton history is recorded
+        mc = ops.McepFn.apply(Xg, m.G, m.D, m.E, m.alpha_vector, 512, 24, 10, algo)
+        assert _lib.last_kernel() == ("mcep_mfma_fwd" if name == "tuned" else "mcep_generic_fwd")
+        (mc * torch.linspace(-1, 1, 25, device=DEV)).sum().backward()
+        outs[name] = (host(mc), host(Xg.grad))
+    close(outs["tuned"][0], g["mcep_f64"], 1e-4, 2e-5)
+    close(outs["tuned"][0], outs["generic"][0], 1e-4, 2e-5)
+    ref = g["grad_mcep_wsum_wrt_X_f64"]
+    for name in outs:
+        err = np.abs(outs[name][1] - ref) / np.abs(ref).max(-1, keepdims=True)
+        assert err.max() < 2e-3, name
+    # ragged tile: 37 frames (not a multiple of 64) through the tuned kernel
+    mc37 = ops.McepFn.apply(X[0, :37], m.G, m.D, m.E, m.alpha_vector, 512, 24, 10, _lib.ALGO_TUNED)
+    close(host(mc37), g["mcep_f64"][0, :37], 1e-4, 2e-5)
+    with pytest.raises(_lib.BackendError):
+        ops.McepFn.apply(X[0, :4].double(), m.G.double(), m.D.double(), m.E.double(), m.alpha_vector.double(),
+                         512, 24, 10, _lib.ALGO_TUNED)
+
+
 def test_mcep_gradcheck_f64():
     gen = torch.Generator().manual_seed(0)
     X = (torch.randn(3, 17, dtype=torch.float64, generator=gen).square() + 0.1).to(DEV).requires_grad_(True)
@@ -444,9 +469,11 @@ def test_acorr_levdur_lpc_small_f64(golden):
 @pytest.mark.parametrize("name,dt", [("f64", torch.float64), ("f32", torch.float32)])
 def test_lpc_datawav_and_randn_golden(golden, name, dt):
     g1, g2 = golden("datawav"), golden("randn")
-    tol = dict(rtol=1e-5, atol=1e-7) if dt == torch.float64 else dict(rtol=1e-4, atol=1e-4)
-    for x_np, ref, acr in ((wav_float(g1["pcm"], np.float64), g1["lpc_f64"], g1["acorr_f64"]),
-                           (g2["x"], g2["lpc_f64"], None)):
+    # float32 on real speech: the Yule-Walker system is ill-conditioned (the reference's own f32
+    # result is 8.8e-4 away from its f64 result); float32 rounding of x*w alone moves a by 2e-4.
+    for x_np, ref, acr, atol32 in ((wav_float(g1["pcm"], np.float64), g1["lpc_f64"], g1["acorr_f64"], 5e-4),
+                                   (g2["x"], g2["lpc_f64"], None, 1e-4)):
+        tol = dict(rtol=1e-5, atol=1e-7) if dt == torch.float64 else dict(rtol=1e-4, atol=atol32)
         x = dev(x_np, dt)
         xw = dsp.Window(400, dtype=dt, device=DEV)(dsp.Frame(400, 80)(x))
         if acr is not None:
