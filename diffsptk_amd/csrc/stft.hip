@@ -484,13 +484,29 @@ __device__ __forceinline__ void fft16(cf (&v)[16])
 }
 #define FFT16_OUT(k) (4 * ((k)&3) + ((k) >> 2))
 
-constexpr int kFPB = 16;        // frames per workgroup pass (4 waves x 4 frames)
+constexpr int kFPW = 4;         // frames per wave (16 lanes each)
 constexpr int kZStride = 272;   // complex elements per frame region: 16 x 17 (padded transpose)
 
+// real-FFT split of the 256-point complex spectrum z (natural order, LDS) at bin k:
+// X[k] = E - i W O,  E = (a + conj(b))/2, O = (a - conj(b))/2, a = Z[k], b = Z[256-k],
+// W = exp(-2 pi i k / 512) = tw[k] = (cos, -sin).
+__device__ __forceinline__ cf rfft_split(const cf* __restrict__ z, const cf* __restrict__ tw, int k)
+{
+    cf a = z[k & 255], bq = z[(256 - k) & 255];
+    cf e = {0.5f * (a.re + bq.re), 0.5f * (a.im - bq.im)};
+    cf o = {0.5f * (a.re - bq.re), 0.5f * (a.im + bq.im)};
+    cf t = tw[k];
+    return cf{e.re + (t.re * o.im + t.im * o.re), e.im - (t.re * o.re - t.im * o.im)};
+}
+
 // ShortTimeFourierTransform._forward stft.py:237-241 for nfft = 512, float32.
-// dynamic LDS layout (bytes): in_buf[(kFPB-1)*P + 512 (+pad)] floats | zbuf[kFPB][272] cf |
-//                             tw[257] cf | fmax[kFPB] floats
-__global__ __launch_bounds__(256) void stft512_fwd_kernel(
+// One wave64 per workgroup, autonomous (no inter-wave barriers): it owns kFPW = 4 consecutive
+// frames of one utterance per pass -- the 3P + L samples they share are read from HBM once into
+// LDS -- and writes their 4 x 257 output rows as one contiguous, 16-byte aligned run of float4.
+// dynamic LDS layout: in_buf[in_floats] floats | zbuf[kFPW][272] cf | tw[257] cf | fmax[kFPW]
+// ABL: 0 production | 1 no output stores | 2 no FFT butterflies | 3 no input staging (tools/bench_stft.cpp)
+template <int ABL>
+__global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
     const float* __restrict__ x, long Tlen, long N, int L, int P, int left, int mode, int zmean,
     const float* __restrict__ w, const float* __restrict__ twiddle, float eps, int use_floor,
     float floor_lin, int fmt, float* __restrict__ y, long total_chunks, int chunks_per_utt,
@@ -499,16 +515,15 @@ __global__ __launch_bounds__(256) void stft512_fwd_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* in_buf = reinterpret_cast<float*>(smem_raw);
     cf* zbuf = reinterpret_cast<cf*>(in_buf + in_floats);
-    cf* tw = zbuf + kFPB * kZStride;
+    cf* tw = zbuf + kFPW * kZStride;
     float* fmax = reinterpret_cast<float*>(tw + 257);
 
-    const int tid = threadIdx.x;
-    const int j = tid & 15;             // lane within the frame group
-    const int fl = tid >> 4;            // frame slot within the chunk (0..15)
-    const int span = (kFPB - 1) * P + 512;
+    const int lane = threadIdx.x;
+    const int j = lane & 15;   // lane within the frame group
+    const int fl = lane >> 4;  // frame slot within the pass (0..3)
 
-    // per-block constants: post-processing twiddles, per-lane window and W256^(j*k1)
-    for (int k = tid; k < 257; k += 256) tw[k] = cf{twiddle[2 * k], twiddle[2 * k + 1]};  // (cos,-sin)(2 pi k/512)
+    // per-wave constants: post-processing twiddles, per-lane window and W256^(j*k1)
+    for (int k = lane; k < 257; k += 64) tw[k] = cf{twiddle[2 * k], twiddle[2 * k + 1]};
     float wreg[32];
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
@@ -524,19 +539,28 @@ __global__ __launch_bounds__(256) void stft512_fwd_kernel(
     const float inv_L = 1.f / (float)L;
     const int K = 257;
     const bool complex_out = fmt == DSA_SPEC_COMPLEX;
+    cf* zf = zbuf + fl * kZStride;
 
     for (long c = blockIdx.x; c < total_chunks; c += gridDim.x) {
         const long b = c / chunks_per_utt;
-        const long frame0 = (c - b * chunks_per_utt) * kFPB;
-        const int nvalid = (int)((N - frame0) < kFPB ? (N - frame0) : kFPB);
+        const long frame0 = (c - b * chunks_per_utt) * kFPW;
+        const int nvalid = (int)((N - frame0) < kFPW ? (N - frame0) : kFPW);
         const float* xb = x + b * Tlen;
-        __syncthreads();  // previous chunk's output phase done with zbuf / in_buf
+        __syncthreads();  // previous pass is done with in_buf / zbuf (single-wave workgroup)
         // ---- stage the shared waveform stretch (each sample read from HBM once) ----
-        {
+        if (ABL != 3) {
             const long g0 = frame0 * P - left;
-            const int need = (nvalid - 1) * P + L;  // samples any valid frame can touch
-            for (int s = tid; s < span; s += 256)
-                in_buf[s] = s < need ? load_padded(xb, g0 + s, Tlen, mode) : 0.f;
+            const int need = (nvalid - 1) * P + L;  // samples the valid frames touch
+            const bool interior = g0 >= 0 && g0 + need <= Tlen;
+            if (interior && (((size_t)(xb + g0)) & 15) == 0) {
+                const float4* src4 = reinterpret_cast<const float4*>(xb + g0);
+                float4* dst4 = reinterpret_cast<float4*>(in_buf);
+                const int n4 = need >> 2;
+                for (int s = lane; s < n4; s += 64) dst4[s] = src4[s];
+                for (int s = (n4 << 2) + lane; s < need; s += 64) in_buf[s] = xb[g0 + s];
+            } else {
+                for (int s = lane; s < need; s += 64) in_buf[s] = load_padded(xb, g0 + s, Tlen, mode);
+            }
         }
         __syncthreads();
         // ---- per frame: window, 256-point complex FFT (16 lanes x 16 points) ----
@@ -548,8 +572,8 @@ __global__ __launch_bounds__(256) void stft512_fwd_kernel(
             for (int m1 = 0; m1 < 16; ++m1) {
                 int l = 2 * j + 32 * m1;
                 float a0 = src[32 * m1], a1 = src[32 * m1 + 1];
-                a0 = l < L ? a0 : 0.f;       // keep non-finite samples out of frames that do
-                a1 = l + 1 < L ? a1 : 0.f;   // not contain them (zero padding is exact)
+                a0 = l < L ? a0 : 0.f;       // samples past the frame are never used (also keeps
+                a1 = l + 1 < L ? a1 : 0.f;   // non-finite neighbours out of frames not containing them)
                 v[m1] = cf{a0, a1};
                 sum += a0 + a1;
             }
@@ -567,8 +591,7 @@ __global__ __launch_bounds__(256) void stft512_fwd_kernel(
                 v[m1] = cf{a0 * wreg[2 * m1], a1 * wreg[2 * m1 + 1]};  // window.py:190
             }
         }
-        fft16<false>(v);
-        cf* zf = zbuf + fl * kZStride;
+        if (ABL != 2) fft16<false>(v);
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1)  // twiddle, then transposed store [k1][j] (row stride 17)
             zf[k1 * 17 + j] = cmul(v[FFT16_OUT(k1)], t256[k1]);
@@ -576,7 +599,7 @@ __global__ __launch_bounds__(256) void stft512_fwd_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = zf[j * 17 + i];  // lane k1 = j reads A[i][k1]
         __syncthreads();
-        fft16<false>(v);
+        if (ABL != 2) fft16<false>(v);
 #pragma unroll
         for (int k0 = 0; k0 < 16; ++k0) zf[j + 16 * k0] = v[FFT16_OUT(k0)];  // Z[k1 + 16 k0], natural order
         __syncthreads();
@@ -584,13 +607,8 @@ __global__ __launch_bounds__(256) void stft512_fwd_kernel(
         if (use_floor && !complex_out) {
             float m = 0.f;
             for (int k = j; k < K; k += 16) {
-                cf a = zf[k & 255], bq = zf[(256 - k) & 255];
-                cf e = {0.5f * (a.re + bq.re), 0.5f * (a.im - bq.im)};
-                cf o = {0.5f * (a.re - bq.re), 0.5f * (a.im + bq.im)};
-                cf t = tw[k];  // (cos, -sin)
-                float re = e.re + (t.re * o.im + t.im * o.re);
-                float im = e.im - (t.re * o.re - t.im * o.im);
-                float s = re * re + im * im + eps;
+                cf X = rfft_split(zf, tw, k);
+                float s = X.re * X.re + X.im * X.im + eps;
                 m = s > m ? s : m;
             }
 #pragma unroll
@@ -603,23 +621,44 @@ __global__ __launch_bounds__(256) void stft512_fwd_kernel(
         }
         // ---- real-FFT split + formatter fused into the coalesced write of the output tile ----
         {
-            const long out0 = (b * N + frame0) * K;
-            const int total = nvalid * K;
-            for (int idx = tid; idx < total; idx += 256) {
-                int f = idx / K;
-                int k = idx - f * K;
-                const cf* z = zbuf + f * kZStride;
-                cf a = z[k & 255], bq = z[(256 - k) & 255];
-                // X[k] = E - i W O,  E = (a + conj(b))/2, O = (a - conj(b))/2, W = exp(-2 pi i k/512)
-                cf e = {0.5f * (a.re + bq.re), 0.5f * (a.im - bq.im)};
-                cf o = {0.5f * (a.re - bq.re), 0.5f * (a.im + bq.im)};
-                cf t = tw[k];
-                float re = e.re + (t.re * o.im + t.im * o.re);
-                float im = e.im - (t.re * o.re - t.im * o.im);
-                if (complex_out) {
-                    reinterpret_cast<float2*>(y)[out0 + idx] = make_float2(re, im);
-                } else {
-                    float s = re * re + im * im + eps;  // spec.py:173
+            const long row0 = b * N + frame0;
+            const long out0 = row0 * K;
+            if (complex_out) {
+                const int total = nvalid * K;
+                for (int idx = lane; idx < total; idx += 64) {
+                    int f = idx >= 3 * K ? 3 : (idx >= 2 * K ? 2 : (idx >= K ? 1 : 0));
+                    cf X = rfft_split(zbuf + f * kZStride, tw, idx - f * K);
+                    reinterpret_cast<float2*>(y)[out0 + idx] = make_float2(X.re, X.im);
+                }
+            } else if (nvalid == kFPW && (row0 & 3) == 0) {
+                // 4 rows x 257 floats = 257 float4, 16-byte aligned because row0 % 4 == 0
+                float4* y4 = reinterpret_cast<float4*>(y + out0);
+#pragma unroll 1
+                for (int jj = 0; jj < 5; ++jj) {
+                    const int t = lane + 64 * jj;
+                    if (t < K) {
+                        float o4[4];
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) {
+                            const int idx = 4 * t + cc;
+                            const int f = idx >= 3 * K ? 3 : (idx >= 2 * K ? 2 : (idx >= K ? 1 : 0));
+                            cf X = rfft_split(zbuf + f * kZStride, tw, idx - f * K);
+                            float s = X.re * X.re + X.im * X.im + eps;  // spec.py:173
+                            if (use_floor) {
+                                float flv = fmax[f] * floor_lin;
+                                s = s > flv ? s : flv;
+                            }
+                            o4[cc] = spec_format(s, fmt);
+                        }
+                        if (ABL != 1 || o4[0] == 123.456f) y4[t] = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                    }
+                }
+            } else {
+                const int total = nvalid * K;
+                for (int idx = lane; idx < total; idx += 64) {
+                    int f = idx >= 3 * K ? 3 : (idx >= 2 * K ? 2 : (idx >= K ? 1 : 0));
+                    cf X = rfft_split(zbuf + f * kZStride, tw, idx - f * K);
+                    float s = X.re * X.re + X.im * X.im + eps;
                     if (use_floor) {
                         float flv = fmax[f] * floor_lin;
                         s = s > flv ? s : flv;
@@ -650,11 +689,11 @@ static int launch_row_dft(const void* x, int64_t B, int64_t Tlen, int64_t N, int
     return check_launch("row_dft_generic");
 }
 
-static int stft512_lds_bytes(int P, int* in_floats)
+static int stft512_lds_bytes(int L, int P, int* in_floats)
 {
-    int span = (kFPB - 1) * P + 512;
+    int span = (kFPW - 1) * P + L;
     *in_floats = (span + 3) & ~3;
-    return *in_floats * 4 + kFPB * kZStride * 8 + 257 * 8 + kFPB * 4;
+    return *in_floats * 4 + kFPW * kZStride * 8 + 257 * 8 + 16;
 }
 
 }  // namespace dsa
@@ -862,22 +901,20 @@ DSA_EXPORT int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int3
     if (B * N == 0) return DSA_OK;
     int left = center ? L / 2 : 0;
     int in_floats = 0;
-    int lds = stft512_lds_bytes(P, &in_floats);
-    bool tuned_ok = dtype == DSA_F32 && nfft == 512 && L <= 512 && lds <= 160 * 1024;
+    int lds = stft512_lds_bytes(L, P, &in_floats);
+    bool tuned_ok = dtype == DSA_F32 && nfft == 512 && L <= 512 && lds <= 64 * 1024;
     if (algo == DSA_ALGO_TUNED && !tuned_ok)
         return fail(DSA_ERR_UNSUPPORTED, "stft: tuned kernel needs float32, fft_length 512, frame_length <= 512%s");
     if (tuned_ok && algo != DSA_ALGO_GENERIC) {
-        int chunks_per_utt = (int)((N + kFPB - 1) / kFPB);
+        int chunks_per_utt = (int)((N + kFPW - 1) / kFPW);
         long total_chunks = (long)B * chunks_per_utt;
-        if (lds > 48 * 1024)
-            hipFuncSetAttribute((const void*)stft512_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        int blocks_per_cu = 160 * 1024 / lds;
-        if (blocks_per_cu > 8) blocks_per_cu = 8;
-        if (blocks_per_cu < 1) blocks_per_cu = 1;
-        long grid = 256L * blocks_per_cu;
+        int waves_per_cu = 160 * 1024 / lds;
+        if (waves_per_cu > 16) waves_per_cu = 16;
+        if (waves_per_cu < 1) waves_per_cu = 1;
+        long grid = 256L * waves_per_cu;  // persistent single-wave workgroups
         if (grid > total_chunks) grid = total_chunks;
         float floor_lin = use_floor ? (float)pow(10.0, relative_floor_db / 10.0) : 0.f;
-        hipLaunchKernelGGL(stft512_fwd_kernel, dim3((unsigned)grid), dim3(256), lds, st, (const float*)x,
+        hipLaunchKernelGGL(stft512_fwd_kernel<0>, dim3((unsigned)grid), dim3(64), lds, st, (const float*)x,
                            (long)T, (long)N, L, P, left, pad_mode, zmean, (const float*)w,
                            (const float*)twiddle, (float)eps, use_floor, floor_lin, out_format, (float*)y,
                            total_chunks, chunks_per_utt, in_floats);
