@@ -23,6 +23,7 @@
 // 1028 B in + 100 B out per frame.
 #include "common.h"
 
+#include <stdlib.h>
 #include <utility>
 
 namespace dsa {
@@ -34,7 +35,8 @@ constexpr int H = 256, K = 257;   // nfft = 512
 constexpr int M1 = 25, M2 = 49;   // cep_order 24
 constexpr int KS = 7;             // k-steps of the first product (28 >= M1 coefficients)
 constexpr int NR = 7;             // local rows per lane group (ceil(M1 / 4))
-constexpr int RS = 66;            // per-frame stride of the rt / rr windows in LDS (floats)
+constexpr int RS = 68;            // per-frame stride of the rt / rr windows in LDS (floats; 68 % 32 = 4:
+                                  // the quad-layout reads of 8 frames x 4 lanes hit 32 distinct banks)
 // LDS carve-up (floats)
 constexpr int DT_OFF = 0;                       // [16 mt][2 half][64 lane][4]
 constexpr int ET_OFF = DT_OFF + 16 * 2 * 64 * 4;  // [3 it][16 mt][64 lane][4 r]
@@ -46,6 +48,17 @@ constexpr int WAVE_OFF = AV_OFF + 28;           // per wave: rt [16][RS], rr [16
 constexpr int WAVE_FLOATS = 2 * 16 * RS;
 constexpr int LDS_FLOATS = WAVE_OFF + 4 * WAVE_FLOATS;
 }  // namespace mm
+
+// exp(x) for |x| < 87 without control flow: x log2(e) = n + r with the product carried in two
+// floats (Cody-Waite), v_exp_f32 on the reduced argument, v_ldexp_f32 for 2^n.  ~1 ulp.
+__device__ __forceinline__ float exp_nobranch(float x)
+{
+    constexpr float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f;
+    const float nn = __builtin_rintf(x * L2E_HI);
+    float r = __builtin_fmaf(x, L2E_HI, -nn);
+    r = __builtin_fmaf(x, L2E_LO, r);
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(r), (int)nn);
+}
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
 {
@@ -299,27 +312,718 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_fwd_kernel(
     }
 }
 
+// =====================================================================================
+// v2: 8 waves per workgroup (two per SIMD), no workgroup barriers inside the iteration, and a
+// SYMMETRIC row-cyclic elimination: only columns j >= 4m of local row m are kept (91 registers
+// instead of 175), multipliers come from the broadcast pivot row (a[i][k] = a[k][i]), and the
+// solution updates mc as soon as each x_k is known.  With <= 256 registers per wave the second
+// wave of a SIMD runs its MFMA chains while the first is in the (latency-bound) solve.
+// =====================================================================================
+#ifdef DSA_MCEP_TIMING
+__device__ unsigned long long g_mcep_stamps[64];
+#define DSA_STAMP(i)                                                                   \
+    do {                                                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && tile == 0 && iter == 1)             \
+            g_mcep_stamps[i] = __builtin_readcyclecounter();                            \
+    } while (0)
+#else
+#define DSA_STAMP(i)
+#endif
+
+namespace mm2 {
+using namespace mm;
+constexpr int lds_floats(int waves) { return WAVE_OFF + waves * WAVE_FLOATS; }
+}  // namespace mm2
+
+// Branch-free per-lane selection by lane group: gm[i] is all-ones where g == i (hipcc turns
+// nested ?: on lane-dependent conditions into exec-mask control flow; the bit form stays VALU).
+struct GroupMask {
+    unsigned m[4];
+    unsigned gt[4];  // gt[i]: all-ones where g > i
+};
+__device__ __forceinline__ GroupMask make_group_mask(int g)
+{
+    GroupMask q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        q.m[i] = g == i ? 0xffffffffu : 0u;
+        q.gt[i] = g > i ? 0xffffffffu : 0u;
+    }
+    return q;
+}
+__device__ __forceinline__ float sel4(const GroupMask& q, float c0, float c1, float c2, float c3)
+{
+    unsigned r = (__float_as_uint(c0) & q.m[0]) | (__float_as_uint(c1) & q.m[1]) | (__float_as_uint(c2) & q.m[2]) |
+                 (__float_as_uint(c3) & q.m[3]);
+    return __uint_as_float(r);
+}
+__device__ __forceinline__ float keep_if(unsigned mask, float v) { return __uint_as_float(__float_as_uint(v) & mask); }
+// 1/x: v_rcp_f32 (1 ulp) + one Newton step
+__device__ __forceinline__ float rcp_nr(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    return r * __builtin_fmaf(-x, r, 2.f);
+}
+
+// value of lane Q of this lane's quad (DPP quad_perm broadcast: a plain VALU move, no LDS)
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), Q * 0x55, 0xf, 0xf, true));
+}
+
+// local symmetric row block: row m keeps columns 4m .. 24
+struct SymRows {
+    float r0[25], r1[21], r2[17], r3[13], r4[9], r5[5], r6[1];
+};
+template <int m>
+__device__ __forceinline__ float* sym_row(SymRows& a)
+{
+    if constexpr (m == 0) return a.r0;
+    else if constexpr (m == 1) return a.r1;
+    else if constexpr (m == 2) return a.r2;
+    else if constexpr (m == 3) return a.r3;
+    else if constexpr (m == 4) return a.r4;
+    else if constexpr (m == 5) return a.r5;
+    else return a.r6;
+}
+
+template <int k, int m>
+__device__ __forceinline__ void sym_update_row(SymRows& a, float (&b)[mm::NR], const float (&prow)[mm::M1],
+                                               float pb, float inv, const GroupMask& gq)
+{
+    using namespace mm;
+    constexpr int gk = k & 3, mk = k >> 2;
+    if constexpr (m >= mk && m < NR) {
+        // multiplier a[i][k] / a[k][k] with a[i][k] = a[k][i] = prow[i], i = 4m + g
+        constexpr int i0 = 4 * m;
+        const float c0 = (i0 + 0 > k && i0 + 0 < M1) ? prow[i0 + 0 < M1 ? i0 + 0 : 0] : 0.f;
+        const float c1 = (i0 + 1 > k && i0 + 1 < M1) ? prow[i0 + 1 < M1 ? i0 + 1 : 0] : 0.f;
+        const float c2 = (i0 + 2 > k && i0 + 2 < M1) ? prow[i0 + 2 < M1 ? i0 + 2 : 0] : 0.f;
+        const float c3 = (i0 + 3 > k && i0 + 3 < M1) ? prow[i0 + 3 < M1 ? i0 + 3 : 0] : 0.f;
+        (void)gk;
+        const float fct = sel4(gq, c0, c1, c2, c3) * inv;
+        float* row = sym_row<m>(a);
+        constexpr int j0 = (4 * m > k + 1) ? 4 * m : k + 1;
+#pragma unroll
+        for (int j = j0; j < M1; ++j) row[j - 4 * m] -= fct * prow[j];
+        b[m] -= fct * pb;
+        sym_update_row<k, m + 1>(a, b, prow, pb, inv, gq);
+    }
+}
+
+template <int k>
+__device__ __forceinline__ void sym_elim_step(SymRows& a, float (&b)[mm::NR], int n, const GroupMask& gq)
+{
+    using namespace mm;
+    constexpr int gk = k & 3, mk = k >> 2;
+    (void)n;
+    float prow[M1];
+    float* prw = sym_row<mk>(a);
+#pragma unroll
+    for (int j = k; j < M1; ++j) prow[j] = quad_bcast<gk>(prw[j - 4 * mk]);
+    const float pb = quad_bcast<gk>(b[mk]);
+    const float inv = rcp_nr(prow[k]);
+    sym_update_row<k, mk>(a, b, prow, pb, inv, gq);
+}
+
+template <int k, int m>
+__device__ __forceinline__ void sym_backsub_rows(SymRows& a, float (&b)[mm::NR], float xk)
+{
+    constexpr int mk = k >> 2;
+    if constexpr (m <= mk) {
+        b[m] -= sym_row<m>(a)[k - 4 * m] * xk;
+        sym_backsub_rows<k, m + 1>(a, b, xk);
+    }
+}
+
+template <int k>
+__device__ __forceinline__ void sym_backsub_step(SymRows& a, float (&b)[mm::NR], float (&mcB)[mm::KS], int n,
+                                                 const GroupMask& gq)
+{
+    constexpr int gk = k & 3, mk = k >> 2;
+    (void)n;
+    const float xk = quad_bcast<gk>(b[mk] * rcp_nr(sym_row<mk>(a)[k - 4 * mk]));
+    mcB[mk] = __uint_as_float(__float_as_uint(mcB[mk]) | (__float_as_uint(xk) & gq.m[gk]));  // x[4 mk + g']
+    sym_backsub_rows<k, 0>(a, b, xk);
+}
+
+template <int... Ks>
+__device__ __forceinline__ void sym_elim_all(SymRows& a, float (&b)[mm::NR], int n, const GroupMask& gq,
+                                             std::integer_sequence<int, Ks...>)
+{
+    (sym_elim_step<Ks>(a, b, n, gq), ...);
+}
+template <int... Ks>
+__device__ __forceinline__ void sym_backsub_all(SymRows& a, float (&b)[mm::NR], float (&mcB)[mm::KS], int n,
+                                                const GroupMask& gq, std::integer_sequence<int, Ks...>)
+{
+    (sym_backsub_step<mm::M1 - 1 - Ks>(a, b, mcB, n, gq), ...);
+}
+
+template <int m>
+__device__ __forceinline__ void sym_build_rows(SymRows& a, float (&b)[mm::NR], const float* rt_g, const float* rr_g,
+                                               const float* avs, int g)
+{
+    using namespace mm;
+    if constexpr (m < NR) {
+        // row i = g + 4m, columns j = 4m..24:  R[i][j] = r[|i-j|] = rr[27 + i - j],  Q[i][j] = rt[i + j]
+        // (mcep.py:219-221); rt_g = rt + g, rr_g = rr + 27 + g are this lane's shifted windows
+        // rows 4m .. 4m+3 all exist unless this is the last block (only g = 0 has row 24 when M1 = 25)
+        constexpr bool all_valid = 4 * m + 3 < M1;
+        const unsigned vmask = (all_valid || g + 4 * m < M1) ? 0xffffffffu : 0u;
+        float* row = sym_row<m>(a);
+#pragma unroll
+        for (int j = 4 * m; j < M1; ++j) {
+            const float v = rt_g[4 * m + j] + rr_g[4 * m - j];
+            row[j - 4 * m] = all_valid ? v : keep_if(vmask, v);
+        }
+        const float bv = rt_g[4 * m] - avs[g + 4 * m];  // mcep.py:216-217
+        b[m] = all_valid ? bv : keep_if(vmask, bv);
+        sym_build_rows<m + 1>(a, b, rt_g, rr_g, avs, g);
+    }
+}
+
+// WAVES = 4: one wave per SIMD with the whole 512-entry register file (no spills);
+// WAVES = 8: two waves per SIMD at <= 256 registers (log X spills to scratch).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2(
+    const float* __restrict__ X, long F, int n_iter, const float* __restrict__ G,
+    const float* __restrict__ D, const float* __restrict__ E, const float* __restrict__ av,
+    float* __restrict__ mc_out, float* __restrict__ hist, long ntiles16)
+{
+    using namespace mm2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+
+    // ---------------- operand images: built once per workgroup ----------------
+    for (int idx = tid; idx < 16 * 2 * 64 * 4; idx += WAVES * 64) {
+        int q = idx & 3, l = (idx >> 2) & 63, half = (idx >> 8) & 1, mt = idx >> 9;
+        int k = 4 * (half * 4 + q) + (l >> 4);
+        lds[DT_OFF + idx] = k < M1 ? D[k * K + mt * 16 + (l & 15)] : 0.f;
+    }
+    for (int idx = tid; idx < 3 * 16 * 64 * 4; idx += WAVES * 64) {
+        int r = idx & 3, l = (idx >> 2) & 63, mt = (idx >> 8) & 15, it = idx >> 12;
+        lds[ET_OFF + idx] = E[(mt * 16 + (l >> 4) * 4 + r) * M2 + it * 16 + (l & 15)];
+    }
+    {
+        const int t2 = tid & 255;
+        int r = t2 & 3, gg = (t2 >> 2) & 3, mt = t2 >> 4;
+        lds[E48_OFF + t2] = E[(mt * 16 + gg * 4 + r) * M2 + 48];
+    }
+    if (tid < M2) lds[E256_OFF + tid] = E[H * M2 + tid];
+    if (tid < 28) {
+        lds[D256_OFF + tid] = tid < M1 ? D[tid * K + H] : 0.f;
+        lds[AV_OFF + tid] = tid < M1 ? av[tid] : 0.f;
+    }
+    __syncthreads();  // the only workgroup barrier: from here on every wave runs on its own
+
+    float* rt_lds = lds + WAVE_OFF + wave * WAVE_FLOATS + n * RS;  // this lane's frame windows
+    float* rr_lds = rt_lds + 16 * RS;
+    const f32x4* Dt4 = reinterpret_cast<const f32x4*>(lds + DT_OFF);
+    const f32x4* Et4 = reinterpret_cast<const f32x4*>(lds + ET_OFF);
+    const f32x4* E484 = reinterpret_cast<const f32x4*>(lds + E48_OFF);
+    const long wave_id = (long)blockIdx.x * WAVES + wave;
+    const long wave_stride = (long)gridDim.x * WAVES;
+    // solve layout: the 4 lanes of a QUAD share a frame (nq = lane >> 2, gs = lane & 3), so the
+    // pivot-row broadcasts of the elimination are DPP quad_perm moves instead of ds_bpermute
+    const int nq = lane >> 2, gs = lane & 3;
+    const GroupMask gq = make_group_mask(gs);
+    float* rt_q = lds + WAVE_OFF + wave * WAVE_FLOATS + nq * RS;
+    float* rr_q = rt_q + 16 * RS;
+
+    for (long tile = wave_id; tile < ntiles16; tile += wave_stride) {
+        const long f_raw = tile * 16 + n;
+        const bool f_ok = f_raw < F;
+        const long f = f_ok ? f_raw : F - 1;  // tail lanes recompute the last frame, never store
+        const float* xf = X + f * K;
+
+        f32x4 logx[16];
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt) {
+            const float* p = xf + mt * 16 + 4 * g;
+            logx[mt] = f32x4{logf(p[0]), logf(p[1]), logf(p[2]), logf(p[3])};  // mcep.py:203
+        }
+        const float logx256 = logf(xf[H]);
+
+        // ---------------- mc0^T = G^T logx^T  (mcep.py:204-207) ----------------
+        float mcB[KS];
+        {
+            f32x4 accG[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int out = it * 16 + n;
+                const bool ov = out < M1;
+#pragma unroll
+                for (int mt = 0; mt < 16; ++mt) {
+                    const float* gp = G + (mt * 16 + 4 * g) * M1 + out;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accG[it] = mfma4(ov ? gp[r * M1] : 0.f, logx[mt][r], accG[it]);
+                }
+                accG[it] = mfma4((ov && g == 0) ? G[H * M1 + out] : 0.f, g == 0 ? logx256 : 0.f, accG[it]);
+            }
+            // accG[it][r] = mc0[coef it*16 + 4g + r]; re-distribute through this wave's LDS window
+            // (wave-private data: LDS executes a wave's accesses in program order)
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rt_lds[it * 16 + 4 * g + r] = accG[it][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) mcB[ks] = (4 * ks + g < M1) ? rt_lds[4 * ks + g] : 0.f;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (hist && f_ok)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                if (4 * ks + g < M1) hist[f * M1 + 4 * ks + g] = mcB[ks];
+
+        for (int iter = 0; iter < n_iter; ++iter) {
+            // ------------- per 16-bin tile: d^T = D^T mc^T, e = exp(log X - 2 d) (mcep.py:210-212),
+            // and straight on into rt^T += E^T e^T (mcep.py:214-215): e never leaves 4 registers ----
+            DSA_STAMP(0);
+            f32x4 accB[3] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+            float rt48 = 0.f;
+            // Software pipeline, pinned with sched_group_barrier: per 16-bin tile mt the matrix pipe
+            // gets 7 MFMAs of the D-chain of tile mt+1 (two accumulators) and 12 of the E-chain of
+            // tile mt (three accumulators, round-robin: no dependent-MFMA stall); the ~36 VALU
+            // instructions of exp(tile mt) and the operand ds_reads are slotted into the MFMA
+            // issue gaps (one wave cannot overlap MFMA and VALU unless they alternate in program order).
+            f32x4 pa = {0, 0, 0, 0}, qa = {0, 0, 0, 0};
+            {
+                const f32x4 a0 = Dt4[lane], a1 = Dt4[64 + lane];
+                pa = mfma4(a0[0], mcB[0], pa);
+                qa = mfma4(a1[0], mcB[4], qa);
+                pa = mfma4(a0[1], mcB[1], pa);
+                qa = mfma4(a1[1], mcB[5], qa);
+                pa = mfma4(a0[2], mcB[2], pa);
+                qa = mfma4(a1[2], mcB[6], qa);
+                pa = mfma4(a0[3], mcB[3], pa);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) {
+                const int mn = mt + 1 < 16 ? mt + 1 : 15;
+                const f32x4 a0 = Dt4[(mn * 2 + 0) * 64 + lane];
+                const f32x4 a1 = Dt4[(mn * 2 + 1) * 64 + lane];
+                const f32x4 ea0 = Et4[(0 * 16 + mt) * 64 + lane];
+                const f32x4 ea1 = Et4[(1 * 16 + mt) * 64 + lane];
+                const f32x4 ea2 = Et4[(2 * 16 + mt) * 64 + lane];
+                const f32x4 c48 = E484[mt * 4 + g];
+                const f32x4 acc = pa + qa;
+                f32x4 pn = {0, 0, 0, 0}, qn = {0, 0, 0, 0};
+                f32x4 e;
+                // D-chain of the next tile: issued while exp of this tile runs on the VALU
+                if (mt + 1 < 16) {
+                    pn = mfma4(a0[0], mcB[0], pn);
+                    qn = mfma4(a1[0], mcB[4], qn);
+                    pn = mfma4(a0[1], mcB[1], pn);
+                    qn = mfma4(a1[1], mcB[5], qn);
+                    pn = mfma4(a0[2], mcB[2], pn);
+                    qn = mfma4(a1[2], mcB[6], qn);
+                    pn = mfma4(a0[3], mcB[3], pn);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e[r] = exp_nobranch(logx[mt][r] - 2.f * acc[r]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    accB[0] = mfma4(ea0[r], e[r], accB[0]);
+                    accB[1] = mfma4(ea1[r], e[r], accB[1]);
+                    accB[2] = mfma4(ea2[r], e[r], accB[2]);
+                }
+                rt48 += e[0] * c48[0] + e[1] * c48[1] + e[2] * c48[2] + e[3] * c48[3];
+                pa = pn;
+                qa = qn;
+                // issue pattern for this tile: (1 MFMA, 5 VALU) x 7 for the D-chain + exp, then
+                // (1 MFMA, 1 VALU/DS) x 12 for the E-chain and the next tile's operand reads
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                }
+            }
+            float d256 = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) d256 += mcB[ks] * lds[D256_OFF + 4 * ks + g];
+            d256 += __shfl_xor(d256, 16, 64);
+            d256 += __shfl_xor(d256, 32, 64);
+            const float e256 = exp_nobranch(logx256 - 2.f * d256);
+#pragma unroll
+            for (int it = 0; it < 3; ++it)
+                accB[it] = mfma4(g == 0 ? lds[E256_OFF + it * 16 + n] : 0.f, g == 0 ? e256 : 0.f, accB[it]);
+            rt48 += __shfl_xor(rt48, 16, 64);
+            rt48 += __shfl_xor(rt48, 32, 64);
+            rt48 += e256 * lds[E256_OFF + 48];
+
+            // ------------- rt and its reflection into this frame's LDS windows -------------
+            DSA_STAMP(1);
+#pragma unroll
+            for (int it = 0; it < 3; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = it * 16 + 4 * g + r;
+                    const float v = accB[it][r];
+                    rt_lds[idx] = v;
+                    if (idx <= 27) {  // rr[27 + d] = r[|d|]
+                        rr_lds[27 + idx] = v;
+                        rr_lds[27 - idx] = v;
+                    }
+                }
+            if (g == 0) rt_lds[48] = rt48;
+            __builtin_amdgcn_wave_barrier();
+            DSA_STAMP(2);
+
+            // ------------- local rows of R + Q, symmetric elimination, back substitution -------------
+            SymRows a;
+            float b[NR];
+            sym_build_rows<0>(a, b, rt_q + gs, rr_q + 27 + gs, lds + AV_OFF, gs);
+            __builtin_amdgcn_wave_barrier();
+            DSA_STAMP(3);
+            sym_elim_all(a, b, nq, gq, std::make_integer_sequence<int, M1>{});
+            DSA_STAMP(4);
+            float xq[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // xq[ks] = x[4 ks + gs] of frame nq
+            sym_backsub_all(a, b, xq, nq, gq, std::make_integer_sequence<int, M1>{});
+            // back to the MFMA layout through the (now free) rt window: mc += x  (mcep.py:222)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) rt_q[4 * ks + gs] = xq[ks];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) mcB[ks] += rt_lds[4 * ks + g];
+            __builtin_amdgcn_wave_barrier();
+            DSA_STAMP(5);
+            if (hist && f_ok)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    if (4 * ks + g < M1) hist[((long)(iter + 1) * F + f) * M1 + 4 * ks + g] = mcB[ks];
+        }
+        if (f_ok)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                if (4 * ks + g < M1) mc_out[f * M1 + 4 * ks + g] = mcB[ks];
+    }
+}
+
 int mcep_mfma_supported(int nfft, int M, int dtype) { return dtype == DSA_F32 && nfft == 512 && M == 24; }
+
+// =====================================================================================
+// v3: role-split workgroup.  Waves 0-3 ("matrix" role) keep log X of TWO 16-frame groups in
+// registers and run only the MFMA chains + exp; waves 4-7 ("solver" role) own mc and run only
+// the build / elimination / back-substitution.  Wave w and wave w+4 sit on the same SIMD, whose
+// matrix pipe and VALU are then busy at the same time: while the matrix wave forms rt for group A
+// the solver wave eliminates group B, and they swap every phase (one workgroup barrier per
+// phase).  Neither role needs more than 256 registers, so nothing spills.
+//   phase p: matrix wave -> group p & 1, Newton step p >> 1;  solver wave -> group (p-1) & 1, step (p-1) >> 1
+// Hand-off through LDS: rt windows (matrix -> solver), mc in the same window (solver -> matrix);
+// mc0 travels through the mc_out buffer in global memory.
+// =====================================================================================
+namespace mm3 {
+using namespace mm;
+constexpr int GROUP_FLOATS = 2 * 16 * RS;                 // rt + rr windows of one 16-frame group
+constexpr int PAIR_FLOATS = 2 * GROUP_FLOATS;             // two groups per matrix/solver pair
+constexpr int LDS_FLOATS = WAVE_OFF + 4 * PAIR_FLOATS;    // operand images + 4 pairs
+}  // namespace mm3
+
+__global__ __launch_bounds__(512, 2) void mcep_mfma_fwd_kernel_v3(
+    const float* __restrict__ X, long F, int n_iter, const float* __restrict__ G,
+    const float* __restrict__ D, const float* __restrict__ E, const float* __restrict__ av,
+    float* __restrict__ mc_out, float* __restrict__ hist, long nbt)
+{
+    using namespace mm3;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int pair = wave & 3;
+    const bool matrix_role = wave < 4;
+
+    // ---------------- operand images: built once per workgroup ----------------
+    for (int idx = tid; idx < 16 * 2 * 64 * 4; idx += 512) {
+        int q = idx & 3, l = (idx >> 2) & 63, half = (idx >> 8) & 1, mt = idx >> 9;
+        int k = 4 * (half * 4 + q) + (l >> 4);
+        lds[DT_OFF + idx] = k < M1 ? D[k * K + mt * 16 + (l & 15)] : 0.f;
+    }
+    for (int idx = tid; idx < 3 * 16 * 64 * 4; idx += 512) {
+        int r = idx & 3, l = (idx >> 2) & 63, mt = (idx >> 8) & 15, it = idx >> 12;
+        lds[ET_OFF + idx] = E[(mt * 16 + (l >> 4) * 4 + r) * M2 + it * 16 + (l & 15)];
+    }
+    if (tid < 256) {
+        int r = tid & 3, gg = (tid >> 2) & 3, mt = tid >> 4;
+        lds[E48_OFF + tid] = E[(mt * 16 + gg * 4 + r) * M2 + 48];
+    }
+    if (tid < M2) lds[E256_OFF + tid] = E[H * M2 + tid];
+    if (tid < 28) {
+        lds[D256_OFF + tid] = tid < M1 ? D[tid * K + H] : 0.f;
+        lds[AV_OFF + tid] = tid < M1 ? av[tid] : 0.f;
+    }
+    __syncthreads();
+
+    float* pair_lds = lds + WAVE_OFF + pair * PAIR_FLOATS;
+    const int nphase = 2 * n_iter + 1;
+
+    if (matrix_role) {
+        // =============================== matrix role ===============================
+        const int n = lane & 15, g = lane >> 4;
+        const f32x4* Dt4 = reinterpret_cast<const f32x4*>(lds + DT_OFF);
+        const f32x4* Et4 = reinterpret_cast<const f32x4*>(lds + ET_OFF);
+        const f32x4* E484 = reinterpret_cast<const f32x4*>(lds + E48_OFF);
+        const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)G, 0, K * M1 * 4, 0x00020000);
+
+        // one phase of one group: (step 0: load log X, mc0 = G^T log X) ; rt = E^T exp(log X - 2 D^T mc)
+        auto phase = [&](f32x4(&logx)[16], float& logx256, int grp, int step, long f0) __attribute__((always_inline)) {
+            float* rt_w = pair_lds + grp * GROUP_FLOATS + n * RS;  // this lane's frame windows
+            float* rr_w = rt_w + 16 * RS;
+            const long f_raw = f0 + n;
+            const bool f_ok = f_raw < F;
+            const long f = f_ok ? f_raw : F - 1;
+            float mcB[KS];
+            if (step == 0) {
+                const float* xf = X + f * K;
+#pragma unroll
+                for (int mt = 0; mt < 16; ++mt) {
+                    const float* p = xf + mt * 16 + 4 * g;
+                    logx[mt] = f32x4{logf(p[0]), logf(p[1]), logf(p[2]), logf(p[3])};  // mcep.py:203
+                }
+                logx256 = logf(xf[H]);
+                f32x4 accG[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+                // G operands by buffer loads: one VGPR offset per output tile, the (mt, r) part of
+                // the address is a scalar immediate -- keeps the address arithmetic out of VGPRs
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {  // mc0^T = G^T logx^T  (mcep.py:204-207)
+                    const int out = it * 16 + n;
+                    const bool ov = out < M1;
+                    const int voff = ((4 * g) * M1 + (ov ? out : 0)) * 4;
+#pragma unroll
+                    for (int mt = 0; mt < 16; ++mt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float gv = __builtin_bit_cast(
+                                float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, voff, (mt * 16 + r) * M1 * 4, 0));
+                            accG[it] = mfma4(ov ? gv : 0.f, logx[mt][r], accG[it]);
+                        }
+                    }
+                    const float g256 = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, (ov ? out : 0) * 4, H * M1 * 4, 0));
+                    accG[it] = mfma4((ov && g == 0) ? g256 : 0.f, g == 0 ? logx256 : 0.f, accG[it]);
+                }
+                // accG[it][r] = mc0[it*16 + 4g + r]: to the solver through mc_out (and hist[0]),
+                // to this wave's B-operand layout through the (free) rt window
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = it * 16 + 4 * g + r;
+                        rt_w[c] = accG[it][r];
+                        if (f_ok && c < M1) {
+                            mc_out[f * M1 + c] = accG[it][r];
+                            if (hist) hist[f * M1 + c] = accG[it][r];
+                        }
+                    }
+                __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) mcB[ks] = (4 * ks + g < M1) ? rt_w[4 * ks + g] : 0.f;
+            __builtin_amdgcn_wave_barrier();
+
+            f32x4 accB[3] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+            float rt48 = 0.f;
+            auto d_chain = [&](int mt) __attribute__((always_inline)) -> f32x4 {  // d^T = D^T mc^T, two accumulators (mcep.py:210-211)
+                const f32x4 a0 = Dt4[(mt * 2 + 0) * 64 + lane];
+                const f32x4 a1 = Dt4[(mt * 2 + 1) * 64 + lane];
+                f32x4 pa = {0, 0, 0, 0}, qa = {0, 0, 0, 0};
+                pa = mfma4(a0[0], mcB[0], pa);
+                qa = mfma4(a1[0], mcB[4], qa);
+                pa = mfma4(a0[1], mcB[1], pa);
+                qa = mfma4(a1[1], mcB[5], qa);
+                pa = mfma4(a0[2], mcB[2], pa);
+                qa = mfma4(a1[2], mcB[6], qa);
+                pa = mfma4(a0[3], mcB[3], pa);
+                return pa + qa;
+            };
+            f32x4 acc = d_chain(0);
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) {
+                f32x4 acc_next = acc;
+                if (mt + 1 < 16) acc_next = d_chain(mt + 1);
+                f32x4 e;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e[r] = exp_nobranch(logx[mt][r] - 2.f * acc[r]);  // mcep.py:212
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {  // rt^T += E^T e^T  (mcep.py:214-215)
+                    const f32x4 a = Et4[(it * 16 + mt) * 64 + lane];
+                    accB[it] = mfma4(a[0], e[0], accB[it]);
+                    accB[it] = mfma4(a[1], e[1], accB[it]);
+                    accB[it] = mfma4(a[2], e[2], accB[it]);
+                    accB[it] = mfma4(a[3], e[3], accB[it]);
+                }
+                const f32x4 c48 = E484[mt * 4 + g];
+                rt48 += e[0] * c48[0] + e[1] * c48[1] + e[2] * c48[2] + e[3] * c48[3];
+                acc = acc_next;
+            }
+            float d256 = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) d256 += mcB[ks] * lds[D256_OFF + 4 * ks + g];
+            d256 += __shfl_xor(d256, 16, 64);
+            d256 += __shfl_xor(d256, 32, 64);
+            const float e256 = exp_nobranch(logx256 - 2.f * d256);
+#pragma unroll
+            for (int it = 0; it < 3; ++it)
+                accB[it] = mfma4(g == 0 ? lds[E256_OFF + it * 16 + n] : 0.f, g == 0 ? e256 : 0.f, accB[it]);
+            rt48 += __shfl_xor(rt48, 16, 64);
+            rt48 += __shfl_xor(rt48, 32, 64);
+            rt48 += e256 * lds[E256_OFF + 48];
+#pragma unroll
+            for (int it = 0; it < 3; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = it * 16 + 4 * g + r;
+                    const float v = accB[it][r];
+                    rt_w[idx] = v;
+                    if (idx <= 27) {  // rr[27 + d] = r[|d|]
+                        rr_w[27 + idx] = v;
+                        rr_w[27 - idx] = v;
+                    }
+                }
+            if (g == 0) rt_w[48] = rt48;
+        };
+
+        f32x4 logxA[16], logxB[16];
+        float l256A = 0.f, l256B = 0.f;
+        for (long bt = blockIdx.x; bt < nbt; bt += gridDim.x) {
+            const long fbase = bt * 128 + pair * 32;
+            for (int p = 0; p < nphase; ++p) {
+                if (p < 2 * n_iter) {
+                    if ((p & 1) == 0) phase(logxA, l256A, 0, p >> 1, fbase);
+                    else phase(logxB, l256B, 1, p >> 1, fbase + 16);
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        // =============================== solver role ===============================
+        const int nq = lane >> 2, gs = lane & 3;  // the 4 lanes of a quad share a frame
+        const GroupMask gq = make_group_mask(gs);
+        float mcqA[KS], mcqB[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) mcqA[ks] = mcqB[ks] = 0.f;
+
+        auto solve = [&](float(&mcq)[KS], int grp, int step, long f0) __attribute__((always_inline)) {
+            float* rt_q = pair_lds + grp * GROUP_FLOATS + nq * RS;
+            float* rr_q = rt_q + 16 * RS;
+            const long f = f0 + nq;
+            const bool f_ok = f < F;
+            if (step == 0) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    mcq[ks] = (f_ok && 4 * ks + gs < M1) ? mc_out[f * M1 + 4 * ks + gs] : 0.f;
+            }
+            SymRows a;
+            float b[NR];
+            sym_build_rows<0>(a, b, rt_q + gs, rr_q + 27 + gs, lds + AV_OFF, gs);
+            __builtin_amdgcn_wave_barrier();
+            sym_elim_all(a, b, nq, gq, std::make_integer_sequence<int, M1>{});
+            float xq[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            sym_backsub_all(a, b, xq, nq, gq, std::make_integer_sequence<int, M1>{});
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                mcq[ks] += xq[ks];  // mcep.py:222
+                rt_q[4 * ks + gs] = mcq[ks];  // next step's B operand for the matrix wave
+                if (f_ok && 4 * ks + gs < M1) {
+                    if (hist) hist[((long)(step + 1) * F + f) * M1 + 4 * ks + gs] = mcq[ks];
+                    if (step == n_iter - 1) mc_out[f * M1 + 4 * ks + gs] = mcq[ks];
+                }
+            }
+        };
+
+        for (long bt = blockIdx.x; bt < nbt; bt += gridDim.x) {
+            const long fbase = bt * 128 + pair * 32;
+            for (int p = 0; p < nphase; ++p) {
+                if (p >= 1) {
+                    const int q = p - 1;
+                    if ((q & 1) == 0) solve(mcqA, 0, q >> 1, fbase);
+                    else solve(mcqB, 1, q >> 1, fbase + 16);
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+static int launch_v3(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E,
+                     const void* av, void* mc, void* hist, hipStream_t st)
+{
+    const int lds_bytes = mm3::LDS_FLOATS * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)mcep_mfma_fwd_kernel_v3, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_bytes) != hipSuccess)
+            return fail(DSA_ERR_LAUNCH, "mcep_mfma: cannot reserve the LDS operand images%s");
+        attr_set = true;
+    }
+    long nbt = (long)((F + 127) / 128);
+    long grid = nbt < 256 ? nbt : 256;  // one persistent workgroup per CU
+    hipLaunchKernelGGL(mcep_mfma_fwd_kernel_v3, dim3((unsigned)grid), dim3(512), lds_bytes, st, (const float*)X,
+                       (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E, (const float*)av,
+                       (float*)mc, (float*)hist, nbt);
+    return check_launch("mcep_mfma_fwd_split");
+}
+
+template <int WAVES>
+static int launch_v2(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E,
+                     const void* av, void* mc, void* hist, hipStream_t st, const char* name)
+{
+    const int lds_bytes = mm2::lds_floats(WAVES) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)mcep_mfma_fwd_kernel_v2<WAVES>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return fail(DSA_ERR_LAUNCH, "mcep_mfma: cannot reserve the LDS operand images%s");
+        attr_set = true;
+    }
+    long ntiles16 = (long)((F + 15) / 16);
+    long blocks = (ntiles16 + WAVES - 1) / WAVES;
+    long grid = blocks < 256 ? blocks : 256;  // one persistent workgroup per CU
+    hipLaunchKernelGGL((mcep_mfma_fwd_kernel_v2<WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
+                       (const float*)X, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
+                       (const float*)av, (float*)mc, (float*)hist, ntiles16);
+    return check_launch(name);
+}
 
 int mcep_mfma_fwd(const void* X, int64_t F, int nfft, int M, int n_iter, const void* G, const void* D,
                   const void* E, const void* av, void* mc, void* hist, hipStream_t st)
 {
     (void)nfft;
     (void)M;
-    const int lds_bytes = mm::LDS_FLOATS * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)mcep_mfma_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds_bytes) != hipSuccess)
-            return fail(DSA_ERR_LAUNCH, "mcep_mfma: cannot reserve %s of LDS", "117 KB");
-        attr_set = true;
+    // DSA_MCEP_VARIANT (A/B knob): 8 = two waves per SIMD (default, fastest measured), 4 = one wave
+    // per SIMD, 3 = role-split matrix/solver waves, 1 = first kernel (full elimination, ds_bpermute)
+    static const int variant = [] {
+        const char* e = getenv("DSA_MCEP_VARIANT");
+        return e ? atoi(e) : 8;
+    }();
+    if (variant == 1) {
+        const int lds_bytes = mm::LDS_FLOATS * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)mcep_mfma_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    lds_bytes) != hipSuccess)
+                return fail(DSA_ERR_LAUNCH, "mcep_mfma: cannot reserve %s of LDS", "117 KB");
+            attr_set = true;
+        }
+        long ntiles = (long)((F + 63) / 64);
+        long grid = ntiles < 256 ? ntiles : 256;
+        hipLaunchKernelGGL(mcep_mfma_fwd_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, st, (const float*)X,
+                           (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E, (const float*)av,
+                           (float*)mc, (float*)hist, ntiles);
+        return check_launch("mcep_mfma_fwd_v1");
     }
-    long ntiles = (long)((F + 63) / 64);
-    long grid = ntiles < 256 ? ntiles : 256;  // one persistent workgroup per CU
-    hipLaunchKernelGGL(mcep_mfma_fwd_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, st, (const float*)X,
-                       (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E, (const float*)av,
-                       (float*)mc, (float*)hist, ntiles);
-    return check_launch("mcep_mfma_fwd");
+    if (variant == 4) return launch_v2<4>(X, F, n_iter, G, D, E, av, mc, hist, st, "mcep_mfma_fwd_w4");
+    if (variant == 3 && n_iter >= 1) return launch_v3(X, F, n_iter, G, D, E, av, mc, hist, st);
+    return launch_v2<8>(X, F, n_iter, G, D, E, av, mc, hist, st, "mcep_mfma_fwd");
 }
 
 }  // namespace dsa

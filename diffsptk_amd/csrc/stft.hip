@@ -486,44 +486,33 @@ __device__ __forceinline__ void fft16(cf (&v)[16])
 
 constexpr int kFPW = 4;         // frames per wave (16 lanes each)
 constexpr int kZStride = 272;   // complex elements per frame region: 16 x 17 (padded transpose)
-
-// real-FFT split of the 256-point complex spectrum z (natural order, LDS) at bin k:
-// X[k] = E - i W O,  E = (a + conj(b))/2, O = (a - conj(b))/2, a = Z[k], b = Z[256-k],
-// W = exp(-2 pi i k / 512) = tw[k] = (cos, -sin).
-__device__ __forceinline__ cf rfft_split(const cf* __restrict__ z, const cf* __restrict__ tw, int k)
-{
-    cf a = z[k & 255], bq = z[(256 - k) & 255];
-    cf e = {0.5f * (a.re + bq.re), 0.5f * (a.im - bq.im)};
-    cf o = {0.5f * (a.re - bq.re), 0.5f * (a.im + bq.im)};
-    cf t = tw[k];
-    return cf{e.re + (t.re * o.im + t.im * o.re), e.im - (t.re * o.re - t.im * o.im)};
-}
+constexpr int kTile = kFPW * 257;  // floats in one output tile (4 rows)
 
 // ShortTimeFourierTransform._forward stft.py:237-241 for nfft = 512, float32.
 // One wave64 per workgroup, autonomous (no inter-wave barriers): it owns kFPW = 4 consecutive
 // frames of one utterance per pass -- the 3P + L samples they share are read from HBM once into
 // LDS -- and writes their 4 x 257 output rows as one contiguous, 16-byte aligned run of float4.
-// dynamic LDS layout: in_buf[in_floats] floats | zbuf[kFPW][272] cf | tw[257] cf | fmax[kFPW]
-// ABL: 0 production | 1 no output stores | 2 no FFT butterflies | 3 no input staging (tools/bench_stft.cpp)
-template <int ABL>
+// dynamic LDS layout: io_buf[io_floats] (input stretch, later the staged output tile) |
+//                     zbuf[kFPW][272] cf | fmax[kFPW]
+// ABL: 0 production | 1 no output stores | 2 no FFT butterflies | 3 no input staging
+//      (ablation knob for tools/bench_stft.cpp)
+template <int ABL, bool ZMEAN>
 __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
-    const float* __restrict__ x, long Tlen, long N, int L, int P, int left, int mode, int zmean,
+    const float* __restrict__ x, long Tlen, long N, int L, int P, int left, int mode,
     const float* __restrict__ w, const float* __restrict__ twiddle, float eps, int use_floor,
     float floor_lin, int fmt, float* __restrict__ y, long total_chunks, int chunks_per_utt,
-    int in_floats)
+    int io_floats)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* in_buf = reinterpret_cast<float*>(smem_raw);
-    cf* zbuf = reinterpret_cast<cf*>(in_buf + in_floats);
-    cf* tw = zbuf + kFPW * kZStride;
-    float* fmax = reinterpret_cast<float*>(tw + 257);
+    float* io_buf = reinterpret_cast<float*>(smem_raw);
+    cf* zbuf = reinterpret_cast<cf*>(io_buf + io_floats);
+    float* fmax = reinterpret_cast<float*>(zbuf + kFPW * kZStride);
 
     const int lane = threadIdx.x;
     const int j = lane & 15;   // lane within the frame group
     const int fl = lane >> 4;  // frame slot within the pass (0..3)
 
-    // per-wave constants: post-processing twiddles, per-lane window and W256^(j*k1)
-    for (int k = lane; k < 257; k += 64) tw[k] = cf{twiddle[2 * k], twiddle[2 * k + 1]};
+    // per-wave constants: per-lane window, W256^(j*k1), and the split twiddles of this lane's bins
     float wreg[32];
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
@@ -536,6 +525,8 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
         int m = 2 * j * k1;  // W256^(j k1) = W512^(2 j k1)
         t256[k1] = cf{twiddle[2 * m], twiddle[2 * m + 1]};
     }
+    const cf twA = cf{twiddle[2 * lane], twiddle[2 * lane + 1]};                // W512^lane
+    const cf twB = cf{twiddle[2 * (lane + 64)], twiddle[2 * (lane + 64) + 1]};  // W512^(lane+64)
     const float inv_L = 1.f / (float)L;
     const int K = 257;
     const bool complex_out = fmt == DSA_SPEC_COMPLEX;
@@ -546,7 +537,7 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
         const long frame0 = (c - b * chunks_per_utt) * kFPW;
         const int nvalid = (int)((N - frame0) < kFPW ? (N - frame0) : kFPW);
         const float* xb = x + b * Tlen;
-        __syncthreads();  // previous pass is done with in_buf / zbuf (single-wave workgroup)
+        __syncthreads();  // previous pass is done with io_buf / zbuf (single-wave workgroup)
         // ---- stage the shared waveform stretch (each sample read from HBM once) ----
         if (ABL != 3) {
             const long g0 = frame0 * P - left;
@@ -554,41 +545,50 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
             const bool interior = g0 >= 0 && g0 + need <= Tlen;
             if (interior && (((size_t)(xb + g0)) & 15) == 0) {
                 const float4* src4 = reinterpret_cast<const float4*>(xb + g0);
-                float4* dst4 = reinterpret_cast<float4*>(in_buf);
+                float4* dst4 = reinterpret_cast<float4*>(io_buf);
                 const int n4 = need >> 2;
                 for (int s = lane; s < n4; s += 64) dst4[s] = src4[s];
-                for (int s = (n4 << 2) + lane; s < need; s += 64) in_buf[s] = xb[g0 + s];
+                for (int s = (n4 << 2) + lane; s < need; s += 64) io_buf[s] = xb[g0 + s];
             } else {
-                for (int s = lane; s < need; s += 64) in_buf[s] = load_padded(xb, g0 + s, Tlen, mode);
+                for (int s = lane; s < need; s += 64) io_buf[s] = load_padded(xb, g0 + s, Tlen, mode);
             }
         }
         __syncthreads();
         // ---- per frame: window, 256-point complex FFT (16 lanes x 16 points) ----
         cf v[16];
         {
-            const float* src = in_buf + fl * P + 2 * j;
+            const float* src = io_buf + fl * P + 2 * j;
+            const int lim = L - 2 * j;  // element (m1, c) belongs to the frame iff 32 m1 + c < lim
             float sum = 0.f;
 #pragma unroll
             for (int m1 = 0; m1 < 16; ++m1) {
-                int l = 2 * j + 32 * m1;
-                float a0 = src[32 * m1], a1 = src[32 * m1 + 1];
-                a0 = l < L ? a0 : 0.f;       // samples past the frame are never used (also keeps
-                a1 = l + 1 < L ? a1 : 0.f;   // non-finite neighbours out of frames not containing them)
+                // samples past the frame are never touched: zero padding is exact and non-finite
+                // neighbours stay out of frames that do not contain them
+                float a0 = 0.f, a1 = 0.f;
+                if (32 * m1 + 32 <= L) {  // wave-uniform: whole group inside the frame
+                    a0 = src[32 * m1];
+                    a1 = src[32 * m1 + 1];
+                } else if (32 * m1 < L) {  // the one group straddling the frame end
+                    a0 = 32 * m1 < lim ? src[32 * m1] : 0.f;
+                    a1 = 32 * m1 + 1 < lim ? src[32 * m1 + 1] : 0.f;
+                }
                 v[m1] = cf{a0, a1};
-                sum += a0 + a1;
+                if (ZMEAN) sum += a0 + a1;
             }
             float mean = 0.f;
-            if (zmean) {  // frame.py:139-140: mean over the L samples of the frame
+            if (ZMEAN) {  // frame.py:139-140: mean over the L samples of the frame
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
                 mean = sum * inv_L;
             }
 #pragma unroll
             for (int m1 = 0; m1 < 16; ++m1) {
-                int l = 2 * j + 32 * m1;
-                float a0 = l < L ? v[m1].re - mean : 0.f;
-                float a1 = l + 1 < L ? v[m1].im - mean : 0.f;
-                v[m1] = cf{a0 * wreg[2 * m1], a1 * wreg[2 * m1 + 1]};  // window.py:190
+                float a0 = v[m1].re, a1 = v[m1].im;
+                if (ZMEAN) {
+                    a0 = 32 * m1 < lim ? a0 - mean : 0.f;
+                    a1 = 32 * m1 + 1 < lim ? a1 - mean : 0.f;
+                }
+                v[m1] = cf{a0 * wreg[2 * m1], a1 * wreg[2 * m1 + 1]};  // window.py:190 (wreg = 0 past L)
             }
         }
         if (ABL != 2) fft16<false>(v);
@@ -603,68 +603,94 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
 #pragma unroll
         for (int k0 = 0; k0 < 16; ++k0) zf[j + 16 * k0] = v[FFT16_OUT(k0)];  // Z[k1 + 16 k0], natural order
         __syncthreads();
-        // ---- optional relative floor: per-frame maximum of |X|^2 + eps (spec.py:174-176) ----
-        if (use_floor && !complex_out) {
-            float m = 0.f;
-            for (int k = j; k < K; k += 16) {
-                cf X = rfft_split(zf, tw, k);
-                float s = X.re * X.re + X.im * X.im + eps;
-                m = s > m ? s : m;
-            }
+        // ---- real-FFT split, two bins (k, 256-k) per lane from one pair (Z[k], Z[256-k]) ----
+        //   S = a + conj(b), Dd = a - conj(b), Pp = W Dd:
+        //   2 X[k] = (S.re + Pp.im, S.im - Pp.re),  2 X[256-k] = (S.re - Pp.im, -S.im - Pp.re)
+        const long row0 = b * N + frame0;
+        const long out0 = row0 * K;
+        float* stage = io_buf;  // the input stretch is dead: reuse it for the 4 x 257 tile
+        float2* y2 = reinterpret_cast<float2*>(y);
+        float fm[kFPW] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
-                float u = __shfl_xor(m, o, 16);
-                m = u > m ? u : m;
-            }
-            if (j == 0) fmax[fl] = m;
-            __syncthreads();
-        }
-        // ---- real-FFT split + formatter fused into the coalesced write of the output tile ----
-        {
-            const long row0 = b * N + frame0;
-            const long out0 = row0 * K;
-            if (complex_out) {
-                const int total = nvalid * K;
-                for (int idx = lane; idx < total; idx += 64) {
-                    int f = idx >= 3 * K ? 3 : (idx >= 2 * K ? 2 : (idx >= K ? 1 : 0));
-                    cf X = rfft_split(zbuf + f * kZStride, tw, idx - f * K);
-                    reinterpret_cast<float2*>(y)[out0 + idx] = make_float2(X.re, X.im);
+        for (int f = 0; f < kFPW; ++f) {
+            const cf* z = zbuf + f * kZStride;
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                // part 0: k = lane (0..63); part 1: k = lane + 64; part 2: k = 128 (lane 0 only)
+                const int k = part == 0 ? lane : (part == 1 ? lane + 64 : 128);
+                if (part == 2 && lane != 0) continue;
+                const cf W = part == 0 ? twA : (part == 1 ? twB : cf{0.f, -1.f});
+                const cf a = z[k], bq = z[(256 - k) & 255];
+                const cf S = {a.re + bq.re, a.im - bq.im};
+                const cf Dd = {a.re - bq.re, a.im + bq.im};
+                const cf Pp = cmul(W, Dd);
+                const cf X1 = {0.5f * (S.re + Pp.im), 0.5f * (S.im - Pp.re)};
+                const cf X2 = {0.5f * (S.re - Pp.im), 0.5f * (-S.im - Pp.re)};
+                if (complex_out) {
+                    if (f < nvalid && ABL != 1) {
+                        y2[out0 + f * K + k] = make_float2(X1.re, X1.im);
+                        if (part != 2) y2[out0 + f * K + 256 - k] = make_float2(X2.re, X2.im);
+                    }
+                } else {
+                    const float s1 = X1.re * X1.re + X1.im * X1.im + eps;  // spec.py:173
+                    const float s2 = X2.re * X2.re + X2.im * X2.im + eps;
+                    stage[f * K + k] = s1;
+                    if (part != 2) stage[f * K + 256 - k] = s2;
+                    if (use_floor) {
+                        const float mx = s1 > s2 ? s1 : s2;
+                        fm[f] = mx > fm[f] ? mx : fm[f];
+                    }
                 }
-            } else if (nvalid == kFPW && (row0 & 3) == 0) {
-                // 4 rows x 257 floats = 257 float4, 16-byte aligned because row0 % 4 == 0
-                float4* y4 = reinterpret_cast<float4*>(y + out0);
-#pragma unroll 1
-                for (int jj = 0; jj < 5; ++jj) {
-                    const int t = lane + 64 * jj;
-                    if (t < K) {
-                        float o4[4];
+            }
+        }
+        if (complex_out) continue;
+        if (use_floor) {  // per-frame maximum for the relative floor (spec.py:174-176)
+#pragma unroll
+            for (int f = 0; f < kFPW; ++f) {
+                float m = wave_max(fm[f]);
+                if (lane == 0) fmax[f] = m;
+            }
+        }
+        __syncthreads();
+        // ---- formatter + coalesced write of the staged tile ----
+        const bool plain = !use_floor && fmt == DSA_SPEC_POWER;
+        if (nvalid == kFPW && (row0 & 3) == 0) {
+            // 4 rows x 257 floats = 257 float4, 16-byte aligned because row0 % 4 == 0
+            float4* y4 = reinterpret_cast<float4*>(y + out0);
+            const float4* s4 = reinterpret_cast<const float4*>(stage);
+#pragma unroll
+            for (int jj = 0; jj < 5; ++jj) {
+                const int t = lane + 64 * jj;
+                if (t < K) {
+                    float4 q = s4[t];
+                    if (!plain) {
+                        float o4[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                         for (int cc = 0; cc < 4; ++cc) {
                             const int idx = 4 * t + cc;
-                            const int f = idx >= 3 * K ? 3 : (idx >= 2 * K ? 2 : (idx >= K ? 1 : 0));
-                            cf X = rfft_split(zbuf + f * kZStride, tw, idx - f * K);
-                            float s = X.re * X.re + X.im * X.im + eps;  // spec.py:173
+                            float sv = o4[cc];
                             if (use_floor) {
-                                float flv = fmax[f] * floor_lin;
-                                s = s > flv ? s : flv;
+                                const int f = idx >= 3 * K ? 3 : (idx >= 2 * K ? 2 : (idx >= K ? 1 : 0));
+                                const float flv = fmax[f] * floor_lin;
+                                sv = sv > flv ? sv : flv;
                             }
-                            o4[cc] = spec_format(s, fmt);
+                            o4[cc] = spec_format(sv, fmt);
                         }
-                        if (ABL != 1 || o4[0] == 123.456f) y4[t] = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                        q = make_float4(o4[0], o4[1], o4[2], o4[3]);
                     }
+                    if (ABL != 1 || q.x == 123.456f) y4[t] = q;
                 }
-            } else {
-                const int total = nvalid * K;
-                for (int idx = lane; idx < total; idx += 64) {
-                    int f = idx >= 3 * K ? 3 : (idx >= 2 * K ? 2 : (idx >= K ? 1 : 0));
-                    cf X = rfft_split(zbuf + f * kZStride, tw, idx - f * K);
-                    float s = X.re * X.re + X.im * X.im + eps;
-                    if (use_floor) {
-                        float flv = fmax[f] * floor_lin;
-                        s = s > flv ? s : flv;
-                    }
-                    y[out0 + idx] = spec_format(s, fmt);
+            }
+        } else {
+            const int total = nvalid * K;
+            for (int idx = lane; idx < total; idx += 64) {
+                float sv = stage[idx];
+                if (use_floor) {
+                    const int f = idx >= 3 * K ? 3 : (idx >= 2 * K ? 2 : (idx >= K ? 1 : 0));
+                    const float flv = fmax[f] * floor_lin;
+                    sv = sv > flv ? sv : flv;
                 }
+                y[out0 + idx] = spec_format(sv, fmt);
             }
         }
     }
@@ -689,11 +715,25 @@ static int launch_row_dft(const void* x, int64_t B, int64_t Tlen, int64_t N, int
     return check_launch("row_dft_generic");
 }
 
-static int stft512_lds_bytes(int L, int P, int* in_floats)
+static int stft512_lds_bytes(int L, int P, int* io_floats)
 {
     int span = (kFPW - 1) * P + L;
-    *in_floats = (span + 3) & ~3;
-    return *in_floats * 4 + kFPW * kZStride * 8 + 257 * 8 + 16;
+    if (span < kTile) span = kTile;  // the region doubles as the staged output tile
+    *io_floats = (span + 3) & ~3;
+    return *io_floats * 4 + kFPW * kZStride * 8 + 16;
+}
+
+template <int ABL>
+static void stft512_launch(bool zmean, dim3 grid, int lds, hipStream_t st, const float* x, long T, long N, int L,
+                           int P, int left, int mode, const float* w, const float* tw, float eps, int use_floor,
+                           float floor_lin, int fmt, float* y, long total_chunks, int chunks_per_utt, int io_floats)
+{
+    if (zmean)
+        hipLaunchKernelGGL((stft512_fwd_kernel<ABL, true>), grid, dim3(64), lds, st, x, T, N, L, P, left, mode, w, tw,
+                           eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
+    else
+        hipLaunchKernelGGL((stft512_fwd_kernel<ABL, false>), grid, dim3(64), lds, st, x, T, N, L, P, left, mode, w, tw,
+                           eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
 }
 
 }  // namespace dsa
@@ -914,10 +954,9 @@ DSA_EXPORT int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int3
         long grid = 256L * waves_per_cu;  // persistent single-wave workgroups
         if (grid > total_chunks) grid = total_chunks;
         float floor_lin = use_floor ? (float)pow(10.0, relative_floor_db / 10.0) : 0.f;
-        hipLaunchKernelGGL(stft512_fwd_kernel<0>, dim3((unsigned)grid), dim3(64), lds, st, (const float*)x,
-                           (long)T, (long)N, L, P, left, pad_mode, zmean, (const float*)w,
-                           (const float*)twiddle, (float)eps, use_floor, floor_lin, out_format, (float*)y,
-                           total_chunks, chunks_per_utt, in_floats);
+        stft512_launch<0>(zmean != 0, dim3((unsigned)grid), lds, st, (const float*)x, (long)T, (long)N, L, P, left,
+                          pad_mode, (const float*)w, (const float*)twiddle, (float)eps, use_floor, floor_lin,
+                          out_format, (float*)y, total_chunks, chunks_per_utt, in_floats);
         return check_launch("stft512_fwd");
     }
     if (dtype == DSA_F32)

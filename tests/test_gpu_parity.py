@@ -394,7 +394,7 @@ def test_mcep_tuned_vs_generic_and_history(golden):
     for name, algo in (("generic", _lib.ALGO_GENERIC), ("tuned", _lib.ALGO_TUNED)):
         Xg = X.clone().requires_grad_(True)  # requires_grad => the Newton history is recorded
         mc = ops.McepFn.apply(Xg, m.G, m.D, m.E, m.alpha_vector, 512, 24, 10, algo)
-        assert _lib.last_kernel() == ("mcep_mfma_fwd" if name == "tuned" else "mcep_generic_fwd")
+        assert _lib.last_kernel().startswith("mcep_mfma_fwd" if name == "tuned" else "mcep_generic_fwd")
         (mc * torch.linspace(-1, 1, 25, device=DEV)).sum().backward()
         outs[name] = (host(mc), host(Xg.grad))
     close(outs["tuned"][0], g["mcep_f64"], 1e-4, 2e-5)

@@ -22,12 +22,12 @@ static float run(const float* x, long B, long T, const float* w, const float* tw
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i)
-        hipLaunchKernelGGL(dsa::stft512_fwd_kernel<ABL>, dim3((unsigned)grid), dim3(64), lds, 0, x, T, N, L, P, 200, 0, 0, w,
-                           tw, 1e-9f, 0, 0.f, 3, y, total_chunks, chunks_per_utt, in_floats);
+        dsa::stft512_launch<ABL>(false, dim3((unsigned)grid), lds, 0, x, T, N, L, P, 200, 0, w, tw, 1e-9f, 0, 0.f, 3, y,
+                                 total_chunks, chunks_per_utt, in_floats);
     hipEventRecord(e0);
     for (int i = 0; i < iters; ++i)
-        hipLaunchKernelGGL(dsa::stft512_fwd_kernel<ABL>, dim3((unsigned)grid), dim3(64), lds, 0, x, T, N, L, P, 200, 0, 0, w,
-                           tw, 1e-9f, 0, 0.f, 3, y, total_chunks, chunks_per_utt, in_floats);
+        dsa::stft512_launch<ABL>(false, dim3((unsigned)grid), lds, 0, x, T, N, L, P, 200, 0, w, tw, 1e-9f, 0, 0.f, 3, y,
+                                 total_chunks, chunks_per_utt, in_floats);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
