@@ -488,6 +488,17 @@ constexpr int kFPW = 4;         // frames per wave (16 lanes each)
 constexpr int kZStride = 272;   // complex elements per frame region: 16 x 17 (padded transpose)
 constexpr int kTile = kFPW * 257;  // floats in one output tile (4 rows)
 
+#ifdef DSA_STFT_TIMING
+__device__ unsigned long long g_stft_stamps[16];
+#define STFT_STAMP(i)                                                                 \
+    do {                                                                              \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && c == (long)blockIdx.x + gridDim.x) \
+            g_stft_stamps[i] = __builtin_readcyclecounter();                          \
+    } while (0)
+#else
+#define STFT_STAMP(i)
+#endif
+
 // ShortTimeFourierTransform._forward stft.py:237-241 for nfft = 512, float32.
 // One wave64 per workgroup, autonomous (no inter-wave barriers): it owns kFPW = 4 consecutive
 // frames of one utterance per pass -- the 3P + L samples they share are read from HBM once into
@@ -538,6 +549,7 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
         const int nvalid = (int)((N - frame0) < kFPW ? (N - frame0) : kFPW);
         const float* xb = x + b * Tlen;
         __syncthreads();  // previous pass is done with io_buf / zbuf (single-wave workgroup)
+        STFT_STAMP(0);
         // ---- stage the shared waveform stretch (each sample read from HBM once) ----
         if (ABL != 3) {
             const long g0 = frame0 * P - left;
@@ -554,6 +566,7 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
             }
         }
         __syncthreads();
+        STFT_STAMP(1);
         // ---- per frame: window, 256-point complex FFT (16 lanes x 16 points) ----
         cf v[16];
         {
@@ -591,18 +604,24 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
                 v[m1] = cf{a0 * wreg[2 * m1], a1 * wreg[2 * m1 + 1]};  // window.py:190 (wreg = 0 past L)
             }
         }
+        STFT_STAMP(2);
         if (ABL != 2) fft16<false>(v);
+        STFT_STAMP(3);
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1)  // twiddle, then transposed store [k1][j] (row stride 17)
             zf[k1 * 17 + j] = cmul(v[FFT16_OUT(k1)], t256[k1]);
         __syncthreads();
+        STFT_STAMP(4);
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = zf[j * 17 + i];  // lane k1 = j reads A[i][k1]
         __syncthreads();
+        STFT_STAMP(5);
         if (ABL != 2) fft16<false>(v);
+        STFT_STAMP(6);
 #pragma unroll
         for (int k0 = 0; k0 < 16; ++k0) zf[j + 16 * k0] = v[FFT16_OUT(k0)];  // Z[k1 + 16 k0], natural order
         __syncthreads();
+        STFT_STAMP(7);
         // ---- real-FFT split, two bins (k, 256-k) per lane from one pair (Z[k], Z[256-k]) ----
         //   S = a + conj(b), Dd = a - conj(b), Pp = W Dd:
         //   2 X[k] = (S.re + Pp.im, S.im - Pp.re),  2 X[256-k] = (S.re - Pp.im, -S.im - Pp.re)
@@ -652,6 +671,7 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
             }
         }
         __syncthreads();
+        STFT_STAMP(8);
         // ---- formatter + coalesced write of the staged tile ----
         const bool plain = !use_floor && fmt == DSA_SPEC_POWER;
         if (nvalid == kFPW && (row0 & 3) == 0) {
@@ -693,6 +713,7 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
                 y[out0 + idx] = spec_format(sv, fmt);
             }
         }
+        STFT_STAMP(9);
     }
 }
 
@@ -948,8 +969,10 @@ DSA_EXPORT int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int3
     if (tuned_ok && algo != DSA_ALGO_GENERIC) {
         int chunks_per_utt = (int)((N + kFPW - 1) / kFPW);
         long total_chunks = (long)B * chunks_per_utt;
-        int waves_per_cu = 160 * 1024 / lds;
-        if (waves_per_cu > 16) waves_per_cu = 16;
+        // persistent single-wave workgroups; every one of them must be resident from the start, so
+        // leave headroom under the 160 KB of LDS (12 x 13.3 KB does not always fit: measured slower)
+        int waves_per_cu = 144 * 1024 / lds;
+        if (waves_per_cu > 8) waves_per_cu = 8;
         if (waves_per_cu < 1) waves_per_cu = 1;
         long grid = 256L * waves_per_cu;  // persistent single-wave workgroups
         if (grid > total_chunks) grid = total_chunks;

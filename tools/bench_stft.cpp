@@ -60,6 +60,16 @@ int main(int argc, char** argv)
         float t1 = run<1>(x, B, T, w, tw, y, 20, wpc);
         float t2 = run<2>(x, B, T, w, tw, y, 20, wpc);
         float t3 = run<3>(x, B, T, w, tw, y, 20, wpc);
+#ifdef DSA_STFT_TIMING
+        {
+            run<0>(x, B, T, w, tw, y, 1, wpc);
+            unsigned long long st[16];
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(dsa::g_stft_stamps), sizeof(st));
+            printf("  phase cycles: stage %llu | window %llu | fft1 %llu | tw+T-write %llu | T-read %llu | fft2 %llu | Z-write %llu | split %llu | copy-out %llu\n",
+                   st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6],
+                   st[8] - st[7], st[9] - st[8]);
+        }
+#endif
         printf("B=%ld waves/CU=%2d  full %8.1f us (%6.1f GB/s) | no-store %8.1f | no-fft %8.1f | no-load %8.1f\n", B, wpc, t0,
                bytes / t0 * 1e-3, t1, t2, t3);
     }
