@@ -493,6 +493,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2
     float* __restrict__ mc_out, float* __restrict__ hist, long ntiles16)
 {
     using namespace mm2;
+    // exp(ln X - 2 d) = exp2(log2 X - 2 log2(e) d): log2 / exp2 are single gfx950 instructions, so
+    // the D operand image is pre-scaled by -2 log2(e) and log2 X is what stays in registers;
+    // mc0 = ln X . G becomes log2 X . (ln 2 G).
+    constexpr float kNeg2Log2e = -2.885390081777926815f, kLn2 = 0.693147180559945309f;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2
     for (int idx = tid; idx < 16 * 2 * 64 * 4; idx += WAVES * 64) {
         int q = idx & 3, l = (idx >> 2) & 63, half = (idx >> 8) & 1, mt = idx >> 9;
         int k = 4 * (half * 4 + q) + (l >> 4);
-        lds[DT_OFF + idx] = k < M1 ? D[k * K + mt * 16 + (l & 15)] : 0.f;
+        lds[DT_OFF + idx] = k < M1 ? kNeg2Log2e * D[k * K + mt * 16 + (l & 15)] : 0.f;
     }
     for (int idx = tid; idx < 3 * 16 * 64 * 4; idx += WAVES * 64) {
         int r = idx & 3, l = (idx >> 2) & 63, mt = (idx >> 8) & 15, it = idx >> 12;
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2
     }
     if (tid < M2) lds[E256_OFF + tid] = E[H * M2 + tid];
     if (tid < 28) {
-        lds[D256_OFF + tid] = tid < M1 ? D[tid * K + H] : 0.f;
+        lds[D256_OFF + tid] = tid < M1 ? kNeg2Log2e * D[tid * K + H] : 0.f;
         lds[AV_OFF + tid] = tid < M1 ? av[tid] : 0.f;
     }
     __syncthreads();  // the only workgroup barrier: from here on every wave runs on its own
@@ -544,9 +548,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2
 #pragma unroll
         for (int mt = 0; mt < 16; ++mt) {
             const float* p = xf + mt * 16 + 4 * g;
-            logx[mt] = f32x4{logf(p[0]), logf(p[1]), logf(p[2]), logf(p[3])};  // mcep.py:203
+            logx[mt] = f32x4{__log2f(p[0]), __log2f(p[1]), __log2f(p[2]), __log2f(p[3])};  // mcep.py:203 (base 2)
         }
-        const float logx256 = logf(xf[H]);
+        const float logx256 = __log2f(xf[H]);
 
         // ---------------- mc0^T = G^T logx^T  (mcep.py:204-207) ----------------
         float mcB[KS];
@@ -560,9 +564,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2
                 for (int mt = 0; mt < 16; ++mt) {
                     const float* gp = G + (mt * 16 + 4 * g) * M1 + out;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) accG[it] = mfma4(ov ? gp[r * M1] : 0.f, logx[mt][r], accG[it]);
+                    for (int r = 0; r < 4; ++r) accG[it] = mfma4(ov ? kLn2 * gp[r * M1] : 0.f, logx[mt][r], accG[it]);
                 }
-                accG[it] = mfma4((ov && g == 0) ? G[H * M1 + out] : 0.f, g == 0 ? logx256 : 0.f, accG[it]);
+                accG[it] = mfma4((ov && g == 0) ? kLn2 * G[H * M1 + out] : 0.f, g == 0 ? logx256 : 0.f, accG[it]);
             }
             // accG[it][r] = mc0[coef it*16 + 4g + r]; re-distribute through this wave's LDS window
             // (wave-private data: LDS executes a wave's accesses in program order)
@@ -615,6 +619,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2
                 f32x4 pn = {0, 0, 0, 0}, qn = {0, 0, 0, 0};
                 f32x4 e;
                 // D-chain of the next tile: issued while exp of this tile runs on the VALU
+#if defined(DSA_MCEP_ABL) && DSA_MCEP_ABL == 2
+                if (mt + 1 < 16) { pn = a0 * mcB[0]; qn = a1 * mcB[1]; } else
+#endif
                 if (mt + 1 < 16) {
                     pn = mfma4(a0[0], mcB[0], pn);
                     qn = mfma4(a1[0], mcB[4], qn);
@@ -625,13 +632,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2
                     pn = mfma4(a0[3], mcB[3], pn);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) e[r] = exp_nobranch(logx[mt][r] - 2.f * acc[r]);
+                for (int r = 0; r < 4; ++r) {
+#if defined(DSA_MCEP_ABL) && DSA_MCEP_ABL == 1
+                    e[r] = logx[mt][r] + acc[r];
+#else
+                    e[r] = __builtin_amdgcn_exp2f(logx[mt][r] + acc[r]);  // mcep.py:212
+#endif
+                }
+#if defined(DSA_MCEP_ABL) && DSA_MCEP_ABL == 3
+                accB[0] += e * ea0; accB[1] += e * ea1; accB[2] += e * ea2;
+#else
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     accB[0] = mfma4(ea0[r], e[r], accB[0]);
                     accB[1] = mfma4(ea1[r], e[r], accB[1]);
                     accB[2] = mfma4(ea2[r], e[r], accB[2]);
                 }
+#endif
                 rt48 += e[0] * c48[0] + e[1] * c48[1] + e[2] * c48[2] + e[3] * c48[3];
                 pa = pn;
                 qa = qn;
@@ -654,7 +671,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2
             for (int ks = 0; ks < KS; ++ks) d256 += mcB[ks] * lds[D256_OFF + 4 * ks + g];
             d256 += __shfl_xor(d256, 16, 64);
             d256 += __shfl_xor(d256, 32, 64);
-            const float e256 = exp_nobranch(logx256 - 2.f * d256);
+            const float e256 = __builtin_amdgcn_exp2f(logx256 + d256);
 #pragma unroll
             for (int it = 0; it < 3; ++it)
                 accB[it] = mfma4(g == 0 ? lds[E256_OFF + it * 16 + n] : 0.f, g == 0 ? e256 : 0.f, accB[it]);

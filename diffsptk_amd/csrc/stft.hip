@@ -485,7 +485,6 @@ __device__ __forceinline__ void fft16(cf (&v)[16])
 #define FFT16_OUT(k) (4 * ((k)&3) + ((k) >> 2))
 
 constexpr int kFPW = 4;         // frames per wave (16 lanes each)
-constexpr int kZStride = 272;   // complex elements per frame region: 16 x 17 (padded transpose)
 constexpr int kTile = kFPW * 257;  // floats in one output tile (4 rows)
 
 #ifdef DSA_STFT_TIMING
@@ -503,8 +502,13 @@ __device__ unsigned long long g_stft_stamps[16];
 // One wave64 per workgroup, autonomous (no inter-wave barriers): it owns kFPW = 4 consecutive
 // frames of one utterance per pass -- the 3P + L samples they share are read from HBM once into
 // LDS -- and writes their 4 x 257 output rows as one contiguous, 16-byte aligned run of float4.
-// dynamic LDS layout: io_buf[io_floats] (input stretch, later the staged output tile) |
-//                     zbuf[kFPW][272] cf | fmax[kFPW]
+// LDS is kept to ~10 KB per wave so that 12+ waves fit a CU (the pass is a long dependent chain;
+// throughput comes from waves in flight):
+//   zbuf[kFPW][256] cf : (a) first the input stretch (3P + L floats), (b) then the 16 x 16
+//                        transpose tiles (XOR-swizzled: element (k1, j) at k1*16 + (j ^ k1)),
+//                        (c) then the spectra Z in natural order, (d) finally the staged 4 x 257
+//                        output tile -- each use is dead before the next begins;
+//   t256[16][16] cf    : W256^(j k1), shared by the 4 frames;   fmax[kFPW].
 // ABL: 0 production | 1 no output stores | 2 no FFT butterflies | 3 no input staging
 //      (ablation knob for tools/bench_stft.cpp)
 template <int ABL, bool ZMEAN>
@@ -515,40 +519,40 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
     int io_floats)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* io_buf = reinterpret_cast<float*>(smem_raw);
-    cf* zbuf = reinterpret_cast<cf*>(io_buf + io_floats);
-    float* fmax = reinterpret_cast<float*>(zbuf + kFPW * kZStride);
+    cf* zbuf = reinterpret_cast<cf*>(smem_raw);
+    float* io_buf = reinterpret_cast<float*>(smem_raw);  // aliases zbuf (see above)
+    cf* t256 = zbuf + kFPW * 256;
+    float* fmax = reinterpret_cast<float*>(t256 + 256);
+    (void)io_floats;
 
     const int lane = threadIdx.x;
     const int j = lane & 15;   // lane within the frame group
     const int fl = lane >> 4;  // frame slot within the pass (0..3)
 
-    // per-wave constants: per-lane window, W256^(j*k1), and the split twiddles of this lane's bins
+    // per-wave constants: per-lane window, W256^(j*k1) table, split twiddles of this lane's bins
     float wreg[32];
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
         int l = 2 * j + 32 * (r >> 1) + (r & 1);
         wreg[r] = l < L ? w[l] : 0.f;
     }
-    cf t256[16];
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) {
-        int m = 2 * j * k1;  // W256^(j k1) = W512^(2 j k1)
-        t256[k1] = cf{twiddle[2 * m], twiddle[2 * m + 1]};
+    for (int i = lane; i < 256; i += 64) {
+        int m = 2 * (i & 15) * (i >> 4);  // entry [k1 = i >> 4][j = i & 15]: W256^(j k1) = W512^(2 j k1)
+        t256[i] = cf{twiddle[2 * m], twiddle[2 * m + 1]};
     }
     const cf twA = cf{twiddle[2 * lane], twiddle[2 * lane + 1]};                // W512^lane
     const cf twB = cf{twiddle[2 * (lane + 64)], twiddle[2 * (lane + 64) + 1]};  // W512^(lane+64)
     const float inv_L = 1.f / (float)L;
     const int K = 257;
     const bool complex_out = fmt == DSA_SPEC_COMPLEX;
-    cf* zf = zbuf + fl * kZStride;
+    cf* zf = zbuf + fl * 256;
 
     for (long c = blockIdx.x; c < total_chunks; c += gridDim.x) {
         const long b = c / chunks_per_utt;
         const long frame0 = (c - b * chunks_per_utt) * kFPW;
         const int nvalid = (int)((N - frame0) < kFPW ? (N - frame0) : kFPW);
         const float* xb = x + b * Tlen;
-        __syncthreads();  // previous pass is done with io_buf / zbuf (single-wave workgroup)
+        __syncthreads();  // previous pass is done with the LDS tile (single-wave workgroup)
         STFT_STAMP(0);
         // ---- stage the shared waveform stretch (each sample read from HBM once) ----
         if (ABL != 3) {
@@ -604,16 +608,17 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
                 v[m1] = cf{a0 * wreg[2 * m1], a1 * wreg[2 * m1 + 1]};  // window.py:190 (wreg = 0 past L)
             }
         }
+        __syncthreads();  // every lane has its samples: the stretch may be overwritten
         STFT_STAMP(2);
         if (ABL != 2) fft16<false>(v);
         STFT_STAMP(3);
 #pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1)  // twiddle, then transposed store [k1][j] (row stride 17)
-            zf[k1 * 17 + j] = cmul(v[FFT16_OUT(k1)], t256[k1]);
+        for (int k1 = 0; k1 < 16; ++k1)  // twiddle, then transposed store: (k1, j) -> k1*16 + (j ^ k1)
+            zf[k1 * 16 + (j ^ k1)] = cmul(v[FFT16_OUT(k1)], t256[k1 * 16 + j]);
         __syncthreads();
         STFT_STAMP(4);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = zf[j * 17 + i];  // lane k1 = j reads A[i][k1]
+        for (int i = 0; i < 16; ++i) v[i] = zf[j * 16 + (i ^ j)];  // lane k1 = j reads A[i][k1]
         __syncthreads();
         STFT_STAMP(5);
         if (ABL != 2) fft16<false>(v);
@@ -625,36 +630,50 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
         // ---- real-FFT split, two bins (k, 256-k) per lane from one pair (Z[k], Z[256-k]) ----
         //   S = a + conj(b), Dd = a - conj(b), Pp = W Dd:
         //   2 X[k] = (S.re + Pp.im, S.im - Pp.re),  2 X[256-k] = (S.re - Pp.im, -S.im - Pp.re)
+        // All pairs are read before anything is written: the staged tile reuses the same LDS.
         const long row0 = b * N + frame0;
         const long out0 = row0 * K;
-        float* stage = io_buf;  // the input stretch is dead: reuse it for the 4 x 257 tile
+        float* stage = io_buf;
         float2* y2 = reinterpret_cast<float2*>(y);
+        cf pa[kFPW][3], pb[kFPW][3];
+#pragma unroll
+        for (int f = 0; f < kFPW; ++f) {
+            const cf* z = zbuf + f * 256;
+            pa[f][0] = z[lane];
+            pb[f][0] = z[(256 - lane) & 255];
+            pa[f][1] = z[lane + 64];
+            pb[f][1] = z[192 - lane];
+            pa[f][2] = z[128];  // bin 128 pairs with itself (same value on every lane)
+            pb[f][2] = pa[f][2];
+        }
+        __syncthreads();
         float fm[kFPW] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int f = 0; f < kFPW; ++f) {
-            const cf* z = zbuf + f * kZStride;
 #pragma unroll
             for (int part = 0; part < 3; ++part) {
-                // part 0: k = lane (0..63); part 1: k = lane + 64; part 2: k = 128 (lane 0 only)
+                // part 0: k = lane (0..63); part 1: k = lane + 64; part 2: k = 128 (stored by lane 0)
                 const int k = part == 0 ? lane : (part == 1 ? lane + 64 : 128);
-                if (part == 2 && lane != 0) continue;
                 const cf W = part == 0 ? twA : (part == 1 ? twB : cf{0.f, -1.f});
-                const cf a = z[k], bq = z[(256 - k) & 255];
+                const cf a = pa[f][part], bq = pb[f][part];
                 const cf S = {a.re + bq.re, a.im - bq.im};
                 const cf Dd = {a.re - bq.re, a.im + bq.im};
                 const cf Pp = cmul(W, Dd);
                 const cf X1 = {0.5f * (S.re + Pp.im), 0.5f * (S.im - Pp.re)};
                 const cf X2 = {0.5f * (S.re - Pp.im), 0.5f * (-S.im - Pp.re)};
+                const bool mine = part != 2 || lane == 0;
                 if (complex_out) {
-                    if (f < nvalid && ABL != 1) {
+                    if (f < nvalid && ABL != 1 && mine) {
                         y2[out0 + f * K + k] = make_float2(X1.re, X1.im);
                         if (part != 2) y2[out0 + f * K + 256 - k] = make_float2(X2.re, X2.im);
                     }
                 } else {
                     const float s1 = X1.re * X1.re + X1.im * X1.im + eps;  // spec.py:173
                     const float s2 = X2.re * X2.re + X2.im * X2.im + eps;
-                    stage[f * K + k] = s1;
-                    if (part != 2) stage[f * K + 256 - k] = s2;
+                    if (mine) {
+                        stage[f * K + k] = s1;
+                        if (part != 2) stage[f * K + 256 - k] = s2;
+                    }
                     if (use_floor) {
                         const float mx = s1 > s2 ? s1 : s2;
                         fm[f] = mx > fm[f] ? mx : fm[f];
@@ -738,10 +757,11 @@ static int launch_row_dft(const void* x, int64_t B, int64_t Tlen, int64_t N, int
 
 static int stft512_lds_bytes(int L, int P, int* io_floats)
 {
+    // the input stretch and the staged output tile both live inside the 4 x 256 complex tile
     int span = (kFPW - 1) * P + L;
-    if (span < kTile) span = kTile;  // the region doubles as the staged output tile
     *io_floats = (span + 3) & ~3;
-    return *io_floats * 4 + kFPW * kZStride * 8 + 16;
+    if (*io_floats > kFPW * 512) return 1 << 30;  // stretch does not fit: use the generic kernel
+    return kFPW * 256 * 8 + 256 * 8 + 16;
 }
 
 template <int ABL>
@@ -972,7 +992,7 @@ DSA_EXPORT int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int3
         // persistent single-wave workgroups; every one of them must be resident from the start, so
         // leave headroom under the 160 KB of LDS (12 x 13.3 KB does not always fit: measured slower)
         int waves_per_cu = 144 * 1024 / lds;
-        if (waves_per_cu > 8) waves_per_cu = 8;
+        if (waves_per_cu > 12) waves_per_cu = 12;
         if (waves_per_cu < 1) waves_per_cu = 1;
         long grid = 256L * waves_per_cu;  // persistent single-wave workgroups
         if (grid > total_chunks) grid = total_chunks;

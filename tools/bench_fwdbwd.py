@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""BASELINE configs[2]/[3]: STFT + mcep forward+backward and the LPC branch, timed with HIP events.
+usage: python tools/bench_fwdbwd.py [B]"""
+import sys, os, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import diffsptk_amd as dsp
+from diffsptk_amd import ops
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+dev = "cuda"
+x = torch.randn(B, 16000, device=dev)
+stft = dsp.STFT(400, 80, 512, device=dev)
+mcep = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, device=dev)
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+def fwd():
+    with torch.no_grad(): return mcep(stft(x))
+def fwdbwd():
+    xg = x.clone().requires_grad_(True)
+    mcep(stft(xg)).mean().backward()
+    return xg.grad
+frames = B * 200
+t_f, t_fb = timeit(fwd), timeit(fwdbwd)
+print(f"B={B}: stft+mcep fwd {t_f:.3f} ms ({frames/t_f*1e3:.3e} frames/s) | fwd+bwd {t_fb:.3f} ms ({frames/t_fb*1e3:.3e} frames/s)")
+# pieces of the backward
+xg = x.clone().requires_grad_(True)
+X = stft(xg); Xd = X.detach().requires_grad_(True)
+mc = mcep(Xd)
+g = torch.ones_like(mc) / mc.numel()
+t_mb = timeit(lambda: torch.autograd.grad(mc, Xd, g, retain_graph=True))
+gX = torch.autograd.grad(mc, Xd, g, retain_graph=True)[0]
+t_sb = timeit(lambda: torch.autograd.grad(X, xg, gX, retain_graph=True))
+print(f"   mcep bwd {t_mb:.3f} ms | stft bwd {t_sb:.3f} ms")
+w = dsp.Window(400, device=dev).window
+t_l = timeit(lambda: ops.frame_window_lpc(x, w, 400, 80, 24, 1e-5))
+fr, wn, lpc = dsp.Frame(400, 80), dsp.Window(400, device=dev), dsp.LPC(400, 24, eps=1e-5, device=dev)
+t_lm = timeit(lambda: lpc(wn(fr(x))))
+def lpc_fb():
+    xg = x.clone().requires_grad_(True); lpc(wn(fr(xg))).mean().backward()
+t_lfb = timeit(lpc_fb)
+print(f"   LPC fused fwd {t_l:.3f} ms ({frames/t_l*1e3:.3e} frames/s) | module chain fwd {t_lm:.3f} ms | fwd+bwd {t_lfb:.3f} ms")
