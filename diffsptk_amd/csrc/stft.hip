@@ -755,6 +755,259 @@ static int launch_row_dft(const void* x, int64_t B, int64_t Tlen, int64_t N, int
     return check_launch("row_dft_generic");
 }
 
+// Backward of stft512_fwd_kernel (autograd of stft.py:237-241), same
+// wave-per-pass structure and LDS tile.  Per pass of 4 frames:
+//   recompute Z (stage, window, FFT-256) -> split into X[k] -> cotangent S[k] of the half spectrum
+//   (power formats: gs[k] X[k] with gs = gy * format'(s);  complex: gy / 2) -> Hermitian-pack into a
+//   256-point complex spectrum Zin[k] = (a + b) + i conj(W^k) (a - b), a = S[k], b = conj(S[256-k]) ->
+//   inverse FFT-256 (same radix-16 x 16 code, conjugated twiddles) = cotangent of the windowed
+//   frame -> times window (-> zmean adjoint) -> overlap-add of the 4 frames inside the pass ->
+//   one contiguous partial span of 3P + L samples per pass, written to `part` (pass-major).
+// A second kernel (stft_span_gather_kernel) adds the <= ceil((3P+L)/(4P)) partial spans that cover
+// each waveform sample in a fixed order: deterministic, no atomics.
+template <bool ZMEAN>
+__global__ __launch_bounds__(64, 3) void stft512_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gy, long Tlen, long N, int L, int P, int left,
+    int mode, const float* __restrict__ w, const float* __restrict__ twiddle, float eps, int fmt,
+    float* __restrict__ part, long total_chunks, int chunks_per_utt, int span)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf* zbuf = reinterpret_cast<cf*>(smem_raw);
+    float* io_buf = reinterpret_cast<float*>(smem_raw);
+    cf* t256 = zbuf + kFPW * 256;
+
+    const int lane = threadIdx.x;
+    const int j = lane & 15, fl = lane >> 4;
+    float wreg[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        int l = 2 * j + 32 * (r >> 1) + (r & 1);
+        wreg[r] = l < L ? w[l] : 0.f;
+    }
+    for (int i = lane; i < 256; i += 64) {
+        int m = 2 * (i & 15) * (i >> 4);
+        t256[i] = cf{twiddle[2 * m], twiddle[2 * m + 1]};
+    }
+    const cf twA = cf{twiddle[2 * lane], twiddle[2 * lane + 1]};
+    const cf twB = cf{twiddle[2 * (lane + 64)], twiddle[2 * (lane + 64) + 1]};
+    const float inv_L = 1.f / (float)L;
+    const int K = 257;
+    const bool complex_out = fmt == DSA_SPEC_COMPLEX;
+    cf* zf = zbuf + fl * 256;
+    const float2* gy2 = reinterpret_cast<const float2*>(gy);
+
+    for (long c = blockIdx.x; c < total_chunks; c += gridDim.x) {
+        const long b = c / chunks_per_utt;
+        const long frame0 = (c - b * chunks_per_utt) * kFPW;
+        const int nvalid = (int)((N - frame0) < kFPW ? (N - frame0) : kFPW);
+        const float* xb = x + b * Tlen;
+        __syncthreads();
+        {   // stage the input stretch
+            const long g0 = frame0 * P - left;
+            const int need = (nvalid - 1) * P + L;
+            const bool interior = g0 >= 0 && g0 + need <= Tlen;
+            if (interior && (((size_t)(xb + g0)) & 15) == 0) {
+                const float4* src4 = reinterpret_cast<const float4*>(xb + g0);
+                float4* dst4 = reinterpret_cast<float4*>(io_buf);
+                const int n4 = need >> 2;
+                for (int s = lane; s < n4; s += 64) dst4[s] = src4[s];
+                for (int s = (n4 << 2) + lane; s < need; s += 64) io_buf[s] = xb[g0 + s];
+            } else {
+                for (int s = lane; s < need; s += 64) io_buf[s] = load_padded(xb, g0 + s, Tlen, mode);
+            }
+        }
+        __syncthreads();
+        cf v[16];
+        const int lim = L - 2 * j;
+        {
+            const float* src = io_buf + fl * P + 2 * j;
+            float sum = 0.f;
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) {
+                float a0 = 0.f, a1 = 0.f;
+                if (32 * m1 + 32 <= L) {
+                    a0 = src[32 * m1];
+                    a1 = src[32 * m1 + 1];
+                } else if (32 * m1 < L) {
+                    a0 = 32 * m1 < lim ? src[32 * m1] : 0.f;
+                    a1 = 32 * m1 + 1 < lim ? src[32 * m1 + 1] : 0.f;
+                }
+                v[m1] = cf{a0, a1};
+                if (ZMEAN) sum += a0 + a1;
+            }
+            float mean = 0.f;
+            if (ZMEAN) {
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+                mean = sum * inv_L;
+            }
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) {
+                float a0 = v[m1].re, a1 = v[m1].im;
+                if (ZMEAN) {
+                    a0 = 32 * m1 < lim ? a0 - mean : 0.f;
+                    a1 = 32 * m1 + 1 < lim ? a1 - mean : 0.f;
+                }
+                v[m1] = cf{a0 * wreg[2 * m1], a1 * wreg[2 * m1 + 1]};
+            }
+        }
+        __syncthreads();
+        fft16<false>(v);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) zf[k1 * 16 + (j ^ k1)] = cmul(v[FFT16_OUT(k1)], t256[k1 * 16 + j]);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = zf[j * 16 + (i ^ j)];
+        __syncthreads();
+        fft16<false>(v);
+#pragma unroll
+        for (int k0 = 0; k0 < 16; ++k0) zf[j + 16 * k0] = v[FFT16_OUT(k0)];
+        __syncthreads();
+        // ---- split, cotangent, Hermitian packing (pairs read first, then written in place) ----
+        const long out0 = (b * N + frame0) * K;
+        cf pa[kFPW][3], pb[kFPW][3];
+#pragma unroll
+        for (int f = 0; f < kFPW; ++f) {
+            const cf* z = zbuf + f * 256;
+            pa[f][0] = z[lane];
+            pb[f][0] = z[(256 - lane) & 255];
+            pa[f][1] = z[lane + 64];
+            pb[f][1] = z[192 - lane];
+            pa[f][2] = z[128];
+            pb[f][2] = pa[f][2];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < kFPW; ++f) {
+            cf* z = zbuf + f * 256;
+            const bool fv = f < nvalid;
+#pragma unroll
+            for (int part_i = 0; part_i < 3; ++part_i) {
+                const int k = part_i == 0 ? lane : (part_i == 1 ? lane + 64 : 128);
+                const cf W = part_i == 0 ? twA : (part_i == 1 ? twB : cf{0.f, -1.f});
+                const cf a = pa[f][part_i], bq = pb[f][part_i];
+                const cf S = {a.re + bq.re, a.im - bq.im};
+                const cf Dd = {a.re - bq.re, a.im + bq.im};
+                const cf Pp = cmul(W, Dd);
+                const cf X1 = {0.5f * (S.re + Pp.im), 0.5f * (S.im - Pp.re)};     // X[k]
+                const cf X2 = {0.5f * (S.re - Pp.im), 0.5f * (-S.im - Pp.re)};    // X[256-k]
+                // half-spectrum cotangents S1 = S[k], S2 = S[256-k]
+                cf S1, S2;
+                if (complex_out) {
+                    const float2 g1 = fv ? gy2[out0 + f * K + k] : make_float2(0.f, 0.f);
+                    const float2 g2 = fv ? gy2[out0 + f * K + 256 - k] : make_float2(0.f, 0.f);
+                    S1 = cf{0.5f * g1.x, 0.5f * g1.y};
+                    S2 = cf{0.5f * g2.x, 0.5f * g2.y};
+                } else {
+                    const float s1 = X1.re * X1.re + X1.im * X1.im + eps;
+                    const float s2 = X2.re * X2.re + X2.im * X2.im + eps;
+                    float g1 = fv ? gy[out0 + f * K + k] : 0.f;
+                    float g2 = fv ? gy[out0 + f * K + 256 - k] : 0.f;
+                    switch (fmt) {  // d format(s) / d s  (spec.py:123-132)
+                    case DSA_SPEC_DB: g1 *= 4.342944819032518f / s1; g2 *= 4.342944819032518f / s2; break;
+                    case DSA_SPEC_LOGMAG: g1 *= 0.5f / s1; g2 *= 0.5f / s2; break;
+                    case DSA_SPEC_MAG: g1 *= 0.5f / sqrtf(s1); g2 *= 0.5f / sqrtf(s2); break;
+                    default: break;
+                    }
+                    S1 = cf{g1 * X1.re, g1 * X1.im};
+                    S2 = cf{g2 * X2.re, g2 * X2.im};
+                }
+                if (part_i == 0) {
+                    // k = 0 pairs with 256: both real-valued bins carry the full (not half) weight
+                    const float s0r = lane == 0 ? 2.f * S1.re : S1.re, s0i = lane == 0 ? 0.f : S1.im;
+                    const float s6r = lane == 0 ? 2.f * S2.re : S2.re, s6i = lane == 0 ? 0.f : S2.im;
+                    S1 = cf{s0r, s0i};
+                    S2 = cf{s6r, s6i};
+                }
+                // Zin[k] = (a + b) + i Q, Zin[256-k] = conj(a + b) + i conj(Q), a = S1, b = conj(S2),
+                // Q = conj(W) (a - b)
+                const cf ab = {S1.re + S2.re, S1.im - S2.im};
+                const cf amb = {S1.re - S2.re, S1.im + S2.im};
+                const cf Q = cmul(cf{W.re, -W.im}, amb);
+                if (part_i == 2) {
+                    if (lane == 0) z[128] = cf{2.f * S1.re, -2.f * S1.im};  // 2 conj(S[128])
+                } else {
+                    z[k] = cf{ab.re - Q.im, ab.im + Q.re};
+                    if (!(part_i == 0 && lane == 0)) z[256 - k] = cf{ab.re + Q.im, -ab.im + Q.re};
+                }
+            }
+        }
+        __syncthreads();
+        // ---- inverse FFT-256 (unnormalised, conjugated twiddles), same data movement ----
+#pragma unroll
+        for (int m1 = 0; m1 < 16; ++m1) v[m1] = zf[j + 16 * m1];
+        __syncthreads();
+        fft16<true>(v);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {
+            const cf t = t256[k1 * 16 + j];
+            zf[k1 * 16 + (j ^ k1)] = cmul(v[FFT16_OUT(k1)], cf{t.re, -t.im});
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = zf[j * 16 + (i ^ j)];
+        __syncthreads();
+        fft16<true>(v);
+        // lane j now holds time points m = j + 16 k0: samples l = 2m, 2m+1 -- the forward's own
+        // register <-> sample map, so the window (and zmean adjoint) reuse wreg / the 16-lane sum
+        {
+            float gsum = 0.f;
+#pragma unroll
+            for (int k0 = 0; k0 < 16; ++k0) {
+                cf o = v[FFT16_OUT(k0)];
+                o = cf{o.re * wreg[2 * k0], o.im * wreg[2 * k0 + 1]};
+                v[FFT16_OUT(k0)] = o;
+                if (ZMEAN) gsum += o.re + o.im;
+            }
+            float gm = 0.f;
+            if (ZMEAN) {
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) gsum += __shfl_xor(gsum, o, 16);
+                gm = gsum * inv_L;
+            }
+#pragma unroll
+            for (int k0 = 0; k0 < 16; ++k0) {
+                cf o = v[FFT16_OUT(k0)];
+                if (ZMEAN) {
+                    o.re = 32 * k0 < lim ? o.re - gm : 0.f;
+                    o.im = 32 * k0 + 1 < lim ? o.im - gm : 0.f;
+                }
+                zf[j + 16 * k0] = o;  // gframe[l] as floats: l = 2 (j + 16 k0) + {0, 1}
+            }
+        }
+        __syncthreads();
+        // ---- overlap-add of the pass's frames; one contiguous partial span per pass ----
+        float* dst = part + c * (long)span;
+        for (int sidx = lane; sidx < span; sidx += 64) {
+            float acc = 0.f;
+#pragma unroll
+            for (int f = 0; f < kFPW; ++f) {
+                const int l = sidx - f * P;
+                if (f < nvalid && l >= 0 && l < L) acc += reinterpret_cast<const float*>(zbuf + f * 256)[l];
+            }
+            dst[sidx] = acc;
+        }
+    }
+}
+
+// gx[b][t] = sum over the passes whose span covers t (adjoint of the on-the-fly padding: positions
+// outside [0, T) are dropped for constant padding -- other modes use the generic backward).
+__global__ void stft_span_gather_kernel(const float* __restrict__ part, long Tlen, int P, int left, int span,
+                                        int chunks_per_utt, float* __restrict__ gx)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long b = blockIdx.y;
+    if (t >= Tlen) return;
+    const long p = t + left;          // position in the padded signal
+    const long stride = (long)kFPW * P;  // pass c starts at padded position c * stride
+    long c_hi = p / stride;
+    if (c_hi > chunks_per_utt - 1) c_hi = chunks_per_utt - 1;
+    long c_lo = p - span + 1 <= 0 ? 0 : (p - span + stride) / stride;
+    float acc = 0.f;
+    for (long c = c_lo; c <= c_hi; ++c) acc += part[(b * chunks_per_utt + c) * (long)span + (p - c * stride)];
+    gx[b * Tlen + t] = acc;
+}
+
 static int stft512_lds_bytes(int L, int P, int* io_floats)
 {
     // the input stretch and the staged output tile both live inside the 4 x 256 complex tile
@@ -1105,8 +1358,47 @@ DSA_EXPORT int dsa_stft_bwd(const void* gy, const void* x, int64_t B, int64_t T,
     DSA_REQUIRE(pad_mode >= 0 && pad_mode <= 3, "stft_bwd: unknown pad mode");
     DSA_REQUIRE(out_format >= 0 && out_format <= 4, "stft_bwd: unknown out_format");
     if (B == 0) return DSA_OK;
-    (void)algo;
     hipStream_t st = (hipStream_t)stream;
+    {
+        int io_floats = 0;
+        int lds = stft512_lds_bytes(L, P, &io_floats);
+        bool tuned_ok = dtype == DSA_F32 && nfft == 512 && L <= 512 && lds <= 64 * 1024 && !use_floor && !gw &&
+                        pad_mode == DSA_PAD_CONSTANT;
+        if (algo == DSA_ALGO_TUNED && !tuned_ok)
+            return fail(DSA_ERR_UNSUPPORTED,
+                        "stft_bwd: tuned kernel needs float32, fft_length 512, constant padding, no floor, fixed window%s");
+        if (tuned_ok && algo != DSA_ALGO_GENERIC) {
+            int64_t N = dsa_num_frames(T, P);
+            int chunks_per_utt = (int)((N + kFPW - 1) / kFPW);
+            long total_chunks = (long)B * chunks_per_utt;
+            int span = (kFPW - 1) * P + L;
+            float* part = nullptr;
+            if (hipMallocAsync((void**)&part, sizeof(float) * (size_t)total_chunks * span, st) != hipSuccess)
+                return fail(DSA_ERR_LAUNCH, "stft_bwd: workspace allocation failed%s");
+            int waves_per_cu = 144 * 1024 / lds;
+            if (waves_per_cu > 12) waves_per_cu = 12;
+            long grid = 256L * waves_per_cu;
+            if (grid > total_chunks) grid = total_chunks;
+            int left = center ? L / 2 : 0;
+            if (zmean)
+                hipLaunchKernelGGL((stft512_bwd_kernel<true>), dim3((unsigned)grid), dim3(64), lds, st, (const float*)x,
+                                   (const float*)gy, (long)T, (long)N, L, P, left, pad_mode, (const float*)w,
+                                   (const float*)twiddle, (float)eps, out_format, part, total_chunks, chunks_per_utt, span);
+            else
+                hipLaunchKernelGGL((stft512_bwd_kernel<false>), dim3((unsigned)grid), dim3(64), lds, st, (const float*)x,
+                                   (const float*)gy, (long)T, (long)N, L, P, left, pad_mode, (const float*)w,
+                                   (const float*)twiddle, (float)eps, out_format, part, total_chunks, chunks_per_utt, span);
+            int rc = check_launch("stft512_bwd");
+            if (rc == DSA_OK) {
+                dim3 g2((unsigned)((T + 255) / 256), (unsigned)B);
+                hipLaunchKernelGGL(stft_span_gather_kernel, g2, dim3(256), 0, st, (const float*)part, (long)T, P, left,
+                                   span, chunks_per_utt, (float*)gx);
+                rc = check_launch("stft512_bwd");
+            }
+            (void)hipFreeAsync(part, st);
+            return rc;
+        }
+    }
     if (dtype == DSA_F32)
         return stft_bwd_generic<float>(gy, x, B, T, L, P, nfft, w, twiddle, center, zmean, pad_mode, eps, use_floor,
                                        relative_floor_db, out_format, gx, gw, st);

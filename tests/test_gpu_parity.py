@@ -283,6 +283,50 @@ def test_stft_backward_golden(golden, name, dt):
     assert np.abs(host(x.grad) - ref).max() < tol * scale
 
 
+def test_stft_backward_tuned_vs_generic_and_autograd():
+    """float32 tuned backward kernel (FFT-based, partial spans + gather) against the generic
+    backward and against autograd of the torch-op port in float64."""
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(3, 2100, generator=gen)
+    for L, P in ((400, 80), (512, 128), (25, 10), (399, 77)):
+        for kw in (dict(), dict(center=False), dict(zmean=True), dict(out_format="db"), dict(out_format="magnitude"),
+                   dict(out_format="log-magnitude", eps=1e-3), dict(out_format="complex")):
+            m = dsp.STFT(L, P, 512, device=DEV, **kw)
+            fmt = {"power": 3, "db": 0, "log-magnitude": 1, "magnitude": 2, "complex": 4}[kw.get("out_format", "power")]
+            grads = {}
+            for name, algo in (("tuned", _lib.ALGO_TUNED), ("generic", _lib.ALGO_GENERIC)):
+                xg = x.to(DEV).requires_grad_(True)
+                y = ops.StftFn.apply(xg, m.window, m.twiddle, L, P, 512, kw.get("center", True), kw.get("zmean", False),
+                                     "constant", kw.get("eps", 1e-9), None, fmt, algo)
+                wts = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+                if y.is_complex():
+                    loss = (y.real * wts.to(DEV)).sum() + 0.5 * (y.imag * wts.to(DEV)).sum()
+                else:
+                    loss = (y * wts.to(DEV)).sum()
+                loss.backward()
+                # (dsa_last_kernel is per host thread and backward runs on the autograd thread; the
+                # ALGO_TUNED request itself fails loudly if the tuned kernel cannot take the case)
+                grads[name] = host(xg.grad)
+            scale = np.abs(grads["generic"]).max()
+            # log-type formats divide by s: bins near eps amplify float32 FFT-vs-DFT rounding
+            tol_tg = 2e-5 if fmt in (3, 4) else 3e-4
+            assert np.abs(grads["tuned"] - grads["generic"]).max() < tol_tg * scale, (L, P, kw)
+            # float64 autograd of the reference op sequence
+            xc = x.double().clone().requires_grad_(True)
+            wc = torch.from_numpy(O.window_table(L)).double()
+            fr = TP.frame(xc, L, P, kw.get("center", True), kw.get("zmean", False)) * wc
+            Z = torch.fft.rfft(torch.nn.functional.pad(fr, (0, 512 - L)), n=512)
+            wts64 = wts.double()
+            if fmt == 4:
+                lr = (Z.real * wts64).sum() + 0.5 * (Z.imag * wts64).sum()
+            else:
+                sv = Z.abs().square() + kw.get("eps", 1e-9)
+                yr = {3: sv, 0: 10 * torch.log10(sv), 1: 0.5 * torch.log(sv), 2: sv.sqrt()}[fmt]
+                lr = (yr * wts64).sum()
+            lr.backward()
+            assert np.abs(grads["tuned"] - xc.grad.numpy()).max() < (2e-4 if fmt in (3, 4) else 1e-3) * scale, (L, P, kw)
+
+
 def test_stft_backward_options_vs_autograd():
     gen = torch.Generator().manual_seed(11)
     x = torch.randn(2, 300, dtype=torch.float64, generator=gen)
