@@ -275,6 +275,8 @@ static int mcep_generic_bwd(const void* gmc, const void* X, const void* hist, in
 int mcep_mfma_supported(int nfft, int M, int dtype);
 int mcep_mfma_fwd(const void* X, int64_t F, int nfft, int M, int n_iter, const void* G, const void* D,
                   const void* E, const void* av, void* mc, void* hist, hipStream_t st);
+int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* G, const void* D,
+                  const void* E, const void* av, void* gX, hipStream_t st);
 
 }  // namespace dsa
 
@@ -344,7 +346,11 @@ DSA_EXPORT int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist,
     DSA_REQUIRE(mc_hist != nullptr, "mcep_bwd: the forward history is required");
     if (F == 0) return DSA_OK;
     hipStream_t st = (hipStream_t)stream;
-    (void)algo;
+    bool tuned_ok = mcep_mfma_supported(nfft, M, dtype) != 0;
+    if (algo == DSA_ALGO_TUNED && !tuned_ok)
+        return fail(DSA_ERR_UNSUPPORTED, "mcep_bwd: tuned kernel needs float32, fft_length 512, cep_order 24%s");
+    if (tuned_ok && algo != DSA_ALGO_GENERIC)
+        return mcep_mfma_bwd(gmc, X, mc_hist, F, n_iter, G, D, E, alpha_vec, gX, st);
     if (dtype == DSA_F32) return mcep_generic_bwd<float>(gmc, X, mc_hist, F, nfft, M, n_iter, G, D, E, alpha_vec, gX, st);
     if (dtype == DSA_F64) return mcep_generic_bwd<double>(gmc, X, mc_hist, F, nfft, M, n_iter, G, D, E, alpha_vec, gX, st);
     return fail(DSA_ERR_UNSUPPORTED, "mcep_bwd: unsupported dtype%s");

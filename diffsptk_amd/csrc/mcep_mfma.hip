@@ -730,6 +730,397 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2
 int mcep_mfma_supported(int nfft, int M, int dtype) { return dtype == DSA_F32 && nfft == 512 && M == 24; }
 
 // =====================================================================================
+// Backward of the unrolled Newton iteration (what autograd gives the reference: SURVEY.md
+// section 3.5), float32 / fft_length 512 / cep_order 24, same wave mapping as the forward.
+// For step k (cotangent mbar of mc_{k+1}, saved iterate mc_k):
+//   re-form e = exp(ln X - 2 mc_k D), rt = e E and the system A = T(rt[:25]) + H(rt)   (forward code)
+//   solve A [g | u] = [rt[:25] - alpha | mbar]      (two right-hand sides in one elimination)
+//   rtbar[m] = -sum_{i+j=m} u_i g_j - [m<=24] (sum_{|i-j|=m} u_i g_j - u_m)
+//   ebar^T = E rtbar^T  (MFMA; operand gathered from the forward's E^T image);  zbar = ebar * e
+//   lbar += zbar ;  mbar <- mbar - 2 D zbar^T   (MFMA on the D^T image; C/D registers are the B operand)
+// and finally lbar += G mbar_0, gX = lbar / X.
+// =====================================================================================
+template <int k, int m>
+__device__ __forceinline__ void sym2_update_row(SymRows& a, float (&b)[mm::NR], float (&b2)[mm::NR],
+                                                const float (&prow)[mm::M1], float pb, float pb2, float inv,
+                                                const GroupMask& gq)
+{
+    using namespace mm;
+    constexpr int mk = k >> 2;
+    if constexpr (m >= mk && m < NR) {
+        constexpr int i0 = 4 * m;
+        const float c0 = (i0 + 0 > k && i0 + 0 < M1) ? prow[i0 + 0 < M1 ? i0 + 0 : 0] : 0.f;
+        const float c1 = (i0 + 1 > k && i0 + 1 < M1) ? prow[i0 + 1 < M1 ? i0 + 1 : 0] : 0.f;
+        const float c2 = (i0 + 2 > k && i0 + 2 < M1) ? prow[i0 + 2 < M1 ? i0 + 2 : 0] : 0.f;
+        const float c3 = (i0 + 3 > k && i0 + 3 < M1) ? prow[i0 + 3 < M1 ? i0 + 3 : 0] : 0.f;
+        const float fct = sel4(gq, c0, c1, c2, c3) * inv;
+        float* row = sym_row<m>(a);
+        constexpr int j0 = (4 * m > k + 1) ? 4 * m : k + 1;
+#pragma unroll
+        for (int j = j0; j < M1; ++j) row[j - 4 * m] -= fct * prow[j];
+        b[m] -= fct * pb;
+        b2[m] -= fct * pb2;
+        sym2_update_row<k, m + 1>(a, b, b2, prow, pb, pb2, inv, gq);
+    }
+}
+template <int k>
+__device__ __forceinline__ void sym2_elim_step(SymRows& a, float (&b)[mm::NR], float (&b2)[mm::NR],
+                                               const GroupMask& gq)
+{
+    using namespace mm;
+    constexpr int gk = k & 3, mk = k >> 2;
+    float prow[M1];
+    float* prw = sym_row<mk>(a);
+#pragma unroll
+    for (int j = k; j < M1; ++j) prow[j] = quad_bcast<gk>(prw[j - 4 * mk]);
+    const float pb = quad_bcast<gk>(b[mk]), pb2 = quad_bcast<gk>(b2[mk]);
+    const float inv = rcp_nr(prow[k]);
+    sym2_update_row<k, mk>(a, b, b2, prow, pb, pb2, inv, gq);
+}
+template <int k, int m>
+__device__ __forceinline__ void sym2_backsub_rows(SymRows& a, float (&b)[mm::NR], float (&b2)[mm::NR], float xk,
+                                                  float uk)
+{
+    constexpr int mk = k >> 2;
+    if constexpr (m <= mk) {
+        const float aik = sym_row<m>(a)[k - 4 * m];
+        b[m] -= aik * xk;
+        b2[m] -= aik * uk;
+        sym2_backsub_rows<k, m + 1>(a, b, b2, xk, uk);
+    }
+}
+// full solution vectors on every lane of the quad: gv = A^{-1} b, uv = A^{-1} b2
+template <int k>
+__device__ __forceinline__ void sym2_backsub_step(SymRows& a, float (&b)[mm::NR], float (&b2)[mm::NR],
+                                                  float (&gv)[mm::M1], float (&uv)[mm::M1])
+{
+    constexpr int gk = k & 3, mk = k >> 2;
+    const float rinv = rcp_nr(sym_row<mk>(a)[k - 4 * mk]);
+    const float xk = quad_bcast<gk>(b[mk] * rinv), uk = quad_bcast<gk>(b2[mk] * rinv);
+    gv[k] = xk;
+    uv[k] = uk;
+    sym2_backsub_rows<k, 0>(a, b, b2, xk, uk);
+}
+template <int... Ks>
+__device__ __forceinline__ void sym2_elim_all(SymRows& a, float (&b)[mm::NR], float (&b2)[mm::NR],
+                                              const GroupMask& gq, std::integer_sequence<int, Ks...>)
+{
+    (sym2_elim_step<Ks>(a, b, b2, gq), ...);
+}
+template <int... Ks>
+__device__ __forceinline__ void sym2_backsub_all(SymRows& a, float (&b)[mm::NR], float (&b2)[mm::NR],
+                                                 float (&gv)[mm::M1], float (&uv)[mm::M1],
+                                                 std::integer_sequence<int, Ks...>)
+{
+    (sym2_backsub_step<mm::M1 - 1 - Ks>(a, b, b2, gv, uv), ...);
+}
+// rtbar[m] for compile-time m (every lane of the quad computes all of them: static registers only)
+template <int m>
+__device__ __forceinline__ float rtbar_at(const float (&gv)[mm::M1], const float (&uv)[mm::M1])
+{
+    using namespace mm;
+    float acc = 0.f;
+    constexpr int ilo = m - (M1 - 1) > 0 ? m - (M1 - 1) : 0;
+    constexpr int ihi = m < M1 - 1 ? m : M1 - 1;
+#pragma unroll
+    for (int i = ilo; i <= ihi; ++i) acc -= uv[i] * gv[m - i];  // Hankel diagonals: i + j = m
+    if constexpr (m < M1) {
+#pragma unroll
+        for (int i = 0; i + m < M1; ++i) {  // Toeplitz diagonals: |i - j| = m
+            acc -= uv[i] * gv[i + m];
+            if (m > 0) acc -= uv[i + m] * gv[i];
+        }
+        acc += uv[m];  // through the right-hand side rt[:25] - alpha
+    }
+    return acc;
+}
+template <int... Ms>
+__device__ __forceinline__ void rtbar_store(float* dst, const float (&gv)[mm::M1], const float (&uv)[mm::M1],
+                                            std::integer_sequence<int, Ms...>)
+{
+    ((dst[Ms] = rtbar_at<Ms>(gv, uv)), ...);
+}
+
+namespace mmb {
+using namespace mm;
+constexpr int WAVES = 4;
+constexpr int WAVE_FLOATS_B = 3 * 16 * RS;  // rt, rr and an exchange window per frame
+constexpr int LDS_FLOATS = WAVE_OFF + WAVES * WAVE_FLOATS_B;
+}  // namespace mmb
+
+__global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel(
+    const float* __restrict__ gmc, const float* __restrict__ X, const float* __restrict__ hist, long F, int n_iter,
+    const float* __restrict__ G, const float* __restrict__ D, const float* __restrict__ E,
+    const float* __restrict__ av, float* __restrict__ gX, long ntiles16)
+{
+    using namespace mmb;
+    constexpr float kNeg2Log2e = -2.885390081777926815f, kLn2 = 0.693147180559945309f;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+
+    // ---------------- operand images (identical to the forward kernel's) ----------------
+    for (int idx = tid; idx < 16 * 2 * 64 * 4; idx += WAVES * 64) {
+        int q = idx & 3, l = (idx >> 2) & 63, half = (idx >> 8) & 1, mt = idx >> 9;
+        int k = 4 * (half * 4 + q) + (l >> 4);
+        lds[DT_OFF + idx] = k < M1 ? kNeg2Log2e * D[k * K + mt * 16 + (l & 15)] : 0.f;
+    }
+    for (int idx = tid; idx < 3 * 16 * 64 * 4; idx += WAVES * 64) {
+        int r = idx & 3, l = (idx >> 2) & 63, mt = (idx >> 8) & 15, it = idx >> 12;
+        lds[ET_OFF + idx] = E[(mt * 16 + (l >> 4) * 4 + r) * M2 + it * 16 + (l & 15)];
+    }
+    {
+        int r = tid & 3, gg = (tid >> 2) & 3, mt = tid >> 4;
+        lds[E48_OFF + tid] = E[(mt * 16 + gg * 4 + r) * M2 + 48];
+    }
+    if (tid < 52) lds[E256_OFF + tid] = tid < M2 ? E[H * M2 + tid] : 0.f;
+    if (tid < 28) {
+        lds[D256_OFF + tid] = tid < M1 ? kNeg2Log2e * D[tid * K + H] : 0.f;
+        lds[AV_OFF + tid] = tid < M1 ? av[tid] : 0.f;
+    }
+    __syncthreads();
+
+    float* wave_lds = lds + WAVE_OFF + wave * WAVE_FLOATS_B;
+    float* win_n = wave_lds + n * RS;          // rt window of frame n (MFMA-layout view)
+    float* rr_n = win_n + 16 * RS;
+    float* aux_n = win_n + 32 * RS;            // exchange window
+    const int nq = lane >> 2, gs = lane & 3;   // solve layout: a quad per frame
+    float* win_q = wave_lds + nq * RS;
+    float* rr_q = win_q + 16 * RS;
+    float* aux_q = win_q + 32 * RS;
+    const GroupMask gq = make_group_mask(gs);
+    const f32x4* Dt4 = reinterpret_cast<const f32x4*>(lds + DT_OFF);
+    const f32x4* Et4 = reinterpret_cast<const f32x4*>(lds + ET_OFF);
+    const f32x4* E484 = reinterpret_cast<const f32x4*>(lds + E48_OFF);
+    const long wave_id = (long)blockIdx.x * WAVES + wave;
+    const long wave_stride = (long)gridDim.x * WAVES;
+    // gathers of the transposed-role operands out of the forward images:
+    //   E[bin = mt*16 + bl][out = 4ks + g]        = Et[((ks>>2)*16 + mt)*256 + 16*(ks&3) + eb_lane]
+    //   -2log2e D[coef = it2*16 + bl][bin = mt*16 + 4g + r] = Dt[(mt*2 + it2)*256 + db_lane + 4r]
+    const int bl = lane & 15;
+    const int eb_lane = ((bl >> 2) * 16 + g) * 4 + (bl & 3);
+    const int db_lane = ((bl & 3) * 16 + 4 * g) * 4 + (bl >> 2);
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)G, 0, K * M1 * 4, 0x00020000);
+
+    for (long tile = wave_id; tile < ntiles16; tile += wave_stride) {
+        const long f_raw = tile * 16 + n;
+        const bool f_ok = f_raw < F;
+        const long f = f_ok ? f_raw : F - 1;
+        const float* xf = X + f * K;
+        f32x4 logx[16], lbar[16];
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt) {
+            const float* p = xf + mt * 16 + 4 * g;
+            logx[mt] = f32x4{__log2f(p[0]), __log2f(p[1]), __log2f(p[2]), __log2f(p[3])};
+            lbar[mt] = f32x4{0, 0, 0, 0};
+        }
+        const float logx256 = __log2f(xf[H]);
+        float lbar256 = 0.f;
+        // mbar in the C/D layout of a 28-row product: tile it2, reg r <-> coefficient it2*16 + 4g + r
+        f32x4 mbarC[2];
+#pragma unroll
+        for (int it2 = 0; it2 < 2; ++it2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = it2 * 16 + 4 * g + r;
+                mbarC[it2][r] = c < M1 ? gmc[f * M1 + c] : 0.f;
+            }
+
+        for (int iter = n_iter - 1; iter >= 0; --iter) {
+            float mcB[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                mcB[ks] = (4 * ks + g < M1) ? hist[((long)iter * F + f) * M1 + 4 * ks + g] : 0.f;
+            // ---- forward quantities of this step: e (kept in registers), rt -> LDS windows ----
+            f32x4 e[16];
+            f32x4 accB[3] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+            float rt48 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) {
+                const f32x4 a0 = Dt4[(mt * 2 + 0) * 64 + lane];
+                const f32x4 a1 = Dt4[(mt * 2 + 1) * 64 + lane];
+                f32x4 pa = {0, 0, 0, 0}, qa = {0, 0, 0, 0};
+                pa = mfma4(a0[0], mcB[0], pa);
+                qa = mfma4(a1[0], mcB[4], qa);
+                pa = mfma4(a0[1], mcB[1], pa);
+                qa = mfma4(a1[1], mcB[5], qa);
+                pa = mfma4(a0[2], mcB[2], pa);
+                qa = mfma4(a1[2], mcB[6], qa);
+                pa = mfma4(a0[3], mcB[3], pa);
+                const f32x4 acc = pa + qa;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e[mt][r] = __builtin_amdgcn_exp2f(logx[mt][r] + acc[r]);
+                const f32x4 ea0 = Et4[(0 * 16 + mt) * 64 + lane];
+                const f32x4 ea1 = Et4[(1 * 16 + mt) * 64 + lane];
+                const f32x4 ea2 = Et4[(2 * 16 + mt) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    accB[0] = mfma4(ea0[r], e[mt][r], accB[0]);
+                    accB[1] = mfma4(ea1[r], e[mt][r], accB[1]);
+                    accB[2] = mfma4(ea2[r], e[mt][r], accB[2]);
+                }
+                const f32x4 c48 = E484[mt * 4 + g];
+                rt48 += e[mt][0] * c48[0] + e[mt][1] * c48[1] + e[mt][2] * c48[2] + e[mt][3] * c48[3];
+            }
+            float d256 = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) d256 += mcB[ks] * lds[D256_OFF + 4 * ks + g];
+            d256 += __shfl_xor(d256, 16, 64);
+            d256 += __shfl_xor(d256, 32, 64);
+            const float e256 = __builtin_amdgcn_exp2f(logx256 + d256);
+#pragma unroll
+            for (int it = 0; it < 3; ++it)
+                accB[it] = mfma4(g == 0 ? lds[E256_OFF + it * 16 + n] : 0.f, g == 0 ? e256 : 0.f, accB[it]);
+            rt48 += __shfl_xor(rt48, 16, 64);
+            rt48 += __shfl_xor(rt48, 32, 64);
+            rt48 += e256 * lds[E256_OFF + 48];
+#pragma unroll
+            for (int it = 0; it < 3; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = it * 16 + 4 * g + r;
+                    const float v = accB[it][r];
+                    win_n[idx] = v;
+                    if (idx <= 27) {
+                        rr_n[27 + idx] = v;
+                        rr_n[27 - idx] = v;
+                    }
+                }
+            if (g == 0) win_n[48] = rt48;
+            // mbar to the exchange window (C/D layout writer -> quad-layout reader)
+#pragma unroll
+            for (int it2 = 0; it2 < 2; ++it2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) aux_n[it2 * 16 + 4 * g + r] = mbarC[it2][r];
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- solve A [gv | uv] = [rt[:25] - alpha | mbar] in the quad layout ----
+            float gv[M1], uv[M1];
+            {
+                SymRows a;
+                float b[NR], b2[NR];
+                sym_build_rows<0>(a, b, win_q + gs, rr_q + 27 + gs, lds + AV_OFF, gs);
+#pragma unroll
+                for (int m = 0; m < NR; ++m) b2[m] = keep_if((4 * m + 3 < M1 || 4 * m + gs < M1) ? 0xffffffffu : 0u, aux_q[4 * m + gs]);
+                __builtin_amdgcn_wave_barrier();
+                sym2_elim_all(a, b, b2, gq, std::make_integer_sequence<int, M1>{});
+                sym2_backsub_all(a, b, b2, gv, uv, std::make_integer_sequence<int, M1>{});
+            }
+            // ---- rtbar (all 49 entries on every lane; lane 0 of the quad publishes them) ----
+            if (gs == 0) {
+                rtbar_store(aux_q, gv, uv, std::make_integer_sequence<int, M2>{});
+                aux_q[49] = 0.f;
+                aux_q[50] = 0.f;
+                aux_q[51] = 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+            float rtbB[13];
+#pragma unroll
+            for (int ks = 0; ks < 13; ++ks) rtbB[ks] = aux_n[4 * ks + g];
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- ebar^T = E rtbar^T ; zbar = ebar * e ; lbar += zbar ; mbar += (-2 D) zbar^T ----
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) {
+                f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 12; ++ks) {
+                    const float av_ = lds[ET_OFF + ((ks >> 2) * 16 + mt) * 256 + 16 * (ks & 3) + eb_lane];
+                    acc = mfma4(av_, rtbB[ks], acc);
+                }
+                acc = mfma4(g == 0 ? lds[E48_OFF + mt * 16 + bl] : 0.f, rtbB[12], acc);  // out = 48 (only g = 0 slot)
+                f32x4 zb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    zb[r] = acc[r] * e[mt][r];
+                    lbar[mt][r] += zb[r];
+                    zb[r] *= kLn2;  // the D image is scaled by -2 log2(e): (-2 log2e D)(ln2 zbar) = -2 D zbar
+                }
+#pragma unroll
+                for (int it2 = 0; it2 < 2; ++it2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        mbarC[it2] = mfma4(lds[DT_OFF + (mt * 2 + it2) * 256 + db_lane + 4 * r], zb[r], mbarC[it2]);
+            }
+            // Nyquist bin
+            float eb256 = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 13; ++ks) eb256 += rtbB[ks] * lds[E256_OFF + 4 * ks + g];  // slots 49..51 are 0
+            eb256 += __shfl_xor(eb256, 16, 64);
+            eb256 += __shfl_xor(eb256, 32, 64);
+            const float zb256 = eb256 * e256;
+            lbar256 += zb256;
+#pragma unroll
+            for (int it2 = 0; it2 < 2; ++it2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = it2 * 16 + 4 * g + r;
+                    if (c < 28) mbarC[it2][r] += (zb256 * kLn2) * lds[D256_OFF + c];
+                }
+        }
+
+        // ---- lbar += G mbar_0 (mcep.py:204-207 adjoint); gX = lbar / X ----
+#pragma unroll
+        for (int it2 = 0; it2 < 2; ++it2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) aux_n[it2 * 16 + 4 * g + r] = mbarC[it2][r];
+        __builtin_amdgcn_wave_barrier();
+        float m0B[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) m0B[ks] = (4 * ks + g < M1) ? aux_n[4 * ks + g] : 0.f;
+        __builtin_amdgcn_wave_barrier();
+        const int gvoff = (bl * M1 + g) * 4;
+        float part256 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c = 4 * ks + g;
+            const float g256 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, (c < M1 ? c : 0) * 4, H * M1 * 4, 0));
+            part256 += (c < M1 ? g256 : 0.f) * m0B[ks];
+        }
+        part256 += __shfl_xor(part256, 16, 64);
+        part256 += __shfl_xor(part256, 32, 64);
+        lbar256 += part256;
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt) {
+            f32x4 acc = lbar[mt];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float gvv = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, gvoff, (mt * 16 * M1 + 4 * ks) * 4, 0));
+                acc = mfma4((4 * ks + g < M1) ? gvv : 0.f, m0B[ks], acc);
+            }
+            if (f_ok) {
+                float* dst = gX + f * K + mt * 16 + 4 * g;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[r] = acc[r] * __builtin_amdgcn_exp2f(-logx[mt][r]);
+            }
+        }
+        if (f_ok && g == 0) gX[f * K + H] = lbar256 * __builtin_amdgcn_exp2f(-logx256);
+    }
+}
+
+int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* G, const void* D,
+                  const void* E, const void* av, void* gX, hipStream_t st)
+{
+    const int lds_bytes = mmb::LDS_FLOATS * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)mcep_mfma_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_bytes) != hipSuccess)
+            return fail(DSA_ERR_LAUNCH, "mcep_mfma_bwd: cannot reserve the LDS operand images%s");
+        attr_set = true;
+    }
+    long ntiles16 = (long)((F + 15) / 16);
+    long blocks = (ntiles16 + mmb::WAVES - 1) / mmb::WAVES;
+    long grid = blocks < 256 ? blocks : 256;
+    hipLaunchKernelGGL(mcep_mfma_bwd_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, st, (const float*)gmc,
+                       (const float*)X, (const float*)hist, (long)F, n_iter, (const float*)G, (const float*)D,
+                       (const float*)E, (const float*)av, (float*)gX, ntiles16);
+    return check_launch("mcep_mfma_bwd");
+}
+
+// =====================================================================================
 // v3: role-split workgroup.  Waves 0-3 ("matrix" role) keep log X of TWO 16-frame groups in
 // registers and run only the MFMA chains + exp; waves 4-7 ("solver" role) own mc and run only
 // the build / elimination / back-substitution.  Wave w and wave w+4 sit on the same SIMD, whose

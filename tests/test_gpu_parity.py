@@ -447,9 +447,16 @@ def test_mcep_tuned_vs_generic_and_history(golden):
     for name in outs:
         err = np.abs(outs[name][1] - ref) / np.abs(ref).max(-1, keepdims=True)
         assert err.max() < 2e-3, name
+    # the MFMA backward agrees with the generic backward far inside the golden tolerance
+    errtg = np.abs(outs["tuned"][1] - outs["generic"][1]) / np.abs(ref).max(-1, keepdims=True)
+    assert errtg.max() < 2e-4
     # ragged tile: 37 frames (not a multiple of 64) through the tuned kernel
-    mc37 = ops.McepFn.apply(X[0, :37], m.G, m.D, m.E, m.alpha_vector, 512, 24, 10, _lib.ALGO_TUNED)
+    X37 = X[0, :37].clone().requires_grad_(True)
+    mc37 = ops.McepFn.apply(X37, m.G, m.D, m.E, m.alpha_vector, 512, 24, 10, _lib.ALGO_TUNED)
     close(host(mc37), g["mcep_f64"][0, :37], 1e-4, 2e-5)
+    (mc37 * torch.linspace(-1, 1, 25, device=DEV)).sum().backward()
+    err37 = np.abs(host(X37.grad) - ref[0, :37]) / np.abs(ref[0, :37]).max(-1, keepdims=True)
+    assert err37.max() < 2e-3
     with pytest.raises(_lib.BackendError):
         ops.McepFn.apply(X[0, :4].double(), m.G.double(), m.D.double(), m.E.double(), m.alpha_vector.double(),
                          512, 24, 10, _lib.ALGO_TUNED)
