@@ -16,6 +16,8 @@
 // against the float64 reference (tests/test_lpc_gpu.py states the tolerance).
 #include "common.h"
 
+#include <utility>
+
 namespace dsa {
 
 template <typename T>
@@ -273,6 +275,144 @@ __global__ void frame_window_lpc_kernel(const T* __restrict__ x, long Tlen, long
     levinson_wave_reg<T>(r_lane, M, eps, out + f * (M + 1));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tuned fused Frame -> Window -> autocorrelation -> Levinson for float32 input, lpc_order 24,
+// frame_length <= 512 (README.md:198-201 of the reference; BASELINE configs[3]).
+//   * one wave64 per workgroup owns up to 64 consecutive frames of one utterance;
+//   * autocorrelation: 4 frames per pass (16 lanes each) out of one LDS-resident stretch of
+//     3P + L samples (each sample read from HBM once); lane j of a frame owns a contiguous run of
+//     samples, keeps 25 + 24 windowed samples in registers (as float64: products of float32 are
+//     exact) and accumulates its 25 lag sums with 625 statically indexed float64 FMAs per 25-sample
+//     block; the 16 partials are added by an xor butterfly;
+//   * Levinson-Durbin: one frame per LANE for all 64 frames at once, float64, fully unrolled in
+//     registers (no cross-lane traffic at all), then [K, a_1..a_24] is written out.
+// dynamic LDS: in_buf[(3P + L) rounded] floats | wtab[L + 64] floats | rbuf[64][25] doubles
+constexpr int kLpcM1 = 25;
+
+template <int... Is>
+__device__ __forceinline__ void lag_block(double (&acc)[kLpcM1], const double (&xw)[2 * kLpcM1 - 1],
+                                          std::integer_sequence<int, Is...>)
+{
+    // acc[m] += xw[i] * xw[i + m] for i, m in 0..24, flattened (Is = 25 i + m)
+    ((acc[Is % kLpcM1] = __builtin_fma(xw[Is / kLpcM1], xw[Is / kLpcM1 + Is % kLpcM1], acc[Is % kLpcM1])), ...);
+}
+
+__global__ __launch_bounds__(64, 2) void frame_window_lpc24_kernel(
+    const float* __restrict__ x, long Tlen, long N, int L, int P, int left, int mode,
+    const float* __restrict__ w, double eps, float* __restrict__ out, long total_sc, int sc_per_utt,
+    int in_floats, int wtab_floats)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* in_buf = reinterpret_cast<float*>(smem_raw);
+    float* wtab = in_buf + in_floats;
+    double* rbuf = reinterpret_cast<double*>(wtab + wtab_floats);
+    const int lane = threadIdx.x;
+    const int j = lane & 15, fl = lane >> 4;
+    const int C = (L + 15) >> 4;                       // samples per lane
+    const int nblk = (C + kLpcM1 - 1) / kLpcM1;        // 25-sample blocks per lane
+    for (int l = lane; l < wtab_floats; l += 64) wtab[l] = l < L ? w[l] : 0.f;
+
+    for (long sc = blockIdx.x; sc < total_sc; sc += gridDim.x) {
+        const long b = sc / sc_per_utt;
+        const long fbase = (sc - b * sc_per_utt) * 64;
+        const int nfr = (int)((N - fbase) < 64 ? (N - fbase) : 64);
+        const float* xb = x + b * Tlen;
+        const int npass = (nfr + 3) >> 2;
+        for (int p = 0; p < npass; ++p) {
+            const long frame0 = fbase + 4 * p;
+            const int nvalid = (int)((N - frame0) < 4 ? (N - frame0) : 4);
+            __syncthreads();
+            {   // stage the shared stretch; zero-fill what the lanes may read beyond it
+                const long g0 = frame0 * P - left;
+                const int need = (nvalid - 1) * P + L;
+                const bool interior = g0 >= 0 && g0 + need <= Tlen;
+                if (interior && (((size_t)(xb + g0)) & 15) == 0 && (need & 3) == 0) {
+                    const float4* src4 = reinterpret_cast<const float4*>(xb + g0);
+                    float4* dst4 = reinterpret_cast<float4*>(in_buf);
+                    for (int sidx = lane; sidx < (need >> 2); sidx += 64) dst4[sidx] = src4[sidx];
+                } else {
+                    for (int sidx = lane; sidx < need; sidx += 64) in_buf[sidx] = load_padded(xb, g0 + sidx, Tlen, mode);
+                }
+                for (int sidx = need + lane; sidx < in_floats; sidx += 64) in_buf[sidx] = 0.f;
+            }
+            __syncthreads();
+            double acc[kLpcM1];
+#pragma unroll
+            for (int m = 0; m < kLpcM1; ++m) acc[m] = 0.0;
+            const float* fsrc = in_buf + fl * P;
+            for (int blk = 0; blk < nblk; ++blk) {
+                const int t0 = j * C + blk * kLpcM1;  // this lane's block start within the frame
+                const int own = C - blk * kLpcM1;     // samples of the block that belong to the lane
+                double xw[2 * kLpcM1 - 1];
+#pragma unroll
+                for (int i = 0; i < 2 * kLpcM1 - 1; ++i) {
+                    const int t = t0 + i;
+                    // window.py:190 in float32 (as the reference), then exact promotion; zero past the
+                    // frame, and zero for "own" positions that belong to the next lane (i >= own)
+                    const float v = (t < L) ? fsrc[t] * wtab[t] : 0.f;
+                    xw[i] = (double)v;
+                }
+                if (own >= kLpcM1) {
+                    lag_block(acc, xw, std::make_integer_sequence<int, kLpcM1 * kLpcM1>{});
+                } else {
+                    // partial last block: the leading factor stops at the end of the lane's own run
+#pragma unroll
+                    for (int i = 0; i < kLpcM1; ++i) {
+                        const double li = i < own ? xw[i] : 0.0;
+#pragma unroll
+                        for (int m = 0; m < kLpcM1; ++m) acc[m] = __builtin_fma(li, xw[i + m], acc[m]);
+                    }
+                }
+            }
+            // add the 16 lanes of the frame (xor butterfly inside the 16-lane group)
+#pragma unroll
+            for (int m = 0; m < kLpcM1; ++m) {
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) acc[m] += __shfl_xor(acc[m], o, 16);
+            }
+            if (fl < nvalid) {
+                double* rrow = rbuf + (size_t)(4 * p + fl) * kLpcM1;
+#pragma unroll
+                for (int m = 0; m < kLpcM1; ++m)
+                    if ((m & 15) == j) rrow[m] = acc[m];  // lane j stores lags j and j + 16
+            }
+        }
+        __syncthreads();
+        // ---- Levinson-Durbin, one frame per lane (levdur.py:113-127 as a recursion) ----
+        if (lane < nfr) {
+            double r[kLpcM1], a[kLpcM1];
+#pragma unroll
+            for (int m = 0; m < kLpcM1; ++m) {
+                r[m] = rbuf[(size_t)lane * kLpcM1 + m];
+                a[m] = 0.0;
+            }
+            double Ecur = r[0] + eps;
+#pragma unroll
+            for (int m = 1; m < kLpcM1; ++m) {
+                double s = r[m];
+#pragma unroll
+                for (int q = 1; q < m; ++q) s = __builtin_fma(a[q], r[m - q], s);
+                const double kk = -s / Ecur;
+#pragma unroll
+                for (int q = 1; 2 * q <= m; ++q) {
+                    const double aq = a[q], amq = a[m - q];
+                    a[q] = __builtin_fma(kk, amq, aq);
+                    if (q != m - q) a[m - q] = __builtin_fma(kk, aq, amq);
+                }
+                a[m] = kk;
+                Ecur *= (1.0 - kk * kk);
+            }
+            double gsum = r[0];  // un-regularised r0 (levdur.py:124)
+#pragma unroll
+            for (int m = 1; m < kLpcM1; ++m) gsum = __builtin_fma(r[m], a[m], gsum);
+            float* o = out + ((b * N + fbase + lane) * (long)kLpcM1);
+            o[0] = (float)sqrt(gsum);
+#pragma unroll
+            for (int m = 1; m < kLpcM1; ++m) o[m] = (float)a[m];
+        }
+    }
+}
+
 template <typename T>
 static int acorr_fwd_impl(const void* x, int64_t F, int L, int M, int fmt, void* r, hipStream_t st)
 {
@@ -424,6 +564,23 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
     if (F == 0) return DSA_OK;
     int left = center ? L / 2 : 0;
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSA_F32 && M == 24 && L <= 512 && L >= 25) {
+        int in_floats = ((3 * P + L + 64 + kLpcM1 * 2) + 3) & ~3;
+        int wtab_floats = (L + 64 + 3) & ~3;
+        size_t lds_t = (size_t)(in_floats + wtab_floats) * 4 + 64 * kLpcM1 * sizeof(double);
+        if (lds_t <= 60 * 1024) {
+            int sc_per_utt = (int)((N + 63) / 64);
+            long total_sc = (long)B * sc_per_utt;
+            int waves_per_cu = (int)(144 * 1024 / lds_t);
+            if (waves_per_cu > 8) waves_per_cu = 8;
+            long grid = 256L * waves_per_cu;
+            if (grid > total_sc) grid = total_sc;
+            hipLaunchKernelGGL(frame_window_lpc24_kernel, dim3((unsigned)grid), dim3(64), lds_t, st, (const float*)x,
+                               (long)T, (long)N, L, P, left, pad_mode, (const float*)w, eps, (float*)out, total_sc,
+                               sc_per_utt, in_floats, wtab_floats);
+            return check_launch("frame_window_lpc24_fwd");
+        }
+    }
     const int nw = 4;
     size_t esz = dtype == DSA_F32 ? 4 : 8;
     size_t lds = (size_t)L * esz * nw;
