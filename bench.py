@@ -45,6 +45,18 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.
 FP32_PEAK_TFLOPS = 157.3    # fp32 MFMA dense peak = fp32 vector peak (same guide)
 
 
+def pmc_traffic(kernel: str, frames: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected separately and corrected as MI355X_MICROARCH.md prescribes), rescaled to
+    this launch's frame count; None when no counter file covers the kernel."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            k = json.load(f)["kernels"][kernel]
+        return k["hbm_bytes_per_launch"] * frames / k["frames_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(seconds_budget: float = 12.0):
     """Reference CPU path (stock ATen ops, oracle/torch_port.py) on a bounded sample."""
     from oracle import torch_port as TP
@@ -182,7 +194,7 @@ def main():
                 "achieved": MCEP_FLOP_PER_FRAME * frames_rank / t_mcep / 1e12,
                 "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": MCEP_FLOP_PER_FRAME * frames_rank / t_mcep / 1e12 / FP32_PEAK_TFLOPS,
-                "traffic": None, "avg_launch_ms": t_mcep * 1e3,
+                "traffic": pmc_traffic(kernels["mcep"], frames_rank), "avg_launch_ms": t_mcep * 1e3,
                 "flop_per_frame": MCEP_FLOP_PER_FRAME,
                 "note": "fp32 MFMA dense peak == fp32 vector peak (157.3 TFLOP/s); flops are the composed-matrix "
                         "algorithm's (DESIGN.md), lower than the reference formulation's 0.71-0.75 MFLOP/frame",
@@ -192,7 +204,9 @@ def main():
                 "achieved": STFT_BYTES_PER_FRAME * frames_rank / t_stft / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": STFT_BYTES_PER_FRAME * frames_rank / t_stft / 1e9 / HBM_PEAK_GBS,
-                "traffic": None, "avg_launch_ms": t_stft * 1e3, "bytes_per_frame": STFT_BYTES_PER_FRAME,
+                "traffic": pmc_traffic(kernels["stft"], frames_rank), "avg_launch_ms": t_stft * 1e3,
+                "bytes_per_frame": STFT_BYTES_PER_FRAME,
+                "traffic_note": "bytes per launch from profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
