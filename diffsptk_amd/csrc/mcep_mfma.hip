@@ -486,11 +486,106 @@ __device__ __forceinline__ void sym_build_rows(SymRows& a, float (&b)[mm::NR], c
 
 // WAVES = 4: one wave per SIMD with the whole 512-entry register file (no spills);
 // WAVES = 8: two waves per SIMD at <= 256 registers (log X spills to scratch).
+// ---------------------------------------------------------------------------------------------
+// Column-cyclic symmetric elimination in the quad layout.  Lane gs of a quad owns COLUMNS
+// j = gs + 4c (c = 0..6) of every row; row i keeps its entries c >= i >> 2 (upper triangle plus at
+// most three harmless sub-diagonal ones): 109 registers.  At step k the pivot row's own-column
+// entries are already local; only the 24 - k multipliers a[k][i] / a[k][k] (by symmetry elements of
+// the pivot ROW) are broadcast, each from the lane that owns column i -- no lane-dependent
+// selection anywhere.  Column 25 (lane 1, slot c = 6) carries the right-hand side and column 26
+// (lane 2, slot c = 6) an optional second one, so they ride along the row updates for free.
+// ---------------------------------------------------------------------------------------------
+namespace colm {
+using namespace mm;
+constexpr int row_len(int i) { return 7 - (i >> 2); }
+constexpr int row_off(int i)
+{
+    int o = 0;
+    for (int q = 0; q < i; ++q) o += row_len(q);
+    return o;
+}
+constexpr int TOTAL = row_off(M1);  // 109
+}  // namespace colm
+#define COL_AT(a, i, c) (a)[colm::row_off(i) + (c) - ((i) >> 2)]
+
+// rt0 / rr0: un-shifted windows of this lane's frame; rhs2: second right-hand side (or nullptr)
+template <int i>
+__device__ __forceinline__ void col_build_rows(float (&a)[colm::TOTAL], const float* rt0, const float* rr0,
+                                               const float* avs, const float* rhs2, int gs, const GroupMask& gq)
+{
+    using namespace mm;
+    if constexpr (i < M1) {
+        const float* rt_g = rt0 + gs;
+        const float* rr_g = rr0 + 27 - gs;
+        // entry (i, j = gs + 4c): R[i][j] + Q[i][j] = rr[27 + i - j] + rt[i + j]  (mcep.py:219-221)
+#pragma unroll
+        for (int c = i >> 2; c < 6; ++c) COL_AT(a, i, c) = rt_g[i + 4 * c] + rr_g[i - 4 * c];
+        const float v24 = rt_g[i + 24] + rr_g[i - 24];   // column 24 exists on lane 0 only
+        const float r1 = rt0[i] - avs[i];                // mcep.py:216-217
+        const float r2 = rhs2 ? rhs2[i] : 0.f;
+        COL_AT(a, i, 6) = sel4(gq, v24, r1, r2, 0.f);
+        col_build_rows<i + 1>(a, rt0, rr0, avs, rhs2, gs, gq);
+    }
+}
+
+template <int k, int i>
+__device__ __forceinline__ void col_update_rows(float (&a)[colm::TOTAL], float inv)
+{
+    using namespace mm;
+    if constexpr (i < M1) {
+        // multiplier a[i][k] / a[k][k] = a[k][i] / a[k][k]: column i of the pivot row lives on lane i & 3
+        const float mi = quad_bcast<(i & 3)>(COL_AT(a, k, i >> 2)) * inv;
+#pragma unroll
+        for (int c = i >> 2; c < 7; ++c) COL_AT(a, i, c) -= mi * COL_AT(a, k, c);
+        col_update_rows<k, i + 1>(a, inv);
+    }
+}
+template <int k>
+__device__ __forceinline__ void col_elim_step(float (&a)[colm::TOTAL])
+{
+    const float inv = rcp_nr(quad_bcast<(k & 3)>(COL_AT(a, k, k >> 2)));
+    col_update_rows<k, k + 1>(a, inv);
+}
+template <int... Ks>
+__device__ __forceinline__ void col_elim_all(float (&a)[colm::TOTAL], std::integer_sequence<int, Ks...>)
+{
+    (col_elim_step<Ks>(a), ...);
+}
+
+// back substitution of right-hand side RHS (1 or 2): xq[c] accumulates x[gs + 4c]; the slot of the
+// right-hand-side column is preset to -1 on its owner lane, so  sum_j U[k][j] x_j - b_k  is one dot product
+template <int k>
+__device__ __forceinline__ float col_backsub_step(const float (&a)[colm::TOTAL], float (&xq)[mm::KS],
+                                                  const GroupMask& gq)
+{
+    float sl = 0.f;
+#pragma unroll
+    for (int c = k >> 2; c < 7; ++c) sl = __builtin_fmaf(COL_AT(a, k, c), xq[c], sl);
+    sl += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sl), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+    sl += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sl), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+    const float xk = -sl * rcp_nr(quad_bcast<(k & 3)>(COL_AT(a, k, k >> 2)));
+    xq[k >> 2] = __uint_as_float(__float_as_uint(xq[k >> 2]) | (__float_as_uint(xk) & gq.m[k & 3]));
+    return xk;
+}
+template <int... Ks>
+__device__ __forceinline__ void col_backsub_all(const float (&a)[colm::TOTAL], float (&xq)[mm::KS],
+                                                const GroupMask& gq, std::integer_sequence<int, Ks...>)
+{
+    ((void)col_backsub_step<mm::M1 - 1 - Ks>(a, xq, gq), ...);
+}
+template <int... Ks>
+__device__ __forceinline__ void col_backsub_full(const float (&a)[colm::TOTAL], float (&xq)[mm::KS],
+                                                 float (&xv)[mm::M1], const GroupMask& gq,
+                                                 std::integer_sequence<int, Ks...>)
+{
+    ((xv[mm::M1 - 1 - Ks] = col_backsub_step<mm::M1 - 1 - Ks>(a, xq, gq)), ...);
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2(
     const float* __restrict__ X, long F, int n_iter, const float* __restrict__ G,
     const float* __restrict__ D, const float* __restrict__ E, const float* __restrict__ av,
-    float* __restrict__ mc_out, float* __restrict__ hist, long ntiles16)
+    float* __restrict__ mc_out, float* __restrict__ hist, long ntiles16, unsigned int* __restrict__ queue)
 {
     using namespace mm2;
     // exp(ln X - 2 d) = exp2(log2 X - 2 log2(e) d): log2 / exp2 are single gfx950 instructions, so
@@ -538,7 +633,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2
     float* rt_q = lds + WAVE_OFF + wave * WAVE_FLOATS + nq * RS;
     float* rr_q = rt_q + 16 * RS;
 
-    for (long tile = wave_id; tile < ntiles16; tile += wave_stride) {
+    // dynamic tile queue: the first round is static (tile = wave slot), later tiles are drawn from a
+    // device counter, so the tail of a launch is one tile long instead of a whole static round
+    for (long tile = wave_id; tile < ntiles16;) {
         const long f_raw = tile * 16 + n;
         const bool f_ok = f_raw < F;
         const long f = f_ok ? f_raw : F - 1;  // tail lanes recompute the last frame, never store
@@ -698,15 +795,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2
             DSA_STAMP(2);
 
             // ------------- local rows of R + Q, symmetric elimination, back substitution -------------
-            SymRows a;
-            float b[NR];
-            sym_build_rows<0>(a, b, rt_q + gs, rr_q + 27 + gs, lds + AV_OFF, gs);
+            float a[colm::TOTAL];
+            col_build_rows<0>(a, rt_q, rr_q, lds + AV_OFF, (const float*)nullptr, gs, gq);
             __builtin_amdgcn_wave_barrier();
             DSA_STAMP(3);
-            sym_elim_all(a, b, nq, gq, std::make_integer_sequence<int, M1>{});
+            col_elim_all(a, std::make_integer_sequence<int, M1>{});
             DSA_STAMP(4);
-            float xq[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // xq[ks] = x[4 ks + gs] of frame nq
-            sym_backsub_all(a, b, xq, nq, gq, std::make_integer_sequence<int, M1>{});
+            // xq[ks] = x[4 ks + gs] of frame nq; slot 6 of lane 1 is the right-hand-side column (x = -1)
+            float xq[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[1], -1.f)};
+            col_backsub_all(a, xq, gq, std::make_integer_sequence<int, M1>{});
+            xq[6] = keep_if(gq.m[0], xq[6]);  // only lane 0's slot 6 is a solution component (x[24])
             // back to the MFMA layout through the (now free) rt window: mc += x  (mcep.py:222)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) rt_q[4 * ks + gs] = xq[ks];
@@ -724,6 +822,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 if (4 * ks + g < M1) mc_out[f * M1 + 4 * ks + g] = mcB[ks];
+        unsigned int nxt = 0;
+        if (lane == 0) nxt = atomicAdd(queue, 1u);
+        tile = wave_stride + (long)__builtin_amdgcn_readfirstlane((int)nxt);
     }
 }
 
@@ -995,17 +1096,17 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel(
                 for (int r = 0; r < 4; ++r) aux_n[it2 * 16 + 4 * g + r] = mbarC[it2][r];
             __builtin_amdgcn_wave_barrier();
 
-            // ---- solve A [gv | uv] = [rt[:25] - alpha | mbar] in the quad layout ----
+            // ---- solve A [gv | uv] = [rt[:25] - alpha | mbar] in the quad layout (column-cyclic) ----
             float gv[M1], uv[M1];
             {
-                SymRows a;
-                float b[NR], b2[NR];
-                sym_build_rows<0>(a, b, win_q + gs, rr_q + 27 + gs, lds + AV_OFF, gs);
-#pragma unroll
-                for (int m = 0; m < NR; ++m) b2[m] = keep_if((4 * m + 3 < M1 || 4 * m + gs < M1) ? 0xffffffffu : 0u, aux_q[4 * m + gs]);
+                float a[colm::TOTAL];
+                col_build_rows<0>(a, win_q, rr_q, lds + AV_OFF, aux_q, gs, gq);
                 __builtin_amdgcn_wave_barrier();
-                sym2_elim_all(a, b, b2, gq, std::make_integer_sequence<int, M1>{});
-                sym2_backsub_all(a, b, b2, gv, uv, std::make_integer_sequence<int, M1>{});
+                col_elim_all(a, std::make_integer_sequence<int, M1>{});
+                float xq1[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[1], -1.f)};
+                col_backsub_full(a, xq1, gv, gq, std::make_integer_sequence<int, M1>{});
+                float xq2[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[2], -1.f)};
+                col_backsub_full(a, xq2, uv, gq, std::make_integer_sequence<int, M1>{});
             }
             // ---- rtbar (all 49 entries on every lane; lane 0 of the quad publishes them) ----
             if (gs == 0) {
@@ -1381,6 +1482,18 @@ static int launch_v3(const void* X, int64_t F, int n_iter, const void* G, const 
     return check_launch("mcep_mfma_fwd_split");
 }
 
+// rotating pool of tile-queue counters (one per in-flight launch; zeroed on the launch stream)
+static unsigned int* queue_slot(hipStream_t st)
+{
+    static unsigned int* pool = nullptr;
+    static unsigned int next = 0;
+    constexpr unsigned int kSlots = 256;
+    if (!pool && hipMalloc((void**)&pool, kSlots * sizeof(unsigned int)) != hipSuccess) return nullptr;
+    unsigned int* q = pool + (next++ % kSlots);
+    if (hipMemsetAsync(q, 0, sizeof(unsigned int), st) != hipSuccess) return nullptr;
+    return q;
+}
+
 template <int WAVES>
 static int launch_v2(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E,
                      const void* av, void* mc, void* hist, hipStream_t st, const char* name)
@@ -1396,9 +1509,11 @@ static int launch_v2(const void* X, int64_t F, int n_iter, const void* G, const 
     long ntiles16 = (long)((F + 15) / 16);
     long blocks = (ntiles16 + WAVES - 1) / WAVES;
     long grid = blocks < 256 ? blocks : 256;  // one persistent workgroup per CU
+    unsigned int* queue = queue_slot(st);
+    if (!queue) return fail(DSA_ERR_LAUNCH, "mcep_mfma: cannot set up the tile queue%s");
     hipLaunchKernelGGL((mcep_mfma_fwd_kernel_v2<WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
                        (const float*)X, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
-                       (const float*)av, (float*)mc, (float*)hist, ntiles16);
+                       (const float*)av, (float*)mc, (float*)hist, ntiles16, queue);
     return check_launch(name);
 }
 
