@@ -528,23 +528,45 @@ __device__ __forceinline__ void col_build_rows(float (&a)[colm::TOTAL], const fl
     }
 }
 
+// acc += quad_bcast<Q>(s0) * s1 in ONE instruction: the DPP quad_perm broadcast is the src0 modifier
+// of v_fmac_f32 (hipcc CSEs builtin DPP moves into separate v_mov_b32_dpp instead of fusing them)
+template <int Q>
+__device__ __forceinline__ void fmac_quad_bcast(float& acc, float s0, float s1)
+{
+    if constexpr (Q == 0)
+        asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(s0), "v"(s1));
+    else if constexpr (Q == 1)
+        asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(s0), "v"(s1));
+    else if constexpr (Q == 2)
+        asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(s0), "v"(s1));
+    else
+        asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(s0), "v"(s1));
+}
+
 template <int k, int i>
-__device__ __forceinline__ void col_update_rows(float (&a)[colm::TOTAL], float inv)
+__device__ __forceinline__ void col_update_rows(float (&a)[colm::TOTAL], const float (&pneg)[7])
 {
     using namespace mm;
     if constexpr (i < M1) {
-        // multiplier a[i][k] / a[k][k] = a[k][i] / a[k][k]: column i of the pivot row lives on lane i & 3
-        const float mi = quad_bcast<(i & 3)>(COL_AT(a, k, i >> 2)) * inv;
+        // row_i -= (a[k][i] / a[k][k]) row_k.  The multiplier is element i of the pre-scaled pivot row
+        // (pneg = -row_k / a[k][k]), which lives on lane i & 3 of the quad
 #pragma unroll
-        for (int c = i >> 2; c < 7; ++c) COL_AT(a, i, c) -= mi * COL_AT(a, k, c);
-        col_update_rows<k, i + 1>(a, inv);
+        for (int c = i >> 2; c < 7; ++c) fmac_quad_bcast<(i & 3)>(COL_AT(a, i, c), pneg[(i >> 2) - (k >> 2)], COL_AT(a, k, c));
+        col_update_rows<k, i + 1>(a, pneg);
     }
 }
 template <int k>
 __device__ __forceinline__ void col_elim_step(float (&a)[colm::TOTAL])
 {
-    const float inv = rcp_nr(quad_bcast<(k & 3)>(COL_AT(a, k, k >> 2)));
-    col_update_rows<k, k + 1>(a, inv);
+    const float ninv = -rcp_nr(quad_bcast<(k & 3)>(COL_AT(a, k, k >> 2)));
+    float pneg[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = k >> 2; c < 7; ++c) pneg[c - (k >> 2)] = COL_AT(a, k, c) * ninv;
+    // VALU write -> DPP read of pneg needs 2 wait states, which hipcc cannot see inside inline asm; the
+    // dummy in/out operands pin the nop after the multiplies
+    asm volatile("s_nop 1"
+                 : "+v"(pneg[0]), "+v"(pneg[1]), "+v"(pneg[2]), "+v"(pneg[3]), "+v"(pneg[4]), "+v"(pneg[5]), "+v"(pneg[6]));
+    col_update_rows<k, k + 1>(a, pneg);
 }
 template <int... Ks>
 __device__ __forceinline__ void col_elim_all(float (&a)[colm::TOTAL], std::integer_sequence<int, Ks...>)
@@ -630,6 +652,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2
     // pivot-row broadcasts of the elimination are DPP quad_perm moves instead of ds_bpermute
     const int nq = lane >> 2, gs = lane & 3;
     const GroupMask gq = make_group_mask(gs);
+#ifdef DSA_MCEP_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_mcep_stamps[8] = __builtin_readcyclecounter();
+#endif
     float* rt_q = lds + WAVE_OFF + wave * WAVE_FLOATS + nq * RS;
     float* rr_q = rt_q + 16 * RS;
 
@@ -825,6 +850,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_v2
         unsigned int nxt = 0;
         if (lane == 0) nxt = atomicAdd(queue, 1u);
         tile = wave_stride + (long)__builtin_amdgcn_readfirstlane((int)nxt);
+#ifdef DSA_MCEP_TIMING
+        if (blockIdx.x == 0 && threadIdx.x == 0) { g_mcep_stamps[9] = __builtin_readcyclecounter(); g_mcep_stamps[10] += 1; }
+#endif
     }
 }
 
