@@ -540,8 +540,8 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
         int m = 2 * (i & 15) * (i >> 4);  // entry [k1 = i >> 4][j = i & 15]: W256^(j k1) = W512^(2 j k1)
         t256[i] = cf{twiddle[2 * m], twiddle[2 * m + 1]};
     }
-    const cf twA = cf{twiddle[2 * lane], twiddle[2 * lane + 1]};                // W512^lane
-    const cf twB = cf{twiddle[2 * (lane + 64)], twiddle[2 * (lane + 64) + 1]};  // W512^(lane+64)
+    const cf twA = cf{twiddle[2 * (lane + 1)], twiddle[2 * (lane + 1) + 1]};    // W512^(lane+1)
+    const cf twB = cf{twiddle[2 * (lane + 65)], twiddle[2 * (lane + 65) + 1]};  // W512^(lane+65)
     const float inv_L = 1.f / (float)L;
     const int K = 257;
     const bool complex_out = fmt == DSA_SPEC_COMPLEX;
@@ -577,18 +577,16 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
             const float* src = io_buf + fl * P + 2 * j;
             const int lim = L - 2 * j;  // element (m1, c) belongs to the frame iff 32 m1 + c < lim
             float sum = 0.f;
+            // all 16 LDS reads are issued back to back (reading past the frame stays inside the tile);
+            // samples past the frame are then selected away, never multiplied: zero padding is exact
+            // and non-finite neighbours stay out of frames that do not contain them
+            float2 raw[16];
+#pragma unroll
+            for (int m1 = 0; m1 < 16; ++m1) raw[m1] = make_float2(src[32 * m1], src[32 * m1 + 1]);
 #pragma unroll
             for (int m1 = 0; m1 < 16; ++m1) {
-                // samples past the frame are never touched: zero padding is exact and non-finite
-                // neighbours stay out of frames that do not contain them
-                float a0 = 0.f, a1 = 0.f;
-                if (32 * m1 + 32 <= L) {  // wave-uniform: whole group inside the frame
-                    a0 = src[32 * m1];
-                    a1 = src[32 * m1 + 1];
-                } else if (32 * m1 < L) {  // the one group straddling the frame end
-                    a0 = 32 * m1 < lim ? src[32 * m1] : 0.f;
-                    a1 = 32 * m1 + 1 < lim ? src[32 * m1 + 1] : 0.f;
-                }
+                const float a0 = 32 * m1 < lim ? raw[m1].x : 0.f;
+                const float a1 = 32 * m1 + 1 < lim ? raw[m1].y : 0.f;
                 v[m1] = cf{a0, a1};
                 if (ZMEAN) sum += a0 + a1;
             }
@@ -635,49 +633,64 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
         const long out0 = row0 * K;
         float* stage = io_buf;
         float2* y2 = reinterpret_cast<float2*>(y);
-        cf pa[kFPW][3], pb[kFPW][3];
+        // pairs (k, 256 - k) for k = 1..128: part 0 -> k = lane + 1, part 1 -> k = lane + 65 (lane 63
+        // gets the self-pair k = 128); bins 0 and 256 come from Z[0] alone: X[0] = re + im, X[256] = re - im
+        cf pa[kFPW][2], pb[kFPW][2], z0[kFPW];
 #pragma unroll
         for (int f = 0; f < kFPW; ++f) {
             const cf* z = zbuf + f * 256;
-            pa[f][0] = z[lane];
-            pb[f][0] = z[(256 - lane) & 255];
-            pa[f][1] = z[lane + 64];
-            pb[f][1] = z[192 - lane];
-            pa[f][2] = z[128];  // bin 128 pairs with itself (same value on every lane)
-            pb[f][2] = pa[f][2];
+            pa[f][0] = z[lane + 1];
+            pb[f][0] = z[255 - lane];
+            pa[f][1] = z[lane + 65];
+            pb[f][1] = z[191 - lane];
+            z0[f] = z[0];
         }
         __syncthreads();
         float fm[kFPW] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int f = 0; f < kFPW; ++f) {
 #pragma unroll
-            for (int part = 0; part < 3; ++part) {
-                // part 0: k = lane (0..63); part 1: k = lane + 64; part 2: k = 128 (stored by lane 0)
-                const int k = part == 0 ? lane : (part == 1 ? lane + 64 : 128);
-                const cf W = part == 0 ? twA : (part == 1 ? twB : cf{0.f, -1.f});
+            for (int part = 0; part < 2; ++part) {
+                const int k = part == 0 ? lane + 1 : lane + 65;
+                const cf W = part == 0 ? twA : twB;
                 const cf a = pa[f][part], bq = pb[f][part];
                 const cf S = {a.re + bq.re, a.im - bq.im};
                 const cf Dd = {a.re - bq.re, a.im + bq.im};
                 const cf Pp = cmul(W, Dd);
                 const cf X1 = {0.5f * (S.re + Pp.im), 0.5f * (S.im - Pp.re)};
                 const cf X2 = {0.5f * (S.re - Pp.im), 0.5f * (-S.im - Pp.re)};
-                const bool mine = part != 2 || lane == 0;
                 if (complex_out) {
-                    if (f < nvalid && ABL != 1 && mine) {
+                    if (f < nvalid && ABL != 1) {
                         y2[out0 + f * K + k] = make_float2(X1.re, X1.im);
-                        if (part != 2) y2[out0 + f * K + 256 - k] = make_float2(X2.re, X2.im);
+                        y2[out0 + f * K + 256 - k] = make_float2(X2.re, X2.im);
                     }
                 } else {
                     const float s1 = X1.re * X1.re + X1.im * X1.im + eps;  // spec.py:173
                     const float s2 = X2.re * X2.re + X2.im * X2.im + eps;
-                    if (mine) {
-                        stage[f * K + k] = s1;
-                        if (part != 2) stage[f * K + 256 - k] = s2;
-                    }
+                    stage[f * K + k] = s1;
+                    stage[f * K + 256 - k] = s2;
                     if (use_floor) {
                         const float mx = s1 > s2 ? s1 : s2;
                         fm[f] = mx > fm[f] ? mx : fm[f];
                     }
+                }
+            }
+            // the two real-valued end bins
+            const float x0 = z0[f].re + z0[f].im, x256 = z0[f].re - z0[f].im;
+            if (complex_out) {
+                if (f < nvalid && ABL != 1 && lane == 0) {
+                    y2[out0 + f * K] = make_float2(x0, 0.f);
+                    y2[out0 + f * K + 256] = make_float2(x256, 0.f);
+                }
+            } else {
+                const float s0 = x0 * x0 + eps, s256 = x256 * x256 + eps;
+                if (lane == 0) {
+                    stage[f * K] = s0;
+                    stage[f * K + 256] = s256;
+                }
+                if (use_floor) {
+                    const float mx = s0 > s256 ? s0 : s256;
+                    fm[f] = mx > fm[f] ? mx : fm[f];
                 }
             }
         }
