@@ -7,8 +7,8 @@ alpha=0.42, n_iter=10) on synthetic 16 kHz waveforms, one process per GPU.
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over this rank's shard of utterances (inputs resident in
-HBM): fused STFT kernel -> mel-cepstral analysis kernel -> (N > 1) ONE all-gather of the
-(B, 200, 25) features over RCCL.  Weak scaling: 1024 utterances x 1 s per GPU, so N = 8 is
+HBM): fused STFT kernel -> mel-cepstral analysis kernel -> (N > 1) all-gather of the (B, 200, 25)
+features over RCCL, issued per quarter-batch chunk so that it overlaps the next chunk's kernels.  Weak scaling: 1024 utterances x 1 s per GPU, so N = 8 is
 BASELINE.json configs[4] (batch 8192 sharded 8x) and N = 1 is its per-GPU shard.
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying, besides the headline
@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="utterances per GPU (weak scaling)")
+    ap.add_argument("--chunks", type=int, default=4, help="N > 1: utterance chunks per step (gather/compute overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--algo", choices=["auto", "generic", "tuned"], default="auto")
     args = ap.parse_args()
@@ -132,34 +133,43 @@ def main():
     stft = dsp.STFT(FL, FP, NFFT, device=dev)
     mcep = dsp.MelCepstralAnalysis(fft_length=NFFT, cep_order=M, alpha=ALPHA, n_iter=N_ITER, device=dev)
 
-    def step():
-        X = ops.StftFn.apply(x, stft.window, stft.twiddle, FL, FP, NFFT, True, False, "constant", 1e-9, None, 3, algo)
-        mc = ops.McepFn.apply(X, mcep.G, mcep.D, mcep.E, mcep.alpha_vector, NFFT, M, N_ITER, algo)
-        return all_gather_features(mc, B * world) if world > 1 else mc
+    from diffsptk_amd.dist import analyze_chunked_overlap
 
+    n_chunks = 1 if world == 1 else args.chunks
     kernels = {}
+    ev_log = []  # (stft_start, stft_end/mcep_start, mcep_end) HIP events of every launch pair in the timed region
+
+    def compute(xc, record=False):
+        """the hot path on one chunk of utterances; optionally bracketed by HIP events"""
+        if record:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+        X = ops.StftFn.apply(xc, stft.window, stft.twiddle, FL, FP, NFFT, True, False, "constant", 1e-9, None, 3, algo)
+        if record:
+            e[1].record()
+        else:
+            kernels["stft"] = _lib.last_kernel()
+        mc = ops.McepFn.apply(X, mcep.G, mcep.D, mcep.E, mcep.alpha_vector, NFFT, M, N_ITER, algo)
+        if record:
+            e[2].record()
+            ev_log.append((e, xc.size(0)))
+        else:
+            kernels["mcep"] = _lib.last_kernel()
+        return mc
+
+    def step(record=False):
+        # N > 1: features of chunk c are all-gathered (RCCL) while chunk c+1 is computed
+        return analyze_chunked_overlap(x, lambda xc: compute(xc, record), n_chunks)
+
     with torch.no_grad():
         for _ in range(max(args.warmup, 1)):
-            X = ops.StftFn.apply(x, stft.window, stft.twiddle, FL, FP, NFFT, True, False, "constant", 1e-9, None, 3, algo)
-            kernels["stft"] = _lib.last_kernel()
-            ops.McepFn.apply(X, mcep.G, mcep.D, mcep.E, mcep.alpha_vector, NFFT, M, N_ITER, algo)
-            kernels["mcep"] = _lib.last_kernel()
-            del X
-        for _ in range(args.warmup):
             step()
-        # per-kernel HIP events on the launch stream (torch's current stream), inside the timed region
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            ev[i][0].record()
-            X = ops.StftFn.apply(x, stft.window, stft.twiddle, FL, FP, NFFT, True, False, "constant", 1e-9, None, 3, algo)
-            ev[i][1].record()
-            mc = ops.McepFn.apply(X, mcep.G, mcep.D, mcep.E, mcep.alpha_vector, NFFT, M, N_ITER, algo)
-            ev[i][2].record()
-            out = all_gather_features(mc, B * world) if world > 1 else mc
+            out = step(record=True)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -171,8 +181,10 @@ def main():
     assert out.shape == (B * world, FRAMES_PER_UTT, M1) and bool(torch.isfinite(out).all())
 
     frames_rank = B * FRAMES_PER_UTT
-    t_stft = statistics.mean(e[0].elapsed_time(e[1]) for e in ev) * 1e-3
-    t_mcep = statistics.mean(e[1].elapsed_time(e[2]) for e in ev) * 1e-3
+    # average duration and frame count of ONE launch (a launch covers one chunk)
+    t_stft = statistics.mean(e[0].elapsed_time(e[1]) for e, _ in ev_log) * 1e-3
+    t_mcep = statistics.mean(e[1].elapsed_time(e[2]) for e, _ in ev_log) * 1e-3
+    frames_launch = statistics.mean(nb for _, nb in ev_log) * FRAMES_PER_UTT
     if rank == 0:
         res = {
             "metric": "frames/sec STFT->mcep (fl=400 fp=80 nfft=512 M=24)",
@@ -187,24 +199,25 @@ def main():
                             f"per GPU ({frames_rank} frames), alpha={ALPHA} n_iter={N_ITER}; N=8 is the full "
                             "8192-utterance batch; features all-gathered over RCCL when N>1",
                 "utterances_per_gpu": B, "global_batch": B * world, "frames_per_step": frames_rank * world,
-                "parallelism": f"dp{world}", "kernels": kernels,
+                "parallelism": f"dp{world}", "kernels": kernels, "chunks_per_step": n_chunks,
             },
             "roofline": {
                 "kernel": kernels["mcep"], "bound": "mfma",
-                "achieved": MCEP_FLOP_PER_FRAME * frames_rank / t_mcep / 1e12,
+                "achieved": MCEP_FLOP_PER_FRAME * frames_launch / t_mcep / 1e12,
                 "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": MCEP_FLOP_PER_FRAME * frames_rank / t_mcep / 1e12 / FP32_PEAK_TFLOPS,
-                "traffic": pmc_traffic(kernels["mcep"], frames_rank), "avg_launch_ms": t_mcep * 1e3,
+                "frac": MCEP_FLOP_PER_FRAME * frames_launch / t_mcep / 1e12 / FP32_PEAK_TFLOPS,
+                "traffic": pmc_traffic(kernels["mcep"], frames_launch), "avg_launch_ms": t_mcep * 1e3,
+                "frames_per_launch": frames_launch,
                 "flop_per_frame": MCEP_FLOP_PER_FRAME,
                 "note": "fp32 MFMA dense peak == fp32 vector peak (157.3 TFLOP/s); flops are the composed-matrix "
                         "algorithm's (DESIGN.md), lower than the reference formulation's 0.71-0.75 MFLOP/frame",
             },
             "roofline_stft": {
                 "kernel": kernels["stft"], "bound": "hbm",
-                "achieved": STFT_BYTES_PER_FRAME * frames_rank / t_stft / 1e9,
+                "achieved": STFT_BYTES_PER_FRAME * frames_launch / t_stft / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": STFT_BYTES_PER_FRAME * frames_rank / t_stft / 1e9 / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(kernels["stft"], frames_rank), "avg_launch_ms": t_stft * 1e3,
+                "frac": STFT_BYTES_PER_FRAME * frames_launch / t_stft / 1e9 / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(kernels["stft"], frames_launch), "avg_launch_ms": t_stft * 1e3,
                 "bytes_per_frame": STFT_BYTES_PER_FRAME,
                 "traffic_note": "bytes per launch from profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
             },

@@ -67,3 +67,31 @@ def analyze_sharded(x: torch.Tensor, compute: Callable[[torch.Tensor], torch.Ten
     lo, hi = shard_bounds(x.size(0), world, rank)
     local = compute(x[lo:hi])
     return all_gather_features(local, x.size(0), group) if gather else local
+
+
+def analyze_chunked_overlap(x_local: torch.Tensor, compute: Callable[[torch.Tensor], torch.Tensor], n_chunks: int = 4,
+                            group=None) -> torch.Tensor:
+    """Compute this rank's shard ``x_local`` (B_r, T) in ``n_chunks`` utterance chunks and all-gather
+    each chunk's features as soon as they exist, so the collective of chunk c runs (on RCCL's own
+    stream) while chunk c+1 is being computed.  Every rank must hold the same number of utterances.
+
+    Returns the gathered features (world * B_r, ...) in rank-major order -- the same tensor
+    ``all_gather_features(compute(x_local))`` returns, only the exchange is hidden behind compute.
+    """
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return compute(x_local)
+    world = dist.get_world_size(group)
+    B = x_local.size(0)
+    n_chunks = max(1, min(n_chunks, B))
+    bounds = [shard_bounds(B, n_chunks, c) for c in range(n_chunks)]
+    out = None
+    pending = []
+    for lo, hi in bounds:
+        feat = compute(x_local[lo:hi]).contiguous()
+        if out is None:
+            out = feat.new_empty((world, B, *feat.shape[1:]))
+        # rank r's chunk lands in out[r, lo:hi]: one contiguous destination per rank
+        pending.append((dist.all_gather([out[r, lo:hi] for r in range(world)], feat, group=group, async_op=True), feat))
+    for work, _keep in pending:
+        work.wait()
+    return out.reshape(world * B, *out.shape[2:])

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from diffsptk_amd.dist import all_gather_features, analyze_sharded, shard_bounds
+from diffsptk_amd.dist import all_gather_features, analyze_chunked_overlap, analyze_sharded, shard_bounds
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -53,6 +53,10 @@ def _worker(rank, world, port, B, q):
         ok = out.shape == (B, 15, 9) and loc.shape[0] == hi - lo and torch.equal(out[lo:hi], loc)
         again = all_gather_features(loc, B)
         ok = ok and torch.equal(again, out)
+        if B % world == 0:  # the overlapped variant needs equal shards
+            for nch in (1, 2, 3):
+                ov = analyze_chunked_overlap(x[lo:hi], compute, n_chunks=nch)
+                ok = ok and torch.equal(ov, out)
         if rank == 0:
             q.put((ok, out.numpy()))
     finally:
