@@ -424,6 +424,107 @@ __global__ void spec_ratio_kernel(const T* __restrict__ ab, const T* __restrict_
     }
 }
 
+// Backward of Spectrum with a denominator (spec.py:160-177): X = K |B| / |A| (or K / |A| when b is
+// absent), s = X^2 + eps -> floor -> format.  One block per row; B(w), A(w) recomputed by direct DFT.
+//   Xbar = 2 X sbar;  |B|bar = Xbar K / |A|;  |A|bar = -Xbar X / |A|;  Kbar = sum_k Xbar X / K
+//   bbar[l] = Re sum_k (|B|bar B/|B|) e^{+i theta k l}   (same for a[1:], a[0] = K gets Kbar)
+// dynamic LDS: (lb + la + 5K) elements of T.
+template <typename T>
+__global__ void spec_ratio_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ b, int lb,
+                                      const T* __restrict__ a, int la, int nfft, const T* __restrict__ twiddle,
+                                      T eps, int use_floor, T floor_lin, int fmt, T* __restrict__ gb,
+                                      T* __restrict__ ga)
+{
+    extern __shared__ unsigned char smem_raw[];
+    __shared__ T scratch[16];
+    const int K = nfft / 2 + 1;
+    T* bs = reinterpret_cast<T*>(smem_raw);
+    T* as = bs + lb;            // a1 = [1, a[1:]]
+    T* Bre = as + la;
+    T* Bim = Bre + K;
+    T* Are = Bim + K;
+    T* Aim = Are + K;
+    T* gsv = Aim + K;           // cotangent of s per bin, later Xbar
+    const long f = blockIdx.x;
+    const int Lb = lb < nfft ? lb : nfft, La = la < nfft ? la : nfft;
+    for (int l = threadIdx.x; l < lb; l += blockDim.x) bs[l] = b ? b[f * lb + l] : T(0);
+    for (int l = threadIdx.x; l < la; l += blockDim.x) as[l] = l == 0 ? T(1) : a[f * la + l];
+    __syncthreads();
+    const T gain = a[f * la];
+    T smax = 0;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        T br = 0, bi = 0, ar = 0, ai = 0;
+        int idx = 0;
+        for (int l = 0; l < (Lb > La ? Lb : La); ++l) {
+            const T c = twiddle[2 * idx], sn = twiddle[2 * idx + 1];
+            if (b && l < Lb) { br += bs[l] * c; bi += bs[l] * sn; }
+            if (l < La) { ar += as[l] * c; ai += as[l] * sn; }
+            idx += k;
+            if (idx >= nfft) idx -= nfft;
+        }
+        Bre[k] = br; Bim[k] = bi; Are[k] = ar; Aim[k] = ai;
+        const T ab = b ? dsa_sqrt(br * br + bi * bi) : T(1), aa = dsa_sqrt(ar * ar + ai * ai);
+        const T X = gain * ab / aa;
+        const T sv = X * X + eps;
+        smax = sv > smax ? sv : smax;
+    }
+    const T m = use_floor ? block_max(smax, scratch) : T(0);
+    const T fl = m * floor_lin;
+    __syncthreads();
+    T lost = 0;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const T ab = b ? dsa_sqrt(Bre[k] * Bre[k] + Bim[k] * Bim[k]) : T(1);
+        const T aa = dsa_sqrt(Are[k] * Are[k] + Aim[k] * Aim[k]);
+        const T X = gain * ab / aa;
+        const T sv = X * X + eps;
+        const bool floored = use_floor && sv < fl;
+        const T se = floored ? fl : sv;
+        T g = gy[f * K + k];
+        switch (fmt) {
+        case DSA_SPEC_DB: g *= T(4.342944819032518) / se; break;
+        case DSA_SPEC_LOGMAG: g *= T(0.5) / se; break;
+        case DSA_SPEC_MAG: g *= T(0.5) / dsa_sqrt(se); break;
+        default: break;
+        }
+        if (floored) { lost += g; g = 0; }
+        gsv[k] = g;
+    }
+    const T tot = use_floor ? block_sum(lost, scratch) * floor_lin : T(0);
+    __syncthreads();
+    T kacc = 0;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const T ab = b ? dsa_sqrt(Bre[k] * Bre[k] + Bim[k] * Bim[k]) : T(1);
+        const T aa = dsa_sqrt(Are[k] * Are[k] + Aim[k] * Aim[k]);
+        const T X = gain * ab / aa;
+        T gs = gsv[k];
+        if (use_floor && (X * X + eps) == m) gs += tot;
+        const T Xbar = T(2) * X * gs;
+        kacc += Xbar * ab / aa;                       // dX/dK = |B|/|A|
+        const T abar_b = Xbar * gain / aa;            // d/d|B|
+        const T abar_a = -Xbar * X / aa;              // d/d|A|
+        // complex cotangents of B and A through the amplitude (0 at an exact zero, like torch.abs)
+        const T sb = (b && ab > T(0)) ? abar_b / ab : T(0), sa = aa > T(0) ? abar_a / aa : T(0);
+        Bre[k] *= sb; Bim[k] *= sb; Are[k] *= sa; Aim[k] *= sa;
+    }
+    const T kbar = block_sum(kacc, scratch);
+    __syncthreads();
+    for (int l = threadIdx.x; l < (lb > la ? lb : la); l += blockDim.x) {
+        T accb = 0, acca = 0;
+        if (l < nfft) {
+            int idx = 0;
+            for (int k = 0; k < K; ++k) {
+                const T c = twiddle[2 * idx], sn = twiddle[2 * idx + 1];
+                accb += Bre[k] * c + Bim[k] * sn;
+                acca += Are[k] * c + Aim[k] * sn;
+                idx += l;
+                if (idx >= nfft) idx -= nfft;
+            }
+        }
+        if (gb && l < lb) gb[f * lb + l] = accb;
+        if (l < la) ga[f * la + l] = l == 0 ? kbar : acca;
+    }
+}
+
 // remove_gain (utils/private.py:200-209): a1 = [1, a[1:]]
 template <typename T>
 __global__ void remove_gain_kernel(const T* __restrict__ a, long F, int la, T* __restrict__ a1)
@@ -1348,10 +1449,27 @@ DSA_EXPORT int dsa_spec_bwd(const void* gy, const void* b, int32_t lb, const voi
 {
     DSA_REQUIRE(b || a, "spec_bwd: either b or a must be specified");
     DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "spec_bwd: fft_length must be positive even");
-    if (a || ga)
-        return fail(DSA_ERR_UNSUPPORTED, "spec_bwd: the denominator (a) branch has no backward kernel yet%s");
-    (void)la;
     hipStream_t st = (hipStream_t)stream;
+    if (a) {
+        DSA_REQUIRE(ga != nullptr, "spec_bwd: ga is required when a is given");
+        if (F == 0) return DSA_OK;
+        const int K = nfft / 2 + 1;
+        const size_t esz = dtype == DSA_F32 ? 4 : 8;
+        const size_t lds = esz * ((size_t)lb + la + 5 * (size_t)K);
+        if (lds > 60 * 1024) return fail(DSA_ERR_UNSUPPORTED, "spec_bwd: rows too long for LDS%s");
+        const double fl = use_floor ? pow(10.0, relative_floor_db / 10.0) : 0.0;
+        if (dtype == DSA_F32)
+            hipLaunchKernelGGL((spec_ratio_bwd_kernel<float>), dim3((unsigned)F), dim3(128), lds, st, (const float*)gy,
+                               (const float*)b, b ? lb : 0, (const float*)a, la, nfft, (const float*)twiddle, (float)eps,
+                               use_floor, (float)fl, out_format, (float*)gb, (float*)ga);
+        else if (dtype == DSA_F64)
+            hipLaunchKernelGGL((spec_ratio_bwd_kernel<double>), dim3((unsigned)F), dim3(128), lds, st, (const double*)gy,
+                               (const double*)b, b ? lb : 0, (const double*)a, la, nfft, (const double*)twiddle, eps,
+                               use_floor, fl, out_format, (double*)gb, (double*)ga);
+        else
+            return fail(DSA_ERR_UNSUPPORTED, "spec_bwd: unsupported dtype%s");
+        return check_launch("spec_ratio_bwd");
+    }
     if (dtype == DSA_F32)
         return launch_row_dft_bwd<float>(b, F, lb, 1, lb, lb, 0, 0, 0, nullptr, nfft, twiddle, 1, out_format, eps,
                                          use_floor, relative_floor_db, gy, gb, nullptr, st);

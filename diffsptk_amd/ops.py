@@ -187,19 +187,17 @@ class SpecFn(torch.autograd.Function):
     def backward(ctx, gy):
         bc, ac, twiddle = ctx.saved_tensors
         fft_length, eps, relative_floor_db, fmt = ctx.cfg
-        if ac is not None:
-            raise NotImplementedError(
-                "diffsptk_amd: backward through Spectrum's denominator (a) branch is not implemented"
-            )
         gy = gy.contiguous()
-        F = bc.numel() // bc.size(-1)
-        gb = torch.empty_like(bc)
+        ref = bc if bc is not None else ac
+        F = ref.numel() // ref.size(-1)
+        gb = torch.empty_like(bc) if bc is not None else None
+        ga = torch.empty_like(ac) if ac is not None else None
         use_floor = relative_floor_db is not None
         with torch.cuda.device(gy.device):
-            _call("dsa_spec_bwd", _p(gy), _p(bc), bc.size(-1), None, 0, F, fft_length, float(eps),
-                  int(use_floor), float(relative_floor_db or 0.0), fmt, _p(twiddle), _dtype_code(bc), _p(gb),
-                  None, _stream())
-        return gb, None, None, None, None, None, None
+            _call("dsa_spec_bwd", _p(gy), _p(bc), bc.size(-1) if bc is not None else 0, _p(ac),
+                  ac.size(-1) if ac is not None else 0, F, fft_length, float(eps), int(use_floor),
+                  float(relative_floor_db or 0.0), fmt, _p(twiddle), _dtype_code(ref), _p(gb), _p(ga), _stream())
+        return gb, ga, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------- STFT

@@ -162,6 +162,36 @@ def test_fftr_spec_backward_vs_autograd():
             close(host(xg.grad), xc.grad.numpy(), 1e-8, 1e-10)
 
 
+def test_spec_rational_branch_backward_vs_autograd():
+    """Spectrum with a denominator (spec.py:160-171): gradients wrt b and a (gain + coefficients)."""
+    gen = torch.Generator().manual_seed(21)
+    b = torch.randn(3, 6, dtype=torch.float64, generator=gen)
+    a = torch.randn(3, 5, dtype=torch.float64, generator=gen)
+    a[:, 0] = a[:, 0].abs() + 0.5
+    for o in ("db", "log-magnitude", "magnitude", "power"):
+        for rf in (None, -10):
+            for use_b in (True, False):
+                bg = b.to(DEV).requires_grad_(True) if use_b else None
+                ag = a.to(DEV).requires_grad_(True)
+                y = F.spec(bg, ag, fft_length=16, eps=0.01, relative_floor=rf, out_format=o)
+                wts = torch.randn(y.shape, dtype=torch.float64, generator=gen)
+                (y * wts.to(DEV)).sum().backward()
+                bc = b.clone().requires_grad_(True) if use_b else None
+                ac = a.clone().requires_grad_(True)
+                a1 = torch.cat([torch.ones(3, 1, dtype=torch.float64), ac[:, 1:]], -1)
+                den = torch.fft.rfft(a1, n=16).abs()
+                X = ac[:, :1] * (torch.fft.rfft(bc, n=16).abs() / den) if use_b else ac[:, :1] / den
+                sv = X.square() + 0.01
+                if rf is not None:
+                    sv = torch.maximum(sv, sv.amax(-1, keepdim=True) * 10 ** (rf / 10))
+                yr = {"db": 10 * torch.log10(sv), "log-magnitude": 0.5 * torch.log(sv), "magnitude": sv.sqrt(), "power": sv}[o]
+                close(host(y), yr.detach().numpy(), 1e-9, 1e-11)
+                (yr * wts).sum().backward()
+                close(host(ag.grad), ac.grad.numpy(), 1e-8, 1e-10)
+                if use_b:
+                    close(host(bg.grad), bc.grad.numpy(), 1e-8, 1e-10)
+
+
 # ----------------------------------------------------------------------------- a5 STFT
 def test_stft_small_generic_f64(golden):
     g = golden("grids")
