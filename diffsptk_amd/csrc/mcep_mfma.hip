@@ -1491,6 +1491,10 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_fwd_kernel_v3(
     }
 }
 
+}  // namespace dsa
+#include "mcep_mfma_f16.h"
+namespace dsa {
+
 static int launch_v3(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E,
                      const void* av, void* mc, void* hist, hipStream_t st)
 {
@@ -1545,6 +1549,29 @@ static int launch_v2(const void* X, int64_t F, int n_iter, const void* G, const 
     return check_launch(name);
 }
 
+template <int WAVES>
+static int launch_h(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E,
+                    const void* av, void* mc, void* hist, hipStream_t st, const char* name)
+{
+    const int lds_bytes = mh::h_lds_floats(WAVES) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)mcep_mfma_fwd_kernel_h<WAVES>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return fail(DSA_ERR_LAUNCH, "mcep_mfma: cannot reserve the LDS operand images%s");
+        attr_set = true;
+    }
+    long ntiles16 = (long)((F + 15) / 16);
+    long blocks = (ntiles16 + WAVES - 1) / WAVES;
+    long grid = blocks < 256 ? blocks : 256;  // one persistent workgroup per CU
+    unsigned int* queue = queue_slot(st);
+    if (!queue) return fail(DSA_ERR_LAUNCH, "mcep_mfma: cannot set up the tile queue%s");
+    hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
+                       (const float*)X, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
+                       (const float*)av, (float*)mc, (float*)hist, ntiles16, queue);
+    return check_launch(name);
+}
+
 int mcep_mfma_fwd(const void* X, int64_t F, int nfft, int M, int n_iter, const void* G, const void* D,
                   const void* E, const void* av, void* mc, void* hist, hipStream_t st)
 {
@@ -1572,6 +1599,7 @@ int mcep_mfma_fwd(const void* X, int64_t F, int nfft, int M, int n_iter, const v
                            (float*)mc, (float*)hist, ntiles);
         return check_launch("mcep_mfma_fwd_v1");
     }
+    if (variant == 16) return launch_h<8>(X, F, n_iter, G, D, E, av, mc, hist, st, "mcep_mfma_fwd_h");
     if (variant == 4) return launch_v2<4>(X, F, n_iter, G, D, E, av, mc, hist, st, "mcep_mfma_fwd_w4");
     if (variant == 3 && n_iter >= 1) return launch_v3(X, F, n_iter, G, D, E, av, mc, hist, st);
     return launch_v2<8>(X, F, n_iter, G, D, E, av, mc, hist, st, "mcep_mfma_fwd");

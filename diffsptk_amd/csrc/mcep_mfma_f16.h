@@ -1,0 +1,308 @@
+// Split-precision variant of the tuned mel-cepstral forward (included by mcep_mfma.hip).
+//
+// fp32 MFMA runs at the fp32 VECTOR rate and shares the vector datapath, so in
+// mcep_mfma_fwd_kernel_v2 the two matrix chains of a Newton step (d = mc D, rt = e E) cost as much
+// as the whole 25 x 25 solve.  binary16 MFMA is a separate unit, 16x faster per flop.  Here each
+// float32 operand is split into two binary16 pieces, x = hi + lo (|x - hi - lo| <= 2^-22 |x|), and a
+// product is three MFMAs accumulated in float32:  a b ~= ah bh + ah bl + al bh  (the dropped al bl
+// term is 2^-22 |a b|) -- float32-grade accuracy (tools/proto_f16split.py: error of the converged
+// mel-cepstrum against the float64 golden is unchanged), at 3/16 of the fp32 MFMA cost.
+//   * the constant operands (D^T, E^T images) are split once per workgroup into LDS, scaled by
+//     powers of two so that their lo pieces stay normal binary16 numbers;
+//   * mc is scaled by 2^10 (|mc| < 64 for any float32 power spectrum), e = exp2(t) by a per-frame
+//     power of two 2^(15 - ceil(max t)), so the largest e is in (2^14, 2^15] (binary16 max 65504);
+//     the scalings are exact and undone with v_ldexp_f32 / inside an FMA;
+//   * the k-slots of v_mfma_f32_16x16x32_f16 pair lane group g, element i of A with the same of B,
+//     so TWO 16-bin C/D tiles of the first chain are, converted and packed, ONE B operand of the
+//     second chain: as in the fp32 kernel, e never leaves registers.
+// Everything outside the two chains (log2 X, mc0 chain, Nyquist bin, rt[48], the quad-layout
+// elimination) is the code of mcep_mfma_fwd_kernel_v2.
+#pragma once
+
+namespace dsa {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+namespace mh {
+using namespace mm;
+constexpr float SD = 16.f;      // scale of the D^T image (|-2 log2(e) D| <= ~7)
+constexpr float SM = 1024.f;    // scale of mc
+constexpr float SE = 65536.f;   // scale of the E^T image (|E| <= ~0.01)
+constexpr int SE_LOG2 = 16;
+constexpr int EMAX_LOG2 = 15;   // largest scaled e is <= 2^15
+// LDS carve-up (float units; same region sizes as namespace mm: the binary16 hi + lo images take
+// exactly the room of one float32 image)
+constexpr int DH_OFF = 0;                    // [16 mt][64 lane] f16x8
+constexpr int DL_OFF = DH_OFF + 16 * 64 * 4;
+constexpr int EH_OFF = DL_OFF + 16 * 64 * 4;  // [3 it][8 j][64 lane] f16x8
+constexpr int EL_OFF = EH_OFF + 24 * 64 * 4;
+constexpr int H_E48 = EL_OFF + 24 * 64 * 4;  // [16 mt][4 g][4 r] float
+constexpr int H_E256 = H_E48 + 256;      // [48] scaled by SE, [48] = unscaled E[256][48]
+constexpr int H_D256 = H_E256 + 52;      // [32]
+constexpr int H_AV = H_D256 + 32;        // [28]
+constexpr int H_WAVE = H_AV + 28;
+constexpr int h_lds_floats(int waves) { return H_WAVE + waves * WAVE_FLOATS; }
+}  // namespace mh
+
+__device__ __forceinline__ f32x4 mfma_h(f16x8 a, f16x8 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// x = hi + lo in binary16 (round to nearest): two values at a time
+__device__ __forceinline__ void split2(float x0, float x1, f16x2& hi, f16x2& lo)
+{
+    hi = __builtin_convertvector(f32x2v{x0, x1}, f16x2);
+    lo = __builtin_convertvector(f32x2v{x0 - (float)hi[0], x1 - (float)hi[1]}, f16x2);
+}
+__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
+    const float* __restrict__ X, long F, int n_iter, const float* __restrict__ G,
+    const float* __restrict__ D, const float* __restrict__ E, const float* __restrict__ av,
+    float* __restrict__ mc_out, float* __restrict__ hist, long ntiles16, unsigned int* __restrict__ queue)
+{
+    using namespace mh;
+    constexpr float kNeg2Log2e = -2.885390081777926815f, kLn2 = 0.693147180559945309f;
+    constexpr float kInvSDM = 1.f / (SD * SM);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+
+    // ---------------- operand images (binary16 hi / lo): built once per workgroup ----------------
+    {
+        _Float16* dh = reinterpret_cast<_Float16*>(lds + DH_OFF);
+        _Float16* dl = reinterpret_cast<_Float16*>(lds + DL_OFF);
+        for (int idx = tid; idx < 16 * 64 * 8; idx += WAVES * 64) {
+            const int i = idx & 7, l = (idx >> 3) & 63, mt = idx >> 9;
+            const int k = 8 * (l >> 4) + i;  // k-slot (g, i) <-> coefficient 8 g + i
+            const float v = k < M1 ? (kNeg2Log2e * SD) * D[k * K + mt * 16 + (l & 15)] : 0.f;
+            split1(v, dh[idx], dl[idx]);
+        }
+        _Float16* eh = reinterpret_cast<_Float16*>(lds + EH_OFF);
+        _Float16* el = reinterpret_cast<_Float16*>(lds + EL_OFF);
+        for (int idx = tid; idx < 24 * 64 * 8; idx += WAVES * 64) {
+            const int i = idx & 7, l = (idx >> 3) & 63, j = (idx >> 9) & 7, it = idx >> 12;
+            // k-slot (g, i = 4 t + r) <-> bin 32 j + 16 t + 4 g + r: C/D register r of tile 2 j + t
+            const int bin = 32 * j + 16 * (i >> 2) + 4 * (l >> 4) + (i & 3);
+            const float v = SE * E[bin * M2 + it * 16 + (l & 15)];
+            split1(v, eh[idx], el[idx]);
+        }
+    }
+    {
+        const int t2 = tid & 255;
+        int r = t2 & 3, gg = (t2 >> 2) & 3, mt = t2 >> 4;
+        lds[H_E48 + t2] = E[(mt * 16 + gg * 4 + r) * M2 + 48];
+    }
+    if (tid < 48) lds[H_E256 + tid] = SE * E[H * M2 + tid];
+    if (tid == 48) lds[H_E256 + 48] = E[H * M2 + 48];
+    if (tid < 32) lds[H_D256 + tid] = tid < M1 ? kNeg2Log2e * D[tid * K + H] : 0.f;
+    if (tid < 28) lds[H_AV + tid] = tid < M1 ? av[tid] : 0.f;
+    __syncthreads();  // the only workgroup barrier
+
+    float* rt_lds = lds + H_WAVE + wave * WAVE_FLOATS + n * RS;
+    float* rr_lds = rt_lds + 16 * RS;
+    const f16x8* DH = reinterpret_cast<const f16x8*>(lds + DH_OFF);
+    const f16x8* DL = reinterpret_cast<const f16x8*>(lds + DL_OFF);
+    const f16x8* EH = reinterpret_cast<const f16x8*>(lds + EH_OFF);
+    const f16x8* EL = reinterpret_cast<const f16x8*>(lds + EL_OFF);
+    const f32x4* E484 = reinterpret_cast<const f32x4*>(lds + H_E48);
+    const long wave_id = (long)blockIdx.x * WAVES + wave;
+    const long wave_stride = (long)gridDim.x * WAVES;
+    const int nq = lane >> 2, gs = lane & 3;
+    const GroupMask gq = make_group_mask(gs);
+    const unsigned g_lt3 = g < 3 ? 0xffffffffu : 0u;
+    float* rt_q = lds + H_WAVE + wave * WAVE_FLOATS + nq * RS;
+    float* rr_q = rt_q + 16 * RS;
+
+    for (long tile = wave_id; tile < ntiles16;) {
+        const long f_raw = tile * 16 + n;
+        const bool f_ok = f_raw < F;
+        const long f = f_ok ? f_raw : F - 1;
+        const float* xf = X + f * K;
+
+        f32x4 logx[16];
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt) {
+            const float* p = xf + mt * 16 + 4 * g;
+            logx[mt] = f32x4{__log2f(p[0]), __log2f(p[1]), __log2f(p[2]), __log2f(p[3])};  // mcep.py:203 (base 2)
+        }
+        const float logx256 = __log2f(xf[H]);
+
+        // ---------------- mc0^T = G^T logx^T  (mcep.py:204-207), float32 MFMA ----------------
+        // mcv[i] = mc[8 g + i] of frame n: the B operand slots of the first chain
+        float mcv[8];
+        {
+            f32x4 accG[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int out = it * 16 + n;
+                const bool ov = out < M1;
+#pragma unroll
+                for (int mt = 0; mt < 16; ++mt) {
+                    const float* gp = G + (mt * 16 + 4 * g) * M1 + out;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accG[it] = mfma4(ov ? kLn2 * gp[r * M1] : 0.f, logx[mt][r], accG[it]);
+                }
+                accG[it] = mfma4((ov && g == 0) ? kLn2 * G[H * M1 + out] : 0.f, g == 0 ? logx256 : 0.f, accG[it]);
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rt_lds[it * 16 + 4 * g + r] = accG[it][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mcv[i] = rt_lds[8 * g + i];  // coefficients >= 25 come out 0
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (hist && f_ok)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (8 * g + i < M1) hist[f * M1 + 8 * g + i] = mcv[i];
+
+        for (int iter = 0; iter < n_iter; ++iter) {
+            DSA_STAMP(0);
+            // ------------- first chain: t = log2 X - 2 log2(e) d,  d^T = D^T mc^T  (mcep.py:210-212) -----
+            f16x8 bh, bl;
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                f16x2 h, l;
+                split2(mcv[i] * SM, mcv[i + 1] * SM, h, l);
+                bh[i] = h[0]; bh[i + 1] = h[1];
+                bl[i] = l[0]; bl[i + 1] = l[1];
+            }
+            f32x4 t[16];
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) {
+                const f16x8 ah = DH[mt * 64 + lane], al = DL[mt * 64 + lane];
+                f32x4 c = {0, 0, 0, 0};
+                c = mfma_h(al, bh, c);
+                c = mfma_h(ah, bl, c);
+                c = mfma_h(ah, bh, c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[mt][r] = __builtin_fmaf(c[r], kInvSDM, logx[mt][r]);
+            }
+            float d256 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d256 = __builtin_fmaf(mcv[i], lds[H_D256 + 8 * g + i], d256);
+            d256 += __shfl_xor(d256, 16, 64);
+            d256 += __shfl_xor(d256, 32, 64);
+            const float t256 = logx256 + d256;
+            // per-frame power-of-two scale: the largest exp2(t + sh) of the frame is in (2^14, 2^15]
+            float tmax = t256;
+#pragma unroll
+            for (int mt = 0; mt < 16; mt += 2) {
+                tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(t[mt][0], t[mt][1]));
+                tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(t[mt][2], t[mt][3]));
+                tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(t[mt + 1][0], t[mt + 1][1]));
+                tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(t[mt + 1][2], t[mt + 1][3]));
+            }
+            tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mi = __builtin_ceilf(tmax);
+            const float sh = (float)EMAX_LOG2 - mi;
+            const int back = (int)mi - EMAX_LOG2;  // rt = 2^back (scaled sums)
+
+            // ------------- second chain: rt^T += E^T e^T  (mcep.py:214-215) -------------
+            f32x4 accB[3] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+            float rt48 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f16x8 eh, el;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int mt = 2 * j + tt;
+                    const f32x4 c48 = E484[mt * 4 + g];
+                    float e[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        e[r] = __builtin_amdgcn_exp2f(t[mt][r] + sh);  // mcep.py:212
+                        rt48 = __builtin_fmaf(e[r], c48[r], rt48);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        f16x2 h, l;
+                        split2(e[r], e[r + 1], h, l);
+                        eh[4 * tt + r] = h[0]; eh[4 * tt + r + 1] = h[1];
+                        el[4 * tt + r] = l[0]; el[4 * tt + r + 1] = l[1];
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const f16x8 ah = EH[(it * 8 + j) * 64 + lane], al = EL[(it * 8 + j) * 64 + lane];
+                    accB[it] = mfma_h(al, eh, accB[it]);
+                    accB[it] = mfma_h(ah, el, accB[it]);
+                    accB[it] = mfma_h(ah, eh, accB[it]);
+                }
+            }
+            const float e256 = __builtin_amdgcn_exp2f(t256 + sh);
+#pragma unroll
+            for (int it = 0; it < 3; ++it)
+                accB[it] = mfma4(g == 0 ? lds[H_E256 + it * 16 + n] : 0.f, g == 0 ? e256 : 0.f, accB[it]);
+            rt48 += __shfl_xor(rt48, 16, 64);
+            rt48 += __shfl_xor(rt48, 32, 64);
+            rt48 = __builtin_fmaf(e256, lds[H_E256 + 48], rt48);
+            rt48 = __builtin_ldexpf(rt48, back);
+
+            // ------------- rt and its reflection into this frame's LDS windows -------------
+            DSA_STAMP(1);
+#pragma unroll
+            for (int it = 0; it < 3; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = it * 16 + 4 * g + r;
+                    const float v = __builtin_ldexpf(accB[it][r], back - SE_LOG2);
+                    rt_lds[idx] = v;
+                    if (idx <= 27) {  // rr[27 + d] = r[|d|]
+                        rr_lds[27 + idx] = v;
+                        rr_lds[27 - idx] = v;
+                    }
+                }
+            if (g == 0) rt_lds[48] = rt48;
+            __builtin_amdgcn_wave_barrier();
+            DSA_STAMP(2);
+
+            // ------------- rows of R + Q, symmetric elimination, back substitution (as v2) -------------
+            float a[colm::TOTAL];
+            col_build_rows<0>(a, rt_q, rr_q, lds + H_AV, (const float*)nullptr, gs, gq);
+            __builtin_amdgcn_wave_barrier();
+            DSA_STAMP(3);
+            col_elim_all(a, std::make_integer_sequence<int, M1>{});
+            DSA_STAMP(4);
+            float xq[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[1], -1.f)};
+            col_backsub_all(a, xq, gq, std::make_integer_sequence<int, M1>{});
+            xq[6] = keep_if(gq.m[0], xq[6]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) rt_q[4 * ks + gs] = xq[ks];
+            __builtin_amdgcn_wave_barrier();
+            // mc += x  (mcep.py:222); window entries 28.. still hold rt, and 25..27 are zero
+            mcv[0] += rt_lds[8 * g];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) mcv[i] += keep_if(g_lt3, rt_lds[8 * g + i]);
+            __builtin_amdgcn_wave_barrier();
+            DSA_STAMP(5);
+            if (hist && f_ok)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (8 * g + i < M1) hist[((long)(iter + 1) * F + f) * M1 + 8 * g + i] = mcv[i];
+        }
+        if (f_ok)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (8 * g + i < M1) mc_out[f * M1 + 8 * g + i] = mcv[i];
+        unsigned int nxt = 0;
+        if (lane == 0) nxt = atomicAdd(queue, 1u);
+        tile = wave_stride + (long)__builtin_amdgcn_readfirstlane((int)nxt);
+    }
+}
+
+}  // namespace dsa
