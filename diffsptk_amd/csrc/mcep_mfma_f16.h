@@ -111,16 +111,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
 
     float* rt_lds = lds + H_WAVE + wave * WAVE_FLOATS + n * RS;
     float* rr_lds = rt_lds + 16 * RS;
-    const f16x8* DH = reinterpret_cast<const f16x8*>(lds + DH_OFF);
-    const f16x8* DL = reinterpret_cast<const f16x8*>(lds + DL_OFF);
-    const f16x8* EH = reinterpret_cast<const f16x8*>(lds + EH_OFF);
-    const f16x8* EL = reinterpret_cast<const f16x8*>(lds + EL_OFF);
+    // Two opaque lane bases for the operand images: ds_read immediates reach 64 KB, the images span
+    // 80 KB, and left to itself hipcc materialises (and then spills) one address register per far read
+    int lane_a = lane, lane_b = lane + EL_OFF / 4;
+    asm volatile("" : "+v"(lane_a), "+v"(lane_b));
+    const f16x8* DH = reinterpret_cast<const f16x8*>(lds + DH_OFF) + lane_a;
+    const f16x8* DL = reinterpret_cast<const f16x8*>(lds + DL_OFF) + lane_a;
+    const f16x8* EH = reinterpret_cast<const f16x8*>(lds + EH_OFF) + lane_a;
+    const f16x8* EL = reinterpret_cast<const f16x8*>(lds) + lane_b;
     const f32x4* E484 = reinterpret_cast<const f32x4*>(lds + H_E48);
     const long wave_id = (long)blockIdx.x * WAVES + wave;
     const long wave_stride = (long)gridDim.x * WAVES;
     const int nq = lane >> 2, gs = lane & 3;
     const GroupMask gq = make_group_mask(gs);
-    const unsigned g_lt3 = g < 3 ? 0xffffffffu : 0u;
+    const unsigned g_lt3 = g < 3 ? 0xffffffffu : 0u, g_eq0 = g == 0 ? 0xffffffffu : 0u;
     float* rt_q = lds + H_WAVE + wave * WAVE_FLOATS + nq * RS;
     float* rr_q = rt_q + 16 * RS;
 
@@ -139,6 +143,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
         const float logx256 = __log2f(xf[H]);
 
         // ---------------- mc0^T = G^T logx^T  (mcep.py:204-207), float32 MFMA ----------------
+        // (G re-read per tile through an opaque pointer: hoisted out of the tile loop its 130 values
+        //  per lane would live in scratch)
+        const float* Gt = G;
+        asm volatile("" : "+s"(Gt));
         // mcv[i] = mc[8 g + i] of frame n: the B operand slots of the first chain
         float mcv[8];
         {
@@ -149,11 +157,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                 const bool ov = out < M1;
 #pragma unroll
                 for (int mt = 0; mt < 16; ++mt) {
-                    const float* gp = G + (mt * 16 + 4 * g) * M1 + out;
+                    const float* gp = Gt + (mt * 16 + 4 * g) * M1 + out;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) accG[it] = mfma4(ov ? kLn2 * gp[r * M1] : 0.f, logx[mt][r], accG[it]);
                 }
-                accG[it] = mfma4((ov && g == 0) ? kLn2 * G[H * M1 + out] : 0.f, g == 0 ? logx256 : 0.f, accG[it]);
+                accG[it] = mfma4((ov && g == 0) ? kLn2 * Gt[H * M1 + out] : 0.f, g == 0 ? logx256 : 0.f, accG[it]);
             }
 #pragma unroll
             for (int it = 0; it < 2; ++it)
@@ -180,43 +188,54 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                 bh[i] = h[0]; bh[i + 1] = h[1];
                 bl[i] = l[0]; bl[i + 1] = l[1];
             }
-            f32x4 t[16];
-#pragma unroll
-            for (int mt = 0; mt < 16; ++mt) {
-                const f16x8 ah = DH[mt * 64 + lane], al = DL[mt * 64 + lane];
-                f32x4 c = {0, 0, 0, 0};
+            // one 16-bin tile of the chain; cinit preloads every accumulator element (see pass 2)
+            auto dtile = [&](int mt, float cinit) __attribute__((always_inline)) {
+                const f16x8 ah = DH[mt * 64], al = DL[mt * 64];
+                f32x4 c = {cinit, cinit, cinit, cinit};
                 c = mfma_h(al, bh, c);
                 c = mfma_h(ah, bl, c);
                 c = mfma_h(ah, bh, c);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) t[mt][r] = __builtin_fmaf(c[r], kInvSDM, logx[mt][r]);
-            }
+                return c;
+            };
             float d256 = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) d256 = __builtin_fmaf(mcv[i], lds[H_D256 + 8 * g + i], d256);
             d256 += __shfl_xor(d256, 16, 64);
             d256 += __shfl_xor(d256, 32, 64);
             const float t256 = logx256 + d256;
-            // per-frame power-of-two scale: the largest exp2(t + sh) of the frame is in (2^14, 2^15]
+            // pass 1: per-frame max of t, for the power-of-two scale that puts the largest exp2(t + sh)
+            // of the frame in (2^14, 2^15].  t is NOT kept (64 registers): binary16 MFMAs are cheap
+            // enough to run the chain again in pass 2.
             float tmax = t256;
 #pragma unroll
-            for (int mt = 0; mt < 16; mt += 2) {
-                tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(t[mt][0], t[mt][1]));
-                tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(t[mt][2], t[mt][3]));
-                tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(t[mt + 1][0], t[mt + 1][1]));
-                tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(t[mt + 1][2], t[mt + 1][3]));
+            for (int mt = 0; mt < 16; ++mt) {
+                const f32x4 c = dtile(mt, 0.f);
+                const float u0 = __builtin_fmaxf(__builtin_fmaf(c[0], kInvSDM, logx[mt][0]),
+                                                 __builtin_fmaf(c[1], kInvSDM, logx[mt][1]));
+                const float u1 = __builtin_fmaxf(__builtin_fmaf(c[2], kInvSDM, logx[mt][2]),
+                                                 __builtin_fmaf(c[3], kInvSDM, logx[mt][3]));
+                tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(u0, u1));
             }
             tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float mi = __builtin_ceilf(tmax);
             const float sh = (float)EMAX_LOG2 - mi;
             const int back = (int)mi - EMAX_LOG2;  // rt = 2^back (scaled sums)
+            // the shift rides in the accumulator preload: t + sh = logx + (sh SD SM + sum) / (SD SM)
+            const float cinit = sh * (SD * SM);
 
-            // ------------- second chain: rt^T += E^T e^T  (mcep.py:214-215) -------------
+            // ------------- pass 2: e = exp2(t + sh), second chain rt^T += E^T e^T  (mcep.py:212-215);
+            // the first chain of bins 32 (j + 1) .. is issued ahead of the vector work of bins 32 j .. ----
             f32x4 accB[3] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
             float rt48 = 0.f;
+            f32x4 cc[2] = {dtile(0, cinit), dtile(1, cinit)};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+                f32x4 cn[2] = {cc[0], cc[1]};
+                if (j < 7) {
+                    cn[0] = dtile(2 * j + 2, cinit);
+                    cn[1] = dtile(2 * j + 3, cinit);
+                }
                 f16x8 eh, el;
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
@@ -225,7 +244,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                     float e[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        e[r] = __builtin_amdgcn_exp2f(t[mt][r] + sh);  // mcep.py:212
+                        e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(cc[tt][r], kInvSDM, logx[mt][r]));  // mcep.py:212
                         rt48 = __builtin_fmaf(e[r], c48[r], rt48);
                     }
 #pragma unroll
@@ -238,16 +257,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                 }
 #pragma unroll
                 for (int it = 0; it < 3; ++it) {
-                    const f16x8 ah = EH[(it * 8 + j) * 64 + lane], al = EL[(it * 8 + j) * 64 + lane];
+                    const f16x8 ah = EH[(it * 8 + j) * 64], al = EL[(it * 8 + j) * 64];
                     accB[it] = mfma_h(al, eh, accB[it]);
                     accB[it] = mfma_h(ah, el, accB[it]);
                     accB[it] = mfma_h(ah, eh, accB[it]);
                 }
+                cc[0] = cn[0];
+                cc[1] = cn[1];
             }
             const float e256 = __builtin_amdgcn_exp2f(t256 + sh);
 #pragma unroll
-            for (int it = 0; it < 3; ++it)
-                accB[it] = mfma4(g == 0 ? lds[H_E256 + it * 16 + n] : 0.f, g == 0 ? e256 : 0.f, accB[it]);
+            for (int it = 0; it < 3; ++it)  // Nyquist bin: one float32 k-step, k-slot 0 only (bit-mask select: no branch)
+                accB[it] = mfma4(keep_if(g_eq0, lds[H_E256 + it * 16 + n]), keep_if(g_eq0, e256), accB[it]);
             rt48 += __shfl_xor(rt48, 16, 64);
             rt48 += __shfl_xor(rt48, 32, 64);
             rt48 = __builtin_fmaf(e256, lds[H_E256 + 48], rt48);
@@ -255,19 +276,32 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
 
             // ------------- rt and its reflection into this frame's LDS windows -------------
             DSA_STAMP(1);
-#pragma unroll
-            for (int it = 0; it < 3; ++it)
+            {
+                // rt[idx], idx = 16 it + 4 g + r, and for idx <= 27 its reflection rr[27 +- idx].  The stores
+                // are unconditional: lane group 3 of tile 1 (idx 28..31) is pointed at free slots 55..62 of
+                // the window instead of being masked off (a masked store is an exec-mask branch each).
+                int g_it = g;
+                asm volatile("" : "+v"(g_it));  // keeps the address selects inside the loop (not live across the solve)
+                float* rtw = rt_lds + 4 * g_it;
+                float* rra = rr_lds + 27 + 4 * g_it;
+                float* rrb = rr_lds + 27 - 4 * g_it;
+                float* rra1 = g_it < 3 ? rra + 16 : rr_lds + 55;
+                float* rrb1 = g_it < 3 ? rrb - 16 : rr_lds + 62;
+                const int bk = back - SE_LOG2;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int idx = it * 16 + 4 * g + r;
-                    const float v = __builtin_ldexpf(accB[it][r], back - SE_LOG2);
-                    rt_lds[idx] = v;
-                    if (idx <= 27) {  // rr[27 + d] = r[|d|]
-                        rr_lds[27 + idx] = v;
-                        rr_lds[27 - idx] = v;
-                    }
+                    const float v0 = __builtin_ldexpf(accB[0][r], bk);
+                    const float v1 = __builtin_ldexpf(accB[1][r], bk);
+                    rtw[r] = v0;
+                    rra[r] = v0;
+                    rrb[-r] = v0;
+                    rtw[16 + r] = v1;
+                    rra1[r] = v1;
+                    rrb1[-r] = v1;
+                    rtw[32 + r] = __builtin_ldexpf(accB[2][r], bk);
                 }
-            if (g == 0) rt_lds[48] = rt48;
+                rt_lds[48] = rt48;  // same value on the four lanes of a frame
+            }
             __builtin_amdgcn_wave_barrier();
             DSA_STAMP(2);
 
