@@ -1577,11 +1577,12 @@ int mcep_mfma_fwd(const void* X, int64_t F, int nfft, int M, int n_iter, const v
 {
     (void)nfft;
     (void)M;
-    // DSA_MCEP_VARIANT (A/B knob): 8 = two waves per SIMD (default, fastest measured), 4 = one wave
-    // per SIMD, 3 = role-split matrix/solver waves, 1 = first kernel (full elimination, ds_bpermute)
+    // DSA_MCEP_VARIANT (A/B knob): 16 = split-precision binary16 MFMA chains, two waves per SIMD
+    // (default, fastest measured); 8 = float32 MFMA chains, two waves per SIMD; 4 = one wave per
+    // SIMD; 3 = role-split matrix/solver waves; 1 = first kernel (full elimination, ds_bpermute)
     static const int variant = [] {
         const char* e = getenv("DSA_MCEP_VARIANT");
-        return e ? atoi(e) : 8;
+        return e ? atoi(e) : 16;
     }();
     if (variant == 1) {
         const int lds_bytes = mm::LDS_FLOATS * 4;
@@ -1599,10 +1600,10 @@ int mcep_mfma_fwd(const void* X, int64_t F, int nfft, int M, int n_iter, const v
                            (float*)mc, (float*)hist, ntiles);
         return check_launch("mcep_mfma_fwd_v1");
     }
-    if (variant == 16) return launch_h<8>(X, F, n_iter, G, D, E, av, mc, hist, st, "mcep_mfma_fwd_h");
+    if (variant == 8) return launch_v2<8>(X, F, n_iter, G, D, E, av, mc, hist, st, "mcep_mfma_fwd_f32");
     if (variant == 4) return launch_v2<4>(X, F, n_iter, G, D, E, av, mc, hist, st, "mcep_mfma_fwd_w4");
     if (variant == 3 && n_iter >= 1) return launch_v3(X, F, n_iter, G, D, E, av, mc, hist, st);
-    return launch_v2<8>(X, F, n_iter, G, D, E, av, mc, hist, st, "mcep_mfma_fwd");
+    return launch_h<8>(X, F, n_iter, G, D, E, av, mc, hist, st, "mcep_mfma_fwd");
 }
 
 }  // namespace dsa

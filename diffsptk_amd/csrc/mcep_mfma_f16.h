@@ -127,6 +127,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
     const unsigned g_lt3 = g < 3 ? 0xffffffffu : 0u, g_eq0 = g == 0 ? 0xffffffffu : 0u;
     float* rt_q = lds + H_WAVE + wave * WAVE_FLOATS + nq * RS;
     float* rr_q = rt_q + 16 * RS;
+#ifdef DSA_MCEP_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_mcep_stamps[8] = __builtin_readcyclecounter();
+#endif
 
     for (long tile = wave_id; tile < ntiles16;) {
         const long f_raw = tile * 16 + n;
@@ -336,6 +339,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
         unsigned int nxt = 0;
         if (lane == 0) nxt = atomicAdd(queue, 1u);
         tile = wave_stride + (long)__builtin_amdgcn_readfirstlane((int)nxt);
+#ifdef DSA_MCEP_TIMING
+        if (blockIdx.x == 0 && threadIdx.x == 0) { g_mcep_stamps[9] = __builtin_readcyclecounter(); g_mcep_stamps[10] += 1; }
+#endif
     }
 }
 

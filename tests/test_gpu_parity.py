@@ -460,6 +460,25 @@ def test_mcep_backward_wrt_spectrum_golden(golden):
         assert err.max() < rel
 
 
+def test_mcep_tuned_dynamic_range(golden):
+    """The tuned kernel computes its two matrix chains as three binary16 MFMA products per operand
+    pair with per-frame power-of-two scaling (csrc/mcep_mfma_f16.h).  Spectral tilts of 80 / 160 dB
+    and overall levels from 1e-24 to 1e+24 must stay inside the float32 parity tolerance against
+    the float64 generic path on the same input (mcep.py:189-224)."""
+    g = golden("datawav")
+    X0 = torch.from_numpy(g["stft_power_f32"]).reshape(-1, 257)
+    m32 = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, device=DEV)
+    m64 = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, device=DEV, dtype=torch.float64)
+    tilt = torch.linspace(0, 1, 257)
+    for db, level in ((0, 1.0), (80, 1.0), (160, 1.0), (-80, 1.0), (0, 1e-24), (0, 1e24), (80, 1e-18)):
+        X = (X0 * 10 ** (-db / 10 * tilt) * level).to(torch.float32)
+        y = host(m32(X.to(DEV)))
+        assert _lib.last_kernel().startswith("mcep_mfma_fwd")
+        ref = host(m64(X.to(DEV).double()))
+        assert np.isfinite(y).all(), (db, level)
+        close(y, ref, 1e-4, 2e-5)
+
+
 def test_mcep_tuned_vs_generic_and_history(golden):
     g = golden("randn")
     X = dev(g["stft_power_f32"])

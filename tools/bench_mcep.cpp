@@ -33,11 +33,12 @@ int main(int argc, char** argv)
     hipMemcpy(av, hav.data(), 100, hipMemcpyHostToDevice);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int variant : {4, 8}) {
+    for (int variant : {4, 8, 16}) {
         float ms = 0;
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
-            if (variant == 4) dsa::launch_v2<4>(X, F, 10, G, D, E, av, mc, nullptr, 0, "w4");
+            if (variant == 16) dsa::launch_h<8>(X, F, 10, G, D, E, av, mc, nullptr, 0, "h8");
+            else if (variant == 4) dsa::launch_v2<4>(X, F, 10, G, D, E, av, mc, nullptr, 0, "w4");
             else dsa::launch_v2<8>(X, F, 10, G, D, E, av, mc, nullptr, 0, "w8");
             hipEventRecord(e1);
             hipEventSynchronize(e1);
