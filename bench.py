@@ -210,7 +210,10 @@ def main():
                 "frames_per_launch": frames_launch,
                 "flop_per_frame": MCEP_FLOP_PER_FRAME,
                 "note": "fp32 MFMA dense peak == fp32 vector peak (157.3 TFLOP/s); flops are the composed-matrix "
-                        "algorithm's (DESIGN.md), lower than the reference formulation's 0.71-0.75 MFLOP/frame",
+                        "algorithm's (DESIGN.md), lower than the reference formulation's 0.71-0.75 MFLOP/frame, "
+                        "each counted once.  The two matrix chains of a Newton step execute as three binary16 "
+                        "MFMA products per fp32 operand pair (hi/lo split, fp32 accumulate, fp32-grade parity: "
+                        "tests/test_gpu_parity.py); the 25x25 solve is unpacked fp32 VALU, which now bounds the kernel",
             },
             "roofline_stft": {
                 "kernel": kernels["stft"], "bound": "hbm",
