@@ -1526,6 +1526,16 @@ static unsigned int* queue_slot(hipStream_t st)
     return q;
 }
 
+// rotating pool of operand-image workspaces for the split-precision kernel (112 KB each)
+static _Float16* image_slot()
+{
+    static _Float16* pool = nullptr;
+    static unsigned int next = 0;
+    constexpr unsigned int kSlots = 64;
+    if (!pool && hipMalloc((void**)&pool, (size_t)kSlots * mh::IMG_BYTES) != hipSuccess) return nullptr;
+    return pool + (size_t)(next++ % kSlots) * (mh::IMG_BYTES / 2);
+}
+
 template <int WAVES>
 static int launch_v2(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E,
                      const void* av, void* mc, void* hist, hipStream_t st, const char* name)
@@ -1565,10 +1575,13 @@ static int launch_h(const void* X, int64_t F, int n_iter, const void* G, const v
     long blocks = (ntiles16 + WAVES - 1) / WAVES;
     long grid = blocks < 256 ? blocks : 256;  // one persistent workgroup per CU
     unsigned int* queue = queue_slot(st);
-    if (!queue) return fail(DSA_ERR_LAUNCH, "mcep_mfma: cannot set up the tile queue%s");
+    _Float16* img = image_slot();
+    if (!queue || !img) return fail(DSA_ERR_LAUNCH, "mcep_mfma: cannot set up the tile queue / operand images%s");
+    hipLaunchKernelGGL(mcep_h_prep_kernel, dim3((mh::IMG_D + mh::IMG_E + mh::IMG_G + 255) / 256), dim3(256), 0, st,
+                       (const float*)G, (const float*)D, (const float*)E, img);
     hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
                        (const float*)X, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
-                       (const float*)av, (float*)mc, (float*)hist, ntiles16, queue);
+                       (const float*)av, (float*)mc, (float*)hist, ntiles16, queue, (const _Float16*)img);
     return check_launch(name);
 }
 

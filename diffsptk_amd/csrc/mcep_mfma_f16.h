@@ -32,6 +32,13 @@ constexpr float SD = 16.f;      // scale of the D^T image (|-2 log2(e) D| <= ~7)
 constexpr float SM = 1024.f;    // scale of mc
 constexpr float SE = 65536.f;   // scale of the E^T image (|E| <= ~0.01)
 constexpr int SE_LOG2 = 16;
+constexpr float SG = 4096.f;    // scale of the (ln 2) G^T image (|G| <= 0.13 for |alpha| <= 0.95)
+constexpr float SL = 128.f;     // scale of log2 X (|log2 X| < 150 for any float32 input)
+// operand images in global memory (binary16 elements), written by mcep_h_prep_kernel once per launch
+constexpr int IMG_D = 16 * 64 * 8, IMG_E = 24 * 64 * 8, IMG_G = 16 * 64 * 8;
+constexpr int IMG_DH = 0, IMG_DL = IMG_DH + IMG_D, IMG_EH = IMG_DL + IMG_D, IMG_EL = IMG_EH + IMG_E;
+constexpr int IMG_GH = IMG_EL + IMG_E, IMG_GL = IMG_GH + IMG_G, IMG_HALVES = IMG_GL + IMG_G;
+constexpr int IMG_BYTES = IMG_HALVES * 2 + 32 * 4;  // + the Nyquist row G[256][0..24] as float32
 constexpr int EMAX_LOG2 = 15;   // largest scaled e is <= 2^15
 // LDS carve-up (float units; same region sizes as namespace mm: the binary16 hi + lo images take
 // exactly the room of one float32 image)
@@ -64,11 +71,46 @@ __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo)
     lo = (_Float16)(x - (float)hi);
 }
 
+// Operand images of the three constant matrices, split into binary16 hi / lo, in the exact
+// per-lane order the MFMAs consume them (one 16-byte element per lane and k-step).  One tiny launch
+// ahead of the main kernel; the workgroups of the main kernel then copy D / E images straight into
+// LDS and stream the G image (used once per tile) from L2.
+__global__ __launch_bounds__(256) void mcep_h_prep_kernel(const float* __restrict__ G, const float* __restrict__ D,
+                                                          const float* __restrict__ E, _Float16* __restrict__ img)
+{
+    using namespace mh;
+    constexpr float kNeg2Log2e = -2.885390081777926815f, kLn2 = 0.693147180559945309f;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int i = idx & 7, l = (idx >> 3) & 63;
+    if (idx < IMG_D) {
+        const int mt = idx >> 9;
+        const int k = 8 * (l >> 4) + i;  // k-slot (g, i) <-> coefficient 8 g + i
+        const float v = k < M1 ? (kNeg2Log2e * SD) * D[k * K + mt * 16 + (l & 15)] : 0.f;
+        split1(v, img[IMG_DH + idx], img[IMG_DL + idx]);
+    } else if (idx < IMG_D + IMG_E) {
+        const int e = idx - IMG_D;
+        const int j = (e >> 9) & 7, it = e >> 12;
+        // k-slot (g, i = 4 t + r) <-> bin 32 j + 16 t + 4 g + r: C/D register r of tile 2 j + t
+        const int bin = 32 * j + 16 * (i >> 2) + 4 * (l >> 4) + (i & 3);
+        const float v = SE * E[bin * M2 + it * 16 + (l & 15)];
+        split1(v, img[IMG_EH + e], img[IMG_EL + e]);
+    } else if (idx < IMG_D + IMG_E + IMG_G) {
+        const int e = idx - IMG_D - IMG_E;
+        const int j = (e >> 9) & 7, it = e >> 12;
+        const int bin = 32 * j + 16 * (i >> 2) + 4 * (l >> 4) + (i & 3);
+        const int coef = it * 16 + (l & 15);
+        const float v = coef < M1 ? (kLn2 * SG) * G[bin * M1 + coef] : 0.f;
+        split1(v, img[IMG_GH + e], img[IMG_GL + e]);
+    }
+    if (idx < 32) reinterpret_cast<float*>(img + IMG_HALVES)[idx] = idx < M1 ? G[H * M1 + idx] : 0.f;
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
     const float* __restrict__ X, long F, int n_iter, const float* __restrict__ G,
     const float* __restrict__ D, const float* __restrict__ E, const float* __restrict__ av,
-    float* __restrict__ mc_out, float* __restrict__ hist, long ntiles16, unsigned int* __restrict__ queue)
+    float* __restrict__ mc_out, float* __restrict__ hist, long ntiles16, unsigned int* __restrict__ queue,
+    const _Float16* __restrict__ img)
 {
     using namespace mh;
     constexpr float kNeg2Log2e = -2.885390081777926815f, kLn2 = 0.693147180559945309f;
@@ -78,25 +120,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
     const int lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
 
-    // ---------------- operand images (binary16 hi / lo): built once per workgroup ----------------
+    // ---------------- operand images (binary16 hi / lo): copied from the prepared global images ----------------
     {
-        _Float16* dh = reinterpret_cast<_Float16*>(lds + DH_OFF);
-        _Float16* dl = reinterpret_cast<_Float16*>(lds + DL_OFF);
-        for (int idx = tid; idx < 16 * 64 * 8; idx += WAVES * 64) {
-            const int i = idx & 7, l = (idx >> 3) & 63, mt = idx >> 9;
-            const int k = 8 * (l >> 4) + i;  // k-slot (g, i) <-> coefficient 8 g + i
-            const float v = k < M1 ? (kNeg2Log2e * SD) * D[k * K + mt * 16 + (l & 15)] : 0.f;
-            split1(v, dh[idx], dl[idx]);
-        }
-        _Float16* eh = reinterpret_cast<_Float16*>(lds + EH_OFF);
-        _Float16* el = reinterpret_cast<_Float16*>(lds + EL_OFF);
-        for (int idx = tid; idx < 24 * 64 * 8; idx += WAVES * 64) {
-            const int i = idx & 7, l = (idx >> 3) & 63, j = (idx >> 9) & 7, it = idx >> 12;
-            // k-slot (g, i = 4 t + r) <-> bin 32 j + 16 t + 4 g + r: C/D register r of tile 2 j + t
-            const int bin = 32 * j + 16 * (i >> 2) + 4 * (l >> 4) + (i & 3);
-            const float v = SE * E[bin * M2 + it * 16 + (l & 15)];
-            split1(v, eh[idx], el[idx]);
-        }
+        const f32x4* src = reinterpret_cast<const f32x4*>(img);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds + DH_OFF);
+        for (int idx = tid; idx < (2 * IMG_D + 2 * IMG_E) / 8; idx += WAVES * 64) dst[idx] = src[idx];
     }
     {
         const int t2 = tid & 255;
@@ -131,7 +159,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
     if (blockIdx.x == 0 && threadIdx.x == 0) g_mcep_stamps[8] = __builtin_readcyclecounter();
 #endif
 
+#ifdef DSA_MCEP_TIMING
+    int tcount = 0;
+#define DSA_STAMP_T(i)                                                                   \
+    do {                                                                                 \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && tcount == 2) g_mcep_stamps[i] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define DSA_STAMP_T(i)
+#endif
     for (long tile = wave_id; tile < ntiles16;) {
+        DSA_STAMP_T(16);
         const long f_raw = tile * 16 + n;
         const bool f_ok = f_raw < F;
         const long f = f_ok ? f_raw : F - 1;
@@ -144,27 +182,45 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             logx[mt] = f32x4{__log2f(p[0]), __log2f(p[1]), __log2f(p[2]), __log2f(p[3])};  // mcep.py:203 (base 2)
         }
         const float logx256 = __log2f(xf[H]);
+        DSA_STAMP_T(17);
 
-        // ---------------- mc0^T = G^T logx^T  (mcep.py:204-207), float32 MFMA ----------------
-        // (G re-read per tile through an opaque pointer: hoisted out of the tile loop its 130 values
-        //  per lane would live in scratch)
-        const float* Gt = G;
-        asm volatile("" : "+s"(Gt));
+        // ---------------- mc0^T = G^T logx^T  (mcep.py:204-207): split-precision MFMA, the G^T image
+        // streamed from global memory (L2-resident, 32 KB, read once per tile) ----------------
         // mcv[i] = mc[8 g + i] of frame n: the B operand slots of the first chain
         float mcv[8];
         {
+            // (opaque per tile: hoisted out of the tile loop the 32 operand loads would live in scratch)
+            const _Float16* imgt = img;
+            asm volatile("" : "+s"(imgt));
+            const f16x8* GH = reinterpret_cast<const f16x8*>(imgt + IMG_GH) + lane;
+            const f16x8* GL = reinterpret_cast<const f16x8*>(imgt + IMG_GL) + lane;
             f32x4 accG[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int out = it * 16 + n;
-                const bool ov = out < M1;
+            for (int j = 0; j < 8; ++j) {
+                f16x8 lh, ll;
 #pragma unroll
-                for (int mt = 0; mt < 16; ++mt) {
-                    const float* gp = Gt + (mt * 16 + 4 * g) * M1 + out;
+                for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) accG[it] = mfma4(ov ? kLn2 * gp[r * M1] : 0.f, logx[mt][r], accG[it]);
+                    for (int r = 0; r < 4; r += 2) {
+                        f16x2 h, l;
+                        split2(logx[2 * j + tt][r] * SL, logx[2 * j + tt][r + 1] * SL, h, l);
+                        lh[4 * tt + r] = h[0]; lh[4 * tt + r + 1] = h[1];
+                        ll[4 * tt + r] = l[0]; ll[4 * tt + r + 1] = l[1];
+                    }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const f16x8 ah = GH[(it * 8 + j) * 64], al = GL[(it * 8 + j) * 64];
+                    accG[it] = mfma_h(al, lh, accG[it]);
+                    accG[it] = mfma_h(ah, ll, accG[it]);
+                    accG[it] = mfma_h(ah, lh, accG[it]);
                 }
-                accG[it] = mfma4((ov && g == 0) ? kLn2 * Gt[H * M1 + out] : 0.f, g == 0 ? logx256 : 0.f, accG[it]);
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {  // Nyquist bin: one float32 k-step on k-slot 0
+                const int out = it * 16 + n;
+                const float gv = out < M1 ? (kLn2 * SG * SL) * reinterpret_cast<const float*>(imgt + IMG_HALVES)[out] : 0.f;
+                accG[it] = mfma4(keep_if(g_eq0, gv), keep_if(g_eq0, logx256), accG[it]);
+                accG[it] *= 1.f / (SG * SL);
             }
 #pragma unroll
             for (int it = 0; it < 2; ++it)
@@ -180,6 +236,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             for (int i = 0; i < 8; ++i)
                 if (8 * g + i < M1) hist[f * M1 + 8 * g + i] = mcv[i];
 
+        DSA_STAMP_T(18);
+        // ticket for this wave's next tile, drawn now: the atomic's round trip hides behind the iterations
+        unsigned int nxt = 0;
+        if (lane == 0) nxt = atomicAdd(queue, 1u);
         for (int iter = 0; iter < n_iter; ++iter) {
             DSA_STAMP(0);
             // ------------- first chain: t = log2 X - 2 log2(e) d,  d^T = D^T mc^T  (mcep.py:210-212) -----
@@ -332,14 +392,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                 for (int i = 0; i < 8; ++i)
                     if (8 * g + i < M1) hist[((long)(iter + 1) * F + f) * M1 + 8 * g + i] = mcv[i];
         }
+        DSA_STAMP_T(19);
         if (f_ok)
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 if (8 * g + i < M1) mc_out[f * M1 + 8 * g + i] = mcv[i];
-        unsigned int nxt = 0;
-        if (lane == 0) nxt = atomicAdd(queue, 1u);
+        DSA_STAMP_T(20);
         tile = wave_stride + (long)__builtin_amdgcn_readfirstlane((int)nxt);
+        DSA_STAMP_T(21);
 #ifdef DSA_MCEP_TIMING
+        ++tcount;
         if (blockIdx.x == 0 && threadIdx.x == 0) { g_mcep_stamps[9] = __builtin_readcyclecounter(); g_mcep_stamps[10] += 1; }
 #endif
     }
