@@ -1520,9 +1520,9 @@ static unsigned int* queue_slot(hipStream_t st)
     static unsigned int* pool = nullptr;
     static unsigned int next = 0;
     constexpr unsigned int kSlots = 256;
-    if (!pool && hipMalloc((void**)&pool, kSlots * sizeof(unsigned int)) != hipSuccess) return nullptr;
-    unsigned int* q = pool + (next++ % kSlots);
-    if (hipMemsetAsync(q, 0, sizeof(unsigned int), st) != hipSuccess) return nullptr;
+    if (!pool && hipMalloc((void**)&pool, 2 * kSlots * sizeof(unsigned int)) != hipSuccess) return nullptr;
+    unsigned int* q = pool + 2 * (next++ % kSlots);  // two counters per launch
+    if (hipMemsetAsync(q, 0, 2 * sizeof(unsigned int), st) != hipSuccess) return nullptr;
     return q;
 }
 
@@ -1579,9 +1579,12 @@ static int launch_h(const void* X, int64_t F, int n_iter, const void* G, const v
     if (!queue || !img) return fail(DSA_ERR_LAUNCH, "mcep_mfma: cannot set up the tile queue / operand images%s");
     hipLaunchKernelGGL(mcep_h_prep_kernel, dim3((mh::IMG_D + mh::IMG_E + mh::IMG_G + 255) / 256), dim3(256), 0, st,
                        (const float*)G, (const float*)D, (const float*)E, img);
+    // see the ticket comment in the kernel: a short last round goes to one wave per SIMD pair
+    const long slots = grid * WAVES, full = ntiles16 / slots * slots, rest = ntiles16 - full;
+    const long tiles_shared = (full > 0 && rest > 0 && rest <= slots / 2) ? full : ntiles16;
     hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
                        (const float*)X, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
-                       (const float*)av, (float*)mc, (float*)hist, ntiles16, queue, (const _Float16*)img);
+                       (const float*)av, (float*)mc, (float*)hist, ntiles16, tiles_shared, queue, (const _Float16*)img);
     return check_launch(name);
 }
 

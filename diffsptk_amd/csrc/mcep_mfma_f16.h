@@ -109,8 +109,8 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
     const float* __restrict__ X, long F, int n_iter, const float* __restrict__ G,
     const float* __restrict__ D, const float* __restrict__ E, const float* __restrict__ av,
-    float* __restrict__ mc_out, float* __restrict__ hist, long ntiles16, unsigned int* __restrict__ queue,
-    const _Float16* __restrict__ img)
+    float* __restrict__ mc_out, float* __restrict__ hist, long ntiles16, long tiles_shared,
+    unsigned int* __restrict__ queue, const _Float16* __restrict__ img)
 {
     using namespace mh;
     constexpr float kNeg2Log2e = -2.885390081777926815f, kLn2 = 0.693147180559945309f;
@@ -170,6 +170,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
 #endif
     for (long tile = wave_id; tile < ntiles16;) {
         DSA_STAMP_T(16);
+#ifdef DSA_MCEP_TIMING
+        if (blockIdx.x == 0 && threadIdx.x == 0 && tcount < 12) { g_mcep_stamps[32 + tcount] = __builtin_readcyclecounter(); g_mcep_stamps[48 + tcount] = (unsigned long long)tile; }
+#endif
         const long f_raw = tile * 16 + n;
         const bool f_ok = f_raw < F;
         const long f = f_ok ? f_raw : F - 1;
@@ -237,9 +240,24 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                 if (8 * g + i < M1) hist[f * M1 + 8 * g + i] = mcv[i];
 
         DSA_STAMP_T(18);
-        // ticket for this wave's next tile, drawn now: the atomic's round trip hides behind the iterations
-        unsigned int nxt = 0;
-        if (lane == 0) nxt = atomicAdd(queue, 1u);
+        // Ticket for this wave's next tile, drawn now: the atomic's round trip hides behind the iterations.
+        // Tiles [0, tiles_shared) are open to every wave.  When the launch ends in a round that fills at
+        // most half of the wave slots, those last tiles sit behind a second counter that only the first
+        // wave of each SIMD pair draws from: a SIMD then finishes with ONE wave at full issue rate
+        // instead of two waves at half rate each (the tail is one tile long either way).
+        long tile_next;
+        {
+            unsigned int nxt = 0;
+            if (lane == 0) nxt = atomicAdd(queue, 1u);
+            tile_next = wave_stride + (long)__builtin_amdgcn_readfirstlane((int)nxt);
+            if (tile_next >= tiles_shared) {
+                tile_next = ntiles16;
+                if (wave < WAVES / 2 && tiles_shared < ntiles16) {
+                    if (lane == 0) nxt = atomicAdd(queue + 1, 1u);
+                    tile_next = tiles_shared + (long)__builtin_amdgcn_readfirstlane((int)nxt);
+                }
+            }
+        }
         for (int iter = 0; iter < n_iter; ++iter) {
             DSA_STAMP(0);
             // ------------- first chain: t = log2 X - 2 log2(e) d,  d^T = D^T mc^T  (mcep.py:210-212) -----
@@ -398,7 +416,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             for (int i = 0; i < 8; ++i)
                 if (8 * g + i < M1) mc_out[f * M1 + 8 * g + i] = mcv[i];
         DSA_STAMP_T(20);
-        tile = wave_stride + (long)__builtin_amdgcn_readfirstlane((int)nxt);
+        tile = tile_next;
         DSA_STAMP_T(21);
 #ifdef DSA_MCEP_TIMING
         ++tcount;

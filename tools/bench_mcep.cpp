@@ -44,12 +44,17 @@ int main(int argc, char** argv)
             hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);
         }
-        unsigned long long st[32];
+        unsigned long long st[64];
         hipMemcpyFromSymbol(st, HIP_SYMBOL(dsa::g_mcep_stamps), sizeof(st));
         printf("   wave 0: %llu ticks from start to last tile end, %llu tiles (all reps) => tick rate %.1f MHz if the wave spans the kernel\n",
                st[9] - st[8], st[10], (st[9] - st[8]) / (ms * 1e3));
         printf("waves=%d  kernel %.3f ms | cycles: mfma+exp %llu  rt->lds %llu  build %llu  elim %llu  backsub %llu\n", variant,
                ms, st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4]);
+        if (variant == 16) {
+            printf("   wave 0 tile starts (ticks since kernel start: tile id):");
+            for (int i = 0; i < 12 && st[32 + i] > st[8]; ++i) printf("  %llu:%llu", st[32 + i] - st[8], st[48 + i]);
+            printf("  end %llu\n", st[9] - st[8]);
+        }
         if (variant == 16)
             printf("   third tile of wave 0: X load + log2 %llu  mc0 chain %llu  10 iterations %llu  store %llu  queue %llu\n",
                    st[17] - st[16], st[18] - st[17], st[19] - st[18], st[20] - st[19], st[21] - st[20]);
