@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="utterances per GPU (weak scaling)")
-    ap.add_argument("--chunks", type=int, default=4, help="N > 1: utterance chunks per step (gather/compute overlap)")
+    ap.add_argument("--chunks", type=int, default=2, help="N > 1: utterance chunks per step (gather/compute overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--algo", choices=["auto", "generic", "tuned"], default="auto")
     args = ap.parse_args()

@@ -69,11 +69,17 @@ def analyze_sharded(x: torch.Tensor, compute: Callable[[torch.Tensor], torch.Ten
     return all_gather_features(local, x.size(0), group) if gather else local
 
 
-def analyze_chunked_overlap(x_local: torch.Tensor, compute: Callable[[torch.Tensor], torch.Tensor], n_chunks: int = 4,
-                            group=None) -> torch.Tensor:
+def analyze_chunked_overlap(x_local: torch.Tensor, compute: Callable[[torch.Tensor], torch.Tensor], n_chunks: int = 2,
+                            group=None, alternate_streams: bool = True) -> torch.Tensor:
     """Compute this rank's shard ``x_local`` (B_r, T) in ``n_chunks`` utterance chunks and all-gather
     each chunk's features as soon as they exist, so the collective of chunk c runs (on RCCL's own
     stream) while chunk c+1 is being computed.  Every rank must hold the same number of utterances.
+
+    On a GPU the chunks alternate between the current stream and one side stream
+    (``alternate_streams``): the persistent mel-cepstral kernel ends in a tail of partly idle CUs,
+    and a chunk launched on the other stream fills that tail instead of queueing behind it
+    (tools/ab_chunks.py: 2 chunks on 2 streams cost the same as one unchunked launch, 0.96 ms per
+    1024 utterances; 4 chunks cost +20 %).
 
     Returns the gathered features (world * B_r, ...) in rank-major order -- the same tensor
     ``all_gather_features(compute(x_local))`` returns, only the exchange is hidden behind compute.
@@ -84,14 +90,38 @@ def analyze_chunked_overlap(x_local: torch.Tensor, compute: Callable[[torch.Tens
     B = x_local.size(0)
     n_chunks = max(1, min(n_chunks, B))
     bounds = [shard_bounds(B, n_chunks, c) for c in range(n_chunks)]
+    use_side = alternate_streams and x_local.is_cuda and n_chunks > 1
+    main = torch.cuda.current_stream(x_local.device) if use_side else None
+    side = torch.cuda.Stream(x_local.device) if use_side else None
+    if use_side:
+        side.wait_stream(main)  # the input was produced on the current stream
     out = None
     pending = []
-    for lo, hi in bounds:
-        feat = compute(x_local[lo:hi]).contiguous()
-        if out is None:
-            out = feat.new_empty((world, B, *feat.shape[1:]))
-        # rank r's chunk lands in out[r, lo:hi]: one contiguous destination per rank
-        pending.append((dist.all_gather([out[r, lo:hi] for r in range(world)], feat, group=group, async_op=True), feat))
+    for c, (lo, hi) in enumerate(bounds):
+        on_side = use_side and c % 2 == 1
+        if on_side and out is not None:
+            side.wait_stream(main)  # `out` was allocated on the current stream
+        ctx = torch.cuda.stream(side) if on_side else _NullContext()
+        with ctx:
+            feat = compute(x_local[lo:hi]).contiguous()
+            if out is None:
+                out = feat.new_empty((world, B, *feat.shape[1:]))
+            # rank r's chunk lands in out[r, lo:hi]: one contiguous destination per rank; the collective
+            # is ordered after this chunk's kernels on the stream that is current here
+            work = dist.all_gather([out[r, lo:hi] for r in range(world)], feat, group=group, async_op=True)
+        pending.append((work, feat))
     for work, _keep in pending:
         work.wait()
+    if use_side:
+        main.wait_stream(side)
+        for _work, keep in pending:
+            keep.record_stream(main)
     return out.reshape(world * B, *out.shape[2:])
+
+
+class _NullContext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False

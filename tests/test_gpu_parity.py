@@ -608,3 +608,35 @@ def test_lpc_config4_batch1024_sampled():
     close(host(a[sel]), O.frame_window_lpc(x[sel].double().numpy()), 1e-4, 1e-4)
     a_mod = dsp.LPC(400, 24, eps=1e-5, device=DEV)(dsp.Window(400, device=DEV)(dsp.Frame(400, 80)(xd[:64])))
     close(host(a_mod), host(a[:64]), 1e-6, 1e-6)
+
+
+def test_chunked_overlap_alternating_streams(monkeypatch):
+    """dist.analyze_chunked_overlap on a GPU alternates chunks between two streams.  Only one GPU is
+    available to this suite, so the collective is replaced by a stand-in that copies the local chunk
+    into every rank's slot on the stream that is current at the call (what RCCL orders against); the
+    gathered result must equal the unchunked computation, for even and odd chunk counts."""
+    import torch.distributed as tdist
+
+    from diffsptk_amd import dist as ddist
+
+    class _Work:
+        def wait(self):
+            return True
+
+    def fake_all_gather(outs, src, group=None, async_op=False):
+        for o in outs:
+            o.copy_(src)
+        return _Work()
+
+    monkeypatch.setattr(tdist, "is_initialized", lambda: True)
+    monkeypatch.setattr(tdist, "get_world_size", lambda group=None: 2)
+    monkeypatch.setattr(tdist, "all_gather", fake_all_gather)
+    stft = dsp.STFT(400, 80, 512, device=DEV)
+    mcep = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=3, device=DEV)
+    x = torch.randn(12, 4000, generator=torch.Generator().manual_seed(5)).to(DEV)
+    ref = mcep(stft(x))
+    for n_chunks in (1, 2, 3, 5):
+        y = ddist.analyze_chunked_overlap(x, lambda w: mcep(stft(w)), n_chunks)
+        torch.cuda.synchronize()
+        assert y.shape == (24, *ref.shape[1:])
+        assert torch.equal(y[:12], ref) and torch.equal(y[12:], ref)
