@@ -65,6 +65,20 @@ __device__ __forceinline__ void split2(float x0, float x1, f16x2& hi, f16x2& lo)
     hi = __builtin_convertvector(f32x2v{x0, x1}, f16x2);
     lo = __builtin_convertvector(f32x2v{x0 - (float)hi[0], x1 - (float)hi[1]}, f16x2);
 }
+// c * s + b on both halves of a register pair: v_pk_fma_f32 (two flops per lane and issue slot)
+#ifdef DSA_MCEP_NOPK
+__device__ __forceinline__ f32x2v fma2(f32x2v c, float s, f32x2v b)
+{
+    float r0 = __builtin_fmaf(c[0], s, b[0]), r1 = __builtin_fmaf(c[1], s, b[1]);
+    asm volatile("" : "+v"(r0));
+    return f32x2v{r0, r1};
+}
+#else
+__device__ __forceinline__ f32x2v fma2(f32x2v c, float s, f32x2v b) { return c * f32x2v{s, s} + b; }
+#endif
+__device__ __forceinline__ f32x2v lo2(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2v hi2(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+
 __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo)
 {
     hi = (_Float16)x;
@@ -291,11 +305,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
 #pragma unroll
             for (int mt = 0; mt < 16; ++mt) {
                 const f32x4 c = dtile(mt, 0.f);
-                const float u0 = __builtin_fmaxf(__builtin_fmaf(c[0], kInvSDM, logx[mt][0]),
-                                                 __builtin_fmaf(c[1], kInvSDM, logx[mt][1]));
-                const float u1 = __builtin_fmaxf(__builtin_fmaf(c[2], kInvSDM, logx[mt][2]),
-                                                 __builtin_fmaf(c[3], kInvSDM, logx[mt][3]));
-                tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(u0, u1));
+                const f32x2v ta = fma2(lo2(c), kInvSDM, lo2(logx[mt])), tb = fma2(hi2(c), kInvSDM, hi2(logx[mt]));
+                tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(__builtin_fmaxf(ta[0], ta[1]), __builtin_fmaxf(tb[0], tb[1])));
             }
             tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             // ------------- pass 2: e = exp2(t + sh), second chain rt^T += E^T e^T  (mcep.py:212-215);
             // the first chain of bins 32 (j + 1) .. is issued ahead of the vector work of bins 32 j .. ----
             f32x4 accB[3] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-            float rt48 = 0.f;
+            f32x2v rt48v = {0.f, 0.f};
             f32x4 cc[2] = {dtile(0, cinit), dtile(1, cinit)};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -322,12 +333,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                 for (int tt = 0; tt < 2; ++tt) {
                     const int mt = 2 * j + tt;
                     const f32x4 c48 = E484[mt * 4 + g];
-                    float e[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(cc[tt][r], kInvSDM, logx[mt][r]));  // mcep.py:212
-                        rt48 = __builtin_fmaf(e[r], c48[r], rt48);
-                    }
+                    const f32x2v ta = fma2(lo2(cc[tt]), kInvSDM, lo2(logx[mt])), tb = fma2(hi2(cc[tt]), kInvSDM, hi2(logx[mt]));
+                    const float e[4] = {__builtin_amdgcn_exp2f(ta[0]), __builtin_amdgcn_exp2f(ta[1]),
+                                        __builtin_amdgcn_exp2f(tb[0]), __builtin_amdgcn_exp2f(tb[1])};  // mcep.py:212
+                    rt48v = f32x2v{e[0], e[1]} * lo2(c48) + rt48v;
+                    rt48v = f32x2v{e[2], e[3]} * hi2(c48) + rt48v;
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
                         f16x2 h, l;
@@ -350,6 +360,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
 #pragma unroll
             for (int it = 0; it < 3; ++it)  // Nyquist bin: one float32 k-step, k-slot 0 only (bit-mask select: no branch)
                 accB[it] = mfma4(keep_if(g_eq0, lds[H_E256 + it * 16 + n]), keep_if(g_eq0, e256), accB[it]);
+            float rt48 = rt48v[0] + rt48v[1];
             rt48 += __shfl_xor(rt48, 16, 64);
             rt48 += __shfl_xor(rt48, 32, 64);
             rt48 = __builtin_fmaf(e256, lds[H_E256 + 48], rt48);

@@ -35,7 +35,7 @@ int main(int argc, char** argv)
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int variant : {4, 8, 16}) {
         float ms = 0;
-        for (int rep = 0; rep < 3; ++rep) {
+        for (int rep = 0; rep < (argc > 2 ? atoi(argv[2]) : 3); ++rep) {
             hipEventRecord(e0);
             if (variant == 16) dsa::launch_h<8>(X, F, 10, G, D, E, av, mc, nullptr, 0, "h8");
             else if (variant == 4) dsa::launch_v2<4>(X, F, 10, G, D, E, av, mc, nullptr, 0, "w4");
