@@ -24,6 +24,8 @@
 #include "common.h"
 
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
 #include <utility>
 
 namespace dsa {
@@ -1514,26 +1516,35 @@ static int launch_v3(const void* X, int64_t F, int n_iter, const void* G, const 
     return check_launch("mcep_mfma_fwd_split");
 }
 
-// rotating pool of tile-queue counters (one per in-flight launch; zeroed on the launch stream)
+// Rotating pools of per-launch scratch (tile-queue counters, operand images of the split-precision
+// kernel).  Allocated once under std::call_once, slots handed out by an atomic counter: launches
+// from several host threads / streams never share a slot unless more than kSlots are in flight.
 static unsigned int* queue_slot(hipStream_t st)
 {
     static unsigned int* pool = nullptr;
-    static unsigned int next = 0;
+    static std::once_flag once;
+    static std::atomic<unsigned int> next{0};
     constexpr unsigned int kSlots = 256;
-    if (!pool && hipMalloc((void**)&pool, 2 * kSlots * sizeof(unsigned int)) != hipSuccess) return nullptr;
-    unsigned int* q = pool + 2 * (next++ % kSlots);  // two counters per launch
+    std::call_once(once, [] {
+        if (hipMalloc((void**)&pool, 2 * kSlots * sizeof(unsigned int)) != hipSuccess) pool = nullptr;
+    });
+    if (!pool) return nullptr;
+    unsigned int* q = pool + 2 * (next.fetch_add(1, std::memory_order_relaxed) % kSlots);  // two counters per launch
     if (hipMemsetAsync(q, 0, 2 * sizeof(unsigned int), st) != hipSuccess) return nullptr;
     return q;
 }
 
-// rotating pool of operand-image workspaces for the split-precision kernel (112 KB each)
 static _Float16* image_slot()
 {
     static _Float16* pool = nullptr;
-    static unsigned int next = 0;
-    constexpr unsigned int kSlots = 64;
-    if (!pool && hipMalloc((void**)&pool, (size_t)kSlots * mh::IMG_BYTES) != hipSuccess) return nullptr;
-    return pool + (size_t)(next++ % kSlots) * (mh::IMG_BYTES / 2);
+    static std::once_flag once;
+    static std::atomic<unsigned int> next{0};
+    constexpr unsigned int kSlots = 64;  // 112 KB each
+    std::call_once(once, [] {
+        if (hipMalloc((void**)&pool, (size_t)kSlots * mh::IMG_BYTES) != hipSuccess) pool = nullptr;
+    });
+    if (!pool) return nullptr;
+    return pool + (size_t)(next.fetch_add(1, std::memory_order_relaxed) % kSlots) * (mh::IMG_BYTES / 2);
 }
 
 template <int WAVES>
