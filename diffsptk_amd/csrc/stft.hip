@@ -1146,6 +1146,8 @@ static void stft512_launch(bool zmean, dim3 grid, int lds, hipStream_t st, const
 
 }  // namespace dsa
 
+#include "stft_mfma.h"
+
 using namespace dsa;
 
 // =========================================================================== C-ABI
@@ -1353,6 +1355,15 @@ DSA_EXPORT int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int3
     bool tuned_ok = dtype == DSA_F32 && nfft == 512 && L <= 512 && lds <= 64 * 1024;
     if (algo == DSA_ALGO_TUNED && !tuned_ok)
         return fail(DSA_ERR_UNSUPPORTED, "stft: tuned kernel needs float32, fft_length 512, frame_length <= 512%s");
+    // DSA_STFT_VARIANT (A/B knob): 1 = matrix-core kernel where it applies (default), 0 = register FFT only
+    static const int stft_variant = [] {
+        const char* e = getenv("DSA_STFT_VARIANT");
+        return e ? atoi(e) : 0;
+    }();
+    if (tuned_ok && algo != DSA_ALGO_GENERIC && stft_variant == 1 && !zmean && !use_floor &&
+        out_format != DSA_SPEC_COMPLEX)
+        return stft512_mfma_launch((const float*)x, (long)B, (long)T, (long)N, L, P, left, pad_mode, (const float*)w,
+                                   (float)eps, out_format, (float*)y, st);
     if (tuned_ok && algo != DSA_ALGO_GENERIC) {
         int chunks_per_utt = (int)((N + kFPW - 1) / kFPW);
         long total_chunks = (long)B * chunks_per_utt;
