@@ -1358,10 +1358,11 @@ DSA_EXPORT int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int3
     // DSA_STFT_VARIANT (A/B knob): 1 = matrix-core kernel where it applies (default), 0 = register FFT only
     static const int stft_variant = [] {
         const char* e = getenv("DSA_STFT_VARIANT");
-        return e ? atoi(e) : 0;
+        return e ? atoi(e) : 1;
     }();
     if (tuned_ok && algo != DSA_ALGO_GENERIC && stft_variant == 1 && !zmean && !use_floor &&
-        out_format != DSA_SPEC_COMPLEX)
+        out_format != DSA_SPEC_COMPLEX && pad_mode == DSA_PAD_CONSTANT && T < (1L << 29) && (L & 3) == 0 &&
+        (P & 3) == 0 && (left & 3) == 0 && 15 * P + L <= 2048)
         return stft512_mfma_launch((const float*)x, (long)B, (long)T, (long)N, L, P, left, pad_mode, (const float*)w,
                                    (float)eps, out_format, (float*)y, st);
     if (tuned_ok && algo != DSA_ALGO_GENERIC) {

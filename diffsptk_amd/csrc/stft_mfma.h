@@ -105,35 +105,52 @@ static const float* stft_mfma_tables()
     return dev;
 }
 
+// Packed complex arithmetic on (re, im) register pairs.  The half-swaps and sign flips of complex
+// products and of multiplications by -i are operand modifiers of the packed instructions (op_sel /
+// neg_lo / neg_hi); hipcc materialises them as extra v_mov / v_xor, hence the inline assembly.
 __device__ __forceinline__ sf32x2 cmul2(sf32x2 a, sf32x2 t)
 {
-    // (a.x t.x - a.y t.y, a.y t.x + a.x t.y): two packed instructions
-    return a * sf32x2{t.x, t.x} + sf32x2{-a.y, a.x} * sf32x2{t.y, t.y};
+    // t1 = (a.x t.x, a.y t.x) in plain C: `a` comes straight out of MFMA accumulators, and only an
+    // instruction the compiler knows gets the MFMA-result wait states in front of it;
+    // r = (t1.x - a.y t.y, t1.y + a.x t.y)
+    const sf32x2 t1 = a * sf32x2{t.x, t.x};
+    sf32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(t), "v"(t1));
+    return r;
 }
-__device__ __forceinline__ sf32x2 mul_neg_i(sf32x2 a) { return sf32x2{a.y, -a.x}; }  // -i a
+__device__ __forceinline__ sf32x2 add_negi(sf32x2 a, sf32x2 b)  // a - i b = (a.x + b.y, a.y - b.x)
+{
+    sf32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ sf32x2 add_posi(sf32x2 a, sf32x2 b)  // a + i b = (a.x - b.y, a.y + b.x)
+{
+    sf32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ sf32x2 diff_sum(sf32x2 b)  // (b.x - b.y, b.x + b.y)
+{
+    sf32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(r) : "v"(b), "v"(b));
+    return r;
+}
 
-// out[j] = sum_p W8^(p j) u[p]
+// out[j] = sum_p W8^(p j) u[p]: 26 packed instructions
 __device__ __forceinline__ void dft8(const sf32x2 (&u)[8], sf32x2 (&y)[8])
 {
-    constexpr float R2 = 0.70710678118654752f;
+    const sf32x2 r2 = {0.70710678118654752f, 0.70710678118654752f};
     const sf32x2 s04 = u[0] + u[4], d04 = u[0] - u[4], s26 = u[2] + u[6], d26 = u[2] - u[6];
     const sf32x2 s15 = u[1] + u[5], d15 = u[1] - u[5], s37 = u[3] + u[7], d37 = u[3] - u[7];
-    const sf32x2 a0 = s04 + s26, a2 = s04 - s26, a1 = d04 + mul_neg_i(d26), a3 = d04 - mul_neg_i(d26);
-    const sf32x2 b0 = s15 + s37, b2 = s15 - s37, b1 = d15 + mul_neg_i(d37), b3 = d15 - mul_neg_i(d37);
-    // W8^1 b1 = (1 - i)/sqrt2 b1,  W8^2 b2 = -i b2,  W8^3 b3 = (-1 - i)/sqrt2 b3
-    const sf32x2 w1 = sf32x2{b1.x + b1.y, b1.y - b1.x} * sf32x2{R2, R2};
-    const sf32x2 w2 = mul_neg_i(b2);
-    const sf32x2 w3 = sf32x2{b3.y - b3.x, -b3.x - b3.y} * sf32x2{R2, R2};
+    const sf32x2 a0 = s04 + s26, a2 = s04 - s26, a1 = add_negi(d04, d26), a3 = add_posi(d04, d26);
+    const sf32x2 b0 = s15 + s37, b2 = s15 - s37, b1 = add_negi(d15, d37), b3 = add_posi(d15, d37);
+    // W8^1 b1 = r2 (b1.x + b1.y, b1.y - b1.x);  W8^2 b2 = -i b2;  W8^3 b3 = -r2 (b3.x - b3.y, b3.x + b3.y)
+    const sf32x2 t1 = add_negi(b1, b1), t3 = diff_sum(b3);
     y[0] = a0 + b0; y[4] = a0 - b0;
-    y[1] = a1 + w1; y[5] = a1 - w1;
-    y[2] = a2 + w2; y[6] = a2 - w2;
-    y[3] = a3 + w3; y[7] = a3 - w3;
-}
-
-// non-constant padding modes (index arithmetic with 64-bit remainders): out of line, edges only
-__device__ __attribute__((noinline)) float stft_mfma_load_padded(const float* xb, long t, long Tlen, int mode)
-{
-    return load_padded(xb, t, Tlen, mode);
+    y[1] = t1 * r2 + a1; y[5] = a1 - t1 * r2;
+    y[2] = add_negi(a2, b2); y[6] = add_posi(a2, b2);
+    y[3] = a3 - t3 * r2; y[7] = t3 * r2 + a3;
 }
 
 template <bool PLAIN>
@@ -143,9 +160,10 @@ __global__ __launch_bounds__(sm::WAVES * 64, 2) void stft512_mfma_kernel(
     float* __restrict__ y, long total_tiles, int tiles_per_utt)
 {
     using namespace sm;
+    (void)mode;  // constant padding only (the dispatcher keeps the other modes on the register-FFT kernel)
     extern __shared__ __attribute__((aligned(16))) float slds[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tiles, descriptors
     const int c = lane & 15, g = lane >> 4;
 
     for (int i = tid; i < TAB_IMG_WORDS + 512 + 16; i += WAVES * 64) slds[i] = tab[i];
@@ -162,58 +180,85 @@ __global__ __launch_bounds__(sm::WAVES * 64, 2) void stft512_mfma_kernel(
 
     const long wave_id = (long)blockIdx.x * WAVES + wave;
     const long wave_stride = (long)gridDim.x * WAVES;
+#ifdef DSA_STFT_TIMING
+#define MSTAMP(i)                                                                                  \
+    do {                                                                                           \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && tile == wave_id + 2 * wave_stride)              \
+            g_stft_stamps[i] = __builtin_readcyclecounter();                                       \
+    } while (0)
+#else
+#define MSTAMP(i)
+#endif
+    // Stage-in of a tile: the 15 P + L samples its 16 frames share, in fully coalesced 16-byte loads.
+    // (Letting every lane load its own 256-byte run from global memory costs one L1 tag lookup per lane
+    // and instruction: the kernel then runs at the texture pipe's pace, 3x slower.)  The loads go
+    // through a buffer descriptor of the utterance [xb, xb + T): the hardware range check returns 0 for
+    // every dword outside it, which IS constant (zero) padding at both edges -- no branches.  They are
+    // issued one tile ahead (8 x 4 registers), so HBM latency hides behind the matrix products.
+    constexpr int PRE = 8;  // 16-byte pieces per lane: up to 2048 samples per tile
+    const int n4 = (15 * P + L + 3) >> 2;
+    sf32x4 pre[PRE];
+    auto prefetch = [&](long tl) __attribute__((always_inline)) {
+        // branch-free: past the last tile the descriptor covers 0 bytes (every load returns 0), and the
+        // pieces past the 15 P + L samples get an offset outside any utterance
+        const bool live = tl < total_tiles;
+        const long tb = live ? tl / tiles_per_utt : 0;
+        const long t_tile = (tl - tb * tiles_per_utt) * 16 * (long)P - left;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(x + tb * Tlen), 0, live ? (int)(Tlen * 4) : 0, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < PRE; ++it) {
+            const int s4i = lane + 64 * it;
+            const unsigned off = s4i < n4 ? (unsigned)((t_tile + 4 * s4i) * 4) : 0xfffffff0u;
+            pre[it] = __builtin_bit_cast(sf32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0));
+        }
+    };
+    prefetch(wave_id);
+    const float* run = stage + c * P + 64 * g;           // this lane's run: samples 0 .. 63 (+ 256) of its frame
+    const bool head_full = L >= 256;                      // every sample of k-step 0 is inside the frame
     for (long tile = wave_id; tile < total_tiles; tile += wave_stride) {
+        MSTAMP(0);
         const long b = tile / tiles_per_utt;
         const long f0 = (tile - b * tiles_per_utt) * 16;
         const int nvalid = (int)((N - f0) < 16 ? (N - f0) : 16);
         const bool fvalid = c < nvalid;
-        const float* xb = x + b * Tlen;
-        const long t_frame = (f0 + c) * (long)P - left;  // signal index of sample 0 of this lane's frame
 
         // ---------------- this lane's 2 x 64 samples: window, per-frame scale, binary16 split ----------------
-        // B operand of phase p, k-step ks: slot i <-> sample n = 256 ks + 64 g + 8 i + p
-        sf16x8 bh[2][8], bl[2][8];
-        float xw[2][64];
+        // B operand of phase p, k-step ks: slot i <-> sample n = 256 ks + 64 g + 8 i + p.
+        // Two passes over the same 2 x 16 pieces of 16 bytes: first the per-frame maximum of |x w|, then
+        // scale, split and pack -- the raw samples are never all live next to the 128 registers of
+        // packed operands.
+        {
+            sf32x4* st4 = reinterpret_cast<sf32x4*>(stage);
+#pragma unroll
+            for (int it = 0; it < PRE; ++it) {
+                const int s4i = lane + 64 * it;
+                st4[s4i] = pre[it];   // (pieces past the 15 P + L samples hold zeros; the tile has room for all 8 KB)
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // a piece = 4 consecutive samples of this lane's run, times the window; samples past the frame are
+        // never read (zero padding is exact; non-finite neighbours stay out of frames that do not
+        // contain them: frame.py:135-138).  frame_length and frame_period are multiples of 4 here.
+        auto piece = [&](int ks, int q, unsigned pass_tag) __attribute__((always_inline)) {
+            (void)pass_tag;
+            const int n = 256 * ks + 64 * g + 4 * q;   // frame-relative index of the first sample
+            sf32x4 v = {0.f, 0.f, 0.f, 0.f};
+            // (k-step 0 of the usual frame lengths >= 256 needs no per-lane test: one uniform branch)
+            if ((ks == 0 && head_full) ? fvalid : (fvalid && n < L))
+                v = *reinterpret_cast<const sf32x4*>(run + 256 * ks + 4 * q) * *reinterpret_cast<const sf32x4*>(slds + L_WIN + n);   // window.py:190
+            return v;
+        };
         float amax = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int n0 = 256 * ks + 64 * g;
-            const long t0 = t_frame + n0;
-            const float* wl = slds + L_WIN + n0;
-            // samples past the frame are selected away, never multiplied: zero padding is exact and
-            // non-finite neighbours stay out of frames that do not contain them (frame.py:135-138)
-            const int need = L - n0 < 64 ? (L - n0 < 0 ? 0 : ((L - n0 + 3) & ~3)) : 64;  // floats this run touches
-            const bool fast = fvalid && t0 >= 0 && t0 + need <= Tlen && (((size_t)(xb + t0)) & 15) == 0;
-            if (fast) {
-                const sf32x4* src = reinterpret_cast<const sf32x4*>(xb + t0);
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    sf32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (4 * q < need) v = src[q];
-                    const sf32x4 ww = *reinterpret_cast<const sf32x4*>(wl + 4 * q);
-                    xw[ks][4 * q + 0] = n0 + 4 * q + 0 < L ? v.x * ww.x : 0.f;   // window.py:190
-                    xw[ks][4 * q + 1] = n0 + 4 * q + 1 < L ? v.y * ww.y : 0.f;
-                    xw[ks][4 * q + 2] = n0 + 4 * q + 2 < L ? v.z * ww.z : 0.f;
-                    xw[ks][4 * q + 3] = n0 + 4 * q + 3 < L ? v.w * ww.w : 0.f;
-                }
-            } else {
-                // utterance edges (on-the-fly padding), unaligned rows, frames past the end of the utterance
-#pragma unroll
-                for (int e = 0; e < 64; ++e) {
-                    const long t = t0 + e;
-                    float v = 0.f;
-                    if (fvalid && n0 + e < L) {
-                        if (t >= 0 && t < Tlen) v = xb[t];
-                        else if (mode != DSA_PAD_CONSTANT) v = stft_mfma_load_padded(xb, t, Tlen, mode);
-                        v *= wl[e];
-                    }
-                    xw[ks][e] = v;
-                }
+            for (int q = 0; q < 16; ++q) {
+                const sf32x4 v = piece(ks, q, 0u);
+                amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v.x)), __builtin_fabsf(v.y));
+                amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v.z)), __builtin_fabsf(v.w));
             }
-#pragma unroll
-            for (int e = 0; e < 64; e += 2)
-                amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(xw[ks][e]), __builtin_fabsf(xw[ks][e + 1])));
-        }
+        MSTAMP(1);
         amax = __builtin_fmaxf(amax, __shfl_xor(amax, 16, 64));
         amax = __builtin_fmaxf(amax, __shfl_xor(amax, 32, 64));
         // amax = 2^(ex-1) [1, 2):  scaled samples are below 2^14
@@ -221,19 +266,28 @@ __global__ __launch_bounds__(sm::WAVES * 64, 2) void stft512_mfma_kernel(
         const float scale = __builtin_ldexpf(1.f, XMAX_LOG2 - ex);
         // |X|^2 = (accumulated value)^2 * 4^-(SA_LOG2 + XMAX_LOG2 - ex)
         const float c2 = __builtin_ldexpf(1.f, 2 * (ex - XMAX_LOG2 - SA_LOG2));
+        sf16x8 bh[2][8], bl[2][8];
+        const unsigned tag = 0u;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int p = 0; p < 8; ++p)
+            for (int qq = 0; qq < 16; qq += 4)
 #pragma unroll
-                for (int i = 0; i < 8; i += 2) {
-                    const float v0 = xw[ks][8 * i + p] * scale, v1 = xw[ks][8 * (i + 1) + p] * scale;
-                    const sf16x2 h = __builtin_convertvector(sf32x2{v0, v1}, sf16x2);
-                    const sf16x2 l = __builtin_convertvector(sf32x2{v0 - (float)h[0], v1 - (float)h[1]}, sf16x2);
-                    bh[ks][p][i] = h[0]; bh[ks][p][i + 1] = h[1];
-                    bl[ks][p][i] = l[0]; bl[ks][p][i + 1] = l[1];
+                for (int qo = 0; qo < 2; ++qo) {
+                    // pieces q and q + 2 hold slots i = q >> 1 and i + 1 of the phases 4 (q & 1) .. + 3
+                    const int q = qq + qo, i = q >> 1, pb = 4 * (q & 1);
+                    const sf32x4 va = piece(ks, q, tag) * scale, vb = piece(ks, q + 2, tag) * scale;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const sf16x2 h = __builtin_convertvector(sf32x2{va[j], vb[j]}, sf16x2);
+                        const sf16x2 l = __builtin_convertvector(sf32x2{va[j] - (float)h[0], vb[j] - (float)h[1]}, sf16x2);
+                        bh[ks][pb + j][i] = h[0]; bh[ks][pb + j][i + 1] = h[1];
+                        bl[ks][pb + j][i] = l[0]; bl[ks][pb + j][i + 1] = l[1];
+                    }
                 }
 
+        MSTAMP(2);
+        __builtin_amdgcn_wave_barrier();  // the staged samples are consumed: the tile now collects the output
         // ---------------- per 16 rows: eight sub-DFT products, then twiddle + DFT-8 over the phases ----------------
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -249,6 +303,14 @@ __global__ __launch_bounds__(sm::WAVES * 64, 2) void stft512_mfma_kernel(
                     acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks][p], acc[p], 0, 0, 0);
                     acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ks][p], acc[p], 0, 0, 0);
                 }
+            }
+            if (mt == 3) {
+                // The next tile's samples are requested as soon as the packed operands are dead (after the
+                // last matrix product): HBM latency hides behind the last twiddle / DFT-8 block and the
+                // output copy, and the 32 prefetch registers never coexist with the 128 operand registers.
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch(tile + wave_stride);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -316,20 +378,22 @@ __global__ __launch_bounds__(sm::WAVES * 64, 2) void stft512_mfma_kernel(
                 }
             }
         }
+        MSTAMP(3);
         __builtin_amdgcn_wave_barrier();
         // ---------------- the staged 16 x 257 tile leaves as one contiguous run ----------------
         const long out0 = (b * N + f0) * K;
-        const int total = nvalid * K;
-        if ((out0 & 3) == 0) {
+        if (nvalid == 16 && (out0 & 3) == 0) {
             sf32x4* y4 = reinterpret_cast<sf32x4*>(y + out0);
             const sf32x4* s4 = reinterpret_cast<const sf32x4*>(stage);
-            const int n4 = total >> 2;
-            for (int t = lane; t < n4; t += 64) y4[t] = s4[t];
-            for (int t = (n4 << 2) + lane; t < total; t += 64) y[out0 + t] = stage[t];
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) y4[lane + 64 * it] = s4[lane + 64 * it];   // (4 in flight: the prefetch
+            if (lane < 16 * K / 4 - 1024) y4[lane + 1024] = s4[lane + 1024];           //  registers stay resident)
         } else {
+            const int total = nvalid * K;
             for (int t = lane; t < total; t += 64) y[out0 + t] = stage[t];
         }
         __builtin_amdgcn_wave_barrier();
+        MSTAMP(4);
     }
 }
 
