@@ -1355,10 +1355,11 @@ DSA_EXPORT int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int3
     bool tuned_ok = dtype == DSA_F32 && nfft == 512 && L <= 512 && lds <= 64 * 1024;
     if (algo == DSA_ALGO_TUNED && !tuned_ok)
         return fail(DSA_ERR_UNSUPPORTED, "stft: tuned kernel needs float32, fft_length 512, frame_length <= 512%s");
-    // DSA_STFT_VARIANT (A/B knob): 1 = matrix-core kernel where it applies (default), 0 = register FFT only
+    // DSA_STFT_VARIANT: 0 = register-FFT kernel (default); 1 = experimental matrix-core kernel where it
+    // applies (faster, but see the STATUS note in stft_mfma.h: not yet deterministic)
     static const int stft_variant = [] {
         const char* e = getenv("DSA_STFT_VARIANT");
-        return e ? atoi(e) : 1;
+        return e ? atoi(e) : 0;
     }();
     if (tuned_ok && algo != DSA_ALGO_GENERIC && stft_variant == 1 && !zmean && !use_floor &&
         out_format != DSA_SPEC_COMPLEX && pad_mode == DSA_PAD_CONSTANT && T < (1L << 29) && (L & 3) == 0 &&

@@ -213,7 +213,7 @@ def test_stft_datawav_golden(golden, name, dt):
     g = golden("datawav")
     x = dev(wav_float(g["pcm"], np.float64), dt)
     y = dsp.STFT(400, 80, 512, dtype=dt, device=DEV)(x)
-    assert _lib.last_kernel() == ("stft512_mfma_fwd" if dt == torch.float32 else "row_dft_generic")
+    assert _lib.last_kernel() == ("stft512_fwd" if dt == torch.float32 else "row_dft_generic")
     assert y.shape == (240, 257)
     if dt == torch.float64:
         close(host(y), g["stft_power_f64"], **F64)
@@ -237,15 +237,10 @@ def test_stft_tuned_vs_generic_vs_oracle_options():
         dict(out_format="db"), dict(out_format="log-magnitude"), dict(out_format="magnitude"),
         dict(relative_floor=-30), dict(relative_floor=-30, out_format="db"), dict(eps=0.0),
     ]
-    for L, P in ((400, 80), (512, 128), (25, 10), (399, 77), (512, 64), (256, 100), (320, 40), (12, 4)):
+    for L, P in ((400, 80), (512, 128), (25, 10), (399, 77), (512, 64), (256, 104), (320, 40), (16, 8), (12, 4)):
         for kw in cases:
             y = F.stft(xd, frame_length=L, frame_period=P, fft_length=512, **kw)
-            # the matrix-core kernel takes the real-valued formats with constant padding when the frame
-            # geometry is 16-byte friendly; everything else stays on the register-FFT kernel
-            left = L // 2 if kw.get("center", True) else 0
-            mfma = (L % 4 == 0 and P % 4 == 0 and left % 4 == 0 and 15 * P + L <= 2048 and not kw.get("zmean") and
-                    kw.get("mode", "constant") == "constant" and kw.get("relative_floor") is None)
-            assert _lib.last_kernel() == ("stft512_mfma_fwd" if mfma else "stft512_fwd"), (L, P, kw)
+            assert _lib.last_kernel() == "stft512_fwd", (L, P, kw)
             ref = O.stft(x64, L, P, 512, **kw)
             if kw.get("out_format") in ("db", "log-magnitude"):
                 scale = 10 / np.log(10) if kw["out_format"] == "db" else 0.5
