@@ -1231,9 +1231,18 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel(
     }
 }
 
+int mcep_mfma_bwd_h(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* G, const void* D,
+                    const void* E, const void* av, void* gX, hipStream_t st);
+
 int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* G, const void* D,
                   const void* E, const void* av, void* gX, hipStream_t st)
 {
+    // DSA_MCEP_BWD_VARIANT (A/B knob): 16 = split-precision binary16 MFMA chains (default), 8 = float32 MFMA chains
+    static const int variant = [] {
+        const char* e = getenv("DSA_MCEP_BWD_VARIANT");
+        return e ? atoi(e) : 16;
+    }();
+    if (variant == 16) return mcep_mfma_bwd_h(gmc, X, hist, F, n_iter, G, D, E, av, gX, st);
     const int lds_bytes = mmb::LDS_FLOATS * 4;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1495,6 +1504,7 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_fwd_kernel_v3(
 
 }  // namespace dsa
 #include "mcep_mfma_f16.h"
+#include "mcep_mfma_bwd_f16.h"
 namespace dsa {
 
 static int launch_v3(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E,
@@ -1597,6 +1607,47 @@ static int launch_h(const void* X, int64_t F, int n_iter, const void* G, const v
                        (const float*)X, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
                        (const float*)av, (float*)mc, (float*)hist, ntiles16, tiles_shared, queue, (const _Float16*)img);
     return check_launch(name);
+}
+
+static _Float16* image_slot_b()
+{
+    static _Float16* pool = nullptr;
+    static std::once_flag once;
+    static std::atomic<unsigned int> next{0};
+    constexpr unsigned int kSlots = 32;  // 240 KB each
+    constexpr size_t kStride = ((size_t)mhb::IMG_B_BYTES + 255) & ~(size_t)255;
+    std::call_once(once, [] {
+        if (hipMalloc((void**)&pool, kSlots * kStride) != hipSuccess) pool = nullptr;
+    });
+    if (!pool) return nullptr;
+    return pool + (size_t)(next.fetch_add(1, std::memory_order_relaxed) % kSlots) * (kStride / 2);
+}
+
+int mcep_mfma_bwd_h(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* G, const void* D,
+                    const void* E, const void* av, void* gX, hipStream_t st)
+{
+    const int lds_bytes = mhb::B_LDS_FLOATS * 4;
+    static std::once_flag once;
+    static bool attr_ok = true;
+    std::call_once(once, [&] {
+        attr_ok = hipFuncSetAttribute((const void*)mcep_mfma_bwd_kernel_h, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      lds_bytes) == hipSuccess;
+    });
+    if (!attr_ok) return fail(DSA_ERR_LAUNCH, "mcep_mfma_bwd: cannot reserve the LDS operand images%s");
+    unsigned int* queue = queue_slot(st);
+    _Float16* img = image_slot_b();
+    if (!queue || !img) return fail(DSA_ERR_LAUNCH, "mcep_mfma_bwd: cannot set up the tile queue / operand images%s");
+    hipLaunchKernelGGL(mcep_h_prep_kernel, dim3((mh::IMG_D + mh::IMG_E + mh::IMG_G + 255) / 256), dim3(256), 0, st,
+                       (const float*)G, (const float*)D, (const float*)E, img);
+    hipLaunchKernelGGL(mcep_hb_prep_kernel, dim3((mhb::IMG_EB + mhb::IMG_DB + mhb::IMG_GB + 255) / 256), dim3(256), 0, st,
+                       (const float*)G, (const float*)D, (const float*)E, img);
+    long ntiles16 = (long)((F + 15) / 16);
+    long blocks = (ntiles16 + mhb::WAVES_B - 1) / mhb::WAVES_B;
+    long grid = blocks < 256 ? blocks : 256;
+    hipLaunchKernelGGL(mcep_mfma_bwd_kernel_h, dim3((unsigned)grid), dim3(256), lds_bytes, st, (const float*)gmc,
+                       (const float*)X, (const float*)hist, (long)F, n_iter, (const float*)av, (float*)gX, ntiles16, queue,
+                       (const _Float16*)img);
+    return check_launch("mcep_mfma_bwd");
 }
 
 int mcep_mfma_fwd(const void* X, int64_t F, int nfft, int M, int n_iter, const void* G, const void* D,

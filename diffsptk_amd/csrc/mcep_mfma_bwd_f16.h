@@ -1,0 +1,458 @@
+// Split-precision backward of the tuned mel-cepstral analysis (included by mcep_mfma.hip after
+// mcep_mfma_f16.h).  Same mathematics as mcep_mfma_bwd_kernel (reverse sweep over the unrolled Newton
+// iteration from the saved iterates, mcep.py:189-224 under autograd), with every matrix chain on
+// v_mfma_f32_16x16x32_f16 as three binary16 products per float32 operand pair:
+//   forward re-computation   d^T = D^T mc_k^T,  rt^T = E^T e^T          (images DH/DL, EH/EL in LDS)
+//   backward                 ebar^T = E rtbar^T                          (image EB, 64 KB, streamed from L2)
+//                            mbar^T += (-2 D) zbar^T,  zbar = ebar * e   (image DB in LDS)
+//   epilogue                 lbar^T += G mbar_0^T                        (image GB, streamed once per tile)
+// The cotangent operands (rtbar, zbar, mbar_0) have no a-priori range, so each is scaled per frame by
+// a power of two taken from its own maximum before the binary16 split (frames are MFMA columns: a
+// per-frame scale factors out of the product exactly); e is scaled as in the forward kernel.
+// One wave = 16 frames, 4 waves per workgroup (512 registers: log2 X, lbar, e and zbar stay resident),
+// tiles drawn from a device counter.
+#pragma once
+
+namespace dsa {
+
+namespace mhb {
+using namespace mh;
+constexpr int WAVES_B = 4;
+constexpr float SEB = 65536.f;   // scale of the E image with bins as rows (|E| <= ~0.0044)
+constexpr int SEB_LOG2 = 16;
+constexpr float SDB = 256.f;     // scale of the -2 D image (|2 D| <= ~2.2)
+constexpr int SDB_LOG2 = 8;
+constexpr float SGB = 4096.f;    // scale of the G image with bins as rows (|G| <= 0.13)
+constexpr int SGB_LOG2 = 12;
+constexpr int VMAX_LOG2 = 13;    // per-frame scaled cotangents are below 2^13
+// backward images (binary16 elements) behind the forward ones in the per-launch workspace
+constexpr int IMG_EB = 16 * 2 * 64 * 8, IMG_DB = 2 * 8 * 64 * 8, IMG_GB = 16 * 64 * 8;
+constexpr int B_BASE = IMG_BYTES / 2;                 // halves: forward images + the Nyquist row of G
+constexpr int IMG_EBH = B_BASE, IMG_EBL = IMG_EBH + IMG_EB;
+constexpr int IMG_DBH = IMG_EBL + IMG_EB, IMG_DBL = IMG_DBH + IMG_DB;
+constexpr int IMG_GBH = IMG_DBL + IMG_DB, IMG_GBL = IMG_GBH + IMG_GB;
+constexpr int IMG_B_HALVES = IMG_GBL + IMG_GB;
+constexpr int TAIL_B = 32 + 64 + 256;                 // float32: -2 D[c][256] | E[256][m] | E[bin][48]
+constexpr int IMG_B_BYTES = IMG_B_HALVES * 2 + TAIL_B * 4;
+// LDS carve-up (float units)
+constexpr int B_DB = EL_OFF + 24 * 64 * 4;            // DB hi | lo: 2 x 4096 floats
+constexpr int B_E48 = B_DB + 2 * IMG_DB / 2;          // [16 mt][4 g][4 r]
+constexpr int B_E256 = B_E48 + 256;                   // [48] scaled by SE, [48] unscaled, then [64] unscaled E[256][m] (0 past 48)
+constexpr int B_D256 = B_E256 + 52 + 64;              // [32] -2 log2(e) D[c][256], then [32] -2 D[c][256]
+constexpr int B_AV = B_D256 + 64;                     // [28]
+constexpr int B_WAVE = B_AV + 28;
+constexpr int FS = 180;                               // per-frame record: rt [0,52) | rr [52,116) | aux [116,180)
+constexpr int B_WAVE_FLOATS = 16 * FS;
+constexpr int B_LDS_FLOATS = B_WAVE + WAVES_B * B_WAVE_FLOATS;
+}  // namespace mhb
+
+__global__ __launch_bounds__(256) void mcep_hb_prep_kernel(const float* __restrict__ G, const float* __restrict__ D,
+                                                           const float* __restrict__ E, _Float16* __restrict__ img)
+{
+    using namespace mhb;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int i = idx & 7, l = (idx >> 3) & 63;
+    if (idx < IMG_EB) {
+        // ebar^T = E rtbar^T: rows = bins 16 mt + (l & 15), k-slot (g, i) of k-step ks <-> m = 32 ks + 8 g + i
+        const int ks = (idx >> 9) & 1, mt = idx >> 10;
+        const int m = 32 * ks + 8 * (l >> 4) + i;
+        const float v = m < M2 ? SEB * E[(mt * 16 + (l & 15)) * M2 + m] : 0.f;
+        split1(v, img[IMG_EBH + idx], img[IMG_EBL + idx]);
+    } else if (idx < IMG_EB + IMG_DB) {
+        // mbar^T += (-2 D) zbar^T: rows = coefficients 16 it2 + (l & 15), k-slot (g, i = 4 t + r) of step j
+        // <-> bin 32 j + 16 t + 4 g + r (C/D register r of tile 2 j + t)
+        const int e = idx - IMG_EB;
+        const int j = (e >> 9) & 7, it2 = e >> 12;
+        const int bin = 32 * j + 16 * (i >> 2) + 4 * (l >> 4) + (i & 3);
+        const int c = it2 * 16 + (l & 15);
+        const float v = c < M1 ? (-2.f * SDB) * D[c * K + bin] : 0.f;
+        split1(v, img[IMG_DBH + e], img[IMG_DBL + e]);
+    } else if (idx < IMG_EB + IMG_DB + IMG_GB) {
+        // lbar^T += G mbar_0^T: rows = bins, one k-step: k-slot (g, i) <-> coefficient 8 g + i
+        const int e = idx - IMG_EB - IMG_DB;
+        const int mt = e >> 9;
+        const int c = 8 * (l >> 4) + i;
+        const float v = c < M1 ? SGB * G[(mt * 16 + (l & 15)) * M1 + c] : 0.f;
+        split1(v, img[IMG_GBH + e], img[IMG_GBL + e]);
+    }
+    float* tail = reinterpret_cast<float*>(img + IMG_B_HALVES);
+    if (idx < 32) tail[idx] = idx < M1 ? -2.f * D[idx * K + H] : 0.f;
+    if (idx >= 32 && idx < 96) tail[idx] = idx - 32 < M2 ? E[H * M2 + idx - 32] : 0.f;
+    if (idx >= 96 && idx < 96 + 256) tail[idx] = E[(idx - 96) * M2 + 48];
+}
+
+// v = hi + lo (binary16), eight values of one MFMA operand
+__device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo)
+{
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        f16x2 h, l;
+        split2(v[i], v[i + 1], h, l);
+        hi[i] = h[0]; hi[i + 1] = h[1];
+        lo[i] = l[0]; lo[i + 1] = l[1];
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
+    const float* __restrict__ gmc, const float* __restrict__ X, const float* __restrict__ hist, long F, int n_iter,
+    const float* __restrict__ av, float* __restrict__ gX, long ntiles16, unsigned int* __restrict__ queue,
+    const _Float16* __restrict__ img)
+{
+    using namespace mhb;
+    constexpr float kNeg2Log2e = -2.885390081777926815f;
+    constexpr float kInvSDM = 1.f / (SD * SM);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+
+    // ---------------- operand images and small tables ----------------
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(img);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds + DH_OFF);
+        for (int idx = tid; idx < (2 * IMG_D + 2 * IMG_E) / 8; idx += WAVES_B * 64) dst[idx] = src[idx];
+        const f32x4* srcb = reinterpret_cast<const f32x4*>(img + IMG_DBH);
+        f32x4* dstb = reinterpret_cast<f32x4*>(lds + B_DB);
+        for (int idx = tid; idx < 2 * IMG_DB / 8; idx += WAVES_B * 64) dstb[idx] = srcb[idx];
+    }
+    const float* tail_f = reinterpret_cast<const float*>(img + IMG_HALVES);     // G[256][c] (forward workspace tail)
+    const float* tail_b = reinterpret_cast<const float*>(img + IMG_B_HALVES);   // -2 D[c][256] | E[256][m] | E[bin][48]
+    {
+        const int r = tid & 3, gg = (tid >> 2) & 3, mt = tid >> 4;
+        lds[B_E48 + tid] = tail_b[96 + mt * 16 + gg * 4 + r];
+    }
+    if (tid < 48) lds[B_E256 + tid] = SE * tail_b[32 + tid];     // Nyquist k-step of the rt chain (scaled image)
+    if (tid == 48) lds[B_E256 + 48] = tail_b[32 + 48];            // rt[48] is a float32 dot product
+    if (tid < 64) lds[B_E256 + 52 + tid] = tail_b[32 + tid];      // E[256][m], m < 64 (0 past 48): ebar of the Nyquist bin
+    if (tid < 32) {
+        lds[B_D256 + tid] = 1.4426950408889634f * tail_b[tid];    // -2 log2(e) D[c][256]
+        lds[B_D256 + 32 + tid] = tail_b[tid];                     // -2 D[c][256]
+    }
+    if (tid < 28) lds[B_AV + tid] = tid < M1 ? av[tid] : 0.f;
+    __syncthreads();
+
+    float* wave_lds = lds + B_WAVE + wave * B_WAVE_FLOATS;
+    float* rt_n = wave_lds + n * FS;           // this lane's frame, MFMA-layout view
+    float* rr_n = rt_n + 52;
+    float* aux_n = rt_n + 116;
+    const int nq = lane >> 2, gs = lane & 3;   // solve layout: a quad per frame
+    float* rt_q = wave_lds + nq * FS;
+    float* rr_q = rt_q + 52;
+    float* aux_q = rt_q + 116;
+    const GroupMask gq = make_group_mask(gs);
+    const unsigned g_eq0 = g == 0 ? 0xffffffffu : 0u;
+    int lane_a = lane, lane_b = lane + EL_OFF / 4, lane_c = lane + B_DB / 4;
+    asm volatile("" : "+v"(lane_a), "+v"(lane_b), "+v"(lane_c));
+    const f16x8* DH = reinterpret_cast<const f16x8*>(lds + DH_OFF) + lane_a;
+    const f16x8* DL = reinterpret_cast<const f16x8*>(lds + DL_OFF) + lane_a;
+    const f16x8* EH = reinterpret_cast<const f16x8*>(lds + EH_OFF) + lane_a;
+    const f16x8* EL = reinterpret_cast<const f16x8*>(lds) + lane_b;
+    const f16x8* DBH = reinterpret_cast<const f16x8*>(lds) + lane_c;
+    const f16x8* DBL = DBH + IMG_DB / 8;
+    const f32x4* E484 = reinterpret_cast<const f32x4*>(lds + B_E48);
+    const long wave_id = (long)blockIdx.x * WAVES_B + wave;
+    const long wave_stride = (long)gridDim.x * WAVES_B;
+
+    for (long tile = wave_id; tile < ntiles16;) {
+        const long f_raw = tile * 16 + n;
+        const bool f_ok = f_raw < F;
+        const long f = f_ok ? f_raw : F - 1;
+        const float* xf = X + f * K;
+        f32x4 logx[16], lbar[16];
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt) {
+            const float* p = xf + mt * 16 + 4 * g;
+            logx[mt] = f32x4{__log2f(p[0]), __log2f(p[1]), __log2f(p[2]), __log2f(p[3])};
+            lbar[mt] = f32x4{0, 0, 0, 0};
+        }
+        const float logx256 = __log2f(xf[H]);
+        float lbar256 = 0.f;
+        // mbar in the C/D layout of a 32-row product: tile it2, register r <-> coefficient 16 it2 + 4 g + r
+        f32x4 mbarC[2];
+#pragma unroll
+        for (int it2 = 0; it2 < 2; ++it2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = it2 * 16 + 4 * g + r;
+                mbarC[it2][r] = c < M1 ? gmc[f * M1 + c] : 0.f;
+            }
+        unsigned int nxt = 0;
+        if (lane == 0) nxt = atomicAdd(queue, 1u);
+        const long tile_next = wave_stride + (long)__builtin_amdgcn_readfirstlane((int)nxt);
+
+        for (int iter = n_iter - 1; iter >= 0; --iter) {
+            float mcv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mcv[i] = (8 * g + i < M1) ? hist[((long)iter * F + f) * M1 + 8 * g + i] : 0.f;
+            // ---------------- forward quantities of this step: e (kept, scaled by 2^sh), rt -> LDS windows ----------------
+            f16x8 bh, bl;
+            {
+                float ms[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ms[i] = mcv[i] * SM;
+                split8(ms, bh, bl);
+            }
+            f32x4 ep[16];
+            float d256 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d256 = __builtin_fmaf(mcv[i], lds[B_D256 + 8 * g + i], d256);
+            d256 += __shfl_xor(d256, 16, 64);
+            d256 += __shfl_xor(d256, 32, 64);
+            const float t256 = logx256 + d256;
+            float tmax = t256;
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) {
+                const f16x8 ah = DH[mt * 64], al = DL[mt * 64];
+                f32x4 c = {0, 0, 0, 0};
+                c = mfma_h(al, bh, c);
+                c = mfma_h(ah, bl, c);
+                c = mfma_h(ah, bh, c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ep[mt][r] = __builtin_fmaf(c[r], kInvSDM, logx[mt][r]);
+                    tmax = __builtin_fmaxf(tmax, ep[mt][r]);
+                }
+            }
+            tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mi = __builtin_ceilf(tmax);
+            const float sh = (float)EMAX_LOG2 - mi;
+            const int back = (int)mi - EMAX_LOG2;   // e = 2^back ep
+            f32x4 accB[3] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+            float rt48 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float ev[8];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int mt = 2 * j + tt;
+                    const f32x4 c48 = E484[mt * 4 + g];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ep[mt][r] = __builtin_amdgcn_exp2f(ep[mt][r] + sh);
+                        ev[4 * tt + r] = ep[mt][r];
+                        rt48 = __builtin_fmaf(ep[mt][r], c48[r], rt48);
+                    }
+                }
+                f16x8 eh, el;
+                split8(ev, eh, el);
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const f16x8 ah = EH[(it * 8 + j) * 64], al = EL[(it * 8 + j) * 64];
+                    accB[it] = mfma_h(al, eh, accB[it]);
+                    accB[it] = mfma_h(ah, el, accB[it]);
+                    accB[it] = mfma_h(ah, eh, accB[it]);
+                }
+            }
+            const float e256 = __builtin_amdgcn_exp2f(t256 + sh);   // scaled like ep
+#pragma unroll
+            for (int it = 0; it < 3; ++it)
+                accB[it] = mfma4(keep_if(g_eq0, lds[B_E256 + it * 16 + n]), keep_if(g_eq0, e256), accB[it]);
+            rt48 += __shfl_xor(rt48, 16, 64);
+            rt48 += __shfl_xor(rt48, 32, 64);
+            rt48 = __builtin_fmaf(e256, lds[B_E256 + 48], rt48);
+            rt48 = __builtin_ldexpf(rt48, back);
+            {
+                int g_it = g;
+                asm volatile("" : "+v"(g_it));
+                float* rtw = rt_n + 4 * g_it;
+                float* rra = rr_n + 27 + 4 * g_it;
+                float* rrb = rr_n + 27 - 4 * g_it;
+                float* rra1 = g_it < 3 ? rra + 16 : rr_n + 55;
+                float* rrb1 = g_it < 3 ? rrb - 16 : rr_n + 62;
+                const int bk = back - SE_LOG2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v0 = __builtin_ldexpf(accB[0][r], bk);
+                    const float v1 = __builtin_ldexpf(accB[1][r], bk);
+                    rtw[r] = v0;
+                    rra[r] = v0;
+                    rrb[-r] = v0;
+                    rtw[16 + r] = v1;
+                    rra1[r] = v1;
+                    rrb1[-r] = v1;
+                    rtw[32 + r] = __builtin_ldexpf(accB[2][r], bk);
+                }
+                rt_n[48] = rt48;
+                // mbar to the exchange window (C/D layout writer -> quad-layout reader)
+#pragma unroll
+                for (int it2 = 0; it2 < 2; ++it2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) aux_n[it2 * 16 + 4 * g_it + r] = mbarC[it2][r];
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            // ---------------- solve A [gv | uv] = [rt[:25] - alpha | mbar] in the quad layout ----------------
+            float gv[M1], uv[M1];
+            {
+                float a[colm::TOTAL];
+                col_build_rows<0>(a, rt_q, rr_q, lds + B_AV, aux_q, gs, gq);
+                __builtin_amdgcn_wave_barrier();
+                col_elim_all(a, std::make_integer_sequence<int, M1>{});
+                float xq1[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[1], -1.f)};
+                col_backsub_full(a, xq1, gv, gq, std::make_integer_sequence<int, M1>{});
+                float xq2[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[2], -1.f)};
+                col_backsub_full(a, xq2, uv, gq, std::make_integer_sequence<int, M1>{});
+            }
+            // ---------------- rtbar (49 entries), scaled per frame to below 2^13, into the exchange window ----------------
+            int s_r;   // rtbar = 2^-s_r (window contents)
+            {
+                float rb[M2];
+                rtbar_store(rb, gv, uv, std::make_integer_sequence<int, M2>{});
+                float amax = 0.f;
+#pragma unroll
+                for (int m = 0; m < M2; ++m) amax = __builtin_fmaxf(amax, __builtin_fabsf(rb[m]));
+                s_r = VMAX_LOG2 - __builtin_amdgcn_frexp_expf(amax);
+                if (gs == 0) {
+#pragma unroll
+                    for (int m = 0; m < M2; ++m) aux_q[m] = __builtin_ldexpf(rb[m], s_r);
+#pragma unroll
+                    for (int m = M2; m < 63; ++m) aux_q[m] = 0.f;
+                    aux_q[63] = __int_as_float(s_r);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            f16x8 rbh[2], rbl[2];
+            float eb256 = 0.f;
+            const int s_rn = __float_as_int(aux_n[63]);   // the scale of THIS lane's frame in the MFMA layout
+            {
+                float rv[16];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    rv[i] = aux_n[8 * g + i];
+                    rv[8 + i] = g < 3 ? aux_n[32 + 8 * g + i] : 0.f;     // slot 63 of group 3 holds the scale, not data
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    eb256 = __builtin_fmaf(rv[i], lds[B_E256 + 52 + 8 * g + i], eb256);
+                    eb256 = __builtin_fmaf(rv[8 + i], lds[B_E256 + 52 + 32 + 8 * g + i], eb256);
+                }
+                float lo8[8], hi8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { lo8[i] = rv[i]; hi8[i] = rv[8 + i]; }
+                split8(lo8, rbh[0], rbl[0]);
+                split8(hi8, rbh[1], rbl[1]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            eb256 += __shfl_xor(eb256, 16, 64);
+            eb256 += __shfl_xor(eb256, 32, 64);
+
+            // ---------------- ebar^T = E rtbar^T ; zbar = ebar * e ; lbar += zbar ----------------
+            // zbar = acc * ep * 2^kz,  kz = -(s_r + SEB_LOG2) + back
+            const int kz = back - s_rn - SEB_LOG2;
+            f32x4 zb[16];
+            float zmax = 0.f;
+            {
+                const _Float16* imgt = img;
+                asm volatile("" : "+s"(imgt));
+                const f16x8* EBH = reinterpret_cast<const f16x8*>(imgt + IMG_EBH) + lane;
+                const f16x8* EBL = reinterpret_cast<const f16x8*>(imgt + IMG_EBL) + lane;
+#pragma unroll
+                for (int mt = 0; mt < 16; ++mt) {
+                    f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const f16x8 ah = EBH[(mt * 2 + ks) * 64], al = EBL[(mt * 2 + ks) * 64];
+                        acc = mfma_h(al, rbh[ks], acc);
+                        acc = mfma_h(ah, rbl[ks], acc);
+                        acc = mfma_h(ah, rbh[ks], acc);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = __builtin_ldexpf(acc[r] * ep[mt][r], kz);
+                        zb[mt][r] = z;
+                        lbar[mt][r] += z;
+                        zmax = __builtin_fmaxf(zmax, __builtin_fabsf(z));
+                    }
+                }
+            }
+            const float zb256 = __builtin_ldexpf(eb256 * e256, back - s_rn);
+            lbar256 += zb256;
+            // ---------------- mbar^T += (-2 D) zbar^T : zbar scaled per frame to below 2^13 ----------------
+            zmax = __builtin_fmaxf(zmax, __shfl_xor(zmax, 16, 64));
+            zmax = __builtin_fmaxf(zmax, __shfl_xor(zmax, 32, 64));
+            const int s_z = VMAX_LOG2 - __builtin_amdgcn_frexp_expf(zmax);
+            {
+                f32x4 acc2[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float zv[8];
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zv[4 * tt + r] = __builtin_ldexpf(zb[2 * j + tt][r], s_z);
+                    f16x8 zh, zl;
+                    split8(zv, zh, zl);
+#pragma unroll
+                    for (int it2 = 0; it2 < 2; ++it2) {
+                        const f16x8 ah = DBH[(it2 * 8 + j) * 64], al = DBL[(it2 * 8 + j) * 64];
+                        acc2[it2] = mfma_h(al, zh, acc2[it2]);
+                        acc2[it2] = mfma_h(ah, zl, acc2[it2]);
+                        acc2[it2] = mfma_h(ah, zh, acc2[it2]);
+                    }
+                }
+#pragma unroll
+                for (int it2 = 0; it2 < 2; ++it2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = it2 * 16 + 4 * g + r;   // < 32
+                        mbarC[it2][r] += __builtin_ldexpf(acc2[it2][r], -s_z - SDB_LOG2);
+                        mbarC[it2][r] = __builtin_fmaf(zb256, lds[B_D256 + 32 + c], mbarC[it2][r]);   // Nyquist bin (table is 0 past c = 24)
+                    }
+            }
+        }
+
+        // ---------------- lbar += G mbar_0 (mcep.py:204-207 adjoint); gX = lbar / X ----------------
+#pragma unroll
+        for (int it2 = 0; it2 < 2; ++it2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) aux_n[it2 * 16 + 4 * g + r] = mbarC[it2][r];
+        __builtin_amdgcn_wave_barrier();
+        float m0[8];
+        float mmax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            m0[i] = (8 * g + i < M1) ? aux_n[8 * g + i] : 0.f;
+            mmax = __builtin_fmaxf(mmax, __builtin_fabsf(m0[i]));
+        }
+        __builtin_amdgcn_wave_barrier();
+        mmax = __builtin_fmaxf(mmax, __shfl_xor(mmax, 16, 64));
+        mmax = __builtin_fmaxf(mmax, __shfl_xor(mmax, 32, 64));
+        const int s_m = VMAX_LOG2 - __builtin_amdgcn_frexp_expf(mmax);
+        float part256 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) part256 = __builtin_fmaf(m0[i], tail_f[8 * g + i], part256);   // G[256][c] (0 past c = 24)
+        part256 += __shfl_xor(part256, 16, 64);
+        part256 += __shfl_xor(part256, 32, 64);
+        lbar256 += part256;
+        {
+            float ms[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ms[i] = __builtin_ldexpf(m0[i], s_m);
+            f16x8 mh8, ml8;
+            split8(ms, mh8, ml8);
+            const _Float16* imgt = img;
+            asm volatile("" : "+s"(imgt));
+            const f16x8* GBH = reinterpret_cast<const f16x8*>(imgt + IMG_GBH) + lane;
+            const f16x8* GBL = reinterpret_cast<const f16x8*>(imgt + IMG_GBL) + lane;
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) {
+                const f16x8 ah = GBH[mt * 64], al = GBL[mt * 64];
+                f32x4 acc = {0, 0, 0, 0};
+                acc = mfma_h(al, mh8, acc);
+                acc = mfma_h(ah, ml8, acc);
+                acc = mfma_h(ah, mh8, acc);
+                if (f_ok) {
+                    float* dst = gX + f * K + mt * 16 + 4 * g;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dst[r] = (lbar[mt][r] + __builtin_ldexpf(acc[r], -s_m - SGB_LOG2)) * __builtin_amdgcn_exp2f(-logx[mt][r]);
+                }
+            }
+        }
+        if (f_ok && g == 0) gX[f * K + H] = lbar256 * __builtin_amdgcn_exp2f(-logx256);
+        tile = tile_next;
+    }
+}
+
+}  // namespace dsa
