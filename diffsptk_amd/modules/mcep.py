@@ -54,13 +54,16 @@ class MelCepstralAnalysis(BaseFunctionalModule):
                     module: bool = True) -> Precomputed:
         MelCepstralAnalysis._check(fft_length, cep_order, alpha, n_iter)
         tens = _device_matrices(fft_length, cep_order, float(alpha), device, dtype, cache=not module)
-        return Precomputed(values={"fft_length": fft_length, "cep_order": cep_order, "n_iter": n_iter},
+        # The tuned kernels hold the warping matrices as scaled binary16 hi/lo images whose scales are
+        # chosen for |alpha| <= 0.95 (csrc/mcep_mfma_f16.h); more extreme warping stays on the generic kernel.
+        algo = _lib.ALGO_AUTO if abs(alpha) <= 0.95 else _lib.ALGO_GENERIC
+        return Precomputed(values={"fft_length": fft_length, "cep_order": cep_order, "n_iter": n_iter, "algo": algo},
                            tensors=tens)
 
     @staticmethod
     def _forward(x: torch.Tensor, *, fft_length: int, cep_order: int, n_iter: int, G: torch.Tensor,
-                 D: torch.Tensor, E: torch.Tensor, alpha_vector: torch.Tensor) -> torch.Tensor:
-        return ops.McepFn.apply(x, G, D, E, alpha_vector, fft_length, cep_order, n_iter, _lib.ALGO_AUTO)
+                 D: torch.Tensor, E: torch.Tensor, alpha_vector: torch.Tensor, algo: int = _lib.ALGO_AUTO) -> torch.Tensor:
+        return ops.McepFn.apply(x, G, D, E, alpha_vector, fft_length, cep_order, n_iter, algo)
 
 
 _MAT_CACHE: dict = {}

@@ -479,6 +479,21 @@ def test_mcep_tuned_dynamic_range(golden):
         close(y, ref, 1e-4, 2e-5)
 
 
+def test_mcep_extreme_alpha_keeps_generic_kernel(golden):
+    """|alpha| > 0.95 is outside the range the binary16 operand images of the tuned kernel are scaled
+    for: the module routes it to the generic kernel, and the result still matches float64."""
+    g = golden("datawav")
+    X = torch.from_numpy(g["stft_power_f32"]).reshape(-1, 257)[:64].to(DEV)
+    m32 = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.97, n_iter=2, device=DEV)
+    y = host(m32(X))
+    assert _lib.last_kernel().startswith("mcep_generic_fwd")
+    m64 = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.97, n_iter=2, device=DEV, dtype=torch.float64)
+    close(y, host(m64(X.double())), 2e-3, 2e-3)   # alpha = 0.97 is ill-conditioned in float32 (reference alike)
+    m = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.9, n_iter=2, device=DEV)
+    m(X)
+    assert _lib.last_kernel().startswith("mcep_mfma_fwd")
+
+
 def test_mcep_tuned_vs_generic_and_history(golden):
     g = golden("randn")
     X = dev(g["stft_power_f32"])

@@ -177,3 +177,15 @@ def test_get_alpha_and_read(golden, tmp_path):
     x, sr = dsp.read(p)
     assert sr == 16000 and x.shape == (19200,) and x.dtype == torch.float32
     np.testing.assert_array_equal(x.numpy(), (pcm / 32768.0).astype(np.float32))
+
+
+def test_mcep_module_routes_extreme_alpha_to_generic():
+    """The tuned mel-cepstral kernels scale their binary16 operand images for |alpha| <= 0.95."""
+    import torch
+
+    from diffsptk_amd import _lib
+    from diffsptk_amd.modules.mcep import MelCepstralAnalysis
+
+    for alpha, algo in ((0.42, _lib.ALGO_AUTO), (-0.95, _lib.ALGO_AUTO), (0.96, _lib.ALGO_GENERIC), (-0.99, _lib.ALGO_GENERIC)):
+        pre = MelCepstralAnalysis._precompute(512, 24, alpha, 3, "cpu", torch.float32)
+        assert pre.values["algo"] == algo
