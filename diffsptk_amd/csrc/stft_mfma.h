@@ -33,7 +33,8 @@
 // previous tile left in the LDS staging row -- 16 of 5.3e7 outputs (tools/dbg_stft3.py).  Ruled out so
 // far: MFMA-result latency (128-cycle s_sleep between the products and their first use), the inline
 // assembly below (a plain-vector-code build shows it too), strict aliasing, LDS bank-conflict layout
-// (a phase-major staging variant shows it more often).  Until that is root-caused the dispatcher keeps
+// (a phase-major staging variant shows it more often), s_waitcnt vmcnt(0) before the staged samples
+// are consumed, s_waitcnt lgkmcnt(0) after every group of staging writes.  Until that is root-caused the dispatcher keeps
 // the register-FFT kernel as the default.
 #pragma once
 
