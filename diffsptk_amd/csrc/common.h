@@ -123,6 +123,8 @@ __device__ __forceinline__ float dsa_log(float v) { return logf(v); }
 __device__ __forceinline__ double dsa_log(double v) { return log(v); }
 __device__ __forceinline__ float dsa_exp(float v) { return expf(v); }
 __device__ __forceinline__ double dsa_exp(double v) { return exp(v); }
+__device__ __forceinline__ float dsa_pow(float a, float b) { return powf(a, b); }
+__device__ __forceinline__ double dsa_pow(double a, double b) { return pow(a, b); }
 __device__ __forceinline__ float dsa_sqrt(float v) { return sqrtf(v); }
 __device__ __forceinline__ double dsa_sqrt(double v) { return sqrt(v); }
 __device__ __forceinline__ float dsa_log10(float v) { return log10f(v); }

@@ -23,6 +23,29 @@ def frame(x: Tensor, frame_length: int = 400, frame_period: int = 80, center: bo
     return nn.Frame._func(x, frame_length, frame_period, center=center, zmean=zmean, mode=mode)
 
 
+def dct(x: Tensor, dct_type: int = 2) -> Tensor:
+    """Discrete cosine transform x:(..., L) -> (..., L)."""
+    return nn.DiscreteCosineTransform._func(x, dct_type=dct_type)
+
+
+def fbank(x: Tensor, n_channel: int, sample_rate: int, f_min: float = 0, f_max: float | None = None,
+          floor: float = 1e-5, gamma: float = 0, scale: str = "htk", erb_factor: float | None = None,
+          use_power: bool = False, out_format: str | int = "y"):
+    """Mel filter-bank analysis of power spectra x:(..., L/2+1) -> (..., C) (and log energy)."""
+    return nn.MelFilterBankAnalysis._func(x, n_channel=n_channel, sample_rate=sample_rate, f_min=f_min, f_max=f_max,
+                                          floor=floor, gamma=gamma, scale=scale, erb_factor=erb_factor,
+                                          use_power=use_power, out_format=out_format)
+
+
+def mfcc(x: Tensor, mfcc_order: int, n_channel: int, sample_rate: int, lifter: int = 1, f_min: float = 0,
+         f_max: float | None = None, floor: float = 1e-5, gamma: float = 0, scale: str = "htk",
+         erb_factor: float | None = None, out_format: str | int = "y") -> Tensor:
+    """MFCC analysis of power spectra x:(..., L/2+1) -> (..., M) (+ C0 / energy)."""
+    return nn.MelFrequencyCepstralCoefficientsAnalysis._func(
+        x, mfcc_order=mfcc_order, n_channel=n_channel, sample_rate=sample_rate, lifter=lifter, f_min=f_min,
+        f_max=f_max, floor=floor, gamma=gamma, scale=scale, erb_factor=erb_factor, out_format=out_format)
+
+
 def freqt(c: Tensor, out_order: int, alpha: float = 0) -> Tensor:
     """Frequency transform c:(..., M1+1) -> (..., M2+1)."""
     return nn.FrequencyTransform._func(c, out_order=out_order, alpha=alpha)

@@ -1,5 +1,9 @@
 from .acorr import Autocorrelation
 from .base import BaseFunctionalModule, Precomputed
+from .dct import DiscreteCosineTransform
+from .dct import DiscreteCosineTransform as DCT
+from .fbank import MelFilterBankAnalysis
+from .fbank import MelFilterBankAnalysis as FBANK
 from .fftr import RealValuedFastFourierTransform
 from .frame import Frame
 from .freqt import FrequencyTransform
@@ -7,13 +11,16 @@ from .levdur import LevinsonDurbin
 from .lpc import LinearPredictiveCodingAnalysis
 from .lpc import LinearPredictiveCodingAnalysis as LPC
 from .mcep import MelCepstralAnalysis
+from .mfcc import MelFrequencyCepstralCoefficientsAnalysis
+from .mfcc import MelFrequencyCepstralCoefficientsAnalysis as MFCC
 from .spec import Spectrum
 from .stft import ShortTimeFourierTransform
 from .stft import ShortTimeFourierTransform as STFT
 from .window import Window
 
 __all__ = [
-    "Autocorrelation", "BaseFunctionalModule", "Frame", "FrequencyTransform", "LPC", "LevinsonDurbin",
-    "LinearPredictiveCodingAnalysis", "MelCepstralAnalysis", "Precomputed",
+    "Autocorrelation", "BaseFunctionalModule", "DCT", "DiscreteCosineTransform", "FBANK", "Frame",
+    "FrequencyTransform", "LPC", "LevinsonDurbin", "LinearPredictiveCodingAnalysis", "MFCC", "MelCepstralAnalysis",
+    "MelFilterBankAnalysis", "MelFrequencyCepstralCoefficientsAnalysis", "Precomputed",
     "RealValuedFastFourierTransform", "STFT", "ShortTimeFourierTransform", "Spectrum", "Window",
 ]

@@ -275,6 +275,43 @@ class MatmulRowsFn(torch.autograd.Function):
         return gc, None
 
 
+# ----------------------------------------------------------------------------------- fbank
+class FbankFn(torch.autograd.Function):
+    """y, E = mel filter bank outputs and log energy of power spectra (fbank.py:306-321).
+    H is a fixed matrix here (a learnable basis is not supported by the kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, H, floor, gamma, use_power):
+        _require_device(x, H)
+        _same_dtype(x, H)
+        xc, Hc = x.contiguous(), H.contiguous()
+        K, Cn = Hc.shape
+        F = xc.numel() // K
+        y = torch.empty(*xc.shape[:-1], Cn, device=x.device, dtype=x.dtype)
+        E = torch.empty(*xc.shape[:-1], 1, device=x.device, dtype=x.dtype)
+        with torch.cuda.device(x.device):
+            _call("dsa_fbank_fwd", _p(xc), F, K, _p(Hc), Cn, float(floor), float(gamma), int(bool(use_power)),
+                  _dtype_code(xc), _p(y), _p(E), _stream())
+        ctx.save_for_backward(xc, Hc)
+        ctx.cfg = (float(floor), float(gamma), int(bool(use_power)))
+        return y, E
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, gE):
+        xc, Hc = ctx.saved_tensors
+        floor, gamma, use_power = ctx.cfg
+        K, Cn = Hc.shape
+        F = xc.numel() // K
+        gyc = gy.contiguous() if gy is not None else torch.zeros(*xc.shape[:-1], Cn, device=xc.device, dtype=xc.dtype)
+        gEc = gE.contiguous() if gE is not None else None
+        gx = torch.empty_like(xc)
+        with torch.cuda.device(xc.device):
+            _call("dsa_fbank_bwd", _p(gyc), _p(gEc) if gEc is not None else None, _p(xc), F, K, _p(Hc), Cn, floor, gamma,
+                  use_power, _dtype_code(xc), _p(gx), _stream())
+        return gx, None, None, None, None
+
+
 # ----------------------------------------------------------------------------------- mcep
 class McepFn(torch.autograd.Function):
     """MelCepstralAnalysis._forward (mcep.py:189-224) with composed linear stages."""

@@ -160,3 +160,122 @@ def mcep_matrices(fft_length: int, cep_order: int, alpha: float):
     E = IC @ A_r
     av = (-alpha) ** np.arange(M + 1, dtype=np.float64)
     return G, D, E, av, A_f, A_i, A_r
+
+
+# ------------------------------------------------------------------ mel filter bank / DCT
+def hz_to_auditory(f, scale: str):
+    """Auditory scales of the reference (utils/private.py:241-274)."""
+    f = np.asarray(f, dtype=np.float64)
+    if scale == "htk":
+        return 1127.0 * np.log1p(f / 700.0)
+    if scale in ("oshaughnessy", "mel"):
+        return 2595.0 * np.log10(1.0 + f / 700.0)
+    if scale in ("chakroborty", "inverted-mel"):
+        return 2195.286 - 2595.0 * np.log10(1.0 + (4031.25 - f) / 700.0)
+    if scale in ("traunmuller", "bark"):
+        return (26.81 * f) / (1960.0 + f) - 0.53
+    if scale == "linear":
+        return f
+    raise ValueError(f"scale {scale} is not supported.")
+
+
+def auditory_to_hz(z, scale: str):
+    """Inverse of hz_to_auditory (utils/private.py:277-288)."""
+    z = np.asarray(z, dtype=np.float64)
+    if scale == "htk":
+        return 700.0 * np.expm1(z / 1127.0)
+    if scale in ("oshaughnessy", "mel"):
+        return 700.0 * (np.power(10.0, z / 2595.0) - 1.0)
+    if scale in ("chakroborty", "inverted-mel"):
+        return 4031.25 - 700.0 * (np.power(10.0, (2195.286 - z) / 2595.0) - 1.0)
+    if scale in ("traunmuller", "bark"):
+        return 1960.0 * (z + 0.53) / (26.28 - z)
+    if scale == "linear":
+        return z
+    raise ValueError(f"scale {scale} is not supported.")
+
+
+def fbank_matrix(fft_length: int, n_channel: int, sample_rate: int, f_min: float = 0.0, f_max: float | None = None,
+                 scale: str = "htk", erb_factor: float | None = None) -> np.ndarray:
+    """Triangular filter-bank weights H (L/2+1, C) of MelFilterBankAnalysis._precompute (fbank.py:232-291)."""
+    K = fft_length // 2 + 1
+    if f_max is None:
+        f_max = sample_rate / 2
+    H = np.zeros((K, n_channel), dtype=np.float64)
+    if erb_factor is None:
+        z_lo = float(hz_to_auditory(f_min, scale))
+        z_hi = float(hz_to_auditory(f_max, scale))
+        k_lo = max(1, int(f_min / sample_rate * fft_length + 1.5))
+        k_hi = min(fft_length // 2, int(f_max / sample_rate * fft_length + 0.5))
+        # channel centres 1 .. C+1 on the auditory axis; centre 0 would be z_lo itself
+        centres = (z_hi - z_lo) / (n_channel + 1) * np.arange(1, n_channel + 2) + z_lo
+        widths = np.diff(np.concatenate(([z_lo], centres)))
+        for k in range(k_lo, k_hi):
+            z = float(hz_to_auditory(sample_rate * k / fft_length, scale))
+            m = int(np.argmax(z <= centres))          # first centre at or above the bin
+            w = (centres[m] - z) / widths[m]           # weight of the lower neighbour
+            if m > 0:
+                H[k, m - 1] = w
+            if m < n_channel:
+                H[k, m] = 1.0 - w
+        return H
+    a, b, c = erb_factor * 6.23e-6, erb_factor * 93.39e-3, erb_factor * 28.52
+
+    def edge_centre(f, first):
+        s = 1.0 if first else -1.0
+        ah, bh, ch = s * 0.5 / (700.0 + f), s * 700.0 / (700.0 + f), -s * 0.5 * f * (1.0 + 700.0 / (700.0 + f))
+        bb, cb = (b - bh) / (a - ah), (c - ch) / (a - ah)
+        return 0.5 * (-bb + np.sqrt(bb * bb - 4.0 * cb))
+
+    zc = np.linspace(float(hz_to_auditory(edge_centre(f_min, True), scale)),
+                     float(hz_to_auditory(edge_centre(f_max, False), scale)), n_channel)
+    fc = auditory_to_hz(zc, scale)
+    erb = a * fc ** 2 + b * fc + c
+    fl = -(700.0 + erb) + np.sqrt(erb ** 2 + (700.0 + fc) ** 2)
+    fh = fl + 2.0 * erb
+    f = np.linspace(0.0, sample_rate / 2, K)
+    for m in range(n_channel):
+        up = (fl[m] <= f) & (f < fc[m])
+        H[up, m] = (f[up] - fl[m]) / (fc[m] - fl[m])
+        dn = (fc[m] <= f) & (f <= fh[m])
+        H[dn, m] = (fh[m] - f[dn]) / (fh[m] - fc[m])
+    return H
+
+
+def dct_matrix(dct_length: int, dct_type: int = 2) -> np.ndarray:
+    """Orthonormal DCT-I..IV matrix W (L, L), y = x @ W (dct.py:99-133)."""
+    L = dct_length
+    n = np.arange(L, dtype=np.float64)
+    k = np.arange(L, dtype=np.float64)
+    if dct_type in (2, 4):
+        n = n + 0.5
+    if dct_type in (3, 4):
+        k = k + 0.5
+    n = n * (math.pi / ((L - 1) if dct_type == 1 else L))
+    if dct_type == 1:
+        z0 = np.full(L, 1.0)
+        z0[0] = z0[-1] = math.sqrt(0.5)
+        z1 = np.full(L, 2.0)
+        z1[0] = z1[-1] = 1.0
+        z = z0[None, :] * np.sqrt(z1 / (L - 1))[:, None]
+    elif dct_type == 2:
+        zz = np.full(L, 2.0)
+        zz[0] = 1.0
+        z = np.sqrt(zz / L)[None, :]
+    elif dct_type == 3:
+        zz = np.full(L, 2.0)
+        zz[0] = 1.0
+        z = np.sqrt(zz / L)[:, None]
+    elif dct_type == 4:
+        z = math.sqrt(2.0 / L)
+    else:
+        raise ValueError(f"dct_type {dct_type} is not supported.")
+    return z * np.cos(k[None, :] * n[:, None])
+
+
+def mfcc_lifter(mfcc_order: int, lifter: int) -> np.ndarray:
+    """Liftering vector of mfcc.py:224-226 (entry 0 scales C0 by sqrt 2)."""
+    r = np.arange(mfcc_order + 1, dtype=np.float64)
+    v = 1.0 + (lifter / 2.0) * np.sin((math.pi / lifter) * r)   # lifter = 0: ZeroDivisionError, as in the reference
+    v[0] = math.sqrt(2.0)
+    return v

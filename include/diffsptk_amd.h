@@ -123,6 +123,16 @@ int dsa_freqt_fwd(const void* c, int64_t F, int32_t L1, const void* A, int32_t L
 int dsa_freqt_bwd(const void* gout, int64_t F, int32_t L1, const void* A, int32_t L2,
                   int32_t dtype, void* gc, void* stream);
 
+/* ------------------------------------------------------------------ f1  mel filter bank
+ * MelFilterBankAnalysis._forward, fbank.py:306-321.  x:(F,K) power spectrum, H:(K,C) filter weights:
+ *   y:(F,C) = glog(max(s @ H, floor)), s = x (use_power) or sqrt(x), glog = log (gamma 0) or (y^gamma-1)/gamma;
+ *   E:(F) = log((2 sum_{0<k<K-1} x_k + x_0 + x_{K-1}) / (2 (K-1)))   (E may be NULL).
+ * MFCC (mfcc.py:244-256) = this + dsa_freqt_fwd with the DCT-II matrix times the liftering vector. */
+int dsa_fbank_fwd(const void* x, int64_t F, int32_t K, const void* H, int32_t C, double floor, double gamma,
+                  int32_t use_power, int32_t dtype, void* y, void* E, void* stream);
+int dsa_fbank_bwd(const void* gy, const void* gE, const void* x, int64_t F, int32_t K, const void* H, int32_t C,
+                  double floor, double gamma, int32_t use_power, int32_t dtype, void* gx, void* stream);
+
 /* ------------------------------------------------------------------ a8-a10  mel-cepstral analysis
  * MelCepstralAnalysis._forward, mcep.py:189-224 (incl. symmetric_toeplitz / hankel,
  * utils/private.py:291-302, and the torch.linalg.solve call at mcep.py:221).

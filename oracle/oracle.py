@@ -259,3 +259,61 @@ def frame_window_lpc(x, *, frame_length=400, frame_period=80, lpc_order=24, eps=
 
 def window_apply(x, w):
     return window(x, w, None)
+
+
+# ------------------------------------------------------------------ mel filter bank / MFCC
+def _to_aud(f, scale):
+    f = np.asarray(f, dtype=np.float64)
+    return {"htk": lambda: 1127 * np.log1p(f / 700), "mel": lambda: 2595 * np.log10(1 + f / 700),
+            "inverted-mel": lambda: 2195.286 - 2595 * np.log10(1 + (4031.25 - f) / 700),
+            "bark": lambda: 26.81 * f / (1960 + f) - 0.53, "linear": lambda: f}[scale]()
+
+
+def fbank_matrix(fft_length, n_channel, sample_rate, f_min=0.0, f_max=None, scale="htk"):
+    """Triangular weights (K, C) of fbank.py:242-266 (erb_factor None), vectorised over the bins."""
+    f_max = sample_rate / 2 if f_max is None else f_max
+    K = fft_length // 2 + 1
+    lo, hi = _to_aud(f_min, scale), _to_aud(f_max, scale)
+    k0 = max(1, int(f_min / sample_rate * fft_length + 1.5))
+    k1 = min(fft_length // 2, int(f_max / sample_rate * fft_length + 0.5))
+    cen = lo + (hi - lo) / (n_channel + 1) * np.arange(0, n_channel + 2)   # cen[0] = lo .. cen[C+1] = hi
+    H = np.zeros((K, n_channel))
+    ks = np.arange(k0, k1)
+    z = _to_aud(sample_rate * ks / fft_length, scale)
+    up = np.searchsorted(cen[1:], z, side="left") + 1                        # first centre index >= z (1-based)
+    w_lo = (cen[up] - z) / (cen[up] - cen[up - 1])
+    for k, m, w in zip(ks, up, w_lo):
+        if m >= 2:
+            H[k, m - 2] = w
+        if m <= n_channel:
+            H[k, m - 1] = 1 - w
+    return H
+
+
+def fbank(X, H, floor=1e-5, gamma=0.0, use_power=False):
+    """y:(..., C), E:(..., 1) through the C restatement (oracle_fbank)."""
+    X2, lead = _as2d(X)
+    Hc = np.ascontiguousarray(H, dtype=X2.dtype)
+    F, K = X2.shape
+    Cn = Hc.shape[1]
+    y = np.empty((F, Cn), dtype=X2.dtype)
+    E = np.empty((F,), dtype=X2.dtype)
+    getattr(lib(), "oracle_fbank" + _sfx(X2.dtype))(_ptr(X2), C.c_long(F), K, _ptr(Hc), Cn, C.c_double(floor),
+                                                    C.c_double(gamma), int(bool(use_power)), _ptr(y), _ptr(E))
+    return y.reshape(*lead, Cn), E.reshape(*lead, 1)
+
+
+def dct2_matrix(L):
+    n = (np.arange(L) + 0.5) * (np.pi / L)
+    z = np.sqrt(np.where(np.arange(L) == 0, 1.0, 2.0) / L)
+    return z[None, :] * np.cos(np.outer(n, np.arange(L)))
+
+
+def mfcc(X, H, mfcc_order, lifter=1, floor=1e-5, gamma=0.0):
+    """(y:(..., M), c:(..., 1), E:(..., 1)) of mfcc.py:244-256."""
+    fb, E = fbank(X, H, floor, gamma, False)
+    cy = fb @ dct2_matrix(H.shape[1]).astype(fb.dtype)[:, : mfcc_order + 1]
+    lift = 1 + (lifter / 2) * np.sin(np.pi / lifter * np.arange(mfcc_order + 1))
+    lift[0] = np.sqrt(2.0)
+    cy = cy * lift.astype(fb.dtype)
+    return cy[..., 1:], cy[..., :1], E

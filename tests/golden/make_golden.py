@@ -218,6 +218,46 @@ def main():
     g6["lpc_out"] = npy(d.LPC(30, 14, eps=0, dtype=f64)(xp))
     np.savez_compressed(os.path.join(HERE, "grids.npz"), **g6)
 
+    # ------------------------------------------------------------------ mel filter bank / MFCC
+    g7 = {}
+    X64 = torch.from_numpy(g1["stft_power_f64"]).clone()      # data.wav power spectrum (240, 257)
+    for name, dt in DT.items():
+        Xd = X64.to(dt)
+        fb = d.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, out_format="y,E", dtype=dt)
+        y, E = fb(Xd)
+        g7[f"fbank_y_{name}"], g7[f"fbank_E_{name}"] = npy(y), npy(E)
+        fbp = d.MelFilterBankAnalysis(fft_length=512, n_channel=80, sample_rate=16000, f_min=50, f_max=7600, floor=1e-3,
+                                      gamma=-0.5, scale="mel", use_power=True, out_format="yE", dtype=dt)
+        g7[f"fbank_pow_yE_{name}"] = npy(fbp(Xd))
+        mf = d.MFCC(fft_length=512, mfcc_order=12, n_channel=40, sample_rate=16000, lifter=22, out_format="ycE", dtype=dt)
+        g7[f"mfcc_ycE_{name}"] = npy(mf(Xd))
+        Xg = Xd.clone().requires_grad_(True)
+        out = mf(Xg)
+        (out * torch.linspace(-1, 1, out.size(-1), dtype=dt)).sum().backward()
+        g7[f"grad_mfcc_wsum_{name}"] = npy(Xg.grad)
+        Xg = Xd.clone().requires_grad_(True)
+        out = fbp(Xg)
+        (out * torch.linspace(1, 2, out.size(-1), dtype=dt)).sum().backward()
+        g7[f"grad_fbank_pow_wsum_{name}"] = npy(Xg.grad)
+    g7["H_htk40"] = npy(d.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, dtype=f64).H)
+    g7["H_mel80"] = npy(fbp.H.double()) if False else npy(d.MelFilterBankAnalysis(
+        fft_length=512, n_channel=80, sample_rate=16000, f_min=50, f_max=7600, scale="mel", dtype=f64).H)
+    g7["H_bark_erb"] = npy(d.MelFilterBankAnalysis(fft_length=2048, n_channel=40, sample_rate=8000, scale="bark",
+                                                   erb_factor=0.5, dtype=f64).H)
+    g7["dct2_40"] = npy(d.DCT(40, 2, dtype=f64).W)
+    # doctest known answers (fbank.py:142-153, mfcc.py:132-143) with their input spectrum
+    st = d.STFT(frame_length=10, frame_period=10, fft_length=32)
+    xs = st(d.ramp(19))
+    g7["doc_spec"] = npy(xs)
+    g7["doc_fbank"] = npy(d.MelFilterBankAnalysis(fft_length=32, n_channel=4, sample_rate=8000)(xs))
+    g7["doc_mfcc"] = npy(d.MFCC(fft_length=32, mfcc_order=4, n_channel=8, sample_rate=8000)(xs))
+    # the reference test's small configuration (tests/test_fbank.py:24-36): floor = 1
+    xr = torch.rand(2, 17, dtype=f64) * 4
+    g7["grid_x"] = npy(xr)
+    g7["grid_fbank_yE"] = npy(d.MelFilterBankAnalysis(fft_length=32, n_channel=10, sample_rate=8000, f_min=300, f_max=3400,
+                                                      floor=1, out_format=1, dtype=f64)(xr))
+    np.savez_compressed(os.path.join(HERE, "fbank.npz"), **g7)
+
     meta = {
         "reference": "sp-nitech/diffsptk 4.0.0 (/root/reference)",
         "torch": torch.__version__,
@@ -227,7 +267,7 @@ def main():
     }
     with open(os.path.join(HERE, "META.json"), "w") as f:
         json.dump(meta, f, indent=1)
-    for fn in ("tables.npz", "datawav.npz", "randn.npz", "grids.npz"):
+    for fn in ("tables.npz", "datawav.npz", "randn.npz", "grids.npz", "fbank.npz"):
         print(fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, "KiB")
 
 

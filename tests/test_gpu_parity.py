@@ -655,3 +655,78 @@ def test_chunked_overlap_alternating_streams(monkeypatch):
         torch.cuda.synchronize()
         assert y.shape == (24, *ref.shape[1:])
         assert torch.equal(y[:12], ref) and torch.equal(y[12:], ref)
+
+
+# ----------------------------------------------------------------------------- f1 mel filter bank / MFCC
+@pytest.mark.parametrize("name,dt", [("f64", torch.float64), ("f32", torch.float32)])
+def test_fbank_mfcc_golden_forward_backward(golden, name, dt):
+    """MelFilterBankAnalysis / MFCC (fbank.py:306-321, mfcc.py:244-256) on the data.wav power spectrum:
+    outputs and input gradients against the reference's own results."""
+    g, gw = golden("fbank"), golden("datawav")
+    X = dev(gw["stft_power_f64"], dt)
+    rt, at = (1e-5, 1e-8) if dt == torch.float64 else (2e-4, 2e-4)
+    y, E = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, out_format="y,E", device=DEV, dtype=dt)(X)
+    assert _lib.last_kernel() == "fbank_fwd"
+    close(host(y), g[f"fbank_y_{name}"], rt, at)
+    close(host(E), g[f"fbank_E_{name}"], rt, at)
+    fbp = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=80, sample_rate=16000, f_min=50, f_max=7600, floor=1e-3,
+                                    gamma=-0.5, scale="mel", use_power=True, out_format="yE", device=DEV, dtype=dt)
+    Xg = X.clone().requires_grad_(True)
+    out = fbp(Xg)
+    close(host(out), g[f"fbank_pow_yE_{name}"], rt, at)
+    (out * torch.linspace(1, 2, out.size(-1), dtype=dt, device=DEV)).sum().backward()
+    ref = g["grad_fbank_pow_wsum_f64"]
+    assert np.abs(host(Xg.grad) - ref).max() <= (1e-8 if dt == torch.float64 else 2e-4) * np.abs(ref).max()
+    mf = dsp.MFCC(fft_length=512, mfcc_order=12, n_channel=40, sample_rate=16000, lifter=22, out_format="ycE", device=DEV, dtype=dt)
+    Xg = X.clone().requires_grad_(True)
+    out = mf(Xg)
+    close(host(out), g[f"mfcc_ycE_{name}"], rt, 10 * at)
+    (out * torch.linspace(-1, 1, out.size(-1), dtype=dt, device=DEV)).sum().backward()
+    ref = g["grad_mfcc_wsum_f64"]
+    # amplitude-domain filter bank: d sqrt(x) / dx is huge at the near-empty bins of speech; bound per frame
+    err = np.abs(host(Xg.grad) - ref) / np.abs(ref).max(-1, keepdims=True)
+    assert err.max() <= (1e-8 if dt == torch.float64 else 5e-4)
+
+
+def test_fbank_mfcc_functional_formats_and_gradcheck(golden):
+    g = golden("fbank")
+    xs = dev(g["doc_spec"], torch.float64)
+    close(host(F.fbank(xs, 4, 8000)), g["doc_fbank"], 1e-5, 1e-6)
+    close(host(F.mfcc(xs, 4, 8, 8000)), g["doc_mfcc"], 1e-5, 1e-5)
+    xr = dev(g["grid_x"])
+    close(host(F.fbank(xr, 10, 8000, f_min=300, f_max=3400, floor=1, out_format=1)), g["grid_fbank_yE"], 1e-10, 1e-12)
+    y, E = F.fbank(xr, 10, 8000, out_format="y,E")
+    assert y.shape == (2, 10) and E.shape == (2, 1)
+    close(host(F.dct(xr)), g["grid_x"] @ O.dct2_matrix(17), 1e-12, 1e-13)
+    # ragged leading dims and a frame count that is not a multiple of 4
+    x3 = torch.rand(3, 7, 33, dtype=torch.float64, generator=torch.Generator().manual_seed(2)).to(DEV) + 0.1
+    for kw in (dict(), dict(use_power=True, gamma=0.3), dict(floor=0.5), dict(scale="bark", erb_factor=0.7)):
+        yo, Eo = O.fbank(host(x3), tables_H(64, 12, 8000, kw), kw.get("floor", 1e-5), kw.get("gamma", 0.0), kw.get("use_power", False))
+        yy = F.fbank(x3, 12, 8000, out_format="yE", **kw)
+        close(host(yy), np.concatenate([yo, Eo], -1), 1e-10, 1e-12)
+    xg = (torch.rand(5, 17, dtype=torch.float64, generator=torch.Generator().manual_seed(3)) + 0.5).to(DEV).requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda t: F.fbank(t, 6, 8000, out_format="yE"), (xg,), eps=1e-6, atol=1e-6, rtol=1e-5)
+    assert torch.autograd.gradcheck(lambda t: F.fbank(t, 6, 8000, use_power=True, gamma=-0.4, out_format="yE"), (xg,), eps=1e-6, atol=1e-6, rtol=1e-5)
+    assert torch.autograd.gradcheck(lambda t: F.mfcc(t, 4, 6, 8000, lifter=3, out_format="ycE"), (xg,), eps=1e-6, atol=1e-6, rtol=1e-5)
+
+
+def tables_H(L, C, sr, kw):
+    from diffsptk_amd.utils import tables
+
+    return tables.fbank_matrix(L, C, sr, 0.0, None, kw.get("scale", "htk"), kw.get("erb_factor"))
+
+
+def test_stft_fbank_chain_full_size():
+    """README.md:238-243 of the reference: STFT -> filter bank at the bench size; size-independent properties
+    (energy = log mean power over the circle; channel outputs are monotone in a gain applied to the input)."""
+    x = torch.randn(64, 16000, generator=torch.Generator().manual_seed(4)).to(DEV)
+    stft = dsp.STFT(400, 80, 512, device=DEV)
+    fb = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, use_power=True, out_format="y,E", device=DEV)
+    X = stft(x)
+    y, E = fb(X)
+    assert y.shape == (64, 200, 40) and E.shape == (64, 200, 1) and torch.isfinite(y).all()
+    Xh = X.double()
+    Eref = torch.log(((2 * Xh[..., 1:-1]).sum(-1) + Xh[..., 0] + Xh[..., -1]) / 512).unsqueeze(-1)
+    close(host(E), host(Eref), 1e-5, 1e-5)
+    y4, _ = fb(4 * X)     # power-domain bank is linear before the log: + log 4 on every channel above the floor
+    close(host(y4 - y), np.full(y.shape, np.log(4.0)), 1e-4, 1e-4)

@@ -189,3 +189,32 @@ def test_mcep_module_routes_extreme_alpha_to_generic():
     for alpha, algo in ((0.42, _lib.ALGO_AUTO), (-0.95, _lib.ALGO_AUTO), (0.96, _lib.ALGO_GENERIC), (-0.99, _lib.ALGO_GENERIC)):
         pre = MelCepstralAnalysis._precompute(512, 24, alpha, 3, "cpu", torch.float32)
         assert pre.values["algo"] == algo
+
+
+def test_fbank_mfcc_module_contract():
+    """Constructor checks of the filter-bank / MFCC modules (fbank.py:170-196, mfcc.py:162-168)."""
+    import pytest
+
+    import diffsptk_amd as dsp
+
+    ok = dict(fft_length=512, n_channel=40, sample_rate=16000)
+    bad = [(dict(ok, fft_length=1), "fft_length must be greater than 1."), (dict(ok, n_channel=0), "n_channel must be positive."),
+           (dict(ok, sample_rate=0), "sample_rate must be positive."), (dict(ok, f_min=8000), "Invalid f_min."),
+           (dict(ok, f_max=9000), "Invalid f_min and f_max."), (dict(ok, floor=0), "floor must be positive."),
+           (dict(ok, gamma=1.5), "gamma must be in [-1, 1]."), (dict(ok, erb_factor=0), "erb_factor must be positive."),
+           (dict(ok, out_format="z"), "out_format z is not supported.")]
+    for kw, msg in bad:
+        import re
+
+        with pytest.raises(ValueError, match=re.escape(msg)):
+            dsp.MelFilterBankAnalysis(**kw)
+    m = dsp.MelFilterBankAnalysis(**ok)
+    assert m.H.shape == (257, 40) and list(m.state_dict()) == []
+    with pytest.raises(ValueError, match="mfcc_order must be less than n_channel."):
+        dsp.MFCC(fft_length=512, mfcc_order=40, n_channel=40, sample_rate=16000)
+    with pytest.raises(ValueError, match="lifter must be non-negative."):
+        dsp.MFCC(fft_length=512, mfcc_order=12, n_channel=40, sample_rate=16000, lifter=-1)
+    mf = dsp.MFCC(fft_length=512, mfcc_order=12, n_channel=40, sample_rate=16000, lifter=22)
+    assert mf.W.shape == (40, 13) and mf.H.shape == (257, 40)
+    with pytest.raises(ValueError, match="dct_type must be in"):
+        dsp.DCT(8, 5)
