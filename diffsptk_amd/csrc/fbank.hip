@@ -3,16 +3,18 @@
 //     y = glog(max(s @ H, floor)),  s = x (use_power) or sqrt(x);   E = log((2 sum_inner x + x_0 + x_last) / (2 (K-1)))
 // Generic kernel pair (float32 / float64, any K, C): one wave64 owns 4 consecutive frames per pass, keeps
 // their spectra interleaved in LDS ([K][4]: one 16-byte broadcast read feeds 4 FMAs) and lane c owns
-// channel c.  H (K x C, triangular filters, 41 KB at K = 257, C = 40) is read through L1/L2; it may be
-// a learnable dense matrix, so no sparsity is assumed.  HBM: 4 K + 4 C bytes per frame (1188 B at
-// K = 257, C = 40).  MFCC (mfcc.py:244-256) = this kernel + the DCT-II/lifter matrix product on the
+// channel c.  H (K x C, triangular filters, 41 KB at K = 257, C = 40) is copied to LDS once per
+// workgroup; while copying, every channel's range of non-zero bins (and, for the backward, every bin's
+// range of non-zero channels) is recorded, so the loops touch only the ~2 K / C bins a triangular
+// filter covers -- discovered from the data, not assumed: a dense matrix simply gets full ranges.
+// HBM: 4 K + 4 C bytes per frame (1188 B at K = 257, C = 40).  MFCC (mfcc.py:244-256) = this kernel + the DCT-II/lifter matrix product on the
 // frequency-transform kernel (dsa_freqt_fwd).
 #include "common.h"
 
 namespace dsa {
 
 constexpr int kFbFrames = 4;   // frames per wave and pass
-constexpr int kFbWaves = 4;    // waves per workgroup
+constexpr int kFbMaxWaves = 16;  // waves per workgroup (as many as the LDS tiles next to the H copy allow)
 
 template <typename T>
 __device__ __forceinline__ T glog_fwd(T y, T gamma)
@@ -44,16 +46,54 @@ __device__ __forceinline__ void fbank_stage(const T* __restrict__ x, long f0, lo
     for (int fi = 0; fi < kFbFrames; ++fi) esum[fi] = wave_sum(esum[fi]);
 }
 
-template <typename T>
-__global__ __launch_bounds__(kFbWaves * 64) void fbank_fwd_kernel(const T* __restrict__ x, long F, int K,
+// H -> LDS and the non-zero ranges: lo_c / hi_c over bins for channel c (forward), lo_k / hi_k over channels
+// for bin k (backward).  HLDS = false (matrix too large for LDS): H stays in global memory, full ranges.
+template <typename T, bool HLDS>
+__device__ __forceinline__ const T* fbank_prepare(const T* __restrict__ H, int K, int C, T* Hs, int* rng_c, int* rng_k)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (HLDS)
+        for (int i = tid; i < K * C; i += nt) Hs[i] = H[i];
+    __syncthreads();
+    const T* Hm = HLDS ? Hs : H;
+    for (int c = tid; c < C; c += nt) {
+        int lo = K, hi = 0;
+        if (HLDS) {
+            for (int k = 0; k < K; ++k)
+                if (Hm[(long)k * C + c] != T(0)) { lo = k < lo ? k : lo; hi = k + 1; }
+        } else { lo = 0; hi = K; }
+        rng_c[2 * c] = lo < hi ? lo : 0;
+        rng_c[2 * c + 1] = hi;
+    }
+    if (rng_k)
+        for (int k = tid; k < K; k += nt) {
+            int lo = C, hi = 0;
+            if (HLDS) {
+                for (int c = 0; c < C; ++c)
+                    if (Hm[(long)k * C + c] != T(0)) { lo = c < lo ? c : lo; hi = c + 1; }
+            } else { lo = 0; hi = C; }
+            rng_k[2 * k] = lo < hi ? lo : 0;
+            rng_k[2 * k + 1] = hi;
+        }
+    __syncthreads();
+    return Hm;
+}
+
+template <typename T, bool HLDS>
+__global__ __launch_bounds__(kFbMaxWaves * 64) void fbank_fwd_kernel(const T* __restrict__ x, long F, int K,
                                                                   const T* __restrict__ H, int C, T floor, T gamma,
                                                                   int use_power, T* __restrict__ y, T* __restrict__ E)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    T* tile = reinterpret_cast<T*>(fb_smem) + (size_t)wave * K * kFbFrames;
+    T* tiles = reinterpret_cast<T*>(fb_smem);
+    const int nwaves = blockDim.x >> 6;
+    T* Hs = tiles + (size_t)nwaves * K * kFbFrames;
+    int* rng_c = reinterpret_cast<int*>(Hs + (HLDS ? (size_t)K * C : 0));
+    const T* Hm = fbank_prepare<T, HLDS>(H, K, C, Hs, rng_c, nullptr);
+    T* tile = tiles + (size_t)wave * K * kFbFrames;
     const long groups = (F + kFbFrames - 1) / kFbFrames;
-    for (long grp = (long)blockIdx.x * kFbWaves + wave; grp < groups; grp += (long)gridDim.x * kFbWaves) {
+    for (long grp = (long)blockIdx.x * nwaves + wave; grp < groups; grp += (long)gridDim.x * nwaves) {
         const long f0 = grp * kFbFrames;
         T esum[kFbFrames];
         __builtin_amdgcn_wave_barrier();
@@ -61,8 +101,9 @@ __global__ __launch_bounds__(kFbWaves * 64) void fbank_fwd_kernel(const T* __res
         __builtin_amdgcn_wave_barrier();
         for (int c = lane; c < C; c += 64) {
             T acc[kFbFrames] = {T(0), T(0), T(0), T(0)};
-            for (int k = 0; k < K; ++k) {
-                const T h = H[(long)k * C + c];
+            const int k1 = rng_c[2 * c + 1];
+            for (int k = rng_c[2 * c]; k < k1; ++k) {
+                const T h = Hm[(long)k * C + c];
 #pragma unroll
                 for (int fi = 0; fi < kFbFrames; ++fi) acc[fi] += tile[k * kFbFrames + fi] * h;   // fbank.py:316
             }
@@ -83,18 +124,24 @@ __global__ __launch_bounds__(kFbWaves * 64) void fbank_fwd_kernel(const T* __res
 }
 
 // gx = (gy * glog'(max(s H, floor)) * [s H >= floor]) H^T * ds/dx  +  gE * w / S
-template <typename T>
-__global__ __launch_bounds__(kFbWaves * 64) void fbank_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ gE,
+template <typename T, bool HLDS>
+__global__ __launch_bounds__(kFbMaxWaves * 64) void fbank_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ gE,
                                                                   const T* __restrict__ x, long F, int K,
                                                                   const T* __restrict__ H, int C, T floor, T gamma,
                                                                   int use_power, T* __restrict__ gx)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    T* tile = reinterpret_cast<T*>(fb_smem) + (size_t)wave * (K + C) * kFbFrames;
+    T* tiles = reinterpret_cast<T*>(fb_smem);
+    const int nwaves = blockDim.x >> 6;
+    T* Hs = tiles + (size_t)nwaves * (K + C) * kFbFrames;
+    int* rng_c = reinterpret_cast<int*>(Hs + (HLDS ? (size_t)K * C : 0));
+    int* rng_k = rng_c + 2 * C;
+    const T* Hm = fbank_prepare<T, HLDS>(H, K, C, Hs, rng_c, rng_k);
+    T* tile = tiles + (size_t)wave * (K + C) * kFbFrames;
     T* tch = tile + (size_t)K * kFbFrames;   // [C][4]: channel cotangents
     const long groups = (F + kFbFrames - 1) / kFbFrames;
-    for (long grp = (long)blockIdx.x * kFbWaves + wave; grp < groups; grp += (long)gridDim.x * kFbWaves) {
+    for (long grp = (long)blockIdx.x * nwaves + wave; grp < groups; grp += (long)gridDim.x * nwaves) {
         const long f0 = grp * kFbFrames;
         T esum[kFbFrames];
         __builtin_amdgcn_wave_barrier();
@@ -102,8 +149,9 @@ __global__ __launch_bounds__(kFbWaves * 64) void fbank_bwd_kernel(const T* __res
         __builtin_amdgcn_wave_barrier();
         for (int c = lane; c < C; c += 64) {
             T acc[kFbFrames] = {T(0), T(0), T(0), T(0)};
-            for (int k = 0; k < K; ++k) {
-                const T h = H[(long)k * C + c];
+            const int k1 = rng_c[2 * c + 1];
+            for (int k = rng_c[2 * c]; k < k1; ++k) {
+                const T h = Hm[(long)k * C + c];
 #pragma unroll
                 for (int fi = 0; fi < kFbFrames; ++fi) acc[fi] += tile[k * kFbFrames + fi] * h;
             }
@@ -117,8 +165,9 @@ __global__ __launch_bounds__(kFbWaves * 64) void fbank_bwd_kernel(const T* __res
         __builtin_amdgcn_wave_barrier();
         for (int k = lane; k < K; k += 64) {
             T acc[kFbFrames] = {T(0), T(0), T(0), T(0)};
-            const T* hrow = H + (long)k * C;
-            for (int c = 0; c < C; ++c) {
+            const T* hrow = Hm + (long)k * C;
+            const int c1 = rng_k[2 * k + 1];
+            for (int c = rng_k[2 * k]; c < c1; ++c) {
                 const T h = hrow[c];
 #pragma unroll
                 for (int fi = 0; fi < kFbFrames; ++fi) acc[fi] += tch[c * kFbFrames + fi] * h;
@@ -141,18 +190,50 @@ static int fbank_launch(bool bwd, const void* gy, const void* gE, const void* x,
                         double floor, double gamma, int use_power, void* y, void* E, void* gx, hipStream_t st)
 {
     if (F == 0) return DSA_OK;
-    const size_t lds = sizeof(T) * (size_t)kFbWaves * kFbFrames * (size_t)(bwd ? K + C : K);
-    if (lds > 60 * 1024) return fail(DSA_ERR_UNSUPPORTED, "fbank: spectrum too long for LDS%s");
+    const size_t tile1 = sizeof(T) * kFbFrames * (size_t)(bwd ? K + C : K);   // per wave
+    const size_t ranges = sizeof(int) * 2 * (size_t)(bwd ? K + C : C);
+    const size_t hmat = sizeof(T) * (size_t)K * C;
+    const size_t budget = 150 * 1024;
+    if (4 * tile1 + ranges > budget) return fail(DSA_ERR_UNSUPPORTED, "fbank: spectrum too long for LDS%s");
+    const bool hlds = 4 * tile1 + ranges + hmat <= budget;   // else H stays in global memory (full ranges)
+    long waves = (long)((budget - ranges - (hlds ? hmat : 0)) / tile1);
+    if (waves > kFbMaxWaves) waves = kFbMaxWaves;
     const long groups = (F + kFbFrames - 1) / kFbFrames;
-    long blocks = (groups + kFbWaves - 1) / kFbWaves;
-    if (blocks > 256L * 8) blocks = 256L * 8;
+    if (waves > groups) waves = groups < 1 ? 1 : groups;
+    const size_t lds = (size_t)waves * tile1 + ranges + (hlds ? hmat : 0);
+    long blocks = (groups + waves - 1) / waves;
+    if (blocks > 256) blocks = 256;   // one persistent workgroup per CU; H is copied once each
+    const int kFbWaves = (int)waves;
+#define DSA_FB_ATTR(kern)                                                                                        \
+    do {                                                                                                         \
+        static bool done = false;                                                                                \
+        if (!done && lds > 48 * 1024) {                                                                          \
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != \
+                hipSuccess)                                                                                      \
+                return fail(DSA_ERR_LAUNCH, "fbank: cannot reserve LDS for the filter matrix%s");               \
+            done = true;                                                                                         \
+        }                                                                                                        \
+    } while (0)
     if (!bwd) {
-        hipLaunchKernelGGL((fbank_fwd_kernel<T>), dim3((unsigned)blocks), dim3(kFbWaves * 64), lds, st, (const T*)x, (long)F,
-                           K, (const T*)H, C, (T)floor, (T)gamma, use_power, (T*)y, (T*)E);
+        if (hlds) {
+            DSA_FB_ATTR((fbank_fwd_kernel<T, true>));
+            hipLaunchKernelGGL((fbank_fwd_kernel<T, true>), dim3((unsigned)blocks), dim3(kFbWaves * 64), lds, st, (const T*)x,
+                               (long)F, K, (const T*)H, C, (T)floor, (T)gamma, use_power, (T*)y, (T*)E);
+        } else {
+            hipLaunchKernelGGL((fbank_fwd_kernel<T, false>), dim3((unsigned)blocks), dim3(kFbWaves * 64), lds, st, (const T*)x,
+                               (long)F, K, (const T*)H, C, (T)floor, (T)gamma, use_power, (T*)y, (T*)E);
+        }
         return check_launch("fbank_fwd");
     }
-    hipLaunchKernelGGL((fbank_bwd_kernel<T>), dim3((unsigned)blocks), dim3(kFbWaves * 64), lds, st, (const T*)gy, (const T*)gE,
-                       (const T*)x, (long)F, K, (const T*)H, C, (T)floor, (T)gamma, use_power, (T*)gx);
+    if (hlds) {
+        DSA_FB_ATTR((fbank_bwd_kernel<T, true>));
+        hipLaunchKernelGGL((fbank_bwd_kernel<T, true>), dim3((unsigned)blocks), dim3(kFbWaves * 64), lds, st, (const T*)gy,
+                           (const T*)gE, (const T*)x, (long)F, K, (const T*)H, C, (T)floor, (T)gamma, use_power, (T*)gx);
+    } else {
+        hipLaunchKernelGGL((fbank_bwd_kernel<T, false>), dim3((unsigned)blocks), dim3(kFbWaves * 64), lds, st, (const T*)gy,
+                           (const T*)gE, (const T*)x, (long)F, K, (const T*)H, C, (T)floor, (T)gamma, use_power, (T*)gx);
+    }
+#undef DSA_FB_ATTR
     return check_launch("fbank_bwd");
 }
 

@@ -47,3 +47,15 @@ def lpc_fb():
     xg = x.clone().requires_grad_(True); lpc(wn(fr(xg))).mean().backward()
 t_lfb = timeit(lpc_fb)
 print(f"   LPC fused fwd {t_l:.3f} ms ({frames/t_l*1e3:.3e} frames/s) | module chain fwd {t_lm:.3f} ms | fwd+bwd {t_lfb:.3f} ms")
+# filter bank / MFCC on the STFT power spectrum
+fb = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, use_power=True, device=dev)
+mf = dsp.MFCC(fft_length=512, mfcc_order=12, n_channel=40, sample_rate=16000, lifter=22, device=dev)
+with torch.no_grad():
+    Xs = stft(x)
+    t_fb = timeit(lambda: fb(Xs))
+    t_mf = timeit(lambda: mf(Xs))
+    t_sfb = timeit(lambda: mf(stft(x)))
+Xr = Xs.clone().requires_grad_(True)
+t_mfb = timeit(lambda: torch.autograd.grad(mf(Xr).sum(), Xr))
+print(f"   fbank(40) fwd {t_fb:.3f} ms ({1188*frames/t_fb/1e6:.0f} GB/s) | MFCC(12) fwd {t_mf:.3f} ms | STFT->MFCC {t_sfb:.3f} ms "
+      f"({frames/t_sfb*1e3:.3e} frames/s) | MFCC fwd+bwd {t_mfb:.3f} ms")
