@@ -34,7 +34,10 @@
 // far: MFMA-result latency (128-cycle s_sleep between the products and their first use), the inline
 // assembly below (a plain-vector-code build shows it too), strict aliasing, LDS bank-conflict layout
 // (a phase-major staging variant shows it more often), s_waitcnt vmcnt(0) before the staged samples
-// are consumed, s_waitcnt lgkmcnt(0) after every group of staging writes.  Until that is root-caused the dispatcher keeps
+// are consumed, s_waitcnt lgkmcnt(0) after every group of staging writes, early-clobber outputs on
+// the asm helpers (destination != source).  A sentinel-filled staging tile shows the bad bins ARE
+// written, with a wrong value: an intermediate of the twiddle / DFT-8 block is wrong in lanes 48..63
+// (the last quarter of a wave64 vector operation) of one instruction -- tools/dbg_stft4.py.  Until that is root-caused the dispatcher keeps
 // the register-FFT kernel as the default.
 #pragma once
 
