@@ -45,6 +45,16 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.
 FP32_PEAK_TFLOPS = 157.3    # fp32 MFMA dense peak = fp32 vector peak (same guide)
 
 
+def pmc_derived(kernel: str):
+    """Unit-busy fractions / occupancy of `kernel` derived from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json "derived"; north_star: LDS / VALU occupancy of the recursion stage)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)["kernels"][kernel].get("derived")
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel: str, frames: int):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE collected separately and corrected as MI355X_MICROARCH.md prescribes), rescaled to
@@ -207,6 +217,7 @@ def main():
                 "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": MCEP_FLOP_PER_FRAME * frames_launch / t_mcep / 1e12 / FP32_PEAK_TFLOPS,
                 "traffic": pmc_traffic(kernels["mcep"], frames_launch), "avg_launch_ms": t_mcep * 1e3,
+                "pmc": pmc_derived(kernels["mcep"]),
                 "frames_per_launch": frames_launch,
                 "flop_per_frame": MCEP_FLOP_PER_FRAME,
                 "note": "fp32 MFMA dense peak == fp32 vector peak (157.3 TFLOP/s); flops are the composed-matrix "
@@ -221,6 +232,7 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": STFT_BYTES_PER_FRAME * frames_launch / t_stft / 1e9 / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(kernels["stft"], frames_launch), "avg_launch_ms": t_stft * 1e3,
+                "pmc": pmc_derived(kernels["stft"]),
                 "bytes_per_frame": STFT_BYTES_PER_FRAME,
                 "traffic_note": "bytes per launch from profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
             },

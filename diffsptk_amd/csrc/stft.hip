@@ -587,6 +587,10 @@ __device__ __forceinline__ void fft16(cf (&v)[16])
 
 constexpr int kFPW = 4;         // frames per wave (16 lanes each)
 constexpr int kTile = kFPW * 257;  // floats in one output tile (4 rows)
+// Per-frame stride of the forward kernel's complex tile: ODD, so that the 8-byte transposed reads of the two
+// frames a 32-lane LDS service group covers land on opposite bank parities (stride 256: 2-way conflict on
+// every one of the 16 reads; PMC: 39 % of the kernel's LDS cycles were conflict cycles).
+constexpr int kZS = 257;
 
 #ifdef DSA_STFT_TIMING
 __device__ unsigned long long g_stft_stamps[16];
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf* zbuf = reinterpret_cast<cf*>(smem_raw);
     float* io_buf = reinterpret_cast<float*>(smem_raw);  // aliases zbuf (see above)
-    cf* t256 = zbuf + kFPW * 256;
+    cf* t256 = zbuf + kFPW * kZS;
     float* fmax = reinterpret_cast<float*>(t256 + 256);
     (void)io_floats;
 
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
     const float inv_L = 1.f / (float)L;
     const int K = 257;
     const bool complex_out = fmt == DSA_SPEC_COMPLEX;
-    cf* zf = zbuf + fl * 256;
+    cf* zf = zbuf + fl * kZS;
 
     for (long c = blockIdx.x; c < total_chunks; c += gridDim.x) {
         const long b = c / chunks_per_utt;
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
         cf pa[kFPW][2], pb[kFPW][2], z0[kFPW];
 #pragma unroll
         for (int f = 0; f < kFPW; ++f) {
-            const cf* z = zbuf + f * 256;
+            const cf* z = zbuf + f * kZS;
             pa[f][0] = z[lane + 1];
             pb[f][0] = z[255 - lane];
             pa[f][1] = z[lane + 65];
@@ -1128,7 +1132,7 @@ static int stft512_lds_bytes(int L, int P, int* io_floats)
     int span = (kFPW - 1) * P + L;
     *io_floats = (span + 3) & ~3;
     if (*io_floats > kFPW * 512) return 1 << 30;  // stretch does not fit: use the generic kernel
-    return kFPW * 256 * 8 + 256 * 8 + 16;
+    return kFPW * kZS * 8 + 256 * 8 + 16;   // (the backward kernel keeps stride 256 inside the same allocation)
 }
 
 template <int ABL>
