@@ -1148,6 +1148,30 @@ static void stft512_launch(bool zmean, dim3 grid, int lds, hipStream_t st, const
                            eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
 }
 
+// ---- inverse path helpers ----
+// irfft(Y)[n] = sum_k c_k / N Re(Y_k e^{+2 pi i k n / N}), c = 1 at DC / Nyquist, 2 in between (ifftr.py:138):
+// that is the ADJOINT of rfft (the backward kernels of this file) applied to G_k = c_k / N Y_k.
+template <typename T>
+__global__ void irfft_scale_kernel(const T* __restrict__ y, long total, int K, int nfft, T* __restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // complex element index
+    if (i >= total) return;
+    const int k = (int)(i % K);
+    const T c = ((k == 0 || k == nfft / 2) ? T(1) : T(2)) / T(nfft);
+    out[2 * i] = y[2 * i] * c;
+    out[2 * i + 1] = y[2 * i + 1] * c;
+}
+// Unframe._forward unframe.py:203-205: x / (sum of squared windows + 1e-16), the divisor shared by all rows
+template <typename T>
+__global__ void div_rows_kernel(const T* __restrict__ x, long B, long Tlen, const T* __restrict__ d, T eps,
+                                T* __restrict__ out)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Tlen) return;
+    const T r = T(1) / (d[t] + eps);
+    for (long b = blockIdx.y; b < B; b += gridDim.y) out[b * Tlen + t] = x[b * Tlen + t] * r;
+}
+
 }  // namespace dsa
 
 #include "stft_mfma.h"
@@ -1554,4 +1578,38 @@ DSA_EXPORT int dsa_stft_bwd(const void* gy, const void* x, int64_t B, int64_t T,
         return stft_bwd_generic<double>(gy, x, B, T, L, P, nfft, w, twiddle, center, zmean, pad_mode, eps,
                                         use_floor, relative_floor_db, out_format, gx, gw, st);
     return fail(DSA_ERR_UNSUPPORTED, "stft_bwd: unsupported dtype%s");
+}
+
+// --------------------------------------------------------------------------- inverse path (8(f) row 2)
+DSA_EXPORT int dsa_irfft_scale(const void* y, int64_t F, int32_t nfft, int32_t dtype, void* out, void* stream)
+{
+    DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "irfft_scale: fft_length must be positive even");
+    const int K = nfft / 2 + 1;
+    const long total = (long)F * K;
+    if (total == 0) return DSA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (dtype == DSA_F32)
+        hipLaunchKernelGGL((irfft_scale_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)y, total, K, nfft, (float*)out);
+    else if (dtype == DSA_F64)
+        hipLaunchKernelGGL((irfft_scale_kernel<double>), dim3(blocks), dim3(256), 0, st, (const double*)y, total, K, nfft, (double*)out);
+    else
+        return fail(DSA_ERR_UNSUPPORTED, "irfft_scale: unsupported dtype%s");
+    return check_launch("irfft_scale");
+}
+
+DSA_EXPORT int dsa_div_rows(const void* x, int64_t B, int64_t T, const void* d, double eps, int32_t dtype, void* out,
+                            void* stream)
+{
+    DSA_REQUIRE(B >= 0 && T >= 0, "div_rows: sizes must be non-negative");
+    if (B * T == 0) return DSA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((T + 255) / 256), (unsigned)(B < 1024 ? B : 1024));
+    if (dtype == DSA_F32)
+        hipLaunchKernelGGL((div_rows_kernel<float>), grid, dim3(256), 0, st, (const float*)x, (long)B, (long)T, (const float*)d, (float)eps, (float*)out);
+    else if (dtype == DSA_F64)
+        hipLaunchKernelGGL((div_rows_kernel<double>), grid, dim3(256), 0, st, (const double*)x, (long)B, (long)T, (const double*)d, eps, (double*)out);
+    else
+        return fail(DSA_ERR_UNSUPPORTED, "div_rows: unsupported dtype%s");
+    return check_launch("div_rows");
 }

@@ -51,6 +51,27 @@ def freqt(c: Tensor, out_order: int, alpha: float = 0) -> Tensor:
     return nn.FrequencyTransform._func(c, out_order=out_order, alpha=alpha)
 
 
+def ifftr(y: Tensor, out_length: int | None = None) -> Tensor:
+    """Inverse FFT of a half spectrum y:(..., L/2+1) complex -> (..., out_length) real."""
+    return nn.RealValuedInverseFastFourierTransform._func(y, out_length=out_length)
+
+
+def istft(y: Tensor, *, out_length: int | None = None, frame_length: int = 400, frame_period: int = 80,
+          fft_length: int = 512, center: bool = True, window: str | int = "blackman", norm: str | int = "power",
+          symmetric: bool = True) -> Tensor:
+    """Inverse STFT y:(..., T/P, N/2+1) complex -> (..., T)."""
+    return nn.InverseShortTimeFourierTransform._func(y, out_length, frame_length=frame_length, frame_period=frame_period,
+                                                     fft_length=fft_length, center=center, window=window, norm=norm,
+                                                     symmetric=symmetric)
+
+
+def unframe(y: Tensor, *, out_length: int | None = None, frame_period: int = 80, center: bool = True,
+            window: str | int = "rectangular", norm: str | int = "none", symmetric: bool = True) -> Tensor:
+    """Overlap-add framed waveforms y:(..., T/P, L) -> (..., T)."""
+    return nn.Unframe._func(y, out_length, frame_period=frame_period, center=center, window=window, norm=norm,
+                            symmetric=symmetric)
+
+
 def levdur(r: Tensor, eps: float | None = None) -> Tensor:
     """Solve the Yule-Walker system r:(..., M+1) -> gain and LPC coefficients (..., M+1)."""
     return nn.LevinsonDurbin._func(r, eps=eps)

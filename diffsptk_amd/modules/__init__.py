@@ -6,6 +6,9 @@ from .fbank import MelFilterBankAnalysis
 from .fbank import MelFilterBankAnalysis as FBANK
 from .fftr import RealValuedFastFourierTransform
 from .frame import Frame
+from .ifftr import RealValuedInverseFastFourierTransform
+from .istft import InverseShortTimeFourierTransform
+from .istft import InverseShortTimeFourierTransform as ISTFT
 from .freqt import FrequencyTransform
 from .levdur import LevinsonDurbin
 from .lpc import LinearPredictiveCodingAnalysis
@@ -16,11 +19,12 @@ from .mfcc import MelFrequencyCepstralCoefficientsAnalysis as MFCC
 from .spec import Spectrum
 from .stft import ShortTimeFourierTransform
 from .stft import ShortTimeFourierTransform as STFT
+from .unframe import Unframe
 from .window import Window
 
 __all__ = [
     "Autocorrelation", "BaseFunctionalModule", "DCT", "DiscreteCosineTransform", "FBANK", "Frame",
-    "FrequencyTransform", "LPC", "LevinsonDurbin", "LinearPredictiveCodingAnalysis", "MFCC", "MelCepstralAnalysis",
+    "FrequencyTransform", "ISTFT", "InverseShortTimeFourierTransform", "RealValuedInverseFastFourierTransform", "Unframe", "LPC", "LevinsonDurbin", "LinearPredictiveCodingAnalysis", "MFCC", "MelCepstralAnalysis",
     "MelFilterBankAnalysis", "MelFrequencyCepstralCoefficientsAnalysis", "Precomputed",
     "RealValuedFastFourierTransform", "STFT", "ShortTimeFourierTransform", "Spectrum", "Window",
 ]

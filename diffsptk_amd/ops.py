@@ -275,6 +275,181 @@ class MatmulRowsFn(torch.autograd.Function):
         return gc, None
 
 
+# ----------------------------------------------------------------------------------- inverse path (8(f) row 2)
+# irfft = adjoint of rfft applied to c_k / N Y_k, overlap-add = adjoint of framing: the inverse ops run on
+# the BACKWARD entry points of the analysis ops (and their gradients on the forward ones).
+def _real_dtype(t):
+    return {torch.complex64: torch.float32, torch.complex128: torch.float64}.get(t.dtype, t.dtype)
+
+
+def _irfft_scale(yr, fft_length):
+    """yr: (..., K, 2) real view of the half spectrum -> c_k / N * yr (ifftr.py:138)."""
+    K = fft_length // 2 + 1
+    out = torch.empty_like(yr)
+    with torch.cuda.device(yr.device):
+        _call("dsa_irfft_scale", _p(yr), yr.numel() // (2 * K), fft_length, _dtype_code(yr), _p(out), _stream())
+    return out
+
+
+def _div_rows(x2, d, eps=1e-16):
+    out = torch.empty_like(x2)
+    with torch.cuda.device(x2.device):
+        _call("dsa_div_rows", _p(x2), x2.size(0), x2.size(1), _p(d), float(eps), _dtype_code(x2), _p(out), _stream())
+    return out
+
+
+def _fold_plan(N, L, P, center, out_length):
+    """Signal length T the caller gets (unframe.py:176-192) and the length / frame count (Tc, Nc) the adjoint
+    kernels are run with: Nc = num_frames(Tc) >= N (missing frames are zero), Tc >= T."""
+    left = L // 2 if center else 0
+    full = (N - 1) * P + L - left
+    if out_length is None:
+        T = N * P if center else full
+    else:
+        T = out_length
+    T = max(0, min(T, full))        # slicing past the folded signal just ends there
+    Tc = T if (T > 0 and num_frames(T, P) >= N) else max(T, (N - 1) * P + 1)
+    return T, Tc, num_frames(Tc, P)
+
+
+def _pad_frames(t, N, Nc, dim):
+    if Nc == N:
+        return t
+    shape = list(t.shape)
+    shape[dim] = Nc - N
+    return torch.cat((t, t.new_zeros(shape)), dim=dim)
+
+
+def _window_sq_sum(w, N, Nc, L, P, center, Tc):
+    """Overlap-added squared window of the N frames, (Tc,): the divisor of unframe.py:204."""
+    fr = (w * w).reshape(1, 1, L).expand(1, N, L)
+    fr = _pad_frames(fr, N, Nc, 1).contiguous()
+    d = torch.empty(1, Tc, device=w.device, dtype=w.dtype)
+    with torch.cuda.device(w.device):
+        _call("dsa_frame_bwd", _p(fr), 1, Tc, L, P, int(center), 0, 0, _dtype_code(fr), _p(d), _stream())
+    return d.reshape(Tc)
+
+
+class IfftrFn(torch.autograd.Function):
+    """x:(..., out_length) = irfft(y:(..., L/2+1))[..., :out_length]  (ifftr.py:131-142)."""
+
+    @staticmethod
+    def forward(ctx, y, fft_length, out_length, twiddle):
+        _require_device(y, twiddle)
+        yr = torch.view_as_real(y.resolve_conj()).contiguous()
+        K = fft_length // 2 + 1
+        F = yr.numel() // (2 * K)
+        G = _irfft_scale(yr, fft_length)
+        x0 = torch.zeros(F, out_length, device=y.device, dtype=yr.dtype)   # the adjoint is linear: any valid point
+        x = torch.empty(*y.shape[:-1], out_length, device=y.device, dtype=yr.dtype)
+        with torch.cuda.device(y.device):
+            _call("dsa_fftr_bwd", _p(G), _p(x0), F, out_length, fft_length, 0, _p(twiddle), _dtype_code(yr), _p(x), _stream())
+        ctx.save_for_backward(twiddle)
+        ctx.cfg = (fft_length, out_length)
+        return x
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gx):
+        (twiddle,) = ctx.saved_tensors
+        fft_length, out_length = ctx.cfg
+        gx = gx.contiguous()
+        K = fft_length // 2 + 1
+        F = gx.numel() // out_length
+        Y = torch.empty(*gx.shape[:-1], K, 2, device=gx.device, dtype=gx.dtype)
+        with torch.cuda.device(gx.device):
+            _call("dsa_fftr_fwd", _p(gx), F, out_length, fft_length, 0, _p(twiddle), _dtype_code(gx), _p(Y), _stream())
+        return torch.view_as_complex(_irfft_scale(Y, fft_length)), None, None, None
+
+
+class UnframeFn(torch.autograd.Function):
+    """x:(..., T) = overlap-add(y * w) / overlap-add(w^2)  (unframe.py:164-211); y:(..., N, L)."""
+
+    @staticmethod
+    def forward(ctx, y, w, P, center, out_length):
+        _require_device(y, w)
+        _same_dtype(y, w)
+        if y.dim() <= 1:
+            raise ValueError("Input must be at least 2D tensor.")
+        yc, wc = y.contiguous(), w.contiguous()
+        N, L = yc.shape[-2:]
+        B = yc.numel() // (N * L)
+        T, Tc, Nc = _fold_plan(N, L, P, center, out_length)
+        yw = torch.empty_like(yc)
+        num = torch.empty(B, Tc, device=y.device, dtype=y.dtype)
+        with torch.cuda.device(y.device):
+            _call("dsa_window_fwd", _p(yc), B * N, L, _p(wc), L, _dtype_code(yc), _p(yw), _stream())
+            ywp = _pad_frames(yw.reshape(B, N, L), N, Nc, 1).contiguous()
+            _call("dsa_frame_bwd", _p(ywp), B, Tc, L, P, int(center), 0, 0, _dtype_code(yc), _p(num), _stream())
+        d = _window_sq_sum(wc, N, Nc, L, P, center, Tc)
+        x = _div_rows(num, d)
+        ctx.save_for_backward(wc, d)
+        ctx.cfg = (yc.shape, P, center, T, Tc, Nc)
+        return x[:, :T].reshape(*yc.shape[:-2], T)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gx):
+        wc, d = ctx.saved_tensors
+        shape, P, center, T, Tc, Nc = ctx.cfg
+        N, L = shape[-2:]
+        B = gx.numel() // max(T, 1)
+        g2 = gx.reshape(B, T)
+        if Tc != T:
+            g2 = torch.cat((g2, g2.new_zeros(B, Tc - T)), dim=1)
+        g2 = _div_rows(g2.contiguous(), d)
+        fr = torch.empty(B, Nc, L, device=gx.device, dtype=gx.dtype)
+        gy = torch.empty(B * N, L, device=gx.device, dtype=gx.dtype)
+        with torch.cuda.device(gx.device):
+            _call("dsa_frame_fwd", _p(g2), B, Tc, L, P, int(center), 0, 0, _dtype_code(g2), _p(fr), _stream())
+            frn = fr[:, :N].contiguous()
+            _call("dsa_window_fwd", _p(frn), B * N, L, _p(wc), L, _dtype_code(frn), _p(gy), _stream())
+        return gy.reshape(shape), None, None, None, None
+
+
+class IstftFn(torch.autograd.Function):
+    """x:(..., T) = unframe(irfft(y)[..., :L])  (istft.py:186-193), fused: the complex-cotangent STFT backward
+    kernel IS windowed inverse FFT + overlap-add."""
+
+    @staticmethod
+    def forward(ctx, y, window, twiddle, L, P, fft_length, center, out_length, algo):
+        _require_device(y, window, twiddle)
+        yr = torch.view_as_real(y.resolve_conj()).contiguous()
+        wc = window.contiguous()
+        N, K = yr.shape[-3:-1]
+        B = yr.numel() // (N * K * 2)
+        T, Tc, Nc = _fold_plan(N, L, P, center, out_length)
+        G = _pad_frames(_irfft_scale(yr, fft_length).reshape(B, N, K, 2), N, Nc, 1).contiguous()
+        x0 = torch.zeros(B, Tc, device=y.device, dtype=yr.dtype)
+        num = torch.empty(B, Tc, device=y.device, dtype=yr.dtype)
+        with torch.cuda.device(y.device):
+            _call("dsa_stft_bwd", _p(G), _p(x0), B, Tc, L, P, fft_length, _p(wc), _p(twiddle), int(center), 0, 0, 0.0, 0,
+                  0.0, 4, _dtype_code(yr), algo, _p(num), None, _stream())
+        d = _window_sq_sum(wc, N, Nc, L, P, center, Tc)
+        x = _div_rows(num, d)
+        ctx.save_for_backward(wc, twiddle, d)
+        ctx.cfg = (y.shape, L, P, fft_length, center, T, Tc, Nc, algo)
+        return x[:, :T].reshape(*y.shape[:-2], T)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gx):
+        wc, twiddle, d = ctx.saved_tensors
+        shape, L, P, fft_length, center, T, Tc, Nc, algo = ctx.cfg
+        N, K = shape[-2:]
+        B = gx.numel() // max(T, 1)
+        g2 = gx.reshape(B, T)
+        if Tc != T:
+            g2 = torch.cat((g2, g2.new_zeros(B, Tc - T)), dim=1)
+        g2 = _div_rows(g2.contiguous(), d)
+        Y = torch.empty(B, Nc, K, 2, device=gx.device, dtype=gx.dtype)
+        with torch.cuda.device(gx.device):
+            _call("dsa_stft_fwd", _p(g2), B, Tc, L, P, fft_length, _p(wc), _p(twiddle), int(center), 0, 0, 0.0, 0, 0.0, 4,
+                  _dtype_code(g2), algo, _p(Y), _stream())
+        gy = _irfft_scale(Y[:, :N].contiguous(), fft_length)
+        return (torch.view_as_complex(gy).reshape(shape),) + (None,) * 8
+
+
 # ----------------------------------------------------------------------------------- fbank
 class FbankFn(torch.autograd.Function):
     """y, E = mel filter bank outputs and log energy of power spectra (fbank.py:306-321).

@@ -133,6 +133,16 @@ int dsa_fbank_fwd(const void* x, int64_t F, int32_t K, const void* H, int32_t C,
 int dsa_fbank_bwd(const void* gy, const void* gE, const void* x, int64_t F, int32_t K, const void* H, int32_t C,
                   double floor, double gamma, int32_t use_power, int32_t dtype, void* gx, void* stream);
 
+/* ------------------------------------------------------------------ f2  inverse path
+ * RealValuedInverseFastFourierTransform ifftr.py:131-142, Unframe unframe.py:164-211, InverseShortTimeFourier-
+ * Transform istft.py:186-193.  irfft is the ADJOINT of rfft applied to G_k = c_k / N Y_k (c = 1 at DC and
+ * Nyquist, else 2), and overlap-add is the adjoint of framing: the inverse path runs on the backward entries
+ * above (dsa_fftr_bwd / dsa_frame_bwd / dsa_stft_bwd with complex cotangents) plus these two helpers.
+ *   dsa_irfft_scale: y:(F,nfft/2+1) complex pairs -> out = c_k / nfft * y
+ *   dsa_div_rows:    out:(B,T) = x / (d:(T) + eps)   (d = overlap-added squared window, eps = 1e-16) */
+int dsa_irfft_scale(const void* y, int64_t F, int32_t nfft, int32_t dtype, void* out, void* stream);
+int dsa_div_rows(const void* x, int64_t B, int64_t T, const void* d, double eps, int32_t dtype, void* out, void* stream);
+
 /* ------------------------------------------------------------------ a8-a10  mel-cepstral analysis
  * MelCepstralAnalysis._forward, mcep.py:189-224 (incl. symmetric_toeplitz / hankel,
  * utils/private.py:291-302, and the torch.linalg.solve call at mcep.py:221).

@@ -317,3 +317,42 @@ def mfcc(X, H, mfcc_order, lifter=1, floor=1e-5, gamma=0.0):
     lift[0] = np.sqrt(2.0)
     cy = cy * lift.astype(fb.dtype)
     return cy[..., 1:], cy[..., :1], E
+
+
+# ------------------------------------------------------------------ inverse path
+def ifftr(Y, out_length=None):
+    """irfft(Y)[..., :out_length] by the definition (ifftr.py:138): own O(N^2) sum, float64."""
+    Y = np.asarray(Y)
+    K = Y.shape[-1]
+    n = 2 * (K - 1)
+    L = n if out_length is None else out_length
+    k = np.arange(K)
+    c = np.where((k == 0) | (k == K - 1), 1.0, 2.0) / n
+    ang = 2 * np.pi * np.outer(k, np.arange(L)) / n
+    return (Y.real * c) @ np.cos(ang) - (Y.imag * c) @ np.sin(ang)
+
+
+def unframe(y, frame_period, center=True, w=None, out_length=None):
+    """fold(y w) / (fold(w w) + 1e-16) with the centre trim (unframe.py:176-207): plain loops."""
+    y = np.asarray(y, dtype=np.float64)
+    N, L = y.shape[-2:]
+    w = np.ones(L) if w is None else np.asarray(w, dtype=np.float64)
+    lead = y.shape[:-2]
+    y2 = y.reshape(-1, N, L)
+    full = (N - 1) * frame_period + L
+    num = np.zeros((y2.shape[0], full))
+    den = np.zeros(full)
+    for f in range(N):
+        num[:, f * frame_period: f * frame_period + L] += y2[:, f] * w
+        den[f * frame_period: f * frame_period + L] += w * w
+    x = num / (den + 1e-16)
+    s = L // 2 if center else 0
+    if out_length is None and center:
+        out_length = N * frame_period
+    e = None if out_length is None else s + out_length
+    return x[:, s:e].reshape(*lead, -1)
+
+
+def istft(Y, frame_length, frame_period, center=True, w=None, out_length=None):
+    """unframe(ifftr(Y)[..., :L]) (istft.py:186-193)."""
+    return unframe(ifftr(Y, frame_length), frame_period, center, w, out_length)

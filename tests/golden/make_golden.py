@@ -258,6 +258,36 @@ def main():
                                                       floor=1, out_format=1, dtype=f64)(xr))
     np.savez_compressed(os.path.join(HERE, "fbank.npz"), **g7)
 
+    # ------------------------------------------------------------------ inverse path
+    g8 = {}
+    yc = torch.randn(3, 9, dtype=torch.complex128)
+    g8["ifftr_y"] = npy(yc)
+    g8["ifftr_full"] = npy(d.RealValuedInverseFastFourierTransform(16, dtype=f64)(yc))
+    g8["ifftr_5"] = npy(d.RealValuedInverseFastFourierTransform(16, 5, dtype=f64)(yc))
+    fr = torch.randn(2, 7, 12, dtype=f64)
+    g8["unframe_y"] = npy(fr)
+    for tag, kw, ol in (("default", dict(), None), ("nocenter", dict(center=False), None),
+                        ("blackman_20", dict(window="blackman", norm="power"), 20),
+                        ("hanning_long", dict(window="hanning"), 40), ("nocenter_9", dict(center=False), 9)):
+        g8[f"unframe_{tag}"] = npy(d.Unframe(12, 4, dtype=f64, **kw)(fr, out_length=ol))
+    g8["unframe_doc"] = npy(d.Unframe(5, 2)(d.Frame(5, 2)(d.ramp(1, 9))))
+    ys = torch.randn(2, 10, 33, dtype=torch.complex128)
+    g8["istft_y"] = npy(ys)
+    g8["istft_default"] = npy(d.ISTFT(40, 8, 64, dtype=f64)(ys))
+    g8["istft_len70"] = npy(d.ISTFT(40, 8, 64, dtype=f64)(ys, out_length=70))
+    g8["istft_nocenter_hamming"] = npy(d.ISTFT(40, 8, 64, center=False, window="hamming", norm="none", dtype=f64)(ys))
+    ysg = ys.clone().requires_grad_(True)
+    out = d.ISTFT(40, 8, 64, dtype=f64)(ysg)
+    (out * torch.linspace(-1, 1, out.size(-1), dtype=f64)).sum().backward()
+    g8["grad_istft_wsum"] = npy(ysg.grad)
+    # analysis -> synthesis round trip at the bench configuration on data.wav (tests/test_istft.py:26-58)
+    xw = torch.from_numpy(pcm.astype(np.float64) / 32768.0)
+    for name, dt in DT.items():
+        st = d.STFT(400, 80, 512, out_format="complex", dtype=dt)
+        ist = d.ISTFT(400, 80, 512, dtype=dt)
+        g8[f"roundtrip_{name}"] = npy(ist(st(xw.to(dt)), out_length=xw.numel()))
+    np.savez_compressed(os.path.join(HERE, "inverse.npz"), **g8)
+
     meta = {
         "reference": "sp-nitech/diffsptk 4.0.0 (/root/reference)",
         "torch": torch.__version__,
@@ -267,7 +297,7 @@ def main():
     }
     with open(os.path.join(HERE, "META.json"), "w") as f:
         json.dump(meta, f, indent=1)
-    for fn in ("tables.npz", "datawav.npz", "randn.npz", "grids.npz", "fbank.npz"):
+    for fn in ("tables.npz", "datawav.npz", "randn.npz", "grids.npz", "fbank.npz", "inverse.npz"):
         print(fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, "KiB")
 
 

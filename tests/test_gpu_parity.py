@@ -730,3 +730,60 @@ def test_stft_fbank_chain_full_size():
     close(host(E), host(Eref), 1e-5, 1e-5)
     y4, _ = fb(4 * X)     # power-domain bank is linear before the log: + log 4 on every channel above the floor
     close(host(y4 - y), np.full(y.shape, np.log(4.0)), 1e-4, 1e-4)
+
+
+# ----------------------------------------------------------------------------- f2 inverse path
+def test_inverse_path_golden(golden):
+    """ifftr / Unframe / ISTFT (ifftr.py:131-142, unframe.py:164-211, istft.py:186-193) on the adjoint kernels,
+    float64, against the reference's outputs; the ISTFT gradient w.r.t. the complex spectrogram too."""
+    g = golden("inverse")
+    yc = torch.from_numpy(g["ifftr_y"]).to(DEV)
+    close(host(dsp.RealValuedInverseFastFourierTransform(16, device=DEV, dtype=torch.float64)(yc)), g["ifftr_full"], 1e-11, 1e-12)
+    close(host(F.ifftr(yc, 5)), g["ifftr_5"], 1e-11, 1e-12)
+    fr = dev(g["unframe_y"])
+    close(host(dsp.Unframe(12, 4, device=DEV, dtype=torch.float64)(fr)), g["unframe_default"], 1e-11, 1e-12)
+    close(host(F.unframe(fr, frame_period=4, center=False)), g["unframe_nocenter"], 1e-11, 1e-12)
+    close(host(F.unframe(fr, out_length=20, frame_period=4, window="blackman", norm="power")), g["unframe_blackman_20"], 1e-10, 1e-12)
+    close(host(F.unframe(fr, out_length=40, frame_period=4, window="hanning")), g["unframe_hanning_long"], 1e-10, 1e-12)
+    close(host(F.unframe(fr, out_length=9, frame_period=4, center=False)), g["unframe_nocenter_9"], 1e-11, 1e-12)
+    doc = dsp.Unframe(5, 2, device=DEV)(dsp.Frame(5, 2)(torch.arange(1.0, 10.0, device=DEV)))
+    close(host(doc), g["unframe_doc"], 1e-6, 1e-6)
+    ys = torch.from_numpy(g["istft_y"]).to(DEV)
+    ist = dsp.ISTFT(40, 8, 64, device=DEV, dtype=torch.float64)
+    ysg = ys.clone().requires_grad_(True)
+    out = ist(ysg)
+    close(host(out), g["istft_default"], 1e-10, 1e-12)
+    (out * torch.linspace(-1, 1, out.size(-1), dtype=torch.float64, device=DEV)).sum().backward()
+    close(host(ysg.grad), g["grad_istft_wsum"], 1e-9, 1e-11)
+    close(host(ist(ys, out_length=70)), g["istft_len70"], 1e-10, 1e-12)
+    close(host(F.istft(ys, frame_length=40, frame_period=8, fft_length=64, center=False, window="hamming", norm="none")),
+          g["istft_nocenter_hamming"], 1e-10, 1e-12)
+
+
+@pytest.mark.parametrize("name,dt,tol", [("f64", torch.float64, 1e-11), ("f32", torch.float32, 2e-6)])
+def test_stft_istft_round_trip(golden, name, dt, tol):
+    """tests/test_istft.py:26-58 of the reference: ISTFT(STFT(x)) = x at fl=400 fp=80 nfft=512 on data.wav (float32:
+    both directions on the tuned FFT kernels), and at the bench size on noise."""
+    g, gw = golden("inverse"), golden("datawav")
+    x = dev(wav_float(gw["pcm"], np.float64), dt)
+    st = dsp.STFT(400, 80, 512, out_format="complex", device=DEV, dtype=dt)
+    ist = dsp.ISTFT(400, 80, 512, device=DEV, dtype=dt)
+    xr = ist(st(x), out_length=x.numel())
+    if dt == torch.float32:
+        assert _lib.last_kernel() == "div_rows"
+    close(host(xr), g[f"roundtrip_{name}"], 0, 10 * tol)
+    assert (xr - x).abs().max().item() < tol
+    xb = torch.randn(64, 16000, generator=torch.Generator().manual_seed(7)).to(DEV, dt)
+    xbr = ist(st(xb))            # default length N * P = 16000
+    assert xbr.shape == xb.shape and (xbr - xb).abs().max().item() < 20 * tol
+
+
+def test_inverse_path_gradcheck():
+    gen = torch.Generator().manual_seed(11)
+    yc = torch.randn(2, 5, 9, dtype=torch.complex128, generator=gen).to(DEV).requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda t: F.ifftr(t, 7), (yc,), eps=1e-6, atol=1e-7, rtol=1e-6)
+    assert torch.autograd.gradcheck(lambda t: F.istft(t, frame_length=12, frame_period=4, fft_length=16, out_length=18), (yc,),
+                                    eps=1e-6, atol=1e-7, rtol=1e-6)
+    fr = torch.randn(2, 6, 10, dtype=torch.float64, generator=gen).to(DEV).requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda t: F.unframe(t, frame_period=3, window="hamming"), (fr,), eps=1e-6, atol=1e-7, rtol=1e-6)
+    assert torch.autograd.gradcheck(lambda t: F.unframe(t, out_length=11, frame_period=5, center=False), (fr,), eps=1e-6, atol=1e-7, rtol=1e-6)
