@@ -59,3 +59,12 @@ Xr = Xs.clone().requires_grad_(True)
 t_mfb = timeit(lambda: torch.autograd.grad(mf(Xr).sum(), Xr))
 print(f"   fbank(40) fwd {t_fb:.3f} ms ({1188*frames/t_fb/1e6:.0f} GB/s) | MFCC(12) fwd {t_mf:.3f} ms | STFT->MFCC {t_sfb:.3f} ms "
       f"({frames/t_sfb*1e3:.3e} frames/s) | MFCC fwd+bwd {t_mfb:.3f} ms")
+# analysis -> synthesis round trip
+stc = dsp.STFT(400, 80, 512, out_format="complex", device=dev)
+ist = dsp.ISTFT(400, 80, 512, device=dev)
+with torch.no_grad():
+    Z = stc(x)
+    t_sc = timeit(lambda: stc(x))
+    t_is = timeit(lambda: ist(Z))
+    err = (ist(Z) - x).abs().max().item()
+print(f"   STFT complex fwd {t_sc:.3f} ms | ISTFT {t_is:.3f} ms ({frames/t_is*1e3:.3e} frames/s) | round-trip max error {err:.2e}")
