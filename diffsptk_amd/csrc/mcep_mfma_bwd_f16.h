@@ -180,7 +180,13 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
         if (lane == 0) nxt = atomicAdd(queue, 1u);
         const long tile_next = wave_stride + (long)__builtin_amdgcn_readfirstlane((int)nxt);
 
+#ifdef DSA_MCEP_TIMING
+#define BSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && tile == wave_id && iter == n_iter - 2) g_mcep_stamps[40 + i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BSTAMP(i)
+#endif
         for (int iter = n_iter - 1; iter >= 0; --iter) {
+            BSTAMP(0);
             float mcv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) mcv[i] = (8 * g + i < M1) ? hist[((long)iter * F + f) * M1 + 8 * g + i] : 0.f;
@@ -282,6 +288,7 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             }
             __builtin_amdgcn_wave_barrier();
 
+            BSTAMP(1);
             // ---------------- solve A [gv | uv] = [rt[:25] - alpha | mbar] in the quad layout ----------------
             float gv[M1], uv[M1];
             {
@@ -294,6 +301,7 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
                 float xq2[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[2], -1.f)};
                 col_backsub_full(a, xq2, uv, gq, std::make_integer_sequence<int, M1>{});
             }
+            BSTAMP(2);
             // ---------------- rtbar (49 entries), scaled per frame to below 2^13, into the exchange window ----------------
             int s_r;   // rtbar = 2^-s_r (window contents)
             {
@@ -337,6 +345,7 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             eb256 += __shfl_xor(eb256, 16, 64);
             eb256 += __shfl_xor(eb256, 32, 64);
 
+            BSTAMP(3);
             // ---------------- ebar^T = E rtbar^T ; zbar = ebar * e ; lbar += zbar ----------------
             // zbar = acc * ep * 2^kz,  kz = -(s_r + SEB_LOG2) + back
             const int kz = back - s_rn - SEB_LOG2;
@@ -345,8 +354,8 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             {
                 const _Float16* imgt = img;
                 asm volatile("" : "+s"(imgt));
-                const f16x8* EBH = reinterpret_cast<const f16x8*>(imgt + IMG_EBH) + lane;
-                const f16x8* EBL = reinterpret_cast<const f16x8*>(imgt + IMG_EBL) + lane;
+                const gf16x8_ptr EBH = (gf16x8_ptr)(imgt + IMG_EBH) + lane;
+                const gf16x8_ptr EBL = (gf16x8_ptr)(imgt + IMG_EBL) + lane;
 #pragma unroll
                 for (int mt = 0; mt < 16; ++mt) {
                     f32x4 acc = {0, 0, 0, 0};
@@ -368,6 +377,7 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             }
             const float zb256 = __builtin_ldexpf(eb256 * e256, back - s_rn);
             lbar256 += zb256;
+            BSTAMP(4);
             // ---------------- mbar^T += (-2 D) zbar^T : zbar scaled per frame to below 2^13 ----------------
             zmax = __builtin_fmaxf(zmax, __shfl_xor(zmax, 16, 64));
             zmax = __builtin_fmaxf(zmax, __shfl_xor(zmax, 32, 64));
@@ -400,6 +410,7 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
                         mbarC[it2][r] = __builtin_fmaf(zb256, lds[B_D256 + 32 + c], mbarC[it2][r]);   // Nyquist bin (table is 0 past c = 24)
                     }
             }
+            BSTAMP(5);
         }
 
         // ---------------- lbar += G mbar_0 (mcep.py:204-207 adjoint); gX = lbar / X ----------------
@@ -433,8 +444,8 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             split8(ms, mh8, ml8);
             const _Float16* imgt = img;
             asm volatile("" : "+s"(imgt));
-            const f16x8* GBH = reinterpret_cast<const f16x8*>(imgt + IMG_GBH) + lane;
-            const f16x8* GBL = reinterpret_cast<const f16x8*>(imgt + IMG_GBL) + lane;
+            const gf16x8_ptr GBH = (gf16x8_ptr)(imgt + IMG_GBH) + lane;
+            const gf16x8_ptr GBL = (gf16x8_ptr)(imgt + IMG_GBL) + lane;
 #pragma unroll
             for (int mt = 0; mt < 16; ++mt) {
                 const f16x8 ah = GBH[mt * 64], al = GBL[mt * 64];

@@ -25,6 +25,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// explicit global address space: a pointer that went through an opaque asm statement is otherwise loaded from
+// with FLAT instructions, which count on the LDS counter too and stall every LDS wait behind an L2 round trip
+typedef const __attribute__((address_space(1))) f16x8* gf16x8_ptr;
+typedef const __attribute__((address_space(1))) float* gf32_ptr;
 
 namespace mh {
 using namespace mm;
@@ -209,8 +213,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             // (opaque per tile: hoisted out of the tile loop the 32 operand loads would live in scratch)
             const _Float16* imgt = img;
             asm volatile("" : "+s"(imgt));
-            const f16x8* GH = reinterpret_cast<const f16x8*>(imgt + IMG_GH) + lane;
-            const f16x8* GL = reinterpret_cast<const f16x8*>(imgt + IMG_GL) + lane;
+            const gf16x8_ptr GH = (gf16x8_ptr)(imgt + IMG_GH) + lane;
+            const gf16x8_ptr GL = (gf16x8_ptr)(imgt + IMG_GL) + lane;
             f32x4 accG[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
 #pragma unroll
             for (int it = 0; it < 2; ++it) {  // Nyquist bin: one float32 k-step on k-slot 0
                 const int out = it * 16 + n;
-                const float gv = out < M1 ? (kLn2 * SG * SL) * reinterpret_cast<const float*>(imgt + IMG_HALVES)[out] : 0.f;
+                const float gv = out < M1 ? (kLn2 * SG * SL) * ((gf32_ptr)(imgt + IMG_HALVES))[out] : 0.f;
                 accG[it] = mfma4(keep_if(g_eq0, gv), keep_if(g_eq0, logx256), accG[it]);
                 accG[it] *= 1.f / (SG * SL);
             }
