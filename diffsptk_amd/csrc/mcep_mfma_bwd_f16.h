@@ -290,33 +290,76 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
 
             BSTAMP(1);
             // ---------------- solve A [gv | uv] = [rt[:25] - alpha | mbar] in the quad layout ----------------
-            float gv[M1], uv[M1];
+            // quad-layout solutions: xq1[c] = g[gs + 4 c], xq2[c] = u[gs + 4 c]
+            float xq1[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[1], -1.f)};
+            float xq2[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[2], -1.f)};
             {
                 float a[colm::TOTAL];
                 col_build_rows<0>(a, rt_q, rr_q, lds + B_AV, aux_q, gs, gq);
                 __builtin_amdgcn_wave_barrier();
                 col_elim_all(a, std::make_integer_sequence<int, M1>{});
-                float xq1[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[1], -1.f)};
-                col_backsub_full(a, xq1, gv, gq, std::make_integer_sequence<int, M1>{});
-                float xq2[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[2], -1.f)};
-                col_backsub_full(a, xq2, uv, gq, std::make_integer_sequence<int, M1>{});
+                col_backsub_all(a, xq1, gq, std::make_integer_sequence<int, M1>{});
+                col_backsub_all(a, xq2, gq, std::make_integer_sequence<int, M1>{});
+                // slot 6 holds x[24] on lane 0 only (the other lanes' slot 6 are the right-hand-side markers)
+                xq1[KS - 1] = keep_if(gq.m[0], xq1[KS - 1]);
+                xq2[KS - 1] = keep_if(gq.m[0], xq2[KS - 1]);
             }
             BSTAMP(2);
             // ---------------- rtbar (49 entries), scaled per frame to below 2^13, into the exchange window ----------------
             int s_r;   // rtbar = 2^-s_r (window contents)
             {
+                // rtbar[m] = -sum_{i+j=m} u_i g_j - [m<25] (sum_{|i-j|=m} u_i g_j - u_m), split over the quad by
+                // i = gs + 4 c: lane gs holds uq[c] = u[gs + 4 c] (the quad-layout solution xq2) and reads two
+                // shifted copies of g through the exchange window -- gsh1[k] = g[k - gs], gsh2[k] = g[k + gs]
+                // (zero outside 0..24) -- so every index below is a compile-time constant; 4 x fewer
+                // multiply-adds than every lane forming all 49 sums, then one quad all-reduce per entry.
+                const float (&uq)[KS] = xq2;
+                // window: [0,3) zeros | g[0..24] at 3..27 | zeros to 33: every lane stores its own quarter of g
+#pragma unroll
+                for (int k = 0; k < 3; ++k) aux_q[k] = 0.f;
+#pragma unroll
+                for (int c = 0; c < KS; ++c) aux_q[3 + gs + 4 * c] = xq1[c];   // c = 6: x[24] at 27, zeros at 28..30
+#pragma unroll
+                for (int k = 31; k < 34; ++k) aux_q[k] = 0.f;
+                __builtin_amdgcn_wave_barrier();
+                float gsh1[28], gsh2[31];                      // gsh2 index k + 3, k = -3 .. 27
+                const float* w1 = aux_q + 3 - gs;
+                const float* w2 = aux_q + gs;
+#pragma unroll
+                for (int k = 0; k < 28; ++k) gsh1[k] = w1[k];
+#pragma unroll
+                for (int k = 0; k < 31; ++k) gsh2[k] = w2[k];
+                __builtin_amdgcn_wave_barrier();
                 float rb[M2];
-                rtbar_store(rb, gv, uv, std::make_integer_sequence<int, M2>{});
+#pragma unroll
+                for (int m = 0; m < M2; ++m) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int c = 0; c < KS; ++c) {
+                        if (m - 4 * c >= 0 && m - 4 * c <= 27) acc = __builtin_fmaf(-uq[c], gsh1[m - 4 * c], acc);          // i + j = m
+                        if (m < M1 && 4 * c + m <= 27) acc = __builtin_fmaf(-uq[c], gsh2[4 * c + m + 3], acc);               // j - i = m
+                        if (m < M1 && m > 0 && 4 * c - m >= -3) acc = __builtin_fmaf(-uq[c], gsh2[4 * c - m + 3], acc);      // i - j = m
+                    }
+                    if (m < M1) acc += keep_if(gq.m[m & 3], uq[m >> 2]);   // through the right-hand side rt[:25] - alpha
+                    acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                    acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+                    rb[m] = acc;
+                }
                 float amax = 0.f;
 #pragma unroll
                 for (int m = 0; m < M2; ++m) amax = __builtin_fmaxf(amax, __builtin_fabsf(rb[m]));
                 s_r = VMAX_LOG2 - __builtin_amdgcn_frexp_expf(amax);
-                if (gs == 0) {
+                // the four lanes of a quad hold identical sums: all of them store (16-byte pieces, same values)
+                f32x4* aux4 = reinterpret_cast<f32x4*>(aux_q);
 #pragma unroll
-                    for (int m = 0; m < M2; ++m) aux_q[m] = __builtin_ldexpf(rb[m], s_r);
+                for (int q4 = 0; q4 < 16; ++q4) {
+                    f32x4 v;
 #pragma unroll
-                    for (int m = M2; m < 63; ++m) aux_q[m] = 0.f;
-                    aux_q[63] = __int_as_float(s_r);
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = 4 * q4 + e;
+                        v[e] = m < M2 ? __builtin_ldexpf(rb[m < M2 ? m : 0], s_r) : (m == 63 ? __int_as_float(s_r) : 0.f);
+                    }
+                    aux4[q4] = v;
                 }
             }
             __builtin_amdgcn_wave_barrier();
