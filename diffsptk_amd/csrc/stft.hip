@@ -616,6 +616,10 @@ __device__ unsigned long long g_stft_stamps[16];
 //   t256[16][16] cf    : W256^(j k1), shared by the 4 frames;   fmax[kFPW].
 // ABL: 0 production | 1 no output stores | 2 no FFT butterflies | 3 no input staging
 //      (ablation knob for tools/bench_stft.cpp)
+// The workgroup IS one wave: LDS operations of a wave execute in order, so the phases only need a compiler
+// fence.  (__syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: its vmcnt(0) made every pass wait for the
+// previous pass's output stores before touching LDS.)
+#define DSA_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 template <int ABL, bool ZMEAN>
 __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
     const float* __restrict__ x, long Tlen, long N, int L, int P, int left, int mode,
@@ -657,7 +661,7 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
         const long frame0 = (c - b * chunks_per_utt) * kFPW;
         const int nvalid = (int)((N - frame0) < kFPW ? (N - frame0) : kFPW);
         const float* xb = x + b * Tlen;
-        __syncthreads();  // previous pass is done with the LDS tile (single-wave workgroup)
+        DSA_WAVE_SYNC();  // previous pass is done with the LDS tile (single-wave workgroup)
         STFT_STAMP(0);
         // ---- stage the shared waveform stretch (each sample read from HBM once) ----
         if (ABL != 3) {
@@ -674,7 +678,7 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
                 for (int s = lane; s < need; s += 64) io_buf[s] = load_padded(xb, g0 + s, Tlen, mode);
             }
         }
-        __syncthreads();
+        DSA_WAVE_SYNC();
         STFT_STAMP(1);
         // ---- per frame: window, 256-point complex FFT (16 lanes x 16 points) ----
         cf v[16];
@@ -711,24 +715,24 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
                 v[m1] = cf{a0 * wreg[2 * m1], a1 * wreg[2 * m1 + 1]};  // window.py:190 (wreg = 0 past L)
             }
         }
-        __syncthreads();  // every lane has its samples: the stretch may be overwritten
+        DSA_WAVE_SYNC();  // every lane has its samples: the stretch may be overwritten
         STFT_STAMP(2);
         if (ABL != 2) fft16<false>(v);
         STFT_STAMP(3);
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1)  // twiddle, then transposed store: (k1, j) -> k1*16 + (j ^ k1)
             zf[k1 * 16 + (j ^ k1)] = cmul(v[FFT16_OUT(k1)], t256[k1 * 16 + j]);
-        __syncthreads();
+        DSA_WAVE_SYNC();
         STFT_STAMP(4);
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = zf[j * 16 + (i ^ j)];  // lane k1 = j reads A[i][k1]
-        __syncthreads();
+        DSA_WAVE_SYNC();
         STFT_STAMP(5);
         if (ABL != 2) fft16<false>(v);
         STFT_STAMP(6);
 #pragma unroll
         for (int k0 = 0; k0 < 16; ++k0) zf[j + 16 * k0] = v[FFT16_OUT(k0)];  // Z[k1 + 16 k0], natural order
-        __syncthreads();
+        DSA_WAVE_SYNC();
         STFT_STAMP(7);
         // ---- real-FFT split, two bins (k, 256-k) per lane from one pair (Z[k], Z[256-k]) ----
         //   S = a + conj(b), Dd = a - conj(b), Pp = W Dd:
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
             pb[f][1] = z[191 - lane];
             z0[f] = z[0];
         }
-        __syncthreads();
+        DSA_WAVE_SYNC();
         float fm[kFPW] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int f = 0; f < kFPW; ++f) {
@@ -807,7 +811,7 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
                 if (lane == 0) fmax[f] = m;
             }
         }
-        __syncthreads();
+        DSA_WAVE_SYNC();
         STFT_STAMP(8);
         // ---- formatter + coalesced write of the staged tile ----
         const bool plain = !use_floor && fmt == DSA_SPEC_POWER;
