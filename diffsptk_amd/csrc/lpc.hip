@@ -416,6 +416,223 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tuned backward of LinearPredictiveCodingAnalysis for float32 frames, lpc_order 24, 25 <= L <= 512
+// (the adjoint of acorr.py:110-120 + levdur.py:113-127 in one launch).  One wave64 per workgroup
+// owns 64 consecutive frames:
+//   A. lag sums r[0..24] recomputed 4 frames per pass (16 lanes each) exactly as in the forward;
+//   B. one frame per LANE, float64, fully unrolled: the Levinson recursion is re-run and carries a
+//      general right-hand side along (u = (R + eps I)^{-1} abar, by the order-update with the
+//      reversed predictor), then with sbar = Kbar / (2K), v = u - sbar a (because R a = -r_1):
+//        rbar[m] = -sum_{|i-j|=m} v_i a_j  (+ sbar a_m - v_m for m >= 1;  + sbar for m = 0);
+//   C. xbar[l] = sum_m rbar[m] (x[l+m] + x[l-m]), 4 frames per pass, each lane a contiguous run of
+//      samples with the 49-sample window in registers (2 x 625 float64 FMAs per 25 samples), the
+//      result staged through LDS and written back as whole rows.
+// dynamic LDS: in_buf[4][S] floats (24 zeros | frame | zeros) | out_buf[4][16 C] floats |
+//              rbuf[64][25] doubles (r, then rbar) | gbuf[64 * 25] floats (cotangent rows)
+template <int... Is>
+__device__ __forceinline__ void corr_block_fwd(double (&acc)[kLpcM1], const double (&g)[kLpcM1],
+                                               const double (&xw)[2 * kLpcM1 - 1], std::integer_sequence<int, Is...>)
+{
+    // acc[i] += g[m] * xw[i + m]   (Is = 25 i + m)
+    ((acc[Is / kLpcM1] = __builtin_fma(g[Is % kLpcM1], xw[Is / kLpcM1 + Is % kLpcM1], acc[Is / kLpcM1])), ...);
+}
+
+template <int... Is>
+__device__ __forceinline__ void corr_block_rev(double (&acc)[kLpcM1], const double (&g)[kLpcM1],
+                                               const double (&xw)[2 * kLpcM1 - 1], std::integer_sequence<int, Is...>)
+{
+    // acc[i] += g[m] * xw[24 + i - m]   (xw[24 + i] is the lane's sample i)
+    ((acc[Is / kLpcM1] =
+          __builtin_fma(g[Is % kLpcM1], xw[kLpcM1 - 1 + Is / kLpcM1 - Is % kLpcM1], acc[Is / kLpcM1])),
+     ...);
+}
+
+__global__ __launch_bounds__(64, 1) void lpc24_bwd_kernel(const float* __restrict__ gout,
+                                                          const float* __restrict__ x, long F, int L, double eps,
+                                                          float* __restrict__ gx, long total_sc, int S, int So)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* in_buf = reinterpret_cast<float*>(smem_raw);
+    float* out_buf = in_buf + 4 * S;
+    double* rbuf = reinterpret_cast<double*>(out_buf + 4 * So);
+    float* gbuf = reinterpret_cast<float*>(rbuf + 64 * kLpcM1);
+    const int lane = threadIdx.x;
+    const int j = lane & 15, fl = lane >> 4;
+    const int C = (L + 15) >> 4;
+    const int nblk = (C + kLpcM1 - 1) / kLpcM1;
+    const bool vec4 = (L & 3) == 0 && ((((size_t)x) | ((size_t)gx)) & 15) == 0;
+    for (int l = lane; l < 4 * S; l += 64) in_buf[l] = 0.f;  // the pads stay zero for the whole kernel
+
+    auto stage = [&](long frame0, int nvalid) {
+        __syncthreads();
+        for (int fr = 0; fr < nvalid; ++fr) {
+            const float* src = x + (frame0 + fr) * (long)L;
+            float* dst = in_buf + fr * S + (kLpcM1 - 1);
+            if (vec4) {
+                for (int q = lane; q < (L >> 2); q += 64)
+                    reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(src)[q];
+            } else {
+                for (int t = lane; t < L; t += 64) dst[t] = src[t];
+            }
+        }
+        __syncthreads();
+    };
+
+    for (long sc = blockIdx.x; sc < total_sc; sc += gridDim.x) {
+        const long fbase = sc * 64;
+        const int nfr = (int)((F - fbase) < 64 ? (F - fbase) : 64);
+        const int npass = (nfr + 3) >> 2;
+        __syncthreads();
+        for (int q = lane; q < nfr * kLpcM1; q += 64) gbuf[q] = gout[fbase * kLpcM1 + q];
+        // ---- A: lag sums ----
+        for (int p = 0; p < npass; ++p) {
+            const int nvalid = (nfr - 4 * p) < 4 ? (nfr - 4 * p) : 4;
+            stage(fbase + 4 * p, nvalid);
+            double acc[kLpcM1];
+#pragma unroll
+            for (int m = 0; m < kLpcM1; ++m) acc[m] = 0.0;
+            const float* fsrc = in_buf + fl * S + (kLpcM1 - 1);
+            for (int blk = 0; blk < nblk; ++blk) {
+                const int t0 = j * C + blk * kLpcM1;
+                const int own = C - blk * kLpcM1;
+                double xw[2 * kLpcM1 - 1];
+#pragma unroll
+                for (int i = 0; i < 2 * kLpcM1 - 1; ++i) xw[i] = (double)fsrc[t0 + i];
+                if (own >= kLpcM1) {
+                    lag_block(acc, xw, std::make_integer_sequence<int, kLpcM1 * kLpcM1>{});
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kLpcM1; ++i) {
+                        const double li = i < own ? xw[i] : 0.0;
+#pragma unroll
+                        for (int m = 0; m < kLpcM1; ++m) acc[m] = __builtin_fma(li, xw[i + m], acc[m]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < kLpcM1; ++m) {
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) acc[m] += __shfl_xor(acc[m], o, 16);
+            }
+            if (fl < nvalid) {
+                double* rrow = rbuf + (size_t)(4 * p + fl) * kLpcM1;
+#pragma unroll
+                for (int m = 0; m < kLpcM1; ++m)
+                    if ((m & 15) == j) rrow[m] = acc[m];
+            }
+        }
+        __syncthreads();
+        // ---- B: adjoint of the Yule-Walker solve, one frame per lane ----
+        if (lane < nfr) {
+            double r[kLpcM1], a[kLpcM1], u[kLpcM1];
+            double* row = rbuf + (size_t)lane * kLpcM1;
+            const float* go = gbuf + lane * kLpcM1;
+#pragma unroll
+            for (int m = 0; m < kLpcM1; ++m) {
+                r[m] = row[m];
+                a[m] = 0.0;
+                u[m] = 0.0;
+            }
+            double Ecur = r[0] + eps;
+#pragma unroll
+            for (int m = 1; m < kLpcM1; ++m) {
+                // order update of the general solve with the order-(m-1) predictor and its error
+                double d = (double)go[m];
+#pragma unroll
+                for (int q = 1; q < m; ++q) d = __builtin_fma(-r[m - q], u[q], d);
+                const double mu = d / Ecur;
+#pragma unroll
+                for (int q = 1; q < m; ++q) u[q] = __builtin_fma(mu, a[m - q], u[q]);
+                u[m] = mu;
+                // Levinson step (as in the forward kernel)
+                double s = r[m];
+#pragma unroll
+                for (int q = 1; q < m; ++q) s = __builtin_fma(a[q], r[m - q], s);
+                const double kk = -s / Ecur;
+#pragma unroll
+                for (int q = 1; 2 * q <= m; ++q) {
+                    const double aq = a[q], amq = a[m - q];
+                    a[q] = __builtin_fma(kk, amq, aq);
+                    if (q != m - q) a[m - q] = __builtin_fma(kk, aq, amq);
+                }
+                a[m] = kk;
+                Ecur *= (1.0 - kk * kk);
+            }
+            double gsum = r[0];
+#pragma unroll
+            for (int m = 1; m < kLpcM1; ++m) gsum = __builtin_fma(r[m], a[m], gsum);
+            const double sbar = (double)go[0] / (2.0 * sqrt(gsum));
+#pragma unroll
+            for (int m = 1; m < kLpcM1; ++m) u[m] = __builtin_fma(-sbar, a[m], u[m]);  // v
+#pragma unroll
+            for (int m = 0; m < kLpcM1; ++m) {
+                double acc = (m == 0) ? sbar : __builtin_fma(sbar, a[m], -u[m]);
+#pragma unroll
+                for (int i = 1; i + m < kLpcM1; ++i) {
+                    if (m < kLpcM1 - 1) {
+                        acc = __builtin_fma(-u[i], a[i + m], acc);
+                        if (m > 0) acc = __builtin_fma(-u[i + m], a[i], acc);
+                    }
+                }
+                row[m] = acc;
+            }
+        }
+        __syncthreads();
+        // ---- C: adjoint of the lag sums ----
+        for (int p = 0; p < npass; ++p) {
+            const int nvalid = (nfr - 4 * p) < 4 ? (nfr - 4 * p) : 4;
+            stage(fbase + 4 * p, nvalid);
+            double g[kLpcM1];
+            {
+                const double* grow = rbuf + (size_t)(4 * p + (fl < nvalid ? fl : 0)) * kLpcM1;
+#pragma unroll
+                for (int m = 0; m < kLpcM1; ++m) g[m] = grow[m];
+            }
+            const float* fsrc = in_buf + fl * S + (kLpcM1 - 1);
+            float* odst = out_buf + fl * So;
+            for (int blk = 0; blk < nblk; ++blk) {
+                const int t0 = j * C + blk * kLpcM1;
+                const int own = C - blk * kLpcM1;
+                double acc[kLpcM1];
+#pragma unroll
+                for (int i = 0; i < kLpcM1; ++i) acc[i] = 0.0;
+                {
+                    double xw[2 * kLpcM1 - 1];
+#pragma unroll
+                    for (int i = 0; i < 2 * kLpcM1 - 1; ++i) xw[i] = (double)fsrc[t0 + i];
+                    corr_block_fwd(acc, g, xw, std::make_integer_sequence<int, kLpcM1 * kLpcM1>{});
+                }
+                {
+                    double xw[2 * kLpcM1 - 1];
+#pragma unroll
+                    for (int i = 0; i < 2 * kLpcM1 - 1; ++i) xw[i] = (double)fsrc[t0 - (kLpcM1 - 1) + i];
+                    corr_block_rev(acc, g, xw, std::make_integer_sequence<int, kLpcM1 * kLpcM1>{});
+                }
+                if (own >= kLpcM1) {
+#pragma unroll
+                    for (int i = 0; i < kLpcM1; ++i) odst[t0 + i] = (float)acc[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kLpcM1; ++i)
+                        if (i < own) odst[t0 + i] = (float)acc[i];
+                }
+            }
+            __syncthreads();
+            for (int fr = 0; fr < nvalid; ++fr) {
+                float* dst = gx + (fbase + 4 * p + fr) * (long)L;
+                const float* src = out_buf + fr * So;
+                if (vec4) {
+                    for (int q = lane; q < (L >> 2); q += 64)
+                        reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(src)[q];
+                } else {
+                    for (int t = lane; t < L; t += 64) dst[t] = src[t];
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 static int acorr_fwd_impl(const void* x, int64_t F, int L, int M, int fmt, void* r, hipStream_t st)
 {
@@ -573,6 +790,18 @@ DSA_EXPORT int dsa_lpc_bwd(const void* gout, const void* x, const void* out, int
 {
     DSA_REQUIRE(L > 0 && M >= 0 && M < L && F >= 0, "lpc_bwd: lpc_order must be less than frame_length");
     if (F == 0) return DSA_OK;
+    if (dtype == DSA_F32 && M == 24 && L >= 25 && L <= 512) {
+        const int C = (L + 15) >> 4, nblk = (C + kLpcM1 - 1) / kLpcM1;
+        const int S = (2 * (kLpcM1 - 1) + 15 * C + kLpcM1 * nblk + 4 + 3) & ~3;  // 24 | reach of the last lane | 24
+        const int So = (16 * C + 3) & ~3;
+        size_t lds_t = (size_t)(4 * S + 4 * So) * 4 + 64 * kLpcM1 * (sizeof(double) + sizeof(float));
+        long total_sc = (long)((F + 63) / 64);
+        long grid = 256L * 4;
+        if (grid > total_sc) grid = total_sc;
+        hipLaunchKernelGGL(lpc24_bwd_kernel, dim3((unsigned)grid), dim3(64), lds_t, (hipStream_t)stream,
+                           (const float*)gout, (const float*)x, (long)F, L, eps, (float*)gx, total_sc, S, So);
+        return check_launch("lpc24_bwd");
+    }
     if (dtype == DSA_F32) return lpc_bwd_impl<float>(gout, x, out, F, L, M, eps, gx, (hipStream_t)stream);
     if (dtype == DSA_F64) return lpc_bwd_impl<double>(gout, x, out, F, L, M, eps, gx, (hipStream_t)stream);
     return fail(DSA_ERR_UNSUPPORTED, "lpc_bwd: unsupported dtype%s");

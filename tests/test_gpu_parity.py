@@ -618,6 +618,30 @@ def test_lpc_backward_golden(golden):
         assert np.abs(host(x.grad) - ref).max() < rel * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("L,Fr", [(400, 131), (25, 7), (26, 64), (127, 65), (401, 70), (512, 129)])
+def test_lpc_tuned_backward_matches_float64_path(L, Fr):
+    """The float32 order-24 backward (one fused kernel: lag sums, the Yule-Walker adjoint by a
+    Levinson order-update, the lag-sum adjoint) against the float64 generic kernels on the same
+    float32-valued frames; ragged frame counts and every frame-length class of the kernel."""
+    gen = torch.Generator().manual_seed(L * 1000 + Fr)
+    x32 = torch.randn(Fr, L, generator=gen)
+    gy = torch.randn(Fr, 25, generator=gen)
+    grads = {}
+    for dt in (torch.float32, torch.float64):
+        x = x32.to(DEV, dt).requires_grad_(True)
+        a = dsp.LPC(L, 24, eps=1e-5, dtype=dt, device=DEV)(x)
+        a.backward(gy.to(DEV, dt))
+        if dt == torch.float32:  # the autograd thread has its own last-kernel slot: call the entry point here too
+            gyd, gx2 = gy.to(DEV), torch.empty(Fr, L, device=DEV)
+            ops._call("dsa_lpc_bwd", ops._p(gyd), ops._p(x.detach()), ops._p(a.detach()), Fr, L, 24, 1e-5,
+                      ops._dtype_code(gx2), ops._p(gx2), ops._stream())
+            assert _lib.last_kernel() == "lpc24_bwd"
+            assert torch.equal(gx2, x.grad)
+        grads[dt] = host(x.grad).astype(np.float64)
+    ref = grads[torch.float64]
+    assert np.abs(grads[torch.float32] - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
 def test_lpc_config4_batch1024_sampled():
     x = torch.randn(1024, 16000, generator=torch.Generator().manual_seed(0))
     xd = x.to(DEV)
