@@ -11,7 +11,18 @@
 // frequency-transform kernel (dsa_freqt_fwd).
 #include "common.h"
 
+#include <cstdlib>
+#include <mutex>
+#include <type_traits>
+
 namespace dsa {
+
+static bool env_flag(const char* name)
+{
+    const char* v = std::getenv(name);
+    return v && v[0] && v[0] != '0';
+}
+
 
 constexpr int kFbFrames = 4;   // frames per wave and pass
 constexpr int kFbMaxWaves = 16;  // waves per workgroup (as many as the LDS tiles next to the H copy allow)
@@ -185,6 +196,340 @@ __global__ __launch_bounds__(kFbMaxWaves * 64) void fbank_bwd_kernel(const T* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Matrix-core forward for float32 spectra and C <= 48 channels (the MFCC / log-mel front end of
+// SURVEY 8(f) row 1): s H is a 16 x K by K x 48 product per tile of 16 frames on
+// v_mfma_f32_16x16x4_f32 (float32 products, float32 accumulation: no precision is given up).
+//   * the 16 x K tile is one contiguous stretch of the spectrum: copied to LDS with 16-byte loads,
+//     one tile AHEAD of the products (the loads of tile n+1 are in flight while tile n multiplies);
+//   * product step s pairs the 4 k-slots of the instruction with the bins
+//     64 (s / 16) + s % 16 + 16 kq: with the odd row stride K = 257 the 64 operand reads of a step
+//     fall on 32 distinct banks twice (the minimum);
+//   * H is expanded ONCE per workgroup into a per-channel-tile PROGRAM in LDS: the list of steps whose
+//     4 x 16 block of H is not all zero (the triangular filters leave more than half of the blocks
+//     empty; discovered from the data -- a dense H simply lists every step) and, per listed step, the
+//     B operand in lane order (zero beyond K and C).  The inner loop is branch-free: 8 entries per
+//     batch, the next batch's bin offsets fetched while this batch multiplies;
+//   * with use_power and a free column (C < 48) the log-energy weights w_k / (2 (K - 1)) ride as one
+//     more column of H, so E falls out of the same accumulators; otherwise one pass of operand reads
+//     sums the energy on the vector unit;
+//   * epilogue: floor, glog, 64-byte runs of 16 channels per frame straight from the accumulators.
+constexpr int kFmRows = 16, kFmWaves = 4, kFmPre = 20, kFmU = 8;  // K <= 320
+#ifdef DSA_FBANK_TIMING
+__device__ unsigned long long g_fbank_stamps[16];
+#define FB_STAMP(n) do { if (blockIdx.x == 0 && threadIdx.x == 0 && tl == stride) g_fbank_stamps[n] = __builtin_readcyclecounter(); } while (0)
+#define FB_STAMP0(n) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_fbank_stamps[n] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FB_STAMP(n)
+#define FB_STAMP0(n)
+#endif
+typedef float fm_f4 __attribute__((ext_vector_type(4)));
+
+template <int NQ>   // 16-byte loads per lane and tile: ceil(4 K / 64) rounded up to one of 5, 9, 17, 20
+__global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const float* __restrict__ x, long F, int K,
+                                                                      const float* __restrict__ H, int C, float floor,
+                                                                      float gamma, int use_power, float* __restrict__ y,
+                                                                      float* __restrict__ E, int nsteps, int cap,
+                                                                      int tile_floats, int vec4)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
+    float* himg = reinterpret_cast<float*>(fb_smem);                         // [3][cap][64]
+    int* prog = reinterpret_cast<int*>(himg + (size_t)3 * cap * 64);         // [3][cap]: bin offset of k-slot 0, or -1
+    int* cnt = prog + 3 * cap;                                               // [8]: entries per tile | unchecked entries per tile
+    unsigned* smask = reinterpret_cast<unsigned*>(cnt + 8);                  // [nsteps rounded]
+    float* tiles = reinterpret_cast<float*>(smask + ((nsteps + 3) & ~3));
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, kq = lane >> 4;
+    FB_STAMP0(0);
+    float* tile = tiles + (size_t)wave * tile_floats;
+    const float* arow = tile + i * K;
+    const float* arow_kq = arow + (kq << 4);
+    const int klim = K - (kq << 4);   // k-slot kq of an entry is inside the row iff off < klim
+    const long ntiles = (F + kFmRows - 1) / kFmRows;
+    const long stride = (long)gridDim.x * kFmWaves;
+    const int n4 = (kFmRows * K) >> 2;  // 16 K floats = 4 K float4
+    fm_f4 pre[NQ];
+    auto issue = [&](long tl) {  // 16-byte loads of a full tile into registers (no wait here)
+        if (tl < ntiles && vec4 && (tl + 1) * kFmRows <= F) {
+            const fm_f4* src = reinterpret_cast<const fm_f4*>(x + tl * (long)kFmRows * K);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)   // no predicate, no branch (index clamped): either makes the compiler wait per load
+                pre[q] = src[q * 64 + lane < n4 ? q * 64 + lane : n4 - 1];   // (nontemporal loads: 10x slower to issue)
+        }
+    };
+    long tl = (long)blockIdx.x * kFmWaves + wave;
+    issue(tl);   // the first tile is in flight while the program is built
+    FB_STAMP0(7);
+    const int ecol = (use_power && C < 48 && E) ? C : -1;
+    const bool yvec4 = (((size_t)y) & 15) == 0;   // every tile starts 64 C bytes further
+    const float ew = 1.f / (float)(2 * (K - 1));
+    {   // H -> LDS (the tile buffers are free until the first tile is staged): the program is built from LDS
+        float* Hs = tiles;
+        const int nh = K * C;
+        if ((((size_t)H) & 15) == 0) {
+            const int nh4 = nh >> 2;
+#pragma unroll 4
+            for (int q = threadIdx.x; q < nh4; q += kFmWaves * 64)
+                reinterpret_cast<fm_f4*>(Hs)[q] = reinterpret_cast<const fm_f4*>(H)[q];
+            for (int q = (nh4 << 2) + threadIdx.x; q < nh; q += kFmWaves * 64) Hs[q] = H[q];
+        } else {
+#pragma unroll 4
+            for (int q = threadIdx.x; q < nh; q += kFmWaves * 64) Hs[q] = H[q];
+        }
+    }
+    __syncthreads();
+    FB_STAMP0(8);
+    const float* Hl = tiles;
+    auto hval = [&](int bin, int ch) -> float {   // branch-free (clamped read + selects): lets the reads of a batch overlap
+        const float h = Hl[(bin < K ? bin : K - 1) * C + (ch < C ? ch : C - 1)];
+        const float e = (ch == ecol) ? ((bin == 0 || bin == K - 1) ? ew : 2.f * ew) : 0.f;   // fbank.py:319-320
+        return bin < K ? (ch < C ? h : e) : 0.f;
+    };
+    for (int s0 = wave * 4; s0 < nsteps; s0 += kFmWaves * 4) {   // 4 steps x 3 channel tiles per wave and round
+        float v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + u;
+            const int bin = s < nsteps ? ((s >> 4) << 6) + (s & 15) + (kq << 4) : K;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) v[u][t] = hval(bin, 16 * t + i);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned m = 0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                if (__ballot(v[u][t] != 0.f) != 0ull) m |= 1u << t;
+            if (lane == 0 && s0 + u < nsteps) smask[s0 + u] = m;
+        }
+    }
+    __syncthreads();
+    FB_STAMP0(9);
+    if (wave < 3) {   // wave t compacts the step list of channel tile t (ballot + prefix count)
+        const int t = wave;
+        int n = 0, nfull = 0;
+        for (int s0 = 0; s0 < nsteps; s0 += 64) {
+            const int s = s0 + lane;
+            const bool bit = s < nsteps && ((smask[s < nsteps ? s : 0] >> t) & 1u);
+            const unsigned long long bits = __ballot(bit);
+            const int off = ((s >> 4) << 6) + (s & 15);
+            if (bit) prog[t * cap + n + __popcll(bits & ((1ull << lane) - 1ull))] = off;
+            n += __popcll(bits);
+            nfull += __popcll(__ballot(bit && off + 48 < K));   // a prefix of the list (offsets ascend)
+        }
+        for (int e = n + lane; e < cap; e += 64) prog[t * cap + e] = -1;   // batch padding and the read-ahead region
+        if (lane == 0) {
+            cnt[t] = (n + kFmU - 1) / kFmU * kFmU;
+            cnt[4 + t] = nfull / kFmU * kFmU;   // whole batches whose 4 k-slots all lie inside the row: no range checks
+        }
+    }
+    __syncthreads();
+    FB_STAMP0(10);
+    for (int t = 0; t < 3; ++t) {
+        const int n = cnt[t];   // a multiple of kFmU = 8
+        for (int e0 = wave * 8; e0 < n; e0 += kFmWaves * 8) {
+            int off[8];
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) off[u] = prog[t * cap + e0 + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = hval(off[u] >= 0 ? off[u] + (kq << 4) : K, 16 * t + i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) himg[(size_t)(t * cap + e0 + u) * 64 + lane] = v[u];
+        }
+    }
+    __syncthreads();
+    FB_STAMP0(11);
+    int n_t[3], nf_t[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        n_t[t] = __builtin_amdgcn_readfirstlane(cnt[t]);
+        nf_t[t] = __builtin_amdgcn_readfirstlane(cnt[4 + t]);
+    }
+
+    FB_STAMP0(1);
+    for (; tl < ntiles; tl += stride) {
+        const long f0 = tl * kFmRows;
+        FB_STAMP(2);
+        __builtin_amdgcn_wave_barrier();
+        if (vec4 && f0 + kFmRows <= F) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (q * 64 + lane < n4) {
+                    fm_f4 v = pre[q];
+                    if (!use_power) v = fm_f4{__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y), __builtin_amdgcn_sqrtf(v.z), __builtin_amdgcn_sqrtf(v.w)};  // fbank.py:315 (v_sqrt_f32: 1 ulp)
+                    reinterpret_cast<fm_f4*>(tile)[q * 64 + lane] = v;
+                }
+        } else {  // ragged last tile or unaligned spectrum: element loads, missing rows read as 1
+            const long have = (F - f0 < kFmRows ? F - f0 : kFmRows) * (long)K;
+            for (int e = lane; e < kFmRows * K; e += 64) {
+                const float v = e < have ? x[f0 * K + e] : 1.f;
+                tile[e] = use_power ? v : __builtin_amdgcn_sqrtf(v);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        FB_STAMP(3);
+        issue(tl + stride);
+        FB_STAMP(4);
+        fm_f4 acc[3][2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t][0] = acc[t][1] = fm_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int* pg = prog + t * cap;
+            const float* hb = himg + (size_t)t * cap * 64 + lane;
+            // float32 MFMA and the vector ALU share one datapath on this chip: every vector instruction in this
+            // loop costs matrix time, so the common case (all 4 k-slots inside the row) is one address add per
+            // product and the range-checked form only runs for the last, partial block of bins.
+            // Software pipeline: batch n+1's operand reads are issued before batch n's products, batch n+2's bin
+            // offsets before that (the lists are padded with -1 for two batches beyond their end).
+            auto run = [&](int eb, int ee, auto chk) {
+                constexpr bool kCheck = decltype(chk)::value;
+                if (eb >= ee) return;
+                int off[kFmU];
+                float a[kFmU], b[kFmU];
+                auto fetch = [&](int e0) {
+#pragma unroll
+                    for (int u = 0; u < kFmU; ++u) {
+                        if (kCheck) {
+                            const bool ok = (unsigned)off[u] < (unsigned)klim;   // off = -1 wraps to a huge value
+                            const float v = arow_kq[ok ? off[u] : 0];
+                            a[u] = ok ? v : 0.f;
+                        } else {
+                            a[u] = arow_kq[off[u]];
+                        }
+                        b[u] = hb[(size_t)(e0 + u) * 64];
+                    }
+                };
+#pragma unroll
+                for (int u = 0; u < kFmU; ++u) off[u] = pg[eb + u];
+                fetch(eb);
+#pragma unroll
+                for (int u = 0; u < kFmU; ++u) off[u] = pg[eb + kFmU + u];
+                asm volatile("" ::: "memory");
+                for (int e0 = eb; e0 < ee; e0 += kFmU) {
+                    float ac[kFmU], bc[kFmU];
+#pragma unroll
+                    for (int u = 0; u < kFmU; ++u) {
+                        ac[u] = a[u];
+                        bc[u] = b[u];
+                    }
+                    fetch(e0 + kFmU);
+#pragma unroll
+                    for (int u = 0; u < kFmU; ++u) off[u] = pg[e0 + 2 * kFmU + u];
+                    asm volatile("" ::: "memory");   // the reads above stay above the products (the scheduler sinks them otherwise)
+#pragma unroll
+                    for (int u = 0; u < kFmU; ++u)
+                        acc[t][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], bc[u], acc[t][u & 1], 0, 0, 0);
+                }
+            };
+            run(0, nf_t[t], std::false_type{});
+            run(nf_t[t], n_t[t], std::true_type{});
+        }
+        FB_STAMP(5);
+        float es = 0.f;
+        if (E && ecol < 0) {   // energy on the vector unit: every bin of the row once
+#pragma unroll 8
+            for (int s = 0; s < nsteps; ++s) {
+                const int bin = ((s >> 4) << 6) + (s & 15) + (kq << 4);
+                const float a = bin < K ? arow[bin < K ? bin : 0] : 0.f;
+                const float w = (bin == 0 || bin == K - 1) ? 1.f : 2.f;
+                es += use_power ? w * a : w * a * a;
+            }
+            es += __shfl_xor(es, 16);
+            es += __shfl_xor(es, 32);
+        }
+        FB_STAMP(6);
+#ifdef FB_DIRECT_STORE
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const fm_f4 d = acc[t][0] + acc[t][1];
+            const int ch = 16 * t + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long f = f0 + 4 * kq + r;
+                if (f < F) {
+                    if (ch < C) {
+                        const float v = d[r] > floor ? d[r] : floor;
+                        y[f * C + ch] = glog_fwd(v, gamma);
+                    } else if (ch == ecol) {
+                        E[f] = dsa_log(d[r]);
+                    }
+                }
+            }
+        }
+        if (E && ecol < 0 && lane < kFmRows && f0 + lane < F) E[f0 + lane] = dsa_log(es * ew);
+        continue;
+#endif
+        // the 16 x C results are one contiguous stretch of y: through the (now free) tile buffer, 16-byte stores
+        __builtin_amdgcn_wave_barrier();
+        float* ost = tile;                      // [16][C]
+        float* est = tile + kFmRows * C;        // [16]
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const fm_f4 d = acc[t][0] + acc[t][1];
+            const int ch = 16 * t + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int fr = 4 * kq + r;
+                if (ch < C) {
+                    const float v = d[r] > floor ? d[r] : floor;                    // fbank.py:317
+                    ost[fr * C + ch] = glog_fwd(v, gamma);
+                } else if (ch == ecol) {
+                    est[fr] = dsa_log(d[r]);                                        // fbank.py:320
+                }
+            }
+        }
+        if (E && ecol < 0 && lane < kFmRows) est[lane] = dsa_log(es * ew);
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int rows = (int)(F - f0 < kFmRows ? F - f0 : kFmRows);
+            const int n = rows * C;
+            float* dst = y + f0 * C;
+            if (yvec4) {
+                for (int q = lane; q < (n >> 2); q += 64) reinterpret_cast<fm_f4*>(dst)[q] = reinterpret_cast<const fm_f4*>(ost)[q];
+                for (int q = (n & ~3) + lane; q < n; q += 64) dst[q] = ost[q];
+            } else {
+                for (int q = lane; q < n; q += 64) dst[q] = ost[q];
+            }
+            if (E && lane < rows) E[f0 + lane] = est[lane];
+        }
+    }
+}
+
+static int fbank_mfma_launch(const void* x, int64_t F, int K, const void* H, int C, double floor, double gamma,
+                             int use_power, void* y, void* E, hipStream_t st)
+{
+    const int nsteps = 16 * (K / 64) + ((K % 64) < 16 ? (K % 64) : 16);
+    const int tile_floats = (kFmRows * K + 3) & ~3;
+    const int cap = ((nsteps + kFmU - 1) / kFmU + 3) * kFmU;   // every list padded to a batch, plus the read-ahead batches
+    const size_t lds = ((size_t)3 * cap * 64 + 3 * cap + 8 + ((nsteps + 3) & ~3) + (size_t)kFmWaves * tile_floats) * 4;
+    const long ntiles = (long)((F + kFmRows - 1) / kFmRows);
+    long blocks = (ntiles + kFmWaves - 1) / kFmWaves;
+    if (blocks > 256) blocks = 256;
+    const int vec4 = (((size_t)x) & 15) == 0;
+    const int nq = (4 * K + 63) / 64;
+#define DSA_FM_LAUNCH(NQ)                                                                                              \
+    do {                                                                                                               \
+        static std::once_flag once;                                                                                    \
+        static bool attr_ok = false;                                                                                   \
+        std::call_once(once, [] {                                                                                      \
+            attr_ok = hipFuncSetAttribute((const void*)fbank_mfma_fwd_kernel<NQ>,                                      \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;       \
+        });                                                                                                            \
+        if (!attr_ok) return fail(DSA_ERR_LAUNCH, "fbank: cannot reserve LDS for the operand images%s");              \
+        hipLaunchKernelGGL(fbank_mfma_fwd_kernel<NQ>, dim3((unsigned)blocks), dim3(kFmWaves * 64), lds, st,            \
+                           (const float*)x, (long)F, K, (const float*)H, C, (float)floor, (float)gamma, use_power,     \
+                           (float*)y, (float*)E, nsteps, cap, tile_floats, vec4);                                      \
+    } while (0)
+    if (nq <= 5) DSA_FM_LAUNCH(5);
+    else if (nq <= 9) DSA_FM_LAUNCH(9);
+    else if (nq <= 17) DSA_FM_LAUNCH(17);
+    else DSA_FM_LAUNCH(20);
+#undef DSA_FM_LAUNCH
+    return check_launch("fbank_mfma_fwd");
+}
+
 template <typename T>
 static int fbank_launch(bool bwd, const void* gy, const void* gE, const void* x, int64_t F, int K, const void* H, int C,
                         double floor, double gamma, int use_power, void* y, void* E, void* gx, hipStream_t st)
@@ -247,6 +592,8 @@ DSA_EXPORT int dsa_fbank_fwd(const void* x, int64_t F, int32_t K, const void* H,
     DSA_REQUIRE(F >= 0 && K >= 2 && C >= 1, "fbank: sizes must be positive");
     DSA_REQUIRE(floor > 0 && gamma >= -1 && gamma <= 1, "fbank: floor must be positive and gamma in [-1, 1]");
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSA_F32 && C <= 48 && K <= 16 * kFmPre && K > C && F > 0 && !env_flag("DSA_FBANK_GENERIC"))
+        return fbank_mfma_launch(x, F, K, H, C, floor, gamma, use_power, y, E, st);
     if (dtype == DSA_F32) return fbank_launch<float>(false, nullptr, nullptr, x, F, K, H, C, floor, gamma, use_power, y, E, nullptr, st);
     if (dtype == DSA_F64) return fbank_launch<double>(false, nullptr, nullptr, x, F, K, H, C, floor, gamma, use_power, y, E, nullptr, st);
     return fail(DSA_ERR_UNSUPPORTED, "fbank: unsupported dtype%s");

@@ -695,7 +695,7 @@ def test_fbank_mfcc_golden_forward_backward(golden, name, dt):
     X = dev(gw["stft_power_f64"], dt)
     rt, at = (1e-5, 1e-8) if dt == torch.float64 else (2e-4, 2e-4)
     y, E = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, out_format="y,E", device=DEV, dtype=dt)(X)
-    assert _lib.last_kernel() == "fbank_fwd"
+    assert _lib.last_kernel() == ("fbank_mfma_fwd" if dt == torch.float32 else "fbank_fwd")
     close(host(y), g[f"fbank_y_{name}"], rt, at)
     close(host(E), g[f"fbank_E_{name}"], rt, at)
     fbp = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=80, sample_rate=16000, f_min=50, f_max=7600, floor=1e-3,
@@ -743,6 +743,53 @@ def tables_H(L, C, sr, kw):
     from diffsptk_amd.utils import tables
 
     return tables.fbank_matrix(L, C, sr, 0.0, None, kw.get("scale", "htk"), kw.get("erb_factor"))
+
+
+@pytest.mark.parametrize("K,C,Fr,use_power,dense", [(257, 40, 1000, True, False), (257, 40, 37, False, False),
+                                                      (257, 48, 16, True, True), (129, 24, 333, False, False),
+                                                      (320, 12, 50, True, True), (33, 7, 5, True, False),
+                                                      (65, 1, 130, False, True)])
+def test_fbank_matrix_core_forward_matches_float64(K, C, Fr, use_power, dense, monkeypatch):
+    """The float32 matrix-core filter bank (16-frame tiles on v_mfma_f32_16x16x4_f32, empty blocks of the
+    triangular H skipped) against the float64 generic kernel and the float32 generic kernel: ragged frame
+    counts, spectra of every block class (K % 64 in {1, 33, 0, 1}), dense matrices, a spectrum pointer that
+    is not 16-byte aligned, and an Inf bin that must stay inside its own frame."""
+    from diffsptk_amd.utils import tables
+
+    gen = torch.Generator().manual_seed(K * 100 + C)
+    x = (torch.rand(Fr + 1, K, generator=gen) * 10 + 1e-3) ** 3
+    if dense:
+        H = torch.rand(K, C, generator=gen).double()
+    else:
+        H = torch.from_numpy(np.asarray(tables.fbank_matrix(2 * (K - 1), C, 16000, 0.0, None, "htk", None))).double()
+    outs = {}
+    for key, dt, generic, off in (("f64", torch.float64, False, 0), ("mfma", torch.float32, False, 0),
+                                  ("generic", torch.float32, True, 0), ("unaligned", torch.float32, False, 1)):
+        if generic:
+            monkeypatch.setenv("DSA_FBANK_GENERIC", "1")
+        else:
+            monkeypatch.delenv("DSA_FBANK_GENERIC", raising=False)
+        xd = x.to(DEV, dt)[off:off + Fr]          # off = 1: the view starts K * 4 bytes into the buffer
+        y, E = ops.FbankFn.apply(xd, H.to(DEV, dt), 1e-5, 0.0, use_power)
+        want = "fbank_fwd" if (generic or dt == torch.float64) else "fbank_mfma_fwd"
+        assert _lib.last_kernel() == want
+        outs[key] = (host(y).astype(np.float64), host(E).astype(np.float64))
+    ref_y, ref_E = outs["f64"]
+    for key in ("mfma", "generic"):
+        close(outs[key][0], ref_y, 2e-5, 2e-5)
+        close(outs[key][1], ref_E, 2e-5, 2e-5)
+    xr = x.to(DEV)[1:1 + Fr].double()
+    yr, Er = ops.FbankFn.apply(xr, H.to(DEV), 1e-5, 0.0, use_power)
+    close(outs["unaligned"][0], host(yr), 2e-5, 2e-5)
+    close(outs["unaligned"][1], host(Er), 2e-5, 2e-5)
+    monkeypatch.delenv("DSA_FBANK_GENERIC", raising=False)
+    xi = x.to(DEV)[:Fr].clone()
+    xi[Fr // 2, K // 3] = float("inf")
+    yi, Ei = ops.FbankFn.apply(xi, H.float().to(DEV), 1e-5, 0.0, use_power)
+    keep = np.arange(Fr) != Fr // 2
+    close(host(yi)[keep], outs["mfma"][0][keep], 1e-6, 1e-6)
+    close(host(Ei)[keep], outs["mfma"][1][keep], 1e-6, 1e-6)
+    assert not np.isfinite(host(Ei)[Fr // 2]).all()
 
 
 def test_stft_fbank_chain_full_size():
