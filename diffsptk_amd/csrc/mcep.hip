@@ -57,6 +57,68 @@ __global__ void matmul_rows_t_kernel(const T* __restrict__ g, long F, int L1, co
     }
 }
 
+// out(F,Lout) = c(F,Lin) @ M for a SMALL matrix (M and a 64-row tile of c fit in LDS): M = A (L1 x L2,
+// TRANS = false) or A^T (TRANS = true).  Persistent workgroups of 256 threads; per tile of 64 rows the
+// rows are copied to LDS as one contiguous stretch (row stride Lin + 1: conflict-free), and a thread owns
+// output column i for 4 consecutive rows (one read of M feeds 4 FMAs; the rows' reads are broadcasts).
+// The one-workgroup-per-row kernels above launch F tiny workgroups: 0.10 ms for the 40 x 13 DCT of 204 800
+// frames against 0.02 ms here.
+constexpr int kMrRows = 64;
+
+template <typename T, bool TRANS>
+__global__ __launch_bounds__(256) void matmul_rows_lds_kernel(const T* __restrict__ c, long F, int Lin,
+                                                              const T* __restrict__ A, int L1, int L2, int Lout,
+                                                              T* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Ms = reinterpret_cast<T*>(smem_raw);   // [Lin][Lout]
+    T* cs = Ms + (size_t)Lin * Lout;          // [64][Lin + 1]
+    const int S = Lin + 1;
+    for (int q = threadIdx.x; q < Lin * Lout; q += 256) {
+        const int j = q / Lout, i = q - j * Lout;
+        Ms[q] = TRANS ? A[(long)i * L2 + j] : A[(long)j * L2 + i];
+    }
+    const long ntiles = (F + kMrRows - 1) / kMrRows;
+    const int items = Lout * (kMrRows / 4);
+    for (long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long f0 = tl * kMrRows;
+        const int rows = (int)(F - f0 < kMrRows ? F - f0 : kMrRows);
+        __syncthreads();
+        for (int q = threadIdx.x; q < kMrRows * Lin; q += 256) {
+            const int r = q / Lin, j = q - r * Lin;
+            cs[r * S + j] = r < rows ? c[f0 * Lin + q] : T(0);
+        }
+        __syncthreads();
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int rg = it / Lout, i = it - rg * Lout;
+            const T* c0 = cs + (4 * rg) * S;
+            T acc[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll 4
+            for (int j = 0; j < Lin; ++j) {
+                const T a = Ms[j * Lout + i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += c0[q * S + j] * a;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (4 * rg + q < rows) out[(f0 + 4 * rg + q) * Lout + i] = acc[q];
+        }
+    }
+}
+
+template <typename T, bool TRANS>
+static bool matmul_rows_lds_launch(const void* c, int64_t F, int Lin, const void* A, int L1, int L2, int Lout, void* out,
+                                   hipStream_t st)
+{
+    const size_t lds = sizeof(T) * ((size_t)Lin * Lout + (size_t)kMrRows * (Lin + 1));
+    if (lds > 48 * 1024 || F < 4 * kMrRows) return false;
+    long blocks = (long)((F + kMrRows - 1) / kMrRows);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL((matmul_rows_lds_kernel<T, TRANS>), dim3((unsigned)blocks), dim3(256), lds, st, (const T*)c, (long)F,
+                       Lin, (const T*)A, L1, L2, Lout, (T*)out);
+    return true;
+}
+
 // Reduce the (M1 x M1) symmetric positive definite system held in LDS as an augmented
 // row-major matrix Aug[M1][W] (W - M1 right-hand sides) to diagonal form by Gauss-Jordan
 // elimination without pivoting; afterwards x_c[i] = Aug[i][M1 + c] / Aug[i][i].
@@ -288,6 +350,9 @@ DSA_EXPORT int dsa_freqt_fwd(const void* c, int64_t F, int32_t L1, const void* A
     DSA_REQUIRE(L1 > 0 && L2 > 0 && F >= 0, "freqt: sizes must be positive");
     if (F == 0) return DSA_OK;
     hipStream_t st = (hipStream_t)stream;
+    if ((dtype == DSA_F32 && matmul_rows_lds_launch<float, false>(c, F, L1, A, L1, L2, L2, out, st)) ||
+        (dtype == DSA_F64 && matmul_rows_lds_launch<double, false>(c, F, L1, A, L1, L2, L2, out, st)))
+        return check_launch("freqt_lds_fwd");
     int threads = L2 >= 192 ? 256 : (L2 >= 96 ? 128 : 64);
     if (dtype == DSA_F32)
         hipLaunchKernelGGL((matmul_rows_kernel<float>), dim3((unsigned)F), dim3(threads), sizeof(float) * L1, st,
@@ -306,6 +371,9 @@ DSA_EXPORT int dsa_freqt_bwd(const void* gout, int64_t F, int32_t L1, const void
     DSA_REQUIRE(L1 > 0 && L2 > 0 && F >= 0, "freqt_bwd: sizes must be positive");
     if (F == 0) return DSA_OK;
     hipStream_t st = (hipStream_t)stream;
+    if ((dtype == DSA_F32 && matmul_rows_lds_launch<float, true>(gout, F, L2, A, L1, L2, L1, gc, st)) ||
+        (dtype == DSA_F64 && matmul_rows_lds_launch<double, true>(gout, F, L2, A, L1, L2, L1, gc, st)))
+        return check_launch("freqt_lds_bwd");
     int threads = L1 >= 192 ? 256 : (L1 >= 96 ? 128 : 64);
     if (dtype == DSA_F32)
         hipLaunchKernelGGL((matmul_rows_t_kernel<float>), dim3((unsigned)F), dim3(threads), sizeof(float) * L2, st,
