@@ -284,8 +284,9 @@ __global__ void row_dft_bwd_kernel(const T* __restrict__ x, long Tlen, long N, i
     __syncthreads();
     for (int l = threadIdx.x; l < L; l += blockDim.x) xc[l] -= mean;
     __syncthreads();
+    const bool inverse_cot = out_kind == 1 && fmt == DSA_SPEC_COMPLEX_INV;
     const bool complex_out = (out_kind == 0 && fmt == DSA_FFTR_COMPLEX) ||
-                             (out_kind == 1 && fmt == DSA_SPEC_COMPLEX);
+                             (out_kind == 1 && fmt == DSA_SPEC_COMPLEX) || inverse_cot;
     T smax = 0;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         T re = 0, im = 0;
@@ -301,6 +302,11 @@ __global__ void row_dft_bwd_kernel(const T* __restrict__ x, long Tlen, long N, i
         if (complex_out) {
             cr = gy[(f * K + k) * 2];
             ci = gy[(f * K + k) * 2 + 1];
+            if (inverse_cot) {   // irfft weights c_k / nfft
+                const T ck = ((k == 0 || k == K - 1) ? T(1) : T(2)) / T(nfft);
+                cr *= ck;
+                ci *= ck;
+            }
         } else if (out_kind == 0) {
             T g = gy[f * K + k];
             switch (fmt) {
@@ -914,7 +920,11 @@ __global__ __launch_bounds__(64, 3) void stft512_bwd_kernel(
     const cf twB = cf{twiddle[2 * (lane + 64)], twiddle[2 * (lane + 64) + 1]};
     const float inv_L = 1.f / (float)L;
     const int K = 257;
-    const bool complex_out = fmt == DSA_SPEC_COMPLEX;
+    const bool complex_out = fmt == DSA_SPEC_COMPLEX || fmt == DSA_SPEC_COMPLEX_INV;
+    // complex cotangent: the adjoint takes g / 2 (g at the two real-valued bins); the inverse transform's
+    // weights c_k / 512 on top of that make it g / 512 everywhere
+    const float cot_scale = fmt == DSA_SPEC_COMPLEX_INV ? 1.f / 512.f : 0.5f;
+    const float cot_edge = fmt == DSA_SPEC_COMPLEX_INV ? 1.f : 2.f;
     cf* zf = zbuf + fl * 256;
     const float2* gy2 = reinterpret_cast<const float2*>(gy);
 
@@ -1018,8 +1028,8 @@ __global__ __launch_bounds__(64, 3) void stft512_bwd_kernel(
                 if (complex_out) {
                     const float2 g1 = fv ? gy2[out0 + f * K + k] : make_float2(0.f, 0.f);
                     const float2 g2 = fv ? gy2[out0 + f * K + 256 - k] : make_float2(0.f, 0.f);
-                    S1 = cf{0.5f * g1.x, 0.5f * g1.y};
-                    S2 = cf{0.5f * g2.x, 0.5f * g2.y};
+                    S1 = cf{cot_scale * g1.x, cot_scale * g1.y};
+                    S2 = cf{cot_scale * g2.x, cot_scale * g2.y};
                 } else {
                     const float s1 = X1.re * X1.re + X1.im * X1.im + eps;
                     const float s2 = X2.re * X2.re + X2.im * X2.im + eps;
@@ -1036,8 +1046,9 @@ __global__ __launch_bounds__(64, 3) void stft512_bwd_kernel(
                 }
                 if (part_i == 0) {
                     // k = 0 pairs with 256: both real-valued bins carry the full (not half) weight
-                    const float s0r = lane == 0 ? 2.f * S1.re : S1.re, s0i = lane == 0 ? 0.f : S1.im;
-                    const float s6r = lane == 0 ? 2.f * S2.re : S2.re, s6i = lane == 0 ? 0.f : S2.im;
+                    const float e0 = complex_out ? cot_edge : 2.f;
+                    const float s0r = lane == 0 ? e0 * S1.re : S1.re, s0i = lane == 0 ? 0.f : S1.im;
+                    const float s6r = lane == 0 ? e0 * S2.re : S2.re, s6i = lane == 0 ? 0.f : S2.im;
                     S1 = cf{s0r, s0i};
                     S2 = cf{s6r, s6i};
                 }
@@ -1532,7 +1543,7 @@ DSA_EXPORT int dsa_stft_bwd(const void* gy, const void* x, int64_t B, int64_t T,
     DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0, "stft_bwd: sizes must be positive");
     DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "stft_bwd: fft_length must be positive even");
     DSA_REQUIRE(pad_mode >= 0 && pad_mode <= 3, "stft_bwd: unknown pad mode");
-    DSA_REQUIRE(out_format >= 0 && out_format <= 4, "stft_bwd: unknown out_format");
+    DSA_REQUIRE(out_format >= 0 && out_format <= 5, "stft_bwd: unknown out_format");
     if (B == 0) return DSA_OK;
     hipStream_t st = (hipStream_t)stream;
     {

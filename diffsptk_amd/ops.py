@@ -419,12 +419,12 @@ class IstftFn(torch.autograd.Function):
         N, K = yr.shape[-3:-1]
         B = yr.numel() // (N * K * 2)
         T, Tc, Nc = _fold_plan(N, L, P, center, out_length)
-        G = _pad_frames(_irfft_scale(yr, fft_length).reshape(B, N, K, 2), N, Nc, 1).contiguous()
+        G = _pad_frames(yr.reshape(B, N, K, 2), N, Nc, 1).contiguous()   # the kernel applies c_k / nfft (format 5)
         x0 = torch.zeros(B, Tc, device=y.device, dtype=yr.dtype)
         num = torch.empty(B, Tc, device=y.device, dtype=yr.dtype)
         with torch.cuda.device(y.device):
             _call("dsa_stft_bwd", _p(G), _p(x0), B, Tc, L, P, fft_length, _p(wc), _p(twiddle), int(center), 0, 0, 0.0, 0,
-                  0.0, 4, _dtype_code(yr), algo, _p(num), None, _stream())
+                  0.0, 5, _dtype_code(yr), algo, _p(num), None, _stream())
         d = _window_sq_sum(wc, N, Nc, L, P, center, Tc)
         x = _div_rows(num, d)
         ctx.save_for_backward(wc, twiddle, d)

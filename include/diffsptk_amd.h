@@ -47,7 +47,10 @@ enum { DSA_PAD_CONSTANT = 0, DSA_PAD_REFLECT = 1, DSA_PAD_REPLICATE = 2, DSA_PAD
 /* fftr.py:110-121 */
 enum { DSA_FFTR_COMPLEX = 0, DSA_FFTR_REAL = 1, DSA_FFTR_IMAG = 2, DSA_FFTR_AMPLITUDE = 3, DSA_FFTR_POWER = 4 };
 /* spec.py:123-132 (+ complex pass-through of stft.py:211-222) */
-enum { DSA_SPEC_DB = 0, DSA_SPEC_LOGMAG = 1, DSA_SPEC_MAG = 2, DSA_SPEC_POWER = 3, DSA_SPEC_COMPLEX = 4 };
+enum { DSA_SPEC_DB = 0, DSA_SPEC_LOGMAG = 1, DSA_SPEC_MAG = 2, DSA_SPEC_POWER = 3, DSA_SPEC_COMPLEX = 4,
+       /* dsa_stft_bwd only: gy is a complex spectrogram to INVERT (istft.py:186-193): the kernel applies the
+        * inverse real transform's weights c_k / nfft (c = 1 at k = 0 and nfft/2, else 2) while loading it */
+       DSA_SPEC_COMPLEX_INV = 5 };
 /* acorr.py:94-107 */
 enum { DSA_ACORR_NAIVE = 0, DSA_ACORR_NORMALIZED = 1, DSA_ACORR_BIASED = 2, DSA_ACORR_UNBIASED = 3 };
 /* kernel selection: AUTO picks the tuned gfx950 kernel when the configuration allows it */
