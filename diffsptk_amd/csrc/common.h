@@ -127,6 +127,10 @@ __device__ __forceinline__ float dsa_pow(float a, float b) { return powf(a, b); 
 __device__ __forceinline__ double dsa_pow(double a, double b) { return pow(a, b); }
 __device__ __forceinline__ float dsa_sqrt(float v) { return sqrtf(v); }
 __device__ __forceinline__ double dsa_sqrt(double v) { return sqrt(v); }
+__device__ __forceinline__ float dsa_cos(float v) { return cosf(v); }
+__device__ __forceinline__ double dsa_cos(double v) { return cos(v); }
+__device__ __forceinline__ float dsa_sin(float v) { return sinf(v); }
+__device__ __forceinline__ double dsa_sin(double v) { return sin(v); }
 __device__ __forceinline__ float dsa_log10(float v) { return log10f(v); }
 __device__ __forceinline__ double dsa_log10(double v) { return log10(v); }
 

@@ -1187,6 +1187,51 @@ __global__ void div_rows_kernel(const T* __restrict__ x, long B, long Tlen, cons
     for (long b = blockIdx.y; b < B; b += gridDim.y) out[b * Tlen + t] = x[b * Tlen + t] * r;
 }
 
+// One Griffin-Lim phase update (griffin.py:263-282), element-wise over (B, N, K) complex bins:
+//   t' = t (first) or (1 - gamma) d_prev + gamma t;   diff = t' - t_prev;   c = t' + alpha diff;   d = t' + beta diff;
+//   z = sqrt(y + 1e-16) * c / (|c| + eps);   t_prev <- t',  d_prev <- d.
+// t:(B, Nt, K) is the STFT of the previous estimate (Nt >= N frames; the extra ones are dropped, griffin.py:270);
+// t == nullptr initialises: z = sqrt(y + 1e-16) * exp(i phase) (phase == nullptr: zeros).
+template <typename T>
+__global__ void griffin_update_kernel(const T* __restrict__ t, long B, long Nt, long N, int K, const T* __restrict__ y,
+                                      const T* __restrict__ phase, T* __restrict__ t_prev, T* __restrict__ d_prev, int first,
+                                      T alpha, T beta, T gamma, T eps, T* __restrict__ z)
+{
+    const long NK = N * K, total = B * NK;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const T s = dsa_sqrt(y[i] + T(1e-16));   // griffin.py:263-264
+        T cr, ci;
+        if (!t) {
+            const T ph = phase ? phase[i] : T(0);
+            z[2 * i] = s * dsa_cos(ph);
+            z[2 * i + 1] = s * dsa_sin(ph);
+            continue;
+        }
+        const long b = i / NK;
+        const long it = b * Nt * K + (i - b * NK);
+        T tr = t[2 * it], ti = t[2 * it + 1], dr, di;
+        if (first) {
+            cr = dr = tr;
+            ci = di = ti;
+        } else {
+            tr = (T(1) - gamma) * d_prev[2 * i] + gamma * tr;
+            ti = (T(1) - gamma) * d_prev[2 * i + 1] + gamma * ti;
+            const T fr = tr - t_prev[2 * i], fi = ti - t_prev[2 * i + 1];
+            cr = tr + alpha * fr;
+            ci = ti + alpha * fi;
+            dr = tr + beta * fr;
+            di = ti + beta * fi;
+        }
+        t_prev[2 * i] = tr;
+        t_prev[2 * i + 1] = ti;
+        d_prev[2 * i] = dr;
+        d_prev[2 * i + 1] = di;
+        const T r = s / (dsa_sqrt(cr * cr + ci * ci) + eps);   // griffin.py:281
+        z[2 * i] = cr * r;
+        z[2 * i + 1] = ci * r;
+    }
+}
+
 }  // namespace dsa
 
 #include "stft_mfma.h"
@@ -1627,4 +1672,28 @@ DSA_EXPORT int dsa_div_rows(const void* x, int64_t B, int64_t T, const void* d, 
     else
         return fail(DSA_ERR_UNSUPPORTED, "div_rows: unsupported dtype%s");
     return check_launch("div_rows");
+}
+
+DSA_EXPORT int dsa_griffin_update(const void* t, int64_t B, int64_t Nt, int64_t N, int32_t K, const void* y, const void* phase,
+                                  void* t_prev, void* d_prev, int32_t first, double alpha, double beta, double gamma,
+                                  double eps, int32_t dtype, void* z, void* stream)
+{
+    DSA_REQUIRE(B >= 0 && N >= 0 && K > 0 && Nt >= N, "griffin_update: the transform must cover the spectrogram's frames");
+    DSA_REQUIRE(!t || (t_prev && d_prev), "griffin_update: the momentum buffers are required after the initial step");
+    const long total = (long)B * N * K;
+    if (total == 0) return DSA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (dtype == DSA_F32)
+        hipLaunchKernelGGL((griffin_update_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)t, (long)B,
+                           (long)Nt, (long)N, K, (const float*)y, (const float*)phase, (float*)t_prev, (float*)d_prev, first,
+                           (float)alpha, (float)beta, (float)gamma, (float)eps, (float*)z);
+    else if (dtype == DSA_F64)
+        hipLaunchKernelGGL((griffin_update_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st, (const double*)t, (long)B,
+                           (long)Nt, (long)N, K, (const double*)y, (const double*)phase, (double*)t_prev, (double*)d_prev,
+                           first, alpha, beta, gamma, eps, (double*)z);
+    else
+        return fail(DSA_ERR_UNSUPPORTED, "griffin_update: unsupported dtype%s");
+    return check_launch("griffin_update");
 }

@@ -65,6 +65,16 @@ def istft(y: Tensor, *, out_length: int | None = None, frame_length: int = 400, 
                                                      symmetric=symmetric)
 
 
+def griffin(y: Tensor, *, out_length: int | None = None, frame_length: int = 400, frame_period: int = 80,
+            fft_length: int = 512, center: bool = True, mode: str = "constant", window: str | int = "blackman",
+            norm: str | int = "power", symmetric: bool = True, n_iter: int = 100, alpha: float = 0.99,
+            beta: float = 0.99, gamma: float = 1.1, init_phase: str = "random", verbose: bool = False) -> Tensor:
+    """Griffin-Lim phase reconstruction y:(..., T/P, N/2+1) power spectrogram -> (..., T)."""
+    return nn.GriffinLim._func(y, out_length, frame_length=frame_length, frame_period=frame_period, fft_length=fft_length,
+                               center=center, mode=mode, window=window, norm=norm, symmetric=symmetric, n_iter=n_iter,
+                               alpha=alpha, beta=beta, gamma=gamma, init_phase=init_phase, verbose=verbose)
+
+
 def unframe(y: Tensor, *, out_length: int | None = None, frame_period: int = 80, center: bool = True,
             window: str | int = "rectangular", norm: str | int = "none", symmetric: bool = True) -> Tensor:
     """Overlap-add framed waveforms y:(..., T/P, L) -> (..., T)."""

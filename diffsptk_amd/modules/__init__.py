@@ -6,6 +6,7 @@ from .fbank import MelFilterBankAnalysis
 from .fbank import MelFilterBankAnalysis as FBANK
 from .fftr import RealValuedFastFourierTransform
 from .frame import Frame
+from .griffin import GriffinLim
 from .ifftr import RealValuedInverseFastFourierTransform
 from .istft import InverseShortTimeFourierTransform
 from .istft import InverseShortTimeFourierTransform as ISTFT
@@ -23,7 +24,7 @@ from .unframe import Unframe
 from .window import Window
 
 __all__ = [
-    "Autocorrelation", "BaseFunctionalModule", "DCT", "DiscreteCosineTransform", "FBANK", "Frame",
+    "Autocorrelation", "BaseFunctionalModule", "DCT", "DiscreteCosineTransform", "FBANK", "Frame", "GriffinLim",
     "FrequencyTransform", "ISTFT", "InverseShortTimeFourierTransform", "RealValuedInverseFastFourierTransform", "Unframe", "LPC", "LevinsonDurbin", "LinearPredictiveCodingAnalysis", "MFCC", "MelCepstralAnalysis",
     "MelFilterBankAnalysis", "MelFrequencyCepstralCoefficientsAnalysis", "Precomputed",
     "RealValuedFastFourierTransform", "STFT", "ShortTimeFourierTransform", "Spectrum", "Window",

@@ -450,6 +450,30 @@ class IstftFn(torch.autograd.Function):
         return (torch.view_as_complex(gy).reshape(shape),) + (None,) * 8
 
 
+def griffin_update(t, y, phase, t_prev, d_prev, first, alpha, beta, gamma, eps, out=None):
+    """One Griffin-Lim phase update (griffin.py:263-284, element-wise part): returns the next complex
+    spectrogram sqrt(y + 1e-16) c / (|c| + eps); t_prev / d_prev (real views, (..., K, 2)) are updated in place.
+    t=None is the initial step (phase=None: zeros)."""
+    _require_device(y)
+    K = y.size(-1)
+    N = y.size(-2) if y.dim() >= 2 else 1
+    B = y.numel() // max(N * K, 1)
+    z = out if out is not None else torch.empty(*y.shape, dtype=torch.complex64 if y.dtype == torch.float32 else torch.complex128,
+                                                device=y.device)
+    zr = torch.view_as_real(z)
+    tr, Nt = None, N
+    if t is not None:
+        if not t.is_complex() or t.size(-1) != K or t.size(-2) < N:
+            raise ValueError("griffin_update: t must be the complex STFT of the current estimate")
+        tr = torch.view_as_real(t.resolve_conj()).contiguous()
+        Nt = t.size(-2)
+    with torch.cuda.device(y.device):
+        _call("dsa_griffin_update", _p(tr) if tr is not None else None, B, Nt, N, K, _p(y), _p(phase) if phase is not None else None,
+              _p(t_prev), _p(d_prev), int(bool(first)), float(alpha), float(beta), float(gamma), float(eps), _dtype_code(y),
+              _p(zr), _stream())
+    return z
+
+
 # ----------------------------------------------------------------------------------- fbank
 class FbankFn(torch.autograd.Function):
     """y, E = mel filter bank outputs and log energy of power spectra (fbank.py:306-321).

@@ -145,6 +145,14 @@ int dsa_fbank_bwd(const void* gy, const void* gE, const void* x, int64_t F, int3
  *   dsa_div_rows:    out:(B,T) = x / (d:(T) + eps)   (d = overlap-added squared window, eps = 1e-16) */
 int dsa_irfft_scale(const void* y, int64_t F, int32_t nfft, int32_t dtype, void* out, void* stream);
 int dsa_div_rows(const void* x, int64_t B, int64_t T, const void* d, double eps, int32_t dtype, void* out, void* stream);
+/* GriffinLim._forward griffin.py:263-284: the element-wise part of one phase-reconstruction step between
+ * z -> dsa_stft_bwd (inverse) -> dsa_stft_fwd (complex) -> t.  y:(B,N,K) power spectrogram; t:(B,Nt,K) complex
+ * pairs (Nt >= N, surplus frames dropped; NULL = initial step with phase:(B,N,K) or NULL for zeros);
+ * t_prev, d_prev:(B,N,K) complex pairs, updated in place; first != 0 on the first step; z:(B,N,K) complex pairs
+ * = sqrt(y + 1e-16) c / (|c| + eps), the next spectrogram to invert. */
+int dsa_griffin_update(const void* t, int64_t B, int64_t Nt, int64_t N, int32_t K, const void* y, const void* phase,
+                       void* t_prev, void* d_prev, int32_t first, double alpha, double beta, double gamma, double eps,
+                       int32_t dtype, void* z, void* stream);
 
 /* ------------------------------------------------------------------ a8-a10  mel-cepstral analysis
  * MelCepstralAnalysis._forward, mcep.py:189-224 (incl. symmetric_toeplitz / hankel,

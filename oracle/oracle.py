@@ -356,3 +356,30 @@ def unframe(y, frame_period, center=True, w=None, out_length=None):
 def istft(Y, frame_length, frame_period, center=True, w=None, out_length=None):
     """unframe(ifftr(Y)[..., :L]) (istft.py:186-193)."""
     return unframe(ifftr(Y, frame_length), frame_period, center, w, out_length)
+
+
+def griffin(y, frame_length, frame_period, fft_length, *, out_length=None, center=True, window="blackman",
+            norm="power", symmetric=True, n_iter=100, alpha=0.99, beta=0.99, gamma=1.1, phase=None):
+    """GriffinLim._forward (griffin.py:263-292) with the initial phase given (None: zeros): float64 numpy over
+    this oracle's own stft / istft."""
+    y = np.asarray(y, dtype=np.float64)
+    N = y.shape[-2]
+    eps = 1e-16
+    s = np.sqrt(y + eps)
+    angle = np.exp(1j * (np.zeros_like(s) if phase is None else np.asarray(phase, dtype=np.float64)))
+    w = window_table(frame_length, window, norm, symmetric)
+    kw = dict(center=center, window=window, norm=norm, symmetric=symmetric, eps=0.0, out_format="complex")
+    t_prev = d_prev = 0
+    for n in range(n_iter):
+        x = istft(s * angle, frame_length, frame_period, center, w, out_length)
+        t = stft(x, frame_length, frame_period, fft_length, **kw)[..., :N, :]
+        if n == 0:
+            c = d = t
+        else:
+            t = (1 - gamma) * d_prev + gamma * t
+            diff = t - t_prev
+            c = t + alpha * diff
+            d = t + beta * diff
+        angle = c / (np.abs(c) + eps)
+        t_prev, d_prev = t, d
+    return istft(s * angle, frame_length, frame_period, center, w, out_length)

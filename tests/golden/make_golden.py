@@ -288,6 +288,24 @@ def main():
         g8[f"roundtrip_{name}"] = npy(ist(st(xw.to(dt)), out_length=xw.numel()))
     np.savez_compressed(os.path.join(HERE, "inverse.npz"), **g8)
 
+    # ------------------------------------------------------------------ Griffin-Lim (griffin.py)
+    g9 = {}
+    sp = dict(frame_length=3, frame_period=1, fft_length=8)
+    xd = d.ramp(1, 3)
+    g9["doc_y"] = npy(d.GriffinLim(**sp, n_iter=10, init_phase="zeros")(d.STFT(**sp, out_format="power")(xd), out_length=3))
+    xs = xw[2000:6000]
+    for name, dt in DT.items():
+        X = d.STFT(400, 80, 512, out_format="power", dtype=dt)(xs.to(dt))
+        if name == "f64":
+            g9["seg_power"] = npy(X)
+        for it in (0, 1, 5):
+            g9[f"seg_iter{it}_{name}"] = npy(d.GriffinLim(400, 80, 512, n_iter=it, init_phase="zeros", dtype=dt)(X, out_length=xs.numel()))
+    Xb = d.STFT(64, 16, 64, window="hanning", norm="none", out_format="power", dtype=f64)(torch.randn(3, 700, dtype=f64))
+    g9["rand_power"] = npy(Xb)
+    g9["rand_iter4"] = npy(d.GriffinLim(64, 16, 64, window="hanning", norm="none", n_iter=4, alpha=0.5, beta=0.2, gamma=1.3,
+                                        init_phase="zeros", dtype=f64)(Xb))
+    np.savez_compressed(os.path.join(HERE, "griffin.npz"), **g9)
+
     meta = {
         "reference": "sp-nitech/diffsptk 4.0.0 (/root/reference)",
         "torch": torch.__version__,
@@ -297,7 +315,7 @@ def main():
     }
     with open(os.path.join(HERE, "META.json"), "w") as f:
         json.dump(meta, f, indent=1)
-    for fn in ("tables.npz", "datawav.npz", "randn.npz", "grids.npz", "fbank.npz", "inverse.npz"):
+    for fn in ("tables.npz", "datawav.npz", "randn.npz", "grids.npz", "fbank.npz", "inverse.npz", "griffin.npz"):
         print(fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, "KiB")
 
 

@@ -873,6 +873,46 @@ def test_stft_istft_round_trip(golden, name, dt, tol):
     assert xbr.shape == xb.shape and (xbr - xb).abs().max().item() < 20 * tol
 
 
+@pytest.mark.parametrize("name,dt,tol", [("f64", torch.float64, 1e-9), ("f32", torch.float32, 2e-3)])
+def test_griffin_lim_golden(golden, name, dt, tol):
+    """GriffinLim (griffin.py:263-292; inverse STFT -> complex STFT -> one element-wise update kernel per step)
+    against the reference's waveforms after 0 / 1 / 5 accelerated iterations on a data.wav segment, and a random
+    batch with other momenta and window.  float32: each step divides by |c| + 1e-16, so rounding differences in
+    near-empty bins re-enter the next inverse transform at full amplitude (the reference's own float32 and
+    float64 runs differ by 1e-3 of the peak after 5 steps)."""
+    g = golden("griffin")
+    X = dev(g["seg_power"], dt)
+    for it in (0, 1, 5):
+        y = dsp.GriffinLim(400, 80, 512, n_iter=it, init_phase="zeros", device=DEV, dtype=dt)(X, out_length=4000)
+        ref = g[f"seg_iter{it}_{name}"]
+        assert y.shape == (4000,) and np.abs(host(y) - ref).max() <= tol * np.abs(ref).max()
+    if dt == torch.float64:
+        yb = F.griffin(dev(g["rand_power"], dt), frame_length=64, frame_period=16, fft_length=64, window="hanning", norm="none",
+                       n_iter=4, alpha=0.5, beta=0.2, gamma=1.3, init_phase="zeros")
+        assert np.abs(host(yb) - g["rand_iter4"]).max() <= tol * np.abs(g["rand_iter4"]).max()
+    assert _lib.last_kernel() == "div_rows"
+
+
+def test_griffin_lim_full_size_properties():
+    """Bench-size batch, float32, random initial phase: the estimate's spectrogram approaches the target
+    (spectral convergence improves with the iteration count) and the update kernel keeps |z| = sqrt(y)."""
+    x = torch.randn(32, 16000, generator=torch.Generator().manual_seed(9)).to(DEV)
+    X = dsp.STFT(400, 80, 512, device=DEV)(x)
+    s = torch.sqrt(X)
+    errs = []
+    for it in (1, 8, 32):
+        torch.manual_seed(0)
+        y = dsp.GriffinLim(400, 80, 512, n_iter=it, init_phase="random", device=DEV)(X, out_length=16000)
+        assert y.shape == x.shape and torch.isfinite(y).all()
+        sy = torch.sqrt(dsp.STFT(400, 80, 512, eps=0, device=DEV)(y))
+        errs.append((torch.linalg.norm(sy - s) / torch.linalg.norm(s)).item())
+    assert errs[0] > errs[1] > errs[2] and errs[2] < 0.25, errs
+    tp = torch.empty(*X.shape, 2, device=DEV)
+    z = ops.griffin_update(None, X.contiguous(), None, tp, torch.empty_like(tp), True, 0.99, 0.99, 1.1, 1e-16)
+    assert _lib.last_kernel() == "griffin_update"
+    close(host(z.abs()), host(torch.sqrt(X + 1e-16)), 1e-6, 1e-7)
+
+
 def test_inverse_path_gradcheck():
     gen = torch.Generator().manual_seed(11)
     yc = torch.randn(2, 5, 9, dtype=torch.complex128, generator=gen).to(DEV).requires_grad_(True)

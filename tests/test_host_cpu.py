@@ -218,3 +218,23 @@ def test_fbank_mfcc_module_contract():
     assert mf.W.shape == (40, 13) and mf.H.shape == (257, 40)
     with pytest.raises(ValueError, match="dct_type must be in"):
         dsp.DCT(8, 5)
+
+
+def test_griffin_lim_module_contract():
+    """Constructor checks of GriffinLim (griffin.py:150-163, 188-193) and the no-CPU-fallback rule."""
+    import re
+
+    import pytest
+    import torch
+
+    import diffsptk_amd as dsp
+
+    for kw, msg in ((dict(n_iter=-1), "n_iter must be non-negative."), (dict(alpha=-1), "alpha must be non-negative."),
+                    (dict(beta=-0.1), "beta must be non-negative."), (dict(gamma=-2), "gamma must be non-negative."),
+                    (dict(init_phase="ones"), "init_phase: ones is not supported.")):
+        with pytest.raises(ValueError, match=re.escape(msg)):
+            dsp.GriffinLim(400, 80, 512, **kw)
+    m = dsp.GriffinLim(400, 80, 512, n_iter=3, init_phase="zeros")
+    assert list(m.state_dict()) == [] and m.n_iter == 3 and isinstance(m.istft, dsp.ISTFT) and isinstance(m.stft, dsp.STFT)
+    with pytest.raises(RuntimeError, match="device"):
+        m(torch.rand(5, 257))     # host tensor: there is no CPU path

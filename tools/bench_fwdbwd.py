@@ -68,3 +68,8 @@ with torch.no_grad():
     t_is = timeit(lambda: ist(Z))
     err = (ist(Z) - x).abs().max().item()
 print(f"   STFT complex fwd {t_sc:.3f} ms | ISTFT {t_is:.3f} ms ({frames/t_is*1e3:.3e} frames/s) | round-trip max error {err:.2e}")
+gl = dsp.GriffinLim(400, 80, 512, n_iter=8, init_phase="zeros", device=dev)
+with torch.no_grad():
+    Xp = stft(x)
+    t_gl = timeit(lambda: gl(Xp, out_length=x.size(-1)))
+print(f"   Griffin-Lim 8 iterations {t_gl:.3f} ms ({t_gl/8:.3f} ms per iteration: ISTFT + complex STFT + update)")
