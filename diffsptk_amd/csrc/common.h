@@ -38,6 +38,12 @@ inline int check_launch(const char* name)
     return DSA_OK;
 }
 
+// matrix-core "transform of the spectrum x (K x C) matrix" launcher of fbank.hip, shared with fftcep.hip
+// (use_power: 0 sqrt x | 1 x | 2 log x;  post_mode 0: floor + glog, 1: scale with the first column halved,
+//  3: first and last column halved;  needs float32, C <= 48, C < K <= 320)
+int fbank_mfma_launch_ex(const void* x, int64_t F, int K, const void* H, int C, int ldh, double floor, double gamma,
+                         int use_power, int post_mode, double post_scale, void* y, void* E, hipStream_t st, const char* name);
+
 #define DSA_REQUIRE(cond, msg)                                              \
     do {                                                                    \
         if (!(cond)) return dsa::fail(DSA_ERR_INVALID_ARGUMENT, "%s", msg); \

@@ -214,6 +214,10 @@ __global__ __launch_bounds__(kFbMaxWaves * 64) void fbank_bwd_kernel(const T* __
 //     more column of H, so E falls out of the same accumulators; otherwise one pass of operand reads
 //     sums the energy on the vector unit;
 //   * epilogue: floor, glog, 64-byte runs of 16 channels per frame straight from the accumulators.
+// The same kernel serves other "transform of the spectrum, then a K x C matrix" front ends: use_power selects the
+// input transform (0: sqrt x, 1: x, 2: log x), H may be a column slice of a wider matrix (row stride ldh), and
+// post_mode 1 replaces floor + glog by a plain scaling with the first coefficient halved (cepstral analysis,
+// fftcep.py:122-135 with n_iter = 0: log x against the first M + 1 columns of the even cosine matrix).
 constexpr int kFmRows = 16, kFmWaves = 4, kFmPre = 20, kFmU = 8;  // K <= 320
 #ifdef DSA_FBANK_TIMING
 __device__ unsigned long long g_fbank_stamps[16];
@@ -230,7 +234,8 @@ __global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const flo
                                                                       const float* __restrict__ H, int C, float floor,
                                                                       float gamma, int use_power, float* __restrict__ y,
                                                                       float* __restrict__ E, int nsteps, int cap,
-                                                                      int tile_floats, int vec4)
+                                                                      int tile_floats, int vec4, int ldh, int post_mode,
+                                                                      float post_scale)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
     float* himg = reinterpret_cast<float*>(fb_smem);                         // [3][cap][64]
@@ -260,13 +265,19 @@ __global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const flo
     long tl = (long)blockIdx.x * kFmWaves + wave;
     issue(tl);   // the first tile is in flight while the program is built
     FB_STAMP0(7);
-    const int ecol = (use_power && C < 48 && E) ? C : -1;
+    const int ecol = (use_power == 1 && C < 48 && E) ? C : -1;
     const bool yvec4 = (((size_t)y) & 15) == 0;   // every tile starts 64 C bytes further
     const float ew = 1.f / (float)(2 * (K - 1));
     {   // H -> LDS (the tile buffers are free until the first tile is staged): the program is built from LDS
         float* Hs = tiles;
         const int nh = K * C;
-        if ((((size_t)H) & 15) == 0) {
+        if (ldh != C) {
+#pragma unroll 4
+            for (int q = threadIdx.x; q < nh; q += kFmWaves * 64) {
+                const int bin = q / C;
+                Hs[q] = H[(long)bin * ldh + (q - bin * C)];
+            }
+        } else if ((((size_t)H) & 15) == 0) {
             const int nh4 = nh >> 2;
 #pragma unroll 4
             for (int q = threadIdx.x; q < nh4; q += kFmWaves * 64)
@@ -357,14 +368,15 @@ __global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const flo
             for (int q = 0; q < NQ; ++q)
                 if (q * 64 + lane < n4) {
                     fm_f4 v = pre[q];
-                    if (!use_power) v = fm_f4{__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y), __builtin_amdgcn_sqrtf(v.z), __builtin_amdgcn_sqrtf(v.w)};  // fbank.py:315 (v_sqrt_f32: 1 ulp)
+                    if (use_power == 0) v = fm_f4{__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y), __builtin_amdgcn_sqrtf(v.z), __builtin_amdgcn_sqrtf(v.w)};  // fbank.py:315 (v_sqrt_f32: 1 ulp)
+                    if (use_power == 2) v = fm_f4{dsa_log(v.x), dsa_log(v.y), dsa_log(v.z), dsa_log(v.w)};   // fftcep.py:122
                     reinterpret_cast<fm_f4*>(tile)[q * 64 + lane] = v;
                 }
         } else {  // ragged last tile or unaligned spectrum: element loads, missing rows read as 1
             const long have = (F - f0 < kFmRows ? F - f0 : kFmRows) * (long)K;
             for (int e = lane; e < kFmRows * K; e += 64) {
                 const float v = e < have ? x[f0 * K + e] : 1.f;
-                tile[e] = use_power ? v : __builtin_amdgcn_sqrtf(v);
+                tile[e] = use_power == 1 ? v : (use_power == 2 ? dsa_log(v) : __builtin_amdgcn_sqrtf(v));
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -473,8 +485,12 @@ __global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const flo
             for (int r = 0; r < 4; ++r) {
                 const int fr = 4 * kq + r;
                 if (ch < C) {
-                    const float v = d[r] > floor ? d[r] : floor;                    // fbank.py:317
-                    ost[fr * C + ch] = glog_fwd(v, gamma);
+                    if (post_mode) {
+                        ost[fr * C + ch] = d[r] * ((ch == 0 || ((post_mode & 2) && ch == C - 1)) ? 0.5f * post_scale : post_scale);
+                    } else {
+                        const float v = d[r] > floor ? d[r] : floor;                // fbank.py:317
+                        ost[fr * C + ch] = glog_fwd(v, gamma);
+                    }
                 } else if (ch == ecol) {
                     est[fr] = dsa_log(d[r]);                                        // fbank.py:320
                 }
@@ -497,8 +513,8 @@ __global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const flo
     }
 }
 
-static int fbank_mfma_launch(const void* x, int64_t F, int K, const void* H, int C, double floor, double gamma,
-                             int use_power, void* y, void* E, hipStream_t st)
+int fbank_mfma_launch_ex(const void* x, int64_t F, int K, const void* H, int C, int ldh, double floor, double gamma,
+                         int use_power, int post_mode, double post_scale, void* y, void* E, hipStream_t st, const char* name)
 {
     const int nsteps = 16 * (K / 64) + ((K % 64) < 16 ? (K % 64) : 16);
     const int tile_floats = (kFmRows * K + 3) & ~3;
@@ -520,14 +536,20 @@ static int fbank_mfma_launch(const void* x, int64_t F, int K, const void* H, int
         if (!attr_ok) return fail(DSA_ERR_LAUNCH, "fbank: cannot reserve LDS for the operand images%s");              \
         hipLaunchKernelGGL(fbank_mfma_fwd_kernel<NQ>, dim3((unsigned)blocks), dim3(kFmWaves * 64), lds, st,            \
                            (const float*)x, (long)F, K, (const float*)H, C, (float)floor, (float)gamma, use_power,     \
-                           (float*)y, (float*)E, nsteps, cap, tile_floats, vec4);                                      \
+                           (float*)y, (float*)E, nsteps, cap, tile_floats, vec4, ldh, post_mode, (float)post_scale);   \
     } while (0)
     if (nq <= 5) DSA_FM_LAUNCH(5);
     else if (nq <= 9) DSA_FM_LAUNCH(9);
     else if (nq <= 17) DSA_FM_LAUNCH(17);
     else DSA_FM_LAUNCH(20);
 #undef DSA_FM_LAUNCH
-    return check_launch("fbank_mfma_fwd");
+    return check_launch(name);
+}
+
+static int fbank_mfma_launch(const void* x, int64_t F, int K, const void* H, int C, double floor, double gamma,
+                             int use_power, void* y, void* E, hipStream_t st)
+{
+    return fbank_mfma_launch_ex(x, F, K, H, C, C, floor, gamma, use_power ? 1 : 0, 0, 1.0, y, E, st, "fbank_mfma_fwd");
 }
 
 template <typename T>

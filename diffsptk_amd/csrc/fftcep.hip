@@ -1,0 +1,246 @@
+// Cepstral analysis by the improved cepstral method:
+// CepstralAnalysis._forward, diffsptk/modules/fftcep.py:116-136.
+//
+// MI355X-first restatement.  Every transform of the reference acts on a real, even sequence, so all of them
+// are ONE (H x H) cosine matrix A[k][n] = c_k cos(2 pi k n / L)  (H = L/2 + 1, c = 1 at k = 0 and H - 1, else 2):
+//     irfft(log x)[:H]     = (log x) A / L          (fftcep.py:122)
+//     hfft(e)[:H]          = e A                    (fftcep.py:127; the output is even, its first H values suffice)
+//     ihfft(y).real        = y A / L                (fftcep.py:129)
+// so one frame is:  ehat = log(x) A / L;  v = ehat[:N];  e = ehat with [:N] zeroed;  n_iter times
+//     y = e A with negatives set to 0;  e2 = y A / L;  t = (1 + accel) e2[:N];  v += t;  e = e2 - pad(t);
+// out = v with the end point(s) halved (fftcep.py:134-135).  With n_iter = 0 (the default) only N columns of A
+// are touched.  Generic kernel pair (float32 / float64, any L, M): one workgroup per frame, the frame's vectors
+// in LDS, thread n owns column n of every product (A is row-major: the reads of a row are coalesced and L2
+// resident).  The backward runs the adjoint chain with the clamp masks the forward saved (bit sets), using
+// A[n][k] = (c_n / c_k) A[k][n] so that both directions stream A the same way.
+#include "common.h"
+
+#include <cstdlib>
+
+namespace dsa {
+
+template <typename T>
+__device__ __forceinline__ T fc_weight(int k, int H) { return (k == 0 || k == H - 1) ? T(1) : T(2); }
+
+// dst[n] = scale * sum_{k < klim} src[k] A[k][n] for n < nlim  (all threads; src in LDS; result returned per thread
+// for n = threadIdx.x + 256 r through the callback)
+template <typename T, typename Fn>
+__device__ __forceinline__ void fc_product(const T* __restrict__ A, int H, const T* src, int klim, int nlim, Fn&& sink)
+{
+    for (int n = threadIdx.x; n < nlim; n += blockDim.x) {
+        T s0 = 0, s1 = 0;
+        int k = 0;
+        for (; k + 1 < klim; k += 2) {
+            s0 += src[k] * A[(long)k * H + n];
+            s1 += src[k + 1] * A[(long)(k + 1) * H + n];
+        }
+        if (k < klim) s0 += src[k] * A[(long)k * H + n];
+        sink(n, s0 + s1);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fftcep_fwd_kernel(const T* __restrict__ x, long F, int H, int N,
+                                                         const T* __restrict__ A, T accel, int n_iter,
+                                                         T* __restrict__ out, unsigned long long* __restrict__ masks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fc_smem[];
+    T* e = reinterpret_cast<T*>(fc_smem);   // [H]
+    T* y = e + H;                           // [H]
+    T* v = y + H;                           // [N]
+    const long f = blockIdx.x;
+    const T invL = T(1) / T(2 * (H - 1));
+    const int W64 = (H + 63) / 64;
+    for (int k = threadIdx.x; k < H; k += blockDim.x) e[k] = dsa_log(x[f * H + k]);   // fftcep.py:122
+    __syncthreads();
+    fc_product<T>(A, H, e, H, n_iter > 0 ? H : N, [&](int n, T s) { y[n] = s * invL; });
+    __syncthreads();
+    for (int n = threadIdx.x; n < H; n += blockDim.x) {   // fftcep.py:123-124
+        if (n < N) v[n] = y[n];
+        e[n] = n < N ? T(0) : y[n];
+    }
+    __syncthreads();
+    for (int it = 0; it < n_iter; ++it) {
+        // y = hfft(e) with negatives cleared (fftcep.py:127-128); the clamp pattern is kept for the backward
+        for (int n0 = 0; n0 < H; n0 += blockDim.x) {
+            const int n = n0 + threadIdx.x;
+            T s = 0;
+            if (n < H) {
+                T s0 = 0, s1 = 0;
+                int k = 0;
+                for (; k + 1 < H; k += 2) {
+                    s0 += e[k] * A[(long)k * H + n];
+                    s1 += e[k + 1] * A[(long)(k + 1) * H + n];
+                }
+                if (k < H) s0 += e[k] * A[(long)k * H + n];
+                s = s0 + s1;
+            }
+            const bool keep = n < H && !(s < T(0));
+            if (n < H) y[n] = s < T(0) ? T(0) : s;
+            const unsigned long long bits = __ballot(keep);
+            if (masks && (threadIdx.x & 63) == 0 && n0 + (int)threadIdx.x < H)
+                masks[(f * n_iter + it) * W64 + ((n0 + threadIdx.x) >> 6)] = bits;
+        }
+        __syncthreads();
+        T r[2] = {T(0), T(0)};   // e2 = ihfft(y).real (fftcep.py:129): up to 2 columns per thread (H <= 512)
+        int cnt = 0;
+        for (int n = threadIdx.x; n < H; n += blockDim.x) {
+            T s0 = 0, s1 = 0;
+            int k = 0;
+            for (; k + 1 < H; k += 2) {
+                s0 += y[k] * A[(long)k * H + n];
+                s1 += y[k + 1] * A[(long)(k + 1) * H + n];
+            }
+            if (k < H) s0 += y[k] * A[(long)k * H + n];
+            r[cnt++] = (s0 + s1) * invL;
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int n = threadIdx.x; n < H; n += blockDim.x) {   // fftcep.py:130-132
+            const T e2 = r[cnt++];
+            if (n < N) {
+                const T t = e2 * (T(1) + accel);
+                v[n] += t;
+                e[n] = e2 - t;
+            } else {
+                e[n] = e2;
+            }
+        }
+        __syncthreads();
+    }
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {   // fftcep.py:134-135
+        const bool half = n == 0 || (H == N && n == N - 1);
+        out[f * N + n] = half ? T(0.5) * v[n] : v[n];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fftcep_bwd_kernel(const T* __restrict__ gout, const T* __restrict__ x, long F, int H,
+                                                         int N, const T* __restrict__ A, T accel, int n_iter,
+                                                         const unsigned long long* __restrict__ masks, T* __restrict__ gx)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fc_smem[];
+    T* ge = reinterpret_cast<T*>(fc_smem);   // [H]  cotangent of e, pre-divided by c_k when used as a product input
+    T* gy = ge + H;                          // [H]
+    T* gv = gy + H;                          // [N]
+    const long f = blockIdx.x;
+    const T invL = T(1) / T(2 * (H - 1));
+    const int W64 = (H + 63) / 64;
+    for (int n = threadIdx.x; n < H; n += blockDim.x) {
+        if (n < N) {
+            const bool half = n == 0 || (H == N && n == N - 1);
+            gv[n] = (half ? T(0.5) : T(1)) * gout[f * N + n];
+        }
+        ge[n] = T(0);
+    }
+    __syncthreads();
+    for (int it = n_iter - 1; it >= 0; --it) {
+        // through e = e2 - pad(t), v += t, t = (1 + accel) e2[:N]:  ge2[:N] = (1 + accel) gv - accel ge[:N]
+        for (int k = threadIdx.x; k < H; k += blockDim.x) {
+            const T g2 = k < N ? (T(1) + accel) * gv[k] - accel * ge[k] : ge[k];
+            ge[k] = g2 / fc_weight<T>(k, H);
+        }
+        __syncthreads();
+        // e2 = y A / L  =>  gy[n] = sum_k ge2[k] A[n][k] / L = (c_n / L) sum_k (ge2[k] / c_k) A[k][n];  then the clamp
+        for (int n0 = 0; n0 < H; n0 += blockDim.x) {
+            const int n = n0 + threadIdx.x;
+            if (n < H) {
+                T s0 = 0, s1 = 0;
+                int k = 0;
+                for (; k + 1 < H; k += 2) {
+                    s0 += ge[k] * A[(long)k * H + n];
+                    s1 += ge[k + 1] * A[(long)(k + 1) * H + n];
+                }
+                if (k < H) s0 += ge[k] * A[(long)k * H + n];
+                const unsigned long long bits = masks[(f * n_iter + it) * W64 + (n >> 6)];
+                const bool keep = (bits >> (n & 63)) & 1ull;
+                // stored pre-divided by c_n for the next product: (c_n / L) s / c_n
+                gy[n] = keep ? (s0 + s1) * invL : T(0);
+            }
+        }
+        __syncthreads();
+        // y = clamp(e A)  =>  ge[n] = sum_k gz[k] A[n][k] = c_n sum_k (gz[k] / c_k) A[k][n]
+        T r[2] = {T(0), T(0)};
+        int cnt = 0;
+        for (int n = threadIdx.x; n < H; n += blockDim.x) {
+            T s0 = 0, s1 = 0;
+            int k = 0;
+            for (; k + 1 < H; k += 2) {
+                s0 += gy[k] * A[(long)k * H + n];
+                s1 += gy[k + 1] * A[(long)(k + 1) * H + n];
+            }
+            if (k < H) s0 += gy[k] * A[(long)k * H + n];
+            r[cnt++] = (s0 + s1) * fc_weight<T>(n, H);
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int n = threadIdx.x; n < H; n += blockDim.x) ge[n] = r[cnt++];
+        __syncthreads();
+    }
+    // ehat = log(x) A / L feeds v (first N) and the initial e (the rest)
+    for (int k = threadIdx.x; k < H; k += blockDim.x) gy[k] = (k < N ? gv[k] : ge[k]) / fc_weight<T>(k, H);
+    __syncthreads();
+    const int klim = n_iter > 0 ? H : N;
+    for (int n = threadIdx.x; n < H; n += blockDim.x) {
+        T s0 = 0, s1 = 0;
+        int k = 0;
+        for (; k + 1 < klim; k += 2) {
+            s0 += gy[k] * A[(long)k * H + n];
+            s1 += gy[k + 1] * A[(long)(k + 1) * H + n];
+        }
+        if (k < klim) s0 += gy[k] * A[(long)k * H + n];
+        gx[f * H + n] = (s0 + s1) * fc_weight<T>(n, H) * invL / x[f * H + n];
+    }
+}
+
+template <typename T>
+static int fftcep_launch(bool bwd, const void* gout, const void* x, int64_t F, int H, int N, const void* A, double accel,
+                         int n_iter, void* out, void* masks, void* gx, hipStream_t st)
+{
+    if (F == 0) return DSA_OK;
+    const size_t lds = sizeof(T) * (2 * (size_t)H + N);
+    if (H > 512 || lds > 60 * 1024) return fail(DSA_ERR_UNSUPPORTED, "fftcep: fft_length above 1022 is not supported%s");
+    if (!bwd)
+        hipLaunchKernelGGL((fftcep_fwd_kernel<T>), dim3((unsigned)F), dim3(256), lds, st, (const T*)x, (long)F, H, N,
+                           (const T*)A, (T)accel, n_iter, (T*)out, (unsigned long long*)masks);
+    else
+        hipLaunchKernelGGL((fftcep_bwd_kernel<T>), dim3((unsigned)F), dim3(256), lds, st, (const T*)gout, (const T*)x,
+                           (long)F, H, N, (const T*)A, (T)accel, n_iter, (const unsigned long long*)masks, (T*)gx);
+    return check_launch(bwd ? "fftcep_bwd" : "fftcep_fwd");
+}
+
+}  // namespace dsa
+
+using namespace dsa;
+
+DSA_EXPORT int dsa_fftcep_fwd(const void* x, int64_t F, int32_t fft_length, int32_t cep_order, const void* A, double accel,
+                              int32_t n_iter, int32_t dtype, void* out, void* masks, void* stream)
+{
+    DSA_REQUIRE(fft_length > 1 && fft_length % 2 == 0 && cep_order >= 0 && fft_length >= 2 * cep_order && F >= 0,
+                "fftcep: cep_order must be less than or equal to fft_length // 2");
+    DSA_REQUIRE(accel >= 0 && n_iter >= 0, "fftcep: accel and n_iter must be non-negative");
+    const int H = fft_length / 2 + 1, N = cep_order + 1;
+    hipStream_t st = (hipStream_t)stream;
+    // n_iter = 0: out = log(x) A[:, :N] / L with the first coefficient halved -- the matrix-core front-end kernel
+    if (dtype == DSA_F32 && n_iter == 0 && N <= 48 && N < H && H <= 320 && F > 0) {
+        const char* g = getenv("DSA_FFTCEP_GENERIC");
+        if (!(g && g[0] && g[0] != '0'))
+            return fbank_mfma_launch_ex(x, F, H, A, N, H, 1.0, 0.0, 2, 1, 1.0 / fft_length, out, nullptr, st, "fftcep_mfma_fwd");
+    }
+    if (dtype == DSA_F32) return fftcep_launch<float>(false, nullptr, x, F, H, N, A, accel, n_iter, out, masks, nullptr, st);
+    if (dtype == DSA_F64) return fftcep_launch<double>(false, nullptr, x, F, H, N, A, accel, n_iter, out, masks, nullptr, st);
+    return fail(DSA_ERR_UNSUPPORTED, "fftcep: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_fftcep_bwd(const void* gout, const void* x, int64_t F, int32_t fft_length, int32_t cep_order, const void* A,
+                              double accel, int32_t n_iter, const void* masks, int32_t dtype, void* gx, void* stream)
+{
+    DSA_REQUIRE(fft_length > 1 && fft_length % 2 == 0 && cep_order >= 0 && fft_length >= 2 * cep_order && F >= 0,
+                "fftcep_bwd: cep_order must be less than or equal to fft_length // 2");
+    DSA_REQUIRE(n_iter == 0 || masks, "fftcep_bwd: the clamp masks of the forward are required when n_iter > 0");
+    const int H = fft_length / 2 + 1, N = cep_order + 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSA_F32) return fftcep_launch<float>(true, gout, x, F, H, N, A, accel, n_iter, nullptr, (void*)masks, gx, st);
+    if (dtype == DSA_F64) return fftcep_launch<double>(true, gout, x, F, H, N, A, accel, n_iter, nullptr, (void*)masks, gx, st);
+    return fail(DSA_ERR_UNSUPPORTED, "fftcep_bwd: unsupported dtype%s");
+}

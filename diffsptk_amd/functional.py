@@ -65,6 +65,11 @@ def istft(y: Tensor, *, out_length: int | None = None, frame_length: int = 400, 
                                                      symmetric=symmetric)
 
 
+def fftcep(x: Tensor, cep_order: int, accel: float = 0, n_iter: int = 0) -> Tensor:
+    """Cepstral analysis of power spectra x:(..., L/2+1) -> (..., M+1)."""
+    return nn.CepstralAnalysis._func(x, cep_order=cep_order, accel=accel, n_iter=n_iter)
+
+
 def griffin(y: Tensor, *, out_length: int | None = None, frame_length: int = 400, frame_period: int = 80,
             fft_length: int = 512, center: bool = True, mode: str = "constant", window: str | int = "blackman",
             norm: str | int = "power", symmetric: bool = True, n_iter: int = 100, alpha: float = 0.99,

@@ -4,6 +4,7 @@ from .dct import DiscreteCosineTransform
 from .dct import DiscreteCosineTransform as DCT
 from .fbank import MelFilterBankAnalysis
 from .fbank import MelFilterBankAnalysis as FBANK
+from .fftcep import CepstralAnalysis
 from .fftr import RealValuedFastFourierTransform
 from .frame import Frame
 from .griffin import GriffinLim
@@ -24,7 +25,7 @@ from .unframe import Unframe
 from .window import Window
 
 __all__ = [
-    "Autocorrelation", "BaseFunctionalModule", "DCT", "DiscreteCosineTransform", "FBANK", "Frame", "GriffinLim",
+    "Autocorrelation", "BaseFunctionalModule", "CepstralAnalysis", "DCT", "DiscreteCosineTransform", "FBANK", "Frame", "GriffinLim",
     "FrequencyTransform", "ISTFT", "InverseShortTimeFourierTransform", "RealValuedInverseFastFourierTransform", "Unframe", "LPC", "LevinsonDurbin", "LinearPredictiveCodingAnalysis", "MFCC", "MelCepstralAnalysis",
     "MelFilterBankAnalysis", "MelFrequencyCepstralCoefficientsAnalysis", "Precomputed",
     "RealValuedFastFourierTransform", "STFT", "ShortTimeFourierTransform", "Spectrum", "Window",

@@ -474,6 +474,43 @@ def griffin_update(t, y, phase, t_prev, d_prev, first, alpha, beta, gamma, eps, 
     return z
 
 
+class FftcepFn(torch.autograd.Function):
+    """CepstralAnalysis._forward (fftcep.py:116-136): x:(..., L/2+1) power spectra -> (..., M+1)."""
+
+    @staticmethod
+    def forward(ctx, x, A, cep_order, accel, n_iter):
+        _require_device(x, A)
+        _same_dtype(x, A)
+        xc, Ac = x.contiguous(), A.contiguous()
+        H = xc.size(-1)
+        L = 2 * (H - 1)
+        F = xc.numel() // H
+        out = torch.empty(*xc.shape[:-1], cep_order + 1, device=x.device, dtype=x.dtype)
+        masks = None
+        if n_iter > 0 and x.requires_grad:
+            masks = torch.empty(F, n_iter, (H + 63) // 64, device=x.device, dtype=torch.int64)
+        with torch.cuda.device(x.device):
+            _call("dsa_fftcep_fwd", _p(xc), F, L, cep_order, _p(Ac), float(accel), n_iter, _dtype_code(xc), _p(out),
+                  _p(masks) if masks is not None else None, _stream())
+        ctx.save_for_backward(xc, Ac, masks)
+        ctx.cfg = (L, cep_order, float(accel), n_iter)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        xc, Ac, masks = ctx.saved_tensors
+        L, M, accel, n_iter = ctx.cfg
+        H = xc.size(-1)
+        F = xc.numel() // H
+        gc = g.contiguous()
+        gx = torch.empty_like(xc)
+        with torch.cuda.device(g.device):
+            _call("dsa_fftcep_bwd", _p(gc), _p(xc), F, L, M, _p(Ac), accel, n_iter, _p(masks) if masks is not None else None,
+                  _dtype_code(xc), _p(gx), _stream())
+        return gx, None, None, None, None
+
+
 # ----------------------------------------------------------------------------------- fbank
 class FbankFn(torch.autograd.Function):
     """y, E = mel filter bank outputs and log energy of power spectra (fbank.py:306-321).

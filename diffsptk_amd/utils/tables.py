@@ -279,3 +279,13 @@ def mfcc_lifter(mfcc_order: int, lifter: int) -> np.ndarray:
     v = 1.0 + (lifter / 2.0) * np.sin((math.pi / lifter) * r)   # lifter = 0: ZeroDivisionError, as in the reference
     v[0] = math.sqrt(2.0)
     return v
+
+
+def even_cosine_matrix(fft_length: int) -> np.ndarray:
+    """A (H, H), H = L/2 + 1: A[k][n] = c_k cos(2 pi k n / L), c = 1 at k = 0 and L/2, else 2.  For a real even
+    sequence e, hfft(e)[:H] = e @ A and irfft(e)[:H] = ihfft(e).real = e @ A / L (fftcep.py:122-129)."""
+    H = fft_length // 2 + 1
+    k = np.arange(H, dtype=np.float64)
+    c = np.where((k == 0) | (k == H - 1), 1.0, 2.0)
+    idx = np.outer(np.arange(H), np.arange(H)) % fft_length          # exact argument reduction
+    return c[:, None] * np.cos(2.0 * math.pi * idx / fft_length)

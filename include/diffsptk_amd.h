@@ -154,6 +154,17 @@ int dsa_griffin_update(const void* t, int64_t B, int64_t Nt, int64_t N, int32_t 
                        void* t_prev, void* d_prev, int32_t first, double alpha, double beta, double gamma, double eps,
                        int32_t dtype, void* z, void* stream);
 
+/* ------------------------------------------------------------------ f3  cepstral analysis
+ * CepstralAnalysis._forward fftcep.py:116-136 (improved cepstral method).  x:(F, L/2+1) power spectra ->
+ * out:(F, M+1).  A:(L/2+1, L/2+1) = c_k cos(2 pi k n / L) (c = 1 at k = 0 and L/2, else 2), device, row-major:
+ * every transform of the reference (irfft / hfft / ihfft of even real sequences) is a product with it.
+ * masks:(F, n_iter, ceil((L/2+1)/64)) uint64 bit sets of the clamp pattern, written by the forward for the
+ * backward (may be NULL when n_iter == 0 or no gradient is needed). */
+int dsa_fftcep_fwd(const void* x, int64_t F, int32_t fft_length, int32_t cep_order, const void* A, double accel,
+                   int32_t n_iter, int32_t dtype, void* out, void* masks, void* stream);
+int dsa_fftcep_bwd(const void* gout, const void* x, int64_t F, int32_t fft_length, int32_t cep_order, const void* A,
+                   double accel, int32_t n_iter, const void* masks, int32_t dtype, void* gx, void* stream);
+
 /* ------------------------------------------------------------------ a8-a10  mel-cepstral analysis
  * MelCepstralAnalysis._forward, mcep.py:189-224 (incl. symmetric_toeplitz / hankel,
  * utils/private.py:291-302, and the torch.linalg.solve call at mcep.py:221).

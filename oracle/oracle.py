@@ -383,3 +383,24 @@ def griffin(y, frame_length, frame_period, fft_length, *, out_length=None, cente
         angle = c / (np.abs(c) + eps)
         t_prev, d_prev = t, d
     return istft(s * angle, frame_length, frame_period, center, w, out_length)
+
+
+def fftcep(X, cep_order, accel=0.0, n_iter=0):
+    """CepstralAnalysis._forward (fftcep.py:116-136) with numpy's FFTs on float64."""
+    X = np.asarray(X, dtype=np.float64)
+    N = cep_order + 1
+    H = X.shape[-1]
+    e = np.fft.irfft(np.log(X))                                   # fftcep.py:122
+    v = e[..., :N].copy()
+    pad = [(0, 0)] * (X.ndim - 1)
+    e = np.pad(e[..., N:H], pad + [(N, 0)])
+    for _ in range(n_iter):
+        e = np.fft.hfft(e)                                        # fftcep.py:127
+        e[e < 0] = 0
+        e = np.fft.ihfft(e).real
+        t = e[..., :N] * (1 + accel)
+        v = v + t
+        e = e - np.pad(t, pad + [(0, H - N)])
+    idx = [0, N - 1] if H == N else [0]                           # fftcep.py:134-135
+    v[..., idx] *= 0.5
+    return v

@@ -306,6 +306,27 @@ def main():
                                         init_phase="zeros", dtype=f64)(Xb))
     np.savez_compressed(os.path.join(HERE, "griffin.npz"), **g9)
 
+    # ------------------------------------------------------------------ cepstral analysis (fftcep.py)
+    g10 = {}
+    g10["doc_c"] = npy(d.CepstralAnalysis(fft_length=16, cep_order=3)(d.STFT(frame_length=10, frame_period=10, fft_length=16)(d.ramp(19))))
+    Xr = torch.distributions.Gamma(2.0, 1.0).sample((6, 17)).to(f64) + 1e-3
+    g10["rand_x"] = npy(Xr)
+    for tag, kw in (("i0", dict()), ("i3", dict(n_iter=3)), ("i2a", dict(n_iter=2, accel=0.5))):
+        g10[f"rand_{tag}"] = npy(d.CepstralAnalysis(fft_length=32, cep_order=5, **kw)(Xr))
+    Xe = torch.distributions.Gamma(2.0, 1.0).sample((4, 9)).to(f64) + 1e-3
+    g10["edge_x"] = npy(Xe)
+    g10["edge_i2"] = npy(d.CepstralAnalysis(fft_length=16, cep_order=8, n_iter=2)(Xe))      # H == N: both ends halved
+    Xw = torch.from_numpy(np.load(os.path.join(HERE, "datawav.npz"))["stft_power_f64"])
+    for name, dt in DT.items():
+        for tag, kw in (("i0", dict()), ("i3a", dict(n_iter=3, accel=0.2))):
+            g10[f"wav_{tag}_{name}"] = npy(d.CepstralAnalysis(fft_length=512, cep_order=24, **kw)(Xw.to(dt)))
+    for tag, kw in (("i0", dict()), ("i3a", dict(n_iter=3, accel=0.2))):
+        Xg = Xw.clone().requires_grad_(True)
+        out = d.CepstralAnalysis(fft_length=512, cep_order=24, **kw)(Xg)
+        (out * torch.linspace(-1, 1, 25, dtype=f64)).sum().backward()
+        g10[f"grad_wav_{tag}"] = npy(Xg.grad)
+    np.savez_compressed(os.path.join(HERE, "fftcep.npz"), **g10)
+
     meta = {
         "reference": "sp-nitech/diffsptk 4.0.0 (/root/reference)",
         "torch": torch.__version__,
@@ -315,7 +336,7 @@ def main():
     }
     with open(os.path.join(HERE, "META.json"), "w") as f:
         json.dump(meta, f, indent=1)
-    for fn in ("tables.npz", "datawav.npz", "randn.npz", "grids.npz", "fbank.npz", "inverse.npz", "griffin.npz"):
+    for fn in ("tables.npz", "datawav.npz", "randn.npz", "grids.npz", "fbank.npz", "inverse.npz", "griffin.npz", "fftcep.npz"):
         print(fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, "KiB")
 
 

@@ -922,3 +922,51 @@ def test_inverse_path_gradcheck():
     fr = torch.randn(2, 6, 10, dtype=torch.float64, generator=gen).to(DEV).requires_grad_(True)
     assert torch.autograd.gradcheck(lambda t: F.unframe(t, frame_period=3, window="hamming"), (fr,), eps=1e-6, atol=1e-7, rtol=1e-6)
     assert torch.autograd.gradcheck(lambda t: F.unframe(t, out_length=11, frame_period=5, center=False), (fr,), eps=1e-6, atol=1e-7, rtol=1e-6)
+
+
+# ----------------------------------------------------------------------------- f3 cepstral analysis
+@pytest.mark.parametrize("name,dt", [("f64", torch.float64), ("f32", torch.float32)])
+def test_fftcep_golden_forward_backward(golden, name, dt):
+    """CepstralAnalysis (fftcep.py:116-136) on the cosine-matrix kernels against the reference: doctest, random
+    spectra with 0 / 3 / accelerated iterations, the H == N edge, data.wav outputs and input gradients."""
+    g, gw = golden("fftcep"), golden("datawav")
+    rt, at = (1e-9, 1e-11) if dt == torch.float64 else (2e-4, 2e-5)
+    X = dev(g["rand_x"], dt)
+    close(host(dsp.CepstralAnalysis(fft_length=32, cep_order=5, device=DEV, dtype=dt)(X)), g["rand_i0"], rt, at)
+    assert _lib.last_kernel() == ("fftcep_fwd" if dt == torch.float64 else "fftcep_mfma_fwd")   # n_iter = 0, float32: matrix cores
+    close(host(F.fftcep(X, 5, n_iter=3)), g["rand_i3"], rt, at)
+    assert _lib.last_kernel() == "fftcep_fwd"
+    close(host(F.fftcep(X, 5, accel=0.5, n_iter=2)), g["rand_i2a"], rt, at)
+    close(host(F.fftcep(dev(g["edge_x"], dt), 8, n_iter=2)), g["edge_i2"], rt, at)
+    x = torch.arange(19.0, device=DEV)
+    doc = dsp.CepstralAnalysis(fft_length=16, cep_order=3, device=DEV)(dsp.STFT(frame_length=10, frame_period=10, fft_length=16, device=DEV)(x))
+    close(host(doc), g["doc_c"], 1e-4, 1e-4)
+    Xw = dev(gw["stft_power_f64"], dt)
+    for tag, kw in (("i0", dict()), ("i3a", dict(n_iter=3, accel=0.2))):
+        Xg = Xw.clone().requires_grad_(True)
+        out = dsp.CepstralAnalysis(fft_length=512, cep_order=24, device=DEV, dtype=dt, **kw)(Xg)
+        close(host(out), g[f"wav_{tag}_{name}"], rt, 10 * at)
+        (out * torch.linspace(-1, 1, 25, dtype=dt, device=DEV)).sum().backward()
+        ref = g[f"grad_wav_{tag}"]
+        err = np.abs(host(Xg.grad) - ref) / np.abs(ref).max(-1, keepdims=True)   # 1/x at near-empty bins: bound per frame
+        assert err.max() <= (1e-9 if dt == torch.float64 else 5e-4)
+
+
+def test_fftcep_gradcheck_and_full_size():
+    gen = torch.Generator().manual_seed(13)
+    xg = (torch.rand(4, 17, dtype=torch.float64, generator=gen) + 0.3).to(DEV).requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda t: F.fftcep(t, 6), (xg,), eps=1e-6, atol=1e-7, rtol=1e-6)
+    assert torch.autograd.gradcheck(lambda t: F.fftcep(t, 6, accel=0.3, n_iter=2), (xg,), eps=1e-7, atol=1e-6, rtol=1e-5)
+    assert torch.autograd.gradcheck(lambda t: F.fftcep(t, 16, n_iter=1), (xg,), eps=1e-7, atol=1e-6, rtol=1e-5)   # H == N
+    # bench-size STFT -> fftcep: c_0 is the mean log power over the circle (halved), a gain g on x adds log(g) / ... only to c_0
+    x = torch.randn(64, 16000, generator=gen).to(DEV)
+    X = dsp.STFT(400, 80, 512, device=DEV)(x)
+    c = dsp.CepstralAnalysis(fft_length=512, cep_order=24, device=DEV)(X)
+    assert c.shape == (64, 200, 25) and torch.isfinite(c).all()
+    lx = torch.log(X.double())
+    c0 = ((2 * lx[..., 1:-1]).sum(-1) + lx[..., 0] + lx[..., -1]) / 512 * 0.5
+    close(host(c[..., 0]), host(c0), 1e-5, 1e-5)
+    c4 = dsp.CepstralAnalysis(fft_length=512, cep_order=24, device=DEV)(4 * X)
+    d = host(c4 - c)
+    close(d[..., 0], np.full(d.shape[:-1], 0.5 * np.log(4.0)), 1e-4, 1e-4)
+    assert np.abs(d[..., 1:]).max() < 1e-4

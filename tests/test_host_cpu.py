@@ -238,3 +238,21 @@ def test_griffin_lim_module_contract():
     assert list(m.state_dict()) == [] and m.n_iter == 3 and isinstance(m.istft, dsp.ISTFT) and isinstance(m.stft, dsp.STFT)
     with pytest.raises(RuntimeError, match="device"):
         m(torch.rand(5, 257))     # host tensor: there is no CPU path
+
+
+def test_fftcep_module_contract():
+    """Constructor checks of CepstralAnalysis (fftcep.py:95-106)."""
+    import re
+
+    import pytest
+
+    import diffsptk_amd as dsp
+
+    ok = dict(fft_length=512, cep_order=24)
+    for kw, msg in ((dict(ok, fft_length=1), "fft_length must be greater than 1."), (dict(ok, cep_order=-1), "cep_order must be non-negative."),
+                    (dict(ok, cep_order=257), "cep_order must be less than or equal to fft_length // 2."),
+                    (dict(ok, accel=-1), "accel must be non-negative."), (dict(ok, n_iter=-1), "n_iter must be non-negative.")):
+        with pytest.raises(ValueError, match=re.escape(msg)):
+            dsp.CepstralAnalysis(**kw)
+    m = dsp.CepstralAnalysis(**ok, n_iter=2)
+    assert m.A.shape == (257, 257) and list(m.state_dict()) == [] and m.in_dim == 257

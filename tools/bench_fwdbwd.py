@@ -73,3 +73,12 @@ with torch.no_grad():
     Xp = stft(x)
     t_gl = timeit(lambda: gl(Xp, out_length=x.size(-1)))
 print(f"   Griffin-Lim 8 iterations {t_gl:.3f} ms ({t_gl/8:.3f} ms per iteration: ISTFT + complex STFT + update)")
+# cepstral analysis of the STFT output
+fc0 = dsp.CepstralAnalysis(fft_length=512, cep_order=24, device=dev)
+fc2 = dsp.CepstralAnalysis(fft_length=512, cep_order=24, n_iter=2, device=dev)
+with torch.no_grad():
+    t_fc0 = timeit(lambda: fc0(Xp))
+    t_fc2 = timeit(lambda: fc2(Xp))
+Xq = Xp.clone().requires_grad_(True)
+t_fcb = timeit(lambda: torch.autograd.grad(fc0(Xq).sum(), Xq))
+print(f"   fftcep(24) fwd {t_fc0:.3f} ms ({frames/t_fc0*1e3:.3e} frames/s) | n_iter=2 fwd {t_fc2:.3f} ms | n_iter=0 fwd+bwd {t_fcb:.3f} ms")
