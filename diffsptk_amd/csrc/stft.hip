@@ -893,7 +893,9 @@ static int launch_row_dft(const void* x, int64_t B, int64_t Tlen, int64_t N, int
 //   one contiguous partial span of 3P + L samples per pass, written to `part` (pass-major).
 // A second kernel (stft_span_gather_kernel) adds the <= ceil((3P+L)/(4P)) partial spans that cover
 // each waveform sample in a fixed order: deterministic, no atomics.
-template <bool ZMEAN>
+// CPLX: the cotangent is complex (format "complex" or an inverse transform): X is not needed, so the
+// input stretch is not staged and the forward FFT is skipped.
+template <bool ZMEAN, bool CPLX = false>
 __global__ __launch_bounds__(64, 3) void stft512_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gy, long Tlen, long N, int L, int P, int left,
     int mode, const float* __restrict__ w, const float* __restrict__ twiddle, float eps, int fmt,
@@ -934,6 +936,9 @@ __global__ __launch_bounds__(64, 3) void stft512_bwd_kernel(
         const int nvalid = (int)((N - frame0) < kFPW ? (N - frame0) : kFPW);
         const float* xb = x + b * Tlen;
         __syncthreads();
+        cf v[16];
+        const int lim = L - 2 * j;
+        if constexpr (!CPLX) {
         {   // stage the input stretch
             const long g0 = frame0 * P - left;
             const int need = (nvalid - 1) * P + L;
@@ -949,8 +954,6 @@ __global__ __launch_bounds__(64, 3) void stft512_bwd_kernel(
             }
         }
         __syncthreads();
-        cf v[16];
-        const int lim = L - 2 * j;
         {
             const float* src = io_buf + fl * P + 2 * j;
             float sum = 0.f;
@@ -995,18 +998,23 @@ __global__ __launch_bounds__(64, 3) void stft512_bwd_kernel(
 #pragma unroll
         for (int k0 = 0; k0 < 16; ++k0) zf[j + 16 * k0] = v[FFT16_OUT(k0)];
         __syncthreads();
+        }
         // ---- split, cotangent, Hermitian packing (pairs read first, then written in place) ----
         const long out0 = (b * N + frame0) * K;
         cf pa[kFPW][3], pb[kFPW][3];
 #pragma unroll
         for (int f = 0; f < kFPW; ++f) {
             const cf* z = zbuf + f * 256;
-            pa[f][0] = z[lane];
-            pb[f][0] = z[(256 - lane) & 255];
-            pa[f][1] = z[lane + 64];
-            pb[f][1] = z[192 - lane];
-            pa[f][2] = z[128];
-            pb[f][2] = pa[f][2];
+            if constexpr (CPLX) {
+                pa[f][0] = pb[f][0] = pa[f][1] = pb[f][1] = pa[f][2] = pb[f][2] = cf{0.f, 0.f};
+            } else {
+                pa[f][0] = z[lane];
+                pb[f][0] = z[(256 - lane) & 255];
+                pa[f][1] = z[lane + 64];
+                pb[f][1] = z[192 - lane];
+                pa[f][2] = z[128];
+                pb[f][2] = pa[f][2];
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -1612,14 +1620,16 @@ DSA_EXPORT int dsa_stft_bwd(const void* gy, const void* x, int64_t B, int64_t T,
             long grid = 256L * waves_per_cu;
             if (grid > total_chunks) grid = total_chunks;
             int left = center ? L / 2 : 0;
-            if (zmean)
-                hipLaunchKernelGGL((stft512_bwd_kernel<true>), dim3((unsigned)grid), dim3(64), lds, st, (const float*)x,
-                                   (const float*)gy, (long)T, (long)N, L, P, left, pad_mode, (const float*)w,
-                                   (const float*)twiddle, (float)eps, out_format, part, total_chunks, chunks_per_utt, span);
-            else
-                hipLaunchKernelGGL((stft512_bwd_kernel<false>), dim3((unsigned)grid), dim3(64), lds, st, (const float*)x,
-                                   (const float*)gy, (long)T, (long)N, L, P, left, pad_mode, (const float*)w,
-                                   (const float*)twiddle, (float)eps, out_format, part, total_chunks, chunks_per_utt, span);
+            const bool cplx = out_format == DSA_SPEC_COMPLEX || out_format == DSA_SPEC_COMPLEX_INV;
+#define DSA_STFT_BWD_LAUNCH(ZM, CP)                                                                                       \
+    hipLaunchKernelGGL((stft512_bwd_kernel<ZM, CP>), dim3((unsigned)grid), dim3(64), lds, st, (const float*)x,            \
+                       (const float*)gy, (long)T, (long)N, L, P, left, pad_mode, (const float*)w, (const float*)twiddle, \
+                       (float)eps, out_format, part, total_chunks, chunks_per_utt, span)
+            if (zmean && cplx) DSA_STFT_BWD_LAUNCH(true, true);
+            else if (zmean) DSA_STFT_BWD_LAUNCH(true, false);
+            else if (cplx) DSA_STFT_BWD_LAUNCH(false, true);
+            else DSA_STFT_BWD_LAUNCH(false, false);
+#undef DSA_STFT_BWD_LAUNCH
             int rc = check_launch("stft512_bwd");
             if (rc == DSA_OK) {
                 dim3 g2((unsigned)((T + 255) / 256), (unsigned)B);
