@@ -456,7 +456,8 @@ __global__ __launch_bounds__(64, 1) void lpc24_bwd_kernel(const float* __restric
     float* in_buf = reinterpret_cast<float*>(smem_raw);
     float* out_buf = in_buf + 4 * S;
     double* rbuf = reinterpret_cast<double*>(out_buf + 4 * So);
-    float* gbuf = reinterpret_cast<float*>(rbuf + 64 * kLpcM1);
+    // the cotangent rows are dead before the output staging starts: they share its buffer when it is large enough
+    float* gbuf = 4 * So >= 64 * kLpcM1 ? out_buf : reinterpret_cast<float*>(rbuf + 64 * kLpcM1);
     const int lane = threadIdx.x;
     const int j = lane & 15, fl = lane >> 4;
     const int C = (L + 15) >> 4;
@@ -794,9 +795,10 @@ DSA_EXPORT int dsa_lpc_bwd(const void* gout, const void* x, const void* out, int
         const int C = (L + 15) >> 4, nblk = (C + kLpcM1 - 1) / kLpcM1;
         const int S = (2 * (kLpcM1 - 1) + 15 * C + kLpcM1 * nblk + 4 + 3) & ~3;  // 24 | reach of the last lane | 24
         const int So = (16 * C + 3) & ~3;
-        size_t lds_t = (size_t)(4 * S + 4 * So) * 4 + 64 * kLpcM1 * (sizeof(double) + sizeof(float));
+        size_t lds_t = (size_t)(4 * S + 4 * So) * 4 + 64 * kLpcM1 * sizeof(double) +
+                       (4 * So >= 64 * kLpcM1 ? 0 : 64 * kLpcM1 * sizeof(float));
         long total_sc = (long)((F + 63) / 64);
-        long grid = 256L * 4;
+        long grid = 256L * 4;   // 280 registers: one wave per SIMD (a 256-register build spills and is slower)
         if (grid > total_sc) grid = total_sc;
         hipLaunchKernelGGL(lpc24_bwd_kernel, dim3((unsigned)grid), dim3(64), lds_t, (hipStream_t)stream,
                            (const float*)gout, (const float*)x, (long)F, L, eps, (float*)gx, total_sc, S, So);
