@@ -662,9 +662,17 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
     const bool complex_out = fmt == DSA_SPEC_COMPLEX;
     cf* zf = zbuf + fl * kZS;
 
-    for (long c = blockIdx.x; c < total_chunks; c += gridDim.x) {
-        const long b = c / chunks_per_utt;
-        const long frame0 = (c - b * chunks_per_utt) * kFPW;
+    // (utterance, chunk) of pass c advance incrementally: one 64-bit division per wave instead of one per pass
+    long b = (long)blockIdx.x / chunks_per_utt;
+    int ci = (int)((long)blockIdx.x - b * chunks_per_utt);
+    const long b_step = (long)gridDim.x / chunks_per_utt;
+    const int ci_step = (int)((long)gridDim.x - b_step * chunks_per_utt);
+    for (long c = blockIdx.x; c < total_chunks; c += gridDim.x, b += b_step, ci += ci_step) {
+        if (ci >= chunks_per_utt) {
+            ci -= chunks_per_utt;
+            ++b;
+        }
+        const long frame0 = (long)ci * kFPW;
         const int nvalid = (int)((N - frame0) < kFPW ? (N - frame0) : kFPW);
         const float* xb = x + b * Tlen;
         DSA_WAVE_SYNC();  // previous pass is done with the LDS tile (single-wave workgroup)
@@ -930,9 +938,17 @@ __global__ __launch_bounds__(64, 3) void stft512_bwd_kernel(
     cf* zf = zbuf + fl * 256;
     const float2* gy2 = reinterpret_cast<const float2*>(gy);
 
-    for (long c = blockIdx.x; c < total_chunks; c += gridDim.x) {
-        const long b = c / chunks_per_utt;
-        const long frame0 = (c - b * chunks_per_utt) * kFPW;
+    // (utterance, chunk) of pass c advance incrementally: one 64-bit division per wave instead of one per pass
+    long b = (long)blockIdx.x / chunks_per_utt;
+    int ci = (int)((long)blockIdx.x - b * chunks_per_utt);
+    const long b_step = (long)gridDim.x / chunks_per_utt;
+    const int ci_step = (int)((long)gridDim.x - b_step * chunks_per_utt);
+    for (long c = blockIdx.x; c < total_chunks; c += gridDim.x, b += b_step, ci += ci_step) {
+        if (ci >= chunks_per_utt) {
+            ci -= chunks_per_utt;
+            ++b;
+        }
+        const long frame0 = (long)ci * kFPW;
         const int nvalid = (int)((N - frame0) < kFPW ? (N - frame0) : kFPW);
         const float* xb = x + b * Tlen;
         __syncthreads();
