@@ -626,13 +626,18 @@ __device__ unsigned long long g_stft_stamps[16];
 // fence.  (__syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: its vmcnt(0) made every pass wait for the
 // previous pass's output stores before touching LDS.)
 #define DSA_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
-template <int ABL, bool ZMEAN>
+// PLAIN: power format, no relative floor, constant padding, fixed at compile time (the bench path): the format
+// branches and the per-frame maxima leave the register allocation.
+template <int ABL, bool ZMEAN, bool PLAIN = false>
 __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
-    const float* __restrict__ x, long Tlen, long N, int L, int P, int left, int mode,
-    const float* __restrict__ w, const float* __restrict__ twiddle, float eps, int use_floor,
-    float floor_lin, int fmt, float* __restrict__ y, long total_chunks, int chunks_per_utt,
+    const float* __restrict__ x, long Tlen, long N, int L, int P, int left, int mode_arg,
+    const float* __restrict__ w, const float* __restrict__ twiddle, float eps, int use_floor_arg,
+    float floor_lin, int fmt_arg, float* __restrict__ y, long total_chunks, int chunks_per_utt,
     int io_floats)
 {
+    const int use_floor = PLAIN ? 0 : use_floor_arg;
+    const int fmt = PLAIN ? (int)DSA_SPEC_POWER : fmt_arg;
+    const int mode = PLAIN ? (int)DSA_PAD_CONSTANT : mode_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf* zbuf = reinterpret_cast<cf*>(smem_raw);
     float* io_buf = reinterpret_cast<float*>(smem_raw);  // aliases zbuf (see above)
@@ -698,7 +703,10 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
         cf v[16];
         {
             const float* src = io_buf + fl * P + 2 * j;
-            const int lim = L - 2 * j;  // element (m1, c) belongs to the frame iff 32 m1 + c < lim
+            int lim = L - 2 * j;  // element (m1, c) belongs to the frame iff 32 m1 + c < lim
+            // recomputed per pass on purpose: hoisted out of the pass loop, the 32 lane masks of the selects below
+            // occupy 64 scalar registers for the whole kernel and push the loop's scalars into spills
+            asm volatile("" : "+v"(lim));
             float sum = 0.f;
             // all 16 LDS reads are issued back to back (reading past the frame stays inside the tile);
             // samples past the frame are then selected away, never multiplied: zero padding is exact
@@ -1179,8 +1187,12 @@ static void stft512_launch(bool zmean, dim3 grid, int lds, hipStream_t st, const
                            int P, int left, int mode, const float* w, const float* tw, float eps, int use_floor,
                            float floor_lin, int fmt, float* y, long total_chunks, int chunks_per_utt, int io_floats)
 {
+    const bool plain = !use_floor && fmt == DSA_SPEC_POWER && mode == DSA_PAD_CONSTANT;
     if (zmean)
         hipLaunchKernelGGL((stft512_fwd_kernel<ABL, true>), grid, dim3(64), lds, st, x, T, N, L, P, left, mode, w, tw,
+                           eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
+    else if (plain)
+        hipLaunchKernelGGL((stft512_fwd_kernel<ABL, false, true>), grid, dim3(64), lds, st, x, T, N, L, P, left, mode, w, tw,
                            eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
     else
         hipLaunchKernelGGL((stft512_fwd_kernel<ABL, false>), grid, dim3(64), lds, st, x, T, N, L, P, left, mode, w, tw,
