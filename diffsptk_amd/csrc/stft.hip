@@ -909,14 +909,21 @@ static int launch_row_dft(const void* x, int64_t B, int64_t Tlen, int64_t N, int
 //   one contiguous partial span of 3P + L samples per pass, written to `part` (pass-major).
 // A second kernel (stft_span_gather_kernel) adds the <= ceil((3P+L)/(4P)) partial spans that cover
 // each waveform sample in a fixed order: deterministic, no atomics.
+#ifndef DSA_STFT_BWD_WAVES
+#define DSA_STFT_BWD_WAVES 3
+#endif
 // CPLX: the cotangent is complex (format "complex" or an inverse transform): X is not needed, so the
 // input stretch is not staged and the forward FFT is skipped.
-template <bool ZMEAN, bool CPLX = false>
-__global__ __launch_bounds__(64, 3) void stft512_bwd_kernel(
+// PLAIN: power format with constant padding, fixed at compile time (the training path of the bench
+// configuration): the format switch and the padding modes leave the register allocation.
+template <bool ZMEAN, bool CPLX = false, bool PLAIN = false>
+__global__ __launch_bounds__(64, DSA_STFT_BWD_WAVES) void stft512_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gy, long Tlen, long N, int L, int P, int left,
-    int mode, const float* __restrict__ w, const float* __restrict__ twiddle, float eps, int fmt,
+    int mode_arg, const float* __restrict__ w, const float* __restrict__ twiddle, float eps, int fmt_arg,
     float* __restrict__ part, long total_chunks, int chunks_per_utt, int span)
 {
+    const int fmt = PLAIN ? (int)DSA_SPEC_POWER : fmt_arg;
+    const int mode = PLAIN ? (int)DSA_PAD_CONSTANT : mode_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf* zbuf = reinterpret_cast<cf*>(smem_raw);
     float* io_buf = reinterpret_cast<float*>(smem_raw);
@@ -961,7 +968,8 @@ __global__ __launch_bounds__(64, 3) void stft512_bwd_kernel(
         const float* xb = x + b * Tlen;
         __syncthreads();
         cf v[16];
-        const int lim = L - 2 * j;
+        int lim = L - 2 * j;
+        asm volatile("" : "+v"(lim));   // per pass on purpose: hoisted, the lane masks of the selects fill the scalar registers
         if constexpr (!CPLX) {
         {   // stage the input stretch
             const long g0 = frame0 * P - left;
@@ -1644,19 +1652,20 @@ DSA_EXPORT int dsa_stft_bwd(const void* gy, const void* x, int64_t B, int64_t T,
             if (hipMallocAsync((void**)&part, sizeof(float) * (size_t)total_chunks * span, st) != hipSuccess)
                 return fail(DSA_ERR_LAUNCH, "stft_bwd: workspace allocation failed%s");
             int waves_per_cu = 144 * 1024 / lds;
-            if (waves_per_cu > 12) waves_per_cu = 12;
+            if (waves_per_cu > 4 * DSA_STFT_BWD_WAVES) waves_per_cu = 4 * DSA_STFT_BWD_WAVES;
             long grid = 256L * waves_per_cu;
             if (grid > total_chunks) grid = total_chunks;
             int left = center ? L / 2 : 0;
             const bool cplx = out_format == DSA_SPEC_COMPLEX || out_format == DSA_SPEC_COMPLEX_INV;
-#define DSA_STFT_BWD_LAUNCH(ZM, CP)                                                                                       \
-    hipLaunchKernelGGL((stft512_bwd_kernel<ZM, CP>), dim3((unsigned)grid), dim3(64), lds, st, (const float*)x,            \
+#define DSA_STFT_BWD_LAUNCH(ZM, CP, PL)                                                                                   \
+    hipLaunchKernelGGL((stft512_bwd_kernel<ZM, CP, PL>), dim3((unsigned)grid), dim3(64), lds, st, (const float*)x,        \
                        (const float*)gy, (long)T, (long)N, L, P, left, pad_mode, (const float*)w, (const float*)twiddle, \
                        (float)eps, out_format, part, total_chunks, chunks_per_utt, span)
-            if (zmean && cplx) DSA_STFT_BWD_LAUNCH(true, true);
-            else if (zmean) DSA_STFT_BWD_LAUNCH(true, false);
-            else if (cplx) DSA_STFT_BWD_LAUNCH(false, true);
-            else DSA_STFT_BWD_LAUNCH(false, false);
+            if (zmean && cplx) DSA_STFT_BWD_LAUNCH(true, true, false);
+            else if (zmean) DSA_STFT_BWD_LAUNCH(true, false, false);
+            else if (cplx) DSA_STFT_BWD_LAUNCH(false, true, false);
+            else if (out_format == DSA_SPEC_POWER && pad_mode == DSA_PAD_CONSTANT) DSA_STFT_BWD_LAUNCH(false, false, true);
+            else DSA_STFT_BWD_LAUNCH(false, false, false);
 #undef DSA_STFT_BWD_LAUNCH
             int rc = check_launch("stft512_bwd");
             if (rc == DSA_OK) {
