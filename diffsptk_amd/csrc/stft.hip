@@ -542,7 +542,7 @@ __global__ void remove_gain_kernel(const T* __restrict__ a, long F, int la, T* _
 
 // =========================================================================== tuned rFFT-512 path
 
-struct cf {
+struct alignas(8) cf {   // 8-byte aligned: LDS accesses of a complex value become one ds_read_b64 / ds_write_b64 (not read2_b32 pairs)
     float re, im;
 };
 __device__ __forceinline__ cf operator+(cf a, cf b) { return {a.re + b.re, a.im + b.im}; }
