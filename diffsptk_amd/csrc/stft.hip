@@ -672,6 +672,10 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
     int ci = (int)((long)blockIdx.x - b * chunks_per_utt);
     const long b_step = (long)gridDim.x / chunks_per_utt;
     const int ci_step = (int)((long)gridDim.x - b_step * chunks_per_utt);
+    // PLAIN: the NEXT pass's stretch is fetched into registers (3 x float4 per lane) while this pass computes, so
+    // the HBM round trip leaves the dependent chain of a pass; possible because this instantiation does not spill.
+    float4 pre0 = make_float4(0.f, 0.f, 0.f, 0.f), pre1 = pre0, pre2 = pre0;
+    bool pre_ok = false;
     for (long c = blockIdx.x; c < total_chunks; c += gridDim.x, b += b_step, ci += ci_step) {
         if (ci >= chunks_per_utt) {
             ci -= chunks_per_utt;
@@ -687,7 +691,13 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
             const long g0 = frame0 * P - left;
             const int need = (nvalid - 1) * P + L;  // samples the valid frames touch
             const bool interior = g0 >= 0 && g0 + need <= Tlen;
-            if (interior && (((size_t)(xb + g0)) & 15) == 0) {
+            if (PLAIN && pre_ok) {
+                float4* dst4 = reinterpret_cast<float4*>(io_buf);
+                const int n4 = need >> 2;
+                if (lane < n4) dst4[lane] = pre0;
+                if (lane + 64 < n4) dst4[lane + 64] = pre1;
+                if (lane + 128 < n4) dst4[lane + 128] = pre2;
+            } else if (interior && (((size_t)(xb + g0)) & 15) == 0) {
                 const float4* src4 = reinterpret_cast<const float4*>(xb + g0);
                 float4* dst4 = reinterpret_cast<float4*>(io_buf);
                 const int n4 = need >> 2;
@@ -699,6 +709,30 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
         }
         DSA_WAVE_SYNC();
         STFT_STAMP(1);
+        if (PLAIN && ABL != 3) {   // issue the next pass's loads (no wait here)
+            long b2 = b + b_step;
+            int ci2 = ci + ci_step;
+            if (ci2 >= chunks_per_utt) {
+                ci2 -= chunks_per_utt;
+                ++b2;
+            }
+            pre_ok = false;
+            if (c + gridDim.x < total_chunks) {
+                const long fr2 = (long)ci2 * kFPW;
+                const int nv2 = (int)((N - fr2) < kFPW ? (N - fr2) : kFPW);
+                const long g2 = fr2 * P - left;
+                const int need2 = (nv2 - 1) * P + L;
+                const float* xb2 = x + b2 * Tlen;
+                if (g2 >= 0 && g2 + need2 <= Tlen && (((size_t)(xb2 + g2)) & 15) == 0 && (need2 & 3) == 0 && need2 <= 768) {
+                    const float4* src4 = reinterpret_cast<const float4*>(xb2 + g2);
+                    const int n4 = need2 >> 2;
+                    pre0 = src4[lane < n4 ? lane : n4 - 1];
+                    pre1 = src4[lane + 64 < n4 ? lane + 64 : n4 - 1];
+                    pre2 = src4[lane + 128 < n4 ? lane + 128 : n4 - 1];
+                    pre_ok = true;
+                }
+            }
+        }
         // ---- per frame: window, 256-point complex FFT (16 lanes x 16 points) ----
         cf v[16];
         {
