@@ -596,7 +596,7 @@ constexpr int kTile = kFPW * 257;  // floats in one output tile (4 rows)
 // Per-frame stride of the forward kernel's complex tile: ODD, so that the 8-byte transposed reads of the two
 // frames a 32-lane LDS service group covers land on opposite bank parities (stride 256: 2-way conflict on
 // every one of the 16 reads; PMC: 39 % of the kernel's LDS cycles were conflict cycles).
-constexpr int kZS = 257;
+constexpr int kZS = 272;   // = 16 x 17: the padded transpose tile of a frame (see the forward kernel)
 
 #ifdef DSA_STFT_TIMING
 __device__ unsigned long long g_stft_stamps[16];
@@ -616,7 +616,7 @@ __device__ unsigned long long g_stft_stamps[16];
 // LDS is kept to ~10 KB per wave so that 12+ waves fit a CU (the pass is a long dependent chain;
 // throughput comes from waves in flight):
 //   zbuf[kFPW][256] cf : (a) first the input stretch (3P + L floats), (b) then the 16 x 16
-//                        transpose tiles (XOR-swizzled: element (k1, j) at k1*16 + (j ^ k1)),
+//                        transpose tiles (row stride 17: element (k1, j) at k1*17 + j),
 //                        (c) then the spectra Z in natural order, (d) finally the staged 4 x 257
 //                        output tile -- each use is dead before the next begins;
 //   t256[16][16] cf    : W256^(j k1), shared by the 4 frames;   fmax[kFPW].
@@ -628,7 +628,10 @@ __device__ unsigned long long g_stft_stamps[16];
 #define DSA_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 // PLAIN: power format, no relative floor, constant padding, fixed at compile time (the bench path): the format
 // branches and the per-frame maxima leave the register allocation.
-template <int ABL, bool ZMEAN, bool PLAIN = false>
+// LC: frame length fixed at compile time (0 = runtime).  With LC = 400 the selects that cut a lane's 32 samples at
+// the frame end fold away for 15 of the 16 sample pairs, and the three pairs past the frame are constant zeros
+// that the compiler propagates through the first FFT stage.
+template <int ABL, bool ZMEAN, bool PLAIN = false, int LC = 0>
 __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
     const float* __restrict__ x, long Tlen, long N, int L, int P, int left, int mode_arg,
     const float* __restrict__ w, const float* __restrict__ twiddle, float eps, int use_floor_arg,
@@ -737,10 +740,10 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
         cf v[16];
         {
             const float* src = io_buf + fl * P + 2 * j;
-            int lim = L - 2 * j;  // element (m1, c) belongs to the frame iff 32 m1 + c < lim
+            int lim = (LC ? LC : L) - 2 * j;  // element (m1, c) belongs to the frame iff 32 m1 + c < lim
             // recomputed per pass on purpose: hoisted out of the pass loop, the 32 lane masks of the selects below
             // occupy 64 scalar registers for the whole kernel and push the loop's scalars into spills
-            asm volatile("" : "+v"(lim));
+            if (!LC) asm volatile("" : "+v"(lim));
             float sum = 0.f;
             // all 16 LDS reads are issued back to back (reading past the frame stays inside the tile);
             // samples past the frame are then selected away, never multiplied: zero padding is exact
@@ -776,12 +779,12 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
         if (ABL != 2) fft16<false>(v);
         STFT_STAMP(3);
 #pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1)  // twiddle, then transposed store: (k1, j) -> k1*16 + (j ^ k1)
-            zf[k1 * 16 + (j ^ k1)] = cmul(v[FFT16_OUT(k1)], t256[k1 * 16 + j]);
+        for (int k1 = 0; k1 < 16; ++k1)  // twiddle, then transposed store: (k1, j) -> k1*17 + j (row stride 17: every
+            zf[k1 * 17 + j] = cmul(v[FFT16_OUT(k1)], t256[k1 * 16 + j]);   // address is lane base + immediate, no XOR math)
         DSA_WAVE_SYNC();
         STFT_STAMP(4);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = zf[j * 16 + (i ^ j)];  // lane k1 = j reads A[i][k1]
+        for (int i = 0; i < 16; ++i) v[i] = zf[j * 17 + i];  // lane k1 = j reads A[i][k1]: 34 j floats apart, 16 distinct bank pairs
         DSA_WAVE_SYNC();
         STFT_STAMP(5);
         if (ABL != 2) fft16<false>(v);
@@ -1233,6 +1236,9 @@ static void stft512_launch(bool zmean, dim3 grid, int lds, hipStream_t st, const
     if (zmean)
         hipLaunchKernelGGL((stft512_fwd_kernel<ABL, true>), grid, dim3(64), lds, st, x, T, N, L, P, left, mode, w, tw,
                            eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
+    else if (plain && L == 400)
+        hipLaunchKernelGGL((stft512_fwd_kernel<ABL, false, true, 400>), grid, dim3(64), lds, st, x, T, N, L, P, left, mode, w,
+                           tw, eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
     else if (plain)
         hipLaunchKernelGGL((stft512_fwd_kernel<ABL, false, true>), grid, dim3(64), lds, st, x, T, N, L, P, left, mode, w, tw,
                            eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
