@@ -661,7 +661,8 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
     }
     for (int i = lane; i < 256; i += 64) {
         int m = 2 * (i & 15) * (i >> 4);  // entry [k1 = i >> 4][j = i & 15]: W256^(j k1) = W512^(2 j k1)
-        t256[i] = cf{twiddle[2 * m], twiddle[2 * m + 1]};
+        // HALVED: the factor 1/2 of the real-FFT split X[k] = (S + ...) / 2 rides on the twiddle (exact: a power of two)
+        t256[i] = cf{0.5f * twiddle[2 * m], 0.5f * twiddle[2 * m + 1]};
     }
     const cf twA = cf{twiddle[2 * (lane + 1)], twiddle[2 * (lane + 1) + 1]};    // W512^(lane+1)
     const cf twB = cf{twiddle[2 * (lane + 65)], twiddle[2 * (lane + 65) + 1]};  // W512^(lane+65)
@@ -825,8 +826,8 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
                 const cf S = {a.re + bq.re, a.im - bq.im};
                 const cf Dd = {a.re - bq.re, a.im + bq.im};
                 const cf Pp = cmul(W, Dd);
-                const cf X1 = {0.5f * (S.re + Pp.im), 0.5f * (S.im - Pp.re)};
-                const cf X2 = {0.5f * (S.re - Pp.im), 0.5f * (-S.im - Pp.re)};
+                const cf X1 = {S.re + Pp.im, S.im - Pp.re};     // Z arrives halved (see t256)
+                const cf X2 = {S.re - Pp.im, -S.im - Pp.re};
                 if (complex_out) {
                     if (f < nvalid && ABL != 1) {
                         y2[out0 + f * K + k] = make_float2(X1.re, X1.im);
@@ -844,7 +845,7 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
                 }
             }
             // the two real-valued end bins
-            const float x0 = z0[f].re + z0[f].im, x256 = z0[f].re - z0[f].im;
+            const float x0 = 2.f * (z0[f].re + z0[f].im), x256 = 2.f * (z0[f].re - z0[f].im);   // these two take Z[0] whole
             if (complex_out) {
                 if (f < nvalid && ABL != 1 && lane == 0) {
                     y2[out0 + f * K] = make_float2(x0, 0.f);
