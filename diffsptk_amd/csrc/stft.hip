@@ -602,7 +602,7 @@ constexpr int kZS = 272;   // = 16 x 17: the padded transpose tile of a frame (s
 __device__ unsigned long long g_stft_stamps[16];
 #define STFT_STAMP(i)                                                                 \
     do {                                                                              \
-        if (blockIdx.x == 0 && threadIdx.x == 0 && c == (long)blockIdx.x + gridDim.x) \
+        if (wid == 0 && lane == 0 && c == nw)                                         \
             g_stft_stamps[i] = __builtin_readcyclecounter();                          \
     } while (0)
 #else
@@ -631,8 +631,12 @@ __device__ unsigned long long g_stft_stamps[16];
 // LC: frame length fixed at compile time (0 = runtime).  With LC = 400 the selects that cut a lane's 32 samples at
 // the frame end fold away for 15 of the 16 sample pairs, and the three pairs past the frame are constant zeros
 // that the compiler propagates through the first FFT stage.
+// The PLAIN instantiations need < 128 registers (stft.hip is built without packed-float32 selection), so four
+// waves fit a SIMD; LDS is what limits them then, so two waves share a workgroup and with it the 2 KB twiddle table
+// (8 workgroups x 19.5 KB per CU).  The waves stay autonomous: each fills the whole table itself (identical values)
+// before its first use, and no barrier is ever needed.
 template <int ABL, bool ZMEAN, bool PLAIN = false, int LC = 0>
-__global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
+__global__ __launch_bounds__(PLAIN ? 128 : 64, PLAIN ? 4 : 3) void stft512_fwd_kernel(
     const float* __restrict__ x, long Tlen, long N, int L, int P, int left, int mode_arg,
     const float* __restrict__ w, const float* __restrict__ twiddle, float eps, int use_floor_arg,
     float floor_lin, int fmt_arg, float* __restrict__ y, long total_chunks, int chunks_per_utt,
@@ -642,13 +646,16 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
     const int fmt = PLAIN ? (int)DSA_SPEC_POWER : fmt_arg;
     const int mode = PLAIN ? (int)DSA_PAD_CONSTANT : mode_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf* zbuf = reinterpret_cast<cf*>(smem_raw);
-    float* io_buf = reinterpret_cast<float*>(smem_raw);  // aliases zbuf (see above)
-    cf* t256 = zbuf + kFPW * kZS;
+    constexpr int WPB = PLAIN ? 2 : 1;   // waves per workgroup
+    const int wv = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    cf* zbuf = reinterpret_cast<cf*>(smem_raw) + wv * kFPW * kZS;
+    float* io_buf = reinterpret_cast<float*>(zbuf);  // aliases zbuf (see above)
+    cf* t256 = reinterpret_cast<cf*>(smem_raw) + WPB * kFPW * kZS;
     float* fmax = reinterpret_cast<float*>(t256 + 256);
     (void)io_floats;
+    const long wid = (long)blockIdx.x * WPB + wv, nw = (long)gridDim.x * WPB;   // this wave, all waves
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int j = lane & 15;   // lane within the frame group
     const int fl = lane >> 4;  // frame slot within the pass (0..3)
 
@@ -672,15 +679,15 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
     cf* zf = zbuf + fl * kZS;
 
     // (utterance, chunk) of pass c advance incrementally: one 64-bit division per wave instead of one per pass
-    long b = (long)blockIdx.x / chunks_per_utt;
-    int ci = (int)((long)blockIdx.x - b * chunks_per_utt);
-    const long b_step = (long)gridDim.x / chunks_per_utt;
-    const int ci_step = (int)((long)gridDim.x - b_step * chunks_per_utt);
+    long b = wid / chunks_per_utt;
+    int ci = (int)(wid - b * chunks_per_utt);
+    const long b_step = nw / chunks_per_utt;
+    const int ci_step = (int)(nw - b_step * chunks_per_utt);
     // PLAIN: the NEXT pass's stretch is fetched into registers (3 x float4 per lane) while this pass computes, so
     // the HBM round trip leaves the dependent chain of a pass; possible because this instantiation does not spill.
     float4 pre0 = make_float4(0.f, 0.f, 0.f, 0.f), pre1 = pre0, pre2 = pre0;
     bool pre_ok = false;
-    for (long c = blockIdx.x; c < total_chunks; c += gridDim.x, b += b_step, ci += ci_step) {
+    for (long c = wid; c < total_chunks; c += nw, b += b_step, ci += ci_step) {
         if (ci >= chunks_per_utt) {
             ci -= chunks_per_utt;
             ++b;
@@ -721,7 +728,7 @@ __global__ __launch_bounds__(64, 3) void stft512_fwd_kernel(
                 ++b2;
             }
             pre_ok = false;
-            if (c + gridDim.x < total_chunks) {
+            if (c + nw < total_chunks) {
                 const long fr2 = (long)ci2 * kFPW;
                 const int nv2 = (int)((N - fr2) < kFPW ? (N - fr2) : kFPW);
                 const long g2 = fr2 * P - left;
@@ -1237,12 +1244,16 @@ static void stft512_launch(bool zmean, dim3 grid, int lds, hipStream_t st, const
     if (zmean)
         hipLaunchKernelGGL((stft512_fwd_kernel<ABL, true>), grid, dim3(64), lds, st, x, T, N, L, P, left, mode, w, tw,
                            eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
-    else if (plain && L == 400)
-        hipLaunchKernelGGL((stft512_fwd_kernel<ABL, false, true, 400>), grid, dim3(64), lds, st, x, T, N, L, P, left, mode, w,
-                           tw, eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
-    else if (plain)
-        hipLaunchKernelGGL((stft512_fwd_kernel<ABL, false, true>), grid, dim3(64), lds, st, x, T, N, L, P, left, mode, w, tw,
-                           eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
+    else if (plain) {   // `grid` counts waves; the plain instantiations pair them into 128-thread workgroups
+        const dim3 g2((grid.x + 1) / 2);
+        const int lds2 = 2 * kFPW * kZS * 8 + 256 * 8 + 16;
+        if (L == 400)
+            hipLaunchKernelGGL((stft512_fwd_kernel<ABL, false, true, 400>), g2, dim3(128), lds2, st, x, T, N, L, P, left, mode,
+                               w, tw, eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
+        else
+            hipLaunchKernelGGL((stft512_fwd_kernel<ABL, false, true>), g2, dim3(128), lds2, st, x, T, N, L, P, left, mode, w,
+                               tw, eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
+    }
     else
         hipLaunchKernelGGL((stft512_fwd_kernel<ABL, false>), grid, dim3(64), lds, st, x, T, N, L, P, left, mode, w, tw,
                            eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
@@ -1551,7 +1562,9 @@ DSA_EXPORT int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int3
         int waves_per_cu = 144 * 1024 / lds;
         if (waves_per_cu > 12) waves_per_cu = 12;
         if (waves_per_cu < 1) waves_per_cu = 1;
-        long grid = 256L * waves_per_cu;  // persistent single-wave workgroups
+        if (!zmean && !use_floor && out_format == DSA_SPEC_POWER && pad_mode == DSA_PAD_CONSTANT)
+            waves_per_cu = 16;   // the plain instantiations: four waves per SIMD
+        long grid = 256L * waves_per_cu;  // persistent waves
         if (grid > total_chunks) grid = total_chunks;
         float floor_lin = use_floor ? (float)pow(10.0, relative_floor_db / 10.0) : 0.f;
         stft512_launch<0>(zmean != 0, dim3((unsigned)grid), lds, st, (const float*)x, (long)T, (long)N, L, P, left,

@@ -55,7 +55,7 @@ int main(int argc, char** argv)
     hipMemcpy(w, hw.data(), 400 * 4, hipMemcpyHostToDevice);
     hipMemcpy(tw, htw.data(), 1024 * 4, hipMemcpyHostToDevice);
     double bytes = (double)B * N * 1348.0;
-    for (int wpc : {4, 8, 12}) {
+    for (int wpc : {8, 12, 16}) {
         float t0 = run<0>(x, B, T, w, tw, y, 20, wpc);
         float t1 = run<1>(x, B, T, w, tw, y, 20, wpc);
         float t2 = run<2>(x, B, T, w, tw, y, 20, wpc);
