@@ -962,7 +962,7 @@ static int launch_row_dft(const void* x, int64_t B, int64_t Tlen, int64_t N, int
 // PLAIN: power format with constant padding, fixed at compile time (the training path of the bench
 // configuration): the format switch and the padding modes leave the register allocation.
 template <bool ZMEAN, bool CPLX = false, bool PLAIN = false>
-__global__ __launch_bounds__(64, DSA_STFT_BWD_WAVES) void stft512_bwd_kernel(
+__global__ __launch_bounds__(PLAIN ? 128 : 64, PLAIN ? 4 : DSA_STFT_BWD_WAVES) void stft512_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gy, long Tlen, long N, int L, int P, int left,
     int mode_arg, const float* __restrict__ w, const float* __restrict__ twiddle, float eps, int fmt_arg,
     float* __restrict__ part, long total_chunks, int chunks_per_utt, int span)
@@ -970,11 +970,14 @@ __global__ __launch_bounds__(64, DSA_STFT_BWD_WAVES) void stft512_bwd_kernel(
     const int fmt = PLAIN ? (int)DSA_SPEC_POWER : fmt_arg;
     const int mode = PLAIN ? (int)DSA_PAD_CONSTANT : mode_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf* zbuf = reinterpret_cast<cf*>(smem_raw);
-    float* io_buf = reinterpret_cast<float*>(smem_raw);
-    cf* t256 = zbuf + kFPW * 256;
+    constexpr int WPB = PLAIN ? 2 : 1;   // waves per workgroup (they share the twiddle table only, as in the forward)
+    const int wv = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    cf* zbuf = reinterpret_cast<cf*>(smem_raw) + wv * kFPW * kZS;
+    float* io_buf = reinterpret_cast<float*>(zbuf);
+    cf* t256 = WPB > 1 ? reinterpret_cast<cf*>(smem_raw) + WPB * kFPW * kZS : zbuf + kFPW * 256;
+    const long wid = (long)blockIdx.x * WPB + wv, nw = (long)gridDim.x * WPB;
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int j = lane & 15, fl = lane >> 4;
     float wreg[32];
 #pragma unroll
@@ -999,11 +1002,11 @@ __global__ __launch_bounds__(64, DSA_STFT_BWD_WAVES) void stft512_bwd_kernel(
     const float2* gy2 = reinterpret_cast<const float2*>(gy);
 
     // (utterance, chunk) of pass c advance incrementally: one 64-bit division per wave instead of one per pass
-    long b = (long)blockIdx.x / chunks_per_utt;
-    int ci = (int)((long)blockIdx.x - b * chunks_per_utt);
-    const long b_step = (long)gridDim.x / chunks_per_utt;
-    const int ci_step = (int)((long)gridDim.x - b_step * chunks_per_utt);
-    for (long c = blockIdx.x; c < total_chunks; c += gridDim.x, b += b_step, ci += ci_step) {
+    long b = wid / chunks_per_utt;
+    int ci = (int)(wid - b * chunks_per_utt);
+    const long b_step = nw / chunks_per_utt;
+    const int ci_step = (int)(nw - b_step * chunks_per_utt);
+    for (long c = wid; c < total_chunks; c += nw, b += b_step, ci += ci_step) {
         if (ci >= chunks_per_utt) {
             ci -= chunks_per_utt;
             ++b;
@@ -1011,7 +1014,7 @@ __global__ __launch_bounds__(64, DSA_STFT_BWD_WAVES) void stft512_bwd_kernel(
         const long frame0 = (long)ci * kFPW;
         const int nvalid = (int)((N - frame0) < kFPW ? (N - frame0) : kFPW);
         const float* xb = x + b * Tlen;
-        __syncthreads();
+        DSA_WAVE_SYNC();
         cf v[16];
         int lim = L - 2 * j;
         asm volatile("" : "+v"(lim));   // per pass on purpose: hoisted, the lane masks of the selects fill the scalar registers
@@ -1030,7 +1033,7 @@ __global__ __launch_bounds__(64, DSA_STFT_BWD_WAVES) void stft512_bwd_kernel(
                 for (int s = lane; s < need; s += 64) io_buf[s] = load_padded(xb, g0 + s, Tlen, mode);
             }
         }
-        __syncthreads();
+        DSA_WAVE_SYNC();
         {
             const float* src = io_buf + fl * P + 2 * j;
             float sum = 0.f;
@@ -1063,18 +1066,18 @@ __global__ __launch_bounds__(64, DSA_STFT_BWD_WAVES) void stft512_bwd_kernel(
                 v[m1] = cf{a0 * wreg[2 * m1], a1 * wreg[2 * m1 + 1]};
             }
         }
-        __syncthreads();
+        DSA_WAVE_SYNC();
         fft16<false>(v);
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) zf[k1 * 16 + (j ^ k1)] = cmul(v[FFT16_OUT(k1)], t256[k1 * 16 + j]);
-        __syncthreads();
+        DSA_WAVE_SYNC();
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = zf[j * 16 + (i ^ j)];
-        __syncthreads();
+        DSA_WAVE_SYNC();
         fft16<false>(v);
 #pragma unroll
         for (int k0 = 0; k0 < 16; ++k0) zf[j + 16 * k0] = v[FFT16_OUT(k0)];
-        __syncthreads();
+        DSA_WAVE_SYNC();
         }
         // ---- split, cotangent, Hermitian packing (pairs read first, then written in place) ----
         const long out0 = (b * N + frame0) * K;
@@ -1093,7 +1096,7 @@ __global__ __launch_bounds__(64, DSA_STFT_BWD_WAVES) void stft512_bwd_kernel(
                 pb[f][2] = pa[f][2];
             }
         }
-        __syncthreads();
+        DSA_WAVE_SYNC();
 #pragma unroll
         for (int f = 0; f < kFPW; ++f) {
             cf* z = zbuf + f * 256;
@@ -1150,21 +1153,21 @@ __global__ __launch_bounds__(64, DSA_STFT_BWD_WAVES) void stft512_bwd_kernel(
                 }
             }
         }
-        __syncthreads();
+        DSA_WAVE_SYNC();
         // ---- inverse FFT-256 (unnormalised, conjugated twiddles), same data movement ----
 #pragma unroll
         for (int m1 = 0; m1 < 16; ++m1) v[m1] = zf[j + 16 * m1];
-        __syncthreads();
+        DSA_WAVE_SYNC();
         fft16<true>(v);
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) {
             const cf t = t256[k1 * 16 + j];
             zf[k1 * 16 + (j ^ k1)] = cmul(v[FFT16_OUT(k1)], cf{t.re, -t.im});
         }
-        __syncthreads();
+        DSA_WAVE_SYNC();
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = zf[j * 16 + (i ^ j)];
-        __syncthreads();
+        DSA_WAVE_SYNC();
         fft16<true>(v);
         // lane j now holds time points m = j + 16 k0: samples l = 2m, 2m+1 -- the forward's own
         // register <-> sample map, so the window (and zmean adjoint) reuse wreg / the 16-lane sum
@@ -1193,7 +1196,7 @@ __global__ __launch_bounds__(64, DSA_STFT_BWD_WAVES) void stft512_bwd_kernel(
                 zf[j + 16 * k0] = o;  // gframe[l] as floats: l = 2 (j + 16 k0) + {0, 1}
             }
         }
-        __syncthreads();
+        DSA_WAVE_SYNC();
         // ---- overlap-add of the pass's frames; one contiguous partial span per pass ----
         float* dst = part + c * (long)span;
         for (int sidx = lane; sidx < span; sidx += 64) {
@@ -1722,7 +1725,16 @@ DSA_EXPORT int dsa_stft_bwd(const void* gy, const void* x, int64_t B, int64_t T,
             if (zmean && cplx) DSA_STFT_BWD_LAUNCH(true, true, false);
             else if (zmean) DSA_STFT_BWD_LAUNCH(true, false, false);
             else if (cplx) DSA_STFT_BWD_LAUNCH(false, true, false);
-            else if (out_format == DSA_SPEC_POWER && pad_mode == DSA_PAD_CONSTANT) DSA_STFT_BWD_LAUNCH(false, false, true);
+            else if (out_format == DSA_SPEC_POWER && pad_mode == DSA_PAD_CONSTANT) {
+                // the plain instantiation: four waves per SIMD in two-wave workgroups (as the forward)
+                long waves = 256L * 16;
+                if (waves > total_chunks) waves = total_chunks;
+                const int lds2 = 2 * kFPW * kZS * 8 + 256 * 8 + 16;
+                hipLaunchKernelGGL((stft512_bwd_kernel<false, false, true>), dim3((unsigned)((waves + 1) / 2)), dim3(128), lds2,
+                                   st, (const float*)x, (const float*)gy, (long)T, (long)N, L, P, left, pad_mode,
+                                   (const float*)w, (const float*)twiddle, (float)eps, out_format, part, total_chunks,
+                                   chunks_per_utt, span);
+            }
             else DSA_STFT_BWD_LAUNCH(false, false, false);
 #undef DSA_STFT_BWD_LAUNCH
             int rc = check_launch("stft512_bwd");
