@@ -962,7 +962,7 @@ static int launch_row_dft(const void* x, int64_t B, int64_t Tlen, int64_t N, int
 // PLAIN: power format with constant padding, fixed at compile time (the training path of the bench
 // configuration): the format switch and the padding modes leave the register allocation.
 template <bool ZMEAN, bool CPLX = false, bool PLAIN = false>
-__global__ __launch_bounds__(PLAIN ? 128 : 64, PLAIN ? 4 : DSA_STFT_BWD_WAVES) void stft512_bwd_kernel(
+__global__ __launch_bounds__((PLAIN || CPLX) ? 128 : 64, (PLAIN || CPLX) ? 4 : DSA_STFT_BWD_WAVES) void stft512_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gy, long Tlen, long N, int L, int P, int left,
     int mode_arg, const float* __restrict__ w, const float* __restrict__ twiddle, float eps, int fmt_arg,
     float* __restrict__ part, long total_chunks, int chunks_per_utt, int span)
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(PLAIN ? 128 : 64, PLAIN ? 4 : DSA_STFT_BWD_WAVES) v
     const int fmt = PLAIN ? (int)DSA_SPEC_POWER : fmt_arg;
     const int mode = PLAIN ? (int)DSA_PAD_CONSTANT : mode_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int WPB = PLAIN ? 2 : 1;   // waves per workgroup (they share the twiddle table only, as in the forward)
+    constexpr int WPB = (PLAIN || CPLX) ? 2 : 1;   // waves per workgroup (they share the twiddle table only, as in the forward)
     const int wv = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     cf* zbuf = reinterpret_cast<cf*>(smem_raw) + wv * kFPW * kZS;
     float* io_buf = reinterpret_cast<float*>(zbuf);
@@ -1722,9 +1722,21 @@ DSA_EXPORT int dsa_stft_bwd(const void* gy, const void* x, int64_t B, int64_t T,
     hipLaunchKernelGGL((stft512_bwd_kernel<ZM, CP, PL>), dim3((unsigned)grid), dim3(64), lds, st, (const float*)x,        \
                        (const float*)gy, (long)T, (long)N, L, P, left, pad_mode, (const float*)w, (const float*)twiddle, \
                        (float)eps, out_format, part, total_chunks, chunks_per_utt, span)
-            if (zmean && cplx) DSA_STFT_BWD_LAUNCH(true, true, false);
+            if (cplx) {
+                long waves = 256L * 16;
+                if (waves > total_chunks) waves = total_chunks;
+                const int lds2 = 2 * kFPW * kZS * 8 + 256 * 8 + 16;
+                const dim3 g2((unsigned)((waves + 1) / 2));
+                if (zmean)
+                    hipLaunchKernelGGL((stft512_bwd_kernel<true, true, false>), g2, dim3(128), lds2, st, (const float*)x,
+                                       (const float*)gy, (long)T, (long)N, L, P, left, pad_mode, (const float*)w,
+                                       (const float*)twiddle, (float)eps, out_format, part, total_chunks, chunks_per_utt, span);
+                else
+                    hipLaunchKernelGGL((stft512_bwd_kernel<false, true, false>), g2, dim3(128), lds2, st, (const float*)x,
+                                       (const float*)gy, (long)T, (long)N, L, P, left, pad_mode, (const float*)w,
+                                       (const float*)twiddle, (float)eps, out_format, part, total_chunks, chunks_per_utt, span);
+            }
             else if (zmean) DSA_STFT_BWD_LAUNCH(true, false, false);
-            else if (cplx) DSA_STFT_BWD_LAUNCH(false, true, false);
             else if (out_format == DSA_SPEC_POWER && pad_mode == DSA_PAD_CONSTANT) {
                 // the plain instantiation: four waves per SIMD in two-wave workgroups (as the forward)
                 long waves = 256L * 16;
