@@ -636,7 +636,7 @@ __device__ unsigned long long g_stft_stamps[16];
 // (8 workgroups x 19.5 KB per CU).  The waves stay autonomous: each fills the whole table itself (identical values)
 // before its first use, and no barrier is ever needed.
 template <int ABL, bool ZMEAN, bool PLAIN = false, int LC = 0>
-__global__ __launch_bounds__(PLAIN ? 128 : 64, PLAIN ? 4 : 3) void stft512_fwd_kernel(
+__global__ __launch_bounds__(128, 4) void stft512_fwd_kernel(
     const float* __restrict__ x, long Tlen, long N, int L, int P, int left, int mode_arg,
     const float* __restrict__ w, const float* __restrict__ twiddle, float eps, int use_floor_arg,
     float floor_lin, int fmt_arg, float* __restrict__ y, long total_chunks, int chunks_per_utt,
@@ -646,12 +646,12 @@ __global__ __launch_bounds__(PLAIN ? 128 : 64, PLAIN ? 4 : 3) void stft512_fwd_k
     const int fmt = PLAIN ? (int)DSA_SPEC_POWER : fmt_arg;
     const int mode = PLAIN ? (int)DSA_PAD_CONSTANT : mode_arg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int WPB = PLAIN ? 2 : 1;   // waves per workgroup
-    const int wv = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    constexpr int WPB = 2;   // waves per workgroup
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     cf* zbuf = reinterpret_cast<cf*>(smem_raw) + wv * kFPW * kZS;
     float* io_buf = reinterpret_cast<float*>(zbuf);  // aliases zbuf (see above)
     cf* t256 = reinterpret_cast<cf*>(smem_raw) + WPB * kFPW * kZS;
-    float* fmax = reinterpret_cast<float*>(t256 + 256);
+    float* fmax = reinterpret_cast<float*>(t256 + 256) + wv * kFPW;
     (void)io_floats;
     const long wid = (long)blockIdx.x * WPB + wv, nw = (long)gridDim.x * WPB;   // this wave, all waves
 
@@ -1238,28 +1238,26 @@ static int stft512_lds_bytes(int L, int P, int* io_floats)
     return kFPW * kZS * 8 + 256 * 8 + 16;   // (the backward kernel keeps stride 256 inside the same allocation)
 }
 
+static int stft512_lds_bytes2() { return 2 * kFPW * kZS * 8 + 256 * 8 + 2 * kFPW * 4; }   // two waves + the shared table
+
 template <int ABL>
 static void stft512_launch(bool zmean, dim3 grid, int lds, hipStream_t st, const float* x, long T, long N, int L,
                            int P, int left, int mode, const float* w, const float* tw, float eps, int use_floor,
                            float floor_lin, int fmt, float* y, long total_chunks, int chunks_per_utt, int io_floats)
 {
+    // `grid` counts waves; they are paired into 128-thread workgroups that share the twiddle table
+    (void)lds;
     const bool plain = !use_floor && fmt == DSA_SPEC_POWER && mode == DSA_PAD_CONSTANT;
-    if (zmean)
-        hipLaunchKernelGGL((stft512_fwd_kernel<ABL, true>), grid, dim3(64), lds, st, x, T, N, L, P, left, mode, w, tw,
-                           eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
-    else if (plain) {   // `grid` counts waves; the plain instantiations pair them into 128-thread workgroups
-        const dim3 g2((grid.x + 1) / 2);
-        const int lds2 = 2 * kFPW * kZS * 8 + 256 * 8 + 16;
-        if (L == 400)
-            hipLaunchKernelGGL((stft512_fwd_kernel<ABL, false, true, 400>), g2, dim3(128), lds2, st, x, T, N, L, P, left, mode,
-                               w, tw, eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
-        else
-            hipLaunchKernelGGL((stft512_fwd_kernel<ABL, false, true>), g2, dim3(128), lds2, st, x, T, N, L, P, left, mode, w,
-                               tw, eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
-    }
-    else
-        hipLaunchKernelGGL((stft512_fwd_kernel<ABL, false>), grid, dim3(64), lds, st, x, T, N, L, P, left, mode, w, tw,
-                           eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats);
+    const dim3 g2((grid.x + 1) / 2);
+    const int lds2 = stft512_lds_bytes2();
+#define DSA_STFT_FWD_LAUNCH(ZM, PL, LCV)                                                                                 \
+    hipLaunchKernelGGL((stft512_fwd_kernel<ABL, ZM, PL, LCV>), g2, dim3(128), lds2, st, x, T, N, L, P, left, mode, w, tw, \
+                       eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats)
+    if (zmean) DSA_STFT_FWD_LAUNCH(true, false, 0);
+    else if (plain && L == 400) DSA_STFT_FWD_LAUNCH(false, true, 400);
+    else if (plain) DSA_STFT_FWD_LAUNCH(false, true, 0);
+    else DSA_STFT_FWD_LAUNCH(false, false, 0);
+#undef DSA_STFT_FWD_LAUNCH
 }
 
 // ---- inverse path helpers ----
@@ -1565,8 +1563,7 @@ DSA_EXPORT int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int3
         int waves_per_cu = 144 * 1024 / lds;
         if (waves_per_cu > 12) waves_per_cu = 12;
         if (waves_per_cu < 1) waves_per_cu = 1;
-        if (!zmean && !use_floor && out_format == DSA_SPEC_POWER && pad_mode == DSA_PAD_CONSTANT)
-            waves_per_cu = 16;   // the plain instantiations: four waves per SIMD
+        waves_per_cu = 16;   // four waves per SIMD (two-wave workgroups, 19.5 KB of LDS each)
         long grid = 256L * waves_per_cu;  // persistent waves
         if (grid > total_chunks) grid = total_chunks;
         float floor_lin = use_floor ? (float)pow(10.0, relative_floor_db / 10.0) : 0.f;
