@@ -41,7 +41,8 @@ class BackendError(RuntimeError):
 
 def _sources():
     files = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = files + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mcep_mfma_f16.h"), os.path.join(CSRC, "mcep_mfma_bwd_f16.h"), os.path.join(CSRC, "stft_mfma.h"), os.path.join(_ROOT, "include", "diffsptk_amd.h")]
+    deps = files + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mcep_mfma_f16.h"), os.path.join(CSRC, "mcep_mfma_bwd_f16.h"), os.path.join(CSRC, "stft_mfma.h"), os.path.join(_ROOT, "include", "diffsptk_amd.h"),
+                    os.path.abspath(__file__)]   # the build flags live in this file
     return files, deps
 
 
