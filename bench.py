@@ -11,6 +11,10 @@ HBM): fused STFT kernel -> mel-cepstral analysis kernel -> (N > 1) all-gather of
 features over RCCL, issued per quarter-batch chunk so that it overlaps the next chunk's kernels.  Weak scaling: 1024 utterances x 1 s per GPU, so N = 8 is
 BASELINE.json configs[4] (batch 8192 sharded 8x) and N = 1 is its per-GPU shard.
 
+Timing: an untimed clock ramp (--ramp-seconds, default 0.3 s of the same steps: the first ~20 ms after idle run
+10 % slower), W warmup steps, then exactly K steps between barrier + synchronize; defaults K = 200, W = 20
+(0.2 s of GPU time).  HIP events bracket the two launches of every fourth timed step (per-kernel averages).
+
 Rank 0 prints ONE JSON line (contract in the task statement) carrying, besides the headline
 value, `roofline` for the dominant kernel (mel-cepstral analysis, fp32 MFMA/VALU bound),
 `roofline_stft` for the fused Frame+Window+rFFT stage (HBM bound) and `cpu_baseline`
