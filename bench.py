@@ -132,13 +132,19 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if os.environ.get("DSA_BENCH_SINGLE_DEVICE"):   # functional test of the N > 1 control flow on a one-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("DSA_BENCH_BACKEND", "nccl")   # "gloo" only for the one-GPU functional test
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import diffsptk_amd as dsp
     from diffsptk_amd import _lib, ops
@@ -174,27 +180,46 @@ def main():
             kernels["mcep"] = _lib.last_kernel()
         return mc
 
+    in_flight = []   # N > 1: (features, handle) of the previous step, whose last all-gather overlaps this step
+
     def step(record=False):
-        # N > 1: features of chunk c are all-gathered (RCCL) while chunk c+1 is computed
-        return analyze_chunked_overlap(x, lambda xc: compute(xc, record), n_chunks)
+        # N > 1: features of chunk c are all-gathered (RCCL) while chunk c+1 is computed; the LAST chunk's
+        # collective is left in flight and completed one step later (a streaming consumer reads batch k while
+        # batch k+1 is computed), so it hides behind the next step's kernels instead of ending every step
+        if world == 1:
+            return analyze_chunked_overlap(x, lambda xc: compute(xc, record), n_chunks)
+        out, handle = analyze_chunked_overlap(x, lambda xc: compute(xc, record), n_chunks, defer=True)
+        in_flight.append((out, handle))
+        while len(in_flight) > 1:
+            in_flight.pop(0)[1].wait()
+        return out
+
+    def drain():
+        while in_flight:
+            in_flight.pop(0)[1].wait()
 
     with torch.no_grad():
-        if args.ramp_seconds > 0:   # clock ramp: untimed, same workload
+        if args.ramp_seconds > 0:   # clock ramp: untimed, same workload; a fixed count when N > 1 (collectives must match)
             t_ramp = time.perf_counter()
-            while time.perf_counter() - t_ramp < args.ramp_seconds:
+            rounds = 0
+            while (time.perf_counter() - t_ramp < args.ramp_seconds) if world == 1 else (rounds < 30):
                 for _ in range(10):
                     step()
+                drain()
                 torch.cuda.synchronize()
+                rounds += 1
         for _ in range(max(args.warmup, 1)):
             step()
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            # HIP events between the two launches cost about a tenth of a step, so only every fourth step of the
-            # timed region carries them (the per-kernel averages below come from those launches)
+            # HIP events bracket the two launches of every fourth step of the timed region only (the per-kernel
+            # averages below come from those launches)
             out = step(record=(i % 4 == 0))
+        drain()   # every collective of the K steps completes inside the timed region
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

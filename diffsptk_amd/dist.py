@@ -69,8 +69,21 @@ def analyze_sharded(x: torch.Tensor, compute: Callable[[torch.Tensor], torch.Ten
     return all_gather_features(local, x.size(0), group) if gather else local
 
 
+class PendingGather:
+    """Handle of the collectives a deferred ``analyze_chunked_overlap`` left in flight: ``wait()`` orders the
+    current stream (or, on CPU, the caller) after them.  The gathered tensor must not be read before."""
+
+    def __init__(self, works, keep):
+        self._works, self._keep = list(works), list(keep)
+
+    def wait(self) -> None:
+        for w in self._works:
+            w.wait()
+        self._works, self._keep = [], []
+
+
 def analyze_chunked_overlap(x_local: torch.Tensor, compute: Callable[[torch.Tensor], torch.Tensor], n_chunks: int = 2,
-                            group=None, alternate_streams: bool = True) -> torch.Tensor:
+                            group=None, alternate_streams: bool = True, defer: bool = False):
     """Compute this rank's shard ``x_local`` (B_r, T) in ``n_chunks`` utterance chunks and all-gather
     each chunk's features as soon as they exist, so the collective of chunk c runs (on RCCL's own
     stream) while chunk c+1 is being computed.  Every rank must hold the same number of utterances.
@@ -83,9 +96,14 @@ def analyze_chunked_overlap(x_local: torch.Tensor, compute: Callable[[torch.Tens
 
     Returns the gathered features (world * B_r, ...) in rank-major order -- the same tensor
     ``all_gather_features(compute(x_local))`` returns, only the exchange is hidden behind compute.
+
+    ``defer=True`` returns ``(features, PendingGather)`` without waiting for the collectives: the LAST chunk's
+    all-gather has nothing of this call left to hide behind, but the caller's next batch can -- call
+    ``PendingGather.wait()`` before the features are read (a streaming caller does so one batch later).
     """
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return compute(x_local)
+        out1 = compute(x_local)
+        return (out1, PendingGather([], [])) if defer else out1
     world = dist.get_world_size(group)
     B = x_local.size(0)
     n_chunks = max(1, min(n_chunks, B))
@@ -110,13 +128,16 @@ def analyze_chunked_overlap(x_local: torch.Tensor, compute: Callable[[torch.Tens
             # is ordered after this chunk's kernels on the stream that is current here
             work = dist.all_gather([out[r, lo:hi] for r in range(world)], feat, group=group, async_op=True)
         pending.append((work, feat))
-    for work, _keep in pending:
-        work.wait()
     if use_side:
         main.wait_stream(side)
         for _work, keep in pending:
             keep.record_stream(main)
-    return out.reshape(world * B, *out.shape[2:])
+    handle = PendingGather([w for w, _ in pending], [k for _, k in pending] + [out])
+    res = out.reshape(world * B, *out.shape[2:])
+    if defer:
+        return res, handle
+    handle.wait()
+    return res
 
 
 class _NullContext:

@@ -57,6 +57,14 @@ def _worker(rank, world, port, B, q):
             for nch in (1, 2, 3):
                 ov = analyze_chunked_overlap(x[lo:hi], compute, n_chunks=nch)
                 ok = ok and torch.equal(ov, out)
+            # deferred completion: two batches in flight, each read only after its own handle was waited for
+            ov1, h1 = analyze_chunked_overlap(x[lo:hi], compute, n_chunks=2, defer=True)
+            ov2, h2 = analyze_chunked_overlap(x[lo:hi], compute, n_chunks=3, defer=True)
+            h1.wait()
+            ok = ok and torch.equal(ov1, out)
+            h2.wait()
+            h2.wait()   # idempotent
+            ok = ok and torch.equal(ov2, out)
         if rank == 0:
             q.put((ok, out.numpy()))
     finally:

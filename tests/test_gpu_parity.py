@@ -684,6 +684,18 @@ def test_chunked_overlap_alternating_streams(monkeypatch):
         torch.cuda.synchronize()
         assert y.shape == (24, *ref.shape[1:])
         assert torch.equal(y[:12], ref) and torch.equal(y[12:], ref)
+    # deferred completion (what bench.py does for N > 1): the next batch is launched before the previous wait
+    ya, ha = ddist.analyze_chunked_overlap(x, lambda w: mcep(stft(w)), 2, defer=True)
+    yb, hb = ddist.analyze_chunked_overlap(x, lambda w: mcep(stft(w)), 2, defer=True)
+    ha.wait()
+    hb.wait()
+    torch.cuda.synchronize()
+    for y in (ya, yb):
+        assert torch.equal(y[:12], ref) and torch.equal(y[12:], ref)
+    y1, h1 = ddist.analyze_chunked_overlap(x, lambda w: mcep(stft(w)), 1, defer=True)
+    h1.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(y1[:12], ref)
 
 
 # ----------------------------------------------------------------------------- f1 mel filter bank / MFCC
