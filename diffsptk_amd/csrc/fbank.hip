@@ -452,27 +452,6 @@ __global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const flo
             es += __shfl_xor(es, 32);
         }
         FB_STAMP(6);
-#ifdef FB_DIRECT_STORE
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const fm_f4 d = acc[t][0] + acc[t][1];
-            const int ch = 16 * t + i;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long f = f0 + 4 * kq + r;
-                if (f < F) {
-                    if (ch < C) {
-                        const float v = d[r] > floor ? d[r] : floor;
-                        y[f * C + ch] = glog_fwd(v, gamma);
-                    } else if (ch == ecol) {
-                        E[f] = dsa_log(d[r]);
-                    }
-                }
-            }
-        }
-        if (E && ecol < 0 && lane < kFmRows && f0 + lane < F) E[f0 + lane] = dsa_log(es * ew);
-        continue;
-#endif
         // the 16 x C results are one contiguous stretch of y: through the (now free) tile buffer, 16-byte stores
         __builtin_amdgcn_wave_barrier();
         float* ost = tile;                      // [16][C]
