@@ -982,3 +982,40 @@ def test_fftcep_gradcheck_and_full_size():
     d = host(c4 - c)
     close(d[..., 0], np.full(d.shape[:-1], 0.5 * np.log(4.0)), 1e-4, 1e-4)
     assert np.abs(d[..., 1:]).max() < 1e-4
+
+
+# ----------------------------------------------------------------------------- run-to-run determinism
+def test_tuned_kernels_are_bitwise_reproducible():
+    """Every tuned kernel of the path twice (and a third time after other work) on the same inputs: forward and
+    backward results must be bit-identical -- the dynamic tile queues, two-wave workgroups, span gathers and
+    in-place momentum buffers may not leak scheduling order into the numbers."""
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(96, 16000, generator=gen).to(DEV)
+    stft = dsp.STFT(400, 80, 512, device=DEV)
+    stc = dsp.STFT(400, 80, 512, out_format="complex", device=DEV)
+    ist = dsp.ISTFT(400, 80, 512, device=DEV)
+    mcep = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, device=DEV)
+    fb = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, use_power=True, out_format="yE", device=DEV)
+    lpc = dsp.LPC(400, 24, eps=1e-5, device=DEV)
+    fr, wn = dsp.Frame(400, 80), dsp.Window(400, device=DEV)
+    cep = dsp.CepstralAnalysis(fft_length=512, cep_order=24, n_iter=1, device=DEV)
+
+    def run():
+        xg = x.clone().requires_grad_(True)
+        X = stft(xg)
+        mc = mcep(X)
+        y = fb(X)
+        a = lpc(wn(fr(xg)))
+        c = cep(X)
+        Z = stc(xg)
+        xr = ist(Z, out_length=16000)
+        loss = (mc * torch.linspace(-1, 1, 25, device=DEV)).sum() + y.sum() * 1e-3 + (a * 0.1).sum() + c.sum() + (xr * xr).sum()
+        (g,) = torch.autograd.grad(loss, xg)
+        return [t.detach().clone() for t in (X, mc, y, a, c, torch.view_as_real(Z), xr, g)]
+
+    ref = run()
+    again = run()
+    _ = mcep(stft(torch.randn(300, 16000, device=DEV)))   # unrelated work in between (other tile counts, pool slots)
+    third = run()
+    for name, r, a2, a3 in zip(("stft", "mcep", "fbank", "lpc", "fftcep", "stft complex", "istft", "grad"), ref, again, third):
+        assert torch.equal(r, a2) and torch.equal(r, a3), name
