@@ -5,7 +5,7 @@ set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --ramp-seconds 0 --no-cpu-baseline"
 i=0
 for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \

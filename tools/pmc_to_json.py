@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from the rocprofv3 --pmc passes of tools/pmc_passes.sh (what bench.py reports as
+`traffic` and `pmc`).  usage: python tools/pmc_to_json.py <dir with p*/p*_counter_collection.csv> <source label>"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+KERNELS = {"mcep_mfma_fwd": "mcep_mfma_fwd_kernel_h", "stft512_fwd": "stft512_fwd_kernel"}
+WAVES_PER_SIMD = {"mcep_mfma_fwd": 2, "stft512_fwd": 4}
+FRAMES = 204800
+
+acc = defaultdict(lambda: [0.0, 0])
+for f in sorted(glob.glob(sys.argv[1] + "/p*/p*_counter_collection.csv")):
+    for row in csv.DictReader(open(f)):
+        for key, pat in KERNELS.items():
+            if pat in row["Kernel_Name"]:
+                a = acc[(key, row["Counter_Name"])]
+                a[0] += float(row["Counter_Value"])
+                a[1] += 1
+out = {"source": sys.argv[2] if len(sys.argv) > 2 else sys.argv[1],
+       "note": "KB per launch. Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 counts wide coalesced reads at half "
+               "their bytes: hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; WRITE_SIZE is used as reported.",
+       "kernels": {}}
+for key in KERNELS:
+    c = {n: s / k for (kk, n), (s, k) in acc.items() if kk == key}
+    if "FETCH_SIZE" not in c:
+        continue
+    cyc = c["GRBM_GUI_ACTIVE"] / 8
+    out["kernels"][key] = {
+        "FETCH_SIZE_KB": round(c["FETCH_SIZE"], 1), "WRITE_SIZE_KB": round(c["WRITE_SIZE"], 1),
+        "hbm_bytes_per_launch": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024, "frames_per_launch": FRAMES,
+        "derived": {
+            "cycles": round(cyc, 1),
+            "valu_busy": round(4 * c["SQ_ACTIVE_INST_VALU"] / (1024 * cyc), 3),
+            "mfma_busy": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * cyc), 3),
+            "lds_busy": round(c["SQ_LDS_IDX_ACTIVE"] / (256 * cyc), 3),
+            "lds_conflict_frac": round(c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1), 3),
+            "waves_per_simd": WAVES_PER_SIMD[key],
+            "valu_insts_per_frame": round(c["SQ_INSTS_VALU"] / FRAMES, 1),
+            "mfma_insts_per_frame": round(c.get("SQ_INSTS_MFMA", 0.0) / FRAMES, 1),
+        },
+    }
+out["derived_note"] = ("Derived from the same --pmc passes (gfx950: 256 CUs, 1024 SIMDs, 8 XCDs). cycles = GRBM_GUI_ACTIVE / 8; "
+                       "valu_busy = 4 * SQ_ACTIVE_INST_VALU / (1024 * cycles); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 * cycles); "
+                       "lds_busy = SQ_LDS_IDX_ACTIVE / (256 * cycles); lds_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; "
+                       "waves_per_simd = resident waves per SIMD of the persistent launch; valu_insts_per_frame = SQ_INSTS_VALU / "
+                       "frames (wave instructions).  Counter runs serialise the kernels and lower the clock: cycles here are longer "
+                       "than the un-instrumented launch.")
+json.dump(out, sys.stdout, indent=1)
+print()
