@@ -42,7 +42,8 @@ inline int check_launch(const char* name)
 // (use_power: 0 sqrt x | 1 x | 2 log x;  post_mode 0: floor + glog, 1: scale with the first column halved,
 //  3: first and last column halved;  needs float32, C <= 48, C < K <= 320)
 int fbank_mfma_launch_ex(const void* x, int64_t F, int K, const void* H, int C, int ldh, double floor, double gamma,
-                         int use_power, int post_mode, double post_scale, void* y, void* E, hipStream_t st, const char* name);
+                         int use_power, int post_mode, double post_scale, void* y, void* E, hipStream_t st, const char* name,
+                         const void* W2 = nullptr, int Mo = 0, void* z = nullptr);   // optional second product z = y W2
 
 #define DSA_REQUIRE(cond, msg)                                              \
     do {                                                                    \

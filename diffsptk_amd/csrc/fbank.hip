@@ -235,7 +235,8 @@ __global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const flo
                                                                       float gamma, int use_power, float* __restrict__ y,
                                                                       float* __restrict__ E, int nsteps, int cap,
                                                                       int tile_floats, int vec4, int ldh, int post_mode,
-                                                                      float post_scale)
+                                                                      float post_scale, const float* __restrict__ W2, int Mo,
+                                                                      float* __restrict__ z)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
     float* himg = reinterpret_cast<float*>(fb_smem);                         // [3][cap][64]
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const flo
     int* cnt = prog + 3 * cap;                                               // [8]: entries per tile | unchecked entries per tile
     unsigned* smask = reinterpret_cast<unsigned*>(cnt + 8);                  // [nsteps rounded]
     float* tiles = reinterpret_cast<float*>(smask + ((nsteps + 3) & ~3));
+    float* wimg = tiles + (size_t)kFmWaves * tile_floats;   // [12][64]: second product's B operands (MFCC: DCT x lifter)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, kq = lane >> 4;
     FB_STAMP0(0);
@@ -351,6 +353,13 @@ __global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const flo
     }
     __syncthreads();
     FB_STAMP0(11);
+    if (W2) {   // z = y W2 (C x Mo, Mo <= 16): k-slot kq of step s is channel 4 s + kq, column = lane & 15
+        for (int q = threadIdx.x; q < 12 * 64; q += kFmWaves * 64) {
+            const int ch = 4 * (q >> 6) + ((q & 63) >> 4), col = q & 15;
+            wimg[q] = (ch < C && col < Mo) ? W2[ch * Mo + col] : 0.f;
+        }
+        __syncthreads();
+    }
     int n_t[3], nf_t[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -477,7 +486,21 @@ __global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const flo
         }
         if (E && ecol < 0 && lane < kFmRows) est[lane] = dsa_log(es * ew);
         __builtin_amdgcn_wave_barrier();
-        {
+        if (W2) {   // MFCC: the DCT-II x lifter product straight from the staged log filter-bank outputs (mfcc.py:249-252)
+            fm_f4 zc = fm_f4{0.f, 0.f, 0.f, 0.f};
+            const int csteps = (C + 3) >> 2;
+            for (int sidx = 0; sidx < csteps; ++sidx) {
+                const int ch = 4 * sidx + kq;
+                const float a = ch < C ? ost[i * C + (ch < C ? ch : 0)] : 0.f;
+                zc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wimg[sidx * 64 + lane], zc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long f = f0 + 4 * kq + r;
+                if (f < F && i < Mo) z[f * Mo + i] = zc[r];
+            }
+        }
+        if (y) {
             const int rows = (int)(F - f0 < kFmRows ? F - f0 : kFmRows);
             const int n = rows * C;
             float* dst = y + f0 * C;
@@ -487,18 +510,29 @@ __global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const flo
             } else {
                 for (int q = lane; q < n; q += 64) dst[q] = ost[q];
             }
-            if (E && lane < rows) E[f0 + lane] = est[lane];
         }
+        if (E && lane < kFmRows && f0 + lane < F) E[f0 + lane] = est[lane];
     }
 }
 
+static size_t fbank_mfma_lds_bytes(int K, bool second_product)
+{
+    const int nsteps = 16 * (K / 64) + ((K % 64) < 16 ? (K % 64) : 16);
+    const int tile_floats = (kFmRows * K + 3) & ~3;
+    const int cap = ((nsteps + kFmU - 1) / kFmU + 3) * kFmU;
+    return ((size_t)3 * cap * 64 + 3 * cap + 8 + ((nsteps + 3) & ~3) + (size_t)kFmWaves * tile_floats +
+            (second_product ? 12 * 64 : 0)) * 4;
+}
+
 int fbank_mfma_launch_ex(const void* x, int64_t F, int K, const void* H, int C, int ldh, double floor, double gamma,
-                         int use_power, int post_mode, double post_scale, void* y, void* E, hipStream_t st, const char* name)
+                         int use_power, int post_mode, double post_scale, void* y, void* E, hipStream_t st, const char* name,
+                         const void* W2, int Mo, void* z)
 {
     const int nsteps = 16 * (K / 64) + ((K % 64) < 16 ? (K % 64) : 16);
     const int tile_floats = (kFmRows * K + 3) & ~3;
     const int cap = ((nsteps + kFmU - 1) / kFmU + 3) * kFmU;   // every list padded to a batch, plus the read-ahead batches
-    const size_t lds = ((size_t)3 * cap * 64 + 3 * cap + 8 + ((nsteps + 3) & ~3) + (size_t)kFmWaves * tile_floats) * 4;
+    const size_t lds = fbank_mfma_lds_bytes(K, W2 != nullptr);
+    if (lds > 160 * 1024) return fail(DSA_ERR_UNSUPPORTED, "fbank: spectrum too long for the matrix-core kernel's LDS%s");
     const long ntiles = (long)((F + kFmRows - 1) / kFmRows);
     long blocks = (ntiles + kFmWaves - 1) / kFmWaves;
     if (blocks > 256) blocks = 256;
@@ -515,7 +549,8 @@ int fbank_mfma_launch_ex(const void* x, int64_t F, int K, const void* H, int C, 
         if (!attr_ok) return fail(DSA_ERR_LAUNCH, "fbank: cannot reserve LDS for the operand images%s");              \
         hipLaunchKernelGGL(fbank_mfma_fwd_kernel<NQ>, dim3((unsigned)blocks), dim3(kFmWaves * 64), lds, st,            \
                            (const float*)x, (long)F, K, (const float*)H, C, (float)floor, (float)gamma, use_power,     \
-                           (float*)y, (float*)E, nsteps, cap, tile_floats, vec4, ldh, post_mode, (float)post_scale);   \
+                           (float*)y, (float*)E, nsteps, cap, tile_floats, vec4, ldh, post_mode, (float)post_scale,    \
+                           (const float*)W2, Mo, (float*)z);                                                          \
     } while (0)
     if (nq <= 5) DSA_FM_LAUNCH(5);
     else if (nq <= 9) DSA_FM_LAUNCH(9);
@@ -528,7 +563,8 @@ int fbank_mfma_launch_ex(const void* x, int64_t F, int K, const void* H, int C, 
 static int fbank_mfma_launch(const void* x, int64_t F, int K, const void* H, int C, double floor, double gamma,
                              int use_power, void* y, void* E, hipStream_t st)
 {
-    return fbank_mfma_launch_ex(x, F, K, H, C, C, floor, gamma, use_power ? 1 : 0, 0, 1.0, y, E, st, "fbank_mfma_fwd");
+    return fbank_mfma_launch_ex(x, F, K, H, C, C, floor, gamma, use_power ? 1 : 0, 0, 1.0, y, E, st, "fbank_mfma_fwd", nullptr, 0,
+                                nullptr);
 }
 
 template <typename T>
@@ -608,4 +644,27 @@ DSA_EXPORT int dsa_fbank_bwd(const void* gy, const void* gE, const void* x, int6
     if (dtype == DSA_F32) return fbank_launch<float>(true, gy, gE, x, F, K, H, C, floor, gamma, use_power, nullptr, nullptr, gx, st);
     if (dtype == DSA_F64) return fbank_launch<double>(true, gy, gE, x, F, K, H, C, floor, gamma, use_power, nullptr, nullptr, gx, st);
     return fail(DSA_ERR_UNSUPPORTED, "fbank_bwd: unsupported dtype%s");
+}
+
+// MFCC front end (mfcc.py:244-256): z = glog(max(s H, floor)) W, W:(C, Mo) = DCT-II x truncation x lifter; the filter-bank
+// outputs themselves are not written.  Fused into the matrix-core kernel when it applies (float32, C <= 48, Mo <= 16),
+// else the two generic launches with a stream-ordered temporary.
+DSA_EXPORT int dsa_fbank_dct_fwd(const void* x, int64_t F, int32_t K, const void* H, int32_t C, const void* W, int32_t Mo,
+                                 double floor, double gamma, int32_t use_power, int32_t dtype, void* z, void* E, void* stream)
+{
+    DSA_REQUIRE(F >= 0 && K >= 2 && C >= 1 && Mo >= 1, "fbank_dct: sizes must be positive");
+    DSA_REQUIRE(floor > 0 && gamma >= -1 && gamma <= 1, "fbank_dct: floor must be positive and gamma in [-1, 1]");
+    if (F == 0) return DSA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSA_F32 && C <= 48 && Mo <= 16 && K <= 16 * kFmPre && K > C && fbank_mfma_lds_bytes(K, true) <= 160 * 1024 &&
+        !env_flag("DSA_FBANK_GENERIC"))
+        return fbank_mfma_launch_ex(x, F, K, H, C, C, floor, gamma, use_power ? 1 : 0, 0, 1.0, nullptr, E, st, "fbank_dct_mfma_fwd",
+                                    W, Mo, z);
+    const size_t esz = dtype == DSA_F64 ? 8 : 4;
+    void* y = nullptr;
+    if (hipMallocAsync(&y, esz * (size_t)F * C, st) != hipSuccess) return fail(DSA_ERR_LAUNCH, "fbank_dct: workspace allocation failed%s");
+    int rc = dsa_fbank_fwd(x, F, K, H, C, floor, gamma, use_power, dtype, y, E, stream);
+    if (rc == DSA_OK) rc = dsa_freqt_fwd(y, F, C, W, Mo, dtype, z, stream);
+    (void)hipFreeAsync(y, st);
+    return rc;
 }

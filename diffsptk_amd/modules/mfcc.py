@@ -60,8 +60,8 @@ class MelFrequencyCepstralCoefficientsAnalysis(BaseFunctionalModule):
     @staticmethod
     def _forward(x: torch.Tensor, *, floor: float, gamma: float, out_format: str, H: torch.Tensor,
                  W: torch.Tensor) -> torch.Tensor:
-        fb, E = ops.FbankFn.apply(x, H, floor, gamma, False)     # mfcc.py:200 use_power=False
-        cy = ops.MatmulRowsFn.apply(fb, W)                         # DCT-II, truncation and lifter in one product
+        # amplitude-domain filter bank (mfcc.py:200 use_power=False) and DCT-II x truncation x lifter in ONE launch
+        cy, E = ops.MfccFn.apply(x, H, W, floor, gamma, False)
         c, y = cy[..., :1], cy[..., 1:]
         if out_format == "y":
             return y

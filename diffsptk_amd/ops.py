@@ -548,6 +548,49 @@ class FbankFn(torch.autograd.Function):
         return gx, None, None, None, None
 
 
+class MfccFn(torch.autograd.Function):
+    """cy, E = (glog(max(s H, floor)) W, log energy) in one launch (mfcc.py:244-256): W:(C, M+1) is DCT-II x truncation
+    x liftering vector.  Backward = the transposed product through W, then the filter-bank backward."""
+
+    @staticmethod
+    def forward(ctx, x, H, W, floor, gamma, use_power):
+        _require_device(x, H, W)
+        _same_dtype(x, H)
+        _same_dtype(x, W)
+        xc, Hc, Wc = x.contiguous(), H.contiguous(), W.contiguous()
+        K, Cn = Hc.shape
+        Mo = Wc.size(1)
+        F = xc.numel() // K
+        z = torch.empty(*xc.shape[:-1], Mo, device=x.device, dtype=x.dtype)
+        E = torch.empty(*xc.shape[:-1], 1, device=x.device, dtype=x.dtype)
+        with torch.cuda.device(x.device):
+            _call("dsa_fbank_dct_fwd", _p(xc), F, K, _p(Hc), Cn, _p(Wc), Mo, float(floor), float(gamma), int(bool(use_power)),
+                  _dtype_code(xc), _p(z), _p(E), _stream())
+        ctx.save_for_backward(xc, Hc, Wc)
+        ctx.cfg = (float(floor), float(gamma), int(bool(use_power)))
+        return z, E
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gz, gE):
+        xc, Hc, Wc = ctx.saved_tensors
+        floor, gamma, use_power = ctx.cfg
+        K, Cn = Hc.shape
+        Mo = Wc.size(1)
+        F = xc.numel() // K
+        gy = torch.empty(*xc.shape[:-1], Cn, device=xc.device, dtype=xc.dtype)
+        gx = torch.empty_like(xc)
+        gEc = gE.contiguous() if gE is not None else None
+        with torch.cuda.device(xc.device):
+            if gz is not None:
+                _call("dsa_freqt_bwd", _p(gz.contiguous()), F, Cn, _p(Wc), Mo, _dtype_code(xc), _p(gy), _stream())
+            else:
+                gy.zero_()
+            _call("dsa_fbank_bwd", _p(gy), _p(gEc) if gEc is not None else None, _p(xc), F, K, _p(Hc), Cn, floor, gamma,
+                  use_power, _dtype_code(xc), _p(gx), _stream())
+        return gx, None, None, None, None, None
+
+
 # ----------------------------------------------------------------------------------- mcep
 class McepFn(torch.autograd.Function):
     """MelCepstralAnalysis._forward (mcep.py:189-224) with composed linear stages."""

@@ -135,6 +135,11 @@ int dsa_fbank_fwd(const void* x, int64_t F, int32_t K, const void* H, int32_t C,
                   int32_t use_power, int32_t dtype, void* y, void* E, void* stream);
 int dsa_fbank_bwd(const void* gy, const void* gE, const void* x, int64_t F, int32_t K, const void* H, int32_t C,
                   double floor, double gamma, int32_t use_power, int32_t dtype, void* gx, void* stream);
+/* MelFrequencyCepstralCoefficientsAnalysis._forward mfcc.py:244-256 in one launch: z:(F,Mo) = glog(max(s H, floor)) W,
+ * W:(C,Mo) = DCT-II x truncation x liftering vector (device); E:(F) log energy as dsa_fbank_fwd (may be NULL).  The
+ * filter-bank outputs are not materialised; the backward is dsa_freqt_bwd (through W) followed by dsa_fbank_bwd. */
+int dsa_fbank_dct_fwd(const void* x, int64_t F, int32_t K, const void* H, int32_t C, const void* W, int32_t Mo, double floor,
+                      double gamma, int32_t use_power, int32_t dtype, void* z, void* E, void* stream);
 
 /* ------------------------------------------------------------------ f2  inverse path
  * RealValuedInverseFastFourierTransform ifftr.py:131-142, Unframe unframe.py:164-211, InverseShortTimeFourier-

@@ -721,6 +721,7 @@ def test_fbank_mfcc_golden_forward_backward(golden, name, dt):
     mf = dsp.MFCC(fft_length=512, mfcc_order=12, n_channel=40, sample_rate=16000, lifter=22, out_format="ycE", device=DEV, dtype=dt)
     Xg = X.clone().requires_grad_(True)
     out = mf(Xg)
+    assert _lib.last_kernel() == ("fbank_dct_mfma_fwd" if dt == torch.float32 else "freqt_fwd")   # float32: one fused launch
     close(host(out), g[f"mfcc_ycE_{name}"], rt, 10 * at)
     (out * torch.linspace(-1, 1, out.size(-1), dtype=dt, device=DEV)).sum().backward()
     ref = g["grad_mfcc_wsum_f64"]
