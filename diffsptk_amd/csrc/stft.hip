@@ -43,6 +43,34 @@ __global__ void frame_fwd_kernel(const T* __restrict__ x, long Tlen, long N, int
     }
 }
 
+// Frame without zmean, float32, L % 4 == 0: four samples per thread and a 16-byte store (the rows of y are 16-byte
+// aligned then); the four samples come as one 16-byte load when the source run is inside the waveform and aligned
+// (P, left multiples of 4), else one by one through the padding rule.  Persistent grid: the one-workgroup-per-frame
+// kernel above launches B * N tiny workgroups (0.17 ms per 204 800 frames against 0.07 ms here).
+__global__ __launch_bounds__(256) void frame_fwd_vec4_kernel(const float* __restrict__ x, long Tlen, long N, long F, int L, int P,
+                                                             int left, int mode, int src_aligned, float* __restrict__ y)
+{
+    const int L4 = L >> 2;
+    const long total = F * L4;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+        const long f = q / L4;
+        const int l = (int)(q - f * L4) << 2;
+        const long b = f / N, n = f - b * N;
+        const float* xb = x + b * Tlen;
+        const long s0 = n * P + l - left;
+        float4 v;
+        if (src_aligned && s0 >= 0 && s0 + 4 <= Tlen) {
+            v = *reinterpret_cast<const float4*>(xb + s0);
+        } else {
+            v.x = load_padded(xb, s0, Tlen, mode);
+            v.y = load_padded(xb, s0 + 1, Tlen, mode);
+            v.z = load_padded(xb, s0 + 2, Tlen, mode);
+            v.w = load_padded(xb, s0 + 3, Tlen, mode);
+        }
+        *reinterpret_cast<float4*>(y + f * (long)L + l) = v;
+    }
+}
+
 // adjoint of Frame: gx[b,t] = sum over (n,l) whose source index is t of g'[b,n,l], where
 // g' = gy - mean_l(gy) if zmean.  Gather formulation (deterministic, no atomics) for constant
 // padding; the non-constant modes fold several padded positions onto one sample and use a
@@ -1363,6 +1391,14 @@ DSA_EXPORT int dsa_frame_fwd(const void* x, int64_t B, int64_t T, int32_t L, int
     int left = center ? L / 2 : 0;
     int threads = L >= 192 ? 256 : (L >= 96 ? 128 : 64);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSA_F32 && !zmean && (L & 3) == 0 && (((size_t)y) & 15) == 0 && F * (int64_t)L >= 4096) {
+        const int src_aligned = (P & 3) == 0 && (left & 3) == 0 && (T & 3) == 0 && (((size_t)x) & 15) == 0;
+        long blocks = (long)((F * (int64_t)(L >> 2) + 255) / 256);
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(frame_fwd_vec4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (long)T, (long)N,
+                           (long)F, L, P, left, pad_mode, src_aligned, (float*)y);
+        return check_launch("frame_fwd_vec4");
+    }
     if (dtype == DSA_F32)
         hipLaunchKernelGGL((frame_fwd_kernel<float>), dim3((unsigned)F), dim3(threads), 0, st,
                            (const float*)x, (long)T, (long)N, L, P, left, zmean, pad_mode, (float*)y);

@@ -87,8 +87,15 @@ def test_frame_pad_modes_bit_exact_and_backward(golden):
 def test_frame_big_matches_oracle():
     x = torch.randn(3, 16000, generator=torch.Generator().manual_seed(0))
     y = host(dsp.Frame(400, 80)(x.to(DEV)))
+    assert _lib.last_kernel() == "frame_fwd_vec4"      # 16-byte loads and stores
     assert y.shape == (3, 200, 400)
     assert np.array_equal(y, O.frame(x.numpy(), 400, 80))
+    # the same kernel with sources that are not 16-byte aligned, every padding rule, and an odd waveform length
+    x2 = torch.randn(3, 15999, generator=torch.Generator().manual_seed(1))
+    for P, center, mode in ((81, True, "reflect"), (80, False, "replicate"), (37, True, "circular"), (80, True, "constant")):
+        y2 = host(dsp.Frame(400, P, center=center, mode=mode)(x2.to(DEV)))
+        assert _lib.last_kernel() == "frame_fwd_vec4"
+        assert np.array_equal(y2, O.frame(x2.numpy(), 400, P, center, False, mode))
 
 
 # ----------------------------------------------------------------------------- a2 Window
