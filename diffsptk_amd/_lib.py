@@ -112,6 +112,7 @@ SIGNATURES = {
     "dsa_freqt_bwd": (C.c_int, [_P, _L, _I, _P, _I, _I, _P, _P]),
     "dsa_irfft_scale": (C.c_int, [_P, _L, _I, _I, _P, _P]),
     "dsa_div_rows": (C.c_int, [_P, _L, _L, _P, _D, _I, _P, _P]),
+    "dsa_istft_fwd": (C.c_int, [_P, _L, _L, _I, _I, _I, _P, _P, _I, _P, _D, _I, _I, _P, _P]),
     "dsa_fbank_dct_fwd": (C.c_int, [_P, _L, _I, _P, _I, _P, _I, _D, _D, _I, _I, _P, _P, _P]),
     "dsa_fftcep_fwd": (C.c_int, [_P, _L, _I, _I, _P, _D, _I, _I, _P, _P, _P]),
     "dsa_fftcep_bwd": (C.c_int, [_P, _P, _L, _I, _I, _P, _D, _I, _P, _I, _P, _P]),

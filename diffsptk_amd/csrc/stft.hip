@@ -1241,8 +1241,11 @@ __global__ __launch_bounds__((PLAIN || CPLX) ? 128 : 64, (PLAIN || CPLX) ? 4 : D
 
 // gx[b][t] = sum over the passes whose span covers t (adjoint of the on-the-fly padding: positions
 // outside [0, T) are dropped for constant padding -- other modes use the generic backward).
+// div != nullptr (inverse STFT): the sum is divided by div[t] + div_eps, the overlap-added squared window
+// (unframe.py:203-205), so Unframe's division costs no pass of its own.
 __global__ void stft_span_gather_kernel(const float* __restrict__ part, long Tlen, int P, int left, int span,
-                                        int chunks_per_utt, float* __restrict__ gx)
+                                        int chunks_per_utt, float* __restrict__ gx, const float* __restrict__ div,
+                                        float div_eps)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long b = blockIdx.y;
@@ -1254,7 +1257,7 @@ __global__ void stft_span_gather_kernel(const float* __restrict__ part, long Tle
     long c_lo = p - span + 1 <= 0 ? 0 : (p - span + stride) / stride;
     float acc = 0.f;
     for (long c = c_lo; c <= c_hi; ++c) acc += part[(b * chunks_per_utt + c) * (long)span + (p - c * stride)];
-    gx[b * Tlen + t] = acc;
+    gx[b * Tlen + t] = div ? acc / (div[t] + div_eps) : acc;
 }
 
 static int stft512_lds_bytes(int L, int P, int* io_floats)
@@ -1718,10 +1721,13 @@ DSA_EXPORT int dsa_spec_bwd(const void* gy, const void* b, int32_t lb, const voi
     return fail(DSA_ERR_UNSUPPORTED, "spec_bwd: unsupported dtype%s");
 }
 
-DSA_EXPORT int dsa_stft_bwd(const void* gy, const void* x, int64_t B, int64_t T, int32_t L, int32_t P,
-                            int32_t nfft, const void* w, const void* twiddle, int32_t center, int32_t zmean,
-                            int32_t pad_mode, double eps, int32_t use_floor, double relative_floor_db,
-                            int32_t out_format, int32_t dtype, int32_t algo, void* gx, void* gw, void* stream)
+// dsa_stft_bwd and dsa_istft_fwd: div / div_eps only with out_format DSA_SPEC_COMPLEX_INV (the result is divided by
+// div[t] + div_eps); x may be NULL then (a complex cotangent needs no X; the generic kernels get zeros).
+static int stft_bwd_impl(const void* gy, const void* x, int64_t B, int64_t T, int32_t L, int32_t P,
+                         int32_t nfft, const void* w, const void* twiddle, int32_t center, int32_t zmean,
+                         int32_t pad_mode, double eps, int32_t use_floor, double relative_floor_db,
+                         int32_t out_format, int32_t dtype, int32_t algo, void* gx, void* gw, void* stream,
+                         const void* div, double div_eps)
 {
     DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0, "stft_bwd: sizes must be positive");
     DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "stft_bwd: fft_length must be positive even");
@@ -1786,20 +1792,50 @@ DSA_EXPORT int dsa_stft_bwd(const void* gy, const void* x, int64_t B, int64_t T,
             if (rc == DSA_OK) {
                 dim3 g2((unsigned)((T + 255) / 256), (unsigned)B);
                 hipLaunchKernelGGL(stft_span_gather_kernel, g2, dim3(256), 0, st, (const float*)part, (long)T, P, left,
-                                   span, chunks_per_utt, (float*)gx);
+                                   span, chunks_per_utt, (float*)gx, (const float*)div, (float)div_eps);
                 rc = check_launch("stft512_bwd");
             }
             (void)hipFreeAsync(part, st);
             return rc;
         }
     }
-    if (dtype == DSA_F32)
-        return stft_bwd_generic<float>(gy, x, B, T, L, P, nfft, w, twiddle, center, zmean, pad_mode, eps, use_floor,
-                                       relative_floor_db, out_format, gx, gw, st);
-    if (dtype == DSA_F64)
-        return stft_bwd_generic<double>(gy, x, B, T, L, P, nfft, w, twiddle, center, zmean, pad_mode, eps,
-                                        use_floor, relative_floor_db, out_format, gx, gw, st);
-    return fail(DSA_ERR_UNSUPPORTED, "stft_bwd: unsupported dtype%s");
+    if (dtype != DSA_F32 && dtype != DSA_F64) return fail(DSA_ERR_UNSUPPORTED, "stft_bwd: unsupported dtype%s");
+    const size_t esz = dtype == DSA_F32 ? 4 : 8;
+    void* x0 = nullptr;
+    if (!x) {   // inverse transform through the generic kernels: they read a waveform, give them zeros
+        if (hipMallocAsync(&x0, esz * (size_t)B * T, st) != hipSuccess || hipMemsetAsync(x0, 0, esz * (size_t)B * T, st) != hipSuccess)
+            return fail(DSA_ERR_LAUNCH, "istft: workspace allocation failed%s");
+        x = x0;
+    }
+    int rc = dtype == DSA_F32
+                 ? stft_bwd_generic<float>(gy, x, B, T, L, P, nfft, w, twiddle, center, zmean, pad_mode, eps, use_floor,
+                                           relative_floor_db, out_format, gx, gw, st)
+                 : stft_bwd_generic<double>(gy, x, B, T, L, P, nfft, w, twiddle, center, zmean, pad_mode, eps, use_floor,
+                                            relative_floor_db, out_format, gx, gw, st);
+    if (x0) (void)hipFreeAsync(x0, st);
+    if (rc == DSA_OK && div) rc = dsa_div_rows(gx, B, T, div, div_eps, dtype, gx, stream);
+    return rc;
+}
+
+DSA_EXPORT int dsa_stft_bwd(const void* gy, const void* x, int64_t B, int64_t T, int32_t L, int32_t P,
+                            int32_t nfft, const void* w, const void* twiddle, int32_t center, int32_t zmean,
+                            int32_t pad_mode, double eps, int32_t use_floor, double relative_floor_db,
+                            int32_t out_format, int32_t dtype, int32_t algo, void* gx, void* gw, void* stream)
+{
+    DSA_REQUIRE(x != nullptr, "stft_bwd: the waveform is required");
+    return stft_bwd_impl(gy, x, B, T, L, P, nfft, w, twiddle, center, zmean, pad_mode, eps, use_floor, relative_floor_db,
+                         out_format, dtype, algo, gx, gw, stream, nullptr, 0.0);
+}
+
+// InverseShortTimeFourierTransform._forward istft.py:186-193 in one call: y:(B,N,nfft/2+1) complex pairs ->
+// out:(B,T) = overlap-add(window * irfft(y)[:L]) / (d + d_eps), d:(T) the overlap-added squared window.
+DSA_EXPORT int dsa_istft_fwd(const void* y, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft, const void* w,
+                             const void* twiddle, int32_t center, const void* d, double d_eps, int32_t dtype, int32_t algo,
+                             void* out, void* stream)
+{
+    DSA_REQUIRE(d != nullptr, "istft: the window-square sum is required");
+    return stft_bwd_impl(y, nullptr, B, T, L, P, nfft, w, twiddle, center, 0, DSA_PAD_CONSTANT, 0.0, 0, 0.0,
+                         DSA_SPEC_COMPLEX_INV, dtype, algo, out, nullptr, stream, d, d_eps);
 }
 
 // --------------------------------------------------------------------------- inverse path (8(f) row 2)

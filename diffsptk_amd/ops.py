@@ -419,14 +419,12 @@ class IstftFn(torch.autograd.Function):
         N, K = yr.shape[-3:-1]
         B = yr.numel() // (N * K * 2)
         T, Tc, Nc = _fold_plan(N, L, P, center, out_length)
-        G = _pad_frames(yr.reshape(B, N, K, 2), N, Nc, 1).contiguous()   # the kernel applies c_k / nfft (format 5)
-        x0 = torch.zeros(B, Tc, device=y.device, dtype=yr.dtype)
-        num = torch.empty(B, Tc, device=y.device, dtype=yr.dtype)
-        with torch.cuda.device(y.device):
-            _call("dsa_stft_bwd", _p(G), _p(x0), B, Tc, L, P, fft_length, _p(wc), _p(twiddle), int(center), 0, 0, 0.0, 0,
-                  0.0, 5, _dtype_code(yr), algo, _p(num), None, _stream())
+        G = _pad_frames(yr.reshape(B, N, K, 2), N, Nc, 1).contiguous()
         d = _window_sq_sum(wc, N, Nc, L, P, center, Tc)
-        x = _div_rows(num, d)
+        x = torch.empty(B, Tc, device=y.device, dtype=yr.dtype)
+        with torch.cuda.device(y.device):   # inverse weights while loading, overlap-add, division by d + 1e-16: one entry
+            _call("dsa_istft_fwd", _p(G), B, Tc, L, P, fft_length, _p(wc), _p(twiddle), int(center), _p(d), 1e-16,
+                  _dtype_code(yr), algo, _p(x), _stream())
         ctx.save_for_backward(wc, twiddle, d)
         ctx.cfg = (y.shape, L, P, fft_length, center, T, Tc, Nc, algo)
         return x[:, :T].reshape(*y.shape[:-2], T)

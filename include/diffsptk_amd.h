@@ -150,6 +150,13 @@ int dsa_fbank_dct_fwd(const void* x, int64_t F, int32_t K, const void* H, int32_
  *   dsa_div_rows:    out:(B,T) = x / (d:(T) + eps)   (d = overlap-added squared window, eps = 1e-16) */
 int dsa_irfft_scale(const void* y, int64_t F, int32_t nfft, int32_t dtype, void* out, void* stream);
 int dsa_div_rows(const void* x, int64_t B, int64_t T, const void* d, double eps, int32_t dtype, void* out, void* stream);
+/* InverseShortTimeFourierTransform._forward istft.py:186-193 in one call: y:(B,N,nfft/2+1) complex pairs, N =
+ * dsa_num_frames(T, P) -> out:(B,T) = overlap-add(w * irfft(y)[:L]) / (d + d_eps); w:(L) synthesis window, d:(T) the
+ * overlap-added squared window (unframe.py:203-205), twiddle as dsa_stft_fwd.  Float32 / fft_length 512 runs on the
+ * tuned STFT backward kernel (inverse weights while loading, division inside the span gather). */
+int dsa_istft_fwd(const void* y, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft, const void* w,
+                  const void* twiddle, int32_t center, const void* d, double d_eps, int32_t dtype, int32_t algo,
+                  void* out, void* stream);
 /* GriffinLim._forward griffin.py:263-284: the element-wise part of one phase-reconstruction step between
  * z -> dsa_stft_bwd (inverse) -> dsa_stft_fwd (complex) -> t.  y:(B,N,K) power spectrogram; t:(B,Nt,K) complex
  * pairs (Nt >= N, surplus frames dropped; NULL = initial step with phase:(B,N,K) or NULL for zeros);
