@@ -227,8 +227,9 @@ __global__ void row_dft_kernel(const T* __restrict__ x, long Tlen, long N, int L
     __syncthreads();
     const int K = nfft / 2 + 1;
     const int Lc = L < nfft ? L : nfft;  // rfft(x, n) crops when the row is longer than n
+    const bool inverse_adj = out_kind == 1 && fmt == DSA_SPEC_COMPLEX_INV;   // complex output times c_k / nfft
     const bool complex_out = (out_kind == 0 && fmt == DSA_FFTR_COMPLEX) ||
-                             (out_kind == 1 && fmt == DSA_SPEC_COMPLEX);
+                             (out_kind == 1 && fmt == DSA_SPEC_COMPLEX) || inverse_adj;
     T smax = 0;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         T re = 0, im = 0;
@@ -241,8 +242,9 @@ __global__ void row_dft_kernel(const T* __restrict__ x, long Tlen, long N, int L
             if (idx >= nfft) idx -= nfft;
         }
         if (complex_out) {
-            y[(f * K + k) * 2] = re;
-            y[(f * K + k) * 2 + 1] = im;
+            const T sc = inverse_adj ? ((k == 0 || k == K - 1) ? T(1) : T(2)) / T(nfft) : T(1);
+            y[(f * K + k) * 2] = re * sc;
+            y[(f * K + k) * 2 + 1] = im * sc;
         } else if (out_kind == 0) {
             T v;
             switch (fmt) {
@@ -703,7 +705,10 @@ __global__ __launch_bounds__(128, 4) void stft512_fwd_kernel(
     const cf twB = cf{twiddle[2 * (lane + 65)], twiddle[2 * (lane + 65) + 1]};  // W512^(lane+65)
     const float inv_L = 1.f / (float)L;
     const int K = 257;
-    const bool complex_out = fmt == DSA_SPEC_COMPLEX;
+    const bool complex_out = fmt == DSA_SPEC_COMPLEX || fmt == DSA_SPEC_COMPLEX_INV;
+    // DSA_SPEC_COMPLEX_INV as a FORWARD format: the complex spectrum times c_k / 512 (the adjoint of the inverse
+    // transform's weights: the backward of dsa_istft_fwd)
+    const float osc = fmt == DSA_SPEC_COMPLEX_INV ? 2.f / 512.f : 1.f, osc_edge = fmt == DSA_SPEC_COMPLEX_INV ? 1.f / 512.f : 1.f;
     cf* zf = zbuf + fl * kZS;
 
     // (utterance, chunk) of pass c advance incrementally: one 64-bit division per wave instead of one per pass
@@ -865,8 +870,8 @@ __global__ __launch_bounds__(128, 4) void stft512_fwd_kernel(
                 const cf X2 = {S.re - Pp.im, -S.im - Pp.re};
                 if (complex_out) {
                     if (f < nvalid && ABL != 1) {
-                        y2[out0 + f * K + k] = make_float2(X1.re, X1.im);
-                        y2[out0 + f * K + 256 - k] = make_float2(X2.re, X2.im);
+                        y2[out0 + f * K + k] = make_float2(X1.re * osc, X1.im * osc);
+                        y2[out0 + f * K + 256 - k] = make_float2(X2.re * osc, X2.im * osc);
                     }
                 } else {
                     const float s1 = X1.re * X1.re + X1.im * X1.im + eps;  // spec.py:173
@@ -883,8 +888,8 @@ __global__ __launch_bounds__(128, 4) void stft512_fwd_kernel(
             const float x0 = 2.f * (z0[f].re + z0[f].im), x256 = 2.f * (z0[f].re - z0[f].im);   // these two take Z[0] whole
             if (complex_out) {
                 if (f < nvalid && ABL != 1 && lane == 0) {
-                    y2[out0 + f * K] = make_float2(x0, 0.f);
-                    y2[out0 + f * K + 256] = make_float2(x256, 0.f);
+                    y2[out0 + f * K] = make_float2(x0 * osc_edge, 0.f);
+                    y2[out0 + f * K + 256] = make_float2(x256 * osc_edge, 0.f);
                 }
             } else {
                 const float s0 = x0 * x0 + eps, s256 = x256 * x256 + eps;
@@ -1569,7 +1574,7 @@ DSA_EXPORT int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int3
     DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0, "stft: sizes must be positive");
     DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "stft: fft_length must be positive even");
     DSA_REQUIRE(pad_mode >= 0 && pad_mode <= 3, "stft: unknown pad mode");
-    DSA_REQUIRE(out_format >= 0 && out_format <= 4, "stft: unknown out_format");
+    DSA_REQUIRE(out_format >= 0 && out_format <= 5, "stft: unknown out_format");
     DSA_REQUIRE(pad_mode != DSA_PAD_REFLECT || (L / 2 < T && L - 1 < T) || T == 1,
                 "stft: reflect padding needs pad < input length");
     hipStream_t st = (hipStream_t)stream;

@@ -442,9 +442,9 @@ class IstftFn(torch.autograd.Function):
         g2 = _div_rows(g2.contiguous(), d)
         Y = torch.empty(B, Nc, K, 2, device=gx.device, dtype=gx.dtype)
         with torch.cuda.device(gx.device):
-            _call("dsa_stft_fwd", _p(g2), B, Tc, L, P, fft_length, _p(wc), _p(twiddle), int(center), 0, 0, 0.0, 0, 0.0, 4,
-                  _dtype_code(g2), algo, _p(Y), _stream())
-        gy = _irfft_scale(Y[:, :N].contiguous(), fft_length)
+            _call("dsa_stft_fwd", _p(g2), B, Tc, L, P, fft_length, _p(wc), _p(twiddle), int(center), 0, 0, 0.0, 0, 0.0, 5,
+                  _dtype_code(g2), algo, _p(Y), _stream())   # format 5: complex output times c_k / nfft
+        gy = Y[:, :N].contiguous()
         return (torch.view_as_complex(gy).reshape(shape),) + (None,) * 8
 
 

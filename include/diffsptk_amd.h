@@ -48,8 +48,9 @@ enum { DSA_PAD_CONSTANT = 0, DSA_PAD_REFLECT = 1, DSA_PAD_REPLICATE = 2, DSA_PAD
 enum { DSA_FFTR_COMPLEX = 0, DSA_FFTR_REAL = 1, DSA_FFTR_IMAG = 2, DSA_FFTR_AMPLITUDE = 3, DSA_FFTR_POWER = 4 };
 /* spec.py:123-132 (+ complex pass-through of stft.py:211-222) */
 enum { DSA_SPEC_DB = 0, DSA_SPEC_LOGMAG = 1, DSA_SPEC_MAG = 2, DSA_SPEC_POWER = 3, DSA_SPEC_COMPLEX = 4,
-       /* dsa_stft_bwd only: gy is a complex spectrogram to INVERT (istft.py:186-193): the kernel applies the
-        * inverse real transform's weights c_k / nfft (c = 1 at k = 0 and nfft/2, else 2) while loading it */
+       /* the inverse real transform's weights c_k / nfft (c = 1 at k = 0 and nfft/2, else 2) folded into the STFT
+        * kernels: in dsa_stft_bwd / dsa_istft_fwd the complex spectrogram to INVERT (istft.py:186-193) is weighted
+        * while it is loaded; in dsa_stft_fwd the complex output is weighted (the adjoint: the backward of the ISTFT) */
        DSA_SPEC_COMPLEX_INV = 5 };
 /* acorr.py:94-107 */
 enum { DSA_ACORR_NAIVE = 0, DSA_ACORR_NORMALIZED = 1, DSA_ACORR_BIASED = 2, DSA_ACORR_UNBIASED = 3 };

@@ -89,3 +89,6 @@ with torch.no_grad():
 Xq = Xp.clone().requires_grad_(True)
 t_fcb = timeit(lambda: torch.autograd.grad(fc0(Xq).sum(), Xq))
 print(f"   fftcep(24) fwd {t_fc0:.3f} ms ({frames/t_fc0*1e3:.3e} frames/s) | n_iter=2 fwd {t_fc2:.3f} ms | n_iter=0 fwd+bwd {t_fcb:.3f} ms")
+Zg = Z.clone().requires_grad_(True)
+t_isb = timeit(lambda: torch.autograd.grad(ist(Zg).sum(), Zg))
+print(f"   ISTFT fwd+bwd {t_isb:.3f} ms")
