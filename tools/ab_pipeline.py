@@ -26,7 +26,7 @@ def run(nstream, K=40):
     return (time.perf_counter() - t0) / K * 1e3
 
 
-for _ in range(3):
-    run(1, 5); run(2, 6)
+for _ in range(8):   # clock ramp
+    run(1, 40); run(2, 40)
 for n in (1, 2, 1, 2):
-    print(f"{n} stream(s): {run(n):.4f} ms/step")
+    print(f"{n} stream(s): {run(n, 200):.4f} ms/step")
