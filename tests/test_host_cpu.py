@@ -256,3 +256,18 @@ def test_fftcep_module_contract():
             dsp.CepstralAnalysis(**kw)
     m = dsp.CepstralAnalysis(**ok, n_iter=2)
     assert m.A.shape == (257, 257) and list(m.state_dict()) == [] and m.in_dim == 257
+
+
+def test_build_recipe_is_consistent():
+    """Every per-source flag set names a source of the build, every source exists, and the library on disk
+    exports the entry points the header declares (the loader checks each signature on load)."""
+    import os
+
+    from diffsptk_amd import _lib
+
+    assert set(_lib.SOURCE_FLAGS) <= set(_lib.SOURCES)
+    files, deps = _lib._sources()
+    assert all(os.path.exists(f) for f in files + deps)
+    lib = _lib.load()
+    for name in _lib.SIGNATURES:
+        assert hasattr(lib, name), name
