@@ -292,6 +292,26 @@ __global__ void frame_window_lpc_kernel(const T* __restrict__ x, long Tlen, long
 // dynamic LDS: in_buf[(3P + L) rounded] floats | wtab[L + 64] floats | rbuf[64][25] doubles
 constexpr int kLpcM1 = 25;
 
+// Sum over the 16 lanes of a DPP row, left in every lane: four rotate-and-add steps (row_ror 8, 4, 2, 1) on the
+// vector ALU.  (`__shfl_xor` on a double is two ds_bpermute_b32: 200 LDS-crossbar instructions per pass for the 25
+// lag sums, which kept the LDS pipe busier than the float64 FMAs kept the ALU.)  Addition is commutative, so every
+// lane of the row ends with the bit-identical sum.
+template <int SH>
+__device__ __forceinline__ double row_ror_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + SH, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + SH, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_allsum(double v)
+{
+    v += row_ror_f64<8>(v);
+    v += row_ror_f64<4>(v);
+    v += row_ror_f64<2>(v);
+    v += row_ror_f64<1>(v);
+    return v;
+}
+
 template <int... Is>
 __device__ __forceinline__ void lag_block(double (&acc)[kLpcM1], const double (&xw)[2 * kLpcM1 - 1],
                                           std::integer_sequence<int, Is...>)
@@ -370,8 +390,7 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_kernel(
             // add the 16 lanes of the frame (xor butterfly inside the 16-lane group)
 #pragma unroll
             for (int m = 0; m < kLpcM1; ++m) {
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) acc[m] += __shfl_xor(acc[m], o, 16);
+                acc[m] = row16_allsum(acc[m]);
             }
             if (fl < nvalid) {
                 double* rrow = rbuf + (size_t)(4 * p + fl) * kLpcM1;
@@ -513,8 +532,7 @@ __global__ __launch_bounds__(64, 1) void lpc24_bwd_kernel(const float* __restric
             }
 #pragma unroll
             for (int m = 0; m < kLpcM1; ++m) {
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) acc[m] += __shfl_xor(acc[m], o, 16);
+                acc[m] = row16_allsum(acc[m]);
             }
             if (fl < nvalid) {
                 double* rrow = rbuf + (size_t)(4 * p + fl) * kLpcM1;
