@@ -16,6 +16,7 @@
 // against the float64 reference (tests/test_lpc_gpu.py states the tolerance).
 #include "common.h"
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -323,7 +324,7 @@ __device__ __forceinline__ void lag_block(double (&acc)[kLpcM1], const double (&
 __global__ __launch_bounds__(64, 2) void frame_window_lpc24_kernel(
     const float* __restrict__ x, long Tlen, long N, int L, int P, int left, int mode,
     const float* __restrict__ w, double eps, float* __restrict__ out, long total_sc, int sc_per_utt,
-    int in_floats, int wtab_floats)
+    int in_floats, int wtab_floats, unsigned* __restrict__ queue)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* in_buf = reinterpret_cast<float*>(smem_raw);
@@ -335,9 +336,25 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_kernel(
     const int nblk = (C + kLpcM1 - 1) / kLpcM1;        // 25-sample blocks per lane
     for (int l = lane; l < wtab_floats; l += 64) wtab[l] = l < L ? w[l] : 0.f;
 
-    for (long sc = blockIdx.x; sc < total_sc; sc += gridDim.x) {
-        const long b = sc / sc_per_utt;
-        const long fbase = (sc - b * sc_per_utt) * 64;
+    // Work items are "super-chunks" of up to 64 consecutive frames of one utterance, handed out by a ticket
+    // counter with every FULL chunk before the utterances' short tail chunks (200 frames = 64 + 64 + 64 + 8): a
+    // static round-robin gave a quarter of the waves two tail chunks and the rest 128 frames.
+    const long full = N / 64;                       // full chunks per utterance
+    const long total_big = full * (total_sc / sc_per_utt);
+    for (;;) {
+        unsigned ticket = 0;
+        if (lane == 0) ticket = atomicAdd(queue, 1u);
+        const long tk = (long)__builtin_amdgcn_readfirstlane(ticket);
+        if (tk >= total_sc) break;
+        long b, ci;
+        if (tk < total_big) {
+            b = tk / full;
+            ci = tk - b * full;
+        } else {
+            b = tk - total_big;
+            ci = full;
+        }
+        const long fbase = ci * 64;
         const int nfr = (int)((N - fbase) < 64 ? (N - fbase) : 64);
         const float* xb = x + b * Tlen;
         const int npass = (nfr + 3) >> 2;
@@ -848,9 +865,20 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
             if (waves_per_cu > 8) waves_per_cu = 8;
             long grid = 256L * waves_per_cu;
             if (grid > total_sc) grid = total_sc;
+            // ticket counter: a library-owned pool of 64 rotating slots, zeroed in stream order before each launch
+            static unsigned* queue_pool = nullptr;
+            static std::once_flag queue_once;
+            static std::atomic<unsigned> queue_next{0};
+            std::call_once(queue_once, [] {
+                if (hipMalloc((void**)&queue_pool, 64 * sizeof(unsigned)) != hipSuccess) queue_pool = nullptr;
+            });
+            if (!queue_pool) return fail(DSA_ERR_LAUNCH, "frame_window_lpc: cannot allocate the ticket counters%s");
+            unsigned* queue = queue_pool + (queue_next.fetch_add(1) & 63);
+            if (hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess)
+                return fail(DSA_ERR_LAUNCH, "frame_window_lpc: cannot reset the ticket counter%s");
             hipLaunchKernelGGL(frame_window_lpc24_kernel, dim3((unsigned)grid), dim3(64), lds_t, st, (const float*)x,
                                (long)T, (long)N, L, P, left, pad_mode, (const float*)w, eps, (float*)out, total_sc,
-                               sc_per_utt, in_floats, wtab_floats);
+                               sc_per_utt, in_floats, wtab_floats, queue);
             return check_launch("frame_window_lpc24_fwd");
         }
     }
