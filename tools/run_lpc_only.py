@@ -1,5 +1,6 @@
+"""A dozen launches of the fused Frame -> Window -> LPC kernel (for rocprofv3 counter collection)."""
 import os, sys, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import diffsptk_amd as dsp
 from diffsptk_amd import ops
 dev = "cuda"
