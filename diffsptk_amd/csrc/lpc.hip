@@ -486,7 +486,7 @@ __device__ __forceinline__ void corr_block_rev(double (&acc)[kLpcM1], const doub
 
 __global__ __launch_bounds__(64, 1) void lpc24_bwd_kernel(const float* __restrict__ gout,
                                                           const float* __restrict__ x, long F, int L, double eps,
-                                                          float* __restrict__ gx, long total_sc, int S, int So)
+                                                          float* __restrict__ gx, long total_sc, int S, int So, int fpi)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* in_buf = reinterpret_cast<float*>(smem_raw);
@@ -517,8 +517,8 @@ __global__ __launch_bounds__(64, 1) void lpc24_bwd_kernel(const float* __restric
     };
 
     for (long sc = blockIdx.x; sc < total_sc; sc += gridDim.x) {
-        const long fbase = sc * 64;
-        const int nfr = (int)((F - fbase) < 64 ? (F - fbase) : 64);
+        const long fbase = sc * fpi;   // fpi <= 64 frames per work item (see the launcher)
+        const int nfr = (int)((F - fbase) < fpi ? (F - fbase) : fpi);
         const int npass = (nfr + 3) >> 2;
         __syncthreads();
         for (int q = lane; q < nfr * kLpcM1; q += 64) gbuf[q] = gout[fbase * kLpcM1 + q];
@@ -832,11 +832,21 @@ DSA_EXPORT int dsa_lpc_bwd(const void* gout, const void* x, const void* out, int
         const int So = (16 * C + 3) & ~3;
         size_t lds_t = (size_t)(4 * S + 4 * So) * 4 + 64 * kLpcM1 * sizeof(double) +
                        (4 * So >= 64 * kLpcM1 ? 0 : 64 * kLpcM1 * sizeof(float));
-        long total_sc = (long)((F + 63) / 64);
         long grid = 256L * 4;   // 280 registers: one wave per SIMD (a 256-register build spills and is slower)
+        // frames per work item: 64 fills phase B's lanes, but 204 800 frames / 64 = 3200 items are 3.125 per wave --
+        // four rounds with the last one an eighth full.  Pick the multiple of 4 (<= 64) that makes the item count a
+        // whole number of rounds (here 52 frames: 3939 items, 3.85 rounds of 13 passes instead of 4 of 16).
+        int fpi = 64;
+        if (F > grid * 64) {
+            const long rounds = (F + grid * 64 - 1) / (grid * 64);
+            long f = (F + rounds * grid - 1) / (rounds * grid);
+            f = (f + 3) & ~3L;
+            if (f >= 16 && f <= 64) fpi = (int)f;
+        }
+        long total_sc = (long)((F + fpi - 1) / fpi);
         if (grid > total_sc) grid = total_sc;
         hipLaunchKernelGGL(lpc24_bwd_kernel, dim3((unsigned)grid), dim3(64), lds_t, (hipStream_t)stream,
-                           (const float*)gout, (const float*)x, (long)F, L, eps, (float*)gx, total_sc, S, So);
+                           (const float*)gout, (const float*)x, (long)F, L, eps, (float*)gx, total_sc, S, So, fpi);
         return check_launch("lpc24_bwd");
     }
     if (dtype == DSA_F32) return lpc_bwd_impl<float>(gout, x, out, F, L, M, eps, gx, (hipStream_t)stream);

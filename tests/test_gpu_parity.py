@@ -625,7 +625,8 @@ def test_lpc_backward_golden(golden):
         assert np.abs(host(x.grad) - ref).max() < rel * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("L,Fr", [(400, 131), (25, 7), (26, 64), (127, 65), (401, 70), (512, 129)])
+@pytest.mark.parametrize("L,Fr", [(400, 131), (25, 7), (26, 64), (127, 65), (401, 70), (512, 129),
+                                  (400, 70001)])   # > 65 536 frames: work items of fewer than 64 frames (launcher)
 def test_lpc_tuned_backward_matches_float64_path(L, Fr):
     """The float32 order-24 backward (one fused kernel: lag sums, the Yule-Walker adjoint by a
     Levinson order-update, the lag-sum adjoint) against the float64 generic kernels on the same
