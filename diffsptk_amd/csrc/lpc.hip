@@ -324,7 +324,7 @@ __device__ __forceinline__ void lag_block(double (&acc)[kLpcM1], const double (&
 __global__ __launch_bounds__(64, 2) void frame_window_lpc24_kernel(
     const float* __restrict__ x, long Tlen, long N, int L, int P, int left, int mode,
     const float* __restrict__ w, double eps, float* __restrict__ out, long total_sc, int sc_per_utt,
-    int in_floats, int wtab_floats, unsigned* __restrict__ queue)
+    int in_floats, int wtab_floats, unsigned* __restrict__ queue, int fpi)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* in_buf = reinterpret_cast<float*>(smem_raw);
@@ -336,26 +336,18 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_kernel(
     const int nblk = (C + kLpcM1 - 1) / kLpcM1;        // 25-sample blocks per lane
     for (int l = lane; l < wtab_floats; l += 64) wtab[l] = l < L ? w[l] : 0.f;
 
-    // Work items are "super-chunks" of up to 64 consecutive frames of one utterance, handed out by a ticket
-    // counter with every FULL chunk before the utterances' short tail chunks (200 frames = 64 + 64 + 64 + 8): a
-    // static round-robin gave a quarter of the waves two tail chunks and the rest 128 frames.
-    const long full = N / 64;                       // full chunks per utterance
-    const long total_big = full * (total_sc / sc_per_utt);
+    // Work items are chunks of fpi <= 64 consecutive frames of one utterance (the launcher sizes them so that the
+    // utterances split evenly and the item count is close to a whole number of rounds: 200 frames = 4 x 52 instead
+    // of 64 + 64 + 64 + 8), handed out by a ticket counter.
     for (;;) {
         unsigned ticket = 0;
         if (lane == 0) ticket = atomicAdd(queue, 1u);
         const long tk = (long)__builtin_amdgcn_readfirstlane(ticket);
         if (tk >= total_sc) break;
-        long b, ci;
-        if (tk < total_big) {
-            b = tk / full;
-            ci = tk - b * full;
-        } else {
-            b = tk - total_big;
-            ci = full;
-        }
-        const long fbase = ci * 64;
-        const int nfr = (int)((N - fbase) < 64 ? (N - fbase) : 64);
+        const long b = tk / sc_per_utt;
+        const long ci = tk - b * sc_per_utt;
+        const long fbase = ci * fpi;
+        const int nfr = (int)((N - fbase) < fpi ? (N - fbase) : fpi);
         const float* xb = x + b * Tlen;
         const int npass = (nfr + 3) >> 2;
         for (int p = 0; p < npass; ++p) {
@@ -869,11 +861,24 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
         int wtab_floats = (L + 64 + 3) & ~3;
         size_t lds_t = (size_t)(in_floats + wtab_floats) * 4 + 64 * kLpcM1 * sizeof(double);
         if (lds_t <= 60 * 1024) {
-            int sc_per_utt = (int)((N + 63) / 64);
-            long total_sc = (long)B * sc_per_utt;
             int waves_per_cu = (int)(144 * 1024 / lds_t);
             if (waves_per_cu > 8) waves_per_cu = 8;
             long grid = 256L * waves_per_cu;
+            // frames per work item: close to a whole number of items per wave, utterances split evenly
+            int fpi = 64;
+            if (F > grid * 64) {
+                const long k = (F + grid * 64 - 1) / (grid * 64);
+                long f = (F + k * grid - 1) / (k * grid);
+                f = (f + 3) & ~3L;
+                if (f >= 16 && f <= 64) fpi = (int)f;
+            }
+            {
+                const long cpu = (N + fpi - 1) / fpi;            // chunks per utterance
+                long f = ((N + cpu - 1) / cpu + 3) & ~3L;        // ... of equal size
+                if (f >= 4 && f <= 64) fpi = (int)f;
+            }
+            int sc_per_utt = (int)((N + fpi - 1) / fpi);
+            long total_sc = (long)B * sc_per_utt;
             if (grid > total_sc) grid = total_sc;
             // ticket counter: a library-owned pool of 64 rotating slots, zeroed in stream order before each launch
             static unsigned* queue_pool = nullptr;
@@ -888,7 +893,7 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
                 return fail(DSA_ERR_LAUNCH, "frame_window_lpc: cannot reset the ticket counter%s");
             hipLaunchKernelGGL(frame_window_lpc24_kernel, dim3((unsigned)grid), dim3(64), lds_t, st, (const float*)x,
                                (long)T, (long)N, L, P, left, pad_mode, (const float*)w, eps, (float*)out, total_sc,
-                               sc_per_utt, in_floats, wtab_floats, queue);
+                               sc_per_utt, in_floats, wtab_floats, queue, fpi);
             return check_launch("frame_window_lpc24_fwd");
         }
     }
