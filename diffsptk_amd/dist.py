@@ -83,10 +83,26 @@ class PendingGather:
 
 
 def analyze_chunked_overlap(x_local: torch.Tensor, compute: Callable[[torch.Tensor], torch.Tensor], n_chunks: int = 2,
-                            group=None, alternate_streams: bool = True, defer: bool = False):
+                            group=None, alternate_streams: bool = True, defer: bool = False,
+                            layout: str = "rank_major", force_collective: bool = False):
     """Compute this rank's shard ``x_local`` (B_r, T) in ``n_chunks`` utterance chunks and all-gather
     each chunk's features as soon as they exist, so the collective of chunk c runs (on RCCL's own
     stream) while chunk c+1 is being computed.  Every rank must hold the same number of utterances.
+
+    Every chunk is ONE ``all_gather_into_tensor`` that writes in place: the receive buffer is laid out
+    ``(n_chunks, world, B_c, ...)``, so chunk c's collective fills the contiguous block ``buf[c]`` (rank-major
+    inside the chunk) and RCCL neither stages through a flat temporary nor copies out (a list of strided
+    destination views would: +164 MB of device copies per rank and step at 8 x 1024 utterances).  Chunks are
+    therefore EQUAL: ``n_chunks`` is lowered to the largest divisor of B_r not above the request.
+
+    ``layout``:
+      * ``"rank_major"`` (default): returns (world * B_r, ...) in rank-major utterance order -- the tensor
+        ``all_gather_features(compute(x_local))`` returns.  With one chunk this is the receive buffer itself
+        (no copy); with several chunks it is one strided device copy of the buffer after the last collective.
+      * ``"chunk_major"``: returns the receive buffer (n_chunks, world, B_c, ...) as is; utterance
+        ``b = c * B_c + i`` of rank ``r`` is ``out[c, r, i]``.  No copy at any chunk count.
+    A streaming caller that wants the exchange hidden and rank-major order should use ONE chunk with
+    ``defer=True``: the whole gather then runs behind the next batch's kernels (bench.py does this).
 
     On a GPU the chunks alternate between the current stream and one side stream
     (``alternate_streams``): the persistent mel-cepstral kernel ends in a tail of partly idle CUs,
@@ -94,46 +110,58 @@ def analyze_chunked_overlap(x_local: torch.Tensor, compute: Callable[[torch.Tens
     (tools/ab_chunks.py: 2 chunks on 2 streams cost the same as one unchunked launch, 0.96 ms per
     1024 utterances; 4 chunks cost +20 %).
 
-    Returns the gathered features (world * B_r, ...) in rank-major order -- the same tensor
-    ``all_gather_features(compute(x_local))`` returns, only the exchange is hidden behind compute.
-
     ``defer=True`` returns ``(features, PendingGather)`` without waiting for the collectives: the LAST chunk's
     all-gather has nothing of this call left to hide behind, but the caller's next batch can -- call
     ``PendingGather.wait()`` before the features are read (a streaming caller does so one batch later).
+    ``force_collective`` runs the collectives even in a world of one (functional test of the RCCL path on one GPU).
     """
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if layout not in ("rank_major", "chunk_major"):
+        raise ValueError("layout must be 'rank_major' or 'chunk_major'")
+    ready = dist.is_available() and dist.is_initialized()
+    if not ready or (dist.get_world_size(group) == 1 and not force_collective):
         out1 = compute(x_local)
+        if layout == "chunk_major":
+            out1 = out1.reshape(1, 1, *out1.shape)
         return (out1, PendingGather([], [])) if defer else out1
     world = dist.get_world_size(group)
     B = x_local.size(0)
     n_chunks = max(1, min(n_chunks, B))
-    bounds = [shard_bounds(B, n_chunks, c) for c in range(n_chunks)]
+    while B % n_chunks:          # equal chunks: every collective writes one contiguous block in place
+        n_chunks -= 1
+    Bc = B // n_chunks
     use_side = alternate_streams and x_local.is_cuda and n_chunks > 1
     main = torch.cuda.current_stream(x_local.device) if use_side else None
     side = torch.cuda.Stream(x_local.device) if use_side else None
     if use_side:
         side.wait_stream(main)  # the input was produced on the current stream
-    out = None
+    buf = None
     pending = []
-    for c, (lo, hi) in enumerate(bounds):
+    for c in range(n_chunks):
         on_side = use_side and c % 2 == 1
-        if on_side and out is not None:
-            side.wait_stream(main)  # `out` was allocated on the current stream
+        if on_side and buf is not None:
+            side.wait_stream(main)  # `buf` was allocated on the current stream
         ctx = torch.cuda.stream(side) if on_side else _NullContext()
         with ctx:
-            feat = compute(x_local[lo:hi]).contiguous()
-            if out is None:
-                out = feat.new_empty((world, B, *feat.shape[1:]))
-            # rank r's chunk lands in out[r, lo:hi]: one contiguous destination per rank; the collective
-            # is ordered after this chunk's kernels on the stream that is current here
-            work = dist.all_gather([out[r, lo:hi] for r in range(world)], feat, group=group, async_op=True)
+            feat = compute(x_local[c * Bc:(c + 1) * Bc]).contiguous()
+            if buf is None:
+                buf = feat.new_empty((n_chunks, world, Bc, *feat.shape[1:]))
+            # the collective is ordered after this chunk's kernels on the stream that is current here and
+            # fills buf[c] = (world, Bc, ...) directly
+            work = dist.all_gather_into_tensor(buf[c].view(world * Bc, *feat.shape[1:]), feat, group=group, async_op=True)
         pending.append((work, feat))
     if use_side:
         main.wait_stream(side)
         for _work, keep in pending:
             keep.record_stream(main)
-    handle = PendingGather([w for w, _ in pending], [k for _, k in pending] + [out])
-    res = out.reshape(world * B, *out.shape[2:])
+    handle = PendingGather([w for w, _ in pending], [k for _, k in pending] + [buf])
+    if layout == "chunk_major":
+        res = buf
+    elif n_chunks == 1:
+        res = buf.reshape(world * B, *buf.shape[3:])      # a view: rank-major already
+    else:
+        handle.wait()                                      # the reorder reads every chunk
+        res = buf.transpose(0, 1).reshape(world * B, *buf.shape[3:])   # one strided device copy
+        handle = PendingGather([], [buf])
     if defer:
         return res, handle
     handle.wait()

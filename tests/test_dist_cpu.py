@@ -65,6 +65,17 @@ def _worker(rank, world, port, B, q):
             h2.wait()
             h2.wait()   # idempotent
             ok = ok and torch.equal(ov2, out)
+            # chunk-major layout: the receive buffer itself, (n_chunks, world, B_c, ...)
+            cm = analyze_chunked_overlap(x[lo:hi], compute, n_chunks=2, layout="chunk_major")
+            nch, Bc = cm.shape[0], cm.shape[2]
+            ok = ok and cm.shape[:3] == (nch, world, (hi - lo) // nch)
+            for c in range(nch):
+                for r in range(world):
+                    rlo, _ = shard_bounds(B, world, r)
+                    ok = ok and torch.equal(cm[c, r], out[rlo + c * Bc: rlo + (c + 1) * Bc])
+            one, h = analyze_chunked_overlap(x[lo:hi], compute, n_chunks=1, defer=True)   # what bench.py does for N > 1
+            h.wait()
+            ok = ok and torch.equal(one, out)
         if rank == 0:
             q.put((ok, out.numpy()))
     finally:

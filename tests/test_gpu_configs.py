@@ -1,0 +1,134 @@
+"""GPU parity tests at the sizes BASELINE.json names (run with -m gpu on an MI355X).
+
+One test per BASELINE config that is not already run at full size in tests/test_gpu_parity.py:
+
+  configs[2]  STFT + mcep fwd+bwd, batch 256: the BACKWARD at batch 256 against autograd through the
+              float64 ATen port of the reference (oracle/torch_port.py) on sampled utterances -- frames are
+              independent, so d mean(mc) / d x_b only involves utterance b and is checkable utterance by
+              utterance;
+  configs[4]  the per-GPU shard of the 8192-utterance batch (1024 utterances x 1 s): sampled utterances against
+              the C oracle, permutation invariance bit-for-bit, Newton fixed point; plus the 8-way split itself
+              (what each rank of the 8-GPU run computes) emulated shard by shard on this one GPU.
+
+Tolerances: float32 mel-cepstra |mc - mc64| <= 1e-4 |mc64| + 5e-6 (the reference's own float32 run is 6e-6 from
+its float64 run; its test criterion is rtol 1e-4 / atol 1e-6 for a float32 op against SPTK's float32 output,
+tests/utils.py:66-72); gradients 2e-3 of the largest entry of the utterance's gradient (the golden-gradient
+tests use the same bound).
+"""
+import numpy as np
+import pytest
+import torch
+
+import diffsptk_amd as dsp
+from diffsptk_amd import _lib, functional as F
+from oracle import oracle as O
+from oracle import torch_port as TP
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+MC32 = dict(rtol=1e-4, atol=5e-6)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def _modules():
+    stft = dsp.STFT(400, 80, 512, device=DEV)
+    mcep = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, device=DEV)
+    return stft, mcep
+
+
+def test_config3_backward_batch256_vs_float64_autograd():
+    """BASELINE configs[2]: fwd+bwd at batch 256, gradient of mean(mcep(stft(x))) wrt x, on the tuned kernels."""
+    B = 256
+    x = torch.randn(B, 16000, generator=torch.Generator().manual_seed(3))
+    xd = x.to(DEV).requires_grad_(True)
+    stft, mcep = _modules()
+    mc = mcep(stft(xd))
+    assert _lib.last_kernel().startswith("mcep_mfma_fwd")
+    mc.mean().backward()
+    g = host(xd.grad)
+    assert g.shape == (B, 16000) and np.isfinite(g).all()
+    sel = [0, 37, 101, 128, 200, 255]
+    tab = TP.McepTables(512, 24, 0.42, torch.float64)
+    xs = x[sel].double().requires_grad_(True)
+    mcs = TP.stft_mcep(xs, tab)
+    (mcs.sum() / mc.numel()).backward()           # the same functional: mean over ALL B x N x 25 outputs
+    np.testing.assert_allclose(host(mc)[sel], mcs.detach().numpy(), **MC32)
+    ref = xs.grad.numpy()
+    for i, b in enumerate(sel):
+        err = np.abs(g[b] - ref[i]).max()
+        assert err < 2e-3 * np.abs(ref[i]).max(), (b, err, np.abs(ref[i]).max())
+    # utterances are independent in the backward too: permuting the batch permutes the gradient, bit for bit
+    idx = torch.randperm(B, generator=torch.Generator().manual_seed(4)).to(DEV)
+    xp = xd.detach()[idx].clone().requires_grad_(True)
+    mcep(stft(xp)).mean().backward()
+    assert torch.equal(xp.grad, xd.grad[idx])
+
+
+def test_config5_shard_1024_utterances():
+    """BASELINE configs[4], one rank's shard: 1024 utterances x 1 s through STFT -> mcep."""
+    B = 1024
+    x = torch.randn(B, 16000, generator=torch.Generator().manual_seed(11))
+    xd = x.to(DEV)
+    stft, mcep = _modules()
+    X = stft(xd)
+    assert _lib.last_kernel() == "stft512_fwd"
+    mc = mcep(X)
+    assert _lib.last_kernel().startswith("mcep_mfma_fwd")
+    assert mc.shape == (B, 200, 25) and bool(torch.isfinite(mc).all())
+    sel = [0, 171, 342, 513, 684, 855, 1023]
+    x64 = x[sel].double().numpy()
+    X_ref = O.stft(x64, 400, 80, 512)
+    err = np.abs(host(X)[sel] - X_ref) / X_ref.max(-1, keepdims=True)
+    assert err.max() < 2e-6, err.max()
+    np.testing.assert_allclose(host(mc)[sel], O.mcep(X_ref, 24, 0.42, 10), **MC32)
+    idx = torch.randperm(B, generator=torch.Generator().manual_seed(12)).to(DEV)
+    assert torch.equal(mcep(stft(xd[idx])), mc[idx])          # frames are independent: bitwise
+    mc11 = F.mcep(X[:16], 24, 0.42, 11)                       # converged: one more Newton step moves < 1e-4
+    assert float((mc11 - mc[:16]).abs().max()) < 1e-4
+    # Parseval per frame: sum_k c_k |X_k|^2 = nfft * sum_l (w_l x_l)^2  (the window has unit power)
+    fr = dsp.Window(400, device=DEV)(dsp.Frame(400, 80)(xd[:32]))
+    lhs = (2 * X[:32].sum(-1) - X[:32, :, 0] - X[:32, :, -1] - 2 * 255 * 1e-9)
+    rhs = 512 * fr.square().sum(-1)
+    assert float(((lhs - rhs).abs() / rhs).max()) < 1e-4
+
+
+def test_config5_eight_way_split_equals_whole_batch():
+    """The 8-GPU run shards the batch contiguously (diffsptk_amd/dist.py:shard_bounds) and all-gathers the
+    features; every rank's shard computed on its own must reproduce the rows of the whole-batch result bit for
+    bit (what the all-gather then concatenates).  8192 utterances would take 0.5 GB of waveform; the split is
+    exercised on 8 x 96 utterances, ragged last shard included."""
+    from diffsptk_amd.dist import shard_bounds
+
+    stft, mcep = _modules()
+    for B in (768, 761):
+        x = torch.randn(B, 16000, generator=torch.Generator().manual_seed(B)).to(DEV)
+        whole = mcep(stft(x))
+        parts = []
+        for r in range(8):
+            lo, hi = shard_bounds(B, 8, r)
+            parts.append(mcep(stft(x[lo:hi])))
+        assert torch.equal(torch.cat(parts), whole)
+
+
+def test_rccl_path_world1():
+    """The RCCL ("nccl" backend) code path of diffsptk_amd.dist on this one GPU: a world-size-1 process group with
+    the collectives forced on (tools/nccl_smoke.py) -- in-place all_gather_into_tensor per chunk on alternating
+    streams, both layouts, deferred completion.  Two ranks cannot share one device under RCCL, so N > 1 itself is
+    covered by the gloo world-size-2 tests (tests/test_dist_cpu.py) and the driver's 8-GPU run."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_smoke.py")], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode == 0 and "nccl smoke OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]

@@ -675,14 +675,14 @@ def test_chunked_overlap_alternating_streams(monkeypatch):
         def wait(self):
             return True
 
-    def fake_all_gather(outs, src, group=None, async_op=False):
-        for o in outs:
-            o.copy_(src)
+    def fake_all_gather(out, src, group=None, async_op=False):   # out: (world * B_c, ...) block of the receive buffer
+        for r in range(out.size(0) // src.size(0)):
+            out[r * src.size(0):(r + 1) * src.size(0)].copy_(src)
         return _Work()
 
     monkeypatch.setattr(tdist, "is_initialized", lambda: True)
     monkeypatch.setattr(tdist, "get_world_size", lambda group=None: 2)
-    monkeypatch.setattr(tdist, "all_gather", fake_all_gather)
+    monkeypatch.setattr(tdist, "all_gather_into_tensor", fake_all_gather)
     stft = dsp.STFT(400, 80, 512, device=DEV)
     mcep = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=3, device=DEV)
     x = torch.randn(12, 4000, generator=torch.Generator().manual_seed(5)).to(DEV)
