@@ -976,6 +976,10 @@ __global__ __launch_bounds__(128, 4) void stft512_fwd_kernel(
     }
 }
 
+}  // namespace dsa
+#include "stft_pk.h"
+namespace dsa {
+
 // ------------------------------------------------------------------ host-side dispatch helpers
 template <typename T>
 static int launch_row_dft(const void* x, int64_t B, int64_t Tlen, int64_t N, int L, int P, int left,
@@ -1304,6 +1308,21 @@ static void stft512_launch(bool zmean, dim3 grid, int lds, hipStream_t st, const
     const bool plain = !use_floor && fmt == DSA_SPEC_POWER && mode == DSA_PAD_CONSTANT;
     const dim3 g2((grid.x + 1) / 2);
     const int lds2 = stft512_lds_bytes2();
+    // DSA_STFT_PK (A/B knob): 2 = packed-float32 kernel with register-direct stores (stft_pk.h) where it applies
+    // (default), 1 = the same with the staged output tile, 0 = scalar-float32 kernel
+    static const int use_pk = [] {
+        const char* e = getenv("DSA_STFT_PK");
+        return e ? atoi(e) : 2;
+    }();
+    if (use_pk && ABL == 0 && plain && !zmean && L == 400 && (P & 1) == 0 && 3 * P + 512 <= kFPW * kZS * 2) {
+        if (use_pk == 1)   // staged 16-byte stores (A/B)
+            hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, false>), g2, dim3(128), lds2, st, x, T, N, L, P, left, w, tw, eps, y,
+                               total_chunks, chunks_per_utt);
+        else               // 8-byte stores straight from the split's registers (default)
+            hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, true>), g2, dim3(128), lds2, st, x, T, N, L, P, left, w, tw, eps, y,
+                               total_chunks, chunks_per_utt);
+        return;
+    }
 #define DSA_STFT_FWD_LAUNCH(ZM, PL, LCV)                                                                                 \
     hipLaunchKernelGGL((stft512_fwd_kernel<ABL, ZM, PL, LCV>), g2, dim3(128), lds2, st, x, T, N, L, P, left, mode, w, tw, \
                        eps, use_floor, floor_lin, fmt, y, total_chunks, chunks_per_utt, io_floats)

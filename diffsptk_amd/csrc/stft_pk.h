@@ -1,0 +1,538 @@
+// Packed-float32 build of the fused STFT forward for the BASELINE configuration (included by stft.hip).
+//
+// stft512_fwd_kernel is vector-issue bound: 644 wave instructions per 4-frame pass, every complex add two
+// v_add_f32, every complex multiply four.  gfx950 issues v_pk_{add,mul,fma}_f32 at the same rate as the scalar
+// forms, and a complex value IS a register pair -- with the VOP3P operand modifiers (op_sel picks which half of
+// a source feeds each half of the result, neg_lo / neg_hi negate per half) every step of a radix-4 butterfly,
+// the multiplication by +-i and a complex multiply by a twiddle map onto packed instructions WITHOUT any
+// register shuffling:
+//     a + b, a - b                      1 instruction
+//     a - i b, a + i b                  1 instruction (swap the halves of b, negate one)
+//     a * t                             2 instructions (mul by t.re broadcast, fma by t.im broadcast on swapped a)
+//     real-FFT split of a pair          8 instructions for TWO bins incl. |.|^2 + eps (was ~22 per bin pair)
+// The compiler's own packed selection was measured slower on this code (it pairs registers with extra moves,
+// DESIGN.md 3.1), so the arithmetic below is inline assembly on register pairs; loads, stores, addressing and
+// the pass structure are the C++ of stft512_fwd_kernel.  Semantics: ShortTimeFourierTransform._forward,
+// stft.py:237-241 (power format, eps, no relative floor, constant padding, no zmean -- the other options
+// keep the all-options kernel).
+#pragma once
+
+namespace dsa {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f_u4 __attribute__((ext_vector_type(2), aligned(4)));   // a pair of floats at a 4-byte aligned address
+
+// ---- packed complex helpers: (lo, hi) = (re, im).  Modifier semantics checked by tools/test_pk_asm.cpp. ----
+__device__ __forceinline__ v2f pk_add(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_sub(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_add_negi(v2f a, v2f b)   // a - i b = (a.re + b.im, a.im - b.re)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_add_posi(v2f a, v2f b)   // a + i b = (a.re - b.im, a.im + b.re)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_add_conj(v2f a, v2f b)   // a + conj(b) = (a.re + b.re, a.im - b.im)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_sub_conj(v2f a, v2f b)   // a - conj(b) = (a.re - b.re, a.im + b.im)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_mul(v2f a, v2f b)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ v2f pk_fma_sc(v2f a, v2f b, v2f c)   // c uniform, in a scalar register pair
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+__device__ __forceinline__ v2f pk_mul_s(v2f a, v2f b)   // b uniform, in a scalar register pair
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+}
+// complex product a * t, t = (c, s) in VECTOR registers: (a.re c - a.im s, a.im c + a.re s)
+__device__ __forceinline__ v2f pk_cmul(v2f a, v2f t)
+{
+    v2f t1, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t1) : "v"(a), "v"(t));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(t), "v"(t1));
+    return r;
+}
+// the same with the constant t in a SCALAR register pair (the radix-16 twiddles: uniform, 10 scalar registers)
+__device__ __forceinline__ v2f pk_cmul_s(v2f a, v2f t)
+{
+    v2f t1, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t1) : "v"(a), "s"(t));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(t), "v"(t1));
+    return r;
+}
+
+// 4-point forward DFT in place (W4 = -i): 8 packed instructions
+__device__ __forceinline__ void pk_dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3)
+{
+    const v2f s02 = pk_add(a0, a2), d02 = pk_sub(a0, a2), s13 = pk_add(a1, a3), d13 = pk_sub(a1, a3);
+    a0 = pk_add(s02, s13);
+    a2 = pk_sub(s02, s13);
+    a1 = pk_add_negi(d02, d13);
+    a3 = pk_add_posi(d02, d13);
+}
+// the same with a3 == 0 on input (zero padding past the frame: known at compile time): 6 instructions
+__device__ __forceinline__ void pk_dft4_z3(v2f& a0, v2f& a1, v2f& a2, v2f& a3)
+{
+    const v2f s02 = pk_add(a0, a2), d02 = pk_sub(a0, a2), a1in = a1;
+    a0 = pk_add(s02, a1in);
+    a2 = pk_sub(s02, a1in);
+    a1 = pk_add_negi(d02, a1in);
+    a3 = pk_add_posi(d02, a1in);
+}
+// the same with a2 standing for -i a2 (the W16^4 twiddle of the second pass folded into the butterfly)
+__device__ __forceinline__ void pk_dft4_negi2(v2f& a0, v2f& a1, v2f& a2, v2f& a3)
+{
+    const v2f s02 = pk_add_negi(a0, a2), d02 = pk_add_posi(a0, a2), s13 = pk_add(a1, a3), d13 = pk_sub(a1, a3);
+    a0 = pk_add(s02, s13);
+    a2 = pk_sub(s02, s13);
+    a1 = pk_add_negi(d02, d13);
+    a3 = pk_add_posi(d02, d13);
+}
+
+// 16-point forward DFT in registers (radix 4 x 4), output order as fft16: X[k] in v[FFT16_OUT(k)].
+// ZTAIL: v[13], v[14], v[15] are zero on input (never read).  80 packed instructions (74 with ZTAIL).
+template <bool ZTAIL>
+__device__ __forceinline__ void pk_fft16(v2f (&v)[16])
+{
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+    pk_dft4(v[0], v[4], v[8], v[12]);
+    if (ZTAIL) {
+        pk_dft4_z3(v[1], v[5], v[9], v[13]);
+        pk_dft4_z3(v[2], v[6], v[10], v[14]);
+        pk_dft4_z3(v[3], v[7], v[11], v[15]);
+    } else {
+        pk_dft4(v[1], v[5], v[9], v[13]);
+        pk_dft4(v[2], v[6], v[10], v[14]);
+        pk_dft4(v[3], v[7], v[11], v[15]);
+    }
+    // after the first pass v[n0 + 4q] = B[n0][q]; twiddle by W16^(n0 q) = (cos, -sin)(2 pi n0 q / 16)
+    v[5] = pk_cmul_s(v[5], v2f{C1, -S1});     // e = 1
+    v[9] = pk_cmul_s(v[9], v2f{R2, -R2});     // e = 2
+    v[13] = pk_cmul_s(v[13], v2f{S1, -C1});   // e = 3
+    v[6] = pk_cmul_s(v[6], v2f{R2, -R2});     // e = 2
+    //   v[10]: e = 4, a factor -i, folded into the q = 2 butterfly below
+    v[14] = pk_cmul_s(v[14], v2f{-R2, -R2});  // e = 6
+    v[7] = pk_cmul_s(v[7], v2f{S1, -C1});     // e = 3
+    v[11] = pk_cmul_s(v[11], v2f{-R2, -R2});  // e = 6
+    v[15] = pk_cmul_s(v[15], v2f{-C1, S1});   // e = 9
+    pk_dft4(v[0], v[1], v[2], v[3]);
+    pk_dft4(v[4], v[5], v[6], v[7]);
+    pk_dft4_negi2(v[8], v[9], v[10], v[11]);
+    pk_dft4(v[12], v[13], v[14], v[15]);
+}
+
+// ABL (ablation bit mask, tools/bench_stft.cpp only; 0 in the product): 1 no output stores | 2 no butterflies |
+// 4 no waveform loads / staging | 8 no twiddle-table reads | 16 no transposes through LDS | 32 no spectrum
+// round trip (Z write + pair reads) | 64 no staged tile | 128 cycle stamps of wave 0
+#ifdef DSA_STFT_TIMING
+__device__ unsigned long long g_stft_pk_stamps[64];
+#define PK_STAMP(i)                                                                                     \
+    do {                                                                                                \
+        if ((ABL & 128) && blockIdx.x == 0 && threadIdx.x == 0) g_stft_pk_stamps[i] = __builtin_readcyclecounter();  \
+    } while (0)
+#else
+#define PK_STAMP(i)
+#endif
+// The packed forward kernel.  Same pass structure, LDS carve-up, launch geometry and output as
+// stft512_fwd_kernel<0, false, true, LC> (see there); P must be even (8-byte aligned sample pairs in LDS).
+// (stft.hip is built with the compiler's packed-float32 selection switched off, which also makes the assembler
+// reject v_pk_*_f32 in inline assembly: the target attribute switches the feature back on for this kernel only)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DSA_PK_TARGET __attribute__((target("packed-fp32-ops")))
+#else
+#define DSA_PK_TARGET
+#endif
+// DIRECT: the power values leave the split's registers as 4-byte stores (lane = bin: every store instruction writes 64
+// consecutive floats of one row) instead of being staged in LDS for 16-byte stores: the kernel is bound by LDS
+// cycles, and the staged tile costs 18 four-byte LDS writes + 5 sixteen-byte reads per pass (a fifth of them).
+template <int ABL, int LC, bool DIRECT = false>
+__global__ __launch_bounds__(128, 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
+    const float* __restrict__ x, long Tlen, long N, int L, int P, int left, const float* __restrict__ w,
+    const float* __restrict__ twiddle, float eps, float* __restrict__ y, long total_chunks, int chunks_per_utt)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int WPB = 2;   // waves per workgroup (they share the twiddle table, nothing else)
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    v2f* zbuf = reinterpret_cast<v2f*>(smem_raw) + wv * kFPW * kZS;
+    float* io_buf = reinterpret_cast<float*>(zbuf);  // aliases zbuf: stretch -> tiles -> spectra -> staged output
+    v2f* t256 = reinterpret_cast<v2f*>(smem_raw) + WPB * kFPW * kZS;
+    const long nw = (long)gridDim.x * WPB;
+    long wid = (long)blockIdx.x * WPB + wv;
+    if (ABL & 256) {   // experiment: workgroups are dealt round-robin to the 8 XCDs; give every XCD a contiguous eighth of a round
+        const long per = gridDim.x / 8;
+        if (per * 8 == gridDim.x) wid = ((blockIdx.x & 7) * per + (blockIdx.x >> 3)) * WPB + wv;
+    }
+
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;   // lane within the frame group
+    const int fl = lane >> 4;  // frame slot within the pass (0..3)
+    PK_STAMP(0);
+    if (wid >= total_chunks) return;
+    constexpr int NR = LC ? (LC + 31) / 32 : 16;   // sample pairs a lane reads (the rest is zero padding)
+    constexpr int K = 257;
+    // (utterance, chunk) of a pass advance incrementally: one 64-bit division per wave
+    // (32-bit: the wave count and the chunks of an utterance are far below 2^31; 64-bit divisions are ~150 instructions)
+    const long b_step = (long)((unsigned)nw / (unsigned)chunks_per_utt);
+    const int ci_step = (int)(nw - b_step * chunks_per_utt);
+    auto advance = [&](long& bb, int& cc) __attribute__((always_inline)) {
+        bb += b_step;
+        cc += ci_step;
+        if (cc >= chunks_per_utt) {
+            cc -= chunks_per_utt;
+            ++bb;
+        }
+    };
+    // the stretch of samples the (up to) four frames of pass (bb, cc) share, straight from memory into the tile
+    auto stage_sync = [&](long bb, int cc) __attribute__((always_inline)) {
+        if (ABL & 4) return;
+        const long frame0 = (long)cc * kFPW;
+        const int nvalid = (int)((N - frame0) < kFPW ? (N - frame0) : kFPW);
+        const float* xb = x + bb * Tlen;
+        const long g0 = frame0 * P - left;
+        const int need = (nvalid - 1) * P + L;
+        if (g0 >= 0 && g0 + need <= Tlen && (((size_t)(xb + g0)) & 15) == 0) {
+            const float4* src4 = reinterpret_cast<const float4*>(xb + g0);
+            float4* dst4 = reinterpret_cast<float4*>(io_buf);
+            const int n4 = need >> 2;
+            for (int s = lane; s < n4; s += 64) {
+                dst4[s] = src4[s];
+                // (a marker that keeps this loop's tail from being merged with the register-staged writes of the
+                // pass loop: merged, those would inherit this loop's load waits -- and wait for the pass's stores)
+                asm volatile("; stage_sync" : : "v"(s));
+            }
+            for (int s = (n4 << 2) + lane; s < need; s += 64) io_buf[s] = xb[g0 + s];
+        } else {
+            for (int s = lane; s < need; s += 64) io_buf[s] = load_padded(xb, g0 + s, Tlen, (int)DSA_PAD_CONSTANT);
+        }
+    };
+    // Software pipeline over passes.  At the END of pass n the stretch of pass n+1 -- fetched into registers during
+    // pass n -- goes into the (by then free) tile and the fetch for pass n+2 is issued, so every fetch has one whole
+    // pass to arrive.  The wait for it sits BEFORE the output stores of the pass: vector-memory operations retire in
+    // order, and a wait placed after the stores cannot tell them from the loads -- every pass would wait for its
+    // own stores (measured: the pass period then follows the store latency).
+    v4f pre0 = v4f{0.f, 0.f, 0.f, 0.f}, pre1 = pre0, pre2 = pre0;
+    auto prefetch = [&](long bb, int cc) __attribute__((always_inline)) -> bool {
+        if (ABL & 4) return false;
+        const long fr2 = (long)cc * kFPW;
+        const int nv2 = (int)((N - fr2) < kFPW ? (N - fr2) : kFPW);
+        const long g2 = fr2 * P - left;
+        const int need2 = (nv2 - 1) * P + L;
+        const float* xb2 = x + bb * Tlen;
+        if (g2 >= 0 && g2 + need2 <= Tlen && (((size_t)(xb2 + g2)) & 15) == 0 && (need2 & 3) == 0 && need2 <= 768) {
+            const v4f* src4 = reinterpret_cast<const v4f*>(xb2 + g2);
+            const int n4 = need2 >> 2;
+            pre0 = src4[lane < n4 ? lane : n4 - 1];
+            pre1 = src4[lane + 64 < n4 ? lane + 64 : n4 - 1];
+            pre2 = src4[lane + 128 < n4 ? lane + 128 : n4 - 1];
+            return true;
+        }
+        return false;
+    };
+
+    // The first pass's stretch is fetched like every other one -- issued first, so that its round trip to memory
+    // overlaps the table loads below instead of following them.
+    long b = (long)((unsigned)wid / (unsigned)chunks_per_utt);
+    int ci = (int)(wid - b * chunks_per_utt);
+    long c = wid;
+    bool pre_ok = prefetch(b, ci);
+    PK_STAMP(3);
+
+    v2f wreg[NR];
+#pragma unroll
+    for (int m1 = 0; m1 < NR; ++m1) {
+        const int l = 2 * j + 32 * m1;
+        wreg[m1] = v2f{l < L ? w[l] : 0.f, l + 1 < L ? w[l + 1] : 0.f};
+    }
+    {
+        // entry [k1 = i >> 4][j = i & 15]: W256^(j k1) = W512^(2 j k1), HALVED: the 1/2 of the real-FFT split (exact).
+        // The four loads of a lane are issued together (as a loop they were four dependent round trips to memory
+        // at the head of every wave).
+        v2f t4[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int i = lane + 64 * q4;
+            const int m = 2 * (i & 15) * (i >> 4);
+            t4[q4] = *reinterpret_cast<const v2f*>(twiddle + 2 * m);
+        }
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) t256[lane + 64 * q4] = t4[q4] * 0.5f;
+    }
+    // split twiddles W512^k of this lane's two pairs (k, 256 - k): k = lane + 1, lane + 65 (staged output: a store
+    // covers 64 consecutive bins) or k = 2 lane + 1, 2 lane + 2 (DIRECT: the lane's two bins are neighbours)
+    const int kA = DIRECT ? 2 * lane + 1 : lane + 1, kB = DIRECT ? 2 * lane + 2 : lane + 65;
+    v2f twA = v2f{twiddle[2 * kA], twiddle[2 * kA + 1]};
+    v2f twB = v2f{twiddle[2 * kB], twiddle[2 * kB + 1]};
+    const v2f eps2 = v2f{eps, eps};
+    v2f* zf = zbuf + fl * kZS;
+    // Every prologue load is consumed HERE: otherwise the wait for these loop-invariant registers lands at their
+    // first use inside the pass loop, where it would also wait for whatever the pass has in flight.
+#pragma unroll
+    for (int m1 = 0; m1 < NR; ++m1) asm volatile("" : "+v"(wreg[m1]));
+    asm volatile("" : "+v"(twA), "+v"(twB));
+    PK_STAMP(4);
+    if (pre_ok) {
+        const long fr0 = (long)ci * kFPW;
+        const int nv0 = (int)((N - fr0) < kFPW ? (N - fr0) : kFPW);
+        const int n4 = ((nv0 - 1) * P + L) >> 2;
+        asm volatile("" : "+v"(pre0), "+v"(pre1), "+v"(pre2) : : "memory");
+        v4f* dst4 = reinterpret_cast<v4f*>(io_buf);
+        if (lane < n4) dst4[lane] = pre0;
+        if (lane + 64 < n4) dst4[lane + 64] = pre1;
+        if (lane + 128 < n4) dst4[lane + 128] = pre2;
+    } else {
+        stage_sync(b, ci);
+    }
+    PK_STAMP(5);
+    long b1 = b;
+    int ci1 = ci;
+    advance(b1, ci1);
+    bool has1 = c + nw < total_chunks;
+    pre_ok = has1 ? prefetch(b1, ci1) : false;
+    PK_STAMP(1);
+    int pass_no = 0;
+    (void)pass_no;
+    for (;;) {
+        const long frame0 = (long)ci * kFPW;
+        const int nvalid = (int)((N - frame0) < kFPW ? (N - frame0) : kFPW);
+        DSA_WAVE_SYNC();
+#ifdef DSA_STFT_TIMING
+        if ((ABL & 128) && pass_no < 24) PK_STAMP(8 + pass_no);
+        const bool stamp_pass = pass_no == 3;
+        ++pass_no;
+#define PK_PHASE(i) do { if (stamp_pass) PK_STAMP(40 + i); } while (0)
+#else
+#define PK_PHASE(i)
+#endif
+        // ---- per frame: window (window.py:190), 256-point complex FFT (16 lanes x 16 points) ----
+        v2f v[16];
+        {
+            const v2f* src = reinterpret_cast<const v2f*>(io_buf + fl * P + 2 * j);   // P even: 8-byte aligned
+            v2f raw[NR];
+#pragma unroll
+            for (int m1 = 0; m1 < NR; ++m1) raw[m1] = src[16 * m1];   // reads past the frame stay inside the tile
+            // samples past the frame are selected away, never multiplied: zero padding is exact and non-finite
+            // neighbours stay out of frames that do not contain them
+            if (LC) {
+#pragma unroll
+                for (int m1 = 0; m1 < NR; ++m1) {
+                    // element (m1, e) belongs to the frame iff 32 m1 + e + 2 j < LC; only the last pair can straddle
+                    const bool in0 = 32 * m1 + 30 < LC || 32 * m1 + 2 * j < LC;
+                    const bool in1 = 32 * m1 + 31 < LC || 32 * m1 + 1 + 2 * j < LC;
+                    const v2f r = v2f{in0 ? raw[m1].x : 0.f, in1 ? raw[m1].y : 0.f};
+                    v[m1] = pk_mul(r, wreg[m1]);
+                }
+#pragma unroll
+                for (int m1 = NR; m1 < 16; ++m1) v[m1] = v2f{0.f, 0.f};
+            } else {
+                int lim = L - 2 * j;
+                asm volatile("" : "+v"(lim));   // per pass on purpose: hoisted, the select masks occupy 64 scalar registers
+#pragma unroll
+                for (int m1 = 0; m1 < 16; ++m1) {
+                    const v2f r = v2f{32 * m1 < lim ? raw[m1].x : 0.f, 32 * m1 + 1 < lim ? raw[m1].y : 0.f};
+                    v[m1] = pk_mul(r, wreg[m1]);
+                }
+            }
+        }
+        DSA_WAVE_SYNC();  // every lane has its samples: the stretch may be overwritten
+        PK_PHASE(1);
+        if (!(ABL & 2)) pk_fft16<(LC > 0 && NR <= 13)>(v);
+        PK_PHASE(2);
+        if (ABL & 16) {
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) v[k1] = pk_cmul(v[k1], (ABL & 8) ? twA : t256[k1 * 16 + j]);
+        } else {
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1)  // twiddle, then transposed store: (k1, j) -> k1*17 + j
+                zf[k1 * 17 + j] = pk_cmul(v[FFT16_OUT(k1)], (ABL & 8) ? twA : t256[k1 * 16 + j]);
+            DSA_WAVE_SYNC();
+            PK_PHASE(3);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = zf[j * 17 + i];  // lane k1 = j reads A[i][k1]
+            DSA_WAVE_SYNC();
+        }
+        PK_PHASE(4);
+        if (!(ABL & 2)) pk_fft16<false>(v);
+        PK_PHASE(5);
+        if (!(ABL & 32)) {
+#pragma unroll
+            for (int k0 = 0; k0 < 16; ++k0) zf[j + 16 * k0] = v[FFT16_OUT(k0)];  // Z[k1 + 16 k0], natural order
+        }
+        DSA_WAVE_SYNC();
+        PK_PHASE(6);
+        // ---- real-FFT split, two bins (k, 256-k) per lane from one pair (a, b) = (Z[k], Z[256-k]) ----
+        //   S = a + conj(b), Dd = a - conj(b), Pp = W^k Dd   (Z arrives halved, see t256):
+        //   X[k] = (S.re + Pp.im, S.im - Pp.re),  X[256-k] = (S.re - Pp.im, -S.im - Pp.re)
+        // computed as R = (Re X[k], Re X[256-k]) and I = (Im X[k], Im X[256-k]), so that
+        // |X|^2 + eps of BOTH bins is two packed fused multiply-adds (spec.py:173).
+        const long row0 = b * N + frame0;
+        const long out0 = row0 * K;
+        float* stage = io_buf;
+        v2f pa[kFPW][2], pb[kFPW][2], z0[kFPW];
+#pragma unroll
+        for (int f = 0; f < kFPW; ++f) {
+            const v2f* z = zbuf + f * kZS;
+            if (ABL & 32) {
+                pa[f][0] = v[4 * f], pb[f][0] = v[4 * f + 1], pa[f][1] = v[4 * f + 2], pb[f][1] = v[4 * f + 3], z0[f] = v[f];
+            } else {
+                pa[f][0] = z[kA];
+                pb[f][0] = z[256 - kA];
+                pa[f][1] = z[kB];
+                pb[f][1] = z[256 - kB];
+                z0[f] = z[0];
+            }
+        }
+        DSA_WAVE_SYNC();   // all pairs are read before anything is written: the staged tile reuses the same LDS
+        PK_PHASE(7);
+        v2f sink = v2f{0.f, 0.f};
+        (void)sink;
+        const bool tile_aligned = nvalid == kFPW && (row0 & 3) == 0;   // 16-byte aligned because row0 % 4 == 0
+        // the fetch for the NEXT pass has had this whole pass to arrive; it is waited for here, before the stores
+        // (unconditional: on a conditional path the compiler would still schedule its own wait at the register use below)
+        if (DIRECT) asm volatile("" : "+v"(pre0), "+v"(pre1), "+v"(pre2) : : "memory");
+        v2f ends[kFPW];
+#pragma unroll
+        for (int f = 0; f < kFPW; ++f) {
+            // the two real-valued end bins from Z[0] alone: X[0] = 2 (re + im), X[256] = 2 (re - im)
+            v2f E;
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(E) : "v"(z0[f]), "v"(z0[f]));
+            const v2f E4 = pk_mul_s(E, v2f{4.f, 4.f});
+            const v2f se = pk_fma_sc(E4, E, eps2);
+            ends[f] = se;
+            if (ABL & 64) {
+                sink = pk_add(sink, se);
+            } else if (!DIRECT && lane == 0) {
+                stage[f * K] = se.x;
+                stage[f * K + 256] = se.y;
+            }
+            v2f sp[2];
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const int k = part == 0 ? kA : kB;
+                const v2f S = pk_add_conj(pa[f][part], pb[f][part]);
+                const v2f Dd = pk_sub_conj(pa[f][part], pb[f][part]);
+                const v2f Pp = pk_cmul(Dd, part == 0 ? twA : twB);
+                v2f R, I, s;
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(R) : "v"(S), "v"(Pp));
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(I) : "v"(S), "v"(Pp));
+                s = pk_fma_sc(R, R, eps2);
+                s = pk_fma(I, I, s);
+                sp[part] = s;
+                if (ABL & 64) {
+                    sink = pk_add(sink, s);
+                } else if (!DIRECT) {
+                    stage[f * K + k] = s.x;
+                    stage[f * K + 256 - k] = s.y;
+                }
+            }
+            if (DIRECT && !(ABL & 64) && !(ABL & 1) && f < nvalid) {
+                // bins (2 lane + 1, 2 lane + 2) and (254 - 2 lane, 255 - 2 lane): two 8-byte stores, 512 consecutive
+                // bytes of the row per instruction (lane 63 writes bin 128 twice, the same pair either way)
+                float* yr = y + out0 + f * K;
+                if (ABL & 512) {
+                    __builtin_nontemporal_store(v2f{sp[0].x, sp[1].x}, reinterpret_cast<v2f_u4*>(yr + kA));
+                    __builtin_nontemporal_store(v2f{sp[1].y, sp[0].y}, reinterpret_cast<v2f_u4*>(yr + 256 - kB));
+                } else {
+                    *reinterpret_cast<v2f_u4*>(yr + kA) = v2f{sp[0].x, sp[1].x};
+                    *reinterpret_cast<v2f_u4*>(yr + 256 - kB) = v2f{sp[1].y, sp[0].y};
+                }
+            }
+        }
+        if (DIRECT && !(ABL & 1) && !(ABL & 64)) {   // bins 0 and 256 of the (up to) four frames: lanes 0..7, one instruction
+            const int fe = lane >> 1;
+            v2f e = ends[0];
+            e = fe == 1 ? ends[1] : e;
+            e = fe == 2 ? ends[2] : e;
+            e = fe == 3 ? ends[3] : e;
+            if (fe < nvalid) y[out0 + fe * K + ((lane & 1) ? 256 : 0)] = (lane & 1) ? e.y : e.x;
+        }
+        DSA_WAVE_SYNC();
+        PK_PHASE(8);
+        // ---- coalesced write of the staged 4 x 257 tile ----
+        v4f q[5];
+        if (!DIRECT && !(ABL & 64) && tile_aligned) {
+            const v4f* s4 = reinterpret_cast<const v4f*>(stage);
+#pragma unroll
+            for (int jj = 0; jj < 5; ++jj) q[jj] = s4[jj < 4 ? lane + 64 * jj : 256];
+        }
+        if (!DIRECT) asm volatile("" : "+v"(pre0), "+v"(pre1), "+v"(pre2) : : "memory");   // see above
+        if (ABL & 64) {
+            if (sink.x + sink.y == 123.456f) y[out0 + lane] = sink.x;   // keeps the arithmetic alive, never true
+        } else if (DIRECT) {
+        } else if (tile_aligned) {
+            v4f* y4 = reinterpret_cast<v4f*>(y + out0);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if (!(ABL & 1) || q[jj].x == 123.456f) y4[lane + 64 * jj] = q[jj];
+            if (lane == 0 && (!(ABL & 1) || q[4].x == 123.456f)) y4[256] = q[4];
+        } else {
+            const int total = nvalid * K;
+            for (int idx = lane; idx < total; idx += 64) y[out0 + idx] = stage[idx];
+        }
+        PK_PHASE(9);
+        if (!has1) break;
+        // ---- the next pass's stretch into the tile (LDS operations of a wave execute in order: the staged output
+        // has been read), then the fetch for the pass after it ----
+        DSA_WAVE_SYNC();
+        if (pre_ok) {
+            const long fr1 = (long)ci1 * kFPW;
+            const int nv1 = (int)((N - fr1) < kFPW ? (N - fr1) : kFPW);
+            const int n4 = ((nv1 - 1) * P + L) >> 2;
+            v4f* dst4 = reinterpret_cast<v4f*>(io_buf);
+            if (lane < n4) dst4[lane] = pre0;
+            if (lane + 64 < n4) dst4[lane + 64] = pre1;
+            if (lane + 128 < n4) dst4[lane + 128] = pre2;
+        } else {
+            stage_sync(b1, ci1);
+        }
+        c += nw;
+        b = b1;
+        ci = ci1;
+        advance(b1, ci1);
+        has1 = c + nw < total_chunks;
+        pre_ok = has1 ? prefetch(b1, ci1) : false;
+        PK_PHASE(0);
+    }
+    PK_STAMP(2);
+}
+
+}  // namespace dsa
