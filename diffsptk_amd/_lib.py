@@ -30,6 +30,7 @@ SOURCE_FLAGS = {
 }
 
 F32, F64 = 0, 1
+SCRATCH_BYTES = 64   # DSA_SCRATCH_BYTES
 ALGO_AUTO, ALGO_GENERIC, ALGO_TUNED = 0, 1, 2
 
 _lib = None
@@ -41,7 +42,7 @@ class BackendError(RuntimeError):
 
 def _sources():
     files = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = files + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mcep_mfma_f16.h"), os.path.join(CSRC, "mcep_mfma_bwd_f16.h"), os.path.join(CSRC, "stft_mfma.h"), os.path.join(_ROOT, "include", "diffsptk_amd.h"),
+    deps = files + [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + [os.path.join(_ROOT, "include", "diffsptk_amd.h"),
                     os.path.abspath(__file__)]   # the build flags live in this file
     return files, deps
 
@@ -119,15 +120,17 @@ SIGNATURES = {
     "dsa_griffin_update": (C.c_int, [_P, _L, _L, _L, _I, _P, _P, _P, _P, _I, _D, _D, _D, _D, _I, _P, _P]),
     "dsa_fbank_fwd": (C.c_int, [_P, _L, _I, _P, _I, _D, _D, _I, _I, _P, _P, _P]),
     "dsa_fbank_bwd": (C.c_int, [_P, _P, _P, _L, _I, _P, _I, _D, _D, _I, _I, _P, _P]),
-    "dsa_mcep_fwd": (C.c_int, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
-    "dsa_mcep_bwd": (C.c_int, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "dsa_mcep_images_bytes": (C.c_int64, [_I, _I, _I]),
+    "dsa_mcep_prepare": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "dsa_mcep_fwd": (C.c_int, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "dsa_mcep_bwd": (C.c_int, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "dsa_acorr_fwd": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P]),
     "dsa_acorr_bwd": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "dsa_levdur_fwd": (C.c_int, [_P, _L, _I, _D, _I, _P, _P]),
     "dsa_levdur_bwd": (C.c_int, [_P, _P, _P, _L, _I, _D, _I, _P, _P]),
-    "dsa_lpc_fwd": (C.c_int, [_P, _L, _I, _I, _D, _I, _P, _P]),
+    "dsa_lpc_fwd": (C.c_int, [_P, _L, _I, _I, _D, _I, _P, _P, _P]),
     "dsa_lpc_bwd": (C.c_int, [_P, _P, _P, _L, _I, _I, _D, _I, _P, _P]),
-    "dsa_frame_window_lpc_fwd": (C.c_int, [_P, _L, _L, _I, _I, _P, _I, _I, _I, _D, _I, _P, _P]),
+    "dsa_frame_window_lpc_fwd": (C.c_int, [_P, _L, _L, _I, _I, _P, _I, _I, _I, _D, _I, _P, _P, _P]),
 }
 
 

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/diffsptk_amd.h"
 
 #define DSA_EXPORT extern "C" __attribute__((visibility("default")))
@@ -36,6 +38,19 @@ inline int check_launch(const char* name)
         return DSA_ERR_LAUNCH;
     }
     return DSA_OK;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): set once per device the process
+// drives (`done` = bit mask of the devices that have it; a process may drive several GPUs).
+inline bool ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done)
+{
+    int dev = 0;
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+    const uint64_t bit = known ? (uint64_t)1 << dev : 0;
+    if (known && (done.load(std::memory_order_acquire) & bit)) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    if (known) done.fetch_or(bit, std::memory_order_release);
+    return true;
 }
 
 // matrix-core "transform of the spectrum x (K x C) matrix" launcher of fbank.hip, shared with fftcep.hip

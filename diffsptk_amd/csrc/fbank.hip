@@ -540,13 +540,9 @@ int fbank_mfma_launch_ex(const void* x, int64_t F, int K, const void* H, int C, 
     const int nq = (4 * K + 63) / 64;
 #define DSA_FM_LAUNCH(NQ)                                                                                              \
     do {                                                                                                               \
-        static std::once_flag once;                                                                                    \
-        static bool attr_ok = false;                                                                                   \
-        std::call_once(once, [] {                                                                                      \
-            attr_ok = hipFuncSetAttribute((const void*)fbank_mfma_fwd_kernel<NQ>,                                      \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;       \
-        });                                                                                                            \
-        if (!attr_ok) return fail(DSA_ERR_LAUNCH, "fbank: cannot reserve LDS for the operand images%s");              \
+        static std::atomic<uint64_t> attr_devices{0};                                                                  \
+        if (!ensure_dynamic_lds((const void*)fbank_mfma_fwd_kernel<NQ>, 160 * 1024, attr_devices))                     \
+            return fail(DSA_ERR_LAUNCH, "fbank: cannot reserve LDS for the operand images%s");                        \
         hipLaunchKernelGGL(fbank_mfma_fwd_kernel<NQ>, dim3((unsigned)blocks), dim3(kFmWaves * 64), lds, st,            \
                            (const float*)x, (long)F, K, (const float*)H, C, (float)floor, (float)gamma, use_power,     \
                            (float*)y, (float*)E, nsteps, cap, tile_floats, vec4, ldh, post_mode, (float)post_scale,    \
@@ -588,13 +584,9 @@ static int fbank_launch(bool bwd, const void* gy, const void* gE, const void* x,
     const int kFbWaves = (int)waves;
 #define DSA_FB_ATTR(kern)                                                                                        \
     do {                                                                                                         \
-        static bool done = false;                                                                                \
-        if (!done && lds > 48 * 1024) {                                                                          \
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != \
-                hipSuccess)                                                                                      \
-                return fail(DSA_ERR_LAUNCH, "fbank: cannot reserve LDS for the filter matrix%s");               \
-            done = true;                                                                                         \
-        }                                                                                                        \
+        static std::atomic<uint64_t> attr_devices{0};                                                            \
+        if (lds > 48 * 1024 && !ensure_dynamic_lds((const void*)kern, 150 * 1024, attr_devices))                 \
+            return fail(DSA_ERR_LAUNCH, "fbank: cannot reserve LDS for the filter matrix%s");                   \
     } while (0)
     if (!bwd) {
         if (hlds) {

@@ -265,7 +265,7 @@ __global__ void frame_window_lpc_kernel(const T* __restrict__ x, long Tlen, long
     if (active) {
         long b = f / N, n = f - b * N;
         const T* xb = x + b * Tlen;
-        for (int l = lane; l < L; l += 64) xs[l] = load_padded(xb, n * P + l - left, Tlen, mode) * w[l];
+        for (int l = lane; l < L; l += 64) xs[l] = load_padded(xb, n * P + l - left, Tlen, mode) * (w ? w[l] : T(1));
     }
     __syncthreads();
     if (!active) return;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_kernel(
     const int j = lane & 15, fl = lane >> 4;
     const int C = (L + 15) >> 4;                       // samples per lane
     const int nblk = (C + kLpcM1 - 1) / kLpcM1;        // 25-sample blocks per lane
-    for (int l = lane; l < wtab_floats; l += 64) wtab[l] = l < L ? w[l] : 0.f;
+    for (int l = lane; l < wtab_floats; l += 64) wtab[l] = l < L ? (w ? w[l] : 1.f) : 0.f;   // w == NULL: a window of ones
 
     // Work items are chunks of fpi <= 64 consecutive frames of one utterance (the launcher sizes them so that the
     // utterances split evenly and the item count is close to a whole number of rounds: 200 frames = 4 x 52 instead
@@ -784,10 +784,10 @@ static int lpc_bwd_impl(const void* gout, const void* x, const void* out, int64_
 
 DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, const void* w,
                                         int32_t center, int32_t pad_mode, int32_t M, double eps, int32_t dtype,
-                                        void* out, void* stream);
+                                        void* scratch, void* out, void* stream);
 
-DSA_EXPORT int dsa_lpc_fwd(const void* x, int64_t F, int32_t L, int32_t M, double eps, int32_t dtype, void* out,
-                           void* stream)
+DSA_EXPORT int dsa_lpc_fwd(const void* x, int64_t F, int32_t L, int32_t M, double eps, int32_t dtype, void* scratch,
+                           void* out, void* stream)
 {
     DSA_REQUIRE(L > 0 && M >= 0 && M < L && F >= 0 && eps >= 0, "lpc: lpc_order must be less than frame_length");
     if (F == 0) return DSA_OK;
@@ -795,19 +795,9 @@ DSA_EXPORT int dsa_lpc_fwd(const void* x, int64_t F, int32_t L, int32_t M, doubl
     // framed with period L, no centring and a window of ones -- the fused tuned kernel (frame_window_lpc24_kernel)
     // takes it from there: 0.35 ms instead of 1.9 ms per 204 800 frames for the module chain
     // LPC(Window(Frame(x))) of the reference's README.md:198-201.
-    if (dtype == DSA_F32 && M == 24 && L >= 25 && L <= 512) {
-        static float* ones = nullptr;
-        static std::once_flag once;
-        std::call_once(once, [] {
-            std::vector<float> h(512, 1.f);
-            if (hipMalloc((void**)&ones, 512 * sizeof(float)) != hipSuccess) { ones = nullptr; return; }
-            if (hipMemcpy(ones, h.data(), 512 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-                hipFree(ones);
-                ones = nullptr;
-            }
-        });
-        if (ones) return dsa_frame_window_lpc_fwd(x, 1, F * (int64_t)L, L, L, ones, 0, DSA_PAD_CONSTANT, M, eps, dtype, out, stream);
-    }
+    // (w = NULL: the window of ones; scratch = NULL: no ticket counter available, the generic kernel runs)
+    if (dtype == DSA_F32 && M == 24 && L >= 25 && L <= 512 && scratch)
+        return dsa_frame_window_lpc_fwd(x, 1, F * (int64_t)L, L, L, nullptr, 0, DSA_PAD_CONSTANT, M, eps, dtype, scratch, out, stream);
     if (dtype == DSA_F32) return lpc_fwd_impl<float>(x, F, L, M, eps, out, (hipStream_t)stream);
     if (dtype == DSA_F64) return lpc_fwd_impl<double>(x, F, L, M, eps, out, (hipStream_t)stream);
     return fail(DSA_ERR_UNSUPPORTED, "lpc: unsupported dtype%s");
@@ -848,7 +838,7 @@ DSA_EXPORT int dsa_lpc_bwd(const void* gout, const void* x, const void* out, int
 
 DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, const void* w,
                                         int32_t center, int32_t pad_mode, int32_t M, double eps, int32_t dtype,
-                                        void* out, void* stream)
+                                        void* scratch, void* out, void* stream)
 {
     DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0 && M >= 0 && M < L && eps >= 0, "frame_window_lpc: invalid sizes");
     DSA_REQUIRE(pad_mode >= 0 && pad_mode <= 3, "frame_window_lpc: unknown pad mode");
@@ -856,7 +846,7 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
     if (F == 0) return DSA_OK;
     int left = center ? L / 2 : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DSA_F32 && M == 24 && L <= 512 && L >= 25) {
+    if (dtype == DSA_F32 && M == 24 && L <= 512 && L >= 25 && scratch) {   // the tuned kernel draws work items from a counter in `scratch`
         int in_floats = ((3 * P + L + 64 + kLpcM1 * 2) + 3) & ~3;
         int wtab_floats = (L + 64 + 3) & ~3;
         size_t lds_t = (size_t)(in_floats + wtab_floats) * 4 + 64 * kLpcM1 * sizeof(double);
@@ -880,15 +870,8 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
             int sc_per_utt = (int)((N + fpi - 1) / fpi);
             long total_sc = (long)B * sc_per_utt;
             if (grid > total_sc) grid = total_sc;
-            // ticket counter: a library-owned pool of 64 rotating slots, zeroed in stream order before each launch
-            static unsigned* queue_pool = nullptr;
-            static std::once_flag queue_once;
-            static std::atomic<unsigned> queue_next{0};
-            std::call_once(queue_once, [] {
-                if (hipMalloc((void**)&queue_pool, 64 * sizeof(unsigned)) != hipSuccess) queue_pool = nullptr;
-            });
-            if (!queue_pool) return fail(DSA_ERR_LAUNCH, "frame_window_lpc: cannot allocate the ticket counters%s");
-            unsigned* queue = queue_pool + (queue_next.fetch_add(1) & 63);
+            // ticket counter: the first word of the caller's scratch, zeroed in stream order before the launch
+            unsigned* queue = (unsigned*)scratch;
             if (hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess)
                 return fail(DSA_ERR_LAUNCH, "frame_window_lpc: cannot reset the ticket counter%s");
             hipLaunchKernelGGL(frame_window_lpc24_kernel, dim3((unsigned)grid), dim3(64), lds_t, st, (const float*)x,

@@ -309,7 +309,7 @@ static int mcep_generic_fwd(const void* X, int64_t F, int nfft, int M, int n_ite
     int K = nfft / 2 + 1, M1 = M + 1, M2 = 2 * M + 1;
     size_t lds = McepLds<T>::bytes(K, M1, M2);
     if (lds > 160 * 1024) return fail(DSA_ERR_UNSUPPORTED, "mcep: configuration exceeds LDS%s");
-    if (lds > 48 * 1024)
+    if (lds > 48 * 1024)   // (a growing size: set on every such launch, for the current device)
         hipFuncSetAttribute((const void*)mcep_generic_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((mcep_generic_fwd_kernel<T>), dim3((unsigned)F), dim3(128), lds, st, (const T*)X,
                        (long)F, K, M1, M2, n_iter, (const T*)G, (const T*)D, (const T*)E, (const T*)av,
@@ -335,10 +335,12 @@ static int mcep_generic_bwd(const void* gmc, const void* X, const void* hist, in
 
 // tuned kernels (mcep_mfma.hip)
 int mcep_mfma_supported(int nfft, int M, int dtype);
-int mcep_mfma_fwd(const void* X, int64_t F, int nfft, int M, int n_iter, const void* G, const void* D,
-                  const void* E, const void* av, void* mc, void* hist, hipStream_t st);
-int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* G, const void* D,
-                  const void* E, const void* av, void* gX, hipStream_t st);
+int64_t mcep_mfma_images_bytes();
+int mcep_mfma_prepare(const void* G, const void* D, const void* E, void* images, hipStream_t st);
+int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E, const void* av,
+                  const void* images, void* scratch, void* mc, void* hist, hipStream_t st);
+int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* av,
+                  const void* images, void* scratch, void* gX, hipStream_t st);
 
 }  // namespace dsa
 
@@ -386,9 +388,22 @@ DSA_EXPORT int dsa_freqt_bwd(const void* gout, int64_t F, int32_t L1, const void
     return check_launch("freqt_bwd");
 }
 
+DSA_EXPORT int64_t dsa_mcep_images_bytes(int32_t nfft, int32_t M, int32_t dtype)
+{
+    return mcep_mfma_supported(nfft, M, dtype) ? mcep_mfma_images_bytes() : 0;
+}
+
+DSA_EXPORT int dsa_mcep_prepare(const void* G, const void* D, const void* E, int32_t nfft, int32_t M, int32_t dtype,
+                                void* images, void* stream)
+{
+    if (!mcep_mfma_supported(nfft, M, dtype)) return DSA_OK;   // nothing to prepare: the generic kernels read G, D, E
+    DSA_REQUIRE(G && D && E && images, "mcep_prepare: G, D, E and the images buffer are required");
+    return mcep_mfma_prepare(G, D, E, images, (hipStream_t)stream);
+}
+
 DSA_EXPORT int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, int32_t n_iter, const void* G,
                             const void* D, const void* E, const void* alpha_vec, int32_t dtype, int32_t algo,
-                            void* mc, void* mc_hist, void* stream)
+                            const void* images, void* scratch, void* mc, void* mc_hist, void* stream)
 {
     DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "mcep: fft_length must be positive even");
     DSA_REQUIRE(M >= 0 && 2 * M <= nfft, "mcep: cep_order must be in [0, fft_length/2]");
@@ -398,8 +413,10 @@ DSA_EXPORT int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, i
     bool tuned_ok = mcep_mfma_supported(nfft, M, dtype) != 0;
     if (algo == DSA_ALGO_TUNED && !tuned_ok)
         return fail(DSA_ERR_UNSUPPORTED, "mcep: tuned kernel needs float32, fft_length 512, cep_order 24%s");
-    if (tuned_ok && algo != DSA_ALGO_GENERIC)
-        return mcep_mfma_fwd(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);
+    if (algo == DSA_ALGO_TUNED && !(images && scratch))
+        return fail(DSA_ERR_INVALID_ARGUMENT, "mcep: the tuned kernel needs the prepared images (dsa_mcep_prepare) and a scratch buffer%s");
+    if (tuned_ok && algo != DSA_ALGO_GENERIC && images && scratch)
+        return mcep_mfma_fwd(X, F, n_iter, G, D, E, alpha_vec, images, scratch, mc, mc_hist, st);
     if (dtype == DSA_F32) return mcep_generic_fwd<float>(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);
     if (dtype == DSA_F64) return mcep_generic_fwd<double>(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);
     return fail(DSA_ERR_UNSUPPORTED, "mcep: unsupported dtype%s");
@@ -407,7 +424,8 @@ DSA_EXPORT int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, i
 
 DSA_EXPORT int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist, int64_t F, int32_t nfft,
                             int32_t M, int32_t n_iter, const void* G, const void* D, const void* E,
-                            const void* alpha_vec, int32_t dtype, int32_t algo, void* gX, void* stream)
+                            const void* alpha_vec, int32_t dtype, int32_t algo, const void* images, void* scratch,
+                            void* gX, void* stream)
 {
     DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "mcep_bwd: fft_length must be positive even");
     DSA_REQUIRE(M >= 0 && 2 * M <= nfft && n_iter >= 0 && F >= 0, "mcep_bwd: invalid sizes");
@@ -417,8 +435,10 @@ DSA_EXPORT int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist,
     bool tuned_ok = mcep_mfma_supported(nfft, M, dtype) != 0;
     if (algo == DSA_ALGO_TUNED && !tuned_ok)
         return fail(DSA_ERR_UNSUPPORTED, "mcep_bwd: tuned kernel needs float32, fft_length 512, cep_order 24%s");
-    if (tuned_ok && algo != DSA_ALGO_GENERIC)
-        return mcep_mfma_bwd(gmc, X, mc_hist, F, n_iter, G, D, E, alpha_vec, gX, st);
+    if (algo == DSA_ALGO_TUNED && !(images && scratch))
+        return fail(DSA_ERR_INVALID_ARGUMENT, "mcep_bwd: the tuned kernel needs the prepared images (dsa_mcep_prepare) and a scratch buffer%s");
+    if (tuned_ok && algo != DSA_ALGO_GENERIC && images && scratch)
+        return mcep_mfma_bwd(gmc, X, mc_hist, F, n_iter, alpha_vec, images, scratch, gX, st);
     if (dtype == DSA_F32) return mcep_generic_bwd<float>(gmc, X, mc_hist, F, nfft, M, n_iter, G, D, E, alpha_vec, gX, st);
     if (dtype == DSA_F64) return mcep_generic_bwd<double>(gmc, X, mc_hist, F, nfft, M, n_iter, G, D, E, alpha_vec, gX, st);
     return fail(DSA_ERR_UNSUPPORTED, "mcep_bwd: unsupported dtype%s");

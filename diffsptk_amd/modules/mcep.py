@@ -78,6 +78,8 @@ def _device_matrices(fft_length, cep_order, alpha, device, dtype, cache):
     G, D, E, av = tables.mcep_matrices(fft_length, cep_order, alpha)[:4]
     tens = {"G": to(G, device, dtype), "D": to(D, device, dtype), "E": to(E, device, dtype),
             "alpha_vector": to(av, device, dtype)}
+    if tens["G"].device.type == "cuda":   # the tuned kernels' operand images: prepared here, once (ops.mcep_images)
+        ops.mcep_images(tens["G"], tens["D"], tens["E"], fft_length, cep_order)
     if cache:
         _MAT_CACHE[key] = tens
     return tens

@@ -7,6 +7,8 @@ hand-written backward kernels).
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -60,6 +62,42 @@ def _call(name, *args):
 
 def num_frames(T: int, P: int) -> int:
     return 0 if T <= 0 else (T - 1) // P + 1
+
+
+def _scratch(device) -> torch.Tensor:
+    """DSA_SCRATCH_BYTES of per-call workspace for the persistent tuned kernels (include/diffsptk_amd.h,
+    Conventions): a fresh block from PyTorch's stream-ordered caching allocator, so calls that can overlap in
+    time (other streams) never share one -- the library itself owns no device memory."""
+    return torch.empty(_lib.SCRATCH_BYTES, dtype=torch.uint8, device=device)
+
+
+_IMAGES: dict = {}   # id(G) -> (weakref to G, versions, images): prepared operand images, made once per set of matrices
+
+
+def mcep_images(G: torch.Tensor, D: torch.Tensor, E: torch.Tensor, fft_length: int, M: int):
+    """The per-configuration constants of the tuned mel-cepstral kernels (dsa_mcep_prepare): binary16 hi/lo
+    operand images of G, D, E, prepared once per set of matrices and reused by every call (None when the
+    configuration has no tuned kernel).  Keyed by the tensors themselves (weakly) and their version counters, so
+    moving a module to another device or editing a matrix in place prepares new images."""
+    if G.device.type != "cuda" or G.dtype != torch.float32:
+        return None
+    lib = _lib.load()
+    nbytes = lib.dsa_mcep_images_bytes(fft_length, M, _lib.F32)
+    if nbytes <= 0:
+        return None
+    ver = (G._version, D._version, E._version, D.data_ptr(), E.data_ptr())
+    hit = _IMAGES.get(id(G))
+    if hit is not None and hit[0]() is G and hit[1] == ver:
+        return hit[2]
+    Gc, Dc, Ec = G.contiguous(), D.contiguous(), E.contiguous()
+    img = torch.empty(nbytes, dtype=torch.uint8, device=G.device)
+    with torch.cuda.device(G.device):
+        _call("dsa_mcep_prepare", _p(Gc), _p(Dc), _p(Ec), fft_length, M, _lib.F32, _p(img), _stream())
+        torch.cuda.current_stream().synchronize()   # once per configuration: later calls may come from any stream
+    if hit is None or hit[0]() is not G:
+        weakref.finalize(G, _IMAGES.pop, id(G), None)   # the images go when the matrices go
+    _IMAGES[id(G)] = (weakref.ref(G), ver, img)
+    return img
 
 
 # ----------------------------------------------------------------------------------- Frame
@@ -603,12 +641,15 @@ class McepFn(torch.autograd.Function):
         mc = torch.empty(*Xc.shape[:-1], M + 1, device=X.device, dtype=X.dtype)
         need_hist = ctx.needs_input_grad[0]
         hist = torch.empty(n_iter + 1, F, M + 1, device=X.device, dtype=X.dtype) if need_hist else None
+        images = mcep_images(G, D, E, fft_length, M) if algo != _lib.ALGO_GENERIC else None
+        scratch = _scratch(X.device) if images is not None else None
         with torch.cuda.device(X.device):
             _call("dsa_mcep_fwd", _p(Xc), F, fft_length, M, n_iter, _p(G), _p(D), _p(E), _p(av),
-                  _dtype_code(Xc), algo, _p(mc), _p(hist), _stream())
+                  _dtype_code(Xc), algo, _p(images), _p(scratch), _p(mc), _p(hist), _stream())
         if need_hist:
             ctx.save_for_backward(Xc, hist, G, D, E, av)
         ctx.cfg = (fft_length, M, n_iter, algo)
+        ctx.images = images
         return mc
 
     @staticmethod
@@ -620,9 +661,11 @@ class McepFn(torch.autograd.Function):
         K = fft_length // 2 + 1
         F = Xc.numel() // K
         gX = torch.empty_like(Xc)
+        images = ctx.images
+        scratch = _scratch(gmc.device) if images is not None else None
         with torch.cuda.device(gmc.device):
             _call("dsa_mcep_bwd", _p(gmc), _p(Xc), _p(hist), F, fft_length, M, n_iter, _p(G), _p(D), _p(E),
-                  _p(av), _dtype_code(Xc), algo, _p(gX), _stream())
+                  _p(av), _dtype_code(Xc), algo, _p(images), _p(scratch), _p(gX), _stream())
         return (gX,) + (None,) * 8
 
 
@@ -691,8 +734,9 @@ class LpcFn(torch.autograd.Function):
         L = xc.size(-1)
         F = xc.numel() // L
         out = torch.empty(*xc.shape[:-1], M + 1, device=x.device, dtype=x.dtype)
+        scratch = _scratch(x.device)
         with torch.cuda.device(x.device):
-            _call("dsa_lpc_fwd", _p(xc), F, L, M, float(eps), _dtype_code(xc), _p(out), _stream())
+            _call("dsa_lpc_fwd", _p(xc), F, L, M, float(eps), _dtype_code(xc), _p(scratch), _p(out), _stream())
         ctx.save_for_backward(xc, out)
         ctx.cfg = (M, eps)
         return out
@@ -719,7 +763,8 @@ def frame_window_lpc(x, window, L, P, M, eps, center=True, mode="constant"):
     T = xc.size(-1)
     B = xc.numel() // T
     out = torch.empty(*xc.shape[:-1], num_frames(T, P), M + 1, device=x.device, dtype=x.dtype)
+    scratch = _scratch(x.device)
     with torch.cuda.device(x.device):
         _call("dsa_frame_window_lpc_fwd", _p(xc), B, T, L, P, _p(wc), int(center), pad_mode_code(mode), M,
-              float(eps), _dtype_code(xc), _p(out), _stream())
+              float(eps), _dtype_code(xc), _p(scratch), _p(out), _stream())
     return out

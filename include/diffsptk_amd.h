@@ -15,7 +15,16 @@
  *  - tensors are dense row-major ("contiguous"); leading batch dims are flattened by the caller;
  *  - `dtype`: DSA_F32 or DSA_F64 (the reference supports both; CI runs float64);
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous
- *    on that stream, re-entrant, and keep no mutable global state;
+ *    on that stream, re-entrant, and keep no mutable global state: the library allocates NO device memory.
+ *    The tuned kernels need two kinds of workspace, both owned by the caller:
+ *      `scratch`  DSA_SCRATCH_BYTES of device memory per call (work-queue counters of the persistent kernels),
+ *                 zeroed by the library on `stream`; it must not be shared by calls that can overlap in time (one
+ *                 buffer per stream, or one fresh buffer per call from a stream-ordered allocator).  scratch = NULL
+ *                 selects the kernel family that needs none (DSA_ALGO_TUNED then fails with
+ *                 DSA_ERR_INVALID_ARGUMENT);
+ *      `images`   per-CONFIGURATION constants prepared once (dsa_mcep_prepare), read-only afterwards and
+ *                 shareable by any number of concurrent calls on the same device;
+ *    the only per-process state is, per kernel, the set of devices whose dynamic-LDS limit has been raised;
  *  - return value: DSA_OK (0) or a negative dsa_status; dsa_last_error() gives the message of
  *    the last failure on the calling thread.  Nothing throws across the boundary.
  *  - argument VALIDATION of user-facing options (ValueError text etc.) is done by the host
@@ -31,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 100 /* 0.1.0 */
+#define DSA_VERSION 110 /* 0.1.1: caller-owned workspaces (images / scratch), no library-owned device memory */
 
 typedef enum {
     DSA_OK = 0,
@@ -42,6 +51,8 @@ typedef enum {
 } dsa_status;
 
 enum { DSA_F32 = 0, DSA_F64 = 1 };
+/* size of the per-call `scratch` the tuned persistent kernels draw their work items through */
+#define DSA_SCRATCH_BYTES 64
 /* F.pad modes of Frame (frame.py:134-137) */
 enum { DSA_PAD_CONSTANT = 0, DSA_PAD_REFLECT = 1, DSA_PAD_REPLICATE = 2, DSA_PAD_CIRCULAR = 3 };
 /* fftr.py:110-121 */
@@ -189,15 +200,24 @@ int dsa_fftcep_bwd(const void* gout, const void* x, int64_t F, int32_t fft_lengt
  *   alpha_vec:(M+1) = (-alpha)^i                            (mcep.py:179-181)
  * so that one Newton step is  d = mc D ; e = exp(log X - 2 d) ; rt = e E ;
  * mc += solve(T(rt[:M+1]) + H(rt), rt[:M+1] - alpha_vec).
- * mc_hist: NULL or (n_iter+1, F, M+1) receiving mc after 0..n_iter steps (saved for backward). */
+ * mc_hist: NULL or (n_iter+1, F, M+1) receiving mc after 0..n_iter steps (saved for backward).
+ * images / scratch: see Conventions.  The tuned gfx950 kernel (float32, fft_length 512, cep_order 24) consumes G, D, E
+ * as binary16 hi/lo operand images in matrix-core lane order: dsa_mcep_images_bytes() is their size (0 when the
+ * configuration has no tuned kernel: images may then be NULL) and dsa_mcep_prepare() writes them -- once per
+ * configuration, what MelCepstralAnalysis._precompute (mcep.py:133-187) is to the reference.  With
+ * DSA_ALGO_AUTO the tuned kernel runs iff the configuration allows it AND images and scratch are given. */
+int64_t dsa_mcep_images_bytes(int32_t nfft, int32_t M, int32_t dtype);
+int dsa_mcep_prepare(const void* G, const void* D, const void* E, int32_t nfft, int32_t M, int32_t dtype,
+                     void* images, void* stream);
 int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, int32_t n_iter, const void* G,
                  const void* D, const void* E, const void* alpha_vec, int32_t dtype, int32_t algo,
-                 void* mc, void* mc_hist, void* stream);
+                 const void* images, void* scratch, void* mc, void* mc_hist, void* stream);
 /* gradient of the UNROLLED n_iter-step iteration (what autograd gives the reference).
  * gmc:(F,M+1), X, mc_hist as saved by the forward -> gX:(F,nfft/2+1). */
 int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist, int64_t F, int32_t nfft,
                  int32_t M, int32_t n_iter, const void* G, const void* D, const void* E,
-                 const void* alpha_vec, int32_t dtype, int32_t algo, void* gX, void* stream);
+                 const void* alpha_vec, int32_t dtype, int32_t algo, const void* images, void* scratch,
+                 void* gX, void* stream);
 
 /* ------------------------------------------------------------------ a11  autocorrelation
  * Autocorrelation._forward, acorr.py:110-120.  x:(F,L) -> r:(F,M+1).  Computed as direct lag
@@ -218,15 +238,16 @@ int dsa_levdur_bwd(const void* gout, const void* r, const void* out, int64_t F, 
 
 /* ------------------------------------------------------------------ a13  LPC
  * LinearPredictiveCodingAnalysis._forward, lpc.py:137-139 = levdur(acorr(x)); x:(F,L) frames. */
-int dsa_lpc_fwd(const void* x, int64_t F, int32_t L, int32_t M, double eps, int32_t dtype, void* out,
-                void* stream);
+int dsa_lpc_fwd(const void* x, int64_t F, int32_t L, int32_t M, double eps, int32_t dtype, void* scratch,
+                void* out, void* stream);
 int dsa_lpc_bwd(const void* gout, const void* x, const void* out, int64_t F, int32_t L, int32_t M,
                 double eps, int32_t dtype, void* gx, void* stream);
 /* Fused LPC branch of the README (README.md:198-201): LPC(Window(Frame(x))) in one kernel.
- * x:(B,T), w:(L) -> out:(B,N,M+1). */
+ * x:(B,T), w:(L) or NULL (a window of ones) -> out:(B,N,M+1).  scratch: see Conventions (the tuned kernel for
+ * float32 / lpc_order 24 hands out 64-frame work items through a counter). */
 int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P,
                              const void* w, int32_t center, int32_t pad_mode, int32_t M, double eps,
-                             int32_t dtype, void* out, void* stream);
+                             int32_t dtype, void* scratch, void* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -132,3 +132,46 @@ def test_rccl_path_world1():
     res = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_smoke.py")], env=env, capture_output=True,
                          text=True, timeout=300)
     assert res.returncode == 0 and "nccl smoke OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def test_mcep_many_launches_two_tables_four_streams():
+    """The library owns no device memory (include/diffsptk_amd.h, Conventions): operand images are per-configuration
+    constants prepared by the caller's side once, the tile-queue counters live in a per-call scratch.  More
+    launches in flight than any fixed pool could hold -- 4 streams x 40 launches, two different alpha tables
+    interleaved, forward and backward -- must reproduce the single-stream results bit for bit."""
+    from diffsptk_amd import ops
+
+    stft = dsp.STFT(400, 80, 512, device=DEV)
+    mA = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, device=DEV)
+    mB = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.55, n_iter=10, device=DEV)
+    X = stft(torch.randn(48, 16000, generator=torch.Generator().manual_seed(77)).to(DEV))
+    wts = torch.linspace(-1, 1, 25, device=DEV)
+
+    def fwd_bwd(m, Xin):
+        Xg = Xin.clone().requires_grad_(True)
+        mc = m(Xg)
+        (mc * wts).sum().backward()
+        return mc.detach(), Xg.grad
+
+    refA, refB = fwd_bwd(mA, X), fwd_bwd(mB, X)
+    assert not torch.equal(refA[0], refB[0])
+    imgA = ops.mcep_images(mA.G, mA.D, mA.E, 512, 24)
+    assert imgA is not None and imgA is ops.mcep_images(mA.G, mA.D, mA.E, 512, 24)   # prepared once, then cached
+    assert imgA.data_ptr() != ops.mcep_images(mB.G, mB.D, mB.E, 512, 24).data_ptr()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = []
+    for i in range(160):
+        s = streams[i % 4]
+        with torch.cuda.stream(s):
+            m = mA if (i // 4) % 2 == 0 else mB
+            outs.append((i, fwd_bwd(m, X)))
+    torch.cuda.synchronize()
+    for i, (mc, g) in outs:
+        ref = refA if (i // 4) % 2 == 0 else refB
+        assert torch.equal(mc, ref[0]) and torch.equal(g, ref[1]), i
+    # the explicit error instead of a silent fallback: TUNED without the workspaces
+    with pytest.raises(_lib.BackendError):
+        mc = torch.empty(4, 25, device=DEV)
+        ops._call("dsa_mcep_fwd", ops._p(X[0, :4].contiguous()), 4, 512, 24, 10, ops._p(mA.G), ops._p(mA.D), ops._p(mA.E),
+                  ops._p(mA.alpha_vector), _lib.F32, _lib.ALGO_TUNED, None, None, ops._p(mc), None, ops._stream())
