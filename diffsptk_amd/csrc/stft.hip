@@ -80,8 +80,9 @@ __global__ void frame_bwd_const_kernel(const T* __restrict__ gy, const T* __rest
                                        long Tlen, long N, int L, int P, int left,
                                        T* __restrict__ gx)
 {
-    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long b = blockIdx.y;
+    const long tb = (Tlen + blockDim.x - 1) / blockDim.x;   // blocks per utterance: (utterance, block) folded into grid.x
+    const long b = blockIdx.x / tb;
+    long t = ((long)blockIdx.x - b * tb) * blockDim.x + threadIdx.x;
     if (t >= Tlen) return;
     // frames n with 0 <= t + left - n*P < L
     long p = t + left;
@@ -1429,7 +1430,9 @@ DSA_EXPORT int dsa_frame_fwd(const void* x, int64_t B, int64_t T, int32_t L, int
 {
     DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0, "frame: sizes must be positive");
     DSA_REQUIRE(pad_mode >= 0 && pad_mode <= 3, "frame: unknown pad mode");
-    DSA_REQUIRE(pad_mode != DSA_PAD_REFLECT || (L / 2 < T && L - 1 < T) || T == 1,
+    // F.pad(mode="reflect") needs every pad amount -- (L//2, (L-1)//2) centred, (0, L-1) otherwise, frame.py:130-137 --
+    // below the signal length
+    DSA_REQUIRE(pad_mode != DSA_PAD_REFLECT || (center ? L / 2 : L - 1) < T || L == 1,
                 "frame: reflect padding needs pad < input length");
     int64_t N = dsa_num_frames(T, P), F = B * N;
     if (F == 0) return DSA_OK;
@@ -1469,7 +1472,9 @@ static int frame_bwd_impl(const void* gy, int64_t B, int64_t Tlen, int L, int P,
         hipLaunchKernelGGL((row_mean_kernel<T>), dim3((unsigned)F), dim3(64), 0, st, (const T*)gy, L, gmean);
     }
     if (pad_mode == DSA_PAD_CONSTANT) {
-        dim3 grid((unsigned)((Tlen + 255) / 256), (unsigned)B);
+        const int64_t nblk = ((Tlen + 255) / 256) * B;
+        if (nblk > 0x7fffffffLL) return fail(DSA_ERR_UNSUPPORTED, "frame_bwd: batch too large for one launch%s");
+        dim3 grid((unsigned)nblk);
         hipLaunchKernelGGL((frame_bwd_const_kernel<T>), grid, dim3(256), 0, st, (const T*)gy, gmean,
                            (long)Tlen, (long)N, L, P, left, (T*)gx);
     } else {
@@ -1623,7 +1628,9 @@ DSA_EXPORT int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int3
     DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "stft: fft_length must be positive even");
     DSA_REQUIRE(pad_mode >= 0 && pad_mode <= 3, "stft: unknown pad mode");
     DSA_REQUIRE(out_format >= 0 && out_format <= 5, "stft: unknown out_format");
-    DSA_REQUIRE(pad_mode != DSA_PAD_REFLECT || (L / 2 < T && L - 1 < T) || T == 1,
+    // F.pad(mode="reflect") needs every pad amount below the signal length (frame.py:130-137: (L//2, (L-1)//2) when
+    // centred, (0, L-1) otherwise) and rejects a one-sample signal
+    DSA_REQUIRE(pad_mode != DSA_PAD_REFLECT || (center ? L / 2 : L - 1) < T || L == 1,
                 "stft: reflect padding needs pad < input length");
     hipStream_t st = (hipStream_t)stream;
     int64_t N = dsa_num_frames(T, P);

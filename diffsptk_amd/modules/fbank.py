@@ -6,6 +6,7 @@ import torch
 from .. import ops
 from ..utils import tables
 from ..utils.private import check_size, filter_values, to
+from . import _learnable
 from .base import BaseFunctionalModule, Precomputed
 
 _FORMATS = {0: "y", "y": "y", 1: "yE", "yE": "yE", 2: "y,E", "y,E": "y,E"}
@@ -20,10 +21,11 @@ class MelFilterBankAnalysis(BaseFunctionalModule):
                  erb_factor: float | None = None, use_power: bool = False, out_format: str | int = "y",
                  learnable: bool = False, device=None, dtype=None) -> None:
         super().__init__()
-        if learnable:
-            raise NotImplementedError("a learnable filter bank is not supported by the HIP backend.")
         self.in_dim = fft_length // 2 + 1
-        self._register_precomputed(self._precompute(**filter_values(locals(), drop_keys=["learnable"])))
+        # learnable (fbank.py:112-122): H becomes a Parameter; the analysis then runs on stock device operators
+        # (modules/_learnable.py), which also give the gradient for H
+        self._register_precomputed(self._precompute(**filter_values(locals(), drop_keys=["learnable"])),
+                                   learnable=bool(learnable))
 
     def forward(self, x: torch.Tensor):
         check_size(x.size(-1), self.in_dim, "dimension of spectrum")
@@ -66,7 +68,10 @@ class MelFilterBankAnalysis(BaseFunctionalModule):
 
     @staticmethod
     def _forward(x: torch.Tensor, *, floor: float, gamma: float, use_power: bool, out_format: str, H: torch.Tensor):
-        y, E = ops.FbankFn.apply(x, H, floor, gamma, use_power)
+        if H.requires_grad:
+            y, E = _learnable.fbank_with_weights(x, H, floor, gamma, use_power)
+        else:
+            y, E = ops.FbankFn.apply(x, H, floor, gamma, use_power)
         if out_format == "y":
             return y
         if out_format == "yE":

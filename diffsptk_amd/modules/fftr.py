@@ -6,6 +6,7 @@ import torch
 from .. import ops
 from ..utils import tables
 from ..utils.private import filter_values, to
+from . import _learnable
 from .base import BaseFunctionalModule, Precomputed
 
 _FORMATS = {"complex": 0, "real": 1, "imaginary": 2, "amplitude": 3, "power": 4}
@@ -21,13 +22,13 @@ def fftr_format_code(out_format) -> int:
 
 class RealValuedFastFourierTransform(BaseFunctionalModule):
     """x:(..., L) -> rfft(x, n=fft_length) formatted as complex/real/imaginary/amplitude/power
-    (fftr.py:136-151).  The learnable DFT-matrix variant (fftr.py:123-129) is a training
-    feature outside the hot path and is not provided by this backend."""
+    (fftr.py:136-151).  ``learnable=True`` (fftr.py:123-129) makes the DFT matrix a Parameter ``W`` and runs on
+    stock device operators (modules/_learnable.py): a training feature off the kernels' hot path."""
 
     def __init__(self, fft_length: int | None, out_format: str | int = "complex", learnable: bool = False,
                  device=None, dtype=None) -> None:
         super().__init__()
-        self._register_precomputed(self._precompute(**filter_values(locals())))
+        self._register_precomputed(self._precompute(**filter_values(locals())), ("W",) if learnable else False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._call_forward(x)
@@ -48,7 +49,10 @@ class RealValuedFastFourierTransform(BaseFunctionalModule):
         RealValuedFastFourierTransform._check(fft_length)
         fmt = fftr_format_code(out_format)
         if learnable:
-            raise NotImplementedError("diffsptk_amd: the learnable DFT basis is not supported by this backend")
+            if fft_length is None:
+                raise ValueError("fft_length must be specified when learnable is True.")
+            W = to(_learnable.dft_matrix(fft_length), device=device, dtype=dtype)
+            return Precomputed(values={"fft_length": fft_length, "fmt": fmt}, tensors={"W": W})
         if fft_length is None:  # transform length follows the input (torch.fft.rfft(x, n=None))
             return Precomputed(values={"fft_length": None, "fmt": fmt})
         tw = to(tables.twiddle_table(fft_length), device=device, dtype=dtype)
@@ -56,7 +60,9 @@ class RealValuedFastFourierTransform(BaseFunctionalModule):
 
     @staticmethod
     def _forward(x: torch.Tensor, *, fft_length: int | None, fmt: int,
-                 twiddle: torch.Tensor | None = None) -> torch.Tensor:
+                 twiddle: torch.Tensor | None = None, W: torch.Tensor | None = None) -> torch.Tensor:
+        if W is not None:
+            return _learnable.rfft_with_basis(x, W, fft_length, fmt)
         if fft_length is None:
             fft_length = x.size(-1)
             if fft_length % 2 == 1:

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import math
+import warnings
 
 import torch
 
@@ -62,10 +63,20 @@ class GriffinLim(BaseFunctionalModule):
                            layers={"stft": stft, "istft": istft})
 
     @staticmethod
-    @torch.no_grad()
     def _forward(y: torch.Tensor, out_length: int | None, *, n_iter: int, alpha: float, beta: float, gamma: float,
                  init_phase: str, verbose: bool, stft, istft) -> torch.Tensor:
         eps = 1e-16
+        if y.requires_grad and torch.is_grad_enabled():
+            # the reference back-propagates through the unrolled iteration; the phase-update kernel keeps its momentum
+            # buffers in place and records no graph
+            warnings.warn("diffsptk_amd.GriffinLim does not record an autograd graph: the result is detached "
+                          "(the reference differentiates through the iteration).", stacklevel=3)
+        with torch.no_grad():
+            return GriffinLim._iterate(y, out_length, n_iter=n_iter, alpha=alpha, beta=beta, gamma=gamma,
+                                       init_phase=init_phase, verbose=verbose, stft=stft, istft=istft, eps=eps)
+
+    @staticmethod
+    def _iterate(y, out_length, *, n_iter, alpha, beta, gamma, init_phase, verbose, stft, istft, eps):
         yc = y.contiguous()
         phase = None
         if init_phase == "random":   # griffin.py:188-189 (the generator is torch's, as in the reference)
@@ -75,10 +86,10 @@ class GriffinLim(BaseFunctionalModule):
         z = ops.griffin_update(None, yc, phase, t_prev, d_prev, True, alpha, beta, gamma, eps)
         for n in range(n_iter):
             t = stft(istft(z, out_length=out_length))                 # griffin.py:269
-            z = ops.griffin_update(t, yc, None, t_prev, d_prev, n == 0, alpha, beta, gamma, eps, out=z)
-            if verbose:   # griffin.py:286-290; the spectral convergence of the current estimate
-                c = z.abs()
+            if verbose:   # griffin.py:286-290: |STFT| of the current waveform estimate, BEFORE the projection, against the target
+                c = t[..., : yc.size(-2), :].abs()
                 s = torch.sqrt(yc + eps)
                 snr = -10 * torch.log10(torch.linalg.norm(c - s) / torch.linalg.norm(s))
                 print(f"  iter {n + 1:5d}: SNR = {float(snr):g}")
+            z = ops.griffin_update(t, yc, None, t_prev, d_prev, n == 0, alpha, beta, gamma, eps, out=z)
         return istft(z, out_length=out_length)                        # griffin.py:292

@@ -6,6 +6,7 @@ import torch
 from .. import ops
 from ..utils import tables
 from ..utils.private import check_size, filter_values, to
+from . import _learnable
 from .base import BaseFunctionalModule, Precomputed
 
 
@@ -18,10 +19,8 @@ class RealValuedInverseFastFourierTransform(BaseFunctionalModule):
     def __init__(self, fft_length: int, out_length: int | None = None, learnable: bool = False, device=None,
                  dtype=None) -> None:
         super().__init__()
-        if learnable:
-            raise NotImplementedError("diffsptk_amd: the learnable DFT basis is not supported by this backend")
         self.in_dim = fft_length // 2 + 1
-        self._register_precomputed(self._precompute(**filter_values(locals(), drop_keys=["learnable"])))
+        self._register_precomputed(self._precompute(**filter_values(locals())), ("W",) if learnable else False)
 
     def forward(self, y: torch.Tensor) -> torch.Tensor:
         check_size(y.size(-1), self.in_dim, "length of spectrum")
@@ -41,13 +40,20 @@ class RealValuedInverseFastFourierTransform(BaseFunctionalModule):
             raise ValueError("out_length must be in [1, fft_length].")
 
     @staticmethod
-    def _precompute(fft_length: int, out_length: int | None = None, device=None, dtype=None) -> Precomputed:
+    def _precompute(fft_length: int, out_length: int | None = None, learnable: bool = False, device=None,
+                    dtype=None) -> Precomputed:
         RealValuedInverseFastFourierTransform._check(fft_length, out_length)
+        if learnable:   # ifftr.py:125-129: the inverse DFT matrix becomes a Parameter (torch operators, _learnable.py)
+            return Precomputed(values={"fft_length": fft_length, "out_length": out_length or fft_length},
+                               tensors={"W": to(_learnable.idft_matrix(fft_length, out_length), device=device, dtype=dtype)})
         return Precomputed(values={"fft_length": fft_length, "out_length": out_length or fft_length},
                            tensors={"twiddle": to(tables.twiddle_table(fft_length), device=device, dtype=dtype)})
 
     @staticmethod
-    def _forward(y: torch.Tensor, *, fft_length: int, out_length: int, twiddle: torch.Tensor) -> torch.Tensor:
+    def _forward(y: torch.Tensor, *, fft_length: int, out_length: int, twiddle: torch.Tensor | None = None,
+                 W: torch.Tensor | None = None) -> torch.Tensor:
         if not y.is_complex():
             raise ValueError("Input must be a complex tensor.")
+        if W is not None:
+            return _learnable.irfft_with_basis(y, W)
         return ops.IfftrFn.apply(y, fft_length, out_length, twiddle)

@@ -6,6 +6,7 @@ import torch
 from .. import _lib, ops
 from ..utils import tables
 from ..utils.private import filter_values, to
+from . import _learnable
 from .base import BaseFunctionalModule, Precomputed
 from .ifftr import RealValuedInverseFastFourierTransform
 from .unframe import Unframe
@@ -19,7 +20,11 @@ class InverseShortTimeFourierTransform(BaseFunctionalModule):
                  window: str | int = "blackman", norm: str | int = "power", symmetric: bool = True,
                  learnable: bool | list[str] = False, device=None, dtype=None) -> None:
         super().__init__()
-        self._register_precomputed(self._precompute(**filter_values(locals())))
+        pre = self._precompute(**filter_values(locals()))
+        learn_window = learnable is True or (not isinstance(learnable, bool) and "window" in learnable)
+        learn_basis = learnable is True or (not isinstance(learnable, bool) and "basis" in learnable)
+        names = (("window",) if learn_window else ()) + (("W",) if learn_basis else ())
+        self._register_precomputed(pre, names if names else False)
 
     def forward(self, y: torch.Tensor, out_length: int | None = None) -> torch.Tensor:
         return self._call_forward(y, out_length)
@@ -43,20 +48,26 @@ class InverseShortTimeFourierTransform(BaseFunctionalModule):
                     window: str | int = "blackman", norm: str | int = "power", symmetric: bool = True,
                     learnable: bool | list[str] = False, device=None, dtype=None) -> Precomputed:
         InverseShortTimeFourierTransform._check(learnable)
-        if learnable:
-            raise NotImplementedError("diffsptk_amd: learnable synthesis basis / window are not supported by this backend")
         RealValuedInverseFastFourierTransform._check(fft_length, frame_length)
         Unframe._check(frame_length, frame_period)
         w = tables.window_table(frame_length, window, norm, symmetric)
+        tens = {"window": to(w, device=device, dtype=dtype),
+                "twiddle": to(tables.twiddle_table(fft_length), device=device, dtype=dtype)}
+        learn_basis = learnable is True or (not isinstance(learnable, bool) and "basis" in learnable)
+        if learn_basis:
+            tens["W"] = to(_learnable.idft_matrix(fft_length, frame_length), device=device, dtype=dtype)
         return Precomputed(values={"frame_length": frame_length, "frame_period": frame_period, "fft_length": fft_length,
-                                   "center": center},
-                           tensors={"window": to(w, device=device, dtype=dtype),
-                                    "twiddle": to(tables.twiddle_table(fft_length), device=device, dtype=dtype)})
+                                   "center": center, "learn": bool(learnable)},
+                           tensors=tens)
 
     @staticmethod
     def _forward(y: torch.Tensor, out_length: int | None, *, frame_length: int, frame_period: int, fft_length: int,
-                 center: bool, window: torch.Tensor, twiddle: torch.Tensor) -> torch.Tensor:
+                 center: bool, window: torch.Tensor, twiddle: torch.Tensor, learn: bool = False,
+                 W: torch.Tensor | None = None) -> torch.Tensor:
         if not y.is_complex():
             raise ValueError("Input must be a complex tensor.")
+        if learn:   # learnable basis and / or window (istft.py:143-176): stock device operators, modules/_learnable.py
+            fr = _learnable.irfft_with_basis(y, W) if W is not None else torch.fft.irfft(y, n=fft_length)[..., :frame_length]
+            return _learnable.unframe_with_window(fr, window, frame_period, center, out_length)
         return ops.IstftFn.apply(y, window, twiddle, frame_length, frame_period, fft_length, center, out_length,
                                  _lib.ALGO_AUTO)

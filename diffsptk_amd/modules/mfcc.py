@@ -6,6 +6,7 @@ import torch
 from .. import ops
 from ..utils import tables
 from ..utils.private import filter_values, to
+from . import _learnable
 from .base import BaseFunctionalModule, Precomputed
 from .fbank import MelFilterBankAnalysis
 
@@ -22,10 +23,10 @@ class MelFrequencyCepstralCoefficientsAnalysis(BaseFunctionalModule):
                  scale: str = "htk", erb_factor: float | None = None, out_format: str | int = "y",
                  learnable: bool = False, device=None, dtype=None) -> None:
         super().__init__()
-        if learnable:
-            raise NotImplementedError("a learnable filter bank is not supported by the HIP backend.")
         self.in_dim = fft_length // 2 + 1
-        self._register_precomputed(self._precompute(**filter_values(locals(), drop_keys=["learnable"])))
+        # learnable (mfcc.py:118-121): the filter bank H becomes a Parameter (the DCT / lifter matrix W stays fixed)
+        self._register_precomputed(self._precompute(**filter_values(locals(), drop_keys=["learnable"])),
+                                   ("H",) if learnable else False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._call_forward(x)
@@ -61,7 +62,11 @@ class MelFrequencyCepstralCoefficientsAnalysis(BaseFunctionalModule):
     def _forward(x: torch.Tensor, *, floor: float, gamma: float, out_format: str, H: torch.Tensor,
                  W: torch.Tensor) -> torch.Tensor:
         # amplitude-domain filter bank (mfcc.py:200 use_power=False) and DCT-II x truncation x lifter in ONE launch
-        cy, E = ops.MfccFn.apply(x, H, W, floor, gamma, False)
+        if H.requires_grad:
+            yb, E = _learnable.fbank_with_weights(x, H, floor, gamma, False)
+            cy = torch.matmul(yb, W)
+        else:
+            cy, E = ops.MfccFn.apply(x, H, W, floor, gamma, False)
         c, y = cy[..., :1], cy[..., 1:]
         if out_format == "y":
             return y

@@ -6,6 +6,7 @@ import torch
 from .. import ops
 from ..utils import tables
 from ..utils.private import filter_values, to
+from . import _learnable
 from .base import BaseFunctionalModule, Precomputed
 
 _FORMATS = {"db": 0, "log-magnitude": 1, "magnitude": 2, "power": 3}
@@ -26,7 +27,7 @@ class Spectrum(BaseFunctionalModule):
     def __init__(self, fft_length: int, *, eps: float = 0, relative_floor: float | None = None,
                  out_format: str | int = "power", learnable: bool = False) -> None:
         super().__init__()
-        self._register_precomputed(self._precompute(**filter_values(locals())))
+        self._register_precomputed(self._precompute(**filter_values(locals())), ("W",) if learnable else False)
 
     def forward(self, b: torch.Tensor | None = None, a: torch.Tensor | None = None) -> torch.Tensor:
         return self._call_forward(b, a)
@@ -51,8 +52,10 @@ class Spectrum(BaseFunctionalModule):
         Spectrum._check(fft_length, eps, relative_floor)
         if fft_length % 2 == 1:
             raise ValueError("fft_length must be positive even.")
-        if learnable:
-            raise NotImplementedError("diffsptk_amd: the learnable DFT basis is not supported by this backend")
+        if learnable:   # spec.py:133-141: the transform becomes a learnable DFT matrix (torch operators, _learnable.py)
+            return Precomputed(values={"fft_length": fft_length, "eps": eps, "relative_floor": relative_floor,
+                                       "fmt": spec_format_code(out_format)},
+                               tensors={"W": to(_learnable.dft_matrix(fft_length), dtype=torch.get_default_dtype())})
         # the twiddle table follows the input's device/dtype at call time (Spectrum takes no
         # device/dtype argument in the reference either); cached per (device, dtype) below
         return Precomputed(values={"fft_length": fft_length, "eps": eps, "relative_floor": relative_floor,
@@ -60,7 +63,9 @@ class Spectrum(BaseFunctionalModule):
 
     @staticmethod
     def _forward(b: torch.Tensor | None, a: torch.Tensor | None, *, fft_length: int, eps: float,
-                 relative_floor: float | None, fmt: int) -> torch.Tensor:
+                 relative_floor: float | None, fmt: int, W: torch.Tensor | None = None) -> torch.Tensor:
+        if W is not None:
+            return _learnable.spectrum_with_basis(b, a, W, fft_length, eps, relative_floor, fmt)
         if b is None and a is None:
             raise ValueError("Either b or a must be specified.")
         ref = b if b is not None else a

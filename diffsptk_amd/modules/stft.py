@@ -7,6 +7,7 @@ import torch
 from .. import _lib, ops
 from ..utils import tables
 from ..utils.private import filter_values, to
+from . import _learnable
 from .base import BaseFunctionalModule, Precomputed
 from .frame import Frame
 from .spec import Spectrum, spec_format_code
@@ -21,7 +22,8 @@ class ShortTimeFourierTransform(BaseFunctionalModule):
     Same options as the reference (stft.py:86-104): framing (center / zmean / mode), window
     (type / norm / symmetric), spectrum (eps / relative_floor / out_format incl. "complex").
     ``learnable`` may contain "window" (the table becomes a Parameter, its gradient is computed
-    by the backward kernel); the learnable DFT *basis* is not provided by this backend.
+    by the backward kernel) and "basis" (stft.py:179-184: the DFT matrix becomes a Parameter ``W``; framing and
+    windowing stay on the kernels, the transform runs on stock device operators, modules/_learnable.py).
     """
 
     def __init__(self, frame_length: int, frame_period: int, fft_length: int, *, center: bool = True,
@@ -32,7 +34,9 @@ class ShortTimeFourierTransform(BaseFunctionalModule):
         super().__init__()
         pre = self._precompute(**filter_values(locals()))
         learn_window = learnable is True or (not isinstance(learnable, bool) and "window" in learnable)
-        self._register_precomputed(pre, ("window",) if learn_window else False)
+        learn_basis = learnable is True or (not isinstance(learnable, bool) and "basis" in learnable)
+        names = (("window",) if learn_window else ()) + (("W",) if learn_basis else ())
+        self._register_precomputed(pre, names if names else False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._call_forward(x)
@@ -57,8 +61,7 @@ class ShortTimeFourierTransform(BaseFunctionalModule):
                     relative_floor: float | None, out_format: str | int, learnable: bool | list[str],
                     device, dtype, module: bool = True) -> Precomputed:
         ShortTimeFourierTransform._check(learnable)
-        if learnable is True or (not isinstance(learnable, bool) and "basis" in learnable):
-            raise NotImplementedError("diffsptk_amd: the learnable DFT basis is not supported by this backend")
+        learn_basis = learnable is True or (not isinstance(learnable, bool) and "basis" in learnable)
         # same validation as the three sub-modules of the reference cascade
         Frame._check(frame_length, frame_period)
         ops.pad_mode_code(mode)
@@ -73,17 +76,25 @@ class ShortTimeFourierTransform(BaseFunctionalModule):
                 raise ValueError("fft_length must be positive even.")
             fmt = spec_format_code(out_format)
         w = tables.window_table(frame_length, window, norm, symmetric)
+        tens = {"window": to(w, device=device, dtype=dtype),
+                "twiddle": to(tables.twiddle_table(fft_length), device=device, dtype=dtype)}
+        if learn_basis:
+            tens["W"] = to(_learnable.dft_matrix(fft_length), device=device, dtype=dtype)
         return Precomputed(
             values={"frame_length": frame_length, "frame_period": frame_period, "fft_length": fft_length,
                     "center": center, "zmean": zmean, "mode": mode, "eps": eps,
                     "relative_floor": relative_floor, "fmt": fmt},
-            tensors={"window": to(w, device=device, dtype=dtype),
-                     "twiddle": to(tables.twiddle_table(fft_length), device=device, dtype=dtype)},
+            tensors=tens,
         )
 
     @staticmethod
     def _forward(x: torch.Tensor, *, frame_length: int, frame_period: int, fft_length: int, center: bool,
                  zmean: bool, mode: str, eps: float, relative_floor: float | None, fmt: int,
-                 window: torch.Tensor, twiddle: torch.Tensor) -> torch.Tensor:
+                 window: torch.Tensor, twiddle: torch.Tensor, W: torch.Tensor | None = None) -> torch.Tensor:
+        if W is not None:   # learnable basis: Frame and Window kernels, then the transform against W (stft.py:237-241)
+            fr = ops.WindowFn.apply(ops.FrameFn.apply(x, frame_length, frame_period, center, zmean, mode), window, fft_length)
+            if fmt == 4:
+                return _learnable.rfft_with_basis(fr, W, fft_length, 0)
+            return _learnable.spectrum_with_basis(fr, None, W, fft_length, eps, relative_floor, fmt)
         return ops.StftFn.apply(x, window, twiddle, frame_length, frame_period, fft_length, center, zmean,
                                 mode, eps, relative_floor, fmt, _lib.ALGO_AUTO)

@@ -6,6 +6,7 @@ import torch
 from .. import ops
 from ..utils import tables
 from ..utils.private import check_size, filter_values, to
+from . import _learnable
 from .base import BaseFunctionalModule, Precomputed
 
 
@@ -19,13 +20,17 @@ class Unframe(BaseFunctionalModule):
                  norm: str | int = "none", symmetric: bool = True, learnable: bool = False, device=None,
                  dtype=None) -> None:
         super().__init__()
-        if learnable:
-            raise NotImplementedError("diffsptk_amd: a learnable synthesis window is not supported by this backend")
         self.in_dim = frame_length
-        self._register_precomputed(self._precompute(**filter_values(locals(), drop_keys=["learnable"])))
+        # learnable: the synthesis window becomes a Parameter and the overlap-add runs on stock device operators
+        # (modules/_learnable.py) -- the kernels return no gradient for the window of the DIVISOR fold(w * w)
+        self.learnable = bool(learnable)
+        self._register_precomputed(self._precompute(**filter_values(locals(), drop_keys=["learnable"])),
+                                   ("window",) if learnable else False)
 
     def forward(self, y: torch.Tensor, out_length: int | None = None) -> torch.Tensor:
         check_size(y.size(-1), self.in_dim, "length of frame")
+        if self.learnable:
+            return _learnable.unframe_with_window(y, self.window, self.frame_period, self.center, out_length)
         return self._call_forward(y, out_length)
 
     @staticmethod

@@ -375,6 +375,7 @@ class IfftrFn(torch.autograd.Function):
     def forward(ctx, y, fft_length, out_length, twiddle):
         _require_device(y, twiddle)
         yr = torch.view_as_real(y.resolve_conj()).contiguous()
+        _same_dtype(yr, twiddle)   # complex128 spectra need float64 tables: the kernels do not promote
         K = fft_length // 2 + 1
         F = yr.numel() // (2 * K)
         G = _irfft_scale(yr, fft_length)
@@ -453,6 +454,7 @@ class IstftFn(torch.autograd.Function):
     def forward(ctx, y, window, twiddle, L, P, fft_length, center, out_length, algo):
         _require_device(y, window, twiddle)
         yr = torch.view_as_real(y.resolve_conj()).contiguous()
+        _same_dtype(yr, window, twiddle)   # complex128 spectra need float64 tables: the kernels do not promote
         wc = window.contiguous()
         N, K = yr.shape[-3:-1]
         B = yr.numel() // (N * K * 2)
@@ -491,6 +493,7 @@ def griffin_update(t, y, phase, t_prev, d_prev, first, alpha, beta, gamma, eps, 
     spectrogram sqrt(y + 1e-16) c / (|c| + eps); t_prev / d_prev (real views, (..., K, 2)) are updated in place.
     t=None is the initial step (phase=None: zeros)."""
     _require_device(y)
+    _same_dtype(y, phase, t_prev, d_prev)
     K = y.size(-1)
     N = y.size(-2) if y.dim() >= 2 else 1
     B = y.numel() // max(N * K, 1)

@@ -175,3 +175,41 @@ def test_mcep_many_launches_two_tables_four_streams():
         mc = torch.empty(4, 25, device=DEV)
         ops._call("dsa_mcep_fwd", ops._p(X[0, :4].contiguous()), 4, 512, 24, 10, ops._p(mA.G), ops._p(mA.D), ops._p(mA.E),
                   ops._p(mA.alpha_vector), _lib.F32, _lib.ALGO_TUNED, None, None, ops._p(mc), None, ops._stream())
+
+
+def test_learnable_options_match_the_kernels_and_train():
+    """``learnable=`` (stft.py:73-76, fftr.py:123-129, fbank.py:112-122, istft.py, unframe.py): the tables become
+    Parameters and the affected stage runs on stock device operators (modules/_learnable.py).  At initialisation the
+    result must equal the kernels' (same transform), and every Parameter must receive a finite, non-zero gradient."""
+    x = torch.randn(3, 1600, generator=torch.Generator().manual_seed(5)).to(DEV)
+    fixed = dsp.STFT(400, 80, 512, device=DEV)
+    for learn in (True, ["basis"], ["window"]):
+        m = dsp.STFT(400, 80, 512, learnable=learn, device=DEV)
+        y = m(x)
+        ref = fixed(x)
+        err = (y.detach() - ref).abs() / ref.amax(-1, keepdim=True)
+        assert float(err.max()) < 5e-6, (learn, float(err.max()))
+        torch.log(y).sum().backward()
+        for n, p in m.named_parameters():
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) > 0, (learn, n)
+    mc = dsp.STFT(400, 80, 512, out_format="complex", learnable=["basis"], device=DEV)
+    zc = dsp.STFT(400, 80, 512, out_format="complex", device=DEV)(x)
+    assert float((mc(x) - zc).abs().max()) < 1e-4 * float(zc.abs().max())
+    # inverse path: learnable synthesis basis + window reproduce the waveform of the fused kernel
+    inv = dsp.ISTFT(400, 80, 512, learnable=True, device=DEV)
+    xr = inv(zc, out_length=1600)
+    ref = dsp.ISTFT(400, 80, 512, device=DEV)(zc, out_length=1600)
+    assert float((xr - ref).abs().max()) < 2e-5
+    xr.square().sum().backward()
+    assert all(p.grad is not None and float(p.grad.abs().max()) > 0 for p in inv.parameters())
+    # filter bank / MFCC with a learnable H
+    X = fixed(x)
+    fb = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, learnable=True, device=DEV)
+    fb0 = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, device=DEV)
+    np.testing.assert_allclose(host(fb(X)), host(fb0(X)), rtol=2e-5, atol=2e-5)
+    fb(X).sum().backward()
+    assert float(fb.H.grad.abs().max()) > 0
+    mf = dsp.MFCC(fft_length=512, mfcc_order=12, n_channel=40, sample_rate=16000, learnable=True, device=DEV)
+    mf0 = dsp.MFCC(fft_length=512, mfcc_order=12, n_channel=40, sample_rate=16000, device=DEV)
+    np.testing.assert_allclose(host(mf(X)), host(mf0(X)), rtol=1e-4, atol=1e-4)
+    assert [n for n, _ in mf.named_parameters()] == ["H"]

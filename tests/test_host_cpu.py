@@ -271,3 +271,40 @@ def test_build_recipe_is_consistent():
     lib = _lib.load()
     for name in _lib.SIGNATURES:
         assert hasattr(lib, name), name
+
+
+def test_learnable_fallback_operators_match_the_transforms():
+    """modules/_learnable.py (the torch-operator fallbacks behind ``learnable=``) against numpy / the oracle: at
+    initialisation a learnable basis must reproduce the fixed transform it replaces (fftr.py:123-129,
+    ifftr.py:125-129, unframe.py:164-211, fbank.py:306-321)."""
+    from diffsptk_amd.modules import _learnable as Lr
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((5, 20))
+    W = torch.from_numpy(Lr.dft_matrix(32))
+    Y = np.fft.rfft(x, n=32)
+    for fmt, ref in ((0, Y), (1, Y.real), (2, Y.imag), (3, np.abs(Y)), (4, np.abs(Y) ** 2)):
+        np.testing.assert_allclose(Lr.rfft_with_basis(torch.from_numpy(x), W, 32, fmt).numpy(), ref, rtol=1e-12, atol=1e-12)
+    Wi = torch.from_numpy(Lr.idft_matrix(32, 20))
+    np.testing.assert_allclose(Lr.irfft_with_basis(torch.from_numpy(Y), Wi).numpy(), np.fft.irfft(Y, n=32)[:, :20], atol=1e-13)
+    b, a = rng.standard_normal((4, 3)), np.abs(rng.standard_normal((4, 4))) + 1.5
+    s = Lr.spectrum_with_basis(torch.from_numpy(b), torch.from_numpy(a), W, 32, 1e-6, -30.0, 0).numpy()
+    np.testing.assert_allclose(s, O.spec(b, a, fft_length=32, eps=1e-6, relative_floor=-30.0, out_format="db"), rtol=1e-10, atol=1e-10)
+    fr = rng.standard_normal((2, 9, 12))
+    w = O.window_table(12, "hanning", "none") + 0.1
+    for center, out_length in ((True, None), (False, None), (True, 30)):
+        got = Lr.unframe_with_window(torch.from_numpy(fr), torch.from_numpy(w), 4, center, out_length).numpy()
+        np.testing.assert_allclose(got, O.unframe(fr, 4, center=center, w=w, out_length=out_length), rtol=1e-12, atol=1e-12)
+    X = np.abs(rng.standard_normal((6, 17))) + 0.1
+    H = O.fbank_matrix(32, 8, 8000)
+    y, E = Lr.fbank_with_weights(torch.from_numpy(X), torch.from_numpy(H), 1e-5, 0.0, False)
+    yo = O.fbank(X, H, 1e-5, 0.0, False)
+    np.testing.assert_allclose(y.numpy(), yo[0] if isinstance(yo, tuple) else yo, rtol=1e-12)
+    # the learnable options register Parameters, the fixed ones keep the state_dict empty (base.py:64-67)
+    m = dsp.RealValuedFastFourierTransform(32, learnable=True)
+    assert [n for n, _ in m.named_parameters()] == ["W"] and m.W.shape == (32, 34)
+    assert [n for n, _ in dsp.STFT(12, 4, 16, learnable=True).named_parameters()] == ["window", "W"]
+    assert [n for n, _ in dsp.ISTFT(12, 4, 16, learnable=["basis"]).named_parameters()] == ["W"]
+    assert [n for n, _ in dsp.MelFilterBankAnalysis(fft_length=32, n_channel=8, sample_rate=8000, learnable=True).named_parameters()] == ["H"]
+    assert len(dsp.STFT(12, 4, 16).state_dict()) == 0
