@@ -7,19 +7,26 @@ alpha=0.42, n_iter=10) on synthetic 16 kHz waveforms, one process per GPU.
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over this rank's shard of utterances (inputs resident in
-HBM): fused STFT kernel -> mel-cepstral analysis kernel -> (N > 1) all-gather of the (B, 200, 25)
-features over RCCL, issued per quarter-batch chunk so that it overlaps the next chunk's kernels.  Weak scaling: 1024 utterances x 1 s per GPU, so N = 8 is
-BASELINE.json configs[4] (batch 8192 sharded 8x) and N = 1 is its per-GPU shard.
+HBM): fused STFT kernel -> mel-cepstral analysis kernel -> (N > 1) ONE in-place all-gather of the
+(B, 200, 25) features over RCCL, left in flight and completed one step later so that it runs behind the
+next step's kernels.  Weak scaling: 1024 utterances x 1 s per GPU, so N = 8 is BASELINE.json configs[4]
+(batch 8192 sharded 8x) and N = 1 is its per-GPU shard.
 
 Timing: an untimed clock ramp (--ramp-seconds, default 0.3 s of the same steps: the first ~20 ms after idle run
 10 % slower), W warmup steps, then exactly K steps between barrier + synchronize; defaults K = 200, W = 20
 (0.2 s of GPU time).  HIP events bracket the two launches of every fourth timed step (per-kernel averages).
 
-Rank 0 prints ONE JSON line (contract in the task statement) carrying, besides the headline
-value, `roofline` for the dominant kernel (mel-cepstral analysis, fp32 MFMA/VALU bound),
-`roofline_stft` for the fused Frame+Window+rFFT stage (HBM bound) and `cpu_baseline`
-(the reference's op sequence with stock PyTorch CPU ops, oracle/torch_port.py, on a bounded
-sample; N = 1 only).
+Rank 0 prints ONE JSON line (contract in the task statement).  Besides the headline value it carries
+  roofline        the dominant kernel (mel-cepstral analysis): bound "valu_issue" -- vector wave-instructions
+                  issued per second against the machine's issue rate -- with the algorithmic-flop figure beside it;
+  roofline_stft   the fused Frame+Window+rFFT stage (HBM bound, 1348 B/frame): the north star's ">= 50 %" number;
+  configs         the other BASELINE configs measured in the same run (N = 1): config 2 (STFT, batch 64, and the
+                  batch sweep), config 3 (STFT+mcep forward+backward, batch 256 and 1024, with roofline_bwd),
+                  config 4 (fused Frame+Window+LPC, batch 1024, with its roofline);
+  cpu_baseline    the reference's op sequence with stock PyTorch CPU ops (oracle/torch_port.py) on the host cores,
+                  at 1 / 8 / 32 / all physical cores (value = the best), with the host description (N = 1 only).
+`traffic` / `pmc` fields are STATIC: rocprofv3 --pmc passes of this command, committed under profiles/ (a counter
+pass cannot be taken from inside the process being timed); every other number is measured live in this run.
 """
 from __future__ import annotations
 
@@ -40,59 +47,116 @@ FL, FP, NFFT, M, ALPHA, N_ITER = 400, 80, 512, 24, 0.42, 10
 SAMPLES = 16000
 FRAMES_PER_UTT = (SAMPLES - 1) // FP + 1  # 200
 
-# algorithmic work per frame (DESIGN.md section "Kernels and rooflines")
+# algorithmic work per frame
 STFT_BYTES_PER_FRAME = FP * 4 + (NFFT // 2 + 1) * 4  # 320 B read + 1028 B written = 1348 B
+STFT_BWD_BYTES_PER_FRAME = (NFFT // 2 + 1) * 4 + FP * 4 + FP * 4  # grad 1028 B + waveform 320 B read, 320 B written
 K, M1, M2 = NFFT // 2 + 1, M + 1, 2 * M + 1
 _SOLVE_MAC = M1 ** 3 // 3 + M1 * M1  # Cholesky-class elimination + substitutions
 MCEP_FLOP_PER_FRAME = 2 * (K * M1 + N_ITER * (M1 * K + K * M2 + _SOLVE_MAC)) + (N_ITER + 1) * K
+# backward of the unrolled iteration, per step: both forward chains again, one elimination with two right-hand
+# sides, rtbar (Toeplitz + Hankel diagonals), ebar = E rtbar, mbar -= 2 D zbar; once: lbar += G mbar_0
+MCEP_BWD_FLOP_PER_FRAME = 2 * (N_ITER * (M1 * K + K * M2 + M1 ** 3 // 3 + 2 * M1 * M1 + 2 * M1 * M1 + K * M2 + K * M1) + K * M1) \
+    + N_ITER * 3 * K
+LPC_FLOP_PER_FRAME = 2 * FL * M1 + 2 * M * M + 4 * M   # direct lag sums + Levinson recursion, float64
+LPC_BYTES_PER_FRAME = FP * 4 + M1 * 4
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-FP32_PEAK_TFLOPS = 157.3    # fp32 MFMA dense peak = fp32 vector peak (same guide)
+FP32_PEAK_TFLOPS = 157.3    # fp32 vector peak with packed instructions = fp32 MFMA dense peak (same guide)
+FP64_PEAK_TFLOPS = 78.6     # fp64 vector peak (same guide)
+VALU_ISSUE_PEAK_GIPS = 1024 * 2.4 / 4   # 1024 SIMDs, one wave64 vector instruction per 4 cycles, 2.4 GHz: 614.4 G wave-instr/s
+PMC_FILE = os.path.join("profiles", "pmc_traffic.json")
 
 
-def pmc_derived(kernel: str):
-    """Unit-busy fractions / occupancy of `kernel` derived from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json "derived"; north_star: LDS / VALU occupancy of the recursion stage)."""
+def pmc_static(kernel: str):
+    """The committed rocprofv3 --pmc record of `kernel` (profiles/pmc_traffic.json: counters of THIS command taken
+    in separate passes, tools/pmc_passes.sh), or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)["kernels"][kernel].get("derived")
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            d = json.load(f)
+        k = d["kernels"][kernel]
+        k["_source"] = d.get("source", PMC_FILE)
+        return k
     except Exception:
         return None
 
 
-def pmc_traffic(kernel: str, frames: int):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE collected separately and corrected as MI355X_MICROARCH.md prescribes), rescaled to
-    this launch's frame count; None when no counter file covers the kernel."""
+def pmc_traffic(kernel: str, frames: float):
+    """HBM bytes per launch of `kernel` from the static PMC record (FETCH_SIZE and WRITE_SIZE collected separately and
+    corrected as MI355X_MICROARCH.md prescribes), rescaled to this launch's frame count; None without a record."""
+    k = pmc_static(kernel)
+    return None if k is None else k["hbm_bytes_per_launch"] * frames / k["frames_per_launch"]
+
+
+def host_description():
+    d = {"logical_cpus": os.cpu_count(), "torch": torch.__version__}
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            k = json.load(f)["kernels"][kernel]
-        return k["hbm_bytes_per_launch"] * frames / k["frames_per_launch"]
+        import psutil
+
+        d["physical_cores"] = psutil.cpu_count(logical=False)
     except Exception:
-        return None
+        d["physical_cores"] = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                d["cpu_model"] = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    cfg = torch.__config__.show()
+    d["blas"] = next((t.strip() for t in cfg.replace("\n", ",").split(",") if "BLAS_INFO" in t), None)
+    d["mkl"] = next((ln.strip(" -") for ln in cfg.split("\n") if "Math Kernel Library" in ln or "oneAPI Math" in ln), None)
+    d["mkldnn"] = next((ln.strip(" -") for ln in cfg.split("\n") if "MKL-DNN" in ln), None)
+    d["openmp"] = next((ln.strip(" -") for ln in cfg.split("\n") if "OpenMP" in ln), None)
+    return d
 
 
-def cpu_baseline(seconds_budget: float = 12.0):
-    """Reference CPU path (stock ATen ops, oracle/torch_port.py) on a bounded sample."""
+def _cpu_time(fn, budget_s, min_runs, max_runs):
+    fn()   # warm-up
+    times, t_all = [], time.perf_counter()
+    while len(times) < min_runs or (time.perf_counter() - t_all < budget_s and len(times) < max_runs):
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+    return statistics.median(times), len(times)
+
+
+def cpu_baseline():
+    """the reference's op sequence with stock ATen CPU operators (oracle/torch_port.py) on the same
+    synthetic input, float32, at several thread counts -- one core, 8 (the survey's container), 32 and all physical
+    cores -- each a median of >= 3 runs of a workload-sized sample; host described.  `value` is the BEST of them (on
+    a many-core host the small ATen calls of this path lose more to threading than they gain: one core beats 128).
+    ~30 s of CPU time in total."""
     from oracle import torch_port as TP
 
-    threads = torch.get_num_threads()
-    B = 32
-    x = torch.randn(B, SAMPLES, generator=torch.Generator().manual_seed(0))
+    host = host_description()
+    n_all = host.get("physical_cores") or torch.get_num_threads()
     tab = TP.McepTables(NFFT, M, ALPHA, torch.float32)
     w = TP.window_table(FL, dtype=torch.float32)
-    times = []
-    with torch.no_grad():
-        TP.stft_mcep(x[:4], tab, FL, FP, N_ITER, w)  # warm-up
-        t_all = time.perf_counter()
-        while len(times) < 3 or (time.perf_counter() - t_all < seconds_budget and len(times) < 50):
-            t0 = time.perf_counter()
-            TP.stft_mcep(x, tab, FL, FP, N_ITER, w)
-            times.append(time.perf_counter() - t0)
-    med = statistics.median(times)
+    gen = torch.Generator().manual_seed(0)
+    res = {}
+    prev = torch.get_num_threads()
+    plan = [(1, 32, 7.0), (8, 128, 7.0), (32, 256, 7.0), (n_all, 256, 9.0)]
+    seen = set()
+    try:
+        with torch.no_grad():
+            for nthreads, B, budget in plan:
+                nthreads = max(1, min(int(nthreads), int(n_all)))
+                if nthreads in seen:
+                    continue
+                seen.add(nthreads)
+                torch.set_num_threads(nthreads)
+                x = torch.randn(B, SAMPLES, generator=gen)
+                med, n = _cpu_time(lambda: TP.stft_mcep(x, tab, FL, FP, N_ITER, w), budget, 3, 12)
+                res[str(nthreads)] = {"value": B * FRAMES_PER_UTT / med, "threads": nthreads, "utterances": B,
+                                      "frames": B * FRAMES_PER_UTT, "median_s": med, "runs": n}
+    finally:
+        torch.set_num_threads(prev)
+    best = max(res.values(), key=lambda r: r["value"])
     return {
-        "value": B * FRAMES_PER_UTT / med, "unit": "frames/s", "cores": threads, "kind": "port",
-        "sample": f"{B} utterances x 1 s (={B * FRAMES_PER_UTT} frames) STFT->mcep fwd, float32, "
-                  f"stock torch CPU ops (oracle/torch_port.py), median of {len(times)} runs",
+        "value": best["value"], "unit": "frames/s", "cores": best["threads"], "kind": "port",
+        "sample": f"{best['utterances']} utterances x 1 s (={best['frames']} frames) STFT->mcep forward, float32, stock torch CPU "
+                  f"ops (oracle/torch_port.py: the reference's ATen call sequence), best of {sorted(int(k) for k in res)} threads "
+                  f"({best['threads']}), median of {best['runs']} runs",
+        "by_threads": res, "one_core": res.get("1"), "all_cores": res.get(str(max(int(k) for k in res))), "host": host,
     }
 
 
@@ -112,6 +176,124 @@ def c_oracle_baseline():
             "sample": f"{B} utterances x 1 s, C oracle (naive mixed-radix FFT + LU), float32, single run"}
 
 
+def gpu_time(fn, n=30, groups=3):
+    """ms per call of fn(): `groups` groups of n back-to-back calls between two HIP events on the current stream,
+    median over the groups (the launches of a group pipeline through the command processor: kernel time, not
+    kernel + dispatch gap)."""
+    fn()
+    torch.cuda.synchronize()
+    out = []
+    for _ in range(groups):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) / n)
+    return statistics.median(out)
+
+
+def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
+    """BASELINE configs 2, 3, 4 in the same process (N = 1), each with the roofline that bounds it."""
+    res = {}
+    # ---- config 2: fused Frame+Window+rFFT kernel, batch 64 (and the batch sweep: where the stage reaches 50 %) ----
+    sweep = {}
+    with torch.no_grad():
+        for B in (64, 256, 1024, 4096):
+            xb = x1024[:B] if B <= x1024.size(0) else torch.randn(B, SAMPLES, device=dev)
+            t = gpu_time(lambda: stft(xb), n=40) * 1e-3
+            fr = B * FRAMES_PER_UTT
+            sweep[str(B)] = {"us_per_launch": t * 1e6, "GB/s": STFT_BYTES_PER_FRAME * fr / t / 1e9,
+                             "frac": STFT_BYTES_PER_FRAME * fr / t / 1e9 / HBM_PEAK_GBS}
+            del xb
+    c2 = sweep["64"]
+    res["config2_stft_batch64"] = {
+        "workload": "BASELINE configs[1]: fused Frame+Window+rFFT kernel, 64 utterances x 1 s (12 800 frames, 17.3 MB)",
+        "frames/s": 64 * FRAMES_PER_UTT / (c2["us_per_launch"] * 1e-6),
+        "roofline": {"kernel": "stft512_fwd", "bound": "hbm", "achieved": c2["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": c2["frac"], "traffic": None, "avg_launch_ms": c2["us_per_launch"] * 1e-3,
+                     "note": "one pass per wave: the launch is latency-bound (launch + table prologue + one memory round trip "
+                             "+ the end-of-kernel write-back), 17 MB cannot amortise it; see batch_sweep for the size "
+                             "at which the stage reaches its large-batch rate"},
+        "batch_sweep": sweep, "timing": "back-to-back launches (gpu_time)",
+    }
+    # ---- config 3: STFT + mcep forward + backward ----
+    for B in (256, 1024):
+        xb = x1024[:B]
+        fr = B * FRAMES_PER_UTT
+
+        def fwdbwd():
+            xg = xb.clone().requires_grad_(True)
+            mcep(stft(xg)).mean().backward()
+            return xg.grad
+
+        t_fb = gpu_time(fwdbwd, n=10) * 1e-3
+        with torch.no_grad():
+            t_f = gpu_time(lambda: mcep(stft(xb)), n=10) * 1e-3
+        xg = xb.clone().requires_grad_(True)
+        X = stft(xg)
+        Xd = X.detach().requires_grad_(True)
+        mc = mcep(Xd)
+        g = torch.ones_like(mc) / mc.numel()
+        t_mb = gpu_time(lambda: torch.autograd.grad(mc, Xd, g, retain_graph=True), n=10) * 1e-3
+        k_bwd = _lib.last_kernel()
+        gX = torch.autograd.grad(mc, Xd, g, retain_graph=True)[0]
+        t_sb = gpu_time(lambda: torch.autograd.grad(X, xg, gX, retain_graph=True), n=10) * 1e-3
+        pm = pmc_static("mcep_mfma_bwd")
+        ipf = pm["derived"]["valu_insts_per_frame"] if pm else None
+        res[f"config3_fwdbwd_batch{B}"] = {
+            "workload": f"BASELINE configs[2]: STFT + mcep forward + backward of mean(), {B} utterances x 1 s ({fr} frames)",
+            "ms_fwd": t_f * 1e3, "ms_fwd_bwd": t_fb * 1e3, "frames/s": fr / t_fb,
+            "ms_mcep_bwd": t_mb * 1e3, "ms_stft_bwd": t_sb * 1e3,
+            "roofline_bwd": {
+                "kernel": "mcep_mfma_bwd", "bound": "valu_issue",
+                "achieved": (ipf * fr / t_mb / 1e9) if ipf else None, "peak": VALU_ISSUE_PEAK_GIPS,
+                "unit": "G wave-instr/s", "frac": (ipf * fr / t_mb / 1e9 / VALU_ISSUE_PEAK_GIPS) if ipf else None,
+                "traffic": pmc_traffic("mcep_mfma_bwd", fr), "avg_launch_ms": t_mb * 1e3,
+                "algorithmic": {"achieved": MCEP_BWD_FLOP_PER_FRAME * fr / t_mb / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": MCEP_BWD_FLOP_PER_FRAME * fr / t_mb / 1e12 / FP32_PEAK_TFLOPS,
+                                "flop_per_frame": MCEP_BWD_FLOP_PER_FRAME},
+                "pmc": pm["derived"] if pm else None, "pmc_source": pm["_source"] if pm else None,
+                "arith": "five matrix chains as 3-term binary16 MFMA splits (fp32 accumulate), two-right-hand-side 25x25 "
+                         "elimination in unpacked fp32 VALU", "last_kernel": k_bwd,
+            },
+            "roofline_stft_bwd": {"kernel": "stft512_bwd", "bound": "hbm", "achieved": STFT_BWD_BYTES_PER_FRAME * fr / t_sb / 1e9,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": STFT_BWD_BYTES_PER_FRAME * fr / t_sb / 1e9 / HBM_PEAK_GBS,
+                                  "traffic": None, "avg_launch_ms": t_sb * 1e3, "bytes_per_frame": STFT_BWD_BYTES_PER_FRAME},
+            "timing": "back-to-back calls through the module API (gpu_time)",
+        }
+        del xg, X, Xd, mc, g, gX
+    # ---- config 4: LPC branch, fused Frame + Window + acorr + Levinson ----
+    w = dsp.Window(FL, device=dev).window
+    B = 1024
+    fr = B * FRAMES_PER_UTT
+    with torch.no_grad():
+        t_l = gpu_time(lambda: ops.frame_window_lpc(x1024, w, FL, FP, M, 1e-5), n=30) * 1e-3
+        k_lpc = _lib.last_kernel()
+        frm, wn, lpc = dsp.Frame(FL, FP), dsp.Window(FL, device=dev), dsp.LPC(FL, M, eps=1e-5, device=dev)
+        t_chain = gpu_time(lambda: lpc(wn(frm(x1024))), n=10) * 1e-3
+
+    def lpc_fb():
+        xg = x1024.clone().requires_grad_(True)
+        lpc(wn(frm(xg))).mean().backward()
+
+    t_lfb = gpu_time(lpc_fb, n=10) * 1e-3
+    res["config4_lpc_batch1024"] = {
+        "workload": f"BASELINE configs[3]: Frame+Window+acorr+levdur (M=24), {B} utterances x 1 s ({fr} frames), one wave per 64 frames",
+        "frames/s": fr / t_l, "ms_fused_fwd": t_l * 1e3, "ms_module_chain_fwd": t_chain * 1e3, "ms_module_chain_fwd_bwd": t_lfb * 1e3,
+        "roofline": {"kernel": k_lpc, "bound": "valu_issue (float64)", "achieved": LPC_FLOP_PER_FRAME * fr / t_l / 1e12,
+                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s (fp64 vector)", "frac": LPC_FLOP_PER_FRAME * fr / t_l / 1e12 / FP64_PEAK_TFLOPS,
+                     "traffic": None, "avg_launch_ms": t_l * 1e3, "flop_per_frame": LPC_FLOP_PER_FRAME,
+                     "hbm": {"achieved": LPC_BYTES_PER_FRAME * fr / t_l / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": LPC_BYTES_PER_FRAME * fr / t_l / 1e9 / HBM_PEAK_GBS},
+                     "note": "420 B/frame: far from the HBM roof; the lag sums and the recursion run in float64 on the vector "
+                             "unit (unpacked: half of the packed fp64 peak quoted) -- DESIGN.md 3.3"},
+        "timing": "back-to-back launches (gpu_time)",
+    }
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,13 +303,16 @@ def main():
                     help="untimed steps run for this long before the warmup steps so that the GPU clocks have settled "
                          "(the first ~20 ms after idle run 10 %% slower; 0 disables)")
     ap.add_argument("--batch", type=int, default=1024, help="utterances per GPU (weak scaling)")
-    ap.add_argument("--chunks", type=int, default=2, help="N > 1: utterance chunks per step (gather/compute overlap)")
+    ap.add_argument("--chunks", type=int, default=1,
+                    help="N > 1: utterance chunks per step.  1 (default): one in-place all-gather per step, deferred "
+                         "behind the next step's kernels; > 1: chunked gather/compute overlap inside the step")
     ap.add_argument("--streams", type=int, default=1,
                     help="N = 1: with 2, consecutive steps alternate between two streams, so the next step's STFT fills the "
                          "tail of the persistent mel-cepstral kernel (steps are independent batches): +2.5 %% frames/s, "
                          "+7 %% without the instrumented steps (tools/ab_pipeline.py); default 1 keeps the per-kernel "
                          "timings of the roofline objects undisturbed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config 2/3/4 sub-benchmarks (N = 1)")
     ap.add_argument("--algo", choices=["auto", "generic", "tuned"], default="auto")
     args = ap.parse_args()
 
@@ -153,15 +338,13 @@ def main():
 
     import diffsptk_amd as dsp
     from diffsptk_amd import _lib, ops
-    from diffsptk_amd.dist import all_gather_features
+    from diffsptk_amd.dist import analyze_chunked_overlap
 
     algo = {"auto": _lib.ALGO_AUTO, "generic": _lib.ALGO_GENERIC, "tuned": _lib.ALGO_TUNED}[args.algo]
     B = args.batch
     x = torch.randn(B, SAMPLES, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
     stft = dsp.STFT(FL, FP, NFFT, device=dev)
     mcep = dsp.MelCepstralAnalysis(fft_length=NFFT, cep_order=M, alpha=ALPHA, n_iter=N_ITER, device=dev)
-
-    from diffsptk_amd.dist import analyze_chunked_overlap
 
     n_chunks = 1 if world == 1 else args.chunks
     kernels = {}
@@ -185,7 +368,7 @@ def main():
             kernels["mcep"] = _lib.last_kernel()
         return mc
 
-    in_flight = []   # N > 1: (features, handle) of the previous step, whose last all-gather overlaps this step
+    in_flight = []   # N > 1: (features, handle) of the previous step, whose all-gather overlaps this step
 
     # N = 1: steps are independent batches; alternating them between streams lets step k+1's STFT run on the CUs the
     # persistent mel-cepstral kernel of step k has already left (its last round of tiles fills a quarter of the
@@ -198,9 +381,9 @@ def main():
     step_no = [0]
 
     def step(record=False):
-        # N > 1: features of chunk c are all-gathered (RCCL) while chunk c+1 is computed; the LAST chunk's
-        # collective is left in flight and completed one step later (a streaming consumer reads batch k while
-        # batch k+1 is computed), so it hides behind the next step's kernels instead of ending every step
+        # N > 1: the features are all-gathered (RCCL, one in-place all_gather_into_tensor) and the collective is left in
+        # flight and completed one step later (a streaming consumer reads batch k while batch k+1 is computed), so it
+        # hides behind the next step's kernels instead of ending every step
         if world == 1 and side_streams:
             step_no[0] += 1
             if record:
@@ -262,6 +445,17 @@ def main():
     t_mcep = statistics.mean(e[1].elapsed_time(e[2]) for e, _ in ev_log) * 1e-3
     frames_launch = statistics.mean(nb for _, nb in ev_log) * FRAMES_PER_UTT
     if rank == 0:
+        # the same two kernels back to back (no dispatch gap between an event and the launch): what a rocprofv3 kernel
+        # trace reports as the kernels' own durations
+        xl = x[: int(frames_launch // FRAMES_PER_UTT)]
+        with torch.no_grad():
+            Xl = stft(xl)
+            t_stft_b2b = gpu_time(lambda: ops.StftFn.apply(xl, stft.window, stft.twiddle, FL, FP, NFFT, True, False, "constant",
+                                                           1e-9, None, 3, algo), n=40) * 1e-3
+            t_mcep_b2b = gpu_time(lambda: ops.McepFn.apply(Xl, mcep.G, mcep.D, mcep.E, mcep.alpha_vector, NFFT, M, N_ITER, algo),
+                                  n=10) * 1e-3
+        pm_m, pm_s = pmc_static(kernels["mcep"]), pmc_static(kernels["stft"])
+        ipf = pm_m["derived"]["valu_insts_per_frame"] if pm_m else None
         res = {
             "metric": "frames/sec STFT->mcep (fl=400 fp=80 nfft=512 M=24)",
             "value": frames_rank * world * args.steps / elapsed,
@@ -276,21 +470,29 @@ def main():
                             "8192-utterance batch; features all-gathered over RCCL when N>1",
                 "utterances_per_gpu": B, "global_batch": B * world, "frames_per_step": frames_rank * world,
                 "parallelism": f"dp{world}", "kernels": kernels, "chunks_per_step": n_chunks, "streams": n_streams,
+                "arith": "float32 in / out / accumulate; the matrix chains of the mel-cepstral kernel run as 3-term "
+                         "binary16 MFMA splits (hi/lo, dropped lo*lo: ~22-bit products), the STFT in packed float32",
             },
             "roofline": {
-                "kernel": kernels["mcep"], "bound": "mfma",
-                "achieved": MCEP_FLOP_PER_FRAME * frames_launch / t_mcep / 1e12,
-                "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": MCEP_FLOP_PER_FRAME * frames_launch / t_mcep / 1e12 / FP32_PEAK_TFLOPS,
+                "kernel": kernels["mcep"], "bound": "valu_issue",
+                "achieved": (ipf * frames_launch / t_mcep / 1e9) if ipf else None,
+                "peak": VALU_ISSUE_PEAK_GIPS, "unit": "G wave-instr/s",
+                "frac": (ipf * frames_launch / t_mcep / 1e9 / VALU_ISSUE_PEAK_GIPS) if ipf else None,
                 "traffic": pmc_traffic(kernels["mcep"], frames_launch), "avg_launch_ms": t_mcep * 1e3,
-                "pmc": pmc_derived(kernels["mcep"]),
+                "back_to_back_ms": t_mcep_b2b * 1e3,
+                "valu_insts_per_frame": ipf,
+                "algorithmic": {"achieved": MCEP_FLOP_PER_FRAME * frames_launch / t_mcep / 1e12, "peak": FP32_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": MCEP_FLOP_PER_FRAME * frames_launch / t_mcep / 1e12 / FP32_PEAK_TFLOPS,
+                                "flop_per_frame": MCEP_FLOP_PER_FRAME,
+                                "note": "flops of the composed-matrix algorithm (DESIGN.md 3.2), each counted once, against the "
+                                        "packed-fp32 vector peak; NOT a unit utilisation: 77 % of them execute on the binary16 "
+                                        "matrix pipe, the 25x25 solve on unpacked fp32 VALU (peak 78.6)"},
+                "pmc": pm_m["derived"] if pm_m else None, "pmc_source": (pm_m["_source"] + " (static)") if pm_m else None,
                 "frames_per_launch": frames_launch,
-                "flop_per_frame": MCEP_FLOP_PER_FRAME,
-                "note": "fp32 MFMA dense peak == fp32 vector peak (157.3 TFLOP/s); flops are the composed-matrix "
-                        "algorithm's (DESIGN.md), lower than the reference formulation's 0.71-0.75 MFLOP/frame, "
-                        "each counted once.  The two matrix chains of a Newton step execute as three binary16 "
-                        "MFMA products per fp32 operand pair (hi/lo split, fp32 accumulate, fp32-grade parity: "
-                        "tests/test_gpu_parity.py); the 25x25 solve is unpacked fp32 VALU, which now bounds the kernel",
+                "arith": "f16x3 split chains (fp32 accumulate) + fp32 VALU solve",
+                "note": "achieved = vector wave-instructions per frame (static: rocprofv3 SQ_INSTS_VALU of this kernel, "
+                        "profiles/) x frames / measured launch time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles.  The kernel is "
+                        "bound by vector issue inside the 25x25 elimination (DESIGN.md 3.2 / 6)",
             },
             "roofline_stft": {
                 "kernel": kernels["stft"], "bound": "hbm",
@@ -298,11 +500,20 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": STFT_BYTES_PER_FRAME * frames_launch / t_stft / 1e9 / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(kernels["stft"], frames_launch), "avg_launch_ms": t_stft * 1e3,
-                "pmc": pmc_derived(kernels["stft"]),
+                "back_to_back_ms": t_stft_b2b * 1e3,
+                "frac_back_to_back": STFT_BYTES_PER_FRAME * frames_launch / t_stft_b2b / 1e9 / HBM_PEAK_GBS,
+                "pmc": pm_s["derived"] if pm_s else None, "pmc_source": (pm_s["_source"] + " (static)") if pm_s else None,
                 "bytes_per_frame": STFT_BYTES_PER_FRAME,
-                "traffic_note": "bytes per launch from profiles/pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                "note": "avg_launch_ms: HIP events around single launches inside the timed region (what `frac` uses); "
+                        "back_to_back_ms: the same launch repeated between two events after the timed region (module API, "
+                        "no mel-cepstral kernel in between)",
             },
         }
+        if world == 1 and not args.no_configs:
+            try:
+                res["configs"] = other_configs(dsp, ops, _lib, dev, stft, mcep, x)
+            except Exception as e:   # the headline line must survive a failing sub-benchmark
+                res["configs"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]

@@ -1,0 +1,18 @@
+# default bench (as the driver runs it) + kernel trace + PMC passes; outputs under gpurun_out/$1
+OUT=gpurun_out/$1
+mkdir -p $OUT
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+R=$PWD
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $R/$OUT/trace -o trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/$OUT/trace.log 2>&1
+cd $R
+DB=$(find $OUT/trace -name "*.db" | head -1)
+[ -n "$DB" ] && python tools/rocprof_db_summary.py $DB > $OUT/kernel_trace.txt
+bash tools/pmc_passes.sh $1/pmc_fwd fwd
+bash tools/pmc_passes.sh $1/pmc_bwd bwd
+python tools/pmc_summary.py $OUT/pmc_fwd > $OUT/pmc_fwd.txt 2>&1
+python tools/pmc_summary.py $OUT/pmc_bwd > $OUT/pmc_bwd.txt 2>&1
+python tools/pmc_to_json.py $OUT/pmc_fwd,$OUT/pmc_bwd "profiles/r02_pmc_$1 (rocprofv3 --pmc passes of tools/pmc_passes.sh: bench.py --no-configs and tools/run_mcep_bwd_only.py, 204800 frames per launch)" > $OUT/pmc_traffic.json
+rm -rf $OUT/trace/*/*.db.tmp
+head -c 1500 $OUT/bench_driver.json; echo; tail -3 $OUT/bench.err; head -30 $OUT/kernel_trace.txt; cat $OUT/pmc_traffic.json | head -80

@@ -8,12 +8,14 @@ import os
 import sys
 from collections import defaultdict
 
-KERNELS = {"mcep_mfma_fwd": "mcep_mfma_fwd_kernel_h", "stft512_fwd": "stft512_fwd_kernel"}
-WAVES_PER_SIMD = {"mcep_mfma_fwd": 2, "stft512_fwd": 4}
+KERNELS = {"mcep_mfma_fwd": "mcep_mfma_fwd_kernel_h", "stft512_fwd": "stft512_fwd_pk_kernel",
+           "mcep_mfma_bwd": "mcep_mfma_bwd_kernel_h", "stft512_bwd": "stft512_bwd_kernel"}
+WAVES_PER_SIMD = {"mcep_mfma_fwd": 2, "stft512_fwd": 4, "mcep_mfma_bwd": 1, "stft512_bwd": 4}
 FRAMES = 204800
 
 acc = defaultdict(lambda: [0.0, 0])
-for f in sorted(glob.glob(sys.argv[1] + "/p*/p*_counter_collection.csv")):
+dirs = sys.argv[1].split(",")   # several pass directories (forward command, backward command) may be merged
+for f in sorted(g for d in dirs for g in glob.glob(d + "/p*/p*_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         for key, pat in KERNELS.items():
             if pat in row["Kernel_Name"]:
