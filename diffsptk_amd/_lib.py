@@ -16,7 +16,7 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdiffsptk_amd.so")
-SOURCES = ("stft.hip", "mcep.hip", "mcep_mfma.hip", "lpc.hip", "fbank.hip", "fftcep.hip")
+SOURCES = ("stft.hip", "mcep.hip", "mcep_mfma.hip", "lpc.hip", "fbank.hip", "fftcep.hip", "mgc.hip")
 HIPCC_FLAGS = (
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
     "-mcode-object-version=5", "-Wno-unused-value", "-ffp-contract=on",
@@ -124,6 +124,8 @@ SIGNATURES = {
     "dsa_mcep_prepare": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "dsa_mcep_fwd": (C.c_int, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "dsa_mcep_bwd": (C.c_int, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "dsa_thsolve_fwd": (C.c_int, [_P, _P, _P, _L, _I, _I, _P, _P]),
+    "dsa_thsolve_bwd": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P]),
     "dsa_acorr_fwd": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P]),
     "dsa_acorr_bwd": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "dsa_levdur_fwd": (C.c_int, [_P, _L, _I, _D, _I, _P, _P]),

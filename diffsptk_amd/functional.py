@@ -124,3 +124,48 @@ def window(x: Tensor, out_length: int | None = None, *, window: str | int = "bla
            norm: str | int = "power", symmetric: bool = True) -> Tensor:
     """Windowing x:(..., L1) -> (..., L2)."""
     return nn.Window._func(x, out_length, window=window, norm=norm, symmetric=symmetric)
+
+
+# ----------------------------------------------------------------------------- SURVEY 8(f) rows 3-4
+def mc2b(mc: Tensor, alpha: float = 0) -> Tensor:
+    """Mel-cepstrum -> MLSA digital filter coefficients (functional.py:1936)."""
+    return nn.MelCepstrumToMLSADigitalFilterCoefficients._func(mc, alpha=alpha)
+
+
+def b2mc(b: Tensor, alpha: float = 0) -> Tensor:
+    """MLSA digital filter coefficients -> mel-cepstrum (functional.py:86)."""
+    return nn.MLSADigitalFilterCoefficientsToMelCepstrum._func(b, alpha=alpha)
+
+
+def gnorm(x: Tensor, gamma: float = 0, c: int | None = None) -> Tensor:
+    """Gain normalisation of a generalized cepstrum (functional.py:961)."""
+    return nn.GeneralizedCepstrumGainNormalization._func(x, gamma=gamma, c=c)
+
+
+def ignorm(y: Tensor, gamma: float = 0, c: int | None = None) -> Tensor:
+    """Inverse gain normalisation (functional.py:1387)."""
+    return nn.GeneralizedCepstrumInverseGainNormalization._func(y, gamma=gamma, c=c)
+
+
+def mgc2mgc(mc: Tensor, out_order: int, in_alpha: float = 0, out_alpha: float = 0, in_gamma: float = 0,
+            out_gamma: float = 0, in_norm: bool = False, out_norm: bool = False, in_mul: bool = False,
+            out_mul: bool = False, n_fft: int = 512) -> Tensor:
+    """Mel-generalized cepstrum conversion (functional.py:2186)."""
+    return nn.MelGeneralizedCepstrumToMelGeneralizedCepstrum._func(
+        mc, out_order=out_order, in_alpha=in_alpha, out_alpha=out_alpha, in_gamma=in_gamma, out_gamma=out_gamma,
+        in_norm=in_norm, out_norm=out_norm, in_mul=in_mul, out_mul=out_mul, n_fft=n_fft)
+
+
+def mgc2sp(mc: Tensor, fft_length: int, alpha: float = 0, gamma: float = 0, norm: bool = False, mul: bool = False,
+           n_fft: int = 512, out_format: str | int = "power") -> Tensor:
+    """Mel-generalized cepstrum -> spectrum (functional.py:2257)."""
+    return nn.MelGeneralizedCepstrumToSpectrum._func(mc, fft_length=fft_length, alpha=alpha, gamma=gamma, norm=norm,
+                                                     mul=mul, n_fft=n_fft, out_format=out_format)
+
+
+def mgcep(x: Tensor, cep_order: int, alpha: float = 0, gamma: float = 0, c: int | None = None, n_iter: int = 0) -> Tensor:
+    """Mel-generalized cepstral analysis of power spectra (functional.py: mgcep).  A module underneath (the reference's
+    is a BaseNonFunctionalModule too): the composed matrices are cached per configuration by tables.mgcep_matrices."""
+    m = nn.MelGeneralizedCepstralAnalysis(fft_length=2 * x.size(-1) - 2, cep_order=cep_order, alpha=alpha, gamma=gamma,
+                                          c=c, n_iter=n_iter, device=x.device, dtype=x.dtype)
+    return m(x)

@@ -15,7 +15,12 @@ from .freqt import FrequencyTransform
 from .levdur import LevinsonDurbin
 from .lpc import LinearPredictiveCodingAnalysis
 from .lpc import LinearPredictiveCodingAnalysis as LPC
+from .gnorm import GeneralizedCepstrumGainNormalization, GeneralizedCepstrumInverseGainNormalization
+from .mc2b import MelCepstrumToMLSADigitalFilterCoefficients, MLSADigitalFilterCoefficientsToMelCepstrum
 from .mcep import MelCepstralAnalysis
+from .mgc2mgc import MelGeneralizedCepstrumToMelGeneralizedCepstrum
+from .mgc2sp import MelGeneralizedCepstrumToSpectrum
+from .mgcep import MelGeneralizedCepstralAnalysis
 from .mfcc import MelFrequencyCepstralCoefficientsAnalysis
 from .mfcc import MelFrequencyCepstralCoefficientsAnalysis as MFCC
 from .spec import Spectrum
@@ -28,5 +33,8 @@ __all__ = [
     "Autocorrelation", "BaseFunctionalModule", "CepstralAnalysis", "DCT", "DiscreteCosineTransform", "FBANK", "Frame", "GriffinLim",
     "FrequencyTransform", "ISTFT", "InverseShortTimeFourierTransform", "RealValuedInverseFastFourierTransform", "Unframe", "LPC", "LevinsonDurbin", "LinearPredictiveCodingAnalysis", "MFCC", "MelCepstralAnalysis",
     "MelFilterBankAnalysis", "MelFrequencyCepstralCoefficientsAnalysis", "Precomputed",
+    "GeneralizedCepstrumGainNormalization", "GeneralizedCepstrumInverseGainNormalization",
+    "MelCepstrumToMLSADigitalFilterCoefficients", "MLSADigitalFilterCoefficientsToMelCepstrum",
+    "MelGeneralizedCepstrumToMelGeneralizedCepstrum", "MelGeneralizedCepstrumToSpectrum", "MelGeneralizedCepstralAnalysis",
     "RealValuedFastFourierTransform", "STFT", "ShortTimeFourierTransform", "Spectrum", "Window",
 ]

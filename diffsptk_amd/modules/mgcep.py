@@ -1,0 +1,103 @@
+"""Mel-generalized cepstral analysis (reference: mgcep.py) -- SURVEY.md section 8(f), row 3.
+
+gamma = 0 is mel-cepstral analysis (the tuned kernel of modules/mcep.py, as in the reference: mgcep.py:97-105).
+For gamma in [-1, 0) every linear stage of a Newton step (mgcep.py:185-249: cfreqt + rfft; irfft + pfreqt / rfreqt
++ the P / Q transforms) is composed on the host into float64 matrices (utils/tables.py:mgcep_matrices), so a step is
+seven row products on the library's freqt kernel around the pointwise spectrum arithmetic, followed by the
+Toeplitz-plus-Hankel solve kernel (csrc/mgc.hip).  Gradients: the kernels' own backward entries chained by autograd.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..utils import tables
+from ..utils.private import check_size, to
+from .gnorm import GeneralizedCepstrumGainNormalization as _Gnorm
+from .gnorm import GeneralizedCepstrumInverseGainNormalization as _Ignorm
+from .gnorm import get_gamma
+from .mc2b import MelCepstrumToMLSADigitalFilterCoefficients, MLSADigitalFilterCoefficientsToMelCepstrum
+from .mcep import MelCepstralAnalysis
+from .mgc2mgc import MelGeneralizedCepstrumToMelGeneralizedCepstrum
+
+_NAMES = ("Cr", "Ci", "Pr", "Qr", "Qi", "Rr", "Ri", "R1", "Q1")
+
+
+class MelGeneralizedCepstralAnalysis(nn.Module):
+    """x:(..., L/2+1) power spectrum -> mel-generalized cepstrum (..., M+1) (mgcep.py:181-249)."""
+
+    def __init__(self, *, fft_length: int, cep_order: int, alpha: float = 0, gamma: float = 0, c: int | None = None,
+                 n_iter: int = 0, device=None, dtype=None) -> None:
+        super().__init__()
+        gamma = get_gamma(gamma, c)
+        if fft_length <= 1:
+            raise ValueError("fft_length must be greater than 1.")
+        if cep_order < 0:
+            raise ValueError("cep_order must be non-negative.")
+        if fft_length < 2 * cep_order:
+            raise ValueError("cep_order must be less than or equal to fft_length // 2.")
+        if 1 <= abs(alpha):
+            raise ValueError("alpha must be in (-1, 1).")
+        if gamma < -1 or 0 < gamma:
+            raise ValueError("gamma must be in [-1, 0].")
+        if n_iter < 0:
+            raise ValueError("n_iter must be non-negative.")
+        self.fft_length, self.cep_order, self.gamma, self.n_iter = fft_length, cep_order, gamma, n_iter
+        if gamma == 0:
+            self.mcep = MelCepstralAnalysis(fft_length=fft_length, cep_order=cep_order, alpha=alpha, n_iter=n_iter,
+                                            device=device, dtype=dtype)
+            return
+        if cep_order < 1:
+            raise ValueError("cep_order must be positive when gamma is not 0.")
+        for name, mat in tables.mgcep_matrices(fft_length, cep_order, float(alpha)).items():
+            self.register_buffer(name, to(mat, device=device, dtype=dtype), persistent=False)
+        M = cep_order
+        self.b2mc = MLSADigitalFilterCoefficientsToMelCepstrum(M, alpha, device=device, dtype=dtype)
+        self.mc2b = MelCepstrumToMLSADigitalFilterCoefficients(M, alpha, device=device, dtype=dtype)
+        self.gc2gc = MelGeneralizedCepstrumToMelGeneralizedCepstrum(M, M, in_gamma=-1, out_gamma=gamma, device=device,
+                                                                    dtype=dtype)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.gamma == 0:
+            return self.mcep(x)
+        M, H = self.cep_order, self.fft_length // 2
+        check_size(x.size(-1), H + 1, "dimension of spectrum")
+        mm = ops.MatmulRowsFn.apply
+
+        def epsilon(gamma, r, b1):
+            return r[..., 0] + gamma * (r[..., 1:] * b1).sum(-1)
+
+        def newton(gamma, b1):
+            if gamma == -1:                                        # mgcep.py:196-197, 213-215
+                p = mm(x, self.Pr)
+                q = mm(x, self.Q1)
+                r = mm(x, self.R1)
+            else:
+                b = torch.cat((torch.zeros_like(b1[..., :1]), b1), dim=-1)
+                X = 1 + gamma * mm(b, self.Cr)                     # mgcep.py:199-209
+                Y = gamma * mm(b, self.Ci)
+                XX, YY = X * X, Y * Y
+                D = XX + YY
+                pp = x * torch.pow(D, -1 / gamma) / D
+                qq = pp / D
+                p = mm(pp, self.Pr)
+                q = mm(qq * (XX - YY), self.Qr) + mm(qq * (2 * X * Y), self.Qi)
+                r = mm(pp * X, self.Rr) + mm(pp * Y, self.Ri)
+                eps = epsilon(gamma, r, b1)
+            pt = p[..., :M]
+            qt = q[..., 2:] * (1 + gamma)
+            b1 = b1 + ops.ThSolveFn.apply(pt, qt, r[..., 1:])      # mgcep.py:226-230
+            if gamma == -1:
+                eps = epsilon(gamma, r, b1)
+            return torch.sqrt(eps).unsqueeze(-1), b1
+
+        b1 = torch.zeros(*x.shape[:-1], M, device=x.device, dtype=x.dtype)
+        b0, b1 = newton(-1, b1)
+        if self.gamma != -1:
+            b = torch.cat((b0, b1), dim=-1)
+            b = _Gnorm._forward(self.mc2b(self.gc2gc(self.b2mc(_Ignorm._forward(b, gamma=-1)))), gamma=self.gamma)   # b2b, :120-137
+            b1 = b[..., 1:]
+            for _ in range(self.n_iter):
+                b0, b1 = newton(self.gamma, b1)
+        return self.b2mc(_Ignorm._forward(torch.cat((b0, b1), dim=-1), gamma=self.gamma))                             # b2mc, :139-144

@@ -672,6 +672,38 @@ class McepFn(torch.autograd.Function):
         return (gX,) + (None,) * 8
 
 
+# ----------------------------------------------------------------------------------- mgcep (8(f) row 3)
+class ThSolveFn(torch.autograd.Function):
+    """g = solve(symmetric_toeplitz(p) + hankel(q), r) per row (mgcep.py:226-229): p:(..., n), q:(..., 2n-1), r:(..., n)."""
+
+    @staticmethod
+    def forward(ctx, p, q, r):
+        _require_device(p, q, r)
+        _same_dtype(p, q, r)
+        pc, qc, rc = p.contiguous(), q.contiguous(), r.contiguous()
+        n = pc.size(-1)
+        if qc.size(-1) != 2 * n - 1 or rc.size(-1) != n:
+            raise ValueError("thsolve: expected p:(..., n), q:(..., 2n-1), r:(..., n)")
+        F = pc.numel() // n
+        g = torch.empty_like(rc)
+        with torch.cuda.device(p.device):
+            _call("dsa_thsolve_fwd", _p(pc), _p(qc), _p(rc), F, n, _dtype_code(pc), _p(g), _stream())
+        ctx.save_for_backward(pc, qc, g)
+        return g
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gg):
+        pc, qc, g = ctx.saved_tensors
+        n = pc.size(-1)
+        F = pc.numel() // n
+        ggc = gg.contiguous()
+        gp, gq, gr = torch.empty_like(pc), torch.empty_like(qc), torch.empty_like(ggc)
+        with torch.cuda.device(gg.device):
+            _call("dsa_thsolve_bwd", _p(ggc), _p(pc), _p(qc), _p(g), F, n, _dtype_code(pc), _p(gp), _p(gq), _p(gr), _stream())
+        return gp, gq, gr
+
+
 # ----------------------------------------------------------------------------------- LPC branch
 class AcorrFn(torch.autograd.Function):
     @staticmethod

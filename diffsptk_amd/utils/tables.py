@@ -289,3 +289,75 @@ def even_cosine_matrix(fft_length: int) -> np.ndarray:
     c = np.where((k == 0) | (k == H - 1), 1.0, 2.0)
     idx = np.outer(np.arange(H), np.arange(H)) % fft_length          # exact argument reduction
     return c[:, None] * np.cos(2.0 * math.pi * idx / fft_length)
+
+
+# ------------------------------------------------------------------ cepstrum conversions / mgcep
+def mc2b_matrix(cep_order: int, alpha: float) -> np.ndarray:
+    """mc2b.py:111-118: b = mc @ A, A[k][m] = (-alpha)^(k-m) for k >= m (b[m] = mc[m] - alpha b[m+1])."""
+    n = cep_order + 1
+    k = np.arange(n)
+    d = k[:, None] - k[None, :]
+    return np.where(d >= 0, (-alpha) ** np.maximum(d, 0).astype(np.float64), 0.0)
+
+
+def b2mc_matrix(cep_order: int, alpha: float) -> np.ndarray:
+    """b2mc.py: mc = b @ A, mc[m] = b[m] + alpha b[m+1]."""
+    n = cep_order + 1
+    A = np.eye(n)
+    A[np.arange(1, n), np.arange(n - 1)] = alpha
+    return A
+
+
+def mgcep_freqt_matrix(in_order: int, out_order: int, alpha: float) -> np.ndarray:
+    """CoefficientsFrequencyTransform of mgcep.py:255-282 (first row e_0, second row alpha^(j-1) (1 - alpha^2)),
+    (in_order + 1, out_order + 1) -- NOT the matrix of the same name in mcep.py (coef_freqt_matrix above)."""
+    L1, L2 = in_order + 1, out_order + 1
+    A = np.zeros((L2, L1), dtype=np.float64)
+    A[0, 0] = 1.0
+    if L2 > 1 and L1 > 1:
+        A[1, 1:] = alpha ** np.arange(L1 - 1, dtype=np.float64) * (1.0 - alpha * alpha)
+    for i in range(2, L2):
+        prev, cur = A[i - 1], A[i]
+        acc = 0.0
+        for j in range(1, L1):
+            acc = prev[j - 1] + alpha * (acc - prev[j])
+            cur[j] = acc
+    return np.ascontiguousarray(A.T)
+
+
+@functools.lru_cache(maxsize=8)
+def mgcep_matrices(fft_length: int, cep_order: int, alpha: float):
+    """The linear stages of MelGeneralizedCepstralAnalysis.forward (mgcep.py:181-249) composed in float64, so that a
+    Newton step is a handful of row products around the pointwise spectrum arithmetic (H = L/2, K = H + 1 bins):
+      Cr, Ci (M+1, K)   b -> cfreqt -> rfft(., L): real / imaginary part                       (:191-193)
+      Pr     (K, 2M+1)  real half spectrum -> irfft -> pfreqt -> ptrans                         (:212,219)
+      Qr, Qi (K, 2M+1)  complex half spectrum (re, im) -> irfft -> pfreqt -> qtrans             (:217,220)
+      Rr, Ri (K, M+1)   complex half spectrum -> irfft -> rfreqt                                (:218)
+      R1     (K, M+1)   gamma = -1: r = pfreqt(irfft(x))[:M+1]                                  (:213-215)
+      Q1     (K, 2M+1)  gamma = -1: q = qtrans(pfreqt(irfft(x)))"""
+    L, H, M = fft_length, fft_length // 2, cep_order
+    K = H + 1
+    n = np.arange(L, dtype=np.float64)
+    k = np.arange(K, dtype=np.float64)
+    ph = 2.0 * math.pi * np.outer(n, k) / L                      # (L, K)
+    cf = mgcep_freqt_matrix(M, L - 1, -alpha)                    # (M+1, L)
+    Cr, Ci = cf @ np.cos(ph), -(cf @ np.sin(ph))
+    c = np.full((K, 1), 2.0)
+    c[0] = c[-1] = 1.0
+    IR, II = c * np.cos(ph.T) / L, -c * np.sin(ph.T) / L         # (K, L): irfft of (re, im)
+    pf = mgcep_freqt_matrix(L - 1, 2 * M, alpha)                 # (L, 2M+1)
+    rf = mgcep_freqt_matrix(L - 1, M, alpha)                     # (L, M+1)
+    nn = 2 * M + 1
+    P = np.eye(nn)
+    P[np.arange(nn - 1), np.arange(1, nn)] = alpha               # A[:, 1:].fill_diagonal_(alpha), :299
+    P[0, 0] -= alpha * alpha
+    P[0, 1] += alpha
+    P[-1, -1] += alpha
+    Q = np.eye(nn)
+    Q[np.arange(1, nn), np.arange(nn - 1)] = alpha               # A[1:].fill_diagonal_(alpha), :322
+    Q[1, 0] = 0
+    Q[1, 1] += alpha
+    Pt, Qt = P.T, Q.T                                            # the modules right-multiply by A.T
+    base_r, base_i = IR @ pf, II @ pf
+    return {"Cr": Cr, "Ci": Ci, "Pr": base_r @ Pt, "Qr": base_r @ Qt, "Qi": base_i @ Qt, "Rr": IR @ rf, "Ri": II @ rf,
+            "R1": base_r[:, : M + 1].copy(), "Q1": base_r @ Qt}

@@ -219,6 +219,17 @@ int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist, int64_t F,
                  const void* alpha_vec, int32_t dtype, int32_t algo, const void* images, void* scratch,
                  void* gX, void* stream);
 
+/* ------------------------------------------------------------------ f3  mel-generalized cepstral analysis
+ * The Toeplitz-plus-Hankel solve of MelGeneralizedCepstralAnalysis.forward, mgcep.py:226-229 (symmetric_toeplitz /
+ * hankel of utils/private.py:291-302, torch.linalg.solve): g:(F,n) = solve(T(p) + H(q), r), p:(F,n) the first
+ * column of the Toeplitz part, q:(F,2n-1) the anti-diagonals of the Hankel part, r:(F,n); n <= 64, row-pivoted.
+ * Backward: cotangent gg:(F,n) -> gp, gq, gr.  The other stages of the analysis are row products against matrices
+ * the host composes (dsa_freqt_fwd) around pointwise spectrum arithmetic (modules/mgcep.py). */
+int dsa_thsolve_fwd(const void* p, const void* q, const void* r, int64_t F, int32_t n, int32_t dtype, void* g,
+                    void* stream);
+int dsa_thsolve_bwd(const void* gg, const void* p, const void* q, const void* g, int64_t F, int32_t n, int32_t dtype,
+                    void* gp, void* gq, void* gr, void* stream);
+
 /* ------------------------------------------------------------------ a11  autocorrelation
  * Autocorrelation._forward, acorr.py:110-120.  x:(F,L) -> r:(F,M+1).  Computed as direct lag
  * sums (the reference's irfft(|rfft(x, L+M)|^2) is the same quantity: no circular wrap). */

@@ -404,3 +404,221 @@ def fftcep(X, cep_order, accel=0.0, n_iter=0):
     idx = [0, N - 1] if H == N else [0]                           # fftcep.py:134-135
     v[..., idx] *= 0.5
     return v
+
+
+# ----------------------------------------------------------------------------- SURVEY 8(f) rows 3-4
+# Cepstrum conversions and mel-generalized cepstral analysis, float64 numpy (test infrastructure, pinned to
+# tests/golden/synth.npz in tests/test_oracle_golden.py).
+def mc2b(mc, alpha):
+    """MelCepstrumToMLSADigitalFilterCoefficients (mc2b.py:95-99): b[M] = mc[M], b[m] = mc[m] - alpha b[m+1]."""
+    mc = np.asarray(mc, dtype=np.float64)
+    b = mc.copy()
+    for m in range(mc.shape[-1] - 2, -1, -1):
+        b[..., m] = mc[..., m] - alpha * b[..., m + 1]
+    return b
+
+
+def b2mc(b, alpha):
+    """MLSADigitalFilterCoefficientsToMelCepstrum (b2mc.py): mc[m] = b[m] + alpha b[m+1]."""
+    b = np.asarray(b, dtype=np.float64)
+    mc = b.copy()
+    mc[..., :-1] += alpha * b[..., 1:]
+    return mc
+
+
+def gnorm(x, gamma):
+    """GeneralizedCepstrumGainNormalization (gnorm.py:102-112)."""
+    x = np.asarray(x, dtype=np.float64)
+    x0, x1 = x[..., :1], x[..., 1:]
+    if gamma == 0:
+        return np.concatenate((np.exp(x0), x1), -1)
+    z = 1 + gamma * x0
+    return np.concatenate((z ** (1 / gamma), x1 / z), -1)
+
+
+def ignorm(y, gamma):
+    """GeneralizedCepstrumInverseGainNormalization (ignorm.py:99-109)."""
+    y = np.asarray(y, dtype=np.float64)
+    K, y1 = y[..., :1], y[..., 1:]
+    if gamma == 0:
+        return np.concatenate((np.log(K), y1), -1)
+    z = K ** gamma
+    return np.concatenate(((z - 1) / gamma, y1 * z), -1)
+
+
+def gc2gc(c1, out_order, in_gamma, out_gamma, n_fft=512):
+    """GeneralizedCepstrumToGeneralizedCepstrum._forward (mgc2mgc.py:333-361), the FFT formulation."""
+    c1 = np.asarray(c1, dtype=np.float64)
+    c01 = c1.copy()
+    c01[..., 0] = 0
+    C1 = np.fft.fft(c01, n=n_fft)
+    if in_gamma == 0:
+        sC1 = np.exp(C1)
+    else:
+        z = 1 + in_gamma * C1
+        sC1 = np.abs(z) ** (1 / in_gamma) * np.exp(1j * np.angle(z) / in_gamma)
+    if out_gamma == 0:
+        C2 = np.log(np.abs(sC1))                                 # clog of utils/private.py:318-319: the real log-magnitude
+    else:
+        C2 = (np.abs(sC1) ** out_gamma * np.cos(np.angle(sC1) * out_gamma) - 1) / out_gamma
+    c02 = np.fft.ifft(C2).real[..., : out_order + 1]
+    return np.concatenate((c1[..., :1], 2 * c02[..., 1:]), -1)
+
+
+def _gamma_scale(c, s):
+    out = np.asarray(c, dtype=np.float64).copy()
+    out[..., 1:] *= s
+    return out
+
+
+def mgc2mgc(mc, out_order, in_alpha=0.0, out_alpha=0.0, in_gamma=0.0, out_gamma=0.0, in_norm=False, out_norm=False,
+            in_mul=False, out_mul=False, n_fft=512):
+    """MelGeneralizedCepstrumToMelGeneralizedCepstrum (mgc2mgc.py:176-300): the same sequence of elementary steps."""
+    c = np.asarray(mc, dtype=np.float64)
+    in_order = c.shape[-1] - 1
+    if not in_norm and in_mul:                                   # ZerothGammaDivision
+        c = c.copy()
+        c[..., 0] = (c[..., 0] - 1) / in_gamma
+    alpha = (out_alpha - in_alpha) / (1 - in_alpha * out_alpha)
+    if alpha == 0:
+        if in_order == out_order and in_gamma == out_gamma:
+            if not in_mul and out_mul:
+                c = _gamma_scale(c, in_gamma)
+            if not in_norm and out_norm:
+                c = gnorm(c, in_gamma)
+            if in_norm and not out_norm:
+                c = ignorm(c, out_gamma)
+            if in_mul and not out_mul:
+                c = _gamma_scale(c, 1 / out_gamma)
+        else:
+            if in_mul:
+                c = _gamma_scale(c, 1 / in_gamma)
+            if not in_norm:
+                c = gnorm(c, in_gamma)
+            c = gc2gc(c, out_order, in_gamma, out_gamma, n_fft)
+            if not out_norm:
+                c = ignorm(c, out_gamma)
+            if out_mul:
+                c = _gamma_scale(c, out_gamma)
+    else:
+        if in_mul:
+            c = _gamma_scale(c, 1 / in_gamma)
+        if in_norm:
+            c = ignorm(c, in_gamma)
+        c = c @ freqt_matrix(in_order, out_order, alpha)
+        if out_norm or in_gamma != out_gamma:
+            c = gnorm(c, in_gamma)
+        if in_gamma != out_gamma:
+            c = gc2gc(c, out_order, in_gamma, out_gamma, n_fft)
+        if not out_norm and in_gamma != out_gamma:
+            c = ignorm(c, out_gamma)
+        if out_mul:
+            c = _gamma_scale(c, out_gamma)
+    if not out_norm and out_mul:                                 # ZerothGammaMultiplication
+        c = c.copy()
+        c[..., 0] = c[..., 0] * out_gamma + 1
+    return c
+
+
+def mgc2sp(mc, fft_length, alpha=0.0, gamma=0.0, norm=False, mul=False, n_fft=512, out_format="power"):
+    """MelGeneralizedCepstrumToSpectrum (mgc2sp.py:150-202): cepstrum of order fft_length/2, rfft, formatter."""
+    c = mgc2mgc(mc, fft_length // 2, in_alpha=alpha, out_alpha=0.0, in_gamma=gamma, out_gamma=0.0, in_norm=norm,
+                out_norm=False, in_mul=mul, out_mul=False, n_fft=n_fft)
+    sp = np.fft.rfft(c, n=fft_length)
+    if out_format in (0, "db"):
+        return sp.real * (20 / np.log(10))
+    if out_format in (1, "log-magnitude"):
+        return sp.real
+    if out_format in (2, "magnitude"):
+        return np.exp(sp.real)
+    if out_format in (3, "power"):
+        return np.exp(2 * sp.real)
+    if out_format in (4, "cycle"):
+        return sp.imag / np.pi
+    if out_format in (5, "radian"):
+        return sp.imag
+    if out_format in (6, "degree"):
+        return sp.imag * (180 / np.pi)
+    if out_format == "complex":
+        return np.exp(sp.real) * np.exp(1j * sp.imag)
+    raise ValueError(f"out_format {out_format} is not supported.")
+
+
+def coef_freqt_matrix(in_order, out_order, alpha):
+    """CoefficientsFrequencyTransform of mgcep.py:255-282 (first row e_0, second row alpha^(j-1) (1 - alpha^2)):
+    returns (in_order + 1, out_order + 1)."""
+    L1, L2 = in_order + 1, out_order + 1
+    A = np.zeros((L2, L1))
+    A[0, 0] = 1
+    if L2 > 1 and L1 > 1:
+        A[1, 1:] = alpha ** np.arange(L1 - 1) * (1 - alpha * alpha)
+    for i in range(2, L2):
+        for j in range(1, L1):
+            A[i, j] = A[i - 1, j - 1] + alpha * (A[i, j - 1] - A[i - 1, j])
+    return A.T.copy()
+
+
+def pq_matrices(order, alpha):
+    """PTransform / QTransform of mgcep.py:285-331, as (order + 1, order + 1) right-multiplication matrices."""
+    n = order + 1
+    P = np.eye(n)
+    P[np.arange(n - 1), np.arange(1, n)] = alpha
+    P[0, 0] -= alpha * alpha
+    P[0, 1] += alpha
+    P[-1, -1] += alpha
+    Q = np.eye(n)
+    Q[np.arange(1, n), np.arange(n - 1)] = alpha
+    Q[1, 0] = 0
+    Q[1, 1] += alpha
+    return P.T.copy(), Q.T.copy()
+
+
+def mgcep(X, cep_order, alpha=0.0, gamma=0.0, n_iter=0):
+    """MelGeneralizedCepstralAnalysis.forward (mgcep.py:181-249), gamma in [-1, 0)."""
+    X = np.asarray(X, dtype=np.float64)
+    if gamma == 0:
+        return mcep(X, cep_order, alpha, n_iter)
+    M = cep_order
+    H = X.shape[-1] - 1
+    L = 2 * H
+    cfreqt = coef_freqt_matrix(M, L - 1, -alpha)
+    pfreqt = coef_freqt_matrix(L - 1, 2 * M, alpha)
+    rfreqt = coef_freqt_matrix(L - 1, M, alpha)
+    P, Q = pq_matrices(2 * M, alpha)
+    ii = np.arange(M)
+    toep = np.abs(ii[:, None] - ii[None, :])
+    hank = ii[:, None] + ii[None, :]
+
+    def newton(gam, b1):
+        b = np.concatenate((np.zeros_like(b1[..., :1]), b1), -1)
+        C = np.fft.rfft(b @ cfreqt, n=L)
+        if gam == -1:
+            p = np.fft.irfft(X) @ pfreqt
+            q, r = p, p[..., : M + 1]
+        else:
+            Xr, Y = 1 + gam * C.real, gam * C.imag
+            D = Xr * Xr + Y * Y
+            pp = X * D ** (-1 / gam) / D
+            qq = pp / D
+            p = np.fft.irfft(pp) @ pfreqt
+            q = np.fft.irfft(qq * (Xr * Xr - Y * Y) + 1j * qq * (2 * Xr * Y)) @ pfreqt
+            r = np.fft.irfft(pp * Xr + 1j * pp * Y) @ rfreqt
+        p, q = p @ P, q @ Q
+        if gam != -1:
+            eps = r[..., 0] + gam * (r[..., 1:] * b1).sum(-1)
+        pt, qt, rt = p[..., :M], q[..., 2:] * (1 + gam), r[..., 1:]
+        A = pt[..., toep] + qt[..., hank]
+        b1 = b1 + np.linalg.solve(A, rt[..., None])[..., 0]
+        if gam == -1:
+            eps = r[..., 0] + gam * (r[..., 1:] * b1).sum(-1)
+        return np.sqrt(eps)[..., None], b1
+
+    b1 = np.zeros(X.shape[:-1] + (M,))
+    b0, b1 = newton(-1, b1)
+    if gamma != -1:
+        b = np.concatenate((b0, b1), -1)
+        b = gnorm(mc2b(mgc2mgc(b2mc(ignorm(b, -1), alpha), M, in_gamma=-1, out_gamma=gamma), alpha), gamma)   # b2b
+        b1 = b[..., 1:]
+        for _ in range(n_iter):
+            b0, b1 = newton(gamma, b1)
+    return b2mc(ignorm(np.concatenate((b0, b1), -1), gamma), alpha)
