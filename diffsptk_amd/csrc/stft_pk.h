@@ -395,7 +395,18 @@ __global__ __launch_bounds__(128, 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
         PK_PHASE(5);
         if (!(ABL & 32)) {
 #pragma unroll
-            for (int k0 = 0; k0 < 16; ++k0) zf[j + 16 * k0] = v[FFT16_OUT(k0)];  // Z[k1 + 16 k0], natural order
+            for (int k0 = 0; k0 < 16; ++k0) {
+                if (DIRECT) {
+                    // Z[k], k = j + 16 k0, at position k + 1 (k <= 128) or k + 2 (k >= 128; Z[128] at both 129 and 130):
+                    // the split below then reads its two neighbouring pairs (Z[2l+1], Z[2l+2]) and
+                    // (Z[254-2l], Z[255-2l]) as ONE 16-byte aligned access each (as 8-byte reads at a 16-byte lane
+                    // stride they were two-way bank conflicts: 15 % of the kernel's LDS cycles)
+                    zf[j + 16 * k0 + (k0 < 8 ? 1 : 2)] = v[FFT16_OUT(k0)];
+                    if (k0 == 8 && j == 0) zf[129] = v[FFT16_OUT(k0)];
+                } else {
+                    zf[j + 16 * k0] = v[FFT16_OUT(k0)];  // Z[k1 + 16 k0], natural order
+                }
+            }
         }
         DSA_WAVE_SYNC();
         PK_PHASE(6);
@@ -414,11 +425,21 @@ __global__ __launch_bounds__(128, 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
             if (ABL & 32) {
                 pa[f][0] = v[4 * f], pb[f][0] = v[4 * f + 1], pa[f][1] = v[4 * f + 2], pb[f][1] = v[4 * f + 3], z0[f] = v[f];
             } else {
-                pa[f][0] = z[kA];
-                pb[f][0] = z[256 - kA];
-                pa[f][1] = z[kB];
-                pb[f][1] = z[256 - kB];
-                z0[f] = z[0];
+                if (DIRECT) {
+                    const v4f a2 = *reinterpret_cast<const v4f*>(z + 2 * lane + 2);     // Z[2l+1], Z[2l+2]
+                    const v4f b2 = *reinterpret_cast<const v4f*>(z + 256 - 2 * lane);   // Z[254-2l], Z[255-2l]
+                    pa[f][0] = v2f{a2.x, a2.y};
+                    pa[f][1] = v2f{a2.z, a2.w};
+                    pb[f][1] = v2f{b2.x, b2.y};   // partner of kB = 2l+2: Z[254-2l]
+                    pb[f][0] = v2f{b2.z, b2.w};   // partner of kA = 2l+1: Z[255-2l]
+                    z0[f] = z[1];
+                } else {
+                    pa[f][0] = z[kA];
+                    pb[f][0] = z[256 - kA];
+                    pa[f][1] = z[kB];
+                    pb[f][1] = z[256 - kB];
+                    z0[f] = z[0];
+                }
             }
         }
         DSA_WAVE_SYNC();   // all pairs are read before anything is written: the staged tile reuses the same LDS
