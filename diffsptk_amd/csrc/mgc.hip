@@ -134,9 +134,187 @@ static int th_launch(bool bwd, const void* gg, const void* p, const void* q, con
     return check_launch(bwd ? "th_solve_bwd" : "th_solve_fwd");
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Time-variant all-zero filter: AllZeroDigitalFilter._forward_efficient, zerodf.py:207-243 -- the
+// FIR core of the multi-stage / single-stage MLSA filter (mglsadf.py:254-527).
+//   y[t] = sum_{k=0}^{M} h_t[k] x[t - k + z0],   h_t = (1 - w) b[n] + w b[min(n + 1, N - 1)],  n = t / P, w = (t % P) / P
+// (x is zero outside [0, T); z0 = zeroth_index: taps k < z0 look ahead).  ignore_gain divides by the interpolated b[.][0]
+// (z0 < M) or b[.][M] (z0 = M).  One workgroup per frame: both coefficient rows and the frame's stretch of x in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void zerodf_fwd_kernel(const T* __restrict__ x, const T* __restrict__ b, long Tlen, long N,
+                                                         int M, int P, int z0, int ignore_gain, T* __restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* b0 = reinterpret_cast<T*>(smem_raw);   // [M + 1]
+    T* b1 = b0 + (M + 1);                     // [M + 1]
+    T* xs = b1 + (M + 1);                     // [P + M]: x[t0 - M + z0 .. t0 + P - 1 + z0]
+    const long f = blockIdx.x;                // flattened (utterance, frame)
+    const long u = f / N, n = f - u * N;
+    const long n1 = n + 1 < N ? n + 1 : N - 1;
+    const T* br0 = b + (u * N + n) * (M + 1);
+    const T* br1 = b + (u * N + n1) * (M + 1);
+    for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+        b0[k] = br0[k];
+        b1[k] = br1[k];
+    }
+    const long t0 = n * P;
+    const T* xu = x + u * Tlen;
+    for (int i = threadIdx.x; i < P + M; i += blockDim.x) {
+        const long s = t0 - M + z0 + i;
+        xs[i] = (s >= 0 && s < Tlen) ? xu[s] : T(0);
+    }
+    __syncthreads();
+    const int gk = z0 == M ? M : 0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        const T w = (T)i / (T)P;
+        T a0 = 0, a1 = 0;
+        // x[t - k + z0] = xs[i + M - k]
+        for (int k = 0; k <= M; ++k) {
+            const T xv = xs[i + M - k];
+            a0 += b0[k] * xv;
+            a1 += b1[k] * xv;
+        }
+        T v = a0 + w * (a1 - a0);             // torch.lerp(y1, y2, ramp)
+        if (ignore_gain) v /= b0[gk] + w * (b1[gk] - b0[gk]);
+        y[u * Tlen + t0 + i] = v;
+    }
+}
+
+// gx[s] = sum_k gyn[t] h_t[k], t = s - z0 + k (gather: deterministic); gyn = gy / gain when ignore_gain
+template <typename T>
+__global__ __launch_bounds__(256) void zerodf_bwd_x_kernel(const T* __restrict__ gy, const T* __restrict__ b, long B, long Tlen,
+                                                           long N, int M, int P, int z0, int ignore_gain, T* __restrict__ gx)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long u = idx / Tlen, s = idx - u * Tlen;
+    if (u >= B) return;
+    const int gk = z0 == M ? M : 0;
+    T acc = 0;
+    for (int k = 0; k <= M; ++k) {
+        const long t = s - z0 + k;
+        if (t < 0 || t >= Tlen) continue;
+        const long n = t / P;
+        const long n1 = n + 1 < N ? n + 1 : N - 1;
+        const T w = (T)(t - n * P) / (T)P;
+        const T* r0 = b + (u * N + n) * (M + 1);
+        const T* r1 = b + (u * N + n1) * (M + 1);
+        T g = gy[u * Tlen + t];
+        if (ignore_gain) g /= r0[gk] + w * (r1[gk] - r0[gk]);
+        acc += g * (r0[k] + w * (r1[k] - r0[k]));
+    }
+    gx[idx] = acc;
+}
+
+// gb[n][k] = sum over the samples of frame n (weight 1 - w) and of frame n - 1 (weight w; the last frame also takes its
+// own w part) of gyn[t] x[t - k + z0]; with ignore_gain the gain tap additionally receives -gy y / gain.
+template <typename T>
+__global__ __launch_bounds__(256) void zerodf_bwd_b_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ b,
+                                                           const T* __restrict__ y, long Tlen, long N, int M, int P, int z0,
+                                                           int ignore_gain, T* __restrict__ gb)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* gs = reinterpret_cast<T*>(smem_raw);   // [2P]: normalised cotangent times the frame weight, frames n - 1 and n
+    T* xs = gs + 2 * P;                       // [2P + M]
+    T* red = xs + 2 * P + M;                  // [blockDim.x] reduction scratch for the gain tap
+    const long f = blockIdx.x;
+    const long u = f / N, n = f - u * N;
+    const int gk = z0 == M ? M : 0;
+    const long tbase = (n - 1) * P;           // first sample of frame n - 1
+    T gain_part = 0;
+    for (int i = threadIdx.x; i < 2 * P; i += blockDim.x) {
+        const long t = tbase + i;
+        T v = 0;
+        if (t >= 0 && t < Tlen) {
+            const long nt = t / P;            // n - 1 or n
+            const long nt1 = nt + 1 < N ? nt + 1 : N - 1;
+            const T w = (T)(t - nt * P) / (T)P;
+            T wt = 0;                         // weight with which b[n] enters h_t
+            if (nt == n) wt += T(1) - w;
+            if (nt1 == n) wt += w;
+            T g = gy[u * Tlen + t];
+            if (ignore_gain) {
+                const T* r0 = b + (u * N + nt) * (M + 1);
+                const T* r1 = b + (u * N + nt1) * (M + 1);
+                const T gain = r0[gk] + w * (r1[gk] - r0[gk]);
+                g /= gain;
+                gain_part -= wt * g * y[u * Tlen + t];   // d/d gain of (u / gain) = -y / gain, gain = sum wt b[.][gk]
+            }
+            v = wt * g;
+        }
+        gs[i] = v;
+    }
+    const T* xu = x + u * Tlen;
+    for (int i = threadIdx.x; i < 2 * P + M; i += blockDim.x) {
+        const long s = tbase - M + z0 + i;
+        xs[i] = (s >= 0 && s < Tlen) ? xu[s] : T(0);
+    }
+    red[threadIdx.x] = gain_part;
+    __syncthreads();
+    for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+        T acc = 0;
+        for (int i = 0; i < 2 * P; ++i) acc += gs[i] * xs[i + M - k];
+        if (ignore_gain && k == gk)
+            for (int q = 0; q < (int)blockDim.x; ++q) acc += red[q];
+        gb[(u * N + n) * (M + 1) + k] = acc;
+    }
+}
+
+template <typename T>
+static int zerodf_launch_fwd(const void* x, const void* b, int64_t B, int64_t Tlen, int64_t N, int M, int P, int z0, int ig,
+                             void* y, hipStream_t st)
+{
+    const size_t lds = sizeof(T) * (2 * (size_t)(M + 1) + P + M);
+    if (lds > 64 * 1024) return fail(DSA_ERR_UNSUPPORTED, "zerodf: filter too long for LDS%s");
+    hipLaunchKernelGGL((zerodf_fwd_kernel<T>), dim3((unsigned)(B * N)), dim3(P >= 192 ? 256 : (P >= 96 ? 128 : 64)), lds, st,
+                       (const T*)x, (const T*)b, (long)Tlen, (long)N, M, P, z0, ig, (T*)y);
+    return check_launch("zerodf_fwd");
+}
+
+template <typename T>
+static int zerodf_launch_bwd(const void* gy, const void* x, const void* b, const void* y, int64_t B, int64_t Tlen, int64_t N, int M,
+                             int P, int z0, int ig, void* gx, void* gb, hipStream_t st)
+{
+    if (gx) {
+        hipLaunchKernelGGL((zerodf_bwd_x_kernel<T>), dim3((unsigned)((B * Tlen + 255) / 256)), dim3(256), 0, st, (const T*)gy,
+                           (const T*)b, (long)B, (long)Tlen, (long)N, M, P, z0, ig, (T*)gx);
+    }
+    if (gb) {
+        const size_t lds = sizeof(T) * ((size_t)2 * P + 2 * P + M + 256);
+        if (lds > 64 * 1024) return fail(DSA_ERR_UNSUPPORTED, "zerodf_bwd: filter too long for LDS%s");
+        hipLaunchKernelGGL((zerodf_bwd_b_kernel<T>), dim3((unsigned)(B * N)), dim3(256), lds, st, (const T*)gy, (const T*)x,
+                           (const T*)b, (const T*)y, (long)Tlen, (long)N, M, P, z0, ig, (T*)gb);
+    }
+    return check_launch("zerodf_bwd");
+}
+
 }  // namespace dsa
 
 using namespace dsa;
+
+DSA_EXPORT int dsa_zerodf_fwd(const void* x, const void* b, int64_t B, int64_t T, int32_t M, int32_t P, int32_t zeroth_index,
+                              int32_t ignore_gain, int32_t dtype, void* y, void* stream)
+{
+    DSA_REQUIRE(M >= 0 && P > 0 && B >= 0 && T >= 0 && zeroth_index >= 0 && zeroth_index <= M, "zerodf: invalid sizes");
+    DSA_REQUIRE(T % P == 0, "zerodf: the sequence length must be frames x frame_period");
+    if (B * T == 0) return DSA_OK;
+    const int64_t N = T / P;
+    if (dtype == DSA_F32) return zerodf_launch_fwd<float>(x, b, B, T, N, M, P, zeroth_index, ignore_gain, y, (hipStream_t)stream);
+    if (dtype == DSA_F64) return zerodf_launch_fwd<double>(x, b, B, T, N, M, P, zeroth_index, ignore_gain, y, (hipStream_t)stream);
+    return fail(DSA_ERR_UNSUPPORTED, "zerodf: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_zerodf_bwd(const void* gy, const void* x, const void* b, const void* y, int64_t B, int64_t T, int32_t M, int32_t P,
+                              int32_t zeroth_index, int32_t ignore_gain, int32_t dtype, void* gx, void* gb, void* stream)
+{
+    DSA_REQUIRE(M >= 0 && P > 0 && B >= 0 && T >= 0 && zeroth_index >= 0 && zeroth_index <= M && T % P == 0, "zerodf_bwd: invalid sizes");
+    if (B * T == 0) return DSA_OK;
+    const int64_t N = T / P;
+    if (dtype == DSA_F32)
+        return zerodf_launch_bwd<float>(gy, x, b, y, B, T, N, M, P, zeroth_index, ignore_gain, gx, gb, (hipStream_t)stream);
+    if (dtype == DSA_F64)
+        return zerodf_launch_bwd<double>(gy, x, b, y, B, T, N, M, P, zeroth_index, ignore_gain, gx, gb, (hipStream_t)stream);
+    return fail(DSA_ERR_UNSUPPORTED, "zerodf_bwd: unsupported dtype%s");
+}
 
 DSA_EXPORT int dsa_thsolve_fwd(const void* p, const void* q, const void* r, int64_t F, int32_t n, int32_t dtype, void* g,
                                void* stream)

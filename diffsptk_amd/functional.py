@@ -169,3 +169,13 @@ def mgcep(x: Tensor, cep_order: int, alpha: float = 0, gamma: float = 0, c: int 
     m = nn.MelGeneralizedCepstralAnalysis(fft_length=2 * x.size(-1) - 2, cep_order=cep_order, alpha=alpha, gamma=gamma,
                                           c=c, n_iter=n_iter, device=x.device, dtype=x.dtype)
     return m(x)
+
+
+def zerodf(x: Tensor, b: Tensor, frame_period: int = 80, ignore_gain: bool = False) -> Tensor:
+    """Time-variant all-zero filter (functional.py: zerodf)."""
+    return nn.AllZeroDigitalFilter._func(x, b, frame_period=frame_period, ignore_gain=ignore_gain)
+
+
+def linear_intpl(x: Tensor, upsampling_factor: int = 80) -> Tensor:
+    """Linear interpolation of frame-wise parameters (functional.py: linear_intpl)."""
+    return nn.LinearInterpolation._func(x, upsampling_factor=upsampling_factor)

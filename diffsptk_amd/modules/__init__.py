@@ -21,6 +21,9 @@ from .mcep import MelCepstralAnalysis
 from .mgc2mgc import MelGeneralizedCepstrumToMelGeneralizedCepstrum
 from .mgc2sp import MelGeneralizedCepstrumToSpectrum
 from .mgcep import MelGeneralizedCepstralAnalysis
+from .mglsadf import PseudoMGLSADigitalFilter
+from .mglsadf import PseudoMGLSADigitalFilter as MLSA
+from .zerodf import AllZeroDigitalFilter, LinearInterpolation
 from .mfcc import MelFrequencyCepstralCoefficientsAnalysis
 from .mfcc import MelFrequencyCepstralCoefficientsAnalysis as MFCC
 from .spec import Spectrum
@@ -36,5 +39,6 @@ __all__ = [
     "GeneralizedCepstrumGainNormalization", "GeneralizedCepstrumInverseGainNormalization",
     "MelCepstrumToMLSADigitalFilterCoefficients", "MLSADigitalFilterCoefficientsToMelCepstrum",
     "MelGeneralizedCepstrumToMelGeneralizedCepstrum", "MelGeneralizedCepstrumToSpectrum", "MelGeneralizedCepstralAnalysis",
+    "PseudoMGLSADigitalFilter", "MLSA", "AllZeroDigitalFilter", "LinearInterpolation",
     "RealValuedFastFourierTransform", "STFT", "ShortTimeFourierTransform", "Spectrum", "Window",
 ]

@@ -1,0 +1,151 @@
+"""Pseudo MGLSA (mel-generalized log spectrum approximation) synthesis filter (reference: mglsadf.py) -- SURVEY.md
+section 8(f), row 4.
+
+The three modes that do not need torchlpc, for phase in {minimum, maximum, zero}:
+  multi-stage   (mglsadf.py:254-386)  cepstrum of order `cep_order` (mgc2mgc), then `taylor_order` passes of the
+                                      time-variant FIR kernel (csrc/mgc.hip:zerodf) summed with Taylor weights of exp;
+  single-stage  (mglsadf.py:389-526)  impulse response of length `ir_length` (mgc2mgc to gamma = 1, or exp of the
+                                      Hermitian transform for zero phase), then ONE pass of the FIR kernel;
+  freq-domain   (mglsadf.py:529-644)  complex STFT of the excitation times the filter's complex spectrum (mgc2sp),
+                                      inverse STFT -- the fused STFT / ISTFT kernels of the analysis path.
+`mode="pade-approx"` (recursive filter through torchlpc) and `phase="mixed"` raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..utils.private import check_size
+from .gnorm import GeneralizedCepstrumGainNormalization as _Gnorm
+from .gnorm import get_gamma
+from .istft import InverseShortTimeFourierTransform
+from .mc2b import MelCepstrumToMLSADigitalFilterCoefficients, MLSADigitalFilterCoefficientsToMelCepstrum
+from .mgc2mgc import MelGeneralizedCepstrumToMelGeneralizedCepstrum
+from .mgc2sp import MelGeneralizedCepstrumToSpectrum
+from .spec import device_twiddle
+from .stft import ShortTimeFourierTransform
+from .zerodf import LinearInterpolation
+
+
+def _mirror(x: torch.Tensor, half: bool = False) -> torch.Tensor:
+    x0, x1 = x[..., :1], x[..., 1:]
+    if half:
+        x1 = x1 * 0.5
+    return torch.cat((x1.flip(-1), x0, x1), dim=-1)
+
+
+class PseudoMGLSADigitalFilter(nn.Module):
+    """x:(..., T) excitation, mc:(..., T/P, M+1) mel-generalized cepstrum -> y:(..., T) (mglsadf.py:211-252)."""
+
+    def __init__(self, filter_order: int, frame_period: int, *, alpha: float = 0, gamma: float = 0, c: int | None = None,
+                 ignore_gain: bool = False, phase: str = "minimum", mode: str = "multi-stage", device=None, dtype=None,
+                 **kwargs) -> None:
+        super().__init__()
+        if phase == "mixed":
+            raise NotImplementedError("diffsptk_amd: the mixed-phase MLSA filter is not provided by this backend")
+        if phase not in ("minimum", "maximum", "zero"):
+            raise ValueError(f"phase {phase} is not supported.")
+        if not isinstance(filter_order, int):
+            raise ValueError("filter_order must be an integer when phase is not 'mixed'.")
+        if mode == "pade-approx":
+            raise NotImplementedError("diffsptk_amd: the pade-approx MLSA filter needs torchlpc and is not provided")
+        if mode not in ("multi-stage", "single-stage", "freq-domain"):
+            raise ValueError(f"mode {mode} is not supported.")
+        gamma = get_gamma(gamma, c)
+        M = filter_order
+        self.filter_order, self.frame_period, self.mode, self.phase = M, frame_period, mode, phase
+        self.alpha, self.gamma, self.ignore_gain = alpha, gamma, ignore_gain
+        kw = dict(device=device, dtype=dtype)
+        if mode == "multi-stage":
+            self.taylor_order = kwargs.pop("taylor_order", 20)
+            cep_order = kwargs.pop("cep_order", 199)
+            n_fft = kwargs.pop("n_fft", 512)
+            if kwargs.pop("learnable", False):
+                raise NotImplementedError("diffsptk_amd: learnable Taylor coefficients are not provided")
+            if self.taylor_order < 0:
+                raise ValueError("taylor_order must be non-negative.")
+            if alpha == 0 and gamma == 0:
+                cep_order = M
+            self.cep_order = cep_order
+            self.mgc2c = MelGeneralizedCepstrumToMelGeneralizedCepstrum(M, cep_order, in_alpha=alpha, in_gamma=gamma, n_fft=n_fft, **kw)
+            self.linear_intpl = LinearInterpolation(frame_period)
+        elif mode == "single-stage":
+            self.ir_length = kwargs.pop("ir_length", 2000)
+            self.n_fft = kwargs.pop("n_fft", 4096)
+            if phase == "zero":
+                self.mgc2c = MelGeneralizedCepstrumToMelGeneralizedCepstrum(M, self.ir_length - 1, in_alpha=alpha, in_gamma=gamma,
+                                                                            n_fft=self.n_fft, **kw)
+            else:
+                self.mgc2ir = MelGeneralizedCepstrumToMelGeneralizedCepstrum(M, self.ir_length - 1, in_alpha=alpha, in_gamma=gamma,
+                                                                             out_gamma=1, out_mul=True, n_fft=self.n_fft, **kw)
+        else:
+            frame_length = kwargs.pop("frame_length", 400)
+            fft_length = kwargs.pop("fft_length", 512)
+            n_fft = kwargs.pop("n_fft", 512)
+            if frame_length <= 2 * frame_period:
+                raise ValueError("frame_period must be less than half of frame_length.")
+            if ignore_gain:
+                self.mc2b = MelCepstrumToMLSADigitalFilterCoefficients(M, alpha, **kw)
+                self.b2mc = MLSADigitalFilterCoefficientsToMelCepstrum(M, alpha, **kw)
+            self.mgc2sp = MelGeneralizedCepstrumToSpectrum(M, fft_length, alpha=alpha, gamma=gamma, out_format="complex", n_fft=n_fft, **kw)
+            self.stft = ShortTimeFourierTransform(frame_length, frame_period, fft_length, out_format="complex", **kw, **kwargs)
+            self.istft = InverseShortTimeFourierTransform(frame_length, frame_period, fft_length, **kw, **kwargs)
+            kwargs = {}
+        if kwargs:
+            raise TypeError(f"unexpected arguments for mode {mode}: {sorted(kwargs)}")
+
+    def forward(self, x: torch.Tensor, mc: torch.Tensor) -> torch.Tensor:
+        check_size(mc.size(-1), self.filter_order + 1, "dimension of mel-cepstrum")
+        check_size(x.size(-1), mc.size(-2) * self.frame_period, "sequence length")
+        P = self.frame_period
+        if self.mode == "multi-stage":
+            c = self.mgc2c(mc)
+            c0 = c[..., :1]
+            c = torch.cat((torch.zeros_like(c0), c[..., 1:]), dim=-1)          # remove_gain(c, value=0)
+            z0 = 0
+            if self.phase == "maximum":
+                c, z0 = c.flip(-1), self.cep_order
+            elif self.phase == "zero":
+                c, z0 = _mirror(c, half=True), self.cep_order
+            y = x
+            cur = x
+            for i in range(1, self.taylor_order + 1):                            # exp(F) ~ sum_i F^i / i!
+                cur = ops.ZerodfFn.apply(cur, c, P, z0, False) * (1.0 / i)
+                y = y + cur
+            if not self.ignore_gain:
+                y = y * torch.exp(self.linear_intpl(c0)).squeeze(-1)
+            return y
+        if self.mode == "single-stage":
+            L = self.ir_length
+            if self.phase in ("minimum", "maximum"):
+                h = self.mgc2ir(mc)
+                if self.ignore_gain:
+                    h = h / h[..., :1]
+                z0 = 0
+                if self.phase == "maximum":
+                    h, z0 = h.flip(-1), L - 1
+            else:
+                c = self.mgc2c(mc)
+                c = torch.cat((c[..., :1], 0.5 * c[..., 1:]), dim=-1)
+                if self.ignore_gain:
+                    c = torch.cat((torch.zeros_like(c[..., :1]), c[..., 1:]), dim=-1)
+                # ifft(exp(hfft(c, n))).real[:L]: c is real, so hfft(c) = 2 Re rfft(c) - c[0] and the result is the inverse
+                # real transform of a real, even spectrum -- both on the library's real-FFT kernels
+                tw = device_twiddle(self.n_fft, c.device, c.dtype)
+                Xh = 2 * ops.FftrFn.apply(c, self.n_fft, 1, tw) - c[..., :1]
+                E = torch.exp(Xh)
+                h = ops.IfftrFn.apply(torch.complex(E, torch.zeros_like(E)), self.n_fft, L, tw)
+                h, z0 = _mirror(h), L - 1
+            return ops.ZerodfFn.apply(x, h.contiguous(), P, z0, False)
+        c = mc
+        if self.ignore_gain:
+            b = _Gnorm._forward(self.mc2b(mc), gamma=self.gamma)
+            b = torch.cat((torch.zeros_like(b[..., :1]), b[..., 1:]), dim=-1)
+            c = self.b2mc(b)
+        H = self.mgc2sp(c)
+        if self.phase == "maximum":
+            H = H.conj()
+        elif self.phase == "zero":
+            H = H.abs()
+        return self.istft(H * self.stft(x), out_length=x.size(-1))

@@ -704,6 +704,40 @@ class ThSolveFn(torch.autograd.Function):
         return gp, gq, gr
 
 
+class ZerodfFn(torch.autograd.Function):
+    """Time-variant all-zero filter (zerodf.py:207-243): x:(..., T), b:(..., T/P, M+1) -> y:(..., T)."""
+
+    @staticmethod
+    def forward(ctx, x, b, P, zeroth_index, ignore_gain):
+        _require_device(x, b)
+        _same_dtype(x, b)
+        xc, bc = x.contiguous(), b.contiguous()
+        T = xc.size(-1)
+        M = bc.size(-1) - 1
+        B = xc.numel() // max(T, 1)
+        y = torch.empty_like(xc)
+        with torch.cuda.device(x.device):
+            _call("dsa_zerodf_fwd", _p(xc), _p(bc), B, T, M, P, zeroth_index, int(bool(ignore_gain)), _dtype_code(xc), _p(y), _stream())
+        ctx.save_for_backward(xc, bc, y)
+        ctx.cfg = (P, zeroth_index, int(bool(ignore_gain)))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        xc, bc, y = ctx.saved_tensors
+        P, z0, ig = ctx.cfg
+        T = xc.size(-1)
+        M = bc.size(-1) - 1
+        B = xc.numel() // max(T, 1)
+        gyc = gy.contiguous()
+        gx = torch.empty_like(xc) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(bc) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(gy.device):
+            _call("dsa_zerodf_bwd", _p(gyc), _p(xc), _p(bc), _p(y), B, T, M, P, z0, ig, _dtype_code(xc), _p(gx), _p(gb), _stream())
+        return gx, gb, None, None, None
+
+
 # ----------------------------------------------------------------------------------- LPC branch
 class AcorrFn(torch.autograd.Function):
     @staticmethod

@@ -230,6 +230,17 @@ int dsa_thsolve_fwd(const void* p, const void* q, const void* r, int64_t F, int3
 int dsa_thsolve_bwd(const void* gg, const void* p, const void* q, const void* g, int64_t F, int32_t n, int32_t dtype,
                     void* gp, void* gq, void* gr, void* stream);
 
+/* ------------------------------------------------------------------ f4  time-variant all-zero filter
+ * AllZeroDigitalFilter._forward_efficient, zerodf.py:207-243: the FIR core of the multi-stage / single-stage MLSA filter
+ * (mglsadf.py:254-527).  x:(B,T), b:(B,N,M+1) with T = N P -> y:(B,T),
+ *   y[t] = sum_k h_t[k] x[t - k + zeroth_index],  h_t = lerp(b[t / P], b[min(t / P + 1, N - 1)], (t % P) / P);
+ * ignore_gain divides by the interpolated gain tap (b[.][0], or b[.][M] when zeroth_index = M).
+ * Backward: gy, and the forward's x, b, y -> gx:(B,T) and / or gb:(B,N,M+1) (either may be NULL). */
+int dsa_zerodf_fwd(const void* x, const void* b, int64_t B, int64_t T, int32_t M, int32_t P, int32_t zeroth_index,
+                   int32_t ignore_gain, int32_t dtype, void* y, void* stream);
+int dsa_zerodf_bwd(const void* gy, const void* x, const void* b, const void* y, int64_t B, int64_t T, int32_t M, int32_t P,
+                   int32_t zeroth_index, int32_t ignore_gain, int32_t dtype, void* gx, void* gb, void* stream);
+
 /* ------------------------------------------------------------------ a11  autocorrelation
  * Autocorrelation._forward, acorr.py:110-120.  x:(F,L) -> r:(F,M+1).  Computed as direct lag
  * sums (the reference's irfft(|rfft(x, L+M)|^2) is the same quantity: no circular wrap). */

@@ -622,3 +622,96 @@ def mgcep(X, cep_order, alpha=0.0, gamma=0.0, n_iter=0):
         for _ in range(n_iter):
             b0, b1 = newton(gamma, b1)
     return b2mc(ignorm(np.concatenate((b0, b1), -1), gamma), alpha)
+
+
+# ----------------------------------------------------------------------------- MLSA synthesis filter
+def linear_intpl(x, P):
+    """LinearInterpolation._forward (linear_intpl.py:85-117): (..., N, D) -> (..., N P, D), frame n -> n + 1 over P
+    samples, the last frame held."""
+    x = np.asarray(x, dtype=np.float64)
+    nxt = np.concatenate((x[..., 1:, :], x[..., -1:, :]), axis=-2)
+    w = (np.arange(P) / P)[:, None]
+    y = x[..., :, None, :] + w * (nxt - x)[..., :, None, :]
+    return y.reshape(*x.shape[:-2], x.shape[-2] * P, x.shape[-1])
+
+
+def zerodf(x, b, P, ignore_gain=False, zeroth_index=0):
+    """AllZeroDigitalFilter (zerodf.py:184-243): y[t] = sum_k h_t[k] x[t - k + z0] with linearly interpolated taps."""
+    x, b = np.asarray(x, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    M = b.shape[-1] - 1
+    h = linear_intpl(b, P)                                       # (..., T, M+1)
+    T = x.shape[-1]
+    xp = np.concatenate((np.zeros(x.shape[:-1] + (M - zeroth_index,)), x, np.zeros(x.shape[:-1] + (zeroth_index,))), -1)
+    y = np.zeros_like(x)
+    for k in range(M + 1):                                       # x[t - k + z0] = xp[t + M - k]
+        y += h[..., k] * xp[..., M - k: M - k + T]
+    if ignore_gain:
+        y = y / (h[..., 0] if zeroth_index != M or M == 0 else h[..., M])
+    return y
+
+
+def _mirror(x, half=False):
+    x1 = x[..., 1:] * (0.5 if half else 1.0)
+    return np.concatenate((x1[..., ::-1], x[..., :1], x1), -1)
+
+
+def mlsa(x, mc, P, alpha=0.0, gamma=0.0, ignore_gain=False, phase="minimum", mode="multi-stage", **kw):
+    """PseudoMGLSADigitalFilter (mglsadf.py:126-253) for phase in {minimum, maximum, zero}:
+    multi-stage (mglsadf.py:351-386), single-stage (:486-526), freq-domain (:613-644)."""
+    x, mc = np.asarray(x, dtype=np.float64), np.asarray(mc, dtype=np.float64)
+    M = mc.shape[-1] - 1
+    if mode == "multi-stage":
+        taylor_order, cep_order, n_fft = kw.get("taylor_order", 20), kw.get("cep_order", 199), kw.get("n_fft", 512)
+        if alpha == 0 and gamma == 0:
+            cep_order = M
+        c = mgc2mgc(mc, cep_order, in_alpha=alpha, in_gamma=gamma, n_fft=n_fft)
+        c0 = c[..., :1]
+        c = np.concatenate((np.zeros_like(c0), c[..., 1:]), -1)
+        z0 = 0
+        if phase == "maximum":
+            c, z0 = c[..., ::-1], cep_order
+        elif phase == "zero":
+            c, z0 = _mirror(c, half=True), cep_order
+        y = x.copy()
+        cur = x
+        fact = 1.0
+        for i in range(1, taylor_order + 1):
+            cur = zerodf(cur, c, P, zeroth_index=z0) * (1.0 / i)   # weights[i] = (1/i!) / (1/(i-1)!)
+            y = y + cur
+        if not ignore_gain:
+            y = y * np.exp(linear_intpl(c0, P))[..., 0]
+        return y
+    if mode == "single-stage":
+        ir_length, n_fft = kw.get("ir_length", 2000), kw.get("n_fft", 4096)
+        if phase in ("minimum", "maximum"):
+            h = mgc2mgc(mc, ir_length - 1, in_alpha=alpha, in_gamma=gamma, out_gamma=1, out_mul=True, n_fft=n_fft)
+            if ignore_gain:
+                h = h / h[..., :1]
+            z0 = 0
+            if phase == "maximum":
+                h, z0 = h[..., ::-1], ir_length - 1
+        else:
+            c = mgc2mgc(mc, ir_length - 1, in_alpha=alpha, in_gamma=gamma, n_fft=n_fft)
+            c = np.concatenate((c[..., :1], 0.5 * c[..., 1:]), -1)
+            if ignore_gain:
+                c = np.concatenate((np.zeros_like(c[..., :1]), c[..., 1:]), -1)
+            h = np.fft.ifft(np.exp(np.fft.hfft(c, n=n_fft))).real[..., :ir_length]
+            h, z0 = _mirror(h), ir_length - 1
+        return zerodf(x, h, P, zeroth_index=z0)
+    if mode == "freq-domain":
+        L, nfft, n_fft = kw.get("frame_length", 400), kw.get("fft_length", 512), kw.get("n_fft", 512)
+        win = kw.get("window", "blackman")
+        c = mc
+        if ignore_gain:
+            bq = gnorm(mc2b(mc, alpha), gamma)
+            bq[..., 0] = 0
+            c = b2mc(bq, alpha)
+        H = mgc2sp(c, nfft, alpha, gamma, n_fft=n_fft, out_format="complex")
+        if phase == "maximum":
+            H = np.conj(H)
+        elif phase == "zero":
+            H = np.abs(H)
+        w = window_table(L, win)
+        X = stft(x, L, P, nfft, window=win, out_format="complex")
+        return istft(H * X, L, P, w=w, out_length=x.shape[-1])
+    raise ValueError(f"mode {mode} is not supported.")

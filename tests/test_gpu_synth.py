@@ -136,3 +136,82 @@ def test_mgcep_speech_512_and_gamma0_route(golden):
     assert torch.autograd.gradcheck(mg, (Xs,), eps=1e-6, atol=1e-6, rtol=1e-4)
     with pytest.raises(ValueError):
         dsp.MelGeneralizedCepstralAnalysis(fft_length=32, cep_order=4, gamma=0.5)
+
+
+# ----------------------------------------------------------------------------- MLSA synthesis filter (8(f) row 4)
+def test_zerodf_and_linear_intpl(golden):
+    g = golden("mlsa")
+    for z0 in (0, 2, 4):
+        for ig in (0, 1):
+            if ig and z0 == 2:
+                continue
+            x, b = dev(g["zdf_x"]).requires_grad_(True), dev(g["zdf_b"]).requires_grad_(True)
+            m = dsp.AllZeroDigitalFilter(4, 4, ignore_gain=bool(ig), zeroth_index=z0, mode="efficient")
+            y = m(x, b)
+            assert _lib.last_kernel() == "zerodf_fwd"
+            close(host(y), g[f"zdf_{z0}_{ig}"], **F64)
+            (y * torch.linspace(-1, 1, 24, dtype=torch.float64, device=DEV)).sum().backward()
+            close(host(x.grad), g[f"zdf_gx_{z0}_{ig}"], 1e-8, 1e-10)
+            close(host(b.grad), g[f"zdf_gb_{z0}_{ig}"], 1e-8, 1e-10)
+    close(host(dsp.LinearInterpolation(3)(dev(g["intpl_in"]))), g["intpl_out"], **F64)
+    x = torch.randn(2, 12, dtype=torch.float64, generator=torch.Generator().manual_seed(1)).to(DEV).requires_grad_(True)
+    b = (torch.randn(2, 4, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(2)) + torch.tensor([2.0, 0, 0])).to(DEV).requires_grad_(True)
+    for z0, ig in ((0, True), (1, False), (2, True)):
+        assert torch.autograd.gradcheck(lambda a, c: ops.ZerodfFn.apply(a, c, 3, z0, ig), (x, b), eps=1e-6, atol=1e-7, rtol=1e-5)
+    # a long filter in float32 against the float64 oracle (the single-stage filter runs 200 .. 2000 taps)
+    rng = np.random.default_rng(5)
+    xl, bl = rng.standard_normal((3, 800)), 0.05 * rng.standard_normal((3, 10, 400))
+    yl = host(ops.ZerodfFn.apply(dev(xl, torch.float32), dev(bl, torch.float32), 80, 0, False))
+    ref = O.zerodf(xl, bl, 80)
+    assert np.abs(yl - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("mode", ["multi-stage", "single-stage", "freq-domain"])
+def test_mlsa_filter_golden(golden, mode):
+    """tests/test_mglsadf.py of the reference: M = 24, P = 80, alpha = 0.42, c in {0, 2}, with / without the gain."""
+    g = golden("mlsa")
+    params = {"multi-stage": {"taylor_order": 7, "cep_order": 100}, "single-stage": {"ir_length": 200, "n_fft": 512},
+              "freq-domain": {"frame_length": 512, "fft_length": 512, "window": "hamming"}}[mode]
+    x = dev(g["mlsa_x"])
+    for c in (0, 2):
+        mc = dev(g[f"mlsa_mc_c{c}"])
+        for ig in (0, 1):
+            m = dsp.MLSA(24, 80, alpha=0.42, c=c, ignore_gain=bool(ig), phase="minimum", mode=mode, dtype=torch.float64, device=DEV, **params)
+            ref = g[f"mlsa_{mode}_c{c}_{ig}"]
+            y = host(m(x, mc))
+            assert np.abs(y - ref).max() < 1e-7 * np.abs(ref).max(), (mode, c, ig, np.abs(y - ref).max())
+    m32 = dsp.MLSA(24, 80, alpha=0.42, mode=mode, device=DEV, **params)
+    y32 = host(m32(x.float(), dev(g["mlsa_mc_c0"], torch.float32))).astype(np.float64)
+    ref = g[f"mlsa_{mode}_c0_0"]
+    assert np.abs(y32 - ref).max() < 2e-4 * np.abs(ref).max()
+    p2 = {"multi-stage": {"cep_order": 60, "taylor_order": 7}, "single-stage": {"ir_length": 120, "n_fft": 512},
+          "freq-domain": {"frame_length": 512, "fft_length": 512, "window": "hamming"}}[mode]
+    for ph in ("maximum", "zero"):
+        m = dsp.MLSA(24, 80, alpha=0.42, phase=ph, mode=mode, dtype=torch.float64, device=DEV, **p2)
+        ref = g[f"mlsa_{mode}_{ph}"]
+        assert np.abs(host(m(x, dev(g["mlsa_mc_c0"]))) - ref).max() < 1e-7 * np.abs(ref).max(), (mode, ph)
+
+
+def test_mlsa_gradients_and_analysis_synthesis(golden):
+    g = golden("mlsa")
+    x, mc = dev(g["mlsa_x"]).requires_grad_(True), dev(g["mlsa_mc_c0"]).requires_grad_(True)
+    m = dsp.MLSA(24, 80, alpha=0.42, mode="multi-stage", taylor_order=7, cep_order=100, dtype=torch.float64, device=DEV)
+    m(x, mc).square().sum().backward()
+    for got, name in ((x.grad, "mlsa_gx"), (mc.grad, "mlsa_gmc")):
+        ref = g[name]
+        assert np.abs(host(got) - ref).max() < 1e-6 * np.abs(ref).max(), name
+    with pytest.raises(NotImplementedError):
+        dsp.MLSA(24, 80, mode="pade-approx")
+    with pytest.raises(NotImplementedError):
+        dsp.MLSA((24, 24), 80, phase="mixed")
+    # README.md:91-93 of the reference: analysis -> synthesis.  White excitation through the filter of the analysed
+    # cepstra must carry the spectral envelope the cepstra describe (mgc2sp), frame by frame, within the variance of a
+    # periodogram: compared on mel-cepstra of the synthesised signal.
+    stft = dsp.STFT(400, 80, 512, device=DEV)
+    mcep = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, device=DEV)
+    src = torch.randn(1, 16000, generator=torch.Generator().manual_seed(3)).to(DEV)
+    shape = torch.tensor([0.0, 1.2, -0.6, 0.3] + [0.0] * 21, device=DEV)
+    mc_t = shape.expand(1, 200, 25).contiguous()
+    y = dsp.MLSA(24, 80, alpha=0.42, mode="freq-domain", frame_length=400, fft_length=512, device=DEV)(src, mc_t)
+    mc_hat = mcep(stft(y))[:, 20:180].mean(1)
+    assert float((mc_hat[0, 1:4] - shape[1:4]).abs().max()) < 0.15
