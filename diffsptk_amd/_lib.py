@@ -31,6 +31,8 @@ SOURCE_FLAGS = {
 
 F32, F64 = 0, 1
 SCRATCH_BYTES = 64   # DSA_SCRATCH_BYTES
+FBANK_PLAN_FLOATS = 2048   # DSA_FBANK_PLAN_FLOATS
+ERR_UNSUPPORTED = -2       # DSA_ERR_UNSUPPORTED
 ALGO_AUTO, ALGO_GENERIC, ALGO_TUNED = 0, 1, 2
 
 _lib = None
@@ -119,6 +121,8 @@ SIGNATURES = {
     "dsa_fftcep_bwd": (C.c_int, [_P, _P, _L, _I, _I, _P, _D, _I, _P, _I, _P, _P]),
     "dsa_griffin_update": (C.c_int, [_P, _L, _L, _L, _I, _P, _P, _P, _P, _I, _D, _D, _D, _D, _I, _P, _P]),
     "dsa_fbank_fwd": (C.c_int, [_P, _L, _I, _P, _I, _D, _D, _I, _I, _P, _P, _P]),
+    "dsa_fbank_scan_plan": (C.c_int, [_P, _I, _I, _P]),
+    "dsa_stft_fbank_fwd": (C.c_int, [_P, _L, _L, _I, _I, _I, _P, _P, _I, _D, _P, _I, _D, _D, _I, _I, _P, _P]),
     "dsa_fbank_bwd": (C.c_int, [_P, _P, _P, _L, _I, _P, _I, _D, _D, _I, _I, _P, _P]),
     "dsa_mcep_images_bytes": (C.c_int64, [_I, _I, _I]),
     "dsa_mcep_prepare": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),

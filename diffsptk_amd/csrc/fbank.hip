@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kFbMaxWaves * 64) void fbank_fwd_kernel(const T* __
 #pragma unroll
             for (int fi = 0; fi < kFbFrames; ++fi)
                 if (f0 + fi < F) {
-                    const T v = acc[fi] > floor ? acc[fi] : floor;                                   // fbank.py:317
+                    const T v = acc[fi] < floor ? floor : acc[fi];                                   // fbank.py:317 (torch.clip: NaN stays NaN)
                     y[(f0 + fi) * C + c] = glog_fwd(v, gamma);
                 }
         }
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const flo
                     if (post_mode) {
                         ost[fr * C + ch] = d[r] * ((ch == 0 || ((post_mode & 2) && ch == C - 1)) ? 0.5f * post_scale : post_scale);
                     } else {
-                        const float v = d[r] > floor ? d[r] : floor;                // fbank.py:317
+                        const float v = d[r] < floor ? floor : d[r];                // fbank.py:317 (NaN stays NaN)
                         ost[fr * C + ch] = glog_fwd(v, gamma);
                     }
                 } else if (ch == ecol) {

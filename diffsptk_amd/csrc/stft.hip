@@ -1318,10 +1318,10 @@ static void stft512_launch(bool zmean, dim3 grid, int lds, hipStream_t st, const
     if (use_pk && ABL == 0 && plain && !zmean && L == 400 && (P & 1) == 0 && 3 * P + 512 <= kFPW * kZS * 2) {
         if (use_pk == 1)   // staged 16-byte stores (A/B)
             hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, false>), g2, dim3(128), lds2, st, x, T, N, L, P, left, w, tw, eps, y,
-                               total_chunks, chunks_per_utt);
+                               total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0);
         else               // 8-byte stores straight from the split's registers (default)
             hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, true>), g2, dim3(128), lds2, st, x, T, N, L, P, left, w, tw, eps, y,
-                               total_chunks, chunks_per_utt);
+                               total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0);
         return;
     }
 #define DSA_STFT_FWD_LAUNCH(ZM, PL, LCV)                                                                                 \
@@ -1678,6 +1678,121 @@ DSA_EXPORT int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int3
         return launch_row_dft<double>(x, B, T, N, L, P, left, pad_mode, zmean, w, nfft, twiddle, 1, out_format,
                                       eps, use_floor, relative_floor_db, y, st);
     return fail(DSA_ERR_UNSUPPORTED, "stft: unsupported dtype%s");
+}
+
+// --------------------------------------------------------------------------- fused STFT -> mel filter bank
+// Host side of the filter-bank epilogue of stft512_fwd_pk_kernel<.., FB = true> (stft_pk.h).
+// dsa_fbank_scan_plan turns H (host, float64, 257 x C) into the (64, 32) float32 per-lane table; it is the C
+// statement of diffsptk_amd/utils/tables.py:fbank_scan_plan / fbank_scan_table (tests compare the two bit for bit).
+DSA_EXPORT int dsa_fbank_scan_plan(const double* H, int32_t K, int32_t C, float* table)
+{
+    DSA_REQUIRE(H && table, "fbank_scan_plan: null pointer");
+    if (K != 257 || C < 1 || C > 126) return fail(DSA_ERR_UNSUPPORTED, "fbank_scan_plan: needs 257 bins and at most 126 channels%s");
+    int jk[257] = {0};
+    double wd[257] = {0.0}, wu[257] = {0.0};
+    int prev = 0;
+    for (int k = 1; k < K - 1; ++k) {
+        int nz[3], n = 0;
+        for (int c = 0; c < C; ++c) {
+            const double h = H[(size_t)k * C + c];
+            if (!std::isfinite(h)) return fail(DSA_ERR_UNSUPPORTED, "fbank_scan_plan: non-finite weight%s");
+            if (h != 0.0) {
+                if (n < 3) nz[n] = c;
+                ++n;
+            }
+        }
+        int j;
+        if (n == 0) {
+            j = prev;
+        } else if (n == 1) {
+            const int c = nz[0];
+            if (c >= prev) j = c, wu[k] = H[(size_t)k * C + c];
+            else if (c + 1 >= prev) j = c + 1, wd[k] = H[(size_t)k * C + c];
+            else return fail(DSA_ERR_UNSUPPORTED, "fbank_scan_plan: channels are not ordered along the bins%s");
+        } else if (n == 2 && nz[1] == nz[0] + 1 && nz[1] >= prev) {
+            j = nz[1], wd[k] = H[(size_t)k * C + nz[0]], wu[k] = H[(size_t)k * C + nz[1]];
+        } else {
+            return fail(DSA_ERR_UNSUPPORTED, "fbank_scan_plan: a bin feeds more than two adjacent channels%s");
+        }
+        jk[k] = prev = j;
+    }
+    for (int c = 0; c < C; ++c)
+        if (!std::isfinite(H[c]) || !std::isfinite(H[(size_t)(K - 1) * C + c]))
+            return fail(DSA_ERR_UNSUPPORTED, "fbank_scan_plan: non-finite weight%s");
+    memset(table, 0, sizeof(float) * 64 * 32);
+    int32_t* ti = reinterpret_cast<int32_t*>(table);
+    bool valid[2][128] = {{false}};
+    for (int h = 0; h < 2; ++h) {
+        int j0[64], j1[64], run[64];
+        for (int l = 0; l < 64; ++l) {
+            const int b0 = h == 0 ? 2 * l + 1 : 255 - 2 * l, b1 = h == 0 ? 2 * l + 2 : 254 - 2 * l;
+            j0[l] = jk[b0], j1[l] = jk[b1];
+            float* t = table + l * 32;
+            t[0 + h] = (float)wd[b0], t[2 + h] = (float)wu[b0];
+            t[4 + h] = (float)wd[b1], t[6 + h] = (float)wu[b1];
+            if (h == 1 && l == 63) t[4 + h] = t[6 + h] = 0.f;   // bin 128 belongs to the lower half
+            t[8 + h] = j0[l] != j1[l] ? 0.f : 1.f;
+        }
+        run[0] = 0;
+        for (int l = 1; l < 64; ++l) run[l] = (j0[l] == j1[l] && j1[l - 1] == j0[l]) ? run[l - 1] + 1 : 0;
+        for (int l = 0; l < 64; ++l) {
+            float* t = table + l * 32;
+            float* m = t + 10 + 6 * h;
+            m[0] = run[l] >= 1, m[1] = run[l] >= 2, m[2] = run[l] >= 4, m[3] = run[l] >= 8;
+            m[4] = ((l / 16) % 2 == 1) && run[l] >= l % 16 + 1;
+            m[5] = l >= 32 && run[l] >= l - 31;
+            t[22 + h] = (l > 0 && j1[l - 1] == j0[l]) ? 1.f : 0.f;
+            const bool isE = l == 63 || j0[l + 1] != j1[l], isM = j0[l] != j1[l];
+            ti[l * 32 + 24] |= (j1[l] << (8 * h)) | (j0[l] << (16 + 8 * h));
+            ti[l * 32 + 25] |= ((int)isE << h) | ((int)isM << (2 + h));
+            if (isE) valid[h][j1[l]] = true;
+            if (isM) valid[h][j0[l]] = true;
+        }
+    }
+    for (int l = 0; l < 64; ++l)
+        for (int r = 0; r < 2; ++r) {
+            const int c = l + 64 * r;
+            if (c >= C) continue;
+            table[l * 32 + 26 + 2 * r] = (float)H[c];
+            table[l * 32 + 27 + 2 * r] = (float)H[(size_t)(K - 1) * C + c];
+            // channel c reads the up-slope sums of interval c and the down-slope sums of interval c + 1
+            ti[l * 32 + 30] |= ((int)valid[0][c] | ((int)valid[1][c] << 1) | ((int)valid[0][c + 1] << 2) | ((int)valid[1][c + 1] << 3)) << (4 * r);
+        }
+    bool has_ends = false;
+    for (int c = 0; c < C; ++c) has_ends = has_ends || H[c] != 0.0 || H[(size_t)(K - 1) * C + c] != 0.0;
+    if (has_ends)
+        for (int l = 0; l < 64; ++l) ti[l * 32 + 30] |= 256;   // bit 8 (every lane): bins 0 / 256 carry weight
+    return DSA_OK;
+}
+
+DSA_EXPORT int dsa_stft_fbank_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft, const void* w,
+                                  const void* twiddle, int32_t center, double eps, const void* plan, int32_t C, double floor,
+                                  double gamma, int32_t use_power, int32_t dtype, void* y, void* stream)
+{
+    DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0, "stft_fbank: sizes must be positive");
+    DSA_REQUIRE(x && w && twiddle && plan && y, "stft_fbank: null pointer");
+    DSA_REQUIRE(floor > 0, "stft_fbank: floor must be positive");
+    if (!(dtype == DSA_F32 && nfft == 512 && L == 400 && (P & 1) == 0 && 3 * P + 512 <= kFPW * kZS * 2 && C >= 1 && C <= 126))
+        return fail(DSA_ERR_UNSUPPORTED,
+                    "stft_fbank: the fused kernel needs float32, fft_length 512, frame_length 400, an even frame period and at most "
+                    "126 channels (use dsa_stft_fwd + dsa_fbank_fwd)%s");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t N = dsa_num_frames(T, P);
+    if (B * N == 0) return DSA_OK;
+    const int left = center ? L / 2 : 0;
+    const int chunks_per_utt = (int)((N + kFPW - 1) / kFPW);
+    const long total_chunks = (long)B * chunks_per_utt;
+    long waves = 256L * 16;   // four waves per SIMD, four-wave workgroups
+    if (waves > total_chunks) waves = total_chunks;
+    const int lds = 4 * kFPW * kZS * 8 + 256 * 8 + 16 * 13 * 8 + 128 * 8;
+#define DSA_FB_LAUNCH(MODE)                                                                                                  \
+    hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, true, MODE>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, st,     \
+                       (const float*)x, (long)T, (long)N, L, P, left, (const float*)w, (const float*)twiddle, (float)eps,      \
+                       (float*)y, total_chunks, chunks_per_utt, (const float*)plan, (float)floor, (float)gamma, C)
+    if (use_power) DSA_FB_LAUNCH(1);
+    else DSA_FB_LAUNCH(2);
+#undef DSA_FB_LAUNCH
+    return check_launch("stft512_fbank_fwd");
 }
 
 // --------------------------------------------------------------------------- backward entries

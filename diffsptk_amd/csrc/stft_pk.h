@@ -185,17 +185,32 @@ __device__ unsigned long long g_stft_pk_stamps[64];
 // DIRECT: the power values leave the split's registers as 4-byte stores (lane = bin: every store instruction writes 64
 // consecutive floats of one row) instead of being staged in LDS for 16-byte stores: the kernel is bound by LDS
 // cycles, and the staged tile costs 18 four-byte LDS writes + 5 sixteen-byte reads per pass (a fifth of them).
-template <int ABL, int LC, bool DIRECT = false>
-__global__ __launch_bounds__(128, 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
+//
+// FB: the mel filter bank in the epilogue (SURVEY 8(f) row 1 without the spectrum's round trip through memory,
+// fbank.py:306-321 on top of stft.py): `y` is then the (B N, C) filter-bank output glog(max(s H, floor)), s = the
+// power values or their square roots.  H must have the two-adjacent-channels-per-bin structure of the mel filters;
+// the host turns it into the per-lane plan `fbt` (dsa_fbank_scan_plan; tools/proto_fbank_scan.py is a lane-level
+// model): with the DIRECT split a lane holds the neighbouring bins (2l+1, 2l+2) and (255-2l, 254-2l) of a frame,
+// so the bins between two channel centres are a RUN of lanes and the channel sums are segmented scans over lanes
+// (v_fmac_f32_dpp with a 0/1 mask per lane and step: no transposition through LDS, no matrix operand images --
+// neither would fit beside four waves per SIMD).  Four-wave workgroups: the window moves from registers to a
+// shared LDS table to make room for the plan.
+template <int ABL, int LC, bool DIRECT = false, int FBM = 0>   // FBM: 0 spectrum out, 1 filter bank of the power values, 2 of the amplitudes
+__global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
     const float* __restrict__ x, long Tlen, long N, int L, int P, int left, const float* __restrict__ w,
-    const float* __restrict__ twiddle, float eps, float* __restrict__ y, long total_chunks, int chunks_per_utt)
+    const float* __restrict__ twiddle, float eps, float* __restrict__ y, long total_chunks, int chunks_per_utt,
+    const float* __restrict__ fbt, float fb_floor, float fb_gamma, int fbC)
 {
+    constexpr bool FB = FBM != 0;
+    static_assert(!FB || (DIRECT && LC > 0), "the filter-bank epilogue builds on the register-direct split");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int WPB = 2;   // waves per workgroup (they share the twiddle table, nothing else)
+    constexpr int WPB = FB ? 4 : 2;   // waves per workgroup (they share the twiddle table, nothing else)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     v2f* zbuf = reinterpret_cast<v2f*>(smem_raw) + wv * kFPW * kZS;
     float* io_buf = reinterpret_cast<float*>(zbuf);  // aliases zbuf: stretch -> tiles -> spectra -> staged output
     v2f* t256 = reinterpret_cast<v2f*>(smem_raw) + WPB * kFPW * kZS;
+    v2f* wtab = t256 + 256;                          // FB: [16][NR] window pairs
+    v2f* hend = wtab + 16 * (LC ? (LC + 31) / 32 : 16);   // FB: [128] (H[0][c], H[256][c])
     const long nw = (long)gridDim.x * WPB;
     long wid = (long)blockIdx.x * WPB + wv;
     if (ABL & 256) {   // experiment: workgroups are dealt round-robin to the 8 XCDs; give every XCD a contiguous eighth of a round
@@ -278,10 +293,47 @@ __global__ __launch_bounds__(128, 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
     PK_STAMP(3);
 
     v2f wreg[NR];
+    v2f f_wd0, f_wu0, f_wd1, f_wu1, f_nb, f_mM;   // FB: the lane's plan (lower-half bin pair in .x, upper-half pair in .y)
+    float f_mk[12];
+    int f_addr[4], f_valid = 0;
+    if (FB) {
+        // every wave writes the whole (identical) tables, like the twiddle table below: no workgroup barrier needed
+        v2f wt[4], he[2];
 #pragma unroll
-    for (int m1 = 0; m1 < NR; ++m1) {
-        const int l = 2 * j + 32 * m1;
-        wreg[m1] = v2f{l < L ? w[l] : 0.f, l + 1 < L ? w[l + 1] : 0.f};
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int i = lane + 64 * q4;
+            const int l = 2 * (i / NR) + 32 * (i % NR);
+            wt[q4] = v2f{(i < 16 * NR && l < L) ? w[l < L ? l : 0] : 0.f, (i < 16 * NR && l + 1 < L) ? w[l + 1 < L ? l + 1 : 0] : 0.f};
+        }
+        const float* fl_ = fbt + lane * 32;
+        he[0] = v2f{fl_[26], fl_[27]};
+        he[1] = v2f{fl_[28], fl_[29]};
+        const v4f t0 = *reinterpret_cast<const v4f*>(fl_), t1 = *reinterpret_cast<const v4f*>(fl_ + 4);
+        const v4f t2 = *reinterpret_cast<const v4f*>(fl_ + 8), t3 = *reinterpret_cast<const v4f*>(fl_ + 12);
+        const v4f t4 = *reinterpret_cast<const v4f*>(fl_ + 16), t5 = *reinterpret_cast<const v4f*>(fl_ + 20);
+        const int slots_w = __builtin_bit_cast(int, fl_[24]), flags_w = __builtin_bit_cast(int, fl_[25]);
+        f_valid = __builtin_bit_cast(int, fl_[30]);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+            if (lane + 64 * q4 < 16 * NR) wtab[lane + 64 * q4] = wt[q4];
+        hend[lane] = he[0];
+        hend[lane + 64] = he[1];
+        f_wd0 = v2f{t0.x, t0.y}, f_wu0 = v2f{t0.z, t0.w}, f_wd1 = v2f{t1.x, t1.y}, f_wu1 = v2f{t1.z, t1.w};
+        f_nb = v2f{t2.x, t2.y};
+        f_mk[0] = t2.z, f_mk[1] = t2.w, f_mk[2] = t3.x, f_mk[3] = t3.y, f_mk[4] = t3.z, f_mk[5] = t3.w;
+        f_mk[6] = t4.x, f_mk[7] = t4.y, f_mk[8] = t4.z, f_mk[9] = t4.w, f_mk[10] = t5.x, f_mk[11] = t5.y;
+        f_mM = v2f{t5.z, t5.w};
+        // byte offsets of the lane's slot writes inside a [128]-float block; slot 127 is nobody's (C <= 126): "no write"
+        f_addr[0] = 4 * ((flags_w & 1) ? (slots_w & 255) : 127);            // run total of the lower half  -> interval jE
+        f_addr[1] = 4 * ((flags_w & 2) ? ((slots_w >> 8) & 255) : 127);     //              upper half
+        f_addr[2] = 4 * ((flags_w & 4) ? ((slots_w >> 16) & 255) : 127);    // interval closed inside the lane, lower half
+        f_addr[3] = 4 * ((flags_w & 8) ? ((slots_w >> 24) & 255) : 127);    //                                  upper half
+    } else {
+#pragma unroll
+        for (int m1 = 0; m1 < NR; ++m1) {
+            const int l = 2 * j + 32 * m1;
+            wreg[m1] = v2f{l < L ? w[l] : 0.f, l + 1 < L ? w[l + 1] : 0.f};
+        }
     }
     {
         // entry [k1 = i >> 4][j = i & 15]: W256^(j k1) = W512^(2 j k1), HALVED: the 1/2 of the real-FFT split (exact).
@@ -306,8 +358,15 @@ __global__ __launch_bounds__(128, 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
     v2f* zf = zbuf + fl * kZS;
     // Every prologue load is consumed HERE: otherwise the wait for these loop-invariant registers lands at their
     // first use inside the pass loop, where it would also wait for whatever the pass has in flight.
+    if (FB) {
+        asm volatile("" : "+v"(f_wd0), "+v"(f_wu0), "+v"(f_wd1), "+v"(f_wu1), "+v"(f_nb), "+v"(f_mM));
 #pragma unroll
-    for (int m1 = 0; m1 < NR; ++m1) asm volatile("" : "+v"(wreg[m1]));
+        for (int i = 0; i < 12; ++i) asm volatile("" : "+v"(f_mk[i]));
+        asm volatile("" : "+v"(f_addr[0]), "+v"(f_addr[1]), "+v"(f_addr[2]), "+v"(f_addr[3]), "+v"(f_valid));
+    } else {
+#pragma unroll
+        for (int m1 = 0; m1 < NR; ++m1) asm volatile("" : "+v"(wreg[m1]));
+    }
     asm volatile("" : "+v"(twA), "+v"(twB));
     PK_STAMP(4);
     if (pre_ok) {
@@ -359,7 +418,7 @@ __global__ __launch_bounds__(128, 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
                     const bool in0 = 32 * m1 + 30 < LC || 32 * m1 + 2 * j < LC;
                     const bool in1 = 32 * m1 + 31 < LC || 32 * m1 + 1 + 2 * j < LC;
                     const v2f r = v2f{in0 ? raw[m1].x : 0.f, in1 ? raw[m1].y : 0.f};
-                    v[m1] = pk_mul(r, wreg[m1]);
+                    v[m1] = pk_mul(r, FB ? wtab[j * NR + m1] : wreg[m1]);
                 }
 #pragma unroll
                 for (int m1 = NR; m1 < 16; ++m1) v[m1] = v2f{0.f, 0.f};
@@ -485,7 +544,61 @@ __global__ __launch_bounds__(128, 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
                     stage[f * K + 256 - k] = s.y;
                 }
             }
-            if (DIRECT && !(ABL & 64) && !(ABL & 1) && f < nvalid) {
+            if (FB) {
+                // ---- filter bank: the lane's four values of this frame, weighted, summed over the lanes of each interval ----
+                v2f s0 = sp[0], s1 = sp[1];   // (bin 2l+1, bin 255-2l), (bin 2l+2, bin 254-2l)
+                v2f en = se;
+                if (FBM == 2) {               // fbank.py:315: amplitude domain
+                    s0 = v2f{__builtin_amdgcn_sqrtf(s0.x), __builtin_amdgcn_sqrtf(s0.y)};
+                    s1 = v2f{__builtin_amdgcn_sqrtf(s1.x), __builtin_amdgcn_sqrtf(s1.y)};
+                    en = v2f{__builtin_amdgcn_sqrtf(en.x), __builtin_amdgcn_sqrtf(en.y)};
+                    // (the square roots come from the transcendental unit: one idle issue slot before any hand-written
+                    //  instruction may read them -- the compiler does not track hazards into inline assembly; the first
+                    //  version of this epilogue summed them with v_pk_add_f32 and read stale registers)
+                    asm volatile("s_nop 0" : "+v"(s0), "+v"(s1), "+v"(en));
+                }
+                ends[f] = en;
+                // (a non-finite sample makes every bin of its frames non-finite, hence -- every channel has bins of non-zero
+                //  weight -- every channel of those frames, and the scans never mix frames: no extra handling needed)
+                // contributions of the lane's first (c*0) and second (c*1) bin of each half to the down / up sums
+                const float cd0l = s0.x * f_wd0.x, cd0h = s0.y * f_wd0.y, cu0l = s0.x * f_wu0.x, cu0h = s0.y * f_wu0.y;
+                float a0 = __builtin_fmaf(cd0l, f_nb.x, s1.x * f_wd1.x), a1 = __builtin_fmaf(cd0h, f_nb.y, s1.y * f_wd1.y);
+                float a2 = __builtin_fmaf(cu0l, f_nb.x, s1.x * f_wu1.x), a3 = __builtin_fmaf(cu0h, f_nb.y, s1.y * f_wu1.y);
+    // (a DPP operand must have been written at least two issue slots earlier: the leading s_nop covers the first
+    //  step, afterwards three other instructions lie between a write and the next shifted read of a register)
+#define DSA_FB_SCAN(NOP, CTRL, MLO, MHI)                                                 \
+    asm volatile(NOP "v_fmac_f32_dpp %0, %0, %4 " CTRL "\n\t"                                 \
+                 "v_fmac_f32_dpp %1, %1, %5 " CTRL "\n\t"                                 \
+                 "v_fmac_f32_dpp %2, %2, %4 " CTRL "\n\t"                                 \
+                 "v_fmac_f32_dpp %3, %3, %5 " CTRL                                        \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(MLO), "v"(MHI))
+                DSA_FB_SCAN("s_nop 1\n\t", "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1", f_mk[0], f_mk[6]);
+                DSA_FB_SCAN("", "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1", f_mk[1], f_mk[7]);
+                DSA_FB_SCAN("", "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1", f_mk[2], f_mk[8]);
+                DSA_FB_SCAN("", "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1", f_mk[3], f_mk[9]);
+                DSA_FB_SCAN("", "row_bcast:15 row_mask:0xa bank_mask:0xf", f_mk[4], f_mk[10]);
+                DSA_FB_SCAN("", "row_bcast:31 row_mask:0xc bank_mask:0xf", f_mk[5], f_mk[11]);
+#undef DSA_FB_SCAN
+                // intervals that end with the lane's FIRST bin: that bin + the run total of the previous lane
+                float m0 = cd0l, m1 = cd0h, m2 = cu0l, m3 = cu0h;
+                asm volatile("v_fmac_f32_dpp %0, %4, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_fmac_f32_dpp %1, %5, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_fmac_f32_dpp %2, %6, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_fmac_f32_dpp %3, %7, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                             : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3)
+                             : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(f_mM.x), "v"(f_mM.y));
+                // slots [f][down lower | down upper | up lower | up upper][128]: the down and the up sum of an interval are
+                // 1024 bytes apart -- one ds_write2st64_b32 with immediate offsets for every frame
+                char* sl = reinterpret_cast<char*>(zbuf) + f * 2048;
+                *reinterpret_cast<float*>(sl + f_addr[0]) = a0;
+                *reinterpret_cast<float*>(sl + 1024 + f_addr[0]) = a2;
+                *reinterpret_cast<float*>(sl + 512 + f_addr[1]) = a1;
+                *reinterpret_cast<float*>(sl + 1536 + f_addr[1]) = a3;
+                *reinterpret_cast<float*>(sl + f_addr[2]) = m0;
+                *reinterpret_cast<float*>(sl + 1024 + f_addr[2]) = m2;
+                *reinterpret_cast<float*>(sl + 512 + f_addr[3]) = m1;
+                *reinterpret_cast<float*>(sl + 1536 + f_addr[3]) = m3;
+            } else if (DIRECT && !(ABL & 64) && !(ABL & 1) && f < nvalid) {
                 // bins (2 lane + 1, 2 lane + 2) and (254 - 2 lane, 255 - 2 lane): two 8-byte stores, 512 consecutive
                 // bytes of the row per instruction (lane 63 writes bin 128 twice, the same pair either way)
                 float* yr = y + out0 + f * K;
@@ -498,7 +611,57 @@ __global__ __launch_bounds__(128, 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
                 }
             }
         }
-        if (DIRECT && !(ABL & 1) && !(ABL & 64)) {   // bins 0 and 256 of the (up to) four frames: lanes 0..7, one instruction
+        if (FB) {
+            // ---- channel c = up-slope sum of interval c + down-slope sum of interval c + 1 (both halves) + the end bins ----
+            DSA_WAVE_SYNC();
+            const float* slf = reinterpret_cast<const float*>(zbuf);
+            for (int cb = 0; cb < fbC; cb += 64) {
+                const int ch = cb + lane;
+                const int cc = ch < 126 ? ch : 126;
+                const int vb = cb ? (f_valid >> 4) : f_valid;
+                const v2f he = hend[cc];
+                const bool has_ends = (f_valid & 256) != 0;   // some channel weights bin 0 or bin 256 (wave-uniform)
+                float sums[kFPW];
+#pragma unroll
+                for (int f = 0; f < kFPW; ++f) {
+                    const float* q = slf + f * 512 + cc;
+                    float u0 = q[256], u1 = q[384], d0 = q[1], d1 = q[129];
+                    u0 = (vb & 1) ? u0 : 0.f;
+                    u1 = (vb & 2) ? u1 : 0.f;
+                    d0 = (vb & 4) ? d0 : 0.f;
+                    d1 = (vb & 8) ? d1 : 0.f;
+                    float sum = (u0 + u1) + (d0 + d1);
+                    if (has_ends) sum += he.x * ends[f].x + he.y * ends[f].y;
+                    sums[f] = sum < fb_floor ? fb_floor : sum;                               // fbank.py:317 (NaN stays NaN)
+                }
+                if (fb_gamma == 0.f && fb_floor >= 1e-30f) {                                 // fbank.py:318
+                    // v_log_f32 (1 ulp, normal arguments: the sums are >= floor) times ln 2
+#pragma unroll
+                    for (int f = 0; f < kFPW; ++f) sums[f] = __builtin_amdgcn_logf(sums[f]) * 0.69314718055994531f;
+                } else if (fb_gamma == 0.f) {
+#pragma unroll 1
+                    for (int f = 0; f < kFPW; ++f) {
+                        float v = sums[0];
+                        v = f == 1 ? sums[1] : v, v = f == 2 ? sums[2] : v, v = f == 3 ? sums[3] : v;
+                        v = dsa_log(v);
+                        sums[0] = f == 0 ? v : sums[0], sums[1] = f == 1 ? v : sums[1];
+                        sums[2] = f == 2 ? v : sums[2], sums[3] = f == 3 ? v : sums[3];
+                    }
+                } else {
+#pragma unroll 1
+                    for (int f = 0; f < kFPW; ++f) {
+                        float v = sums[0];
+                        v = f == 1 ? sums[1] : v, v = f == 2 ? sums[2] : v, v = f == 3 ? sums[3] : v;
+                        v = (dsa_pow(v, fb_gamma) - 1.f) / fb_gamma;
+                        sums[0] = f == 0 ? v : sums[0], sums[1] = f == 1 ? v : sums[1];
+                        sums[2] = f == 2 ? v : sums[2], sums[3] = f == 3 ? v : sums[3];
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < kFPW; ++f)
+                    if (ch < fbC && f < nvalid && !(ABL & 1)) y[(row0 + f) * fbC + ch] = sums[f];
+            }
+        } else if (DIRECT && !(ABL & 1) && !(ABL & 64)) {   // bins 0 and 256 of the (up to) four frames: lanes 0..7, one instruction
             const int fe = lane >> 1;
             v2f e = ends[0];
             e = fe == 1 ? ends[1] : e;

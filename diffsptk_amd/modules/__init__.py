@@ -15,6 +15,7 @@ from .freqt import FrequencyTransform
 from .levdur import LevinsonDurbin
 from .lpc import LinearPredictiveCodingAnalysis
 from .lpc import LinearPredictiveCodingAnalysis as LPC
+from .fused import FusedSTFTFilterBank, fuse
 from .gnorm import GeneralizedCepstrumGainNormalization, GeneralizedCepstrumInverseGainNormalization
 from .mc2b import MelCepstrumToMLSADigitalFilterCoefficients, MLSADigitalFilterCoefficientsToMelCepstrum
 from .mcep import MelCepstralAnalysis
@@ -40,5 +41,6 @@ __all__ = [
     "MelCepstrumToMLSADigitalFilterCoefficients", "MLSADigitalFilterCoefficientsToMelCepstrum",
     "MelGeneralizedCepstrumToMelGeneralizedCepstrum", "MelGeneralizedCepstrumToSpectrum", "MelGeneralizedCepstralAnalysis",
     "PseudoMGLSADigitalFilter", "MLSA", "AllZeroDigitalFilter", "LinearInterpolation",
+    "FusedSTFTFilterBank", "fuse",
     "RealValuedFastFourierTransform", "STFT", "ShortTimeFourierTransform", "Spectrum", "Window",
 ]

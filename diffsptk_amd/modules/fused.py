@@ -1,0 +1,70 @@
+"""STFT -> mel filter bank (-> MFCC) without the spectrogram's round trip through memory -- SURVEY.md section 8(f), row 1.
+
+The reference runs ``fbank(stft(x))`` as two modules (README.md:238-243 of the reference; stft.py:237-241 then
+fbank.py:306-321 / mfcc.py:244-256), writing and re-reading the (B, N, 257) power spectrogram in between.  ``fuse``
+keeps exactly those two modules and their semantics, and runs them as ONE kernel launch when the configuration is
+the one the packed STFT kernel serves (csrc/stft_pk.h, ``FBM`` variants): the mel sums come out of the registers that
+hold the power values, as segmented scans over the lanes.  Everything else -- other sizes, options, dtypes, matrices
+without the triangular structure, a needed gradient -- runs the two stages on their own kernels, unchanged."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import ops
+from .fbank import MelFilterBankAnalysis
+from .mfcc import MelFrequencyCepstralCoefficientsAnalysis
+from .stft import ShortTimeFourierTransform
+
+_SPEC_POWER, _FFT, _FRAME = 3, 512, 400
+
+
+class FusedSTFTFilterBank(nn.Module):
+    """``analysis(stft(x))`` for ``analysis`` a MelFilterBankAnalysis or a MelFrequencyCepstralCoefficientsAnalysis.
+
+    ``last_path`` tells which route the last call took ("fused" / "two-stage") -- for tests and profiles."""
+
+    def __init__(self, stft: ShortTimeFourierTransform, analysis: nn.Module) -> None:
+        super().__init__()
+        if not isinstance(stft, ShortTimeFourierTransform):
+            raise ValueError("stft must be a ShortTimeFourierTransform.")
+        if not isinstance(analysis, (MelFilterBankAnalysis, MelFrequencyCepstralCoefficientsAnalysis)):
+            raise ValueError("analysis must be a MelFilterBankAnalysis or a MelFrequencyCepstralCoefficientsAnalysis.")
+        if stft.fft_length // 2 + 1 != analysis.in_dim:
+            raise ValueError("stft and analysis disagree on fft_length.")
+        self.stft = stft
+        self.analysis = analysis
+        self.last_path = None
+
+    def _fusable(self, x: torch.Tensor) -> bool:
+        s, a = self.stft, self.analysis
+        if x.dtype != torch.float32 or not x.is_cuda or x.size(-1) < 1:
+            return False
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False   # the fused kernel is forward only
+        if any(isinstance(getattr(m, n, None), nn.Parameter) for m in (s, a) for n in ("window", "W", "H")):
+            return False   # learnable tables run on the differentiable stages
+        if not (s.fmt == _SPEC_POWER and s.mode == "constant" and not s.zmean and s.relative_floor is None
+                and s.fft_length == _FFT and s.frame_length == _FRAME and s.frame_period % 2 == 0
+                and 3 * s.frame_period + 512 <= 2176):
+            return False
+        return a.out_format == "y" and ops.fbank_scan_plan(a.H) is not None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        s, a = self.stft, self.analysis
+        if not self._fusable(x):
+            self.last_path = "two-stage"
+            return a(s(x))
+        self.last_path = "fused"
+        is_mfcc = isinstance(a, MelFrequencyCepstralCoefficientsAnalysis)
+        use_power = False if is_mfcc else a.use_power          # mfcc.py:200: amplitude domain
+        y = ops.stft_fbank(x, s.window, s.twiddle, s.frame_length, s.frame_period, s.fft_length, s.center, s.eps,
+                           ops.fbank_scan_plan(a.H), a.H.size(1), a.floor, a.gamma, use_power)
+        if is_mfcc:   # DCT-II x truncation x lifter (mfcc.py:249-252): one row product on (.., C) values; C0 dropped ("y")
+            y = ops.MatmulRowsFn.apply(y, a.W)[..., 1:]
+        return y
+
+
+def fuse(stft: ShortTimeFourierTransform, analysis: nn.Module) -> FusedSTFTFilterBank:
+    """``fuse(stft, fbank)(x) == fbank(stft(x))``, in one launch where the fused kernel applies."""
+    return FusedSTFTFilterBank(stft, analysis)

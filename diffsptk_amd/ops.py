@@ -587,6 +587,48 @@ class FbankFn(torch.autograd.Function):
         return gx, None, None, None, None
 
 
+_FB_PLANS: dict = {}   # id(H) -> (weakref to H, version, plan or None)
+
+
+def fbank_scan_plan(H: torch.Tensor):
+    """The per-lane plan of the fused STFT -> filter-bank kernel for the (257, C) weights `H` (dsa_fbank_scan_plan: built
+    on the host, one device-to-host copy of H per matrix and version), as a device tensor -- or None when H does not
+    have the two-adjacent-channels-per-bin structure the kernel sums over (the two-kernel path serves those)."""
+    import numpy as np
+
+    key = id(H)
+    hit = _FB_PLANS.get(key)
+    if hit is not None and hit[0]() is H and hit[1] == H._version:
+        return hit[2]
+    plan = None
+    if H.dim() == 2 and H.size(0) == 257 and 1 <= H.size(1) <= 126:
+        Hh = np.ascontiguousarray(H.detach().to("cpu", torch.float64).numpy())
+        table = np.zeros(_lib.FBANK_PLAN_FLOATS, dtype=np.float32)
+        rc = _lib.load().dsa_fbank_scan_plan(Hh.ctypes.data, 257, int(H.size(1)), table.ctypes.data)
+        if rc == 0:
+            plan = torch.from_numpy(table).to(H.device)
+        elif rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc, "dsa_fbank_scan_plan")
+    _FB_PLANS[key] = (weakref.ref(H), H._version, plan)
+    weakref.finalize(H, _FB_PLANS.pop, key, None)
+    return plan
+
+
+def stft_fbank(x, window, twiddle, L, P, fft_length, center, eps, plan, n_channel, floor, gamma, use_power):
+    """y:(..., N, C) = glog(max(s H, floor)) of the STFT power values (or their square roots) in ONE launch
+    (dsa_stft_fbank_fwd: stft.py:148-152 + fbank.py:306-321); forward only."""
+    _require_device(x, window, twiddle, plan)
+    _same_dtype(x, window, twiddle)
+    xc, wc = x.contiguous(), window.contiguous()
+    T = xc.size(-1)
+    B = xc.numel() // T if T > 0 else 0
+    y = torch.empty((*xc.shape[:-1], num_frames(T, P), n_channel), device=x.device, dtype=x.dtype)
+    with torch.cuda.device(x.device):
+        _call("dsa_stft_fbank_fwd", _p(xc), B, T, L, P, fft_length, _p(wc), _p(twiddle), int(center), float(eps), _p(plan),
+              int(n_channel), float(floor), float(gamma), int(bool(use_power)), _dtype_code(xc), _p(y), _stream())
+    return y
+
+
 class MfccFn(torch.autograd.Function):
     """cy, E = (glog(max(s H, floor)) W, log energy) in one launch (mfcc.py:244-256): W:(C, M+1) is DCT-II x truncation
     x liftering vector.  Backward = the transposed product through W, then the filter-bank backward."""

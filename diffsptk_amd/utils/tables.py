@@ -242,6 +242,113 @@ def fbank_matrix(fft_length: int, n_channel: int, sample_rate: int, f_min: float
     return H
 
 
+def fbank_scan_plan(H: np.ndarray):
+    """Per-lane plan of the fused STFT -> filter-bank kernel (csrc/stft_pk.h, `FB` variant) for a 257-bin filter-bank
+    matrix H (K, C) whose rows have at most two non-zero entries, in ADJACENT channels j - 1 ("down" slope) and j ("up"
+    slope), with j non-decreasing over the bins: what `fbank_matrix` builds for the mel / auditory scales
+    (fbank.py:232-291).  Returns None for any other matrix (the two-kernel path serves those).
+
+    Bin k then lies in "interval" j(k) between two channel centres, and channel c is
+        sum over interval c of up(k) s(k)  +  sum over interval c + 1 of down(k) s(k)  (+ the end bins 0 and 256).
+    In the kernel a lane holds the bins (2 l + 1, 2 l + 2) ("lower half") and (255 - 2 l, 254 - 2 l) ("upper half") of
+    a frame, so an interval is a run of neighbouring lanes and its two sums come out of a SEGMENTED inclusive scan
+    over the lanes (DPP row shifts 1, 2, 4, 8, row broadcasts 15 and 31; the `mask` entries say per lane and step
+    whether the source lane belongs to the same run).  A lane whose two bins lie in different intervals closes the
+    first interval itself (`isM`: its first bin + the scan value of the previous lane) and starts a new run with
+    the second; `isE` marks the lanes whose scan value is the total of interval `jE`.
+    tools/proto_fbank_scan.py executes this plan lane by lane in numpy against `s @ H`."""
+    H = np.asarray(H, dtype=np.float64)
+    if H.ndim != 2 or H.shape[0] != 257 or not (1 <= H.shape[1] <= 126) or not np.all(np.isfinite(H)):
+        return None
+    K, C = H.shape
+    jk = np.zeros(K, dtype=np.int64)
+    wd = np.zeros(K)
+    wu = np.zeros(K)
+    prev = 0
+    for k in range(1, K - 1):
+        nz = np.flatnonzero(H[k])
+        if len(nz) == 0:
+            j = prev
+        elif len(nz) == 1:
+            c = int(nz[0])
+            if c >= prev:
+                j, wu[k] = c, H[k, c]
+            elif c + 1 >= prev:
+                j, wd[k] = c + 1, H[k, c]
+            else:
+                return None
+        elif len(nz) == 2 and nz[1] == nz[0] + 1 and nz[1] >= prev:
+            j, wd[k], wu[k] = int(nz[1]), H[k, nz[0]], H[k, nz[1]]
+        else:
+            return None
+        jk[k] = prev = j
+    lane = np.arange(64)
+    plan = {name: np.zeros((64, 2)) for name in ("wd0", "wd1", "wu0", "wu1", "nb", "mM")}
+    plan["mask"] = np.zeros((64, 2, 6))
+    for name in ("isE", "isM", "jE", "jM"):
+        plan[name] = np.zeros((64, 2), dtype=np.int64)
+    for h in range(2):
+        b0 = 2 * lane + 1 if h == 0 else 255 - 2 * lane     # first / second bin of a lane in scan order
+        b1 = 2 * lane + 2 if h == 0 else 254 - 2 * lane
+        j0, j1 = jk[b0], jk[b1]
+        plan["wd0"][:, h], plan["wu0"][:, h] = wd[b0], wu[b0]
+        plan["wd1"][:, h], plan["wu1"][:, h] = wd[b1], wu[b1]
+        if h == 1:   # bin 128 belongs to the lower half
+            plan["wd1"][63, h] = plan["wu1"][63, h] = 0.0
+        boundary = j0 != j1
+        plan["nb"][:, h] = np.where(boundary, 0.0, 1.0)
+        run = np.zeros(64, dtype=np.int64)
+        for ln in range(1, 64):
+            if not boundary[ln] and j1[ln - 1] == j0[ln]:
+                run[ln] = run[ln - 1] + 1
+        for step, d in enumerate((1, 2, 4, 8)):
+            plan["mask"][:, h, step] = run >= d
+        plan["mask"][:, h, 4] = ((lane // 16) % 2 == 1) & (run >= lane % 16 + 1)
+        plan["mask"][:, h, 5] = (lane >= 32) & (run >= lane - 31)
+        plan["mM"][1:, h] = j1[:-1] == j0[1:]
+        plan["isE"][:, h] = np.append(j0[1:] != j1[:-1], True)
+        plan["isM"][:, h] = boundary
+        plan["jE"][:, h], plan["jM"][:, h] = j1, j0
+    plan["C"] = C
+    plan["h0"] = np.zeros(128)
+    plan["h256"] = np.zeros(128)
+    plan["h0"][:C], plan["h256"][:C] = H[0], H[K - 1]
+    return plan
+
+
+def fbank_scan_table(plan) -> np.ndarray:
+    """The plan of `fbank_scan_plan` as the (64, 32) float32 table the kernel reads (integer fields as bit patterns):
+    columns 0-7 weights (wd0, wu0, wd1, wu1) x (lower, upper), 8-9 nb, 10-21 scan masks [half][step], 22-23 mM,
+    24 slot indices (jE lower | jE upper << 8 | jM lower << 16 | jM upper << 24), 25 flags (isE lower, isE upper,
+    isM lower, isM upper), 26 / 27 H[0, lane], H[256, lane], 28 / 29 H[0, lane + 64], H[256, lane + 64],
+    30 which of the four sums channel `lane` (bits 0-3) and channel `lane + 64` (bits 4-7) reads exist; bit 8: some channel weights bin 0 or 256."""
+    t = np.zeros((64, 32), dtype=np.float32)
+    for i, name in enumerate(("wd0", "wu0", "wd1", "wu1")):
+        t[:, 2 * i:2 * i + 2] = plan[name]
+    t[:, 8:10] = plan["nb"]
+    t[:, 10:22] = plan["mask"].reshape(64, 12)
+    t[:, 22:24] = plan["mM"]
+    ti = t.view(np.int32)
+    ti[:, 24] = plan["jE"][:, 0] | (plan["jE"][:, 1] << 8) | (plan["jM"][:, 0] << 16) | (plan["jM"][:, 1] << 24)
+    ti[:, 25] = plan["isE"][:, 0] | (plan["isE"][:, 1] << 1) | (plan["isM"][:, 0] << 2) | (plan["isM"][:, 1] << 3)
+    valid = np.zeros((2, 129), dtype=np.int64)   # (half, interval): some lane writes the interval's sums
+    for h in range(2):
+        valid[h, plan["jE"][plan["isE"][:, h] != 0, h]] = 1
+        valid[h, plan["jM"][plan["isM"][:, h] != 0, h]] = 1
+    C = int(plan["C"])
+    for r in range(2):
+        c = np.arange(64) + 64 * r
+        ok = c < C
+        cc = np.minimum(c, 127)
+        bits = valid[0, cc] | (valid[1, cc] << 1) | (valid[0, cc + 1] << 2) | (valid[1, cc + 1] << 3)
+        ti[:, 30] |= np.where(ok, bits, 0).astype(np.int32) << (4 * r)
+    if np.any(plan["h0"] != 0) or np.any(plan["h256"] != 0):
+        ti[:, 30] |= 256   # bit 8 (every lane): bins 0 / 256 carry weight
+    t[:, 26], t[:, 28] = plan["h0"][:64], plan["h0"][64:]
+    t[:, 27], t[:, 29] = plan["h256"][:64], plan["h256"][64:]
+    return t
+
+
 def dct_matrix(dct_length: int, dct_type: int = 2) -> np.ndarray:
     """Orthonormal DCT-I..IV matrix W (L, L), y = x @ W (dct.py:99-133)."""
     L = dct_length

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 110 /* 0.1.1: caller-owned workspaces (images / scratch), no library-owned device memory */
+#define DSA_VERSION 111 /* 0.1.1: caller-owned workspaces (images / scratch), no library-owned device memory */
 
 typedef enum {
     DSA_OK = 0,
@@ -152,6 +152,20 @@ int dsa_fbank_bwd(const void* gy, const void* gE, const void* x, int64_t F, int3
  * filter-bank outputs are not materialised; the backward is dsa_freqt_bwd (through W) followed by dsa_fbank_bwd. */
 int dsa_fbank_dct_fwd(const void* x, int64_t F, int32_t K, const void* H, int32_t C, const void* W, int32_t Mo, double floor,
                       double gamma, int32_t use_power, int32_t dtype, void* z, void* E, void* stream);
+/* The two stages above in ONE launch -- STFT (stft.py:148-152, power format, constant padding) and
+ * MelFilterBankAnalysis._forward (fbank.py:306-321, out_format "y") without the (B, N, 257) spectrum ever reaching
+ * memory: x:(B,T) -> y:(B, N, C) = glog(max(s @ H, floor)), s = |STFT|^2 + eps (use_power) or its square root.
+ * H enters as the per-lane `plan` (device, DSA_FBANK_PLAN_FLOATS float32) that dsa_fbank_scan_plan builds ON THE
+ * HOST from H:(257, C) float64 row-major: it exists when every bin feeds at most two ADJACENT channels, in
+ * ascending order along the bins (the triangular mel / auditory filters of fbank.py:232-291; C <= 126) -- otherwise
+ * DSA_ERR_UNSUPPORTED, and the two-call path above serves the matrix.  The fused kernel covers float32,
+ * fft_length 512, frame_length 400, even frame_period (else DSA_ERR_UNSUPPORTED).  Forward only: training runs the
+ * two differentiable stages. */
+#define DSA_FBANK_PLAN_FLOATS 2048
+int dsa_fbank_scan_plan(const double* H_host, int32_t K, int32_t C, float* plan_host);
+int dsa_stft_fbank_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft, const void* w,
+                       const void* twiddle, int32_t center, double eps, const void* plan, int32_t C, double floor,
+                       double gamma, int32_t use_power, int32_t dtype, void* y, void* stream);
 
 /* ------------------------------------------------------------------ f2  inverse path
  * RealValuedInverseFastFourierTransform ifftr.py:131-142, Unframe unframe.py:164-211, InverseShortTimeFourier-

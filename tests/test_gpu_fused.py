@@ -1,0 +1,148 @@
+"""GPU parity of the fused STFT -> mel filter bank (-> MFCC) kernel (SURVEY 8(f) row 1 in one launch:
+stft.py:237-241 + fbank.py:306-321 / mfcc.py:244-256; csrc/stft_pk.h, FBM variants).
+
+The checker is the float64 oracle (oracle.stft -> oracle.fbank / oracle.mfcc) on seeded inputs and on data.wav, and
+the library's own two-stage path (already pinned to the reference's goldens in test_gpu_parity.py).
+Tolerance (float32 in, float32 out): the filter-bank outputs are LOGS of sums of positive float32 power values, so
+|y - y64| <= 2e-5 absolute (a relative 2e-5 of the channel sum: the float32 STFT's own rounding, cf. the spectra
+tolerance in test_gpu_parity.py; the segmented scan adds 2e-7) -- the same bound the two-stage path meets."""
+import numpy as np
+import pytest
+import torch
+
+import diffsptk_amd as dsp
+from conftest import wav_float
+from diffsptk_amd import _lib, ops
+from diffsptk_amd.utils import tables
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def oracle_fbank(x, P, C, sr, *, center=True, use_power=False, floor=1e-5, gamma=0.0, f_min=0.0, f_max=None):
+    X = O.stft(np.asarray(x, np.float64), 400, P, 512, center=center, eps=1e-9)
+    H = np.asarray(tables.fbank_matrix(512, C, sr, f_min, f_max, "htk", None))
+    y, _ = O.fbank(X, H, floor, gamma, use_power)
+    return y
+
+
+@pytest.mark.parametrize("C,sr,P,use_power,gamma,center", [
+    (40, 16000, 80, True, 0.0, True),
+    (40, 16000, 80, False, 0.0, True),
+    (80, 16000, 160, True, 0.0, True),
+    (80, 22050, 128, False, -0.5, False),
+    (24, 16000, 100, True, 0.3, True),
+    (126, 48000, 80, False, 0.0, True),
+    (3, 8000, 80, True, 0.0, False),
+])
+def test_fused_fbank_matches_oracle_and_two_stage(C, sr, P, use_power, gamma, center):
+    g = torch.Generator().manual_seed(C + P)
+    # ragged frame counts (N % 4 = 1, 2, 3, 0), a batch with leading dimensions, levels 1e-3 .. 1e+3
+    for shape in ((3, 2, 1601), (5, 803), (2, 4000 + P), (1, 16000)):
+        x = torch.randn(*shape, generator=g) * (10.0 ** torch.empty(*shape[:-1], 1).uniform_(-3, 3, generator=g))
+        xd = x.to(DEV)
+        stft = dsp.STFT(400, P, 512, center=center, device=DEV)
+        fb = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=C, sample_rate=sr, use_power=use_power, gamma=gamma, device=DEV)
+        fused = dsp.fuse(stft, fb)
+        with torch.no_grad():
+            y = fused(xd)
+            assert fused.last_path == "fused" and _lib.last_kernel() == "stft512_fbank_fwd"
+            y2 = fb(stft(xd))
+        ref = oracle_fbank(x.numpy(), P, C, sr, center=center, use_power=use_power, gamma=gamma)
+        assert y.shape == ref.shape
+        if gamma == 0.0:
+            np.testing.assert_allclose(host(y), ref, rtol=0, atol=2e-5)
+            np.testing.assert_allclose(host(y), host(y2), rtol=0, atol=2e-5)
+        else:
+            np.testing.assert_allclose(host(y), ref, rtol=3e-5, atol=3e-5)
+            np.testing.assert_allclose(host(y), host(y2), rtol=3e-5, atol=3e-5)
+
+
+def test_fused_fbank_datawav_and_mfcc(golden):
+    """data.wav (the reference's test signal): filter bank and MFCC through the fused launch against the oracle."""
+    x = wav_float(golden("datawav")["pcm"], np.float64)
+    xd = torch.from_numpy(x).float().to(DEV)
+    stft = dsp.STFT(400, 80, 512, device=DEV)
+    fb = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, device=DEV)
+    mf = dsp.MFCC(fft_length=512, mfcc_order=12, n_channel=40, sample_rate=16000, lifter=22, device=DEV)
+    with torch.no_grad():
+        y = dsp.fuse(stft, fb)(xd)
+        c = dsp.fuse(stft, mf)(xd)
+    X = O.stft(xd.cpu().numpy().astype(np.float64), 400, 80, 512, eps=1e-9)   # the float32 samples the kernel saw
+    H = np.asarray(tables.fbank_matrix(512, 40, 16000, 0.0, None, "htk", None))
+    yref, _ = O.fbank(X, H, 1e-5, 0.0, False)
+    np.testing.assert_allclose(host(y), yref, rtol=0, atol=2e-5)
+    cref = O.mfcc(X, H, 12, 22, 1e-5, 0.0)[0]
+    np.testing.assert_allclose(host(c), cref, rtol=1e-5, atol=3e-4)
+    with torch.no_grad():
+        np.testing.assert_allclose(host(c), host(mf(stft(xd))), rtol=1e-5, atol=3e-4)
+
+
+def test_fused_fbank_bench_size_properties_and_determinism():
+    """BASELINE configs[4] shard size (1024 utterances x 1 s): equals the two-stage path; a gain g on the waveform adds
+    2 log g to every power-domain channel above the floor; two launches are bit-identical; every utterance of a batch
+    of copies gives the same rows (passes are dealt to different waves)."""
+    x = torch.randn(1024, 16000, generator=torch.Generator().manual_seed(5)).to(DEV)
+    stft = dsp.STFT(400, 80, 512, device=DEV)
+    fb = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, use_power=True, device=DEV)
+    fused = dsp.fuse(stft, fb)
+    with torch.no_grad():
+        y = fused(x)
+        assert fused.last_path == "fused" and y.shape == (1024, 200, 40)
+        assert torch.equal(y, fused(x))
+        y2 = fb(stft(x))
+        np.testing.assert_allclose(host(y), host(y2), rtol=0, atol=2e-5)
+        y4 = fused(2 * x)
+        np.testing.assert_allclose(host(y4 - y), np.full(y.shape, np.log(4.0)), rtol=0, atol=1e-4)
+        xc = x[:1].expand(64, -1).contiguous()
+        yc = fused(xc)
+        assert torch.equal(yc, yc[:1].expand_as(yc))
+
+
+def test_fused_falls_back_when_it_must():
+    """Everything the fused kernel does not cover runs the two stages -- same numbers, gradients available."""
+    x = torch.randn(2, 4000, generator=torch.Generator().manual_seed(6)).to(DEV)
+    fb = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, device=DEV)
+    for stft in (dsp.STFT(400, 80, 512, mode="reflect", device=DEV), dsp.STFT(320, 80, 512, device=DEV),
+                 dsp.STFT(400, 80, 512, out_format="magnitude", device=DEV), dsp.STFT(400, 80, 512, zmean=True, device=DEV)):
+        f = dsp.fuse(stft, fb)
+        with torch.no_grad():
+            assert torch.equal(f(x), fb(stft(x))) and f.last_path == "two-stage"
+    stft = dsp.STFT(400, 80, 512, device=DEV)
+    erb = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, erb_factor=1.0, device=DEV)
+    f = dsp.fuse(stft, erb)   # overlapping ERB filters: no scan plan
+    with torch.no_grad():
+        assert ops.fbank_scan_plan(erb.H) is None and torch.equal(f(x), erb(stft(x))) and f.last_path == "two-stage"
+    yE = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, out_format="yE", device=DEV)
+    f = dsp.fuse(stft, yE)
+    with torch.no_grad():
+        assert torch.equal(f(x), yE(stft(x))) and f.last_path == "two-stage"
+    f = dsp.fuse(stft, fb)
+    xg = x.clone().requires_grad_(True)
+    f(xg).sum().backward()   # gradient needed: the differentiable stages
+    assert f.last_path == "two-stage" and xg.grad is not None and torch.isfinite(xg.grad).all()
+    with pytest.raises(ValueError):
+        dsp.fuse(dsp.STFT(400, 80, 1024, device=DEV), fb)
+
+
+def test_fused_nonfinite_sample_stays_in_its_frames():
+    """A NaN sample makes every channel of the frames that contain it non-finite (as the reference's dense product does:
+    every bin of such a frame is NaN) and leaves every other frame untouched."""
+    x = torch.randn(1, 8000, generator=torch.Generator().manual_seed(7))
+    x[0, 4000] = float("nan")
+    xd = x.to(DEV)
+    stft = dsp.STFT(400, 80, 512, device=DEV)
+    fb = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, use_power=True, device=DEV)
+    with torch.no_grad():
+        y = dsp.fuse(stft, fb)(xd)
+        y2 = fb(stft(xd))
+    bad = torch.zeros(y.shape[:-1], dtype=torch.bool, device=DEV)
+    bad[0, 48:53] = True   # frames n with 80 n - 200 <= 4000 < 80 n + 200
+    for out in (y, y2):
+        assert torch.equal((~torch.isfinite(out)).all(-1), bad) and torch.equal((~torch.isfinite(out)).any(-1), bad)
+    np.testing.assert_allclose(host(y[~bad]), host(y2[~bad]), rtol=0, atol=2e-5)

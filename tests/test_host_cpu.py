@@ -31,7 +31,7 @@ def test_library_exports_every_header_symbol():
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert _lib.load().dsa_version() == 110
+    assert _lib.load().dsa_version() == 111
     assert _lib.load().dsa_num_frames(16000, 80) == 200
     assert _lib.load().dsa_num_frames(19200, 80) == 240
 
@@ -308,3 +308,36 @@ def test_learnable_fallback_operators_match_the_transforms():
     assert [n for n, _ in dsp.ISTFT(12, 4, 16, learnable=["basis"]).named_parameters()] == ["W"]
     assert [n for n, _ in dsp.MelFilterBankAnalysis(fft_length=32, n_channel=8, sample_rate=8000, learnable=True).named_parameters()] == ["H"]
     assert len(dsp.STFT(12, 4, 16).state_dict()) == 0
+
+
+def test_fbank_scan_plan_c_and_python_agree_and_the_lane_model_matches_the_matrix():
+    """The per-lane plan of the fused STFT -> filter-bank kernel (dsa_fbank_scan_plan, host code of the library) equals
+    its Python statement bit for bit, a lane-level numpy execution of the plan (DPP semantics of the scan network,
+    tools/proto_fbank_scan.py) reproduces s @ H, and matrices without the triangular structure are refused."""
+    import importlib.util
+
+    from diffsptk_amd.utils import tables
+
+    spec = importlib.util.spec_from_file_location(
+        "proto_fbank_scan", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "proto_fbank_scan.py"))
+    proto = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(proto)
+    lib = _lib.load()
+    rng = np.random.default_rng(1)
+    for C, sr, fmin, fmax in ((40, 16000, 0, None), (80, 16000, 0, None), (24, 16000, 64, 7600), (126, 48000, 0, None), (1, 8000, 0, None)):
+        H = np.ascontiguousarray(tables.fbank_matrix(512, C, sr, fmin, fmax, "htk", None), dtype=np.float64)
+        table = np.zeros(_lib.FBANK_PLAN_FLOATS, dtype=np.float32)
+        assert lib.dsa_fbank_scan_plan(H.ctypes.data, 257, C, table.ctypes.data) == 0
+        plan = tables.fbank_scan_plan(H)
+        assert np.array_equal(table.view(np.int32), tables.fbank_scan_table(plan).reshape(-1).view(np.int32))
+        P = (rng.standard_normal(257) ** 2 * 10.0 ** rng.uniform(-6, 6, 257)).astype(np.float32)
+        y, ref = proto.wave_epilogue(P, plan, C), P.astype(np.float64) @ H
+        assert np.max(np.abs(y - ref) / np.maximum(np.abs(ref), 1e-300)) < 2e-6
+    table = np.zeros(_lib.FBANK_PLAN_FLOATS, dtype=np.float32)
+    for bad in (np.abs(rng.standard_normal((257, 40))), np.asarray(tables.fbank_matrix(512, 40, 16000, 0, None, "htk", 1.0)),
+                np.asarray(tables.fbank_matrix(512, 40, 16000, 0, None, "htk", None))[:, ::-1]):
+        Hb = np.ascontiguousarray(bad, dtype=np.float64)
+        assert lib.dsa_fbank_scan_plan(Hb.ctypes.data, 257, 40, table.ctypes.data) == _lib.ERR_UNSUPPORTED
+        assert tables.fbank_scan_plan(Hb) is None
+    H127 = np.zeros((257, 127))
+    assert lib.dsa_fbank_scan_plan(H127.ctypes.data, 257, 127, table.ctypes.data) == _lib.ERR_UNSUPPORTED
