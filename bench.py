@@ -291,6 +291,33 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
                              "unit (unpacked: half of the packed fp64 peak quoted) -- DESIGN.md 3.3"},
         "timing": "back-to-back launches (gpu_time)",
     }
+    # ---- STFT -> mel filter bank, the fused launch against the two kernels ----
+    fb = dsp.MelFilterBankAnalysis(fft_length=NFFT, n_channel=40, sample_rate=16000, use_power=True, device=dev)
+    fused = dsp.fuse(stft, fb)
+    with torch.no_grad():
+        fused(x1024)
+        k_f = _lib.last_kernel()
+        t_fu = gpu_time(lambda: fused(x1024), n=30) * 1e-3
+        t_2 = gpu_time(lambda: fb(stft(x1024)), n=30) * 1e-3
+    pm = pmc_static("stft512_fbank_fwd")
+    ipf = pm["derived"]["valu_insts_per_frame"] if pm else None
+    fb_bytes = 320 + 4 * 40
+    res["f1_stft_fbank_batch1024"] = {
+        "workload": f"SURVEY 8(f) row 1: STFT -> MelFilterBankAnalysis (40 channels, power domain), {B} utterances x 1 s ({fr} frames), "
+                    "one launch (diffsptk_amd.fuse): the (B, N, 257) spectrogram never reaches memory",
+        "path": fused.last_path, "frames/s": fr / t_fu, "ms_fused": t_fu * 1e3, "ms_two_kernels": t_2 * 1e3,
+        "roofline": {"kernel": k_f, "bound": "valu_issue",
+                     "achieved": (ipf * fr / t_fu / 1e9) if ipf else None, "peak": VALU_ISSUE_PEAK_GIPS, "unit": "G wave-instr/s",
+                     "frac": (ipf * fr / t_fu / 1e9 / VALU_ISSUE_PEAK_GIPS) if ipf else None,
+                     "traffic": pmc_traffic("stft512_fbank_fwd", fr), "avg_launch_ms": t_fu * 1e3,
+                     "hbm": {"achieved": fb_bytes * fr / t_fu / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": fb_bytes * fr / t_fu / 1e9 / HBM_PEAK_GBS, "bytes_per_frame": fb_bytes},
+                     "pmc": pm["derived"] if pm else None, "pmc_source": pm["_source"] if pm else None,
+                     "note": "480 algorithmic bytes per frame (320 in, 160 out): 12 us at the HBM peak -- with the spectrogram's "
+                             "1028 B/frame round trip gone the stage is bound by vector issue and LDS cycles (FFT butterflies + "
+                             "the segmented scans of the filter bank), DESIGN.md 3.35"},
+        "timing": "back-to-back launches (gpu_time)",
+    }
     return res
 
 

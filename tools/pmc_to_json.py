@@ -8,17 +8,20 @@ import os
 import sys
 from collections import defaultdict
 
-KERNELS = {"mcep_mfma_fwd": "mcep_mfma_fwd_kernel_h", "stft512_fwd": "stft512_fwd_pk_kernel",
-           "mcep_mfma_bwd": "mcep_mfma_bwd_kernel_h", "stft512_bwd": "stft512_bwd_kernel"}
-WAVES_PER_SIMD = {"mcep_mfma_fwd": 2, "stft512_fwd": 4, "mcep_mfma_bwd": 1, "stft512_bwd": 4}
+# (name pattern, pattern that must NOT occur): the filter-bank variants of the packed STFT kernel are instantiations
+# <0, 400, true, 1|2> of the same template as the spectrum-out kernel <0, 400, true, 0>
+KERNELS = {"mcep_mfma_fwd": ("mcep_mfma_fwd_kernel_h", None), "stft512_fwd": ("stft512_fwd_pk_kernel<0, 400, true, 0>", None),
+           "stft512_fbank_fwd": ("stft512_fwd_pk_kernel<0, 400, true, 1>", None),
+           "mcep_mfma_bwd": ("mcep_mfma_bwd_kernel_h", None), "stft512_bwd": ("stft512_bwd_kernel", None)}
+WAVES_PER_SIMD = {"mcep_mfma_fwd": 2, "stft512_fwd": 4, "stft512_fbank_fwd": 4, "mcep_mfma_bwd": 1, "stft512_bwd": 4}
 FRAMES = 204800
 
 acc = defaultdict(lambda: [0.0, 0])
 dirs = sys.argv[1].split(",")   # several pass directories (forward command, backward command) may be merged
 for f in sorted(g for d in dirs for g in glob.glob(d + "/p*/p*_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
-        for key, pat in KERNELS.items():
-            if pat in row["Kernel_Name"]:
+        for key, (pat, _) in KERNELS.items():
+            if pat in row["Kernel_Name"].replace("(int)", "").replace("(bool)", ""):
                 a = acc[(key, row["Counter_Name"])]
                 a[0] += float(row["Counter_Value"])
                 a[1] += 1
