@@ -218,7 +218,34 @@ __global__ void window_gw_kernel(const T* __restrict__ gy, const T* __restrict__
 //   out_kind 0: fftr formats (DSA_FFTR_*), 1: spectrum formats (DSA_SPEC_*).
 // twiddle: (nfft, 2) = (cos, -sin)(2 pi m / nfft).
 // dynamic LDS: Lrow elements of T.
+// In-place radix-2 decimation-in-frequency FFT of n = 2^lg complex points held in LDS, run by the whole workgroup
+// (forward sign; tw = (cos, -sin)(2 pi m / n)).  Natural-order input, BIT-REVERSED output: X[k] sits at fft_brev(k, lg).
+// The generic row transforms use it whenever fft_length is a power of two (FFT = true): the direct sum they fall
+// back to costs n^2 / 2 multiply-adds per row -- 8.4 M at the 4096 points the MLSA filter's impulse responses use.
 template <typename T>
+__device__ __forceinline__ void lds_fft_pow2(T* re, T* im, int n, int lg, const T* __restrict__ tw)
+{
+    for (int s = lg - 1; s >= 0; --s) {
+        const int half = 1 << s;
+        const int tstep = n >> (s + 1);
+        for (int t = threadIdx.x; t < (n >> 1); t += blockDim.x) {
+            const int j = t & (half - 1);
+            const int i = ((t >> s) << (s + 1)) | j;
+            const T ar = re[i], ai = im[i], br = re[i + half], bi = im[i + half];
+            const T c = tw[2 * (j * tstep)], sn = tw[2 * (j * tstep) + 1];
+            re[i] = ar + br;
+            im[i] = ai + bi;
+            const T dr = ar - br, di = ai - bi;
+            re[i + half] = dr * c - di * sn;
+            im[i + half] = dr * sn + di * c;
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ int fft_brev(int k, int lg) { return (int)(__brev((unsigned)k) >> (32 - lg)); }
+
+// dynamic LDS: L elements of T (FFT: + 2 nfft).
+template <typename T, bool FFT = false>
 __global__ void row_dft_kernel(const T* __restrict__ x, long Tlen, long N, int L, int P, int left,
                                int mode, int zmean, const T* __restrict__ w, int nfft,
                                const T* __restrict__ twiddle, int out_kind, int fmt, T eps,
@@ -226,6 +253,8 @@ __global__ void row_dft_kernel(const T* __restrict__ x, long Tlen, long N, int L
 {
     extern __shared__ unsigned char smem_raw[];
     T* xs = reinterpret_cast<T*>(smem_raw);
+    T* fre = xs + L;        // FFT only
+    T* fim = fre + nfft;
     __shared__ T scratch[16];
     long f = blockIdx.x;
     long b = f / N, n = f - b * N;
@@ -249,16 +278,30 @@ __global__ void row_dft_kernel(const T* __restrict__ x, long Tlen, long N, int L
     const bool inverse_adj = out_kind == 1 && fmt == DSA_SPEC_COMPLEX_INV;   // complex output times c_k / nfft
     const bool complex_out = (out_kind == 0 && fmt == DSA_FFTR_COMPLEX) ||
                              (out_kind == 1 && fmt == DSA_SPEC_COMPLEX) || inverse_adj;
+    const int lg = 31 - __clz(nfft);
+    if (FFT) {
+        for (int l = threadIdx.x; l < nfft; l += blockDim.x) {
+            fre[l] = l < Lc ? xs[l] : T(0);
+            fim[l] = T(0);
+        }
+        __syncthreads();
+        lds_fft_pow2(fre, fim, nfft, lg, twiddle);
+    }
     T smax = 0;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         T re = 0, im = 0;
-        int idx = 0;
-        for (int l = 0; l < Lc; ++l) {
-            T c = twiddle[2 * idx], s = twiddle[2 * idx + 1];
-            re += xs[l] * c;
-            im += xs[l] * s;
-            idx += k;
-            if (idx >= nfft) idx -= nfft;
+        if (FFT) {
+            const int q = fft_brev(k, lg);
+            re = fre[q], im = fim[q];
+        } else {
+            int idx = 0;
+            for (int l = 0; l < Lc; ++l) {
+                T c = twiddle[2 * idx], s = twiddle[2 * idx + 1];
+                re += xs[l] * c;
+                im += xs[l] * s;
+                idx += k;
+                if (idx >= nfft) idx -= nfft;
+            }
         }
         if (complex_out) {
             const T sc = inverse_adj ? ((k == 0 || k == K - 1) ? T(1) : T(2)) / T(nfft) : T(1);
@@ -304,8 +347,8 @@ __global__ void row_dft_kernel(const T* __restrict__ x, long Tlen, long N, int L
 // window multiply and of zmean.  Output: gframe (F, L) = cotangent of the framed samples (the
 // overlap-add into the waveform is done by frame_bwd); gwpart (F, L) = per-frame contribution
 // to the window gradient (NULL unless the window is learnable).
-// dynamic LDS: (L + 3K) elements of T.
-template <typename T>
+// dynamic LDS: (L + 3K) elements of T (FFT: + 2 nfft).
+template <typename T, bool FFT = false>
 __global__ void row_dft_bwd_kernel(const T* __restrict__ x, long Tlen, long N, int L, int P, int left,
                                    int mode, int zmean, const T* __restrict__ w, int nfft,
                                    const T* __restrict__ twiddle, int out_kind, int fmt, T eps,
@@ -319,6 +362,9 @@ __global__ void row_dft_bwd_kernel(const T* __restrict__ x, long Tlen, long N, i
     const int Lc = L < nfft ? L : nfft;
     T* Cre = xc + L;
     T* Cim = Cre + K;
+    T* fre = Cim + 2 * K;   // FFT only (behind the gs array)
+    T* fim = fre + nfft;
+    const int lg = 31 - __clz(nfft);
     long f = blockIdx.x;
     long b = f / N, n = f - b * N;
     const T* xb = x + b * Tlen;
@@ -336,16 +382,29 @@ __global__ void row_dft_bwd_kernel(const T* __restrict__ x, long Tlen, long N, i
     const bool inverse_cot = out_kind == 1 && fmt == DSA_SPEC_COMPLEX_INV;
     const bool complex_out = (out_kind == 0 && fmt == DSA_FFTR_COMPLEX) ||
                              (out_kind == 1 && fmt == DSA_SPEC_COMPLEX) || inverse_cot;
+    if (FFT) {
+        for (int l = threadIdx.x; l < nfft; l += blockDim.x) {
+            fre[l] = l < Lc ? (w ? xc[l] * w[l] : xc[l]) : T(0);
+            fim[l] = T(0);
+        }
+        __syncthreads();
+        lds_fft_pow2(fre, fim, nfft, lg, twiddle);
+    }
     T smax = 0;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         T re = 0, im = 0;
-        int idx = 0;
-        for (int l = 0; l < Lc; ++l) {
-            T xv = w ? xc[l] * w[l] : xc[l];
-            re += xv * twiddle[2 * idx];
-            im += xv * twiddle[2 * idx + 1];
-            idx += k;
-            if (idx >= nfft) idx -= nfft;
+        if (FFT) {
+            const int q = fft_brev(k, lg);
+            re = fre[q], im = fim[q];
+        } else {
+            int idx = 0;
+            for (int l = 0; l < Lc; ++l) {
+                T xv = w ? xc[l] * w[l] : xc[l];
+                re += xv * twiddle[2 * idx];
+                im += xv * twiddle[2 * idx + 1];
+                idx += k;
+                if (idx >= nfft) idx -= nfft;
+            }
         }
         T cr, ci;
         if (complex_out) {
@@ -417,10 +476,21 @@ __global__ void row_dft_bwd_kernel(const T* __restrict__ x, long Tlen, long N, i
         }
     }
     __syncthreads();
+    if (FFT) {
+        // sum_k Re(C[k] e^{+i theta k l}) = Re FFT(conj(C), zero-extended to nfft points)[l]
+        for (int k = threadIdx.x; k < nfft; k += blockDim.x) {
+            fre[k] = k < K ? Cre[k] : T(0);
+            fim[k] = k < K ? -Cim[k] : T(0);
+        }
+        __syncthreads();
+        lds_fft_pow2(fre, fim, nfft, lg, twiddle);
+    }
     T gsum = 0;
     for (int l = threadIdx.x; l < L; l += blockDim.x) {
         T g = 0;
-        if (l < Lc) {
+        if (FFT) {
+            if (l < Lc) g = fre[fft_brev(l, lg)];
+        } else if (l < Lc) {
             int idx = 0;
             for (int k = 0; k < K; ++k) {
                 g += Cre[k] * twiddle[2 * idx] + Cim[k] * twiddle[2 * idx + 1];
@@ -992,8 +1062,24 @@ static int launch_row_dft(const void* x, int64_t B, int64_t Tlen, int64_t N, int
     if (F == 0) return DSA_OK;
     T floor_lin = use_floor ? (T)pow(10.0, floor_db / 10.0) : T(0);
     size_t lds = sizeof(T) * (size_t)L;
-    if (lds > 60 * 1024) return fail(DSA_ERR_UNSUPPORTED, "row_dft: frame too long for LDS%s");
     int threads = nfft / 2 + 1 >= 192 ? 256 : (nfft / 2 + 1 >= 96 ? 128 : 64);
+    // power-of-two lengths: radix-2 FFT in LDS (DSA_ROWDFT_DIRECT=1 keeps the direct sum, for A/B runs and tests)
+    static const bool direct_only = [] {
+        const char* e = getenv("DSA_ROWDFT_DIRECT");
+        return e && atoi(e) != 0;
+    }();
+    const size_t lds_fft = lds + sizeof(T) * 2 * (size_t)nfft;
+    if (!direct_only && nfft >= 32 && (nfft & (nfft - 1)) == 0 && lds_fft <= 150 * 1024) {
+        static std::atomic<uint64_t> lds_set{0};
+        if (lds_fft > 48 * 1024 &&
+            !ensure_dynamic_lds(reinterpret_cast<const void*>(&row_dft_kernel<T, true>), 150 * 1024, lds_set))
+            return fail(DSA_ERR_LAUNCH, "row_fft: cannot raise the dynamic LDS limit%s");
+        hipLaunchKernelGGL((row_dft_kernel<T, true>), dim3((unsigned)F), dim3(nfft >= 512 ? 256 : threads), lds_fft, st,
+                           (const T*)x, (long)Tlen, (long)N, L, P, left, mode, zmean, (const T*)w, nfft, (const T*)twiddle,
+                           out_kind, fmt, (T)eps, use_floor, floor_lin, (T*)y);
+        return check_launch("row_fft_generic");
+    }
+    if (lds > 60 * 1024) return fail(DSA_ERR_UNSUPPORTED, "row_dft: frame too long for LDS%s");
     hipLaunchKernelGGL((row_dft_kernel<T>), dim3((unsigned)F), dim3(threads), lds, st, (const T*)x,
                        (long)Tlen, (long)N, L, P, left, mode, zmean, (const T*)w, nfft,
                        (const T*)twiddle, out_kind, fmt, (T)eps, use_floor, floor_lin, (T*)y);
@@ -1809,6 +1895,21 @@ static int launch_row_dft_bwd(const void* x, int64_t B, int64_t Tlen, int64_t N,
     T floor_lin = use_floor ? (T)pow(10.0, floor_db / 10.0) : T(0);
     const int K = nfft / 2 + 1;
     size_t lds = sizeof(T) * ((size_t)L + 3 * (size_t)K);
+    static const bool direct_only = [] {
+        const char* e = getenv("DSA_ROWDFT_DIRECT");
+        return e && atoi(e) != 0;
+    }();
+    const size_t lds_fft = lds + sizeof(T) * 2 * (size_t)nfft;
+    if (!direct_only && nfft >= 32 && (nfft & (nfft - 1)) == 0 && lds_fft <= 150 * 1024) {
+        static std::atomic<uint64_t> lds_set{0};
+        if (lds_fft > 48 * 1024 &&
+            !ensure_dynamic_lds(reinterpret_cast<const void*>(&row_dft_bwd_kernel<T, true>), 150 * 1024, lds_set))
+            return fail(DSA_ERR_LAUNCH, "row_fft_bwd: cannot raise the dynamic LDS limit%s");
+        hipLaunchKernelGGL((row_dft_bwd_kernel<T, true>), dim3((unsigned)F), dim3(256), lds_fft, st, (const T*)x, (long)Tlen,
+                           (long)N, L, P, left, mode, zmean, (const T*)w, nfft, (const T*)twiddle, out_kind, fmt,
+                           (T)eps, use_floor, floor_lin, (const T*)gy, (T*)gframe, (T*)gwpart);
+        return check_launch("row_fft_bwd_generic");
+    }
     if (lds > 60 * 1024) return fail(DSA_ERR_UNSUPPORTED, "row_dft_bwd: frame too long for LDS%s");
     hipLaunchKernelGGL((row_dft_bwd_kernel<T>), dim3((unsigned)F), dim3(256), lds, st, (const T*)x, (long)Tlen,
                        (long)N, L, P, left, mode, zmean, (const T*)w, nfft, (const T*)twiddle, out_kind, fmt,

@@ -213,3 +213,49 @@ def test_learnable_options_match_the_kernels_and_train():
     mf0 = dsp.MFCC(fft_length=512, mfcc_order=12, n_channel=40, sample_rate=16000, device=DEV)
     np.testing.assert_allclose(host(mf(X)), host(mf0(X)), rtol=1e-4, atol=1e-4)
     assert [n for n, _ in mf.named_parameters()] == ["H"]
+
+
+@pytest.mark.parametrize("nfft,L,P", [(32, 32, 8), (64, 50, 16), (256, 200, 64), (1024, 1024, 256), (4096, 2000, 2000), (4096, 4096, 1024)])
+def test_generic_rows_power_of_two_fft_matches_oracle_and_autograd(nfft, L, P):
+    """The generic row transforms (fftr / spec / STFT of any size, their backward and the inverse path) run a radix-2 FFT
+    in LDS for power-of-two lengths instead of the direct sum: forward against the float64 oracle, gradient against
+    float64 autograd of the same formula; float64 and float32, zero-padded and cropped rows, zmean + reflect padding."""
+
+    g = torch.Generator().manual_seed(nfft + L)
+    x = torch.randn(3, 4 * P + L, generator=g, dtype=torch.float64)
+    for dt, rt in ((torch.float64, 1e-9), (torch.float32, 2e-4)):
+        xd = x.to(DEV, dt).requires_grad_(True)
+        for fmt in ("complex", "power"):
+            stft = dsp.STFT(L, P, nfft, out_format=fmt, zmean=(fmt == "power"), mode="reflect" if fmt == "power" else "constant",
+                            eps=0.0, dtype=dt, device=DEV)
+            y = stft(xd)
+            if not (dt == torch.float32 and nfft == 512):
+                assert _lib.last_kernel() == "row_fft_generic"
+            ref = O.stft(x.numpy(), L, P, nfft, out_format=fmt, zmean=(fmt == "power"), mode="reflect" if fmt == "power" else "constant", eps=0.0)
+            yh = y.detach().cpu().numpy()
+            scale = np.abs(ref).max()
+            assert np.abs(yh - ref).max() <= rt * scale, (nfft, fmt, dt, np.abs(yh - ref).max() / scale)
+            # gradient of a fixed random functional against float64 autograd of the same formula
+            wgt = torch.randn(y.shape, generator=g, dtype=torch.float64)
+            if fmt == "complex":
+                wgt = torch.complex(wgt, torch.randn(y.shape, generator=g, dtype=torch.float64))
+                loss = (y * wgt.to(DEV).to(y.dtype)).real.sum()
+            else:
+                loss = (y * wgt.to(DEV, dt)).sum()
+            (gx,) = torch.autograd.grad(loss, xd)
+            xr = x.clone().requires_grad_(True)
+            fr = TPframes(xr, L, P, fmt == "power", "reflect" if fmt == "power" else "constant")
+            win = stft.window.detach().cpu().double()
+            Y = torch.fft.rfft(fr * win, n=nfft)
+            lr = (Y * wgt).real.sum() if fmt == "complex" else ((Y.abs() ** 2) * wgt).sum()
+            (gr,) = torch.autograd.grad(lr, xr)
+            gs = gr.abs().max().item()
+            assert (gx.detach().cpu().double() - gr).abs().max().item() <= (1e-9 if dt == torch.float64 else 3e-4) * gs
+
+
+def TPframes(x, L, P, zmean, mode):
+    """Framing of frame.py:130-138 with stock torch ops (test helper)."""
+    left, right = L // 2, (L - 1) // 2
+    xp = torch.nn.functional.pad(x.unsqueeze(0), (left, right), mode=mode).squeeze(0)
+    fr = xp.unfold(-1, L, P)
+    return fr - fr.mean(-1, keepdim=True) if zmean else fr

@@ -8,7 +8,8 @@ Tolerances (stated once, used everywhere below):
   float32 spectra: |y - y64| <= 1e-4 |y64| + 2e-6 max_k y64[frame]   (bins far below the frame
             maximum differ between ANY two float32 FFTs -- the reference's own float32 and
             float64 outputs disagree by 1.9e-3 elementwise on data.wav).
-  float32 mel-cepstra: |mc - mc64| <= 1e-4 |mc64| + 2e-5        (reference f32 vs f64: 6e-6 abs).
+  float32 mel-cepstra: |mc - mc64| <= 1e-4 |mc64| + 1e-5        (reference f32 vs f64: 6e-6 abs; this kernel on
+            data.wav: 6e-6; tests/test_gpu_configs.py holds the bench-size batches to 5e-6).
   float32 LPC: |a - a64| <= 1e-4 |a64| + 1e-4   (float64 recursion inside; the reference's own
             float32 result is 8.8e-4 away from its float64 result).
 """
@@ -220,7 +221,7 @@ def test_stft_datawav_golden(golden, name, dt):
     g = golden("datawav")
     x = dev(wav_float(g["pcm"], np.float64), dt)
     y = dsp.STFT(400, 80, 512, dtype=dt, device=DEV)(x)
-    assert _lib.last_kernel() == ("stft512_fwd" if dt == torch.float32 else "row_dft_generic")
+    assert _lib.last_kernel() == ("stft512_fwd" if dt == torch.float32 else "row_fft_generic")
     assert y.shape == (240, 257)
     if dt == torch.float64:
         close(host(y), g["stft_power_f64"], **F64)
@@ -265,7 +266,7 @@ def test_stft_tuned_vs_generic_vs_oracle_options():
     m = dsp.STFT(400, 80, 512, device=DEV)
     yg = ops.StftFn.apply(xd, m.window, m.twiddle, 400, 80, 512, True, False, "constant", 1e-9, None, 3,
                           _lib.ALGO_GENERIC)
-    assert _lib.last_kernel() == "row_dft_generic"
+    assert _lib.last_kernel() == "row_fft_generic"   # power-of-two length: radix-2 FFT in LDS
     spec_close(host(yg), O.stft(x64, 400, 80, 512))
 
 
@@ -429,13 +430,13 @@ def test_mcep_datawav_golden_and_trace(golden, name, dt):
     if dt == torch.float64:
         close(mc, g["mcep_f64"], **F64)
     else:
-        close(mc, g["mcep_f64"], 1e-4, 2e-5)
-        close(mc, g["mcep_f32"], 1e-4, 2e-5)
+        close(mc, g["mcep_f64"], 1e-4, 1e-5)
+        close(mc, g["mcep_f32"], 1e-4, 1e-5)
     # Newton trace: mc after k = 0..10 iterations for 5 frames
     Xt = X[torch.from_numpy(g["trace_frames"]).to(DEV)]
     for k in (0, 1, 2, 5, 10):
         mk = host(F.mcep(Xt, 24, 0.42, k))
-        tol = F64 if dt == torch.float64 else dict(rtol=1e-4, atol=2e-5)
+        tol = F64 if dt == torch.float64 else dict(rtol=1e-4, atol=1e-5)
         close(mk, g["mcep_trace_f64"][k], **tol)
 
 
@@ -446,7 +447,7 @@ def test_stft_mcep_end_to_end_golden_with_gradient(golden, name, dt):
     stft = dsp.STFT(400, 80, 512, dtype=dt, device=DEV)
     mcep = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, dtype=dt, device=DEV)
     mc = mcep(stft(x))
-    tol = F64 if dt == torch.float64 else dict(rtol=1e-4, atol=2e-5)
+    tol = F64 if dt == torch.float64 else dict(rtol=1e-4, atol=1e-5)
     close(host(mc), g["mcep_f64"], **tol)
     mc.mean().backward()
     ref = g["grad_mcep_mean_f64"]
@@ -483,7 +484,7 @@ def test_mcep_tuned_dynamic_range(golden):
         assert _lib.last_kernel().startswith("mcep_mfma_fwd")
         ref = host(m64(X.to(DEV).double()))
         assert np.isfinite(y).all(), (db, level)
-        close(y, ref, 1e-4, 2e-5)
+        close(y, ref, 1e-4, 1e-5)
 
 
 def test_mcep_extreme_alpha_keeps_generic_kernel(golden):
@@ -512,8 +513,8 @@ def test_mcep_tuned_vs_generic_and_history(golden):
         assert _lib.last_kernel().startswith("mcep_mfma_fwd" if name == "tuned" else "mcep_generic_fwd")
         (mc * torch.linspace(-1, 1, 25, device=DEV)).sum().backward()
         outs[name] = (host(mc), host(Xg.grad))
-    close(outs["tuned"][0], g["mcep_f64"], 1e-4, 2e-5)
-    close(outs["tuned"][0], outs["generic"][0], 1e-4, 2e-5)
+    close(outs["tuned"][0], g["mcep_f64"], 1e-4, 1e-5)
+    close(outs["tuned"][0], outs["generic"][0], 1e-4, 1e-5)
     ref = g["grad_mcep_wsum_wrt_X_f64"]
     for name in outs:
         err = np.abs(outs[name][1] - ref) / np.abs(ref).max(-1, keepdims=True)
@@ -524,7 +525,7 @@ def test_mcep_tuned_vs_generic_and_history(golden):
     # ragged tile: 37 frames (not a multiple of 64) through the tuned kernel
     X37 = X[0, :37].clone().requires_grad_(True)
     mc37 = ops.McepFn.apply(X37, m.G, m.D, m.E, m.alpha_vector, 512, 24, 10, _lib.ALGO_TUNED)
-    close(host(mc37), g["mcep_f64"][0, :37], 1e-4, 2e-5)
+    close(host(mc37), g["mcep_f64"][0, :37], 1e-4, 1e-5)
     (mc37 * torch.linspace(-1, 1, 25, device=DEV)).sum().backward()
     err37 = np.abs(host(X37.grad) - ref[0, :37]) / np.abs(ref[0, :37]).max(-1, keepdims=True)
     assert err37.max() < 2e-3
@@ -565,7 +566,7 @@ def test_mcep_full_size_properties():
     assert torch.equal(mc_p, mc[idx.to(DEV)])  # frames are independent: bitwise
     sel = slice(0, 256, 37)
     ref = O.mcep(O.stft(x[sel].double().numpy(), 400, 80, 512), 24, 0.42, 10)
-    close(host(mc[sel]), ref, 1e-4, 2e-5)
+    close(host(mc[sel]), ref, 1e-4, 1e-5)
     mc11 = F.mcep(X[:8], 24, 0.42, 11)  # one more step moves a converged solution by < 1e-4
     assert float((mc11 - mc[:8]).abs().max()) < 1e-4
 
