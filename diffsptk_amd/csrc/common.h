@@ -58,7 +58,8 @@ inline bool ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64
 //  3: first and last column halved;  needs float32, C <= 48, C < K <= 320)
 int fbank_mfma_launch_ex(const void* x, int64_t F, int K, const void* H, int C, int ldh, double floor, double gamma,
                          int use_power, int post_mode, double post_scale, void* y, void* E, hipStream_t st, const char* name,
-                         const void* W2 = nullptr, int Mo = 0, void* z = nullptr);   // optional second product z = y W2
+                         const void* W2 = nullptr, int Mo = 0, void* z = nullptr,   // optional second product z = y W2
+                         int ldy = 0);   // row stride of y when it is a column slice of a wider matrix (0: C); post_mode 4: plain product
 
 #define DSA_REQUIRE(cond, msg)                                              \
     do {                                                                    \

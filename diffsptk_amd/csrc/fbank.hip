@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const flo
                                                                       float* __restrict__ E, int nsteps, int cap,
                                                                       int tile_floats, int vec4, int ldh, int post_mode,
                                                                       float post_scale, const float* __restrict__ W2, int Mo,
-                                                                      float* __restrict__ z)
+                                                                      float* __restrict__ z, int ldy)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
     float* himg = reinterpret_cast<float*>(fb_smem);                         // [3][cap][64]
@@ -474,7 +474,8 @@ __global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const flo
                 const int fr = 4 * kq + r;
                 if (ch < C) {
                     if (post_mode) {
-                        ost[fr * C + ch] = d[r] * ((ch == 0 || ((post_mode & 2) && ch == C - 1)) ? 0.5f * post_scale : post_scale);
+                        const bool halve = !(post_mode & 4) && (ch == 0 || ((post_mode & 2) && ch == C - 1));   // 4: a plain product
+                        ost[fr * C + ch] = d[r] * (halve ? 0.5f * post_scale : post_scale);
                     } else {
                         const float v = d[r] < floor ? floor : d[r];                // fbank.py:317 (NaN stays NaN)
                         ost[fr * C + ch] = glog_fwd(v, gamma);
@@ -504,7 +505,12 @@ __global__ __launch_bounds__(kFmWaves * 64) void fbank_mfma_fwd_kernel(const flo
             const int rows = (int)(F - f0 < kFmRows ? F - f0 : kFmRows);
             const int n = rows * C;
             float* dst = y + f0 * C;
-            if (yvec4) {
+            if (ldy != C) {   // a column slice of a wider output (row stride ldy): row by row
+                for (int q = lane; q < n; q += 64) {
+                    const int r = q / C;
+                    y[(f0 + r) * (long)ldy + (q - r * C)] = ost[q];
+                }
+            } else if (yvec4) {
                 for (int q = lane; q < (n >> 2); q += 64) reinterpret_cast<fm_f4*>(dst)[q] = reinterpret_cast<const fm_f4*>(ost)[q];
                 for (int q = (n & ~3) + lane; q < n; q += 64) dst[q] = ost[q];
             } else {
@@ -526,7 +532,7 @@ static size_t fbank_mfma_lds_bytes(int K, bool second_product)
 
 int fbank_mfma_launch_ex(const void* x, int64_t F, int K, const void* H, int C, int ldh, double floor, double gamma,
                          int use_power, int post_mode, double post_scale, void* y, void* E, hipStream_t st, const char* name,
-                         const void* W2, int Mo, void* z)
+                         const void* W2, int Mo, void* z, int ldy)
 {
     const int nsteps = 16 * (K / 64) + ((K % 64) < 16 ? (K % 64) : 16);
     const int tile_floats = (kFmRows * K + 3) & ~3;
@@ -546,7 +552,7 @@ int fbank_mfma_launch_ex(const void* x, int64_t F, int K, const void* H, int C, 
         hipLaunchKernelGGL(fbank_mfma_fwd_kernel<NQ>, dim3((unsigned)blocks), dim3(kFmWaves * 64), lds, st,            \
                            (const float*)x, (long)F, K, (const float*)H, C, (float)floor, (float)gamma, use_power,     \
                            (float*)y, (float*)E, nsteps, cap, tile_floats, vec4, ldh, post_mode, (float)post_scale,    \
-                           (const float*)W2, Mo, (float*)z);                                                          \
+                           (const float*)W2, Mo, (float*)z, ldy > 0 ? ldy : C);                                       \
     } while (0)
     if (nq <= 5) DSA_FM_LAUNCH(5);
     else if (nq <= 9) DSA_FM_LAUNCH(9);

@@ -352,6 +352,21 @@ DSA_EXPORT int dsa_freqt_fwd(const void* c, int64_t F, int32_t L1, const void* A
     DSA_REQUIRE(L1 > 0 && L2 > 0 && F >= 0, "freqt: sizes must be positive");
     if (F == 0) return DSA_OK;
     hipStream_t st = (hipStream_t)stream;
+    // long float32 rows (the 257-bin spectra of mgcep.py:199-209 against 25 .. 49-column matrices): the float32 matrix-core
+    // row product of fbank.hip, 48 output columns per launch (exact float32 products, float32 accumulation, as here)
+    static const bool no_mfma = [] {
+        const char* e = getenv("DSA_FREQT_GENERIC");
+        return e && atoi(e) != 0;
+    }();
+    if (dtype == DSA_F32 && L1 > 48 && L1 <= 320 && L2 <= 192 && F >= 1024 && !no_mfma) {
+        for (int c0 = 0; c0 < L2; c0 += 48) {
+            const int cs = L2 - c0 < 48 ? L2 - c0 : 48;
+            const int rc = fbank_mfma_launch_ex(c, F, L1, (const float*)A + c0, cs, L2, 1.0, 0.0, 1, 4, 1.0, (float*)out + c0, nullptr,
+                                                st, "freqt_mfma_fwd", nullptr, 0, nullptr, L2);
+            if (rc != DSA_OK) return rc;
+        }
+        return DSA_OK;
+    }
     if ((dtype == DSA_F32 && matmul_rows_lds_launch<float, false>(c, F, L1, A, L1, L2, L2, out, st)) ||
         (dtype == DSA_F64 && matmul_rows_lds_launch<double, false>(c, F, L1, A, L1, L2, L2, out, st)))
         return check_launch("freqt_lds_fwd");

@@ -9,6 +9,8 @@
 // assembled by the host layer from the library's row-product kernel (modules/mgcep.py).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace dsa {
 
 constexpr int kThMax = 64;
@@ -44,6 +46,69 @@ __device__ void th_gauss_jordan(T* Aug, int n, int W, int nrhs, int* rowof, int 
     }
 }
 
+// Register version for n <= NMAX (NMAX = 24 or 32: cep_order 24 is the usual size): lane i holds row i of the system and
+// its right-hand side in registers, the pivot row reaches the other lanes through v_readlane (the pivot lane is uniform),
+// everything is statically indexed (both loops unrolled).  Same pivot rule as the LDS version below, which remains for
+// larger systems: that one spends ~80 cycles per element on dependent LDS round trips (0.53 ms per 51 200 frames of 24 x 24,
+// 43 % of a mel-generalized analysis), this one ~6 k cycles per frame.
+// Returns in (col, sol): lane i < n was the pivot row of column `col`, and x[col] = sol.
+template <typename T>
+__device__ __forceinline__ T th_readlane(T v, int src)
+{
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+    } else {
+        const long long b = __builtin_bit_cast(long long, v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
+        return __builtin_bit_cast(T, (long long)(((unsigned long long)hi << 32) | lo));
+    }
+}
+template <typename T, int NMAX>
+__device__ __forceinline__ void th_solve_reg(const T* ps, const T* qs, T rhs, int n, int lane, int& col, T& sol)
+{
+    T row[NMAX];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        const int d = lane > j ? lane - j : j - lane;
+        row[j] = (lane < n && j < n) ? ps[d] + qs[lane + j] : T(0);
+    }
+    if (lane >= n) rhs = T(0);
+    bool used = lane >= n;
+    T piv = T(1);
+    col = 0;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+        if (k < n) {   // uniform
+            // pivot = the unused row with the largest |a_ik|: one unsigned key per lane (magnitude bits with the lane in the
+            // low 6 bits: ties and near-ties go to the lowest lane), maximum over the wave by DPP shifts -- cross-lane
+            // shuffles through the LDS crossbar cost 12 dependent round trips per step here
+            const float magf = (float)(row[k] < T(0) ? -row[k] : row[k]);
+            unsigned key = used ? 0u : ((__builtin_bit_cast(unsigned, magf) & 0xffffffc0u) | (unsigned)(63 - lane));
+#define DSA_TH_MAX(CTRL, RM)                                                                                            \
+    {                                                                                                                  \
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, CTRL, RM, 0xf, false);                   \
+        key = o > key ? o : key;                                                                                       \
+    }
+            DSA_TH_MAX(0x111, 0xf) DSA_TH_MAX(0x112, 0xf) DSA_TH_MAX(0x114, 0xf) DSA_TH_MAX(0x118, 0xf)   // row_shr:1, 2, 4, 8
+            DSA_TH_MAX(0x142, 0xa) DSA_TH_MAX(0x143, 0xc)                                                 // row_bcast:15, :31
+#undef DSA_TH_MAX
+            const int p = 63 - (int)(__builtin_amdgcn_readlane((int)key, 63) & 63);
+            const T pk = th_readlane(row[k], p);
+            const T fac = (lane != p) ? row[k] / pk : T(0);
+            if (lane == p) {
+                used = true;
+                col = k;
+                piv = row[k];
+            }
+#pragma unroll
+            for (int j = k + 1; j < NMAX; ++j) row[j] -= fac * th_readlane(row[j], p);
+            rhs -= fac * th_readlane(rhs, p);
+        }
+    }
+    sol = rhs / piv;
+}
+
 template <typename T>
 __device__ void th_build(T* Aug, const T* p, const T* q, int n, int W, int lane)
 {
@@ -54,7 +119,7 @@ __device__ void th_build(T* Aug, const T* p, const T* q, int n, int W, int lane)
         }
 }
 
-template <typename T>
+template <typename T, int NMAX = 0>   // NMAX > 0: register version (n <= NMAX)
 __global__ __launch_bounds__(64) void th_solve_fwd_kernel(const T* __restrict__ p, const T* __restrict__ q,
                                                           const T* __restrict__ r, long F, int n, T* __restrict__ g)
 {
@@ -65,6 +130,19 @@ __global__ __launch_bounds__(64) void th_solve_fwd_kernel(const T* __restrict__ 
     const int lane = threadIdx.x;
     for (long f = blockIdx.x; f < F; f += gridDim.x) {
         __builtin_amdgcn_wave_barrier();
+        if (NMAX > 0) {
+            T* ps = Aug;          // [n]
+            T* qs = Aug + n;      // [2n - 1]
+            if (lane < n) ps[lane] = p[f * n + lane];
+            for (int i = lane; i < 2 * n - 1; i += 64) qs[i] = q[f * (2 * n - 1) + i];
+            const T rhs = lane < n ? r[f * n + lane] : T(0);
+            __builtin_amdgcn_wave_barrier();
+            int col;
+            T sol;
+            th_solve_reg<T, (NMAX > 0 ? NMAX : 1)>(ps, qs, rhs, n, lane, col, sol);
+            if (lane < n) g[f * n + col] = sol;
+            continue;
+        }
         th_build(Aug, p + f * n, q + f * (2 * n - 1), n, W, lane);
         if (lane < n) Aug[lane * W + n] = r[f * n + lane];
         __builtin_amdgcn_wave_barrier();
@@ -76,7 +154,7 @@ __global__ __launch_bounds__(64) void th_solve_fwd_kernel(const T* __restrict__ 
     }
 }
 
-template <typename T>
+template <typename T, int NMAX = 0>
 __global__ __launch_bounds__(64) void th_solve_bwd_kernel(const T* __restrict__ gg, const T* __restrict__ p,
                                                           const T* __restrict__ q, const T* __restrict__ g, long F, int n,
                                                           T* __restrict__ gp, T* __restrict__ gq, T* __restrict__ gr)
@@ -90,18 +168,37 @@ __global__ __launch_bounds__(64) void th_solve_bwd_kernel(const T* __restrict__ 
     const int lane = threadIdx.x;
     for (long f = blockIdx.x; f < F; f += gridDim.x) {
         __builtin_amdgcn_wave_barrier();
-        th_build(Aug, p + f * n, q + f * (2 * n - 1), n, W, lane);
-        if (lane < n) {
-            Aug[lane * W + n] = gg[f * n + lane];   // A is symmetric: u = A^{-T} gbar = A^{-1} gbar
-            gs[lane] = g[f * n + lane];
-        }
-        __builtin_amdgcn_wave_barrier();
-        th_gauss_jordan(Aug, n, W, 1, rowof, lane);
-        if (lane < n) {
-            const int row = rowof[lane];
-            const T ul = Aug[row * W + n] / Aug[row * W + lane];
-            u[lane] = ul;
-            gr[f * n + lane] = ul;
+        if (NMAX > 0) {
+            T* ps = Aug;
+            T* qs = Aug + n;
+            if (lane < n) {
+                ps[lane] = p[f * n + lane];
+                gs[lane] = g[f * n + lane];
+            }
+            for (int i = lane; i < 2 * n - 1; i += 64) qs[i] = q[f * (2 * n - 1) + i];
+            const T rhs = lane < n ? gg[f * n + lane] : T(0);   // A is symmetric: u = A^{-T} gbar = A^{-1} gbar
+            __builtin_amdgcn_wave_barrier();
+            int col;
+            T sol;
+            th_solve_reg<T, (NMAX > 0 ? NMAX : 1)>(ps, qs, rhs, n, lane, col, sol);
+            if (lane < n) {
+                u[col] = sol;
+                gr[f * n + col] = sol;
+            }
+        } else {
+            th_build(Aug, p + f * n, q + f * (2 * n - 1), n, W, lane);
+            if (lane < n) {
+                Aug[lane * W + n] = gg[f * n + lane];   // A is symmetric: u = A^{-T} gbar = A^{-1} gbar
+                gs[lane] = g[f * n + lane];
+            }
+            __builtin_amdgcn_wave_barrier();
+            th_gauss_jordan(Aug, n, W, 1, rowof, lane);
+            if (lane < n) {
+                const int row = rowof[lane];
+                const T ul = Aug[row * W + n] / Aug[row * W + lane];
+                u[lane] = ul;
+                gr[f * n + lane] = ul;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         // Abar = -u g^T on the Toeplitz diagonals |i - j| = k (k < n) and the Hankel anti-diagonals i + j = k (k < 2n-1)
@@ -125,12 +222,23 @@ static int th_launch(bool bwd, const void* gg, const void* p, const void* q, con
 {
     const size_t lds = sizeof(T) * ((size_t)n * (n + 1) + 2 * kThMax) + sizeof(int) * kThMax;
     long grid = F < 256L * 16 ? (long)F : 256L * 16;
-    if (!bwd)
-        hipLaunchKernelGGL((th_solve_fwd_kernel<T>), dim3((unsigned)grid), dim3(64), lds, st, (const T*)p, (const T*)q,
-                           (const T*)r_or_g, (long)F, n, (T*)o1);
-    else
-        hipLaunchKernelGGL((th_solve_bwd_kernel<T>), dim3((unsigned)grid), dim3(64), lds, st, (const T*)gg, (const T*)p,
-                           (const T*)q, (const T*)r_or_g, (long)F, n, (T*)o1, (T*)o2, (T*)o3);
+    static const bool lds_only = [] {
+        const char* e = getenv("DSA_THSOLVE_LDS");
+        return e && atoi(e) != 0;
+    }();
+#define DSA_TH_LAUNCH(NM)                                                                                                  \
+    do {                                                                                                                   \
+        if (!bwd)                                                                                                          \
+            hipLaunchKernelGGL((th_solve_fwd_kernel<T, NM>), dim3((unsigned)grid), dim3(64), lds, st, (const T*)p, (const T*)q, \
+                               (const T*)r_or_g, (long)F, n, (T*)o1);                                                      \
+        else                                                                                                               \
+            hipLaunchKernelGGL((th_solve_bwd_kernel<T, NM>), dim3((unsigned)grid), dim3(64), lds, st, (const T*)gg, (const T*)p, \
+                               (const T*)q, (const T*)r_or_g, (long)F, n, (T*)o1, (T*)o2, (T*)o3);                         \
+    } while (0)
+    if (!lds_only && n <= 24) DSA_TH_LAUNCH(24);
+    else if (!lds_only && n <= 32) DSA_TH_LAUNCH(32);
+    else DSA_TH_LAUNCH(0);
+#undef DSA_TH_LAUNCH
     return check_launch(bwd ? "th_solve_bwd" : "th_solve_fwd");
 }
 
@@ -287,6 +395,76 @@ static int zerodf_launch_bwd(const void* gy, const void* x, const void* b, const
     return check_launch("zerodf_bwd");
 }
 
+// ---------------------------------------------------------------------------------------------
+// The spectrum arithmetic of one Newton step of MelGeneralizedCepstralAnalysis (mgcep.py:199-209), gamma not in {0, -1},
+// in ONE pass over the (F, K) spectra (as stock element-wise operators it is ~20 passes and dominated the step):
+//   C = b1 (Cr[1:], Ci[1:])   (b[0] = 0),  X = 1 + gamma Re C,  Y = gamma Im C,  D = X^2 + Y^2,
+//   pp = x D^(-1/gamma - 1),  qq = pp / D,
+//   out[0] = pp   out[1] = qq (X^2 - Y^2)   out[2] = qq 2 X Y   out[3] = pp X   out[4] = pp Y      (each (F, K))
+// -- the inputs of the five row products against Pr, Qr, Qi, Rr, Ri.  A thread owns one bin: its 2 M matrix entries stay
+// in registers for the workgroup's tile of frames, the frames' coefficients are broadcast from LDS.
+constexpr int kMsFrames = 32, kMsMaxM = 64;
+template <typename T, int MT>   // MT: compile-time bound on M (register-resident matrix columns)
+__global__ __launch_bounds__(320) void mgcep_spectra_kernel(const T* __restrict__ x, const T* __restrict__ b1, long F, int K, int M,
+                                                            const T* __restrict__ Cr, const T* __restrict__ Ci, T gamma,
+                                                            T* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) T bs[kMsFrames * MT];   // row stride MT, zero-padded: static offsets, 16-byte reads
+    const long f0 = (long)blockIdx.x * kMsFrames;
+    const int nf = (int)((F - f0) < kMsFrames ? (F - f0) : kMsFrames);
+    for (int i = threadIdx.x; i < kMsFrames * MT; i += blockDim.x) {
+        const int fi = i / MT, m = i - fi * MT;
+        bs[i] = (fi < nf && m < M) ? b1[(f0 + fi) * M + m] : T(0);
+    }
+    __syncthreads();
+    const T ex = T(-1) / gamma - T(1);
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        T cr[MT], ci[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            cr[m] = m < M ? Cr[(long)(m + 1) * K + k] : T(0);
+            ci[m] = m < M ? Ci[(long)(m + 1) * K + k] : T(0);
+        }
+        for (int fi = 0; fi < nf; ++fi) {
+            T re = 0, im = 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const T b = bs[fi * MT + m];
+                re += b * cr[m];
+                im += b * ci[m];
+            }
+            const T X = T(1) + gamma * re, Y = gamma * im;
+            const T XX = X * X, YY = Y * Y, D = XX + YY;
+            T dp;
+            if constexpr (sizeof(T) == 4) dp = __builtin_amdgcn_exp2f(ex * __builtin_amdgcn_logf(D));   // D > 0; 1 ulp each
+            else dp = dsa_pow(D, ex);
+            const T pp = x[(f0 + fi) * K + k] * dp;
+            const T qq = pp / D;
+            const long o = (f0 + fi) * K + k, S = F * (long)K;
+            out[o] = pp;
+            out[S + o] = qq * (XX - YY);
+            out[2 * S + o] = qq * (T(2) * X * Y);
+            out[3 * S + o] = pp * X;
+            out[4 * S + o] = pp * Y;
+        }
+    }
+}
+
+template <typename T>
+static int mgcep_spectra_launch(const void* x, const void* b1, int64_t F, int K, int M, const void* Cr, const void* Ci, double gamma,
+                                void* out, hipStream_t st)
+{
+    const unsigned grid = (unsigned)((F + kMsFrames - 1) / kMsFrames);
+#define DSA_MS_LAUNCH(MT)                                                                                                  \
+    hipLaunchKernelGGL((mgcep_spectra_kernel<T, MT>), dim3(grid), dim3(K > 256 ? 320 : 256), 0, st, (const T*)x, (const T*)b1,  \
+                       (long)F, K, M, (const T*)Cr, (const T*)Ci, (T)gamma, (T*)out)
+    if (M <= 16) DSA_MS_LAUNCH(16);
+    else if (M <= 32) DSA_MS_LAUNCH(32);
+    else DSA_MS_LAUNCH(64);
+#undef DSA_MS_LAUNCH
+    return check_launch("mgcep_spectra");
+}
+
 }  // namespace dsa
 
 using namespace dsa;
@@ -334,4 +512,18 @@ DSA_EXPORT int dsa_thsolve_bwd(const void* gg, const void* p, const void* q, con
     if (dtype == DSA_F32) return th_launch<float>(true, gg, p, q, g, F, n, gp, gq, gr, (hipStream_t)stream);
     if (dtype == DSA_F64) return th_launch<double>(true, gg, p, q, g, F, n, gp, gq, gr, (hipStream_t)stream);
     return fail(DSA_ERR_UNSUPPORTED, "thsolve_bwd: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_mgcep_spectra(const void* x, const void* b1, int64_t F, int32_t fft_length, int32_t M, const void* Cr,
+                                 const void* Ci, double gamma, int32_t dtype, void* out, void* stream)
+{
+    DSA_REQUIRE(F >= 0 && fft_length > 1 && fft_length % 2 == 0 && M >= 1, "mgcep_spectra: sizes must be positive");
+    DSA_REQUIRE(gamma != 0.0 && gamma >= -1.0 && gamma < 0.0, "mgcep_spectra: gamma must be in [-1, 0)");
+    if (M > kMsMaxM) return fail(DSA_ERR_UNSUPPORTED, "mgcep_spectra: cep_order above 64%s");
+    if (F == 0) return DSA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int K = fft_length / 2 + 1;
+    if (dtype == DSA_F32) return mgcep_spectra_launch<float>(x, b1, F, K, M, Cr, Ci, gamma, out, st);
+    if (dtype == DSA_F64) return mgcep_spectra_launch<double>(x, b1, F, K, M, Cr, Ci, gamma, out, st);
+    return fail(DSA_ERR_UNSUPPORTED, "mgcep_spectra: unsupported dtype%s");
 }

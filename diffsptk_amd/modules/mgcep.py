@@ -8,6 +8,7 @@ Toeplitz-plus-Hankel solve kernel (csrc/mgc.hip).  Gradients: the kernels' own b
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -50,9 +51,14 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
             return
         if cep_order < 1:
             raise ValueError("cep_order must be positive when gamma is not 0.")
-        for name, mat in tables.mgcep_matrices(fft_length, cep_order, float(alpha)).items():
-            self.register_buffer(name, to(mat, device=device, dtype=dtype), persistent=False)
         M = cep_order
+        mats = dict(tables.mgcep_matrices(fft_length, cep_order, float(alpha)))   # (the table function caches its result)
+        # only the columns the step uses (mgcep.py:226-227: pt = p[:M], qt = q[2:]): one 48-column launch per product
+        mats["Pr"] = mats["Pr"][:, :M]
+        for k in ("Qr", "Qi", "Q1"):
+            mats[k] = mats[k][:, 2:]
+        for name, mat in mats.items():
+            self.register_buffer(name, to(np.ascontiguousarray(mat), device=device, dtype=dtype), persistent=False)
         self.b2mc = MLSADigitalFilterCoefficientsToMelCepstrum(M, alpha, device=device, dtype=dtype)
         self.mc2b = MelCepstrumToMLSADigitalFilterCoefficients(M, alpha, device=device, dtype=dtype)
         self.gc2gc = MelGeneralizedCepstrumToMelGeneralizedCepstrum(M, M, in_gamma=-1, out_gamma=gamma, device=device,
@@ -70,9 +76,15 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
 
         def newton(gamma, b1):
             if gamma == -1:                                        # mgcep.py:196-197, 213-215
-                p = mm(x, self.Pr)
-                q = mm(x, self.Q1)
+                pt = mm(x, self.Pr)
+                qt = None                                          # q (1 + gamma) = 0: no Hankel part
                 r = mm(x, self.R1)
+            elif not (torch.is_grad_enabled() and (x.requires_grad or b1.requires_grad)) and M <= 64:
+                S = ops.mgcep_spectra(x, b1, self.Cr, self.Ci, gamma)   # mgcep.py:199-209, one pass (forward only)
+                pt = mm(S[0], self.Pr)
+                qt = (mm(S[1], self.Qr) + mm(S[2], self.Qi)) * (1 + gamma)
+                r = mm(S[3], self.Rr) + mm(S[4], self.Ri)
+                eps = epsilon(gamma, r, b1)
             else:
                 b = torch.cat((torch.zeros_like(b1[..., :1]), b1), dim=-1)
                 X = 1 + gamma * mm(b, self.Cr)                     # mgcep.py:199-209
@@ -81,12 +93,12 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
                 D = XX + YY
                 pp = x * torch.pow(D, -1 / gamma) / D
                 qq = pp / D
-                p = mm(pp, self.Pr)
-                q = mm(qq * (XX - YY), self.Qr) + mm(qq * (2 * X * Y), self.Qi)
+                pt = mm(pp, self.Pr)
+                qt = (mm(qq * (XX - YY), self.Qr) + mm(qq * (2 * X * Y), self.Qi)) * (1 + gamma)
                 r = mm(pp * X, self.Rr) + mm(pp * Y, self.Ri)
                 eps = epsilon(gamma, r, b1)
-            pt = p[..., :M]
-            qt = q[..., 2:] * (1 + gamma)
+            if qt is None:
+                qt = torch.zeros(*pt.shape[:-1], 2 * M - 1, device=pt.device, dtype=pt.dtype)
             b1 = b1 + ops.ThSolveFn.apply(pt, qt, r[..., 1:])      # mgcep.py:226-230
             if gamma == -1:
                 eps = epsilon(gamma, r, b1)

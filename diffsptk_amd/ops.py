@@ -715,6 +715,21 @@ class McepFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------- mgcep (8(f) row 3)
+def mgcep_spectra(x, b1, Cr, Ci, gamma):
+    """(5, ..., K): pp, qq (X^2 - Y^2), qq 2XY, pp X, pp Y of one Newton step of mgcep.py:199-209 in one launch
+    (dsa_mgcep_spectra); forward only."""
+    _require_device(x, b1, Cr, Ci)
+    _same_dtype(x, b1, Cr, Ci)
+    xc, bc = x.contiguous(), b1.contiguous()
+    K, M = xc.size(-1), bc.size(-1)
+    F = xc.numel() // K
+    out = torch.empty((5, *xc.shape), device=x.device, dtype=x.dtype)
+    with torch.cuda.device(x.device):
+        _call("dsa_mgcep_spectra", _p(xc), _p(bc), F, 2 * (K - 1), M, _p(Cr.contiguous()), _p(Ci.contiguous()), float(gamma),
+              _dtype_code(xc), _p(out), _stream())
+    return out
+
+
 class ThSolveFn(torch.autograd.Function):
     """g = solve(symmetric_toeplitz(p) + hankel(q), r) per row (mgcep.py:226-229): p:(..., n), q:(..., 2n-1), r:(..., n)."""
 

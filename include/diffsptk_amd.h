@@ -241,6 +241,13 @@ int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist, int64_t F,
  * the host composes (dsa_freqt_fwd) around pointwise spectrum arithmetic (modules/mgcep.py). */
 int dsa_thsolve_fwd(const void* p, const void* q, const void* r, int64_t F, int32_t n, int32_t dtype, void* g,
                     void* stream);
+/* The pointwise spectrum arithmetic of one Newton step, mgcep.py:199-209 (gamma in [-1, 0), not 0), in one pass:
+ * x:(F,K) power spectra, b1:(F,M) the current coefficients b[1:], Cr, Ci:((M+1),K) the composed cfreqt -> rfft
+ * matrices (tables.mgcep_matrices; row 0 is not read: b[0] = 0 there) -> out:(5,F,K) = pp, qq (X^2 - Y^2), qq 2XY,
+ * pp X, pp Y -- the inputs of the row products against Pr, Qr, Qi, Rr, Ri (dsa_freqt_fwd).  Forward only: with a
+ * gradient needed the module composes the same arithmetic from differentiable operators.  M <= 64. */
+int dsa_mgcep_spectra(const void* x, const void* b1, int64_t F, int32_t fft_length, int32_t M, const void* Cr,
+                      const void* Ci, double gamma, int32_t dtype, void* out, void* stream);
 int dsa_thsolve_bwd(const void* gg, const void* p, const void* q, const void* g, int64_t F, int32_t n, int32_t dtype,
                     void* gp, void* gq, void* gr, void* stream);
 

@@ -20,7 +20,7 @@ import pytest
 import torch
 
 import diffsptk_amd as dsp
-from diffsptk_amd import _lib, functional as F
+from diffsptk_amd import _lib, functional as F, ops
 from oracle import oracle as O
 from oracle import torch_port as TP
 
@@ -259,3 +259,45 @@ def TPframes(x, L, P, zmean, mode):
     xp = torch.nn.functional.pad(x.unsqueeze(0), (left, right), mode=mode).squeeze(0)
     fr = xp.unfold(-1, L, P)
     return fr - fr.mean(-1, keepdim=True) if zmean else fr
+
+
+@pytest.mark.parametrize("K,N,Fr", [(257, 49, 4096), (257, 25, 2001), (300, 100, 1500), (129, 3, 1024), (320, 192, 1100)])
+def test_long_row_products_on_matrix_cores(K, N, Fr):
+    """c @ A for long float32 rows (the 257-bin spectra of mgcep against its composed matrices): the float32 matrix-core
+    row product, 48 output columns per launch into a column slice of the result; against float64, with the backward
+    (vector kernels) through autograd, ragged row counts and slice widths."""
+    gen = torch.Generator().manual_seed(K + N)
+    c = torch.randn(Fr, K, dtype=torch.float64, generator=gen)
+    A = torch.randn(K, N, dtype=torch.float64, generator=gen)
+    A[K // 3: K // 3 + 70] = 0.0          # empty blocks are skipped by the kernel's program
+    g = torch.randn(Fr, N, dtype=torch.float64, generator=gen)
+    cd = c.to(DEV, torch.float32).requires_grad_(True)
+    out = ops.MatmulRowsFn.apply(cd, A.to(DEV, torch.float32))
+    assert _lib.last_kernel() == "freqt_mfma_fwd"
+    out.backward(g.to(DEV, torch.float32))
+    ref, gref = (c @ A).numpy(), (g @ A.T).numpy()
+    assert np.abs(out.detach().cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+    assert np.abs(cd.grad.cpu().numpy() - gref).max() <= 2e-5 * np.abs(gref).max()
+    out64 = ops.MatmulRowsFn.apply(c.to(DEV), A.to(DEV))      # float64 keeps the vector kernels
+    assert _lib.last_kernel() != "freqt_mfma_fwd"
+    assert np.abs(out64.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float64, 1e-10), (torch.float32, 2e-4)])
+def test_mgcep_fused_spectrum_arithmetic_equals_the_differentiable_chain(dt, tol):
+    """MelGeneralizedCepstralAnalysis (gamma != 0) without a gradient runs the spectrum arithmetic of a Newton step as one
+    kernel (dsa_mgcep_spectra) and the five long row products on matrix cores (float32); with a gradient it composes the
+    same step from differentiable operators.  Same result, and against the float64 oracle."""
+    x = torch.randn(8, 4000, generator=torch.Generator().manual_seed(11), dtype=torch.float64)
+    X = dsp.STFT(400, 80, 512, dtype=dt, device=DEV)(x.to(DEV, dt))
+    for gamma, M in ((-0.5, 24), (-0.25, 30), (-1 / 3, 12)):
+        mg = dsp.MelGeneralizedCepstralAnalysis(fft_length=512, cep_order=M, alpha=0.42, gamma=gamma, n_iter=4, dtype=dt, device=DEV)
+        a = mg(X)
+        assert _lib.last_kernel() != "" and not a.requires_grad
+        Xg = X.clone().requires_grad_(True)
+        b = mg(Xg)
+        assert b.requires_grad
+        scale = float(b.abs().max())
+        assert float((a - b.detach()).abs().max()) <= tol * scale
+        ref = O.mgcep(X.double().cpu().numpy(), M, 0.42, gamma, 4)
+        assert np.abs(a.double().cpu().numpy() - ref).max() <= (1e-8 if dt == torch.float64 else 5e-4) * np.abs(ref).max()
