@@ -338,6 +338,8 @@ def main():
                          "tail of the persistent mel-cepstral kernel (steps are independent batches): +2.5 %% frames/s, "
                          "+7 %% without the instrumented steps (tools/ab_pipeline.py); default 1 keeps the per-kernel "
                          "timings of the roofline objects undisturbed")
+    ap.add_argument("--record-every", type=int, default=4,
+                    help="HIP events bracket the two launches of every n-th step of the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the config 2/3/4 sub-benchmarks (N = 1)")
     ap.add_argument("--algo", choices=["auto", "generic", "tuned"], default="auto")
@@ -454,7 +456,7 @@ def main():
         for i in range(args.steps):
             # HIP events bracket the two launches of every fourth step of the timed region only (the per-kernel
             # averages below come from those launches; with --streams > 1 those steps run alone)
-            out = step(record=(i % 4 == 0))
+            out = step(record=(i % max(1, args.record_every) == 0))
         drain()   # every collective of the K steps completes inside the timed region
         torch.cuda.synchronize()
         if world > 1:

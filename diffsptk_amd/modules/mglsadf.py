@@ -8,7 +8,9 @@ The three modes that do not need torchlpc, for phase in {minimum, maximum, zero}
                                       Hermitian transform for zero phase), then ONE pass of the FIR kernel;
   freq-domain   (mglsadf.py:529-644)  complex STFT of the excitation times the filter's complex spectrum (mgc2sp),
                                       inverse STFT -- the fused STFT / ISTFT kernels of the analysis path.
-`mode="pade-approx"` (recursive filter through torchlpc) and `phase="mixed"` raise NotImplementedError.
+`phase="mixed"` (mglsadf.py:144-147, 240-246) takes mc:(.., N + M + 1) = c_{-N} .. c_{-1}, c_0 .. c_M with
+filter_order = (N, M) (or one integer for N = M): the maximum-phase part rides on the same kernels as a second cepstrum.
+`mode="pade-approx"` (recursive filter through torchlpc, absent here) raises NotImplementedError.
 """
 from __future__ import annotations
 
@@ -42,17 +44,18 @@ class PseudoMGLSADigitalFilter(nn.Module):
                  ignore_gain: bool = False, phase: str = "minimum", mode: str = "multi-stage", device=None, dtype=None,
                  **kwargs) -> None:
         super().__init__()
-        if phase == "mixed":
-            raise NotImplementedError("diffsptk_amd: the mixed-phase MLSA filter is not provided by this backend")
-        if phase not in ("minimum", "maximum", "zero"):
+        if phase not in ("minimum", "maximum", "zero", "mixed"):
             raise ValueError(f"phase {phase} is not supported.")
-        if not isinstance(filter_order, int):
+        if phase != "mixed" and not isinstance(filter_order, int):
             raise ValueError("filter_order must be an integer when phase is not 'mixed'.")
         if mode == "pade-approx":
             raise NotImplementedError("diffsptk_amd: the pade-approx MLSA filter needs torchlpc and is not provided")
         if mode not in ("multi-stage", "single-stage", "freq-domain"):
             raise ValueError(f"mode {mode} is not supported.")
         gamma = get_gamma(gamma, c)
+        if phase == "mixed":
+            self._init_mixed(filter_order, frame_period, alpha, gamma, ignore_gain, mode, dict(device=device, dtype=dtype), kwargs)
+            return
         M = filter_order
         self.filter_order, self.frame_period, self.mode, self.phase = M, frame_period, mode, phase
         self.alpha, self.gamma, self.ignore_gain = alpha, gamma, ignore_gain
@@ -95,7 +98,98 @@ class PseudoMGLSADigitalFilter(nn.Module):
         if kwargs:
             raise TypeError(f"unexpected arguments for mode {mode}: {sorted(kwargs)}")
 
+    # ---- mixed phase (mglsadf.py:144-147, 240-246): filter_order = (N, M), maximum-phase part first ----
+    def _init_mixed(self, filter_order, frame_period, alpha, gamma, ignore_gain, mode, kw, kwargs) -> None:
+        def pair(v):
+            return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+        N, M = pair(filter_order)
+        self.orders, self.frame_period, self.mode, self.phase = (N, M), frame_period, mode, "mixed"
+        self.alpha, self.gamma, self.ignore_gain = alpha, gamma, ignore_gain
+        mgc = MelGeneralizedCepstrumToMelGeneralizedCepstrum
+        if mode == "multi-stage":
+            self.taylor_order = kwargs.pop("taylor_order", 20)
+            co_max, co_min = pair(kwargs.pop("cep_order", 199))
+            n_fft = kwargs.pop("n_fft", 512)
+            if kwargs.pop("learnable", False):
+                raise NotImplementedError("diffsptk_amd: learnable Taylor coefficients are not provided")
+            if self.taylor_order < 0:
+                raise ValueError("taylor_order must be non-negative.")
+            if alpha == 0 and gamma == 0:                                    # mglsadf.py:281-282
+                co_max, co_min = N, M
+            self.cep_orders = (co_max, co_min)
+            self.mgc2c = nn.ModuleList([mgc(M, co_min, in_alpha=alpha, in_gamma=gamma, n_fft=n_fft, **kw),
+                                        mgc(N, co_max, in_alpha=alpha, in_gamma=gamma, n_fft=n_fft, **kw)])
+            self.linear_intpl = LinearInterpolation(frame_period)
+        elif mode == "single-stage":
+            il_max, il_min = pair(kwargs.pop("ir_length", 2000))
+            self.ir_lengths, self.n_fft = (il_max, il_min), kwargs.pop("n_fft", 4096)
+            if self.n_fft < il_max + il_min - 1:
+                raise ValueError("n_fft must be large value.")
+            self.mgc2c = nn.ModuleList([mgc(M, il_min - 1, in_alpha=alpha, in_gamma=gamma, n_fft=self.n_fft, **kw),
+                                        mgc(N, il_max - 1, in_alpha=alpha, in_gamma=gamma, n_fft=self.n_fft, **kw)])
+        else:
+            frame_length = kwargs.pop("frame_length", 400)
+            fft_length = kwargs.pop("fft_length", 512)
+            n_fft = kwargs.pop("n_fft", 512)
+            if frame_length <= 2 * frame_period:
+                raise ValueError("frame_period must be less than half of frame_length.")
+            if ignore_gain:
+                self.mc2b = nn.ModuleList([MelCepstrumToMLSADigitalFilterCoefficients(o, alpha, **kw) for o in (M, N)])
+                self.b2mc = nn.ModuleList([MLSADigitalFilterCoefficientsToMelCepstrum(o, alpha, **kw) for o in (M, N)])
+            self.mgc2sp = nn.ModuleList([MelGeneralizedCepstrumToSpectrum(o, fft_length, alpha=alpha, gamma=gamma, out_format="complex",
+                                                                          n_fft=n_fft, **kw) for o in (M, N)])
+            self.stft = ShortTimeFourierTransform(frame_length, frame_period, fft_length, out_format="complex", **kw, **kwargs)
+            self.istft = InverseShortTimeFourierTransform(frame_length, frame_period, fft_length, **kw, **kwargs)
+            kwargs.clear()
+        if kwargs:
+            raise TypeError(f"unexpected arguments for mode {mode}: {sorted(kwargs)}")
+
+    def _forward_mixed(self, x: torch.Tensor, mc: torch.Tensor) -> torch.Tensor:
+        N, M = self.orders
+        check_size(mc.size(-1), N + M + 1, "dimension of mel-cepstrum")
+        check_size(x.size(-1), mc.size(-2) * self.frame_period, "sequence length")
+        P = self.frame_period
+        mc_min = mc[..., N:]
+        mc_max = torch.cat((torch.zeros_like(mc[..., :1]), mc[..., :N].flip(-1)), dim=-1)   # (0, c_{-1}, .., c_{-N})
+        if self.mode == "multi-stage":                                       # mglsadf.py:356-365
+            c_min, c_max = self.mgc2c[0](mc_min), self.mgc2c[1](mc_max)
+            c0 = c_min[..., :1] + c_max[..., :1]
+            c = torch.cat((c_max[..., 1:].flip(-1), torch.zeros_like(c0), c_min[..., 1:]), dim=-1).contiguous()
+            y = x
+            cur = x
+            for i in range(1, self.taylor_order + 1):
+                cur = ops.ZerodfFn.apply(cur, c, P, self.cep_orders[0], False) * (1.0 / i)
+                y = y + cur
+            if not self.ignore_gain:
+                y = y * torch.exp(self.linear_intpl(c0)).squeeze(-1)
+            return y
+        if self.mode == "single-stage":                                      # mglsadf.py:507-521
+            il_max, il_min = self.ir_lengths
+            c_min, c_max = self.mgc2c[0](mc_min), self.mgc2c[1](mc_max)
+            c0 = torch.zeros_like(c_min[..., :1]) if self.ignore_gain else c_min[..., :1] + c_max[..., :1]
+            c = torch.cat((c_max[..., 1:].flip(-1), c0, c_min[..., 1:]), dim=-1)
+            c = torch.nn.functional.pad(c, (0, self.n_fft - c.size(-1)))
+            shift = il_max - 1
+            c = torch.roll(c, -shift, dims=-1).contiguous()
+            # c2mpir.py:98-101 with ir_length = n_fft: ifft(exp(fft(c))).real; c is real, so the half spectrum carries it all
+            tw = device_twiddle(self.n_fft, c.device, c.dtype)
+            C = ops.FftrFn.apply(c, self.n_fft, 0, tw)
+            h = ops.IfftrFn.apply(torch.exp(C), self.n_fft, self.n_fft, tw)
+            h = torch.roll(h, shift, dims=-1)[..., : il_min + il_max - 1]
+            return ops.ZerodfFn.apply(x, h.contiguous(), P, shift, False)
+        Hs = []                                                              # mglsadf.py:617-637
+        for i, c in enumerate((mc_min, mc_max)):
+            if self.ignore_gain:
+                b = _Gnorm._forward(self.mc2b[i](c), gamma=self.gamma)
+                b = torch.cat((torch.zeros_like(b[..., :1]), b[..., 1:]), dim=-1)
+                c = self.b2mc[i](b)
+            Hs.append(self.mgc2sp[i](c))
+        return self.istft(Hs[0] * Hs[1].conj() * self.stft(x), out_length=x.size(-1))
+
     def forward(self, x: torch.Tensor, mc: torch.Tensor) -> torch.Tensor:
+        if self.phase == "mixed":
+            return self._forward_mixed(x, mc)
         check_size(mc.size(-1), self.filter_order + 1, "dimension of mel-cepstrum")
         check_size(x.size(-1), mc.size(-2) * self.frame_period, "sequence length")
         P = self.frame_period

@@ -655,6 +655,62 @@ def _mirror(x, half=False):
     return np.concatenate((x1[..., ::-1], x[..., :1], x1), -1)
 
 
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def mlsa_mixed(x, mc, P, orders, alpha=0.0, gamma=0.0, ignore_gain=False, mode="multi-stage", **kw):
+    """PseudoMGLSADigitalFilter(phase="mixed") (mglsadf.py:144-147, 240-246; multi-stage :356-365, single-stage :507-521,
+    freq-domain :636-637).  mc:(.., N + M + 1) = c_{-N} .. c_{-1}, c_0 .. c_M; orders = (N, M) as the reference's
+    filter_order; cep_order / ir_length pairs are (maximum-phase, minimum-phase) too."""
+    x, mc = np.asarray(x, dtype=np.float64), np.asarray(mc, dtype=np.float64)
+    N, M = _pair(orders)
+    mc_min = mc[..., N:]
+    mc_max = np.concatenate((np.zeros_like(mc[..., :1]), mc[..., :N][..., ::-1]), -1)   # (0, c_{-1}, .., c_{-N})
+    if mode == "multi-stage":
+        taylor_order, n_fft = kw.get("taylor_order", 20), kw.get("n_fft", 512)
+        co_max, co_min = _pair(kw.get("cep_order", 199))
+        c_min = mgc2mgc(mc_min, co_min, in_alpha=alpha, in_gamma=gamma, n_fft=n_fft)
+        c_max = mgc2mgc(mc_max, co_max, in_alpha=alpha, in_gamma=gamma, n_fft=n_fft)
+        c0 = c_min[..., :1] + c_max[..., :1]
+        c = np.concatenate((c_max[..., 1:][..., ::-1], np.zeros_like(c0), c_min[..., 1:]), -1)
+        y, cur = x.copy(), x
+        for i in range(1, taylor_order + 1):
+            cur = zerodf(cur, c, P, zeroth_index=co_max) * (1.0 / i)
+            y = y + cur
+        if not ignore_gain:
+            y = y * np.exp(linear_intpl(c0, P))[..., 0]
+        return y
+    if mode == "single-stage":
+        n_fft = kw.get("n_fft", 4096)
+        il_max, il_min = _pair(kw.get("ir_length", 2000))
+        c_min = mgc2mgc(mc_min, il_min - 1, in_alpha=alpha, in_gamma=gamma, n_fft=n_fft)
+        c_max = mgc2mgc(mc_max, il_max - 1, in_alpha=alpha, in_gamma=gamma, n_fft=n_fft)
+        c0 = np.zeros_like(c_min[..., :1]) if ignore_gain else c_min[..., :1] + c_max[..., :1]
+        c = np.concatenate((c_max[..., 1:][..., ::-1], c0, c_min[..., 1:]), -1)
+        c = np.concatenate((c, np.zeros(c.shape[:-1] + (n_fft - c.shape[-1],))), -1)
+        shift = il_max - 1
+        c = np.roll(c, -shift, -1)
+        h = np.fft.ifft(np.exp(np.fft.fft(c, n=n_fft))).real          # c2mpir.py:98-101 with ir_length = n_fft
+        h = np.roll(h, shift, -1)[..., : il_min + il_max - 1]
+        return zerodf(x, h, P, zeroth_index=shift)
+    if mode == "freq-domain":
+        L, nfft, n_fft = kw.get("frame_length", 400), kw.get("fft_length", 512), kw.get("n_fft", 512)
+        win = kw.get("window", "blackman")
+        Hs = []
+        for c in (mc_min, mc_max):
+            if ignore_gain:
+                bq = gnorm(mc2b(c, alpha), gamma)
+                bq[..., 0] = 0
+                c = b2mc(bq, alpha)
+            Hs.append(mgc2sp(c, nfft, alpha, gamma, n_fft=n_fft, out_format="complex"))
+        H = Hs[0] * np.conj(Hs[1])
+        w = window_table(L, win)
+        X = stft(x, L, P, nfft, window=win, out_format="complex")
+        return istft(H * X, L, P, w=w, out_length=x.shape[-1])
+    raise ValueError(f"mode {mode} is not supported.")
+
+
 def mlsa(x, mc, P, alpha=0.0, gamma=0.0, ignore_gain=False, phase="minimum", mode="multi-stage", **kw):
     """PseudoMGLSADigitalFilter (mglsadf.py:126-253) for phase in {minimum, maximum, zero}:
     multi-stage (mglsadf.py:351-386), single-stage (:486-526), freq-domain (:613-644)."""

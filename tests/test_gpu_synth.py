@@ -202,8 +202,8 @@ def test_mlsa_gradients_and_analysis_synthesis(golden):
         assert np.abs(host(got) - ref).max() < 1e-6 * np.abs(ref).max(), name
     with pytest.raises(NotImplementedError):
         dsp.MLSA(24, 80, mode="pade-approx")
-    with pytest.raises(NotImplementedError):
-        dsp.MLSA((24, 24), 80, phase="mixed")
+    with pytest.raises(ValueError):
+        dsp.MLSA((24, 24), 80, phase="minimum")
     # README.md:91-93 of the reference: analysis -> synthesis.  White excitation through the filter of the analysed
     # cepstra must carry the spectral envelope the cepstra describe (mgc2sp), frame by frame, within the variance of a
     # periodogram: compared on mel-cepstra of the synthesised signal.
@@ -215,3 +215,34 @@ def test_mlsa_gradients_and_analysis_synthesis(golden):
     y = dsp.MLSA(24, 80, alpha=0.42, mode="freq-domain", frame_length=400, fft_length=512, device=DEV)(src, mc_t)
     mc_hat = mcep(stft(y))[:, 20:180].mean(1)
     assert float((mc_hat[0, 1:4] - shape[1:4]).abs().max()) < 0.15
+
+
+@pytest.mark.parametrize("mode", ["multi-stage", "single-stage", "freq-domain"])
+def test_mlsa_mixed_phase_golden(golden, mode):
+    """PseudoMGLSADigitalFilter(phase="mixed") (mglsadf.py:144-147, 240-246): mc = c_{-12} .. c_{-1}, c_0 .. c_24, against the
+    reference's outputs, float64 and float32; equal orders given as one integer, with the gradients."""
+    g, b = golden("mlsa_mixed"), golden("mlsa")
+    params = {"multi-stage": {"taylor_order": 7, "cep_order": (40, 60)}, "single-stage": {"ir_length": (80, 120), "n_fft": 512},
+              "freq-domain": {"frame_length": 512, "fft_length": 512, "window": "hamming"}}[mode]
+    x = dev(b["mlsa_x"])
+    for c in (0, 2):
+        mc = dev(g[f"mc_c{c}"])
+        for ig in (0, 1):
+            m = dsp.MLSA((12, 24), 80, alpha=0.42, c=c, ignore_gain=bool(ig), phase="mixed", mode=mode, dtype=torch.float64, device=DEV, **params)
+            ref = g[f"{mode}_c{c}_{ig}"]
+            y = host(m(x, mc))
+            assert np.abs(y - ref).max() < 1e-7 * np.abs(ref).max(), (mode, c, ig, np.abs(y - ref).max())
+    m32 = dsp.MLSA((12, 24), 80, alpha=0.42, phase="mixed", mode=mode, device=DEV, **params)
+    y32 = host(m32(x.float(), dev(g["mc_c0"], torch.float32))).astype(np.float64)
+    ref = g[f"{mode}_c0_0"]
+    assert np.abs(y32 - ref).max() < 3e-4 * np.abs(ref).max()
+    if mode == "multi-stage":
+        xg, mg = dev(b["mlsa_x"]).requires_grad_(True), dev(g["mc_equal"]).requires_grad_(True)
+        m = dsp.MLSA(24, 80, alpha=0.42, phase="mixed", mode="multi-stage", taylor_order=6, cep_order=50, dtype=torch.float64, device=DEV)
+        y = m(xg, mg)
+        assert np.abs(host(y) - g["multi_equal"]).max() < 1e-7 * np.abs(g["multi_equal"]).max()
+        y.square().sum().backward()
+        for got, name in ((xg.grad, "gx"), (mg.grad, "gmc")):
+            assert np.abs(host(got) - g[name]).max() < 1e-6 * np.abs(g[name]).max(), name
+    with pytest.raises(ValueError):
+        dsp.MLSA((12, 24), 80, phase="mixed", mode=mode, device=DEV, **params)(x.float(), dev(g["mc_c0"], torch.float32)[..., :-1])
