@@ -318,6 +318,41 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
                              "the segmented scans of the filter bank), DESIGN.md 3.35"},
         "timing": "back-to-back launches (gpu_time)",
     }
+    # ---- one timing per module at 256 utterances x 1 s (51 200 frames) ----
+    Bq = 256
+    xq = x1024[:Bq]
+    frq = Bq * FRAMES_PER_UTT
+    rows = {}
+
+    def timed(name, fn, n=5):
+        rows[name] = {"ms": gpu_time(fn, n=n, groups=2), "kernel": _lib.last_kernel()}
+        rows[name]["Mframes/s"] = frq / rows[name]["ms"] / 1e3
+
+    with torch.no_grad():
+        Xq = stft(xq)
+        stc = dsp.STFT(FL, FP, NFFT, out_format="complex", device=dev)
+        ist = dsp.ISTFT(FL, FP, NFFT, device=dev)
+        Zq = stc(xq)
+        timed("f2 ISTFT", lambda: ist(Zq), n=10)
+        gl = dsp.GriffinLim(FL, FP, NFFT, n_iter=4, init_phase="zeros", device=dev)
+        timed("f2 GriffinLim (4 iterations)", lambda: gl(Xq, out_length=xq.size(-1)), n=3)
+        for it in (0, 3):
+            ca = dsp.CepstralAnalysis(fft_length=NFFT, cep_order=M, n_iter=it, device=dev)
+            timed(f"f3 CepstralAnalysis n_iter={it}", lambda: ca(Xq), n=10)
+        mg = dsp.MelGeneralizedCepstralAnalysis(fft_length=NFFT, cep_order=M, alpha=ALPHA, gamma=-0.5, n_iter=N_ITER, device=dev)
+        timed("f3 MelGeneralizedCepstralAnalysis gamma=-0.5 n_iter=10", lambda: mg(Xq), n=2)
+        mcq = mcep(Xq)
+        m2s = dsp.MelGeneralizedCepstrumToSpectrum(M, NFFT, alpha=ALPHA, device=dev)
+        timed("f4 mgc2sp", lambda: m2s(mcq), n=10)
+        m2b = dsp.MelCepstrumToMLSADigitalFilterCoefficients(M, ALPHA, device=dev)
+        timed("f4 mc2b", lambda: m2b(mcq), n=10)
+        exc = torch.randn(Bq, SAMPLES, device=dev)
+        for mode, kw in (("multi-stage", {}), ("single-stage", {}), ("freq-domain", dict(frame_length=FL, fft_length=NFFT))):
+            ml = dsp.MLSA(M, FP, alpha=ALPHA, mode=mode, device=dev, **kw)
+            timed(f"f4 MLSA {mode}", lambda: ml(exc, mcq), n=2)
+    res["f_rows_batch256"] = {"workload": f"SURVEY 8(f) rows 2-4, {Bq} utterances x 1 s ({frq} frames / {Bq * SAMPLES} samples), float32, "
+                                          "module API, default options unless named", "rows": rows,
+                              "timing": "back-to-back calls (gpu_time); `kernel` = the last kernel family the call dispatched to"}
     return res
 
 

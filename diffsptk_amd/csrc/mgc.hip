@@ -367,10 +367,80 @@ __global__ __launch_bounds__(256) void zerodf_bwd_b_kernel(const T* __restrict__
     }
 }
 
+// Long filters (M >= 64: the 200-tap cepstra of the multi-stage MLSA filter, the 2000-tap impulse responses of the
+// single-stage one) with P <= 128: the taps are dealt to 8 slices of 32 threads, a thread keeps up to four output samples
+// (i = l, l + 32, ..) in registers -- two coefficient reads feed eight multiply-adds instead of two, and all 256 threads work
+// where the kernel above keeps P of them busy -- and the slices' partial sums meet in LDS (fixed order: deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void zerodf_fwd_sliced_kernel(const T* __restrict__ x, const T* __restrict__ b, long Tlen, long N,
+                                                                int M, int P, int z0, int ignore_gain, T* __restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* b0 = reinterpret_cast<T*>(smem_raw);   // [M + 1]
+    T* b1 = b0 + (M + 1);                     // [M + 1]
+    T* xs = b1 + (M + 1);                     // [128 + M]: x[t0 - M + z0 ..], zero beyond the frame's stretch
+    T* part = xs + (128 + M);                 // [8][2][128]
+    const long f = blockIdx.x;
+    const long u = f / N, n = f - u * N;
+    const long n1 = n + 1 < N ? n + 1 : N - 1;
+    const T* br0 = b + (u * N + n) * (M + 1);
+    const T* br1 = b + (u * N + n1) * (M + 1);
+    for (int k = threadIdx.x; k <= M; k += blockDim.x) {
+        b0[k] = br0[k];
+        b1[k] = br1[k];
+    }
+    const long t0 = n * P;
+    const T* xu = x + u * Tlen;
+    for (int i = threadIdx.x; i < 128 + M; i += blockDim.x) {
+        const long s = t0 - M + z0 + i;
+        xs[i] = (i < P + M && s >= 0 && s < Tlen) ? xu[s] : T(0);
+    }
+    __syncthreads();
+    const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int per = (M + 8) / 8;              // ceil((M + 1) / 8)
+    const int k0 = g * per, k1 = (k0 + per < M + 1) ? k0 + per : M + 1;
+    T a0[4] = {T(0), T(0), T(0), T(0)}, a1[4] = {T(0), T(0), T(0), T(0)};
+    for (int k = k0; k < k1; ++k) {
+        const T c0 = b0[k], c1 = b1[k];
+        const T* xp = xs + (M - k) + l;       // x[t - k + z0] = xs[i + M - k]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const T xv = xp[32 * j];
+            a0[j] += c0 * xv;
+            a1[j] += c1 * xv;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        part[(g * 2 + 0) * 128 + l + 32 * j] = a0[j];
+        part[(g * 2 + 1) * 128 + l + 32 * j] = a1[j];
+    }
+    __syncthreads();
+    const int gk = z0 == M ? M : 0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        T s0 = 0, s1 = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            s0 += part[(q * 2 + 0) * 128 + i];
+            s1 += part[(q * 2 + 1) * 128 + i];
+        }
+        const T w = (T)i / (T)P;
+        T v = s0 + w * (s1 - s0);             // torch.lerp(y1, y2, ramp)
+        if (ignore_gain) v /= b0[gk] + w * (b1[gk] - b0[gk]);
+        y[u * Tlen + t0 + i] = v;
+    }
+}
+
 template <typename T>
 static int zerodf_launch_fwd(const void* x, const void* b, int64_t B, int64_t Tlen, int64_t N, int M, int P, int z0, int ig,
                              void* y, hipStream_t st)
 {
+    const size_t lds_s = sizeof(T) * (2 * (size_t)(M + 1) + 128 + M + 8 * 2 * 128);
+    if (M >= 64 && P <= 128 && lds_s <= 64 * 1024) {
+        hipLaunchKernelGGL((zerodf_fwd_sliced_kernel<T>), dim3((unsigned)(B * N)), dim3(256), lds_s, st, (const T*)x, (const T*)b,
+                           (long)Tlen, (long)N, M, P, z0, ig, (T*)y);
+        return check_launch("zerodf_sliced_fwd");
+    }
     const size_t lds = sizeof(T) * (2 * (size_t)(M + 1) + P + M);
     if (lds > 64 * 1024) return fail(DSA_ERR_UNSUPPORTED, "zerodf: filter too long for LDS%s");
     hipLaunchKernelGGL((zerodf_fwd_kernel<T>), dim3((unsigned)(B * N)), dim3(P >= 192 ? 256 : (P >= 96 ? 128 : 64)), lds, st,
