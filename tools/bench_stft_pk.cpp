@@ -25,7 +25,7 @@ static float run(int iters, int waves_per_cu)
     hipEventCreate(&e1);
     auto launch = [&] {
         hipLaunchKernelGGL((dsa::stft512_fwd_pk_kernel<ABL, 400, DIRECT>), dim3((unsigned)((grid + 1) / 2)), dim3(128), lds2, 0, gx, gT, gN, L,
-                           P, 200, gw, gtw, 1e-9f, gy, total_chunks, chunks_per_utt);
+                           P, 200, gw, gtw, 1e-9f, gy, total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0);
     };
     for (int i = 0; i < 3; ++i) launch();
     hipEventRecord(e0);
@@ -70,6 +70,9 @@ int main(int argc, char** argv)
         printf("  DIRECT stores: full %.1f | no-store %.1f | no-load %.1f | no-fft %.1f | no load/store %.1f | wpc12 %.1f\n", run<0, true>(20, wpc), run<1, true>(20, wpc),
                run<4, true>(20, wpc), run<2, true>(20, wpc), run<5, true>(20, wpc), run<0, true>(20, 12));
     }
+    for (int rep = 0; rep < 3; ++rep)
+        printf("DIRECT stagger: base %.1f | start staggered by block/256 (1024) %.1f | by wave parity too (2048) %.1f\n", run<0, true>(20, 16),
+               run<1024, true>(20, 16), run<1024 + 2048, true>(20, 16));
     for (int rep = 0; rep < 2; ++rep)
         printf("DIRECT variants: base %.1f | xcd-contiguous %.1f | nontemporal %.1f | both %.1f | xcd, staged %.1f\n", run<0, true>(20, 16), run<256, true>(20, 16),
                run<512, true>(20, 16), run<768, true>(20, 16), run<256, false>(20, 16));
@@ -92,19 +95,23 @@ int main(int argc, char** argv)
         printf("DIRECT vs staged: %zu differing of %zu, worst %.3e\n", bad, n, worst);
     }
 #ifdef DSA_STFT_TIMING
-    {
-        float t = run<128>(1, 16);
+    auto timeline = [&](const char* tag, float t) {
         unsigned long long st[64];
         hipMemcpyFromSymbol(st, HIP_SYMBOL(dsa::g_stft_pk_stamps), sizeof(st));
-        printf("timeline of wave 0 (cycles; kernel incl. launch %.1f us): prologue %llu | whole wave %llu\n", t, st[1] - st[0], st[2] - st[0]);
+        printf("timeline of wave 0, %s (cycles; kernel incl. launch %.1f us): prologue %llu | whole wave %llu\n", tag, t, st[1] - st[0], st[2] - st[0]);
         printf("  prologue: to prefetch issued %llu | tables loaded %llu | first stretch staged %llu | second prefetch issued %llu\n", st[3] - st[0],
                st[4] - st[3], st[5] - st[4], st[1] - st[5]);
         printf("  pass starts (delta):");
         for (int i = 1; i < 14; ++i) printf(" %llu", st[8 + i] > st[8 + i - 1] ? st[8 + i] - st[8 + i - 1] : 0ULL);
-        printf("\n  pass 3 phases: stage %llu | window-read+prefetch-issue %llu | fft1 %llu | tw+T-write %llu | T-read %llu | fft2 %llu | Z-write %llu | pair-read %llu | split+stage-write %llu | copy-out %llu\n",
-               st[40] - st[8 + 3], st[41] - st[40], st[42] - st[41], st[43] - st[42], st[44] - st[43], st[45] - st[44], st[46] - st[45],
-               st[47] - st[46], st[48] - st[47], st[49] - st[48]);
-    }
+        printf("\n  pass 3 phases: window-read %llu | fft1 %llu | tw+T-write %llu | T-read %llu | fft2 %llu | Z-write %llu | pair-read %llu | "
+               "split(+fetch wait, stores) %llu | copy-out %llu | next stretch staged + prefetch issued %llu\n",
+               st[41] - st[8 + 3], st[42] - st[41], st[43] - st[42], st[44] - st[43], st[45] - st[44], st[46] - st[45],
+               st[47] - st[46], st[48] - st[47], st[49] - st[48], st[40] - st[49]);
+    };
+    timeline("staged", run<128>(1, 16));
+    timeline("DIRECT", run<128, true>(1, 16));
+    timeline("DIRECT, no stores", run<128 + 1, true>(1, 16));
+    timeline("DIRECT, no loads", run<128 + 4, true>(1, 16));
 #endif
     return 0;
 }
