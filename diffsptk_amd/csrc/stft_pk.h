@@ -163,7 +163,7 @@ __device__ __forceinline__ void pk_fft16(v2f (&v)[16])
 
 // ABL (ablation bit mask, tools/bench_stft.cpp only; 0 in the product): 1 no output stores | 2 no butterflies |
 // 4 no waveform loads / staging | 8 no twiddle-table reads | 16 no transposes through LDS | 32 no spectrum
-// round trip (Z write + pair reads) | 64 no staged tile | 128 cycle stamps of wave 0 | 1024 (+2048) staggered start
+// round trip (Z write + pair reads) | 64 no staged tile | 128 cycle stamps of wave 0
 #ifdef DSA_STFT_TIMING
 __device__ unsigned long long g_stft_pk_stamps[64];
 #define PK_STAMP(i)                                                                                     \
@@ -382,10 +382,6 @@ __global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_
         stage_sync(b, ci);
     }
     PK_STAMP(5);
-    if (ABL & 1024) {   // experiment: the (up to) 8 workgroups of a CU start their pass loops an eighth of a pass apart
-        int k = (int)((blockIdx.x >> 8) & 7) * 2 + ((ABL & 2048) ? wv : 0);
-        for (int q = 0; q < k; ++q) __builtin_amdgcn_s_sleep(8);
-    }
     long b1 = b;
     int ci1 = ci;
     advance(b1, ci1);

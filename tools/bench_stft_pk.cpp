@@ -70,9 +70,6 @@ int main(int argc, char** argv)
         printf("  DIRECT stores: full %.1f | no-store %.1f | no-load %.1f | no-fft %.1f | no load/store %.1f | wpc12 %.1f\n", run<0, true>(20, wpc), run<1, true>(20, wpc),
                run<4, true>(20, wpc), run<2, true>(20, wpc), run<5, true>(20, wpc), run<0, true>(20, 12));
     }
-    for (int rep = 0; rep < 3; ++rep)
-        printf("DIRECT stagger: base %.1f | start staggered by block/256 (1024) %.1f | by wave parity too (2048) %.1f\n", run<0, true>(20, 16),
-               run<1024, true>(20, 16), run<1024 + 2048, true>(20, 16));
     for (int rep = 0; rep < 2; ++rep)
         printf("DIRECT variants: base %.1f | xcd-contiguous %.1f | nontemporal %.1f | both %.1f | xcd, staged %.1f\n", run<0, true>(20, 16), run<256, true>(20, 16),
                run<512, true>(20, 16), run<768, true>(20, 16), run<256, false>(20, 16));
