@@ -62,7 +62,7 @@ LPC_BYTES_PER_FRAME = FP * 4 + M1 * 4
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3    # fp32 vector peak with packed instructions = fp32 MFMA dense peak (same guide)
 FP64_PEAK_TFLOPS = 78.6     # fp64 vector peak (same guide)
-VALU_ISSUE_PEAK_GIPS = 1024 * 2.4 / 4   # 1024 SIMDs, one wave64 vector instruction per 4 cycles, 2.4 GHz: 614.4 G wave-instr/s
+VALU_ISSUE_PEAK_GIPS = 1024 * 2.4 / 2   # 1024 SIMD-32s, one wave64 vector instruction per 2 cycles (MI355X_MICROARCH.md), 2.4 GHz: 1228.8 G wave-instr/s
 PMC_FILE = os.path.join("profiles", "pmc_traffic.json")
 
 
@@ -554,9 +554,14 @@ def main():
                 "pmc": pm_m["derived"] if pm_m else None, "pmc_source": (pm_m["_source"] + " (static)") if pm_m else None,
                 "frames_per_launch": frames_launch,
                 "arith": "f16x3 split chains (fp32 accumulate) + fp32 VALU solve",
+                "two_wave_issue_cap": {"peak": VALU_ISSUE_PEAK_GIPS / 2,
+                                       "frac": (ipf * frames_launch / t_mcep / 1e9 / (VALU_ISSUE_PEAK_GIPS / 2)) if ipf else None,
+                                       "note": "a wave64 issues at most one vector instruction per ~8 cycles (tools/bench_clock.cpp): "
+                                               "the two waves per SIMD this kernel's 256 registers allow can fill half of the port"},
                 "note": "achieved = vector wave-instructions per frame (static: rocprofv3 SQ_INSTS_VALU of this kernel, "
-                        "profiles/) x frames / measured launch time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles.  The kernel is "
-                        "bound by vector issue inside the 25x25 elimination (DESIGN.md 3.2 / 6)",
+                        "profiles/) x frames / measured launch time; peak = 1024 SIMD-32s x 2.4 GHz / 2 cycles per wave64 "
+                        "instruction.  The kernel is bound by vector issue inside the 25x25 elimination at two waves per SIMD "
+                        "(DESIGN.md 3.2 / 6)",
             },
             "roofline_stft": {
                 "kernel": kernels["stft"], "bound": "hbm",

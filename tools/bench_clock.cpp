@@ -19,6 +19,21 @@ __global__ void valu_kernel(float* out, unsigned long long* ticks, int iters)
     if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1 - t0;
 }
 
+__global__ void valu_pk_kernel(float* out, unsigned long long* ticks, int iters)
+{
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    v2 a0 = {(float)threadIdx.x, 1.f}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; ++i) {
+        asm volatile("v_pk_fma_f32 %0, %0, %0, %0\n v_pk_fma_f32 %1, %1, %1, %1\n v_pk_fma_f32 %2, %2, %2, %2\n v_pk_fma_f32 %3, %3, %3, %3\n"
+                     "v_pk_fma_f32 %4, %4, %4, %4\n v_pk_fma_f32 %5, %5, %5, %5\n v_pk_fma_f32 %6, %6, %6, %6\n v_pk_fma_f32 %7, %7, %7, %7"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0.x + a1.x + a2.x + a3.x + a4.y + a5.y + a6.y + a7.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1 - t0;
+}
+
 template <int BYTES>
 __global__ void lds_kernel(float* out, unsigned long long* ticks, int iters)
 {
@@ -64,7 +79,7 @@ int main()
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const int iters = 20000;
-    for (int waves_per_cu : {4, 16}) {
+    for (int waves_per_cu : {4, 8, 12, 16}) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
             hipLaunchKernelGGL(valu_kernel, dim3(256), dim3(64 * waves_per_cu), 0, 0, out, ticks, iters);
@@ -74,9 +89,21 @@ int main()
             hipEventElapsedTime(&ms, e0, e1);
             unsigned long long t;
             hipMemcpy(&t, ticks, 8, hipMemcpyDeviceToHost);
-            printf("VALU  %2d waves/CU: %.3f ms, %llu ticks -> %.2f GHz tick rate, %.2f ticks per v_fma_f32 per wave (x %d waves per SIMD)\n", waves_per_cu, ms, t,
-                   t / (ms * 1e6), (double)t / (8.0 * iters), waves_per_cu / 4);
+            printf("VALU  %2d waves/CU: %.3f ms, %llu ticks -> %.2f GHz tick rate, %.2f ticks per v_fma_f32 per wave (x %d waves per SIMD); %.1f TFLOP/s\n", waves_per_cu, ms, t,
+                   t / (ms * 1e6), (double)t / (8.0 * iters), waves_per_cu / 4, 256.0 * waves_per_cu * 8.0 * iters * 64 * 2 / (ms * 1e-3) / 1e12);
         }
+    }
+    for (int waves_per_cu : {4, 8, 16}) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(valu_pk_kernel, dim3(256), dim3(64 * waves_per_cu), 0, 0, out, ticks, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long t;
+        hipMemcpy(&t, ticks, 8, hipMemcpyDeviceToHost);
+        printf("VALU pk %2d waves/CU: %.3f ms, %llu ticks -> %.2f GHz, %.2f ticks per v_pk_fma_f32 per wave; %.1f TFLOP/s\n", waves_per_cu, ms, t, t / (ms * 1e6),
+               (double)t / (8.0 * iters), 256.0 * waves_per_cu * 8.0 * iters * 64 * 4 / (ms * 1e-3) / 1e12);
     }
 #define LDS_RUN(B)                                                                                                             \
     for (int waves_per_cu : {4, 16}) {                                                                                         \
