@@ -5,7 +5,7 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/$OUT/trace -o trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/$OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/$OUT/trace -o trace -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-configs > $R/$OUT/trace.log 2>&1
 cd $R
 DB=$(find $OUT/trace -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocprof_db_summary.py $DB > $OUT/kernel_trace.txt
