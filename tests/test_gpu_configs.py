@@ -301,3 +301,27 @@ def test_mgcep_fused_spectrum_arithmetic_equals_the_differentiable_chain(dt, tol
         assert float((a - b.detach()).abs().max()) <= tol * scale
         ref = O.mgcep(X.double().cpu().numpy(), M, 0.42, gamma, 4)
         assert np.abs(a.double().cpu().numpy() - ref).max() <= (1e-8 if dt == torch.float64 else 5e-4) * np.abs(ref).max()
+
+
+def test_bench_two_ranks_on_one_device():
+    """bench.py's N > 1 control flow (sharded batch, deferred in-place all-gather, drain inside the timed region, MAX over
+    ranks, one JSON line from rank 0) as two processes on ONE device over gloo -- the 8-GPU RCCL run itself is the
+    driver's; this catches argument / rendezvous / shape breakage before it."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSA_BENCH_SINGLE_DEVICE="1", DSA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29561", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "64",
+           "--ramp-seconds", "0"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
+    assert "configs" not in d and "cpu_baseline" not in d   # N = 1 only
