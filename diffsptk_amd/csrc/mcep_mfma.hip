@@ -142,6 +142,25 @@ __device__ __forceinline__ void col_build_rows(float (&a)[colm::TOTAL], const fl
     }
 }
 
+// The same rows with slot c = 6 read through two per-lane pointers instead of computed three ways and selected:
+// lane 0 of a quad: rt[24 + i] + rr[3 + i] (column 24), lane 1: rt[i] + (-alpha_vec[i]) (the right-hand side), lanes 2, 3:
+// 0 + 0 (pa6 / pb6 point at this frame's windows, at the negated alpha table, or at a row of zeros).  Bit-identical to
+// col_build_rows with rhs2 = nullptr; 6 instructions fewer per row (the forward kernel is bound by vector issue).
+template <int i>
+__device__ __forceinline__ void col_build_rows_p(float (&a)[colm::TOTAL], const float* rt0, const float* rr0,
+                                                 const float* pa6, const float* pb6, int gs)
+{
+    using namespace mm;
+    if constexpr (i < M1) {
+        const float* rt_g = rt0 + gs;
+        const float* rr_g = rr0 + 27 - gs;
+#pragma unroll
+        for (int c = i >> 2; c < 6; ++c) COL_AT(a, i, c) = rt_g[i + 4 * c] + rr_g[i - 4 * c];
+        COL_AT(a, i, 6) = pa6[i] + pb6[i];
+        col_build_rows_p<i + 1>(a, rt0, rr0, pa6, pb6, gs);
+    }
+}
+
 // acc += quad_bcast<Q>(s0) * s1 in ONE instruction: the DPP quad_perm broadcast is the src0 modifier
 // of v_fmac_f32 (hipcc CSEs builtin DPP moves into separate v_mov_b32_dpp instead of fusing them)
 template <int Q>
@@ -254,6 +273,15 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
     // see the ticket comment in the kernel: a short last round goes to one wave per SIMD pair
     const long slots = grid * WAVES, full = ntiles16 / slots * slots, rest = ntiles16 - full;
     const long tiles_shared = (full > 0 && rest > 0 && rest <= slots / 2) ? full : ntiles16;
+    static const bool old6 = [] {
+        const char* e = getenv("DSA_MCEP_OLD6");
+        return e && atoi(e) != 0;
+    }();
+    if (old6)
+        hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES, true>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
+                           (const float*)X, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
+                           (const float*)av, (float*)mc, (float*)hist, ntiles16, tiles_shared, queue, (const _Float16*)images);
+    else
     hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
                        (const float*)X, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
                        (const float*)av, (float*)mc, (float*)hist, ntiles16, tiles_shared, queue, (const _Float16*)images);

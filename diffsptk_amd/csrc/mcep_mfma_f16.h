@@ -54,7 +54,9 @@ constexpr int H_E48 = EL_OFF + 24 * 64 * 4;  // [16 mt][4 g][4 r] float
 constexpr int H_E256 = H_E48 + 256;      // [48] scaled by SE, [48] = unscaled E[256][48]
 constexpr int H_D256 = H_E256 + 52;      // [32]
 constexpr int H_AV = H_D256 + 32;        // [28]
-constexpr int H_WAVE = H_AV + 28;
+constexpr int H_NAV = H_AV + 28;         // [28] -alpha_vec, zero-padded
+constexpr int H_ZERO = H_NAV + 28;       // [28] zeros
+constexpr int H_WAVE = H_ZERO + 28;
 constexpr int h_lds_floats(int waves) { return H_WAVE + waves * WAVE_FLOATS; }
 }  // namespace mh
 
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void mcep_h_prep_kernel(const float* __restric
     if (idx < 32) reinterpret_cast<float*>(img + IMG_HALVES)[idx] = idx < M1 ? G[H * M1 + idx] : 0.f;
 }
 
-template <int WAVES>
+template <int WAVES, bool OLD6 = false>   // OLD6: round-1 form of the rows' slot 6 (A/B only)
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
     const float* __restrict__ X, long F, int n_iter, const float* __restrict__ G,
     const float* __restrict__ D, const float* __restrict__ E, const float* __restrict__ av,
@@ -152,7 +154,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
     if (tid < 48) lds[H_E256 + tid] = SE * E[H * M2 + tid];
     if (tid == 48) lds[H_E256 + 48] = E[H * M2 + 48];
     if (tid < 32) lds[H_D256 + tid] = tid < M1 ? kNeg2Log2e * D[tid * K + H] : 0.f;
-    if (tid < 28) lds[H_AV + tid] = tid < M1 ? av[tid] : 0.f;
+    if (tid < 28) {
+        const float a_ = tid < M1 ? av[tid] : 0.f;
+        lds[H_AV + tid] = a_;
+        lds[H_NAV + tid] = -a_;
+        lds[H_ZERO + tid] = 0.f;
+    }
     __syncthreads();  // the only workgroup barrier
 
     float* rt_lds = lds + H_WAVE + wave * WAVE_FLOATS + n * RS;
@@ -403,7 +410,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
 
             // ------------- rows of R + Q, symmetric elimination, back substitution (as v2) -------------
             float a[colm::TOTAL];
-            col_build_rows<0>(a, rt_q, rr_q, lds + H_AV, (const float*)nullptr, gs, gq);
+            if (OLD6) {
+                col_build_rows<0>(a, rt_q, rr_q, lds + H_AV, (const float*)nullptr, gs, gq);
+            } else {
+                // slot c = 6 of every row through two per-lane pointers (see col_build_rows_p); re-derived every step so
+                // that they do not occupy registers across the chains
+                int gsv = gs;
+                asm volatile("" : "+v"(gsv));
+                const float* pa6 = gsv == 0 ? rt_q + 24 : (gsv == 1 ? rt_q : lds + H_ZERO);
+                const float* pb6 = gsv == 0 ? rr_q + 3 : (gsv == 1 ? lds + H_NAV : lds + H_ZERO);
+                col_build_rows_p<0>(a, rt_q, rr_q, pa6, pb6, gs);
+            }
             __builtin_amdgcn_wave_barrier();
             DSA_STAMP(3);
             col_elim_all(a, std::make_integer_sequence<int, M1>{});
