@@ -192,13 +192,27 @@ template <int k>
 __device__ __forceinline__ void col_elim_step(float (&a)[colm::TOTAL])
 {
     const float ninv = -rcp_nr(quad_bcast<(k & 3)>(COL_AT(a, k, k >> 2)));
-    float pneg[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float pneg[7];
+    constexpr int NP = 7 - (k >> 2);   // entries of the pivot row this lane owns
 #pragma unroll
-    for (int c = k >> 2; c < 7; ++c) pneg[c - (k >> 2)] = COL_AT(a, k, c) * ninv;
+    for (int c = 0; c < 7; ++c) pneg[c] = c < NP ? COL_AT(a, k, (c < NP ? c : 0) + (k >> 2)) * ninv : 0.f;
     // VALU write -> DPP read of pneg needs 2 wait states, which hipcc cannot see inside inline asm; the
-    // dummy in/out operands pin the nop after the multiplies
-    asm volatile("s_nop 1"
-                 : "+v"(pneg[0]), "+v"(pneg[1]), "+v"(pneg[2]), "+v"(pneg[3]), "+v"(pneg[4]), "+v"(pneg[5]), "+v"(pneg[6]));
+    // dummy in/out operands pin the nop after the multiplies.  Only the NP live entries are operands: naming all
+    // seven made the compiler materialise the unused tail (a v_mov 0 each: 66 instructions per 25 x 25 system).
+    if constexpr (NP == 7)
+        asm volatile("s_nop 1" : "+v"(pneg[0]), "+v"(pneg[1]), "+v"(pneg[2]), "+v"(pneg[3]), "+v"(pneg[4]), "+v"(pneg[5]), "+v"(pneg[6]));
+    else if constexpr (NP == 6)
+        asm volatile("s_nop 1" : "+v"(pneg[0]), "+v"(pneg[1]), "+v"(pneg[2]), "+v"(pneg[3]), "+v"(pneg[4]), "+v"(pneg[5]));
+    else if constexpr (NP == 5)
+        asm volatile("s_nop 1" : "+v"(pneg[0]), "+v"(pneg[1]), "+v"(pneg[2]), "+v"(pneg[3]), "+v"(pneg[4]));
+    else if constexpr (NP == 4)
+        asm volatile("s_nop 1" : "+v"(pneg[0]), "+v"(pneg[1]), "+v"(pneg[2]), "+v"(pneg[3]));
+    else if constexpr (NP == 3)
+        asm volatile("s_nop 1" : "+v"(pneg[0]), "+v"(pneg[1]), "+v"(pneg[2]));
+    else if constexpr (NP == 2)
+        asm volatile("s_nop 1" : "+v"(pneg[0]), "+v"(pneg[1]));
+    else
+        asm volatile("s_nop 1" : "+v"(pneg[0]));
     col_update_rows<k, k + 1>(a, pneg);
 }
 template <int... Ks>
@@ -219,7 +233,8 @@ __device__ __forceinline__ float col_backsub_step(const float (&a)[colm::TOTAL],
     sl += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sl), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
     sl += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sl), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
     const float xk = -sl * rcp_nr(quad_bcast<(k & 3)>(COL_AT(a, k, k >> 2)));
-    xq[k >> 2] = __uint_as_float(__float_as_uint(xq[k >> 2]) | (__float_as_uint(xk) & gq.m[k & 3]));
+    // the owner lane of column k takes xk, the others keep their slot: one v_cndmask_b32 (the slot is still 0 on the owner)
+    xq[k >> 2] = gq.m[k & 3] ? xk : xq[k >> 2];
     return xk;
 }
 template <int... Ks>
