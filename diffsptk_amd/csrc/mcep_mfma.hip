@@ -288,15 +288,6 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
     // see the ticket comment in the kernel: a short last round goes to one wave per SIMD pair
     const long slots = grid * WAVES, full = ntiles16 / slots * slots, rest = ntiles16 - full;
     const long tiles_shared = (full > 0 && rest > 0 && rest <= slots / 2) ? full : ntiles16;
-    static const bool old6 = [] {
-        const char* e = getenv("DSA_MCEP_OLD6");
-        return e && atoi(e) != 0;
-    }();
-    if (old6)
-        hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES, true>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
-                           (const float*)X, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
-                           (const float*)av, (float*)mc, (float*)hist, ntiles16, tiles_shared, queue, (const _Float16*)images);
-    else
     hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
                        (const float*)X, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
                        (const float*)av, (float*)mc, (float*)hist, ntiles16, tiles_shared, queue, (const _Float16*)images);

@@ -69,7 +69,13 @@ __device__ __forceinline__ f32x4 mfma_h(f16x8 a, f16x8 b, f32x4 c)
 __device__ __forceinline__ void split2(float x0, float x1, f16x2& hi, f16x2& lo)
 {
     hi = __builtin_convertvector(f32x2v{x0, x1}, f16x2);
-    lo = __builtin_convertvector(f32x2v{x0 - (float)hi[0], x1 - (float)hi[1]}, f16x2);
+    // x - float(hi), exact, as ONE v_fma_mix_f32 per value (binary16 operand taken from its half register): the compiler's
+    // form is a conversion plus a subtraction (64 values per lane and Newton step in a kernel bound by vector issue)
+    const unsigned hb = __builtin_bit_cast(unsigned, hi);
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(x1));
+    lo = __builtin_convertvector(f32x2v{l0, l1}, f16x2);
 }
 // c * s + b on both halves of a register pair: v_pk_fma_f32 (two flops per lane and issue slot)
 #ifdef DSA_MCEP_NOPK
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256) void mcep_h_prep_kernel(const float* __restric
     if (idx < 32) reinterpret_cast<float*>(img + IMG_HALVES)[idx] = idx < M1 ? G[H * M1 + idx] : 0.f;
 }
 
-template <int WAVES, bool OLD6 = false>   // OLD6: round-1 form of the rows' slot 6 (A/B only)
+template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
     const float* __restrict__ X, long F, int n_iter, const float* __restrict__ G,
     const float* __restrict__ D, const float* __restrict__ E, const float* __restrict__ av,
@@ -387,9 +393,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                 asm volatile("" : "+v"(g_it));  // keeps the address selects inside the loop (not live across the solve)
                 float* rtw = rt_lds + 4 * g_it;
                 float* rra = rr_lds + 27 + 4 * g_it;
-                float* rrb = rr_lds + 27 - 4 * g_it;
+                float* rrb = rr_lds + 24 - 4 * g_it;            // rr[27 - idx] = rrb[3 - r]: immediate offsets stay non-negative
                 float* rra1 = g_it < 3 ? rra + 16 : rr_lds + 55;
-                float* rrb1 = g_it < 3 ? rrb - 16 : rr_lds + 62;
+                float* rrb1 = g_it < 3 ? rrb - 16 : rr_lds + 59;
                 const int bk = back - SE_LOG2;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -397,10 +403,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                     const float v1 = __builtin_ldexpf(accB[1][r], bk);
                     rtw[r] = v0;
                     rra[r] = v0;
-                    rrb[-r] = v0;
+                    rrb[3 - r] = v0;
                     rtw[16 + r] = v1;
                     rra1[r] = v1;
-                    rrb1[-r] = v1;
+                    rrb1[3 - r] = v1;
                     rtw[32 + r] = __builtin_ldexpf(accB[2][r], bk);
                 }
                 rt_lds[48] = rt48;  // same value on the four lanes of a frame
@@ -410,9 +416,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
 
             // ------------- rows of R + Q, symmetric elimination, back substitution (as v2) -------------
             float a[colm::TOTAL];
-            if (OLD6) {
-                col_build_rows<0>(a, rt_q, rr_q, lds + H_AV, (const float*)nullptr, gs, gq);
-            } else {
+            {
                 // slot c = 6 of every row through two per-lane pointers (see col_build_rows_p); re-derived every step so
                 // that they do not occupy registers across the chains
                 int gsv = gs;
