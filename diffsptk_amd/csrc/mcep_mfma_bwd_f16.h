@@ -40,7 +40,9 @@ constexpr int B_E48 = B_DB + 2 * IMG_DB / 2;          // [16 mt][4 g][4 r]
 constexpr int B_E256 = B_E48 + 256;                   // [48] scaled by SE, [48] unscaled, then [64] unscaled E[256][m] (0 past 48)
 constexpr int B_D256 = B_E256 + 52 + 64;              // [32] -2 log2(e) D[c][256], then [32] -2 D[c][256]
 constexpr int B_AV = B_D256 + 64;                     // [28]
-constexpr int B_WAVE = B_AV + 28;
+constexpr int B_NAV = B_AV + 28;                      // [28] -alpha_vec, zero-padded
+constexpr int B_ZERO = B_NAV + 28;                    // [28] zeros
+constexpr int B_WAVE = B_ZERO + 28;
 constexpr int FS = 180;                               // per-frame record: rt [0,52) | rr [52,116) | aux [116,180)
 constexpr int B_WAVE_FLOATS = 16 * FS;
 constexpr int B_LDS_FLOATS = B_WAVE + WAVES_B * B_WAVE_FLOATS;
@@ -128,7 +130,12 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
         lds[B_D256 + tid] = 1.4426950408889634f * tail_b[tid];    // -2 log2(e) D[c][256]
         lds[B_D256 + 32 + tid] = tail_b[tid];                     // -2 D[c][256]
     }
-    if (tid < 28) lds[B_AV + tid] = tid < M1 ? av[tid] : 0.f;
+    if (tid < 28) {
+        const float a_ = tid < M1 ? av[tid] : 0.f;
+        lds[B_AV + tid] = a_;
+        lds[B_NAV + tid] = -a_;
+        lds[B_ZERO + tid] = 0.f;
+    }
     __syncthreads();
 
     float* wave_lds = lds + B_WAVE + wave * B_WAVE_FLOATS;
@@ -295,7 +302,16 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             float xq2[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[2], -1.f)};
             {
                 float a[colm::TOTAL];
-                col_build_rows<0>(a, rt_q, rr_q, lds + B_AV, aux_q, gs, gq);
+                {
+                    // slot 6 of every row through two per-lane pointers (col_build_rows_p): lane 0 column 24, lane 1 the
+                    // right-hand side rt[:25] - alpha, lane 2 the second right-hand side mbar (+ 0), lane 3 zeros
+                    int gsv = gs;
+                    asm volatile("" : "+v"(gsv));
+                    const float* zr = lds + B_ZERO;
+                    const float* pa6 = gsv == 0 ? rt_q + 24 : (gsv == 1 ? rt_q : (gsv == 2 ? aux_q : zr));
+                    const float* pb6 = gsv == 0 ? rr_q + 3 : (gsv == 1 ? lds + B_NAV : zr);
+                    col_build_rows_p<0>(a, rt_q, rr_q, pa6, pb6, gs);
+                }
                 __builtin_amdgcn_wave_barrier();
                 col_elim_all(a, std::make_integer_sequence<int, M1>{});
                 col_backsub_all(a, xq1, gq, std::make_integer_sequence<int, M1>{});
