@@ -214,6 +214,10 @@ __device__ __forceinline__ void col_elim_step(float (&a)[colm::TOTAL])
     else
         asm volatile("s_nop 1" : "+v"(pneg[0]));
     col_update_rows<k, k + 1>(a, pneg);
+    // the pivot row stays behind NORMALISED and negated (-row_k / a_kk: a register renaming, no instruction): the back
+    // substitution then needs neither the reciprocal nor its broadcast again
+#pragma unroll
+    for (int c = 0; c < NP; ++c) COL_AT(a, k, c + (k >> 2)) = pneg[c];
 }
 template <int... Ks>
 __device__ __forceinline__ void col_elim_all(float (&a)[colm::TOTAL], std::integer_sequence<int, Ks...>)
@@ -223,6 +227,7 @@ __device__ __forceinline__ void col_elim_all(float (&a)[colm::TOTAL], std::integ
 
 // back substitution of right-hand side RHS (1 or 2): xq[c] accumulates x[gs + 4c]; the slot of the
 // right-hand-side column is preset to -1 on its owner lane, so  sum_j U[k][j] x_j - b_k  is one dot product
+// (the rows arrive as -U[k][.] / U[k][k] from col_elim_step: the dot product is x_k itself)
 template <int k>
 __device__ __forceinline__ float col_backsub_step(const float (&a)[colm::TOTAL], float (&xq)[mm::KS],
                                                   const GroupMask& gq)
@@ -232,7 +237,8 @@ __device__ __forceinline__ float col_backsub_step(const float (&a)[colm::TOTAL],
     for (int c = k >> 2; c < 7; ++c) sl = __builtin_fmaf(COL_AT(a, k, c), xq[c], sl);
     sl += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sl), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
     sl += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sl), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
-    const float xk = -sl * rcp_nr(quad_bcast<(k & 3)>(COL_AT(a, k, k >> 2)));
+    // rows are normalised and negated by the elimination: sum_j (-U_kj / U_kk) x_j with x_rhs = -1 IS x_k
+    const float xk = sl;
     // the owner lane of column k takes xk, the others keep their slot: one v_cndmask_b32 (the slot is still 0 on the owner)
     xq[k >> 2] = gq.m[k & 3] ? xk : xq[k >> 2];
     return xk;
