@@ -191,7 +191,9 @@ __device__ __forceinline__ void col_update_rows(float (&a)[colm::TOTAL], const f
 template <int k>
 __device__ __forceinline__ void col_elim_step(float (&a)[colm::TOTAL])
 {
-    const float ninv = -rcp_nr(quad_bcast<(k & 3)>(COL_AT(a, k, k >> 2)));
+    // v_rcp_f32 (1 ulp) without a Newton step: the error of the pivot reciprocal enters the solution like one more rounding
+    // of the elimination, and the outer Newton iteration only ever uses the solve for an UPDATE
+    const float ninv = -__builtin_amdgcn_rcpf(quad_bcast<(k & 3)>(COL_AT(a, k, k >> 2)));
     float pneg[7];
     constexpr int NP = 7 - (k >> 2);   // entries of the pivot row this lane owns
 #pragma unroll
