@@ -63,6 +63,9 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.
 FP32_PEAK_TFLOPS = 157.3    # fp32 vector peak with packed instructions = fp32 MFMA dense peak (same guide)
 FP64_PEAK_TFLOPS = 78.6     # fp64 vector peak (same guide)
 VALU_ISSUE_PEAK_GIPS = 1024 * 2.4 / 2   # 1024 SIMD-32s, one wave64 vector instruction per 2 cycles (MI355X_MICROARCH.md), 2.4 GHz: 1228.8 G wave-instr/s
+# measured on an MI355X (tools/bench_issue.cpp -> profiles/r02_issue_calibration.txt): independent v_fmac_f32_dpp streams, every
+# SIMD holding {waves} waves; 1024 SIMDs x waves / (ns per instruction and wave)
+VALU_ISSUE_MEASURED_GIPS = {1: 1024 * 1 / 3.20, 2: 1024 * 2 / 4.78, 4: 1024 * 4 / 7.96}
 PMC_FILE = os.path.join("profiles", "pmc_traffic.json")
 
 
@@ -254,6 +257,13 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
                 "algorithmic": {"achieved": MCEP_BWD_FLOP_PER_FRAME * fr / t_mb / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": MCEP_BWD_FLOP_PER_FRAME * fr / t_mb / 1e12 / FP32_PEAK_TFLOPS,
                                 "flop_per_frame": MCEP_BWD_FLOP_PER_FRAME},
+                "calibrated": {"peak_4_waves_per_simd": VALU_ISSUE_MEASURED_GIPS[4], "peak_1_wave_per_simd": VALU_ISSUE_MEASURED_GIPS[1],
+                               "frac_of_4_wave_peak": ipf * fr / t_mb / 1e9 / VALU_ISSUE_MEASURED_GIPS[4],
+                               "frac_at_this_occupancy": ipf * fr / t_mb / 1e9 / VALU_ISSUE_MEASURED_GIPS[1],
+                               "unit": "G wave-instr/s",
+                               "note": "measured issue rate of independent v_fmac_f32_dpp streams with 4 / 1 waves per SIMD "
+                                       "(tools/bench_issue.cpp, profiles/r02_issue_calibration.txt); this kernel holds one wave per "
+                                       "SIMD (396 registers)"} if ipf else None,
                 "pmc": pm["derived"] if pm else None, "pmc_source": pm["_source"] if pm else None,
                 "arith": "five matrix chains as 3-term binary16 MFMA splits (fp32 accumulate), two-right-hand-side 25x25 "
                          "elimination in unpacked fp32 VALU", "last_kernel": k_bwd,
@@ -554,10 +564,16 @@ def main():
                 "pmc": pm_m["derived"] if pm_m else None, "pmc_source": (pm_m["_source"] + " (static)") if pm_m else None,
                 "frames_per_launch": frames_launch,
                 "arith": "f16x3 split chains (fp32 accumulate) + fp32 VALU solve",
-                "two_wave_issue_cap": {"peak": VALU_ISSUE_PEAK_GIPS / 2,
-                                       "frac": (ipf * frames_launch / t_mcep / 1e9 / (VALU_ISSUE_PEAK_GIPS / 2)) if ipf else None,
-                                       "note": "a wave64 issues at most one vector instruction per ~8 cycles (tools/bench_clock.cpp): "
-                                               "the two waves per SIMD this kernel's 256 registers allow can fill half of the port"},
+                "calibrated": (lambda a: {
+                    "peak_4_waves_per_simd": VALU_ISSUE_MEASURED_GIPS[4], "peak_2_waves_per_simd": VALU_ISSUE_MEASURED_GIPS[2],
+                    "frac_of_4_wave_peak": a / VALU_ISSUE_MEASURED_GIPS[4], "frac_at_this_occupancy": a / VALU_ISSUE_MEASURED_GIPS[2],
+                    "unit": "G wave-instr/s",
+                    "note": "what the chip sustains on a stream of independent v_fmac_f32_dpp (this kernel's dominant instruction) "
+                            "with every SIMD holding 4 / 2 waves: tools/bench_issue.cpp, profiles/r02_issue_calibration.txt "
+                            "(7.96 / 4.78 ns per instruction and wave; the clock gives way under vector load, so the 2-cycle port "
+                            "of `peak` is never reached by FMA-class instructions).  The kernel's 256 registers allow 2 waves per "
+                            "SIMD; its 110 MFMA instructions per frame take issue slots too and are not counted in `achieved`"})(
+                    ipf * frames_launch / t_mcep / 1e9) if ipf else None,
                 "note": "achieved = vector wave-instructions per frame (static: rocprofv3 SQ_INSTS_VALU of this kernel, "
                         "profiles/) x frames / measured launch time; peak = 1024 SIMD-32s x 2.4 GHz / 2 cycles per wave64 "
                         "instruction.  The kernel is bound by vector issue inside the 25x25 elimination at two waves per SIMD "
