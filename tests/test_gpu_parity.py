@@ -8,8 +8,9 @@ Tolerances (stated once, used everywhere below):
   float32 spectra: |y - y64| <= 1e-4 |y64| + 2e-6 max_k y64[frame]   (bins far below the frame
             maximum differ between ANY two float32 FFTs -- the reference's own float32 and
             float64 outputs disagree by 1.9e-3 elementwise on data.wav).
-  float32 mel-cepstra: |mc - mc64| <= 1e-4 |mc64| + 1e-5        (reference f32 vs f64: 6e-6 abs; this kernel on
-            data.wav: 6e-6; tests/test_gpu_configs.py holds the bench-size batches to 5e-6).
+  float32 mel-cepstra: |mc - mc64| <= 1e-4 |mc64| + 5e-6        (F32_MCEP; reference f32 vs f64: 6e-6 abs; this kernel on
+            data.wav: 6e-6 on c0 ~ 8; tests/test_gpu_configs.py holds the bench-size batches to 5e-6).  Only the
+            dynamic-range test (spectral tilts of 80 / 160 dB) uses a looser bound, stated there.
   float32 LPC: |a - a64| <= 1e-4 |a64| + 1e-4   (float64 recursion inside; the reference's own
             float32 result is 8.8e-4 away from its float64 result).
 """
@@ -26,6 +27,7 @@ from oracle import torch_port as TP
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 F64 = dict(rtol=1e-5, atol=1e-8)
+F32_MCEP = dict(rtol=1e-4, atol=5e-6)   # float32 mel-cepstra against the float64 goldens (|mc| ~ 0.01 .. 10)
 
 
 def dev(a, dtype=None):
@@ -430,13 +432,13 @@ def test_mcep_datawav_golden_and_trace(golden, name, dt):
     if dt == torch.float64:
         close(mc, g["mcep_f64"], **F64)
     else:
-        close(mc, g["mcep_f64"], 1e-4, 1e-5)
-        close(mc, g["mcep_f32"], 1e-4, 1e-5)
+        close(mc, g["mcep_f64"], **F32_MCEP)
+        close(mc, g["mcep_f32"], **F32_MCEP)
     # Newton trace: mc after k = 0..10 iterations for 5 frames
     Xt = X[torch.from_numpy(g["trace_frames"]).to(DEV)]
     for k in (0, 1, 2, 5, 10):
         mk = host(F.mcep(Xt, 24, 0.42, k))
-        tol = F64 if dt == torch.float64 else dict(rtol=1e-4, atol=1e-5)
+        tol = F64 if dt == torch.float64 else F32_MCEP
         close(mk, g["mcep_trace_f64"][k], **tol)
 
 
@@ -447,7 +449,7 @@ def test_stft_mcep_end_to_end_golden_with_gradient(golden, name, dt):
     stft = dsp.STFT(400, 80, 512, dtype=dt, device=DEV)
     mcep = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, dtype=dt, device=DEV)
     mc = mcep(stft(x))
-    tol = F64 if dt == torch.float64 else dict(rtol=1e-4, atol=1e-5)
+    tol = F64 if dt == torch.float64 else F32_MCEP
     close(host(mc), g["mcep_f64"], **tol)
     mc.mean().backward()
     ref = g["grad_mcep_mean_f64"]
@@ -484,7 +486,7 @@ def test_mcep_tuned_dynamic_range(golden):
         assert _lib.last_kernel().startswith("mcep_mfma_fwd")
         ref = host(m64(X.to(DEV).double()))
         assert np.isfinite(y).all(), (db, level)
-        close(y, ref, 1e-4, 1e-5)
+        close(y, ref, 1e-4, 1e-5)   # the one looser bound: c0 reaches +-60 at levels of 1e+-24, tilted frames lose bits
 
 
 def test_mcep_extreme_alpha_keeps_generic_kernel(golden):
@@ -513,8 +515,8 @@ def test_mcep_tuned_vs_generic_and_history(golden):
         assert _lib.last_kernel().startswith("mcep_mfma_fwd" if name == "tuned" else "mcep_generic_fwd")
         (mc * torch.linspace(-1, 1, 25, device=DEV)).sum().backward()
         outs[name] = (host(mc), host(Xg.grad))
-    close(outs["tuned"][0], g["mcep_f64"], 1e-4, 1e-5)
-    close(outs["tuned"][0], outs["generic"][0], 1e-4, 1e-5)
+    close(outs["tuned"][0], g["mcep_f64"], **F32_MCEP)
+    close(outs["tuned"][0], outs["generic"][0], **F32_MCEP)
     ref = g["grad_mcep_wsum_wrt_X_f64"]
     for name in outs:
         err = np.abs(outs[name][1] - ref) / np.abs(ref).max(-1, keepdims=True)
@@ -525,7 +527,7 @@ def test_mcep_tuned_vs_generic_and_history(golden):
     # ragged tile: 37 frames (not a multiple of 64) through the tuned kernel
     X37 = X[0, :37].clone().requires_grad_(True)
     mc37 = ops.McepFn.apply(X37, m.G, m.D, m.E, m.alpha_vector, 512, 24, 10, _lib.ALGO_TUNED)
-    close(host(mc37), g["mcep_f64"][0, :37], 1e-4, 1e-5)
+    close(host(mc37), g["mcep_f64"][0, :37], **F32_MCEP)
     (mc37 * torch.linspace(-1, 1, 25, device=DEV)).sum().backward()
     err37 = np.abs(host(X37.grad) - ref[0, :37]) / np.abs(ref[0, :37]).max(-1, keepdims=True)
     assert err37.max() < 2e-3
