@@ -82,6 +82,16 @@ def pmc_static(kernel: str):
         return None
 
 
+def grad_and_kernel(_lib, y, x, cot):
+    """(gradient, name of the kernel family that produced it): dsa_last_kernel() is per thread and the backward runs on
+    autograd's worker thread, so a hook on x reads it there."""
+    names = []
+    h = x.register_hook(lambda g: names.append(_lib.last_kernel()))
+    (gx,) = torch.autograd.grad(y, x, cot, retain_graph=True)
+    h.remove()
+    return gx, (names[-1] if names else None)
+
+
 def pmc_traffic(kernel: str, frames: float):
     """HBM bytes per launch of `kernel` from the static PMC record (FETCH_SIZE and WRITE_SIZE collected separately and
     corrected as MI355X_MICROARCH.md prescribes), rescaled to this launch's frame count; None without a record."""
@@ -240,9 +250,9 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
         mc = mcep(Xd)
         g = torch.ones_like(mc) / mc.numel()
         t_mb = gpu_time(lambda: torch.autograd.grad(mc, Xd, g, retain_graph=True), n=10) * 1e-3
-        k_bwd = _lib.last_kernel()
-        gX = torch.autograd.grad(mc, Xd, g, retain_graph=True)[0]
+        gX, k_bwd = grad_and_kernel(_lib, mc, Xd, g)
         t_sb = gpu_time(lambda: torch.autograd.grad(X, xg, gX, retain_graph=True), n=10) * 1e-3
+        _, k_sbwd = grad_and_kernel(_lib, X, xg, gX)
         pm = pmc_static("mcep_mfma_bwd")
         ipf = pm["derived"]["valu_insts_per_frame"] if pm else None
         res[f"config3_fwdbwd_batch{B}"] = {
@@ -268,9 +278,15 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
                 "arith": "five matrix chains as 3-term binary16 MFMA splits (fp32 accumulate), two-right-hand-side 25x25 "
                          "elimination in unpacked fp32 VALU", "last_kernel": k_bwd,
             },
-            "roofline_stft_bwd": {"kernel": "stft512_bwd", "bound": "hbm", "achieved": STFT_BWD_BYTES_PER_FRAME * fr / t_sb / 1e9,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": STFT_BWD_BYTES_PER_FRAME * fr / t_sb / 1e9 / HBM_PEAK_GBS,
-                                  "traffic": None, "avg_launch_ms": t_sb * 1e3, "bytes_per_frame": STFT_BWD_BYTES_PER_FRAME},
+            "roofline_stft_bwd": (lambda pmb: {
+                "kernel": k_sbwd, "bound": "hbm", "achieved": STFT_BWD_BYTES_PER_FRAME * fr / t_sb / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": STFT_BWD_BYTES_PER_FRAME * fr / t_sb / 1e9 / HBM_PEAK_GBS,
+                "traffic": pmc_traffic("stft512_bwd", fr), "avg_launch_ms": t_sb * 1e3, "bytes_per_frame": STFT_BWD_BYTES_PER_FRAME,
+                "pmc": pmb["derived"] if pmb else None, "pmc_source": pmb["_source"] if pmb else None,
+                "note": "one launch: forward transform recomputed, cotangent packed, inverse transform, overlap-add carried in "
+                        "registers (csrc/stft_bwd_pk.h); 1668 algorithmic bytes per frame.  Not HBM-bound in practice: the LDS "
+                        "pipe (two transposes per transform, four transforms' worth per pass) and vector issue share the time "
+                        "(pmc: lds_busy / valu_busy), DESIGN.md 3.1"})(pmc_static("stft512_bwd")),
             "timing": "back-to-back calls through the module API (gpu_time)",
         }
         del xg, X, Xd, mc, g, gX

@@ -1049,6 +1049,7 @@ __global__ __launch_bounds__(128, 4) void stft512_fwd_kernel(
 
 }  // namespace dsa
 #include "stft_pk.h"
+#include "stft_bwd_pk.h"
 namespace dsa {
 
 // ------------------------------------------------------------------ host-side dispatch helpers
@@ -2024,6 +2025,42 @@ static int stft_bwd_impl(const void* gy, const void* x, int64_t B, int64_t T, in
             int chunks_per_utt = (int)((N + kFPW - 1) / kFPW);
             long total_chunks = (long)B * chunks_per_utt;
             int span = (kFPW - 1) * P + L;
+            // the packed kernel with the overlap-add carried in registers (stft_bwd_pk.h): one launch, no workspace.
+            // DSA_STFT_BWD_PK=0 keeps the two-kernel path (A/B)
+            {
+            const bool cplx = out_format == DSA_SPEC_COMPLEX || out_format == DSA_SPEC_COMPLEX_INV;
+            const int left = center ? L / 2 : 0;
+            static const int use_pk = [] {
+                const char* e = getenv("DSA_STFT_BWD_PK");
+                return e ? atoi(e) : 1;
+            }();
+            if (use_pk && !zmean && L == 400 && P == 80 && (cplx || out_format == DSA_SPEC_POWER)) {
+                const int ppu = chunks_per_utt;                       // passes of four frames per utterance
+                const long waves = 256L * 16;
+                long want = (waves + B - 1) / B;                       // runs per utterance that fill the chip ...
+                static const int min_run = [] {   // A/B knob: shortest run of passes a wave takes (each run adds one warm-up pass)
+                    const char* e = getenv("DSA_STFT_BWD_MINRUN");
+                    return e && atoi(e) > 0 ? atoi(e) : 4;
+                }();
+                const long longest = ppu / min_run > 0 ? ppu / min_run : 1;
+                const int runs = (int)(want < longest ? want : longest);
+                const long items = (long)B * runs;
+                const long wv = items < waves ? items : waves;
+                const dim3 g2((unsigned)((wv + 3) / 4));             // four-wave workgroups share the twiddle and window tables
+                const int lds2 = 4 * kFPW * kZS * 8 + 256 * 8 + 16 * 13 * 8;
+                const float cs = out_format == DSA_SPEC_COMPLEX_INV ? 1.f / 512.f : 0.5f;
+                const float ce = out_format == DSA_SPEC_COMPLEX_INV ? 1.f : 2.f;
+                if (cplx)
+                    hipLaunchKernelGGL((stft512_bwd_pk_kernel<400, 80, true>), g2, dim3(256), lds2, st, (const float*)x,
+                                       (const float*)gy, (long)T, (long)N, left, (const float*)w, (const float*)twiddle, cs, ce,
+                                       (float*)gx, items, runs, ppu, (const float*)div, (float)div_eps);
+                else
+                    hipLaunchKernelGGL((stft512_bwd_pk_kernel<400, 80, false>), g2, dim3(256), lds2, st, (const float*)x,
+                                       (const float*)gy, (long)T, (long)N, left, (const float*)w, (const float*)twiddle, cs, ce,
+                                       (float*)gx, items, runs, ppu, (const float*)div, (float)div_eps);
+                return check_launch("stft512_bwd_pk");
+            }
+            }
             float* part = nullptr;
             if (hipMallocAsync((void**)&part, sizeof(float) * (size_t)total_chunks * span, st) != hipSuccess)
                 return fail(DSA_ERR_LAUNCH, "stft_bwd: workspace allocation failed%s");
