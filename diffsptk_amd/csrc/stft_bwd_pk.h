@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
     constexpr int SPAN = 3 * PC + LC;           // samples a pass touches
     constexpr int NI = (SPAN + 63) / 64;        // samples per lane of the span
     constexpr int NS = 4 * PC / 64;             // ... of which the first NS are complete after the pass
+    constexpr int TB = 4;                       // twiddle-table reads per batch
     static_assert(PC % 16 == 0 && LC - PC <= 4 * PC && NI - NS <= NS && SPAN <= 2 * kFPW * kZS, "unsupported frame geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -296,8 +297,16 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
             }
             DSA_WAVE_SYNC();
             pk_fft16<(NR <= 13)>(v);
+            // (the table reads go in batches of TB ahead of the stores they feed: read -> multiply -> store one at a time
+            // would wait out an LDS round trip per element -- the compiler cannot move a table read above a tile store)
 #pragma unroll
-            for (int k1 = 0; k1 < 16; ++k1) zf[k1 * 17 + j] = pk_cmul(v[FFT16_OUT(k1)], t256[k1 * 16 + j]);
+            for (int kb = 0; kb < 16; kb += TB) {
+                v2f tw[TB];
+#pragma unroll
+                for (int q = 0; q < TB; ++q) tw[q] = t256[(kb + q) * 16 + j];
+#pragma unroll
+                for (int q = 0; q < TB; ++q) zf[(kb + q) * 17 + j] = pk_cmul(v[FFT16_OUT(kb + q)], tw[q]);
+            }
             DSA_WAVE_SYNC();
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = zf[j * 17 + i];
@@ -329,6 +338,15 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
             zm = pk_add_posi_conj(ab, Q);
         };
         const float s0 = lane == 0 ? gsc0 : gsc;
+        v2f za0[kFPW], zb0[kFPW], za1[kFPW], zb1[kFPW], zmid = v2f{0.f, 0.f};   // all reads ahead of the in-place writes (see TB)
+        if constexpr (!CPLX) {
+#pragma unroll
+            for (int f = 0; f < kFPW; ++f) {
+                const v2f* z = zbuf + f * kZS;
+                za0[f] = z[lane], zb0[f] = z[(256 - lane) & 255], za1[f] = z[lane + 64], zb1[f] = z[192 - lane];
+            }
+            zmid = zbuf[(lane & 3) * kZS + 128];
+        }
 #pragma unroll
         for (int f = 0; f < kFPW; ++f) {
             v2f* z = zbuf + f * kZS;
@@ -344,7 +362,7 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
                 z[lane + 64] = zk;
                 z[192 - lane] = zm;
             } else {
-                const v2f a0 = z[lane], b0 = z[(256 - lane) & 255], a1 = z[lane + 64], b1 = z[192 - lane];
+                const v2f a0 = za0[f], b0 = zb0[f], a1 = za1[f], b1 = zb1[f];
                 pack(a0, b0, twA, gA[f] * s0, v2f{0.f, 0.f}, zk, zm);
                 z[lane] = zk;
                 if (lane != 0) z[256 - lane] = zm;
@@ -356,7 +374,7 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
         {   // bin 128 (W = -i) of frame `lane`
             v2f* z = zbuf + (lane & 3) * kZS;
             v2f zk, zm;
-            const v2f a = CPLX ? v2f{0.f, 0.f} : z[128];
+            const v2f a = zmid;
             pack(a, a, v2f{0.f, -1.f}, gM * gsc, gM * gsc, zk, zm);
             if (lane < kFPW) z[128] = zk;
         }
@@ -374,7 +392,13 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
         DSA_WAVE_SYNC();
         pk_ifft16(v);
 #pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) zf[k1 * 17 + j] = pk_cmul_conj(v[FFT16_OUT(k1)], t256[k1 * 16 + j]);
+        for (int kb = 0; kb < 16; kb += TB) {
+            v2f tw[TB];
+#pragma unroll
+            for (int q = 0; q < TB; ++q) tw[q] = t256[(kb + q) * 16 + j];
+#pragma unroll
+            for (int q = 0; q < TB; ++q) zf[(kb + q) * 17 + j] = pk_cmul_conj(v[FFT16_OUT(kb + q)], tw[q]);
+        }
         DSA_WAVE_SYNC();
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = zf[j * 17 + i];

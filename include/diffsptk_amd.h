@@ -15,7 +15,10 @@
  *  - tensors are dense row-major ("contiguous"); leading batch dims are flattened by the caller;
  *  - `dtype`: DSA_F32 or DSA_F64 (the reference supports both; CI runs float64);
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous
- *    on that stream, re-entrant, and keep no mutable global state: the library allocates NO device memory.
+ *    on that stream, re-entrant, and keep no mutable global state: the library keeps NO device memory (the only
+ *    allocations it makes are transient, stream-ordered hipMallocAsync / hipFreeAsync pairs inside one call: the partial
+ *    spans of dsa_stft_bwd / dsa_istft_fwd for frame geometries other than L = 400, P = 80 -- that geometry runs the
+ *    one-launch kernel that needs none -- and the zero waveform of the generic inverse path).
  *    The tuned kernels need two kinds of workspace, both owned by the caller:
  *      `scratch`  DSA_SCRATCH_BYTES of device memory per call (work-queue counters of the persistent kernels),
  *                 zeroed by the library on `stream`; it must not be shared by calls that can overlap in time (one
@@ -179,7 +182,7 @@ int dsa_div_rows(const void* x, int64_t B, int64_t T, const void* d, double eps,
 /* InverseShortTimeFourierTransform._forward istft.py:186-193 in one call: y:(B,N,nfft/2+1) complex pairs, N =
  * dsa_num_frames(T, P) -> out:(B,T) = overlap-add(w * irfft(y)[:L]) / (d + d_eps); w:(L) synthesis window, d:(T) the
  * overlap-added squared window (unframe.py:203-205), twiddle as dsa_stft_fwd.  Float32 / fft_length 512 runs on the
- * tuned STFT backward kernel (inverse weights while loading, division inside the span gather). */
+ * tuned STFT backward kernels (inverse weights while loading; the division happens as the samples are stored). */
 int dsa_istft_fwd(const void* y, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft, const void* w,
                   const void* twiddle, int32_t center, const void* d, double d_eps, int32_t dtype, int32_t algo,
                   void* out, void* stream);

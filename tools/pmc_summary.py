@@ -9,7 +9,7 @@ from collections import defaultdict
 acc = defaultdict(lambda: [0.0, 0])
 for f in sorted(glob.glob(sys.argv[1] + "/p*/p*_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
-        name = row["Kernel_Name"].split("(")[0][:40]
+        name = row["Kernel_Name"].split("(")[0][:64]
         if not name.startswith("dsa::") and "dsa" not in name:
             continue
         k = (name, row["Counter_Name"])
