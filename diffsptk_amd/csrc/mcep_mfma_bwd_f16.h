@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const __amdgpu_buffer_rsrc_t img_rsrc = image_rsrc(img, IMG_B_BYTES);   // the streamed E / G images (kernel argument: uniform)
     const int n = lane & 15, g = lane >> 4;
 
     // ---------------- operand images and small tables ----------------
@@ -411,16 +412,14 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             f32x4 zb[16];
             float zmax = 0.f;
             {
-                const _Float16* imgt = img;
-                asm volatile("" : "+s"(imgt));
-                const gf16x8_ptr EBH = (gf16x8_ptr)(imgt + IMG_EBH) + lane;
-                const gf16x8_ptr EBL = (gf16x8_ptr)(imgt + IMG_EBL) + lane;
+                const unsigned lane16 = (unsigned)lane * 16u;
 #pragma unroll
                 for (int mt = 0; mt < 16; ++mt) {
                     f32x4 acc = {0, 0, 0, 0};
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        const f16x8 ah = EBH[(mt * 2 + ks) * 64], al = EBL[(mt * 2 + ks) * 64];
+                        const f16x8 ah = gload8(img_rsrc, lane16, 2 * (IMG_EBH + (mt * 2 + ks) * 512));
+                        const f16x8 al = gload8(img_rsrc, lane16, 2 * (IMG_EBL + (mt * 2 + ks) * 512));
                         acc = mfma_h(al, rbh[ks], acc);
                         acc = mfma_h(ah, rbl[ks], acc);
                         acc = mfma_h(ah, rbh[ks], acc);
@@ -501,13 +500,10 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             for (int i = 0; i < 8; ++i) ms[i] = __builtin_ldexpf(m0[i], s_m);
             f16x8 mh8, ml8;
             split8(ms, mh8, ml8);
-            const _Float16* imgt = img;
-            asm volatile("" : "+s"(imgt));
-            const gf16x8_ptr GBH = (gf16x8_ptr)(imgt + IMG_GBH) + lane;
-            const gf16x8_ptr GBL = (gf16x8_ptr)(imgt + IMG_GBL) + lane;
+            const unsigned lane16 = (unsigned)lane * 16u;
 #pragma unroll
             for (int mt = 0; mt < 16; ++mt) {
-                const f16x8 ah = GBH[mt * 64], al = GBL[mt * 64];
+                const f16x8 ah = gload8(img_rsrc, lane16, 2 * (IMG_GBH + mt * 512)), al = gload8(img_rsrc, lane16, 2 * (IMG_GBL + mt * 512));
                 f32x4 acc = {0, 0, 0, 0};
                 acc = mfma_h(al, mh8, acc);
                 acc = mfma_h(ah, ml8, acc);

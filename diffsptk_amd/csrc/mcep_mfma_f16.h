@@ -28,6 +28,19 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // explicit global address space: a pointer that went through an opaque asm statement is otherwise loaded from
 // with FLAT instructions, which count on the LDS counter too and stall every LDS wait behind an L2 round trip
 typedef const __attribute__((address_space(1))) f16x8* gf16x8_ptr;
+// Streaming the operand images from L2: a buffer descriptor over the image block (wave-uniform) + a 32-bit lane offset +
+// a constant -- buffer_load_dwordx4 takes all three without a vector instruction (as 64-bit per-lane pointers the steps
+// beyond the 4 KB immediate cost two carry-chained vector additions per window: 94 vector instructions per tile and step)
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const _Float16* base, int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f16x8 gload8(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_bytes, int const_bytes)
+{
+    const i32x4v r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_bytes, const_bytes, 0);
+    return __builtin_bit_cast(f16x8, r);
+}
 typedef const __attribute__((address_space(1))) float* gf32_ptr;
 
 namespace mh {
