@@ -17,6 +17,12 @@
 //    first): deterministic, last-bit different from before.
 #pragma once
 
+// DSA_SBWD_ABL (ablation bit mask for tools/gpu_ab_lib.sh builds only; 0 in the product): 1 no cotangent loads | 2 no
+// waveform fetch | 4 no stores | 8 no forward transform | 16 no inverse transform | 32 no overlap-add gather
+#ifndef DSA_SBWD_ABL
+#define DSA_SBWD_ABL 0
+#endif
+
 namespace dsa {
 
 __device__ __forceinline__ v2f pk_add_posi_conj(v2f ab, v2f q)   // conj(ab - i q) = (ab.re + q.im, q.re - ab.im)
@@ -179,6 +185,12 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
     // k (gA, gB) and their partners 256 - k (gA2, gB2); gM: bin 128 of frame `lane` (lanes 0..3)
     v2f gA[kFPW], gB[kFPW], gA2[kFPW], gB2[kFPW], gM;
     auto load_g = [&](const Cursor& c) __attribute__((always_inline)) {
+        if (DSA_SBWD_ABL & 1) {
+#pragma unroll
+            for (int f = 0; f < kFPW; ++f) gA[f] = gB[f] = gA2[f] = gB2[f] = v2f{1.f + c.p, 0.5f};
+            gM = v2f{1.f, 1.f};
+            return;
+        }
         const long frame0 = (long)c.p * kFPW;
         const int nvalid = (int)((N - frame0) < kFPW ? (N - frame0) : kFPW);
         // one 64-bit base per pass; everything else is a 32-bit lane offset plus an immediate
@@ -237,6 +249,10 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
     static_assert(CPLX || ((SPAN & 3) == 0 && n4 <= 192), "stretch does not fit the three prefetch registers");
     auto prefetch_x = [&](const Cursor& c) __attribute__((always_inline)) -> bool {
         if constexpr (CPLX) return false;
+        if (DSA_SBWD_ABL & 2) {
+            pre0 = pre1 = pre2 = v4f{0.25f, -0.5f, 1.f, 0.125f};
+            return true;
+        }
         const long g0 = (long)c.p * kFPW * P - left;
         const float* xs = x + c.b * Tlen + g0;
         if (g0 >= 0 && g0 + SPAN <= Tlen && (((size_t)xs) & 15) == 0) {
@@ -296,7 +312,7 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
                 }
             }
             DSA_WAVE_SYNC();
-            pk_fft16<(NR <= 13)>(v);
+            if (!(DSA_SBWD_ABL & 8)) pk_fft16<(NR <= 13)>(v);
             // (the table reads go in batches of TB ahead of the stores they feed: read -> multiply -> store one at a time
             // would wait out an LDS round trip per element -- the compiler cannot move a table read above a tile store)
 #pragma unroll
@@ -311,7 +327,7 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = zf[j * 17 + i];
             DSA_WAVE_SYNC();
-            pk_fft16<false>(v);
+            if (!(DSA_SBWD_ABL & 8)) pk_fft16<false>(v);
 #pragma unroll
             for (int k0 = 0; k0 < 16; ++k0) zf[j + 16 * k0] = v[FFT16_OUT(k0)];   // Z[k] / 2, natural order
             DSA_WAVE_SYNC();
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
 #pragma unroll
         for (int m1 = 0; m1 < 16; ++m1) v[m1] = zf[j + 16 * m1];
         DSA_WAVE_SYNC();
-        pk_ifft16(v);
+        if (!(DSA_SBWD_ABL & 16)) pk_ifft16(v);
 #pragma unroll
         for (int kb = 0; kb < 16; kb += TB) {
             v2f tw[TB];
@@ -403,7 +419,7 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = zf[j * 17 + i];
         DSA_WAVE_SYNC();
-        pk_ifft16(v);
+        if (!(DSA_SBWD_ABL & 16)) pk_ifft16(v);
         // lane j holds time points m = j + 16 k0 = samples 2m, 2m + 1: the forward's register <-> sample map
 #pragma unroll
         for (int k0 = 0; k0 < NR; ++k0) zf[j + 16 * k0] = pk_mul(v[FFT16_OUT(k0)], wrow[k0]);
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
 #pragma unroll
             for (int f = 0; f < kFPW; ++f) {
                 const int lo = 64 * i - P * f;   // l of lane 0
-                if (lo + 63 < 0 || lo >= L) continue;
+                if (lo + 63 < 0 || lo >= L || ((DSA_SBWD_ABL & 32) && f > 0)) continue;
                 const float* gf = reinterpret_cast<const float*>(zbuf + f * kZS);
                 if (lo >= 0 && lo + 63 < L) {
                     acc[i] += gf[lo + lane];
@@ -429,7 +445,7 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
                 }
             }
         }
-        if (!warm) {
+        if (!warm && (!(DSA_SBWD_ABL & 4) || acc[0] == 123.456f)) {
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const long t = g0 + lane + 64 * i;
