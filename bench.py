@@ -325,6 +325,14 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
         k_f = _lib.last_kernel()
         t_fu = gpu_time(lambda: fused(x1024), n=30) * 1e-3
         t_2 = gpu_time(lambda: fb(stft(x1024)), n=30) * 1e-3
+    def fb_fwdbwd(mod):
+        xg = x1024.detach().requires_grad_(True)
+        y = mod(xg)
+        y.backward(torch.ones_like(y))
+
+    t_fu_fb = gpu_time(lambda: fb_fwdbwd(fused), n=10) * 1e-3
+    path_fb = fused.last_path
+    t_2_fb = gpu_time(lambda: fb_fwdbwd(lambda t: fb(stft(t))), n=10) * 1e-3
     pm = pmc_static("stft512_fbank_fwd")
     ipf = pm["derived"]["valu_insts_per_frame"] if pm else None
     fb_bytes = 320 + 4 * 40
@@ -332,6 +340,10 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
         "workload": f"SURVEY 8(f) row 1: STFT -> MelFilterBankAnalysis (40 channels, power domain), {B} utterances x 1 s ({fr} frames), "
                     "one launch (diffsptk_amd.fuse): the (B, N, 257) spectrogram never reaches memory",
         "path": fused.last_path, "frames/s": fr / t_fu, "ms_fused": t_fu * 1e3, "ms_two_kernels": t_2 * 1e3,
+        "fwd_bwd": {"ms_fused": t_fu_fb * 1e3, "ms_two_stage": t_2_fb * 1e3, "path": path_fb,
+                    "note": "forward + backward of sum(y) w.r.t. the waveform through the module API: fused = the one-launch forward, "
+                            "dsa_fbank_bins_bwd (channel cotangents -> bins) and the packed STFT backward, no spectrogram kept; "
+                            "two-stage = STFT and filter bank as separate differentiable modules"},
         "roofline": {"kernel": k_f, "bound": "valu_issue",
                      "achieved": (ipf * fr / t_fu / 1e9) if ipf else None, "peak": VALU_ISSUE_PEAK_GIPS, "unit": "G wave-instr/s",
                      "frac": (ipf * fr / t_fu / 1e9 / VALU_ISSUE_PEAK_GIPS) if ipf else None,

@@ -124,6 +124,8 @@ SIGNATURES = {
     "dsa_fbank_scan_plan": (C.c_int, [_P, _I, _I, _P]),
     "dsa_mgcep_spectra": (C.c_int, [_P, _P, _L, _I, _I, _P, _P, _D, _I, _P, _P]),
     "dsa_stft_fbank_fwd": (C.c_int, [_P, _L, _L, _I, _I, _I, _P, _P, _I, _D, _P, _I, _D, _D, _I, _I, _P, _P]),
+    "dsa_fbank_bins_plan": (C.c_int, [_P, _I, _I, _P]),
+    "dsa_fbank_bins_bwd": (C.c_int, [_P, _P, _L, _I, _I, _P, _D, _D, _I, _P, _P]),
     "dsa_fbank_bwd": (C.c_int, [_P, _P, _P, _L, _I, _P, _I, _D, _D, _I, _I, _P, _P]),
     "dsa_mcep_images_bytes": (C.c_int64, [_I, _I, _I]),
     "dsa_mcep_prepare": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),

@@ -11,7 +11,9 @@
 // frequency-transform kernel (dsa_freqt_fwd).
 #include "common.h"
 
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <type_traits>
 
@@ -665,4 +667,83 @@ DSA_EXPORT int dsa_fbank_dct_fwd(const void* x, int64_t F, int32_t K, const void
     if (rc == DSA_OK) rc = dsa_freqt_fwd(y, F, C, W, Mo, dtype, z, stream);
     (void)hipFreeAsync(y, st);
     return rc;
+}
+
+// ---- cotangent of the filter-bank INPUT from the cotangent of its OUTPUT, for matrices with at most two adjacent
+// channels per bin (the mel / auditory filters): the backward of the fused STFT -> filter-bank launch, which keeps no
+// spectrum.  With y = glog(max(s H, floor)) saved,  d y_c / d (s H)_c = exp(-y_c)  (gamma = 0)  resp.
+// (1 + gamma y_c)^((gamma - 1) / gamma), and 0 where the floor clamped (torch.clip in fbank.py:312), so
+//     g[f][k] = w0[k] Q(f, c_k) + w1[k] Q(f, c_k + 1),   Q(f, c) = gy[f][c] * that factor
+// -- two multiply-adds per bin instead of a (C x K) product (as a dense row product this step cost more than the STFT
+// backward it feeds).  Memory-bound: reads 8 C bytes, writes 4 K bytes per frame.
+namespace dsa {
+__global__ __launch_bounds__(256) void fbank_bins_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, long F, int K,
+                                                             int C, const float4* __restrict__ table, float thr, float gamma,
+                                                             float* __restrict__ g)
+{
+    const long total = F * K;
+    const float ex = gamma == 0.f ? 0.f : (gamma - 1.f) / gamma;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long f = i / K;
+        const int k = (int)(i - f * K);
+        const float4 t = table[k];
+        const int c0 = __float_as_int(t.x);
+        const int c1 = c0 + 1 < C ? c0 + 1 : c0;
+        const float y0 = y[f * C + c0], y1 = y[f * C + c1];
+        const float d0 = gamma == 0.f ? __expf(-y0) : dsa_pow(1.f + gamma * y0, ex);
+        const float d1 = gamma == 0.f ? __expf(-y1) : dsa_pow(1.f + gamma * y1, ex);
+        const float q0 = y0 > thr ? gy[f * C + c0] * d0 : 0.f;
+        const float q1 = y1 > thr ? gy[f * C + c1] * d1 : 0.f;
+        g[i] = t.y * q0 + t.z * q1;
+    }
+}
+}  // namespace dsa
+
+// table[k] = {bits(c_k), w0, w1, 0}: H[k][c_k] = w0, H[k][c_k + 1] = w1 are the only non-zero entries of row k
+// (c_k + 1 == C: w1 = 0).  DSA_ERR_UNSUPPORTED when a row has more, or non-adjacent, non-zero entries.
+DSA_EXPORT int dsa_fbank_bins_plan(const double* H, int32_t K, int32_t C, float* table)
+{
+    DSA_REQUIRE(H && table && K >= 1 && C >= 1, "fbank_bins_plan: bad arguments");
+    for (int k = 0; k < K; ++k) {
+        int first = -1, count = 0, last = -1;
+        for (int c = 0; c < C; ++c) {
+            const double v = H[(size_t)k * C + c];
+            if (!(v == v) || v > 1.7e308 || v < -1.7e308) return fail(DSA_ERR_UNSUPPORTED, "fbank_bins_plan: non-finite matrix%s");
+            if (v != 0.0) {
+                if (first < 0) first = c;
+                last = c;
+                ++count;
+            }
+        }
+        if (count > 2 || (count == 2 && last != first + 1))
+            return fail(DSA_ERR_UNSUPPORTED, "fbank_bins_plan: a bin feeds more than two adjacent channels%s");
+        int c0 = first < 0 ? 0 : first;
+        float w0 = first < 0 ? 0.f : (float)H[(size_t)k * C + c0];
+        float w1 = count == 2 ? (float)H[(size_t)k * C + c0 + 1] : 0.f;
+        int32_t bits = c0;
+        float fb;
+        memcpy(&fb, &bits, 4);
+        table[4 * k + 0] = fb;
+        table[4 * k + 1] = w0;
+        table[4 * k + 2] = w1;
+        table[4 * k + 3] = 0.f;
+    }
+    return DSA_OK;
+}
+
+DSA_EXPORT int dsa_fbank_bins_bwd(const void* gy, const void* y, int64_t F, int32_t K, int32_t C, const void* table, double floor,
+                                  double gamma, int32_t dtype, void* g, void* stream)
+{
+    DSA_REQUIRE(F >= 0 && K >= 1 && C >= 1, "fbank_bins_bwd: sizes must be positive");
+    DSA_REQUIRE(floor > 0 && gamma >= -1 && gamma <= 1, "fbank_bins_bwd: floor must be positive and gamma in [-1, 1]");
+    if (dtype != DSA_F32) return fail(DSA_ERR_UNSUPPORTED, "fbank_bins_bwd: float32 only (the fused forward it differentiates is)%s");
+    if (F == 0) return DSA_OK;
+    // glog(floor) as the forward kernels produce it, plus four units in the last place: their logarithm is the hardware's
+    double thr_d = gamma == 0 ? log(floor) : (pow(floor, gamma) - 1.0) / gamma;
+    const float thr = (float)(thr_d + 4.8e-7 * fabs(thr_d) + 1e-30);
+    long blocks = ((long)F * K + 255) / 256;
+    if (blocks > 256L * 32) blocks = 256L * 32;
+    hipLaunchKernelGGL(dsa::fbank_bins_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)gy,
+                       (const float*)y, (long)F, K, C, (const float4*)table, thr, (float)gamma, (float*)g);
+    return dsa::check_launch("fbank_bins_bwd");
 }

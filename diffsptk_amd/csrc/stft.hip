@@ -2034,7 +2034,7 @@ static int stft_bwd_impl(const void* gy, const void* x, int64_t B, int64_t T, in
                 const char* e = getenv("DSA_STFT_BWD_PK");
                 return e ? atoi(e) : 1;
             }();
-            if (use_pk && !zmean && L == 400 && P == 80 && (cplx || out_format == DSA_SPEC_POWER)) {
+            if (use_pk && !zmean && L == 400 && P == 80 && (cplx || out_format == DSA_SPEC_POWER || out_format == DSA_SPEC_MAG)) {
                 const int ppu = chunks_per_utt;                       // passes of four frames per utterance
                 const long waves = 256L * 16;
                 long want = (waves + B - 1) / B;                       // runs per utterance that fill the chip ...
@@ -2053,11 +2053,15 @@ static int stft_bwd_impl(const void* gy, const void* x, int64_t B, int64_t T, in
                 if (cplx)
                     hipLaunchKernelGGL((stft512_bwd_pk_kernel<400, 80, true>), g2, dim3(256), lds2, st, (const float*)x,
                                        (const float*)gy, (long)T, (long)N, left, (const float*)w, (const float*)twiddle, cs, ce,
-                                       (float*)gx, items, runs, ppu, (const float*)div, (float)div_eps);
+                                       (float*)gx, items, runs, ppu, (const float*)div, (float)div_eps, (float)eps);
+                else if (out_format == DSA_SPEC_MAG)
+                    hipLaunchKernelGGL((stft512_bwd_pk_kernel<400, 80, false, true>), g2, dim3(256), lds2, st, (const float*)x,
+                                       (const float*)gy, (long)T, (long)N, left, (const float*)w, (const float*)twiddle, cs, ce,
+                                       (float*)gx, items, runs, ppu, (const float*)div, (float)div_eps, (float)eps);
                 else
                     hipLaunchKernelGGL((stft512_bwd_pk_kernel<400, 80, false>), g2, dim3(256), lds2, st, (const float*)x,
                                        (const float*)gy, (long)T, (long)N, left, (const float*)w, (const float*)twiddle, cs, ce,
-                                       (float*)gx, items, runs, ppu, (const float*)div, (float)div_eps);
+                                       (float*)gx, items, runs, ppu, (const float*)div, (float)div_eps, (float)eps);
                 return check_launch("stft512_bwd_pk");
             }
             }

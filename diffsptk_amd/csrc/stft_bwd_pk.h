@@ -103,12 +103,15 @@ __device__ __forceinline__ void pk_ifft16(v2f (&v)[16])
 // launcher).  CPLX: the cotangent is complex (format "complex", or the inverse transform with scale 1/512): the
 // waveform is not needed.  `div` != nullptr: the stored value is divided by div[t] + div_eps (Unframe's
 // normalisation, unframe.py:203-205).
-template <int LC, int PC, bool CPLX>
+// MAG (real cotangent only): the cotangent belongs to sqrt(|X|^2 + eps) instead of |X|^2 + eps (spec.py:129, the
+// amplitude-domain filter bank / MFCC front end): one more factor 1 / (2 sqrt(.)) per bin.
+template <int LC, int PC, bool CPLX, bool MAG = false>
 __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
     const float* __restrict__ x, const float* __restrict__ gy, long Tlen, long N, int left, const float* __restrict__ w,
     const float* __restrict__ twiddle, float cot_scale, float cot_edge, float* __restrict__ gx, long total_items,
-    int runs_per_utt, int passes_per_utt, const float* __restrict__ div, float div_eps)
+    int runs_per_utt, int passes_per_utt, const float* __restrict__ div, float div_eps, float eps)
 {
+    static_assert(!(CPLX && MAG), "the magnitude factor belongs to a real cotangent");
     constexpr int L = LC, P = PC, K = 257;
     constexpr int NR = (LC + 31) / 32;          // sample pairs of a lane inside the frame
     constexpr int SPAN = 3 * PC + LC;           // samples a pass touches
@@ -345,8 +348,15 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
             } else {
                 const v2f S = pk_add_conj(a, bq), Dd = pk_sub_conj(a, bq);
                 const v2f Pp = pk_cmul(Dd, W);
-                A = pk_mul_lo(pk_add_negi(S, Pp), g);
-                Bv = pk_mul_hi(pk_add_posi(S, Pp), g);
+                const v2f X1 = pk_add_negi(S, Pp), Y2 = pk_add_posi(S, Pp);   // X[k], conj(X[256 - k])
+                if constexpr (MAG) {
+                    // d sqrt(s) / d s = 1 / (2 sqrt(s)), s = |X|^2 + eps of either bin (v_rsq_f32: 1 ulp)
+                    const float s1 = __builtin_fmaf(X1.x, X1.x, __builtin_fmaf(X1.y, X1.y, eps));
+                    const float s2 = __builtin_fmaf(Y2.x, Y2.x, __builtin_fmaf(Y2.y, Y2.y, eps));
+                    g = v2f{g.x * (0.5f * __builtin_amdgcn_rsqf(s1)), g.y * (0.5f * __builtin_amdgcn_rsqf(s2))};
+                }
+                A = pk_mul_lo(X1, g);
+                Bv = pk_mul_hi(Y2, g);
             }
             const v2f ab = pk_add(A, Bv), amb = pk_sub(A, Bv);
             const v2f Q = pk_cmul_conj(amb, W);

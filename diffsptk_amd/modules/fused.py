@@ -4,8 +4,9 @@ The reference runs ``fbank(stft(x))`` as two modules (README.md:238-243 of the r
 fbank.py:306-321 / mfcc.py:244-256), writing and re-reading the (B, N, 257) power spectrogram in between.  ``fuse``
 keeps exactly those two modules and their semantics, and runs them as ONE kernel launch when the configuration is
 the one the packed STFT kernel serves (csrc/stft_pk.h, ``FBM`` variants): the mel sums come out of the registers that
-hold the power values, as segmented scans over the lanes.  Everything else -- other sizes, options, dtypes, matrices
-without the triangular structure, a needed gradient -- runs the two stages on their own kernels, unchanged."""
+hold the power values, as segmented scans over the lanes.  A gradient flows back through three launches that never
+need the spectrogram either (ops.StftFbankFn).  Everything else -- other sizes, options, dtypes, matrices without the
+triangular structure, learnable tables -- runs the two stages on their own kernels, unchanged."""
 from __future__ import annotations
 
 import torch
@@ -40,15 +41,13 @@ class FusedSTFTFilterBank(nn.Module):
         s, a = self.stft, self.analysis
         if x.dtype != torch.float32 or not x.is_cuda or x.size(-1) < 1:
             return False
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return False   # the fused kernel is forward only
         if any(isinstance(getattr(m, n, None), nn.Parameter) for m in (s, a) for n in ("window", "W", "H")):
             return False   # learnable tables run on the differentiable stages
         if not (s.fmt == _SPEC_POWER and s.mode == "constant" and not s.zmean and s.relative_floor is None
                 and s.fft_length == _FFT and s.frame_length == _FRAME and s.frame_period % 2 == 0
                 and 3 * s.frame_period + 512 <= 2176):
             return False
-        return a.out_format == "y" and ops.fbank_scan_plan(a.H) is not None
+        return a.out_format == "y" and ops.fbank_scan_plan(a.H) is not None and ops.fbank_bins_table(a.H) is not None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         s, a = self.stft, self.analysis
@@ -58,8 +57,10 @@ class FusedSTFTFilterBank(nn.Module):
         self.last_path = "fused"
         is_mfcc = isinstance(a, MelFrequencyCepstralCoefficientsAnalysis)
         use_power = False if is_mfcc else a.use_power          # mfcc.py:200: amplitude domain
-        y = ops.stft_fbank(x, s.window, s.twiddle, s.frame_length, s.frame_period, s.fft_length, s.center, s.eps,
-                           ops.fbank_scan_plan(a.H), a.H.size(1), a.floor, a.gamma, use_power)
+        # with a gradient needed the same launch runs as an autograd Function (backward: channel cotangents -> bins -> the
+        # STFT backward kernel; ops.StftFbankFn)
+        y = ops.StftFbankFn.apply(x, s.window, s.twiddle, a.H, ops.fbank_scan_plan(a.H), s.frame_length, s.frame_period,
+                                  s.fft_length, s.center, s.eps, a.floor, a.gamma, use_power)
         if is_mfcc:   # DCT-II x truncation x lifter (mfcc.py:249-252): one row product on (.., C) values; C0 dropped ("y")
             y = ops.MatmulRowsFn.apply(y, a.W)[..., 1:]
         return y

@@ -7,6 +7,7 @@ hand-written backward kernels).
 """
 from __future__ import annotations
 
+import math
 import weakref
 
 import torch
@@ -616,7 +617,7 @@ def fbank_scan_plan(H: torch.Tensor):
 
 def stft_fbank(x, window, twiddle, L, P, fft_length, center, eps, plan, n_channel, floor, gamma, use_power):
     """y:(..., N, C) = glog(max(s H, floor)) of the STFT power values (or their square roots) in ONE launch
-    (dsa_stft_fbank_fwd: stft.py:148-152 + fbank.py:306-321); forward only."""
+    (dsa_stft_fbank_fwd: stft.py:148-152 + fbank.py:306-321); no autograd graph (StftFbankFn wraps it with one)."""
     _require_device(x, window, twiddle, plan)
     _same_dtype(x, window, twiddle)
     xc, wc = x.contiguous(), window.contiguous()
@@ -627,6 +628,61 @@ def stft_fbank(x, window, twiddle, L, P, fft_length, center, eps, plan, n_channe
         _call("dsa_stft_fbank_fwd", _p(xc), B, T, L, P, fft_length, _p(wc), _p(twiddle), int(center), float(eps), _p(plan),
               int(n_channel), float(floor), float(gamma), int(bool(use_power)), _dtype_code(xc), _p(y), _stream())
     return y
+
+
+_BINS_TABLES: dict = {}   # id(H) -> (weakref to H, version, table or None)
+
+
+def fbank_bins_table(H: torch.Tensor):
+    """Device table of dsa_fbank_bins_bwd for the filter-bank matrix H (dsa_fbank_bins_plan: built on the host, once per
+    matrix and version) -- or None when a bin feeds more than two adjacent channels."""
+    import numpy as np
+
+    key = id(H)
+    hit = _BINS_TABLES.get(key)
+    if hit is not None and hit[0]() is H and hit[1] == H._version:
+        return hit[2]
+    t = None
+    if H.dim() == 2:
+        Hh = np.ascontiguousarray(H.detach().to("cpu", torch.float64).numpy())
+        table = np.zeros(4 * H.size(0), dtype=np.float32)
+        if _lib.load().dsa_fbank_bins_plan(Hh.ctypes.data, int(H.size(0)), int(H.size(1)), table.ctypes.data) == 0:
+            t = torch.from_numpy(table).to(H.device)
+    _BINS_TABLES[key] = (weakref.ref(H), H._version, t)
+    return t
+
+
+class StftFbankFn(torch.autograd.Function):
+    """stft_fbank with a gradient.  Forward: the one-launch kernel (the spectrogram never exists).  Backward, two launches:
+    dsa_fbank_bins_bwd spreads the channel cotangents times d glog / d s (from the SAVED OUTPUT; 0 where the floor clamped, as
+    torch.clip does in fbank.py:312) over the bins -- two multiply-adds per bin, the matrix has two entries per row -- and the
+    result enters dsa_stft_bwd as the cotangent of the power / magnitude spectrum (which it recomputes from the waveform)."""
+
+    @staticmethod
+    def forward(ctx, x, window, twiddle, H, plan, L, P, fft_length, center, eps, floor, gamma, use_power):
+        y = stft_fbank(x, window, twiddle, L, P, fft_length, center, eps, plan, H.size(1), floor, gamma, use_power)
+        ctx.save_for_backward(x.contiguous(), window.contiguous(), twiddle, fbank_bins_table(H), y)
+        ctx.cfg = (L, P, fft_length, center, eps, floor, gamma, use_power, H.size(0), H.size(1))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        xc, wc, twiddle, table, y = ctx.saved_tensors
+        L, P, fft_length, center, eps, floor, gamma, use_power, K, Cn = ctx.cfg
+        gy = gy.contiguous()
+        F = gy.numel() // Cn
+        g = torch.empty(*gy.shape[:-1], K, device=gy.device, dtype=gy.dtype)
+        T = xc.size(-1)
+        B = xc.numel() // T
+        gx = torch.empty_like(xc)
+        with torch.cuda.device(gy.device):
+            _call("dsa_fbank_bins_bwd", _p(gy), _p(y), F, K, Cn, _p(table), float(floor), float(gamma), _dtype_code(gy), _p(g),
+                  _stream())
+            _call("dsa_stft_bwd", _p(g), _p(xc), B, T, L, P, fft_length, _p(wc), _p(twiddle), int(center), 0,
+                  pad_mode_code("constant"), float(eps), 0, 0.0, 3 if use_power else 2, _dtype_code(xc), _lib.ALGO_AUTO,
+                  _p(gx), None, _stream())
+        return (gx,) + (None,) * 12
 
 
 class MfccFn(torch.autograd.Function):

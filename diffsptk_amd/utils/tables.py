@@ -468,3 +468,26 @@ def mgcep_matrices(fft_length: int, cep_order: int, alpha: float):
     base_r, base_i = IR @ pf, II @ pf
     return {"Cr": Cr, "Ci": Ci, "Pr": base_r @ Pt, "Qr": base_r @ Qt, "Qi": base_i @ Qt, "Rr": IR @ rf, "Ri": II @ rf,
             "R1": base_r[:, : M + 1].copy(), "Q1": base_r @ Qt}
+
+
+def fbank_bins_table(H: np.ndarray):
+    """Per-bin table of the fused filter bank's backward (dsa_fbank_bins_bwd; the C twin is dsa_fbank_bins_plan): row k =
+    (bits of c_k as float32, w0, w1, 0) with H[k, c_k] = w0 and H[k, c_k + 1] = w1 the only non-zero entries of row k.
+    None when a bin feeds more than two adjacent channels."""
+    H = np.asarray(H, dtype=np.float64)
+    if H.ndim != 2 or not np.all(np.isfinite(H)):
+        return None
+    K, C = H.shape
+    idx = np.zeros(K, dtype=np.int32)
+    out = np.zeros((K, 4), dtype=np.float32)
+    for k in range(K):
+        nz = np.flatnonzero(H[k])
+        if len(nz) > 2 or (len(nz) == 2 and nz[1] != nz[0] + 1):
+            return None
+        if len(nz):
+            idx[k] = nz[0]
+            out[k, 1] = H[k, nz[0]]
+            if len(nz) == 2:
+                out[k, 2] = H[k, nz[1]]
+    out[:, 0] = idx.view(np.float32)
+    return out

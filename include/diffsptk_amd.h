@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 111 /* 0.1.1: caller-owned workspaces (images / scratch), no library-owned device memory */
+#define DSA_VERSION 112 /* 0.1.2: + backward of the fused STFT -> filter bank (dsa_fbank_bins_plan / dsa_fbank_bins_bwd) */
 
 typedef enum {
     DSA_OK = 0,
@@ -162,13 +162,21 @@ int dsa_fbank_dct_fwd(const void* x, int64_t F, int32_t K, const void* H, int32_
  * HOST from H:(257, C) float64 row-major: it exists when every bin feeds at most two ADJACENT channels, in
  * ascending order along the bins (the triangular mel / auditory filters of fbank.py:232-291; C <= 126) -- otherwise
  * DSA_ERR_UNSUPPORTED, and the two-call path above serves the matrix.  The fused kernel covers float32,
- * fft_length 512, frame_length 400, even frame_period (else DSA_ERR_UNSUPPORTED).  Forward only: training runs the
- * two differentiable stages. */
+ * fft_length 512, frame_length 400, even frame_period (else DSA_ERR_UNSUPPORTED).
+ * Its BACKWARD needs no spectrum either: dsa_fbank_bins_bwd turns the cotangent gy:(F, C) of the output and the saved
+ * output y:(F, C) into the cotangent g:(F, K) of the filter bank's input -- g[k] = w0 Q(c_k) + w1 Q(c_k + 1),
+ * Q(c) = gy_c * dglog/ds at s = glog^-1(y_c), 0 where the floor clamped (fbank.py:312-321 differentiated) -- through the
+ * per-bin `table` (device, 4 K float32: {bits of c_k, w0, w1, 0} per bin) that dsa_fbank_bins_plan builds ON THE HOST from
+ * H:(K, C) float64 (DSA_ERR_UNSUPPORTED when a bin feeds more than two adjacent channels); g then enters dsa_stft_bwd as
+ * the cotangent of the power (use_power) or magnitude spectrum.  float32. */
 #define DSA_FBANK_PLAN_FLOATS 2048
 int dsa_fbank_scan_plan(const double* H_host, int32_t K, int32_t C, float* plan_host);
 int dsa_stft_fbank_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft, const void* w,
                        const void* twiddle, int32_t center, double eps, const void* plan, int32_t C, double floor,
                        double gamma, int32_t use_power, int32_t dtype, void* y, void* stream);
+int dsa_fbank_bins_plan(const double* H_host, int32_t K, int32_t C, float* table_host);
+int dsa_fbank_bins_bwd(const void* gy, const void* y, int64_t F, int32_t K, int32_t C, const void* table, double floor,
+                       double gamma, int32_t dtype, void* g, void* stream);
 
 /* ------------------------------------------------------------------ f2  inverse path
  * RealValuedInverseFastFourierTransform ifftr.py:131-142, Unframe unframe.py:164-211, InverseShortTimeFourier-

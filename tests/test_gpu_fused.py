@@ -122,10 +122,11 @@ def test_fused_falls_back_when_it_must():
     f = dsp.fuse(stft, yE)
     with torch.no_grad():
         assert torch.equal(f(x), yE(stft(x))) and f.last_path == "two-stage"
-    f = dsp.fuse(stft, fb)
+    fbl = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, learnable=True, device=DEV)
+    f = dsp.fuse(stft, fbl)   # a learnable basis: its gradient needs the differentiable stages
     xg = x.clone().requires_grad_(True)
-    f(xg).sum().backward()   # gradient needed: the differentiable stages
-    assert f.last_path == "two-stage" and xg.grad is not None and torch.isfinite(xg.grad).all()
+    f(xg).sum().backward()
+    assert f.last_path == "two-stage" and xg.grad is not None and fbl.H.grad is not None
     with pytest.raises(ValueError):
         dsp.fuse(dsp.STFT(400, 80, 1024, device=DEV), fb)
 
@@ -146,3 +147,61 @@ def test_fused_nonfinite_sample_stays_in_its_frames():
     for out in (y, y2):
         assert torch.equal((~torch.isfinite(out)).all(-1), bad) and torch.equal((~torch.isfinite(out)).any(-1), bad)
     np.testing.assert_allclose(host(y[~bad]), host(y2[~bad]), rtol=0, atol=2e-5)
+
+
+def _float64_fbank_gradient(x, cot, C, sr, use_power, gamma, floor=1e-5):
+    from oracle import torch_port as TP
+    H = torch.from_numpy(np.asarray(tables.fbank_matrix(512, C, sr, 0.0, None, "htk", None))).double()
+    xr = x.double().clone().requires_grad_(True)
+    Pw = TP.stft_power(xr, 400, 80, 512)
+    s = torch.clip((Pw if use_power else torch.sqrt(Pw)) @ H, min=floor)   # fbank.py:306-321
+    y = torch.log(s) if gamma == 0 else (torch.pow(s, gamma) - 1) / gamma
+    (y * cot.double()).sum().backward()
+    return xr.grad
+
+
+@pytest.mark.parametrize("C,sr,use_power,gamma", [(40, 16000, True, 0.0), (40, 16000, False, 0.0), (80, 22050, True, -0.3),
+                                                  (24, 16000, False, 0.4), (126, 48000, True, 0.0)])
+def test_fused_gradient_matches_float64_autograd_and_the_two_stage_path(C, sr, use_power, gamma):
+    """With a gradient needed the fused launch still runs (forward) and its backward -- channel cotangents spread over the
+    bins (dsa_fbank_bins_bwd), then the STFT backward kernel -- never needs the spectrogram.  Against float64 autograd of
+    the reference's formulation and against the two differentiable stages: 1e-5 of the utterance's largest gradient entry
+    (measured 4e-7 .. 4e-6; levels 1e-2 .. 30)."""
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(3, 8000, generator=g) * torch.tensor([1e-2, 1.0, 30.0]).view(3, 1)
+    stft = dsp.STFT(400, 80, 512, device=DEV)
+    fb = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=C, sample_rate=sr, use_power=use_power, gamma=gamma, device=DEV)
+    fused = dsp.fuse(stft, fb)
+    xa = x.to(DEV).requires_grad_(True)
+    ya = fused(xa)
+    assert fused.last_path == "fused"
+    cot = torch.randn(ya.shape, generator=g)
+    (ga,) = torch.autograd.grad(ya, xa, cot.to(DEV))
+    xb = x.to(DEV).requires_grad_(True)
+    (gb,) = torch.autograd.grad(fb(stft(xb)), xb, cot.to(DEV))
+    ref = _float64_fbank_gradient(x, cot, C, sr, use_power, gamma)
+    scale = ref.abs().amax(-1)
+    assert float(((ga.cpu().double() - ref).abs().amax(-1) / scale).max()) < 1e-5
+    assert float(((ga - gb).abs().amax(-1).cpu().double() / scale).max()) < 1e-5
+
+
+def test_fused_mfcc_gradient_and_floor_clamp():
+    """MFCC on top of the fused launch (amplitude domain, DCT + lifter as one row product) back-propagates like the two
+    stages; a silent utterance sits on the floor in every channel: its gradient is exactly zero, as torch.clip's is."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(4, 4000, generator=g)
+    x[2] = 0.0
+    stft = dsp.STFT(400, 80, 512, device=DEV)
+    mf = dsp.MFCC(fft_length=512, mfcc_order=12, n_channel=40, sample_rate=16000, lifter=22, device=DEV)
+    fused = dsp.fuse(stft, mf)
+    xa = x.to(DEV).requires_grad_(True)
+    ya = fused(xa)
+    cot = torch.randn(ya.shape, generator=g).to(DEV)
+    (ga,) = torch.autograd.grad(ya, xa, cot)
+    assert fused.last_path == "fused"
+    xb = x.to(DEV).requires_grad_(True)
+    (gb,) = torch.autograd.grad(mf(stft(xb)), xb, cot)
+    assert torch.equal(ga[2], torch.zeros_like(ga[2])) and torch.equal(gb[2], torch.zeros_like(gb[2]))
+    keep = [0, 1, 3]
+    scale = gb[keep].abs().amax(-1)
+    assert float(((ga[keep] - gb[keep]).abs().amax(-1) / scale).max()) < 1e-5

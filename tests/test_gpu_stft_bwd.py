@@ -60,6 +60,22 @@ def test_power_gradient_matches_float64_autograd(shape, center):
     assert float(err.max()) < 2e-6
 
 
+def test_magnitude_gradient_matches_float64_autograd():
+    """out_format "magnitude" (spec.py:129: sqrt(|X|^2 + eps)) on the same kernel with one more factor per bin."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 8000, generator=g) * torch.tensor([1e-3, 1.0, 100.0]).view(3, 1)
+    st = dsp.STFT(400, 80, 512, out_format="magnitude", device=DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    y = st(xd)
+    wt = torch.randn(y.shape, generator=g)
+    gx, kern = grad_and_kernel(y, xd, wt.to(DEV))
+    assert kern == "stft512_bwd_pk"
+    xr = x.double().clone().requires_grad_(True)
+    (torch.sqrt(TP.stft_power(xr, 400, 80, 512)) * wt.double()).sum().backward()
+    err = (gx.cpu().double() - xr.grad).abs().amax(-1) / xr.grad.abs().amax(-1)
+    assert float(err.max()) < 2e-6
+
+
 def test_gradient_does_not_depend_on_the_run_partition():
     """An utterance alone or among 3 / 300 copies (its 50 passes cut into 12 runs) and among 1024 copies (4 runs):
     bit-identical gradients -- the carried partial sums of a run's warm-up pass are the same
@@ -131,7 +147,7 @@ def test_complex_cotangent_and_inverse_stft_against_the_oracle():
 def test_other_geometries_keep_their_kernels():
     x = torch.randn(2, 4000, generator=torch.Generator().manual_seed(14)).to(DEV)
     for st in (dsp.STFT(320, 80, 512, device=DEV), dsp.STFT(400, 100, 512, device=DEV), dsp.STFT(400, 80, 512, zmean=True, device=DEV),
-               dsp.STFT(400, 80, 512, out_format="magnitude", device=DEV)):
+               dsp.STFT(400, 80, 512, out_format="log-magnitude", device=DEV)):
         xd = x.clone().requires_grad_(True)
         y = st(xd)
         gx, kern = grad_and_kernel(y, xd, torch.ones_like(y))

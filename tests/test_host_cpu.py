@@ -31,7 +31,7 @@ def test_library_exports_every_header_symbol():
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert _lib.load().dsa_version() == 111
+    assert _lib.load().dsa_version() == 112
     assert _lib.load().dsa_num_frames(16000, 80) == 200
     assert _lib.load().dsa_num_frames(19200, 80) == 240
 
@@ -341,3 +341,25 @@ def test_fbank_scan_plan_c_and_python_agree_and_the_lane_model_matches_the_matri
         assert tables.fbank_scan_plan(Hb) is None
     H127 = np.zeros((257, 127))
     assert lib.dsa_fbank_scan_plan(H127.ctypes.data, 257, 127, table.ctypes.data) == _lib.ERR_UNSUPPORTED
+
+
+def test_fbank_bins_table_c_and_python_agree_and_reproduce_the_matrix():
+    """The per-bin table of the fused filter bank's backward (dsa_fbank_bins_plan, host code of the library) equals its
+    Python twin bit for bit, and spreading channel values through it IS the product with H^T."""
+    lib = _lib.load()
+    rng = np.random.default_rng(2)
+    for C, sr in ((40, 16000), (80, 22050), (3, 8000), (126, 48000)):
+        H = np.ascontiguousarray(np.asarray(tables.fbank_matrix(512, C, sr, 0.0, None, "htk", None), dtype=np.float64))
+        t = np.zeros(4 * 257, dtype=np.float32)
+        assert lib.dsa_fbank_bins_plan(H.ctypes.data, 257, C, t.ctypes.data) == 0
+        tp = tables.fbank_bins_table(H)
+        assert np.array_equal(t.view(np.uint32), tp.reshape(-1).view(np.uint32))
+        c0 = tp[:, 0].copy().view(np.int32)
+        c1 = np.minimum(c0 + 1, C - 1)
+        q = rng.standard_normal((5, C))
+        g = tp[:, 1] * q[:, c0] + tp[:, 2] * q[:, c1]
+        np.testing.assert_allclose(g, q @ H.astype(np.float32).astype(np.float64).T, rtol=1e-12, atol=1e-12)
+    Hb = rng.random((257, 5))   # dense rows: not a two-channels-per-bin matrix
+    t = np.zeros(4 * 257, dtype=np.float32)
+    assert lib.dsa_fbank_bins_plan(np.ascontiguousarray(Hb).ctypes.data, 257, 5, t.ctypes.data) == _lib.ERR_UNSUPPORTED
+    assert tables.fbank_bins_table(Hb) is None
