@@ -12,8 +12,8 @@ from collections import defaultdict
 # <0, 400, true, 1|2> of the same template as the spectrum-out kernel <0, 400, true, 0>
 KERNELS = {"mcep_mfma_fwd": ("mcep_mfma_fwd_kernel_h", None), "stft512_fwd": ("stft512_fwd_pk_kernel<0, 400, true, 0>", None),
            "stft512_fbank_fwd": ("stft512_fwd_pk_kernel<0, 400, true, 1>", None),
-           "mcep_mfma_bwd": ("mcep_mfma_bwd_kernel_h", None), "stft512_bwd": ("stft512_bwd_pk_kernel<400, 80, false>", None),
-           "stft512_istft": ("stft512_bwd_pk_kernel<400, 80, true>", None)}
+           "mcep_mfma_bwd": ("mcep_mfma_bwd_kernel_h", None), "stft512_bwd": ("stft512_bwd_pk_kernel<400, 80, false, false>", None),
+           "stft512_istft": ("stft512_bwd_pk_kernel<400, 80, true, false>", None)}
 WAVES_PER_SIMD = {"mcep_mfma_fwd": 2, "stft512_fwd": 4, "stft512_fbank_fwd": 4, "mcep_mfma_bwd": 1, "stft512_bwd": 4, "stft512_istft": 4}
 FRAMES = 204800
 
