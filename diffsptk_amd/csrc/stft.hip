@@ -1358,21 +1358,22 @@ __global__ __launch_bounds__((PLAIN || CPLX) ? 128 : 64, (PLAIN || CPLX) ? 4 : D
 // outside [0, T) are dropped for constant padding -- other modes use the generic backward).
 // div != nullptr (inverse STFT): the sum is divided by div[t] + div_eps, the overlap-added squared window
 // (unframe.py:203-205), so Unframe's division costs no pass of its own.
-__global__ void stft_span_gather_kernel(const float* __restrict__ part, long Tlen, int P, int left, int span,
+__global__ void stft_span_gather_kernel(const float* __restrict__ part, long B, long Tlen, int P, int left, int span,
                                         int chunks_per_utt, float* __restrict__ gx, const float* __restrict__ div,
                                         float div_eps)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long b = blockIdx.y;
     if (t >= Tlen) return;
     const long p = t + left;          // position in the padded signal
     const long stride = (long)kFPW * P;  // pass c starts at padded position c * stride
     long c_hi = p / stride;
     if (c_hi > chunks_per_utt - 1) c_hi = chunks_per_utt - 1;
     long c_lo = p - span + 1 <= 0 ? 0 : (p - span + stride) / stride;
-    float acc = 0.f;
-    for (long c = c_lo; c <= c_hi; ++c) acc += part[(b * chunks_per_utt + c) * (long)span + (p - c * stride)];
-    gx[b * Tlen + t] = div ? acc / (div[t] + div_eps) : acc;
+    for (long b = blockIdx.y; b < B; b += gridDim.y) {   // grid.y is capped at 65535 utterances
+        float acc = 0.f;
+        for (long c = c_lo; c <= c_hi; ++c) acc += part[(b * chunks_per_utt + c) * (long)span + (p - c * stride)];
+        gx[b * Tlen + t] = div ? acc / (div[t] + div_eps) : acc;
+    }
 }
 
 static int stft512_lds_bytes(int L, int P, int* io_floats)
@@ -2107,8 +2108,8 @@ static int stft_bwd_impl(const void* gy, const void* x, int64_t B, int64_t T, in
 #undef DSA_STFT_BWD_LAUNCH
             int rc = check_launch("stft512_bwd");
             if (rc == DSA_OK) {
-                dim3 g2((unsigned)((T + 255) / 256), (unsigned)B);
-                hipLaunchKernelGGL(stft_span_gather_kernel, g2, dim3(256), 0, st, (const float*)part, (long)T, P, left,
+                dim3 g2((unsigned)((T + 255) / 256), (unsigned)(B < 65535 ? B : 65535));
+                hipLaunchKernelGGL(stft_span_gather_kernel, g2, dim3(256), 0, st, (const float*)part, (long)B, (long)T, P, left,
                                    span, chunks_per_utt, (float*)gx, (const float*)div, (float)div_eps);
                 rc = check_launch("stft512_bwd");
             }
