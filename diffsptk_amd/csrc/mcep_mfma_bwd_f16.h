@@ -198,6 +198,19 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             float mcv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) mcv[i] = (8 * g + i < M1) ? hist[((long)iter * F + f) * M1 + 8 * g + i] : 0.f;
+            // The step's own solution g = A^-1 (rt[:25] - alpha) is the difference of two SAVED iterates (mcep.py:224:
+            // mc <- mc + g) for every step but the last one, whose result is not in the history: there the second
+            // back substitution recomputes it.  Fetched here, in the solve's quad layout (k = gs + 4 c), used after the solve.
+            const bool g_saved = iter + 1 < n_iter;
+            float gh[KS];
+            if (g_saved) {
+                const long fq_raw = tile * 16 + nq;
+                const float* h0 = hist + ((long)iter * F + (fq_raw < F ? fq_raw : F - 1)) * M1;
+                const float* h1 = h0 + F * M1;
+#pragma unroll
+                for (int c = 0; c < KS - 1; ++c) gh[c] = h1[gs + 4 * c] - h0[gs + 4 * c];
+                gh[KS - 1] = keep_if(gq.m[0], h1[M1 - 1] - h0[M1 - 1]);   // k = 24 on lane 0 only
+            }
             // ---------------- forward quantities of this step: e (kept, scaled by 2^sh), rt -> LDS windows ----------------
             f16x8 bh, bl;
             {
@@ -315,10 +328,15 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
                 }
                 __builtin_amdgcn_wave_barrier();
                 col_elim_all(a, std::make_integer_sequence<int, M1>{});
-                col_backsub_all(a, xq1, gq, std::make_integer_sequence<int, M1>{});
+                if (g_saved) {
+#pragma unroll
+                    for (int c = 0; c < KS; ++c) xq1[c] = gh[c];
+                } else {
+                    col_backsub_all(a, xq1, gq, std::make_integer_sequence<int, M1>{});
+                    xq1[KS - 1] = keep_if(gq.m[0], xq1[KS - 1]);
+                }
                 col_backsub_all(a, xq2, gq, std::make_integer_sequence<int, M1>{});
                 // slot 6 holds x[24] on lane 0 only (the other lanes' slot 6 are the right-hand-side markers)
-                xq1[KS - 1] = keep_if(gq.m[0], xq1[KS - 1]);
                 xq2[KS - 1] = keep_if(gq.m[0], xq2[KS - 1]);
             }
             BSTAMP(2);
