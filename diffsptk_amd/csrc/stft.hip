@@ -2035,7 +2035,7 @@ static int stft_bwd_impl(const void* gy, const void* x, int64_t B, int64_t T, in
                 const char* e = getenv("DSA_STFT_BWD_PK");
                 return e ? atoi(e) : 1;
             }();
-            if (use_pk && !zmean && L == 400 && P == 80 && (cplx || out_format == DSA_SPEC_POWER || out_format == DSA_SPEC_MAG)) {
+            if (use_pk && !zmean && L == 400 && (P == 80 || P == 160) && (cplx || out_format == DSA_SPEC_POWER || out_format == DSA_SPEC_MAG)) {
                 const int ppu = chunks_per_utt;                       // passes of four frames per utterance
                 const long waves = 256L * 16;
                 long want = (waves + B - 1) / B;                       // runs per utterance that fill the chip ...
@@ -2051,18 +2051,21 @@ static int stft_bwd_impl(const void* gy, const void* x, int64_t B, int64_t T, in
                 const int lds2 = 4 * kFPW * kZS * 8 + 256 * 8 + 16 * 13 * 8;
                 const float cs = out_format == DSA_SPEC_COMPLEX_INV ? 1.f / 512.f : 0.5f;
                 const float ce = out_format == DSA_SPEC_COMPLEX_INV ? 1.f : 2.f;
-                if (cplx)
-                    hipLaunchKernelGGL((stft512_bwd_pk_kernel<400, 80, true>), g2, dim3(256), lds2, st, (const float*)x,
-                                       (const float*)gy, (long)T, (long)N, left, (const float*)w, (const float*)twiddle, cs, ce,
-                                       (float*)gx, items, runs, ppu, (const float*)div, (float)div_eps, (float)eps);
-                else if (out_format == DSA_SPEC_MAG)
-                    hipLaunchKernelGGL((stft512_bwd_pk_kernel<400, 80, false, true>), g2, dim3(256), lds2, st, (const float*)x,
-                                       (const float*)gy, (long)T, (long)N, left, (const float*)w, (const float*)twiddle, cs, ce,
-                                       (float*)gx, items, runs, ppu, (const float*)div, (float)div_eps, (float)eps);
-                else
-                    hipLaunchKernelGGL((stft512_bwd_pk_kernel<400, 80, false>), g2, dim3(256), lds2, st, (const float*)x,
-                                       (const float*)gy, (long)T, (long)N, left, (const float*)w, (const float*)twiddle, cs, ce,
-                                       (float*)gx, items, runs, ppu, (const float*)div, (float)div_eps, (float)eps);
+                // frame periods of 5 ms and 10 ms at 16 kHz (the 25 ms window): one instantiation each
+#define DSA_STFT_BWD_PK_LAUNCH(PC, CP, MG)                                                                                   \
+    hipLaunchKernelGGL((stft512_bwd_pk_kernel<400, PC, CP, MG>), g2, dim3(256), lds2, st, (const float*)x, (const float*)gy, \
+                       (long)T, (long)N, left, (const float*)w, (const float*)twiddle, cs, ce, (float*)gx, items, runs, ppu,   \
+                       (const float*)div, (float)div_eps, (float)eps)
+                if (P == 80) {
+                    if (cplx) DSA_STFT_BWD_PK_LAUNCH(80, true, false);
+                    else if (out_format == DSA_SPEC_MAG) DSA_STFT_BWD_PK_LAUNCH(80, false, true);
+                    else DSA_STFT_BWD_PK_LAUNCH(80, false, false);
+                } else {
+                    if (cplx) DSA_STFT_BWD_PK_LAUNCH(160, true, false);
+                    else if (out_format == DSA_SPEC_MAG) DSA_STFT_BWD_PK_LAUNCH(160, false, true);
+                    else DSA_STFT_BWD_PK_LAUNCH(160, false, false);
+                }
+#undef DSA_STFT_BWD_PK_LAUNCH
                 return check_launch("stft512_bwd_pk");
             }
             }

@@ -99,8 +99,8 @@ __device__ __forceinline__ void pk_ifft16(v2f (&v)[16])
     pk_idft4(v[12], v[13], v[14], v[15]);
 }
 
-// LC / PC: frame length and period at compile time (LC <= 512, PC a multiple of 16, LC - PC <= 4 PC <= 320 + ...: see the
-// launcher).  CPLX: the cotangent is complex (format "complex", or the inverse transform with scale 1/512): the
+// LC / PC: frame length and period at compile time (LC <= 512, PC a multiple of 16, LC - PC <= 4 PC: one warm-up pass
+// covers everything a run inherits; instantiated for 400 / 80 and 400 / 160, see the launcher).  CPLX: the cotangent is complex (format "complex", or the inverse transform with scale 1/512): the
 // waveform is not needed.  `div` != nullptr: the stored value is divided by div[t] + div_eps (Unframe's
 // normalisation, unframe.py:203-205).
 // MAG (real cotangent only): the cotangent belongs to sqrt(|X|^2 + eps) instead of |X|^2 + eps (spec.py:129, the
@@ -247,22 +247,25 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
     };
     // the stretch of samples a pass's four frames share: fetched into registers one pass ahead (interior, aligned
     // stretches), written to the tile when the pass begins
-    v4f pre0 = v4f{0.f, 0.f, 0.f, 0.f}, pre1 = pre0, pre2 = pre0;
     constexpr int n4 = SPAN >> 2;
-    static_assert(CPLX || ((SPAN & 3) == 0 && n4 <= 192), "stretch does not fit the three prefetch registers");
+    constexpr int NPRE = (n4 + 63) / 64;   // 16-byte fetches per lane and stretch
+    static_assert(CPLX || (SPAN & 3) == 0, "the stretch is fetched in 16-byte pieces");
+    v4f pre[NPRE];
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) pre[q] = v4f{0.f, 0.f, 0.f, 0.f};
     auto prefetch_x = [&](const Cursor& c) __attribute__((always_inline)) -> bool {
         if constexpr (CPLX) return false;
         if (DSA_SBWD_ABL & 2) {
-            pre0 = pre1 = pre2 = v4f{0.25f, -0.5f, 1.f, 0.125f};
+#pragma unroll
+            for (int q = 0; q < NPRE; ++q) pre[q] = v4f{0.25f, -0.5f, 1.f, 0.125f};
             return true;
         }
         const long g0 = (long)c.p * kFPW * P - left;
         const float* xs = x + c.b * Tlen + g0;
         if (g0 >= 0 && g0 + SPAN <= Tlen && (((size_t)xs) & 15) == 0) {
             const v4f* src4 = reinterpret_cast<const v4f*>(xs);
-            pre0 = src4[lane < n4 ? lane : n4 - 1];
-            pre1 = src4[lane + 64 < n4 ? lane + 64 : n4 - 1];
-            pre2 = src4[lane + 128 < n4 ? lane + 128 : n4 - 1];
+#pragma unroll
+            for (int q = 0; q < NPRE; ++q) pre[q] = src4[lane + 64 * q < n4 ? lane + 64 * q : n4 - 1];
             return true;
         }
         return false;
@@ -285,11 +288,12 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
         if constexpr (!CPLX) {
             // ---- the stretch into the tile ----
             if (pre_ok) {
-                asm volatile("" : "+v"(pre0), "+v"(pre1), "+v"(pre2) : : "memory");
+#pragma unroll
+                for (int q = 0; q < NPRE; ++q) asm volatile("" : "+v"(pre[q]) : : "memory");
                 v4f* dst4 = reinterpret_cast<v4f*>(io_buf);
-                if (lane < n4) dst4[lane] = pre0;
-                if (lane + 64 < n4) dst4[lane + 64] = pre1;
-                if (lane + 128 < n4) dst4[lane + 128] = pre2;
+#pragma unroll
+                for (int q = 0; q < NPRE; ++q)
+                    if (lane + 64 * q < n4) dst4[lane + 64 * q] = pre[q];
             } else {
                 const float* xb = x + cur.b * Tlen;
                 for (int s = lane; s < SPAN; s += 64) io_buf[s] = load_padded(xb, g0 + s, Tlen, (int)DSA_PAD_CONSTANT);

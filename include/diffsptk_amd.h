@@ -17,7 +17,7 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous
  *    on that stream, re-entrant, and keep no mutable global state: the library keeps NO device memory (the only
  *    allocations it makes are transient, stream-ordered hipMallocAsync / hipFreeAsync pairs inside one call: the partial
- *    spans of dsa_stft_bwd / dsa_istft_fwd for frame geometries other than L = 400, P = 80 -- that geometry runs the
+ *    spans of dsa_stft_bwd / dsa_istft_fwd for frame geometries other than L = 400, P = 80 / 160 -- those run the
  *    one-launch kernel that needs none -- and the zero waveform of the generic inverse path).
  *    The tuned kernels need two kinds of workspace, both owned by the caller:
  *      `scratch`  DSA_SCRATCH_BYTES of device memory per call (work-queue counters of the persistent kernels),

@@ -76,6 +76,46 @@ def test_magnitude_gradient_matches_float64_autograd():
     assert float(err.max()) < 2e-6
 
 
+@pytest.mark.parametrize("shape,center", [((3, 16000), True), ((2, 4001), True), ((5, 1283), False), ((2, 159), True)])
+def test_ten_millisecond_period_runs_the_same_kernel(shape, center):
+    """frame_period 160 (25 ms window, 10 ms hop at 16 kHz): its own instantiation (two carried / ten stored samples per
+    lane and pass): power and magnitude gradients against float64 autograd, the inverse STFT against the oracle, and the
+    run-partition invariance."""
+    g = torch.Generator().manual_seed(shape[-1])
+    x = torch.randn(*shape, generator=g)
+    for fmt in ("power", "magnitude"):
+        st = dsp.STFT(400, 160, 512, center=center, out_format=fmt, device=DEV)
+        xd = x.to(DEV).requires_grad_(True)
+        y = st(xd)
+        wt = torch.randn(y.shape, generator=g)
+        gx, kern = grad_and_kernel(y, xd, wt.to(DEV))
+        assert kern == "stft512_bwd_pk"
+        xr = x.double().clone().requires_grad_(True)
+        Pw = TP.stft_power(xr, 400, 160, 512, center=center)
+        ((Pw if fmt == "power" else torch.sqrt(Pw)) * wt.double()).sum().backward()
+        err = (gx.cpu().double() - xr.grad).abs().amax(-1) / xr.grad.abs().amax(-1)
+        assert float(err.max()) < 2e-6, fmt
+    if center:
+        stc = dsp.STFT(400, 160, 512, out_format="complex", device=DEV)
+        ist = dsp.ISTFT(400, 160, 512, device=DEV)
+        with torch.no_grad():
+            yc = stc(x.to(DEV))
+            xr32 = ist(yc, out_length=shape[-1])
+        assert _lib.last_kernel() == "stft512_bwd_pk"
+        ref = O.istft(host(yc).astype(np.complex128), 400, 160, w=O.window_table(400, "blackman", "power", True), out_length=shape[-1])
+        np.testing.assert_allclose(host(xr32), ref, rtol=0, atol=2e-6 * np.abs(ref).max())
+    if shape == (3, 16000):   # alone (100 frames = 25 passes in 6 runs) and among 1024 copies (4 runs): bit-identical
+        st = dsp.STFT(400, 160, 512, device=DEV)
+        wt1 = torch.randn(1, 100, 257, generator=g).to(DEV)
+        outs = []
+        for B in (1, 1024):
+            xd = x[:1].expand(B, -1).contiguous().to(DEV).requires_grad_(True)
+            (gx,) = torch.autograd.grad(st(xd), xd, wt1.expand(B, -1, -1).contiguous())
+            assert torch.equal(gx, gx[:1].expand_as(gx))
+            outs.append(gx[0].clone())
+        assert torch.equal(outs[0], outs[1])
+
+
 def test_gradient_does_not_depend_on_the_run_partition():
     """An utterance alone or among 3 / 300 copies (its 50 passes cut into 12 runs) and among 1024 copies (4 runs):
     bit-identical gradients -- the carried partial sums of a run's warm-up pass are the same
