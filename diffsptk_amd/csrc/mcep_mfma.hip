@@ -252,6 +252,77 @@ __device__ __forceinline__ void col_backsub_all(const float (&a)[colm::TOTAL], f
     ((void)col_backsub_step<mm::M1 - 1 - Ks>(a, xq, gq), ...);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The same solve for the Toeplitz-plus-Hankel systems of the mel-generalized cepstral analysis (mgcep.py:226-229:
+// solve(symmetric_toeplitz(p) + hankel(q), r), n = 24 = the cepstral order): 16 systems per wave in the quad layout, no
+// pivoting -- the matrix is the Hessian of a criterion that is convex for -1 <= gamma <= 0 (SPTK's theq() solves it
+// without pivoting for the same reason).  The 24 x 24 system rides in the 25 x 25 machinery with row / column 24 as an
+// identity pair: row 24 stores slot 6 only (diagonal 1 on lane 0, right-hand side 0 on lane 1) and column 24 of the other
+// rows comes through the slot-6 pointers as zeros, so it never couples.  One system per wave with a pivot search
+// (th_solve_reg, csrc/mgc.hip) took 0.2 ms per 51 200 systems; this takes ~20 us.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTq = 136;   // floats per system in LDS: q window [0, 52) | mirrored p window [52, 104) | r [104, 132) (136 % 32 = 8)
+__global__ __launch_bounds__(256) void thsolve_quad24_kernel(const float* __restrict__ p, const float* __restrict__ q,
+                                                             const float* __restrict__ r, long F, float* __restrict__ g)
+{
+    using namespace mm;
+    __shared__ __attribute__((aligned(16))) float lds[4 * 16 * kTq + 64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* wl = lds + wave * 16 * kTq;
+    float* cst = lds + 4 * 16 * kTq;           // [0, 28): zeros | [32, 57): e_24
+    if (threadIdx.x < 64) cst[threadIdx.x] = threadIdx.x == 32 + 24 ? 1.f : 0.f;
+    __syncthreads();
+    const int nq = lane >> 2, gs = lane & 3;
+    const GroupMask gq = make_group_mask(gs);
+    const long ntiles = (F + 15) / 16;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        __builtin_amdgcn_wave_barrier();
+        // stage: every lane fills a share of the 16 records (missing systems: the identity, right-hand side 0)
+        for (int e = lane; e < 16 * kTq; e += 64) {
+            const int fr = e / kTq, k = e - fr * kTq;
+            const long f = tile * 16 + fr;
+            float v = 0.f;
+            if (f < F) {
+                if (k < 52) v = k < 47 ? q[f * 47 + k] : 0.f;
+                else if (k < 104) {
+                    const int d = k - 52 - 27, ad = d < 0 ? -d : d;
+                    v = ad < 24 ? p[f * 24 + ad] : 0.f;
+                } else if (k < 104 + 24) v = r[f * 24 + (k - 104)];
+            } else if (k == 52 + 27) v = 1.f;   // p[0] = 1: a regular (identity) system
+            wl[e] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float* rt_q = wl + nq * kTq;
+        const float* rr_q = rt_q + 52;
+        float xq[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[1], -1.f)};
+        {
+            float a[colm::TOTAL];
+            int gsv = gs;
+            asm volatile("" : "+v"(gsv));
+            const float* zr = cst;
+            const float* pa6 = gsv == 0 ? cst + 32 : (gsv == 1 ? rt_q + 104 : zr);   // column 24: e_24 | right-hand side | 0
+            col_build_rows_p<0>(a, rt_q, rr_q, pa6, zr, gs);
+            col_elim_all(a, std::make_integer_sequence<int, M1>{});
+            col_backsub_all(a, xq, gq, std::make_integer_sequence<int, M1>{});
+        }
+        const long f = tile * 16 + nq;
+        if (f < F) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) g[f * 24 + gs + 4 * c] = xq[c];
+        }
+    }
+}
+
+int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, void* g, hipStream_t st)
+{
+    long blocks = ((F + 15) / 16 + 3) / 4;
+    if (blocks > 256L * 4) blocks = 256L * 4;
+    hipLaunchKernelGGL(thsolve_quad24_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)p, (const float*)q,
+                       (const float*)r, (long)F, (float*)g);
+    return check_launch("th_solve_quad_fwd");
+}
+
 }  // namespace dsa
 #include "mcep_mfma_f16.h"
 #include "mcep_mfma_bwd_f16.h"

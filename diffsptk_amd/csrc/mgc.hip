@@ -569,6 +569,12 @@ DSA_EXPORT int dsa_thsolve_fwd(const void* p, const void* q, const void* r, int6
 {
     DSA_REQUIRE(n >= 1 && n <= kThMax && F >= 0, "thsolve: order must be in [1, 64]");
     if (F == 0) return DSA_OK;
+    // cepstral order 24, float32: the unpivoted quad-layout solve of the mel-cepstral kernels (DSA_THSOLVE_QUAD=0: A/B)
+    static const bool quad = [] {
+        const char* e = getenv("DSA_THSOLVE_QUAD");
+        return !e || atoi(e) != 0;
+    }();
+    if (dtype == DSA_F32 && n == 24 && quad && F > 0) return thsolve_quad24_fwd(p, q, r, F, g, (hipStream_t)stream);
     if (dtype == DSA_F32) return th_launch<float>(false, nullptr, p, q, r, F, n, g, nullptr, nullptr, (hipStream_t)stream);
     if (dtype == DSA_F64) return th_launch<double>(false, nullptr, p, q, r, F, n, g, nullptr, nullptr, (hipStream_t)stream);
     return fail(DSA_ERR_UNSUPPORTED, "thsolve: unsupported dtype%s");

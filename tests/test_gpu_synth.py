@@ -94,8 +94,27 @@ def test_thsolve_kernel_vs_numpy_and_gradcheck():
         ref = np.linalg.solve(A, r[..., None])[..., 0]
         for dt, tol in ((torch.float64, 1e-9), (torch.float32, 2e-4)):
             gsol = ops.ThSolveFn.apply(dev(p, dt), dev(q, dt), dev(r, dt))
-            assert _lib.last_kernel() == "th_solve_fwd"
+            # cepstral order 24 in float32: the unpivoted quad-layout solve shared with the mel-cepstral kernels
+            assert _lib.last_kernel() == ("th_solve_quad_fwd" if (n == 24 and dt == torch.float32) else "th_solve_fwd")
             assert np.abs(host(gsol) - ref).max() < tol * max(1.0, np.abs(ref).max()), (n, dt)
+    # bench-size batch of 24 x 24 systems with the spectrum-like structure of the analysis (positive definite, condition
+    # numbers up to 1e4): every system against float64
+    Fr, n = 51200 + 7, 24
+    w = np.exp(rng.standard_normal((Fr, 64)) * 1.5)                       # positive "spectra"
+    om = np.pi * (np.arange(64) + 0.5) / 64
+    ii = np.arange(n)
+    pk = (w[:, None, :] * np.cos(om[None, None, :] * ii[None, :, None])).sum(-1)            # toeplitz part
+    qk = 0.5 * (w[:, None, :] * np.cos(om[None, None, :] * np.arange(2 * n - 1)[None, :, None])).sum(-1)   # hankel part
+    rk = rng.standard_normal((Fr, n))
+    gsol = ops.ThSolveFn.apply(dev(pk, torch.float32), dev(qk, torch.float32), dev(rk, torch.float32))
+    assert _lib.last_kernel() == "th_solve_quad_fwd"
+    sel = rng.choice(Fr, 400, replace=False)
+    sel[:3] = [0, Fr - 1, Fr - 7]
+    A = pk[sel][:, np.abs(ii[:, None] - ii[None, :])] + qk[sel][:, ii[:, None] + ii[None, :]]
+    ref = np.linalg.solve(A, rk[sel][..., None])[..., 0]
+    err = np.abs(host(gsol)[sel] - ref).max(-1) / np.abs(ref).max(-1)
+    assert err.max() < 5e-3 and np.median(err) < 2e-5, (err.max(), np.median(err))
+    assert bool(torch.isfinite(gsol).all())
     p = dev(p[:4, :6] + 3.0).requires_grad_(True)
     q = dev(q[:4, :11]).requires_grad_(True)
     r = dev(r[:4, :6]).requires_grad_(True)
