@@ -100,9 +100,10 @@ __device__ __forceinline__ void pk_ifft16(v2f (&v)[16])
 }
 
 // LC / PC: frame length and period at compile time (LC <= 512, PC a multiple of 16, LC - PC <= 4 PC: one warm-up pass
-// covers everything a run inherits; instantiated for 400 / 80 and 400 / 160, see the launcher).  CPLX: the cotangent is complex (format "complex", or the inverse transform with scale 1/512): the
-// waveform is not needed.  `div` != nullptr: the stored value is divided by div[t] + div_eps (Unframe's
-// normalisation, unframe.py:203-205).
+// covers everything a run inherits; instantiated for 400 / 80 and 400 / 160, see the launcher).
+// CPLX: the cotangent is complex (format "complex", or the inverse transform with scale 1/512): the waveform is not
+// needed.  `div` != nullptr: the stored value is divided by div[t] + div_eps (Unframe's normalisation,
+// unframe.py:203-205).
 // MAG (real cotangent only): the cotangent belongs to sqrt(|X|^2 + eps) instead of |X|^2 + eps (spec.py:129, the
 // amplitude-domain filter bank / MFCC front end): one more factor 1 / (2 sqrt(.)) per bin.
 template <int LC, int PC, bool CPLX, bool MAG = false>
