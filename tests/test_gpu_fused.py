@@ -185,6 +185,32 @@ def test_fused_gradient_matches_float64_autograd_and_the_two_stage_path(C, sr, u
     assert float(((ga - gb).abs().amax(-1).cpu().double() / scale).max()) < 1e-5
 
 
+@pytest.mark.parametrize("shape,P,center", [((2, 4001), 80, True), ((3, 1283), 160, False), ((1, 5, 401), 160, True)])
+def test_fused_gradient_ragged_lengths_and_the_ten_millisecond_period(shape, P, center):
+    """Odd lengths (utterances off the 16-byte grid), uncentred framing, leading batch dimensions and frame_period 160:
+    the fused forward + its two-launch backward against the two differentiable stages and float64."""
+    from oracle import torch_port as TP
+    g = torch.Generator().manual_seed(shape[-1])
+    x = torch.randn(*shape, generator=g)
+    stft = dsp.STFT(400, P, 512, center=center, device=DEV)
+    fb = dsp.MelFilterBankAnalysis(fft_length=512, n_channel=40, sample_rate=16000, use_power=True, device=DEV)
+    fused = dsp.fuse(stft, fb)
+    xa = x.to(DEV).requires_grad_(True)
+    ya = fused(xa)
+    assert fused.last_path == "fused"
+    cot = torch.randn(ya.shape, generator=g)
+    (ga,) = torch.autograd.grad(ya, xa, cot.to(DEV))
+    xb = x.to(DEV).requires_grad_(True)
+    (gb,) = torch.autograd.grad(fb(stft(xb)), xb, cot.to(DEV))
+    H = torch.from_numpy(np.asarray(tables.fbank_matrix(512, 40, 16000, 0.0, None, "htk", None))).double()
+    xr = x.double().clone().requires_grad_(True)
+    y64 = torch.log(torch.clip(TP.stft_power(xr, 400, P, 512, center=center) @ H, min=1e-5))
+    (y64 * cot.double()).sum().backward()
+    scale = xr.grad.abs().amax(-1)
+    assert float(((ga.cpu().double() - xr.grad).abs().amax(-1) / scale).max()) < 1e-5
+    assert float(((ga - gb).abs().amax(-1).cpu().double() / scale).max()) < 1e-5
+
+
 def test_fused_mfcc_gradient_and_floor_clamp():
     """MFCC on top of the fused launch (amplitude domain, DCT + lifter as one row product) back-propagates like the two
     stages; a silent utterance sits on the floor in every channel: its gradient is exactly zero, as torch.clip's is."""
