@@ -225,19 +225,51 @@ __global__ void window_gw_kernel(const T* __restrict__ gy, const T* __restrict__
 template <typename T>
 __device__ __forceinline__ void lds_fft_pow2(T* re, T* im, int n, int lg, const T* __restrict__ tw)
 {
-    for (int s = lg - 1; s >= 0; --s) {
-        const int half = 1 << s;
+    // Two radix-2 stages at a time (s and s - 1): the four points i0, i0 + h/2, i0 + h, i0 + h + h/2 (bits s and s - 1 of
+    // i0 clear) are closed under both, so they pass through registers once -- half the LDS traffic and barriers of
+    // stage-by-stage radix 2, a sixth of its twiddle reads (from memory: one per group; the second pair's stage-s twiddle is
+    // -i times the first's -- a quarter turn further -- and stage s - 1's is its square), same bit-reversed output.
+    int s = lg - 1;
+    for (; s >= 1; s -= 2) {
+        const int h = 1 << s, h2 = h >> 1;
         const int tstep = n >> (s + 1);
+        for (int t = threadIdx.x; t < (n >> 2); t += blockDim.x) {
+            const int j = t & (h2 - 1);
+            const int i0 = ((t >> (s - 1)) << (s + 1)) | j;
+            const T a0r = re[i0], a0i = im[i0], a1r = re[i0 + h2], a1i = im[i0 + h2];
+            const T a2r = re[i0 + h], a2i = im[i0 + h], a3r = re[i0 + h + h2], a3i = im[i0 + h + h2];
+            const T c1 = tw[2 * (j * tstep)], s1 = tw[2 * (j * tstep) + 1];   // W^(j tstep): the group's one table read
+            const T c2 = s1, s2 = -c1;                                          // W^((j + h/2) tstep) = -i W^(j tstep)
+            const T c3 = c1 * c1 - s1 * s1, s3 = T(2) * c1 * s1;                // W^(2 j tstep), the twiddle of stage s - 1
+            // stage s
+            const T u0r = a0r + a2r, u0i = a0i + a2i, d0r = a0r - a2r, d0i = a0i - a2i;
+            const T u1r = a1r + a3r, u1i = a1i + a3i, d1r = a1r - a3r, d1i = a1i - a3i;
+            const T v0r = d0r * c1 - d0i * s1, v0i = d0r * s1 + d0i * c1;
+            const T v1r = d1r * c2 - d1i * s2, v1i = d1r * s2 + d1i * c2;
+            // stage s - 1
+            re[i0] = u0r + u1r;
+            im[i0] = u0i + u1i;
+            const T e0r = u0r - u1r, e0i = u0i - u1i;
+            re[i0 + h2] = e0r * c3 - e0i * s3;
+            im[i0 + h2] = e0r * s3 + e0i * c3;
+            re[i0 + h] = v0r + v1r;
+            im[i0 + h] = v0i + v1i;
+            const T e1r = v0r - v1r, e1i = v0i - v1i;
+            re[i0 + h + h2] = e1r * c3 - e1i * s3;
+            im[i0 + h + h2] = e1r * s3 + e1i * c3;
+        }
+        __syncthreads();
+    }
+    if (s == 0) {   // odd number of stages: the last one on its own (half = 1, twiddle 1)
         for (int t = threadIdx.x; t < (n >> 1); t += blockDim.x) {
-            const int j = t & (half - 1);
-            const int i = ((t >> s) << (s + 1)) | j;
-            const T ar = re[i], ai = im[i], br = re[i + half], bi = im[i + half];
-            const T c = tw[2 * (j * tstep)], sn = tw[2 * (j * tstep) + 1];
+            const int i = t << 1;
+            const T ar = re[i], ai = im[i], br = re[i + 1], bi = im[i + 1];
+            const T c = tw[0], sn = tw[1];
             re[i] = ar + br;
             im[i] = ai + bi;
             const T dr = ar - br, di = ai - bi;
-            re[i + half] = dr * c - di * sn;
-            im[i + half] = dr * sn + di * c;
+            re[i + 1] = dr * c - di * sn;
+            im[i + 1] = dr * sn + di * c;
         }
         __syncthreads();
     }
