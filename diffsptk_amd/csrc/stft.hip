@@ -414,7 +414,8 @@ __global__ void row_dft_bwd_kernel(const T* __restrict__ x, long Tlen, long N, i
     const bool inverse_cot = out_kind == 1 && fmt == DSA_SPEC_COMPLEX_INV;
     const bool complex_out = (out_kind == 0 && fmt == DSA_FFTR_COMPLEX) ||
                              (out_kind == 1 && fmt == DSA_SPEC_COMPLEX) || inverse_cot;
-    if (FFT) {
+    // a complex cotangent (format "complex", the inverse transforms) does not depend on the spectrum: no forward transform
+    if (FFT && !complex_out) {
         for (int l = threadIdx.x; l < nfft; l += blockDim.x) {
             fre[l] = l < Lc ? (w ? xc[l] * w[l] : xc[l]) : T(0);
             fim[l] = T(0);
@@ -425,7 +426,8 @@ __global__ void row_dft_bwd_kernel(const T* __restrict__ x, long Tlen, long N, i
     T smax = 0;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
         T re = 0, im = 0;
-        if (FFT) {
+        if (complex_out) {
+        } else if (FFT) {
             const int q = fft_brev(k, lg);
             re = fre[q], im = fim[q];
         } else {
