@@ -63,19 +63,46 @@ __device__ __forceinline__ void fc_fft_product(const T* src, int klim, int H, T*
         fim[k] = T(0);
     }
     __syncthreads();
-    // lds_fft_pow2 of stft.hip, restated here for this translation unit (forward sign, natural in, bit-reversed out)
-    for (int sft = lg - 1; sft >= 0; --sft) {
-        const int half = 1 << sft, tstep = L >> (sft + 1);
+    // lds_fft_pow2 of stft.hip, restated here for this translation unit (forward sign, natural in, bit-reversed out): two
+    // radix-2 stages per pass through registers (the four points i0, i0 + h/2, i0 + h, i0 + h + h/2 are closed under
+    // stages s and s - 1): half the LDS traffic and barriers; the second pair's twiddle is -i times the first's, stage
+    // s - 1's is its square
+    int sft = lg - 1;
+    for (; sft >= 1; sft -= 2) {
+        const int h = 1 << sft, h2 = h >> 1, tstep = L >> (sft + 1);
+        for (int t = threadIdx.x; t < (L >> 2); t += blockDim.x) {
+            const int j = t & (h2 - 1);
+            const int i0 = ((t >> (sft - 1)) << (sft + 1)) | j;
+            const T a0r = fre[i0], a0i = fim[i0], a1r = fre[i0 + h2], a1i = fim[i0 + h2];
+            const T a2r = fre[i0 + h], a2i = fim[i0 + h], a3r = fre[i0 + h + h2], a3i = fim[i0 + h + h2];
+            const T c1 = tw[2 * (j * tstep)], s1 = tw[2 * (j * tstep) + 1];
+            const T c2 = s1, s2 = -c1;
+            const T c3 = c1 * c1 - s1 * s1, s3 = T(2) * c1 * s1;
+            const T u0r = a0r + a2r, u0i = a0i + a2i, d0r = a0r - a2r, d0i = a0i - a2i;
+            const T u1r = a1r + a3r, u1i = a1i + a3i, d1r = a1r - a3r, d1i = a1i - a3i;
+            const T v0r = d0r * c1 - d0i * s1, v0i = d0r * s1 + d0i * c1;
+            const T v1r = d1r * c2 - d1i * s2, v1i = d1r * s2 + d1i * c2;
+            fre[i0] = u0r + u1r;
+            fim[i0] = u0i + u1i;
+            const T e0r = u0r - u1r, e0i = u0i - u1i;
+            fre[i0 + h2] = e0r * c3 - e0i * s3;
+            fim[i0 + h2] = e0r * s3 + e0i * c3;
+            fre[i0 + h] = v0r + v1r;
+            fim[i0 + h] = v0i + v1i;
+            const T e1r = v0r - v1r, e1i = v0i - v1i;
+            fre[i0 + h + h2] = e1r * c3 - e1i * s3;
+            fim[i0 + h + h2] = e1r * s3 + e1i * c3;
+        }
+        __syncthreads();
+    }
+    if (sft == 0) {   // odd number of stages: the last one on its own (half = 1, twiddle 1)
         for (int t = threadIdx.x; t < (L >> 1); t += blockDim.x) {
-            const int j = t & (half - 1);
-            const int i = ((t >> sft) << (sft + 1)) | j;
-            const T ar = fre[i], ai = fim[i], br = fre[i + half], bi = fim[i + half];
-            const T c = tw[2 * (j * tstep)], sn = tw[2 * (j * tstep) + 1];
+            const int i = t << 1;
+            const T ar = fre[i], ai = fim[i], br = fre[i + 1], bi = fim[i + 1];
             fre[i] = ar + br;
             fim[i] = ai + bi;
-            const T dr = ar - br, di = ai - bi;
-            fre[i + half] = dr * c - di * sn;
-            fim[i + half] = dr * sn + di * c;
+            fre[i + 1] = ar - br;
+            fim[i + 1] = ai - bi;
         }
         __syncthreads();
     }
