@@ -431,10 +431,107 @@ __global__ __launch_bounds__(256) void zerodf_fwd_sliced_kernel(const T* __restr
     }
 }
 
+// The same filters with the taps AND the samples blocked by four: a thread owns four consecutive output samples and a
+// contiguous range of 4-tap blocks; with the taps stored reversed (br[kk] = b[M - kk]) a block needs the eight samples
+// xs[4 (l + m) .. + 7] -- two aligned 16-byte reads, one of them carried over from the previous block -- and two
+// 16-byte coefficient reads (broadcasts): 3 LDS reads per 32 multiply-adds (the kernel above: 6 per 8, which bound it).
+// The tap ranges of the 256 / ceil(P / 4) thread groups meet in LDS in a fixed order (deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void zerodf_fwd_blocked_kernel(const T* __restrict__ x, const T* __restrict__ b, long Tlen, long N,
+                                                                 int M, int P, int z0, int ignore_gain, T* __restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int NB = (M + 4) / 4;               // 4-tap blocks: ceil((M + 1) / 4)
+    const int nt = (P + 3) / 4;               // threads per group (four samples each)
+    const int G = 256 / nt;                   // tap-range groups
+    const int PP = nt * 4;
+    T* br0 = reinterpret_cast<T*>(smem_raw);  // [4 NB] reversed taps of frame n, zero-padded
+    T* br1 = br0 + 4 * NB;                    // [4 NB] ... of frame n + 1
+    T* xs = br1 + 4 * NB;                     // [PP + 4 NB + 4]: x[t0 - M + z0 ..], zero beyond the frame's stretch
+    T* part = xs + (PP + 4 * NB + 4);         // [G][2][PP]
+    const long f = blockIdx.x;
+    const long u = f / N, n = f - u * N;
+    const long n1 = n + 1 < N ? n + 1 : N - 1;
+    const T* r0 = b + (u * N + n) * (M + 1);
+    const T* r1 = b + (u * N + n1) * (M + 1);
+    for (int kk = threadIdx.x; kk < 4 * NB; kk += blockDim.x) {
+        br0[kk] = kk <= M ? r0[M - kk] : T(0);
+        br1[kk] = kk <= M ? r1[M - kk] : T(0);
+    }
+    const long t0 = n * P;
+    const T* xu = x + u * Tlen;
+    for (int i = threadIdx.x; i < PP + 4 * NB + 4; i += blockDim.x) {
+        const long sidx = t0 - M + z0 + i;
+        xs[i] = (i < P + M && sidx >= 0 && sidx < Tlen) ? xu[sidx] : T(0);
+    }
+    __syncthreads();
+    const int g = threadIdx.x / nt, l = threadIdx.x - g * nt;
+    if (g < G) {
+        const int per = (NB + G - 1) / G;
+        const int m0 = g * per, m1 = (m0 + per < NB) ? m0 + per : NB;
+        T a0[4] = {T(0), T(0), T(0), T(0)}, a1[4] = {T(0), T(0), T(0), T(0)};
+        T wv[8];
+        if (m0 < m1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wv[q] = xs[4 * (l + m0) + q];
+        }
+        for (int m = m0; m < m1; ++m) {
+            T c0[4], c1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                wv[4 + q] = xs[4 * (l + m + 1) + q];
+                c0[q] = br0[4 * m + q];
+                c1[q] = br1[4 * m + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a0[q] += c0[r] * wv[q + r];
+                    a1[q] += c1[r] * wv[q + r];
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wv[q] = wv[4 + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            part[(g * 2 + 0) * PP + 4 * l + q] = a0[q];
+            part[(g * 2 + 1) * PP + 4 * l + q] = a1[q];
+        }
+    }
+    __syncthreads();
+    const int gk = z0 == M ? M : 0;
+    const T g0 = r0[gk], g1 = r1[gk];
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        T s0 = 0, s1 = 0;
+        for (int q = 0; q < G; ++q) {
+            s0 += part[(q * 2 + 0) * PP + i];
+            s1 += part[(q * 2 + 1) * PP + i];
+        }
+        const T w = (T)i / (T)P;
+        T v = s0 + w * (s1 - s0);             // torch.lerp(y1, y2, ramp)
+        if (ignore_gain) v /= g0 + w * (g1 - g0);
+        y[u * Tlen + t0 + i] = v;
+    }
+}
+
 template <typename T>
 static int zerodf_launch_fwd(const void* x, const void* b, int64_t B, int64_t Tlen, int64_t N, int M, int P, int z0, int ig,
                              void* y, hipStream_t st)
 {
+    {   // long filters: taps and samples blocked by four (DSA_ZERODF_SLICED=1 keeps the older sliced kernel: A/B)
+        static const bool sliced_only = [] {
+            const char* e = getenv("DSA_ZERODF_SLICED");
+            return e && atoi(e) != 0;
+        }();
+        const int NB = (M + 4) / 4, nt = (P + 3) / 4;
+        const size_t lds_b = sizeof(T) * ((size_t)8 * NB + (size_t)(4 * nt + 4 * NB + 4) + (size_t)(256 / (nt > 0 ? nt : 1)) * 2 * 4 * nt);
+        if (!sliced_only && M >= 64 && P >= 4 && P <= 128 && lds_b <= 64 * 1024) {
+            hipLaunchKernelGGL((zerodf_fwd_blocked_kernel<T>), dim3((unsigned)(B * N)), dim3(256), lds_b, st, (const T*)x, (const T*)b,
+                               (long)Tlen, (long)N, M, P, z0, ig, (T*)y);
+            return check_launch("zerodf_blocked_fwd");
+        }
+    }
     const size_t lds_s = sizeof(T) * (2 * (size_t)(M + 1) + 128 + M + 8 * 2 * 128);
     if (M >= 64 && P <= 128 && lds_s <= 64 * 1024) {
         hipLaunchKernelGGL((zerodf_fwd_sliced_kernel<T>), dim3((unsigned)(B * N)), dim3(256), lds_s, st, (const T*)x, (const T*)b,

@@ -181,10 +181,10 @@ def test_zerodf_and_linear_intpl(golden):
     rng = np.random.default_rng(5)
     xl, bl = rng.standard_normal((3, 800)), 0.05 * rng.standard_normal((3, 10, 400))
     yl = host(ops.ZerodfFn.apply(dev(xl, torch.float32), dev(bl, torch.float32), 80, 0, False))
-    assert _lib.last_kernel() == "zerodf_sliced_fwd"   # M >= 64, P <= 128: taps dealt to 8 slices of 32 threads
+    assert _lib.last_kernel() == "zerodf_blocked_fwd"   # M >= 64, P <= 128: taps and samples blocked by four
     ref = O.zerodf(xl, bl, 80)
     assert np.abs(yl - ref).max() < 2e-5 * np.abs(ref).max()
-    # the tap-sliced kernel on every shape class: tap counts that do / do not divide by 8, P in {5, 80, 128}, look-ahead taps,
+    # the blocked kernel on every shape class: tap counts that do / do not divide by 4, P in {5, 80, 128}, look-ahead taps,
     # gain normalisation on either end tap, float64; P = 160 and short filters keep the one-thread-per-sample kernel
     for M_, P_, z0, ig in ((64, 80, 0, False), (199, 80, 199, True), (301, 128, 100, False), (70, 5, 0, True), (1999, 80, 0, False)):
         nfr = 4
@@ -193,7 +193,7 @@ def test_zerodf_and_linear_intpl(golden):
         bs_[..., -1] += 1.5
         for dt, tol in ((torch.float64, 1e-11), (torch.float32, 3e-5)):
             out = host(ops.ZerodfFn.apply(dev(xs_, dt), dev(bs_, dt), P_, z0, ig))
-            assert _lib.last_kernel() == "zerodf_sliced_fwd", (M_, P_, dt)
+            assert _lib.last_kernel() == "zerodf_blocked_fwd", (M_, P_, dt)
             ref = O.zerodf(xs_, bs_, P_, ig, z0)
             assert np.abs(out - ref).max() < tol * np.abs(ref).max(), (M_, P_, z0, ig, dt)
     out = host(ops.ZerodfFn.apply(dev(rng.standard_normal((1, 320))), dev(rng.standard_normal((1, 2, 101))), 160, 0, False))
