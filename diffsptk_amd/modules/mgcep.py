@@ -74,7 +74,7 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
         def epsilon(gamma, r, b1):
             return r[..., 0] + gamma * (r[..., 1:] * b1).sum(-1)
 
-        def newton(gamma, b1):
+        def newton(gamma, b1, need_gain=True):   # need_gain: b0 = sqrt(eps) is only read after the LAST step of a run
             if gamma == -1:                                        # mgcep.py:196-197, 213-215
                 pt = mm(x, self.Pr)
                 qt = None                                          # q (1 + gamma) = 0: no Hankel part
@@ -84,7 +84,7 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
                 pt = mm(S[0], self.Pr)
                 qt = (mm(S[1], self.Qr) + mm(S[2], self.Qi)) * (1 + gamma)
                 r = mm(S[3], self.Rr) + mm(S[4], self.Ri)
-                eps = epsilon(gamma, r, b1)
+                eps = epsilon(gamma, r, b1) if need_gain else None
             else:
                 b = torch.cat((torch.zeros_like(b1[..., :1]), b1), dim=-1)
                 X = 1 + gamma * mm(b, self.Cr)                     # mgcep.py:199-209
@@ -96,13 +96,13 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
                 pt = mm(pp, self.Pr)
                 qt = (mm(qq * (XX - YY), self.Qr) + mm(qq * (2 * X * Y), self.Qi)) * (1 + gamma)
                 r = mm(pp * X, self.Rr) + mm(pp * Y, self.Ri)
-                eps = epsilon(gamma, r, b1)
+                eps = epsilon(gamma, r, b1) if need_gain else None
             if qt is None:
                 qt = torch.zeros(*pt.shape[:-1], 2 * M - 1, device=pt.device, dtype=pt.dtype)
             b1 = b1 + ops.ThSolveFn.apply(pt, qt, r[..., 1:])      # mgcep.py:226-230
             if gamma == -1:
                 eps = epsilon(gamma, r, b1)
-            return torch.sqrt(eps).unsqueeze(-1), b1
+            return (torch.sqrt(eps).unsqueeze(-1) if eps is not None else None), b1
 
         b1 = torch.zeros(*x.shape[:-1], M, device=x.device, dtype=x.dtype)
         b0, b1 = newton(-1, b1)
@@ -110,6 +110,6 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
             b = torch.cat((b0, b1), dim=-1)
             b = _Gnorm._forward(self.mc2b(self.gc2gc(self.b2mc(_Ignorm._forward(b, gamma=-1)))), gamma=self.gamma)   # b2b, :120-137
             b1 = b[..., 1:]
-            for _ in range(self.n_iter):
-                b0, b1 = newton(self.gamma, b1)
+            for it in range(self.n_iter):
+                b0, b1 = newton(self.gamma, b1, need_gain=it == self.n_iter - 1)
         return self.b2mc(_Ignorm._forward(torch.cat((b0, b1), dim=-1), gamma=self.gamma))                             # b2mc, :139-144
