@@ -260,7 +260,7 @@ __device__ __forceinline__ void col_backsub_all(const float (&a)[colm::TOTAL], f
 // without pivoting for the same reason).  The 24 x 24 system rides in the 25 x 25 machinery with row / column 24 as an
 // identity pair: row 24 stores slot 6 only (diagonal 1 on lane 0, right-hand side 0 on lane 1) and column 24 of the other
 // rows comes through the slot-6 pointers as zeros, so it never couples.  One system per wave with a pivot search
-// (th_solve_reg, csrc/mgc.hip) took 0.2 ms per 51 200 systems; this takes ~20 us.
+// (th_solve_reg, csrc/mgc.hip) took 0.2 ms per 51 200 systems; this takes 0.06 ms.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTq = 136;   // floats per system in LDS: q window [0, 52) | mirrored p window [52, 104) | r [104, 132) (136 % 32 = 8)
 __global__ __launch_bounds__(256) void thsolve_quad24_kernel(const float* __restrict__ p, const float* __restrict__ q,
