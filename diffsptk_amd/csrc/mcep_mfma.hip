@@ -260,7 +260,7 @@ __device__ __forceinline__ void col_backsub_all(const float (&a)[colm::TOTAL], f
 // without pivoting for the same reason).  The 24 x 24 system rides in the 25 x 25 machinery with row / column 24 as an
 // identity pair: row 24 stores slot 6 only (diagonal 1 on lane 0, right-hand side 0 on lane 1) and column 24 of the other
 // rows comes through the slot-6 pointers as zeros, so it never couples.  One system per wave with a pivot search
-// (th_solve_reg, csrc/mgc.hip) took 0.2 ms per 51 200 systems; this takes 0.06 ms.
+// (th_solve_reg, csrc/mgc.hip) took 0.2 ms per 51 200 systems; this takes 0.02 ms.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTq = 136;   // floats per system in LDS: q window [0, 52) | mirrored p window [52, 104) | r [104, 132) (136 % 32 = 8)
 __global__ __launch_bounds__(256) void thsolve_quad24_kernel(const float* __restrict__ p, const float* __restrict__ q,
@@ -278,19 +278,38 @@ __global__ __launch_bounds__(256) void thsolve_quad24_kernel(const float* __rest
     const long ntiles = (F + 15) / 16;
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
         __builtin_amdgcn_wave_barrier();
-        // stage: every lane fills a share of the 16 records (missing systems: the identity, right-hand side 0)
-        for (int e = lane; e < 16 * kTq; e += 64) {
-            const int fr = e / kTq, k = e - fr * kTq;
-            const long f = tile * 16 + fr;
-            float v = 0.f;
-            if (f < F) {
-                if (k < 52) v = k < 47 ? q[f * 47 + k] : 0.f;
-                else if (k < 104) {
-                    const int d = k - 52 - 27, ad = d < 0 ? -d : d;
-                    v = ad < 24 ? p[f * 24 + ad] : 0.f;
-                } else if (k < 104 + 24) v = r[f * 24 + (k - 104)];
-            } else if (k == 52 + 27) v = 1.f;   // p[0] = 1: a regular (identity) system
-            wl[e] = v;
+        // stage the 16 records (missing systems: the identity, right-hand side 0).  The tile's q, p and r rows are three
+        // CONTIGUOUS runs of memory: each is copied by an unrolled loop of independent loads (as one loop over the record
+        // layout with a guarded load per element, every element waited out its own round trip: 43 of the kernel's 59 us)
+        const long fbase = tile * 16;
+        const long nvalid = (F - fbase) < 16 ? (F - fbase) : 16;
+        for (int e = lane; e < 16 * kTq; e += 64) wl[e] = 0.f;
+        float vq[12], vp[6], vr[6];
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {   // 16 x 47 = 752 values of q
+            const int idx = lane + 64 * it;
+            const bool ok = idx < 752 && idx < nvalid * 47;
+            vq[it] = ok ? q[fbase * 47 + (ok ? idx : 0)] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {    // 16 x 24 = 384 values of p and of r
+            const int idx = lane + 64 * it;
+            const bool ok = idx < nvalid * 24;
+            vp[it] = ok ? p[fbase * 24 + (ok ? idx : 0)] : ((idx % 24) == 0 ? 1.f : 0.f);   // missing system: p = e_0
+            vr[it] = ok ? r[fbase * 24 + (ok ? idx : 0)] : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+            const int idx = lane + 64 * it;
+            if (idx < 752) wl[(idx / 47) * kTq + (idx % 47)] = vq[it];
+        }
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int idx = lane + 64 * it, fr = idx / 24, k = idx - fr * 24;
+            wl[fr * kTq + 52 + 27 + k] = vp[it];     // mirrored Toeplitz window: p[|d|] at 27 + d
+            wl[fr * kTq + 52 + 27 - k] = vp[it];
+            wl[fr * kTq + 104 + k] = vr[it];
         }
         __builtin_amdgcn_wave_barrier();
         const float* rt_q = wl + nq * kTq;
