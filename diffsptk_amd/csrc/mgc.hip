@@ -454,15 +454,41 @@ __global__ __launch_bounds__(256) void zerodf_fwd_blocked_kernel(const T* __rest
     const long n1 = n + 1 < N ? n + 1 : N - 1;
     const T* r0 = b + (u * N + n) * (M + 1);
     const T* r1 = b + (u * N + n1) * (M + 1);
-    for (int kk = threadIdx.x; kk < 4 * NB; kk += blockDim.x) {
-        br0[kk] = kk <= M ? r0[M - kk] : T(0);
-        br1[kk] = kk <= M ? r1[M - kk] : T(0);
-    }
+    // (four independent loads per round: a load -> store loop waits out one round trip to memory per element)
     const long t0 = n * P;
     const T* xu = x + u * Tlen;
-    for (int i = threadIdx.x; i < PP + 4 * NB + 4; i += blockDim.x) {
-        const long sidx = t0 - M + z0 + i;
-        xs[i] = (i < P + M && sidx >= 0 && sidx < Tlen) ? xu[sidx] : T(0);
+    for (int kb = threadIdx.x; kb < 4 * NB; kb += 4 * blockDim.x) {
+        T v0[4], v1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kk = kb + q * blockDim.x;
+            const bool ok = kk <= M;
+            v0[q] = ok ? r0[M - (ok ? kk : M)] : T(0);
+            v1[q] = ok ? r1[M - (ok ? kk : M)] : T(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kk = kb + q * blockDim.x;
+            if (kk < 4 * NB) {
+                br0[kk] = v0[q];
+                br1[kk] = v1[q];
+            }
+        }
+    }
+    for (int ib = threadIdx.x; ib < PP + 4 * NB + 4; ib += 4 * blockDim.x) {
+        T v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ib + q * blockDim.x;
+            const long sidx = t0 - M + z0 + i;
+            const bool ok = i < P + M && sidx >= 0 && sidx < Tlen;
+            v[q] = ok ? xu[ok ? sidx : 0] : T(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ib + q * blockDim.x;
+            if (i < PP + 4 * NB + 4) xs[i] = v[q];
+        }
     }
     __syncthreads();
     const int g = threadIdx.x / nt, l = threadIdx.x - g * nt;
