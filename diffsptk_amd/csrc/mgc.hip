@@ -618,7 +618,15 @@ __global__ __launch_bounds__(320) void mgcep_spectra_kernel(const T* __restrict_
             cr[m] = m < M ? Cr[(long)(m + 1) * K + k] : T(0);
             ci[m] = m < M ? Ci[(long)(m + 1) * K + k] : T(0);
         }
-        for (int fi = 0; fi < nf; ++fi) {
+        for (int fb = 0; fb < nf; fb += 8) {
+        // (the eight spectrum values of a round are fetched together, ahead of the arithmetic: one round trip, not eight)
+        T xv8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xv8[q] = x[(f0 + (fb + q < nf ? fb + q : nf - 1)) * K + k];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int fi = fb + q;
+            if (fi >= nf) break;
             T re = 0, im = 0;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -631,7 +639,7 @@ __global__ __launch_bounds__(320) void mgcep_spectra_kernel(const T* __restrict_
             T dp;
             if constexpr (sizeof(T) == 4) dp = __builtin_amdgcn_exp2f(ex * __builtin_amdgcn_logf(D));   // D > 0; 1 ulp each
             else dp = dsa_pow(D, ex);
-            const T pp = x[(f0 + fi) * K + k] * dp;
+            const T pp = xv8[q] * dp;
             const T qq = pp / D;
             const long o = (f0 + fi) * K + k, S = F * (long)K;
             out[o] = pp;
@@ -639,6 +647,7 @@ __global__ __launch_bounds__(320) void mgcep_spectra_kernel(const T* __restrict_
             out[2 * S + o] = qq * (T(2) * X * Y);
             out[3 * S + o] = pp * X;
             out[4 * S + o] = pp * Y;
+        }
         }
     }
 }
