@@ -53,14 +53,21 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
 }
 
 #ifdef DSA_MCEP_TIMING
+// Phase stamps of a Newton step (tools/bench_mcep.cpp): the cycle counter goes into SCALAR registers, without a branch (a
+// conditional store at every stamp split the step's basic block and with it the instruction schedule being measured); the
+// stamps of one (tile, step) are written out by DSA_STAMPS_FLUSH at the end of the step.
 __device__ unsigned long long g_mcep_stamps[64];
-#define DSA_STAMP(i)                                                                   \
+#define DSA_STAMPS_DECL unsigned dsa_st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define DSA_STAMP(i) dsa_st_[i] = (unsigned)__builtin_readcyclecounter()
+#define DSA_STAMPS_FLUSH                                                                \
     do {                                                                               \
         if (blockIdx.x == 0 && threadIdx.x == 0 && tile == 0 && iter == 1)             \
-            g_mcep_stamps[i] = __builtin_readcyclecounter();                            \
+            for (int i_ = 0; i_ < 12; ++i_) g_mcep_stamps[i_] = dsa_st_[i_];            \
     } while (0)
 #else
+#define DSA_STAMPS_DECL
 #define DSA_STAMP(i)
+#define DSA_STAMPS_FLUSH
 #endif
 
 // Branch-free per-lane selection by lane group: gm[i] is all-ones where g == i (hipcc turns
@@ -91,6 +98,27 @@ __device__ __forceinline__ float rcp_nr(float x)
 {
     float r = __builtin_amdgcn_rcpf(x);
     return r * __builtin_fmaf(-x, r, 2.f);
+}
+
+// Reductions over the four lane groups g = lane >> 4 of a frame (lanes n, n + 16, n + 32, n + 48) without the LDS crossbar:
+// v_permlane16_swap / v_permlane32_swap (gfx950) exchange the odd 16-lane rows of one register with the even rows of another
+// (resp. the upper half of one with the lower half of the other); with both operands holding x the two results are
+// (x of the even row | x of the odd row) on both rows of a pair, so one add / max of the pair is x (op) x[lane ^ 16] -- three
+// vector instructions and no memory latency, where __shfl_xor is a ds_bpermute_b32 round trip (~100+ cycles on the wave's
+// in-order critical path, six of them per Newton step).
+__device__ __forceinline__ float rows_sum4(float x)
+{
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float rows_max4(float x)
+{
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __builtin_fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __builtin_fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
 // value of lane Q of this lane's quad (DPP quad_perm broadcast: a plain VALU move, no LDS)
@@ -252,6 +280,143 @@ __device__ __forceinline__ void col_backsub_all(const float (&a)[colm::TOTAL], f
     ((void)col_backsub_step<mm::M1 - 1 - Ks>(a, xq, gq), ...);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The same elimination with its rank-1 updates on v_mfma_f32_4x4x1_16b_f32 (round 3).
+// One instruction is 16 independent 4 x 4 outer products D_b += A_b (x) B_b, block b = the lanes 4b .. 4b + 3: exactly the
+// quad layout -- 16 systems per wave, lane gs of a quad owning the columns gs + 4c.  The matrix is kept as 4 x 4 BLOCKS,
+// block (rg, cg) = rows 4 rg .. 4 rg + 3 x columns 4 cg .. 4 cg + 3 as one register quadruple (register i = row 4 rg + i, the
+// lane = the column within the group): the C / D operand.  With the pivot row scaled to m = -row_k / a_kk, the update of
+// block (rg, cg) is ONE instruction with A = slot rg of m (lane i: the multiplier of row 4 rg + i -- by symmetry that is
+// where it already is) and B = slot cg of the unscaled pivot row (lane j: column 4 cg + j): no broadcast, no DPP, no
+// wait states, 305 matrix instructions per 25 x 25 system (+ right-hand sides in column group 6) instead of 986
+// v_fmac_f32_dpp.  tools/bench_issue.cpp (profiles/r03_issue_calibration*.txt) has the prices: a v_fmac_f32(_dpp) occupies a
+// SIMD for 4 cycles (64 multiply-adds), the 4 x 4 x 1 product for 8 (256): twice the multiply-adds per cycle, on the same
+// datapath (the float32 products and the vector ALU do NOT overlap, neither within a wave nor across the waves of a SIMD).
+// The elimination's arithmetic is the same fmaf(multiplier, pivot-row entry, entry) per element as in the column-cyclic code
+// above (rows <= k of the pivot's own row group are kept by zeroing their lanes of A); the back substitution divides by the
+// pivot at the end of each row instead of reading pre-scaled rows.
+// ---------------------------------------------------------------------------------------------
+namespace blk {
+constexpr int NG = 7;                                     // row / column groups (28 >= 25 rows, + right-hand sides)
+constexpr int NBLK = NG * (NG + 1) / 2;                   // upper-triangular blocks: 28 quadruples = 112 registers
+constexpr int at(int rg, int cg) { return rg * NG - rg * (rg - 1) / 2 + (cg - rg); }
+}  // namespace blk
+
+__device__ __forceinline__ f32x4 mfma441(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
+// rows of R + Q in block layout; slot 6 through the two per-lane pointers of col_build_rows_p (column 24 | right-hand side
+// | second right-hand side or zero | zero).  Rows 25 .. 27 are padding: never pivots, never read.
+template <int rg>
+__device__ __forceinline__ void blk_build_rows(f32x4 (&a)[blk::NBLK], const float* rt0, const float* rr0, const float* pa6,
+                                               const float* pb6, int gs)
+{
+    using namespace mm;
+    if constexpr (rg < blk::NG) {
+        const float* rt_g = rt0 + gs;
+        const float* rr_g = rr0 + 27 - gs;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * rg + i;
+            if (row < M1) {
+#pragma unroll
+                for (int c = rg; c < 6; ++c) a[blk::at(rg, c)][i] = rt_g[row + 4 * c] + rr_g[row - 4 * c];
+                a[blk::at(rg, 6)][i] = pa6[row] + pb6[row];
+            } else {
+                a[blk::at(rg, 6)][i] = 0.f;
+            }
+        }
+        blk_build_rows<rg + 1>(a, rt0, rr0, pa6, pb6, gs);
+    }
+}
+
+template <int k, int rg>
+__device__ __forceinline__ void blk_update_groups(f32x4 (&a)[blk::NBLK], const float (&m)[blk::NG])
+{
+    if constexpr (rg < blk::NG) {
+        // A = the multipliers of rows 4 rg .. 4 rg + 3 (slot rg of the scaled pivot row), B = the pivot row where it stands
+#pragma unroll
+        for (int c = rg; c < blk::NG; ++c) a[blk::at(rg, c)] = mfma441(m[rg], a[blk::at(k >> 2, c)][k & 3], a[blk::at(rg, c)]);
+        blk_update_groups<k, rg + 1>(a, m);
+    }
+}
+
+// One step.  The pivot row stays in place UNSCALED (writing single elements of the register quadruples makes the compiler
+// copy whole quadruples); its scaled copy m = -row_k / a_kk lives for this step only, and the back substitution divides by
+// the pivot again (one v_rcp_f32_dpp per row).
+template <int k>
+__device__ __forceinline__ void blk_elim_step(f32x4 (&a)[blk::NBLK], const GroupMask& gq, float (&ninvs)[mm::M1])
+{
+    using namespace blk;
+    constexpr int c0 = k >> 2, q = k & 3;
+    if constexpr (k == mm::M1 - 1) ninvs[k] = -__builtin_amdgcn_rcpf(quad_bcast<q>(a[at(c0, c0)][q]));
+    if constexpr (k < mm::M1 - 1) {
+        // The vector instructions of a step in ONE run ahead of its matrix instructions: a vector instruction between two
+        // 4 x 4 x 1 products costs ~9 cycles on top of its own issue (tools/bench_issue.cpp, "mix" rows), and left alone the
+        // scheduler sprinkles the multiplies between the products.
+#ifdef DSA_MCEP_PRIO_ELIM
+        __builtin_amdgcn_s_setprio(DSA_MCEP_PRIO_ELIM);
+#endif
+        const float ninv = -__builtin_amdgcn_rcpf(quad_bcast<q>(a[at(c0, c0)][q]));
+        ninvs[k] = ninv;
+        float m[NG];
+#pragma unroll
+        for (int c = 0; c < NG; ++c) m[c] = c >= c0 ? a[at(c0, c >= c0 ? c : c0)][q] * ninv : 0.f;
+        // the pivot's own row group: rows <= k keep their values (their lanes of A are zero)
+        const float m0 = keep_if(gq.gt[q], m[c0]);
+#ifndef DSA_MCEP_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef DSA_MCEP_PRIO_ELIM
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        if constexpr (q < 3) {
+#pragma unroll
+            for (int c = c0; c < NG; ++c) a[at(c0, c)] = mfma441(m0, a[at(c0, c)][q], a[at(c0, c)]);
+        }
+        blk_update_groups<k, c0 + 1>(a, m);
+#ifndef DSA_MCEP_NO_SCHED_BARRIER
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+}
+template <int... Ks>
+__device__ __forceinline__ void blk_elim_all(f32x4 (&a)[blk::NBLK], const GroupMask& gq, float (&ninvs)[mm::M1],
+                                             std::integer_sequence<int, Ks...>)
+{
+    (blk_elim_step<Ks>(a, gq, ninvs), ...);
+}
+
+// back substitution over the unscaled rows: x_k = -(sum_{j > k} U_kj x_j - b_k) / U_kk with the right-hand-side slot of xq
+// preset to -1 on its owner lane (the diagonal and the sub-diagonal lanes of slot k >> 2 still hold 0 in xq)
+template <int k>
+__device__ __forceinline__ float blk_backsub_step(const f32x4 (&a)[blk::NBLK], float (&xq)[mm::KS], const GroupMask& gq,
+                                                  const float (&ninvs)[mm::M1])
+{
+    constexpr int c0 = k >> 2, q = k & 3;
+#ifdef DSA_MCEP_RECOMPUTE_NINV
+    const float ninv = -__builtin_amdgcn_rcpf(quad_bcast<q>(a[blk::at(c0, c0)][q]));
+#else
+    const float ninv = ninvs[k];   // the negated pivot reciprocals of the elimination (quad-uniform)
+#endif
+    float sl = 0.f;
+#pragma unroll
+    for (int c = c0; c < 7; ++c) sl = __builtin_fmaf(a[blk::at(c0, c)][q], xq[c], sl);
+    sl += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sl), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+    sl += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sl), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+    const float xk = sl * ninv;
+    xq[c0] = gq.m[q] ? xk : xq[c0];
+    return xk;
+}
+template <int... Ks>
+__device__ __forceinline__ void blk_backsub_all(const f32x4 (&a)[blk::NBLK], float (&xq)[mm::KS], const GroupMask& gq,
+                                                const float (&ninvs)[mm::M1], std::integer_sequence<int, Ks...>)
+{
+    ((void)blk_backsub_step<mm::M1 - 1 - Ks>(a, xq, gq, ninvs), ...);
+}
 
 // ---------------------------------------------------------------------------------------------
 // The same solve for the Toeplitz-plus-Hankel systems of the mel-generalized cepstral analysis (mgcep.py:226-229:

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
     float* rt_q = lds + H_WAVE + wave * WAVE_FLOATS + nq * RS;
     float* rr_q = rt_q + 16 * RS;
 #ifdef DSA_MCEP_TIMING
-    if (blockIdx.x == 0 && threadIdx.x == 0) g_mcep_stamps[8] = __builtin_readcyclecounter();
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_mcep_stamps[12] = __builtin_readcyclecounter();
 #endif
 
 #ifdef DSA_MCEP_TIMING
@@ -211,6 +211,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
     } while (0)
 #else
 #define DSA_STAMP_T(i)
+#endif
+#ifdef DSA_MCEP_ABL_ONEWAVE   // timing experiment: one working wave per SIMD (the critical path of a wave on its own)
+    if (wave >= WAVES / 2) return;
 #endif
     for (long tile = wave_id; tile < ntiles16;) {
         DSA_STAMP_T(16);
@@ -303,6 +306,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             }
         }
         for (int iter = 0; iter < n_iter; ++iter) {
+            DSA_STAMPS_DECL;
             DSA_STAMP(0);
             // ------------- first chain: t = log2 X - 2 log2(e) d,  d^T = D^T mc^T  (mcep.py:210-212) -----
             f16x8 bh, bl;
@@ -313,6 +317,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                 bh[i] = h[0]; bh[i + 1] = h[1];
                 bl[i] = l[0]; bl[i + 1] = l[1];
             }
+            float d256 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d256 = __builtin_fmaf(mcv[i], lds[H_D256 + 8 * g + i], d256);
+            d256 = rows_sum4(d256);
+            const float t256 = logx256 + d256;
+            DSA_STAMP(6);
+#ifdef DSA_MCEP_CHAINS_R2   // the compiler-scheduled chains of round 2 (A/B builds)
             // one 16-bin tile of the chain; cinit preloads every accumulator element (see pass 2)
             auto dtile = [&](int mt, float cinit) __attribute__((always_inline)) {
                 const f16x8 ah = DH[mt * 64], al = DL[mt * 64];
@@ -322,12 +333,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                 c = mfma_h(ah, bh, c);
                 return c;
             };
-            float d256 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) d256 = __builtin_fmaf(mcv[i], lds[H_D256 + 8 * g + i], d256);
-            d256 += __shfl_xor(d256, 16, 64);
-            d256 += __shfl_xor(d256, 32, 64);
-            const float t256 = logx256 + d256;
             // pass 1: per-frame max of t, for the power-of-two scale that puts the largest exp2(t + sh)
             // of the frame in (2^14, 2^15].  t is NOT kept (64 registers): binary16 MFMAs are cheap
             // enough to run the chain again in pass 2.
@@ -338,8 +343,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                 const f32x2v ta = fma2(lo2(c), kInvSDM, lo2(logx[mt])), tb = fma2(hi2(c), kInvSDM, hi2(logx[mt]));
                 tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(__builtin_fmaxf(ta[0], ta[1]), __builtin_fmaxf(tb[0], tb[1])));
             }
-            tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = rows_max4(tmax);
             const float mi = __builtin_ceilf(tmax);
             const float sh = (float)EMAX_LOG2 - mi;
             const int back = (int)mi - EMAX_LOG2;  // rt = 2^back (scaled sums)
@@ -386,13 +390,325 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                 cc[0] = cn[0];
                 cc[1] = cn[1];
             }
+#elif defined(DSA_MCEP_CHAINS_2PASS)   // pipelined, but the first chain run twice (A/B builds)
+            // Round 3: the two chains as an explicit software pipeline.  A wave issues in order, and a binary16 product
+            // occupies the matrix pipe for 16 cycles: products written back to back make the wave sit on the pipe while its own
+            // vector work waits behind them (one wave alone spent 6.8 k cycles in this phase against 2.7 k of matrix time and
+            // ~2 k of vector time).  Here every product is followed by a couple of vector instructions of the PREVIOUS tile pair
+            // (sched_barrier pins the order between the slots; LDS reads and scalar instructions may cross), dependent products
+            // of one accumulator are two to six slots apart.
+#define DSA_SB() __builtin_amdgcn_sched_barrier(0x0004)
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            // pass 1: per-frame max of t, for the power-of-two scale that puts the largest exp2(t + sh) of the frame in
+            // (2^14, 2^15].  t is NOT kept (64 registers): the chain runs again in pass 2 with the shift preloaded.
+            // Operand images are read from LDS one body ahead of their products (the reads are pinned by the barriers too).
+            float tmax = t256;
+            {
+                f32x4 ca, cb;
+                f16x8 ala = DL[0], aha = DH[0], alb = DL[64], ahb = DH[64];
+                ca = mfma_h(ala, bh, zero4); cb = mfma_h(alb, bh, zero4);
+                ca = mfma_h(aha, bl, ca);    cb = mfma_h(ahb, bl, cb);
+                ca = mfma_h(aha, bh, ca);    cb = mfma_h(ahb, bh, cb);
+                ala = DL[2 * 64]; alb = DL[3 * 64]; aha = DH[2 * 64]; ahb = DH[3 * 64];
+                DSA_SB();
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const f32x4 pa = ca, pb = cb;
+                    const int na = p < 6 ? 2 * p + 4 : 0, nb = p < 6 ? 2 * p + 5 : 0;   // operands of the body after this one
+                    f16x8 aha_n = aha, ahb_n = ahb;
+                    if (p < 6) { aha_n = DH[na * 64]; ahb_n = DH[nb * 64]; }
+                    if (p < 7) ca = mfma_h(ala, bh, zero4);
+                    DSA_SB();
+                    const f32x2v ta = fma2(lo2(pa), kInvSDM, lo2(logx[2 * p])), tb = fma2(hi2(pa), kInvSDM, hi2(logx[2 * p]));
+                    DSA_SB();
+                    if (p < 7) cb = mfma_h(alb, bh, zero4);
+                    if (p < 6) { ala = DL[na * 64]; alb = DL[nb * 64]; }
+                    DSA_SB();
+                    tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, ta[0]), ta[1]);
+                    tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, tb[0]), tb[1]);
+                    DSA_SB();
+                    if (p < 7) ca = mfma_h(aha, bl, ca);
+                    DSA_SB();
+                    const f32x2v ua = fma2(lo2(pb), kInvSDM, lo2(logx[2 * p + 1])), ub = fma2(hi2(pb), kInvSDM, hi2(logx[2 * p + 1]));
+                    DSA_SB();
+                    if (p < 7) cb = mfma_h(ahb, bl, cb);
+                    DSA_SB();
+                    tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, ua[0]), ua[1]);
+                    DSA_SB();
+                    if (p < 7) ca = mfma_h(aha, bh, ca);
+                    DSA_SB();
+                    tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, ub[0]), ub[1]);
+                    DSA_SB();
+                    if (p < 7) cb = mfma_h(ahb, bh, cb);
+                    aha = aha_n; ahb = ahb_n;
+                    DSA_SB();
+                }
+            }
+            DSA_STAMP(7);
+            // operands of the first two tile pairs of pass 2, read behind the reduction of the maximum
+            f16x8 ala = DL[0], aha = DH[0], alb = DL[64], ahb = DH[64];
+            tmax = rows_max4(tmax);
+            const float mi = __builtin_ceilf(tmax);
+            const float sh = (float)EMAX_LOG2 - mi;
+            const int back = (int)mi - EMAX_LOG2;  // rt = 2^back (scaled sums)
+            // the shift rides in the accumulator preload: t + sh = logx + (sh SD SM + sum) / (SD SM)
+            const float cinit = sh * (SD * SM);
+            const f32x4 cinit4 = {cinit, cinit, cinit, cinit};
+            DSA_STAMP(8);
+
+            // ------------- pass 2: e = exp2(t + sh), second chain rt^T += E^T e^T  (mcep.py:212-215).  Body j: the products of
+            // the second chain for bins 32 (j - 1) .. and of the first chain for bins 32 (j + 1) .., one per slot, around the
+            // vector work of bins 32 j .. (t, exp2, the rt[48] column, the binary16 split) -------------
+            f32x4 accB[3] = {zero4, zero4, zero4};
+            f32x2v rt48v = {0.f, 0.f};
+            f32x4 cc0, cc1;
+            cc0 = mfma_h(ala, bh, cinit4); cc1 = mfma_h(alb, bh, cinit4);
+            cc0 = mfma_h(aha, bl, cc0);    cc1 = mfma_h(ahb, bl, cc1);
+            cc0 = mfma_h(aha, bh, cc0);    cc1 = mfma_h(ahb, bh, cc1);
+            ala = DL[2 * 64]; alb = DL[3 * 64]; aha = DH[2 * 64]; ahb = DH[3 * 64];
+            f16x8 eah[3] = {}, eal[3] = {};
+            DSA_SB();
+            f16x8 eh_p = {}, el_p = {};
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                // products of this body: second chain of pair j - 1 (nine: three terms x three output tiles), first chain
+                // of pair j + 1 (six: three terms x two tiles); their operands were read during the previous body
+                const int na = j < 6 ? 2 * j + 4 : 0, nb = j < 6 ? 2 * j + 5 : 0;   // first-chain operands of the NEXT body
+                f32x4 cn0 = cc0, cn1 = cc1;
+                f16x8 eh = eh_p, el = el_p;
+                f16x8 eah_n[3] = {eah[0], eah[1], eah[2]};
+                f32x4 c48[2] = {zero4, zero4};
+                if (j < 8) {
+#pragma unroll
+                    for (int it = 0; it < 3; ++it) eah_n[it] = EH[(it * 8 + j) * 64];
+                    c48[0] = E484[(2 * j) * 4 + g];
+                    c48[1] = E484[(2 * j + 1) * 4 + g];
+                }
+                auto prodE = [&](int i) __attribute__((always_inline)) {   // i = 3 term + it
+                    if (j > 0) {
+                        const int it = i % 3, term = i / 3;
+                        accB[it] = mfma_h(term == 0 ? eal[it] : eah[it], term == 1 ? el_p : eh_p, accB[it]);
+                    }
+                };
+                auto prodD = [&](int i) __attribute__((always_inline)) {   // i = 2 term + tile
+                    if (j < 7) {
+                        const int term = i >> 1;
+                        if ((i & 1) == 0) cn0 = mfma_h(term == 0 ? ala : aha, term == 1 ? bl : bh, term == 0 ? cinit4 : cn0);
+                        else cn1 = mfma_h(term == 0 ? alb : ahb, term == 1 ? bl : bh, term == 0 ? cinit4 : cn1);
+                    }
+                };
+                // vector work of tile tt of pair j in six pieces
+                f32x2v ta[2], tb[2];
+                float e[2][4];
+                auto vecA = [&](int tt) __attribute__((always_inline)) {
+                    const f32x4 c = tt ? cc1 : cc0;
+                    ta[tt] = fma2(lo2(c), kInvSDM, lo2(logx[(2 * j + tt) & 15]));
+                    tb[tt] = fma2(hi2(c), kInvSDM, hi2(logx[(2 * j + tt) & 15]));
+                };
+                auto vecB = [&](int tt) __attribute__((always_inline)) {
+                    e[tt][0] = __builtin_amdgcn_exp2f(ta[tt][0]);  // mcep.py:212
+                    e[tt][1] = __builtin_amdgcn_exp2f(ta[tt][1]);
+                };
+                auto vecC = [&](int tt) __attribute__((always_inline)) {
+                    e[tt][2] = __builtin_amdgcn_exp2f(tb[tt][0]);
+                    e[tt][3] = __builtin_amdgcn_exp2f(tb[tt][1]);
+                };
+                auto vecD = [&](int tt) __attribute__((always_inline)) {
+                    rt48v = f32x2v{e[tt][0], e[tt][1]} * lo2(c48[tt]) + rt48v;
+                    rt48v = f32x2v{e[tt][2], e[tt][3]} * hi2(c48[tt]) + rt48v;
+                };
+                auto vecE = [&](int tt, int r) __attribute__((always_inline)) {
+                    f16x2 h, l;
+                    split2(e[tt][r], e[tt][r + 1], h, l);
+                    eh[4 * tt + r] = h[0]; eh[4 * tt + r + 1] = h[1];
+                    el[4 * tt + r] = l[0]; el[4 * tt + r + 1] = l[1];
+                };
+                const bool vw = j < 8;   // body 8 only drains the second chain
+                prodE(0); DSA_SB(); if (vw) vecA(0); DSA_SB();
+                prodD(0); DSA_SB(); if (vw) vecB(0); DSA_SB();
+                prodE(1); DSA_SB(); if (vw) vecC(0); DSA_SB();
+                prodD(1);
+                if (j < 6) { ala = DL[na * 64]; alb = DL[nb * 64]; }
+                DSA_SB(); if (vw) vecA(1); DSA_SB();
+                prodE(2);
+                if (j < 8) {
+#pragma unroll
+                    for (int it = 0; it < 3; ++it) eal[it] = EL[(it * 8 + j) * 64];
+                }
+                DSA_SB(); if (vw) vecD(0); DSA_SB();
+                prodD(2); DSA_SB(); if (vw) vecB(1); DSA_SB();
+                prodE(3); DSA_SB(); if (vw) vecE(0, 0); DSA_SB();
+                prodD(3); DSA_SB(); if (vw) vecC(1); DSA_SB();
+                prodE(4); DSA_SB(); if (vw) vecE(0, 2); DSA_SB();
+                prodD(4); DSA_SB(); if (vw) vecD(1); DSA_SB();
+                prodE(5); DSA_SB(); if (vw) vecE(1, 0); DSA_SB();
+                prodD(5);
+                if (j < 6) { aha = DH[na * 64]; ahb = DH[nb * 64]; }
+                DSA_SB();
+                prodE(6); DSA_SB(); if (vw) vecE(1, 2); DSA_SB();
+                prodE(7); DSA_SB();
+                prodE(8); DSA_SB();
+                cc0 = cn0; cc1 = cn1;
+                eh_p = eh; el_p = el;
+#pragma unroll
+                for (int it = 0; it < 3; ++it) eah[it] = eah_n[it];
+            }
+#undef DSA_SB
+            DSA_STAMP(9);
+#else
+            // Round 3: the two chains as an explicit software pipeline, the first chain run ONCE.
+            // A wave issues in order, at most one instruction per ~4.3 cycles whatever its kind (tools/bench_issue.cpp), and a
+            // binary16 product occupies the matrix pipe for 16 cycles; a product that accumulates into the result of the
+            // previous one waits out its full latency (27 cycles per product measured for two interleaved chains).  Left to the
+            // compiler, the products came out in clusters with the wave's own vector work waiting behind them (one wave alone
+            // spent 6.8 k cycles in this phase against 2.7 k of matrix time and ~2 k of vector time).  Here every product is
+            // followed by a few vector instructions of the PREVIOUS group of tiles (sched_barrier pins the order between the slots,
+            // LDS reads included: the operand images are read one body ahead of their products), and products into one
+            // accumulator are at least four slots apart.
+            // With the elimination in register quadruples that are dead during this phase there is room to KEEP t (64
+            // registers): the first chain no longer runs a second time for the shifted exponent (48 products, 16 LDS reads and
+            // their issue slots per step); the shift is one packed add per value pair.
+#define DSA_SB() __builtin_amdgcn_sched_barrier(0x0004)
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 tt[16];
+            float tmax = t256;
+            {
+                // pass A: t = log2 X + (D^T mc^T) / (SD SM) in groups of four tiles, running maximum
+                f16x8 al[4], ah[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { al[i] = DL[i * 64]; ah[i] = DH[i * 64]; }
+                f32x4 c[4] = {zero4, zero4, zero4, zero4}, pc[4] = {zero4, zero4, zero4, zero4};
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const bool pm = q < 4, vw = q > 0;   // products of group q, vector work of group q - 1
+                    f16x8 ah_n[4] = {ah[0], ah[1], ah[2], ah[3]};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (q < 3) ah_n[i] = DH[(4 * q + 4 + i) * 64];
+                        if (pm) c[i] = mfma_h(al[i], bh, zero4);
+                        DSA_SB();
+                        if (vw) tt[4 * q - 4 + i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (vw) {
+                            const f32x2v ta = fma2(lo2(pc[i]), kInvSDM, lo2(logx[4 * q - 4 + i]));
+                            const f32x2v tb = fma2(hi2(pc[i]), kInvSDM, hi2(logx[4 * q - 4 + i]));
+                            tt[4 * q - 4 + i] = f32x4{ta[0], ta[1], tb[0], tb[1]};
+                        }
+                        DSA_SB();
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (pm) c[i] = mfma_h(ah[i], bl, c[i]);
+                        if (q < 3) al[i] = DL[(4 * q + 4 + i) * 64];
+                        DSA_SB();
+                        if (vw) {
+                            const f32x4 v = tt[4 * q - 4 + i];
+                            tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, v[0]), v[1]);
+                            tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, v[2]), v[3]);
+                        }
+                        DSA_SB();
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (pm) c[i] = mfma_h(ah[i], bh, c[i]);
+                        DSA_SB();
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { pc[i] = c[i]; ah[i] = ah_n[i]; }
+                }
+            }
+            DSA_STAMP(7);
+            // operands of the first body of pass B, read behind the reduction of the maximum
+            f16x8 eah[3], eal[3];
+#pragma unroll
+            for (int it = 0; it < 3; ++it) { eah[it] = EH[(it * 8) * 64]; eal[it] = EL[(it * 8) * 64]; }
+            tmax = rows_max4(tmax);
+            const float mi = __builtin_ceilf(tmax);
+            const float sh = (float)EMAX_LOG2 - mi;
+            const int back = (int)mi - EMAX_LOG2;  // rt = 2^back (scaled sums)
+            DSA_STAMP(8);
+
+            // ------------- pass B: e = exp2(t + sh), second chain rt^T += E^T e^T  (mcep.py:212-215).  Body j: the nine products
+            // for bins 32 (j - 1) .. (three terms x three output tiles), one per slot, around the vector work of bins 32 j ..
+            // (shift, exp2, the rt[48] column, the binary16 split) -------------
+            f32x4 accB[3] = {zero4, zero4, zero4};
+            f32x2v rt48v = {0.f, 0.f};
+            f16x8 eh_p = {}, el_p = {};
+            DSA_SB();
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                f16x8 eh = eh_p, el = el_p;
+                f16x8 eah_n[3] = {eah[0], eah[1], eah[2]};
+                f32x4 c48[2] = {zero4, zero4};
+                if (j < 8) {
+                    c48[0] = E484[(2 * j) * 4 + g];
+                    c48[1] = E484[(2 * j + 1) * 4 + g];
+                }
+                if (j > 0 && j < 8) {
+#pragma unroll
+                    for (int it = 0; it < 3; ++it) eah_n[it] = EH[(it * 8 + j) * 64];
+                }
+                auto prodE = [&](int i) __attribute__((always_inline)) {   // i = 3 term + it
+                    if (j > 0) {
+                        const int it = i % 3, term = i / 3;
+                        accB[it] = mfma_h(term == 0 ? eal[it] : eah[it], term == 1 ? el_p : eh_p, accB[it]);
+                    }
+                };
+                f32x2v ta[2], tb[2];
+                float e[2][4];
+                auto vecA = [&](int t_) __attribute__((always_inline)) {
+                    const f32x4 v = tt[(2 * j + t_) & 15];
+                    ta[t_] = lo2(v) + f32x2v{sh, sh};
+                    tb[t_] = hi2(v) + f32x2v{sh, sh};
+                };
+                auto vecB = [&](int t_) __attribute__((always_inline)) {
+                    e[t_][0] = __builtin_amdgcn_exp2f(ta[t_][0]);  // mcep.py:212
+                    e[t_][1] = __builtin_amdgcn_exp2f(ta[t_][1]);
+                };
+                auto vecC = [&](int t_) __attribute__((always_inline)) {
+                    e[t_][2] = __builtin_amdgcn_exp2f(tb[t_][0]);
+                    e[t_][3] = __builtin_amdgcn_exp2f(tb[t_][1]);
+                };
+                auto vecD = [&](int t_) __attribute__((always_inline)) {
+                    rt48v = f32x2v{e[t_][0], e[t_][1]} * lo2(c48[t_]) + rt48v;
+                    rt48v = f32x2v{e[t_][2], e[t_][3]} * hi2(c48[t_]) + rt48v;
+                };
+                auto vecE = [&](int t_, int r) __attribute__((always_inline)) {
+                    f16x2 h, l;
+                    split2(e[t_][r], e[t_][r + 1], h, l);
+                    eh[4 * t_ + r] = h[0]; eh[4 * t_ + r + 1] = h[1];
+                    el[4 * t_ + r] = l[0]; el[4 * t_ + r + 1] = l[1];
+                };
+                const bool vw = j < 8;   // body 8 only drains the second chain
+                prodE(0); DSA_SB(); if (vw) { vecA(0); vecB(0); } DSA_SB();
+                prodE(1); DSA_SB(); if (vw) { vecC(0); vecA(1); } DSA_SB();
+                prodE(2);
+                if (j > 0 && j < 8) {
+#pragma unroll
+                    for (int it = 0; it < 3; ++it) eal[it] = EL[(it * 8 + j) * 64];
+                }
+                DSA_SB(); if (vw) { vecD(0); vecB(1); } DSA_SB();
+                prodE(3); DSA_SB(); if (vw) vecE(0, 0); DSA_SB();
+                prodE(4); DSA_SB(); if (vw) { vecC(1); vecD(1); } DSA_SB();
+                prodE(5); DSA_SB(); if (vw) vecE(0, 2); DSA_SB();
+                prodE(6); DSA_SB(); if (vw) vecE(1, 0); DSA_SB();
+                prodE(7); DSA_SB(); if (vw) vecE(1, 2); DSA_SB();
+                prodE(8); DSA_SB();
+                eh_p = eh; el_p = el;
+#pragma unroll
+                for (int it = 0; it < 3; ++it) eah[it] = eah_n[it];
+            }
+#undef DSA_SB
+            DSA_STAMP(9);
+#endif
             const float e256 = __builtin_amdgcn_exp2f(t256 + sh);
 #pragma unroll
-            for (int it = 0; it < 3; ++it)  // Nyquist bin: one float32 k-step, k-slot 0 only (bit-mask select: no branch)
-                accB[it] = mfma4(keep_if(g_eq0, lds[H_E256 + it * 16 + n]), keep_if(g_eq0, e256), accB[it]);
+            for (int it = 0; it < 3; ++it) {   // Nyquist bin: rt[16 it + 4 g + r] += E[256][.] e[256], two packed multiply-adds per tile
+                const f32x4 w = *reinterpret_cast<const f32x4*>(lds + H_E256 + it * 16 + 4 * g);
+                const f32x2v lo = fma2(lo2(w), e256, lo2(accB[it])), hi = fma2(hi2(w), e256, hi2(accB[it]));
+                accB[it] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
             float rt48 = rt48v[0] + rt48v[1];
-            rt48 += __shfl_xor(rt48, 16, 64);
-            rt48 += __shfl_xor(rt48, 32, 64);
+            rt48 = rows_sum4(rt48);
             rt48 = __builtin_fmaf(e256, lds[H_E256 + 48], rt48);
             rt48 = __builtin_ldexpf(rt48, back);
 
@@ -428,7 +744,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             DSA_STAMP(2);
 
             // ------------- rows of R + Q, symmetric elimination, back substitution (as v2) -------------
+#ifdef DSA_MCEP_SOLVE_VALU   // the column-cyclic v_fmac_f32_dpp elimination of rounds 1-2 (A/B builds; bit-identical results)
             float a[colm::TOTAL];
+#else
+            f32x4 a[blk::NBLK];
+#endif
             {
                 // slot c = 6 of every row through two per-lane pointers (see col_build_rows_p); re-derived every step so
                 // that they do not occupy registers across the chains
@@ -436,14 +756,28 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                 asm volatile("" : "+v"(gsv));
                 const float* pa6 = gsv == 0 ? rt_q + 24 : (gsv == 1 ? rt_q : lds + H_ZERO);
                 const float* pb6 = gsv == 0 ? rr_q + 3 : (gsv == 1 ? lds + H_NAV : lds + H_ZERO);
+#ifdef DSA_MCEP_SOLVE_VALU
                 col_build_rows_p<0>(a, rt_q, rr_q, pa6, pb6, gs);
+#else
+                blk_build_rows<0>(a, rt_q, rr_q, pa6, pb6, gs);
+#endif
             }
             __builtin_amdgcn_wave_barrier();
             DSA_STAMP(3);
+            float xq[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[1], -1.f)};
+#ifdef DSA_MCEP_SOLVE_VALU
             col_elim_all(a, std::make_integer_sequence<int, M1>{});
             DSA_STAMP(4);
-            float xq[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[1], -1.f)};
             col_backsub_all(a, xq, gq, std::make_integer_sequence<int, M1>{});
+#else
+            float ninvs[M1];
+            blk_elim_all(a, gq, ninvs, std::make_integer_sequence<int, M1>{});
+            DSA_STAMP(4);
+#ifdef DSA_MCEP_PRIO_BACKSUB
+            __builtin_amdgcn_s_setprio(DSA_MCEP_PRIO_BACKSUB);
+#endif
+            blk_backsub_all(a, xq, gq, ninvs, std::make_integer_sequence<int, M1>{});
+#endif
             xq[6] = keep_if(gq.m[0], xq[6]);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) rt_q[4 * ks + gs] = xq[ks];
@@ -453,7 +787,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
 #pragma unroll
             for (int i = 1; i < 8; ++i) mcv[i] += keep_if(g_lt3, rt_lds[8 * g + i]);
             __builtin_amdgcn_wave_barrier();
+#ifdef DSA_MCEP_PRIO_BACKSUB
+            __builtin_amdgcn_s_setprio(0);
+#endif
             DSA_STAMP(5);
+            DSA_STAMPS_FLUSH;
             if (hist && f_ok)
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
@@ -469,7 +807,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
         DSA_STAMP_T(21);
 #ifdef DSA_MCEP_TIMING
         ++tcount;
-        if (blockIdx.x == 0 && threadIdx.x == 0) { g_mcep_stamps[9] = __builtin_readcyclecounter(); g_mcep_stamps[10] += 1; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { g_mcep_stamps[13] = __builtin_readcyclecounter(); g_mcep_stamps[14] += 1; }
 #endif
     }
 }
