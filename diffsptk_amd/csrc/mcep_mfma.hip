@@ -357,9 +357,6 @@ __device__ __forceinline__ void blk_elim_step(f32x4 (&a)[blk::NBLK], const Group
         // The vector instructions of a step in ONE run ahead of its matrix instructions: a vector instruction between two
         // 4 x 4 x 1 products costs ~9 cycles on top of its own issue (tools/bench_issue.cpp, "mix" rows), and left alone the
         // scheduler sprinkles the multiplies between the products.
-#ifdef DSA_MCEP_PRIO_ELIM
-        __builtin_amdgcn_s_setprio(DSA_MCEP_PRIO_ELIM);
-#endif
         const float ninv = -__builtin_amdgcn_rcpf(quad_bcast<q>(a[at(c0, c0)][q]));
         ninvs[k] = ninv;
         float m[NG];
@@ -367,20 +364,13 @@ __device__ __forceinline__ void blk_elim_step(f32x4 (&a)[blk::NBLK], const Group
         for (int c = 0; c < NG; ++c) m[c] = c >= c0 ? a[at(c0, c >= c0 ? c : c0)][q] * ninv : 0.f;
         // the pivot's own row group: rows <= k keep their values (their lanes of A are zero)
         const float m0 = keep_if(gq.gt[q], m[c0]);
-#ifndef DSA_MCEP_NO_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef DSA_MCEP_PRIO_ELIM
-        __builtin_amdgcn_s_setprio(0);
-#endif
         if constexpr (q < 3) {
 #pragma unroll
             for (int c = c0; c < NG; ++c) a[at(c0, c)] = mfma441(m0, a[at(c0, c)][q], a[at(c0, c)]);
         }
         blk_update_groups<k, c0 + 1>(a, m);
-#ifndef DSA_MCEP_NO_SCHED_BARRIER
         __builtin_amdgcn_sched_barrier(0);
-#endif
     }
 }
 template <int... Ks>
@@ -391,31 +381,41 @@ __device__ __forceinline__ void blk_elim_all(f32x4 (&a)[blk::NBLK], const GroupM
 }
 
 // back substitution over the unscaled rows: x_k = -(sum_{j > k} U_kj x_j - b_k) / U_kk with the right-hand-side slot of xq
-// preset to -1 on its owner lane (the diagonal and the sub-diagonal lanes of slot k >> 2 still hold 0 in xq)
-template <int k>
-__device__ __forceinline__ float blk_backsub_step(const f32x4 (&a)[blk::NBLK], float (&xq)[mm::KS], const GroupMask& gq,
+// preset to -1 on its owner lane (the diagonal and the sub-diagonal lanes of slot k >> 2 still hold 0 in xq).
+// Row group by row group: the sums over the FINISHED column groups (c > rg) of the group's four rows are packed two rows to
+// an instruction (a register pair of the quadruple times the broadcast x slot); only the row's own column group, the quad
+// reduction and the division are serial.
+template <int rg>
+__device__ __forceinline__ void blk_backsub_group(const f32x4 (&a)[blk::NBLK], float (&xq)[mm::KS], const GroupMask& gq,
                                                   const float (&ninvs)[mm::M1])
 {
-    constexpr int c0 = k >> 2, q = k & 3;
-#ifdef DSA_MCEP_RECOMPUTE_NINV
-    const float ninv = -__builtin_amdgcn_rcpf(quad_bcast<q>(a[blk::at(c0, c0)][q]));
-#else
-    const float ninv = ninvs[k];   // the negated pivot reciprocals of the elimination (quad-uniform)
-#endif
-    float sl = 0.f;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f};
 #pragma unroll
-    for (int c = c0; c < 7; ++c) sl = __builtin_fmaf(a[blk::at(c0, c)][q], xq[c], sl);
-    sl += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sl), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
-    sl += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sl), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
-    const float xk = sl * ninv;
-    xq[c0] = gq.m[q] ? xk : xq[c0];
-    return xk;
+    for (int c = rg + 1; c < blk::NG; ++c) {
+        const f32x4 v = a[blk::at(rg, c)];
+        const f2 x = {xq[c], xq[c]};
+        p01 = __builtin_shufflevector(v, v, 0, 1) * x + p01;
+        if constexpr (4 * rg + 2 < mm::M1) p23 = __builtin_shufflevector(v, v, 2, 3) * x + p23;
+    }
+    const float part[4] = {p01[0], p01[1], p23[0], p23[1]};
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+        const int k = 4 * rg + i;
+        if (k < mm::M1) {
+            float sl = __builtin_fmaf(a[blk::at(rg, rg)][i], xq[rg], part[i]);
+            sl += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sl), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+            sl += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sl), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+            const float xk = sl * ninvs[k];   // the negated pivot reciprocals of the elimination (quad-uniform)
+            xq[rg] = gq.m[i] ? xk : xq[rg];
+        }
+    }
 }
-template <int... Ks>
+template <int... Gs>
 __device__ __forceinline__ void blk_backsub_all(const f32x4 (&a)[blk::NBLK], float (&xq)[mm::KS], const GroupMask& gq,
-                                                const float (&ninvs)[mm::M1], std::integer_sequence<int, Ks...>)
+                                                const float (&ninvs)[mm::M1], std::integer_sequence<int, Gs...>)
 {
-    ((void)blk_backsub_step<mm::M1 - 1 - Ks>(a, xq, gq, ninvs), ...);
+    (blk_backsub_group<blk::NG - 1 - Gs>(a, xq, gq, ninvs), ...);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -481,14 +481,15 @@ __global__ __launch_bounds__(256) void thsolve_quad24_kernel(const float* __rest
         const float* rr_q = rt_q + 52;
         float xq[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[1], -1.f)};
         {
-            float a[colm::TOTAL];
+            f32x4 a[blk::NBLK];
+            float ninvs[M1];
             int gsv = gs;
             asm volatile("" : "+v"(gsv));
             const float* zr = cst;
             const float* pa6 = gsv == 0 ? cst + 32 : (gsv == 1 ? rt_q + 104 : zr);   // column 24: e_24 | right-hand side | 0
-            col_build_rows_p<0>(a, rt_q, rr_q, pa6, zr, gs);
-            col_elim_all(a, std::make_integer_sequence<int, M1>{});
-            col_backsub_all(a, xq, gq, std::make_integer_sequence<int, M1>{});
+            blk_build_rows<0>(a, rt_q, rr_q, pa6, zr, gs);
+            blk_elim_all(a, gq, ninvs, std::make_integer_sequence<int, M1>{});
+            blk_backsub_all(a, xq, gq, ninvs, std::make_integer_sequence<int, blk::NG>{});
         }
         const long f = tile * 16 + nq;
         if (f < F) {

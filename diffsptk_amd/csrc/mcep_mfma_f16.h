@@ -82,13 +82,17 @@ __device__ __forceinline__ f32x4 mfma_h(f16x8 a, f16x8 b, f32x4 c)
 __device__ __forceinline__ void split2(float x0, float x1, f16x2& hi, f16x2& lo)
 {
     hi = __builtin_convertvector(f32x2v{x0, x1}, f16x2);
-    // x - float(hi), exact, as ONE v_fma_mix_f32 per value (binary16 operand taken from its half register): the compiler's
-    // form is a conversion plus a subtraction (64 values per lane and Newton step in a kernel bound by vector issue)
+    // lo = binary16(x - float(hi)), the difference exact in float32: ONE v_fma_mixlo_f16 / v_fma_mixhi_f16 per value (binary16
+    // operand taken from its half register, float32 multiply-add, result rounded into the low / high half of the destination).
+    // Round 2 used v_fma_mix_f32 + a packed conversion (three instructions per pair), the compiler's own form is five.
     const unsigned hb = __builtin_bit_cast(unsigned, hi);
-    float l0, l1;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(x0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(x1));
-    lo = __builtin_convertvector(f32x2v{l0, l1}, f16x2);
+    // (one statement: the compiler does not see a half-register write inside inline assembly, and gfx950 wants a wait state
+    // between such a write and the next vector instruction touching the register -- the second half's read-modify-write)
+    unsigned lb;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\ts_nop 0\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 0"
+        : "=&v"(lb) : "v"(hb), "v"(x0), "v"(x1));
+    lo = __builtin_bit_cast(f16x2, lb);
 }
 // c * s + b on both halves of a register pair: v_pk_fma_f32 (two flops per lane and issue slot)
 #ifdef DSA_MCEP_NOPK
@@ -323,239 +327,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             d256 = rows_sum4(d256);
             const float t256 = logx256 + d256;
             DSA_STAMP(6);
-#ifdef DSA_MCEP_CHAINS_R2   // the compiler-scheduled chains of round 2 (A/B builds)
-            // one 16-bin tile of the chain; cinit preloads every accumulator element (see pass 2)
-            auto dtile = [&](int mt, float cinit) __attribute__((always_inline)) {
-                const f16x8 ah = DH[mt * 64], al = DL[mt * 64];
-                f32x4 c = {cinit, cinit, cinit, cinit};
-                c = mfma_h(al, bh, c);
-                c = mfma_h(ah, bl, c);
-                c = mfma_h(ah, bh, c);
-                return c;
-            };
-            // pass 1: per-frame max of t, for the power-of-two scale that puts the largest exp2(t + sh)
-            // of the frame in (2^14, 2^15].  t is NOT kept (64 registers): binary16 MFMAs are cheap
-            // enough to run the chain again in pass 2.
-            float tmax = t256;
-#pragma unroll
-            for (int mt = 0; mt < 16; ++mt) {
-                const f32x4 c = dtile(mt, 0.f);
-                const f32x2v ta = fma2(lo2(c), kInvSDM, lo2(logx[mt])), tb = fma2(hi2(c), kInvSDM, hi2(logx[mt]));
-                tmax = __builtin_fmaxf(tmax, __builtin_fmaxf(__builtin_fmaxf(ta[0], ta[1]), __builtin_fmaxf(tb[0], tb[1])));
-            }
-            tmax = rows_max4(tmax);
-            const float mi = __builtin_ceilf(tmax);
-            const float sh = (float)EMAX_LOG2 - mi;
-            const int back = (int)mi - EMAX_LOG2;  // rt = 2^back (scaled sums)
-            // the shift rides in the accumulator preload: t + sh = logx + (sh SD SM + sum) / (SD SM)
-            const float cinit = sh * (SD * SM);
-
-            // ------------- pass 2: e = exp2(t + sh), second chain rt^T += E^T e^T  (mcep.py:212-215);
-            // the first chain of bins 32 (j + 1) .. is issued ahead of the vector work of bins 32 j .. ----
-            f32x4 accB[3] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-            f32x2v rt48v = {0.f, 0.f};
-            f32x4 cc[2] = {dtile(0, cinit), dtile(1, cinit)};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                f32x4 cn[2] = {cc[0], cc[1]};
-                if (j < 7) {
-                    cn[0] = dtile(2 * j + 2, cinit);
-                    cn[1] = dtile(2 * j + 3, cinit);
-                }
-                f16x8 eh, el;
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int mt = 2 * j + tt;
-                    const f32x4 c48 = E484[mt * 4 + g];
-                    const f32x2v ta = fma2(lo2(cc[tt]), kInvSDM, lo2(logx[mt])), tb = fma2(hi2(cc[tt]), kInvSDM, hi2(logx[mt]));
-                    const float e[4] = {__builtin_amdgcn_exp2f(ta[0]), __builtin_amdgcn_exp2f(ta[1]),
-                                        __builtin_amdgcn_exp2f(tb[0]), __builtin_amdgcn_exp2f(tb[1])};  // mcep.py:212
-                    rt48v = f32x2v{e[0], e[1]} * lo2(c48) + rt48v;
-                    rt48v = f32x2v{e[2], e[3]} * hi2(c48) + rt48v;
-#pragma unroll
-                    for (int r = 0; r < 4; r += 2) {
-                        f16x2 h, l;
-                        split2(e[r], e[r + 1], h, l);
-                        eh[4 * tt + r] = h[0]; eh[4 * tt + r + 1] = h[1];
-                        el[4 * tt + r] = l[0]; el[4 * tt + r + 1] = l[1];
-                    }
-                }
-#pragma unroll
-                for (int it = 0; it < 3; ++it) {
-                    const f16x8 ah = EH[(it * 8 + j) * 64], al = EL[(it * 8 + j) * 64];
-                    accB[it] = mfma_h(al, eh, accB[it]);
-                    accB[it] = mfma_h(ah, el, accB[it]);
-                    accB[it] = mfma_h(ah, eh, accB[it]);
-                }
-                cc[0] = cn[0];
-                cc[1] = cn[1];
-            }
-#elif defined(DSA_MCEP_CHAINS_2PASS)   // pipelined, but the first chain run twice (A/B builds)
-            // Round 3: the two chains as an explicit software pipeline.  A wave issues in order, and a binary16 product
-            // occupies the matrix pipe for 16 cycles: products written back to back make the wave sit on the pipe while its own
-            // vector work waits behind them (one wave alone spent 6.8 k cycles in this phase against 2.7 k of matrix time and
-            // ~2 k of vector time).  Here every product is followed by a couple of vector instructions of the PREVIOUS tile pair
-            // (sched_barrier pins the order between the slots; LDS reads and scalar instructions may cross), dependent products
-            // of one accumulator are two to six slots apart.
-#define DSA_SB() __builtin_amdgcn_sched_barrier(0x0004)
-            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-            // pass 1: per-frame max of t, for the power-of-two scale that puts the largest exp2(t + sh) of the frame in
-            // (2^14, 2^15].  t is NOT kept (64 registers): the chain runs again in pass 2 with the shift preloaded.
-            // Operand images are read from LDS one body ahead of their products (the reads are pinned by the barriers too).
-            float tmax = t256;
-            {
-                f32x4 ca, cb;
-                f16x8 ala = DL[0], aha = DH[0], alb = DL[64], ahb = DH[64];
-                ca = mfma_h(ala, bh, zero4); cb = mfma_h(alb, bh, zero4);
-                ca = mfma_h(aha, bl, ca);    cb = mfma_h(ahb, bl, cb);
-                ca = mfma_h(aha, bh, ca);    cb = mfma_h(ahb, bh, cb);
-                ala = DL[2 * 64]; alb = DL[3 * 64]; aha = DH[2 * 64]; ahb = DH[3 * 64];
-                DSA_SB();
-#pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    const f32x4 pa = ca, pb = cb;
-                    const int na = p < 6 ? 2 * p + 4 : 0, nb = p < 6 ? 2 * p + 5 : 0;   // operands of the body after this one
-                    f16x8 aha_n = aha, ahb_n = ahb;
-                    if (p < 6) { aha_n = DH[na * 64]; ahb_n = DH[nb * 64]; }
-                    if (p < 7) ca = mfma_h(ala, bh, zero4);
-                    DSA_SB();
-                    const f32x2v ta = fma2(lo2(pa), kInvSDM, lo2(logx[2 * p])), tb = fma2(hi2(pa), kInvSDM, hi2(logx[2 * p]));
-                    DSA_SB();
-                    if (p < 7) cb = mfma_h(alb, bh, zero4);
-                    if (p < 6) { ala = DL[na * 64]; alb = DL[nb * 64]; }
-                    DSA_SB();
-                    tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, ta[0]), ta[1]);
-                    tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, tb[0]), tb[1]);
-                    DSA_SB();
-                    if (p < 7) ca = mfma_h(aha, bl, ca);
-                    DSA_SB();
-                    const f32x2v ua = fma2(lo2(pb), kInvSDM, lo2(logx[2 * p + 1])), ub = fma2(hi2(pb), kInvSDM, hi2(logx[2 * p + 1]));
-                    DSA_SB();
-                    if (p < 7) cb = mfma_h(ahb, bl, cb);
-                    DSA_SB();
-                    tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, ua[0]), ua[1]);
-                    DSA_SB();
-                    if (p < 7) ca = mfma_h(aha, bh, ca);
-                    DSA_SB();
-                    tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, ub[0]), ub[1]);
-                    DSA_SB();
-                    if (p < 7) cb = mfma_h(ahb, bh, cb);
-                    aha = aha_n; ahb = ahb_n;
-                    DSA_SB();
-                }
-            }
-            DSA_STAMP(7);
-            // operands of the first two tile pairs of pass 2, read behind the reduction of the maximum
-            f16x8 ala = DL[0], aha = DH[0], alb = DL[64], ahb = DH[64];
-            tmax = rows_max4(tmax);
-            const float mi = __builtin_ceilf(tmax);
-            const float sh = (float)EMAX_LOG2 - mi;
-            const int back = (int)mi - EMAX_LOG2;  // rt = 2^back (scaled sums)
-            // the shift rides in the accumulator preload: t + sh = logx + (sh SD SM + sum) / (SD SM)
-            const float cinit = sh * (SD * SM);
-            const f32x4 cinit4 = {cinit, cinit, cinit, cinit};
-            DSA_STAMP(8);
-
-            // ------------- pass 2: e = exp2(t + sh), second chain rt^T += E^T e^T  (mcep.py:212-215).  Body j: the products of
-            // the second chain for bins 32 (j - 1) .. and of the first chain for bins 32 (j + 1) .., one per slot, around the
-            // vector work of bins 32 j .. (t, exp2, the rt[48] column, the binary16 split) -------------
-            f32x4 accB[3] = {zero4, zero4, zero4};
-            f32x2v rt48v = {0.f, 0.f};
-            f32x4 cc0, cc1;
-            cc0 = mfma_h(ala, bh, cinit4); cc1 = mfma_h(alb, bh, cinit4);
-            cc0 = mfma_h(aha, bl, cc0);    cc1 = mfma_h(ahb, bl, cc1);
-            cc0 = mfma_h(aha, bh, cc0);    cc1 = mfma_h(ahb, bh, cc1);
-            ala = DL[2 * 64]; alb = DL[3 * 64]; aha = DH[2 * 64]; ahb = DH[3 * 64];
-            f16x8 eah[3] = {}, eal[3] = {};
-            DSA_SB();
-            f16x8 eh_p = {}, el_p = {};
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                // products of this body: second chain of pair j - 1 (nine: three terms x three output tiles), first chain
-                // of pair j + 1 (six: three terms x two tiles); their operands were read during the previous body
-                const int na = j < 6 ? 2 * j + 4 : 0, nb = j < 6 ? 2 * j + 5 : 0;   // first-chain operands of the NEXT body
-                f32x4 cn0 = cc0, cn1 = cc1;
-                f16x8 eh = eh_p, el = el_p;
-                f16x8 eah_n[3] = {eah[0], eah[1], eah[2]};
-                f32x4 c48[2] = {zero4, zero4};
-                if (j < 8) {
-#pragma unroll
-                    for (int it = 0; it < 3; ++it) eah_n[it] = EH[(it * 8 + j) * 64];
-                    c48[0] = E484[(2 * j) * 4 + g];
-                    c48[1] = E484[(2 * j + 1) * 4 + g];
-                }
-                auto prodE = [&](int i) __attribute__((always_inline)) {   // i = 3 term + it
-                    if (j > 0) {
-                        const int it = i % 3, term = i / 3;
-                        accB[it] = mfma_h(term == 0 ? eal[it] : eah[it], term == 1 ? el_p : eh_p, accB[it]);
-                    }
-                };
-                auto prodD = [&](int i) __attribute__((always_inline)) {   // i = 2 term + tile
-                    if (j < 7) {
-                        const int term = i >> 1;
-                        if ((i & 1) == 0) cn0 = mfma_h(term == 0 ? ala : aha, term == 1 ? bl : bh, term == 0 ? cinit4 : cn0);
-                        else cn1 = mfma_h(term == 0 ? alb : ahb, term == 1 ? bl : bh, term == 0 ? cinit4 : cn1);
-                    }
-                };
-                // vector work of tile tt of pair j in six pieces
-                f32x2v ta[2], tb[2];
-                float e[2][4];
-                auto vecA = [&](int tt) __attribute__((always_inline)) {
-                    const f32x4 c = tt ? cc1 : cc0;
-                    ta[tt] = fma2(lo2(c), kInvSDM, lo2(logx[(2 * j + tt) & 15]));
-                    tb[tt] = fma2(hi2(c), kInvSDM, hi2(logx[(2 * j + tt) & 15]));
-                };
-                auto vecB = [&](int tt) __attribute__((always_inline)) {
-                    e[tt][0] = __builtin_amdgcn_exp2f(ta[tt][0]);  // mcep.py:212
-                    e[tt][1] = __builtin_amdgcn_exp2f(ta[tt][1]);
-                };
-                auto vecC = [&](int tt) __attribute__((always_inline)) {
-                    e[tt][2] = __builtin_amdgcn_exp2f(tb[tt][0]);
-                    e[tt][3] = __builtin_amdgcn_exp2f(tb[tt][1]);
-                };
-                auto vecD = [&](int tt) __attribute__((always_inline)) {
-                    rt48v = f32x2v{e[tt][0], e[tt][1]} * lo2(c48[tt]) + rt48v;
-                    rt48v = f32x2v{e[tt][2], e[tt][3]} * hi2(c48[tt]) + rt48v;
-                };
-                auto vecE = [&](int tt, int r) __attribute__((always_inline)) {
-                    f16x2 h, l;
-                    split2(e[tt][r], e[tt][r + 1], h, l);
-                    eh[4 * tt + r] = h[0]; eh[4 * tt + r + 1] = h[1];
-                    el[4 * tt + r] = l[0]; el[4 * tt + r + 1] = l[1];
-                };
-                const bool vw = j < 8;   // body 8 only drains the second chain
-                prodE(0); DSA_SB(); if (vw) vecA(0); DSA_SB();
-                prodD(0); DSA_SB(); if (vw) vecB(0); DSA_SB();
-                prodE(1); DSA_SB(); if (vw) vecC(0); DSA_SB();
-                prodD(1);
-                if (j < 6) { ala = DL[na * 64]; alb = DL[nb * 64]; }
-                DSA_SB(); if (vw) vecA(1); DSA_SB();
-                prodE(2);
-                if (j < 8) {
-#pragma unroll
-                    for (int it = 0; it < 3; ++it) eal[it] = EL[(it * 8 + j) * 64];
-                }
-                DSA_SB(); if (vw) vecD(0); DSA_SB();
-                prodD(2); DSA_SB(); if (vw) vecB(1); DSA_SB();
-                prodE(3); DSA_SB(); if (vw) vecE(0, 0); DSA_SB();
-                prodD(3); DSA_SB(); if (vw) vecC(1); DSA_SB();
-                prodE(4); DSA_SB(); if (vw) vecE(0, 2); DSA_SB();
-                prodD(4); DSA_SB(); if (vw) vecD(1); DSA_SB();
-                prodE(5); DSA_SB(); if (vw) vecE(1, 0); DSA_SB();
-                prodD(5);
-                if (j < 6) { aha = DH[na * 64]; ahb = DH[nb * 64]; }
-                DSA_SB();
-                prodE(6); DSA_SB(); if (vw) vecE(1, 2); DSA_SB();
-                prodE(7); DSA_SB();
-                prodE(8); DSA_SB();
-                cc0 = cn0; cc1 = cn1;
-                eh_p = eh; el_p = el;
-#pragma unroll
-                for (int it = 0; it < 3; ++it) eah[it] = eah_n[it];
-            }
-#undef DSA_SB
-            DSA_STAMP(9);
-#else
             // Round 3: the two chains as an explicit software pipeline, the first chain run ONCE.
             // A wave issues in order, at most one instruction per ~4.3 cycles whatever its kind (tools/bench_issue.cpp), and a
             // binary16 product occupies the matrix pipe for 16 cycles; a product that accumulates into the result of the
@@ -630,8 +401,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             // ------------- pass B: e = exp2(t + sh), second chain rt^T += E^T e^T  (mcep.py:212-215).  Body j: the nine products
             // for bins 32 (j - 1) .. (three terms x three output tiles), one per slot, around the vector work of bins 32 j ..
             // (shift, exp2, the rt[48] column, the binary16 split) -------------
-            f32x4 accB[3] = {zero4, zero4, zero4};
+            // the Nyquist bin first: rt[16 it + 4 g + r] = E[256][.] e[256] preloads the accumulators of the second chain (body 0 has
+            // no products to wait for), its share of rt[48] is added with the reduction at the end
+            const float e256 = __builtin_amdgcn_exp2f(t256 + sh);
+            f32x4 accB[3];
+#pragma unroll
+            for (int it = 0; it < 3; ++it) accB[it] = *reinterpret_cast<const f32x4*>(lds + H_E256 + it * 16 + 4 * g) * e256;
+            const float rt48n = e256 * lds[H_E256 + 48];
             f32x2v rt48v = {0.f, 0.f};
+            float rt48 = 0.f;
             f16x8 eh_p = {}, el_p = {};
             DSA_SB();
 #pragma unroll
@@ -681,6 +459,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                 const bool vw = j < 8;   // body 8 only drains the second chain
                 prodE(0); DSA_SB(); if (vw) { vecA(0); vecB(0); } DSA_SB();
                 prodE(1); DSA_SB(); if (vw) { vecC(0); vecA(1); } DSA_SB();
+                if (j == 8) rt48 = rows_sum4(rt48v[0] + rt48v[1]) + rt48n;   // the drain body has room for the rt[48] reduction
                 prodE(2);
                 if (j > 0 && j < 8) {
 #pragma unroll
@@ -699,17 +478,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             }
 #undef DSA_SB
             DSA_STAMP(9);
-#endif
-            const float e256 = __builtin_amdgcn_exp2f(t256 + sh);
-#pragma unroll
-            for (int it = 0; it < 3; ++it) {   // Nyquist bin: rt[16 it + 4 g + r] += E[256][.] e[256], two packed multiply-adds per tile
-                const f32x4 w = *reinterpret_cast<const f32x4*>(lds + H_E256 + it * 16 + 4 * g);
-                const f32x2v lo = fma2(lo2(w), e256, lo2(accB[it])), hi = fma2(hi2(w), e256, hi2(accB[it]));
-                accB[it] = f32x4{lo[0], lo[1], hi[0], hi[1]};
-            }
-            float rt48 = rt48v[0] + rt48v[1];
-            rt48 = rows_sum4(rt48);
-            rt48 = __builtin_fmaf(e256, lds[H_E256 + 48], rt48);
             rt48 = __builtin_ldexpf(rt48, back);
 
             // ------------- rt and its reflection into this frame's LDS windows -------------
@@ -773,10 +541,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             float ninvs[M1];
             blk_elim_all(a, gq, ninvs, std::make_integer_sequence<int, M1>{});
             DSA_STAMP(4);
-#ifdef DSA_MCEP_PRIO_BACKSUB
-            __builtin_amdgcn_s_setprio(DSA_MCEP_PRIO_BACKSUB);
-#endif
-            blk_backsub_all(a, xq, gq, ninvs, std::make_integer_sequence<int, M1>{});
+            blk_backsub_all(a, xq, gq, ninvs, std::make_integer_sequence<int, blk::NG>{});
 #endif
             xq[6] = keep_if(gq.m[0], xq[6]);
 #pragma unroll
@@ -787,9 +552,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
 #pragma unroll
             for (int i = 1; i < 8; ++i) mcv[i] += keep_if(g_lt3, rt_lds[8 * g + i]);
             __builtin_amdgcn_wave_barrier();
-#ifdef DSA_MCEP_PRIO_BACKSUB
-            __builtin_amdgcn_s_setprio(0);
-#endif
             DSA_STAMP(5);
             DSA_STAMPS_FLUSH;
             if (hist && f_ok)

@@ -2,6 +2,8 @@
 (reference: diffsptk/functional.py:23,797,859,905,1659,1700,1956,2916,2963,3142)."""
 from __future__ import annotations
 
+import functools
+
 from torch import Tensor
 
 from . import modules as nn
@@ -166,14 +168,21 @@ def mgc2sp(mc: Tensor, fft_length: int, alpha: float = 0, gamma: float = 0, norm
 def mgcep(x: Tensor, cep_order: int, alpha: float = 0, gamma: float = 0, c: int | None = None, n_iter: int = 0) -> Tensor:
     """Mel-generalized cepstral analysis of power spectra (functional.py: mgcep).  A module underneath (the reference's
     is a BaseNonFunctionalModule too): the composed matrices are cached per configuration by tables.mgcep_matrices."""
-    m = nn.MelGeneralizedCepstralAnalysis(fft_length=2 * x.size(-1) - 2, cep_order=cep_order, alpha=alpha, gamma=gamma,
-                                          c=c, n_iter=n_iter, device=x.device, dtype=x.dtype)
-    return m(x)
+    return _mgcep_module(2 * x.size(-1) - 2, cep_order, float(alpha), float(gamma), c, n_iter, x.device, x.dtype)(x)
 
 
-def zerodf(x: Tensor, b: Tensor, frame_period: int = 80, ignore_gain: bool = False) -> Tensor:
-    """Time-variant all-zero filter (functional.py: zerodf)."""
-    return nn.AllZeroDigitalFilter._func(x, b, frame_period=frame_period, ignore_gain=ignore_gain)
+@functools.lru_cache(maxsize=16)
+def _mgcep_module(fft_length, cep_order, alpha, gamma, c, n_iter, device, dtype):
+    # one module per (configuration, device, dtype): a call does not upload the composed matrices again
+    return nn.MelGeneralizedCepstralAnalysis(fft_length=fft_length, cep_order=cep_order, alpha=alpha, gamma=gamma, c=c,
+                                             n_iter=n_iter, device=device, dtype=dtype)
+
+
+def zerodf(x: Tensor, b: Tensor, frame_period: int = 80, ignore_gain: bool = False, zeroth_index: int = 0,
+           mode: str = "direct") -> Tensor:
+    """Time-variant all-zero filter (functional.py:3250-3294: zerodf)."""
+    return nn.AllZeroDigitalFilter._func(x, b, frame_period=frame_period, ignore_gain=ignore_gain,
+                                         zeroth_index=zeroth_index, mode=mode)
 
 
 def linear_intpl(x: Tensor, upsampling_factor: int = 80) -> Tensor:

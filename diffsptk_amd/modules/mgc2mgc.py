@@ -8,6 +8,8 @@ between -- like the gain steps -- is element-wise device code.
 """
 from __future__ import annotations
 
+import math
+
 import torch
 
 from .. import ops
@@ -32,6 +34,10 @@ def gc2gc(c1: torch.Tensor, out_order: int, in_gamma: float, out_gamma: float, n
     if out_gamma == 0:
         C2 = torch.log(mag)                                        # clog keeps the log-magnitude only (private.py:318-319)
     else:
+        # the reference forms polar(r, theta) and takes .angle() of it again (mgc2mgc.py:349-355): the phase is WRAPPED to
+        # (-pi, pi] before it is scaled by out_gamma, which matters for non-integer out_gamma once |theta| > pi (strong
+        # resonances, |in_gamma| < 1); cos is even, so which end of the interval the boundary maps to does not matter
+        ang = torch.remainder(ang + math.pi, 2 * math.pi) - math.pi
         C2 = (mag ** out_gamma * torch.cos(ang * out_gamma) - 1) / out_gamma
     c02 = ops.IfftrFn.apply(torch.complex(C2, torch.zeros_like(C2)), n_fft, out_order + 1, tw)   # ifft(C2).real[:M2+1]
     return torch.cat((c1[..., :1], 2 * c02[..., 1:]), dim=-1)

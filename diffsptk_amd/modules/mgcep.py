@@ -51,6 +51,8 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
             return
         if cep_order < 1:
             raise ValueError("cep_order must be positive when gamma is not 0.")
+        if cep_order > 64:   # the Toeplitz-plus-Hankel solve keeps a system per wave (csrc/mgc.hip): say so here, not at the first call
+            raise ValueError("cep_order must be at most 64 when gamma is not 0 (limit of the device solver).")
         M = cep_order
         mats = dict(tables.mgcep_matrices(fft_length, cep_order, float(alpha)))   # (the table function caches its result)
         # only the columns the step uses (mgcep.py:226-227: pt = p[:M], qt = q[2:]): one 48-column launch per product

@@ -159,7 +159,7 @@ class PseudoMGLSADigitalFilter(nn.Module):
             y = x
             cur = x
             for i in range(1, self.taylor_order + 1):
-                cur = ops.ZerodfFn.apply(cur, c, P, self.cep_orders[0], False) * (1.0 / i)
+                cur = ops.zerodf(cur, c, P, self.cep_orders[0], False) * (1.0 / i)
                 y = y + cur
             if not self.ignore_gain:
                 y = y * torch.exp(self.linear_intpl(c0)).squeeze(-1)
@@ -177,7 +177,7 @@ class PseudoMGLSADigitalFilter(nn.Module):
             C = ops.FftrFn.apply(c, self.n_fft, 0, tw)
             h = ops.IfftrFn.apply(torch.exp(C), self.n_fft, self.n_fft, tw)
             h = torch.roll(h, shift, dims=-1)[..., : il_min + il_max - 1]
-            return ops.ZerodfFn.apply(x, h.contiguous(), P, shift, False)
+            return ops.zerodf(x, h.contiguous(), P, shift, False)
         Hs = []                                                              # mglsadf.py:617-637
         for i, c in enumerate((mc_min, mc_max)):
             if self.ignore_gain:
@@ -205,7 +205,7 @@ class PseudoMGLSADigitalFilter(nn.Module):
             y = x
             cur = x
             for i in range(1, self.taylor_order + 1):                            # exp(F) ~ sum_i F^i / i!
-                cur = ops.ZerodfFn.apply(cur, c, P, z0, False) * (1.0 / i)
+                cur = ops.zerodf(cur, c, P, z0, False) * (1.0 / i)
                 y = y + cur
             if not self.ignore_gain:
                 y = y * torch.exp(self.linear_intpl(c0)).squeeze(-1)
@@ -231,7 +231,7 @@ class PseudoMGLSADigitalFilter(nn.Module):
                 E = torch.exp(Xh)
                 h = ops.IfftrFn.apply(torch.complex(E, torch.zeros_like(E)), self.n_fft, L, tw)
                 h, z0 = _mirror(h), L - 1
-            return ops.ZerodfFn.apply(x, h.contiguous(), P, z0, False)
+            return ops.zerodf(x, h.contiguous(), P, z0, False)
         c = mc
         if self.ignore_gain:
             b = _Gnorm._forward(self.mc2b(mc), gamma=self.gamma)

@@ -93,4 +93,4 @@ class AllZeroDigitalFilter(BaseFunctionalModule):
     @staticmethod
     def _forward(x: torch.Tensor, b: torch.Tensor, *, frame_period: int, ignore_gain: bool, zeroth_index: int) -> torch.Tensor:
         check_size(x.size(-1), b.size(-2) * frame_period, "sequence length")
-        return ops.ZerodfFn.apply(x, b, frame_period, zeroth_index, ignore_gain)
+        return ops.zerodf(x, b, frame_period, zeroth_index, ignore_gain)

@@ -86,18 +86,24 @@ def mcep_images(G: torch.Tensor, D: torch.Tensor, E: torch.Tensor, fft_length: i
     nbytes = lib.dsa_mcep_images_bytes(fft_length, M, _lib.F32)
     if nbytes <= 0:
         return None
-    ver = (G._version, D._version, E._version, D.data_ptr(), E.data_ptr())
+    ver = (G._version, D._version, E._version, G.data_ptr(), D.data_ptr(), E.data_ptr())
     hit = _IMAGES.get(id(G))
     if hit is not None and hit[0]() is G and hit[1] == ver:
+        if not hit[3].query():   # prepared on another stream and possibly not done yet
+            with torch.cuda.device(G.device):
+                torch.cuda.current_stream().wait_event(hit[3])
         return hit[2]
     Gc, Dc, Ec = G.contiguous(), D.contiguous(), E.contiguous()
     img = torch.empty(nbytes, dtype=torch.uint8, device=G.device)
     with torch.cuda.device(G.device):
         _call("dsa_mcep_prepare", _p(Gc), _p(Dc), _p(Ec), fft_length, M, _lib.F32, _p(img), _stream())
-        torch.cuda.current_stream().synchronize()   # once per configuration: later calls may come from any stream
+        # once per configuration; later calls may come from any stream, so they wait for this event on THEIR stream (no host
+        # synchronisation: the preparation can sit inside a stream capture)
+        ready = torch.cuda.Event()
+        ready.record()
     if hit is None or hit[0]() is not G:
         weakref.finalize(G, _IMAGES.pop, id(G), None)   # the images go when the matrices go
-    _IMAGES[id(G)] = (weakref.ref(G), ver, img)
+    _IMAGES[id(G)] = (weakref.ref(G), ver, img, ready)
     return img
 
 
@@ -648,6 +654,8 @@ def fbank_bins_table(H: torch.Tensor):
         table = np.zeros(4 * H.size(0), dtype=np.float32)
         if _lib.load().dsa_fbank_bins_plan(Hh.ctypes.data, int(H.size(0)), int(H.size(1)), table.ctypes.data) == 0:
             t = torch.from_numpy(table).to(H.device)
+    if hit is None or hit[0]() is not H:
+        weakref.finalize(H, _BINS_TABLES.pop, key, None)   # the table goes when the matrix goes
     _BINS_TABLES[key] = (weakref.ref(H), H._version, t)
     return t
 
@@ -797,6 +805,8 @@ class ThSolveFn(torch.autograd.Function):
         n = pc.size(-1)
         if qc.size(-1) != 2 * n - 1 or rc.size(-1) != n:
             raise ValueError("thsolve: expected p:(..., n), q:(..., 2n-1), r:(..., n)")
+        if qc.shape[:-1] != pc.shape[:-1] or rc.shape[:-1] != pc.shape[:-1]:   # the kernels index q and r by p's row number
+            raise ValueError(f"thsolve: leading dimensions differ (p {tuple(pc.shape)}, q {tuple(qc.shape)}, r {tuple(rc.shape)})")
         F = pc.numel() // n
         g = torch.empty_like(rc)
         with torch.cuda.device(p.device):
@@ -828,6 +838,10 @@ class ZerodfFn(torch.autograd.Function):
         T = xc.size(-1)
         M = bc.size(-1) - 1
         B = xc.numel() // max(T, 1)
+        # the kernels index the coefficient rows by (utterance, frame): the leading dimensions must agree (zerodf() below
+        # broadcasts them the way the reference's tensor arithmetic does before it gets here)
+        if bc.dim() < 2 or bc.shape[:-2] != xc.shape[:-1] or bc.size(-2) * P != T:
+            raise ValueError(f"zerodf: coefficients {tuple(bc.shape)} do not match the signal {tuple(xc.shape)} at frame period {P}")
         y = torch.empty_like(xc)
         with torch.cuda.device(x.device):
             _call("dsa_zerodf_fwd", _p(xc), _p(bc), B, T, M, P, zeroth_index, int(bool(ignore_gain)), _dtype_code(xc), _p(y), _stream())
@@ -849,6 +863,23 @@ class ZerodfFn(torch.autograd.Function):
         with torch.cuda.device(gy.device):
             _call("dsa_zerodf_bwd", _p(gyc), _p(xc), _p(bc), _p(y), B, T, M, P, z0, ig, _dtype_code(xc), _p(gx), _p(gb), _stream())
         return gx, gb, None, None, None
+
+
+def zerodf(x, b, P, zeroth_index, ignore_gain):
+    """ZerodfFn with the leading dimensions of x:(..., T) and b:(..., T/P, M+1) broadcast against each other first, as the
+    reference's tensor arithmetic does (zerodf.py:207-243 accepts e.g. a batch of signals with one unbatched coefficient
+    matrix).  expand() is an autograd operation, so the gradient of a broadcast operand is summed back by autograd."""
+    if b.dim() < 2:
+        raise ValueError("zerodf: b must have at least two dimensions (frames, coefficients).")
+    try:
+        batch = torch.broadcast_shapes(x.shape[:-1], b.shape[:-2])
+    except RuntimeError as e:
+        raise ValueError(f"zerodf: leading dimensions of x {tuple(x.shape)} and b {tuple(b.shape)} do not broadcast") from e
+    if tuple(x.shape[:-1]) != tuple(batch):
+        x = x.expand(*batch, x.size(-1))
+    if tuple(b.shape[:-2]) != tuple(batch):
+        b = b.expand(*batch, *b.shape[-2:])
+    return ZerodfFn.apply(x, b, P, zeroth_index, ignore_gain)
 
 
 # ----------------------------------------------------------------------------------- LPC branch

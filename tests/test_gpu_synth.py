@@ -280,3 +280,68 @@ def test_mlsa_mixed_phase_golden(golden, mode):
             assert np.abs(host(got) - g[name]).max() < 1e-6 * np.abs(g[name]).max(), name
     with pytest.raises(ValueError):
         dsp.MLSA((12, 24), 80, phase="mixed", mode=mode, device=DEV, **params)(x.float(), dev(g["mc_c0"], torch.float32)[..., :-1])
+
+
+def test_gc2gc_wraps_large_phases(golden):
+    """mgc2mgc.py:349-355: the phase is wrapped to (-pi, pi] before it is scaled by out_gamma; reference outputs for cepstra
+    whose unwrapped phase reaches 4 pi (tests/golden/gc2gc_phase.npz), and the gradient against float64 autograd of the
+    reference's formulation written with stock operators."""
+    from diffsptk_amd.modules.mgc2mgc import gc2gc
+
+    g = golden("gc2gc_phase")
+    c = dev(g["c"])
+    for ig, og, oo, nf in g["cases"]:
+        key = f"gc2gc_{ig}_{og}_{int(oo)}_{int(nf)}"
+        y = gc2gc(c, int(oo), float(ig), float(og), int(nf))
+        close(host(y), g[key], rtol=1e-9, atol=1e-11)
+
+    def ref(c1, oo, ig, og, nf):   # the reference's op sequence (mgc2mgc.py:333-361)
+        c01 = torch.nn.functional.pad(c1[..., 1:], (1, 0))
+        C1 = torch.fft.fft(c01, n=nf)
+        if ig == 0:
+            s = torch.polar(torch.exp(C1.real), C1.imag)
+        else:
+            z = 1 + ig * C1
+            s = torch.polar(z.abs() ** (1 / ig), z.angle() / ig)
+        C2 = torch.log(s.abs()) if og == 0 else ((s.abs() ** og) * torch.cos(s.angle() * og) - 1) / og
+        c02 = torch.fft.ifft(C2).real[..., : oo + 1]
+        return torch.cat((c1[..., :1], 2 * c02[..., 1:]), -1)
+
+    ig, og, oo, nf = -0.25, -0.4, 12, 64
+    w = torch.randn(4, oo + 1, dtype=torch.float64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    c1 = c.clone().requires_grad_(True)
+    (gk,) = torch.autograd.grad((gc2gc(c1, oo, ig, og, nf) * w).sum(), c1)
+    c2 = c.clone().requires_grad_(True)
+    (gr,) = torch.autograd.grad((ref(c2, oo, ig, og, nf) * w).sum(), c2)
+    close(host(gk), host(gr), rtol=1e-7, atol=1e-9 * float(gr.abs().max()))
+
+
+def test_zerodf_broadcasts_leading_dims_and_rejects_mismatches():
+    """The reference's direct mode takes x:(B, T) with an unbatched b:(N, M+1) (tensor broadcasting, zerodf.py:207-243); the
+    kernels index b by (utterance, frame), so the host layer expands first -- and a shape that does not broadcast raises
+    instead of reading out of bounds."""
+    P, M, N, B = 10, 3, 6, 3
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(B, N * P, dtype=torch.float64, device=DEV, generator=gen)
+    b = torch.randn(N, M + 1, dtype=torch.float64, device=DEV, generator=gen)
+    y = F.zerodf(x, b, P)
+    y_each = torch.stack([F.zerodf(x[i], b, P) for i in range(B)])
+    close(host(y), host(y_each), rtol=0, atol=0)
+    close(host(y), O.zerodf(host(x), np.broadcast_to(host(b), (B, N, M + 1)), P), rtol=1e-10, atol=1e-12)
+    # gradient of the broadcast operand = the sum over the batch
+    bg = b.clone().requires_grad_(True)
+    (gb,) = torch.autograd.grad(F.zerodf(x, bg, P).square().sum(), bg)
+    be = b.expand(B, N, M + 1).contiguous().requires_grad_(True)
+    (gbe,) = torch.autograd.grad(F.zerodf(x, be, P).square().sum(), be)
+    close(host(gb), host(gbe.sum(0)), rtol=1e-12, atol=1e-12)
+    assert gb.shape == b.shape
+    # one signal, a batch of filters
+    y2 = F.zerodf(x[0], b.expand(2, N, M + 1) * torch.tensor([1.0, 2.0], dtype=torch.float64, device=DEV)[:, None, None], P)
+    assert y2.shape == (2, N * P)
+    with pytest.raises(ValueError):
+        F.zerodf(x, torch.randn(2, N, M + 1, dtype=torch.float64, device=DEV), P)       # 3 signals, 2 filter sets
+    with pytest.raises(ValueError):
+        ops.ZerodfFn.apply(x, b, P, 0, False)                                             # the raw op refuses the mismatch
+    with pytest.raises(ValueError):
+        ops.ThSolveFn.apply(torch.rand(4, 5, dtype=torch.float64, device=DEV) + 2, torch.rand(5 * 2 - 1, dtype=torch.float64, device=DEV),
+                            torch.rand(4, 5, dtype=torch.float64, device=DEV))
