@@ -2,7 +2,6 @@
 from __future__ import annotations
 
 import math
-import warnings
 
 import torch
 
@@ -17,7 +16,9 @@ class GriffinLim(BaseFunctionalModule):
     """y:(..., T/P, N/2+1) power spectrogram -> x:(..., T) by the accelerated Griffin-Lim iteration
     (griffin.py:263-284).  One step = inverse STFT (the STFT backward kernel with inverse-transform weights) ->
     complex STFT -> ONE element-wise launch for the momentum mix, the projection c / (|c| + eps) and the next
-    spectrogram sqrt(y) * angle.  Forward only: the iteration is run without building an autograd graph."""
+    spectrogram sqrt(y) * angle.  When a gradient with respect to y is wanted, the same iteration runs unrolled with the
+    element-wise part as complex tensor arithmetic (the reference's own formulation, griffin.py:263-292) around the
+    differentiable STFT / inverse STFT kernels, so autograd differentiates through it as in the reference."""
 
     def __init__(self, frame_length: int, frame_period: int, fft_length: int, *, center: bool = True,
                  mode: str = "constant", window: str | int = "blackman", norm: str | int = "power",
@@ -67,13 +68,32 @@ class GriffinLim(BaseFunctionalModule):
                  init_phase: str, verbose: bool, stft, istft) -> torch.Tensor:
         eps = 1e-16
         if y.requires_grad and torch.is_grad_enabled():
-            # the reference back-propagates through the unrolled iteration; the phase-update kernel keeps its momentum
-            # buffers in place and records no graph
-            warnings.warn("diffsptk_amd.GriffinLim does not record an autograd graph: the result is detached "
-                          "(the reference differentiates through the iteration).", stacklevel=3)
+            return GriffinLim._iterate_autograd(y, out_length, n_iter=n_iter, alpha=alpha, beta=beta, gamma=gamma,
+                                                init_phase=init_phase, stft=stft, istft=istft, eps=eps)
         with torch.no_grad():
             return GriffinLim._iterate(y, out_length, n_iter=n_iter, alpha=alpha, beta=beta, gamma=gamma,
                                        init_phase=init_phase, verbose=verbose, stft=stft, istft=istft, eps=eps)
+
+    @staticmethod
+    def _iterate_autograd(y, out_length, *, n_iter, alpha, beta, gamma, init_phase, stft, istft, eps):
+        """griffin.py:263-292 with a graph: the momentum mix and the projection as complex tensor arithmetic, the transforms on
+        the differentiable kernels (same random phase draw as the graph-free path)."""
+        s = torch.sqrt(y + eps)
+        phase = 2 * math.pi * torch.rand_like(y.detach().contiguous()) if init_phase == "random" else torch.zeros_like(y)
+        angle = torch.polar(torch.ones_like(phase), phase)
+        t_prev = d_prev = None
+        for n in range(n_iter):
+            t = stft(istft(s * angle, out_length=out_length))[..., : s.size(-2), :]
+            if n == 0:
+                c = d = t
+            else:
+                t = (1 - gamma) * d_prev + gamma * t
+                diff = t - t_prev
+                c = t + alpha * diff
+                d = t + beta * diff
+            angle = c / (c.abs() + eps)
+            t_prev, d_prev = t, d
+        return istft(s * angle, out_length=out_length)
 
     @staticmethod
     def _iterate(y, out_length, *, n_iter, alpha, beta, gamma, init_phase, verbose, stft, istft, eps):

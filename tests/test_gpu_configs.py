@@ -59,7 +59,8 @@ def test_config3_backward_batch256_vs_float64_autograd():
     ref = xs.grad.numpy()
     for i, b in enumerate(sel):
         err = np.abs(g[b] - ref[i]).max()
-        assert err < 2e-3 * np.abs(ref[i]).max(), (b, err, np.abs(ref[i]).max())
+        # measured 3.2e-7 ... 8.7e-7 of the utterance's largest entry (tools/measure_tolerances.py): bound = 3 x the worst
+        assert err < 3e-6 * np.abs(ref[i]).max(), (b, err, np.abs(ref[i]).max())
     # utterances are independent in the backward too: permuting the batch permutes the gradient, bit for bit
     idx = torch.randperm(B, generator=torch.Generator().manual_seed(4)).to(DEV)
     xp = xd.detach()[idx].clone().requires_grad_(True)
@@ -300,7 +301,7 @@ def test_mgcep_fused_spectrum_arithmetic_equals_the_differentiable_chain(dt, tol
         scale = float(b.abs().max())
         assert float((a - b.detach()).abs().max()) <= tol * scale
         ref = O.mgcep(X.double().cpu().numpy(), M, 0.42, gamma, 4)
-        assert np.abs(a.double().cpu().numpy() - ref).max() <= (1e-8 if dt == torch.float64 else 5e-4) * np.abs(ref).max()
+        assert np.abs(a.double().cpu().numpy() - ref).max() <= (1e-8 if dt == torch.float64 else 3e-6) * np.abs(ref).max()   # float32 measured 8.4e-7
 
 
 def test_bench_two_ranks_on_one_device():
@@ -325,3 +326,25 @@ def test_bench_two_ranks_on_one_device():
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2"
     assert "configs" not in d and "cpu_baseline" not in d   # N = 1 only
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (WORLD_SIZE unset): bench.py starts the ranks itself through
+    torch.distributed.run on the loopback address and rank 0's JSON line comes through -- what a driver that runs
+    `python bench.py --gpus N` gets.  Two ranks on this box's one device (DSA_BENCH_SINGLE_DEVICE), collectives over gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DSA_BENCH_SINGLE_DEVICE="1", DSA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "32",
+           "--ramp-seconds", "0"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["config"]["global_batch"] == 64

@@ -144,7 +144,8 @@ def test_mgcep_speech_512_and_gamma0_route(golden):
     close(host(m(X)), g["mgcep512_c3_5"], **F64)
     m32 = dsp.MelGeneralizedCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, c=3, n_iter=5, device=DEV)
     y32 = host(m32(X.float())).astype(np.float64)
-    assert np.abs(y32 - g["mgcep512_c3_5"]).max() < 5e-3              # float32 through pow(D, 3) on speech spectra (reference alike)
+    # float32 through pow(D, 3) on speech spectra: measured 2.9e-4 (coefficients up to 53; tools/measure_tolerances.py)
+    assert np.abs(y32 - g["mgcep512_c3_5"]).max() < 1e-3
     # gamma = 0 routes to the tuned mel-cepstral kernel (mgcep.py:97-105)
     m0 = dsp.MelGeneralizedCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, gamma=0, n_iter=10, device=DEV)
     y0 = m0(X.float())
