@@ -188,12 +188,15 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
         if (lane == 0) nxt = atomicAdd(queue, 1u);
         const long tile_next = wave_stride + (long)__builtin_amdgcn_readfirstlane((int)nxt);
 
-#ifdef DSA_MCEP_TIMING
-#define BSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && tile == wave_id && iter == n_iter - 2) g_mcep_stamps[40 + i] = __builtin_readcyclecounter(); } while (0)
+#ifdef DSA_MCEP_TIMING   // branch-free phase stamps in scalar registers, flushed at the end of the step (see DSA_STAMP)
+#define BSTAMP(i) bst_[i] = (unsigned)__builtin_readcyclecounter()
 #else
 #define BSTAMP(i)
 #endif
         for (int iter = n_iter - 1; iter >= 0; --iter) {
+#ifdef DSA_MCEP_TIMING
+            unsigned bst_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
             BSTAMP(0);
             float mcv[8];
 #pragma unroll
@@ -223,8 +226,7 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             float d256 = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) d256 = __builtin_fmaf(mcv[i], lds[B_D256 + 8 * g + i], d256);
-            d256 += __shfl_xor(d256, 16, 64);
-            d256 += __shfl_xor(d256, 32, 64);
+            d256 = rows_sum4(d256);
             const float t256 = logx256 + d256;
             float tmax = t256;
 #pragma unroll
@@ -240,8 +242,7 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
                     tmax = __builtin_fmaxf(tmax, ep[mt][r]);
                 }
             }
-            tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = __builtin_fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = rows_max4(tmax);
             const float mi = __builtin_ceilf(tmax);
             const float sh = (float)EMAX_LOG2 - mi;
             const int back = (int)mi - EMAX_LOG2;   // e = 2^back ep
@@ -275,8 +276,7 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
 #pragma unroll
             for (int it = 0; it < 3; ++it)
                 accB[it] = mfma4(keep_if(g_eq0, lds[B_E256 + it * 16 + n]), keep_if(g_eq0, e256), accB[it]);
-            rt48 += __shfl_xor(rt48, 16, 64);
-            rt48 += __shfl_xor(rt48, 32, 64);
+            rt48 = rows_sum4(rt48);
             rt48 = __builtin_fmaf(e256, lds[B_E256 + 48], rt48);
             rt48 = __builtin_ldexpf(rt48, back);
             {
@@ -315,6 +315,10 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             float xq1[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[1], -1.f)};
             float xq2[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[2], -1.f)};
             {
+                // The column-cyclic v_fmac_f32_dpp elimination of rounds 1-2 stays HERE: this kernel holds one wave per SIMD with
+                // 512 registers, the compiler keeps the register quadruples of the 4 x 4 x 1 form (blk_*, the forward's solve) in
+                // the accumulation file, and every vector instruction that touches an element then needs a v_accvgpr_read first
+                // (two back substitutions read all 112): measured 2.19 ms against 2.03 ms with this form.
                 float a[colm::TOTAL];
                 {
                     // slot 6 of every row through two per-lane pointers (col_build_rows_p): lane 0 column 24, lane 1 the
@@ -420,8 +424,7 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
                 split8(hi8, rbh[1], rbl[1]);
             }
             __builtin_amdgcn_wave_barrier();
-            eb256 += __shfl_xor(eb256, 16, 64);
-            eb256 += __shfl_xor(eb256, 32, 64);
+            eb256 = rows_sum4(eb256);
 
             BSTAMP(3);
             // ---------------- ebar^T = E rtbar^T ; zbar = ebar * e ; lbar += zbar ----------------
@@ -455,8 +458,7 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             lbar256 += zb256;
             BSTAMP(4);
             // ---------------- mbar^T += (-2 D) zbar^T : zbar scaled per frame to below 2^13 ----------------
-            zmax = __builtin_fmaxf(zmax, __shfl_xor(zmax, 16, 64));
-            zmax = __builtin_fmaxf(zmax, __shfl_xor(zmax, 32, 64));
+            zmax = rows_max4(zmax);
             const int s_z = VMAX_LOG2 - __builtin_amdgcn_frexp_expf(zmax);
             {
                 f32x4 acc2[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
@@ -487,6 +489,10 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
                     }
             }
             BSTAMP(5);
+#ifdef DSA_MCEP_TIMING
+            if (blockIdx.x == 0 && threadIdx.x == 0 && tile == wave_id && iter == n_iter - 2)
+                for (int i_ = 0; i_ < 8; ++i_) g_mcep_stamps[40 + i_] = bst_[i_];
+#endif
         }
 
         // ---------------- lbar += G mbar_0 (mcep.py:204-207 adjoint); gX = lbar / X ----------------
@@ -503,14 +509,12 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             mmax = __builtin_fmaxf(mmax, __builtin_fabsf(m0[i]));
         }
         __builtin_amdgcn_wave_barrier();
-        mmax = __builtin_fmaxf(mmax, __shfl_xor(mmax, 16, 64));
-        mmax = __builtin_fmaxf(mmax, __shfl_xor(mmax, 32, 64));
+        mmax = rows_max4(mmax);
         const int s_m = VMAX_LOG2 - __builtin_amdgcn_frexp_expf(mmax);
         float part256 = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) part256 = __builtin_fmaf(m0[i], tail_f[8 * g + i], part256);   // G[256][c] (0 past c = 24)
-        part256 += __shfl_xor(part256, 16, 64);
-        part256 += __shfl_xor(part256, 32, 64);
+        part256 = rows_sum4(part256);
         lbar256 += part256;
         {
             float ms[8];
