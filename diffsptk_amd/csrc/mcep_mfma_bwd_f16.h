@@ -193,27 +193,35 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
 #else
 #define BSTAMP(i)
 #endif
+        float mcv_n[8], h0_n[KS], h1_n[KS];
+        auto load_step = [&](int it_) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mcv_n[i] = (8 * g + i < M1) ? hist[((long)it_ * F + f) * M1 + 8 * g + i] : 0.f;
+            const long fq_raw = tile * 16 + nq;
+            const float* h0 = hist + ((long)it_ * F + (fq_raw < F ? fq_raw : F - 1)) * M1;
+            const float* h1 = it_ + 1 < n_iter ? h0 + F * M1 : h0;   // the last forward step's result is not in the history
+#pragma unroll
+            for (int c = 0; c < KS - 1; ++c) { h0_n[c] = h0[gs + 4 * c]; h1_n[c] = h1[gs + 4 * c]; }
+            h0_n[KS - 1] = h0[M1 - 1]; h1_n[KS - 1] = h1[M1 - 1];
+        };
+        load_step(n_iter - 1);
         for (int iter = n_iter - 1; iter >= 0; --iter) {
 #ifdef DSA_MCEP_TIMING
-            unsigned bst_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned bst_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
             BSTAMP(0);
+            // this step's iterate and (for every step but the last of the forward sweep) the step's own solution
+            // g = A^-1 (rt[:25] - alpha) as the difference of two SAVED iterates (mcep.py:224: mc <- mc + g): both were requested
+            // one step ahead (a load from the history costs a round trip to memory at the head of every step otherwise)
             float mcv[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) mcv[i] = (8 * g + i < M1) ? hist[((long)iter * F + f) * M1 + 8 * g + i] : 0.f;
-            // The step's own solution g = A^-1 (rt[:25] - alpha) is the difference of two SAVED iterates (mcep.py:224:
-            // mc <- mc + g) for every step but the last one, whose result is not in the history: there the second
-            // back substitution recomputes it.  Fetched here, in the solve's quad layout (k = gs + 4 c), used after the solve.
+            for (int i = 0; i < 8; ++i) mcv[i] = mcv_n[i];
             const bool g_saved = iter + 1 < n_iter;
             float gh[KS];
-            if (g_saved) {
-                const long fq_raw = tile * 16 + nq;
-                const float* h0 = hist + ((long)iter * F + (fq_raw < F ? fq_raw : F - 1)) * M1;
-                const float* h1 = h0 + F * M1;
 #pragma unroll
-                for (int c = 0; c < KS - 1; ++c) gh[c] = h1[gs + 4 * c] - h0[gs + 4 * c];
-                gh[KS - 1] = keep_if(gq.m[0], h1[M1 - 1] - h0[M1 - 1]);   // k = 24 on lane 0 only
-            }
+            for (int c = 0; c < KS; ++c) gh[c] = h1_n[c] - h0_n[c];
+            gh[KS - 1] = keep_if(gq.m[0], gh[KS - 1]);   // k = 24 on lane 0 only
+            if (iter > 0) load_step(iter - 1);
             // ---------------- forward quantities of this step: e (kept, scaled by 2^sh), rt -> LDS windows ----------------
             f16x8 bh, bl;
             {
@@ -228,55 +236,129 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             for (int i = 0; i < 8; ++i) d256 = __builtin_fmaf(mcv[i], lds[B_D256 + 8 * g + i], d256);
             d256 = rows_sum4(d256);
             const float t256 = logx256 + d256;
+            // The two forward chains as an explicit software pipeline (see the forward kernel): one binary16 product per slot, the
+            // vector work of the previous group of tiles between the products, operand images read one body ahead; products
+            // into one accumulator four slots apart (a dependent product waits out the full latency of its predecessor).
+#define DSA_SB() __builtin_amdgcn_sched_barrier(0x0004)
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
             float tmax = t256;
+            {
+                f16x8 al[4], ah[4];
 #pragma unroll
-            for (int mt = 0; mt < 16; ++mt) {
-                const f16x8 ah = DH[mt * 64], al = DL[mt * 64];
-                f32x4 c = {0, 0, 0, 0};
-                c = mfma_h(al, bh, c);
-                c = mfma_h(ah, bl, c);
-                c = mfma_h(ah, bh, c);
+                for (int i = 0; i < 4; ++i) { al[i] = DL[i * 64]; ah[i] = DH[i * 64]; }
+                f32x4 c[4] = {zero4, zero4, zero4, zero4}, pc[4] = {zero4, zero4, zero4, zero4};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ep[mt][r] = __builtin_fmaf(c[r], kInvSDM, logx[mt][r]);
-                    tmax = __builtin_fmaxf(tmax, ep[mt][r]);
+                for (int q = 0; q < 5; ++q) {
+                    const bool pm = q < 4, vw = q > 0;   // products of group q, vector work of group q - 1
+                    f16x8 ah_n[4] = {ah[0], ah[1], ah[2], ah[3]};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (q < 3) ah_n[i] = DH[(4 * q + 4 + i) * 64];
+                        if (pm) c[i] = mfma_h(al[i], bh, zero4);
+                        DSA_SB();
+                        if (vw) {
+                            const f32x2v ta = fma2(lo2(pc[i]), kInvSDM, lo2(logx[4 * q - 4 + i]));
+                            const f32x2v tb = fma2(hi2(pc[i]), kInvSDM, hi2(logx[4 * q - 4 + i]));
+                            ep[4 * q - 4 + i] = f32x4{ta[0], ta[1], tb[0], tb[1]};
+                        }
+                        DSA_SB();
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (pm) c[i] = mfma_h(ah[i], bl, c[i]);
+                        if (q < 3) al[i] = DL[(4 * q + 4 + i) * 64];
+                        DSA_SB();
+                        if (vw) {
+                            const f32x4 v = ep[4 * q - 4 + i];
+                            tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, v[0]), v[1]);
+                            tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, v[2]), v[3]);
+                        }
+                        DSA_SB();
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (pm) c[i] = mfma_h(ah[i], bh, c[i]);
+                        DSA_SB();
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { pc[i] = c[i]; ah[i] = ah_n[i]; }
                 }
             }
+            BSTAMP(6);
+            f16x8 eah[3], eal[3];
+#pragma unroll
+            for (int it = 0; it < 3; ++it) { eah[it] = EH[(it * 8) * 64]; eal[it] = EL[(it * 8) * 64]; }
             tmax = rows_max4(tmax);
             const float mi = __builtin_ceilf(tmax);
             const float sh = (float)EMAX_LOG2 - mi;
             const int back = (int)mi - EMAX_LOG2;   // e = 2^back ep
-            f32x4 accB[3] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-            float rt48 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float ev[8];
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int mt = 2 * j + tt;
-                    const f32x4 c48 = E484[mt * 4 + g];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        ep[mt][r] = __builtin_amdgcn_exp2f(ep[mt][r] + sh);
-                        ev[4 * tt + r] = ep[mt][r];
-                        rt48 = __builtin_fmaf(ep[mt][r], c48[r], rt48);
-                    }
-                }
-                f16x8 eh, el;
-                split8(ev, eh, el);
-#pragma unroll
-                for (int it = 0; it < 3; ++it) {
-                    const f16x8 ah = EH[(it * 8 + j) * 64], al = EL[(it * 8 + j) * 64];
-                    accB[it] = mfma_h(al, eh, accB[it]);
-                    accB[it] = mfma_h(ah, el, accB[it]);
-                    accB[it] = mfma_h(ah, eh, accB[it]);
-                }
-            }
             const float e256 = __builtin_amdgcn_exp2f(t256 + sh);   // scaled like ep
+            // the Nyquist bin preloads the accumulators of the second chain
+            f32x4 accB[3];
 #pragma unroll
-            for (int it = 0; it < 3; ++it)
-                accB[it] = mfma4(keep_if(g_eq0, lds[B_E256 + it * 16 + n]), keep_if(g_eq0, e256), accB[it]);
-            rt48 = rows_sum4(rt48);
+            for (int it = 0; it < 3; ++it) accB[it] = *reinterpret_cast<const f32x4*>(lds + B_E256 + it * 16 + 4 * g) * e256;
+            f32x2v rt48v = {0.f, 0.f};
+            float rt48 = 0.f;
+            f16x8 eh_p = {}, el_p = {};
+            DSA_SB();
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                f16x8 eh = eh_p, el = el_p;
+                f16x8 eah_n[3] = {eah[0], eah[1], eah[2]};
+                f32x4 c48[2] = {zero4, zero4};
+                if (j < 8) {
+                    c48[0] = E484[(2 * j) * 4 + g];
+                    c48[1] = E484[(2 * j + 1) * 4 + g];
+                }
+                if (j > 0 && j < 8) {
+#pragma unroll
+                    for (int it = 0; it < 3; ++it) eah_n[it] = EH[(it * 8 + j) * 64];
+                }
+                auto prodE = [&](int i) __attribute__((always_inline)) {   // i = 3 term + it
+                    if (j > 0) {
+                        const int it = i % 3, term = i / 3;
+                        accB[it] = mfma_h(term == 0 ? eal[it] : eah[it], term == 1 ? el_p : eh_p, accB[it]);
+                    }
+                };
+                auto vecA = [&](int t_) __attribute__((always_inline)) {   // e = exp2(t + sh), kept for zbar = ebar * e
+                    const int mt = (2 * j + t_) & 15;
+                    const f32x2v ta = lo2(ep[mt]) + f32x2v{sh, sh}, tb = hi2(ep[mt]) + f32x2v{sh, sh};
+                    ep[mt] = f32x4{__builtin_amdgcn_exp2f(ta[0]), __builtin_amdgcn_exp2f(ta[1]), __builtin_amdgcn_exp2f(tb[0]),
+                                   __builtin_amdgcn_exp2f(tb[1])};
+                };
+                auto vecD = [&](int t_) __attribute__((always_inline)) {
+                    const int mt = (2 * j + t_) & 15;
+                    rt48v = lo2(ep[mt]) * lo2(c48[t_]) + rt48v;
+                    rt48v = hi2(ep[mt]) * hi2(c48[t_]) + rt48v;
+                };
+                auto vecE = [&](int t_, int r) __attribute__((always_inline)) {
+                    const int mt = (2 * j + t_) & 15;
+                    f16x2 h, l;
+                    split2(ep[mt][r], ep[mt][r + 1], h, l);
+                    eh[4 * t_ + r] = h[0]; eh[4 * t_ + r + 1] = h[1];
+                    el[4 * t_ + r] = l[0]; el[4 * t_ + r + 1] = l[1];
+                };
+                const bool vw = j < 8;   // body 8 only drains the second chain
+                prodE(0); DSA_SB(); if (vw) vecA(0); DSA_SB();
+                prodE(1); DSA_SB(); if (vw) vecA(1); DSA_SB();
+                if (j == 8) rt48 = rows_sum4(rt48v[0] + rt48v[1]);
+                prodE(2);
+                if (j > 0 && j < 8) {
+#pragma unroll
+                    for (int it = 0; it < 3; ++it) eal[it] = EL[(it * 8 + j) * 64];
+                }
+                DSA_SB(); if (vw) vecD(0); DSA_SB();
+                prodE(3); DSA_SB(); if (vw) vecE(0, 0); DSA_SB();
+                prodE(4); DSA_SB(); if (vw) vecD(1); DSA_SB();
+                prodE(5); DSA_SB(); if (vw) vecE(0, 2); DSA_SB();
+                prodE(6); DSA_SB(); if (vw) vecE(1, 0); DSA_SB();
+                prodE(7); DSA_SB(); if (vw) vecE(1, 2); DSA_SB();
+                prodE(8); DSA_SB();
+                eh_p = eh; el_p = el;
+#pragma unroll
+                for (int it = 0; it < 3; ++it) eah[it] = eah_n[it];
+            }
+            BSTAMP(7);
             rt48 = __builtin_fmaf(e256, lds[B_E256 + 48], rt48);
             rt48 = __builtin_ldexpf(rt48, back);
             {
@@ -433,24 +515,57 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             f32x4 zb[16];
             float zmax = 0.f;
             {
+                // groups of four tiles: 24 products (2 k-steps x 3 terms x 4 tiles; the four tiles' accumulators take turns, so a
+                // product is four slots behind its predecessor in the same accumulator), the streamed E image of the NEXT group
+                // requested while this group multiplies, the vector work of the PREVIOUS group between the products
                 const unsigned lane16 = (unsigned)lane * 16u;
+                f16x8 ah[4][2], al[4][2];
 #pragma unroll
-                for (int mt = 0; mt < 16; ++mt) {
-                    f32x4 acc = {0, 0, 0, 0};
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        const f16x8 ah = gload8(img_rsrc, lane16, 2 * (IMG_EBH + (mt * 2 + ks) * 512));
-                        const f16x8 al = gload8(img_rsrc, lane16, 2 * (IMG_EBL + (mt * 2 + ks) * 512));
-                        acc = mfma_h(al, rbh[ks], acc);
-                        acc = mfma_h(ah, rbl[ks], acc);
-                        acc = mfma_h(ah, rbh[ks], acc);
+                        ah[i][ks] = gload8(img_rsrc, lane16, 2 * (IMG_EBH + (i * 2 + ks) * 512));
+                        al[i][ks] = gload8(img_rsrc, lane16, 2 * (IMG_EBL + (i * 2 + ks) * 512));
+                    }
+                f32x4 acc[4] = {zero4, zero4, zero4, zero4}, pacc[4] = {zero4, zero4, zero4, zero4};
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const bool pm = q < 4, vw = q > 0;
+                    f16x8 ah_n[4][2], al_n[4][2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) { ah_n[i][ks] = ah[i][ks]; al_n[i][ks] = al[i][ks]; }
+                    auto vec = [&](int i, int half) __attribute__((always_inline)) {
+                        // zbar = ebar * e (mcep.py:212 adjoint): two bins per instruction, exact power-of-two rescale
+                        const int mt = 4 * q - 4 + i;
+                        const f32x2v a2 = half ? hi2(pacc[i]) : lo2(pacc[i]), e2 = half ? hi2(ep[mt]) : lo2(ep[mt]);
+                        const f32x2v m2 = a2 * e2;
+                        const float z0 = __builtin_ldexpf(m2[0], kz), z1 = __builtin_ldexpf(m2[1], kz);
+                        zb[mt][2 * half] = z0; zb[mt][2 * half + 1] = z1;
+                        const f32x2v l2 = (half ? hi2(lbar[mt]) : lo2(lbar[mt])) + f32x2v{z0, z1};
+                        lbar[mt][2 * half] = l2[0]; lbar[mt][2 * half + 1] = l2[1];
+                        zmax = __builtin_fmaxf(__builtin_fmaxf(zmax, __builtin_fabsf(z0)), __builtin_fabsf(z1));
+                    };
+#pragma unroll
+                    for (int term = 0; term < 6; ++term) {   // (k-step, term) = (0, lo hi) (0, hi lo) (0, hi hi) (1, ..) ..
+                        const int ks = term / 3, tr = term % 3;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (pm) acc[i] = mfma_h(tr == 0 ? al[i][ks] : ah[i][ks], tr == 1 ? rbl[ks] : rbh[ks], term == 0 ? zero4 : acc[i]);
+                            // the next group's image: each operand register is requested right after its last use
+                            if (q < 3 && tr == 0) al_n[i][ks] = gload8(img_rsrc, lane16, 2 * (IMG_EBL + ((4 * q + 4 + i) * 2 + ks) * 512));
+                            if (q < 3 && tr == 2) ah_n[i][ks] = gload8(img_rsrc, lane16, 2 * (IMG_EBH + ((4 * q + 4 + i) * 2 + ks) * 512));
+                            DSA_SB();
+                            if (vw && term < 2) vec(i, term);
+                            DSA_SB();
+                        }
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float z = __builtin_ldexpf(acc[r] * ep[mt][r], kz);
-                        zb[mt][r] = z;
-                        lbar[mt][r] += z;
-                        zmax = __builtin_fmaxf(zmax, __builtin_fabsf(z));
+                    for (int i = 0; i < 4; ++i) {
+                        pacc[i] = acc[i];
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) { ah[i][ks] = ah_n[i][ks]; al[i][ks] = al_n[i][ks]; }
                     }
                 }
             }
@@ -461,37 +576,63 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             zmax = rows_max4(zmax);
             const int s_z = VMAX_LOG2 - __builtin_amdgcn_frexp_expf(zmax);
             {
-                f32x4 acc2[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+                // body j: the six products of bins 32 (j - 1) .. into FOUR accumulators (coefficient tile x parity of j: a product
+                // is four slots behind its predecessor in the same accumulator), around the rescale + binary16 split of bins 32 j ..
+                f32x4 acc2[2][2] = {{zero4, zero4}, {zero4, zero4}};
+                f16x8 zh_p = {}, zl_p = {};
+                f16x8 dh[2], dl[2];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float zv[8];
+                for (int it2 = 0; it2 < 2; ++it2) { dh[it2] = DBH[(it2 * 8) * 64]; dl[it2] = DBL[(it2 * 8) * 64]; }
+                DSA_SB();
+                BSTAMP(8);
 #pragma unroll
-                    for (int tt = 0; tt < 2; ++tt)
+                for (int j = 0; j < 9; ++j) {
+                    f16x8 zh = zh_p, zl = zl_p;
+                    f16x8 dh_n[2] = {dh[0], dh[1]}, dl_n[2] = {dl[0], dl[1]};
+                    if (j > 0 && j < 8) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) zv[4 * tt + r] = __builtin_ldexpf(zb[2 * j + tt][r], s_z);
-                    f16x8 zh, zl;
-                    split8(zv, zh, zl);
-#pragma unroll
-                    for (int it2 = 0; it2 < 2; ++it2) {
-                        const f16x8 ah = DBH[(it2 * 8 + j) * 64], al = DBL[(it2 * 8 + j) * 64];
-                        acc2[it2] = mfma_h(al, zh, acc2[it2]);
-                        acc2[it2] = mfma_h(ah, zl, acc2[it2]);
-                        acc2[it2] = mfma_h(ah, zh, acc2[it2]);
+                        for (int it2 = 0; it2 < 2; ++it2) { dh_n[it2] = DBH[(it2 * 8 + j) * 64]; dl_n[it2] = DBL[(it2 * 8 + j) * 64]; }
                     }
+                    auto prodM = [&](int i) __attribute__((always_inline)) {   // i = 2 term + it2
+                        if (j > 0) {
+                            const int it2 = i & 1, term = i >> 1;
+                            f32x4& a2 = acc2[it2][(j - 1) & 1];
+                            a2 = mfma_h(term == 0 ? dl[it2] : dh[it2], term == 1 ? zl_p : zh_p, a2);
+                        }
+                    };
+                    auto vecZ = [&](int t_, int r) __attribute__((always_inline)) {
+                        const int mt = (2 * j + t_) & 15;
+                        f16x2 h, l;
+                        split2(__builtin_ldexpf(zb[mt][r], s_z), __builtin_ldexpf(zb[mt][r + 1], s_z), h, l);
+                        zh[4 * t_ + r] = h[0]; zh[4 * t_ + r + 1] = h[1];
+                        zl[4 * t_ + r] = l[0]; zl[4 * t_ + r + 1] = l[1];
+                    };
+                    const bool vw = j < 8;
+                    prodM(0); DSA_SB(); if (vw) vecZ(0, 0); DSA_SB();
+                    prodM(1); DSA_SB(); if (vw) vecZ(0, 2); DSA_SB();
+                    prodM(2); DSA_SB(); if (vw) vecZ(1, 0); DSA_SB();
+                    prodM(3); DSA_SB(); if (vw) vecZ(1, 2); DSA_SB();
+                    prodM(4); DSA_SB();
+                    prodM(5); DSA_SB();
+                    zh_p = zh; zl_p = zl;
+#pragma unroll
+                    for (int it2 = 0; it2 < 2; ++it2) { dh[it2] = dh_n[it2]; dl[it2] = dl_n[it2]; }
                 }
+                BSTAMP(9);
 #pragma unroll
                 for (int it2 = 0; it2 < 2; ++it2)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int c = it2 * 16 + 4 * g + r;   // < 32
-                        mbarC[it2][r] += __builtin_ldexpf(acc2[it2][r], -s_z - SDB_LOG2);
+                        mbarC[it2][r] += __builtin_ldexpf(acc2[it2][0][r] + acc2[it2][1][r], -s_z - SDB_LOG2);
                         mbarC[it2][r] = __builtin_fmaf(zb256, lds[B_D256 + 32 + c], mbarC[it2][r]);   // Nyquist bin (table is 0 past c = 24)
                     }
             }
+#undef DSA_SB
             BSTAMP(5);
 #ifdef DSA_MCEP_TIMING
             if (blockIdx.x == 0 && threadIdx.x == 0 && tile == wave_id && iter == n_iter - 2)
-                for (int i_ = 0; i_ < 8; ++i_) g_mcep_stamps[40 + i_] = bst_[i_];
+                for (int i_ = 0; i_ < 16; ++i_) g_mcep_stamps[40 + i_] = bst_[i_];
 #endif
         }
 

@@ -58,10 +58,12 @@ int main(int argc, char** argv)
     }
     unsigned long long st[64];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(dsa::g_mcep_stamps), sizeof(st));
-    unsigned s[8];
-    for (int i = 0; i < 8; ++i) s[i] = (unsigned)st[40 + i];
+    unsigned s[16];
+    for (int i = 0; i < 16; ++i) s[i] = (unsigned)st[40 + i];
     printf("kernel %.4f ms (best of the last %d) | wave 0, first tile, second step, cycles: forward chains + windows %u  build + solve %u  rtbar + scale %u  ebar chain %u  mbar chain %u  = %u\n",
            best, reps - reps / 2, s[1] - s[0], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[5] - s[4], s[5] - s[0]);
+    printf("   forward: first chain %u  reduction + second chain %u  windows %u | mbar: prologue %u  bodies %u  epilogue %u\n", s[6] - s[0], s[7] - s[6],
+           s[1] - s[7], s[8] - s[4], s[9] - s[8], s[5] - s[9]);
     std::vector<float> h(4);
     hipMemcpy(h.data(), gX, 16, hipMemcpyDeviceToHost);
     printf("   gX[0..3] = %g %g %g %g\n", h[0], h[1], h[2], h[3]);
