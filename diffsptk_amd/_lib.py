@@ -22,11 +22,10 @@ HIPCC_FLAGS = (
     "-mcode-object-version=5", "-Wno-unused-value", "-ffp-contract=on",
 )
 # Per-source additions.  stft.hip: the compiler's automatic v_pk_*_f32 selection costs the register-FFT kernels
-# more in register-pairing moves than it saves (forward 88 -> 82 us per 204 800 frames without it); the
-# experimental matrix-core STFT (stft_mfma.h: hand-written packed inline asm, not yet deterministic) is left out
-# of the product build -- tools/bench_stft_mfma.cpp still compiles it.
+# more in register-pairing moves than it saves (forward 88 -> 82 us per 204 800 frames without it; the packed
+# kernels of stft_pk.h / stft_bwd_pk.h switch the feature back on for themselves and place v_pk_* by hand).
 SOURCE_FLAGS = {
-    "stft.hip": ("-DDSA_NO_STFT_MFMA", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"),
+    "stft.hip": ("-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"),
 }
 
 F32, F64 = 0, 1

@@ -1527,10 +1527,6 @@ __global__ void griffin_update_kernel(const T* __restrict__ t, long B, long Nt, 
 
 }  // namespace dsa
 
-#ifndef DSA_NO_STFT_MFMA
-#include "stft_mfma.h"
-#endif
-
 using namespace dsa;
 
 // =========================================================================== C-ABI
@@ -1763,19 +1759,6 @@ DSA_EXPORT int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int3
     bool tuned_ok = dtype == DSA_F32 && nfft == 512 && L <= 512 && lds <= 64 * 1024;
     if (algo == DSA_ALGO_TUNED && !tuned_ok)
         return fail(DSA_ERR_UNSUPPORTED, "stft: tuned kernel needs float32, fft_length 512, frame_length <= 512%s");
-    // DSA_STFT_VARIANT: 0 = register-FFT kernel (default); 1 = experimental matrix-core kernel where it
-    // applies (faster, but see the STATUS note in stft_mfma.h: not yet deterministic)
-    static const int stft_variant = [] {
-        const char* e = getenv("DSA_STFT_VARIANT");
-        return e ? atoi(e) : 0;
-    }();
-#ifndef DSA_NO_STFT_MFMA
-    if (tuned_ok && algo != DSA_ALGO_GENERIC && stft_variant == 1 && !zmean && !use_floor &&
-        out_format != DSA_SPEC_COMPLEX && pad_mode == DSA_PAD_CONSTANT && T < (1L << 29) && (L & 3) == 0 &&
-        (P & 3) == 0 && (left & 3) == 0 && 15 * P + L <= 2048)
-        return stft512_mfma_launch((const float*)x, (long)B, (long)T, (long)N, L, P, left, pad_mode, (const float*)w,
-                                   (float)eps, out_format, (float*)y, st);
-#endif
     if (tuned_ok && algo != DSA_ALGO_GENERIC) {
         int chunks_per_utt = (int)((N + kFPW - 1) / kFPW);
         long total_chunks = (long)B * chunks_per_utt;

@@ -218,6 +218,14 @@ __global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_
         if (per * 8 == gridDim.x) wid = ((blockIdx.x & 7) * per + (blockIdx.x >> 3)) * WPB + wv;
     }
 
+    if (ABL & (1024 | 2048 | 4096)) {
+        // experiment: consecutive workgroup ids sit on different XCDs (id % 8), so neighbouring passes -- which share L - P samples --
+        // never share an L2.  Here the workgroups of one XCD take C CONSECUTIVE logical workgroups out of every 8 C (the passes
+        // in flight stay one contiguous window of the output, unlike the XCD-contiguous order above)
+        constexpr unsigned C = (ABL & 1024) ? 4 : ((ABL & 2048) ? 2 : 8);
+        const unsigned bq = blockIdx.x, xcd = bq & 7, r = bq >> 3;
+        if (gridDim.x % (8 * C) == 0) wid = (long)((r / C) * (8 * C) + xcd * C + (r % C)) * WPB + wv;
+    }
     const int lane = threadIdx.x & 63;
     const int j = lane & 15;   // lane within the frame group
     const int fl = lane >> 4;  // frame slot within the pass (0..3)

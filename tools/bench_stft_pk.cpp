@@ -1,5 +1,5 @@
 // Ablation / timeline microbenchmark of the packed STFT forward kernel (dev tool, not shipped):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mcode-object-version=5 -Wno-unused-value -DDSA_NO_STFT_MFMA \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mcode-object-version=5 -Wno-unused-value \
 //         -DDSA_STFT_TIMING -Xclang -target-feature -Xclang -packed-fp32-ops -I. tools/bench_stft_pk.cpp -o build/bench_stft_pk
 #include "../diffsptk_amd/csrc/stft.hip"
 
@@ -73,6 +73,9 @@ int main(int argc, char** argv)
     for (int rep = 0; rep < 2; ++rep)
         printf("DIRECT variants: base %.1f | xcd-contiguous %.1f | nontemporal %.1f | both %.1f | xcd, staged %.1f\n", run<0, true>(20, 16), run<256, true>(20, 16),
                run<512, true>(20, 16), run<768, true>(20, 16), run<256, false>(20, 16));
+    for (int rep = 0; rep < 3; ++rep)
+        printf("DIRECT, XCD-chunked workgroup order: base %.1f | C=2 %.1f | C=4 %.1f | C=8 %.1f | base %.1f\n", run<0, true>(20, 16), run<2048, true>(20, 16),
+               run<1024, true>(20, 16), run<4096, true>(20, 16), run<0, true>(20, 16));
     {   // DIRECT against the staged variant, element by element
         size_t n = (size_t)gB * gN * 257;
         std::vector<float> a(n), b(n);

@@ -1,3 +1,6 @@
+// MOVED OUT OF THE PRODUCT TREE in round 3 (was diffsptk_amd/csrc/stft_mfma.h, compiled out since round 2): the matrix-core STFT
+// below leaves one stale bin in about one launch of three and is slower than the packed register FFT of stft_pk.h (119-129 us
+// against 69-73 us per 204 800 frames).  Kept for the record; nothing builds it.
 // Matrix-core STFT for fft_length 512, float32 (included by stft.hip).
 // ShortTimeFourierTransform._forward, stft.py:237-241 = Frame (frame.py:120-141) -> Window
 // (window.py:185-193) -> rfft (fftr.py:136-151) -> |.|^2 + eps / formatter (spec.py:152-178),
