@@ -429,59 +429,89 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             // ---------------- rtbar (49 entries), scaled per frame to below 2^13, into the exchange window ----------------
             int s_r;   // rtbar = 2^-s_r (window contents)
             {
-                // rtbar[m] = -sum_{i+j=m} u_i g_j - [m<25] (sum_{|i-j|=m} u_i g_j - u_m), split over the quad by
-                // i = gs + 4 c: lane gs holds uq[c] = u[gs + 4 c] (the quad-layout solution xq2) and reads two
-                // shifted copies of g through the exchange window -- gsh1[k] = g[k - gs], gsh2[k] = g[k + gs]
-                // (zero outside 0..24) -- so every index below is a compile-time constant; 4 x fewer
-                // multiply-adds than every lane forming all 49 sums, then one quad all-reduce per entry.
-                const float (&uq)[KS] = xq2;
-                // window: [0,3) zeros | g[0..24] at 3..27 | zeros to 33: every lane stores its own quarter of g
+                // rtbar[m] = -sum_{i+j=m} u_i g_j - [m<25] (sum_{|i-j|=m} u_i g_j - u_m), m = 0 .. 48, from the outer product
+                // P = u g^T formed on the float32 matrix instruction: one v_mfma_f32_4x4x1 is the 4 x 4 block
+                // u[4 ri ..] (x) g[4 cj ..] of all 16 frames of the wave (A = slot ri of u, B = slot cj of g: the solve's quad
+                // layout as it stands).  Blocks on one block anti-diagonal (ri + cj = s) accumulate into DH[s], blocks on one
+                // block diagonal (cj - ri = d) into DT[d + 6]: 2 x 49 products.  Entry [i'][j'] (register i', lane j') of DH[s]
+                // belongs to m = 4 s + i' + j', of DT[d + 6] to the signed offset j - i = 4 d + j' - i'; the sums over the
+                // entries of equal m are three quad rotations per accumulator (DPP operands of the additions) with a lane select
+                // for the entries that spill into the neighbouring slot.  Result in the quad layout: lane w of slot s holds m = 4 s + w.
+                // (Rounds 1-2: ~420 multiply-adds and 98 quad reductions per frame quad on the vector ALU, every lane forming all 49.)
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 DH[13], DT[13];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) aux_q[k] = 0.f;
+                for (int k = 0; k < 13; ++k) { DH[k] = z4; DT[k] = z4; }
 #pragma unroll
-                for (int c = 0; c < KS; ++c) aux_q[3 + gs + 4 * c] = xq1[c];   // c = 6: x[24] at 27, zeros at 28..30
+                for (int ri = 0; ri < KS; ++ri)
 #pragma unroll
-                for (int k = 31; k < 34; ++k) aux_q[k] = 0.f;
-                __builtin_amdgcn_wave_barrier();
-                float gsh1[28], gsh2[31];                      // gsh2 index k + 3, k = -3 .. 27
-                const float* w1 = aux_q + 3 - gs;
-                const float* w2 = aux_q + gs;
-#pragma unroll
-                for (int k = 0; k < 28; ++k) gsh1[k] = w1[k];
-#pragma unroll
-                for (int k = 0; k < 31; ++k) gsh2[k] = w2[k];
-                __builtin_amdgcn_wave_barrier();
-                float rb[M2];
-#pragma unroll
-                for (int m = 0; m < M2; ++m) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int c = 0; c < KS; ++c) {
-                        if (m - 4 * c >= 0 && m - 4 * c <= 27) acc = __builtin_fmaf(-uq[c], gsh1[m - 4 * c], acc);          // i + j = m
-                        if (m < M1 && 4 * c + m <= 27) acc = __builtin_fmaf(-uq[c], gsh2[4 * c + m + 3], acc);               // j - i = m
-                        if (m < M1 && m > 0 && 4 * c - m >= -3) acc = __builtin_fmaf(-uq[c], gsh2[4 * c - m + 3], acc);      // i - j = m
+                    for (int cj = 0; cj < KS; ++cj) {
+                        DH[ri + cj] = mfma441(xq2[ri], xq1[cj], DH[ri + cj]);
+                        DT[cj - ri + 6] = mfma441(xq2[ri], xq1[cj], DT[cj - ri + 6]);
                     }
-                    if (m < M1) acc += keep_if(gq.m[m & 3], uq[m >> 2]);   // through the right-hand side rt[:25] - alpha
-                    acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-                    acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
-                    rb[m] = acc;
+                // quad rotations: dst lane w <- src lane perm[w]
+                auto rotR = [](float v, int k) __attribute__((always_inline)) {   // w <- (w - k) mod 4
+                    const int ctrl = k == 1 ? 0x93 : (k == 2 ? 0x4E : 0x39);    // [3,0,1,2] [2,3,0,1] [1,2,3,0]
+                    return k == 1 ? __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x93, 0xf, 0xf, true))
+                           : k == 2 ? __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true))
+                                    : __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x39, 0xf, 0xf, true));
+                    (void)ctrl;
+                };
+                auto rotL = [](float v, int k) __attribute__((always_inline)) {   // w <- (w + k) mod 4
+                    return k == 1 ? __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x39, 0xf, 0xf, true))   // [1,2,3,0]
+                           : k == 2 ? __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)) // [2,3,0,1]
+                                    : __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x93, 0xf, 0xf, true)); // [3,0,1,2]
+                };
+                auto refl = [](float v, int k) __attribute__((always_inline)) {   // w <- (k - w) mod 4
+                    return k == 0 ? __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x6C, 0xf, 0xf, true))   // [0,3,2,1]
+                           : k == 1 ? __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)) // [1,0,3,2]
+                           : k == 2 ? __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xC6, 0xf, 0xf, true)) // [2,1,0,3]
+                                    : __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x1B, 0xf, 0xf, true)); // [3,2,1,0]
+                };
+                float rb[13];   // quad layout: lane gs of slot s holds rtbar[4 s + gs]
+#pragma unroll
+                for (int sl = 0; sl < 13; ++sl) {
+                    // Hankel part: entry (i', j') of DH[sl] with i' + j' < 4 stays in slot sl, i' + j' >= 4 belongs to slot sl + 1
+                    float h = DH[sl][0];
+#pragma unroll
+                    for (int ip = 1; ip < 4; ++ip) {
+                        const float prev = sl > 0 ? DH[sl - 1][ip] : 0.f;
+                        h += rotR(gs < 4 - ip ? DH[sl][ip] : prev, ip);
+                    }
+                    float r = -h;
+                    if (sl < 7) {
+                        // Toeplitz part.  j - i = 4 d + (j' - i') >= 0 -> m = j - i: slot d (j' >= i') or d - 1 (j' < i')
+                        float tp = DT[sl + 6][0];
+#pragma unroll
+                        for (int ip = 1; ip < 4; ++ip) {
+                            const float nxt = sl + 7 < 13 ? DT[sl + 7][ip] : 0.f;
+                            tp += rotL(gs >= ip ? DT[sl + 6][ip] : nxt, ip);
+                        }
+                        // i - j = -4 d + (i' - j') > 0 -> m = i - j: slot -d (j' <= i') or -d - 1 (j' > i')
+                        float tn = 0.f;
+#pragma unroll
+                        for (int ip = 0; ip < 4; ++ip) {
+                            const float far = 6 - sl - 1 >= 0 ? DT[6 - sl - 1][ip] : 0.f;
+                            tn += refl(gs <= ip ? DT[6 - sl][ip] : far, ip);
+                        }
+                        if (sl == 0) tn = gs == 0 ? 0.f : tn;   // offset 0 is counted once (it is in tp)
+                        r = r - tp - tn + xq2[sl];              // + u_m: through the right-hand side rt[:25] - alpha
+                    }
+                    rb[sl] = r;
                 }
                 float amax = 0.f;
 #pragma unroll
-                for (int m = 0; m < M2; ++m) amax = __builtin_fmaxf(amax, __builtin_fabsf(rb[m]));
+                for (int sl = 0; sl < 13; ++sl) amax = __builtin_fmaxf(amax, __builtin_fabsf(rb[sl]));
+                amax = __builtin_fmaxf(amax, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(amax), 0xB1, 0xf, 0xf, true)));
+                amax = __builtin_fmaxf(amax, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(amax), 0x4E, 0xf, 0xf, true)));
                 s_r = VMAX_LOG2 - __builtin_amdgcn_frexp_expf(amax);
-                // the four lanes of a quad hold identical sums: all of them store (16-byte pieces, same values)
-                f32x4* aux4 = reinterpret_cast<f32x4*>(aux_q);
+                // every lane stores its own entries: m = 4 s + gs for s < 13 (entries 49 .. 51 are sums of nothing: 0), zeros to 62,
+                // the scale in slot 63
 #pragma unroll
-                for (int q4 = 0; q4 < 16; ++q4) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int m = 4 * q4 + e;
-                        v[e] = m < M2 ? __builtin_ldexpf(rb[m < M2 ? m : 0], s_r) : (m == 63 ? __int_as_float(s_r) : 0.f);
-                    }
-                    aux4[q4] = v;
-                }
+                for (int sl = 0; sl < 13; ++sl) aux_q[4 * sl + gs] = __builtin_ldexpf(rb[sl], s_r);
+                aux_q[52 + gs] = 0.f;
+                aux_q[56 + gs] = 0.f;
+                aux_q[60 + gs] = gs == 3 ? __int_as_float(s_r) : 0.f;
             }
             __builtin_amdgcn_wave_barrier();
             f16x8 rbh[2], rbl[2];
