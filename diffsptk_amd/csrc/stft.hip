@@ -1441,6 +1441,14 @@ static void stft512_launch(bool zmean, dim3 grid, int lds, hipStream_t st, const
         if (use_pk == 1)   // staged 16-byte stores (A/B)
             hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, false>), g2, dim3(128), lds2, st, x, T, N, L, P, left, w, tw, eps, y,
                                total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0);
+#define DSA_PK_XCD(ABLV)                                                                                              \
+    hipLaunchKernelGGL((stft512_fwd_pk_kernel<ABLV, 400, true>), g2, dim3(128), lds2, st, x, T, N, L, P, left, w, tw, eps, y, \
+                       total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0)
+        else if (use_pk == 3) DSA_PK_XCD(1024);   // experiments (A/B): XCD-chunked workgroup order, C = 4 / 8 / 2, XCD-contiguous
+        else if (use_pk == 4) DSA_PK_XCD(4096);
+        else if (use_pk == 5) DSA_PK_XCD(2048);
+        else if (use_pk == 6) DSA_PK_XCD(256);
+#undef DSA_PK_XCD
         else               // 8-byte stores straight from the split's registers (default)
             hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, true>), g2, dim3(128), lds2, st, x, T, N, L, P, left, w, tw, eps, y,
                                total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0);
