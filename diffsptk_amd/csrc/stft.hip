@@ -1448,6 +1448,10 @@ static void stft512_launch(bool zmean, dim3 grid, int lds, hipStream_t st, const
         else if (use_pk == 4) DSA_PK_XCD(4096);
         else if (use_pk == 5) DSA_PK_XCD(2048);
         else if (use_pk == 6) DSA_PK_XCD(256);
+        else if (use_pk == 7)   // the stretch fetched two passes ahead (two register sets, window table in LDS, four-wave workgroups)
+            hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, true, 0, true>), dim3((grid.x + 3) / 4), dim3(256),
+                               4 * kFPW * kZS * 8 + 256 * 8 + 16 * 13 * 8 + 64, st, x, T, N, L, P, left, w, tw, eps, y, total_chunks,
+                               chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0);
 #undef DSA_PK_XCD
         else               // 8-byte stores straight from the split's registers (default)
             hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, true>), g2, dim3(128), lds2, st, x, T, N, L, P, left, w, tw, eps, y,

@@ -195,8 +195,9 @@ __device__ unsigned long long g_stft_pk_stamps[64];
 // (v_fmac_f32_dpp with a 0/1 mask per lane and step: no transposition through LDS, no matrix operand images --
 // neither would fit beside four waves per SIMD).  Four-wave workgroups: the window moves from registers to a
 // shared LDS table to make room for the plan.
-template <int ABL, int LC, bool DIRECT = false, int FBM = 0>   // FBM: 0 spectrum out, 1 filter bank of the power values, 2 of the amplitudes
-__global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
+template <int ABL, int LC, bool DIRECT = false, int FBM = 0, bool PF2 = false>   // FBM: 0 spectrum out, 1 filter bank of the power values, 2 of the amplitudes;
+                                                                            // PF2: the stretch fetched TWO passes ahead (two register sets, window from LDS)
+__global__ __launch_bounds__((FBM || PF2) ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
     const float* __restrict__ x, long Tlen, long N, int L, int P, int left, const float* __restrict__ w,
     const float* __restrict__ twiddle, float eps, float* __restrict__ y, long total_chunks, int chunks_per_utt,
     const float* __restrict__ fbt, float fb_floor, float fb_gamma, int fbC)
@@ -204,7 +205,9 @@ __global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_
     constexpr bool FB = FBM != 0;
     static_assert(!FB || (DIRECT && LC > 0), "the filter-bank epilogue builds on the register-direct split");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int WPB = FB ? 4 : 2;   // waves per workgroup (they share the twiddle table, nothing else)
+    constexpr bool WL = FB || PF2;    // window pairs from a shared LDS table instead of 26 registers per lane
+    static_assert(!PF2 || (DIRECT && LC > 0 && !FB), "PF2 builds on the register-direct plain kernel");
+    constexpr int WPB = WL ? 4 : 2;   // waves per workgroup (they share the twiddle / window tables, nothing else)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     v2f* zbuf = reinterpret_cast<v2f*>(smem_raw) + wv * kFPW * kZS;
     float* io_buf = reinterpret_cast<float*>(zbuf);  // aliases zbuf: stretch -> tiles -> spectra -> staged output
@@ -274,7 +277,8 @@ __global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_
     // order, and a wait placed after the stores cannot tell them from the loads -- every pass would wait for its
     // own stores (measured: the pass period then follows the store latency).
     v4f pre0 = v4f{0.f, 0.f, 0.f, 0.f}, pre1 = pre0, pre2 = pre0;
-    auto prefetch = [&](long bb, int cc) __attribute__((always_inline)) -> bool {
+    v4f prb0 = pre0, prb1 = pre0, prb2 = pre0;   // PF2: the second register set
+    auto prefetch_into = [&](long bb, int cc, v4f& q0, v4f& q1, v4f& q2) __attribute__((always_inline)) -> bool {
         if (ABL & 4) return false;
         const long fr2 = (long)cc * kFPW;
         const int nv2 = (int)((N - fr2) < kFPW ? (N - fr2) : kFPW);
@@ -284,13 +288,14 @@ __global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_
         if (g2 >= 0 && g2 + need2 <= Tlen && (((size_t)(xb2 + g2)) & 15) == 0 && (need2 & 3) == 0 && need2 <= 768) {
             const v4f* src4 = reinterpret_cast<const v4f*>(xb2 + g2);
             const int n4 = need2 >> 2;
-            pre0 = src4[lane < n4 ? lane : n4 - 1];
-            pre1 = src4[lane + 64 < n4 ? lane + 64 : n4 - 1];
-            pre2 = src4[lane + 128 < n4 ? lane + 128 : n4 - 1];
+            q0 = src4[lane < n4 ? lane : n4 - 1];
+            q1 = src4[lane + 64 < n4 ? lane + 64 : n4 - 1];
+            q2 = src4[lane + 128 < n4 ? lane + 128 : n4 - 1];
             return true;
         }
         return false;
     };
+    auto prefetch = [&](long bb, int cc) __attribute__((always_inline)) -> bool { return prefetch_into(bb, cc, pre0, pre1, pre2); };
 
     // The first pass's stretch is fetched like every other one -- issued first, so that its round trip to memory
     // overlaps the table loads below instead of following them.
@@ -298,12 +303,31 @@ __global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_
     int ci = (int)(wid - b * chunks_per_utt);
     long c = wid;
     bool pre_ok = prefetch(b, ci);
+    bool prb_ok = false;
+    long bn1 = b;      // PF2: coordinates of the pass after this wave's first one
+    int cin1 = ci;
+    if (PF2) {
+        advance(bn1, cin1);
+        prb_ok = (wid + nw < total_chunks) ? prefetch_into(bn1, cin1, prb0, prb1, prb2) : false;
+    }
     PK_STAMP(3);
 
     v2f wreg[NR];
     v2f f_wd0, f_wu0, f_wd1, f_wu1, f_nb, f_mM;   // FB: the lane's plan (lower-half bin pair in .x, upper-half pair in .y)
     float f_mk[12];
     int f_addr[4], f_valid = 0;
+    if (WL && !FB) {   // the window table alone (every wave writes the whole, identical table: no barrier needed)
+        v2f wt[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int i = lane + 64 * q4;
+            const int l = 2 * (i / NR) + 32 * (i % NR);
+            wt[q4] = v2f{(i < 16 * NR && l < L) ? w[l < L ? l : 0] : 0.f, (i < 16 * NR && l + 1 < L) ? w[l + 1 < L ? l + 1 : 0] : 0.f};
+        }
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+            if (lane + 64 * q4 < 16 * NR) wtab[lane + 64 * q4] = wt[q4];
+    }
     if (FB) {
         // every wave writes the whole (identical) tables, like the twiddle table below: no workgroup barrier needed
         v2f wt[4], he[2];
@@ -336,7 +360,7 @@ __global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_
         f_addr[1] = 4 * ((flags_w & 2) ? ((slots_w >> 8) & 255) : 127);     //              upper half
         f_addr[2] = 4 * ((flags_w & 4) ? ((slots_w >> 16) & 255) : 127);    // interval closed inside the lane, lower half
         f_addr[3] = 4 * ((flags_w & 8) ? ((slots_w >> 24) & 255) : 127);    //                                  upper half
-    } else {
+    } else if (!WL) {
 #pragma unroll
         for (int m1 = 0; m1 < NR; ++m1) {
             const int l = 2 * j + 32 * m1;
@@ -371,7 +395,7 @@ __global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_
 #pragma unroll
         for (int i = 0; i < 12; ++i) asm volatile("" : "+v"(f_mk[i]));
         asm volatile("" : "+v"(f_addr[0]), "+v"(f_addr[1]), "+v"(f_addr[2]), "+v"(f_addr[3]), "+v"(f_valid));
-    } else {
+    } else if (!WL) {
 #pragma unroll
         for (int m1 = 0; m1 < NR; ++m1) asm volatile("" : "+v"(wreg[m1]));
     }
@@ -394,11 +418,20 @@ __global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_
     int ci1 = ci;
     advance(b1, ci1);
     bool has1 = c + nw < total_chunks;
-    pre_ok = has1 ? prefetch(b1, ci1) : false;
+    if (PF2) {   // pass 1 is already on its way into the second register set; the first set now takes pass 2
+        long b2 = b1;
+        int ci2 = ci1;
+        advance(b2, ci2);
+        pre_ok = (c + 2 * nw < total_chunks) ? prefetch_into(b2, ci2, pre0, pre1, pre2) : false;
+    } else {
+        pre_ok = has1 ? prefetch(b1, ci1) : false;
+    }
     PK_STAMP(1);
     int pass_no = 0;
     (void)pass_no;
-    for (;;) {
+    // One pass.  (q0, q1, q2, qok): the register set that holds the NEXT pass's stretch -- waited for before this pass's stores,
+    // staged into the tile at the end of the pass, then re-used for the fetch one (PF2: two) passes further on.
+    auto run_pass = [&](v4f& q0, v4f& q1, v4f& q2, bool& qok) __attribute__((always_inline)) -> bool {
         const long frame0 = (long)ci * kFPW;
         const int nvalid = (int)((N - frame0) < kFPW ? (N - frame0) : kFPW);
         DSA_WAVE_SYNC();
@@ -426,7 +459,7 @@ __global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_
                     const bool in0 = 32 * m1 + 30 < LC || 32 * m1 + 2 * j < LC;
                     const bool in1 = 32 * m1 + 31 < LC || 32 * m1 + 1 + 2 * j < LC;
                     const v2f r = v2f{in0 ? raw[m1].x : 0.f, in1 ? raw[m1].y : 0.f};
-                    v[m1] = pk_mul(r, FB ? wtab[j * NR + m1] : wreg[m1]);
+                    v[m1] = pk_mul(r, WL ? wtab[j * NR + m1] : wreg[m1]);
                 }
 #pragma unroll
                 for (int m1 = NR; m1 < 16; ++m1) v[m1] = v2f{0.f, 0.f};
@@ -516,7 +549,7 @@ __global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_
         const bool tile_aligned = nvalid == kFPW && (row0 & 3) == 0;   // 16-byte aligned because row0 % 4 == 0
         // the fetch for the NEXT pass has had this whole pass to arrive; it is waited for here, before the stores
         // (unconditional: on a conditional path the compiler would still schedule its own wait at the register use below)
-        if (DIRECT) asm volatile("" : "+v"(pre0), "+v"(pre1), "+v"(pre2) : : "memory");
+        if (DIRECT) asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2) : : "memory");
         v2f ends[kFPW];
 #pragma unroll
         for (int f = 0; f < kFPW; ++f) {
@@ -686,7 +719,7 @@ __global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_
 #pragma unroll
             for (int jj = 0; jj < 5; ++jj) q[jj] = s4[jj < 4 ? lane + 64 * jj : 256];
         }
-        if (!DIRECT) asm volatile("" : "+v"(pre0), "+v"(pre1), "+v"(pre2) : : "memory");   // see above
+        if (!DIRECT) asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2) : : "memory");   // see above
         if (ABL & 64) {
             if (sink.x + sink.y == 123.456f) y[out0 + lane] = sink.x;   // keeps the arithmetic alive, never true
         } else if (DIRECT) {
@@ -701,18 +734,18 @@ __global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_
             for (int idx = lane; idx < total; idx += 64) y[out0 + idx] = stage[idx];
         }
         PK_PHASE(9);
-        if (!has1) break;
+        if (!has1) return false;
         // ---- the next pass's stretch into the tile (LDS operations of a wave execute in order: the staged output
         // has been read), then the fetch for the pass after it ----
         DSA_WAVE_SYNC();
-        if (pre_ok) {
+        if (qok) {
             const long fr1 = (long)ci1 * kFPW;
             const int nv1 = (int)((N - fr1) < kFPW ? (N - fr1) : kFPW);
             const int n4 = ((nv1 - 1) * P + L) >> 2;
             v4f* dst4 = reinterpret_cast<v4f*>(io_buf);
-            if (lane < n4) dst4[lane] = pre0;
-            if (lane + 64 < n4) dst4[lane + 64] = pre1;
-            if (lane + 128 < n4) dst4[lane + 128] = pre2;
+            if (lane < n4) dst4[lane] = q0;
+            if (lane + 64 < n4) dst4[lane + 64] = q1;
+            if (lane + 128 < n4) dst4[lane + 128] = q2;
         } else {
             stage_sync(b1, ci1);
         }
@@ -721,8 +754,24 @@ __global__ __launch_bounds__(FBM ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_
         ci = ci1;
         advance(b1, ci1);
         has1 = c + nw < total_chunks;
-        pre_ok = has1 ? prefetch(b1, ci1) : false;
+        if (PF2) {   // the set just staged takes the stretch two passes ahead
+            long b2 = b1;
+            int ci2 = ci1;
+            advance(b2, ci2);
+            qok = (c + 2 * nw < total_chunks) ? prefetch_into(b2, ci2, q0, q1, q2) : false;
+        } else {
+            qok = has1 ? prefetch_into(b1, ci1, q0, q1, q2) : false;
+        }
         PK_PHASE(0);
+        return true;
+    };
+    if (PF2) {
+        for (;;) {
+            if (!run_pass(prb0, prb1, prb2, prb_ok)) break;
+            if (!run_pass(pre0, pre1, pre2, pre_ok)) break;
+        }
+    } else {
+        while (run_pass(pre0, pre1, pre2, pre_ok)) {}
     }
     PK_STAMP(2);
 }

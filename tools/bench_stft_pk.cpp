@@ -11,7 +11,7 @@ static const float *gx, *gw, *gtw;
 static float* gy;
 static long gB, gT = 16000, gN;
 
-template <int ABL, bool DIRECT = false>
+template <int ABL, bool DIRECT = false, bool PF2 = false>
 static float run(int iters, int waves_per_cu)
 {
     const int L = 400, P = 80;
@@ -24,6 +24,11 @@ static float run(int iters, int waves_per_cu)
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     auto launch = [&] {
+        if (PF2)
+            hipLaunchKernelGGL((dsa::stft512_fwd_pk_kernel<ABL, 400, true, 0, true>), dim3((unsigned)((grid + 3) / 4)), dim3(256),
+                               4 * dsa::kFPW * dsa::kZS * 8 + 256 * 8 + 16 * 13 * 8 + 64, 0, gx, gT, gN, L, P, 200, gw, gtw, 1e-9f, gy,
+                               total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0);
+        else
         hipLaunchKernelGGL((dsa::stft512_fwd_pk_kernel<ABL, 400, DIRECT>), dim3((unsigned)((grid + 1) / 2)), dim3(128), lds2, 0, gx, gT, gN, L,
                            P, 200, gw, gtw, 1e-9f, gy, total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0);
     };
@@ -76,6 +81,22 @@ int main(int argc, char** argv)
     for (int rep = 0; rep < 3; ++rep)
         printf("DIRECT, XCD-chunked workgroup order: base %.1f | C=2 %.1f | C=4 %.1f | C=8 %.1f | base %.1f\n", run<0, true>(20, 16), run<2048, true>(20, 16),
                run<1024, true>(20, 16), run<4096, true>(20, 16), run<0, true>(20, 16));
+    for (int rep = 0; rep < 3; ++rep)
+        printf("two-pass-ahead fetch (PF2): base %.1f | PF2 %.1f | base %.1f | PF2 %.1f | PF2 no-store %.1f | PF2 no-load %.1f\n", run<0, true>(20, 16),
+               run<0, true, true>(20, 16), run<0, true>(20, 16), run<0, true, true>(20, 16), run<1, true, true>(20, 16), run<4, true, true>(20, 16));
+    {   // PF2 against DIRECT, element by element
+        size_t n = (size_t)gB * gN * 257;
+        std::vector<float> a(n), b(n);
+        hipMemset(gy, 0, n * 4);
+        run<0, true>(1, 16);
+        hipMemcpy(a.data(), gy, n * 4, hipMemcpyDeviceToHost);
+        hipMemset(gy, 0, n * 4);
+        run<0, true, true>(1, 16);
+        hipMemcpy(b.data(), gy, n * 4, hipMemcpyDeviceToHost);
+        size_t bad = 0;
+        for (size_t i = 0; i < n; ++i) bad += a[i] != b[i];
+        printf("PF2 vs DIRECT: %zu differing of %zu\n", bad, n);
+    }
     {   // DIRECT against the staged variant, element by element
         size_t n = (size_t)gB * gN * 257;
         std::vector<float> a(n), b(n);
