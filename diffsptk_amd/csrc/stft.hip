@@ -1121,6 +1121,81 @@ static int launch_row_dft(const void* x, int64_t B, int64_t Tlen, int64_t N, int
     return check_launch("row_dft_generic");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Generalized cepstral transformation in ONE launch (GeneralizedCepstrumToGeneralizedCepstrum._forward, mgc2mgc.py:333-361):
+//   c01 = (0, c1[1:]) -> C1 = fft(c01, n) -> s = (1 + g1 C1)^(1/g1) (g1 = 0: exp C1) -> C2 = (|s|^g2 cos(g2 angle(s)) - 1) / g2
+//   (g2 = 0: log |s|) -> c02 = ifft(C2).real[: M2 + 1] -> c2 = (c1[0], 2 c02[1:]).
+// One workgroup per row, the n complex points in LDS; both transforms are the radix-2 LDS transform above: c01 is real, so C1 is
+// Hermitian and C2 is real and even -- its inverse transform IS its forward transform / n, and only the real parts leave.
+// As separate launches (row transform -> five element-wise operators -> adjoint row transform, modules/mgc2mgc.py) the
+// 4096-point spectra of the MLSA filter's impulse responses went through memory seven times (profiles/r02_mlsa_single_stage_trace.txt:
+// 7.2 of the 8.3 ms of the single-stage mode).  Forward only (the module composes the differentiable operators when a gradient is
+// wanted).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gc2gc_fused_kernel(const T* __restrict__ c1, int n_in, int out_order, T g1, T g2, int nfft,
+                                                         const T* __restrict__ tw, T* __restrict__ c2)
+{
+    extern __shared__ unsigned char smem_raw[];
+    T* re = reinterpret_cast<T*>(smem_raw);
+    T* im = re + nfft;
+    const long f = blockIdx.x;
+    const T* row = c1 + f * n_in;
+    const int lg = 31 - __clz(nfft);
+    for (int l = threadIdx.x; l < nfft; l += blockDim.x) {
+        re[l] = (l >= 1 && l < n_in) ? row[l] : T(0);   // fft(c01, n): longer rows are cropped, c01[0] = 0
+        im[l] = T(0);
+    }
+    __syncthreads();
+    lds_fft_pow2(re, im, nfft, lg, tw);
+    // pointwise map, and back to natural order for the second transform: bin k sits at position brev(k); the thread that owns
+    // the pair of positions (p, brev(p)), p <= brev(p), maps both and stores them swapped
+    constexpr T kPi = T(3.14159265358979323846);
+    auto gmap = [&](T cr, T ci) -> T {
+        T lmag, ang;   // log |s|, angle(s) (wrapped to (-pi, pi] as .angle() of the reference's polar(r, theta) is)
+        if (g1 == T(0)) {
+            lmag = cr;
+            ang = ci;
+        } else {
+            const T zr = T(1) + g1 * cr, zi = g1 * ci;
+            lmag = T(0.5) * dsa_log(zr * zr + zi * zi) / g1;
+            ang = atan2(zi, zr) / g1;
+        }
+        if (g2 == T(0)) return lmag;
+        ang -= T(2) * kPi * rint(ang / (T(2) * kPi));
+        return (dsa_exp(g2 * lmag) * cos(ang * g2) - T(1)) / g2;
+    };
+    for (int p = threadIdx.x; p < nfft; p += blockDim.x) {
+        const int q = fft_brev(p, lg);
+        if (p > q) continue;
+        const T vp = gmap(re[p], im[p]);       // bin q
+        const T vq = p == q ? vp : gmap(re[q], im[q]);   // bin p
+        re[q] = vp;
+        re[p] = vq;
+        im[p] = T(0);
+        im[q] = T(0);
+    }
+    __syncthreads();
+    lds_fft_pow2(re, im, nfft, lg, tw);
+    T* out = c2 + f * (long)(out_order + 1);
+    const T sc = T(2) / T(nfft);
+    for (int m = threadIdx.x; m <= out_order; m += blockDim.x)
+        out[m] = m == 0 ? row[0] : (m < nfft ? sc * re[fft_brev(m, lg)] : T(0));
+}
+
+template <typename T>
+static int gc2gc_launch(const void* c1, int64_t F, int n_in, int out_order, double g1, double g2, int nfft, const void* tw, void* c2,
+                        hipStream_t st)
+{
+    const size_t lds = sizeof(T) * 2 * (size_t)nfft;
+    static std::atomic<uint64_t> lds_set{0};
+    if (lds > 48 * 1024 && !ensure_dynamic_lds(reinterpret_cast<const void*>(&gc2gc_fused_kernel<T>), 150 * 1024, lds_set))
+        return fail(DSA_ERR_LAUNCH, "gc2gc: cannot raise the dynamic LDS limit%s");
+    hipLaunchKernelGGL((gc2gc_fused_kernel<T>), dim3((unsigned)F), dim3(256), lds, st, (const T*)c1, n_in, out_order, (T)g1, (T)g2, nfft,
+                       (const T*)tw, (T*)c2);
+    return check_launch("gc2gc_fused");
+}
+
 // Backward of stft512_fwd_kernel (autograd of stft.py:237-241), same
 // wave-per-pass structure and LDS tile.  Per pass of 4 frames:
 //   recompute Z (stage, window, FFT-256) -> split into X[k] -> cotangent S[k] of the half spectrum
@@ -1679,6 +1754,19 @@ DSA_EXPORT int dsa_window_bwd(const void* gy, const void* x, int64_t F, int32_t 
     } else
         return fail(DSA_ERR_UNSUPPORTED, "window_bwd: unsupported dtype%s");
     return check_launch("window_bwd");
+}
+
+DSA_EXPORT int dsa_gc2gc_fwd(const void* c1, int64_t F, int32_t n_in, int32_t out_order, double in_gamma, double out_gamma,
+                             int32_t nfft, const void* twiddle, int32_t dtype, void* c2, void* stream)
+{
+    DSA_REQUIRE(F >= 0 && n_in >= 1 && out_order >= 0, "gc2gc: sizes must be positive");
+    DSA_REQUIRE(nfft >= 4 && (nfft & (nfft - 1)) == 0, "gc2gc: n_fft must be a power of two");
+    if (out_order + 1 > nfft || F > 0x7fffffffLL) return fail(DSA_ERR_UNSUPPORTED, "gc2gc: out_order + 1 must not exceed n_fft%s");
+    if (F == 0) return DSA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DSA_F32 && (size_t)nfft * 8 <= 150 * 1024) return gc2gc_launch<float>(c1, F, n_in, out_order, in_gamma, out_gamma, nfft, twiddle, c2, st);
+    if (dtype == DSA_F64 && (size_t)nfft * 16 <= 150 * 1024) return gc2gc_launch<double>(c1, F, n_in, out_order, in_gamma, out_gamma, nfft, twiddle, c2, st);
+    return fail(DSA_ERR_UNSUPPORTED, "gc2gc: unsupported dtype or n_fft too long for LDS%s");
 }
 
 DSA_EXPORT int dsa_fftr_fwd(const void* x, int64_t F, int32_t len_in, int32_t nfft, int32_t out_format,

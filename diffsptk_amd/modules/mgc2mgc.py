@@ -23,8 +23,12 @@ from .spec import device_twiddle
 
 def gc2gc(c1: torch.Tensor, out_order: int, in_gamma: float, out_gamma: float, n_fft: int) -> torch.Tensor:
     """GeneralizedCepstrumToGeneralizedCepstrum._forward (mgc2mgc.py:333-361)."""
-    c01 = torch.cat((torch.zeros_like(c1[..., :1]), c1[..., 1:]), dim=-1)
     tw = device_twiddle(n_fft, c1.device, c1.dtype)
+    if not (torch.is_grad_enabled() and c1.requires_grad):
+        y = ops.gc2gc_fused(c1, out_order, in_gamma, out_gamma, n_fft, tw)   # one launch, the spectra never leave LDS
+        if y is not None:
+            return y
+    c01 = torch.cat((torch.zeros_like(c1[..., :1]), c1[..., 1:]), dim=-1)
     C1 = ops.FftrFn.apply(c01, n_fft, 0, tw)                       # half of fft(c01, n_fft): the sequence is real
     if in_gamma == 0:
         mag, ang = torch.exp(C1.real), C1.imag                     # cexp

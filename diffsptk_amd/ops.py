@@ -779,6 +779,24 @@ class McepFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------- mgcep (8(f) row 3)
+def gc2gc_fused(c1, out_order, in_gamma, out_gamma, n_fft, twiddle):
+    """GeneralizedCepstrumToGeneralizedCepstrum._forward (mgc2mgc.py:333-361) in one launch (dsa_gc2gc_fwd): c1:(..., M1+1)
+    -> (..., M2+1); forward only.  None when the configuration has no fused kernel (n_fft not a power of two / too long)."""
+    _require_device(c1, twiddle)
+    _same_dtype(c1, twiddle)
+    esz = 8 if c1.dtype == torch.float32 else 16
+    if n_fft < 4 or n_fft & (n_fft - 1) or n_fft * esz > 150 * 1024 or out_order + 1 > n_fft:
+        return None
+    cc = c1.contiguous()
+    n_in = cc.size(-1)
+    F = cc.numel() // n_in
+    out = torch.empty(*cc.shape[:-1], out_order + 1, device=c1.device, dtype=c1.dtype)
+    with torch.cuda.device(c1.device):
+        _call("dsa_gc2gc_fwd", _p(cc), F, n_in, out_order, float(in_gamma), float(out_gamma), n_fft, _p(twiddle), _dtype_code(cc),
+              _p(out), _stream())
+    return out
+
+
 def mgcep_spectra(x, b1, Cr, Ci, gamma):
     """(5, ..., K): pp, qq (X^2 - Y^2), qq 2XY, pp X, pp Y of one Newton step of mgcep.py:199-209 in one launch
     (dsa_mgcep_spectra); forward only."""

@@ -346,3 +346,31 @@ def test_zerodf_broadcasts_leading_dims_and_rejects_mismatches():
     with pytest.raises(ValueError):
         ops.ThSolveFn.apply(torch.rand(4, 5, dtype=torch.float64, device=DEV) + 2, torch.rand(5 * 2 - 1, dtype=torch.float64, device=DEV),
                             torch.rand(4, 5, dtype=torch.float64, device=DEV))
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float64, 1e-10), (torch.float32, 2e-5)])
+def test_gc2gc_fused_kernel_equals_the_operator_chain(golden, dt, tol):
+    """dsa_gc2gc_fwd (one launch, the n_fft-point spectrum in LDS) against the differentiable composition it replaces when no
+    gradient is wanted (row transform -> element-wise operators -> inverse transform), the numpy oracle and the reference's
+    outputs; every gamma case incl. wrapped phases, rows longer and shorter than the output, n_fft up to 4096."""
+    from diffsptk_amd.modules.mgc2mgc import gc2gc
+
+    g = golden("gc2gc_phase")
+    c = dev(g["c"], dt)
+    for ig, og, oo, nf in g["cases"]:
+        y = gc2gc(c, int(oo), float(ig), float(og), int(nf))
+        assert _lib.last_kernel() == "gc2gc_fused" and not y.requires_grad
+        ref = g[f"gc2gc_{ig}_{og}_{int(oo)}_{int(nf)}"]
+        assert np.abs(host(y) - ref).max() <= (1e-9 if dt == torch.float64 else 5e-5) * max(1.0, np.abs(ref).max())
+    gen = torch.Generator().manual_seed(21)
+    for n_in, oo, ig, og, nf in ((25, 1999, 0.0, 1.0, 4096), (25, 24, -0.5, 0.0, 512), (40, 12, -1.0, -0.25, 256), (9, 30, 0.0, -1 / 3, 64),
+                                 (300, 10, -0.5, -0.5, 256)):
+        cr = (torch.randn(6, n_in, dtype=torch.float64, generator=gen) * 0.3 / (1 + torch.arange(n_in, dtype=torch.float64) * 0.3)).to(DEV, dt)
+        fused = gc2gc(cr, oo, ig, og, nf)
+        assert _lib.last_kernel() == "gc2gc_fused"
+        chain = gc2gc(cr.clone().requires_grad_(True), oo, ig, og, nf)      # the differentiable operator chain
+        assert chain.requires_grad and chain.shape == fused.shape == (6, oo + 1)
+        scale = max(1.0, float(chain.abs().max()))
+        assert float((fused - chain.detach()).abs().max()) <= tol * scale, (n_in, oo, ig, og, nf)
+        ref = O.gc2gc(host(cr).astype(np.float64), oo, ig, og, nf)
+        assert np.abs(host(fused) - ref).max() <= (1e-9 if dt == torch.float64 else 5e-5) * max(1.0, np.abs(ref).max())
