@@ -1134,7 +1134,7 @@ static int launch_row_dft(const void* x, int64_t B, int64_t Tlen, int64_t N, int
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void gc2gc_fused_kernel(const T* __restrict__ c1, int n_in, int out_order, T g1, T g2, int nfft,
-                                                         const T* __restrict__ tw, T* __restrict__ c2)
+                                                         const T* __restrict__ tw, int flags, T* __restrict__ c2)
 {
     extern __shared__ unsigned char smem_raw[];
     T* re = reinterpret_cast<T*>(smem_raw);
@@ -1142,8 +1142,19 @@ __global__ __launch_bounds__(256) void gc2gc_fused_kernel(const T* __restrict__ 
     const long f = blockIdx.x;
     const T* row = c1 + f * n_in;
     const int lg = 31 - __clz(nfft);
+    // flags: the per-row scalar steps mgc2mgc.py:217-300 wraps around the transformation, folded in (each was a pass over the
+    // row in memory): 1 gnorm(in_gamma) before, 2 ignorm(out_gamma) after, 4 tail times out_gamma, 8 zeroth coefficient * out_gamma + 1
+    T k0 = row[0], tin = T(1);
+    if (flags & 1) {   // gnorm.py:99-109
+        if (g1 == T(0)) k0 = dsa_exp(row[0]);
+        else {
+            const T z = T(1) + g1 * row[0];
+            k0 = dsa_pow(z, T(1) / g1);
+            tin = T(1) / z;
+        }
+    }
     for (int l = threadIdx.x; l < nfft; l += blockDim.x) {
-        re[l] = (l >= 1 && l < n_in) ? row[l] : T(0);   // fft(c01, n): longer rows are cropped, c01[0] = 0
+        re[l] = (l >= 1 && l < n_in) ? row[l] * tin : T(0);   // fft(c01, n): longer rows are cropped, c01[0] = 0
         im[l] = T(0);
     }
     __syncthreads();
@@ -1178,21 +1189,31 @@ __global__ __launch_bounds__(256) void gc2gc_fused_kernel(const T* __restrict__ 
     __syncthreads();
     lds_fft_pow2(re, im, nfft, lg, tw);
     T* out = c2 + f * (long)(out_order + 1);
-    const T sc = T(2) / T(nfft);
+    T sc = T(2) / T(nfft), o0 = k0;
+    if (flags & 2) {   // ignorm.py:99-109
+        if (g2 == T(0)) o0 = dsa_log(k0);
+        else {
+            const T zz = dsa_pow(k0, g2);
+            o0 = (zz - T(1)) / g2;
+            sc *= zz;
+        }
+    }
+    if (flags & 4) sc *= g2;
+    if (flags & 8) o0 = o0 * g2 + T(1);
     for (int m = threadIdx.x; m <= out_order; m += blockDim.x)
-        out[m] = m == 0 ? row[0] : (m < nfft ? sc * re[fft_brev(m, lg)] : T(0));
+        out[m] = m == 0 ? o0 : (m < nfft ? sc * re[fft_brev(m, lg)] : T(0));
 }
 
 template <typename T>
-static int gc2gc_launch(const void* c1, int64_t F, int n_in, int out_order, double g1, double g2, int nfft, const void* tw, void* c2,
-                        hipStream_t st)
+static int gc2gc_launch(const void* c1, int64_t F, int n_in, int out_order, double g1, double g2, int nfft, const void* tw, int flags,
+                        void* c2, hipStream_t st)
 {
     const size_t lds = sizeof(T) * 2 * (size_t)nfft;
     static std::atomic<uint64_t> lds_set{0};
     if (lds > 48 * 1024 && !ensure_dynamic_lds(reinterpret_cast<const void*>(&gc2gc_fused_kernel<T>), 150 * 1024, lds_set))
         return fail(DSA_ERR_LAUNCH, "gc2gc: cannot raise the dynamic LDS limit%s");
     hipLaunchKernelGGL((gc2gc_fused_kernel<T>), dim3((unsigned)F), dim3(256), lds, st, (const T*)c1, n_in, out_order, (T)g1, (T)g2, nfft,
-                       (const T*)tw, (T*)c2);
+                       (const T*)tw, flags, (T*)c2);
     return check_launch("gc2gc_fused");
 }
 
@@ -1757,15 +1778,16 @@ DSA_EXPORT int dsa_window_bwd(const void* gy, const void* x, int64_t F, int32_t 
 }
 
 DSA_EXPORT int dsa_gc2gc_fwd(const void* c1, int64_t F, int32_t n_in, int32_t out_order, double in_gamma, double out_gamma,
-                             int32_t nfft, const void* twiddle, int32_t dtype, void* c2, void* stream)
+                             int32_t nfft, const void* twiddle, int32_t flags, int32_t dtype, void* c2, void* stream)
 {
     DSA_REQUIRE(F >= 0 && n_in >= 1 && out_order >= 0, "gc2gc: sizes must be positive");
     DSA_REQUIRE(nfft >= 4 && (nfft & (nfft - 1)) == 0, "gc2gc: n_fft must be a power of two");
+    DSA_REQUIRE(flags >= 0 && flags < 16, "gc2gc: unknown flags");
     if (out_order + 1 > nfft || F > 0x7fffffffLL) return fail(DSA_ERR_UNSUPPORTED, "gc2gc: out_order + 1 must not exceed n_fft%s");
     if (F == 0) return DSA_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == DSA_F32 && (size_t)nfft * 8 <= 150 * 1024) return gc2gc_launch<float>(c1, F, n_in, out_order, in_gamma, out_gamma, nfft, twiddle, c2, st);
-    if (dtype == DSA_F64 && (size_t)nfft * 16 <= 150 * 1024) return gc2gc_launch<double>(c1, F, n_in, out_order, in_gamma, out_gamma, nfft, twiddle, c2, st);
+    if (dtype == DSA_F32 && (size_t)nfft * 8 <= 150 * 1024) return gc2gc_launch<float>(c1, F, n_in, out_order, in_gamma, out_gamma, nfft, twiddle, flags, c2, st);
+    if (dtype == DSA_F64 && (size_t)nfft * 16 <= 150 * 1024) return gc2gc_launch<double>(c1, F, n_in, out_order, in_gamma, out_gamma, nfft, twiddle, flags, c2, st);
     return fail(DSA_ERR_UNSUPPORTED, "gc2gc: unsupported dtype or n_fft too long for LDS%s");
 }
 

@@ -47,6 +47,16 @@ def gc2gc(c1: torch.Tensor, out_order: int, in_gamma: float, out_gamma: float, n
     return torch.cat((c1[..., :1], 2 * c02[..., 1:]), dim=-1)
 
 
+def _gc2gc_with_scalar_steps(c, out_order, ig, og, n_fft, gnorm_before, ignorm_after, tail_mul, zeroth_mul):
+    """gnorm -> gc2gc -> ignorm -> GammaMultiplication -> ZerothGammaMultiplication of mgc2mgc.py:217-300 in ONE launch (the
+    scalar steps are flags of dsa_gc2gc_fwd; as separate operators each was a pass over the (..., out_order + 1) rows in memory).
+    Forward only; None when a gradient is wanted or the configuration has no fused kernel."""
+    if torch.is_grad_enabled() and c.requires_grad:
+        return None
+    flags = (1 if gnorm_before else 0) | (2 if ignorm_after else 0) | (4 if tail_mul else 0) | (8 if zeroth_mul else 0)
+    return ops.gc2gc_fused(c, out_order, ig, og, n_fft, device_twiddle(n_fft, c.device, c.dtype), flags)
+
+
 def _scale_tail(c: torch.Tensor, s: float) -> torch.Tensor:
     return torch.cat((c[..., :1], c[..., 1:] * s), dim=-1)
 
@@ -125,6 +135,10 @@ class MelGeneralizedCepstrumToMelGeneralizedCepstrum(BaseFunctionalModule):
             else:
                 if in_mul:
                     c = _scale_tail(c, 1 / ig)
+                fused = _gc2gc_with_scalar_steps(c, out_order, ig, og, n_fft, not in_norm, not out_norm, out_mul,
+                                                 not out_norm and out_mul)
+                if fused is not None:
+                    return fused
                 if not in_norm:
                     c = gn(c, gamma=ig)
                 c = gc2gc(c, out_order, ig, og, n_fft)
@@ -138,6 +152,10 @@ class MelGeneralizedCepstrumToMelGeneralizedCepstrum(BaseFunctionalModule):
             if in_norm:
                 c = ign(c, gamma=ig)
             c = ops.MatmulRowsFn.apply(c, A)             # FrequencyTransform: the library's row-product kernel
+            if ig != og:
+                fused = _gc2gc_with_scalar_steps(c, out_order, ig, og, n_fft, True, not out_norm, out_mul, not out_norm and out_mul)
+                if fused is not None:
+                    return fused
             if out_norm or ig != og:
                 c = gn(c, gamma=ig)
             if ig != og:

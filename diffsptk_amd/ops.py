@@ -779,9 +779,10 @@ class McepFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------- mgcep (8(f) row 3)
-def gc2gc_fused(c1, out_order, in_gamma, out_gamma, n_fft, twiddle):
+def gc2gc_fused(c1, out_order, in_gamma, out_gamma, n_fft, twiddle, flags=0):
     """GeneralizedCepstrumToGeneralizedCepstrum._forward (mgc2mgc.py:333-361) in one launch (dsa_gc2gc_fwd): c1:(..., M1+1)
-    -> (..., M2+1); forward only.  None when the configuration has no fused kernel (n_fft not a power of two / too long)."""
+    -> (..., M2+1); forward only.  `flags` folds the scalar steps around it (1 gnorm before, 2 ignorm after, 4 tail * out_gamma,
+    8 zeroth * out_gamma + 1).  None when the configuration has no fused kernel (n_fft not a power of two / too long)."""
     _require_device(c1, twiddle)
     _same_dtype(c1, twiddle)
     esz = 8 if c1.dtype == torch.float32 else 16
@@ -792,8 +793,8 @@ def gc2gc_fused(c1, out_order, in_gamma, out_gamma, n_fft, twiddle):
     F = cc.numel() // n_in
     out = torch.empty(*cc.shape[:-1], out_order + 1, device=c1.device, dtype=c1.dtype)
     with torch.cuda.device(c1.device):
-        _call("dsa_gc2gc_fwd", _p(cc), F, n_in, out_order, float(in_gamma), float(out_gamma), n_fft, _p(twiddle), _dtype_code(cc),
-              _p(out), _stream())
+        _call("dsa_gc2gc_fwd", _p(cc), F, n_in, out_order, float(in_gamma), float(out_gamma), n_fft, _p(twiddle), int(flags),
+              _dtype_code(cc), _p(out), _stream())
     return out
 
 

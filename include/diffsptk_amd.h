@@ -267,10 +267,13 @@ int dsa_thsolve_bwd(const void* gg, const void* p, const void* q, const void* g,
  * transformation), in ONE launch: c1:(F,n_in) gain-normalised generalized cepstra of in_gamma -> c2:(F,out_order+1) of
  * out_gamma through fft(c01, n_fft) -> (1 + g1 C)^(1/g1) -> (|s|^g2 cos(g2 angle s) - 1) / g2 -> ifft(.).real, n_fft a power of
  * two (the row lives in LDS: 8 n_fft bytes in float32, 16 n_fft in float64, <= 150 KB).  `twiddle`: (n_fft, 2) as for dsa_fftr_fwd.
+ * `flags` folds the per-row scalar steps MelGeneralizedCepstrumToMelGeneralizedCepstrum wraps around it (mgc2mgc.py:217-300):
+ * 1 = gain normalisation with in_gamma before (gnorm.py:99-109), 2 = inverse gain normalisation with out_gamma after
+ * (ignorm.py:99-109), 4 = c[1:] *= out_gamma (GammaMultiplication), 8 = c[0] = c[0] out_gamma + 1 (ZerothGammaMultiplication).
  * Forward only: with a gradient needed the module composes dsa_fftr_fwd / element-wise operators / the inverse transform.
  * This is what mgc2mgc (gamma conversion), mgc2sp and the MLSA filter's impulse responses (mglsadf.py:389-527) run on. */
 int dsa_gc2gc_fwd(const void* c1, int64_t F, int32_t n_in, int32_t out_order, double in_gamma, double out_gamma,
-                  int32_t nfft, const void* twiddle, int32_t dtype, void* c2, void* stream);
+                  int32_t nfft, const void* twiddle, int32_t flags, int32_t dtype, void* c2, void* stream);
 
 /* ------------------------------------------------------------------ f4  time-variant all-zero filter
  * AllZeroDigitalFilter._forward_efficient, zerodf.py:207-243: the FIR core of the multi-stage / single-stage MLSA filter
