@@ -223,8 +223,8 @@ __global__ void window_gw_kernel(const T* __restrict__ gy, const T* __restrict__
 // The generic row transforms use it whenever fft_length is a power of two (FFT = true): the direct sum they fall
 // back to costs n^2 / 2 multiply-adds per row -- 8.4 M at the 4096 points the MLSA filter's impulse responses use.
 template <typename T>
-__device__ __forceinline__ void lds_fft_pow2(T* re, T* im, int n, int lg, const T* __restrict__ tw)
-{
+__device__ __forceinline__ void lds_fft_pow2(T* re, T* im, int n, int lg, const T* __restrict__ tw, int tmul = 1)
+{   // tmul: the table is that of length n * tmul (a half-size transform reads every second entry of the full table)
     // Two radix-2 stages at a time (s and s - 1): the four points i0, i0 + h/2, i0 + h, i0 + h + h/2 (bits s and s - 1 of
     // i0 clear) are closed under both, so they pass through registers once -- half the LDS traffic and barriers of
     // stage-by-stage radix 2, a sixth of its twiddle reads (from memory: one per group; the second pair's stage-s twiddle is
@@ -232,7 +232,7 @@ __device__ __forceinline__ void lds_fft_pow2(T* re, T* im, int n, int lg, const 
     int s = lg - 1;
     for (; s >= 1; s -= 2) {
         const int h = 1 << s, h2 = h >> 1;
-        const int tstep = n >> (s + 1);
+        const int tstep = (n >> (s + 1)) * tmul;
         for (int t = threadIdx.x; t < (n >> 2); t += blockDim.x) {
             const int j = t & (h2 - 1);
             const int i0 = ((t >> (s - 1)) << (s + 1)) | j;
@@ -1136,12 +1136,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void gc2gc_fused_kernel(const T* __restrict__ c1, int n_in, int out_order, T g1, T g2, int nfft,
                                                          const T* __restrict__ tw, int flags, T* __restrict__ c2)
 {
+    // Both transforms act on REAL data (c01, and the real even C2), so each runs as a complex transform of HALF the length on
+    // the packed sequence z[n] = x[2n] + i x[2n+1], followed by the split  X[k] = (Z[k] + conj Z[H-k]) / 2 - i W^k (Z[k] - conj Z[H-k]) / 2
+    // (H = n / 2): half the butterflies and half the LDS traffic of the full-length version (2.59 -> see DESIGN ms per 51 200 rows
+    // of 4096 points).  LDS: re[H] | im[H] | cb[H + 1] (the mapped half spectrum, natural order).
     extern __shared__ unsigned char smem_raw[];
+    const int H = nfft >> 1;
     T* re = reinterpret_cast<T*>(smem_raw);
-    T* im = re + nfft;
+    T* im = re + H;
+    T* cb = im + H;
     const long f = blockIdx.x;
     const T* row = c1 + f * n_in;
-    const int lg = 31 - __clz(nfft);
+    const int lgh = 30 - __clz(nfft);   // log2(H)
     // flags: the per-row scalar steps mgc2mgc.py:217-300 wraps around the transformation, folded in (each was a pass over the
     // row in memory): 1 gnorm(in_gamma) before, 2 ignorm(out_gamma) after, 4 tail times out_gamma, 8 zeroth coefficient * out_gamma + 1
     T k0 = row[0], tin = T(1);
@@ -1153,14 +1159,13 @@ __global__ __launch_bounds__(256) void gc2gc_fused_kernel(const T* __restrict__ 
             tin = T(1) / z;
         }
     }
-    for (int l = threadIdx.x; l < nfft; l += blockDim.x) {
-        re[l] = (l >= 1 && l < n_in) ? row[l] * tin : T(0);   // fft(c01, n): longer rows are cropped, c01[0] = 0
-        im[l] = T(0);
+    for (int n = threadIdx.x; n < H; n += blockDim.x) {   // fft(c01, n): longer rows are cropped, c01[0] = 0
+        const int i0 = 2 * n, i1 = 2 * n + 1;
+        re[n] = (i0 >= 1 && i0 < n_in) ? row[i0] * tin : T(0);
+        im[n] = i1 < n_in ? row[i1] * tin : T(0);
     }
     __syncthreads();
-    lds_fft_pow2(re, im, nfft, lg, tw);
-    // pointwise map, and back to natural order for the second transform: bin k sits at position brev(k); the thread that owns
-    // the pair of positions (p, brev(p)), p <= brev(p), maps both and stores them swapped
+    lds_fft_pow2(re, im, H, lgh, tw, 2);   // Z[k] at position brev(k)
     constexpr T kPi = T(3.14159265358979323846);
     auto gmap = [&](T cr, T ci) -> T {
         T lmag, ang;   // log |s|, angle(s) (wrapped to (-pi, pi] as .angle() of the reference's polar(r, theta) is)
@@ -1176,18 +1181,30 @@ __global__ __launch_bounds__(256) void gc2gc_fused_kernel(const T* __restrict__ 
         ang -= T(2) * kPi * rint(ang / (T(2) * kPi));
         return (dsa_exp(g2 * lmag) * cos(ang * g2) - T(1)) / g2;
     };
-    for (int p = threadIdx.x; p < nfft; p += blockDim.x) {
-        const int q = fft_brev(p, lg);
-        if (p > q) continue;
-        const T vp = gmap(re[p], im[p]);       // bin q
-        const T vq = p == q ? vp : gmap(re[q], im[q]);   // bin p
-        re[q] = vp;
-        re[p] = vq;
-        im[p] = T(0);
-        im[q] = T(0);
+    // split into X[k], X[H - k] and map both (C2 is real and even: cb[k], k = 0 .. H, carries it all)
+    for (int k = threadIdx.x; k <= (H >> 1); k += blockDim.x) {
+        if (k == 0) {
+            const T zr = re[0], zi = im[0];
+            cb[0] = gmap(zr + zi, T(0));
+            cb[H] = gmap(zr - zi, T(0));
+        } else {
+            const int pa = fft_brev(k, lgh), pb = fft_brev(H - k, lgh);
+            const T ar = re[pa], ai = im[pa], br = re[pb], bi = -im[pb];          // A = Z[k], B = conj Z[H - k]
+            const T sr = T(0.5) * (ar + br), si = T(0.5) * (ai + bi), dr = T(0.5) * (ar - br), di = T(0.5) * (ai - bi);
+            const T wr = tw[2 * k], wi = tw[2 * k + 1];                            // W_n^k = (cos, -sin)(2 pi k / n)
+            const T pr = wr * dr - wi * di, pi_ = wr * di + wi * dr;              // W D
+            cb[k] = gmap(sr + pi_, si - pr);                                       // X[k]     = S - i W D
+            cb[H - k] = gmap(sr - pi_, -si - pr);                                  // X[H - k] = conj(S + i W D)
+        }
     }
     __syncthreads();
-    lds_fft_pow2(re, im, nfft, lg, tw);
+    for (int m = threadIdx.x; m < H; m += blockDim.x) {   // pack the even sequence C2[0 .. n - 1]: C2[j] = cb[j <= H ? j : n - j]
+        const int j0 = 2 * m, j1 = 2 * m + 1;
+        re[m] = cb[j0 <= H ? j0 : nfft - j0];
+        im[m] = cb[j1 <= H ? j1 : nfft - j1];
+    }
+    __syncthreads();
+    lds_fft_pow2(re, im, H, lgh, tw, 2);
     T* out = c2 + f * (long)(out_order + 1);
     T sc = T(2) / T(nfft), o0 = k0;
     if (flags & 2) {   // ignorm.py:99-109
@@ -1200,15 +1217,32 @@ __global__ __launch_bounds__(256) void gc2gc_fused_kernel(const T* __restrict__ 
     }
     if (flags & 4) sc *= g2;
     if (flags & 8) o0 = o0 * g2 + T(1);
-    for (int m = threadIdx.x; m <= out_order; m += blockDim.x)
-        out[m] = m == 0 ? o0 : (m < nfft ? sc * re[fft_brev(m, lg)] : T(0));
+    for (int m = threadIdx.x; m <= out_order; m += blockDim.x) {
+        T v;
+        if (m == 0) {
+            v = o0;
+        } else {
+            const int n = m <= H ? m : nfft - m;   // the inverse transform of a real even spectrum is even
+            T y;                                   // Re of the length-n transform of C2 at index n
+            if (n == H) {
+                y = re[0] - im[0];
+            } else {
+                const int pa = fft_brev(n, lgh), pb = fft_brev(H - n, lgh);
+                const T ar = re[pa], ai = im[pa], br = re[pb], bi = -im[pb];
+                const T dr = T(0.5) * (ar - br), di = T(0.5) * (ai - bi);
+                y = T(0.5) * (ar + br) + tw[2 * n] * di + tw[2 * n + 1] * dr;
+            }
+            v = sc * y;
+        }
+        out[m] = v;
+    }
 }
 
 template <typename T>
 static int gc2gc_launch(const void* c1, int64_t F, int n_in, int out_order, double g1, double g2, int nfft, const void* tw, int flags,
                         void* c2, hipStream_t st)
 {
-    const size_t lds = sizeof(T) * 2 * (size_t)nfft;
+    const size_t lds = sizeof(T) * (3 * (size_t)(nfft / 2) + 1);
     static std::atomic<uint64_t> lds_set{0};
     if (lds > 48 * 1024 && !ensure_dynamic_lds(reinterpret_cast<const void*>(&gc2gc_fused_kernel<T>), 150 * 1024, lds_set))
         return fail(DSA_ERR_LAUNCH, "gc2gc: cannot raise the dynamic LDS limit%s");
