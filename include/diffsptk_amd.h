@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 112 /* 0.1.2: + backward of the fused STFT -> filter bank (dsa_fbank_bins_plan / dsa_fbank_bins_bwd) */
+#define DSA_VERSION 113 /* 0.1.2: + backward of the fused STFT -> filter bank (dsa_fbank_bins_plan / dsa_fbank_bins_bwd) */
 
 typedef enum {
     DSA_OK = 0,
