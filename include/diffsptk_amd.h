@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 113 /* 0.1.2: + backward of the fused STFT -> filter bank (dsa_fbank_bins_plan / dsa_fbank_bins_bwd) */
+#define DSA_VERSION 113 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch) */
 
 typedef enum {
     DSA_OK = 0,
