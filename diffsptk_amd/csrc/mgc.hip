@@ -652,6 +652,127 @@ __global__ __launch_bounds__(320) void mgcep_spectra_kernel(const T* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// One Newton step's spectrum arithmetic AND its five row products in ONE launch (float32, fft_length 512, cep_order <= 24):
+//   (re, im) = b1 (Cr, Ci)            first chain: 24 coefficients -> 257 bins, real and imaginary part   (mgcep.py:191-193, 199-201)
+//   X = 1 + g re, Y = g im, D = X^2 + Y^2, pp = x D^(-1/g - 1), qq = pp / D                                 (mgcep.py:202-209)
+//   pt = pp Pr,  qt = (1 + g) (qq (X^2 - Y^2) Qr + qq 2XY Qi),  r = pp X Rr + pp Y Ri                         (mgcep.py:212-220)
+// on v_mfma_f32_16x16x4_f32 with the FRAMES as the N dimension, as in the mel-cepstral kernels: the first chain's result comes out
+// with lane (n, g) register r holding bin 16 mt + 4 g + r of frame n -- exactly a B operand of the second chain if its k-steps are
+// enumerated as (mt, r) with k-slot g <-> bin 16 mt + 4 g + r, so the five spectra feed the second chain from registers and never
+// exist in memory (round 2: dsa_mgcep_spectra wrote them, 263 MB per step at 51 200 frames, and five launches of the matrix-core
+// row product read them back: 0.14 + 5 x 0.05 ms per step).  One wave = 16 frames; the four waves of a workgroup share the
+// operand images of a 16-bin tile through LDS (15 KB per tile, double-buffered, one barrier per tile).  Float32 products with
+// float32 accumulation: nothing given up.  Bins 256 .. 271 are a seventeenth tile whose images are zero past bin 256.
+// `images` (built by the caller once per configuration, tables.mgcep_step_images): per bin tile mt = 0 .. 16
+//   [2 (Cr, Ci)][6 ks][64 l]      A of the first chain:  C[1 + 4 ks + (l >> 4)][16 mt + (l & 15)]                    (768 floats)
+//   [12 c][64 l][4 r]             A of the second chain: W_c[16 mt + 4 (l >> 4) + r][16 tile_c + (l & 15)]           (3072 floats)
+//   chains c: 0-1 Pr (input pp), 2-4 Qr (qq (X^2 - Y^2)), 5-7 Qi (qq 2XY), 8-9 Rr (pp X), 10-11 Ri (pp Y); 16-column tiles of each matrix.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef float ms_f4 __attribute__((ext_vector_type(4)));
+constexpr int kMsTileFloats = 768 + 3072, kMsTiles = 17;
+__global__ __launch_bounds__(256) void mgcep_step_kernel(const float* __restrict__ x, const float* __restrict__ b1, long F, int M, float gamma,
+                                                        const float* __restrict__ img, float* __restrict__ pt, float* __restrict__ qt,
+                                                        float* __restrict__ rr)
+{
+    __shared__ __attribute__((aligned(16))) float tile[2][kMsTileFloats];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const long f_raw = ((long)blockIdx.x * 4 + wave) * 16 + n;
+    const bool f_ok = f_raw < F;
+    const long f = f_ok ? f_raw : F - 1;
+    // B operand of the first chain: b1[4 ks + g] of this lane's frame
+    float bv[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) bv[ks] = 4 * ks + g < M ? b1[f * M + 4 * ks + g] : 0.f;
+    const float ex = -1.f / gamma - 1.f;
+    ms_f4 acc[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) acc[t] = ms_f4{0.f, 0.f, 0.f, 0.f};
+    // staging: 3840 floats = 960 float4 per tile, 256 threads x 4 (threads 240 .. 255 idle on the last one)
+    const ms_f4* img4 = reinterpret_cast<const ms_f4*>(img);
+    ms_f4 st[4];
+    auto fetch = [&](int mt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 256 * q;
+            st[q] = i < kMsTileFloats / 4 ? img4[(long)mt * (kMsTileFloats / 4) + i] : ms_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        ms_f4* d = reinterpret_cast<ms_f4*>(tile[buf]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 256 * q;
+            if (i < kMsTileFloats / 4) d[i] = st[q];
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (int mt = 0; mt < kMsTiles; ++mt) {
+        const int buf = mt & 1;
+        if (mt + 1 < kMsTiles) fetch(mt + 1);
+        // this lane's four spectrum values of the tile: bins 16 mt + 4 g + r (only bin 256 exists in the last tile)
+        ms_f4 xv = {0.f, 0.f, 0.f, 0.f};
+        if (mt < 16) xv = *reinterpret_cast<const ms_f4*>(x + f * 257 + 16 * mt + 4 * g);
+        else if (g == 0) xv[0] = x[f * 257 + 256];
+        const float* t1 = tile[buf];
+        const ms_f4* t2 = reinterpret_cast<const ms_f4*>(tile[buf] + 768);
+        ms_f4 re = {0.f, 0.f, 0.f, 0.f}, im = re;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            re = __builtin_amdgcn_mfma_f32_16x16x4f32(t1[ks * 64 + lane], bv[ks], re, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f32_16x16x4f32(t1[384 + ks * 64 + lane], bv[ks], im, 0, 0, 0);
+        }
+        float s[5][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float X = 1.f + gamma * re[r], Y = gamma * im[r];
+            const float XX = X * X, YY = Y * Y, D = XX + YY;
+            const float dp = __builtin_amdgcn_exp2f(ex * __builtin_amdgcn_logf(D));   // D > 0; 1 ulp each (as dsa_mgcep_spectra)
+            const float pp = xv[r] * dp;
+            const float qq = pp / D;
+            s[0][r] = pp;
+            s[1][r] = qq * (XX - YY);
+            s[2][r] = qq * (2.f * X * Y);
+            s[3][r] = pp * X;
+            s[4][r] = pp * Y;
+        }
+        // second chain: k-step (mt, r), k-slot g <-> bin 16 mt + 4 g + r: the values above ARE the B operands
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            const ms_f4 a = t2[c * 64 + lane];
+            const int in = c < 2 ? 0 : (c < 5 ? 1 : (c < 8 ? 2 : (c < 10 ? 3 : 4)));
+            const int t = c < 2 ? c : (c < 5 ? c : (c < 8 ? c - 3 : (c < 10 ? c - 3 : c - 5)));   // accumulators: 0-1 pt | 2-4 qt | 5-6 r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], s[in][r], acc[t], 0, 0, 0);
+        }
+        if (mt + 1 < kMsTiles) {
+            stage(buf ^ 1);      // the other buffer: its readers finished before the barrier that ended tile mt - 1
+            __syncthreads();
+        }
+    }
+    if (!f_ok) return;
+    // C/D layout: lane (n, g) register r of tile t <-> column 16 t + 4 g + r of frame n
+    const float og = 1.f + gamma;
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (t < 2) {
+                const int col = 16 * t + 4 * g + r;
+                if (col < M) pt[f * M + col] = acc[t][r];
+            } else if (t < 5) {
+                const int col = 16 * (t - 2) + 4 * g + r;
+                if (col < 2 * M - 1) qt[f * (2 * M - 1) + col] = og * acc[t][r];
+            } else {
+                const int col = 16 * (t - 5) + 4 * g + r;
+                if (col < M + 1) rr[f * (M + 1) + col] = acc[t][r];
+            }
+        }
+}
+
 template <typename T>
 static int mgcep_spectra_launch(const void* x, const void* b1, int64_t F, int K, int M, const void* Cr, const void* Ci, double gamma,
                                 void* out, hipStream_t st)
@@ -720,6 +841,18 @@ DSA_EXPORT int dsa_thsolve_bwd(const void* gg, const void* p, const void* q, con
     if (dtype == DSA_F32) return th_launch<float>(true, gg, p, q, g, F, n, gp, gq, gr, (hipStream_t)stream);
     if (dtype == DSA_F64) return th_launch<double>(true, gg, p, q, g, F, n, gp, gq, gr, (hipStream_t)stream);
     return fail(DSA_ERR_UNSUPPORTED, "thsolve_bwd: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_mgcep_step(const void* x, const void* b1, int64_t F, int32_t fft_length, int32_t M, double gamma, const void* images,
+                              int32_t dtype, void* pt, void* qt, void* r, void* stream)
+{
+    DSA_REQUIRE(F >= 0 && M >= 1, "mgcep_step: sizes must be positive");
+    DSA_REQUIRE(gamma != 0.0 && gamma >= -1.0 && gamma < 0.0, "mgcep_step: gamma must be in [-1, 0)");
+    if (dtype != DSA_F32 || fft_length != 512 || M > 24) return fail(DSA_ERR_UNSUPPORTED, "mgcep_step: needs float32, fft_length 512, cep_order <= 24%s");
+    if (F == 0) return DSA_OK;
+    hipLaunchKernelGGL(mgcep_step_kernel, dim3((unsigned)((F + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)b1,
+                       (long)F, (int)M, (float)gamma, (const float*)images, (float*)pt, (float*)qt, (float*)r);
+    return check_launch("mgcep_step");
 }
 
 DSA_EXPORT int dsa_mgcep_spectra(const void* x, const void* b1, int64_t F, int32_t fft_length, int32_t M, const void* Cr,

@@ -61,6 +61,13 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
             mats[k] = mats[k][:, 2:]
         for name, mat in mats.items():
             self.register_buffer(name, to(np.ascontiguousarray(mat), device=device, dtype=dtype), persistent=False)
+        # float32 / fft_length 512 / cep_order <= 24: a step's spectrum arithmetic and its five row products run as ONE launch on
+        # operand images in matrix-instruction order (dsa_mgcep_step)
+        if fft_length == 512 and cep_order <= 24 and (dtype or torch.get_default_dtype()) == torch.float32:
+            self.register_buffer("step_images", to(tables.mgcep_step_images(fft_length, cep_order, float(alpha)), device=device,
+                                                   dtype=torch.float32), persistent=False)
+        else:
+            self.step_images = None
         self.b2mc = MLSADigitalFilterCoefficientsToMelCepstrum(M, alpha, device=device, dtype=dtype)
         self.mc2b = MelCepstrumToMLSADigitalFilterCoefficients(M, alpha, device=device, dtype=dtype)
         self.gc2gc = MelGeneralizedCepstrumToMelGeneralizedCepstrum(M, M, in_gamma=-1, out_gamma=gamma, device=device,
@@ -81,6 +88,10 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
                 pt = mm(x, self.Pr)
                 qt = None                                          # q (1 + gamma) = 0: no Hankel part
                 r = mm(x, self.R1)
+            elif not (torch.is_grad_enabled() and (x.requires_grad or b1.requires_grad)) and self.step_images is not None \
+                    and x.dtype == torch.float32 and self.step_images.device == x.device:
+                pt, qt, r = ops.mgcep_step(x, b1, self.step_images, gamma)   # mgcep.py:199-220 in one launch (forward only)
+                eps = epsilon(gamma, r, b1) if need_gain else None
             elif not (torch.is_grad_enabled() and (x.requires_grad or b1.requires_grad)) and M <= 64:
                 S = ops.mgcep_spectra(x, b1, self.Cr, self.Ci, gamma)   # mgcep.py:199-209, one pass (forward only)
                 pt = mm(S[0], self.Pr)

@@ -798,6 +798,24 @@ def gc2gc_fused(c1, out_order, in_gamma, out_gamma, n_fft, twiddle, flags=0):
     return out
 
 
+def mgcep_step(x, b1, images, gamma):
+    """(pt, qt, r) of one Newton step of mgcep.py:199-220 in one launch (dsa_mgcep_step: spectrum arithmetic + the five row
+    products, float32 / fft_length 512 / cep_order <= 24); forward only."""
+    _require_device(x, b1, images)
+    _same_dtype(x, b1, images)
+    xc, bc = x.contiguous(), b1.contiguous()
+    K, M = xc.size(-1), bc.size(-1)
+    F = xc.numel() // K
+    lead = xc.shape[:-1]
+    pt = torch.empty(*lead, M, device=x.device, dtype=x.dtype)
+    qt = torch.empty(*lead, 2 * M - 1, device=x.device, dtype=x.dtype)
+    r = torch.empty(*lead, M + 1, device=x.device, dtype=x.dtype)
+    with torch.cuda.device(x.device):
+        _call("dsa_mgcep_step", _p(xc), _p(bc), F, 2 * (K - 1), M, float(gamma), _p(images), _dtype_code(xc), _p(pt), _p(qt), _p(r),
+              _stream())
+    return pt, qt, r
+
+
 def mgcep_spectra(x, b1, Cr, Ci, gamma):
     """(5, ..., K): pp, qq (X^2 - Y^2), qq 2XY, pp X, pp Y of one Newton step of mgcep.py:199-209 in one launch
     (dsa_mgcep_spectra); forward only."""

@@ -470,6 +470,42 @@ def mgcep_matrices(fft_length: int, cep_order: int, alpha: float):
             "R1": base_r[:, : M + 1].copy(), "Q1": base_r @ Qt}
 
 
+def mgcep_step_images(fft_length: int, cep_order: int, alpha: float) -> np.ndarray:
+    """Operand images of dsa_mgcep_step (csrc/mgc.hip: layout in the kernel's header comment): per 16-bin tile the A operands of
+    the first chain (Cr, Ci) and of the second chain (Pr[:, :M] | Qr[:, 2:] | Qi[:, 2:] | Rr | Ri in 16-column tiles) in
+    v_mfma_f32_16x16x4_f32 lane order, float32.  fft_length 512, cep_order <= 24."""
+    if fft_length != 512 or not 1 <= cep_order <= 24:
+        raise ValueError("mgcep_step_images: fft_length 512 and cep_order <= 24 only")
+    M, K = cep_order, fft_length // 2 + 1
+    m = mgcep_matrices(fft_length, cep_order, float(alpha))
+    Cr, Ci = m["Cr"], m["Ci"]                                    # (M + 1, K)
+    mats = [(m["Pr"][:, :M], 2), (m["Qr"][:, 2:], 3), (m["Qi"][:, 2:], 3), (m["Rr"], 2), (m["Ri"], 2)]
+    lanes = np.arange(64)
+    li, lg = lanes & 15, lanes >> 4
+    out = np.zeros((17, 768 + 3072), dtype=np.float64)
+    for mt in range(17):
+        a1 = np.zeros((2, 6, 64))
+        for ci_, C in enumerate((Cr, Ci)):
+            for ks in range(6):
+                row = 1 + 4 * ks + lg
+                col = 16 * mt + li
+                ok = (row <= M) & (col < K)
+                a1[ci_, ks, ok] = C[row[ok], col[ok]]
+        a2 = np.zeros((12, 64, 4))
+        c = 0
+        for W, ntile in mats:
+            for t in range(ntile):
+                for r in range(4):
+                    b = 16 * mt + 4 * lg + r
+                    col = 16 * t + li
+                    ok = (b < K) & (col < W.shape[1])
+                    a2[c, ok, r] = W[b[ok], col[ok]]
+                c += 1
+        out[mt, :768] = a1.reshape(-1)
+        out[mt, 768:] = a2.reshape(-1)
+    return out.astype(np.float32)
+
+
 def fbank_bins_table(H: np.ndarray):
     """Per-bin table of the fused filter bank's backward (dsa_fbank_bins_bwd; the C twin is dsa_fbank_bins_plan): row k =
     (bits of c_k as float32, w0, w1, 0) with H[k, c_k] = w0 and H[k, c_k + 1] = w1 the only non-zero entries of row k.

@@ -263,6 +263,13 @@ int dsa_mgcep_spectra(const void* x, const void* b1, int64_t F, int32_t fft_leng
                       const void* Ci, double gamma, int32_t dtype, void* out, void* stream);
 int dsa_thsolve_bwd(const void* gg, const void* p, const void* q, const void* g, int64_t F, int32_t n, int32_t dtype,
                     void* gp, void* gq, void* gr, void* stream);
+/* The same step's spectrum arithmetic AND its five row products in one launch (mgcep.py:199-220; float32, fft_length 512,
+ * cep_order <= 24, gamma in [-1, 0)): x:(F,257), b1:(F,M) -> pt:(F,M) = pp Pr[:, :M], qt:(F,2M-1) = (1 + gamma)(.. Qr[:, 2:] + .. Qi[:, 2:]),
+ * r:(F,M+1) = pp X Rr + pp Y Ri -- the operands of dsa_thsolve_fwd.  The five spectra never exist in memory (dsa_mgcep_spectra writes
+ * them for the float64 / other-size path).  `images`: 17 x 3840 float32, the matrices in matrix-instruction lane order, built by the
+ * caller once per configuration (layout: csrc/mgc.hip, mgcep_step_kernel; diffsptk_amd.utils.tables.mgcep_step_images).  Forward only. */
+int dsa_mgcep_step(const void* x, const void* b1, int64_t F, int32_t fft_length, int32_t M, double gamma, const void* images,
+                   int32_t dtype, void* pt, void* qt, void* r, void* stream);
 /* GeneralizedCepstrumToGeneralizedCepstrum._forward, mgc2mgc.py:333-361 (the FFT formulation of the generalized cepstral
  * transformation), in ONE launch: c1:(F,n_in) gain-normalised generalized cepstra of in_gamma -> c2:(F,out_order+1) of
  * out_gamma through fft(c01, n_fft) -> (1 + g1 C)^(1/g1) -> (|s|^g2 cos(g2 angle s) - 1) / g2 -> ifft(.).real, n_fft a power of
