@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 113 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch) */
+#define DSA_VERSION 113 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch), dsa_mgcep_step */
 
 typedef enum {
     DSA_OK = 0,
