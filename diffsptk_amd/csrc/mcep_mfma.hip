@@ -490,6 +490,17 @@ __global__ __launch_bounds__(256) void thsolve_quad24_kernel(const float* __rest
             blk_build_rows<0>(a, rt_q, rr_q, pa6, zr, gs);
             blk_elim_all(a, gq, ninvs, std::make_integer_sequence<int, M1>{});
             blk_backsub_all(a, xq, gq, ninvs, std::make_integer_sequence<int, blk::NG>{});
+            // No pivoting here: that is sound for the positive definite systems of the analysis (gamma in [-1, 0]), and nothing
+            // guarantees it for an arbitrary caller.  A pivot that is not positive (ninv = -1 / pivot not negative, or not finite)
+            // marks the system: its solution is written as NaN and thsolve_quad24_fwd's second launch re-solves exactly those rows
+            // with row pivoting (th_solve_fwd_kernel, csrc/mgc.hip), as the reference's LAPACK call would.
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < M1 - 1; ++k) bad |= !(ninvs[k] < 0.f && ninvs[k] > -3.0e38f);
+            if (bad) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) xq[c] = __builtin_nanf("");
+            }
         }
         const long f = tile * 16 + nq;
         if (f < F) {
@@ -505,7 +516,8 @@ int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, v
     if (blocks > 256L * 4) blocks = 256L * 4;
     hipLaunchKernelGGL(thsolve_quad24_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)p, (const float*)q,
                        (const float*)r, (long)F, (float*)g);
-    return check_launch("th_solve_quad_fwd");
+    if (int rc = check_launch("th_solve_quad_fwd")) return rc;
+    return thsolve_fix_marked(p, q, r, F, 24, g, st);   // rows the unpivoted elimination gave up on (none, normally)
 }
 
 }  // namespace dsa

@@ -216,6 +216,46 @@ __global__ __launch_bounds__(64) void th_solve_bwd_kernel(const T* __restrict__ 
     }
 }
 
+// Second launch of the unpivoted order-24 path (thsolve_quad24_fwd, csrc/mcep_mfma.hip): a wave looks at 64 solution rows at a
+// time (one coalesced-stride load per lane), and re-solves with row pivoting those the first launch marked with NaN.
+__global__ __launch_bounds__(64) void th_solve_fix_kernel(const float* __restrict__ p, const float* __restrict__ q, const float* __restrict__ r,
+                                                         long F, int n, float* __restrict__ g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* ps = reinterpret_cast<float*>(smem_raw);
+    float* qs = ps + n;
+    const int lane = threadIdx.x;
+    for (long base = (long)blockIdx.x * 64; base < F; base += (long)gridDim.x * 64) {
+        const long fl = base + lane;
+        const float head = fl < F ? g[fl * n] : 0.f;
+        unsigned long long marked = __ballot(head != head);
+        while (marked) {
+            const int b = __builtin_ctzll(marked);
+            marked &= marked - 1;
+            const long f = base + b;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < n) ps[lane] = p[f * n + lane];
+            for (int i = lane; i < 2 * n - 1; i += 64) qs[i] = q[f * (2 * n - 1) + i];
+            const float rhs = lane < n ? r[f * n + lane] : 0.f;
+            __builtin_amdgcn_wave_barrier();
+            int col;
+            float sol;
+            th_solve_reg<float, 24>(ps, qs, rhs, n, lane, col, sol);
+            if (lane < n) g[f * n + col] = sol;
+        }
+    }
+}
+
+int thsolve_fix_marked(const void* p, const void* q, const void* r, int64_t F, int n, void* g, hipStream_t st)
+{
+    if (n > 24) return DSA_OK;
+    long blocks = (F + 63) / 64;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(th_solve_fix_kernel, dim3((unsigned)blocks), dim3(64), sizeof(float) * (3 * n), st, (const float*)p, (const float*)q,
+                       (const float*)r, (long)F, n, (float*)g);
+    return check_launch("th_solve_quad_fwd");
+}
+
 template <typename T>
 static int th_launch(bool bwd, const void* gg, const void* p, const void* q, const void* r_or_g, int64_t F, int n, void* o1,
                      void* o2, void* o3, hipStream_t st)

@@ -249,7 +249,8 @@ int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist, int64_t F,
  * hankel of utils/private.py:291-302, torch.linalg.solve): g:(F,n) = solve(T(p) + H(q), r), p:(F,n) the first
  * column of the Toeplitz part, q:(F,2n-1) the anti-diagonals of the Hankel part, r:(F,n); n <= 64, row-pivoted
  * (float32, n = 24: 16 systems per wave without pivoting, as the mel-cepstral kernels solve theirs -- the matrix is positive
- * definite for the analysis' gamma in [-1, 0]).
+ * definite for the analysis' gamma in [-1, 0]; a system whose elimination meets a non-positive pivot is re-solved with row
+ * pivoting by a second launch, so arbitrary symmetric systems get the pivoted answer the reference's LAPACK call gives).
  * Backward: cotangent gg:(F,n) -> gp, gq, gr.  The other stages of the analysis are row products against matrices
  * the host composes (dsa_freqt_fwd) around pointwise spectrum arithmetic (modules/mgcep.py). */
 int dsa_thsolve_fwd(const void* p, const void* q, const void* r, int64_t F, int32_t n, int32_t dtype, void* g,

@@ -374,3 +374,33 @@ def test_gc2gc_fused_kernel_equals_the_operator_chain(golden, dt, tol):
         assert float((fused - chain.detach()).abs().max()) <= tol * scale, (n_in, oo, ig, og, nf)
         ref = O.gc2gc(host(cr).astype(np.float64), oo, ig, og, nf)
         assert np.abs(host(fused) - ref).max() <= (1e-9 if dt == torch.float64 else 5e-5) * max(1.0, np.abs(ref).max())
+
+
+def test_thsolve_order24_float32_falls_back_to_pivoting_on_indefinite_systems():
+    """The order-24 float32 path eliminates WITHOUT pivoting (sound for the analysis' positive definite systems).  A system whose
+    elimination meets a non-positive pivot is marked and re-solved with row pivoting by the second launch -- what the reference's
+    torch.linalg.solve (LAPACK, pivoted) does for every system: indefinite and zero-leading-pivot systems scattered among positive
+    definite ones, each against numpy."""
+    rng = np.random.default_rng(5)
+    F, n = 2048 + 5, 24
+    ii = np.arange(n)
+    w = np.exp(rng.standard_normal((F, 48)))
+    om = np.pi * (np.arange(48) + 0.5) / 48
+    p = (w[:, None, :] * np.cos(om[None, None, :] * ii[None, :, None])).sum(-1)
+    q = 0.5 * (w[:, None, :] * np.cos(om[None, None, :] * np.arange(2 * n - 1)[None, :, None])).sum(-1)
+    r = rng.standard_normal((F, n))
+    bad = rng.choice(F, 97, replace=False)
+    p[bad[:40]] = rng.standard_normal((40, n)) * 3.0          # symmetric, indefinite
+    q[bad[:40]] = rng.standard_normal((40, 2 * n - 1))
+    p[bad[40:70], 0] = -q[bad[40:70], 0]                       # leading pivot p0 + q0 exactly zero: needs a row exchange
+    p[bad[70:]] *= -1.0                                        # negative definite Toeplitz part
+    A = p[:, np.abs(ii[:, None] - ii[None, :])] + q[:, ii[:, None] + ii[None, :]]
+    ref = np.linalg.solve(A, r[..., None])[..., 0]
+    g = host(ops.ThSolveFn.apply(dev(p, torch.float32), dev(q, torch.float32), dev(r, torch.float32)))
+    assert _lib.last_kernel() == "th_solve_quad_fwd" and np.isfinite(g).all()
+    cond = np.linalg.cond(A)
+    err = np.abs(g - ref).max(-1) / np.abs(ref).max(-1)
+    ok = cond < 1e4                                             # float32: the bound scales with the condition number
+    assert ok[bad].sum() > 40 and err[ok].max() < 2e-2 and np.median(err[bad][ok[bad]]) < 1e-3, (err[ok].max(), np.median(err[bad]))
+    good = np.setdiff1d(np.arange(F), bad)
+    assert np.median(err[good]) < 2e-5
