@@ -33,6 +33,7 @@ SCRATCH_BYTES = 64   # DSA_SCRATCH_BYTES
 FBANK_PLAN_FLOATS = 2048   # DSA_FBANK_PLAN_FLOATS
 ERR_UNSUPPORTED = -2       # DSA_ERR_UNSUPPORTED
 ALGO_AUTO, ALGO_GENERIC, ALGO_TUNED = 0, 1, 2
+ALGO_SCRATCH_IS_CLEAN = 0x100   # DSA_ALGO_SCRATCH_IS_CLEAN
 
 _lib = None
 

@@ -338,7 +338,7 @@ int mcep_mfma_supported(int nfft, int M, int dtype);
 int64_t mcep_mfma_images_bytes();
 int mcep_mfma_prepare(const void* G, const void* D, const void* E, void* images, hipStream_t st);
 int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E, const void* av,
-                  const void* images, void* scratch, void* mc, void* hist, hipStream_t st);
+                  const void* images, void* scratch, void* mc, void* hist, hipStream_t st, bool scratch_clean = false);
 int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* av,
                   const void* images, void* scratch, void* gX, hipStream_t st);
 
@@ -425,13 +425,15 @@ DSA_EXPORT int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, i
     DSA_REQUIRE(n_iter >= 0 && F >= 0, "mcep: n_iter must be non-negative");
     if (F == 0) return DSA_OK;
     hipStream_t st = (hipStream_t)stream;
+    const bool scratch_clean = (algo & DSA_ALGO_SCRATCH_IS_CLEAN) != 0;
+    algo &= ~DSA_ALGO_SCRATCH_IS_CLEAN;
     bool tuned_ok = mcep_mfma_supported(nfft, M, dtype) != 0;
     if (algo == DSA_ALGO_TUNED && !tuned_ok)
         return fail(DSA_ERR_UNSUPPORTED, "mcep: tuned kernel needs float32, fft_length 512, cep_order 24%s");
     if (algo == DSA_ALGO_TUNED && !(images && scratch))
         return fail(DSA_ERR_INVALID_ARGUMENT, "mcep: the tuned kernel needs the prepared images (dsa_mcep_prepare) and a scratch buffer%s");
     if (tuned_ok && algo != DSA_ALGO_GENERIC && images && scratch)
-        return mcep_mfma_fwd(X, F, n_iter, G, D, E, alpha_vec, images, scratch, mc, mc_hist, st);
+        return mcep_mfma_fwd(X, F, n_iter, G, D, E, alpha_vec, images, scratch, mc, mc_hist, st, scratch_clean);
     if (dtype == DSA_F32) return mcep_generic_fwd<float>(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);
     if (dtype == DSA_F64) return mcep_generic_fwd<double>(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);
     return fail(DSA_ERR_UNSUPPORTED, "mcep: unsupported dtype%s");

@@ -542,14 +542,14 @@ int mcep_mfma_prepare(const void* G, const void* D, const void* E, void* images,
 }
 
 // `scratch`: DSA_SCRATCH_BYTES of caller-owned device memory; the first two words are this launch's tile counters.
-static unsigned int* reset_queue(void* scratch, hipStream_t st)
+static unsigned int* reset_queue(void* scratch, hipStream_t st, int words = 2)
 {
-    if (hipMemsetAsync(scratch, 0, 2 * sizeof(unsigned int), st) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(scratch, 0, words * sizeof(unsigned int), st) != hipSuccess) return nullptr;
     return (unsigned int*)scratch;
 }
 
 int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E, const void* av,
-                  const void* images, void* scratch, void* mc, void* hist, hipStream_t st)
+                  const void* images, void* scratch, void* mc, void* hist, hipStream_t st, bool scratch_clean = false)
 {
     constexpr int WAVES = 8;
     const int lds_bytes = mh::h_lds_floats(WAVES) * 4;
@@ -559,7 +559,9 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
     long ntiles16 = (long)((F + 15) / 16);
     long blocks = (ntiles16 + WAVES - 1) / WAVES;
     long grid = blocks < 256 ? blocks : 256;  // one persistent workgroup per CU
-    unsigned int* queue = reset_queue(scratch, st);
+    // the kernel zeroes the counters again when its last wave retires: a caller that vouches for a clean scratch
+    // (DSA_ALGO_SCRATCH_IS_CLEAN) saves the fill launch
+    unsigned int* queue = scratch_clean ? (unsigned int*)scratch : reset_queue(scratch, st, 3);
     if (!queue) return fail(DSA_ERR_LAUNCH, "mcep_mfma: cannot reset the tile queue%s");
     // see the ticket comment in the kernel: a short last round goes to one wave per SIMD pair
     const long slots = grid * WAVES, full = ntiles16 / slots * slots, rest = ntiles16 - full;

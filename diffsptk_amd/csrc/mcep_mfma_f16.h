@@ -217,9 +217,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
 #define DSA_STAMP_T(i)
 #endif
 #ifdef DSA_MCEP_ABL_ONEWAVE   // timing experiment: one working wave per SIMD (the critical path of a wave on its own)
-    if (wave >= WAVES / 2) return;
+    const bool abl_idle = wave >= WAVES / 2;
+#else
+    const bool abl_idle = false;
 #endif
-    for (long tile = wave_id; tile < ntiles16;) {
+    for (long tile = abl_idle ? ntiles16 : wave_id; tile < ntiles16;) {
         DSA_STAMP_T(16);
 #ifdef DSA_MCEP_TIMING
         if (blockIdx.x == 0 && threadIdx.x == 0 && tcount < 12) { g_mcep_stamps[32 + tcount] = __builtin_readcyclecounter(); g_mcep_stamps[48 + tcount] = (unsigned long long)tile; }
@@ -571,6 +573,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
         ++tcount;
         if (blockIdx.x == 0 && threadIdx.x == 0) { g_mcep_stamps[13] = __builtin_readcyclecounter(); g_mcep_stamps[14] += 1; }
 #endif
+    }
+    // the counters go back to zero with the last wave out (every draw of a wave precedes its own arrival here)
+    if (lane == 0) {
+        const unsigned arrived = atomicAdd(queue + 2, 1u);
+        if (arrived == gridDim.x * WAVES - 1) {
+            queue[0] = 0u;
+            queue[1] = 0u;
+            queue[2] = 0u;
+        }
     }
 }
 

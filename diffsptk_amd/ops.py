@@ -72,6 +72,21 @@ def _scratch(device) -> torch.Tensor:
     return torch.empty(_lib.SCRATCH_BYTES, dtype=torch.uint8, device=device)
 
 
+_CLEAN_SCRATCH: dict = {}   # (device index, stream handle) -> a zeroed scratch the mel-cepstral forward keeps clean
+
+
+def _clean_scratch(device) -> torch.Tensor:
+    """A scratch that is zero on entry and left zero by the kernel (DSA_ALGO_SCRATCH_IS_CLEAN): one per (device, stream), so
+    calls on one stream -- which cannot overlap -- share it and calls on different streams never do."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    t = _CLEAN_SCRATCH.get(key)
+    if t is None:
+        t = torch.zeros(_lib.SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+        _CLEAN_SCRATCH[key] = t
+    return t
+
+
 _IMAGES: dict = {}   # id(G) -> (weakref to G, versions, images): prepared operand images, made once per set of matrices
 
 
@@ -751,10 +766,16 @@ class McepFn(torch.autograd.Function):
         need_hist = ctx.needs_input_grad[0]
         hist = torch.empty(n_iter + 1, F, M + 1, device=X.device, dtype=X.dtype) if need_hist else None
         images = mcep_images(G, D, E, fft_length, M) if algo != _lib.ALGO_GENERIC else None
-        scratch = _scratch(X.device) if images is not None else None
+        # the tile queue's counters: a per-(device, stream) scratch that the kernel leaves zeroed (no fill launch per call)
+        scratch = None
+        flag = 0
+        if images is not None:
+            with torch.cuda.device(X.device):
+                scratch = _clean_scratch(X.device)
+            flag = _lib.ALGO_SCRATCH_IS_CLEAN
         with torch.cuda.device(X.device):
             _call("dsa_mcep_fwd", _p(Xc), F, fft_length, M, n_iter, _p(G), _p(D), _p(E), _p(av),
-                  _dtype_code(Xc), algo, _p(images), _p(scratch), _p(mc), _p(hist), _stream())
+                  _dtype_code(Xc), algo | flag, _p(images), _p(scratch), _p(mc), _p(hist), _stream())
         if need_hist:
             ctx.save_for_backward(Xc, hist, G, D, E, av)
         ctx.cfg = (fft_length, M, n_iter, algo)

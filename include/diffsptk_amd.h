@@ -70,6 +70,10 @@ enum { DSA_SPEC_DB = 0, DSA_SPEC_LOGMAG = 1, DSA_SPEC_MAG = 2, DSA_SPEC_POWER = 
 enum { DSA_ACORR_NAIVE = 0, DSA_ACORR_NORMALIZED = 1, DSA_ACORR_BIASED = 2, DSA_ACORR_UNBIASED = 3 };
 /* kernel selection: AUTO picks the tuned gfx950 kernel when the configuration allows it */
 enum { DSA_ALGO_AUTO = 0, DSA_ALGO_GENERIC = 1, DSA_ALGO_TUNED = 2 };
+/* OR-ed into `algo` of dsa_mcep_fwd: the caller guarantees that `scratch` is ZERO on entry (zeroed once, at allocation) and is used
+ * by one call at a time; the library then skips its per-call reset (a 5 us fill launch and a kernel boundary per call) -- the
+ * persistent kernel leaves the counters zeroed when its last wave retires, with or without this flag. */
+#define DSA_ALGO_SCRATCH_IS_CLEAN 0x100
 
 int dsa_version(void);
 const char* dsa_last_error(void);

@@ -79,6 +79,9 @@ int main(int argc, char** argv)
         printf("DIRECT variants: base %.1f | xcd-contiguous %.1f | nontemporal %.1f | both %.1f | xcd, staged %.1f\n", run<0, true>(20, 16), run<256, true>(20, 16),
                run<512, true>(20, 16), run<768, true>(20, 16), run<256, false>(20, 16));
     for (int rep = 0; rep < 3; ++rep)
+        printf("DIRECT, waves per CU: 16 %.1f | 14 %.1f | 12 %.1f | 10 %.1f | 16 %.1f | 14 %.1f\n", run<0, true>(20, 16), run<0, true>(20, 14), run<0, true>(20, 12),
+               run<0, true>(20, 10), run<0, true>(20, 16), run<0, true>(20, 14));
+    for (int rep = 0; rep < 3; ++rep)
         printf("DIRECT, XCD-chunked workgroup order: base %.1f | C=2 %.1f | C=4 %.1f | C=8 %.1f | base %.1f\n", run<0, true>(20, 16), run<2048, true>(20, 16),
                run<1024, true>(20, 16), run<4096, true>(20, 16), run<0, true>(20, 16));
     for (int rep = 0; rep < 3; ++rep)
