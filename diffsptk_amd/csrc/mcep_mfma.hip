@@ -57,6 +57,7 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
 // conditional store at every stamp split the step's basic block and with it the instruction schedule being measured); the
 // stamps of one (tile, step) are written out by DSA_STAMPS_FLUSH at the end of the step.
 __device__ unsigned long long g_mcep_stamps[64];
+__device__ unsigned long long g_mcep_slotlog[2048 * 3];   // per wave slot: entry, exit (100 MHz ticks), tiles run
 #define DSA_STAMPS_DECL unsigned dsa_st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define DSA_STAMP(i) dsa_st_[i] = (unsigned)__builtin_readcyclecounter()
 #define DSA_STAMPS_FLUSH                                                                \

@@ -221,6 +221,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
 #else
     const bool abl_idle = false;
 #endif
+#ifdef DSA_MCEP_TIMING
+    const unsigned long long slot_t0 = wall_clock64();
+    int slot_tiles = 0;
+#endif
     for (long tile = abl_idle ? ntiles16 : wave_id; tile < ntiles16;) {
         DSA_STAMP_T(16);
 #ifdef DSA_MCEP_TIMING
@@ -571,9 +575,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
         DSA_STAMP_T(21);
 #ifdef DSA_MCEP_TIMING
         ++tcount;
+        ++slot_tiles;
         if (blockIdx.x == 0 && threadIdx.x == 0) { g_mcep_stamps[13] = __builtin_readcyclecounter(); g_mcep_stamps[14] += 1; }
 #endif
     }
+#ifdef DSA_MCEP_TIMING
+    if (lane == 0 && wave_id < 2048) {
+        g_mcep_slotlog[3 * wave_id] = slot_t0;
+        g_mcep_slotlog[3 * wave_id + 1] = wall_clock64();
+        g_mcep_slotlog[3 * wave_id + 2] = (unsigned long long)slot_tiles;
+    }
+#endif
     // the counters go back to zero with the last wave out (every draw of a wave precedes its own arrival here)
     if (lane == 0) {
         const unsigned arrived = atomicAdd(queue + 2, 1u);

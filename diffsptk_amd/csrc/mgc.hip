@@ -581,10 +581,220 @@ __global__ __launch_bounds__(256) void zerodf_fwd_blocked_kernel(const T* __rest
     }
 }
 
+// Round 3: several frames per workgroup, every tap of a sample block in ONE thread, float32 on packed multiply-adds.
+// The blocked kernel above spends most of a launch around its inner loop (one frame per workgroup: two barriers, the
+// partial sums of twelve tap ranges through LDS, ~5 blocks of taps per thread).  Here a workgroup takes `nf` consecutive
+// frames of one utterance: a thread owns four consecutive output samples of one frame and (G = 1) all of its taps, so the
+// sums stay in registers; the rows of frame n and n + 1 are stored INTERLEAVED in LDS -- (b_n[k], b_n+1[k]) as one 8-byte
+// pair -- so that the two filters of the interpolation are the two halves of one v_pk_fma_f32 whose other factor is the
+// sample, broadcast by op_sel: 16 packed instructions per 4 taps x 4 samples x 2 rows instead of 32 v_fma_f32 (the packed
+// form is the only one that issues two float32 multiply-adds per lane in 4 cycles: DESIGN 3.2).  Long filters (the
+// 2000-tap impulse responses of the single-stage form) split the taps over G groups of threads that meet in LDS in a fixed
+// order.  Optional epilogue for the Taylor stages of the multi-stage form: y = scale * filter(x), ysum = acc + y.
+// NaN containment: taps beyond M (padding of the last block of four) are skipped, not multiplied by zero.
+typedef float zd_v2f __attribute__((ext_vector_type(2)));
+typedef float zd_v4f __attribute__((ext_vector_type(4)));
+typedef float zd_v4f_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef double zd_v2d __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void zd_fma_lo(zd_v2f& acc, zd_v2f c, zd_v2f w)   // acc += c * w.x (both halves)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(c), "v"(w));
+}
+__device__ __forceinline__ void zd_fma_hi(zd_v2f& acc, zd_v2f c, zd_v2f w)   // acc += c * w.y (both halves)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(c), "v"(w));
+}
+__device__ __forceinline__ void zd_fma_lo(zd_v2d& acc, zd_v2d c, zd_v2d w) { acc += c * w.x; }
+__device__ __forceinline__ void zd_fma_hi(zd_v2d& acc, zd_v2d c, zd_v2d w) { acc += c * w.y; }
+
+template <typename T, int S>
+__global__ __launch_bounds__(256) void zerodf_fwd_rows_kernel(const T* __restrict__ x, const T* __restrict__ b, long Tlen, long N,
+                                                              int M, int P, int z0, int ignore_gain, int nf, int G, T scale,
+                                                              const T* acc, T* __restrict__ y, T* ysum)
+{
+    using V2 = T __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int NB = (M + 4) / 4;                 // 4-tap blocks
+    const int nt = P / S;                       // threads per (frame, tap group): S consecutive samples each
+    V2* brp = reinterpret_cast<V2*>(smem_raw);  // [nf][4 NB]: (b[n][M - kk], b[n + 1][M - kk]), zero beyond kk = M
+    T* xs = reinterpret_cast<T*>(brp + (size_t)nf * 4 * NB);   // [nf P + 4 NB + 8]: x[t0 - M + z0 ..]
+    V2* part = reinterpret_cast<V2*>(xs + ((size_t)nf * P + 4 * NB + 8));   // [nf][G][P] when G > 1
+    const long chunks = (N + nf - 1) / nf;
+    const long u = blockIdx.x / chunks, n0 = (blockIdx.x - u * chunks) * nf;
+    const int frames = (int)((N - n0 < nf) ? N - n0 : nf);
+    const T* bu = b + u * N * (M + 1);
+    // (all loads of a batch first, then the stores: a load -> store loop waits out one trip to memory per element)
+    for (int kk = threadIdx.x; kk < 4 * NB; kk += blockDim.x) {   // a thread walks down one tap: every row is read once
+        const bool tap = kk <= M;
+        const T* col = bu + (M - (tap ? kk : M));
+        T cv[17];
+#pragma unroll
+        for (int p = 0; p <= 16; ++p) {
+            const long row = n0 + p < N ? n0 + p : N - 1;
+            cv[p] = (tap && p <= frames) ? col[row * (M + 1)] : T(0);
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+            if (p < frames) brp[(size_t)p * 4 * NB + kk] = V2{cv[p], cv[p + 1]};
+    }
+    const long t0 = n0 * P;
+    const T* xu = x + u * Tlen;
+    const int xlen = frames * P + 4 * NB + 8;
+    for (int i0 = threadIdx.x; i0 < xlen; i0 += 8 * blockDim.x) {
+        T xv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const long sidx = t0 - M + z0 + i0 + q * (int)blockDim.x;
+            xv[q] = (i0 + q * (int)blockDim.x < xlen && sidx >= 0 && sidx < Tlen) ? xu[sidx] : T(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (i0 + q * (int)blockDim.x < xlen) xs[i0 + q * (int)blockDim.x] = xv[q];
+    }
+    __syncthreads();
+    const int grp = threadIdx.x / nt, l = threadIdx.x - grp * nt;   // grp = fr * G + g
+    const int fr = grp / G, g = grp - fr * G;
+    const bool active = fr < frames;
+    V2 a[S];
+#pragma unroll
+    for (int q = 0; q < S; ++q) a[q] = V2{0, 0};
+    if (active) {
+        // (host: G divides the number of full blocks, so the loop count is the same for every thread of the launch)
+        const int rem = (M + 1) & 3;                       // taps in the last block when it is a partial one
+        const int per = (rem ? NB - 1 : NB) / G;
+        const int m0 = g * per, m_full = m0 + per;
+        const int m1 = (rem != 0 && g == G - 1) ? m_full + 1 : m_full;
+        const V2* cp = brp + (size_t)fr * 4 * NB;
+        const T* xf = xs + fr * P + S * l;
+        // A block of four taps on S samples reads the S + 4 samples xf[4 m .. 4 m + S + 3]: NP = (S + 4) / 2 pairs kept in a
+        // ring of NP registers pairs that advances by two pairs per block -- after NP / 2 blocks (a trip, unrolled) every pair
+        // is back in its slot, so nothing is copied; per block two 16-byte tap reads (broadcasts) and one 16-byte sample read
+        // feed 4 S packed multiply-adds (S = 8: the LDS pipe, which the S = 4 form loads as much as the vector unit, idles).
+        constexpr int NP = (S + 4) / 2, TRIP = NP / 2;
+        V2 R[NP];
+#pragma unroll
+        for (int i = 0; i < NP - 2; ++i) R[i] = *reinterpret_cast<const V2*>(xf + 4 * m0 + 2 * i);
+        auto block = [&](int m, int b) __attribute__((always_inline)) {   // b = (m - m0) % TRIP: the ring's phase
+            V2 c[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] = cp[4 * m + r];
+            R[(2 * b + NP - 2) % NP] = *reinterpret_cast<const V2*>(xf + 4 * m + 2 * (NP - 2));
+            R[(2 * b + NP - 1) % NP] = *reinterpret_cast<const V2*>(xf + 4 * m + 2 * (NP - 1));
+#pragma unroll
+            for (int q = 0; q < S; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if ((q + r) & 1) zd_fma_hi(a[q], c[r], R[(2 * b + ((q + r) >> 1)) % NP]);
+                    else zd_fma_lo(a[q], c[r], R[(2 * b + ((q + r) >> 1)) % NP]);
+                }
+        };
+        int j = 0;
+        for (; j + TRIP <= per; j += TRIP) {   // (uniform trip count: a scalar loop)
+#pragma unroll
+            for (int b = 0; b < TRIP; ++b) block(m0 + j + b, b);
+        }
+        int tail_b = 0;   // blocks left after the last whole trip (the ring's phase restarts at 0 there)
+#pragma unroll
+        for (int b = 0; b < TRIP - 1; ++b)
+            if (j + b < per) {
+                block(m0 + j + b, b);
+                tail_b = b + 1;
+            }
+        if (m_full < m1) {   // the partial last block: only its real taps
+            const int m = m_full;
+            // bring the ring back to phase 0 (at most once per thread)
+            V2 Wn[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) Wn[i] = tail_b == 0 ? R[i] : (tail_b == 1 ? R[(i + 2) % NP] : R[(i + 4) % NP]);
+            Wn[NP - 2] = *reinterpret_cast<const V2*>(xf + 4 * m + 2 * (NP - 2));
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                if (r < rem) {
+                    const V2 cr = cp[4 * m + r];
+#pragma unroll
+                    for (int q = 0; q < S; ++q) {
+                        if ((q + r) & 1) zd_fma_hi(a[q], cr, Wn[(q + r) >> 1]);
+                        else zd_fma_lo(a[q], cr, Wn[(q + r) >> 1]);
+                    }
+                }
+        }
+    }
+    if (G > 1) {
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < S; ++q) part[((size_t)fr * G + g) * P + S * l + q] = a[q];
+        }
+        __syncthreads();
+        if (active && g == 0) {
+#pragma unroll
+            for (int q = 0; q < S; ++q) {
+                V2 sacc = part[((size_t)fr * G) * P + S * l + q];
+                for (int gg = 1; gg < G; ++gg) sacc += part[((size_t)fr * G + gg) * P + S * l + q];
+                a[q] = sacc;
+            }
+        }
+    }
+    if (active && g == 0) {
+        const int gk = z0 == M ? M : 0;
+        const V2 gain = brp[(size_t)fr * 4 * NB + (M - gk)];
+        const long o = u * Tlen + t0 + (long)fr * P + S * l;
+        T v[S];
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+            const T wt = (T)(S * l + q) / (T)P;
+            T r = a[q].x + wt * (a[q].y - a[q].x);          // torch.lerp(y1, y2, ramp)
+            if (ignore_gain) r /= gain.x + wt * (gain.y - gain.x);
+            v[q] = r * scale;
+        }
+        if (y) {
+#pragma unroll
+            for (int q = 0; q < S; ++q) y[o + q] = v[q];
+        }
+        if (ysum) {
+#pragma unroll
+            for (int q = 0; q < S; ++q) ysum[o + q] = acc[o + q] + v[q];
+        }
+    }
+}
+
+// nf frames x G tap groups of P / S threads per 256-thread workgroup within 64 KB of LDS; false: shape not covered
+static bool zerodf_rows_plan(int M, int P, size_t elt, int& S, int& nf, int& G, size_t& lds)
+{
+    if (P % 4 != 0 || P / 4 > 256 || M < 16) return false;
+    S = 4;   // (S = 8 -- half the LDS reads per multiply-add, 160 of 256 threads busy at P = 80 -- measured the same: 1.50 vs 1.46 ms)
+    const int NB = (M + 4) / 4, nt = P / S, groups = 256 / nt;
+    const int nb_full = ((M + 1) & 3) ? NB - 1 : NB;
+    for (nf = groups < 16 ? groups : 16; nf >= 1; --nf) {
+        G = groups / nf;
+        while (G > 1 && nb_full % G != 0) --G;   // equal tap ranges: one loop count for the whole launch
+        lds = (size_t)nf * 4 * NB * 2 * elt + ((size_t)nf * P + 4 * NB + 8) * elt + (G > 1 ? (size_t)nf * G * P * 2 * elt : 0);
+        lds = (lds + 15) & ~(size_t)15;
+        if (lds <= 64 * 1024) return true;
+    }
+    return false;
+}
+
 template <typename T>
 static int zerodf_launch_fwd(const void* x, const void* b, int64_t B, int64_t Tlen, int64_t N, int M, int P, int z0, int ig,
-                             void* y, hipStream_t st)
+                             void* y, hipStream_t st, double scale = 1.0, const void* acc = nullptr, void* ysum = nullptr)
 {
+    static const int variant = [] { const char* e = getenv("DSA_ZERODF"); return e ? atoi(e) : 0; }();   // 1: round-2 kernels (A/B)
+    {
+        int S, nf, G;
+        size_t lds_r;
+        if ((variant == 0 || ysum || scale != 1.0) && zerodf_rows_plan(M, P, sizeof(T), S, nf, G, lds_r)) {
+            const long chunks = (N + nf - 1) / nf;
+            if (S == 8)
+                hipLaunchKernelGGL((zerodf_fwd_rows_kernel<T, 8>), dim3((unsigned)(B * chunks)), dim3(256), lds_r, st, (const T*)x,
+                                   (const T*)b, (long)Tlen, (long)N, M, P, z0, ig, nf, G, (T)scale, (const T*)acc, (T*)y, (T*)ysum);
+            else
+                hipLaunchKernelGGL((zerodf_fwd_rows_kernel<T, 4>), dim3((unsigned)(B * chunks)), dim3(256), lds_r, st, (const T*)x,
+                                   (const T*)b, (long)Tlen, (long)N, M, P, z0, ig, nf, G, (T)scale, (const T*)acc, (T*)y, (T*)ysum);
+            return check_launch("zerodf_rows_fwd");
+        }
+        if (ysum || scale != 1.0) return fail(DSA_ERR_UNSUPPORTED, "zerodf: the scaled / accumulating form needs P % 4 == 0 and M >= 16%s");
+    }
     {   // long filters: taps and samples blocked by four (DSA_ZERODF_SLICED=1 keeps the older sliced kernel: A/B)
         static const bool sliced_only = [] {
             const char* e = getenv("DSA_ZERODF_SLICED");
@@ -842,6 +1052,22 @@ DSA_EXPORT int dsa_zerodf_fwd(const void* x, const void* b, int64_t B, int64_t T
     if (dtype == DSA_F32) return zerodf_launch_fwd<float>(x, b, B, T, N, M, P, zeroth_index, ignore_gain, y, (hipStream_t)stream);
     if (dtype == DSA_F64) return zerodf_launch_fwd<double>(x, b, B, T, N, M, P, zeroth_index, ignore_gain, y, (hipStream_t)stream);
     return fail(DSA_ERR_UNSUPPORTED, "zerodf: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_zerodf_taylor_fwd(const void* x, const void* b, int64_t B, int64_t T, int32_t M, int32_t P, int32_t zeroth_index,
+                                     double scale, const void* acc, int32_t dtype, void* y, void* ysum, void* stream)
+{
+    DSA_REQUIRE(M >= 0 && P > 0 && B >= 0 && T >= 0 && zeroth_index >= 0 && zeroth_index <= M, "zerodf_taylor: invalid sizes");
+    DSA_REQUIRE(T % P == 0, "zerodf_taylor: the sequence length must be frames x frame_period");
+    DSA_REQUIRE((acc != nullptr) == (ysum != nullptr), "zerodf_taylor: acc and ysum come together");
+    DSA_REQUIRE(y != nullptr || ysum != nullptr, "zerodf_taylor: no output");
+    if (B * T == 0) return DSA_OK;
+    const int64_t N = T / P;
+    if (dtype == DSA_F32)
+        return zerodf_launch_fwd<float>(x, b, B, T, N, M, P, zeroth_index, 0, y, (hipStream_t)stream, scale, acc, ysum);
+    if (dtype == DSA_F64)
+        return zerodf_launch_fwd<double>(x, b, B, T, N, M, P, zeroth_index, 0, y, (hipStream_t)stream, scale, acc, ysum);
+    return fail(DSA_ERR_UNSUPPORTED, "zerodf_taylor: unsupported dtype%s");
 }
 
 DSA_EXPORT int dsa_zerodf_bwd(const void* gy, const void* x, const void* b, const void* y, int64_t B, int64_t T, int32_t M, int32_t P,

@@ -37,6 +37,24 @@ def _mirror(x: torch.Tensor, half: bool = False) -> torch.Tensor:
     return torch.cat((x1.flip(-1), x0, x1), dim=-1)
 
 
+
+def _taylor_stages(x: torch.Tensor, c: torch.Tensor, P: int, z0: int, order: int) -> torch.Tensor:
+    """exp(F) x ~ sum_i F^i x / i!  (mglsadf.py:356-365): x <- F x / i, y <- y + x, `order` times.  Without a graph a stage
+    (filter, 1 / i, running sum) is ONE launch, rounded like the three operations it replaces; with one, the differentiable
+    filter and two element-wise operations per stage."""
+    if order >= 1 and ops.zerodf_taylor_supported(x, c, P):
+        y = x.clone(memory_format=torch.contiguous_format)
+        cur = x
+        for i in range(1, order + 1):
+            cur, y = ops.zerodf_taylor(cur, c, P, z0, 1.0 / i, y, want_y=i < order)
+        return y
+    y = x
+    cur = x
+    for i in range(1, order + 1):
+        cur = ops.zerodf(cur, c, P, z0, False) * (1.0 / i)
+        y = y + cur
+    return y
+
 class PseudoMGLSADigitalFilter(nn.Module):
     """x:(..., T) excitation, mc:(..., T/P, M+1) mel-generalized cepstrum -> y:(..., T) (mglsadf.py:211-252)."""
 
@@ -156,11 +174,7 @@ class PseudoMGLSADigitalFilter(nn.Module):
             c_min, c_max = self.mgc2c[0](mc_min), self.mgc2c[1](mc_max)
             c0 = c_min[..., :1] + c_max[..., :1]
             c = torch.cat((c_max[..., 1:].flip(-1), torch.zeros_like(c0), c_min[..., 1:]), dim=-1).contiguous()
-            y = x
-            cur = x
-            for i in range(1, self.taylor_order + 1):
-                cur = ops.zerodf(cur, c, P, self.cep_orders[0], False) * (1.0 / i)
-                y = y + cur
+            y = _taylor_stages(x, c, P, self.cep_orders[0], self.taylor_order)
             if not self.ignore_gain:
                 y = y * torch.exp(self.linear_intpl(c0)).squeeze(-1)
             return y
@@ -202,11 +216,7 @@ class PseudoMGLSADigitalFilter(nn.Module):
                 c, z0 = c.flip(-1), self.cep_order
             elif self.phase == "zero":
                 c, z0 = _mirror(c, half=True), self.cep_order
-            y = x
-            cur = x
-            for i in range(1, self.taylor_order + 1):                            # exp(F) ~ sum_i F^i / i!
-                cur = ops.zerodf(cur, c, P, z0, False) * (1.0 / i)
-                y = y + cur
+            y = _taylor_stages(x, c, P, z0, self.taylor_order)
             if not self.ignore_gain:
                 y = y * torch.exp(self.linear_intpl(c0)).squeeze(-1)
             return y

@@ -940,6 +940,31 @@ def zerodf(x, b, P, zeroth_index, ignore_gain):
     return ZerodfFn.apply(x, b, P, zeroth_index, ignore_gain)
 
 
+def zerodf_taylor_supported(x, b, P) -> bool:
+    """Shapes the fused Taylor-stage launch covers (csrc/mgc.hip:zerodf_rows_plan) -- and no graph is being recorded."""
+    return (P % 4 == 0 and b.size(-1) - 1 >= 16 and b.dim() >= 2 and tuple(b.shape[:-2]) == tuple(x.shape[:-1])
+            and b.size(-2) * P == x.size(-1) and not (torch.is_grad_enabled() and (x.requires_grad or b.requires_grad)))
+
+
+def zerodf_taylor(x, b, P, zeroth_index, scale, acc, want_y=True):
+    """One Taylor stage of the multi-stage MLSA filter without a graph (mglsadf.py:356-365): returns
+    (scale * zerodf(x; b) or None, acc + scale * zerodf(x; b)) from one launch; `acc` is updated in place."""
+    _require_device(x, b, acc)
+    _same_dtype(x, b)
+    _same_dtype(x, acc)
+    xc, bc = x.contiguous(), b.contiguous()
+    if not acc.is_contiguous() or acc.shape != xc.shape:
+        raise ValueError("zerodf_taylor: acc must be a contiguous tensor of the signal's shape")
+    T = xc.size(-1)
+    M = bc.size(-1) - 1
+    B = xc.numel() // max(T, 1)
+    y = torch.empty_like(xc) if want_y else None
+    with torch.cuda.device(x.device):
+        _call("dsa_zerodf_taylor_fwd", _p(xc), _p(bc), B, T, M, P, zeroth_index, float(scale), _p(acc), _dtype_code(xc),
+              _p(y), _p(acc), _stream())
+    return y, acc
+
+
 # ----------------------------------------------------------------------------------- LPC branch
 class AcorrFn(torch.autograd.Function):
     @staticmethod

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 113 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch), dsa_mgcep_step */
+#define DSA_VERSION 114 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch), dsa_mgcep_step */
 
 typedef enum {
     DSA_OK = 0,
@@ -297,6 +297,13 @@ int dsa_zerodf_fwd(const void* x, const void* b, int64_t B, int64_t T, int32_t M
                    int32_t ignore_gain, int32_t dtype, void* y, void* stream);
 int dsa_zerodf_bwd(const void* gy, const void* x, const void* b, const void* y, int64_t B, int64_t T, int32_t M, int32_t P,
                    int32_t zeroth_index, int32_t ignore_gain, int32_t dtype, void* gx, void* gb, void* stream);
+/* One Taylor stage of the multi-stage MLSA filter (mglsadf.py:356-365: x <- F x / i, y <- y + x) in one launch:
+ *   y = scale * zerodf(x; b)   (y may be NULL when only the sum is wanted: the last stage),
+ *   ysum = acc + y             (acc and ysum both NULL or both given; they may be the same buffer).
+ * Rounded exactly like the three separate operations.  Needs P % 4 == 0 and M >= 16 (DSA_ERR_UNSUPPORTED otherwise:
+ * use dsa_zerodf_fwd and element-wise launches). */
+int dsa_zerodf_taylor_fwd(const void* x, const void* b, int64_t B, int64_t T, int32_t M, int32_t P, int32_t zeroth_index,
+                          double scale, const void* acc, int32_t dtype, void* y, void* ysum, void* stream);
 
 /* ------------------------------------------------------------------ a11  autocorrelation
  * Autocorrelation._forward, acorr.py:110-120.  x:(F,L) -> r:(F,M+1).  Computed as direct lag

@@ -182,22 +182,40 @@ def test_zerodf_and_linear_intpl(golden):
     rng = np.random.default_rng(5)
     xl, bl = rng.standard_normal((3, 800)), 0.05 * rng.standard_normal((3, 10, 400))
     yl = host(ops.ZerodfFn.apply(dev(xl, torch.float32), dev(bl, torch.float32), 80, 0, False))
-    assert _lib.last_kernel() == "zerodf_blocked_fwd"   # M >= 64, P <= 128: taps and samples blocked by four
+    assert _lib.last_kernel() == "zerodf_rows_fwd"   # M >= 16, P % 4 == 0: several frames per workgroup, packed multiply-adds
     ref = O.zerodf(xl, bl, 80)
     assert np.abs(yl - ref).max() < 2e-5 * np.abs(ref).max()
-    # the blocked kernel on every shape class: tap counts that do / do not divide by 4, P in {5, 80, 128}, look-ahead taps,
-    # gain normalisation on either end tap, float64; P = 160 and short filters keep the one-thread-per-sample kernel
-    for M_, P_, z0, ig in ((64, 80, 0, False), (199, 80, 199, True), (301, 128, 100, False), (70, 5, 0, True), (1999, 80, 0, False)):
-        nfr = 4
+    # every shape class of the long-filter kernels: tap counts that do / do not divide by 4, P in {5, 80, 128, 160}, look-ahead
+    # taps, gain normalisation on either end tap, more / fewer frames than a workgroup takes, float64; a frame period that
+    # is not a multiple of 4 keeps the one-frame-per-workgroup blocked kernel, short filters the one-thread-per-sample one
+    for M_, P_, z0, ig, nfr, kern in ((64, 80, 0, False, 4, "rows"), (199, 80, 199, True, 31, "rows"), (301, 128, 100, False, 5, "rows"),
+                                      (70, 5, 0, True, 4, "blocked"), (1999, 80, 0, False, 4, "rows"), (1998, 80, 7, True, 3, "rows"),
+                                      (17, 8, 3, False, 70, "rows"), (100, 160, 0, True, 2, "rows"), (202, 80, 0, False, 13, "rows")):
         xs_, bs_ = rng.standard_normal((2, nfr * P_)), 0.05 * rng.standard_normal((2, nfr, M_ + 1))
         bs_[..., 0] += 1.5
         bs_[..., -1] += 1.5
         for dt, tol in ((torch.float64, 1e-11), (torch.float32, 3e-5)):
             out = host(ops.ZerodfFn.apply(dev(xs_, dt), dev(bs_, dt), P_, z0, ig))
-            assert _lib.last_kernel() == "zerodf_blocked_fwd", (M_, P_, dt)
+            assert _lib.last_kernel() == f"zerodf_{kern}_fwd", (M_, P_, dt)
             ref = O.zerodf(xs_, bs_, P_, ig, z0)
             assert np.abs(out - ref).max() < tol * np.abs(ref).max(), (M_, P_, z0, ig, dt)
-    out = host(ops.ZerodfFn.apply(dev(rng.standard_normal((1, 320))), dev(rng.standard_normal((1, 2, 101))), 160, 0, False))
+    # NaN containment: a NaN sample reaches exactly the outputs whose taps touch it (zero PADDING taps must not multiply it)
+    M_, P_, z0 = 17, 8, 3
+    xs_, bs_ = rng.standard_normal((1, 40 * P_)), rng.standard_normal((1, 40, M_ + 1))
+    xs_[0, 100] = np.nan
+    out = host(ops.ZerodfFn.apply(dev(xs_, torch.float32), dev(bs_, torch.float32), P_, z0, False))
+    assert _lib.last_kernel() == "zerodf_rows_fwd"
+    bad = np.flatnonzero(np.isnan(out[0]))
+    assert bad.min() == 100 - z0 and bad.max() == 100 - z0 + M_ and len(bad) == M_ + 1
+    # one Taylor stage of the multi-stage filter in one launch: rounded like filter, scale, add
+    xt, bt = dev(rng.standard_normal((3, 20 * 80)), torch.float32), dev(0.05 * rng.standard_normal((3, 20, 200)), torch.float32)
+    acc = dev(rng.standard_normal((3, 20 * 80)), torch.float32)
+    want_cur = ops.ZerodfFn.apply(xt, bt, 80, 0, False) * (1.0 / 3)
+    want_sum = acc + want_cur
+    cur, ysum = ops.zerodf_taylor(xt, bt, 80, 0, 1.0 / 3, acc.clone())
+    assert torch.equal(cur, want_cur) and torch.equal(ysum, want_sum)
+    assert ops.zerodf_taylor(xt, bt, 80, 0, 1.0 / 3, acc.clone(), want_y=False)[0] is None
+    out = host(ops.ZerodfFn.apply(dev(rng.standard_normal((1, 12))), dev(rng.standard_normal((1, 2, 11))), 6, 0, False))
     assert _lib.last_kernel() == "zerodf_fwd" and np.isfinite(out).all()
 
 

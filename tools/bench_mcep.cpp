@@ -67,6 +67,26 @@ int main(int argc, char** argv)
     printf("   wave 0: %llu ticks from kernel entry to its last tile's end; tile starts (ticks since entry: tile id):", st[13] - st[12]);
     for (int i = 0; i < 12 && st[32 + i] > st[12]; ++i) printf("  %llu:%llu", st[32 + i] - st[12], st[48 + i]);
     printf("\n   => %.3f GHz if wave 0 spans the kernel\n", (st[13] - st[12]) / (best * 1e6));
+    {   // how the launch ends: per wave slot, entry / exit on the 100 MHz clock and the tiles it ran
+        std::vector<unsigned long long> sl(2048 * 3);
+        hipMemcpyFromSymbol(sl.data(), HIP_SYMBOL(dsa::g_mcep_slotlog), sl.size() * 8);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int i = 0; i < 2048; ++i) { if (sl[3 * i] && sl[3 * i] < t0) t0 = sl[3 * i]; if (sl[3 * i + 1] > t1) t1 = sl[3 * i + 1]; }
+        int hist_first[16] = {0}, hist_second[16] = {0}, hist_end[10] = {0};
+        for (int i = 0; i < 2048; ++i) {
+            if (!sl[3 * i]) continue;
+            const int nt = sl[3 * i + 2] < 15 ? (int)sl[3 * i + 2] : 15;
+            ((i & 7) < 4 ? hist_first : hist_second)[nt]++;   // waves 0..3 of a workgroup: the older wave of each SIMD pair
+            hist_end[(sl[3 * i + 1] - t0) * 10 / (t1 - t0 + 1)]++;
+        }
+        printf("   slots: first entry -> last exit %.1f us; tiles per slot, older wave of a SIMD pair:", (t1 - t0) / 100.0);
+        for (int i = 0; i < 16; ++i) if (hist_first[i]) printf(" %d:%d", i, hist_first[i]);
+        printf("  younger wave:");
+        for (int i = 0; i < 16; ++i) if (hist_second[i]) printf(" %d:%d", i, hist_second[i]);
+        printf("\n   slot exits by tenth of the launch:");
+        for (int i = 0; i < 10; ++i) printf(" %d", hist_end[i]);
+        printf("\n");
+    }
     std::vector<float> h(8);
     hipMemcpy(h.data(), mc, 32, hipMemcpyDeviceToHost);
     printf("   mc[0..3] = %g %g %g %g\n", h[0], h[1], h[2], h[3]);
