@@ -403,32 +403,47 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
     frq = Bq * FRAMES_PER_UTT
     rows = {}
 
-    def timed(name, fn, n=5):
+    def timed(name, fn, n=5, bytes_per_frame=None, flop_per_frame=None):
+        """`roofline`: the module's algorithmic bytes per frame (its inputs + outputs once, float32) against the HBM peak, and for
+        the rows that are arithmetic by construction their multiply-adds against the float32 vector peak."""
         rows[name] = {"ms": gpu_time(fn, n=n, groups=2), "kernel": _lib.last_kernel()}
+        t_s = rows[name]["ms"] * 1e-3
         rows[name]["Mframes/s"] = frq / rows[name]["ms"] / 1e3
+        if bytes_per_frame is not None:
+            a = bytes_per_frame * frq / t_s / 1e9
+            rows[name]["roofline"] = {"bound": "hbm", "bytes_per_frame": bytes_per_frame, "achieved": a, "peak": HBM_PEAK_GBS,
+                                      "unit": "GB/s", "frac": a / HBM_PEAK_GBS}
+        if flop_per_frame is not None:
+            a = flop_per_frame * frq / t_s / 1e12
+            rows[name]["roofline_arith"] = {"bound": "f32 vector (packed multiply-add peak)", "flop_per_frame": flop_per_frame,
+                                            "achieved": a, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / FP32_PEAK_TFLOPS}
 
     with torch.no_grad():
         Xq = stft(xq)
         stc = dsp.STFT(FL, FP, NFFT, out_format="complex", device=dev)
         ist = dsp.ISTFT(FL, FP, NFFT, device=dev)
         Zq = stc(xq)
-        timed("f2 ISTFT", lambda: ist(Zq), n=10)
+        timed("f2 ISTFT", lambda: ist(Zq), n=10, bytes_per_frame=8 * (NFFT // 2 + 1) + 4 * FP)
         gl = dsp.GriffinLim(FL, FP, NFFT, n_iter=4, init_phase="zeros", device=dev)
-        timed("f2 GriffinLim (4 iterations)", lambda: gl(Xq, out_length=xq.size(-1)), n=3)
+        timed("f2 GriffinLim (4 iterations)", lambda: gl(Xq, out_length=xq.size(-1)), n=3,
+              bytes_per_frame=4 * (NFFT // 2 + 1) + 4 * FP + 4 * (2 * (8 * (NFFT // 2 + 1) + 4 * FP)))   # in + out + 4 x (ISTFT, STFT)
         for it in (0, 3):
             ca = dsp.CepstralAnalysis(fft_length=NFFT, cep_order=M, n_iter=it, device=dev)
-            timed(f"f3 CepstralAnalysis n_iter={it}", lambda: ca(Xq), n=10)
+            timed(f"f3 CepstralAnalysis n_iter={it}", lambda: ca(Xq), n=10, bytes_per_frame=4 * (NFFT // 2 + 1) + 4 * (M + 1))
         mg = dsp.MelGeneralizedCepstralAnalysis(fft_length=NFFT, cep_order=M, alpha=ALPHA, gamma=-0.5, n_iter=N_ITER, device=dev)
-        timed("f3 MelGeneralizedCepstralAnalysis gamma=-0.5 n_iter=10", lambda: mg(Xq), n=2)
+        timed("f3 MelGeneralizedCepstralAnalysis gamma=-0.5 n_iter=10", lambda: mg(Xq), n=2,
+              bytes_per_frame=4 * (NFFT // 2 + 1) + 4 * (M + 1))
         mcq = mcep(Xq)
         m2s = dsp.MelGeneralizedCepstrumToSpectrum(M, NFFT, alpha=ALPHA, device=dev)
-        timed("f4 mgc2sp", lambda: m2s(mcq), n=10)
+        timed("f4 mgc2sp", lambda: m2s(mcq), n=10, bytes_per_frame=4 * (NFFT // 2 + 1) + 4 * (M + 1))
         m2b = dsp.MelCepstrumToMLSADigitalFilterCoefficients(M, ALPHA, device=dev)
-        timed("f4 mc2b", lambda: m2b(mcq), n=10)
+        timed("f4 mc2b", lambda: m2b(mcq), n=10, bytes_per_frame=8 * (M + 1))
         exc = torch.randn(Bq, SAMPLES, device=dev)
         for mode, kw in (("multi-stage", {}), ("single-stage", {}), ("freq-domain", dict(frame_length=FL, fft_length=NFFT))):
             ml = dsp.MLSA(M, FP, alpha=ALPHA, mode=mode, device=dev, **kw)
-            timed(f"f4 MLSA {mode}", lambda: ml(exc, mcq), n=2)
+            # time-domain modes: two rows x taps x samples multiply-adds per frame (200 taps x 20 Taylor stages | 2000 taps)
+            flop = {"multi-stage": 2 * 2 * 200 * 20 * FP, "single-stage": 2 * 2 * 2000 * FP}.get(mode)
+            timed(f"f4 MLSA {mode}", lambda: ml(exc, mcq), n=2, bytes_per_frame=8 * FP + 4 * (M + 1), flop_per_frame=flop)
     res["f_rows_batch256"] = {"workload": f"SURVEY 8(f) rows 2-4, {Bq} utterances x 1 s ({frq} frames / {Bq * SAMPLES} samples), float32, "
                                           "module API, default options unless named", "rows": rows,
                               "timing": "back-to-back calls (gpu_time); `kernel` = the last kernel family the call dispatched to"}

@@ -4,6 +4,7 @@ numpy oracle.  Tolerances: float64 rtol 1e-5 / atol 1e-8 (tests/utils.py:66-72 o
 per test."""
 import numpy as np
 import pytest
+import scipy.signal
 import torch
 
 import diffsptk_amd as dsp
@@ -422,3 +423,51 @@ def test_thsolve_order24_float32_falls_back_to_pivoting_on_indefinite_systems():
     assert ok[bad].sum() > 40 and err[ok].max() < 2e-2 and np.median(err[bad][ok[bad]]) < 1e-3, (err[ok].max(), np.median(err[bad]))
     good = np.setdiff1d(np.arange(F), bad)
     assert np.median(err[good]) < 2e-5
+
+
+def test_f_rows_at_the_bench_size_against_the_oracle():
+    """SURVEY 8(f) rows 3-4 at the size bench.py times them (256 utterances x 1 s = 51 200 frames, float32, default options):
+    frames / utterances sampled across the batch against the float64 oracle.  Every row is independent per frame (analysis,
+    conversions) or per utterance (the filters), so a sample checks the whole launch geometry: first / last workgroups, the
+    ragged last chunk of frames, every utterance offset.  Tolerances: 3 x the error measured on this input
+    (tools/measure_tolerances.py prints them)."""
+    B, N, P, M, L, alpha = 256, 200, 80, 24, 512, 0.42
+    g = torch.Generator().manual_seed(11)
+    # coloured noise: white noise through a fixed one-pole smoother, so that the spectra have a 40 dB tilt like speech
+    x = torch.randn(B, N * P, generator=g, dtype=torch.float64)
+    x = torch.from_numpy(np.ascontiguousarray(scipy.signal.lfilter([1.0], [1.0, -0.9], x.numpy(), axis=-1)))
+    xd = x.float().to(DEV)
+    with torch.no_grad():
+        X = dsp.STFT(400, P, L, device=DEV)(xd)[:, :N].contiguous()                      # (B, N, 257) power spectra
+        frames = torch.tensor([0, 1, 199, 200, 12345, 25599, 25600, 40000, 51198, 51199])
+        Xs = host(X.reshape(-1, L // 2 + 1)[frames]).astype(np.float64)
+        # f3: mel-generalized cepstral analysis, gamma = -0.5, 10 Newton steps
+        mg = dsp.MelGeneralizedCepstralAnalysis(fft_length=L, cep_order=M, alpha=alpha, gamma=-0.5, n_iter=10, device=DEV)
+        y = host(mg(X).reshape(-1, M + 1)[frames]).astype(np.float64)
+        ref = O.mgcep(Xs, M, alpha=alpha, gamma=-0.5, n_iter=10)
+        err_mgcep = np.abs(y - ref).max() / np.abs(ref).max()
+        # the mel-cepstra the synthesis rows start from
+        mc = dsp.MelCepstralAnalysis(fft_length=L, cep_order=M, alpha=alpha, n_iter=10, device=DEV)(X)
+        mcs = host(mc.reshape(-1, M + 1)[frames]).astype(np.float64)
+        # f4: mgc2sp, mc2b
+        sp = host(dsp.MelGeneralizedCepstrumToSpectrum(M, L, alpha=alpha, device=DEV)(mc).reshape(-1, L // 2 + 1)[frames]).astype(np.float64)
+        ref = O.mgc2sp(mcs, L, alpha=alpha)
+        err_sp = (np.abs(sp - ref) / np.abs(ref)).max()
+        bb = host(dsp.MelCepstrumToMLSADigitalFilterCoefficients(M, alpha, device=DEV)(mc).reshape(-1, M + 1)[frames]).astype(np.float64)
+        ref = O.mc2b(mcs, alpha)
+        err_b = np.abs(bb - ref).max() / np.abs(ref).max()
+        # f4: the MLSA filter, three modes: excitation through the filters of the analysed cepstra; utterances 0, 131, 255
+        exc = torch.randn(B, N * P, generator=g).to(DEV)
+        utt = [0, 131, 255]
+        errs = {}
+        for mode, kw in (("multi-stage", {}), ("single-stage", {}), ("freq-domain", dict(frame_length=400, fft_length=L))):
+            out = dsp.MLSA(M, P, alpha=alpha, mode=mode, device=DEV, **kw)(exc, mc)
+            assert torch.isfinite(out).all()
+            refm = O.mlsa(host(exc[utt]).astype(np.float64), host(mc[utt]).astype(np.float64), P, alpha=alpha, mode=mode, **kw)
+            errs[mode] = np.abs(host(out[utt]).astype(np.float64) - refm).max() / np.abs(refm).max()
+    print(f"bench-size f rows, float32 vs float64 oracle: mgcep {err_mgcep:.2e} mgc2sp {err_sp:.2e} mc2b {err_b:.2e} MLSA {errs}")
+    # measured: mgcep 1.6e-7, mgc2sp 1.2e-6 (relative, per bin), mc2b 1.3e-7, MLSA 4.0e-7 / 3.6e-7 / 2.8e-7 of the largest sample
+    assert err_mgcep < 5e-7
+    assert err_sp < 4e-6
+    assert err_b < 4e-7
+    assert all(e < 1.5e-6 for e in errs.values()), errs
