@@ -351,7 +351,9 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
         "frames/s": fr / t_l, "ms_fused_fwd": t_l * 1e3, "ms_module_chain_fwd": t_chain * 1e3, "ms_module_chain_fwd_bwd": t_lfb * 1e3,
         "roofline": {"kernel": k_lpc, "bound": "valu_issue (float64)", "achieved": LPC_FLOP_PER_FRAME * fr / t_l / 1e12,
                      "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s (fp64 vector)", "frac": LPC_FLOP_PER_FRAME * fr / t_l / 1e12 / FP64_PEAK_TFLOPS,
-                     "traffic": None, "avg_launch_ms": t_l * 1e3, "flop_per_frame": LPC_FLOP_PER_FRAME,
+                     "traffic": pmc_traffic("frame_window_lpc24_fwd", fr), "avg_launch_ms": t_l * 1e3, "flop_per_frame": LPC_FLOP_PER_FRAME,
+                     "pmc": (pmc_static("frame_window_lpc24_fwd") or {}).get("derived"),
+                     "pmc_source": (pmc_static("frame_window_lpc24_fwd") or {}).get("_source"),
                      "hbm": {"achieved": LPC_BYTES_PER_FRAME * fr / t_l / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": LPC_BYTES_PER_FRAME * fr / t_l / 1e9 / HBM_PEAK_GBS},
                      "note": "420 B/frame: far from the HBM roof; the lag sums and the recursion run in float64 on the vector "

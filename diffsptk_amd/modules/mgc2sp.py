@@ -6,7 +6,8 @@ import math
 import torch
 
 from .. import ops
-from ..utils.private import check_size, filter_values
+from ..utils import tables
+from ..utils.private import check_size, filter_values, to
 from .base import BaseFunctionalModule, Precomputed
 from .mgc2mgc import MelGeneralizedCepstrumToMelGeneralizedCepstrum as _Mgc2mgc
 from .spec import device_twiddle
@@ -52,10 +53,24 @@ class MelGeneralizedCepstrumToSpectrum(BaseFunctionalModule):
         pre = _Mgc2mgc._precompute(cep_order, fft_length // 2, in_alpha=alpha, out_alpha=0, in_gamma=gamma, out_gamma=0,
                                    in_norm=norm, out_norm=False, in_mul=mul, out_mul=False, n_fft=n_fft, device=device,
                                    dtype=dtype)
-        return Precomputed(values={"fmt": fmt, "fft_length": fft_length, "cfg": pre.values["cfg"]}, tensors=pre.tensors)
+        tens = dict(pre.tensors)
+        if gamma == 0 and not norm and not mul and cep_order <= fft_length // 2:
+            # the conversion is linear here (frequency transform to order L/2, then the real transform): both folded into one
+            # (M+1, L/2+1) matrix per part, so the spectrum is ONE row product on the matrix cores + the formatter
+            W_re, W_im = tables.cepstrum_to_spectrum_matrices(cep_order, fft_length, pre.values["cfg"][2])   # the warp alpha -> 0
+            if fmt <= 3 or fmt == 7:
+                tens["W_re"] = to(W_re, device=device, dtype=dtype)
+            if fmt >= 4:
+                tens["W_im"] = to(W_im, device=device, dtype=dtype)
+        return Precomputed(values={"fmt": fmt, "fft_length": fft_length, "cfg": pre.values["cfg"]}, tensors=tens)
 
     @staticmethod
-    def _forward(mc: torch.Tensor, *, fmt: int, fft_length: int, cfg, A: torch.Tensor | None = None) -> torch.Tensor:
+    def _forward(mc: torch.Tensor, *, fmt: int, fft_length: int, cfg, A: torch.Tensor | None = None,
+                 W_re: torch.Tensor | None = None, W_im: torch.Tensor | None = None) -> torch.Tensor:
+        if W_re is not None or W_im is not None:
+            re = ops.MatmulRowsFn.apply(mc, W_re) if W_re is not None else None
+            im = ops.MatmulRowsFn.apply(mc, W_im) if W_im is not None else None
+            return MelGeneralizedCepstrumToSpectrum._format(fmt, re, im)
         c = _Mgc2mgc._forward(mc, cfg=cfg, A=A)
         n = (c.size(-1) - 1) * 2
         if fmt <= 3:   # formats of the log-magnitude: the real part alone
@@ -70,3 +85,22 @@ class MelGeneralizedCepstrumToSpectrum(BaseFunctionalModule):
             return im / math.pi if fmt == 4 else (im if fmt == 5 else im * (180 / math.pi))
         sp = ops.FftrFn.apply(c, n, 0, device_twiddle(n, c.device, c.dtype))
         return torch.polar(torch.exp(sp.real), sp.imag)
+
+    @staticmethod
+    def _format(fmt: int, re: torch.Tensor | None, im: torch.Tensor | None) -> torch.Tensor:
+        """mgc2sp.py:193-202 on the log-magnitude `re` / the phase `im`."""
+        if fmt == 0:
+            return re * (20 / math.log(10))
+        if fmt == 1:
+            return re
+        if fmt == 2:
+            return torch.exp(re)
+        if fmt == 3:
+            return torch.exp(2 * re)
+        if fmt == 4:
+            return im / math.pi
+        if fmt == 5:
+            return im
+        if fmt == 6:
+            return im * (180 / math.pi)
+        return torch.polar(torch.exp(re), im)

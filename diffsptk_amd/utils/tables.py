@@ -117,6 +117,21 @@ def freqt_matrix(in_order: int, out_order: int, alpha: float) -> np.ndarray:
     return np.ascontiguousarray(A.T)
 
 
+def cepstrum_to_spectrum_matrices(in_order: int, fft_length: int, alpha: float) -> tuple[np.ndarray, np.ndarray]:
+    """(W_re, W_im), each (in_order+1, fft_length/2+1): the frequency transform of a (mel-)cepstrum to order fft_length/2
+    (freqt.py:115-139; the identity with zero padding at alpha = 0) followed by the real transform of that cepstrum
+    (mgc2sp.py:193-202: `fftr` of the length-(fft_length/2+1) sequence at fft_length points) as ONE matrix each for the
+    real and the imaginary part:  Re = c @ W_re,  Im = c @ W_im.  Valid where mgc2mgc is linear (gamma = 0, no gain
+    normalisation, no gamma multiplication)."""
+    H = fft_length // 2
+    if alpha != 0:
+        A = freqt_matrix(in_order, H, alpha)                       # (in_order+1, H+1)
+    else:
+        A = np.eye(in_order + 1, H + 1, dtype=np.float64)
+    ang = 2.0 * np.pi * np.outer(np.arange(H + 1, dtype=np.float64), np.arange(H + 1, dtype=np.float64)) / fft_length
+    return np.ascontiguousarray(A @ np.cos(ang)), np.ascontiguousarray(-(A @ np.sin(ang)))
+
+
 def coef_freqt_matrix(in_order: int, out_order: int, alpha: float) -> np.ndarray:
     """CoefficientsFrequencyTransform._precompute (mcep.py:264-284), (in_order+1, out_order+1)."""
     L1, L2 = in_order + 1, out_order + 1
