@@ -57,9 +57,11 @@ inline bool ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64
 // (use_power: 0 sqrt x | 1 x | 2 log x;  post_mode 0: floor + glog, 1: scale with the first column halved,
 //  3: first and last column halved;  needs float32, C <= 48, C < K <= 320)
 // 24 x 24 Toeplitz-plus-Hankel systems, float32, 16 per wave in the quad layout (csrc/mcep_mfma.hip)
-int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, void* g, hipStream_t st);
+int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, void* g, hipStream_t st, int r_stride = 24,
+                       int r_off = 0, const void* add = nullptr);
 // re-solves, with row pivoting, the float32 systems whose solution rows start with NaN (csrc/mgc.hip)
-int thsolve_fix_marked(const void* p, const void* q, const void* r, int64_t F, int n, void* g, hipStream_t st);
+int thsolve_fix_marked(const void* p, const void* q, const void* r, int64_t F, int n, void* g, hipStream_t st, int r_stride = 0,
+                       int r_off = 0, const void* add = nullptr);
 int fbank_mfma_launch_ex(const void* x, int64_t F, int K, const void* H, int C, int ldh, double floor, double gamma,
                          int use_power, int post_mode, double post_scale, void* y, void* E, hipStream_t st, const char* name,
                          const void* W2 = nullptr, int Mo = 0, void* z = nullptr,   // optional second product z = y W2

@@ -429,8 +429,11 @@ __device__ __forceinline__ void blk_backsub_all(const f32x4 (&a)[blk::NBLK], flo
 // (th_solve_reg, csrc/mgc.hip) took 0.2 ms per 51 200 systems; this takes 0.02 ms.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTq = 136;   // floats per system in LDS: q window [0, 52) | mirrored p window [52, 104) | r [104, 132) (136 % 32 = 8)
+// `r` rows are r_stride floats apart and start r_off floats in (the Newton step of mgcep hands over its (F, 25) vector with
+// the right-hand side in columns 1 .. 24); `add` (or NULL): g = add + solution (the step's update b <- b + solve(..)).
 __global__ __launch_bounds__(256) void thsolve_quad24_kernel(const float* __restrict__ p, const float* __restrict__ q,
-                                                             const float* __restrict__ r, long F, float* __restrict__ g)
+                                                             const float* __restrict__ r, long F, float* __restrict__ g,
+                                                             int r_stride, int r_off, const float* __restrict__ add)
 {
     using namespace mm;
     __shared__ __attribute__((aligned(16))) float lds[4 * 16 * kTq + 64];
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(256) void thsolve_quad24_kernel(const float* __rest
             const int idx = lane + 64 * it;
             const bool ok = idx < nvalid * 24;
             vp[it] = ok ? p[fbase * 24 + (ok ? idx : 0)] : ((idx % 24) == 0 ? 1.f : 0.f);   // missing system: p = e_0
-            vr[it] = ok ? r[fbase * 24 + (ok ? idx : 0)] : 0.f;
+            vr[it] = ok ? r[(fbase + (ok ? idx / 24 : 0)) * r_stride + r_off + (ok ? idx % 24 : 0)] : 0.f;
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -506,19 +509,20 @@ __global__ __launch_bounds__(256) void thsolve_quad24_kernel(const float* __rest
         const long f = tile * 16 + nq;
         if (f < F) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) g[f * 24 + gs + 4 * c] = xq[c];
+            for (int c = 0; c < 6; ++c) g[f * 24 + gs + 4 * c] = add ? add[f * 24 + gs + 4 * c] + xq[c] : xq[c];
         }
     }
 }
 
-int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, void* g, hipStream_t st)
+int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, void* g, hipStream_t st, int r_stride, int r_off,
+                       const void* add)
 {
     long blocks = ((F + 15) / 16 + 3) / 4;
     if (blocks > 256L * 4) blocks = 256L * 4;
     hipLaunchKernelGGL(thsolve_quad24_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)p, (const float*)q,
-                       (const float*)r, (long)F, (float*)g);
+                       (const float*)r, (long)F, (float*)g, r_stride, r_off, (const float*)add);
     if (int rc = check_launch("th_solve_quad_fwd")) return rc;
-    return thsolve_fix_marked(p, q, r, F, 24, g, st);   // rows the unpivoted elimination gave up on (none, normally)
+    return thsolve_fix_marked(p, q, r, F, 24, g, st, r_stride, r_off, add);   // rows the unpivoted elimination gave up on (none, normally)
 }
 
 }  // namespace dsa

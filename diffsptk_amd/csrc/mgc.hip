@@ -219,7 +219,8 @@ __global__ __launch_bounds__(64) void th_solve_bwd_kernel(const T* __restrict__ 
 // Second launch of the unpivoted order-24 path (thsolve_quad24_fwd, csrc/mcep_mfma.hip): a wave looks at 64 solution rows at a
 // time (one coalesced-stride load per lane), and re-solves with row pivoting those the first launch marked with NaN.
 __global__ __launch_bounds__(64) void th_solve_fix_kernel(const float* __restrict__ p, const float* __restrict__ q, const float* __restrict__ r,
-                                                         long F, int n, float* __restrict__ g)
+                                                         long F, int n, float* __restrict__ g, int r_stride, int r_off,
+                                                         const float* __restrict__ add)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* ps = reinterpret_cast<float*>(smem_raw);
@@ -236,23 +237,25 @@ __global__ __launch_bounds__(64) void th_solve_fix_kernel(const float* __restric
             __builtin_amdgcn_wave_barrier();
             if (lane < n) ps[lane] = p[f * n + lane];
             for (int i = lane; i < 2 * n - 1; i += 64) qs[i] = q[f * (2 * n - 1) + i];
-            const float rhs = lane < n ? r[f * n + lane] : 0.f;
+            const float rhs = lane < n ? r[f * r_stride + r_off + lane] : 0.f;
             __builtin_amdgcn_wave_barrier();
             int col;
             float sol;
             th_solve_reg<float, 24>(ps, qs, rhs, n, lane, col, sol);
-            if (lane < n) g[f * n + col] = sol;
+            if (lane < n) g[f * n + col] = add ? add[f * n + col] + sol : sol;
         }
     }
 }
 
-int thsolve_fix_marked(const void* p, const void* q, const void* r, int64_t F, int n, void* g, hipStream_t st)
+int thsolve_fix_marked(const void* p, const void* q, const void* r, int64_t F, int n, void* g, hipStream_t st, int r_stride, int r_off,
+                       const void* add)
 {
     if (n > 24) return DSA_OK;
+    if (r_stride == 0) r_stride = n;
     long blocks = (F + 63) / 64;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(th_solve_fix_kernel, dim3((unsigned)blocks), dim3(64), sizeof(float) * (3 * n), st, (const float*)p, (const float*)q,
-                       (const float*)r, (long)F, n, (float*)g);
+                       (const float*)r, (long)F, n, (float*)g, r_stride, r_off, (const float*)add);
     return check_launch("th_solve_quad_fwd");
 }
 
@@ -1097,6 +1100,18 @@ DSA_EXPORT int dsa_thsolve_fwd(const void* p, const void* q, const void* r, int6
     if (dtype == DSA_F32) return th_launch<float>(false, nullptr, p, q, r, F, n, g, nullptr, nullptr, (hipStream_t)stream);
     if (dtype == DSA_F64) return th_launch<double>(false, nullptr, p, q, r, F, n, g, nullptr, nullptr, (hipStream_t)stream);
     return fail(DSA_ERR_UNSUPPORTED, "thsolve: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_thsolve_update_fwd(const void* p, const void* q, const void* r, int64_t r_stride, int64_t r_offset, int64_t F,
+                                      int32_t n, int32_t dtype, const void* b_in, void* b_out, void* stream)
+{
+    DSA_REQUIRE(n >= 1 && n <= kThMax && F >= 0, "thsolve_update: order must be in [1, 64]");
+    DSA_REQUIRE(r_offset >= 0 && r_stride >= r_offset + n, "thsolve_update: the right-hand side does not fit its row stride");
+    DSA_REQUIRE(b_in != nullptr && b_out != nullptr && b_in != b_out, "thsolve_update: b_in and b_out must be distinct buffers");
+    if (F == 0) return DSA_OK;
+    if (dtype == DSA_F32 && n == 24)
+        return thsolve_quad24_fwd(p, q, r, F, b_out, (hipStream_t)stream, (int)r_stride, (int)r_offset, b_in);
+    return fail(DSA_ERR_UNSUPPORTED, "thsolve_update: order 24 in float32 only (dsa_thsolve_fwd + an addition otherwise)%s");
 }
 
 DSA_EXPORT int dsa_thsolve_bwd(const void* gg, const void* p, const void* q, const void* g, int64_t F, int32_t n,

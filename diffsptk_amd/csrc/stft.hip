@@ -1246,7 +1246,11 @@ static int gc2gc_launch(const void* c1, int64_t F, int n_in, int out_order, doub
     static std::atomic<uint64_t> lds_set{0};
     if (lds > 48 * 1024 && !ensure_dynamic_lds(reinterpret_cast<const void*>(&gc2gc_fused_kernel<T>), 150 * 1024, lds_set))
         return fail(DSA_ERR_LAUNCH, "gc2gc: cannot raise the dynamic LDS limit%s");
-    hipLaunchKernelGGL((gc2gc_fused_kernel<T>), dim3((unsigned)F), dim3(256), lds, st, (const T*)c1, n_in, out_order, (T)g1, (T)g2, nfft,
+    // short transforms: one wave per row (two butterflies per lane and pass, the passes' barriers are single-wave barriers);
+    // DSA_GC2GC_BLOCK overrides for A/B runs
+    static const int forced = [] { const char* e = getenv("DSA_GC2GC_BLOCK"); return e ? atoi(e) : 0; }();
+    const int block = forced > 0 ? forced : (nfft <= 1024 ? 64 : 256);
+    hipLaunchKernelGGL((gc2gc_fused_kernel<T>), dim3((unsigned)F), dim3(block), lds, st, (const T*)c1, n_in, out_order, (T)g1, (T)g2, nfft,
                        (const T*)tw, flags, (T*)c2);
     return check_launch("gc2gc_fused");
 }

@@ -112,7 +112,10 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
                 eps = epsilon(gamma, r, b1) if need_gain else None
             if qt is None:
                 qt = torch.zeros(*pt.shape[:-1], 2 * M - 1, device=pt.device, dtype=pt.dtype)
-            b1 = b1 + ops.ThSolveFn.apply(pt, qt, r[..., 1:])      # mgcep.py:226-230
+            upd = None
+            if not (torch.is_grad_enabled() and (pt.requires_grad or qt.requires_grad or r.requires_grad or b1.requires_grad)):
+                upd = ops.thsolve_update(pt, qt, r, b1)            # solve + update in one call, r read in place
+            b1 = upd if upd is not None else b1 + ops.ThSolveFn.apply(pt, qt, r[..., 1:])      # mgcep.py:226-230
             if gamma == -1:
                 eps = epsilon(gamma, r, b1)
             return (torch.sqrt(eps).unsqueeze(-1) if eps is not None else None), b1

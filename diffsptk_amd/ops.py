@@ -837,6 +837,22 @@ def mgcep_step(x, b1, images, gamma):
     return pt, qt, r
 
 
+def thsolve_update(pt, qt, r, b1):
+    """b1 + solve(symmetric_toeplitz(pt) + hankel(qt), r[..., 1:])  (mgcep.py:226-230) in one call, the right-hand side read
+    in place from the step's (.., M + 1) vector (dsa_thsolve_update_fwd: order 24, float32); forward only.  None: not covered."""
+    M = pt.size(-1)
+    if M != 24 or pt.dtype != torch.float32 or r.size(-1) != M + 1 or not (pt.is_contiguous() and qt.is_contiguous() and r.is_contiguous()):
+        return None
+    _require_device(pt, qt, r, b1)
+    _same_dtype(pt, qt, r, b1)
+    bc = b1.contiguous()
+    F = pt.numel() // M
+    out = torch.empty_like(bc)
+    with torch.cuda.device(pt.device):
+        _call("dsa_thsolve_update_fwd", _p(pt), _p(qt), _p(r), M + 1, 1, F, M, _dtype_code(pt), _p(bc), _p(out), _stream())
+    return out
+
+
 def mgcep_spectra(x, b1, Cr, Ci, gamma):
     """(5, ..., K): pp, qq (X^2 - Y^2), qq 2XY, pp X, pp Y of one Newton step of mgcep.py:199-209 in one launch
     (dsa_mgcep_spectra); forward only."""

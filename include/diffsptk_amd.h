@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 114 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch), dsa_mgcep_step */
+#define DSA_VERSION 115 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch), dsa_mgcep_step */
 
 typedef enum {
     DSA_OK = 0,
@@ -268,6 +268,11 @@ int dsa_mgcep_spectra(const void* x, const void* b1, int64_t F, int32_t fft_leng
                       const void* Ci, double gamma, int32_t dtype, void* out, void* stream);
 int dsa_thsolve_bwd(const void* gg, const void* p, const void* q, const void* g, int64_t F, int32_t n, int32_t dtype,
                     void* gp, void* gq, void* gr, void* stream);
+/* The Newton update of mgcep.py:226-230 in one call: b_out = b_in + solve(symmetric_toeplitz(p) + hankel(q), r) with the
+ * right-hand side read in place from a wider vector: row f of r starts at r + f * r_stride + r_offset (the step's (F, n + 1)
+ * vector with r_offset = 1).  Order 24 in float32 (DSA_ERR_UNSUPPORTED otherwise); b_in and b_out must not alias. */
+int dsa_thsolve_update_fwd(const void* p, const void* q, const void* r, int64_t r_stride, int64_t r_offset, int64_t F,
+                           int32_t n, int32_t dtype, const void* b_in, void* b_out, void* stream);
 /* The same step's spectrum arithmetic AND its five row products in one launch (mgcep.py:199-220; float32, fft_length 512,
  * cep_order <= 24, gamma in [-1, 0)): x:(F,257), b1:(F,M) -> pt:(F,M) = pp Pr[:, :M], qt:(F,2M-1) = (1 + gamma)(.. Qr[:, 2:] + .. Qi[:, 2:]),
  * r:(F,M+1) = pp X Rr + pp Y Ri -- the operands of dsa_thsolve_fwd.  The five spectra never exist in memory (dsa_mgcep_spectra writes

@@ -423,6 +423,13 @@ def test_thsolve_order24_float32_falls_back_to_pivoting_on_indefinite_systems():
     assert ok[bad].sum() > 40 and err[ok].max() < 2e-2 and np.median(err[bad][ok[bad]]) < 1e-3, (err[ok].max(), np.median(err[bad]))
     good = np.setdiff1d(np.arange(F), bad)
     assert np.median(err[good]) < 2e-5
+    # the Newton update in one call (dsa_thsolve_update_fwd): right-hand side read in place from the step's (F, 25) vector, the
+    # solution added to b -- bit-identical to solve + addition, on the marked systems too
+    r25 = torch.cat((torch.full((F, 1), 7.0), torch.from_numpy(r).float()), -1).to(DEV).contiguous()
+    b_in = torch.randn(F, n, generator=torch.Generator().manual_seed(3)).to(DEV)
+    out = ops.thsolve_update(dev(p, torch.float32), dev(q, torch.float32), r25, b_in)
+    assert out is not None and torch.equal(out, b_in + torch.from_numpy(g).to(DEV))
+    assert ops.thsolve_update(dev(p[:, :8], torch.float32), dev(q[:, :15], torch.float32), r25[:, :9].contiguous(), b_in[:, :8].contiguous()) is None
 
 
 def test_f_rows_at_the_bench_size_against_the_oracle():

@@ -11,7 +11,7 @@
 namespace dsa {
 thread_local char g_last_error[256];
 thread_local const char* g_last_kernel = "";
-int thsolve_fix_marked(const void*, const void*, const void*, int64_t, int, void*, hipStream_t) { return 0; }   // csrc/mgc.hip in the library
+int thsolve_fix_marked(const void*, const void*, const void*, int64_t, int, void*, hipStream_t, int, int, const void*) { return 0; }   // csrc/mgc.hip in the library
 }
 
 int main(int argc, char** argv)
