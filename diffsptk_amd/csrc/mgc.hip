@@ -280,6 +280,8 @@ static int th_launch(bool bwd, const void* gg, const void* p, const void* q, con
     } while (0)
     if (!lds_only && n <= 24) DSA_TH_LAUNCH(24);
     else if (!lds_only && n <= 32) DSA_TH_LAUNCH(32);
+    else if (!lds_only && n <= 48) DSA_TH_LAUNCH(48);   // the orders of the 48 kHz set-ups (34 .. 60): rows in registers too
+    else if (!lds_only && n <= 64) DSA_TH_LAUNCH(64);
     else DSA_TH_LAUNCH(0);
 #undef DSA_TH_LAUNCH
     return check_launch(bwd ? "th_solve_bwd" : "th_solve_fwd");

@@ -8,6 +8,7 @@ hand-written backward kernels).
 from __future__ import annotations
 
 import math
+import os
 import weakref
 
 import torch
@@ -752,6 +753,29 @@ class MfccFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------- mcep
+def _mcep_composed_applies(Xc, M, F) -> bool:
+    """Geometries without a tuned kernel (48 kHz set-ups: fft_length 1024 / 2048, orders 34 .. 60), forward without a graph."""
+    return M + 1 <= 64 and M >= 1 and F >= 256 and os.environ.get("DSA_MCEP_COMPOSED", "1") != "0"
+
+
+def _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter):
+    """mcep.py:203-222 for the geometries the tuned kernel does not cover, as whole-batch launches instead of the one-workgroup-
+    per-frame generic kernel: the two row products of a Newton step are plain GEMMs ((F, M+1) x (M+1, K) and (F, K) x (K, 2M+1):
+    the vendor GEMM through torch.matmul), the Toeplitz-plus-Hankel solve is the library's batched kernel (dsa_thsolve_fwd) on
+    slices of rt.  Same arithmetic order per frame as the reference's formulation; float32 products accumulate in float32."""
+    M1 = M + 1
+    lead = Xc.shape[:-1]
+    logx = torch.log(Xc.reshape(-1, Xc.size(-1)))                       # mcep.py:203
+    mc = logx @ G                                                         # :204-207
+    for _ in range(n_iter):
+        e = torch.exp(torch.sub(logx, mc @ D, alpha=2))                   # :210-212
+        rt = e @ E                                                        # :214-215
+        p = rt[:, :M1].contiguous()
+        q = rt[:, : 2 * M1 - 1].contiguous()
+        mc = mc + ThSolveFn.apply(p, q, p - av)                           # :216-222
+    return mc.reshape(*lead, M1)
+
+
 class McepFn(torch.autograd.Function):
     """MelCepstralAnalysis._forward (mcep.py:189-224) with composed linear stages."""
 
@@ -766,6 +790,8 @@ class McepFn(torch.autograd.Function):
         need_hist = ctx.needs_input_grad[0]
         hist = torch.empty(n_iter + 1, F, M + 1, device=X.device, dtype=X.dtype) if need_hist else None
         images = mcep_images(G, D, E, fft_length, M) if algo != _lib.ALGO_GENERIC else None
+        if images is None and not need_hist and algo != _lib.ALGO_GENERIC and _mcep_composed_applies(Xc, M, F):
+            return _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter)
         # the tile queue's counters: a per-(device, stream) scratch that the kernel leaves zeroed (no fill launch per call)
         scratch = None
         flag = 0

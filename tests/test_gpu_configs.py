@@ -348,3 +348,35 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["config"]["global_batch"] == 64
+
+
+@pytest.mark.parametrize("fl,fp,nfft,M,alpha", [(1200, 240, 2048, 49, 0.55), (1024, 256, 1024, 34, 0.55), (512, 128, 512, 30, 0.42)])
+def test_untuned_geometries_forward_as_whole_batch_launches(monkeypatch, fl, fp, nfft, M, alpha):
+    """The 48 kHz set-ups of the reference's get_alpha table (fft_length 1024 / 2048, orders 34 .. 60) and any other
+    (fft_length, order) without a tuned kernel: without a graph the analysis runs as whole-batch launches (two GEMMs + the
+    batched Toeplitz-plus-Hankel solve per Newton step) instead of the one-workgroup-per-frame kernel.  Both against the
+    float64 oracle on sampled frames, and against each other; with a graph the generic kernel pair runs and its gradient is
+    checked by the existing tests."""
+    x = torch.randn(8, 16 * nfft, generator=torch.Generator().manual_seed(4)).to(DEV)
+    stft = dsp.STFT(fl, fp, nfft, device=DEV)
+    mcep = dsp.MelCepstralAnalysis(fft_length=nfft, cep_order=M, alpha=alpha, n_iter=10, device=DEV)
+    with torch.no_grad():
+        X = stft(x)
+        assert X.shape[0] * X.shape[1] >= 256
+        mc = mcep(X)
+        assert _lib.last_kernel() in ("th_solve_fwd", "th_solve_quad_fwd"), _lib.last_kernel()
+        monkeypatch.setenv("DSA_MCEP_COMPOSED", "0")
+        mc_g = mcep(X)
+        assert _lib.last_kernel() == "mcep_generic_fwd"
+        monkeypatch.delenv("DSA_MCEP_COMPOSED")
+    idx = torch.tensor([0, 1, 17, X.shape[1] - 1, X.shape[1], 3 * X.shape[1] + 5, X.shape[0] * X.shape[1] - 1])
+    ref = O.mcep(host(X.reshape(-1, nfft // 2 + 1)[idx]).astype(np.float64), M, alpha=alpha, n_iter=10)
+    got = host(mc.reshape(-1, M + 1)[idx]).astype(np.float64)
+    np.testing.assert_allclose(got, ref, **MC32)
+    np.testing.assert_allclose(host(mc), host(mc_g), rtol=1e-4, atol=1e-5)
+    # a graph is wanted: the generic kernel pair (history-based backward)
+    Xg = X[:1, :8].clone().requires_grad_(True)
+    y = mcep(Xg)
+    assert _lib.last_kernel() == "mcep_generic_fwd"
+    y.sum().backward()
+    assert bool(torch.isfinite(Xg.grad).all()) and float(Xg.grad.abs().max()) > 0
