@@ -259,6 +259,32 @@ int thsolve_fix_marked(const void* p, const void* q, const void* r, int64_t F, i
     return check_launch("th_solve_quad_fwd");
 }
 
+// Cotangents of the Toeplitz column p and the Hankel sequence q from u = A^{-1} gbar and the forward's solution g:
+// Abar = -u g^T summed along the diagonals |i - j| = k and the anti-diagonals i + j = k.  64 threads per system.
+__global__ __launch_bounds__(256) void th_bwd_sums_kernel(const float* __restrict__ u, const float* __restrict__ g, long F, int n,
+                                                         float* __restrict__ gp, float* __restrict__ gq)
+{
+    __shared__ float us[4][64], gs[4][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long f = (long)blockIdx.x * 4 + w;
+    const bool ok = f < F;
+    us[w][lane] = ok && lane < n ? u[f * n + lane] : 0.f;
+    gs[w][lane] = ok && lane < n ? g[f * n + lane] : 0.f;
+    __syncthreads();
+    if (!ok) return;
+    for (int k = lane; k < 2 * n - 1; k += 64) {
+        float sq = 0.f;
+        const int lo = k - (n - 1) > 0 ? k - (n - 1) : 0, hi = k < n - 1 ? k : n - 1;
+        for (int i = lo; i <= hi; ++i) sq -= us[w][i] * gs[w][k - i];
+        gq[f * (2 * n - 1) + k] = sq;
+        if (k < n) {
+            float sp = 0.f;
+            for (int i = 0; i + k < n; ++i) sp -= us[w][i] * gs[w][i + k] + (k > 0 ? us[w][i + k] * gs[w][i] : 0.f);
+            gp[f * n + k] = sp;
+        }
+    }
+}
+
 template <typename T>
 static int th_launch(bool bwd, const void* gg, const void* p, const void* q, const void* r_or_g, int64_t F, int n, void* o1,
                      void* o2, void* o3, hipStream_t st)
@@ -1028,6 +1054,144 @@ __global__ __launch_bounds__(256) void mgcep_step_kernel(const float* __restrict
         }
 }
 
+// Backward of one Newton step's (pt, qt, r) = mgcep_step(x, b1) (above) in ONE launch, same tiling: a wave = 16 frames, a pass =
+// 16 bins.  Per pass: re / im recomputed (first chain as above), the cotangents of the five spectra at these bins as row products
+// of (gpt | (1 + gamma) gqt | gr) with the TRANSPOSED second-chain matrices (44 k-steps: the cotangent vectors are the B
+// operands, held in registers for the whole launch), the element-wise chain rule, gx written, and the cotangent of (re, im)
+// accumulated into gb1 = gamma (gX Cr^T + gY Ci^T) (16 k-steps).  72 products per pass (forward: 60).
+// Image per tile (tables.mgcep_step_bwd_images): [0, 768) the forward's first-chain operands | [768, 3584) the 44 k-steps
+// A[i = bin 16 mt + (lane & 15)][k = column 4 ks + (lane >> 4)] of Pr (6) | Qr (12) | Qi (12) | Rr (7) | Ri (7) |
+// [3584, 4608) A[i = coefficient 1 + 16 t + (lane & 15)][k = bin 16 mt + 4 (lane >> 4) + r] of Cr (t, r) | Ci (t, r).
+constexpr int kMbTileFloats = 768 + 44 * 64 + 16 * 64;
+__global__ __launch_bounds__(256) void mgcep_step_bwd_kernel(const float* __restrict__ x, const float* __restrict__ b1,
+                                                            const float* __restrict__ gpt, const float* __restrict__ gqt,
+                                                            const float* __restrict__ grr, long F, int M, float gamma,
+                                                            const float* __restrict__ img, const float* __restrict__ gx_in,
+                                                            float* __restrict__ gx, float* __restrict__ gb1)
+{
+    __shared__ __attribute__((aligned(16))) float tile[2][kMbTileFloats];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const long f_raw = ((long)blockIdx.x * 4 + wave) * 16 + n;
+    const bool f_ok = f_raw < F;
+    const long f = f_ok ? f_raw : F - 1;
+    const float og = 1.f + gamma;
+    // B operands held for the whole launch: coefficient / column 4 ks + g of this lane's frame
+    float bv[6], vp[6], vq[12], vr[7];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        bv[ks] = 4 * ks + g < M ? b1[f * M + 4 * ks + g] : 0.f;
+        vp[ks] = 4 * ks + g < M ? gpt[f * M + 4 * ks + g] : 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks) vq[ks] = 4 * ks + g < 2 * M - 1 ? og * gqt[f * (2 * M - 1) + 4 * ks + g] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) vr[ks] = 4 * ks + g < M + 1 ? grr[f * (M + 1) + 4 * ks + g] : 0.f;
+    const float ex = -1.f / gamma - 1.f;
+    ms_f4 accb[2] = {ms_f4{0.f, 0.f, 0.f, 0.f}, ms_f4{0.f, 0.f, 0.f, 0.f}};
+    const ms_f4* img4 = reinterpret_cast<const ms_f4*>(img);
+    constexpr int kQ = (kMbTileFloats / 4 + 255) / 256;   // float4 per thread and tile
+    ms_f4 st[kQ];
+    auto fetch = [&](int mt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) {
+            const int i = tid + 256 * q;
+            st[q] = i < kMbTileFloats / 4 ? img4[(long)mt * (kMbTileFloats / 4) + i] : ms_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        ms_f4* d = reinterpret_cast<ms_f4*>(tile[buf]);
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) {
+            const int i = tid + 256 * q;
+            if (i < kMbTileFloats / 4) d[i] = st[q];
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    for (int mt = 0; mt < kMsTiles; ++mt) {
+        const int buf = mt & 1;
+        if (mt + 1 < kMsTiles) fetch(mt + 1);
+        ms_f4 xv = {0.f, 0.f, 0.f, 0.f};
+        if (mt < 16) xv = *reinterpret_cast<const ms_f4*>(x + f * 257 + 16 * mt + 4 * g);
+        else if (g == 0) xv[0] = x[f * 257 + 256];
+        const float* t1 = tile[buf];
+        const float* t2 = tile[buf] + 768;
+        const float* t3 = tile[buf] + 768 + 44 * 64;
+        ms_f4 re = {0.f, 0.f, 0.f, 0.f}, im = re;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            re = __builtin_amdgcn_mfma_f32_16x16x4f32(t1[ks * 64 + lane], bv[ks], re, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f32_16x16x4f32(t1[384 + ks * 64 + lane], bv[ks], im, 0, 0, 0);
+        }
+        // cotangents of the five spectra at bins 16 mt + 4 g + r
+        ms_f4 gs[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) gs[i] = ms_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) gs[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(t2[ks * 64 + lane], vp[ks], gs[0], 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) {
+            gs[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(t2[(6 + ks) * 64 + lane], vq[ks], gs[1], 0, 0, 0);
+            gs[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(t2[(18 + ks) * 64 + lane], vq[ks], gs[2], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+            gs[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(t2[(30 + ks) * 64 + lane], vr[ks], gs[3], 0, 0, 0);
+            gs[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(t2[(37 + ks) * 64 + lane], vr[ks], gs[4], 0, 0, 0);
+        }
+        float gre[4], gim[4], gxv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float X = 1.f + gamma * re[r], Y = gamma * im[r];
+            const float XX = X * X, YY = Y * Y, D = XX + YY;
+            const float dp = __builtin_amdgcn_exp2f(ex * __builtin_amdgcn_logf(D));
+            const float pp = xv[r] * dp;
+            const float rD = 1.f / D;
+            const float qq = pp * rD;
+            const float g_qq = gs[1][r] * (XX - YY) + gs[2][r] * (2.f * X * Y);
+            const float g_pp = gs[0][r] + gs[3][r] * X + gs[4][r] * Y + g_qq * rD;
+            const float g_D = (g_pp * ex * pp - g_qq * qq) * rD;
+            const float gX = 2.f * qq * (gs[1][r] * X + gs[2][r] * Y) + gs[3][r] * pp + 2.f * X * g_D;
+            const float gY = 2.f * qq * (gs[2][r] * X - gs[1][r] * Y) + gs[4][r] * pp + 2.f * Y * g_D;
+            gre[r] = gamma * gX;
+            gim[r] = gamma * gY;
+            gxv[r] = g_pp * dp;
+        }
+        if (f_ok) {
+            if (mt < 16) {
+                float* dst = gx + f * 257 + 16 * mt + 4 * g;
+                ms_f4 o = {gxv[0], gxv[1], gxv[2], gxv[3]};
+                if (gx_in) o += *reinterpret_cast<const ms_f4*>(gx_in + f * 257 + 16 * mt + 4 * g);
+                *reinterpret_cast<ms_f4*>(dst) = o;
+            } else if (g == 0) {
+                gx[f * 257 + 256] = gxv[0] + (gx_in ? gx_in[f * 257 + 256] : 0.f);
+            }
+        }
+        // gb1[16 t + 4 g + r'] += sum over the tile's bins: k-step r, k-slot g <-> bin 16 mt + 4 g + r
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                accb[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(t3[(t * 4 + r) * 64 + lane], gre[r], accb[t], 0, 0, 0);
+                accb[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(t3[(8 + t * 4 + r) * 64 + lane], gim[r], accb[t], 0, 0, 0);
+            }
+        if (mt + 1 < kMsTiles) {
+            stage(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    if (!f_ok) return;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = 16 * t + 4 * g + r;
+            if (col < M) gb1[f * M + col] = accb[t][r];
+        }
+}
+
 template <typename T>
 static int mgcep_spectra_launch(const void* x, const void* b1, int64_t F, int K, int M, const void* Cr, const void* Ci, double gamma,
                                 void* out, hipStream_t st)
@@ -1121,6 +1285,18 @@ DSA_EXPORT int dsa_thsolve_bwd(const void* gg, const void* p, const void* q, con
 {
     DSA_REQUIRE(n >= 1 && n <= kThMax && F >= 0, "thsolve_bwd: order must be in [1, 64]");
     if (F == 0) return DSA_OK;
+    // order 24, float32: u = A^{-1} gbar on the quad-layout solve (A is symmetric; marked systems re-solved with pivoting as in
+    // the forward), then the diagonal sums (DSA_THSOLVE_QUAD=0: the one-wave-per-system kernel, A/B)
+    static const bool quad = [] {
+        const char* e = getenv("DSA_THSOLVE_QUAD");
+        return !e || atoi(e) != 0;
+    }();
+    if (dtype == DSA_F32 && n == 24 && quad && gp && gq && gr) {
+        if (int rc = thsolve_quad24_fwd(p, q, gg, F, gr, (hipStream_t)stream)) return rc;
+        hipLaunchKernelGGL(th_bwd_sums_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)gr,
+                           (const float*)g, (long)F, (int)n, (float*)gp, (float*)gq);
+        return check_launch("th_solve_quad_bwd");
+    }
     if (dtype == DSA_F32) return th_launch<float>(true, gg, p, q, g, F, n, gp, gq, gr, (hipStream_t)stream);
     if (dtype == DSA_F64) return th_launch<double>(true, gg, p, q, g, F, n, gp, gq, gr, (hipStream_t)stream);
     return fail(DSA_ERR_UNSUPPORTED, "thsolve_bwd: unsupported dtype%s");
@@ -1136,6 +1312,21 @@ DSA_EXPORT int dsa_mgcep_step(const void* x, const void* b1, int64_t F, int32_t 
     hipLaunchKernelGGL(mgcep_step_kernel, dim3((unsigned)((F + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)b1,
                        (long)F, (int)M, (float)gamma, (const float*)images, (float*)pt, (float*)qt, (float*)r);
     return check_launch("mgcep_step");
+}
+
+DSA_EXPORT int dsa_mgcep_step_bwd(const void* x, const void* b1, const void* gpt, const void* gqt, const void* gr, int64_t F,
+                                  int32_t fft_length, int32_t M, double gamma, const void* images_bwd, int32_t dtype, const void* gx_in,
+                                  void* gx, void* gb1, void* stream)
+{
+    DSA_REQUIRE(F >= 0 && M >= 1, "mgcep_step_bwd: sizes must be positive");
+    DSA_REQUIRE(gamma != 0.0 && gamma >= -1.0 && gamma < 0.0, "mgcep_step_bwd: gamma must be in [-1, 0)");
+    if (dtype != DSA_F32 || fft_length != 512 || M > 24)
+        return fail(DSA_ERR_UNSUPPORTED, "mgcep_step_bwd: needs float32, fft_length 512, cep_order <= 24%s");
+    if (F == 0) return DSA_OK;
+    hipLaunchKernelGGL(mgcep_step_bwd_kernel, dim3((unsigned)((F + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (const float*)b1, (const float*)gpt, (const float*)gqt, (const float*)gr, (long)F, (int)M, (float)gamma,
+                       (const float*)images_bwd, (const float*)gx_in, (float*)gx, (float*)gb1);
+    return check_launch("mgcep_step_bwd");
 }
 
 DSA_EXPORT int dsa_mgcep_spectra(const void* x, const void* b1, int64_t F, int32_t fft_length, int32_t M, const void* Cr,

@@ -66,8 +66,11 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
         if fft_length == 512 and cep_order <= 24 and (dtype or torch.get_default_dtype()) == torch.float32:
             self.register_buffer("step_images", to(tables.mgcep_step_images(fft_length, cep_order, float(alpha)), device=device,
                                                    dtype=torch.float32), persistent=False)
+            self.register_buffer("step_images_bwd", to(tables.mgcep_step_bwd_images(fft_length, cep_order, float(alpha)),
+                                                       device=device, dtype=torch.float32), persistent=False)
         else:
             self.step_images = None
+            self.step_images_bwd = None
         self.b2mc = MLSADigitalFilterCoefficientsToMelCepstrum(M, alpha, device=device, dtype=dtype)
         self.mc2b = MelCepstrumToMLSADigitalFilterCoefficients(M, alpha, device=device, dtype=dtype)
         self.gc2gc = MelGeneralizedCepstrumToMelGeneralizedCepstrum(M, M, in_gamma=-1, out_gamma=gamma, device=device,
@@ -91,6 +94,10 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
             elif not (torch.is_grad_enabled() and (x.requires_grad or b1.requires_grad)) and self.step_images is not None \
                     and x.dtype == torch.float32 and self.step_images.device == x.device:
                 pt, qt, r = ops.mgcep_step(x, b1, self.step_images, gamma)   # mgcep.py:199-220 in one launch (forward only)
+                eps = epsilon(gamma, r, b1) if need_gain else None
+            elif self.step_images is not None and x.dtype == torch.float32 and self.step_images.device == x.device:
+                # a graph is wanted: the same launch forward, its adjoint as one launch backward (ops.MgcepStepFn)
+                pt, qt, r = ops.MgcepStepFn.apply(x, b1, self.step_images, self.step_images_bwd, gamma)
                 eps = epsilon(gamma, r, b1) if need_gain else None
             elif not (torch.is_grad_enabled() and (x.requires_grad or b1.requires_grad)) and M <= 64:
                 S = ops.mgcep_spectra(x, b1, self.Cr, self.Ci, gamma)   # mgcep.py:199-209, one pass (forward only)

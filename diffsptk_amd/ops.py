@@ -863,6 +863,38 @@ def mgcep_step(x, b1, images, gamma):
     return pt, qt, r
 
 
+class MgcepStepFn(torch.autograd.Function):
+    """(pt, qt, r) of one Newton step of mgcep.py:199-220 with a graph: forward dsa_mgcep_step, backward dsa_mgcep_step_bwd (one
+    launch each; float32 / fft_length 512 / cep_order <= 24).  x:(..., 257), b1:(..., M)."""
+
+    @staticmethod
+    def forward(ctx, x, b1, images, images_bwd, gamma):
+        pt, qt, r = mgcep_step(x, b1, images, gamma)
+        ctx.save_for_backward(x, b1, images_bwd)
+        ctx.gamma = float(gamma)
+        return pt, qt, r
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gpt, gqt, gr):
+        x, b1, images_bwd = ctx.saved_tensors
+        xc, bc = x.contiguous(), b1.contiguous()
+        K, M = xc.size(-1), bc.size(-1)
+        F = xc.numel() // K
+        lead = xc.shape[:-1]
+
+        def cot(g, n):
+            return torch.zeros(*lead, n, device=xc.device, dtype=xc.dtype) if g is None else g.contiguous()
+
+        gpt, gqt, gr = cot(gpt, M), cot(gqt, 2 * M - 1), cot(gr, M + 1)
+        gx = torch.empty_like(xc)
+        gb = torch.empty_like(bc)
+        with torch.cuda.device(xc.device):
+            _call("dsa_mgcep_step_bwd", _p(xc), _p(bc), _p(gpt), _p(gqt), _p(gr), F, 2 * (K - 1), M, ctx.gamma, _p(images_bwd),
+                  _dtype_code(xc), None, _p(gx), _p(gb), _stream())
+        return gx, gb, None, None, None
+
+
 def thsolve_update(pt, qt, r, b1):
     """b1 + solve(symmetric_toeplitz(pt) + hankel(qt), r[..., 1:])  (mgcep.py:226-230) in one call, the right-hand side read
     in place from the step's (.., M + 1) vector (dsa_thsolve_update_fwd: order 24, float32); forward only.  None: not covered."""

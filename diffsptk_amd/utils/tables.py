@@ -521,6 +521,44 @@ def mgcep_step_images(fft_length: int, cep_order: int, alpha: float) -> np.ndarr
     return out.astype(np.float32)
 
 
+def mgcep_step_bwd_images(fft_length: int, cep_order: int, alpha: float) -> np.ndarray:
+    """Operand images of dsa_mgcep_step_bwd (csrc/mgc.hip:mgcep_step_bwd_kernel): per 16-bin tile the forward's first-chain
+    operands, the second-chain matrices TRANSPOSED (bin rows x column k-steps: Pr[:, :M] 6 | Qr[:, 2:] 12 | Qi[:, 2:] 12 | Rr 7 |
+    Ri 7 k-steps) and (Cr, Ci) with coefficient rows x bin k-steps, in v_mfma_f32_16x16x4_f32 lane order, float32."""
+    if fft_length != 512 or not 1 <= cep_order <= 24:
+        raise ValueError("mgcep_step_bwd_images: fft_length 512 and cep_order <= 24 only")
+    M, K = cep_order, fft_length // 2 + 1
+    m = mgcep_matrices(fft_length, cep_order, float(alpha))
+    Cr, Ci = m["Cr"], m["Ci"]                                    # (M + 1, K)
+    mats = [(m["Pr"][:, :M], 6), (m["Qr"][:, 2:], 12), (m["Qi"][:, 2:], 12), (m["Rr"], 7), (m["Ri"], 7)]
+    fwd = mgcep_step_images(fft_length, cep_order, alpha).astype(np.float64)
+    lanes = np.arange(64)
+    li, lg = lanes & 15, lanes >> 4
+    out = np.zeros((17, 768 + 44 * 64 + 16 * 64), dtype=np.float64)
+    for mt in range(17):
+        out[mt, :768] = fwd[mt, :768]
+        a2 = np.zeros((44, 64))
+        c = 0
+        for W, nks in mats:
+            for ks in range(nks):
+                b = 16 * mt + li
+                col = 4 * ks + lg
+                ok = (b < K) & (col < W.shape[1])
+                a2[c, ok] = W[b[ok], col[ok]]
+                c += 1
+        a3 = np.zeros((2, 2, 4, 64))
+        for ci_, C in enumerate((Cr, Ci)):
+            for t in range(2):
+                for r in range(4):
+                    row = 1 + 16 * t + li
+                    b = 16 * mt + 4 * lg + r
+                    ok = (row <= M) & (b < K)
+                    a3[ci_, t, r, ok] = C[row[ok], b[ok]]
+        out[mt, 768:768 + 44 * 64] = a2.reshape(-1)
+        out[mt, 768 + 44 * 64:] = a3.reshape(-1)
+    return out.astype(np.float32)
+
+
 def fbank_bins_table(H: np.ndarray):
     """Per-bin table of the fused filter bank's backward (dsa_fbank_bins_bwd; the C twin is dsa_fbank_bins_plan): row k =
     (bits of c_k as float32, w0, w1, 0) with H[k, c_k] = w0 and H[k, c_k + 1] = w1 the only non-zero entries of row k.

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 115 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch), dsa_mgcep_step */
+#define DSA_VERSION 116 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch), dsa_mgcep_step */
 
 typedef enum {
     DSA_OK = 0,
@@ -280,6 +280,12 @@ int dsa_thsolve_update_fwd(const void* p, const void* q, const void* r, int64_t 
  * caller once per configuration (layout: csrc/mgc.hip, mgcep_step_kernel; diffsptk_amd.utils.tables.mgcep_step_images).  Forward only. */
 int dsa_mgcep_step(const void* x, const void* b1, int64_t F, int32_t fft_length, int32_t M, double gamma, const void* images,
                    int32_t dtype, void* pt, void* qt, void* r, void* stream);
+/* Backward of dsa_mgcep_step in one launch: cotangents gpt:(F,M), gqt:(F,2M-1), gr:(F,M+1) -> gx:(F,L/2+1) (+ gx_in when not
+ * NULL: the spectrum enters every Newton step, so the steps' contributions accumulate; gx_in may be gx) and gb1:(F,M).
+ * `images_bwd`: 17 x 4608 float32 built by the caller (diffsptk_amd/utils/tables.py:mgcep_step_bwd_images). */
+int dsa_mgcep_step_bwd(const void* x, const void* b1, const void* gpt, const void* gqt, const void* gr, int64_t F,
+                       int32_t fft_length, int32_t M, double gamma, const void* images_bwd, int32_t dtype, const void* gx_in,
+                       void* gx, void* gb1, void* stream);
 /* GeneralizedCepstrumToGeneralizedCepstrum._forward, mgc2mgc.py:333-361 (the FFT formulation of the generalized cepstral
  * transformation), in ONE launch: c1:(F,n_in) gain-normalised generalized cepstra of in_gamma -> c2:(F,out_order+1) of
  * out_gamma through fft(c01, n_fft) -> (1 + g1 C)^(1/g1) -> (|s|^g2 cos(g2 angle s) - 1) / g2 -> ifft(.).real, n_fft a power of

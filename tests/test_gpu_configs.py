@@ -304,6 +304,47 @@ def test_mgcep_fused_spectrum_arithmetic_equals_the_differentiable_chain(dt, tol
         assert np.abs(a.double().cpu().numpy() - ref).max() <= (1e-8 if dt == torch.float64 else 3e-6) * np.abs(ref).max()   # float32 measured 8.4e-7
 
 
+def test_mgcep_step_backward_kernel_against_float64_autograd():
+    """With a gradient wanted the float32 / 512 / order <= 24 analysis runs the fused step forward AND its adjoint as one
+    launch each (ops.MgcepStepFn: dsa_mgcep_step / dsa_mgcep_step_bwd), the order-24 solve's backward on the quad-layout
+    solve + the diagonal sums.  Gradient with respect to the spectrum against autograd through the float64 module (the
+    differentiable operator chain, itself pinned to the reference's exported gradients in tests/test_gpu_synth.py);
+    measured 8e-7 .. 1e-6 of the largest entry (tools/time_mgcep_grad.py)."""
+    g = torch.Generator().manual_seed(21)
+    X = (torch.randn(3, 171, 257, generator=g).square() + 0.1)
+    for gamma, M, n_iter in ((-0.5, 24, 3), (-0.25, 17, 2), (-1.0 / 3, 24, 10)):
+        w = torch.randn(M + 1, generator=g)
+        m32 = dsp.MelGeneralizedCepstralAnalysis(fft_length=512, cep_order=M, alpha=0.42, gamma=gamma, n_iter=n_iter, device=DEV)
+        m64 = dsp.MelGeneralizedCepstralAnalysis(fft_length=512, cep_order=M, alpha=0.42, gamma=gamma, n_iter=n_iter, device=DEV,
+                                                 dtype=torch.float64)
+        xs = X.to(DEV).requires_grad_(True)
+        y = m32(xs)
+        (y * w.to(DEV)).sum().backward()
+        xd = X.double().to(DEV).requires_grad_(True)
+        yd = m64(xd)
+        (yd * w.double().to(DEV)).sum().backward()
+        assert float((y.double() - yd).abs().max()) < 3e-6 * float(yd.abs().max())
+        err = float((xs.grad.double() - xd.grad).abs().max() / xd.grad.abs().max())
+        assert err < 3e-6, (gamma, M, n_iter, err)
+    # the solve's backward alone, order 24: quad-layout solve + diagonal sums against the one-wave-per-system kernel's formulas
+    # in float64
+    n, Fr = 24, 1000 + 3
+    ii = torch.arange(n)
+    wgt = torch.exp(torch.randn(Fr, 48, generator=g, dtype=torch.float64))
+    om = torch.pi * (torch.arange(48, dtype=torch.float64) + 0.5) / 48
+    p = (wgt[:, None, :] * torch.cos(om[None, None, :] * ii[None, :, None])).sum(-1)
+    q = 0.5 * (wgt[:, None, :] * torch.cos(om[None, None, :] * torch.arange(2 * n - 1)[None, :, None])).sum(-1)
+    r = torch.randn(Fr, n, generator=g, dtype=torch.float64)
+    gg = torch.randn(Fr, n, generator=g, dtype=torch.float64)
+    outs = {}
+    for dt in (torch.float32, torch.float64):
+        pp, qq, rr = (t.to(DEV, dt).requires_grad_(True) for t in (p, q, r))
+        (ops.ThSolveFn.apply(pp, qq, rr) * gg.to(DEV, dt)).sum().backward()
+        outs[dt] = (pp.grad.double(), qq.grad.double(), rr.grad.double())
+    for a, b in zip(outs[torch.float32], outs[torch.float64]):
+        assert float((a - b).abs().max()) < 2e-3 * float(b.abs().max())   # float32 solves of systems with condition ~1e3
+
+
 def test_bench_two_ranks_on_one_device():
     """bench.py's N > 1 control flow (sharded batch, deferred in-place all-gather, drain inside the timed region, MAX over
     ranks, one JSON line from rank 0) as two processes on ONE device over gloo -- the 8-GPU RCCL run itself is the
