@@ -636,6 +636,27 @@ __device__ __forceinline__ void zd_fma_hi(zd_v2f& acc, zd_v2f c, zd_v2f w)   // 
 {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(c), "v"(w));
 }
+// two adjacent pairs from a 16-byte aligned LDS address (float: one ds_read_b128); `both` false: only the first is wanted
+__device__ __forceinline__ void zd_load2(const zd_v2f* p, zd_v2f& a, zd_v2f& b, bool both)
+{
+    if (both) {
+        const zd_v4f v = *reinterpret_cast<const zd_v4f*>(p);
+        a = zd_v2f{v.x, v.y};
+        b = zd_v2f{v.z, v.w};
+    } else {
+        a = p[0];
+    }
+}
+__device__ __forceinline__ void zd_load2(const zd_v2d* p, zd_v2d& a, zd_v2d& b, bool both)
+{
+    a = p[0];
+    if (both) b = p[1];
+}
+__device__ __forceinline__ void zd_fma2(zd_v2f& acc, zd_v2f c, zd_v2f w)     // acc += c * w, half by half
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(c), "v"(w));
+}
+__device__ __forceinline__ void zd_fma2(zd_v2d& acc, zd_v2d c, zd_v2d w) { acc += c * w; }
 __device__ __forceinline__ void zd_fma_lo(zd_v2d& acc, zd_v2d c, zd_v2d w) { acc += c * w.x; }
 __device__ __forceinline__ void zd_fma_hi(zd_v2d& acc, zd_v2d c, zd_v2d w) { acc += c * w.y; }
 
@@ -710,8 +731,7 @@ __global__ __launch_bounds__(256) void zerodf_fwd_rows_kernel(const T* __restric
             V2 c[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) c[r] = cp[4 * m + r];
-            R[(2 * b + NP - 2) % NP] = *reinterpret_cast<const V2*>(xf + 4 * m + 2 * (NP - 2));
-            R[(2 * b + NP - 1) % NP] = *reinterpret_cast<const V2*>(xf + 4 * m + 2 * (NP - 1));
+            zd_load2(reinterpret_cast<const V2*>(xf + 4 * m + 2 * (NP - 2)), R[(2 * b + NP - 2) % NP], R[(2 * b + NP - 1) % NP], true);
 #pragma unroll
             for (int q = 0; q < S; ++q)
 #pragma unroll
@@ -852,10 +872,212 @@ static int zerodf_launch_fwd(const void* x, const void* b, int64_t B, int64_t Tl
     return check_launch("zerodf_fwd");
 }
 
+// Round 3: the backward of the time-variant FIR on the forward's pattern (rows of frames n and n + 1 interleaved as pairs,
+// several frames per workgroup, four consecutive samples / taps per thread).  Without ignore_gain:
+//   gx[s] = sum_k gy[t] h_t[k],  t = s - z0 + k  =  sum_t (b[n(t)][k], b[n(t) + 1][k]) . ((1 - w_t) gy[t], w_t gy[t])
+// -- the dot product of two pairs, i.e. ONE packed multiply-add into a pair accumulator whose halves are added at the end.
+// A thread owns four consecutive s and walks t in blocks of four that never straddle a frame (P % 4 == 0; z0 is rounded up
+// to a multiple of 4 by shifting the taps): block m needs the tap pairs 4 m - 3 .. 4 m + 3 of ITS frame's row (stored from
+// position 3, so the window starts 16-byte aligned) and the four weighted cotangent pairs.  Lanes cross frame boundaries at
+// different m, so the window is re-read every block (the kernel is bound by LDS reads, ~1.4 x the multiply-adds).
+// The old kernel: a thread per sample over all taps with two row reads from memory per tap.
+template <typename T, int S>
+__global__ __launch_bounds__(256) void zerodf_bwd_x_rows_kernel(const T* __restrict__ gy, const T* __restrict__ b, long Tlen, long N,
+                                                                int M, int P, int z0, int nf, int nrows, T* __restrict__ gx)
+{
+    using V2 = T __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int dz = (4 - (z0 & 3)) & 3, Mp = M + dz, z0p = z0 + dz;
+    const int NBt = (Mp + S - 1) / 4 + 1;              // blocks of four t per block of S output samples
+    const int RW = (Mp + S + 6 + 3) & ~3;              // pairs per row: tap k' at position k' + S - 1, zeros around
+    const int nt = P / S;
+    V2* rows = reinterpret_cast<V2*>(smem_raw);        // [nrows][RW]
+    V2* up = rows + (size_t)nrows * RW;                // [nf P + 4 NBt]: ((1 - w) gy, w gy) of t = Tstart + j
+    const long chunks = (N + nf - 1) / nf;
+    const long u = blockIdx.x / chunks, n0 = (blockIdx.x - u * chunks) * nf;
+    const int frames = (int)((N - n0 < nf) ? N - n0 : nf);
+    const long Tstart = n0 * P - z0p;                  // t of up[0]
+    // floor division by P for a possibly negative Tstart
+    const long nlo = Tstart >= 0 ? Tstart / P : -((-Tstart + P - 1) / P);
+    const int r0 = (int)(Tstart - nlo * P);            // in [0, P)
+    const T* bu = b + u * N * (M + 1);
+    for (int pos = threadIdx.x; pos < RW; pos += blockDim.x) {
+        const int k = pos - (S - 1) - dz;
+        const bool tap = k >= 0 && k <= M;
+        T cv[25];
+#pragma unroll
+        for (int i = 0; i <= 24; ++i) {
+            const long nn = nlo + i;
+            const long row = nn < 0 ? 0 : (nn < N ? nn : N - 1);
+            cv[i] = (tap && i <= nrows) ? bu[row * (M + 1) + (tap ? k : 0)] : T(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 24; ++i)
+            if (i < nrows) rows[(size_t)i * RW + pos] = V2{cv[i], cv[i + 1]};
+    }
+    const int ulen = frames * P + 4 * NBt;
+    const T* gyu = gy + u * Tlen;
+    for (int j0 = threadIdx.x; j0 < ulen; j0 += 8 * blockDim.x) {
+        T gv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = j0 + q * (int)blockDim.x;
+            const long t = Tstart + j;
+            gv[q] = (j < ulen && t >= 0 && t < Tlen) ? gyu[t] : T(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = j0 + q * (int)blockDim.x;
+            if (j < ulen) {
+                const int ph = (r0 + j) % P;
+                const T w = (T)ph / (T)P;
+                up[j] = V2{gv[q] - w * gv[q], w * gv[q]};
+            }
+        }
+    }
+    __syncthreads();
+    const int fr = threadIdx.x / nt, l = threadIdx.x - fr * nt;
+    if (fr >= frames) return;
+    const int jb0 = fr * P + S * l;                    // this thread's samples are s = n0 P + jb0 + q; block m reads up[jb0 + 4 m ..]
+    int ph = (r0 + jb0) % P;
+    const V2* rp = rows + (size_t)((r0 + jb0) / P) * RW;
+    const V2* upp = up + jb0;
+    V2 a[S];
+#pragma unroll
+    for (int q = 0; q < S; ++q) a[q] = V2{0, 0};
+    for (int m = 0; m < NBt; ++m) {                    // (uniform trip count: a scalar loop)
+        // (two pairs per 16-byte aligned read: the rows and `up` start 32-byte aligned and advance by four pairs a block;
+        // left as pair reads the compiler emits ds_read2_b64, which moves half as many bytes per LDS cycle as ds_read_b128)
+        V2 w[S + 4], uu[4];
+#pragma unroll
+        for (int i = 0; i < S + 3; i += 2) zd_load2(rp + 4 * m + i, w[i], w[i + 1], i + 1 < S + 3);
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) zd_load2(upp + 4 * m + i, uu[i], uu[i + 1], true);
+#pragma unroll
+        for (int q = 0; q < S; ++q)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) zd_fma2(a[q], w[jt - q + S - 1], uu[jt]);
+        ph += 4;
+        if (ph >= P) {
+            ph -= P;
+            rp += RW;
+        }
+    }
+    T* dst = gx + u * Tlen + n0 * P + jb0;
+#pragma unroll
+    for (int q = 0; q < S; ++q) dst[q] = a[q].x + a[q].y;
+}
+
+// gb[n][k] = sum over the samples i of frames n - 1 and n of gs[i] x[t - k + z0], gs = the frame weight of b[n] in h_t times gy
+// (frame n: 1 - w, frame n - 1: w; the last frame also takes its own w part).  A thread owns four consecutive taps and walks
+// the 2 P samples in blocks of four on a sliding window of seven x values (one aligned 16-byte read of x and one of gs per 16
+// multiply-adds); 256 / ceil((M + 1) / 4) frames per workgroup.  The old kernel: a thread per tap, two LDS reads per
+// multiply-add, one frame per workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void zerodf_bwd_b_rows_kernel(const T* __restrict__ gy, const T* __restrict__ x, long Tlen, long N,
+                                                                long BN, int M, int P, int z0, int nfw, T* __restrict__ gb)
+{
+    using V4 = T __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int NBk = (M + 4) / 4;                       // 4-tap blocks
+    const int o = (3 - M) & 3;                         // shift that aligns the x window: (M - k0 - 3 + o) % 4 == 0
+    const int XL = (2 * P + M + 8 + 3) & ~3;           // floats of x per frame
+    T* gs = reinterpret_cast<T*>(smem_raw);            // [nfw][2 P]
+    T* xs = gs + (size_t)nfw * 2 * P;                  // [nfw][XL]: xs[j + o] = x[(n - 1) P - M + z0 + j]
+    const long f0 = (long)blockIdx.x * nfw;
+    for (int fw = 0; fw < nfw; ++fw) {                 // (frame indices per frame, not per element: 64-bit divisions)
+        const long f = f0 + fw;
+        const bool fok = f < BN;
+        const long u = fok ? f / N : 0, n = fok ? f - u * N : 0;
+        const T* gyu = gy + u * Tlen;
+        const T* xu = x + u * Tlen;
+        for (int i = threadIdx.x; i < 2 * P; i += blockDim.x) {
+            const long t = (n - 1) * P + i;
+            T v = 0;
+            if (fok && t >= 0) {
+                // frame of t: n - 1 for i < P, n otherwise; the row b[n] enters h_t with 1 - w in its own frame, with w in the
+                // frame before, and the clamped last frame takes both
+                const int ph = i < P ? i : i - P;
+                const T w = (T)ph / (T)P;
+                const T wt = i < P ? w : ((n == N - 1) ? T(1) : T(1) - w);
+                v = wt * gyu[t];
+            }
+            gs[(size_t)fw * 2 * P + i] = v;
+        }
+        for (int jj = threadIdx.x; jj < XL; jj += blockDim.x) {
+            const int j = jj - o;
+            const long sidx = (n - 1) * P - M + z0 + j;
+            xs[(size_t)fw * XL + jj] = (fok && j >= 0 && sidx >= 0 && sidx < Tlen) ? xu[sidx] : T(0);
+        }
+    }
+    __syncthreads();
+    const int fw = threadIdx.x / NBk, kb = threadIdx.x - fw * NBk;
+    const long f = f0 + fw;
+    if (fw >= nfw || f >= BN) return;
+    const int k0 = 4 * kb;
+    // acc[q] (tap k0 + q) += gs[i + j] xs[i + j + M - k0 - q]: window xw[c] = xs[i + e + c], e = M - k0 - 3, c = j - q + 3
+    const T* gp = gs + (size_t)fw * 2 * P;
+    const T* xp = xs + (size_t)fw * XL + (M - k0 - 3 + o);   // 16-byte aligned
+    T acc[4] = {T(0), T(0), T(0), T(0)};
+    V4 lo = *reinterpret_cast<const V4*>(xp);
+    for (int i = 0; i < 2 * P; i += 4) {
+        const V4 hi = *reinterpret_cast<const V4*>(xp + i + 4);
+        const V4 gv = *reinterpret_cast<const V4*>(gp + i);
+        const T xw[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[q] += gv[j] * xw[j - q + 3];
+        lo = hi;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (k0 + q <= M) gb[f * (M + 1) + k0 + q] = acc[q];
+}
+
 template <typename T>
 static int zerodf_launch_bwd(const void* gy, const void* x, const void* b, const void* y, int64_t B, int64_t Tlen, int64_t N, int M,
                              int P, int z0, int ig, void* gx, void* gb, hipStream_t st)
 {
+    static const int variant = [] { const char* e = getenv("DSA_ZERODF"); return e ? atoi(e) : 0; }();   // 1: round-2 kernels (A/B)
+    const bool rows_ok = variant == 0 && !ig && P % 4 == 0 && P / 4 <= 64 && M >= 16;
+    if (gx && rows_ok) {
+        const int S = 4;   // (eight samples per thread -- 2/3 of the LDS reads per multiply-add, 160 of 256 threads at P = 80 -- measured slower: 163 vs 148 us)
+        const int dz = (4 - (z0 & 3)) & 3, Mp = M + dz, NBt = (Mp + S - 1) / 4 + 1, RW = (Mp + S + 6 + 3) & ~3, nt = P / S;
+        int nf = 256 / nt;
+        if (nf > 16) nf = 16;
+        size_t lds_x = 0;
+        int nrows = 0;
+        for (; nf >= 1; --nf) {
+            nrows = nf + (Mp + P - 1) / P + 2;      // frames the t range of nf output frames can touch
+            lds_x = sizeof(T) * 2 * ((size_t)nrows * RW + (size_t)nf * P + 4 * NBt);
+            if (nrows <= 24 && lds_x <= 64 * 1024) break;
+        }
+        if (nf >= 1) {
+            const long chunks = (N + nf - 1) / nf;
+            if (S == 8)
+                hipLaunchKernelGGL((zerodf_bwd_x_rows_kernel<T, 8>), dim3((unsigned)(B * chunks)), dim3(256), lds_x, st, (const T*)gy,
+                                   (const T*)b, (long)Tlen, (long)N, M, P, z0, nf, nrows, (T*)gx);
+            else
+                hipLaunchKernelGGL((zerodf_bwd_x_rows_kernel<T, 4>), dim3((unsigned)(B * chunks)), dim3(256), lds_x, st, (const T*)gy,
+                                   (const T*)b, (long)Tlen, (long)N, M, P, z0, nf, nrows, (T*)gx);
+            gx = nullptr;
+        }
+    }
+    if (gb && rows_ok) {
+        const int NBk = (M + 4) / 4;
+        int nfw = 256 / NBk;
+        const int XL = (2 * P + M + 8 + 3) & ~3;
+        if (nfw >= 1) {
+            if (nfw > 16) nfw = 16;
+            const size_t lds_b = sizeof(T) * (size_t)nfw * (2 * P + XL);
+            if (lds_b <= 64 * 1024) {
+                hipLaunchKernelGGL((zerodf_bwd_b_rows_kernel<T>), dim3((unsigned)((B * N + nfw - 1) / nfw)), dim3(256), lds_b, st, (const T*)gy,
+                                   (const T*)x, (long)Tlen, (long)N, (long)(B * N), M, P, z0, nfw, (T*)gb);
+                gb = nullptr;
+            }
+        }
+    }
     if (gx) {
         hipLaunchKernelGGL((zerodf_bwd_x_kernel<T>), dim3((unsigned)((B * Tlen + 255) / 256)), dim3(256), 0, st, (const T*)gy,
                            (const T*)b, (long)B, (long)Tlen, (long)N, M, P, z0, ig, (T*)gx);

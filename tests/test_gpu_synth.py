@@ -220,6 +220,39 @@ def test_zerodf_and_linear_intpl(golden):
     assert _lib.last_kernel() == "zerodf_fwd" and np.isfinite(out).all()
 
 
+@pytest.mark.parametrize("M,P,z0,N", [(199, 80, 0, 31), (64, 80, 64, 4), (17, 8, 3, 70), (301, 128, 100, 5), (199, 80, 199, 13),
+                                      (23, 4, 2, 9), (1999, 80, 0, 3), (70, 5, 0, 6)])
+def test_zerodf_backward_kernels_against_autograd_of_the_definition(M, P, z0, N):
+    """The backward of the time-variant FIR (packed multi-frame kernels for M >= 16 and P % 4 == 0, the round-2 kernels
+    otherwise) against autograd through the definition written with tensor operations (zerodf.py:207-243: interpolated taps
+    times the unfolded signal), float64 to 1e-11 and float32 to 2e-5 of the largest entry: look-ahead taps that are / are not a
+    multiple of four, more / fewer frames than a workgroup takes, the clamped last frame."""
+    g = torch.Generator().manual_seed(M + P + z0)
+    B, T = 2, N * P
+    x = torch.randn(B, T, generator=g, dtype=torch.float64)
+    b = 0.1 * torch.randn(B, N, M + 1, generator=g, dtype=torch.float64)
+    gy = torch.randn(B, T, generator=g, dtype=torch.float64)
+
+    def definition(x, b):
+        t = torch.arange(T, device=x.device)
+        n0, w = t // P, (t % P).to(x.dtype) / P
+        n1 = torch.clamp(n0 + 1, max=N - 1)
+        h = b[:, n0] * (1 - w)[None, :, None] + b[:, n1] * w[None, :, None]          # (B, T, M + 1)
+        xp = torch.nn.functional.pad(x, (M, M))
+        idx = t[:, None] - torch.arange(M + 1, device=x.device)[None, :] + z0 + M    # x[t - k + z0]
+        return (h * xp[:, idx]).sum(-1)
+
+    xr, br = x.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    (definition(xr, br) * gy.to(DEV)).sum().backward()
+    for dt, tol in ((torch.float64, 1e-11), (torch.float32, 2e-5)):
+        xk, bk = x.to(DEV, dt).requires_grad_(True), b.to(DEV, dt).requires_grad_(True)
+        y = ops.ZerodfFn.apply(xk, bk, P, z0, False)
+        assert float((y.double() - definition(xr, br)).abs().max()) < (1e-11 if dt == torch.float64 else 3e-5) * float(y.abs().max())
+        (y * gy.to(DEV, dt)).sum().backward()
+        for got, ref in ((xk.grad, xr.grad), (bk.grad, br.grad)):
+            assert float((got.double() - ref).abs().max()) < tol * float(ref.abs().max()), (M, P, z0, N, dt)
+
+
 @pytest.mark.parametrize("mode", ["multi-stage", "single-stage", "freq-domain"])
 def test_mlsa_filter_golden(golden, mode):
     """tests/test_mglsadf.py of the reference: M = 24, P = 80, alpha = 0.42, c in {0, 2}, with / without the gain."""
