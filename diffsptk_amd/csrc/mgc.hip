@@ -883,11 +883,14 @@ static int zerodf_launch_fwd(const void* x, const void* b, int64_t B, int64_t Tl
 // The old kernel: a thread per sample over all taps with two row reads from memory per tap.
 template <typename T, int S>
 __global__ __launch_bounds__(256) void zerodf_bwd_x_rows_kernel(const T* __restrict__ gy, const T* __restrict__ b, long Tlen, long N,
-                                                                int M, int P, int z0, int nf, int nrows, T* __restrict__ gx)
+                                                                int M, int P, int z0, int nf, int nrows, int ldb, int accumulate,
+                                                                T* __restrict__ gx)
 {
+    // (`b` may point at a run of M + 1 taps inside rows of ldb coefficients -- long filters are handled as a sum of
+    // 200-tap pieces: piece c has z0 - c KC as its (possibly negative) zeroth index and accumulates into gx)
     using V2 = T __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int dz = (4 - (z0 & 3)) & 3, Mp = M + dz, z0p = z0 + dz;
+    const int dz = (4 - (((z0 % 4) + 4) & 3)) & 3, Mp = M + dz, z0p = z0 + dz;
     const int NBt = (Mp + S - 1) / 4 + 1;              // blocks of four t per block of S output samples
     const int RW = (Mp + S + 6 + 3) & ~3;              // pairs per row: tap k' at position k' + S - 1, zeros around
     const int nt = P / S;
@@ -900,7 +903,7 @@ __global__ __launch_bounds__(256) void zerodf_bwd_x_rows_kernel(const T* __restr
     // floor division by P for a possibly negative Tstart
     const long nlo = Tstart >= 0 ? Tstart / P : -((-Tstart + P - 1) / P);
     const int r0 = (int)(Tstart - nlo * P);            // in [0, P)
-    const T* bu = b + u * N * (M + 1);
+    const T* bu = b + u * N * ldb;
     for (int pos = threadIdx.x; pos < RW; pos += blockDim.x) {
         const int k = pos - (S - 1) - dz;
         const bool tap = k >= 0 && k <= M;
@@ -909,7 +912,7 @@ __global__ __launch_bounds__(256) void zerodf_bwd_x_rows_kernel(const T* __restr
         for (int i = 0; i <= 24; ++i) {
             const long nn = nlo + i;
             const long row = nn < 0 ? 0 : (nn < N ? nn : N - 1);
-            cv[i] = (tap && i <= nrows) ? bu[row * (M + 1) + (tap ? k : 0)] : T(0);
+            cv[i] = (tap && i <= nrows) ? bu[row * ldb + (tap ? k : 0)] : T(0);
         }
 #pragma unroll
         for (int i = 0; i < 24; ++i)
@@ -965,7 +968,7 @@ __global__ __launch_bounds__(256) void zerodf_bwd_x_rows_kernel(const T* __restr
     }
     T* dst = gx + u * Tlen + n0 * P + jb0;
 #pragma unroll
-    for (int q = 0; q < S; ++q) dst[q] = a[q].x + a[q].y;
+    for (int q = 0; q < S; ++q) dst[q] = (accumulate ? dst[q] : T(0)) + (a[q].x + a[q].y);
 }
 
 // gb[n][k] = sum over the samples i of frames n - 1 and n of gs[i] x[t - k + z0], gs = the frame weight of b[n] in h_t times gy
@@ -975,7 +978,7 @@ __global__ __launch_bounds__(256) void zerodf_bwd_x_rows_kernel(const T* __restr
 // multiply-add, one frame per workgroup.
 template <typename T>
 __global__ __launch_bounds__(256) void zerodf_bwd_b_rows_kernel(const T* __restrict__ gy, const T* __restrict__ x, long Tlen, long N,
-                                                                long BN, int M, int P, int z0, int nfw, T* __restrict__ gb)
+                                                                long BN, int M, int P, int z0, int nfw, int ldb, T* __restrict__ gb)
 {
     using V4 = T __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1032,7 +1035,7 @@ __global__ __launch_bounds__(256) void zerodf_bwd_b_rows_kernel(const T* __restr
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-        if (k0 + q <= M) gb[f * (M + 1) + k0 + q] = acc[q];
+        if (k0 + q <= M) gb[f * ldb + k0 + q] = acc[q];
 }
 
 template <typename T>
@@ -1041,42 +1044,45 @@ static int zerodf_launch_bwd(const void* gy, const void* x, const void* b, const
 {
     static const int variant = [] { const char* e = getenv("DSA_ZERODF"); return e ? atoi(e) : 0; }();   // 1: round-2 kernels (A/B)
     const bool rows_ok = variant == 0 && !ig && P % 4 == 0 && P / 4 <= 64 && M >= 16;
-    if (gx && rows_ok) {
-        const int S = 4;   // (eight samples per thread -- 2/3 of the LDS reads per multiply-add, 160 of 256 threads at P = 80 -- measured slower: 163 vs 148 us)
-        const int dz = (4 - (z0 & 3)) & 3, Mp = M + dz, NBt = (Mp + S - 1) / 4 + 1, RW = (Mp + S + 6 + 3) & ~3, nt = P / S;
-        int nf = 256 / nt;
-        if (nf > 16) nf = 16;
-        size_t lds_x = 0;
-        int nrows = 0;
-        for (; nf >= 1; --nf) {
-            nrows = nf + (Mp + P - 1) / P + 2;      // frames the t range of nf output frames can touch
-            lds_x = sizeof(T) * 2 * ((size_t)nrows * RW + (size_t)nf * P + 4 * NBt);
-            if (nrows <= 24 && lds_x <= 64 * 1024) break;
-        }
-        if (nf >= 1) {
-            const long chunks = (N + nf - 1) / nf;
-            if (S == 8)
-                hipLaunchKernelGGL((zerodf_bwd_x_rows_kernel<T, 8>), dim3((unsigned)(B * chunks)), dim3(256), lds_x, st, (const T*)gy,
-                                   (const T*)b, (long)Tlen, (long)N, M, P, z0, nf, nrows, (T*)gx);
-            else
-                hipLaunchKernelGGL((zerodf_bwd_x_rows_kernel<T, 4>), dim3((unsigned)(B * chunks)), dim3(256), lds_x, st, (const T*)gy,
-                                   (const T*)b, (long)Tlen, (long)N, M, P, z0, nf, nrows, (T*)gx);
-            gx = nullptr;
-        }
-    }
-    if (gb && rows_ok) {
-        const int NBk = (M + 4) / 4;
-        int nfw = 256 / NBk;
-        const int XL = (2 * P + M + 8 + 3) & ~3;
-        if (nfw >= 1) {
-            if (nfw > 16) nfw = 16;
-            const size_t lds_b = sizeof(T) * (size_t)nfw * (2 * P + XL);
-            if (lds_b <= 64 * 1024) {
+    if (rows_ok) {
+        // filters of more than ~200 taps as a sum of pieces (the kernels keep one piece's rows of a few frames in LDS): piece c
+        // = taps [c KC, c KC + Mc], zeroth index z0 - c KC; gx accumulates over the pieces, gb's columns are disjoint
+        const int npieces = (M + 1 + 199) / 200;
+        const int KC = (((M + 1 + npieces - 1) / npieces) + 3) & ~3;
+        bool ok = true;
+        for (int c = 0; c < npieces && ok; ++c) {
+            const int Mc = ((M + 1 - c * KC) < KC ? (M + 1 - c * KC) : KC) - 1, z0c = z0 - c * KC;
+            if (Mc < 0) break;
+            if (gx) {
+                constexpr int S = 4;   // (eight samples per thread -- 2/3 of the LDS reads per multiply-add, 160 of 256 threads at P = 80 -- measured slower)
+                const int dz = (4 - (((z0c % 4) + 4) & 3)) & 3, Mp = Mc + dz, NBt = (Mp + S - 1) / 4 + 1, RW = (Mp + S + 6 + 3) & ~3, nt = P / S;
+                int nf = 256 / nt;
+                if (nf > 16) nf = 16;
+                size_t lds_x = 0;
+                int nrows = 0;
+                for (; nf >= 1; --nf) {
+                    nrows = nf + (Mp + P - 1) / P + 2;      // frames the t range of nf output frames can touch
+                    lds_x = sizeof(T) * 2 * ((size_t)nrows * RW + (size_t)nf * P + 4 * NBt);
+                    if (nrows <= 24 && lds_x <= 64 * 1024) break;
+                }
+                if (nf < 1) { ok = false; break; }
+                const long chunks = (N + nf - 1) / nf;
+                hipLaunchKernelGGL((zerodf_bwd_x_rows_kernel<T, S>), dim3((unsigned)(B * chunks)), dim3(256), lds_x, st, (const T*)gy,
+                                   (const T*)b + c * KC, (long)Tlen, (long)N, Mc, P, z0c, nf, nrows, M + 1, c > 0 ? 1 : 0, (T*)gx);
+            }
+            if (gb) {
+                const int NBk = (Mc + 4) / 4;
+                int nfw = 256 / NBk;
+                const int XL = (2 * P + Mc + 8 + 3) & ~3;
+                if (nfw > 16) nfw = 16;
+                const size_t lds_b = sizeof(T) * (size_t)(nfw > 0 ? nfw : 1) * (2 * P + XL);
+                if (nfw < 1 || lds_b > 64 * 1024) { ok = false; break; }
                 hipLaunchKernelGGL((zerodf_bwd_b_rows_kernel<T>), dim3((unsigned)((B * N + nfw - 1) / nfw)), dim3(256), lds_b, st, (const T*)gy,
-                                   (const T*)x, (long)Tlen, (long)N, (long)(B * N), M, P, z0, nfw, (T*)gb);
-                gb = nullptr;
+                                   (const T*)x, (long)Tlen, (long)N, (long)(B * N), Mc, P, z0c, nfw, M + 1, (T*)gb + c * KC);
             }
         }
+        // (every piece has the same shape class, so `ok` fails on the first piece or never: nothing half-written)
+        if (ok) return check_launch("zerodf_rows_bwd");
     }
     if (gx) {
         hipLaunchKernelGGL((zerodf_bwd_x_kernel<T>), dim3((unsigned)((B * Tlen + 255) / 256)), dim3(256), 0, st, (const T*)gy,
