@@ -10,8 +10,8 @@ from collections import defaultdict
 
 # (name pattern, pattern that must NOT occur): the filter-bank variants of the packed STFT kernel are instantiations
 # <0, 400, true, 1|2> of the same template as the spectrum-out kernel <0, 400, true, 0>
-KERNELS = {"mcep_mfma_fwd": ("mcep_mfma_fwd_kernel_h", None), "stft512_fwd": ("stft512_fwd_pk_kernel<0, 400, true, 0>", None),
-           "stft512_fbank_fwd": ("stft512_fwd_pk_kernel<0, 400, true, 1>", None),
+KERNELS = {"mcep_mfma_fwd": ("mcep_mfma_fwd_kernel_h", None), "stft512_fwd": ("stft512_fwd_pk_kernel<0, 400, true, 0,", None),
+           "stft512_fbank_fwd": ("stft512_fwd_pk_kernel<0, 400, true, 1,", None),
            "mcep_mfma_bwd": ("mcep_mfma_bwd_kernel_h", None), "stft512_bwd": ("stft512_bwd_pk_kernel<400, 80, false, false>", None),
            "stft512_istft": ("stft512_bwd_pk_kernel<400, 80, true, false>", None),
            "frame_window_lpc24_fwd": ("frame_window_lpc24_kernel", None)}
