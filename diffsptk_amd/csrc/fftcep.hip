@@ -165,10 +165,14 @@ __global__ __launch_bounds__(256) void fftcep_fwd_kernel(const T* __restrict__ x
                 masks[(f * n_iter + it) * W64 + ((n0 + threadIdx.x) >> 6)] = bits;
         }
         __syncthreads();
-        T r[2] = {T(0), T(0)};   // e2 = ihfft(y).real (fftcep.py:129): up to 2 columns per thread (H <= 512)
-        int cnt = 0;
+        T r[9];   // e2 = ihfft(y).real (fftcep.py:129): ceil(H / blockDim.x) <= 9 columns per thread (H <= 513, >= 64 threads)
+#pragma unroll
+        for (int i_ = 0; i_ < 9; ++i_) r[i_] = T(0);
         if (FFT) fc_fft_product<T>(y, H, H, fre, fim, tw);
-        for (int n = threadIdx.x; n < H; n += blockDim.x) {
+#pragma unroll
+        for (int cnt = 0; cnt < 9; ++cnt) {   // (static register indices: column cnt of this thread)
+            const int n = threadIdx.x + cnt * (int)blockDim.x;
+            if (n >= H) break;
             T s0 = 0, s1 = 0;
             if (FFT) {
                 s0 = fre[fc_brev(n, lgL)];
@@ -180,12 +184,14 @@ __global__ __launch_bounds__(256) void fftcep_fwd_kernel(const T* __restrict__ x
                 }
                 if (k < H) s0 += y[k] * A[(long)k * H + n];
             }
-            r[cnt++] = (s0 + s1) * invL;
+            r[cnt] = (s0 + s1) * invL;
         }
         __syncthreads();
-        cnt = 0;
-        for (int n = threadIdx.x; n < H; n += blockDim.x) {   // fftcep.py:130-132
-            const T e2 = r[cnt++];
+#pragma unroll
+        for (int cnt = 0; cnt < 9; ++cnt) {   // fftcep.py:130-132
+            const int n = threadIdx.x + cnt * (int)blockDim.x;
+            if (n >= H) break;
+            const T e2 = r[cnt];
             if (n < N) {
                 const T t = e2 * (T(1) + accel);
                 v[n] += t;
@@ -258,10 +264,14 @@ __global__ __launch_bounds__(256) void fftcep_bwd_kernel(const T* __restrict__ g
         }
         __syncthreads();
         // y = clamp(e A)  =>  ge[n] = sum_k gz[k] A[n][k] = c_n sum_k (gz[k] / c_k) A[k][n]
-        T r[2] = {T(0), T(0)};
-        int cnt = 0;
+        T r[9];
+#pragma unroll
+        for (int i_ = 0; i_ < 9; ++i_) r[i_] = T(0);
         if (FFT) fc_fft_product<T>(gy, H, H, fre, fim, tw);
-        for (int n = threadIdx.x; n < H; n += blockDim.x) {
+#pragma unroll
+        for (int cnt = 0; cnt < 9; ++cnt) {
+            const int n = threadIdx.x + cnt * (int)blockDim.x;
+            if (n >= H) break;
             T s0 = 0, s1 = 0;
             if (FFT) {
                 s0 = fre[fc_brev(n, lgL)];
@@ -273,11 +283,14 @@ __global__ __launch_bounds__(256) void fftcep_bwd_kernel(const T* __restrict__ g
                 }
                 if (k < H) s0 += gy[k] * A[(long)k * H + n];
             }
-            r[cnt++] = (s0 + s1) * fc_weight<T>(n, H);
+            r[cnt] = (s0 + s1) * fc_weight<T>(n, H);
         }
         __syncthreads();
-        cnt = 0;
-        for (int n = threadIdx.x; n < H; n += blockDim.x) ge[n] = r[cnt++];
+#pragma unroll
+        for (int cnt = 0; cnt < 9; ++cnt) {
+            const int n = threadIdx.x + cnt * (int)blockDim.x;
+            if (n < H) ge[n] = r[cnt];
+        }
         __syncthreads();
     }
     // ehat = log(x) A / L feeds v (first N) and the initial e (the rest)
@@ -315,11 +328,15 @@ static int fftcep_launch(bool bwd, const void* gout, const void* x, int64_t F, i
     }();
     if (n_iter > 0 && L >= 32 && (L & (L - 1)) == 0 && !direct_only) {   // full H x H products: FFT in LDS
         const size_t lds_fft = lds + sizeof(T) * 3 * (size_t)L;
+        // one wave per frame (DSA_FFTCEP_BLOCK overrides for A/B): the barriers between the butterfly passes become single-wave
+        // barriers and a compute unit holds four times as many frames
+        static const int forced = [] { const char* e = getenv("DSA_FFTCEP_BLOCK"); return e ? atoi(e) : 0; }();
+        const int block = forced > 0 ? forced : 64;
         if (!bwd)
-            hipLaunchKernelGGL((fftcep_fwd_kernel<T, true>), dim3((unsigned)F), dim3(256), lds_fft, st, (const T*)x, (long)F, H, N,
+            hipLaunchKernelGGL((fftcep_fwd_kernel<T, true>), dim3((unsigned)F), dim3(block), lds_fft, st, (const T*)x, (long)F, H, N,
                                (const T*)A, (T)accel, n_iter, (T*)out, (unsigned long long*)masks);
         else
-            hipLaunchKernelGGL((fftcep_bwd_kernel<T, true>), dim3((unsigned)F), dim3(256), lds_fft, st, (const T*)gout, (const T*)x,
+            hipLaunchKernelGGL((fftcep_bwd_kernel<T, true>), dim3((unsigned)F), dim3(block), lds_fft, st, (const T*)gout, (const T*)x,
                                (long)F, H, N, (const T*)A, (T)accel, n_iter, (const unsigned long long*)masks, (T*)gx);
         return check_launch(bwd ? "fftcep_fft_bwd" : "fftcep_fft_fwd");
     }
