@@ -63,6 +63,11 @@ class MelCepstralAnalysis(BaseFunctionalModule):
     @staticmethod
     def _forward(x: torch.Tensor, *, fft_length: int, cep_order: int, n_iter: int, G: torch.Tensor,
                  D: torch.Tensor, E: torch.Tensor, alpha_vector: torch.Tensor, algo: int = _lib.ALGO_AUTO) -> torch.Tensor:
+        if x.requires_grad and torch.is_grad_enabled():
+            # no tuned kernel for this geometry and a graph is wanted: the differentiable whole-batch composition
+            y = ops.mcep_composed(x, G, D, E, alpha_vector, fft_length, cep_order, n_iter, algo)
+            if y is not None:
+                return y
         return ops.McepFn.apply(x, G, D, E, alpha_vector, fft_length, cep_order, n_iter, algo)
 
 

@@ -307,6 +307,16 @@ class StftFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------- freqt
+def _row_product_is_plain_gemm(F, Lin, Lout, elt) -> bool:
+    """True where the library's row-product entry would fall to its one-workgroup-per-row kernel (csrc/mcep.hip:dsa_freqt_fwd /
+    _bwd: the matrix does not fit the LDS-resident kernel's 48 KB and the shape is outside the matrix-core kernel's range --
+    the 1025-bin products of the 48 kHz set-ups): a plain GEMM, handed to the vendor library through torch.matmul."""
+    if os.environ.get("DSA_FREQT_GEMM", "1") == "0" or F < 256:
+        return False
+    lds_fits = elt * (Lin * Lout + 64 * (Lin + 1)) <= 48 * 1024
+    return not lds_fits
+
+
 class MatmulRowsFn(torch.autograd.Function):
     """out = c @ A for a fixed (non-learnable) matrix A (freqt.py:141-143, mcep.py:286-288)."""
 
@@ -317,10 +327,13 @@ class MatmulRowsFn(torch.autograd.Function):
         cc, Ac = c.contiguous(), A.contiguous()
         L1, L2 = Ac.shape
         F = cc.numel() // L1
+        ctx.save_for_backward(Ac)
+        mfma = cc.dtype == torch.float32 and 48 < L1 <= 320 and L2 <= 192 and F >= 1024
+        if not mfma and _row_product_is_plain_gemm(F, L1, L2, cc.element_size()):
+            return torch.matmul(cc, Ac)
         out = torch.empty(*cc.shape[:-1], L2, device=c.device, dtype=c.dtype)
         with torch.cuda.device(c.device):
             _call("dsa_freqt_fwd", _p(cc), F, L1, _p(Ac), L2, _dtype_code(cc), _p(out), _stream())
-        ctx.save_for_backward(Ac)
         return out
 
     @staticmethod
@@ -330,6 +343,8 @@ class MatmulRowsFn(torch.autograd.Function):
         g = g.contiguous()
         L1, L2 = Ac.shape
         F = g.numel() // L2
+        if _row_product_is_plain_gemm(F, L2, L1, g.element_size()):
+            return torch.matmul(g, Ac.t()), None
         gc = torch.empty(*g.shape[:-1], L1, device=g.device, dtype=g.dtype)
         with torch.cuda.device(g.device):
             _call("dsa_freqt_bwd", _p(g), F, L1, _p(Ac), L2, _dtype_code(g), _p(gc), _stream())
@@ -754,8 +769,24 @@ class MfccFn(torch.autograd.Function):
 
 # ----------------------------------------------------------------------------------- mcep
 def _mcep_composed_applies(Xc, M, F) -> bool:
-    """Geometries without a tuned kernel (48 kHz set-ups: fft_length 1024 / 2048, orders 34 .. 60), forward without a graph."""
+    """Geometries without a tuned kernel (48 kHz set-ups: fft_length 1024 / 2048, orders 34 .. 60)."""
     return M + 1 <= 64 and M >= 1 and F >= 256 and os.environ.get("DSA_MCEP_COMPOSED", "1") != "0"
+
+
+def mcep_composed(X, G, D, E, av, fft_length, M, n_iter, algo):
+    """The mel-cepstral analysis for a geometry without a tuned kernel, WITH a graph when one is wanted: the whole-batch
+    launches of _mcep_composed_fwd are differentiable operations (GEMMs, element-wise, ThSolveFn), so autograd runs the
+    backward as whole-batch launches too (the generic kernel pair keeps one workgroup per frame in both directions).
+    None: not applicable (a tuned kernel exists, the generic family was asked for, or the batch is tiny)."""
+    if algo == _lib.ALGO_GENERIC or X.device.type != "cuda":
+        return None
+    K = fft_length // 2 + 1
+    F = X.numel() // K
+    if not _mcep_composed_applies(X, M, F) or mcep_images(G, D, E, fft_length, M) is not None:
+        return None
+    _require_device(X, G, D, E, av)
+    _same_dtype(X, G, D, E, av)
+    return _mcep_composed_fwd(X.contiguous(), G, D, E, av, M, n_iter)
 
 
 def _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter):
@@ -903,6 +934,10 @@ def thsolve_update(pt, qt, r, b1):
         return None
     _require_device(pt, qt, r, b1)
     _same_dtype(pt, qt, r, b1)
+    lead = tuple(pt.shape[:-1])
+    if tuple(qt.shape) != lead + (2 * M - 1,) or tuple(r.shape) != lead + (M + 1,) or tuple(b1.shape) != lead + (M,):
+        raise ValueError(f"thsolve_update: shapes {tuple(pt.shape)}, {tuple(qt.shape)}, {tuple(r.shape)}, {tuple(b1.shape)} do not "
+                         "describe one batch of order-M systems")
     bc = b1.contiguous()
     F = pt.numel() // M
     out = torch.empty_like(bc)
@@ -1029,6 +1064,8 @@ def zerodf_taylor(x, b, P, zeroth_index, scale, acc, want_y=True):
     xc, bc = x.contiguous(), b.contiguous()
     if not acc.is_contiguous() or acc.shape != xc.shape:
         raise ValueError("zerodf_taylor: acc must be a contiguous tensor of the signal's shape")
+    if bc.dim() < 2 or bc.shape[:-2] != xc.shape[:-1] or bc.size(-2) * P != xc.size(-1):
+        raise ValueError(f"zerodf_taylor: coefficients {tuple(bc.shape)} do not match the signal {tuple(xc.shape)} at frame period {P}")
     T = xc.size(-1)
     M = bc.size(-1) - 1
     B = xc.numel() // max(T, 1)

@@ -279,8 +279,10 @@ def test_long_row_products_on_matrix_cores(K, N, Fr):
     ref, gref = (c @ A).numpy(), (g @ A.T).numpy()
     assert np.abs(out.detach().cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
     assert np.abs(cd.grad.cpu().numpy() - gref).max() <= 2e-5 * np.abs(gref).max()
-    out64 = ops.MatmulRowsFn.apply(c.to(DEV), A.to(DEV))      # float64 keeps the vector kernels
-    assert _lib.last_kernel() != "freqt_mfma_fwd"
+    ops.MatmulRowsFn.apply(c[:2].to(DEV), A.to(DEV))          # (a tiny float64 call: one-workgroup-per-row kernel)
+    assert _lib.last_kernel() == "freqt_fwd"
+    out64 = ops.MatmulRowsFn.apply(c.to(DEV), A.to(DEV))      # float64: the LDS-resident vector kernel, or the vendor GEMM when the
+    assert _lib.last_kernel() != "freqt_mfma_fwd"             # operands do not fit LDS -- never the float32 matrix-core kernel
     assert np.abs(out64.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
@@ -415,9 +417,22 @@ def test_untuned_geometries_forward_as_whole_batch_launches(monkeypatch, fl, fp,
     got = host(mc.reshape(-1, M + 1)[idx]).astype(np.float64)
     np.testing.assert_allclose(got, ref, **MC32)
     np.testing.assert_allclose(host(mc), host(mc_g), rtol=1e-4, atol=1e-5)
-    # a graph is wanted: the generic kernel pair (history-based backward)
+    # a graph is wanted: a tiny batch keeps the generic kernel pair (history-based backward); a batch of >= 256 frames runs the
+    # same whole-batch composition with autograd through it -- gradient against the float64 module on the generic pair
     Xg = X[:1, :8].clone().requires_grad_(True)
     y = mcep(Xg)
     assert _lib.last_kernel() == "mcep_generic_fwd"
     y.sum().backward()
     assert bool(torch.isfinite(Xg.grad).all()) and float(Xg.grad.abs().max()) > 0
+    w = torch.randn(M + 1, generator=torch.Generator().manual_seed(6)).to(DEV)
+    Xs = X.reshape(-1, nfft // 2 + 1)[:300]
+    Xc = Xs.clone().requires_grad_(True)
+    (mcep(Xc) * w).sum().backward()
+    assert _lib.last_kernel() != "mcep_generic_fwd"
+    monkeypatch.setenv("DSA_MCEP_COMPOSED", "0")
+    m64 = dsp.MelCepstralAnalysis(fft_length=nfft, cep_order=M, alpha=alpha, n_iter=10, device=DEV, dtype=torch.float64)
+    Xd = Xs.double().clone().requires_grad_(True)
+    (m64(Xd) * w.double()).sum().backward()
+    monkeypatch.delenv("DSA_MCEP_COMPOSED")
+    err = float((Xc.grad.double() - Xd.grad).abs().max() / Xd.grad.abs().max())
+    assert err < 2e-4, err

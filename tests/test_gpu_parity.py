@@ -819,15 +819,19 @@ def test_fbank_matrix_core_forward_matches_float64(K, C, Fr, use_power, dense, m
 @pytest.mark.parametrize("L1,L2,Fr", [(40, 13, 1000), (25, 49, 257), (13, 40, 4096), (257, 8, 300), (40, 13, 100)])
 def test_small_matrix_rows_kernel(L1, L2, Fr):
     """c @ A for the small matrices of DCT / freqt / lifter (64-row tiles, A in LDS) and its transpose product
-    in the backward, float32 and float64, ragged row counts; short inputs keep the one-workgroup-per-row kernel."""
+    in the backward, float32 and float64, ragged row counts; short inputs keep the one-workgroup-per-row kernel, large
+    products whose operands do not fit LDS go to the vendor GEMM (ops._row_product_is_plain_gemm)."""
     gen = torch.Generator().manual_seed(L1 * 7 + L2)
     c = torch.randn(Fr, L1, dtype=torch.float64, generator=gen)
     A = torch.randn(L1, L2, dtype=torch.float64, generator=gen)
     g = torch.randn(Fr, L2, dtype=torch.float64, generator=gen)
     for dt, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
         cd = c.to(DEV, dt).requires_grad_(True)
+        ops.MatmulRowsFn.apply(c[:3].to(DEV, dt), A.to(DEV, dt))       # (a tiny call first: last_kernel() = "freqt_fwd")
         out = ops.MatmulRowsFn.apply(cd, A.to(DEV, dt))
         fits = dt.itemsize * (L1 * L2 + 64 * (L1 + 1)) <= 48 * 1024   # matrix + a 64-row tile in LDS
+        # >= 256 rows whose matrix + tile do not fit LDS are a plain GEMM for the vendor library (no library kernel runs: the name
+        # of the tiny call stays); fewer rows keep the one-workgroup-per-row kernel
         assert _lib.last_kernel() == ("freqt_lds_fwd" if Fr >= 256 and fits else "freqt_fwd")
         out.backward(g.to(DEV, dt))
         ref, gref = (c @ A).numpy(), (g @ A.T).numpy()
