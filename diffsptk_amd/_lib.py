@@ -140,6 +140,7 @@ SIGNATURES = {
     "dsa_zerodf_fwd": (C.c_int, [_P, _P, _L, _L, _I, _I, _I, _I, _I, _P, _P]),
     "dsa_zerodf_bwd": (C.c_int, [_P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P]),
     "dsa_zerodf_taylor_fwd": (C.c_int, [_P, _P, _L, _L, _I, _I, _I, C.c_double, _P, _I, _P, _P, _P]),
+    "dsa_zerodf_taylor_bwd": (C.c_int, [_P, _P, _P, _L, _L, _I, _I, _I, C.c_double, _P, _I, _P, _P, _P]),
     "dsa_acorr_fwd": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P]),
     "dsa_acorr_bwd": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "dsa_levdur_fwd": (C.c_int, [_P, _L, _I, _D, _I, _P, _P]),

@@ -884,8 +884,10 @@ static int zerodf_launch_fwd(const void* x, const void* b, int64_t B, int64_t Tl
 template <typename T, int S>
 __global__ __launch_bounds__(256) void zerodf_bwd_x_rows_kernel(const T* __restrict__ gy, const T* __restrict__ b, long Tlen, long N,
                                                                 int M, int P, int z0, int nf, int nrows, int ldb, int accumulate,
-                                                                T* __restrict__ gx)
+                                                                T scale, const T* add, T* gx)
 {
+    // gx = (accumulate ? gx : (add ? add : 0)) + scale * (the sum): `add` / `scale` serve the Taylor stages of the multi-stage
+    // MLSA filter's backward (G_{i-1} = gy + F^T G_i / i)
     // (`b` may point at a run of M + 1 taps inside rows of ldb coefficients -- long filters are handled as a sum of
     // 200-tap pieces: piece c has z0 - c KC as its (possibly negative) zeroth index and accumulates into gx)
     using V2 = T __attribute__((ext_vector_type(2)));
@@ -968,7 +970,10 @@ __global__ __launch_bounds__(256) void zerodf_bwd_x_rows_kernel(const T* __restr
     }
     T* dst = gx + u * Tlen + n0 * P + jb0;
 #pragma unroll
-    for (int q = 0; q < S; ++q) dst[q] = (accumulate ? dst[q] : T(0)) + (a[q].x + a[q].y);
+    for (int q = 0; q < S; ++q) {
+        const T base = accumulate ? dst[q] : (add ? add[u * Tlen + n0 * P + jb0 + q] : T(0));
+        dst[q] = base + scale * (a[q].x + a[q].y);
+    }
 }
 
 // gb[n][k] = sum over the samples i of frames n - 1 and n of gs[i] x[t - k + z0], gs = the frame weight of b[n] in h_t times gy
@@ -978,7 +983,8 @@ __global__ __launch_bounds__(256) void zerodf_bwd_x_rows_kernel(const T* __restr
 // multiply-add, one frame per workgroup.
 template <typename T>
 __global__ __launch_bounds__(256) void zerodf_bwd_b_rows_kernel(const T* __restrict__ gy, const T* __restrict__ x, long Tlen, long N,
-                                                                long BN, int M, int P, int z0, int nfw, int ldb, T* __restrict__ gb)
+                                                                long BN, int M, int P, int z0, int nfw, int ldb, T scale, int accumulate,
+                                                                T* __restrict__ gb)
 {
     using V4 = T __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1035,13 +1041,15 @@ __global__ __launch_bounds__(256) void zerodf_bwd_b_rows_kernel(const T* __restr
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-        if (k0 + q <= M) gb[f * ldb + k0 + q] = acc[q];
+        if (k0 + q <= M) gb[f * ldb + k0 + q] = (accumulate ? gb[f * ldb + k0 + q] : T(0)) + scale * acc[q];
 }
 
 template <typename T>
 static int zerodf_launch_bwd(const void* gy, const void* x, const void* b, const void* y, int64_t B, int64_t Tlen, int64_t N, int M,
-                             int P, int z0, int ig, void* gx, void* gb, hipStream_t st)
+                             int P, int z0, int ig, void* gx, void* gb, hipStream_t st, double scale = 1.0, const void* gx_add = nullptr,
+                             bool gb_accumulate = false)
 {
+    const bool plain = scale == 1.0 && gx_add == nullptr && !gb_accumulate;
     static const int variant = [] { const char* e = getenv("DSA_ZERODF"); return e ? atoi(e) : 0; }();   // 1: round-2 kernels (A/B)
     const bool rows_ok = variant == 0 && !ig && P % 4 == 0 && P / 4 <= 64 && M >= 16;
     if (rows_ok) {
@@ -1068,7 +1076,8 @@ static int zerodf_launch_bwd(const void* gy, const void* x, const void* b, const
                 if (nf < 1) { ok = false; break; }
                 const long chunks = (N + nf - 1) / nf;
                 hipLaunchKernelGGL((zerodf_bwd_x_rows_kernel<T, S>), dim3((unsigned)(B * chunks)), dim3(256), lds_x, st, (const T*)gy,
-                                   (const T*)b + c * KC, (long)Tlen, (long)N, Mc, P, z0c, nf, nrows, M + 1, c > 0 ? 1 : 0, (T*)gx);
+                                   (const T*)b + c * KC, (long)Tlen, (long)N, Mc, P, z0c, nf, nrows, M + 1, c > 0 ? 1 : 0, (T)scale,
+                                   (const T*)gx_add, (T*)gx);
             }
             if (gb) {
                 const int NBk = (Mc + 4) / 4;
@@ -1078,12 +1087,14 @@ static int zerodf_launch_bwd(const void* gy, const void* x, const void* b, const
                 const size_t lds_b = sizeof(T) * (size_t)(nfw > 0 ? nfw : 1) * (2 * P + XL);
                 if (nfw < 1 || lds_b > 64 * 1024) { ok = false; break; }
                 hipLaunchKernelGGL((zerodf_bwd_b_rows_kernel<T>), dim3((unsigned)((B * N + nfw - 1) / nfw)), dim3(256), lds_b, st, (const T*)gy,
-                                   (const T*)x, (long)Tlen, (long)N, (long)(B * N), Mc, P, z0c, nfw, M + 1, (T*)gb + c * KC);
+                                   (const T*)x, (long)Tlen, (long)N, (long)(B * N), Mc, P, z0c, nfw, M + 1, (T)scale, gb_accumulate ? 1 : 0,
+                                   (T*)gb + c * KC);
             }
         }
         // (every piece has the same shape class, so `ok` fails on the first piece or never: nothing half-written)
         if (ok) return check_launch("zerodf_rows_bwd");
     }
+    if (!plain) return fail(DSA_ERR_UNSUPPORTED, "zerodf_bwd: the scaled / accumulating form needs P % 4 == 0 and M >= 16%s");
     if (gx) {
         hipLaunchKernelGGL((zerodf_bwd_x_kernel<T>), dim3((unsigned)((B * Tlen + 255) / 256)), dim3(256), 0, st, (const T*)gy,
                            (const T*)b, (long)B, (long)Tlen, (long)N, M, P, z0, ig, (T*)gx);
@@ -1478,6 +1489,21 @@ DSA_EXPORT int dsa_zerodf_bwd(const void* gy, const void* x, const void* b, cons
     if (dtype == DSA_F64)
         return zerodf_launch_bwd<double>(gy, x, b, y, B, T, N, M, P, zeroth_index, ignore_gain, gx, gb, (hipStream_t)stream);
     return fail(DSA_ERR_UNSUPPORTED, "zerodf_bwd: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_zerodf_taylor_bwd(const void* G, const void* x, const void* b, int64_t B, int64_t T, int32_t M, int32_t P,
+                                     int32_t zeroth_index, double scale, const void* gy, int32_t dtype, void* G_out, void* gb,
+                                     void* stream)
+{
+    DSA_REQUIRE(M >= 0 && P > 0 && B >= 0 && T >= 0 && zeroth_index >= 0 && zeroth_index <= M && T % P == 0, "zerodf_taylor_bwd: invalid sizes");
+    DSA_REQUIRE(G_out != nullptr && G_out != G, "zerodf_taylor_bwd: G_out must be a buffer of its own");
+    if (B * T == 0) return DSA_OK;
+    const int64_t N = T / P;
+    if (dtype == DSA_F32)
+        return zerodf_launch_bwd<float>(G, x, b, nullptr, B, T, N, M, P, zeroth_index, 0, G_out, gb, (hipStream_t)stream, scale, gy, true);
+    if (dtype == DSA_F64)
+        return zerodf_launch_bwd<double>(G, x, b, nullptr, B, T, N, M, P, zeroth_index, 0, G_out, gb, (hipStream_t)stream, scale, gy, true);
+    return fail(DSA_ERR_UNSUPPORTED, "zerodf_taylor_bwd: unsupported dtype%s");
 }
 
 DSA_EXPORT int dsa_thsolve_fwd(const void* p, const void* q, const void* r, int64_t F, int32_t n, int32_t dtype, void* g,

@@ -42,6 +42,8 @@ def _taylor_stages(x: torch.Tensor, c: torch.Tensor, P: int, z0: int, order: int
     """exp(F) x ~ sum_i F^i x / i!  (mglsadf.py:356-365): x <- F x / i, y <- y + x, `order` times.  Without a graph a stage
     (filter, 1 / i, running sum) is ONE launch, rounded like the three operations it replaces; with one, the differentiable
     filter and two element-wise operations per stage."""
+    if order >= 1 and ops.zerodf_taylor_shapes_ok(x, c, P) and torch.is_grad_enabled() and (x.requires_grad or c.requires_grad):
+        return ops.ZerodfTaylorFn.apply(x, c, P, z0, order)      # with a graph: one launch per stage in either direction
     if order >= 1 and ops.zerodf_taylor_supported(x, c, P):
         y = x.clone(memory_format=torch.contiguous_format)
         cur = x

@@ -314,7 +314,9 @@ def _row_product_is_plain_gemm(F, Lin, Lout, elt) -> bool:
     if os.environ.get("DSA_FREQT_GEMM", "1") == "0" or F < 256:
         return False
     lds_fits = elt * (Lin * Lout + 64 * (Lin + 1)) <= 48 * 1024
-    return not lds_fits
+    # (rows of a few hundred values keep the library's kernels: the GEMM's host-side set-up costs more than they take --
+    # the 200 -> 25 transpose product of the MLSA filter's backward went from 0.1 ms to 10 ms of host time per call)
+    return not lds_fits and max(Lin, Lout) >= 512
 
 
 class MatmulRowsFn(torch.autograd.Function):
@@ -1049,10 +1051,55 @@ def zerodf(x, b, P, zeroth_index, ignore_gain):
     return ZerodfFn.apply(x, b, P, zeroth_index, ignore_gain)
 
 
+def zerodf_taylor_shapes_ok(x, b, P) -> bool:
+    """Shapes the fused Taylor-stage launches cover, forward and backward (csrc/mgc.hip:zerodf_rows_plan, zerodf_launch_bwd)."""
+    return (P % 4 == 0 and 16 <= P <= 256 and b.size(-1) - 1 >= 16 and b.dim() >= 2 and tuple(b.shape[:-2]) == tuple(x.shape[:-1])
+            and b.size(-2) * P == x.size(-1) and x.is_cuda and x.dtype == b.dtype and x.dtype in (torch.float32, torch.float64))
+
+
 def zerodf_taylor_supported(x, b, P) -> bool:
-    """Shapes the fused Taylor-stage launch covers (csrc/mgc.hip:zerodf_rows_plan) -- and no graph is being recorded."""
-    return (P % 4 == 0 and b.size(-1) - 1 >= 16 and b.dim() >= 2 and tuple(b.shape[:-2]) == tuple(x.shape[:-1])
-            and b.size(-2) * P == x.size(-1) and not (torch.is_grad_enabled() and (x.requires_grad or b.requires_grad)))
+    """zerodf_taylor_shapes_ok and no graph is being recorded."""
+    return zerodf_taylor_shapes_ok(x, b, P) and not (torch.is_grad_enabled() and (x.requires_grad or b.requires_grad))
+
+
+class ZerodfTaylorFn(torch.autograd.Function):
+    """y = sum_{i=0}^{order} F^i x / i!  (mglsadf.py:356-365) with a graph: one launch per stage forward (filter, 1 / i, running
+    sum: dsa_zerodf_taylor_fwd), one call per stage backward (dsa_zerodf_taylor_bwd: G_{i-1} = gy + F^T G_i / i and
+    gb += dF(x_{i-1})^T G_i / i) -- instead of the differentiable filter + two element-wise operations per stage and autograd's
+    accumulations.  x:(..., T), b:(..., T/P, M+1), shapes as zerodf_taylor_shapes_ok."""
+
+    @staticmethod
+    def forward(ctx, x, b, P, zeroth_index, order):
+        xc, bc = x.contiguous(), b.contiguous()
+        y = xc.clone()
+        cur = xc
+        stages = [xc]
+        for i in range(1, order + 1):
+            cur, y = zerodf_taylor(cur, bc, P, zeroth_index, 1.0 / i, y, want_y=i < order)
+            if i < order:
+                stages.append(cur)
+        ctx.save_for_backward(bc, *stages)
+        ctx.cfg = (P, zeroth_index, order)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        bc, *stages = ctx.saved_tensors
+        P, z0, order = ctx.cfg
+        gy = gy.contiguous()
+        T = gy.size(-1)
+        M = bc.size(-1) - 1
+        B = gy.numel() // max(T, 1)
+        gb = torch.zeros_like(bc) if ctx.needs_input_grad[1] else None
+        G = gy
+        with torch.cuda.device(gy.device):
+            for i in range(order, 0, -1):
+                G_out = torch.empty_like(gy)
+                _call("dsa_zerodf_taylor_bwd", _p(G), _p(stages[i - 1]), _p(bc), B, T, M, P, z0, 1.0 / i, _p(gy), _dtype_code(gy),
+                      _p(G_out), _p(gb), _stream())
+                G = G_out
+        return (G if ctx.needs_input_grad[0] else None), gb, None, None, None
 
 
 def zerodf_taylor(x, b, P, zeroth_index, scale, acc, want_y=True):

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 116 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch), dsa_mgcep_step */
+#define DSA_VERSION 117 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch), dsa_mgcep_step */
 
 typedef enum {
     DSA_OK = 0,
@@ -315,6 +315,12 @@ int dsa_zerodf_bwd(const void* gy, const void* x, const void* b, const void* y, 
  * use dsa_zerodf_fwd and element-wise launches). */
 int dsa_zerodf_taylor_fwd(const void* x, const void* b, int64_t B, int64_t T, int32_t M, int32_t P, int32_t zeroth_index,
                           double scale, const void* acc, int32_t dtype, void* y, void* ysum, void* stream);
+/* Backward of one Taylor stage (x_i = F x_{i-1} / i, y = sum x_i): with G the cotangent that reaches x_i, one call gives
+ *   G_out = gy + scale * F^T G      (the cotangent that reaches x_{i-1}; gy: the cotangent of y; G_out must not alias G),
+ *   gb   += scale * dF(x_{i-1})^T G (accumulated over the stages: the caller zeroes gb once; may be NULL).
+ * Same shape limits as dsa_zerodf_taylor_fwd. */
+int dsa_zerodf_taylor_bwd(const void* G, const void* x, const void* b, int64_t B, int64_t T, int32_t M, int32_t P,
+                          int32_t zeroth_index, double scale, const void* gy, int32_t dtype, void* G_out, void* gb, void* stream);
 
 /* ------------------------------------------------------------------ a11  autocorrelation
  * Autocorrelation._forward, acorr.py:110-120.  x:(F,L) -> r:(F,M+1).  Computed as direct lag

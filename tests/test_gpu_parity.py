@@ -830,8 +830,8 @@ def test_small_matrix_rows_kernel(L1, L2, Fr):
         ops.MatmulRowsFn.apply(c[:3].to(DEV, dt), A.to(DEV, dt))       # (a tiny call first: last_kernel() = "freqt_fwd")
         out = ops.MatmulRowsFn.apply(cd, A.to(DEV, dt))
         fits = dt.itemsize * (L1 * L2 + 64 * (L1 + 1)) <= 48 * 1024   # matrix + a 64-row tile in LDS
-        # >= 256 rows whose matrix + tile do not fit LDS are a plain GEMM for the vendor library (no library kernel runs: the name
-        # of the tiny call stays); fewer rows keep the one-workgroup-per-row kernel
+        # (rows of >= 512 values whose matrix + tile do not fit LDS are a plain GEMM for the vendor library; these shapes
+        # keep the one-workgroup-per-row kernel when they do not fit)
         assert _lib.last_kernel() == ("freqt_lds_fwd" if Fr >= 256 and fits else "freqt_fwd")
         out.backward(g.to(DEV, dt))
         ref, gref = (c @ A).numpy(), (g @ A.T).numpy()

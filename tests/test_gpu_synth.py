@@ -253,6 +253,31 @@ def test_zerodf_backward_kernels_against_autograd_of_the_definition(M, P, z0, N)
             assert float((got.double() - ref).abs().max()) < tol * float(ref.abs().max()), (M, P, z0, N, dt)
 
 
+@pytest.mark.parametrize("M,P,z0,N,order", [(199, 80, 0, 31, 20), (60, 80, 60, 5, 7), (300, 16, 100, 40, 3)])
+def test_taylor_stages_function_equals_the_stage_by_stage_graph(M, P, z0, N, order):
+    """ops.ZerodfTaylorFn (one launch per stage forward, one call per stage backward: dsa_zerodf_taylor_fwd / _bwd) against the
+    graph autograd builds from the differentiable filter and two element-wise operations per stage (mglsadf.py:356-365):
+    outputs bit-identical, gradients with respect to the signal and the coefficients to float64 / float32 rounding."""
+    g = torch.Generator().manual_seed(M + order)
+    x = torch.randn(2, N * P, generator=g, dtype=torch.float64)
+    b = 0.05 * torch.randn(2, N, M + 1, generator=g, dtype=torch.float64)
+    gy = torch.randn(2, N * P, generator=g, dtype=torch.float64)
+    for dt, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
+        xa, ba = x.to(DEV, dt).requires_grad_(True), b.to(DEV, dt).requires_grad_(True)
+        assert ops.zerodf_taylor_shapes_ok(xa, ba, P)
+        ya = ops.ZerodfTaylorFn.apply(xa, ba, P, z0, order)
+        (ya * gy.to(DEV, dt)).sum().backward()
+        xb, bb = x.to(DEV, dt).requires_grad_(True), b.to(DEV, dt).requires_grad_(True)
+        yb, cur = xb, xb
+        for i in range(1, order + 1):
+            cur = ops.ZerodfFn.apply(cur, bb, P, z0, False) * (1.0 / i)
+            yb = yb + cur
+        (yb * gy.to(DEV, dt)).sum().backward()
+        assert torch.equal(ya.detach(), yb.detach())
+        for got, ref in ((xa.grad, xb.grad), (ba.grad, bb.grad)):
+            assert float((got - ref).abs().max()) <= tol * float(ref.abs().max()), (M, P, dt)
+
+
 @pytest.mark.parametrize("mode", ["multi-stage", "single-stage", "freq-domain"])
 def test_mlsa_filter_golden(golden, mode):
     """tests/test_mglsadf.py of the reference: M = 24, P = 80, alpha = 0.42, c in {0, 2}, with / without the gain."""
