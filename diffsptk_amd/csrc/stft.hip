@@ -1238,6 +1238,138 @@ __global__ __launch_bounds__(256) void gc2gc_fused_kernel(const T* __restrict__ 
     }
 }
 
+// Backward of gc2gc_fused_kernel (flags = 0) in ONE launch per row: gc1 from the row c1 and the cotangent g2 of c2.
+//   c2[0] = c1[0];  c2[m] = 2 c02[m],  c02 = Re ifft(C2),  C2[k] = f(X[k]) for the half spectrum k = 0 .. H of X = fft(c01).
+// Three half-length transforms in LDS: X is recomputed from c01; the cotangent of the even spectrum is a cosine transform of
+// g2, gcb[k] = (2 / n) w_k Re fft(g)[k] (w = 1 at k = 0, H, else 2: cb[k] is read for j = k and j = n - k); the element-wise
+// chain rule gives (gXr, gXi)[k]; and gc01[m] = sum_{k=0}^{H} gXr[k] cos(2 pi k m / n) - gXi[k] sin(2 pi k m / n) is the
+// unnormalised inverse real transform of the Hermitian spectrum Y (Y[0] = gXr[0], Y[H] = gXr[H], Y[k] = (gXr + i gXi)[k] / 2),
+// run as the conjugate of a forward half-length transform of Z[k] = E[k] + i O[k], E = (Y[k] + conj Y[H-k]) / 2,
+// O = conj(W)^k (Y[k] - conj Y[H-k]) / 2.  LDS: re[H] | im[H] | xr[H+1] | xi[H+1] | gcb[H+1].
+template <typename T>
+__global__ __launch_bounds__(256) void gc2gc_fused_bwd_kernel(const T* __restrict__ c1, const T* __restrict__ g2row, int n_in,
+                                                             int out_order, T g1, T g2, int nfft, const T* __restrict__ tw,
+                                                             T* __restrict__ gc1)
+{
+    extern __shared__ unsigned char smem_raw[];
+    const int H = nfft >> 1;
+    T* re = reinterpret_cast<T*>(smem_raw);
+    T* im = re + H;
+    T* xr = im + H;
+    T* xi = xr + (H + 1);
+    T* gcb = xi + (H + 1);
+    const long f = blockIdx.x;
+    const T* row = c1 + f * n_in;
+    const T* grow = g2row + f * (long)(out_order + 1);
+    const int lgh = 30 - __clz(nfft);
+    constexpr T kPi = T(3.14159265358979323846);
+    // half-length transform of a packed real sequence, then the split into the half spectrum (dr, di)[0 .. H]
+    auto split_to = [&](T* dr, T* di) {
+        for (int k = threadIdx.x; k <= (H >> 1); k += blockDim.x) {
+            if (k == 0) {
+                const T zr = re[0], zi = im[0];
+                dr[0] = zr + zi;
+                dr[H] = zr - zi;
+                if (di) {
+                    di[0] = T(0);
+                    di[H] = T(0);
+                }
+            } else {
+                const int pa = fft_brev(k, lgh), pb = fft_brev(H - k, lgh);
+                const T ar = re[pa], ai = im[pa], br = re[pb], bi = -im[pb];
+                const T sr = T(0.5) * (ar + br), si = T(0.5) * (ai + bi), dr_ = T(0.5) * (ar - br), di_ = T(0.5) * (ai - bi);
+                const T wr = tw[2 * k], wi = tw[2 * k + 1];
+                const T pr = wr * dr_ - wi * di_, pi_ = wr * di_ + wi * dr_;
+                dr[k] = sr + pi_;
+                dr[H - k] = sr - pi_;
+                if (di) {
+                    di[k] = si - pr;
+                    di[H - k] = -si - pr;
+                }
+            }
+        }
+    };
+    // ---- X = fft(c01) ----
+    for (int n = threadIdx.x; n < H; n += blockDim.x) {
+        const int i0 = 2 * n, i1 = 2 * n + 1;
+        re[n] = (i0 >= 1 && i0 < n_in) ? row[i0] : T(0);
+        im[n] = i1 < n_in ? row[i1] : T(0);
+    }
+    __syncthreads();
+    lds_fft_pow2(re, im, H, lgh, tw, 2);
+    split_to(xr, xi);
+    __syncthreads();
+    // ---- cosine transform of the cotangent: g[0] = 0, g[m] = g2[m] ----
+    for (int n = threadIdx.x; n < H; n += blockDim.x) {
+        const int i0 = 2 * n, i1 = 2 * n + 1;
+        re[n] = (i0 >= 1 && i0 <= out_order) ? grow[i0] : T(0);
+        im[n] = i1 <= out_order ? grow[i1] : T(0);
+    }
+    __syncthreads();
+    lds_fft_pow2(re, im, H, lgh, tw, 2);
+    split_to(gcb, static_cast<T*>(nullptr));
+    __syncthreads();
+    // ---- element-wise chain rule: (xr, xi)[k] <- (gXr, gXi)[k] ----
+    for (int k = threadIdx.x; k <= H; k += blockDim.x) {
+        const T cr = xr[k], ci = xi[k];
+        const T gc = gcb[k] * ((k == 0 || k == H) ? T(2) : T(4)) / T(nfft);
+        T lmag, ang, l_r, l_i, a_r, a_i;   // log |s|, angle(s) and their partial derivatives with respect to (cr, ci)
+        if (g1 == T(0)) {
+            lmag = cr; ang = ci;
+            l_r = T(1); l_i = T(0); a_r = T(0); a_i = T(1);
+        } else {
+            const T zr = T(1) + g1 * cr, zi = g1 * ci, r2 = zr * zr + zi * zi;
+            lmag = T(0.5) * dsa_log(r2) / g1;
+            ang = atan2(zi, zr) / g1;
+            l_r = zr / r2; l_i = zi / r2; a_r = -zi / r2; a_i = zr / r2;
+        }
+        T f_l, f_a;
+        if (g2 == T(0)) {
+            f_l = T(1); f_a = T(0);
+        } else {
+            ang -= T(2) * kPi * rint(ang / (T(2) * kPi));
+            const T e = dsa_exp(g2 * lmag);
+            f_l = e * cos(ang * g2);
+            f_a = -e * sin(ang * g2);
+        }
+        xr[k] = gc * (f_l * l_r + f_a * a_r);
+        xi[k] = gc * (f_l * l_i + f_a * a_i);
+    }
+    __syncthreads();
+    // ---- gc01 = 2 * conj(fft_H(conj Z)) unpacked ----
+    for (int k = threadIdx.x; k < H; k += blockDim.x) {
+        T yr, yi, br, bi;                      // Y[k], conj Y[H - k]
+        if (k == 0) {
+            yr = xr[0]; yi = T(0);
+            br = xr[H]; bi = T(0);
+        } else {
+            yr = T(0.5) * xr[k]; yi = T(0.5) * xi[k];
+            br = T(0.5) * xr[H - k]; bi = -T(0.5) * xi[H - k];
+        }
+        const T er = T(0.5) * (yr + br), ei = T(0.5) * (yi + bi), dr = T(0.5) * (yr - br), di = T(0.5) * (yi - bi);
+        const T wr = tw[2 * k], wi = -tw[2 * k + 1];            // conj(W)^k = (cos, +sin)(2 pi k / n)
+        const T or_ = wr * dr - wi * di, oi = wr * di + wi * dr;  // O[k]
+        // Z = E + i O = (er - oi) + i (ei + or); the transform runs on conj Z
+        re[k] = er - oi;
+        im[k] = -(ei + or_);
+    }
+    __syncthreads();
+    lds_fft_pow2(re, im, H, lgh, tw, 2);
+    T* out = gc1 + f * n_in;
+    for (int m = threadIdx.x; m < n_in; m += blockDim.x) {
+        T v;
+        if (m == 0) {
+            v = grow[0];
+        } else if (m >= nfft) {
+            v = T(0);                          // (rows longer than the transform are cropped by the forward)
+        } else {
+            const int pos = fft_brev(m >> 1, lgh);
+            v = T(2) * ((m & 1) ? -im[pos] : re[pos]);
+        }
+        out[m] = v;
+    }
+}
+
 template <typename T>
 static int gc2gc_launch(const void* c1, int64_t F, int n_in, int out_order, double g1, double g2, int nfft, const void* tw, int flags,
                         void* c2, hipStream_t st)
@@ -1827,6 +1959,36 @@ DSA_EXPORT int dsa_gc2gc_fwd(const void* c1, int64_t F, int32_t n_in, int32_t ou
     if (dtype == DSA_F32 && (size_t)nfft * 8 <= 150 * 1024) return gc2gc_launch<float>(c1, F, n_in, out_order, in_gamma, out_gamma, nfft, twiddle, flags, c2, st);
     if (dtype == DSA_F64 && (size_t)nfft * 16 <= 150 * 1024) return gc2gc_launch<double>(c1, F, n_in, out_order, in_gamma, out_gamma, nfft, twiddle, flags, c2, st);
     return fail(DSA_ERR_UNSUPPORTED, "gc2gc: unsupported dtype or n_fft too long for LDS%s");
+}
+
+DSA_EXPORT int dsa_gc2gc_bwd(const void* c1, const void* g2, int64_t F, int32_t n_in, int32_t out_order, double in_gamma,
+                             double out_gamma, int32_t nfft, const void* twiddle, int32_t dtype, void* gc1, void* stream)
+{
+    DSA_REQUIRE(F >= 0 && n_in >= 1 && out_order >= 0, "gc2gc_bwd: sizes must be positive");
+    DSA_REQUIRE(nfft >= 4 && (nfft & (nfft - 1)) == 0, "gc2gc_bwd: n_fft must be a power of two (>= 4)");
+    DSA_REQUIRE(out_order + 1 <= nfft, "gc2gc_bwd: out_order + 1 must not exceed n_fft");
+    if (F == 0) return DSA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int block = nfft <= 1024 ? 64 : 256;
+    if (dtype == DSA_F32 && (size_t)nfft * 10 + 64 <= 150 * 1024) {
+        const size_t lds = sizeof(float) * (5 * (size_t)(nfft / 2) + 3);
+        static std::atomic<uint64_t> lds_set{0};
+        if (lds > 48 * 1024 && !ensure_dynamic_lds(reinterpret_cast<const void*>(&gc2gc_fused_bwd_kernel<float>), 150 * 1024, lds_set))
+            return fail(DSA_ERR_LAUNCH, "gc2gc_bwd: cannot raise the dynamic LDS limit%s");
+        hipLaunchKernelGGL((gc2gc_fused_bwd_kernel<float>), dim3((unsigned)F), dim3(block), lds, st, (const float*)c1, (const float*)g2,
+                           n_in, out_order, (float)in_gamma, (float)out_gamma, nfft, (const float*)twiddle, (float*)gc1);
+        return check_launch("gc2gc_fused_bwd");
+    }
+    if (dtype == DSA_F64 && (size_t)nfft * 20 + 64 <= 150 * 1024) {
+        const size_t lds = sizeof(double) * (5 * (size_t)(nfft / 2) + 3);
+        static std::atomic<uint64_t> lds_set{0};
+        if (lds > 48 * 1024 && !ensure_dynamic_lds(reinterpret_cast<const void*>(&gc2gc_fused_bwd_kernel<double>), 150 * 1024, lds_set))
+            return fail(DSA_ERR_LAUNCH, "gc2gc_bwd: cannot raise the dynamic LDS limit%s");
+        hipLaunchKernelGGL((gc2gc_fused_bwd_kernel<double>), dim3((unsigned)F), dim3(block), lds, st, (const double*)c1, (const double*)g2,
+                           n_in, out_order, in_gamma, out_gamma, nfft, (const double*)twiddle, (double*)gc1);
+        return check_launch("gc2gc_fused_bwd");
+    }
+    return fail(DSA_ERR_UNSUPPORTED, "gc2gc_bwd: unsupported dtype or n_fft too long for LDS%s");
 }
 
 DSA_EXPORT int dsa_fftr_fwd(const void* x, int64_t F, int32_t len_in, int32_t nfft, int32_t out_format,

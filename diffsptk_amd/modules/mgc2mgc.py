@@ -28,6 +28,10 @@ def gc2gc(c1: torch.Tensor, out_order: int, in_gamma: float, out_gamma: float, n
         y = ops.gc2gc_fused(c1, out_order, in_gamma, out_gamma, n_fft, tw)   # one launch, the spectra never leave LDS
         if y is not None:
             return y
+    else:
+        y = ops.gc2gc_fn(c1, out_order, in_gamma, out_gamma, n_fft, tw)      # with a graph: one launch forward, one backward
+        if y is not None:
+            return y
     c01 = torch.cat((torch.zeros_like(c1[..., :1]), c1[..., 1:]), dim=-1)
     C1 = ops.FftrFn.apply(c01, n_fft, 0, tw)                       # half of fft(c01, n_fft): the sequence is real
     if in_gamma == 0:

@@ -878,6 +878,40 @@ def gc2gc_fused(c1, out_order, in_gamma, out_gamma, n_fft, twiddle, flags=0):
     return out
 
 
+class Gc2gcFn(torch.autograd.Function):
+    """GeneralizedCepstrumToGeneralizedCepstrum._forward (mgc2mgc.py:333-361) with a graph: dsa_gc2gc_fwd forward, dsa_gc2gc_bwd
+    backward -- one launch each, the n_fft-point spectra never in memory.  Use gc2gc_fn(): None when there is no fused kernel."""
+
+    @staticmethod
+    def forward(ctx, c1, out_order, in_gamma, out_gamma, n_fft, twiddle):
+        y = gc2gc_fused(c1, out_order, in_gamma, out_gamma, n_fft, twiddle)
+        ctx.save_for_backward(c1, twiddle)
+        ctx.cfg = (out_order, float(in_gamma), float(out_gamma), n_fft)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g2):
+        c1, tw = ctx.saved_tensors
+        out_order, ig, og, n_fft = ctx.cfg
+        cc, gc = c1.contiguous(), g2.contiguous()
+        n_in = cc.size(-1)
+        F = cc.numel() // n_in
+        gc1 = torch.empty_like(cc)
+        with torch.cuda.device(cc.device):
+            _call("dsa_gc2gc_bwd", _p(cc), _p(gc), F, n_in, out_order, ig, og, n_fft, _p(tw), _dtype_code(cc), _p(gc1), _stream())
+        return gc1, None, None, None, None, None
+
+
+def gc2gc_fn(c1, out_order, in_gamma, out_gamma, n_fft, twiddle):
+    """Gc2gcFn.apply where the fused kernels cover the configuration (n_fft a power of two whose five half-length arrays fit LDS),
+    else None."""
+    esz = 10 if c1.dtype == torch.float32 else 20
+    if n_fft < 4 or n_fft & (n_fft - 1) or n_fft * esz + 64 > 150 * 1024 or out_order + 1 > n_fft or not c1.is_cuda:
+        return None
+    return Gc2gcFn.apply(c1, out_order, in_gamma, out_gamma, n_fft, twiddle)
+
+
 def mgcep_step(x, b1, images, gamma):
     """(pt, qt, r) of one Newton step of mgcep.py:199-220 in one launch (dsa_mgcep_step: spectrum arithmetic + the five row
     products, float32 / fft_length 512 / cep_order <= 24); forward only."""

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 117 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch), dsa_mgcep_step */
+#define DSA_VERSION 118 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch), dsa_mgcep_step */
 
 typedef enum {
     DSA_OK = 0,
@@ -297,6 +297,11 @@ int dsa_mgcep_step_bwd(const void* x, const void* b1, const void* gpt, const voi
  * This is what mgc2mgc (gamma conversion), mgc2sp and the MLSA filter's impulse responses (mglsadf.py:389-527) run on. */
 int dsa_gc2gc_fwd(const void* c1, int64_t F, int32_t n_in, int32_t out_order, double in_gamma, double out_gamma,
                   int32_t nfft, const void* twiddle, int32_t flags, int32_t dtype, void* c2, void* stream);
+/* Backward of dsa_gc2gc_fwd with flags = 0, one launch: the row c1:(F, n_in) and the cotangent g2:(F, out_order + 1) of c2 ->
+ * gc1:(F, n_in).  n_fft a power of two; float32 up to 8192 points, float64 up to 4096 (the three half-length transforms and the
+ * half spectrum live in LDS). */
+int dsa_gc2gc_bwd(const void* c1, const void* g2, int64_t F, int32_t n_in, int32_t out_order, double in_gamma, double out_gamma,
+                  int32_t nfft, const void* twiddle, int32_t dtype, void* gc1, void* stream);
 
 /* ------------------------------------------------------------------ f4  time-variant all-zero filter
  * AllZeroDigitalFilter._forward_efficient, zerodf.py:207-243: the FIR core of the multi-stage / single-stage MLSA filter

@@ -453,6 +453,47 @@ def test_gc2gc_fused_kernel_equals_the_operator_chain(golden, dt, tol):
         assert np.abs(host(fused) - ref).max() <= (1e-9 if dt == torch.float64 else 5e-5) * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("g1,g2,n_fft,m1,m2", [(0.0, -0.5, 128, 24, 30), (-0.5, 0.0, 64, 8, 12), (-1.0, -1.0 / 3, 512, 24, 24),
+                                              (-0.25, 1.0, 4096, 24, 1999), (0.0, 1.0, 256, 30, 100), (0.0, 0.0, 64, 10, 20)])
+def test_gc2gc_backward_kernel_against_autograd_of_the_definition(g1, g2, n_fft, m1, m2):
+    """dsa_gc2gc_bwd (ops.Gc2gcFn: one launch forward, one backward) against autograd through the definition written with
+    torch.fft (mgc2mgc.py:333-361), float64 to 1e-10 and float32 to 2e-4 of the largest entry; every gamma branch, the
+    4096-point transform of the single-stage MLSA filter's impulse responses included."""
+    import math
+    gen = torch.Generator().manual_seed(n_fft + m1)
+    c1 = 0.3 * torch.randn(37, m1 + 1, generator=gen, dtype=torch.float64)
+    gy = torch.randn(37, m2 + 1, generator=gen, dtype=torch.float64)
+
+    def definition(c):
+        c01 = torch.cat((torch.zeros_like(c[..., :1]), c[..., 1:]), -1)
+        C1 = torch.fft.fft(c01, n=n_fft)
+        if g1 == 0:
+            mag, ang = torch.exp(C1.real), C1.imag
+        else:
+            z = 1 + g1 * C1
+            mag, ang = z.abs() ** (1 / g1), z.angle() / g1
+        if g2 == 0:
+            C2 = torch.log(mag)
+        else:
+            ang = torch.remainder(ang + math.pi, 2 * math.pi) - math.pi
+            C2 = (mag ** g2 * torch.cos(ang * g2) - 1) / g2
+        c02 = torch.fft.ifft(C2).real[..., : m2 + 1]
+        return torch.cat((c[..., :1], 2 * c02[..., 1:]), -1)
+
+    cr = c1.to(DEV).requires_grad_(True)
+    yr = definition(cr)
+    (yr * gy.to(DEV)).sum().backward()
+    from diffsptk_amd.modules.spec import device_twiddle
+    for dt, tol in ((torch.float64, 1e-10), (torch.float32, 2e-4)):
+        ck = c1.to(DEV, dt).requires_grad_(True)
+        y = ops.gc2gc_fn(ck, m2, g1, g2, n_fft, device_twiddle(n_fft, ck.device, dt))
+        assert y is not None and _lib.last_kernel() == "gc2gc_fused"
+        assert float((y.double() - yr).abs().max()) < tol * float(yr.abs().max())
+        (y * gy.to(DEV, dt)).sum().backward()
+        err = float((ck.grad.double() - cr.grad).abs().max() / cr.grad.abs().max())
+        assert err < tol, (g1, g2, n_fft, dt, err)
+
+
 def test_thsolve_order24_float32_falls_back_to_pivoting_on_indefinite_systems():
     """The order-24 float32 path eliminates WITHOUT pivoting (sound for the analysis' positive definite systems).  A system whose
     elimination meets a non-positive pivot is marked and re-solved with row pivoting by the second launch -- what the reference's
