@@ -53,24 +53,31 @@ __device__ __forceinline__ void fc_fft_twiddles(const T* __restrict__ A, int H, 
         tw[2 * m + 1] = T(-0.5) * A[H + (q < 0 ? -q : q)];     // -sin = -cos(2 pi (m - L/4) / L)
     }
 }
+__device__ __forceinline__ int fc_brev(int k, int lg) { return (int)(__brev((unsigned)k) >> (32 - lg)); }
+// Round 3: the even extension of src is REAL, so the L-point transform runs as a complex transform of HALF the length on the
+// packed sequence z[n] = x[2n] + i x[2n+1], followed by the split's real part
+//   Re X[k] = (Zr[k] + Zr[L/2 - k]) / 2 + cos(2 pi k / L) (Zi[k] + Zi[L/2 - k]) / 2 - sin(2 pi k / L) (Zr[k] - Zr[L/2 - k]) / 2
+// (2.25 x fewer butterflies than the full-length transform with a zero imaginary part that this replaced).  Results in
+// natural order in fout[0 .. H - 1].
 template <typename T>
-__device__ __forceinline__ void fc_fft_product(const T* src, int klim, int H, T* fre, T* fim, const T* tw)
+__device__ __forceinline__ void fc_fft_product(const T* src, int klim, int H, T* fre, T* fim, T* fout, const T* tw)
 {
-    const int L = 2 * (H - 1), lg = 31 - __clz(L);
-    for (int k = threadIdx.x; k < L; k += blockDim.x) {
-        const int kk = k < H ? k : L - k;
-        fre[k] = kk < klim ? src[kk] : T(0);
-        fim[k] = T(0);
+    const int L = 2 * (H - 1), n = L >> 1, lg = 31 - __clz(n);
+    for (int m = threadIdx.x; m < n; m += blockDim.x) {
+        const int j0 = 2 * m, j1 = 2 * m + 1;
+        const int k0 = j0 < H ? j0 : L - j0, k1 = j1 < H ? j1 : L - j1;
+        fre[m] = k0 < klim ? src[k0] : T(0);
+        fim[m] = k1 < klim ? src[k1] : T(0);
     }
     __syncthreads();
     // lds_fft_pow2 of stft.hip, restated here for this translation unit (forward sign, natural in, bit-reversed out): two
     // radix-2 stages per pass through registers (the four points i0, i0 + h/2, i0 + h, i0 + h + h/2 are closed under
     // stages s and s - 1): half the LDS traffic and barriers; the second pair's twiddle is -i times the first's, stage
-    // s - 1's is its square
+    // s - 1's is its square.  The twiddle table is the L-point one: W_n^(j n / 2h) = W_L^(j L / 2h).
     int sft = lg - 1;
     for (; sft >= 1; sft -= 2) {
         const int h = 1 << sft, h2 = h >> 1, tstep = L >> (sft + 1);
-        for (int t = threadIdx.x; t < (L >> 2); t += blockDim.x) {
+        for (int t = threadIdx.x; t < (n >> 2); t += blockDim.x) {
             const int j = t & (h2 - 1);
             const int i0 = ((t >> (sft - 1)) << (sft + 1)) | j;
             const T a0r = fre[i0], a0i = fim[i0], a1r = fre[i0 + h2], a1i = fim[i0 + h2];
@@ -96,7 +103,7 @@ __device__ __forceinline__ void fc_fft_product(const T* src, int klim, int H, T*
         __syncthreads();
     }
     if (sft == 0) {   // odd number of stages: the last one on its own (half = 1, twiddle 1)
-        for (int t = threadIdx.x; t < (L >> 1); t += blockDim.x) {
+        for (int t = threadIdx.x; t < (n >> 1); t += blockDim.x) {
             const int i = t << 1;
             const T ar = fre[i], ai = fim[i], br = fre[i + 1], bi = fim[i + 1];
             fre[i] = ar + br;
@@ -106,8 +113,22 @@ __device__ __forceinline__ void fc_fft_product(const T* src, int klim, int H, T*
         }
         __syncthreads();
     }
+    for (int k = threadIdx.x; k < H; k += blockDim.x) {
+        T v;
+        if (k == 0) {
+            v = fre[0] + fim[0];
+        } else if (k == n) {
+            v = fre[0] - fim[0];
+        } else {
+            const int pa = fc_brev(k, lg), pb = fc_brev(n - k, lg);
+            const T ar = fre[pa], ai = fim[pa], br = fre[pb], bi = -fim[pb];
+            const T dr = T(0.5) * (ar - br), di = T(0.5) * (ai - bi);
+            v = T(0.5) * (ar + br) + tw[2 * k] * di + tw[2 * k + 1] * dr;   // tw = (cos, -sin)(2 pi k / L)
+        }
+        fout[k] = v;
+    }
+    __syncthreads();
 }
-__device__ __forceinline__ int fc_brev(int k, int lg) { return (int)(__brev((unsigned)k) >> (32 - lg)); }
 
 template <typename T, bool FFT = false>
 __global__ __launch_bounds__(256) void fftcep_fwd_kernel(const T* __restrict__ x, long F, int H, int N,
@@ -118,10 +139,10 @@ __global__ __launch_bounds__(256) void fftcep_fwd_kernel(const T* __restrict__ x
     T* e = reinterpret_cast<T*>(fc_smem);   // [H]
     T* y = e + H;                           // [H]
     T* v = y + H;                           // [N]
-    T* fre = v + N;                         // FFT: [L] [L] and the twiddles [L]
-    T* fim = fre + 2 * (H - 1);
-    T* tw = fim + 2 * (H - 1);
-    const int lgL = 31 - __clz(2 * (H - 1));
+    T* fre = v + N;                         // FFT: [L/2] [L/2], the real results [H], the twiddles [L]
+    T* fim = fre + (H - 1);
+    T* fout = fim + (H - 1);
+    T* tw = fout + H;
     const long f = blockIdx.x;
     const T invL = T(1) / T(2 * (H - 1));
     const int W64 = (H + 63) / 64;
@@ -129,8 +150,8 @@ __global__ __launch_bounds__(256) void fftcep_fwd_kernel(const T* __restrict__ x
     for (int k = threadIdx.x; k < H; k += blockDim.x) e[k] = dsa_log(x[f * H + k]);   // fftcep.py:122
     __syncthreads();
     if (FFT) {
-        fc_fft_product<T>(e, H, H, fre, fim, tw);
-        for (int n = threadIdx.x; n < H; n += blockDim.x) y[n] = fre[fc_brev(n, lgL)] * invL;
+        fc_fft_product<T>(e, H, H, fre, fim, fout, tw);
+        for (int n = threadIdx.x; n < H; n += blockDim.x) y[n] = fout[n] * invL;
     } else {
         fc_product<T>(A, H, e, H, n_iter > 0 ? H : N, [&](int n, T s) { y[n] = s * invL; });
     }
@@ -142,12 +163,12 @@ __global__ __launch_bounds__(256) void fftcep_fwd_kernel(const T* __restrict__ x
     __syncthreads();
     for (int it = 0; it < n_iter; ++it) {
         // y = hfft(e) with negatives cleared (fftcep.py:127-128); the clamp pattern is kept for the backward
-        if (FFT) fc_fft_product<T>(e, H, H, fre, fim, tw);
+        if (FFT) fc_fft_product<T>(e, H, H, fre, fim, fout, tw);
         for (int n0 = 0; n0 < H; n0 += blockDim.x) {
             const int n = n0 + threadIdx.x;
             T s = 0;
             if (FFT) {
-                if (n < H) s = fre[fc_brev(n, lgL)];
+                if (n < H) s = fout[n];
             } else if (n < H) {
                 T s0 = 0, s1 = 0;
                 int k = 0;
@@ -168,14 +189,14 @@ __global__ __launch_bounds__(256) void fftcep_fwd_kernel(const T* __restrict__ x
         T r[9];   // e2 = ihfft(y).real (fftcep.py:129): ceil(H / blockDim.x) <= 9 columns per thread (H <= 513, >= 64 threads)
 #pragma unroll
         for (int i_ = 0; i_ < 9; ++i_) r[i_] = T(0);
-        if (FFT) fc_fft_product<T>(y, H, H, fre, fim, tw);
+        if (FFT) fc_fft_product<T>(y, H, H, fre, fim, fout, tw);
 #pragma unroll
         for (int cnt = 0; cnt < 9; ++cnt) {   // (static register indices: column cnt of this thread)
             const int n = threadIdx.x + cnt * (int)blockDim.x;
             if (n >= H) break;
             T s0 = 0, s1 = 0;
             if (FFT) {
-                s0 = fre[fc_brev(n, lgL)];
+                s0 = fout[n];
             } else {
                 int k = 0;
                 for (; k + 1 < H; k += 2) {
@@ -217,10 +238,10 @@ __global__ __launch_bounds__(256) void fftcep_bwd_kernel(const T* __restrict__ g
     T* ge = reinterpret_cast<T*>(fc_smem);   // [H]  cotangent of e, pre-divided by c_k when used as a product input
     T* gy = ge + H;                          // [H]
     T* gv = gy + H;                          // [N]
-    T* fre = gv + N;                         // FFT: [L] [L] and the twiddles [L]
-    T* fim = fre + 2 * (H - 1);
-    T* tw = fim + 2 * (H - 1);
-    const int lgL = 31 - __clz(2 * (H - 1));
+    T* fre = gv + N;                         // FFT: [L/2] [L/2], the real results [H], the twiddles [L]
+    T* fim = fre + (H - 1);
+    T* fout = fim + (H - 1);
+    T* tw = fout + H;
     const long f = blockIdx.x;
     const T invL = T(1) / T(2 * (H - 1));
     const int W64 = (H + 63) / 64;
@@ -241,13 +262,13 @@ __global__ __launch_bounds__(256) void fftcep_bwd_kernel(const T* __restrict__ g
         }
         __syncthreads();
         // e2 = y A / L  =>  gy[n] = sum_k ge2[k] A[n][k] / L = (c_n / L) sum_k (ge2[k] / c_k) A[k][n];  then the clamp
-        if (FFT) fc_fft_product<T>(ge, H, H, fre, fim, tw);
+        if (FFT) fc_fft_product<T>(ge, H, H, fre, fim, fout, tw);
         for (int n0 = 0; n0 < H; n0 += blockDim.x) {
             const int n = n0 + threadIdx.x;
             if (n < H) {
                 T s0 = 0, s1 = 0;
                 if (FFT) {
-                    s0 = fre[fc_brev(n, lgL)];
+                    s0 = fout[n];
                 } else {
                     int k = 0;
                     for (; k + 1 < H; k += 2) {
@@ -267,14 +288,14 @@ __global__ __launch_bounds__(256) void fftcep_bwd_kernel(const T* __restrict__ g
         T r[9];
 #pragma unroll
         for (int i_ = 0; i_ < 9; ++i_) r[i_] = T(0);
-        if (FFT) fc_fft_product<T>(gy, H, H, fre, fim, tw);
+        if (FFT) fc_fft_product<T>(gy, H, H, fre, fim, fout, tw);
 #pragma unroll
         for (int cnt = 0; cnt < 9; ++cnt) {
             const int n = threadIdx.x + cnt * (int)blockDim.x;
             if (n >= H) break;
             T s0 = 0, s1 = 0;
             if (FFT) {
-                s0 = fre[fc_brev(n, lgL)];
+                s0 = fout[n];
             } else {
                 int k = 0;
                 for (; k + 1 < H; k += 2) {
@@ -297,11 +318,11 @@ __global__ __launch_bounds__(256) void fftcep_bwd_kernel(const T* __restrict__ g
     for (int k = threadIdx.x; k < H; k += blockDim.x) gy[k] = (k < N ? gv[k] : ge[k]) / fc_weight<T>(k, H);
     __syncthreads();
     const int klim = n_iter > 0 ? H : N;
-    if (FFT) fc_fft_product<T>(gy, klim, H, fre, fim, tw);
+    if (FFT) fc_fft_product<T>(gy, klim, H, fre, fim, fout, tw);
     for (int n = threadIdx.x; n < H; n += blockDim.x) {
         T s0 = 0, s1 = 0;
         if (FFT) {
-            s0 = fre[fc_brev(n, lgL)];
+            s0 = fout[n];
         } else {
             int k = 0;
             for (; k + 1 < klim; k += 2) {
@@ -327,7 +348,7 @@ static int fftcep_launch(bool bwd, const void* gout, const void* x, int64_t F, i
         return e && atoi(e) != 0;
     }();
     if (n_iter > 0 && L >= 32 && (L & (L - 1)) == 0 && !direct_only) {   // full H x H products: FFT in LDS
-        const size_t lds_fft = lds + sizeof(T) * 3 * (size_t)L;
+        const size_t lds_fft = lds + sizeof(T) * (2 * (size_t)L + H);   // transform halves, real results, twiddles
         // one wave per frame (DSA_FFTCEP_BLOCK overrides for A/B): the barriers between the butterfly passes become single-wave
         // barriers and a compute unit holds four times as many frames
         static const int forced = [] { const char* e = getenv("DSA_FFTCEP_BLOCK"); return e ? atoi(e) : 0; }();
