@@ -363,3 +363,46 @@ def test_fbank_bins_table_c_and_python_agree_and_reproduce_the_matrix():
     t = np.zeros(4 * 257, dtype=np.float32)
     assert lib.dsa_fbank_bins_plan(np.ascontiguousarray(Hb).ctypes.data, 257, 5, t.ctypes.data) == _lib.ERR_UNSUPPORTED
     assert tables.fbank_bins_table(Hb) is None
+
+
+def test_round3_host_tables_and_dispatch_rules():
+    """Host-side pieces added in round 3 (no GPU): the folded cepstrum -> spectrum matrices against the two-step numpy
+    computation they replace, the backward operand images of the mgcep step against the matrices they are cut from, and the
+    shape rules that route row products / Taylor stages / the composed analysis."""
+    import torch
+
+    from diffsptk_amd import ops
+    from diffsptk_amd.utils import tables
+
+    # mgc2sp: frequency transform to order L/2, then Re / Im of the L-point transform == one matrix each
+    rng = np.random.default_rng(0)
+    for M, L, alpha in ((24, 512, -0.42), (8, 32, -0.1), (30, 64, 0.0)):
+        W_re, W_im = tables.cepstrum_to_spectrum_matrices(M, L, alpha)
+        c = rng.standard_normal((5, M + 1))
+        A = tables.freqt_matrix(M, L // 2, alpha) if alpha != 0 else np.eye(M + 1, L // 2 + 1)
+        C = np.fft.rfft(c @ A, n=L)
+        np.testing.assert_allclose(c @ W_re, C.real, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(c @ W_im, C.imag, rtol=1e-10, atol=1e-12)
+    # mgcep step, backward images: tile 3, the transposed Pr block (k-step 2) and the Cr block (t = 1, r = 2)
+    M, alpha = 24, 0.42
+    m = tables.mgcep_matrices(512, M, alpha)
+    img = tables.mgcep_step_bwd_images(512, M, alpha).astype(np.float64)
+    assert img.shape == (17, 768 + 44 * 64 + 16 * 64)
+    np.testing.assert_array_equal(img[:, :768], tables.mgcep_step_images(512, M, alpha)[:, :768].astype(np.float64))
+    lanes = np.arange(64)
+    li, lg = lanes & 15, lanes >> 4
+    a2 = img[3, 768:768 + 44 * 64].reshape(44, 64)
+    np.testing.assert_allclose(a2[2], m["Pr"][:, :M][16 * 3 + li, 4 * 2 + lg].astype(np.float32), rtol=0, atol=0)
+    a3 = img[3, 768 + 44 * 64:].reshape(2, 2, 4, 64)
+    row = 1 + 16 * 1 + li
+    want = np.where(row <= M, m["Cr"][np.minimum(row, M), 16 * 3 + 4 * lg + 2], 0.0).astype(np.float32)
+    np.testing.assert_allclose(a3[0, 1, 2], want, rtol=0, atol=0)
+    # dispatch rules
+    assert ops._row_product_is_plain_gemm(12800, 50, 1025, 4) and ops._row_product_is_plain_gemm(12800, 1025, 99, 4)
+    assert not ops._row_product_is_plain_gemm(51200, 25, 200, 4)          # fits LDS
+    assert not ops._row_product_is_plain_gemm(51200, 200, 25, 4)          # short rows keep the library's kernel
+    assert not ops._row_product_is_plain_gemm(100, 50, 1025, 4)           # tiny batch
+    x, b = torch.zeros(2, 160), torch.zeros(2, 2, 40)
+    assert not ops.zerodf_taylor_shapes_ok(x, b, 80)                       # host tensors never take the fused launches
+    assert ops._mcep_composed_applies(None, 49, 12800) and not ops._mcep_composed_applies(None, 64, 12800)
+    assert not ops._mcep_composed_applies(None, 49, 100)
