@@ -10,9 +10,10 @@ All computation runs in hand-written HIP kernels (diffsptk_amd/csrc) through the
 include/diffsptk_amd.h.  There is no CPU fallback.
 """
 from . import functional
+from .graph import Graphed
 from .modules import *  # noqa: F401,F403
 from .modules import __all__ as _module_names
 from .utils.public import get_alpha, read
 
 __version__ = "0.1.0"
-__all__ = [*_module_names, "functional", "get_alpha", "read"]
+__all__ = [*_module_names, "functional", "get_alpha", "read", "Graphed"]

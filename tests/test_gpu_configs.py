@@ -436,3 +436,49 @@ def test_untuned_geometries_forward_as_whole_batch_launches(monkeypatch, fl, fp,
     monkeypatch.delenv("DSA_MCEP_COMPOSED")
     err = float((Xc.grad.double() - Xd.grad).abs().max() / Xd.grad.abs().max())
     assert err < 2e-4, err
+
+
+def test_hot_path_and_f_rows_replay_from_a_hip_graph():
+    """The launches of the analysis (STFT -> mcep), of the mel-generalized analysis and of the multi-stage MLSA filter are plain
+    asynchronous launches on the current stream with caller-owned workspaces, so a whole call can be captured in a HIP graph
+    (torch.cuda.CUDAGraph) and replayed on new data in the static input buffers: bit-identical to the eager call.  (Small
+    batches are launch-bound from Python -- 20 .. 45 launches of 20 .. 90 us; a replay is one submission.)"""
+    stft, mcep = _modules()
+    mg = dsp.MelGeneralizedCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, gamma=-0.5, n_iter=4, device=DEV)
+    ml = dsp.MLSA(24, 80, alpha=0.42, mode="multi-stage", taylor_order=8, device=DEV)
+    gen = torch.Generator().manual_seed(9)
+    x_static = torch.randn(16, 8000, generator=gen).to(DEV)
+
+    def step(x):
+        X = stft(x)
+        mc = mcep(X)
+        return mc, mg(X), ml(x, mc[:, :100])
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():      # warm-up on the capture stream: images, LDS attributes, scratch, allocator
+        for _ in range(2):
+            step(x_static)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(graph, stream=side):
+        outs_static = step(x_static)
+    for seed in (1, 2):
+        x_new = torch.randn(16, 8000, generator=torch.Generator().manual_seed(seed)).to(DEV)
+        with torch.no_grad():
+            want = step(x_new)
+        x_static.copy_(x_new)
+        graph.replay()
+        torch.cuda.synchronize()
+        for got, ref in zip(outs_static, want):
+            assert torch.equal(got, ref)
+    # the packaged form: diffsptk_amd.Graphed
+    g = dsp.Graphed(step, x_static)
+    x_new = torch.randn(16, 8000, generator=torch.Generator().manual_seed(5)).to(DEV)
+    with torch.no_grad():
+        want = step(x_new)
+    got = g(x_new)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    with pytest.raises(ValueError):
+        g(x_new[:8])
