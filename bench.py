@@ -465,10 +465,10 @@ def main():
                     help="N > 1: utterance chunks per step.  1 (default): one in-place all-gather per step, deferred "
                          "behind the next step's kernels; > 1: chunked gather/compute overlap inside the step")
     ap.add_argument("--streams", type=int, default=1,
-                    help="N = 1: with 2, consecutive steps alternate between two streams, so the next step's STFT fills the "
-                         "tail of the persistent mel-cepstral kernel (steps are independent batches): +2.5 %% frames/s, "
-                         "+7 %% without the instrumented steps (tools/ab_pipeline.py); default 1 keeps the per-kernel "
-                         "timings of the roofline objects undisturbed")
+                    help="N = 1: with 2, consecutive steps alternate between two streams, so the next step's STFT can fill the "
+                         "tail of the persistent mel-cepstral kernel (steps are independent batches).  Round 2: +2.5 %% frames/s; "
+                         "with the round-3 kernel (shorter tail, power-limited clock) it costs 3 %% (tools/ab_streams.sh: 3.28e8 vs "
+                         "3.19e8), so the default stays 1 -- which also keeps the per-kernel timings of the roofline objects clean")
     ap.add_argument("--record-every", type=int, default=4,
                     help="HIP events bracket the two launches of every n-th step of the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
