@@ -34,6 +34,8 @@ FBANK_PLAN_FLOATS = 2048   # DSA_FBANK_PLAN_FLOATS
 ERR_UNSUPPORTED = -2       # DSA_ERR_UNSUPPORTED
 ALGO_AUTO, ALGO_GENERIC, ALGO_TUNED = 0, 1, 2
 ALGO_SCRATCH_IS_CLEAN = 0x100   # DSA_ALGO_SCRATCH_IS_CLEAN
+ALGO_SCRATCH_HAS_WORKSPACE = 0x200   # DSA_ALGO_SCRATCH_HAS_WORKSPACE
+MCEP_BWD_WORKSPACE_BYTES = SCRATCH_BYTES + 512 * 16 * 32 * 4   # DSA_MCEP_BWD_WORKSPACE_BYTES
 
 _lib = None
 

@@ -340,7 +340,7 @@ int mcep_mfma_prepare(const void* G, const void* D, const void* E, void* images,
 int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E, const void* av,
                   const void* images, void* scratch, void* mc, void* hist, hipStream_t st, bool scratch_clean = false);
 int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* av,
-                  const void* images, void* scratch, void* gX, hipStream_t st);
+                  const void* images, void* scratch, void* gX, hipStream_t st, bool has_workspace = false);
 
 }  // namespace dsa
 
@@ -449,13 +449,15 @@ DSA_EXPORT int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist,
     DSA_REQUIRE(mc_hist != nullptr, "mcep_bwd: the forward history is required");
     if (F == 0) return DSA_OK;
     hipStream_t st = (hipStream_t)stream;
+    const bool has_workspace = (algo & DSA_ALGO_SCRATCH_HAS_WORKSPACE) != 0;
+    algo &= ~DSA_ALGO_SCRATCH_HAS_WORKSPACE;
     bool tuned_ok = mcep_mfma_supported(nfft, M, dtype) != 0;
     if (algo == DSA_ALGO_TUNED && !tuned_ok)
         return fail(DSA_ERR_UNSUPPORTED, "mcep_bwd: tuned kernel needs float32, fft_length 512, cep_order 24%s");
     if (algo == DSA_ALGO_TUNED && !(images && scratch))
         return fail(DSA_ERR_INVALID_ARGUMENT, "mcep_bwd: the tuned kernel needs the prepared images (dsa_mcep_prepare) and a scratch buffer%s");
     if (tuned_ok && algo != DSA_ALGO_GENERIC && images && scratch)
-        return mcep_mfma_bwd(gmc, X, mc_hist, F, n_iter, alpha_vec, images, scratch, gX, st);
+        return mcep_mfma_bwd(gmc, X, mc_hist, F, n_iter, alpha_vec, images, scratch, gX, st, has_workspace);
     if (dtype == DSA_F32) return mcep_generic_bwd<float>(gmc, X, mc_hist, F, nfft, M, n_iter, G, D, E, alpha_vec, gX, st);
     if (dtype == DSA_F64) return mcep_generic_bwd<double>(gmc, X, mc_hist, F, nfft, M, n_iter, G, D, E, alpha_vec, gX, st);
     return fail(DSA_ERR_UNSUPPORTED, "mcep_bwd: unsupported dtype%s");

@@ -578,20 +578,34 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
 }
 
 int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* av,
-                  const void* images, void* scratch, void* gX, hipStream_t st)
+                  const void* images, void* scratch, void* gX, hipStream_t st, bool has_workspace)
 {
     const int lds_bytes = mhb::B_LDS_FLOATS * 4;
     static std::atomic<uint64_t> attr_devices{0};
     if (!ensure_dynamic_lds((const void*)mcep_mfma_bwd_kernel_h, lds_bytes, attr_devices))
         return fail(DSA_ERR_LAUNCH, "mcep_mfma_bwd: cannot reserve the LDS operand images%s");
-    unsigned int* queue = reset_queue(scratch, st);
+    unsigned int* queue = reset_queue(scratch, st, 13);
     if (!queue) return fail(DSA_ERR_LAUNCH, "mcep_mfma_bwd: cannot reset the tile queue%s");
     long ntiles16 = (long)((F + 15) / 16);
     long blocks = (ntiles16 + mhb::WAVES_B - 1) / mhb::WAVES_B;
     long grid = blocks < 256 ? blocks : 256;
+    // A last round that fills at most half of the wave slots is cut into pieces of Newton steps (see the kernel) when the caller's
+    // scratch carries the hand-over workspace behind the counters (DSA_ALGO_SCRATCH_HAS_WORKSPACE); DSA_MCEP_SPLIT=0: A/B
+    static const bool split_on = [] { const char* e = getenv("DSA_MCEP_SPLIT"); return !(e && e[0] == '0'); }();
+    const long slots = grid * mhb::WAVES_B, rounds = ntiles16 / slots, rest = ntiles16 - rounds * slots;
+    int split_tiles = 0, split_pieces = 0;
+    if (has_workspace && split_on && rounds >= 1 && rest > 0 && rest <= slots / 2 && rest <= 512 && n_iter >= 2) {
+        long pieces = slots / rest;
+        if (pieces > n_iter) pieces = n_iter;
+        if (pieces > rounds + 1) pieces = rounds + 1;
+        if (pieces > 9) pieces = 9;   // one counter word of the scratch per piece level
+        split_tiles = (int)rest;
+        split_pieces = (int)pieces;
+    }
     hipLaunchKernelGGL(mcep_mfma_bwd_kernel_h, dim3((unsigned)grid), dim3(256), lds_bytes, st, (const float*)gmc,
                        (const float*)X, (const float*)hist, (long)F, n_iter, (const float*)av, (float*)gX, ntiles16, queue,
-                       (const _Float16*)images);
+                       (const _Float16*)images, split_tiles, split_pieces,
+                       reinterpret_cast<float*>(static_cast<char*>(scratch) + DSA_SCRATCH_BYTES));
     return check_launch("mcep_mfma_bwd");
 }
 

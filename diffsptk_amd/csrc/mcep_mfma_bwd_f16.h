@@ -42,7 +42,8 @@ constexpr int B_D256 = B_E256 + 52 + 64;              // [32] -2 log2(e) D[c][25
 constexpr int B_AV = B_D256 + 64;                     // [28]
 constexpr int B_NAV = B_AV + 28;                      // [28] -alpha_vec, zero-padded
 constexpr int B_ZERO = B_NAV + 28;                    // [28] zeros
-constexpr int B_WAVE = B_ZERO + 28;
+constexpr int B_SLOT = B_ZERO + 28;                   // [4] the workgroup's first wave-slot number (split tail)
+constexpr int B_WAVE = B_SLOT + 4;
 constexpr int FS = 180;                               // per-frame record: rt [0,52) | rr [52,116) | aux [116,180)
 constexpr int B_WAVE_FLOATS = 16 * FS;
 constexpr int B_LDS_FLOATS = B_WAVE + WAVES_B * B_WAVE_FLOATS;
@@ -97,8 +98,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo
 
 __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
     const float* __restrict__ gmc, const float* __restrict__ X, const float* __restrict__ hist, long F, int n_iter,
-    const float* __restrict__ av, float* __restrict__ gX, long ntiles16, unsigned int* __restrict__ queue,
-    const _Float16* __restrict__ img)
+    const float* __restrict__ av, float* gX, long ntiles16, unsigned int* __restrict__ queue,
+    const _Float16* __restrict__ img, int split_tiles, int split_pieces, float* ws)
 {
     using namespace mhb;
     constexpr float kNeg2Log2e = -2.885390081777926815f;
@@ -137,6 +138,13 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
         lds[B_NAV + tid] = -a_;
         lds[B_ZERO + tid] = 0.f;
     }
+    // Split tail (split_tiles = R > 0; host: the launch would end in a round of R <= slots / 2 tiles, most wave slots idle for
+    // a whole tile).  The backward sweep of a tile carries only (lbar, mbar) from step to step, so the LAST R tiles are cut into
+    // P pieces of ~n_iter / P steps that hand (lbar -> the tile's rows of gX, mbar -> ws) over through memory, and R P slots each
+    // take ONE piece next to their whole tiles: slot s = p R + j runs piece p of split tile j after its first p whole tiles, a
+    // whole tile apart from piece p - 1.  Slot numbers come in ARRIVAL order (one atomic per workgroup): a wave only ever waits
+    // for slots that started before it, whatever the dispatch order.  One wave per SIMD here: the slots run at one speed.
+    if (split_tiles > 0 && tid == 0) reinterpret_cast<unsigned*>(lds + B_SLOT)[0] = atomicAdd(queue + 12, (unsigned)WAVES_B);
     __syncthreads();
 
     float* wave_lds = lds + B_WAVE + wave * B_WAVE_FLOATS;
@@ -158,10 +166,33 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
     const f16x8* DBH = reinterpret_cast<const f16x8*>(lds) + lane_c;
     const f16x8* DBL = DBH + IMG_DB / 8;
     const f32x4* E484 = reinterpret_cast<const f32x4*>(lds + B_E48);
-    const long wave_id = (long)blockIdx.x * WAVES_B + wave;
+    long wave_id = (long)blockIdx.x * WAVES_B + wave;
     const long wave_stride = (long)gridDim.x * WAVES_B;
-
-    for (long tile = wave_id; tile < ntiles16;) {
+    const long nwhole = ntiles16 - split_tiles;   // tiles [0, nwhole) run whole, [nwhole, ntiles16) in pieces
+    int piece_mine = -1, split_j = 0;
+    if (split_tiles > 0) {
+        wave_id = (long)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const unsigned*>(lds + B_SLOT)[0]) + wave;
+        const int pm = (int)(wave_id / split_tiles);
+        if (pm < split_pieces) { piece_mine = pm; split_j = (int)(wave_id - (long)pm * split_tiles); }
+    }
+    long tile_whole = wave_id;   // the next whole tile of this wave (>= nwhole: none left)
+    int whole_started = 0;
+    for (;;) {
+        // ---- this round's work item: a whole tile, or this wave's piece of a split tile (steps it_hi - 1 .. it_lo) ----
+        long tile;
+        int it_hi = n_iter, it_lo = 0;
+        bool is_piece = false;
+        if (piece_mine >= 0 && (whole_started >= piece_mine || tile_whole >= nwhole)) {
+            is_piece = true;
+            tile = nwhole + split_j;
+            it_hi = n_iter - (int)((long)piece_mine * n_iter / split_pieces);
+            it_lo = n_iter - (int)((long)(piece_mine + 1) * n_iter / split_pieces);
+        } else if (tile_whole < nwhole) {
+            tile = tile_whole;
+            ++whole_started;
+        } else {
+            break;
+        }
         const long f_raw = tile * 16 + n;
         const bool f_ok = f_raw < F;
         const long f = f_ok ? f_raw : F - 1;
@@ -177,16 +208,41 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
         float lbar256 = 0.f;
         // mbar in the C/D layout of a 32-row product: tile it2, register r <-> coefficient 16 it2 + 4 g + r
         f32x4 mbarC[2];
+        if (it_hi < n_iter) {
+            // a later piece: (lbar, mbar) as the previous piece left them, once ALL pieces of that level have been published
+            // (device-coherent loads of just these values: a device-scope fence would flush the XCD's L2 under everyone)
+            if (lane == 0)
+                while (__hip_atomic_load(queue + 2 + piece_mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)split_tiles)
+                    __builtin_amdgcn_s_sleep(64);
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            const float* gxf = gX + f * K;
 #pragma unroll
-        for (int it2 = 0; it2 < 2; ++it2)
+            for (int mt = 0; mt < 16; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = it2 * 16 + 4 * g + r;
-                mbarC[it2][r] = c < M1 ? gmc[f * M1 + c] : 0.f;
-            }
-        unsigned int nxt = 0;
-        if (lane == 0) nxt = atomicAdd(queue, 1u);
-        const long tile_next = wave_stride + (long)__builtin_amdgcn_readfirstlane((int)nxt);
+                for (int r = 0; r < 4; ++r)
+                    lbar[mt][r] = __hip_atomic_load(gxf + mt * 16 + 4 * g + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lbar256 = __hip_atomic_load(gxf + H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float* wsf = ws + ((long)split_j * 16 + n) * 32;
+#pragma unroll
+            for (int it2 = 0; it2 < 2; ++it2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    mbarC[it2][r] = __hip_atomic_load(wsf + it2 * 16 + 4 * g + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+#pragma unroll
+            for (int it2 = 0; it2 < 2; ++it2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = it2 * 16 + 4 * g + r;
+                    mbarC[it2][r] = c < M1 ? gmc[f * M1 + c] : 0.f;
+                }
+        }
+        if (!is_piece) {   // (a piece leaves the ticket already held untouched)
+            unsigned int nxt = 0;
+            if (lane == 0) nxt = atomicAdd(queue, 1u);
+            tile_whole = wave_stride + (long)__builtin_amdgcn_readfirstlane((int)nxt);
+        }
 
 #ifdef DSA_MCEP_TIMING   // branch-free phase stamps in scalar registers, flushed at the end of the step (see DSA_STAMP)
 #define BSTAMP(i) bst_[i] = (unsigned)__builtin_readcyclecounter()
@@ -204,8 +260,8 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             for (int c = 0; c < KS - 1; ++c) { h0_n[c] = h0[gs + 4 * c]; h1_n[c] = h1[gs + 4 * c]; }
             h0_n[KS - 1] = h0[M1 - 1]; h1_n[KS - 1] = h1[M1 - 1];
         };
-        load_step(n_iter - 1);
-        for (int iter = n_iter - 1; iter >= 0; --iter) {
+        load_step(it_hi - 1);
+        for (int iter = it_hi - 1; iter >= it_lo; --iter) {
 #ifdef DSA_MCEP_TIMING
             unsigned bst_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -666,6 +722,31 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
 #endif
         }
 
+        if (it_lo > 0) {
+            // hand over: lbar into the tile's rows of gX (the last piece overwrites them with gX), mbar into ws; written through
+            // to device scope and acknowledged, then the level's counter
+            float* gxf = gX + f * K;
+            float* wsf = ws + ((long)split_j * 16 + n) * 32;
+            if (f_ok) {
+#pragma unroll
+                for (int mt = 0; mt < 16; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __hip_atomic_store(gxf + mt * 16 + 4 * g + r, lbar[mt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (g == 0) __hip_atomic_store(gxf + H, lbar256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int it2 = 0; it2 < 2; ++it2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    __hip_atomic_store(wsf + it2 * 16 + 4 * g + r, mbarC[it2][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) atomicAdd(queue + 3 + piece_mine, 1u);
+            piece_mine = -1;
+            continue;
+        }
+        if (is_piece) piece_mine = -1;
         // ---------------- lbar += G mbar_0 (mcep.py:204-207 adjoint); gX = lbar / X ----------------
 #pragma unroll
         for (int it2 = 0; it2 < 2; ++it2)
@@ -710,7 +791,6 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             }
         }
         if (f_ok && g == 0) gX[f * K + H] = lbar256 * __builtin_amdgcn_exp2f(-logx256);
-        tile = tile_next;
     }
 }
 

@@ -851,10 +851,15 @@ class McepFn(torch.autograd.Function):
         F = Xc.numel() // K
         gX = torch.empty_like(Xc)
         images = ctx.images
-        scratch = _scratch(gmc.device) if images is not None else None
+        # the tuned kernel's scratch with the hand-over area of its split tail (DSA_ALGO_SCRATCH_HAS_WORKSPACE): 1 MB from the
+        # caching allocator, stream-ordered
+        scratch, flag = None, 0
+        if images is not None:
+            scratch = torch.empty(_lib.MCEP_BWD_WORKSPACE_BYTES, dtype=torch.uint8, device=gmc.device)
+            flag = _lib.ALGO_SCRATCH_HAS_WORKSPACE
         with torch.cuda.device(gmc.device):
             _call("dsa_mcep_bwd", _p(gmc), _p(Xc), _p(hist), F, fft_length, M, n_iter, _p(G), _p(D), _p(E),
-                  _p(av), _dtype_code(Xc), algo, _p(images), _p(scratch), _p(gX), _stream())
+                  _p(av), _dtype_code(Xc), algo | flag, _p(images), _p(scratch), _p(gX), _stream())
         return (gX,) + (None,) * 8
 
 

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 118 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch), dsa_mgcep_step */
+#define DSA_VERSION 119 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch), dsa_mgcep_step */
 
 typedef enum {
     DSA_OK = 0,
@@ -74,6 +74,11 @@ enum { DSA_ALGO_AUTO = 0, DSA_ALGO_GENERIC = 1, DSA_ALGO_TUNED = 2 };
  * by one call at a time; the library then skips its per-call reset (a 5 us fill launch and a kernel boundary per call) -- the
  * persistent kernel leaves the counters zeroed when its last wave retires, with or without this flag. */
 #define DSA_ALGO_SCRATCH_IS_CLEAN 0x100
+/* OR-ed into `algo` of dsa_mcep_bwd: `scratch` is DSA_MCEP_BWD_WORKSPACE_BYTES long (the counters + a hand-over area).  The tuned
+ * backward then cuts a short last round of tiles into pieces of Newton steps that pass their state through it, so that every wave
+ * slot ends the launch busy (3 200 tiles on 1 024 slots: 3.3 rounds instead of 4).  Without the flag: DSA_SCRATCH_BYTES, no split. */
+#define DSA_ALGO_SCRATCH_HAS_WORKSPACE 0x200
+#define DSA_MCEP_BWD_WORKSPACE_BYTES (DSA_SCRATCH_BYTES + 512 * 16 * 32 * 4)
 
 int dsa_version(void);
 const char* dsa_last_error(void);

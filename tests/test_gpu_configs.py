@@ -438,6 +438,31 @@ def test_untuned_geometries_forward_as_whole_batch_launches(monkeypatch, fl, fp,
     assert err < 2e-4, err
 
 
+@pytest.mark.parametrize("tail_tiles,tail_frames", [(8, 8 * 16 - 13), (512, 512 * 16), (37, 37 * 16 - 1)])
+def test_mcep_backward_split_tail_is_bit_identical_to_whole_tiles(tail_tiles, tail_frames):
+    """The tuned backward cuts a short last round of tiles into pieces of Newton steps that hand (lbar, mbar) over through
+    memory (csrc/mcep_mfma_bwd_f16.h, DSA_ALGO_SCRATCH_HAS_WORKSPACE).  Frames are independent and a piece repeats the whole
+    tile's arithmetic step by step, so the gradient of the tail frames must equal BIT FOR BIT what a launch of those frames
+    alone (fewer tiles than wave slots: no split) computes -- for 2 / 9 / 3 pieces, ragged last tiles included."""
+    _, mcep = _modules()
+    gen = torch.Generator().manual_seed(tail_tiles)
+    F = 2 * 1024 * 16 + tail_frames                      # two full rounds of the 1024 wave slots + the tail
+    X = (torch.randn(F, 257, generator=gen).square() + 0.05).to(DEV)
+    w = torch.randn(25, generator=gen).to(DEV)
+
+    def grad(Xin):
+        Xg = Xin.clone().requires_grad_(True)
+        (mcep(Xg) * w).sum().backward()
+        return Xg.grad
+
+    g_all = grad(X)
+    g_tail = grad(X[-tail_frames:])
+    assert torch.isfinite(g_all).all()
+    assert torch.equal(g_all[-tail_frames:], g_tail)
+    # and the whole tiles of the same launch against a launch of their own
+    assert torch.equal(g_all[:4096], grad(X[:4096]))
+
+
 def test_hot_path_and_f_rows_replay_from_a_hip_graph():
     """The launches of the analysis (STFT -> mcep), of the mel-generalized analysis and of the multi-stage MLSA filter are plain
     asynchronous launches on the current stream with caller-owned workspaces, so a whole call can be captured in a HIP graph
