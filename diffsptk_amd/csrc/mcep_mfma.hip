@@ -578,7 +578,7 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
 }
 
 int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* av,
-                  const void* images, void* scratch, void* gX, hipStream_t st, bool has_workspace)
+                  const void* images, void* scratch, void* gX, hipStream_t st, bool has_workspace = false)
 {
     const int lds_bytes = mhb::B_LDS_FLOATS * 4;
     static std::atomic<uint64_t> attr_devices{0};
