@@ -38,10 +38,19 @@ def _mirror(x: torch.Tensor, half: bool = False) -> torch.Tensor:
 
 
 
-def _taylor_stages(x: torch.Tensor, c: torch.Tensor, P: int, z0: int, order: int) -> torch.Tensor:
+def _taylor_stages(x: torch.Tensor, c: torch.Tensor, P: int, z0: int, order: int, a: torch.Tensor | None = None) -> torch.Tensor:
     """exp(F) x ~ sum_i F^i x / i!  (mglsadf.py:356-365): x <- F x / i, y <- y + x, `order` times.  Without a graph a stage
     (filter, 1 / i, running sum) is ONE launch, rounded like the three operations it replaces; with one, the differentiable
     filter and two element-wise operations per stage."""
+    if a is not None:
+        # learnable=True (mglsadf.py:344-349, 376-379): term i enters the sum times a[i] (a starts as ones): the differentiable
+        # filter per stage, element-wise scale and sum, so that autograd also reaches a
+        y = x * a[0]
+        cur = x
+        for i in range(1, order + 1):
+            cur = ops.zerodf(cur, c, P, z0, False) * (1.0 / i)
+            y = y + cur * a[i]
+        return y
     if order >= 1 and ops.zerodf_taylor_shapes_ok(x, c, P) and torch.is_grad_enabled() and (x.requires_grad or c.requires_grad):
         return ops.ZerodfTaylorFn.apply(x, c, P, z0, order)      # with a graph: one launch per stage in either direction
     if order >= 1 and ops.zerodf_taylor_supported(x, c, P):
@@ -84,10 +93,11 @@ class PseudoMGLSADigitalFilter(nn.Module):
             self.taylor_order = kwargs.pop("taylor_order", 20)
             cep_order = kwargs.pop("cep_order", 199)
             n_fft = kwargs.pop("n_fft", 512)
-            if kwargs.pop("learnable", False):
-                raise NotImplementedError("diffsptk_amd: learnable Taylor coefficients are not provided")
+            learnable = bool(kwargs.pop("learnable", False))
             if self.taylor_order < 0:
                 raise ValueError("taylor_order must be non-negative.")
+            # learnable=True: one weight per Taylor term, initialised to ones (mglsadf.py:344-349)
+            self.a = nn.Parameter(torch.ones(self.taylor_order + 1, device=device, dtype=dtype)) if learnable else None
             if alpha == 0 and gamma == 0:
                 cep_order = M
             self.cep_order = cep_order
@@ -131,10 +141,10 @@ class PseudoMGLSADigitalFilter(nn.Module):
             self.taylor_order = kwargs.pop("taylor_order", 20)
             co_max, co_min = pair(kwargs.pop("cep_order", 199))
             n_fft = kwargs.pop("n_fft", 512)
-            if kwargs.pop("learnable", False):
-                raise NotImplementedError("diffsptk_amd: learnable Taylor coefficients are not provided")
+            learnable = bool(kwargs.pop("learnable", False))
             if self.taylor_order < 0:
                 raise ValueError("taylor_order must be non-negative.")
+            self.a = nn.Parameter(torch.ones(self.taylor_order + 1, device=device, dtype=dtype)) if learnable else None
             if alpha == 0 and gamma == 0:                                    # mglsadf.py:281-282
                 co_max, co_min = N, M
             self.cep_orders = (co_max, co_min)
@@ -176,7 +186,7 @@ class PseudoMGLSADigitalFilter(nn.Module):
             c_min, c_max = self.mgc2c[0](mc_min), self.mgc2c[1](mc_max)
             c0 = c_min[..., :1] + c_max[..., :1]
             c = torch.cat((c_max[..., 1:].flip(-1), torch.zeros_like(c0), c_min[..., 1:]), dim=-1).contiguous()
-            y = _taylor_stages(x, c, P, self.cep_orders[0], self.taylor_order)
+            y = _taylor_stages(x, c, P, self.cep_orders[0], self.taylor_order, self.a)
             if not self.ignore_gain:
                 y = y * torch.exp(self.linear_intpl(c0)).squeeze(-1)
             return y
@@ -218,7 +228,7 @@ class PseudoMGLSADigitalFilter(nn.Module):
                 c, z0 = c.flip(-1), self.cep_order
             elif self.phase == "zero":
                 c, z0 = _mirror(c, half=True), self.cep_order
-            y = _taylor_stages(x, c, P, z0, self.taylor_order)
+            y = _taylor_stages(x, c, P, z0, self.taylor_order, self.a)
             if not self.ignore_gain:
                 y = y * torch.exp(self.linear_intpl(c0)).squeeze(-1)
             return y

@@ -304,6 +304,29 @@ def test_mlsa_filter_golden(golden, mode):
         assert np.abs(host(m(x, dev(g["mlsa_mc_c0"]))) - ref).max() < 1e-7 * np.abs(ref).max(), (mode, ph)
 
 
+def test_mlsa_learnable_taylor_weights(golden):
+    """learnable=True of the multi-stage filter (mglsadf.py:344-349, 376-379): one weight per Taylor term, initialised to ones --
+    same output as the fixed filter, and a gradient with respect to the weights: d/da_i of sum(gy * y) = sum(gy * K * x_i)."""
+    g = golden("mlsa")
+    x, mc = dev(g["mlsa_x"]), dev(g["mlsa_mc_c0"])
+    kw = dict(alpha=0.42, mode="multi-stage", taylor_order=5, cep_order=60, dtype=torch.float64, device=DEV)
+    fixed = dsp.MLSA(24, 80, **kw)
+    learn = dsp.MLSA(24, 80, learnable=True, **kw)
+    assert isinstance(learn.a, torch.nn.Parameter) and learn.a.shape == (6,) and bool((learn.a == 1).all())
+    y0, y1 = fixed(x, mc), learn(x, mc)
+    close(host(y1), host(y0), 1e-12, 1e-12)
+    gy = torch.randn(y1.shape, generator=torch.Generator().manual_seed(0), dtype=torch.float64).to(DEV)
+    (y1 * gy).sum().backward()
+    with torch.no_grad():   # the terms x_i K by differences of truncated filters
+        ys = [dsp.MLSA(24, 80, **{**kw, "taylor_order": k})(x, mc) for k in range(6)]
+        terms = [ys[0]] + [ys[k] - ys[k - 1] for k in range(1, 6)]
+        want = torch.stack([(gy * t).sum() for t in terms])
+    close(host(learn.a.grad), host(want), 1e-8, 1e-10)
+    with torch.no_grad():
+        learn.a[2] = 0.5
+    assert float((learn(x, mc) - y0).abs().max()) > 0
+
+
 def test_mlsa_gradients_and_analysis_synthesis(golden):
     g = golden("mlsa")
     x, mc = dev(g["mlsa_x"]).requires_grad_(True), dev(g["mlsa_mc_c0"]).requires_grad_(True)

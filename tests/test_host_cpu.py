@@ -406,3 +406,17 @@ def test_round3_host_tables_and_dispatch_rules():
     assert not ops.zerodf_taylor_shapes_ok(x, b, 80)                       # host tensors never take the fused launches
     assert ops._mcep_composed_applies(None, 49, 12800) and not ops._mcep_composed_applies(None, 64, 12800)
     assert not ops._mcep_composed_applies(None, 49, 100)
+
+
+def test_mlsa_learnable_constructs_on_the_host():
+    """learnable=True of the multi-stage MLSA filter: a Parameter of taylor_order + 1 ones (mglsadf.py:344-349); the other
+    arguments are checked as in the reference."""
+    import torch
+
+    import diffsptk_amd as dsp
+
+    m = dsp.MLSA(24, 80, alpha=0.42, mode="multi-stage", taylor_order=7, learnable=True)
+    assert isinstance(m.a, torch.nn.Parameter) and m.a.shape == (8,) and bool((m.a == 1).all())
+    assert dsp.MLSA(24, 80, alpha=0.42, mode="multi-stage").a is None
+    with pytest.raises(ValueError):
+        dsp.MLSA(24, 80, mode="multi-stage", taylor_order=-1)
