@@ -7,7 +7,6 @@ hand-written backward kernels).
 """
 from __future__ import annotations
 
-import math
 import os
 import weakref
 

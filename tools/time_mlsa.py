@@ -1,5 +1,5 @@
 """Timing of the MLSA filter modes at the bench size of the f rows (256 utterances x 1 s), float32 against float64 on four utterances."""
-import sys, os, time
+import sys, os
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import diffsptk_amd as dsp
