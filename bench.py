@@ -673,6 +673,10 @@ def main():
                         "code object, tools/isa_mix.py; per-instruction cycles measured with rocprofv3 --pmc on tools/bench_issue.cpp, "
                         "profiles/r03_issue_calibration.txt: multiply-add class 4, two-operand class 2, transcendental 8, 4x4x1 product 8) "
                         "x frames / measured launch time; peak = 1024 SIMDs x 2.4 GHz.  Two waves per SIMD (256 registers)",
+                "power": {"socket_W_under_this_kernel": [1371, 1379], "socket_W_under_stft": [1316, 1333], "cap_W": 1400,
+                          "source": "profiles/r03_power_probe.txt (static: tools/power_probe.sh, rocm-smi while the kernel loops)",
+                          "note": "both headline kernels run at the socket's power cap; the kernel's cycle counter averages "
+                                  "1.99-2.09 GHz over a launch, so the nominal-clock peak above is not reachable"},
             })(datapath_roofline(isa_mix("mcep_mfma_fwd_kernel_h"), N_ITER, frames_launch, t_mcep)),
             "roofline_stft": {
                 "kernel": kernels["stft"], "bound": "hbm",
