@@ -1054,41 +1054,61 @@ static int zerodf_launch_bwd(const void* gy, const void* x, const void* b, const
         // = taps [c KC, c KC + Mc], zeroth index z0 - c KC; gx accumulates over the pieces, gb's columns are disjoint
         const int npieces = (M + 1 + 199) / 200;
         const int KC = (((M + 1 + npieces - 1) / npieces) + 3) & ~3;
-        bool ok = true;
+        // feasibility of BOTH kernels for EVERY piece is decided before anything is launched (round 3 launched gx first and could
+        // then find that gb's rows did not fit LDS: P = 252 / 256 in float32, P >= 124 in float64 -- a half-written backward)
+        struct PiecePlan { int Mc, z0c, nf, nrows, nfw; size_t lds_x, lds_b; };
+        PiecePlan plan[64];
+        bool ok = npieces <= 64;
+        int np_used = 0;
+        constexpr int S = 4;   // (eight samples per thread -- 2/3 of the LDS reads per multiply-add, 160 of 256 threads at P = 80 -- measured slower)
         for (int c = 0; c < npieces && ok; ++c) {
-            const int Mc = ((M + 1 - c * KC) < KC ? (M + 1 - c * KC) : KC) - 1, z0c = z0 - c * KC;
-            if (Mc < 0) break;
+            PiecePlan& pl = plan[c];
+            pl.Mc = ((M + 1 - c * KC) < KC ? (M + 1 - c * KC) : KC) - 1;
+            pl.z0c = z0 - c * KC;
+            if (pl.Mc < 0) break;
+            np_used = c + 1;
+            pl.nf = pl.nrows = pl.nfw = 0;
+            pl.lds_x = pl.lds_b = 0;
             if (gx) {
-                constexpr int S = 4;   // (eight samples per thread -- 2/3 of the LDS reads per multiply-add, 160 of 256 threads at P = 80 -- measured slower)
-                const int dz = (4 - (((z0c % 4) + 4) & 3)) & 3, Mp = Mc + dz, NBt = (Mp + S - 1) / 4 + 1, RW = (Mp + S + 6 + 3) & ~3, nt = P / S;
+                const int dz = (4 - (((pl.z0c % 4) + 4) & 3)) & 3, Mp = pl.Mc + dz, NBt = (Mp + S - 1) / 4 + 1, RW = (Mp + S + 6 + 3) & ~3, nt = P / S;
                 int nf = 256 / nt;
                 if (nf > 16) nf = 16;
-                size_t lds_x = 0;
-                int nrows = 0;
                 for (; nf >= 1; --nf) {
-                    nrows = nf + (Mp + P - 1) / P + 2;      // frames the t range of nf output frames can touch
-                    lds_x = sizeof(T) * 2 * ((size_t)nrows * RW + (size_t)nf * P + 4 * NBt);
-                    if (nrows <= 24 && lds_x <= 64 * 1024) break;
+                    pl.nrows = nf + (Mp + P - 1) / P + 2;      // frames the t range of nf output frames can touch
+                    pl.lds_x = sizeof(T) * 2 * ((size_t)pl.nrows * RW + (size_t)nf * P + 4 * NBt);
+                    if (pl.nrows <= 24 && pl.lds_x <= 64 * 1024) break;
                 }
                 if (nf < 1) { ok = false; break; }
-                const long chunks = (N + nf - 1) / nf;
-                hipLaunchKernelGGL((zerodf_bwd_x_rows_kernel<T, S>), dim3((unsigned)(B * chunks)), dim3(256), lds_x, st, (const T*)gy,
-                                   (const T*)b + c * KC, (long)Tlen, (long)N, Mc, P, z0c, nf, nrows, M + 1, c > 0 ? 1 : 0, (T)scale,
+                pl.nf = nf;
+            }
+            if (gb) {
+                const int NBk = (pl.Mc + 4) / 4;
+                const int XL = (2 * P + pl.Mc + 8 + 3) & ~3;
+                int nfw = 256 / NBk;
+                if (nfw > 16) nfw = 16;
+                for (; nfw >= 1; --nfw) {                      // fewer frames per workgroup until their rows fit LDS
+                    pl.lds_b = sizeof(T) * (size_t)nfw * (2 * P + XL);
+                    if (pl.lds_b <= 64 * 1024) break;
+                }
+                if (nfw < 1) { ok = false; break; }
+                pl.nfw = nfw;
+            }
+        }
+        for (int c = 0; c < np_used && ok; ++c) {
+            const PiecePlan& pl = plan[c];
+            if (gx) {
+                const long chunks = (N + pl.nf - 1) / pl.nf;
+                hipLaunchKernelGGL((zerodf_bwd_x_rows_kernel<T, S>), dim3((unsigned)(B * chunks)), dim3(256), pl.lds_x, st, (const T*)gy,
+                                   (const T*)b + c * KC, (long)Tlen, (long)N, pl.Mc, P, pl.z0c, pl.nf, pl.nrows, M + 1, c > 0 ? 1 : 0, (T)scale,
                                    (const T*)gx_add, (T*)gx);
             }
             if (gb) {
-                const int NBk = (Mc + 4) / 4;
-                int nfw = 256 / NBk;
-                const int XL = (2 * P + Mc + 8 + 3) & ~3;
-                if (nfw > 16) nfw = 16;
-                const size_t lds_b = sizeof(T) * (size_t)(nfw > 0 ? nfw : 1) * (2 * P + XL);
-                if (nfw < 1 || lds_b > 64 * 1024) { ok = false; break; }
-                hipLaunchKernelGGL((zerodf_bwd_b_rows_kernel<T>), dim3((unsigned)((B * N + nfw - 1) / nfw)), dim3(256), lds_b, st, (const T*)gy,
-                                   (const T*)x, (long)Tlen, (long)N, (long)(B * N), Mc, P, z0c, nfw, M + 1, (T)scale, gb_accumulate ? 1 : 0,
-                                   (T*)gb + c * KC);
+                hipLaunchKernelGGL((zerodf_bwd_b_rows_kernel<T>), dim3((unsigned)((B * N + pl.nfw - 1) / pl.nfw)), dim3(256), pl.lds_b, st,
+                                   (const T*)gy, (const T*)x, (long)Tlen, (long)N, (long)(B * N), pl.Mc, P, pl.z0c, pl.nfw, M + 1, (T)scale,
+                                   gb_accumulate ? 1 : 0, (T*)gb + c * KC);
             }
         }
-        // (every piece has the same shape class, so `ok` fails on the first piece or never: nothing half-written)
+        // (nothing was launched unless every piece of both kernels fits)
         if (ok) return check_launch("zerodf_rows_bwd");
     }
     if (!plain) return fail(DSA_ERR_UNSUPPORTED, "zerodf_bwd: the scaled / accumulating form needs P % 4 == 0 and M >= 16%s");
@@ -1187,6 +1207,7 @@ __global__ __launch_bounds__(320) void mgcep_spectra_kernel(const T* __restrict_
 //   chains c: 0-1 Pr (input pp), 2-4 Qr (qq (X^2 - Y^2)), 5-7 Qi (qq 2XY), 8-9 Rr (pp X), 10-11 Ri (pp Y); 16-column tiles of each matrix.
 // ---------------------------------------------------------------------------------------------------------------------------
 typedef float ms_f4 __attribute__((ext_vector_type(4)));
+typedef float ms_f4u __attribute__((ext_vector_type(4), aligned(4)));   // rows of 257 floats: 4-byte aligned only
 constexpr int kMsTileFloats = 768 + 3072, kMsTiles = 17;
 __global__ __launch_bounds__(256) void mgcep_step_kernel(const float* __restrict__ x, const float* __restrict__ b1, long F, int M, float gamma,
                                                         const float* __restrict__ img, float* __restrict__ pt, float* __restrict__ qt,
@@ -1232,7 +1253,7 @@ __global__ __launch_bounds__(256) void mgcep_step_kernel(const float* __restrict
         if (mt + 1 < kMsTiles) fetch(mt + 1);
         // this lane's four spectrum values of the tile: bins 16 mt + 4 g + r (only bin 256 exists in the last tile)
         ms_f4 xv = {0.f, 0.f, 0.f, 0.f};
-        if (mt < 16) xv = *reinterpret_cast<const ms_f4*>(x + f * 257 + 16 * mt + 4 * g);
+        if (mt < 16) xv = *reinterpret_cast<const ms_f4u*>(x + f * 257 + 16 * mt + 4 * g);
         else if (g == 0) xv[0] = x[f * 257 + 256];
         const float* t1 = tile[buf];
         const ms_f4* t2 = reinterpret_cast<const ms_f4*>(tile[buf] + 768);
@@ -1350,7 +1371,7 @@ __global__ __launch_bounds__(256) void mgcep_step_bwd_kernel(const float* __rest
         const int buf = mt & 1;
         if (mt + 1 < kMsTiles) fetch(mt + 1);
         ms_f4 xv = {0.f, 0.f, 0.f, 0.f};
-        if (mt < 16) xv = *reinterpret_cast<const ms_f4*>(x + f * 257 + 16 * mt + 4 * g);
+        if (mt < 16) xv = *reinterpret_cast<const ms_f4u*>(x + f * 257 + 16 * mt + 4 * g);
         else if (g == 0) xv[0] = x[f * 257 + 256];
         const float* t1 = tile[buf];
         const float* t2 = tile[buf] + 768;
@@ -1399,8 +1420,8 @@ __global__ __launch_bounds__(256) void mgcep_step_bwd_kernel(const float* __rest
             if (mt < 16) {
                 float* dst = gx + f * 257 + 16 * mt + 4 * g;
                 ms_f4 o = {gxv[0], gxv[1], gxv[2], gxv[3]};
-                if (gx_in) o += *reinterpret_cast<const ms_f4*>(gx_in + f * 257 + 16 * mt + 4 * g);
-                *reinterpret_cast<ms_f4*>(dst) = o;
+                if (gx_in) o += *reinterpret_cast<const ms_f4u*>(gx_in + f * 257 + 16 * mt + 4 * g);
+                *reinterpret_cast<ms_f4u*>(dst) = o;
             } else if (g == 0) {
                 gx[f * 257 + 256] = gxv[0] + (gx_in ? gx_in[f * 257 + 256] : 0.f);
             }

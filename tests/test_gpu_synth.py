@@ -221,7 +221,8 @@ def test_zerodf_and_linear_intpl(golden):
 
 
 @pytest.mark.parametrize("M,P,z0,N", [(199, 80, 0, 31), (64, 80, 64, 4), (17, 8, 3, 70), (301, 128, 100, 5), (199, 80, 199, 13),
-                                      (23, 4, 2, 9), (1999, 80, 0, 3), (70, 5, 0, 6)])
+                                      (23, 4, 2, 9), (1999, 80, 0, 3), (70, 5, 0, 6),
+                                      (24, 256, 0, 6), (24, 252, 24, 5), (24, 124, 0, 7)])   # gb rows that needed fewer frames per workgroup
 def test_zerodf_backward_kernels_against_autograd_of_the_definition(M, P, z0, N):
     """The backward of the time-variant FIR (packed multi-frame kernels for M >= 16 and P % 4 == 0, the round-2 kernels
     otherwise) against autograd through the definition written with tensor operations (zerodf.py:207-243: interpolated taps
@@ -253,7 +254,8 @@ def test_zerodf_backward_kernels_against_autograd_of_the_definition(M, P, z0, N)
             assert float((got.double() - ref).abs().max()) < tol * float(ref.abs().max()), (M, P, z0, N, dt)
 
 
-@pytest.mark.parametrize("M,P,z0,N,order", [(199, 80, 0, 31, 20), (60, 80, 60, 5, 7), (300, 16, 100, 40, 3)])
+@pytest.mark.parametrize("M,P,z0,N,order", [(199, 80, 0, 31, 20), (60, 80, 60, 5, 7), (300, 16, 100, 40, 3), (24, 256, 0, 6, 5),
+                                            (24, 252, 0, 4, 3)])
 def test_taylor_stages_function_equals_the_stage_by_stage_graph(M, P, z0, N, order):
     """ops.ZerodfTaylorFn (one launch per stage forward, one call per stage backward: dsa_zerodf_taylor_fwd / _bwd) against the
     graph autograd builds from the differentiable filter and two element-wise operations per stage (mglsadf.py:356-365):

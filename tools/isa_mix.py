@@ -30,7 +30,17 @@ def disassemble(lib):
     tmp = "/tmp/isa_mix_%d" % os.getpid()
     os.makedirs(tmp, exist_ok=True)
     fat = os.path.join(tmp, "fat.bin")
-    subprocess.run([OBJDUMP.replace("objdump", "objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib], check=True)
+    # llvm-objcopy without an output operand REWRITES its input: work on a private copy and send the output to a scratch file,
+    # the product library is only ever read (tests/test_host_cpu.py checks its bytes before / after)
+    import shutil
+
+    priv = os.path.join(tmp, "lib_copy.so")
+    shutil.copyfile(lib, priv)
+    subprocess.run([OBJDUMP.replace("objdump", "objcopy"), "--dump-section", ".hip_fatbin=" + fat, priv, os.path.join(tmp, "lib_out.so")],
+                   check=True)
+    for f_ in (priv, os.path.join(tmp, "lib_out.so")):
+        if os.path.exists(f_):
+            os.remove(f_)
     data = open(fat, "rb").read()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
     kernels, pos, n = {}, 0, 0

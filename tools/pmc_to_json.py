@@ -20,19 +20,24 @@ WAVES_PER_SIMD = {"mcep_mfma_fwd": 2, "stft512_fwd": 4, "stft512_fbank_fwd": 4, 
 FRAMES = 204800
 
 acc = defaultdict(lambda: [0.0, 0])
-dirs = sys.argv[1].split(",")   # several pass directories (forward command, backward command) may be merged
-for f in sorted(g for d in dirs for g in glob.glob(d + "/p*/p*_counter_collection.csv")):
-    for row in csv.DictReader(open(f)):
-        for key, (pat, _) in KERNELS.items():
-            if pat in row["Kernel_Name"].replace("(int)", "").replace("(bool)", ""):
-                a = acc[(key, row["Counter_Name"])]
-                a[0] += float(row["Counter_Value"])
-                a[1] += 1
+dirs = sys.argv[1].split(",")   # several pass directories (forward command, backward command, ...)
+# A kernel's record comes from ONE command: the first directory in which it was dispatched.  Dispatches of the same kernel by
+# a later command (e.g. the with-history launch of mcep_mfma_fwd in the backward command) are kept apart under "<key>@<dir>".
+first_dir = {}
+for di, d in enumerate(dirs):
+    for f in sorted(glob.glob(d + "/p*/p*_counter_collection.csv")):
+        for row in csv.DictReader(open(f)):
+            for key, (pat, _) in KERNELS.items():
+                if pat in row["Kernel_Name"].replace("(int)", "").replace("(bool)", ""):
+                    k2 = key if first_dir.setdefault(key, di) == di else key + "@" + os.path.basename(d.rstrip("/"))
+                    a = acc[(k2, row["Counter_Name"])]
+                    a[0] += float(row["Counter_Value"])
+                    a[1] += 1
 out = {"source": sys.argv[2] if len(sys.argv) > 2 else sys.argv[1],
        "note": "KB per launch. Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 counts wide coalesced reads at half "
                "their bytes: hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; WRITE_SIZE is used as reported.",
        "kernels": {}}
-for key in KERNELS:
+for key in sorted({k for k, _ in acc}, key=lambda k: (k.split("@")[0] not in KERNELS, k)):
     c = {n: s / k for (kk, n), (s, k) in acc.items() if kk == key}
     if "FETCH_SIZE" not in c:
         continue
@@ -46,7 +51,7 @@ for key in KERNELS:
             "mfma_busy": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * cyc), 3),
             "lds_busy": round(c["SQ_LDS_IDX_ACTIVE"] / (256 * cyc), 3),
             "lds_conflict_frac": round(c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1), 3),
-            "waves_per_simd": WAVES_PER_SIMD[key],
+            "waves_per_simd": WAVES_PER_SIMD[key.split("@")[0]],
             "valu_insts_per_frame": round(c["SQ_INSTS_VALU"] / FRAMES, 1),
             "mfma_insts_per_frame": round(c.get("SQ_INSTS_MFMA", 0.0) / FRAMES, 1),
         },
