@@ -337,8 +337,13 @@ static int mcep_generic_bwd(const void* gmc, const void* X, const void* hist, in
 int mcep_mfma_supported(int nfft, int M, int dtype);
 int64_t mcep_mfma_images_bytes();
 int mcep_mfma_prepare(const void* G, const void* D, const void* E, void* images, hipStream_t st);
+struct StftIn;
 int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E, const void* av,
-                  const void* images, void* scratch, void* mc, void* hist, hipStream_t st, bool scratch_clean = false);
+                  const void* images, void* scratch, void* mc, void* hist, hipStream_t st, bool scratch_clean = false,
+                  const StftIn* sti = nullptr);
+int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, const void* window, const void* twiddle, double eps,
+                        int n_iter, const void* G, const void* D, const void* E, const void* av, const void* images, void* scratch,
+                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean);
 int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* av,
                   const void* images, void* scratch, void* gX, hipStream_t st, bool has_workspace = false);
 
@@ -437,6 +442,23 @@ DSA_EXPORT int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, i
     if (dtype == DSA_F32) return mcep_generic_fwd<float>(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);
     if (dtype == DSA_F64) return mcep_generic_fwd<double>(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);
     return fail(DSA_ERR_UNSUPPORTED, "mcep: unsupported dtype%s");
+}
+
+DSA_EXPORT int dsa_stft_mcep_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft, const void* window,
+                                 const void* twiddle, int32_t center, double eps, int32_t M, int32_t n_iter, const void* G,
+                                 const void* D, const void* E, const void* alpha_vec, int32_t dtype, int32_t algo,
+                                 const void* images, void* scratch, void* mc, void* mc_hist, void* X_out, void* stream)
+{
+    DSA_REQUIRE(B >= 0 && T >= 0 && P >= 1 && L >= 1 && n_iter >= 0, "stft_mcep: invalid sizes");
+    const bool scratch_clean = (algo & DSA_ALGO_SCRATCH_IS_CLEAN) != 0;
+    const int64_t N = T <= 0 ? 0 : (T - 1) / P + 1;
+    if (!(mcep_mfma_supported(nfft, M, dtype) && L == 400 && B * N < (int64_t(1) << 31) && T < (int64_t(1) << 31)))
+        return fail(DSA_ERR_UNSUPPORTED, "stft_mcep: the fused launch covers float32, frame_length 400, fft_length 512, cep_order 24%s");
+    DSA_REQUIRE(images && scratch, "stft_mcep: the prepared images (dsa_mcep_prepare) and a scratch buffer are required");
+    DSA_REQUIRE(x && window && twiddle && G && D && E && alpha_vec && mc, "stft_mcep: null pointer");
+    if (B * N == 0) return DSA_OK;
+    return stft_mcep_fused_fwd(x, B, T, P, center, window, twiddle, eps, n_iter, G, D, E, alpha_vec, images, scratch, mc, mc_hist,
+                               X_out, (hipStream_t)stream, scratch_clean);
 }
 
 DSA_EXPORT int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist, int64_t F, int32_t nfft,

@@ -553,13 +553,16 @@ static unsigned int* reset_queue(void* scratch, hipStream_t st, int words = 2)
     return (unsigned int*)scratch;
 }
 
+// `sti`: NULL (spectra in X) or the waveform side of the fused STFT -> mel-cepstrum launch (X is then unused)
 int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E, const void* av,
-                  const void* images, void* scratch, void* mc, void* hist, hipStream_t st, bool scratch_clean = false)
+                  const void* images, void* scratch, void* mc, void* hist, hipStream_t st, bool scratch_clean = false,
+                  const StftIn* sti = nullptr)
 {
     constexpr int WAVES = 8;
-    const int lds_bytes = mh::h_lds_floats(WAVES) * 4;
-    static std::atomic<uint64_t> attr_devices{0};
-    if (!ensure_dynamic_lds((const void*)mcep_mfma_fwd_kernel_h<WAVES>, lds_bytes, attr_devices))
+    const int lds_bytes = (sti ? mh::h_lds_floats_fused(WAVES) : mh::h_lds_floats(WAVES)) * 4;
+    static std::atomic<uint64_t> attr_devices{0}, attr_devices_fused{0};
+    if (!(sti ? ensure_dynamic_lds((const void*)mcep_mfma_fwd_kernel_h<WAVES, true>, lds_bytes, attr_devices_fused)
+              : ensure_dynamic_lds((const void*)mcep_mfma_fwd_kernel_h<WAVES, false>, lds_bytes, attr_devices)))
         return fail(DSA_ERR_LAUNCH, "mcep_mfma: cannot reserve the LDS operand images%s");
     long ntiles16 = (long)((F + 15) / 16);
     long blocks = (ntiles16 + WAVES - 1) / WAVES;
@@ -571,10 +574,35 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
     // see the ticket comment in the kernel: a short last round goes to one wave per SIMD pair
     const long slots = grid * WAVES, full = ntiles16 / slots * slots, rest = ntiles16 - full;
     const long tiles_shared = (full > 0 && rest > 0 && rest <= slots / 2) ? full : ntiles16;
-    hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
+    if (sti) {
+        hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES, true>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
+                           (const float*)nullptr, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
+                           (const float*)av, (float*)mc, (float*)hist, ntiles16, tiles_shared, queue, (const _Float16*)images, *sti);
+        return check_launch("stft512_mcep_fused_fwd");
+    }
+    hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES, false>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
                        (const float*)X, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
-                       (const float*)av, (float*)mc, (float*)hist, ntiles16, tiles_shared, queue, (const _Float16*)images);
+                       (const float*)av, (float*)mc, (float*)hist, ntiles16, tiles_shared, queue, (const _Float16*)images, StftIn{});
     return check_launch("mcep_mfma_fwd");
+}
+
+// STFT (frame length 400, fft_length 512, power format, constant padding) -> MelCepstralAnalysis (cep_order 24) in one launch
+int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, const void* window, const void* twiddle, double eps,
+                        int n_iter, const void* G, const void* D, const void* E, const void* av, const void* images, void* scratch,
+                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean)
+{
+    const int64_t N = T <= 0 ? 0 : (T - 1) / P + 1;
+    StftIn sti;
+    sti.x = (const float*)x;
+    sti.Tlen = (long)T;
+    sti.N = (long)N;
+    sti.P = P;
+    sti.left = center ? mh::FU_LC / 2 : 0;
+    sti.w = (const float*)window;
+    sti.twiddle = (const float*)twiddle;
+    sti.eps = (float)eps;
+    sti.X_out = (float*)X_out;
+    return mcep_mfma_fwd(nullptr, B * N, n_iter, G, D, E, av, images, scratch, mc, hist, st, scratch_clean, &sti);
 }
 
 int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* av,

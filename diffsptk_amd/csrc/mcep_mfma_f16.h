@@ -19,7 +19,21 @@
 // elimination) is the code of mcep_mfma_fwd_kernel_v2.
 #pragma once
 
+#include "pk_math.h"
+
 namespace dsa {
+
+// The waveform side of the fused STFT -> mel-cepstrum launch (stft.py:237-241 feeding mcep.py:189-224 without the (B, N, 257)
+// spectrogram's round trip through memory: 320 + 100 bytes per frame instead of 1348 + 1128).
+struct StftIn {
+    const float* x;        // (B, Tlen) waveforms
+    long Tlen, N;          // samples per utterance, frames per utterance
+    int P, left;           // frame period; samples of left padding (L / 2 with center, 0 without)
+    const float* w;        // (400) window
+    const float* twiddle;  // (512, 2) = (cos, -sin)(2 pi m / 512)
+    float eps;             // spec.py:173
+    float* X_out;          // NULL, or (B N, 257): the power spectrogram as a side product (kept for the backward)
+};
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -71,6 +85,18 @@ constexpr int H_NAV = H_AV + 28;         // [28] -alpha_vec, zero-padded
 constexpr int H_ZERO = H_NAV + 28;       // [28] zeros
 constexpr int H_WAVE = H_ZERO + 28;
 constexpr int h_lds_floats(int waves) { return H_WAVE + waves * WAVE_FLOATS; }
+// fused launch: three small tables behind the per-wave regions, shared by the workgroup
+constexpr int FU_LC = 400;                       // frame length the prologue is built for
+constexpr int FU_NR = (FU_LC + 31) / 32;         // sample pairs a lane reads (13)
+constexpr int FU_S = 272;                        // per-frame stride of the staged log-spectra (floats; 272 % 64 = 16: the 16 reading
+                                                 // lanes (4 frames x 4 groups) x 4 words cover the 64 banks exactly once)
+constexpr int FU_T256 = 0;                       // [16 k1][16 j] v2f: W256^(j k1) / 2
+constexpr int FU_WTAB = FU_T256 + 512;           // [16 j][13] v2f window pairs
+constexpr int FU_TWS = FU_WTAB + 2 * 16 * FU_NR; // [64 lane] (W512^(2l+1), W512^(2l+2)) as v4f
+constexpr int FU_FLOATS = FU_TWS + 256;
+static_assert(4 * 272 * 2 == WAVE_FLOATS, "a wave's rt / rr windows double as the STFT tile of four frames");
+static_assert(FU_TWS % 4 == 0 && H_WAVE % 4 == 0 && WAVE_FLOATS % 4 == 0, "16-byte aligned LDS tables");
+constexpr int h_lds_floats_fused(int waves) { return h_lds_floats(waves) + FU_FLOATS; }
 }  // namespace mh
 
 __device__ __forceinline__ f32x4 mfma_h(f16x8 a, f16x8 b, f32x4 c)
@@ -162,12 +188,12 @@ __device__ __forceinline__ void store_mc_row(float* row, int g, const float (&mc
     }
 }
 
-template <int WAVES>
+template <int WAVES, bool FUSED = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
     const float* __restrict__ X, long F, int n_iter, const float* __restrict__ G,
     const float* __restrict__ D, const float* __restrict__ E, const float* __restrict__ av,
     float* __restrict__ mc_out, float* __restrict__ hist, long ntiles16, long tiles_shared,
-    unsigned int* __restrict__ queue, const _Float16* __restrict__ img)
+    unsigned int* __restrict__ queue, const _Float16* __restrict__ img, StftIn sti)
 {
     using namespace mh;
     constexpr float kNeg2Log2e = -2.885390081777926815f, kLn2 = 0.693147180559945309f;
@@ -196,6 +222,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
         lds[H_AV + tid] = a_;
         lds[H_NAV + tid] = -a_;
         lds[H_ZERO + tid] = 0.f;
+    }
+    if (FUSED) {
+        // tables of the STFT prologue (csrc/stft_pk.h keeps the same three per wave / in registers)
+        float* fu = lds + h_lds_floats(WAVES);
+        v2f* t256w = reinterpret_cast<v2f*>(fu + FU_T256);
+        v2f* wtabw = reinterpret_cast<v2f*>(fu + FU_WTAB);
+        v2f* twsw = reinterpret_cast<v2f*>(fu + FU_TWS);
+        if (tid < 256) {
+            const int m = 2 * (tid & 15) * (tid >> 4);   // W256^(j k1) = W512^(2 j k1), halved: the 1/2 of the real-FFT split (exact)
+            t256w[tid] = v2f{0.5f * sti.twiddle[2 * m], 0.5f * sti.twiddle[2 * m + 1]};
+        } else if (tid < 256 + 16 * FU_NR) {
+            const int i = tid - 256;
+            const int l = 2 * (i / FU_NR) + 32 * (i % FU_NR);
+            wtabw[i] = v2f{l < FU_LC ? sti.w[l] : 0.f, l + 1 < FU_LC ? sti.w[l + 1] : 0.f};
+        }
+        if (tid < 128) {   // split twiddles W512^k of lane l's bins k = 2 l + 1, 2 l + 2
+            const int k = 2 * (tid >> 1) + 1 + (tid & 1);
+            twsw[tid] = v2f{sti.twiddle[2 * k], sti.twiddle[2 * k + 1]};
+        }
     }
     __syncthreads();  // the only workgroup barrier
 
@@ -247,15 +292,156 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
         const long f_raw = tile * 16 + n;
         const bool f_ok = f_raw < F;
         const long f = f_ok ? f_raw : F - 1;
-        const float* xf = X + f * K;
 
         f32x4 logx[16];
+        float logx256;
+        if (!FUSED) {
+            const float* xf = X + f * K;
 #pragma unroll
-        for (int mt = 0; mt < 16; ++mt) {
-            const float* p = xf + mt * 16 + 4 * g;
-            logx[mt] = f32x4{__log2f(p[0]), __log2f(p[1]), __log2f(p[2]), __log2f(p[3])};  // mcep.py:203 (base 2)
+            for (int mt = 0; mt < 16; ++mt) {
+                const float* p = xf + mt * 16 + 4 * g;
+                logx[mt] = f32x4{__log2f(p[0]), __log2f(p[1]), __log2f(p[2]), __log2f(p[3])};  // mcep.py:203 (base 2)
+            }
+            logx256 = __log2f(xf[H]);
+        } else {
+            // ---------------- fused: the tile's 16 power spectra straight from the waveform (stft.py:237-241) ----------------
+            // Four passes of four frames, each the pass of stft512_fwd_pk_kernel (csrc/stft_pk.h: 16 lanes per frame, window,
+            // radix-16 x 16 complex FFT of the 256 sample pairs through the wave's LDS region, real-FFT split with |.|^2 + eps on
+            // float32 with the packed kernel's roundings, so the power values are bit-identical to the stand-alone kernel's; as SCALAR vector
+            // instructions: packed ones next to the other wave's 4 x 4 x 1 matrix products deliver stale results, see pk_math.h), then
+            // log2 in the split's layout (every lane busy), staged as 4 x 257 floats and picked up by the 16 lanes (n, g) whose
+            // frames these are, in the matrix-core layout the chains below consume.  The samples come straight from memory /
+            // L2 per frame (neighbouring frames overlap there; a lane reads 13 pairs), requested one pass ahead.
+            const int j = lane & 15, fl = lane >> 4;
+            float* wreg = lds + H_WAVE + wave * WAVE_FLOATS;
+            v2f* zbuf = reinterpret_cast<v2f*>(wreg);
+            v2f* zf = zbuf + fl * 272;
+            const float* fu = lds + h_lds_floats(WAVES);
+            v2f raw[FU_NR];
+            auto fetch = [&](int p) __attribute__((always_inline)) {
+                long fr = tile * 16 + 4 * p + fl;
+                fr = fr < F ? fr : F - 1;
+                const unsigned ub = (unsigned)fr / (unsigned)sti.N;          // F < 2^31 (host-checked)
+                const long nf = fr - (long)ub * sti.N;
+                const long start = nf * sti.P - sti.left;
+                const float* xb = sti.x + (long)ub * sti.Tlen;
+                const bool interior = start >= 0 && start + 32 * FU_NR <= sti.Tlen;
+                if (__builtin_amdgcn_ballot_w64(!interior) == 0) {
+                    const v2f_u4* src = reinterpret_cast<const v2f_u4*>(xb + start + 2 * j);
+#pragma unroll
+                    for (int m1 = 0; m1 < FU_NR; ++m1) raw[m1] = src[16 * m1];
+                } else {   // frames that reach over an end of their utterance: zeros outside (F.pad, constant mode).  Branch-free:
+                           // clamped addresses, the out-of-range values selected away (32-bit: Tlen < 2^31, host-checked)
+                    const int s00 = (int)start + 2 * j, tl = (int)sti.Tlen;
+#pragma unroll
+                    for (int m1 = 0; m1 < FU_NR; ++m1) {
+                        const int s0 = s00 + 32 * m1, s1 = s0 + 1;
+                        const bool ok0 = (unsigned)s0 < (unsigned)tl, ok1 = (unsigned)s1 < (unsigned)tl;
+                        const float a0 = xb[ok0 ? s0 : 0], a1 = xb[ok1 ? s1 : 0];
+                        raw[m1] = v2f{ok0 ? a0 : 0.f, ok1 ? a1 : 0.f};
+                    }
+                }
+            };
+            fetch(0);
+#pragma unroll 1
+            for (int p = 0; p < 4; ++p) {
+                // (opaque per pass: the table reads below are loop invariant, and hoisted out of the pass / tile loops their 62
+                // registers would live -- spilled -- across the whole Newton iteration)
+                int jo = j * FU_NR, j1 = j, l4 = lane;
+                asm volatile("" : "+v"(jo), "+v"(j1), "+v"(l4));
+                const v2f* wtab = reinterpret_cast<const v2f*>(fu + FU_WTAB) + jo;
+                const v2f* t256 = reinterpret_cast<const v2f*>(fu + FU_T256) + j1;
+                v2f v[16];
+#pragma unroll
+                for (int m1 = 0; m1 < FU_NR; ++m1) {
+                    // element (m1, e) belongs to the frame iff 32 m1 + e + 2 j < L; selected, never multiplied: zero padding is
+                    // exact and non-finite neighbours stay out of frames that do not contain them
+                    const bool in0 = 32 * m1 + 30 < FU_LC || 32 * m1 + 2 * j < FU_LC;
+                    const bool in1 = 32 * m1 + 31 < FU_LC || 32 * m1 + 1 + 2 * j < FU_LC;
+                    v[m1] = sc_mul(v2f{in0 ? raw[m1].x : 0.f, in1 ? raw[m1].y : 0.f}, wtab[m1]);
+                }
+#pragma unroll
+                for (int m1 = FU_NR; m1 < 16; ++m1) v[m1] = v2f{0.f, 0.f};
+                if (p < 3) fetch(p + 1);
+                sc_fft16<true>(v);
+#pragma unroll
+                for (int k1 = 0; k1 < 16; ++k1) {
+                    zf[k1 * 17 + j] = sc_cmul(v[FFT16_OUT(k1)], t256[k1 * 16]);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = zf[j * 17 + i];
+                __builtin_amdgcn_wave_barrier();
+                sc_fft16<false>(v);
+#pragma unroll
+                for (int k0 = 0; k0 < 16; ++k0) {
+                    zf[j + 16 * k0 + (k0 < 8 ? 1 : 2)] = v[FFT16_OUT(k0)];   // Z[k] at k + 1 (k <= 128) / k + 2: 16-byte aligned pair reads
+                    if (k0 == 8 && j == 0) zf[129] = v[FFT16_OUT(k0)];
+                }
+                __builtin_amdgcn_wave_barrier();
+                v2f pa[4][2], pb[4][2], z0[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v2f* z = zbuf + q * 272;
+                    const v4f a2 = *reinterpret_cast<const v4f*>(z + 2 * lane + 2);     // Z[2l+1], Z[2l+2]
+                    const v4f b2 = *reinterpret_cast<const v4f*>(z + 256 - 2 * lane);   // Z[254-2l], Z[255-2l]
+                    pa[q][0] = v2f{a2.x, a2.y};
+                    pa[q][1] = v2f{a2.z, a2.w};
+                    pb[q][1] = v2f{b2.x, b2.y};
+                    pb[q][0] = v2f{b2.z, b2.w};
+                    z0[q] = z[1];
+                }
+                const v4f tw2 = reinterpret_cast<const v4f*>(fu + FU_TWS)[l4];
+                const v2f twA = v2f{tw2.x, tw2.y}, twB = v2f{tw2.z, tw2.w};
+                __builtin_amdgcn_wave_barrier();   // every pair is read: the region now takes the staged log-spectra
+                const long fr0 = tile * 16 + 4 * p;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // bins 0 and 256 from Z[0] alone: X[0] = 2 (re + im), X[256] = 2 (re - im) (Z arrives halved)
+                    const v2f Ee = v2f{sc_add1(z0[q].x, z0[q].y), sc_sub1(z0[q].x, z0[q].y)};
+                    const v2f E4 = v2f{sc_mul1s(Ee.x, 4.f), sc_mul1s(Ee.y, 4.f)};
+                    const v2f se = v2f{sc_fma1sc(E4.x, Ee.x, sti.eps), sc_fma1sc(E4.y, Ee.y, sti.eps)};
+                    v2f sp[2];
+#pragma unroll
+                    for (int part = 0; part < 2; ++part) {
+                        // S = a + conj(b), Dd = a - conj(b), Pp = W^k Dd; X[k] = (S.re + Pp.im, S.im - Pp.re),
+                        // X[256-k] = (S.re - Pp.im, -S.im - Pp.re); |.|^2 + eps (spec.py:173) -- roundings as stft_pk.h
+                        const v2f S = sc_add_conj(pa[q][part], pb[q][part]);
+                        const v2f Dd = sc_sub_conj(pa[q][part], pb[q][part]);
+                        const v2f Pp = sc_cmul(Dd, part == 0 ? twA : twB);
+                        const v2f R = v2f{sc_add1(S.x, Pp.y), sc_sub1(S.x, Pp.y)};
+                        const v2f I = v2f{sc_sub1(S.y, Pp.x), sc_nsub1(S.y, Pp.x)};
+                        const v2f s0_ = v2f{sc_fma1sc(R.x, R.x, sti.eps), sc_fma1sc(R.y, R.y, sti.eps)};
+                        sp[part] = v2f{sc_fma1(I.x, I.x, s0_.x), sc_fma1(I.y, I.y, s0_.y)};
+                    }
+                    // sp[0] = (bin 2l+1, bin 255-2l), sp[1] = (bin 2l+2, bin 254-2l)
+                    if (sti.X_out && fr0 + q < F) {   // the spectrogram as a side product (a gradient will need it)
+                        float* yr = sti.X_out + (fr0 + q) * K;
+                        *reinterpret_cast<v2f_u4*>(yr + 2 * lane + 1) = v2f{sp[0].x, sp[1].x};
+                        *reinterpret_cast<v2f_u4*>(yr + 254 - 2 * lane) = v2f{sp[1].y, sp[0].y};
+                        if (lane == 0) {
+                            yr[0] = se.x;
+                            yr[256] = se.y;
+                        }
+                    }
+                    float* st = wreg + q * FU_S;
+                    *reinterpret_cast<v2f_u4*>(st + 2 * lane + 1) = v2f{__log2f(sp[0].x), __log2f(sp[1].x)};     // mcep.py:203 (base 2)
+                    *reinterpret_cast<v2f*>(st + 254 - 2 * lane) = v2f{__log2f(sp[1].y), __log2f(sp[0].y)};
+                    if (lane == 0) {
+                        st[0] = __log2f(se.x);
+                        st[256] = __log2f(se.y);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if ((n >> 2) == p) {
+                    const float* st = wreg + (n & 3) * FU_S;
+#pragma unroll
+                    for (int mt = 0; mt < 16; ++mt) logx[mt] = *reinterpret_cast<const f32x4*>(st + 16 * mt + 4 * g);
+                    logx256 = st[256];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
-        const float logx256 = __log2f(xf[H]);
         DSA_STAMP_T(17);
 
         // ---------------- mc0^T = G^T logx^T  (mcep.py:204-207): split-precision MFMA, the G^T image

@@ -17,149 +17,9 @@
 // keep the all-options kernel).
 #pragma once
 
+#include "pk_math.h"
+
 namespace dsa {
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef float v2f_u4 __attribute__((ext_vector_type(2), aligned(4)));   // a pair of floats at a 4-byte aligned address
-
-// ---- packed complex helpers: (lo, hi) = (re, im).  Modifier semantics checked by tools/test_pk_asm.cpp. ----
-__device__ __forceinline__ v2f pk_add(v2f a, v2f b)
-{
-    v2f r;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ v2f pk_sub(v2f a, v2f b)
-{
-    v2f r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ v2f pk_add_negi(v2f a, v2f b)   // a - i b = (a.re + b.im, a.im - b.re)
-{
-    v2f r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ v2f pk_add_posi(v2f a, v2f b)   // a + i b = (a.re - b.im, a.im + b.re)
-{
-    v2f r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ v2f pk_add_conj(v2f a, v2f b)   // a + conj(b) = (a.re + b.re, a.im - b.im)
-{
-    v2f r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ v2f pk_sub_conj(v2f a, v2f b)   // a - conj(b) = (a.re - b.re, a.im + b.im)
-{
-    v2f r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ v2f pk_mul(v2f a, v2f b)
-{
-    v2f r;
-    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c)
-{
-    v2f r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ v2f pk_fma_sc(v2f a, v2f b, v2f c)   // c uniform, in a scalar register pair
-{
-    v2f r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
-    return r;
-}
-__device__ __forceinline__ v2f pk_mul_s(v2f a, v2f b)   // b uniform, in a scalar register pair
-{
-    v2f r;
-    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
-    return r;
-}
-// complex product a * t, t = (c, s) in VECTOR registers: (a.re c - a.im s, a.im c + a.re s)
-__device__ __forceinline__ v2f pk_cmul(v2f a, v2f t)
-{
-    v2f t1, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t1) : "v"(a), "v"(t));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(t), "v"(t1));
-    return r;
-}
-// the same with the constant t in a SCALAR register pair (the radix-16 twiddles: uniform, 10 scalar registers)
-__device__ __forceinline__ v2f pk_cmul_s(v2f a, v2f t)
-{
-    v2f t1, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t1) : "v"(a), "s"(t));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(t), "v"(t1));
-    return r;
-}
-
-// 4-point forward DFT in place (W4 = -i): 8 packed instructions
-__device__ __forceinline__ void pk_dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3)
-{
-    const v2f s02 = pk_add(a0, a2), d02 = pk_sub(a0, a2), s13 = pk_add(a1, a3), d13 = pk_sub(a1, a3);
-    a0 = pk_add(s02, s13);
-    a2 = pk_sub(s02, s13);
-    a1 = pk_add_negi(d02, d13);
-    a3 = pk_add_posi(d02, d13);
-}
-// the same with a3 == 0 on input (zero padding past the frame: known at compile time): 6 instructions
-__device__ __forceinline__ void pk_dft4_z3(v2f& a0, v2f& a1, v2f& a2, v2f& a3)
-{
-    const v2f s02 = pk_add(a0, a2), d02 = pk_sub(a0, a2), a1in = a1;
-    a0 = pk_add(s02, a1in);
-    a2 = pk_sub(s02, a1in);
-    a1 = pk_add_negi(d02, a1in);
-    a3 = pk_add_posi(d02, a1in);
-}
-// the same with a2 standing for -i a2 (the W16^4 twiddle of the second pass folded into the butterfly)
-__device__ __forceinline__ void pk_dft4_negi2(v2f& a0, v2f& a1, v2f& a2, v2f& a3)
-{
-    const v2f s02 = pk_add_negi(a0, a2), d02 = pk_add_posi(a0, a2), s13 = pk_add(a1, a3), d13 = pk_sub(a1, a3);
-    a0 = pk_add(s02, s13);
-    a2 = pk_sub(s02, s13);
-    a1 = pk_add_negi(d02, d13);
-    a3 = pk_add_posi(d02, d13);
-}
-
-// 16-point forward DFT in registers (radix 4 x 4), output order as fft16: X[k] in v[FFT16_OUT(k)].
-// ZTAIL: v[13], v[14], v[15] are zero on input (never read).  80 packed instructions (74 with ZTAIL).
-template <bool ZTAIL>
-__device__ __forceinline__ void pk_fft16(v2f (&v)[16])
-{
-    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
-    pk_dft4(v[0], v[4], v[8], v[12]);
-    if (ZTAIL) {
-        pk_dft4_z3(v[1], v[5], v[9], v[13]);
-        pk_dft4_z3(v[2], v[6], v[10], v[14]);
-        pk_dft4_z3(v[3], v[7], v[11], v[15]);
-    } else {
-        pk_dft4(v[1], v[5], v[9], v[13]);
-        pk_dft4(v[2], v[6], v[10], v[14]);
-        pk_dft4(v[3], v[7], v[11], v[15]);
-    }
-    // after the first pass v[n0 + 4q] = B[n0][q]; twiddle by W16^(n0 q) = (cos, -sin)(2 pi n0 q / 16)
-    v[5] = pk_cmul_s(v[5], v2f{C1, -S1});     // e = 1
-    v[9] = pk_cmul_s(v[9], v2f{R2, -R2});     // e = 2
-    v[13] = pk_cmul_s(v[13], v2f{S1, -C1});   // e = 3
-    v[6] = pk_cmul_s(v[6], v2f{R2, -R2});     // e = 2
-    //   v[10]: e = 4, a factor -i, folded into the q = 2 butterfly below
-    v[14] = pk_cmul_s(v[14], v2f{-R2, -R2});  // e = 6
-    v[7] = pk_cmul_s(v[7], v2f{S1, -C1});     // e = 3
-    v[11] = pk_cmul_s(v[11], v2f{-R2, -R2});  // e = 6
-    v[15] = pk_cmul_s(v[15], v2f{-C1, S1});   // e = 9
-    pk_dft4(v[0], v[1], v[2], v[3]);
-    pk_dft4(v[4], v[5], v[6], v[7]);
-    pk_dft4_negi2(v[8], v[9], v[10], v[11]);
-    pk_dft4(v[12], v[13], v[14], v[15]);
-}
 
 // ABL (ablation bit mask, tools/bench_stft.cpp only; 0 in the product): 1 no output stores | 2 no butterflies |
 // 4 no waveform loads / staging | 8 no twiddle-table reads | 16 no transposes through LDS | 32 no spectrum

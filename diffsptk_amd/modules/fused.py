@@ -14,6 +14,7 @@ from torch import nn
 
 from .. import ops
 from .fbank import MelFilterBankAnalysis
+from .mcep import MelCepstralAnalysis
 from .mfcc import MelFrequencyCepstralCoefficientsAnalysis
 from .stft import ShortTimeFourierTransform
 
@@ -66,6 +67,49 @@ class FusedSTFTFilterBank(nn.Module):
         return y
 
 
-def fuse(stft: ShortTimeFourierTransform, analysis: nn.Module) -> FusedSTFTFilterBank:
-    """``fuse(stft, fbank)(x) == fbank(stft(x))``, in one launch where the fused kernel applies."""
+class FusedSTFTMelCepstralAnalysis(nn.Module):
+    """``mcep(stft(x))`` -- the BASELINE hot path -- as ONE launch (dsa_stft_mcep_fwd, csrc/mcep_mfma_f16.h: the persistent
+    mel-cepstral wave computes the 16 power spectra of its tile from the waveform itself, with the packed STFT kernel's
+    instructions, and keeps their logarithms in registers; 320 + 100 bytes of memory traffic per frame instead of 1348 + 1128).
+    Power values, and with them the mel-cepstra, are those of the two-kernel path.  With a gradient wanted the launch also
+    writes the spectrogram and the Newton history, and the backward is the two modules' own.  Other configurations
+    (sizes, options, dtypes, learnable tables) run the two modules unchanged.  ``last_path``: "fused" / "two-stage"."""
+
+    def __init__(self, stft: ShortTimeFourierTransform, analysis: MelCepstralAnalysis) -> None:
+        super().__init__()
+        if not isinstance(stft, ShortTimeFourierTransform):
+            raise ValueError("stft must be a ShortTimeFourierTransform.")
+        if not isinstance(analysis, MelCepstralAnalysis):
+            raise ValueError("analysis must be a MelCepstralAnalysis.")
+        if stft.fft_length // 2 + 1 != analysis.in_dim:
+            raise ValueError("stft and analysis disagree on fft_length.")
+        self.stft = stft
+        self.analysis = analysis
+        self.last_path = None
+
+    def _fusable(self, x: torch.Tensor) -> bool:
+        s, a = self.stft, self.analysis
+        if any(isinstance(getattr(s, n, None), nn.Parameter) for n in ("window", "W")) or getattr(s, "W", None) is not None:
+            return False
+        if not (s.fmt == _SPEC_POWER and s.mode == "constant" and not s.zmean and s.relative_floor is None):
+            return False
+        if a.algo == ops._lib.ALGO_GENERIC:
+            return False
+        return ops.stft_mcep_fusable(x, s.window, a.G, s.frame_length, s.frame_period, s.fft_length, a.cep_order)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        s, a = self.stft, self.analysis
+        if not self._fusable(x):
+            self.last_path = "two-stage"
+            return a(s(x))
+        self.last_path = "fused"
+        return ops.StftMcepFn.apply(x, s.window, s.twiddle, a.G, a.D, a.E, a.alpha_vector, s.frame_length, s.frame_period,
+                                    s.fft_length, s.center, s.eps, a.cep_order, a.n_iter)
+
+
+def fuse(stft: ShortTimeFourierTransform, analysis: nn.Module) -> nn.Module:
+    """``fuse(stft, analysis)(x) == analysis(stft(x))`` in one launch where a fused kernel applies: ``analysis`` a
+    MelCepstralAnalysis (the hot path), a MelFilterBankAnalysis or a MelFrequencyCepstralCoefficientsAnalysis."""
+    if isinstance(analysis, MelCepstralAnalysis):
+        return FusedSTFTMelCepstralAnalysis(stft, analysis)
     return FusedSTFTFilterBank(stft, analysis)

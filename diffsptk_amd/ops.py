@@ -808,6 +808,83 @@ def _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter):
     return mc.reshape(*lead, M1)
 
 
+def _mcep_scratch(device):
+    """(scratch, algo flag) of a tuned mel-cepstral forward launch: the per-(device, stream) kept-zero counters
+    (DSA_ALGO_SCRATCH_IS_CLEAN, no fill launch per call) -- except while a HIP graph is being captured: a graph replays on whatever
+    stream is current, possibly next to an eager call that uses the capture stream's counters, so a captured launch gets its
+    own block and the library's reset (a captured memset node) instead."""
+    with torch.cuda.device(device):
+        if torch.cuda.is_current_stream_capturing():
+            return _scratch(device), 0
+        return _clean_scratch(device), _lib.ALGO_SCRATCH_IS_CLEAN
+
+
+def stft_mcep_fusable(x, window, G, L, P, fft_length, M) -> bool:
+    """Configurations dsa_stft_mcep_fwd covers (include/diffsptk_amd.h): float32 device tensors, frame_length 400, fft_length 512,
+    cep_order 24 (the caller checks power format / constant padding / no zmean / no relative floor)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and window.dtype == torch.float32 and G.dtype == torch.float32):
+        return False
+    T = x.size(-1)
+    if T < 1 or T >= 2 ** 31 or L != 400 or fft_length != 512 or M != 24 or P < 1:
+        return False
+    B = x.numel() // T
+    return B * num_frames(T, P) < 2 ** 31
+
+
+class StftMcepFn(torch.autograd.Function):
+    """MelCepstralAnalysis(STFT(x)) in ONE launch (dsa_stft_mcep_fwd; stft.py:237-241 -> mcep.py:189-224): the (B, N, 257) power
+    spectrogram is neither written nor re-read -- unless a gradient is wanted: then the same launch also leaves the spectrogram
+    and the Newton history behind, and the backward is the two stages' own (dsa_mcep_bwd, then dsa_stft_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, window, twiddle, G, D, E, av, L, P, fft_length, center, eps, M, n_iter):
+        _require_device(x, window, twiddle, G, D, E, av)
+        _same_dtype(x, window, twiddle, G, D, E, av)
+        xc, wc = x.contiguous(), window.contiguous()
+        T = xc.size(-1)
+        B = xc.numel() // T
+        N = num_frames(T, P)
+        K = fft_length // 2 + 1
+        F = B * N
+        need_grad = ctx.needs_input_grad[0]
+        mc = torch.empty(*xc.shape[:-1], N, M + 1, device=x.device, dtype=x.dtype)
+        hist = torch.empty(n_iter + 1, F, M + 1, device=x.device, dtype=x.dtype) if need_grad else None
+        X = torch.empty(*xc.shape[:-1], N, K, device=x.device, dtype=x.dtype) if need_grad else None
+        images = mcep_images(G, D, E, fft_length, M)
+        if images is None:
+            raise _lib.BackendError("stft_mcep: no tuned kernel for this configuration (check stft_mcep_fusable first)")
+        scratch, flag = _mcep_scratch(x.device)
+        with torch.cuda.device(x.device):
+            _call("dsa_stft_mcep_fwd", _p(xc), B, T, L, P, fft_length, _p(wc), _p(twiddle), int(center), float(eps), M, n_iter,
+                  _p(G), _p(D), _p(E), _p(av), _dtype_code(xc), _lib.ALGO_AUTO | flag, _p(images), _p(scratch), _p(mc), _p(hist),
+                  _p(X), _stream())
+        if need_grad:
+            ctx.save_for_backward(xc, wc, twiddle, X, hist, G, D, E, av)
+        ctx.cfg = (L, P, fft_length, center, eps, M, n_iter)
+        ctx.images = images
+        return mc
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gmc):
+        xc, wc, twiddle, X, hist, G, D, E, av = ctx.saved_tensors
+        L, P, fft_length, center, eps, M, n_iter = ctx.cfg
+        gmc = gmc.contiguous()
+        K = fft_length // 2 + 1
+        F = X.numel() // K
+        T = xc.size(-1)
+        B = xc.numel() // T
+        gX = torch.empty_like(X)
+        gx = torch.empty_like(xc)
+        scratch = torch.empty(_lib.MCEP_BWD_WORKSPACE_BYTES, dtype=torch.uint8, device=gmc.device)
+        with torch.cuda.device(gmc.device):
+            _call("dsa_mcep_bwd", _p(gmc), _p(X), _p(hist), F, fft_length, M, n_iter, _p(G), _p(D), _p(E), _p(av),
+                  _dtype_code(X), _lib.ALGO_AUTO | _lib.ALGO_SCRATCH_HAS_WORKSPACE, _p(ctx.images), _p(scratch), _p(gX), _stream())
+            _call("dsa_stft_bwd", _p(gX), _p(xc), B, T, L, P, fft_length, _p(wc), _p(twiddle), int(center), 0,
+                  pad_mode_code("constant"), float(eps), 0, 0.0, 3, _dtype_code(xc), _lib.ALGO_AUTO, _p(gx), None, _stream())
+        return (gx,) + (None,) * 13
+
+
 class McepFn(torch.autograd.Function):
     """MelCepstralAnalysis._forward (mcep.py:189-224) with composed linear stages."""
 
@@ -828,9 +905,7 @@ class McepFn(torch.autograd.Function):
         scratch = None
         flag = 0
         if images is not None:
-            with torch.cuda.device(X.device):
-                scratch = _clean_scratch(X.device)
-            flag = _lib.ALGO_SCRATCH_IS_CLEAN
+            scratch, flag = _mcep_scratch(X.device)
         with torch.cuda.device(X.device):
             _call("dsa_mcep_fwd", _p(Xc), F, fft_length, M, n_iter, _p(G), _p(D), _p(E), _p(av),
                   _dtype_code(Xc), algo | flag, _p(images), _p(scratch), _p(mc), _p(hist), _stream())

@@ -246,6 +246,19 @@ int dsa_mcep_prepare(const void* G, const void* D, const void* E, int32_t nfft, 
 int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, int32_t n_iter, const void* G,
                  const void* D, const void* E, const void* alpha_vec, int32_t dtype, int32_t algo,
                  const void* images, void* scratch, void* mc, void* mc_hist, void* stream);
+/* ShortTimeFourierTransform._forward (stft.py:237-241: frame, window, rfft, |.|^2 + eps) feeding
+ * MelCepstralAnalysis._forward (mcep.py:189-224) in ONE launch: x:(B,T) -> mc:(B N, M+1), N = (T-1)/P + 1, without the
+ * (B, N, nfft/2+1) power spectrogram's round trip through memory (320 + 100 bytes per frame instead of 1348 + 1128).  The
+ * persistent mel-cepstral wave computes the 16 spectra of its tile itself, with the instructions of the packed STFT kernel
+ * (bit-identical power values), and takes log2 straight into the registers the Newton iteration keeps them in.
+ * Covers float32, frame_length 400, fft_length 512, cep_order 24, power format, constant padding, no zmean / relative floor
+ * (else DSA_ERR_UNSUPPORTED: call dsa_stft_fwd and dsa_mcep_fwd).  window:(L), twiddle:(nfft,2), G/D/E/alpha_vec/images/
+ * scratch/algo flags as dsa_mcep_fwd; mc_hist: NULL or (n_iter+1, B N, M+1); X_out: NULL or (B N, nfft/2+1) receiving the
+ * power spectrogram as a side product (what dsa_mcep_bwd needs when a gradient is wanted). */
+int dsa_stft_mcep_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft, const void* window,
+                      const void* twiddle, int32_t center, double eps, int32_t M, int32_t n_iter, const void* G,
+                      const void* D, const void* E, const void* alpha_vec, int32_t dtype, int32_t algo,
+                      const void* images, void* scratch, void* mc, void* mc_hist, void* X_out, void* stream);
 /* gradient of the UNROLLED n_iter-step iteration (what autograd gives the reference).
  * gmc:(F,M+1), X, mc_hist as saved by the forward -> gX:(F,nfft/2+1). */
 int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist, int64_t F, int32_t nfft,
