@@ -477,7 +477,7 @@ def compact_line(res: dict, detail_path: str = DETAIL_FILE) -> str:
                                 "scaling", "vs_baseline", "dtype", "data") if k in res}
     cfg = res.get("config", {})
     line["config"] = {k: cfg[k] for k in ("workload", "utterances_per_gpu", "global_batch", "frames_per_step", "parallelism",
-                                          "kernels", "launches_per_step") if k in cfg}
+                                          "kernels", "path", "launches_per_step") if k in cfg}
     for name in ("roofline", "roofline_stft", "roofline_mcep"):
         r = res.get(name)
         if r:
@@ -520,6 +520,12 @@ def main():
                     help="untimed steps run for this long before the warmup steps so that the GPU clocks have settled "
                          "(the first ~20 ms after idle run 10 %% slower; 0 disables)")
     ap.add_argument("--batch", type=int, default=1024, help="utterances per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling: the whole job's utterances, split evenly over the N ranks (BASELINE configs[4] as written is "
+                         "--global-batch 8192: N = 1 runs all 8192 utterances on one GPU, N = 8 runs 1024 each); 0 = weak scaling with --batch per GPU")
+    ap.add_argument("--path", choices=["two-kernel", "fused"], default="two-kernel",
+                    help="the step: fused STFT kernel + mel-cepstral kernel (default: measured faster, profiles/r04_fused_vs_two_kernels_*.txt) "
+                         "or the ONE-launch STFT -> mel-cepstrum kernel (diffsptk_amd.fuse; 420 B/frame of memory traffic instead of 2476)")
     ap.add_argument("--chunks", type=int, default=1,
                     help="N > 1: utterance chunks per step.  1 (default): one in-place all-gather per step, deferred "
                          "behind the next step's kernels; > 1: chunked gather/compute overlap inside the step")
@@ -576,6 +582,11 @@ def main():
 
     algo = {"auto": _lib.ALGO_AUTO, "generic": _lib.ALGO_GENERIC, "tuned": _lib.ALGO_TUNED}[args.algo]
     B = args.batch
+    strong = args.global_batch > 0
+    if strong:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
+        B = args.global_batch // world
     x = torch.randn(B, SAMPLES, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
     stft = dsp.STFT(FL, FP, NFFT, device=dev)
     mcep = dsp.MelCepstralAnalysis(fft_length=NFFT, cep_order=M, alpha=ALPHA, n_iter=N_ITER, device=dev)
@@ -589,6 +600,17 @@ def main():
         if record:
             e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             e[0].record()
+        if args.path == "fused":   # one launch: the spectrogram never exists
+            if record:
+                e[1].record()
+            mc = ops.StftMcepFn.apply(xc, stft.window, stft.twiddle, mcep.G, mcep.D, mcep.E, mcep.alpha_vector, FL, FP, NFFT, True,
+                                      1e-9, M, N_ITER)
+            if record:
+                e[2].record()
+                ev_log.append((e, xc.size(0)))
+            else:
+                kernels["stft"] = kernels["mcep"] = _lib.last_kernel()
+            return mc
         X = ops.StftFn.apply(xc, stft.window, stft.twiddle, FL, FP, NFFT, True, False, "constant", 1e-9, None, 3, algo)
         if record:
             e[1].record()
@@ -696,12 +718,16 @@ def main():
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[4] per-GPU shard: STFT->mcep forward, {B} utterances x 1 s @ 16 kHz "
-                            f"per GPU ({frames_rank} frames), alpha={ALPHA} n_iter={N_ITER}; N=8 is the full "
-                            "8192-utterance batch; features all-gathered over RCCL when N>1",
+                "workload": (f"BASELINE configs[4] as written (strong scaling): STFT->mcep forward, {B * world} utterances x 1 s @ 16 kHz "
+                             f"split over {world} GPU(s) = {B} per GPU ({frames_rank} frames each), alpha={ALPHA} n_iter={N_ITER}; "
+                             "features all-gathered over RCCL when N>1") if strong else
+                            (f"BASELINE configs[4] per-GPU shard: STFT->mcep forward, {B} utterances x 1 s @ 16 kHz "
+                             f"per GPU ({frames_rank} frames), alpha={ALPHA} n_iter={N_ITER}; N=8 is the full "
+                             "8192-utterance batch; features all-gathered over RCCL when N>1"),
+                "path": args.path, "launches_per_step": 1 if args.path == "fused" else 2,
                 "utterances_per_gpu": B, "global_batch": B * world, "frames_per_step": frames_rank * world,
                 "parallelism": f"dp{world}", "kernels": kernels, "chunks_per_step": n_chunks, "streams": n_streams,
                 "arith": "float32 in / out / accumulate; the matrix chains of the mel-cepstral kernel run as 3-term "
@@ -736,7 +762,7 @@ def main():
                           "source": "profiles/r03_power_probe.txt (static: tools/power_probe.sh, rocm-smi while the kernel loops)",
                           "note": "both headline kernels run at the socket's power cap; the kernel's cycle counter averages "
                                   "1.99-2.09 GHz over a launch, so the nominal-clock peak above is not reachable"},
-            })(datapath_roofline(isa_mix("mcep_mfma_fwd_kernel_h"), N_ITER, frames_launch, t_mcep)),
+            })(datapath_roofline(isa_mix("mcep_mfma_fwd_kernel_hILi8ELb1" if args.path == "fused" else "mcep_mfma_fwd_kernel_hILi8ELb0"), N_ITER, frames_launch, t_mcep)),
             "roofline_stft": {
                 "kernel": kernels["stft"], "bound": "hbm",
                 "achieved": STFT_BYTES_PER_FRAME * frames_launch / t_stft / 1e9,
@@ -752,9 +778,30 @@ def main():
                         "no mel-cepstral kernel in between)",
             },
         }
+        if world == 1:
+            try:   # the other path of the same step, back to back (detail file only)
+                fused_mod = dsp.fuse(stft, mcep)
+                with torch.no_grad():
+                    t_fu = gpu_time(lambda: fused_mod(xl), n=10) * 1e-3
+                    k_fu = _lib.last_kernel()
+                    t_two = gpu_time(lambda: mcep(stft(xl)), n=10) * 1e-3
+                fb = FP * 4 + M1 * 4
+                res["fused_path"] = {
+                    "kernel": k_fu, "path": fused_mod.last_path, "ms_per_launch": t_fu * 1e3, "frames/s": frames_launch / t_fu,
+                    "two_kernel_ms_back_to_back": t_two * 1e3,
+                    "roofline": {"kernel": k_fu, "bound": "hbm", "bytes_per_frame": fb, "achieved": fb * frames_launch / t_fu / 1e9,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fb * frames_launch / t_fu / 1e9 / HBM_PEAK_GBS,
+                                 "traffic": pmc_traffic("stft512_mcep_fused_fwd", frames_launch), "avg_launch_ms": t_fu * 1e3},
+                    "note": "diffsptk_amd.fuse(stft, mcep): ONE launch, 320 + 100 algorithmic bytes per frame (SURVEY 8(d)) instead of 1348 + 1128; "
+                            "the persistent mel-cepstral wave computes its tile's 16 spectra itself.  The kernel is bound by the float32 datapath, "
+                            "not by memory: removing the spectrogram's round trip buys no time, and the FFT must run on scalar vector "
+                            "instructions here (packed ones next to the other wave's 4x4x1 matrix products return stale results, "
+                            "profiles/r04_fused_pk_hazard_check_v1.txt), so the two-kernel step stays the default (--path)"}
+            except Exception as e:
+                res["fused_path"] = {"error": repr(e)}
         if world == 1 and not args.no_configs:
             try:
-                res["configs"] = other_configs(dsp, ops, _lib, dev, stft, mcep, x)
+                res["configs"] = other_configs(dsp, ops, _lib, dev, stft, mcep, x[:1024] if x.size(0) >= 1024 else x)
             except Exception as e:   # the headline line must survive a failing sub-benchmark
                 res["configs"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
