@@ -16,7 +16,7 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdiffsptk_amd.so")
-SOURCES = ("stft.hip", "mcep.hip", "mcep_mfma.hip", "lpc.hip", "fbank.hip", "fftcep.hip", "mgc.hip")
+SOURCES = ("stft.hip", "mcep.hip", "mcep_mfma.hip", "lpc.hip", "fbank.hip", "fftcep.hip", "mgc.hip", "rows_gemm.hip", "thsolve_quad.hip")
 HIPCC_FLAGS = (
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
     "-mcode-object-version=5", "-Wno-unused-value", "-ffp-contract=on",
@@ -115,6 +115,9 @@ SIGNATURES = {
     "dsa_stft_bwd": (C.c_int, [_P, _P, _L, _L, _I, _I, _I, _P, _P, _I, _I, _I, _D, _I, _D, _I, _I, _I, _P, _P, _P]),
     "dsa_freqt_fwd": (C.c_int, [_P, _L, _I, _P, _I, _I, _P, _P]),
     "dsa_freqt_bwd": (C.c_int, [_P, _L, _I, _P, _I, _I, _P, _P]),
+    "dsa_rows_gemm": (C.c_int, [_P, _L, _I, _P, _I, _I, _I, _P, _I, _I, _P, _I, _P]),
+    "dsa_mcep_newton_update": (C.c_int, [_P, _L, _I, _P, _I, _P, _P, _P]),
+    "dsa_rows_ew": (C.c_int, [_I, _I, _P, _P, _P, _L, _I, _P, _P, _P]),
     "dsa_irfft_scale": (C.c_int, [_P, _L, _I, _I, _P, _P]),
     "dsa_div_rows": (C.c_int, [_P, _L, _L, _P, _D, _I, _P, _P]),
     "dsa_istft_fwd": (C.c_int, [_P, _L, _L, _I, _I, _I, _P, _P, _I, _P, _D, _I, _I, _P, _P]),

@@ -62,6 +62,9 @@ int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, v
 // re-solves, with row pivoting, the float32 systems whose solution rows start with NaN (csrc/mgc.hip)
 int thsolve_fix_marked(const void* p, const void* q, const void* r, int64_t F, int n, void* g, hipStream_t st, int r_stride = 0,
                        int r_off = 0, const void* add = nullptr);
+// orders 2 .. 55, float32, strided operands (csrc/thsolve_quad.hip)
+int thsolve_quadn_fwd(const void* p, int ldp, const void* q, int ldq, const void* r, int ldr, const void* sub, const void* add, int64_t F,
+                      int n, void* g, hipStream_t st);
 int fbank_mfma_launch_ex(const void* x, int64_t F, int K, const void* H, int C, int ldh, double floor, double gamma,
                          int use_power, int post_mode, double post_scale, void* y, void* E, hipStream_t st, const char* name,
                          const void* W2 = nullptr, int Mo = 0, void* z = nullptr,   // optional second product z = y W2

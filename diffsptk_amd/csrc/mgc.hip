@@ -247,6 +247,54 @@ __global__ __launch_bounds__(64) void th_solve_fix_kernel(const float* __restric
     }
 }
 
+// The same second launch for the general quad-layout solve (csrc/thsolve_quad.hip): strided p / q / r, an optional vector subtracted
+// from every right-hand side and an optional addend, rows in registers up to order NM.
+template <int NM>
+__global__ __launch_bounds__(64) void th_solve_fix_n_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ q, int ldq,
+                                                           const float* __restrict__ r, int ldr, const float* __restrict__ sub,
+                                                           const float* __restrict__ add, long F, int n, float* __restrict__ g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* ps = reinterpret_cast<float*>(smem_raw);
+    float* qs = ps + n;
+    const int lane = threadIdx.x;
+    for (long base = (long)blockIdx.x * 64; base < F; base += (long)gridDim.x * 64) {
+        const long fl = base + lane;
+        const float head = fl < F ? g[fl * n] : 0.f;
+        unsigned long long marked = __ballot(head != head);
+        while (marked) {
+            const int b = __builtin_ctzll(marked);
+            marked &= marked - 1;
+            const long f = base + b;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < n) ps[lane] = p[f * (long)ldp + lane];
+            for (int i = lane; i < 2 * n - 1; i += 64) qs[i] = q[f * (long)ldq + i];
+            const float rhs = lane < n ? r[f * (long)ldr + lane] - (sub ? sub[lane] : 0.f) : 0.f;
+            __builtin_amdgcn_wave_barrier();
+            int col;
+            float sol;
+            th_solve_reg<float, NM>(ps, qs, rhs, n, lane, col, sol);
+            if (lane < n) g[f * n + col] = add ? add[f * n + col] + sol : sol;
+        }
+    }
+}
+
+int thsolve_fix_marked_n(const void* p, int ldp, const void* q, int ldq, const void* r, int ldr, const void* sub, const void* add,
+                         int64_t F, int n, void* g, hipStream_t st)
+{
+    long blocks = (F + 63) / 64;
+    if (blocks > 4096) blocks = 4096;
+    const size_t lds = sizeof(float) * (3 * n);
+#define DSA_FIXN(NM)                                                                                                              \
+    hipLaunchKernelGGL((th_solve_fix_n_kernel<NM>), dim3((unsigned)blocks), dim3(64), lds, st, (const float*)p, ldp, (const float*)q, ldq, \
+                       (const float*)r, ldr, (const float*)sub, (const float*)add, (long)F, n, (float*)g)
+    if (n <= 32) DSA_FIXN(32);
+    else if (n <= 48) DSA_FIXN(48);
+    else DSA_FIXN(64);
+#undef DSA_FIXN
+    return check_launch("th_solve_quadn_fwd");
+}
+
 int thsolve_fix_marked(const void* p, const void* q, const void* r, int64_t F, int n, void* g, hipStream_t st, int r_stride, int r_off,
                        const void* add)
 {
@@ -1535,9 +1583,23 @@ DSA_EXPORT int dsa_thsolve_fwd(const void* p, const void* q, const void* r, int6
         return !e || atoi(e) != 0;
     }();
     if (dtype == DSA_F32 && n == 24 && quad && F > 0) return thsolve_quad24_fwd(p, q, r, F, g, (hipStream_t)stream);
+    // other orders up to 55, float32, a batch that fills waves of 16 systems: the same scheme as a template over the size
+    if (dtype == DSA_F32 && n >= 2 && n <= 55 && quad && F >= 64)
+        return thsolve_quadn_fwd(p, n, q, 2 * n - 1, r, n, nullptr, nullptr, F, n, g, (hipStream_t)stream);
     if (dtype == DSA_F32) return th_launch<float>(false, nullptr, p, q, r, F, n, g, nullptr, nullptr, (hipStream_t)stream);
     if (dtype == DSA_F64) return th_launch<double>(false, nullptr, p, q, r, F, n, g, nullptr, nullptr, (hipStream_t)stream);
     return fail(DSA_ERR_UNSUPPORTED, "thsolve: unsupported dtype%s");
+}
+
+// mcep.py:216-222 for the geometries without a tuned kernel: mc_out = mc_in + solve(T(rt[:n]) + H(rt), rt[:n] - alpha_vec), rt:(F, 2n-1)
+DSA_EXPORT int dsa_mcep_newton_update(const void* rt, int64_t F, int32_t n, const void* alpha_vec, int32_t dtype, const void* mc_in,
+                                      void* mc_out, void* stream)
+{
+    DSA_REQUIRE(n >= 2 && n <= 55 && F >= 0, "mcep_newton_update: order must be in [2, 55]");
+    DSA_REQUIRE(rt && alpha_vec && mc_in && mc_out, "mcep_newton_update: null pointer");
+    if (dtype != DSA_F32) return fail(DSA_ERR_UNSUPPORTED, "mcep_newton_update: float32 only%s");
+    if (F == 0) return DSA_OK;
+    return thsolve_quadn_fwd(rt, 2 * n - 1, rt, 2 * n - 1, rt, 2 * n - 1, alpha_vec, mc_in, F, n, mc_out, (hipStream_t)stream);
 }
 
 DSA_EXPORT int dsa_thsolve_update_fwd(const void* p, const void* q, const void* r, int64_t r_stride, int64_t r_offset, int64_t F,

@@ -306,15 +306,31 @@ class StftFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------- freqt
-def _row_product_is_plain_gemm(F, Lin, Lout, elt) -> bool:
-    """True where the library's row-product entry would fall to its one-workgroup-per-row kernel (csrc/mcep.hip:dsa_freqt_fwd /
-    _bwd: the matrix does not fit the LDS-resident kernel's 48 KB and the shape is outside the matrix-core kernel's range --
-    the 1025-bin products of the 48 kHz set-ups): a plain GEMM, handed to the vendor library through torch.matmul."""
+ROWS_PRO_LOG, ROWS_EPI_EXPSUB, ROWS_TRANS = 1, 2, 4   # DSA_ROWS_* (include/diffsptk_amd.h)
+
+
+def rows_gemm(c, A, flags=0, aux=None):
+    """out = op_out(op_in(c) @ B), B = A or (ROWS_TRANS) A^T: the library's general float32 row product on the matrix instruction
+    (dsa_rows_gemm, csrc/rows_gemm.hip) with the fused log prologue / exp(aux - 2 .) epilogue of the untuned mel-cepstral step."""
+    cc, Ac = c.contiguous(), A.contiguous()
+    K = cc.size(-1)
+    N = Ac.size(0) if flags & ROWS_TRANS else Ac.size(1)
+    F = cc.numel() // K
+    out = torch.empty(*cc.shape[:-1], N, device=c.device, dtype=c.dtype)
+    auxc = None if aux is None else aux.contiguous()
+    with torch.cuda.device(c.device):
+        _call("dsa_rows_gemm", _p(cc), F, K, _p(Ac), Ac.size(1), N, flags, _p(auxc), N, _dtype_code(cc), _p(out), N, _stream())
+    return out
+
+
+def _row_product_is_long(F, Lin, Lout, elt) -> bool:
+    """True where the library's row-product entry (csrc/mcep.hip:dsa_freqt_fwd / _bwd) would fall to its one-workgroup-per-row
+    kernel: the matrix does not fit the LDS-resident kernel's 48 KB and the shape is outside the 257-bin matrix-core kernel's
+    range -- the 1025-bin products of the 48 kHz set-ups.  Those run on the general matrix-core row product (rows_gemm); the
+    choice depends on the geometry and a minimum batch only, never on anything that changes from call to call."""
     if os.environ.get("DSA_FREQT_GEMM", "1") == "0" or F < 256:
         return False
     lds_fits = elt * (Lin * Lout + 64 * (Lin + 1)) <= 48 * 1024
-    # (rows of a few hundred values keep the library's kernels: the GEMM's host-side set-up costs more than they take --
-    # the 200 -> 25 transpose product of the MLSA filter's backward went from 0.1 ms to 10 ms of host time per call)
     return not lds_fits and max(Lin, Lout) >= 512
 
 
@@ -330,8 +346,8 @@ class MatmulRowsFn(torch.autograd.Function):
         F = cc.numel() // L1
         ctx.save_for_backward(Ac)
         mfma = cc.dtype == torch.float32 and 48 < L1 <= 320 and L2 <= 192 and F >= 1024
-        if not mfma and _row_product_is_plain_gemm(F, L1, L2, cc.element_size()):
-            return torch.matmul(cc, Ac)
+        if not mfma and cc.dtype == torch.float32 and _row_product_is_long(F, L1, L2, cc.element_size()):
+            return rows_gemm(cc, Ac)
         out = torch.empty(*cc.shape[:-1], L2, device=c.device, dtype=c.dtype)
         with torch.cuda.device(c.device):
             _call("dsa_freqt_fwd", _p(cc), F, L1, _p(Ac), L2, _dtype_code(cc), _p(out), _stream())
@@ -344,12 +360,58 @@ class MatmulRowsFn(torch.autograd.Function):
         g = g.contiguous()
         L1, L2 = Ac.shape
         F = g.numel() // L2
-        if _row_product_is_plain_gemm(F, L2, L1, g.element_size()):
-            return torch.matmul(g, Ac.t()), None
+        if g.dtype == torch.float32 and _row_product_is_long(F, L2, L1, g.element_size()):
+            return rows_gemm(g, Ac, ROWS_TRANS), None
         gc = torch.empty(*g.shape[:-1], L1, device=g.device, dtype=g.dtype)
         with torch.cuda.device(g.device):
             _call("dsa_freqt_bwd", _p(g), F, L1, _p(Ac), L2, _dtype_code(g), _p(gc), _stream())
         return gc, None
+
+
+class RowsLogFn(torch.autograd.Function):
+    """y = log(x) (mcep.py:203) as the library's own element-wise launch, differentiable (dsa_rows_ew op 0)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        with torch.cuda.device(x.device):
+            _call("dsa_rows_ew", 0, 0, _p(xc), None, None, xc.numel(), _dtype_code(xc), _p(y), None, _stream())
+        ctx.save_for_backward(xc)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (xc,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(xc)
+        with torch.cuda.device(gy.device):
+            _call("dsa_rows_ew", 0, 1, _p(xc), None, _p(gy), xc.numel(), _dtype_code(xc), _p(gx), None, _stream())
+        return gx
+
+
+class RowsExpSubFn(torch.autograd.Function):
+    """y = exp(a - 2 b) (mcep.py:210-212), differentiable (dsa_rows_ew op 1; the backward needs the output only)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ac, bc = a.contiguous(), b.contiguous()
+        y = torch.empty_like(ac)
+        with torch.cuda.device(a.device):
+            _call("dsa_rows_ew", 1, 0, _p(ac), _p(bc), None, ac.numel(), _dtype_code(ac), _p(y), None, _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        ga, gb = torch.empty_like(y), torch.empty_like(y)
+        with torch.cuda.device(gy.device):
+            _call("dsa_rows_ew", 1, 1, _p(y), None, _p(gy), y.numel(), _dtype_code(y), _p(ga), _p(gb), _stream())
+        return ga, gb
 
 
 # ----------------------------------------------------------------------------------- inverse path (8(f) row 2)
@@ -771,7 +833,8 @@ class MfccFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------- mcep
 def _mcep_composed_applies(Xc, M, F) -> bool:
     """Geometries without a tuned kernel (48 kHz set-ups: fft_length 1024 / 2048, orders 34 .. 60)."""
-    return M + 1 <= 64 and M >= 1 and F >= 256 and os.environ.get("DSA_MCEP_COMPOSED", "1") != "0"
+    return (Xc.dtype == torch.float32 and M + 1 <= 64 and M >= 1 and F >= 256
+            and os.environ.get("DSA_MCEP_COMPOSED", "1") != "0")   # float64 keeps the generic kernel pair
 
 
 def mcep_composed(X, G, D, E, av, fft_length, M, n_iter, algo):
@@ -790,21 +853,46 @@ def mcep_composed(X, G, D, E, av, fft_length, M, n_iter, algo):
     return _mcep_composed_fwd(X.contiguous(), G, D, E, av, M, n_iter)
 
 
+def mcep_newton_update(rt, av, mc):
+    """mc + solve(T(rt[:, :n]) + H(rt), rt[:, :n] - av) (mcep.py:216-222; dsa_mcep_newton_update, float32, n <= 55)."""
+    n = mc.size(-1)
+    out = torch.empty_like(mc)
+    with torch.cuda.device(mc.device):
+        _call("dsa_mcep_newton_update", _p(rt), mc.numel() // n, n, _p(av), _dtype_code(mc), _p(mc), _p(out), _stream())
+    return out
+
+
 def _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter):
-    """mcep.py:203-222 for the geometries the tuned kernel does not cover, as whole-batch launches instead of the one-workgroup-
-    per-frame generic kernel: the two row products of a Newton step are plain GEMMs ((F, M+1) x (M+1, K) and (F, K) x (K, 2M+1):
-    the vendor GEMM through torch.matmul), the Toeplitz-plus-Hankel solve is the library's batched kernel (dsa_thsolve_fwd) on
-    slices of rt.  Same arithmetic order per frame as the reference's formulation; float32 products accumulate in float32."""
+    """mcep.py:203-222 for the geometries the tuned kernel does not cover, as whole-batch launches of the library's own kernels
+    instead of the one-workgroup-per-frame generic kernel: per Newton step two matrix-core row products -- (F, M+1) x (M+1, K)
+    with the exp(log X - 2 .) epilogue fused, and (F, K) x (K, 2M+1) (csrc/rows_gemm.hip) -- and the batched
+    Toeplitz-plus-Hankel solve (dsa_thsolve_fwd) on slices of rt.  With a
+    graph wanted the same composition runs on differentiable pieces (RowsLogFn, MatmulRowsFn, RowsExpSubFn, ThSolveFn).  Same
+    arithmetic order per frame as the reference's formulation; float32 products accumulate in float32."""
     M1 = M + 1
     lead = Xc.shape[:-1]
-    logx = torch.log(Xc.reshape(-1, Xc.size(-1)))                       # mcep.py:203
-    mc = logx @ G                                                         # :204-207
+    X2 = Xc.reshape(-1, Xc.size(-1))
+    want_grad = torch.is_grad_enabled() and X2.requires_grad
+    if X2.dtype != torch.float32:
+        raise _lib.BackendError("mcep (whole-batch composition): float32 only")
+    if want_grad:
+        logx = RowsLogFn.apply(X2)                                        # mcep.py:203
+        mc = MatmulRowsFn.apply(logx, G)                                  # :204-207
+    else:
+        logx = RowsLogFn.apply(X2)                                        # kept: every step's epilogue reads it
+        mc = rows_gemm(logx, G)
     for _ in range(n_iter):
-        e = torch.exp(torch.sub(logx, mc @ D, alpha=2))                   # :210-212
-        rt = e @ E                                                        # :214-215
-        p = rt[:, :M1].contiguous()
-        q = rt[:, : 2 * M1 - 1].contiguous()
-        mc = mc + ThSolveFn.apply(p, q, p - av)                           # :216-222
+        if want_grad:
+            e = RowsExpSubFn.apply(logx, MatmulRowsFn.apply(mc, D))       # :210-212
+            rt = MatmulRowsFn.apply(e, E)                                 # :214-215
+        else:
+            e = rows_gemm(mc, D, ROWS_EPI_EXPSUB, aux=logx)               # product and exp(log X - 2 .) in one launch
+            rt = rows_gemm(e, E)
+        if want_grad or M1 > 55:
+            p = rt[:, :M1].contiguous()
+            mc = mc + ThSolveFn.apply(p, rt, p - av)                      # :216-222
+        else:
+            mc = mcep_newton_update(rt, av, mc)                           # the same in one launch: 16 systems per wave
     return mc.reshape(*lead, M1)
 
 

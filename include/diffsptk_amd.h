@@ -246,6 +246,29 @@ int dsa_mcep_prepare(const void* G, const void* D, const void* E, int32_t nfft, 
 int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, int32_t n_iter, const void* G,
                  const void* D, const void* E, const void* alpha_vec, int32_t dtype, int32_t algo,
                  const void* images, void* scratch, void* mc, void* mc_hist, void* stream);
+/* The solve-and-update of a Newton step of MelCepstralAnalysis (mcep.py:216-222) at a geometry without a tuned kernel:
+ * mc_out:(F,n) = mc_in + solve(T(rt[:, :n]) + H(rt), rt[:, :n] - alpha_vec), rt:(F, 2n-1), n = cep_order + 1 in [2, 55], float32.
+ * 16 systems per wave on the float32 matrix instruction, no pivoting; a system that meets a non-positive pivot is re-solved with
+ * row pivoting by a second launch (csrc/thsolve_quad.hip).  mc_out may be mc_in. */
+int dsa_mcep_newton_update(const void* rt, int64_t F, int32_t n, const void* alpha_vec, int32_t dtype, const void* mc_in,
+                           void* mc_out, void* stream);
+/* General float32 row product on the matrix instruction, for shapes the kernels behind dsa_freqt_fwd / _bwd do not cover (rows
+ * of 512 values and more: the 1025-bin products of the 48 kHz set-ups of utils/public.py:22-104) and for the Newton step of
+ * MelCepstralAnalysis (mcep.py:203-215) at geometries without a tuned kernel:
+ *   out:(F,N) = op_out( op_in(c):(F,K) x B:(K,N) ),  B = A (K x N, row stride lda) or, with DSA_ROWS_TRANS, A^T (A: N x K, stride lda)
+ *   DSA_ROWS_PRO_LOG    op_in = log          (mcep.py:203 feeding :204-207)
+ *   DSA_ROWS_EPI_EXPSUB op_out(v) = exp(aux - 2 v), aux:(F,N) with row stride ldaux   (mcep.py:210-212)
+ * Exact float32 products, float32 accumulation (v_mfma_f32_16x16x4_f32).  ldo: row stride of out. */
+#define DSA_ROWS_PRO_LOG 1
+#define DSA_ROWS_EPI_EXPSUB 2
+#define DSA_ROWS_TRANS 4
+int dsa_rows_gemm(const void* c, int64_t F, int32_t K, const void* A, int32_t lda, int32_t N, int32_t flags, const void* aux,
+                  int32_t ldaux, int32_t dtype, void* out, int32_t ldo, void* stream);
+/* element-wise companions of the same analysis when a gradient is wanted (the fused forms keep no operands):
+ *   op 0: o0 = log(a)            backward (backward = 1): o0 = gy / a
+ *   op 1: o0 = exp(a - 2 b)      backward: a = the saved OUTPUT y, o0 = gy y (cotangent of a), o1 = -2 gy y (cotangent of b)   */
+int dsa_rows_ew(int32_t op, int32_t backward, const void* a, const void* b, const void* gy, int64_t n, int32_t dtype, void* o0,
+                void* o1, void* stream);
 /* ShortTimeFourierTransform._forward (stft.py:237-241: frame, window, rfft, |.|^2 + eps) feeding
  * MelCepstralAnalysis._forward (mcep.py:189-224) in ONE launch: x:(B,T) -> mc:(B N, M+1), N = (T-1)/P + 1, without the
  * (B, N, nfft/2+1) power spectrogram's round trip through memory (320 + 100 bytes per frame instead of 1348 + 1128).  The

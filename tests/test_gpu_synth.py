@@ -2,6 +2,8 @@
 analysis and the cepstrum conversions around it, against outputs of the reference (tests/golden/synth.npz) and the
 numpy oracle.  Tolerances: float64 rtol 1e-5 / atol 1e-8 (tests/utils.py:66-72 of the reference); float32 as stated
 per test."""
+import math
+
 import numpy as np
 import pytest
 import scipy.signal
@@ -602,3 +604,52 @@ def test_f_rows_at_the_bench_size_against_the_oracle():
     assert err_sp < 4e-6
     assert err_b < 4e-7
     assert all(e < 1.5e-6 for e in errs.values()), errs
+
+
+@pytest.mark.parametrize("n,F", [(2, 64), (5, 1000), (23, 77), (25, 300), (30, 1025), (35, 64), (43, 130), (50, 1000), (55, 257)])
+def test_thsolve_quad_layout_solver_for_general_orders(n, F):
+    """The Toeplitz-plus-Hankel solve for orders other than 24 (csrc/thsolve_quad.hip: 16 systems per wave, 4 x 4 x 1 matrix
+    products, no pivoting, marked systems re-solved with pivoting) against float64 LAPACK on positive definite systems (the
+    Hessians of the analysis: T + H = 2 sum_w e(w) c(w) c(w)^T), ragged batch sizes; then systems that are NOT positive definite
+    (the fallback must give the pivoted answer); and the fused Newton update of the untuned mel-cepstral step."""
+    g = torch.Generator().manual_seed(n * 1000 + F)
+    K = 4 * n
+    w = torch.arange(K, dtype=torch.float64) * (math.pi / K)
+    cw = torch.cos(torch.arange(2 * n - 1, dtype=torch.float64)[:, None] * w[None, :])        # (2n-1, K)
+    e = torch.rand(F, K, generator=g, dtype=torch.float64) + 0.05
+    rtl = (e @ cw.t()) / K                                                                     # rt[m] = mean_w e(w) cos(m w)
+    p64, q64 = rtl[:, :n].contiguous(), rtl
+    r64 = torch.randn(F, n, generator=g, dtype=torch.float64)
+
+    def dense(p, q):
+        i = torch.arange(n)
+        return p[:, (i[:, None] - i[None, :]).abs()] + q[:, i[:, None] + i[None, :]]
+
+    ref = torch.linalg.solve(dense(p64, q64), r64)
+    pd, qd, rd = p64.float().to(DEV), q64.float().to(DEV), r64.float().to(DEV)
+    got = ops.ThSolveFn.apply(pd, qd, rd)
+    assert _lib.last_kernel() in (("th_solve_quad_fwd",) if n == 24 else ("th_solve_quadn_fwd",)), _lib.last_kernel()
+    ref32 = torch.linalg.solve(dense(pd.double().cpu(), qd.double().cpu()), rd.double().cpu())   # the float32 inputs' own solution
+    cond = torch.linalg.cond(dense(p64, q64)).max()
+    err = float((got.double().cpu() - ref32).abs().max() / ref32.abs().max())
+    assert err < 2e-6 * float(cond) ** 0.5 + 2e-5, (err, float(cond))
+    # not positive definite: random symmetric Toeplitz + Hankel
+    F2 = min(F, 130)
+    p2 = torch.randn(F2, n, generator=g, dtype=torch.float64)
+    q2 = torch.randn(F2, 2 * n - 1, generator=g, dtype=torch.float64)
+    r2 = torch.randn(F2, n, generator=g, dtype=torch.float64)
+    A2 = dense(p2.float().double(), q2.float().double())
+    ref2 = torch.linalg.solve(A2, r2.float().double())
+    got2 = ops.ThSolveFn.apply(p2.float().to(DEV), q2.float().to(DEV), r2.float().to(DEV)).double().cpu()
+    assert bool(torch.isfinite(got2).all())
+    c2 = torch.linalg.cond(A2)
+    ok = c2 < 1e3
+    assert int(ok.sum()) > 0
+    assert float(((got2 - ref2).abs().amax(-1) / ref2.abs().amax(-1))[ok].max()) < 1e-3
+    # the fused Newton update: mc + solve(T(rt[:n]) + H(rt), rt[:n] - av)
+    if 2 <= n <= 55:
+        av = torch.randn(n, generator=g, dtype=torch.float64) * 0.1
+        mc = torch.randn(F, n, generator=g, dtype=torch.float64)
+        upd = ops.mcep_newton_update(qd, av.float().to(DEV), mc.float().to(DEV))
+        ref_u = mc.float().double() + torch.linalg.solve(dense(pd.double().cpu(), qd.double().cpu()), pd.double().cpu() - av.float().double())
+        assert float((upd.double().cpu() - ref_u).abs().max() / ref_u.abs().max()) < 2e-6 * float(cond) ** 0.5 + 2e-5
