@@ -398,10 +398,10 @@ def test_round3_host_tables_and_dispatch_rules():
     want = np.where(row <= M, m["Cr"][np.minimum(row, M), 16 * 3 + 4 * lg + 2], 0.0).astype(np.float32)
     np.testing.assert_allclose(a3[0, 1, 2], want, rtol=0, atol=0)
     # dispatch rules
-    assert ops._row_product_is_plain_gemm(12800, 50, 1025, 4) and ops._row_product_is_plain_gemm(12800, 1025, 99, 4)
-    assert not ops._row_product_is_plain_gemm(51200, 25, 200, 4)          # fits LDS
-    assert not ops._row_product_is_plain_gemm(51200, 200, 25, 4)          # short rows keep the library's kernel
-    assert not ops._row_product_is_plain_gemm(100, 50, 1025, 4)           # tiny batch
+    assert ops._row_product_is_long(12800, 50, 1025, 4) and ops._row_product_is_long(12800, 1025, 99, 4)
+    assert not ops._row_product_is_long(51200, 25, 200, 4)          # fits LDS
+    assert not ops._row_product_is_long(51200, 200, 25, 4)          # short rows keep the library's kernel
+    assert not ops._row_product_is_long(100, 50, 1025, 4)           # tiny batch
     x, b = torch.zeros(2, 160), torch.zeros(2, 2, 40)
     assert not ops.zerodf_taylor_shapes_ok(x, b, 80)                       # host tensors never take the fused launches
     assert ops._mcep_composed_applies(None, 49, 12800) and not ops._mcep_composed_applies(None, 64, 12800)
