@@ -404,8 +404,10 @@ def test_round3_host_tables_and_dispatch_rules():
     assert not ops._row_product_is_long(100, 50, 1025, 4)           # tiny batch
     x, b = torch.zeros(2, 160), torch.zeros(2, 2, 40)
     assert not ops.zerodf_taylor_shapes_ok(x, b, 80)                       # host tensors never take the fused launches
-    assert ops._mcep_composed_applies(None, 49, 12800) and not ops._mcep_composed_applies(None, 64, 12800)
-    assert not ops._mcep_composed_applies(None, 49, 100)
+    x32 = torch.zeros(1)
+    assert ops._mcep_composed_applies(x32, 49, 12800) and not ops._mcep_composed_applies(x32, 64, 12800)
+    assert not ops._mcep_composed_applies(x32, 49, 100)
+    assert not ops._mcep_composed_applies(x32.double(), 49, 12800)          # float64 keeps the generic kernel pair
 
 
 def test_mlsa_learnable_constructs_on_the_host():
