@@ -445,6 +445,166 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 4: the same fused Frame -> Window -> autocorrelation -> Levinson with the lag sums on the float32 MATRIX instruction.
+// The float64 vector unit was the whole kernel above (625 v_fma_f64 per 25 samples and lane: 0.24 ms per 204 800 frames).  Here a
+// wave takes one frame at a time and forms its lag sums as a banded Gram product: with u_b = the b-th block of 16 windowed samples,
+//     C1 = sum_b u_b u_b^T,   C2 = sum_b u_b u_{b+1}^T,   C3 = sum_b u_b u_{b+2}^T        (16 x 16 each)
+// hold every product xw[l] xw[l + m], m <= 24, exactly once: entry (i, j) of C_s is lag 16 (s - 1) + j - i summed over the
+// positions l = i (mod 16).  Operands need no staging at all: lane = i + 16 k of v_mfma_f32_16x16x4_f32 is sample 64 e + lane of
+// the frame -- a coalesced load times the window -- and the B operand of C2 / C3 is the same load 16 / 32 samples further on
+// (L1 hits).  21 matrix instructions per frame (L = 400), float32 products are exact, each entry accumulates <= 7 instructions'
+// worth of products in float32; the 16 entries of a lag are added in FLOAT64 (scattered through LDS so that a lane reads its lag's
+// 16 slots as four 16-byte reads), then Levinson-Durbin in float64, one frame per lane, as above.
+// Accuracy: the lag sums are ~1e-7 r[0] from the exact ones (what the reference's own float32 FFT route has); the exact kernel
+// stays selectable (DSA_LPC_LAGSUMS=f64) and is what float64 input runs.
+template <int NE, int LC>   // NE: registers of 64 samples that cover the frame, ceil(L / 64); LC: the frame length at compile time (0: run time)
+__global__ __launch_bounds__(256, 3) void frame_window_lpc24_mfma_kernel(
+    const float* __restrict__ x, long Tlen, long N, int L_rt, int P, int left, int mode, const float* __restrict__ w, double eps,
+    float* __restrict__ out, long total_sc, int sc_per_utt, unsigned* __restrict__ queue, int fpi)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int DS = 20;                         // floats per lag row of the scatter area (16 slots, 16-byte aligned rows)
+    // dynamic LDS, per wave: rbuf[fpi][25] doubles | dm[26][DS] floats  (fpi = 52 at the bench geometry: three workgroups per CU)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lpc_smem[];
+    const int L = LC ? LC : L_rt;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave_bytes = fpi * kLpcM1 * (int)sizeof(double) + 26 * DS * (int)sizeof(float);
+    double* rbuf = reinterpret_cast<double*>(lpc_smem + (size_t)wave * wave_bytes);
+    float* dm = reinterpret_cast<float*>(rbuf + fpi * kLpcM1);
+    const int j = lane & 15, g = lane >> 4;
+    // window values (w == NULL: ones) and validity of this lane's samples of the three operand sets
+    float wa[NE], wb[NE], wc[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int la = 64 * e + lane, lb = la + 16, lc = la + 32;
+        wa[e] = la < L ? (w ? w[la] : 1.f) : 0.f;
+        wb[e] = lb < L ? (w ? w[lb] : 1.f) : 0.f;
+        wc[e] = lc < L ? (w ? w[lc] : 1.f) : 0.f;
+    }
+    // scatter addresses of this lane's 12 matrix entries: entry (tile s, register r) = C_s[4 g + r][j], lag = 16 s + j - (4 g + r);
+    // lags outside [0, 24] go to the spare row 25
+    int addr[3][4];
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * g + r, lag = 16 * s_ + j - i;
+            addr[s_][r] = ((lag >= 0 && lag < kLpcM1) ? lag : kLpcM1) * DS + i;
+        }
+    for (;;) {
+        unsigned ticket = 0;
+        if (lane == 0) ticket = atomicAdd(queue, 1u);
+        const long tk = (long)__builtin_amdgcn_readfirstlane(ticket);
+        if (tk >= total_sc) break;
+        const long b = tk / sc_per_utt;
+        const long ci = tk - b * sc_per_utt;
+        const long fbase = ci * fpi;
+        const int nfr = (int)((N - fbase) < fpi ? (N - fbase) : fpi);
+        const float* xb = x + b * Tlen;
+        // the samples of frame fi + 1 are requested while frame fi is in the matrix pipeline (a wave works through its frames
+        // serially: loads -> products -> scatter -> sums is one dependent chain per frame)
+        float a[NE], bb[NE], cc[NE];
+        auto fetch = [&](int fi) __attribute__((always_inline)) {
+            const long start = (fbase + fi) * P - left;
+            if (start >= 0 && start + 64 * NE + 32 <= Tlen) {   // uniform: every sample any lane touches exists
+                const float* src = xb + start + lane;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    a[e] = src[64 * e];
+                    bb[e] = src[64 * e + 16];
+                    cc[e] = src[64 * e + 32];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const long l0 = start + 64 * e + lane;
+                    a[e] = load_padded(xb, l0, Tlen, mode);
+                    bb[e] = load_padded(xb, l0 + 16, Tlen, mode);
+                    cc[e] = load_padded(xb, l0 + 32, Tlen, mode);
+                }
+            }
+        };
+        fetch(0);
+        for (int fi = 0; fi < nfr; ++fi) {
+            float va[NE], vb[NE], vc[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                // window.py:190 in float32 (as the reference); samples past the frame are selected away, never multiplied
+                va[e] = 64 * e + lane < L ? a[e] * wa[e] : 0.f;
+                vb[e] = 64 * e + lane + 16 < L ? bb[e] * wb[e] : 0.f;
+                vc[e] = 64 * e + lane + 32 < L ? cc[e] * wc[e] : 0.f;
+            }
+            if (fi + 1 < nfr) fetch(fi + 1);
+            f4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = c1, c3 = c1;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va[e], va[e], c1, 0, 0, 0);
+                // (with the frame length known, operands that lie entirely past the frame are zero: their products are skipped)
+                if (!LC || 64 * e + 16 < LC) c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(va[e], vb[e], c2, 0, 0, 0);
+                if (!LC || 64 * e + 32 < LC) c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(va[e], vc[e], c3, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();   // the previous frame's row reads are done (LDS operations of a wave run in order)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dm[addr[0][r]] = c1[r];
+                dm[addr[1][r]] = c2[r];
+                dm[addr[2][r]] = c3[r];
+            }
+            __builtin_amdgcn_wave_barrier();
+            {
+                // lane (m, h) = (lane & 31, lane >> 5) adds slots 8 h .. 8 h + 7 of lag m in float64; the halves meet through one
+                // cross-half exchange (rows 25 .. 31 read the spare row: finite or not, their sums are never stored)
+                const int m_ = lane & 31, h_ = lane >> 5;
+                const f4* row = reinterpret_cast<const f4*>(dm + (m_ < kLpcM1 ? m_ : kLpcM1) * DS + 8 * h_);
+                const f4 q0 = row[0], q1 = row[1];
+                double sm = ((double)q0[0] + (double)q0[1]) + ((double)q0[2] + (double)q0[3]);
+                sm += ((double)q1[0] + (double)q1[1]) + ((double)q1[2] + (double)q1[3]);
+                const int lo = __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), __double2loint(sm));
+                const int hi = __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), __double2hiint(sm));
+                const double other = __hiloint2double(hi, lo);
+                // the same association on both halves: (slots 0..7) + (slots 8..15)
+                const double tot = h_ == 0 ? sm + other : other + sm;
+                if (lane < kLpcM1) rbuf[fi * kLpcM1 + lane] = tot;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- Levinson-Durbin, one frame per lane (levdur.py:113-127 as a recursion), as in frame_window_lpc24_kernel ----
+        if (lane < nfr) {
+            double r[kLpcM1], al[kLpcM1];
+#pragma unroll
+            for (int m = 0; m < kLpcM1; ++m) {
+                r[m] = rbuf[(size_t)lane * kLpcM1 + m];
+                al[m] = 0.0;
+            }
+            double Ecur = r[0] + eps;
+#pragma unroll
+            for (int m = 1; m < kLpcM1; ++m) {
+                double s_ = r[m];
+#pragma unroll
+                for (int q = 1; q < m; ++q) s_ = __builtin_fma(al[q], r[m - q], s_);
+                const double kk = -s_ / Ecur;
+#pragma unroll
+                for (int q = 1; 2 * q <= m; ++q) {
+                    const double aq = al[q], amq = al[m - q];
+                    al[q] = __builtin_fma(kk, amq, aq);
+                    if (q != m - q) al[m - q] = __builtin_fma(kk, aq, amq);
+                }
+                al[m] = kk;
+                Ecur *= (1.0 - kk * kk);
+            }
+            double gsum = r[0];  // un-regularised r0 (levdur.py:124)
+#pragma unroll
+            for (int m = 1; m < kLpcM1; ++m) gsum = __builtin_fma(r[m], al[m], gsum);
+            float* o = out + ((b * N + fbase + lane) * (long)kLpcM1);
+            o[0] = (float)sqrt(gsum);
+#pragma unroll
+            for (int m = 1; m < kLpcM1; ++m) o[m] = (float)al[m];
+        }
+        __builtin_amdgcn_wave_barrier();   // rbuf is rewritten by the next chunk
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Tuned backward of LinearPredictiveCodingAnalysis for float32 frames, lpc_order 24, 25 <= L <= 512
 // (the adjoint of acorr.py:110-120 + levdur.py:113-127 in one launch).  One wave64 per workgroup
 // owns 64 consecutive frames:
@@ -874,6 +1034,31 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
             unsigned* queue = (unsigned*)scratch;
             if (hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess)
                 return fail(DSA_ERR_LAUNCH, "frame_window_lpc: cannot reset the ticket counter%s");
+            // lag sums: float32 matrix instruction (default) or the float64 vector unit (DSA_LPC_LAGSUMS=f64: exact sums)
+            static const bool exact = [] { const char* e = getenv("DSA_LPC_LAGSUMS"); return e && e[0] == 'f' && e[1] == '6'; }();
+            if (!exact && L <= 512) {
+                const int lds_m = 4 * (fpi * kLpcM1 * (int)sizeof(double) + 26 * 20 * (int)sizeof(float));
+                long wgs = (total_sc + 3) / 4;
+                const long wg_cap = 256L * (lds_m <= 53 * 1024 ? 3 : 2);   // workgroups of four waves per CU
+                if (wgs > wg_cap) wgs = wg_cap;
+#define DSA_LPC_MFMA(NEV, LCV)                                                                                                     \
+    do {                                                                                                                           \
+        static std::atomic<uint64_t> attr_m{0};                                                                                    \
+        if (lds_m > 48 * 1024 && !ensure_dynamic_lds((const void*)frame_window_lpc24_mfma_kernel<NEV, LCV>, lds_m, attr_m))        \
+            return fail(DSA_ERR_LAUNCH, "frame_window_lpc: cannot reserve LDS%s");                                                 \
+        hipLaunchKernelGGL((frame_window_lpc24_mfma_kernel<NEV, LCV>), dim3((unsigned)wgs), dim3(256), lds_m, st, (const float*)x, \
+                           (long)T, (long)N, L, P, left, pad_mode, (const float*)w, eps, (float*)out, total_sc, sc_per_utt, queue, fpi); \
+    } while (0)
+                const int ne = (L + 63) / 64;
+                if (L == 400) DSA_LPC_MFMA(7, 400);   // the 25 ms window at 16 kHz
+                else if (ne <= 4) DSA_LPC_MFMA(4, 0);
+                else if (ne == 5) DSA_LPC_MFMA(5, 0);
+                else if (ne == 6) DSA_LPC_MFMA(6, 0);
+                else if (ne == 7) DSA_LPC_MFMA(7, 0);
+                else DSA_LPC_MFMA(8, 0);
+#undef DSA_LPC_MFMA
+                return check_launch("frame_window_lpc24_mfma_fwd");
+            }
             hipLaunchKernelGGL(frame_window_lpc24_kernel, dim3((unsigned)grid), dim3(64), lds_t, st, (const float*)x,
                                (long)T, (long)N, L, P, left, pad_mode, (const float*)w, eps, (float*)out, total_sc,
                                sc_per_utt, in_floats, wtab_floats, queue, fpi);

@@ -604,7 +604,7 @@ def test_lpc_datawav_and_randn_golden(golden, name, dt):
         if acr is not None:
             close(host(F.acorr(xw, 24)), acr, 1e-4, 1e-7)
         a = dsp.LPC(400, 24, eps=1e-5, dtype=dt, device=DEV)(xw)
-        assert _lib.last_kernel() == ("frame_window_lpc24_fwd" if dt == torch.float32 else "levdur_fwd")
+        assert _lib.last_kernel() == ("frame_window_lpc24_mfma_fwd" if dt == torch.float32 else "levdur_fwd")
         close(host(a), ref, **tol)
         a2 = dsp.LevinsonDurbin(24, eps=1e-5, dtype=dt, device=DEV)(dsp.Autocorrelation(400, 24)(xw))
         if dt == torch.float64:

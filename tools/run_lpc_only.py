@@ -9,5 +9,5 @@ w = dsp.Window(400, device=dev).window
 with torch.no_grad():
     for _ in range(10):
         y = ops.frame_window_lpc(x, w, 400, 80, 24, 1e-5)
-assert _lib.last_kernel() == "frame_window_lpc24_fwd", _lib.last_kernel()
+assert _lib.last_kernel() in ("frame_window_lpc24_fwd", "frame_window_lpc24_mfma_fwd"), _lib.last_kernel()
 torch.cuda.synchronize()
