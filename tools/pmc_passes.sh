@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 CMD="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --ramp-seconds 0 --no-cpu-baseline --no-configs"
 if [ "${2:-fwd}" = "bwd" ]; then CMD="python $GRAFT_REPO_ROOT/tools/run_mcep_bwd_only.py"; fi
 if [ "${2:-fwd}" = "fused" ]; then CMD="python $GRAFT_REPO_ROOT/tools/run_fused_only.py"; fi
+if [ "${2:-fwd}" = "fusedmcep" ]; then CMD="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --ramp-seconds 0 --no-cpu-baseline --no-configs --path fused"; fi
 if [ "${2:-fwd}" = "lpc" ]; then CMD="python $GRAFT_REPO_ROOT/tools/run_lpc_only.py"; fi
 if [ "${2:-fwd}" = "stftbwd" ]; then CMD="env N=6 SMALL=0 python $GRAFT_REPO_ROOT/tools/run_stft_bwd_only.py"; fi
 i=0
