@@ -70,31 +70,22 @@ __device__ __forceinline__ void elim_step(f32x4 (&a)[Blk<NG>::N], int gs, bool& 
     }
     __builtin_amdgcn_sched_barrier(0);
 }
-// Steps K .. : unconditional below NMIN (every order this instantiation serves has them), then nested early exits -- a step
-// under its own `if` would make every register quadruple a phi at every one of the branches
-template <int NG, int NMIN, int K>
-__device__ __forceinline__ void elim_from(f32x4 (&a)[Blk<NG>::N], int n, int gs, bool& bad)
+// All 4 NG - 1 steps, unconditionally: the right-hand side rides in the LAST column (4 NG - 1) whatever the order, and the rows /
+// columns between the order and that column are the identity (pivot 1, multipliers 0) -- no step depends on n at run time (a step
+// under its own `if` makes every register quadruple a phi at every branch: 1.1 KB of scratch per lane at NG = 13).
+template <int NG, int... Ks>
+__device__ __forceinline__ void elim_all(f32x4 (&a)[Blk<NG>::N], int gs, bool& bad, std::integer_sequence<int, Ks...>)
 {
-    if constexpr (K < 4 * NG - 1) {
-        if constexpr (K < NMIN) {
-            elim_step<NG, K>(a, gs, bad);
-            elim_from<NG, NMIN, K + 1>(a, n, gs, bad);
-        } else {
-            if (K < n) {   // uniform
-                elim_step<NG, K>(a, gs, bad);
-                elim_from<NG, NMIN, K + 1>(a, n, gs, bad);
-            }
-        }
-    }
+    (elim_step<NG, Ks>(a, gs, bad), ...);
 }
 
 // x_k = -(sum_{j > k} U_kj x_j - b_k) / U_kk, the right-hand-side slot of xq preset to -1 on its owner lane (the diagonal and
 // sub-diagonal lanes of the row's own slot still hold 0 in xq when the row is solved)
 template <int NG, int RG, int I>
-__device__ __forceinline__ void backsub_row(const f32x4 (&a)[Blk<NG>::N], float (&xq)[NG], const float (&part)[4], int n, int gs)
+__device__ __forceinline__ void backsub_row(const f32x4 (&a)[Blk<NG>::N], float (&xq)[NG], const float (&part)[4], int gs)
 {
     using B = Blk<NG>;
-    if (4 * RG + I < n) {   // uniform
+    if constexpr (4 * RG + I < 4 * NG - 1) {
         const float sl = quad_sum(__builtin_fmaf(a[B::at(RG, RG)][I], xq[RG], part[I]));
         const float diag = quad_bcast<I>(a[B::at(RG, RG)][I]);   // the diagonal element sits on lane I of the quad
         const float xk = -sl * __builtin_amdgcn_rcpf(diag);
@@ -102,7 +93,7 @@ __device__ __forceinline__ void backsub_row(const f32x4 (&a)[Blk<NG>::N], float 
     }
 }
 template <int NG, int RG>
-__device__ __forceinline__ void backsub_group(const f32x4 (&a)[Blk<NG>::N], float (&xq)[NG], int n, int gs)
+__device__ __forceinline__ void backsub_group(const f32x4 (&a)[Blk<NG>::N], float (&xq)[NG], int gs)
 {
     using B = Blk<NG>;
     float part[4] = {0.f, 0.f, 0.f, 0.f};
@@ -112,25 +103,25 @@ __device__ __forceinline__ void backsub_group(const f32x4 (&a)[Blk<NG>::N], floa
 #pragma unroll
         for (int i = 0; i < 4; ++i) part[i] = __builtin_fmaf(v[i], xq[c], part[i]);
     }
-    backsub_row<NG, RG, 3>(a, xq, part, n, gs);
-    backsub_row<NG, RG, 2>(a, xq, part, n, gs);
-    backsub_row<NG, RG, 1>(a, xq, part, n, gs);
-    backsub_row<NG, RG, 0>(a, xq, part, n, gs);
+    backsub_row<NG, RG, 3>(a, xq, part, gs);
+    backsub_row<NG, RG, 2>(a, xq, part, gs);
+    backsub_row<NG, RG, 1>(a, xq, part, gs);
+    backsub_row<NG, RG, 0>(a, xq, part, gs);
 }
 template <int NG, int... Gs>
-__device__ __forceinline__ void backsub_all(const f32x4 (&a)[Blk<NG>::N], float (&xq)[NG], int n, int gs, std::integer_sequence<int, Gs...>)
+__device__ __forceinline__ void backsub_all(const f32x4 (&a)[Blk<NG>::N], float (&xq)[NG], int gs, std::integer_sequence<int, Gs...>)
 {
-    (backsub_group<NG, NG - 1 - Gs>(a, xq, n, gs), ...);
+    (backsub_group<NG, NG - 1 - Gs>(a, xq, gs), ...);
 }
 
 // LDS record of a system (floats): q window [0, QW) | mirrored p window pm[d + n - 1] = p[|d|], d in (-n, n) at [QW, 2 QW) | rhs [2 QW, 2 QW + RW)
-template <int NG, int NMIN>
+template <int NG>
 __global__ __launch_bounds__(256, 1) void thsolve_quadn_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ q, int ldq,
                                                                const float* __restrict__ r, int ldr, const float* __restrict__ sub,
                                                                const float* __restrict__ add, long F, int n, float* __restrict__ g)
 {
     using B = Blk<NG>;
-    constexpr int NMAX = 4 * NG - 1;            // largest order: column n (the right-hand side) must fit the NG column groups
+    constexpr int NMAX = 4 * NG - 1;            // largest order: the right-hand side takes the last of the 4 NG columns
     constexpr int QW = 2 * NMAX + 1;            // >= 2 n - 1, odd: consecutive records start on different banks
     constexpr int REC = 2 * QW + 4 * NG;        // floats per system
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -164,8 +155,8 @@ __global__ __launch_bounds__(256, 1) void thsolve_quadn_kernel(const float* __re
         const float* pm = qs + QW + (n - 1);
         const float* rs = qs + 2 * QW;
         f32x4 a[B::N];
-        // rows of T + H, column n = right-hand side, rows / columns beyond: zero (never pivots; the multipliers of pad rows only
-        // write pad rows)
+        // rows of T + H; the right-hand side in the last column CN = 4 NG - 1; rows / columns n .. CN - 1: the identity
+        constexpr int CN = 4 * NG - 1;
 #pragma unroll
         for (int rg = 0; rg < NG; ++rg) {
 #pragma unroll
@@ -174,21 +165,23 @@ __global__ __launch_bounds__(256, 1) void thsolve_quadn_kernel(const float* __re
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = 4 * rg + i;
-                    float v = 0.f;
+                    float v;
                     if (row < n) {   // uniform
                         const float tv = pm[(col < n ? col : row) - row] + qs[col < n ? row + col : 0];
-                        v = col < n ? tv : (col == n ? rs[row] : 0.f);
+                        v = col < n ? tv : (col == CN ? rs[row] : 0.f);
+                    } else {
+                        v = (col == row && row < CN) ? 1.f : 0.f;
                     }
                     a[B::at(rg, cg)][i] = v;
                 }
             }
         }
         bool bad = false;
-        elim_from<NG, NMIN, 0>(a, n, gs, bad);
+        elim_all<NG>(a, gs, bad, std::make_integer_sequence<int, CN>{});
         float xq[NG];
 #pragma unroll
-        for (int c = 0; c < NG; ++c) xq[c] = (4 * c + gs == n) ? -1.f : 0.f;
-        backsub_all<NG>(a, xq, n, gs, std::make_integer_sequence<int, NG>{});
+        for (int c = 0; c < NG; ++c) xq[c] = (4 * c + gs == CN) ? -1.f : 0.f;
+        backsub_all<NG>(a, xq, gs, std::make_integer_sequence<int, NG>{});
         // every lane of the quad saw the same pivots
         const long f = fbase + nq;
         if (f < F) {
@@ -211,18 +204,18 @@ __global__ __launch_bounds__(256, 1) void thsolve_quadn_kernel(const float* __re
 int thsolve_fix_marked_n(const void* p, int ldp, const void* q, int ldq, const void* r, int ldr, const void* sub, const void* add,
                          int64_t F, int n, void* g, hipStream_t st);
 
-template <int NG, int NMIN>
+template <int NG>
 static int thsolve_quadn_launch(const void* p, int ldp, const void* q, int ldq, const void* r, int ldr, const void* sub, const void* add,
                                 int64_t F, int n, void* g, hipStream_t st)
 {
     constexpr int NMAX = 4 * NG - 1, REC = 2 * (2 * NMAX + 1) + 4 * NG;
     const int lds_bytes = 4 * 16 * REC * (int)sizeof(float);
     static std::atomic<uint64_t> attr{0};
-    if (lds_bytes > 48 * 1024 && !ensure_dynamic_lds((const void*)tq::thsolve_quadn_kernel<NG, NMIN>, lds_bytes, attr))
+    if (lds_bytes > 48 * 1024 && !ensure_dynamic_lds((const void*)tq::thsolve_quadn_kernel<NG>, lds_bytes, attr))
         return fail(DSA_ERR_LAUNCH, "thsolve_quad: cannot reserve LDS%s");
     long blocks = ((F + 15) / 16 + 3) / 4;
     if (blocks > 256) blocks = 256;   // one workgroup per CU (one wave per SIMD: the matrix takes up to 420 registers)
-    hipLaunchKernelGGL((tq::thsolve_quadn_kernel<NG, NMIN>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, (const float*)p, ldp,
+    hipLaunchKernelGGL((tq::thsolve_quadn_kernel<NG>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, (const float*)p, ldp,
                        (const float*)q, ldq, (const float*)r, ldr, (const float*)sub, (const float*)add, (long)F, n, (float*)g);
     if (int rc = check_launch("th_solve_quadn_fwd")) return rc;
     return thsolve_fix_marked_n(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
@@ -234,11 +227,11 @@ int thsolve_quadn_fwd(const void* p, int ldp, const void* q, int ldq, const void
                       int n, void* g, hipStream_t st)
 {
     if (n < 2) return fail(DSA_ERR_UNSUPPORTED, "thsolve_quad: order below 2%s");
-    if (n <= 27) return thsolve_quadn_launch<7, 2>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
-    if (n <= 35) return thsolve_quadn_launch<9, 28>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
-    if (n <= 43) return thsolve_quadn_launch<11, 36>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
-    if (n <= 51) return thsolve_quadn_launch<13, 44>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
-    if (n <= 55) return thsolve_quadn_launch<14, 52>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
+    if (n <= 27) return thsolve_quadn_launch<7>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
+    if (n <= 35) return thsolve_quadn_launch<9>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
+    if (n <= 43) return thsolve_quadn_launch<11>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
+    if (n <= 51) return thsolve_quadn_launch<13>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
+    if (n <= 55) return thsolve_quadn_launch<14>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
     return fail(DSA_ERR_UNSUPPORTED, "thsolve_quad: order above 55%s");
 }
 
