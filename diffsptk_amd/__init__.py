@@ -7,7 +7,11 @@ path of sp-nitech/diffsptk, behind the reference's own module / functional API.
     mc = mcep(stft(x))          # x: (..., T) on the GPU
 
 All computation runs in hand-written HIP kernels (diffsptk_amd/csrc) through the C-ABI declared in
-include/diffsptk_amd.h.  There is no CPU fallback.
+include/diffsptk_amd.h -- no vendor BLAS / FFT library is linked or called.  The only torch-operator
+compositions are the `learnable=` options (modules/_learnable.py, as SURVEY.md 8(b) allows) and scalar
+glue around kernels.  There is no CPU fallback.
+
+    mc = diffsptk.fuse(stft, mcep)(x)   # the same in ONE launch (no spectrogram in memory)
 """
 from . import functional
 from .graph import Graphed

@@ -158,3 +158,18 @@ def test_fused_replays_from_a_hip_graph():
         out2 = g(x1)
     assert torch.equal(out, eager) and torch.equal(out2, eager)
     assert float((out - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
+def test_both_paths_are_deterministic_under_full_load():
+    """Round 4 found packed float32 instructions delivering stale results next to another wave's 4 x 4 x 1 matrix products
+    (DESIGN.md 3.25): about 60 wrong frames per 204 800, different ones in every launch.  Both shipped paths must be free of it:
+    five launches each at the bench size, all bit-identical (the failure was visible in every single launch)."""
+    stft, mcep, fused = _modules()
+    x = torch.randn(1024, 16000, generator=torch.Generator().manual_seed(77)).to(DEV)
+    with torch.no_grad():
+        ref2 = mcep(stft(x))
+        ref1 = fused(x)
+        for _ in range(5):
+            assert torch.equal(mcep(stft(x)), ref2)
+            assert torch.equal(fused(x), ref1)
+    assert float((ref1 - ref2).abs().max()) <= 1e-6 * float(ref2.abs().max())
