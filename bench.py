@@ -350,21 +350,25 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
         "workload": f"BASELINE configs[3]: Frame+Window+acorr+levdur (M=24), {B} utterances x 1 s ({fr} frames), one wave per 64 frames",
         "frames/s": fr / t_l, "ms_fused_fwd": t_l * 1e3, "ms_module_chain_fwd": t_chain * 1e3, "ms_module_chain_fwd_bwd": t_lfb * 1e3,
         "roofline": (lambda mm: {
-                     "kernel": k_lpc, "bound": "f32 matrix instruction (lag sums as a banded Gram product) + float64 vector (Levinson)" if mm
+                     "kernel": k_lpc, "bound": "valu_issue (binary16-split Gram products on the matrix pipe; float64 lag sums and Levinson on the vector ALU)" if mm
                      else "valu_issue (float64)",
                      # executed matrix flops: 21 v_mfma_f32_16x16x4_f32 per frame (2048 flops each) against the dense float32 matrix peak;
                      # exact kernel: algorithmic float64 flops against the float64 vector peak
-                     "achieved": (21 * 2048 * fr / t_l / 1e12) if mm else LPC_FLOP_PER_FRAME * fr / t_l / 1e12,
-                     "peak": FP32_PEAK_TFLOPS if mm else FP64_PEAK_TFLOPS, "unit": "TFLOP/s (f32 matrix, executed)" if mm else "TFLOP/s (fp64 vector)",
-                     "frac": (21 * 2048 * fr / t_l / 1e12 / FP32_PEAK_TFLOPS) if mm else LPC_FLOP_PER_FRAME * fr / t_l / 1e12 / FP64_PEAK_TFLOPS,
+                     # the binding unit is the vector ALU (window, binary16 split, float64 lag sums and Levinson): vector wave-instructions per
+                     # frame (static: profiles/) against the nominal issue rate; exact kernel: float64 flops against the float64 vector peak
+                     "achieved": ((pmc_static(k_lpc) or {}).get("derived", {}).get("valu_insts_per_frame", 0) * fr / t_l / 1e9) if mm
+                     else LPC_FLOP_PER_FRAME * fr / t_l / 1e12,
+                     "peak": VALU_ISSUE_PEAK_GIPS if mm else FP64_PEAK_TFLOPS, "unit": "G wave-instr/s" if mm else "TFLOP/s (fp64 vector)",
+                     "frac": ((pmc_static(k_lpc) or {}).get("derived", {}).get("valu_insts_per_frame", 0) * fr / t_l / 1e9 / VALU_ISSUE_PEAK_GIPS) if mm
+                     else LPC_FLOP_PER_FRAME * fr / t_l / 1e12 / FP64_PEAK_TFLOPS,
                      "traffic": pmc_traffic(k_lpc, fr), "avg_launch_ms": t_l * 1e3, "flop_per_frame": LPC_FLOP_PER_FRAME,
                      "algorithmic_frac_f32": LPC_FLOP_PER_FRAME * fr / t_l / 1e12 / FP32_PEAK_TFLOPS,
                      "pmc": (pmc_static(k_lpc) or {}).get("derived"),
                      "pmc_source": (pmc_static(k_lpc) or {}).get("_source"),
                      "hbm": {"achieved": LPC_BYTES_PER_FRAME * fr / t_l / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": LPC_BYTES_PER_FRAME * fr / t_l / 1e9 / HBM_PEAK_GBS},
-                     "note": "420 B/frame: far from the HBM roof.  Round 4: lag sums on v_mfma_f32_16x16x4_f32 (21 per frame, exact float32 "
-                             "products, float64 only to add the 16 entries of a lag and for the recursion), DESIGN.md 3.3; "
+                     "note": "420 B/frame: far from the HBM roof.  Round 4: lag sums as a banded Gram product on v_mfma_f32_16x16x32_f16 (9 per frame, "
+                             "3-term binary16 splits; float64 only to add the 16 entries of a lag and for the recursion), DESIGN.md 3.3; "
                              "DSA_LPC_LAGSUMS=f64 selects the exact float64-vector kernel of rounds 1-3"})("mfma" in (k_lpc or "")),
         "timing": "back-to-back launches (gpu_time)",
     }

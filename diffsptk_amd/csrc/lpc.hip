@@ -452,17 +452,34 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_kernel(
 // hold every product xw[l] xw[l + m], m <= 24, exactly once: entry (i, j) of C_s is lag 16 (s - 1) + j - i summed over the
 // positions l = i (mod 16).  Operands need no staging at all: lane = i + 16 k of v_mfma_f32_16x16x4_f32 is sample 64 e + lane of
 // the frame -- a coalesced load times the window -- and the B operand of C2 / C3 is the same load 16 / 32 samples further on
-// (L1 hits).  21 matrix instructions per frame (L = 400), float32 products are exact, each entry accumulates <= 7 instructions'
-// worth of products in float32; the 16 entries of a lag are added in FLOAT64 (scattered through LDS so that a lane reads its lag's
+// (L1 hits).  The products run as 3-term binary16 splits on the matrix pipe (9 instructions per frame, see the loop); the 16 entries of a lag are added in FLOAT64 (scattered through LDS so that a lane reads its lag's
 // 16 slots as four 16-byte reads), then Levinson-Durbin in float64, one frame per lane, as above.
 // Accuracy: the lag sums are ~1e-7 r[0] from the exact ones (what the reference's own float32 FFT route has); the exact kernel
 // stays selectable (DSA_LPC_LAGSUMS=f64) and is what float64 input runs.
+// x = hi + lo in binary16 (round to nearest), two values at a time: one packed conversion, then lo = binary16(x - float(hi)) as ONE
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 per value (binary16 operand from its half register, float32 multiply-add, result rounded into
+// the low / high half).  The wait state after each half-register write is what gfx950 wants before the register is touched again
+// (same helper as csrc/mcep_mfma_f16.h:split2).
+typedef _Float16 lp_h2 __attribute__((ext_vector_type(2)));
+typedef float lp_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lp_split2(float x0, float x1, lp_h2& hi, lp_h2& lo)
+{
+    hi = __builtin_convertvector(lp_f2{x0, x1}, lp_h2);
+    const unsigned hb = __builtin_bit_cast(unsigned, hi);
+    unsigned lb;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\ts_nop 0\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 0"
+        : "=&v"(lb) : "v"(hb), "v"(x0), "v"(x1));
+    lo = __builtin_bit_cast(lp_h2, lb);
+}
+
 template <int NE, int LC>   // NE: registers of 64 samples that cover the frame, ceil(L / 64); LC: the frame length at compile time (0: run time)
 __global__ __launch_bounds__(256, 3) void frame_window_lpc24_mfma_kernel(
     const float* __restrict__ x, long Tlen, long N, int L_rt, int P, int left, int mode, const float* __restrict__ w, double eps,
     float* __restrict__ out, long total_sc, int sc_per_utt, unsigned* __restrict__ queue, int fpi)
 {
     typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 lp_h8 __attribute__((ext_vector_type(8)));
     constexpr int DS = 20;                         // floats per lag row of the scatter area (16 slots, 16-byte aligned rows)
     // dynamic LDS, per wave: rbuf[fpi][25] doubles | dm[26][DS] floats  (fpi = 52 at the bench geometry: three workgroups per CU)
     extern __shared__ __attribute__((aligned(16))) unsigned char lpc_smem[];
@@ -535,14 +552,48 @@ __global__ __launch_bounds__(256, 3) void frame_window_lpc24_mfma_kernel(
                 vc[e] = 64 * e + lane + 32 < L ? cc[e] * wc[e] : 0.f;
             }
             if (fi + 1 < nfr) fetch(fi + 1);
-            f4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = c1, c3 = c1;
+            // The Gram products on the BINARY16 matrix pipe (separate from the float32 datapath the float64 sums and the recursion
+            // need): k-slot (g, e) of v_mfma_f32_16x16x32_f16 <-> block 4 e + g, i.e. element e of a lane's operand is its register
+            // e -- sample 64 e + lane -- so A / B are just the lane's eight values packed.  Every value is split hi + lo into two
+            // binary16 numbers after scaling the frame by a power of two that puts its largest sample in [2^13, 2^14) (lo stays a
+            // normal number down to 2^-17 of the maximum); a product is three instructions, hi hi + hi lo + lo hi (the dropped
+            // lo lo is 2^-22 of the product), exact binary16 products accumulated in float32 over the whole frame at once (K = 32
+            // blocks of 16 samples cover 512).  9 matrix instructions per frame instead of 19 float32 ones (round 4, first version:
+            // 608 cycles of the float32 datapath per frame).
+            float fmx = 0.f;
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(va[e], va[e], c1, 0, 0, 0);
-                // (with the frame length known, operands that lie entirely past the frame are zero: their products are skipped)
-                if (!LC || 64 * e + 16 < LC) c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(va[e], vb[e], c2, 0, 0, 0);
-                if (!LC || 64 * e + 32 < LC) c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(va[e], vc[e], c3, 0, 0, 0);
+            for (int e = 0; e < NE; ++e) fmx = __builtin_fmaxf(fmx, __builtin_fabsf(va[e]));   // (vb / vc hold the same samples 16 / 32 on)
+#define DSA_LPC_MAX(CTRL, RM)                                                                                         \
+    fmx = __builtin_fmaxf(fmx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(fmx), CTRL, RM, 0xf, false)))
+            DSA_LPC_MAX(0x111, 0xf); DSA_LPC_MAX(0x112, 0xf); DSA_LPC_MAX(0x114, 0xf); DSA_LPC_MAX(0x118, 0xf);   // row_shr 1, 2, 4, 8
+            DSA_LPC_MAX(0x142, 0xa); DSA_LPC_MAX(0x143, 0xc);                                                     // row_bcast 15, 31
+#undef DSA_LPC_MAX
+            const float fmax_all = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fmx), 63));
+            int fe = __builtin_amdgcn_frexp_expf(fmax_all);            // fmax_all = m 2^fe, m in [0.5, 1)
+            fe = fe < -100 ? -100 : (fe > 100 ? 100 : fe);             // silent frames / denormals: any scale will do
+            const int sh = 14 - fe;                                    // scaled maximum in [2^13, 2^14)
+            lp_h8 ah, al, bh, bl, ch, cl;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                auto sc = [&](const float (&v)[NE], int i) __attribute__((always_inline)) { return i < NE ? __builtin_ldexpf(v[i < NE ? i : 0], sh) : 0.f; };
+                lp_h2 h, l;
+                lp_split2(sc(va, e), sc(va, e + 1), h, l);
+                ah[e] = h[0]; ah[e + 1] = h[1]; al[e] = l[0]; al[e + 1] = l[1];
+                lp_split2(sc(vb, e), sc(vb, e + 1), h, l);
+                bh[e] = h[0]; bh[e + 1] = h[1]; bl[e] = l[0]; bl[e + 1] = l[1];
+                lp_split2(sc(vc, e), sc(vc, e + 1), h, l);
+                ch[e] = h[0]; ch[e + 1] = h[1]; cl[e] = l[0]; cl[e + 1] = l[1];
             }
+            f4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = c1, c3 = c1;
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ah, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ch, c3, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, al, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, cl, c3, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ah, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ch, c3, 0, 0, 0);
             __builtin_amdgcn_wave_barrier();   // the previous frame's row reads are done (LDS operations of a wave run in order)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -564,7 +615,7 @@ __global__ __launch_bounds__(256, 3) void frame_window_lpc24_mfma_kernel(
                 const double other = __hiloint2double(hi, lo);
                 // the same association on both halves: (slots 0..7) + (slots 8..15)
                 const double tot = h_ == 0 ? sm + other : other + sm;
-                if (lane < kLpcM1) rbuf[fi * kLpcM1 + lane] = tot;
+                if (lane < kLpcM1) rbuf[fi * kLpcM1 + lane] = ldexp(tot, -2 * sh);   // the frame's scale, undone exactly
             }
         }
         __builtin_amdgcn_wave_barrier();
