@@ -59,9 +59,6 @@ inline bool ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64
 // 24 x 24 Toeplitz-plus-Hankel systems, float32, 16 per wave in the quad layout (csrc/mcep_mfma.hip)
 int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, void* g, hipStream_t st, int r_stride = 24,
                        int r_off = 0, const void* add = nullptr);
-// re-solves, with row pivoting, the float32 systems whose solution rows start with NaN (csrc/mgc.hip)
-int thsolve_fix_marked(const void* p, const void* q, const void* r, int64_t F, int n, void* g, hipStream_t st, int r_stride = 0,
-                       int r_off = 0, const void* add = nullptr);
 // orders 2 .. 55, float32, strided operands (csrc/thsolve_quad.hip)
 int thsolve_quadn_fwd(const void* p, int ldp, const void* q, int ldq, const void* r, int ldr, const void* sub, const void* add, int64_t F,
                       int n, void* g, hipStream_t st);

@@ -20,6 +20,7 @@
 // round trip, log X stays in 64 VGPRs for all iterations.  Bin 256 (Nyquist) and output rt[48] are one extra
 // k-step / one VALU dot product instead of padded tiles.
 #include "common.h"
+#include "th_solve_reg.h"
 
 #include <stdlib.h>
 #include <utility>
@@ -484,6 +485,7 @@ __global__ __launch_bounds__(256) void thsolve_quad24_kernel(const float* __rest
         const float* rt_q = wl + nq * kTq;
         const float* rr_q = rt_q + 52;
         float xq[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[1], -1.f)};
+        bool bad = false;
         {
             f32x4 a[blk::NBLK];
             float ninvs[M1];
@@ -496,20 +498,29 @@ __global__ __launch_bounds__(256) void thsolve_quad24_kernel(const float* __rest
             blk_backsub_all(a, xq, gq, ninvs, std::make_integer_sequence<int, blk::NG>{});
             // No pivoting here: that is sound for the positive definite systems of the analysis (gamma in [-1, 0]), and nothing
             // guarantees it for an arbitrary caller.  A pivot that is not positive (ninv = -1 / pivot not negative, or not finite)
-            // marks the system: its solution is written as NaN and thsolve_quad24_fwd's second launch re-solves exactly those rows
-            // with row pivoting (th_solve_fwd_kernel, csrc/mgc.hip), as the reference's LAPACK call would.
-            bool bad = false;
+            // marks the system: it is solved again below, with row pivoting, by the whole wave (th_solve_reg.h) -- the answer the
+            // reference's LAPACK call gives.  (Round 3 wrote NaN and re-solved in a second launch that every call paid for.)
 #pragma unroll
             for (int k = 0; k < M1 - 1; ++k) bad |= !(ninvs[k] < 0.f && ninvs[k] > -3.0e38f);
-            if (bad) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) xq[c] = __builtin_nanf("");
-            }
         }
         const long f = tile * 16 + nq;
-        if (f < F) {
+        if (f < F && !bad) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) g[f * 24 + gs + 4 * c] = add ? add[f * 24 + gs + 4 * c] + xq[c] : xq[c];
+        }
+        unsigned long long marked = __ballot(bad && gs == 0 && f < F);
+        while (marked) {   // uniform; normally empty
+            const int bl = __builtin_ctzll(marked);
+            marked &= marked - 1;
+            const int sy = bl >> 2;
+            const float* qs2 = wl + sy * kTq;               // q window
+            const float* ps2 = qs2 + 52 + 27;               // p[d] at the centre of the mirrored window
+            const float rhs = lane < 24 ? qs2[104 + lane] : 0.f;
+            int col;
+            float sol;
+            th_solve_reg<float, 24>(ps2, qs2, rhs, 24, lane, col, sol);
+            const long fs = tile * 16 + sy;
+            if (lane < 24) g[fs * 24 + col] = add ? add[fs * 24 + col] + sol : sol;
         }
     }
 }
@@ -521,8 +532,7 @@ int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, v
     if (blocks > 256L * 4) blocks = 256L * 4;
     hipLaunchKernelGGL(thsolve_quad24_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)p, (const float*)q,
                        (const float*)r, (long)F, (float*)g, r_stride, r_off, (const float*)add);
-    if (int rc = check_launch("th_solve_quad_fwd")) return rc;
-    return thsolve_fix_marked(p, q, r, F, 24, g, st, r_stride, r_off, add);   // rows the unpivoted elimination gave up on (none, normally)
+    return check_launch("th_solve_quad_fwd");
 }
 
 }  // namespace dsa

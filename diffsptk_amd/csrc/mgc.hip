@@ -8,6 +8,7 @@
 // The rest of the analysis (warping / FFT stages composed into row products, pointwise spectrum arithmetic) is
 // assembled by the host layer from the library's row-product kernel (modules/mgcep.py).
 #include "common.h"
+#include "th_solve_reg.h"
 
 #include <cstdlib>
 
@@ -44,69 +45,6 @@ __device__ void th_gauss_jordan(T* Aug, int n, int W, int nrhs, int* rowof, int 
             for (int j = k + 1; j < n + nrhs; ++j) Aug[lane * W + j] -= fac * Aug[p * W + j];
         __builtin_amdgcn_wave_barrier();
     }
-}
-
-// Register version for n <= NMAX (NMAX = 24 or 32: cep_order 24 is the usual size): lane i holds row i of the system and
-// its right-hand side in registers, the pivot row reaches the other lanes through v_readlane (the pivot lane is uniform),
-// everything is statically indexed (both loops unrolled).  Same pivot rule as the LDS version below, which remains for
-// larger systems: that one spends ~80 cycles per element on dependent LDS round trips (0.53 ms per 51 200 frames of 24 x 24,
-// 43 % of a mel-generalized analysis), this one ~6 k cycles per frame.
-// Returns in (col, sol): lane i < n was the pivot row of column `col`, and x[col] = sol.
-template <typename T>
-__device__ __forceinline__ T th_readlane(T v, int src)
-{
-    if constexpr (sizeof(T) == 4) {
-        return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
-    } else {
-        const long long b = __builtin_bit_cast(long long, v);
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
-        return __builtin_bit_cast(T, (long long)(((unsigned long long)hi << 32) | lo));
-    }
-}
-template <typename T, int NMAX>
-__device__ __forceinline__ void th_solve_reg(const T* ps, const T* qs, T rhs, int n, int lane, int& col, T& sol)
-{
-    T row[NMAX];
-#pragma unroll
-    for (int j = 0; j < NMAX; ++j) {
-        const int d = lane > j ? lane - j : j - lane;
-        row[j] = (lane < n && j < n) ? ps[d] + qs[lane + j] : T(0);
-    }
-    if (lane >= n) rhs = T(0);
-    bool used = lane >= n;
-    T piv = T(1);
-    col = 0;
-#pragma unroll
-    for (int k = 0; k < NMAX; ++k) {
-        if (k < n) {   // uniform
-            // pivot = the unused row with the largest |a_ik|: one unsigned key per lane (magnitude bits with the lane in the
-            // low 6 bits: ties and near-ties go to the lowest lane), maximum over the wave by DPP shifts -- cross-lane
-            // shuffles through the LDS crossbar cost 12 dependent round trips per step here
-            const float magf = (float)(row[k] < T(0) ? -row[k] : row[k]);
-            unsigned key = used ? 0u : ((__builtin_bit_cast(unsigned, magf) & 0xffffffc0u) | (unsigned)(63 - lane));
-#define DSA_TH_MAX(CTRL, RM)                                                                                            \
-    {                                                                                                                  \
-        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key, CTRL, RM, 0xf, false);                   \
-        key = o > key ? o : key;                                                                                       \
-    }
-            DSA_TH_MAX(0x111, 0xf) DSA_TH_MAX(0x112, 0xf) DSA_TH_MAX(0x114, 0xf) DSA_TH_MAX(0x118, 0xf)   // row_shr:1, 2, 4, 8
-            DSA_TH_MAX(0x142, 0xa) DSA_TH_MAX(0x143, 0xc)                                                 // row_bcast:15, :31
-#undef DSA_TH_MAX
-            const int p = 63 - (int)(__builtin_amdgcn_readlane((int)key, 63) & 63);
-            const T pk = th_readlane(row[k], p);
-            const T fac = (lane != p) ? row[k] / pk : T(0);
-            if (lane == p) {
-                used = true;
-                col = k;
-                piv = row[k];
-            }
-#pragma unroll
-            for (int j = k + 1; j < NMAX; ++j) row[j] -= fac * th_readlane(row[j], p);
-            rhs -= fac * th_readlane(rhs, p);
-        }
-    }
-    sol = rhs / piv;
 }
 
 template <typename T>
@@ -214,97 +152,6 @@ __global__ __launch_bounds__(64) void th_solve_bwd_kernel(const T* __restrict__ 
             }
         }
     }
-}
-
-// Second launch of the unpivoted order-24 path (thsolve_quad24_fwd, csrc/mcep_mfma.hip): a wave looks at 64 solution rows at a
-// time (one coalesced-stride load per lane), and re-solves with row pivoting those the first launch marked with NaN.
-__global__ __launch_bounds__(64) void th_solve_fix_kernel(const float* __restrict__ p, const float* __restrict__ q, const float* __restrict__ r,
-                                                         long F, int n, float* __restrict__ g, int r_stride, int r_off,
-                                                         const float* __restrict__ add)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* ps = reinterpret_cast<float*>(smem_raw);
-    float* qs = ps + n;
-    const int lane = threadIdx.x;
-    for (long base = (long)blockIdx.x * 64; base < F; base += (long)gridDim.x * 64) {
-        const long fl = base + lane;
-        const float head = fl < F ? g[fl * n] : 0.f;
-        unsigned long long marked = __ballot(head != head);
-        while (marked) {
-            const int b = __builtin_ctzll(marked);
-            marked &= marked - 1;
-            const long f = base + b;
-            __builtin_amdgcn_wave_barrier();
-            if (lane < n) ps[lane] = p[f * n + lane];
-            for (int i = lane; i < 2 * n - 1; i += 64) qs[i] = q[f * (2 * n - 1) + i];
-            const float rhs = lane < n ? r[f * r_stride + r_off + lane] : 0.f;
-            __builtin_amdgcn_wave_barrier();
-            int col;
-            float sol;
-            th_solve_reg<float, 24>(ps, qs, rhs, n, lane, col, sol);
-            if (lane < n) g[f * n + col] = add ? add[f * n + col] + sol : sol;
-        }
-    }
-}
-
-// The same second launch for the general quad-layout solve (csrc/thsolve_quad.hip): strided p / q / r, an optional vector subtracted
-// from every right-hand side and an optional addend, rows in registers up to order NM.
-template <int NM>
-__global__ __launch_bounds__(64) void th_solve_fix_n_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ q, int ldq,
-                                                           const float* __restrict__ r, int ldr, const float* __restrict__ sub,
-                                                           const float* __restrict__ add, long F, int n, float* __restrict__ g)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* ps = reinterpret_cast<float*>(smem_raw);
-    float* qs = ps + n;
-    const int lane = threadIdx.x;
-    for (long base = (long)blockIdx.x * 64; base < F; base += (long)gridDim.x * 64) {
-        const long fl = base + lane;
-        const float head = fl < F ? g[fl * n] : 0.f;
-        unsigned long long marked = __ballot(head != head);
-        while (marked) {
-            const int b = __builtin_ctzll(marked);
-            marked &= marked - 1;
-            const long f = base + b;
-            __builtin_amdgcn_wave_barrier();
-            if (lane < n) ps[lane] = p[f * (long)ldp + lane];
-            for (int i = lane; i < 2 * n - 1; i += 64) qs[i] = q[f * (long)ldq + i];
-            const float rhs = lane < n ? r[f * (long)ldr + lane] - (sub ? sub[lane] : 0.f) : 0.f;
-            __builtin_amdgcn_wave_barrier();
-            int col;
-            float sol;
-            th_solve_reg<float, NM>(ps, qs, rhs, n, lane, col, sol);
-            if (lane < n) g[f * n + col] = add ? add[f * n + col] + sol : sol;
-        }
-    }
-}
-
-int thsolve_fix_marked_n(const void* p, int ldp, const void* q, int ldq, const void* r, int ldr, const void* sub, const void* add,
-                         int64_t F, int n, void* g, hipStream_t st)
-{
-    long blocks = (F + 63) / 64;
-    if (blocks > 4096) blocks = 4096;
-    const size_t lds = sizeof(float) * (3 * n);
-#define DSA_FIXN(NM)                                                                                                              \
-    hipLaunchKernelGGL((th_solve_fix_n_kernel<NM>), dim3((unsigned)blocks), dim3(64), lds, st, (const float*)p, ldp, (const float*)q, ldq, \
-                       (const float*)r, ldr, (const float*)sub, (const float*)add, (long)F, n, (float*)g)
-    if (n <= 32) DSA_FIXN(32);
-    else if (n <= 48) DSA_FIXN(48);
-    else DSA_FIXN(64);
-#undef DSA_FIXN
-    return check_launch("th_solve_quadn_fwd");
-}
-
-int thsolve_fix_marked(const void* p, const void* q, const void* r, int64_t F, int n, void* g, hipStream_t st, int r_stride, int r_off,
-                       const void* add)
-{
-    if (n > 24) return DSA_OK;
-    if (r_stride == 0) r_stride = n;
-    long blocks = (F + 63) / 64;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(th_solve_fix_kernel, dim3((unsigned)blocks), dim3(64), sizeof(float) * (3 * n), st, (const float*)p, (const float*)q,
-                       (const float*)r, (long)F, n, (float*)g, r_stride, r_off, (const float*)add);
-    return check_launch("th_solve_quad_fwd");
 }
 
 // Cotangents of the Toeplitz column p and the Hankel sequence q from u = A^{-1} gbar and the forward's solution g:

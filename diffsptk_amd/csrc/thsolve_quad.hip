@@ -15,10 +15,11 @@
 // LDS, no pivot search.  The right-hand side rides as column n.  Back substitution: row sums per lane, two quad rotations, one
 // multiply by the pivot's reciprocal.
 // No pivoting: sound for the positive definite systems of the analysis; a system whose elimination meets a non-positive or
-// non-finite pivot is written as NaN and re-solved by the pivoted kernel (thsolve_fix_marked_n), as the order-24 path does.
+// non-finite pivot is solved again inside the launch by the whole wave with row pivoting (th_solve_reg.h).
 #include <utility>
 
 #include "common.h"
+#include "th_solve_reg.h"
 
 namespace dsa {
 namespace tq {
@@ -182,27 +183,36 @@ __global__ __launch_bounds__(256, 1) void thsolve_quadn_kernel(const float* __re
 #pragma unroll
         for (int c = 0; c < NG; ++c) xq[c] = (4 * c + gs == CN) ? -1.f : 0.f;
         backsub_all<NG>(a, xq, gs, std::make_integer_sequence<int, NG>{});
-        // every lane of the quad saw the same pivots
+        // every lane of the quad saw the same pivots.  A system whose elimination met a non-positive or non-finite pivot is solved
+        // again HERE, with row pivoting, by the whole wave (one row per lane: th_solve_reg) -- the answer the reference's LAPACK call
+        // gives for an arbitrary symmetric system.  (Rounds 3-4 marked such rows with NaN and re-solved them in a second launch that
+        // every call paid for.)
         const long f = fbase + nq;
         if (f < F) {
 #pragma unroll
             for (int c = 0; c < NG; ++c) {
                 const int col = 4 * c + gs;
-                if (col < n) {
-                    float v = bad ? __builtin_nanf("") : xq[c];
-                    if (add && !bad) v += add[f * (long)n + col];
-                    g[f * (long)n + col] = v;
-                }
+                if (col < n && !bad) g[f * (long)n + col] = add ? add[f * (long)n + col] + xq[c] : xq[c];
             }
+        }
+        unsigned long long marked = __ballot(bad && gs == 0 && f < F);
+        while (marked) {   // uniform; normally empty
+            const int bl = __builtin_ctzll(marked);
+            marked &= marked - 1;
+            const int sy = bl >> 2;
+            const float* qs2 = wl + sy * REC;
+            const float* ps2 = qs2 + QW + (n - 1);          // ps2[d] = p[d]
+            const float rhs = lane < n ? qs2[2 * QW + lane] : 0.f;
+            int col;
+            float sol;
+            th_solve_reg<float, NMAX <= 32 ? 32 : (NMAX <= 48 ? 48 : 64)>(ps2, qs2, rhs, n, lane, col, sol);
+            const long fs = fbase + sy;
+            if (lane < n) g[fs * (long)n + col] = add ? add[fs * (long)n + col] + sol : sol;
         }
     }
 }
 
 }  // namespace tq
-
-// pivoted re-solve of the rows the unpivoted kernel marked (first element NaN): one wave per marked system, th_solve_reg of mgc.hip
-int thsolve_fix_marked_n(const void* p, int ldp, const void* q, int ldq, const void* r, int ldr, const void* sub, const void* add,
-                         int64_t F, int n, void* g, hipStream_t st);
 
 template <int NG>
 static int thsolve_quadn_launch(const void* p, int ldp, const void* q, int ldq, const void* r, int ldr, const void* sub, const void* add,
@@ -217,8 +227,7 @@ static int thsolve_quadn_launch(const void* p, int ldp, const void* q, int ldq, 
     if (blocks > 256) blocks = 256;   // one workgroup per CU (one wave per SIMD: the matrix takes up to 420 registers)
     hipLaunchKernelGGL((tq::thsolve_quadn_kernel<NG>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, (const float*)p, ldp,
                        (const float*)q, ldq, (const float*)r, ldr, (const float*)sub, (const float*)add, (long)F, n, (float*)g);
-    if (int rc = check_launch("th_solve_quadn_fwd")) return rc;
-    return thsolve_fix_marked_n(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
+    return check_launch("th_solve_quadn_fwd");
 }
 
 // float32, 2 <= n <= 55.  p:(F, n) row stride ldp, q:(F, 2n-1) stride ldq, r:(F, n) stride ldr; sub: NULL or (n), subtracted from

@@ -62,6 +62,8 @@ class MelGeneralizedCepstrumToSpectrum(BaseFunctionalModule):
                 tens["W_re"] = to(W_re, device=device, dtype=dtype)
             if fmt >= 4:
                 tens["W_im"] = to(W_im, device=device, dtype=dtype)
+            tens.pop("A", None)   # the frequency-transform matrix is folded into W_re / W_im (equal gammas: the reference's
+                                  # chain is the frequency transform alone, mgc2mgc.py:263-279 -- no n_fft-point step to alias)
         return Precomputed(values={"fmt": fmt, "fft_length": fft_length, "cfg": pre.values["cfg"]}, tensors=tens)
 
     @staticmethod
