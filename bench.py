@@ -794,9 +794,9 @@ def main():
             try:   # the other path of the same step, back to back (detail file only)
                 fused_mod = dsp.fuse(stft, mcep)
                 with torch.no_grad():
-                    t_fu = gpu_time(lambda: fused_mod(xl), n=10) * 1e-3
+                    t_fu = gpu_time(lambda: fused_mod(xl), n=40) * 1e-3
                     k_fu = _lib.last_kernel()
-                    t_two = gpu_time(lambda: mcep(stft(xl)), n=10) * 1e-3
+                    t_two = gpu_time(lambda: mcep(stft(xl)), n=40) * 1e-3
                 fb = FP * 4 + M1 * 4
                 res["fused_path"] = {
                     "kernel": k_fu, "path": fused_mod.last_path, "ms_per_launch": t_fu * 1e3, "frames/s": frames_launch / t_fu,
