@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 119 /* 0.1.3: + dsa_gc2gc_fwd (generalized cepstral transformation in one launch), dsa_mgcep_step */
+#define DSA_VERSION 120 /* 0.1.4: + dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
