@@ -31,7 +31,7 @@ def test_library_exports_every_header_symbol():
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert _lib.load().dsa_version() == 119
+    assert _lib.load().dsa_version() == int(re.search(r"#define DSA_VERSION (\d+)", header).group(1)) >= 120
     assert _lib.load().dsa_num_frames(16000, 80) == 200
     assert _lib.load().dsa_num_frames(19200, 80) == 240
 
