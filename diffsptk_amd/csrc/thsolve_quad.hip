@@ -115,64 +115,73 @@ __device__ __forceinline__ void backsub_all(const f32x4 (&a)[Blk<NG>::N], float 
     (backsub_group<NG, NG - 1 - Gs>(a, xq, gs), ...);
 }
 
-// LDS record of a system (floats): q window [0, QW) | mirrored p window pm[d + n - 1] = p[|d|], d in (-n, n) at [QW, 2 QW) | rhs [2 QW, 2 QW + RW)
-template <int NG>
+// LDS record of a system (floats), REC = 16 NG + 3 (odd: the 16 records of a wave start on different banks):
+//   q window  [0, QW), QW = 8 NG - 1: q[k] at k, zeros from 2 n - 1 on           (the Hankel term of element (i, j) is entry i + j <= 2 CN)
+//   p window  [QW, QW + 4 NG + 3): p[|d|] at QW + 3 + d, d in [-3, 4 NG), zero for |d| >= n   (upper triangle: j - i >= -3 inside a block)
+//   rhs       [QW + 4 NG + 3, REC): r[k] - sub[k], zeros from n on
+// NMIN: the smallest order this instantiation is launched for -- rows and columns below it need no mask.
+template <int NG, int NMIN>
 __global__ __launch_bounds__(256, 1) void thsolve_quadn_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ q, int ldq,
                                                                const float* __restrict__ r, int ldr, const float* __restrict__ sub,
                                                                const float* __restrict__ add, long F, int n, float* __restrict__ g)
 {
     using B = Blk<NG>;
-    constexpr int NMAX = 4 * NG - 1;            // largest order: the right-hand side takes the last of the 4 NG columns
-    constexpr int QW = 2 * NMAX + 1;            // >= 2 n - 1, odd: consecutive records start on different banks
-    constexpr int REC = 2 * QW + 4 * NG;        // floats per system
+    constexpr int CN = 4 * NG - 1;              // the right-hand side's column = the largest order
+    constexpr int QW = 8 * NG - 1;
+    constexpr int PO = QW + 3;                  // p[0]
+    constexpr int RO = QW + 4 * NG + 3;         // rhs[0]
+    constexpr int REC = 16 * NG + 3;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float* wl = lds + wave * 16 * REC;
     const int nq = lane >> 2, gs = lane & 3;
     const long ntiles = (F + 15) / 16;
+    const float subv = (sub && lane < n) ? sub[lane] : 0.f;
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
         __builtin_amdgcn_wave_barrier();
         const long fbase = tile * 16;
         const int nvalid = (int)((F - fbase) < 16 ? (F - fbase) : 16);
-        // stage the 16 records; a missing system is the identity with a zero right-hand side
+        // stage the 16 records, one system per round of the wave (orders up to 55: one load for p and r, two for q); a missing system
+        // is the identity with a zero right-hand side.  (Flat index loops with a division per element were a fifth of the kernel.)
         for (int e = lane; e < 16 * REC; e += 64) wl[e] = 0.f;
         __builtin_amdgcn_wave_barrier();
-        for (int idx = lane; idx < 16 * (2 * n - 1); idx += 64) {
-            const int s = idx / (2 * n - 1), k = idx - s * (2 * n - 1);
-            if (s < nvalid) wl[s * REC + k] = q[(fbase + s) * (long)ldq + k];
-        }
-        for (int idx = lane; idx < 16 * n; idx += 64) {
-            const int s = idx / n, k = idx - s * n;
-            const bool ok = s < nvalid;
-            const float pv = ok ? p[(fbase + s) * (long)ldp + k] : (k == 0 ? 1.f : 0.f);
-            wl[s * REC + QW + (n - 1) + k] = pv;
-            wl[s * REC + QW + (n - 1) - k] = pv;
-            float rv = ok ? r[(fbase + s) * (long)ldr + k] : 0.f;
-            if (ok && sub) rv -= sub[k];
-            wl[s * REC + 2 * QW + k] = rv;
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const bool ok = s < nvalid;   // uniform
+            const long f = fbase + (ok ? s : 0);
+            float* rec = wl + s * REC;
+            const float q0 = q[f * (long)ldq + (lane < 2 * n - 1 ? lane : 0)];
+            const float q1 = q[f * (long)ldq + (lane + 64 < 2 * n - 1 ? lane + 64 : 0)];
+            const float p0 = p[f * (long)ldp + (lane < n ? lane : 0)];
+            const float r0 = r[f * (long)ldr + (lane < n ? lane : 0)];
+            if (lane < 2 * n - 1) rec[lane] = ok ? q0 : 0.f;
+            if (lane + 64 < 2 * n - 1) rec[lane + 64] = ok ? q1 : 0.f;
+            if (lane < n) {
+                const float pv = ok ? p0 : (lane == 0 ? 1.f : 0.f);
+                rec[PO + lane] = pv;
+                if (lane >= 1 && lane <= 3) rec[PO - lane] = pv;
+                rec[RO + lane] = ok ? r0 - subv : 0.f;
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        const float* qs = wl + nq * REC;
-        const float* pm = qs + QW + (n - 1);
-        const float* rs = qs + 2 * QW;
+        const float* qs = wl + nq * REC + gs;        // this lane's views: column offset gs folded in
+        const float* pw = qs + PO;
+        const float* rs = wl + nq * REC + RO;
         f32x4 a[B::N];
-        // rows of T + H; the right-hand side in the last column CN = 4 NG - 1; rows / columns n .. CN - 1: the identity
-        constexpr int CN = 4 * NG - 1;
+        // element (row, col = 4 cg + gs) = p[|col - row|] + q[row + col] -- compile-time offsets from the lane's views -- masked to
+        // the order: columns n .. CN - 1 are zero, rows n .. CN - 1 the identity, column CN the right-hand side
 #pragma unroll
         for (int rg = 0; rg < NG; ++rg) {
 #pragma unroll
             for (int cg = rg; cg < NG; ++cg) {
-                const int col = 4 * cg + gs;
+                const bool cin = 4 * cg + 3 < NMIN || 4 * cg + gs < n;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = 4 * rg + i;
-                    float v;
-                    if (row < n) {   // uniform
-                        const float tv = pm[(col < n ? col : row) - row] + qs[col < n ? row + col : 0];
-                        v = col < n ? tv : (col == CN ? rs[row] : 0.f);
-                    } else {
-                        v = (col == row && row < CN) ? 1.f : 0.f;
-                    }
+                    float v = pw[4 * (cg - rg) - i] + qs[4 * (rg + cg) + i];
+                    if (4 * cg + 3 >= NMIN) v = cin ? v : 0.f;
+                    if (cg == rg && row >= NMIN && row < CN) v = (gs == i && row >= n) ? 1.f : v;
+                    if (cg == NG - 1) v = gs == 3 ? rs[row] : v;
                     a[B::at(rg, cg)][i] = v;
                 }
             }
@@ -200,32 +209,36 @@ __global__ __launch_bounds__(256, 1) void thsolve_quadn_kernel(const float* __re
             const int bl = __builtin_ctzll(marked);
             marked &= marked - 1;
             const int sy = bl >> 2;
+            // opaque copies: everything this cold path derives from (n, lane) is otherwise hoisted out of the tile loop and parked
+            // in scratch for the whole kernel
+            int nn = n, ln = lane;
+            asm volatile("" : "+s"(nn), "+v"(ln));
             const float* qs2 = wl + sy * REC;
-            const float* ps2 = qs2 + QW + (n - 1);          // ps2[d] = p[d]
-            const float rhs = lane < n ? qs2[2 * QW + lane] : 0.f;
+            const float* ps2 = qs2 + PO;                    // ps2[d] = p[d]
+            const float rhs = ln < nn ? qs2[RO + ln] : 0.f;
             int col;
             float sol;
-            th_solve_reg<float, NMAX <= 32 ? 32 : (NMAX <= 48 ? 48 : 64)>(ps2, qs2, rhs, n, lane, col, sol);
+            th_solve_reg<float, CN <= 32 ? 32 : (CN <= 48 ? 48 : 64)>(ps2, qs2, rhs, nn, ln, col, sol);
             const long fs = fbase + sy;
-            if (lane < n) g[fs * (long)n + col] = add ? add[fs * (long)n + col] + sol : sol;
+            if (ln < nn) g[fs * (long)nn + col] = add ? add[fs * (long)nn + col] + sol : sol;
         }
     }
 }
 
 }  // namespace tq
 
-template <int NG>
+template <int NG, int NMIN>
 static int thsolve_quadn_launch(const void* p, int ldp, const void* q, int ldq, const void* r, int ldr, const void* sub, const void* add,
                                 int64_t F, int n, void* g, hipStream_t st)
 {
-    constexpr int NMAX = 4 * NG - 1, REC = 2 * (2 * NMAX + 1) + 4 * NG;
+    constexpr int REC = 16 * NG + 3;
     const int lds_bytes = 4 * 16 * REC * (int)sizeof(float);
     static std::atomic<uint64_t> attr{0};
-    if (lds_bytes > 48 * 1024 && !ensure_dynamic_lds((const void*)tq::thsolve_quadn_kernel<NG>, lds_bytes, attr))
+    if (lds_bytes > 48 * 1024 && !ensure_dynamic_lds((const void*)tq::thsolve_quadn_kernel<NG, NMIN>, lds_bytes, attr))
         return fail(DSA_ERR_LAUNCH, "thsolve_quad: cannot reserve LDS%s");
     long blocks = ((F + 15) / 16 + 3) / 4;
     if (blocks > 256) blocks = 256;   // one workgroup per CU (one wave per SIMD: the matrix takes up to 420 registers)
-    hipLaunchKernelGGL((tq::thsolve_quadn_kernel<NG>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, (const float*)p, ldp,
+    hipLaunchKernelGGL((tq::thsolve_quadn_kernel<NG, NMIN>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, (const float*)p, ldp,
                        (const float*)q, ldq, (const float*)r, ldr, (const float*)sub, (const float*)add, (long)F, n, (float*)g);
     return check_launch("th_solve_quadn_fwd");
 }
@@ -236,11 +249,11 @@ int thsolve_quadn_fwd(const void* p, int ldp, const void* q, int ldq, const void
                       int n, void* g, hipStream_t st)
 {
     if (n < 2) return fail(DSA_ERR_UNSUPPORTED, "thsolve_quad: order below 2%s");
-    if (n <= 27) return thsolve_quadn_launch<7>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
-    if (n <= 35) return thsolve_quadn_launch<9>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
-    if (n <= 43) return thsolve_quadn_launch<11>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
-    if (n <= 51) return thsolve_quadn_launch<13>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
-    if (n <= 55) return thsolve_quadn_launch<14>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
+    if (n <= 27) return thsolve_quadn_launch<7, 2>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
+    if (n <= 35) return thsolve_quadn_launch<9, 28>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
+    if (n <= 43) return thsolve_quadn_launch<11, 36>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
+    if (n <= 51) return thsolve_quadn_launch<13, 44>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
+    if (n <= 55) return thsolve_quadn_launch<14, 52>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
     return fail(DSA_ERR_UNSUPPORTED, "thsolve_quad: order above 55%s");
 }
 

@@ -862,11 +862,23 @@ def mcep_newton_update(rt, av, mc):
     return out
 
 
+def mcep_newton_resid(logx, mc, D, E):
+    """rt = exp(logx - 2 mc D) E (mcep.py:210-215) in one launch (dsa_mcep_newton_resid: float32, 3 <= M + 1 <= 55): e is formed
+    chunk by chunk in the operand layout of the second product and never reaches memory."""
+    n, K = mc.size(-1), logx.size(-1)
+    Dc, Ec = D.contiguous(), E.contiguous()
+    rt = torch.empty(*mc.shape[:-1], 2 * n - 1, device=mc.device, dtype=mc.dtype)
+    with torch.cuda.device(mc.device):
+        _call("dsa_mcep_newton_resid", _p(logx), mc.numel() // n, K, _p(mc), n, _p(Dc), Dc.size(1), _p(Ec), Ec.size(1),
+              _dtype_code(mc), _p(rt), _stream())
+    return rt
+
+
 def _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter):
     """mcep.py:203-222 for the geometries the tuned kernel does not cover, as whole-batch launches of the library's own kernels
-    instead of the one-workgroup-per-frame generic kernel: per Newton step two matrix-core row products -- (F, M+1) x (M+1, K)
-    with the exp(log X - 2 .) epilogue fused, and (F, K) x (K, 2M+1) (csrc/rows_gemm.hip) -- and the batched
-    Toeplitz-plus-Hankel solve (dsa_thsolve_fwd) on slices of rt.  With a
+    instead of the one-workgroup-per-frame generic kernel: per Newton step the two row products (F, M+1) x (M+1, K) and
+    (F, K) x (K, 2M+1) with exp(log X - 2 .) between them as ONE matrix-core launch (dsa_mcep_newton_resid; orders above 54: two
+    launches of dsa_rows_gemm) and the batched Toeplitz-plus-Hankel solve-and-update (dsa_mcep_newton_update).  With a
     graph wanted the same composition runs on differentiable pieces (RowsLogFn, MatmulRowsFn, RowsExpSubFn, ThSolveFn).  Same
     arithmetic order per frame as the reference's formulation; float32 products accumulate in float32."""
     M1 = M + 1
@@ -881,10 +893,13 @@ def _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter):
     else:
         logx = RowsLogFn.apply(X2)                                        # kept: every step's epilogue reads it
         mc = rows_gemm(logx, G)
+    one_launch_resid = os.environ.get("DSA_MCEP_RESID", "1") != "0" and Xc.size(-1) >= 4
     for _ in range(n_iter):
         if want_grad:
             e = RowsExpSubFn.apply(logx, MatmulRowsFn.apply(mc, D))       # :210-212
             rt = MatmulRowsFn.apply(e, E)                                 # :214-215
+        elif 3 <= M1 <= 55 and one_launch_resid:
+            rt = mcep_newton_resid(logx, mc, D, E)                        # :210-215 in one launch, e never stored
         else:
             e = rows_gemm(mc, D, ROWS_EPI_EXPSUB, aux=logx)               # product and exp(log X - 2 .) in one launch
             rt = rows_gemm(e, E)

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 120 /* 0.1.4: + dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
+#define DSA_VERSION 121 /* 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
@@ -252,6 +252,12 @@ int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, int32_t n_it
  * row pivoting by a second launch (csrc/thsolve_quad.hip).  mc_out may be mc_in. */
 int dsa_mcep_newton_update(const void* rt, int64_t F, int32_t n, const void* alpha_vec, int32_t dtype, const void* mc_in,
                            void* mc_out, void* stream);
+/* The spectral half of the same Newton step (mcep.py:210-215) in one launch:
+ *   rt:(F, 2n-1) = exp(logx - 2 mc D) E,   logx:(F,K) = log X, mc:(F,n), D:(n x K, row stride ldd), E:(K x (2n-1), row stride lde),
+ * n = cep_order + 1 in [3, 55], K >= 4, float32.  e = exp(.) is produced chunk by chunk in the operand layout of the second
+ * product (v_mfma_f32_16x16x4_f32 for both) and never reaches memory (csrc/rows_gemm.hip:mcep_resid_mfma_kernel). */
+int dsa_mcep_newton_resid(const void* logx, int64_t F, int32_t K, const void* mc, int32_t n, const void* D, int32_t ldd,
+                          const void* E, int32_t lde, int32_t dtype, void* rt, void* stream);
 /* General float32 row product on the matrix instruction, for shapes the kernels behind dsa_freqt_fwd / _bwd do not cover (rows
  * of 512 values and more: the 1025-bin products of the 48 kHz set-ups of utils/public.py:22-104) and for the Newton step of
  * MelCepstralAnalysis (mcep.py:203-215) at geometries without a tuned kernel:

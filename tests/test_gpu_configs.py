@@ -536,7 +536,8 @@ def test_hot_path_and_f_rows_replay_from_a_hip_graph():
         g(x_new[:8])
 
 
-@pytest.mark.parametrize("F,K,N", [(300, 1025, 99), (1000, 50, 1025), (257, 513, 69), (64, 31, 17), (1, 1025, 121), (513, 1030, 260)])
+@pytest.mark.parametrize("F,K,N", [(300, 1025, 99), (1000, 50, 1025), (257, 513, 69), (64, 31, 17), (1, 1025, 121), (513, 1030, 260),
+                                   (130, 1027, 130), (70, 6, 5), (33, 3, 40), (40, 35, 2), (65, 4, 4)])
 def test_rows_gemm_matrix_core_product_against_float64(F, K, N):
     """The general float32 row product (dsa_rows_gemm, csrc/rows_gemm.hip: what the 1025-bin products of the 48 kHz set-ups run
     on instead of a vendor GEMM): plain, transposed, with the log prologue and with the exp(aux - 2 .) epilogue of the untuned
@@ -571,6 +572,26 @@ def test_rows_gemm_matrix_core_product_against_float64(F, K, N):
         (y * w).sum().backward()           # (the backward's kernel name lives on autograd's thread: rows_gemm_mfma_t)
         gref = w.double().cpu() @ A.double().t()
         assert float((cg.grad.double().cpu() - gref).abs().max()) < 2e-6 * float(gref.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("F,K,M1", [(300, 1025, 50), (1000, 513, 35), (65, 1025, 55), (1, 257, 3), (130, 1027, 25), (64, 100, 41)])
+def test_newton_residual_in_one_launch_against_float64(F, K, M1):
+    """dsa_mcep_newton_resid: rt = exp(log X - 2 mc D) E (mcep.py:210-215) with e formed in registers, against float64 and against
+    the two-launch composition it replaces, on the warping matrices of a real configuration and on ragged sizes (K not a multiple of
+    the 32-bin chunk, rows not a multiple of 64, orders at the ends of the three instantiations).  3e-6 of the largest entry: float32
+    products over up to 1027 bins plus the float32 exp."""
+    g = torch.Generator().manual_seed(F + K + M1)
+    N = 2 * M1 - 1
+    logx = (torch.randn(F, K, generator=g) * 0.5).to(DEV)
+    mc = (torch.randn(F, M1, generator=g) * 0.05).to(DEV)
+    D = (torch.randn(M1, K, generator=g) / M1 ** 0.5).to(DEV)
+    E = (torch.randn(K, N, generator=g) / K).to(DEV)
+    rt = ops.mcep_newton_resid(logx, mc, D, E)
+    assert _lib.last_kernel() == "mcep_resid_mfma"
+    ref = torch.exp(logx.double() - 2 * mc.double() @ D.double()) @ E.double()
+    assert float((rt.double() - ref).abs().max()) < 3e-6 * float(ref.abs().max())
+    two = ops.rows_gemm(ops.rows_gemm(mc, D, ops.ROWS_EPI_EXPSUB, aux=logx), E)
+    assert float((rt - two).abs().max()) < 3e-6 * float(ref.abs().max())
 
 
 def test_untuned_analysis_runs_on_the_library_s_own_kernels_only():
