@@ -434,7 +434,7 @@ def test_untuned_geometries_forward_as_whole_batch_launches(monkeypatch, fl, fp,
         X = stft(x)
         assert X.shape[0] * X.shape[1] >= 256
         mc = mcep(X)
-        assert _lib.last_kernel() in ("th_solve_fwd", "th_solve_quad_fwd", "th_solve_quadn_fwd"), _lib.last_kernel()
+        assert _lib.last_kernel() in ("th_solve_fwd", "th_solve_quad_fwd", "th_solve_quadn_fwd", "th_solve_octn_fwd"), _lib.last_kernel()
         monkeypatch.setenv("DSA_MCEP_COMPOSED", "0")
         mc_g = mcep(X)
         assert _lib.last_kernel() == "mcep_generic_fwd"

@@ -606,10 +606,11 @@ def test_f_rows_at_the_bench_size_against_the_oracle():
     assert all(e < 1.5e-6 for e in errs.values()), errs
 
 
-@pytest.mark.parametrize("n,F", [(2, 64), (5, 1000), (23, 77), (25, 300), (30, 1025), (35, 64), (43, 130), (50, 1000), (55, 257)])
+@pytest.mark.parametrize("n,F", [(2, 64), (5, 1000), (23, 77), (25, 300), (30, 1025), (35, 64), (36, 65), (43, 130), (44, 1000), (50, 1000),
+                                 (51, 67), (52, 200), (55, 257)])
 def test_thsolve_quad_layout_solver_for_general_orders(n, F):
-    """The Toeplitz-plus-Hankel solve for orders other than 24 (csrc/thsolve_quad.hip: 16 systems per wave, 4 x 4 x 1 matrix
-    products, no pivoting, marked systems re-solved with pivoting) against float64 LAPACK on positive definite systems (the
+    """The Toeplitz-plus-Hankel solve for orders other than 24 (csrc/thsolve_quad.hip: 16 systems per wave -- from order 36 on 8, the
+    block columns dealt to the two quads of an octet --, 4 x 4 x 1 matrix products, no pivoting, marked systems re-solved with pivoting) against float64 LAPACK on positive definite systems (the
     Hessians of the analysis: T + H = 2 sum_w e(w) c(w) c(w)^T), ragged batch sizes; then systems that are NOT positive definite
     (the fallback must give the pivoted answer); and the fused Newton update of the untuned mel-cepstral step."""
     g = torch.Generator().manual_seed(n * 1000 + F)
@@ -628,7 +629,9 @@ def test_thsolve_quad_layout_solver_for_general_orders(n, F):
     ref = torch.linalg.solve(dense(p64, q64), r64)
     pd, qd, rd = p64.float().to(DEV), q64.float().to(DEV), r64.float().to(DEV)
     got = ops.ThSolveFn.apply(pd, qd, rd)
-    assert _lib.last_kernel() in (("th_solve_quad_fwd",) if n == 24 else ("th_solve_quadn_fwd",)), _lib.last_kernel()
+    # order 24: the tuned kernel; up to 35: 16 systems per wave (a quad each); from 36: 8 systems per wave (an octet each)
+    want_kernel = "th_solve_quad_fwd" if n == 24 else ("th_solve_quadn_fwd" if n <= 35 else "th_solve_octn_fwd")
+    assert _lib.last_kernel() == want_kernel, _lib.last_kernel()
     ref32 = torch.linalg.solve(dense(pd.double().cpu(), qd.double().cpu()), rd.double().cpu())   # the float32 inputs' own solution
     cond = torch.linalg.cond(dense(p64, q64)).max()
     err = float((got.double().cpu() - ref32).abs().max() / ref32.abs().max())
