@@ -117,6 +117,7 @@ SIGNATURES = {
     "dsa_freqt_bwd": (C.c_int, [_P, _L, _I, _P, _I, _I, _P, _P]),
     "dsa_rows_gemm": (C.c_int, [_P, _L, _I, _P, _I, _I, _I, _P, _I, _I, _P, _I, _P]),
     "dsa_mcep_newton_update": (C.c_int, [_P, _L, _I, _P, _I, _P, _P, _P]),
+    "dsa_mcep_newton_update_bwd": (C.c_int, [_P, _P, _P, _L, _I, _I, _P, _P, _P]),
     "dsa_mcep_newton_resid": (C.c_int, [_P, _L, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P]),
     "dsa_rows_ew": (C.c_int, [_I, _I, _P, _P, _P, _L, _I, _P, _P, _P]),
     "dsa_irfft_scale": (C.c_int, [_P, _L, _I, _I, _P, _P]),

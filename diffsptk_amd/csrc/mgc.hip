@@ -1443,10 +1443,51 @@ DSA_EXPORT int dsa_mcep_newton_update(const void* rt, int64_t F, int32_t n, cons
                                       void* mc_out, void* stream)
 {
     DSA_REQUIRE(n >= 2 && n <= 55 && F >= 0, "mcep_newton_update: order must be in [2, 55]");
-    DSA_REQUIRE(rt && alpha_vec && mc_in && mc_out, "mcep_newton_update: null pointer");
+    DSA_REQUIRE(rt && alpha_vec && mc_out, "mcep_newton_update: null pointer");   // mc_in = NULL: the solution alone
     if (dtype != DSA_F32) return fail(DSA_ERR_UNSUPPORTED, "mcep_newton_update: float32 only%s");
     if (F == 0) return DSA_OK;
     return thsolve_quadn_fwd(rt, 2 * n - 1, rt, 2 * n - 1, rt, 2 * n - 1, alpha_vec, mc_in, F, n, mc_out, (hipStream_t)stream);
+}
+
+// Cotangent of rt from the cotangent of the solution s = solve(T(rt[:n]) + H(rt), rt[:n] - alpha_vec):
+//   u = A^-1 gs (A is symmetric: the same batched solve), then per system
+//   grt[k] = -sum_{i + j = k} u_i s_j  -  [k < n] sum_{|i - j| = k} u_i s_j  +  [k < n] u_k      (Hankel, Toeplitz, right-hand side)
+namespace dsa {
+__global__ __launch_bounds__(256) void newton_update_bwd_sums_kernel(const float* __restrict__ u, const float* __restrict__ s, long F, int n,
+                                                                    float* __restrict__ grt)
+{
+    __shared__ float us[4][64], ss[4][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long f = (long)blockIdx.x * 4 + w;
+    const bool ok = f < F;
+    us[w][lane] = ok && lane < n ? u[f * n + lane] : 0.f;
+    ss[w][lane] = ok && lane < n ? s[f * n + lane] : 0.f;
+    __syncthreads();
+    if (!ok) return;
+    for (int k = lane; k < 2 * n - 1; k += 64) {
+        float acc = 0.f;
+        const int lo = k - (n - 1) > 0 ? k - (n - 1) : 0, hi = k < n - 1 ? k : n - 1;
+        for (int i = lo; i <= hi; ++i) acc -= us[w][i] * ss[w][k - i];
+        if (k < n) {
+            for (int i = 0; i + k < n; ++i) acc -= us[w][i] * ss[w][i + k] + (k > 0 ? us[w][i + k] * ss[w][i] : 0.f);
+            acc += us[w][k];
+        }
+        grt[f * (2 * n - 1) + k] = acc;
+    }
+}
+}  // namespace dsa
+
+DSA_EXPORT int dsa_mcep_newton_update_bwd(const void* gs, const void* rt, const void* sol, int64_t F, int32_t n, int32_t dtype, void* u,
+                                          void* grt, void* stream)
+{
+    DSA_REQUIRE(n >= 2 && n <= 55 && F >= 0, "mcep_newton_update_bwd: order must be in [2, 55]");
+    DSA_REQUIRE(gs && rt && sol && u && grt, "mcep_newton_update_bwd: null pointer");
+    if (dtype != DSA_F32) return fail(DSA_ERR_UNSUPPORTED, "mcep_newton_update_bwd: float32 only%s");
+    if (F == 0) return DSA_OK;
+    if (int rc = thsolve_quadn_fwd(rt, 2 * n - 1, rt, 2 * n - 1, gs, n, nullptr, nullptr, F, n, u, (hipStream_t)stream)) return rc;
+    hipLaunchKernelGGL(dsa::newton_update_bwd_sums_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)u,
+                       (const float*)sol, (long)F, (int)n, (float*)grt);
+    return dsa::check_launch("mcep_newton_update_bwd");
 }
 
 DSA_EXPORT int dsa_thsolve_update_fwd(const void* p, const void* q, const void* r, int64_t r_stride, int64_t r_offset, int64_t F,
@@ -1477,6 +1518,15 @@ DSA_EXPORT int dsa_thsolve_bwd(const void* gg, const void* p, const void* q, con
         hipLaunchKernelGGL(th_bwd_sums_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)gr,
                            (const float*)g, (long)F, (int)n, (float*)gp, (float*)gq);
         return check_launch("th_solve_quad_bwd");
+    }
+    // the other orders the batched forward covers (csrc/thsolve_quad.hip: 2 .. 55, batches from 64 systems): the same two launches.
+    // (The one-wave-per-system backward -- a second pivoted elimination per system -- took 220 us per 12 800 systems of order 50,
+    // 37 % of a forward + backward of the 48 kHz analysis; this takes 39 + 7.)
+    if (dtype == DSA_F32 && n >= 2 && n <= 55 && n != 24 && F >= 64 && quad && gp && gq && gr) {
+        if (int rc = thsolve_quadn_fwd(p, n, q, 2 * n - 1, gg, n, nullptr, nullptr, F, n, gr, (hipStream_t)stream)) return rc;
+        hipLaunchKernelGGL(th_bwd_sums_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)gr,
+                           (const float*)g, (long)F, (int)n, (float*)gp, (float*)gq);
+        return check_launch("th_solve_quadn_bwd");
     }
     if (dtype == DSA_F32) return th_launch<float>(true, gg, p, q, g, F, n, gp, gq, gr, (hipStream_t)stream);
     if (dtype == DSA_F64) return th_launch<double>(true, gg, p, q, g, F, n, gp, gq, gr, (hipStream_t)stream);

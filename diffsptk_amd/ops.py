@@ -862,6 +862,33 @@ def mcep_newton_update(rt, av, mc):
     return out
 
 
+class McepNewtonUpdateFn(torch.autograd.Function):
+    """mc + solve(T(rt[:, :n]) + H(rt), rt[:, :n] - av) with a gradient (mcep.py:216-222): forward = the batched solve (the solution is
+    kept), backward = the same solve on the cotangent and one launch of diagonal sums (dsa_mcep_newton_update_bwd).  As a slice, a
+    subtraction, ThSolveFn and an addition the step was nine small stock launches around the two kernels, in each direction."""
+
+    @staticmethod
+    def forward(ctx, rt, av, mc):
+        rtc = rt.contiguous()
+        n = mc.size(-1)
+        sol = torch.empty_like(mc)
+        with torch.cuda.device(mc.device):
+            _call("dsa_mcep_newton_update", _p(rtc), mc.numel() // n, n, _p(av), _dtype_code(mc), None, _p(sol), _stream())
+        ctx.save_for_backward(rtc, sol)
+        return mc + sol
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        rtc, sol = ctx.saved_tensors
+        n = sol.size(-1)
+        gc = g.contiguous()
+        u, grt = torch.empty_like(sol), torch.empty_like(rtc)
+        with torch.cuda.device(g.device):
+            _call("dsa_mcep_newton_update_bwd", _p(gc), _p(rtc), _p(sol), sol.numel() // n, n, _dtype_code(sol), _p(u), _p(grt), _stream())
+        return grt, None, g
+
+
 def mcep_newton_resid(logx, mc, D, E):
     """rt = exp(logx - 2 mc D) E (mcep.py:210-215) in one launch (dsa_mcep_newton_resid: float32, 3 <= M + 1 <= 55): e is formed
     chunk by chunk in the operand layout of the second product and never reaches memory."""
@@ -903,7 +930,9 @@ def _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter):
         else:
             e = rows_gemm(mc, D, ROWS_EPI_EXPSUB, aux=logx)               # product and exp(log X - 2 .) in one launch
             rt = rows_gemm(e, E)
-        if want_grad or M1 > 55:
+        if want_grad and 2 <= M1 <= 55:
+            mc = McepNewtonUpdateFn.apply(rt, av, mc)                     # :216-222, one node
+        elif want_grad or M1 > 55:
             p = rt[:, :M1].contiguous()
             mc = mc + ThSolveFn.apply(p, rt, p - av)                      # :216-222
         else:

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 121 /* 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
+#define DSA_VERSION 122 /* 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
@@ -252,6 +252,11 @@ int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, int32_t n_it
  * row pivoting by a second launch (csrc/thsolve_quad.hip).  mc_out may be mc_in. */
 int dsa_mcep_newton_update(const void* rt, int64_t F, int32_t n, const void* alpha_vec, int32_t dtype, const void* mc_in,
                            void* mc_out, void* stream);
+/* Its backward.  mc_in = NULL in the call above leaves the solution s alone in mc_out; with gs:(F,n) the cotangent of s this writes
+ * grt:(F, 2n-1), the cotangent of rt: u = A^-1 gs on the same batched solve (A is symmetric; u:(F,n) is caller workspace), then
+ * grt[k] = -sum_{i+j=k} u_i s_j - [k<n] sum_{|i-j|=k} u_i s_j + [k<n] u_k   (Hankel part, Toeplitz part, right-hand side). */
+int dsa_mcep_newton_update_bwd(const void* gs, const void* rt, const void* sol, int64_t F, int32_t n, int32_t dtype, void* u,
+                               void* grt, void* stream);
 /* The spectral half of the same Newton step (mcep.py:210-215) in one launch:
  *   rt:(F, 2n-1) = exp(logx - 2 mc D) E,   logx:(F,K) = log X, mc:(F,n), D:(n x K, row stride ldd), E:(K x (2n-1), row stride lde),
  * n = cep_order + 1 in [3, 55], K >= 4, float32.  e = exp(.) is produced chunk by chunk in the operand layout of the second

@@ -614,3 +614,38 @@ def test_untuned_analysis_runs_on_the_library_s_own_kernels_only():
     names = {e.key for e in prof.key_averages()}
     banned = {"aten::matmul", "aten::mm", "aten::bmm", "aten::addmm", "aten::exp", "aten::log", "aten::linalg_solve", "aten::linalg_solve_ex"}
     assert not (names & banned), names & banned
+
+
+@pytest.mark.parametrize("n,F", [(50, 300), (35, 65), (7, 130)])
+def test_newton_update_with_a_gradient_against_float64_autograd(n, F):
+    """ops.McepNewtonUpdateFn (dsa_mcep_newton_update with mc_in = NULL + dsa_mcep_newton_update_bwd): mc + solve(T(rt[:n]) + H(rt),
+    rt[:n] - av) and the cotangents of rt and mc against float64 autograd through the dense solve, on the Hessians of the analysis
+    (positive definite); 5e-5 of the largest entry at condition numbers of a few hundred."""
+    import math
+
+    g = torch.Generator().manual_seed(n + F)
+    K = 4 * n
+    w = torch.arange(K, dtype=torch.float64) * (math.pi / K)
+    cw = torch.cos(torch.arange(2 * n - 1, dtype=torch.float64)[:, None] * w[None, :])
+    e = torch.rand(F, K, generator=g, dtype=torch.float64) + 0.05
+    rt64 = ((e @ cw.t()) / K).float().double()
+    av = (torch.randn(n, generator=g, dtype=torch.float64) * 0.1).float().double()
+    mc64 = torch.randn(F, n, generator=g, dtype=torch.float64).float().double()
+    wgt = torch.randn(F, n, generator=g, dtype=torch.float64).float().double()
+
+    def dense(rt):
+        i = torch.arange(n)
+        return rt[:, (i[:, None] - i[None, :]).abs()] + rt[:, i[:, None] + i[None, :]]
+
+    rt_r, mc_r = rt64.clone().requires_grad_(True), mc64.clone().requires_grad_(True)
+    out_r = mc_r + torch.linalg.solve(dense(rt_r), rt_r[:, :n] - av)
+    (out_r * wgt).sum().backward()
+    rt_d, mc_d = rt64.float().to(DEV).requires_grad_(True), mc64.float().to(DEV).requires_grad_(True)
+    out_d = ops.McepNewtonUpdateFn.apply(rt_d, av.float().to(DEV), mc_d)
+    assert _lib.last_kernel() in ("th_solve_quadn_fwd", "th_solve_octn_fwd")
+    (out_d * wgt.float().to(DEV)).sum().backward()
+    cond = float(torch.linalg.cond(dense(rt64)).max())
+    tol = 5e-6 * cond ** 0.5 + 5e-5
+    assert float((out_d.detach().double().cpu() - out_r.detach()).abs().max() / out_r.detach().abs().max()) < tol
+    assert float((rt_d.grad.double().cpu() - rt_r.grad).abs().max() / rt_r.grad.abs().max()) < tol
+    assert torch.equal(mc_d.grad.cpu(), wgt.float())

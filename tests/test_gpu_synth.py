@@ -656,3 +656,15 @@ def test_thsolve_quad_layout_solver_for_general_orders(n, F):
         upd = ops.mcep_newton_update(qd, av.float().to(DEV), mc.float().to(DEV))
         ref_u = mc.float().double() + torch.linalg.solve(dense(pd.double().cpu(), qd.double().cpu()), pd.double().cpu() - av.float().double())
         assert float((upd.double().cpu() - ref_u).abs().max() / ref_u.abs().max()) < 2e-6 * float(cond) ** 0.5 + 2e-5
+    # the backward: gr = A^-1 gbar on the same batched solve (A is symmetric), gp / gq = the diagonal / anti-diagonal sums of
+    # -gr g^T (dsa_thsolve_bwd), against float64 autograd through the dense solve; 5e-5 of the largest entry (condition numbers
+    # of a few hundred, float32)
+    if n != 24:
+        pg, qg, rg = (t.clone().requires_grad_(True) for t in (pd, qd, rd))
+        w = torch.randn(F, n, generator=g, dtype=torch.float64)
+        (ops.ThSolveFn.apply(pg, qg, rg) * w.float().to(DEV)).sum().backward()
+        p6, q6, r6 = (t.detach().double().cpu().requires_grad_(True) for t in (pd, qd, rd))
+        (torch.linalg.solve(dense(p6, q6), r6) * w.float().double()).sum().backward()
+        for got_g, ref_g, name in ((pg.grad, p6.grad, "p"), (qg.grad, q6.grad, "q"), (rg.grad, r6.grad, "r")):
+            e = float((got_g.double().cpu() - ref_g).abs().max() / ref_g.abs().max())
+            assert e < 5e-6 * float(cond) ** 0.5 + 5e-5, (name, e, float(cond))
