@@ -14,6 +14,8 @@
 //    The gain keeps the reference's un-regularised r0 (levdur.py:124).
 // Both choices are at least as accurate as the reference's float32 path; parity is judged
 // against the float64 reference (tests/test_lpc_gpu.py states the tolerance).
+#include <type_traits>
+
 #include "common.h"
 
 #include <atomic>
@@ -473,7 +475,10 @@ __device__ __forceinline__ void lp_split2(float x0, float x1, lp_h2& hi, lp_h2& 
     lo = __builtin_bit_cast(lp_h2, lb);
 }
 
-template <int NE, int LC>   // NE: registers of 64 samples that cover the frame, ceil(L / 64); LC: the frame length at compile time (0: run time)
+#ifndef LPC_ABL
+#define LPC_ABL 0   // measurement builds only (tools/gpu_abl_lpc.sh): 1 no recursion, 2 no scatter / sums, 4 no products, 8 no maximum / scale
+#endif
+template <int NE, int LC>   // NE = 8: operand elements per lane (512 samples); LC: the frame length at compile time (0: run time)
 __global__ __launch_bounds__(256, 3) void frame_window_lpc24_mfma_kernel(
     const float* __restrict__ x, long Tlen, long N, int L_rt, int P, int left, int mode, const float* __restrict__ w, double eps,
     float* __restrict__ out, long total_sc, int sc_per_utt, unsigned* __restrict__ queue, int fpi)
@@ -481,22 +486,27 @@ __global__ __launch_bounds__(256, 3) void frame_window_lpc24_mfma_kernel(
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef _Float16 lp_h8 __attribute__((ext_vector_type(8)));
     constexpr int DS = 20;                         // floats per lag row of the scatter area (16 slots, 16-byte aligned rows)
-    // dynamic LDS, per wave: rbuf[fpi][25] doubles | dm[26][DS] floats  (fpi = 52 at the bench geometry: three workgroups per CU)
+    // dynamic LDS, per wave: rbuf[fpi][25] doubles | dm[2][26][DS] floats (a scatter area per frame of a round)  (fpi = 40 at the bench
+    // geometry: three workgroups per CU)
     extern __shared__ __attribute__((aligned(16))) unsigned char lpc_smem[];
     const int L = LC ? LC : L_rt;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int wave_bytes = fpi * kLpcM1 * (int)sizeof(double) + 26 * DS * (int)sizeof(float);
+    const int wave_bytes = fpi * kLpcM1 * (int)sizeof(double) + 2 * 26 * DS * (int)sizeof(float);
     double* rbuf = reinterpret_cast<double*>(lpc_smem + (size_t)wave * wave_bytes);
     float* dm = reinterpret_cast<float*>(rbuf + fpi * kLpcM1);
     const int j = lane & 15, g = lane >> 4;
-    // window values (w == NULL: ones) and validity of this lane's samples of the three operand sets
-    float wa[NE], wb[NE], wc[NE];
+    // Operand element e of lane (j, g) is sample 16 (8 g + e) + j: the lane's eight elements are eight CONSECUTIVE blocks of 16
+    // samples (k-slot (g, e) <-> block 8 g + e; any bijection serves, A and B use the same one).  The operands of C2 / C3 -- the same
+    // samples one / two blocks on -- are then the lane's own elements one / two places on, i.e. (packed two to a register) one
+    // v_alignbit per register resp. the next register, plus element 0 of the lane 16 further on for the last place(s): one
+    // ds_bpermute per frame and half.  (With k-slot <-> block 4 e + g the three operand sets were three loads, window products,
+    // scalings and splits of the same samples: 0.107 of the kernel's 0.145 ms were operand preparation.)
+    // window values (w == NULL: ones); samples past the frame are selected away
+    float wa[8];
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        const int la = 64 * e + lane, lb = la + 16, lc = la + 32;
+    for (int e = 0; e < 8; ++e) {
+        const int la = 128 * g + 16 * e + j;
         wa[e] = la < L ? (w ? w[la] : 1.f) : 0.f;
-        wb[e] = lb < L ? (w ? w[lb] : 1.f) : 0.f;
-        wc[e] = lc < L ? (w ? w[lc] : 1.f) : 0.f;
     }
     // scatter addresses of this lane's 12 matrix entries: entry (tile s, register r) = C_s[4 g + r][j], lag = 16 s + j - (4 g + r);
     // lags outside [0, 24] go to the spare row 25
@@ -518,109 +528,167 @@ __global__ __launch_bounds__(256, 3) void frame_window_lpc24_mfma_kernel(
         const long fbase = ci * fpi;
         const int nfr = (int)((N - fbase) < fpi ? (N - fbase) : fpi);
         const float* xb = x + b * Tlen;
-        // the samples of frame fi + 1 are requested while frame fi is in the matrix pipeline (a wave works through its frames
-        // serially: loads -> products -> scatter -> sums is one dependent chain per frame)
-        float a[NE], bb[NE], cc[NE];
-        auto fetch = [&](int fi) __attribute__((always_inline)) {
+        // TWO frames per round (frame fi + u uses scatter area u): loads -> maximum -> split -> products -> scatter -> sums is one
+        // dependent chain per frame, and at three waves per SIMD a wave that walks its frames one at a time leaves the vector unit
+        // idle half the time (46 % busy, 0.150 ms); the two chains of a round share no data and interleave.  The samples of the
+        // next round are requested while this one is in the matrix pipeline.
+        constexpr int U = 2;
+        float a[U][8];
+        const int soff = 128 * g + j;   // this lane's first sample inside a frame
+        auto fetch = [&](int u, int fi) __attribute__((always_inline)) {
             const long start = (fbase + fi) * P - left;
-            if (start >= 0 && start + 64 * NE + 32 <= Tlen) {   // uniform: every sample any lane touches exists
-                const float* src = xb + start + lane;
+            if (start >= 0 && start + 512 <= Tlen) {   // uniform: every sample any lane touches exists
+                const float* src = xb + start + soff;
 #pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    a[e] = src[64 * e];
-                    bb[e] = src[64 * e + 16];
-                    cc[e] = src[64 * e + 32];
-                }
+                for (int e = 0; e < 8; ++e) a[u][e] = src[16 * e];
             } else {
 #pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    const long l0 = start + 64 * e + lane;
-                    a[e] = load_padded(xb, l0, Tlen, mode);
-                    bb[e] = load_padded(xb, l0 + 16, Tlen, mode);
-                    cc[e] = load_padded(xb, l0 + 32, Tlen, mode);
-                }
+                for (int e = 0; e < 8; ++e) a[u][e] = soff + 16 * e < L ? load_padded(xb, start + soff + 16 * e, Tlen, mode) : 0.f;
             }
         };
-        fetch(0);
-        for (int fi = 0; fi < nfr; ++fi) {
-            float va[NE], vb[NE], vc[NE];
+        // (an odd count: the last round's second frame is the first one again, computed and not stored)
+        // (Tried: the samples of two rounds in flight, two register sets and the round loop unrolled by two -- 0.135 -> 0.145 ms.)
+        fetch(0, 0);
+        fetch(1, 1 < nfr ? 1 : 0);
+        for (int fi = 0; fi < nfr; fi += U) {
+            float va[U][8];
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                // window.py:190 in float32 (as the reference); samples past the frame are selected away, never multiplied
-                va[e] = 64 * e + lane < L ? a[e] * wa[e] : 0.f;
-                vb[e] = 64 * e + lane + 16 < L ? bb[e] * wb[e] : 0.f;
-                vc[e] = 64 * e + lane + 32 < L ? cc[e] * wc[e] : 0.f;
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)   // window.py:190 in float32 (as the reference); samples past the frame are selected away, never multiplied
+                    va[u][e] = soff + 16 * e < L ? a[u][e] * wa[e] : 0.f;
+            if (fi + U < nfr) {
+                fetch(0, fi + U);
+                fetch(1, fi + U + 1 < nfr ? fi + U + 1 : fi + U);
             }
-            if (fi + 1 < nfr) fetch(fi + 1);
             // The Gram products on the BINARY16 matrix pipe (separate from the float32 datapath the float64 sums and the recursion
-            // need): k-slot (g, e) of v_mfma_f32_16x16x32_f16 <-> block 4 e + g, i.e. element e of a lane's operand is its register
-            // e -- sample 64 e + lane -- so A / B are just the lane's eight values packed.  Every value is split hi + lo into two
-            // binary16 numbers after scaling the frame by a power of two that puts its largest sample in [2^13, 2^14) (lo stays a
-            // normal number down to 2^-17 of the maximum); a product is three instructions, hi hi + hi lo + lo hi (the dropped
-            // lo lo is 2^-22 of the product), exact binary16 products accumulated in float32 over the whole frame at once (K = 32
-            // blocks of 16 samples cover 512).  9 matrix instructions per frame instead of 19 float32 ones (round 4, first version:
-            // 608 cycles of the float32 datapath per frame).
-            float fmx = 0.f;
+            // need).  Every value is split hi + lo into two binary16 numbers after scaling the frame by a power of two that puts its
+            // largest sample in [2^13, 2^14) (lo stays a normal number down to 2^-17 of the maximum); a product is three
+            // instructions, hi hi + hi lo + lo hi (the dropped lo lo is 2^-22 of the product), exact binary16 products accumulated
+            // in float32 over the whole frame at once (K = 32 blocks of 16 samples cover 512).  9 matrix instructions per frame
+            // instead of 19 float32 ones (round 4, first version: 608 cycles of the float32 datapath per frame).
+            float fmx[U];
+            int sh[U];
 #pragma unroll
-            for (int e = 0; e < NE; ++e) fmx = __builtin_fmaxf(fmx, __builtin_fabsf(va[e]));   // (vb / vc hold the same samples 16 / 32 on)
-#define DSA_LPC_MAX(CTRL, RM)                                                                                         \
-    fmx = __builtin_fmaxf(fmx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(fmx), CTRL, RM, 0xf, false)))
+            for (int u = 0; u < U; ++u) {
+                fmx[u] = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fmx[u] = __builtin_fmaxf(fmx[u], __builtin_fabsf(va[u][e]));
+            }
+#define DSA_LPC_MAX(CTRL, RM)                                                                                              \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) fmx[u] =                                                                 \
+        __builtin_fmaxf(fmx[u], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(fmx[u]), CTRL, RM, 0xf, false)))
             DSA_LPC_MAX(0x111, 0xf); DSA_LPC_MAX(0x112, 0xf); DSA_LPC_MAX(0x114, 0xf); DSA_LPC_MAX(0x118, 0xf);   // row_shr 1, 2, 4, 8
             DSA_LPC_MAX(0x142, 0xa); DSA_LPC_MAX(0x143, 0xc);                                                     // row_bcast 15, 31
 #undef DSA_LPC_MAX
-            const float fmax_all = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fmx), 63));
-            int fe = __builtin_amdgcn_frexp_expf(fmax_all);            // fmax_all = m 2^fe, m in [0.5, 1)
-            fe = fe < -100 ? -100 : (fe > 100 ? 100 : fe);             // silent frames / denormals: any scale will do
-            const int sh = 14 - fe;                                    // scaled maximum in [2^13, 2^14)
-            lp_h8 ah, al, bh, bl, ch, cl;
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                auto sc = [&](const float (&v)[NE], int i) __attribute__((always_inline)) { return i < NE ? __builtin_ldexpf(v[i < NE ? i : 0], sh) : 0.f; };
-                lp_h2 h, l;
-                lp_split2(sc(va, e), sc(va, e + 1), h, l);
-                ah[e] = h[0]; ah[e + 1] = h[1]; al[e] = l[0]; al[e + 1] = l[1];
-                lp_split2(sc(vb, e), sc(vb, e + 1), h, l);
-                bh[e] = h[0]; bh[e + 1] = h[1]; bl[e] = l[0]; bl[e + 1] = l[1];
-                lp_split2(sc(vc, e), sc(vc, e + 1), h, l);
-                ch[e] = h[0]; ch[e + 1] = h[1]; cl[e] = l[0]; cl[e + 1] = l[1];
+            for (int u = 0; u < U; ++u) {
+                const float fmax_all = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fmx[u]), 63));
+                int fe = __builtin_amdgcn_frexp_expf(fmax_all);            // fmax_all = m 2^fe, m in [0.5, 1)
+                fe = fe < -100 ? -100 : (fe > 100 ? 100 : fe);             // silent frames / denormals: any scale will do
+                sh[u] = (LPC_ABL & 8) ? 3 : 14 - fe;                       // scaled maximum in [2^13, 2^14)
             }
-            f4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = c1, c3 = c1;
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ah, c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c2, 0, 0, 0);
-            c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ch, c3, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, al, c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c2, 0, 0, 0);
-            c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, cl, c3, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ah, c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c2, 0, 0, 0);
-            c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ch, c3, 0, 0, 0);
-            __builtin_amdgcn_wave_barrier();   // the previous frame's row reads are done (LDS operations of a wave run in order)
+            lp_h8 ah[U], al[U], bh[U], bl[U], ch[U], cl[U];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dm[addr[0][r]] = c1[r];
-                dm[addr[1][r]] = c2[r];
-                dm[addr[2][r]] = c3[r];
+            for (int u = 0; u < U; ++u) {
+                typedef unsigned lp_u4 __attribute__((ext_vector_type(4)));
+                lp_u4 hr, lr;   // the packed halves: register k = elements (2 k, 2 k + 1)
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    lp_h2 h, l;
+                    lp_split2(__builtin_ldexpf(va[u][e], sh[u]), __builtin_ldexpf(va[u][e + 1], sh[u]), h, l);
+                    hr[e >> 1] = __builtin_bit_cast(unsigned, h);
+                    lr[e >> 1] = __builtin_bit_cast(unsigned, l);
+                }
+                // elements (0, 1) of the lane 16 further on (blocks 8 (g + 1), 8 (g + 1) + 1); past the last row: zeros
+                unsigned nh = (unsigned)__builtin_amdgcn_ds_bpermute(4 * ((lane + 16) & 63), (int)hr[0]);
+                unsigned nl = (unsigned)__builtin_amdgcn_ds_bpermute(4 * ((lane + 16) & 63), (int)lr[0]);
+                nh = g == 3 ? 0u : nh;
+                nl = g == 3 ? 0u : nl;
+                const lp_u4 bhr = {__builtin_amdgcn_alignbit(hr[1], hr[0], 16), __builtin_amdgcn_alignbit(hr[2], hr[1], 16),
+                                   __builtin_amdgcn_alignbit(hr[3], hr[2], 16), __builtin_amdgcn_alignbit(nh, hr[3], 16)};
+                const lp_u4 blr = {__builtin_amdgcn_alignbit(lr[1], lr[0], 16), __builtin_amdgcn_alignbit(lr[2], lr[1], 16),
+                                   __builtin_amdgcn_alignbit(lr[3], lr[2], 16), __builtin_amdgcn_alignbit(nl, lr[3], 16)};
+                const lp_u4 chr = {hr[1], hr[2], hr[3], nh}, clr = {lr[1], lr[2], lr[3], nl};
+                ah[u] = __builtin_bit_cast(lp_h8, hr);
+                al[u] = __builtin_bit_cast(lp_h8, lr);
+                bh[u] = __builtin_bit_cast(lp_h8, bhr);
+                bl[u] = __builtin_bit_cast(lp_h8, blr);
+                ch[u] = __builtin_bit_cast(lp_h8, chr);
+                cl[u] = __builtin_bit_cast(lp_h8, clr);
             }
+            f4 c1[U], c2[U], c3[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) c1[u] = c2[u] = c3[u] = f4{0.f, 0.f, 0.f, 0.f};
+            if (!(LPC_ABL & 4)) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                c1[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], ah[u], c1[u], 0, 0, 0);
+                c2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], bh[u], c2[u], 0, 0, 0);
+                c3[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], ch[u], c3[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                c1[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], al[u], c1[u], 0, 0, 0);
+                c2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bl[u], c2[u], 0, 0, 0);
+                c3[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], cl[u], c3[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                c1[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], ah[u], c1[u], 0, 0, 0);
+                c2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bh[u], c2[u], 0, 0, 0);
+                c3[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], ch[u], c3[u], 0, 0, 0);
+            }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) { c1[u][0] = va[u][0]; c2[u][0] = va[u][1]; c3[u][0] = va[u][2]; }
+            }
+            if (LPC_ABL & 2) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (lane < kLpcM1 && fi + u < nfr) rbuf[(fi + u) * kLpcM1 + lane] = c1[u][0] + c2[u][1] + c3[u][2] + (lane == 0 ? 1.0 : 0.0);
+                continue;
+            }
+            __builtin_amdgcn_wave_barrier();   // the previous round's row reads are done (LDS operations of a wave run in order)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dm[u * 26 * DS + addr[0][r]] = c1[u][r];
+                    dm[u * 26 * DS + addr[1][r]] = c2[u][r];
+                    dm[u * 26 * DS + addr[2][r]] = c3[u][r];
+                }
             __builtin_amdgcn_wave_barrier();
             {
                 // lane (m, h) = (lane & 31, lane >> 5) adds slots 8 h .. 8 h + 7 of lag m in float64; the halves meet through one
                 // cross-half exchange (rows 25 .. 31 read the spare row: finite or not, their sums are never stored)
                 const int m_ = lane & 31, h_ = lane >> 5;
-                const f4* row = reinterpret_cast<const f4*>(dm + (m_ < kLpcM1 ? m_ : kLpcM1) * DS + 8 * h_);
-                const f4 q0 = row[0], q1 = row[1];
-                double sm = ((double)q0[0] + (double)q0[1]) + ((double)q0[2] + (double)q0[3]);
-                sm += ((double)q1[0] + (double)q1[1]) + ((double)q1[2] + (double)q1[3]);
-                const int lo = __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), __double2loint(sm));
-                const int hi = __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), __double2hiint(sm));
-                const double other = __hiloint2double(hi, lo);
-                // the same association on both halves: (slots 0..7) + (slots 8..15)
-                const double tot = h_ == 0 ? sm + other : other + sm;
-                if (lane < kLpcM1) rbuf[fi * kLpcM1 + lane] = ldexp(tot, -2 * sh);   // the frame's scale, undone exactly
+                double sm[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const f4* row = reinterpret_cast<const f4*>(dm + u * 26 * DS + (m_ < kLpcM1 ? m_ : kLpcM1) * DS + 8 * h_);
+                    const f4 q0 = row[0], q1 = row[1];
+                    sm[u] = ((double)q0[0] + (double)q0[1]) + ((double)q0[2] + (double)q0[3]);
+                    sm[u] += ((double)q1[0] + (double)q1[1]) + ((double)q1[2] + (double)q1[3]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int lo = __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), __double2loint(sm[u]));
+                    const int hi = __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), __double2hiint(sm[u]));
+                    const double other = __hiloint2double(hi, lo);
+                    // the same association on both halves: (slots 0..7) + (slots 8..15)
+                    const double tot = h_ == 0 ? sm[u] + other : other + sm[u];
+                    if (lane < kLpcM1 && fi + u < nfr) rbuf[(fi + u) * kLpcM1 + lane] = ldexp(tot, -2 * sh[u]);   // the frame's scale, undone exactly
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
         // ---- Levinson-Durbin, one frame per lane (levdur.py:113-127 as a recursion), as in frame_window_lpc24_kernel ----
-        if (lane < nfr) {
+        if ((LPC_ABL & 1) && lane < nfr) {
+            float* o = out + ((b * N + fbase + lane) * (long)kLpcM1);
+#pragma unroll
+            for (int m = 0; m < kLpcM1; ++m) o[m] = (float)rbuf[(size_t)lane * kLpcM1 + m];
+        } else if (lane < nfr) {
             double r[kLpcM1], al[kLpcM1];
 #pragma unroll
             for (int m = 0; m < kLpcM1; ++m) {
@@ -1088,7 +1156,18 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
             // lag sums: float32 matrix instruction (default) or the float64 vector unit (DSA_LPC_LAGSUMS=f64: exact sums)
             static const bool exact = [] { const char* e = getenv("DSA_LPC_LAGSUMS"); return e && e[0] == 'f' && e[1] == '6'; }();
             if (!exact && L <= 512) {
-                const int lds_m = 4 * (fpi * kLpcM1 * (int)sizeof(double) + 26 * 20 * (int)sizeof(float));
+                // three workgroups per CU need 4 (200 fpi + 4160) <= 53 KB: at most 47 frames per item, utterances split evenly.
+                // (Tried: frames per item chosen so that every one of the 3072 resident waves gets the same number of items -- 34
+                // frames, 6144 items at the bench size instead of 40 / 5120: 0.135 -> 0.140 ms; more recursion phases on fewer lanes.)
+                if (fpi > 47) {
+                    const long cpu = (N + 46) / 47;
+                    long f = ((N + cpu - 1) / cpu + 3) & ~3L;
+                    if (f > 47) f = 44;
+                    fpi = (int)f;
+                    sc_per_utt = (int)((N + fpi - 1) / fpi);
+                    total_sc = (long)B * sc_per_utt;
+                }
+                const int lds_m = 4 * (fpi * kLpcM1 * (int)sizeof(double) + 2 * 26 * 20 * (int)sizeof(float));
                 long wgs = (total_sc + 3) / 4;
                 const long wg_cap = 256L * (lds_m <= 53 * 1024 ? 3 : 2);   // workgroups of four waves per CU
                 if (wgs > wg_cap) wgs = wg_cap;
@@ -1100,12 +1179,7 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
         hipLaunchKernelGGL((frame_window_lpc24_mfma_kernel<NEV, LCV>), dim3((unsigned)wgs), dim3(256), lds_m, st, (const float*)x, \
                            (long)T, (long)N, L, P, left, pad_mode, (const float*)w, eps, (float*)out, total_sc, sc_per_utt, queue, fpi); \
     } while (0)
-                const int ne = (L + 63) / 64;
-                if (L == 400) DSA_LPC_MFMA(7, 400);   // the 25 ms window at 16 kHz
-                else if (ne <= 4) DSA_LPC_MFMA(4, 0);
-                else if (ne == 5) DSA_LPC_MFMA(5, 0);
-                else if (ne == 6) DSA_LPC_MFMA(6, 0);
-                else if (ne == 7) DSA_LPC_MFMA(7, 0);
+                if (L == 400) DSA_LPC_MFMA(8, 400);   // the 25 ms window at 16 kHz
                 else DSA_LPC_MFMA(8, 0);
 #undef DSA_LPC_MFMA
                 return check_launch("frame_window_lpc24_mfma_fwd");
