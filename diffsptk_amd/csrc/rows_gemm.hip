@@ -100,33 +100,49 @@ __global__ __launch_bounds__(256) void rows_gemm_mfma_kernel(const float* __rest
     // SIMD nothing hid it).  Chunk indices past the end are clamped: a redundant load / a store nobody reads, but no branch.
     const int nchunk = (K + kRgKC - 1) / kRgKC;
     auto clampc = [&](int kc) { return kc < nchunk ? kc : nchunk - 1; };
+    // An INTERIOR chunk needs no repair at all (uniform test, one scalar branch around the selects): every k of the chunk exists, and a
+    // group of four columns that straddles the matrix's edge may simply read on -- into the row below, which exists (hence the extra
+    // row asked for in the plain product) -- because what it brings are columns >= N of B, i.e. columns of the result nobody stores.
+    auto plain_b = [&](int kc) { return !SMALL && clampc(kc) * kRgKC + kRgKC + (TRANS ? 0 : 1) <= K; };
+    auto plain_c = [&](int kc) { return !SMALL && clampc(kc) * kRgKC + kRgKC <= K; };
     rg_f4 sv[4];
     auto fetch = [&](int kc) __attribute__((always_inline)) {
         const int K0 = clampc(kc) * kRgKC;
+        const bool pl = plain_b(kc);
         if (!TRANS) {
             // 32 x 128 floats, 256 threads: thread -> (kk = tid / 8, 16 consecutive columns as four 16-byte loads)
             const int kk = tid >> 3, cq = (tid & 7) * 16;
             const float* src = A + (long)(K0 + kk < K ? K0 + kk : K - 1) * lda + col0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sv[q] = row_raw4<SMALL>(src, cq + 4 * q, ncols);
+            for (int q = 0; q < 4; ++q) {
+                const int cb = cq + 4 * q;
+                if (pl) sv[q] = *reinterpret_cast<const rg_f4u*>(src + (cb < ncols ? cb : 0));
+                else sv[q] = row_raw4<SMALL>(src, cb, ncols);
+            }
         } else {
             // B[k][col] = A[col0 + col][K0 + k]: thread -> (col = tid / 2, 16 consecutive k): reads along K
             const int col = tid >> 1, kq = (tid & 1) * 16;
             const float* src = A + (long)(col0 + (col < ncols ? col : ncols - 1)) * lda;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sv[q] = row_raw4<SMALL>(src, K0 + kq + 4 * q, K);
+            for (int q = 0; q < 4; ++q) {
+                if (pl) sv[q] = *reinterpret_cast<const rg_f4u*>(src + K0 + kq + 4 * q);
+                else sv[q] = row_raw4<SMALL>(src, K0 + kq + 4 * q, K);
+            }
         }
     };
     auto put = [&](int kc, int q) __attribute__((always_inline)) {
         const int K0 = clampc(kc) * kRgKC, buf = kc & 1;
+        const bool pl = plain_b(kc);
         if (!TRANS) {
             const int kk = tid >> 3, cb = (tid & 7) * 16 + 4 * q;
-            const rg_f4 v = row_fix4<SMALL>(sv[q], cb, ncols, K0 + kk < K, 0.f);
+            rg_f4 v = sv[q];
+            if (!pl) v = row_fix4<SMALL>(sv[q], cb, ncols, K0 + kk < K, 0.f);
             *reinterpret_cast<rg_f2*>(&bs[buf][kk * kRgLD + cb]) = rg_f2{v[0], v[1]};   // rows are 8-byte aligned (stride 130)
             *reinterpret_cast<rg_f2*>(&bs[buf][kk * kRgLD + cb + 2]) = rg_f2{v[2], v[3]};
         } else {
             const int col = tid >> 1, kq = (tid & 1) * 16;   // transposed stores
-            const rg_f4 v = row_fix4<SMALL>(sv[q], K0 + kq + 4 * q, K, col < ncols, 0.f);
+            rg_f4 v = sv[q];
+            if (!pl) v = row_fix4<SMALL>(sv[q], K0 + kq + 4 * q, K, col < ncols, 0.f);
 #pragma unroll
             for (int e = 0; e < 4; ++e) bs[buf][(kq + 4 * q + e) * kRgLD + col] = v[e];
         }
@@ -135,12 +151,21 @@ __global__ __launch_bounds__(256) void rows_gemm_mfma_kernel(const float* __rest
     rg_f4 cr[2];
     auto load_c = [&](int kc) __attribute__((always_inline)) {
         const int kb = clampc(kc) * kRgKC + 8 * g;
-        cr[0] = row_raw4<SMALL>(crow, kb, K);
-        cr[1] = row_raw4<SMALL>(crow, kb + 4, K);
+        if (plain_c(kc)) {
+            cr[0] = *reinterpret_cast<const rg_f4u*>(crow + kb);
+            cr[1] = *reinterpret_cast<const rg_f4u*>(crow + kb + 4);
+        } else {
+            cr[0] = row_raw4<SMALL>(crow, kb, K);
+            cr[1] = row_raw4<SMALL>(crow, kb + 4, K);
+        }
     };
     auto take_c = [&](int kc, float (&cv)[8]) __attribute__((always_inline)) {
         const int kb = kc * kRgKC + 8 * g;
-        const rg_f4 a = row_fix4<SMALL>(cr[0], kb, K, true, PRO_LOG ? 1.f : 0.f), b = row_fix4<SMALL>(cr[1], kb + 4, K, true, PRO_LOG ? 1.f : 0.f);
+        rg_f4 a = cr[0], b = cr[1];
+        if (!plain_c(kc)) {
+            a = row_fix4<SMALL>(cr[0], kb, K, true, PRO_LOG ? 1.f : 0.f);
+            b = row_fix4<SMALL>(cr[1], kb + 4, K, true, PRO_LOG ? 1.f : 0.f);
+        }
         cv[0] = a[0], cv[1] = a[1], cv[2] = a[2], cv[3] = a[3], cv[4] = b[0], cv[5] = b[1], cv[6] = b[2], cv[7] = b[3];
     };
 
@@ -312,36 +337,59 @@ __global__ __launch_bounds__(256) void mcep_resid_mfma_kernel(const float* __res
     rg_f4 sv[4], dv[2], cr[2];
     const int skk = tid >> 3, scq = (tid & 7) * 16, dq = (tid & 7) * 4;
     auto clampc = [&](int kc) { return kc < nchunk ? kc : nchunk - 1; };
+    // interior chunks need no repair (see rows_gemm_mfma_kernel): every bin of the chunk exists; a straddling column group of E reads
+    // on into the row below (hence one row more for E); rows of D past the order are row M1 - 1 again, finite, and meet zeros of mc
+    auto plain_e = [&](int kc) { return clampc(kc) * kRgKC + kRgKC + 1 <= K; };
+    auto plain_k = [&](int kc) { return clampc(kc) * kRgKC + kRgKC <= K; };
     auto fetch_e = [&](int kc) __attribute__((always_inline)) {
         const int K0 = clampc(kc) * kRgKC;
         const float* src = E + (long)(K0 + skk < K ? K0 + skk : K - 1) * lde;
+        const bool pl = plain_e(kc);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sv[q] = row_raw4<false>(src, scq + 4 * q, N);
+        for (int q = 0; q < 4; ++q) {
+            const int cb = scq + 4 * q;
+            if (pl) sv[q] = *reinterpret_cast<const rg_f4u*>(src + (cb < N ? cb : 0));
+            else sv[q] = row_raw4<false>(src, cb, N);
+        }
     };
     auto put_e = [&](int kc, int q) __attribute__((always_inline)) {   // quarter q of the thread's 16 columns
         const int K0 = clampc(kc) * kRgKC, buf = kc & 1;
         const int cb = scq + 4 * q;
-        const rg_f4 v = row_fix4<false>(sv[q], cb, N, K0 + skk < K, 0.f);
+        rg_f4 v = sv[q];
+        if (!plain_e(kc)) v = row_fix4<false>(sv[q], cb, N, K0 + skk < K, 0.f);
         *reinterpret_cast<rg_f2*>(&bs[buf][skk * kRgLD + cb]) = rg_f2{v[0], v[1]};
         *reinterpret_cast<rg_f2*>(&bs[buf][skk * kRgLD + cb + 2]) = rg_f2{v[2], v[3]};
     };
     auto fetch_d = [&](int kc) __attribute__((always_inline)) {
         const int K0 = clampc(kc) * kRgKC;
+        const bool pl = plain_k(kc);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int row = skk + 32 * h, rc = row < M1 ? row : M1 - 1;
-            if (32 * h < MT * 4) dv[h] = row_raw4<false>(D + (long)rc * ldd, K0 + dq, K);
+            if (32 * h < MT * 4) {
+                if (pl) dv[h] = *reinterpret_cast<const rg_f4u*>(D + (long)rc * ldd + K0 + dq);
+                else dv[h] = row_raw4<false>(D + (long)rc * ldd, K0 + dq, K);
+            }
         }
     };
     auto put_d = [&](int kc, int h) __attribute__((always_inline)) {
         const int K0 = clampc(kc) * kRgKC, buf = kc & 1;
         const int row = skk + 32 * h;
-        if (row < MT * 4) *reinterpret_cast<rg_f4*>(&dsm[buf][row * LDD + dq]) = row_fix4<false>(dv[h], K0 + dq, K, row < M1, 0.f);
+        if (row < MT * 4) {
+            rg_f4 v = dv[h];
+            if (!plain_k(kc)) v = row_fix4<false>(dv[h], K0 + dq, K, row < M1, 0.f);
+            *reinterpret_cast<rg_f4*>(&dsm[buf][row * LDD + dq]) = v;
+        }
     };
     auto fetch_x = [&](int kc) __attribute__((always_inline)) {
         const int kb = clampc(kc) * kRgKC + 8 * g;
-        cr[0] = row_raw4<false>(xrow, kb, K);
-        cr[1] = row_raw4<false>(xrow, kb + 4, K);
+        if (plain_k(kc)) {
+            cr[0] = *reinterpret_cast<const rg_f4u*>(xrow + kb);
+            cr[1] = *reinterpret_cast<const rg_f4u*>(xrow + kb + 4);
+        } else {
+            cr[0] = row_raw4<false>(xrow, kb, K);
+            cr[1] = row_raw4<false>(xrow, kb + 4, K);
+        }
     };
 
     // Iteration i produces e for chunk i (PROD) and multiplies chunk i - 1 (CONS); everything that is not a matrix instruction is cut
@@ -359,8 +407,12 @@ __global__ __launch_bounds__(256) void mcep_resid_mfma_kernel(const float* __res
         float cn[8];
         if constexpr (PROD) {
             const int kb = i * kRgKC + 8 * g;
-            xa = row_fix4<false>(cr[0], kb, K, true, 0.f);
-            xb = row_fix4<false>(cr[1], kb + 4, K, true, 0.f);
+            xa = cr[0];
+            xb = cr[1];
+            if (!plain_k(i)) {
+                xa = row_fix4<false>(cr[0], kb, K, true, 0.f);
+                xb = row_fix4<false>(cr[1], kb + 4, K, true, 0.f);
+            }
             fetch_x(i + 1);
             // S = mc D[:, chunk i]: two column tiles, MT steps of four
             rg_f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
