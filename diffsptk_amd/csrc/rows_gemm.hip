@@ -286,7 +286,9 @@ static void rows_gemm_launch_t(const void* c, int64_t F, int K, const void* A, i
 // (16 x 32, 2 MT matrix instructions, mc held in MT registers per lane for the whole kernel), turns it from the result layout
 // (lane (j, g): rows 4 g .. 4 g + 3 of column j) into the operand layout (lane (row, g): bins 8 g .. 8 g + 7) through a
 // wave-private LDS tile, applies exp(logx - 2 S) (logx read in that layout, a chunk ahead), and multiplies by the chunk of E as
-// rows_gemm_mfma_kernel does.  Same staging discipline (loads a chunk ahead in registers, operands of step t + 1 read during step t).
+// rows_gemm_mfma_kernel does.  (Tried: S^T = D^T mc^T instead, whose result layout -- lane (frame, g): bins 16 tile + 4 g + r -- is an
+// A operand of the second product as it stands, no LDS tile: 73.2 -> 76.2 us per workgroup; the exp then waits on the end of the
+// S chain instead of on an LDS read that the first matrix instructions of the product cover.)  Same staging discipline (loads a chunk ahead in registers, operands of step t + 1 read during step t).
 
 // exp(x) in five instructions, about 1.5 ulp for results in the normal range: x log2(e) = t + r with t the rounded product and r its
 // exact remainder plus the low part of log2(e), exp2(t) on the transcendental unit (v_exp_f32, 1 ulp), times (1 + r ln 2).  No
