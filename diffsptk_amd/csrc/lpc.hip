@@ -345,7 +345,14 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_kernel(
         unsigned ticket = 0;
         if (lane == 0) ticket = atomicAdd(queue, 1u);
         const long tk = (long)__builtin_amdgcn_readfirstlane(ticket);
-        if (tk >= total_sc) break;
+        if (tk >= total_sc) {
+            // Every wave draws exactly one ticket past the end, so the counter stops at total_sc + (number of waves): the wave that
+            // drew the last of those hands it back zeroed (DSA_LPC_SCRATCH_IS_CLEAN: no fill launch before the next call) -- no
+            // second counter.  (A separate "waves done" counter put 3072 more atomics on one address at the very end: + 0.03 ms.)
+            if (lane == 0 && tk == total_sc + (long)(gridDim.x * (blockDim.x >> 6)) - 1)
+                __hip_atomic_store(queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
         const long b = tk / sc_per_utt;
         const long ci = tk - b * sc_per_utt;
         const long fbase = ci * fpi;
@@ -518,11 +525,28 @@ __global__ __launch_bounds__(256, 3) void frame_window_lpc24_mfma_kernel(
             const int i = 4 * g + r, lag = 16 * s_ + j - i;
             addr[s_][r] = ((lag >= 0 && lag < kLpcM1) ? lag : kLpcM1) * DS + i;
         }
+    // Items are dealt out statically, item = wave + k (number of waves), unless a counter is given (queue != NULL: tickets).  With
+    // the ticket counter every item and every wave's exit was an atomic on ONE address -- 5120 + 3072 of them per launch at the
+    // bench size, about one per 16 ns: the counter's throughput, not the arithmetic, set the launch time (0.105 of 0.135 ms were
+    // left with everything but the loads removed, tools/gpu_abl_lpc.sh).
+    const long nwaves_g = (long)gridDim.x * (blockDim.x >> 6);
+    long next_static = (long)blockIdx.x * (blockDim.x >> 6) + wave;
     for (;;) {
-        unsigned ticket = 0;
-        if (lane == 0) ticket = atomicAdd(queue, 1u);
-        const long tk = (long)__builtin_amdgcn_readfirstlane(ticket);
-        if (tk >= total_sc) break;
+        long tk;
+        if (queue) {
+            unsigned ticket = 0;
+            if (lane == 0) ticket = atomicAdd(queue, 1u);
+            tk = (long)__builtin_amdgcn_readfirstlane(ticket);
+        } else {
+            tk = next_static;
+            next_static += nwaves_g;
+        }
+        if (tk >= total_sc) {
+            // (tickets: every wave draws exactly one past the end, so the counter stops at total_sc + the number of waves; the wave
+            // that drew the last of those hands it back zeroed -- DSA_LPC_SCRATCH_IS_CLEAN: no fill launch before the next call)
+            if (queue && lane == 0 && tk == total_sc + nwaves_g - 1) __hip_atomic_store(queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
         const long b = tk / sc_per_utt;
         const long ci = tk - b * sc_per_utt;
         const long fbase = ci * fpi;
@@ -1120,6 +1144,8 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
                                         void* scratch, void* out, void* stream)
 {
     DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0 && M >= 0 && M < L && eps >= 0, "frame_window_lpc: invalid sizes");
+    const bool scratch_clean = (pad_mode & DSA_LPC_SCRATCH_IS_CLEAN) != 0;   // the caller's scratch is zero and private to this stream
+    pad_mode &= ~DSA_LPC_SCRATCH_IS_CLEAN;
     DSA_REQUIRE(pad_mode >= 0 && pad_mode <= 3, "frame_window_lpc: unknown pad mode");
     int64_t N = dsa_num_frames(T, P), F = B * N;
     if (F == 0) return DSA_OK;
@@ -1149,12 +1175,14 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
             int sc_per_utt = (int)((N + fpi - 1) / fpi);
             long total_sc = (long)B * sc_per_utt;
             if (grid > total_sc) grid = total_sc;
-            // ticket counter: the first word of the caller's scratch, zeroed in stream order before the launch
-            unsigned* queue = (unsigned*)scratch;
-            if (hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess)
-                return fail(DSA_ERR_LAUNCH, "frame_window_lpc: cannot reset the ticket counter%s");
             // lag sums: float32 matrix instruction (default) or the float64 vector unit (DSA_LPC_LAGSUMS=f64: exact sums)
             static const bool exact = [] { const char* e = getenv("DSA_LPC_LAGSUMS"); return e && e[0] == 'f' && e[1] == '6'; }();
+            static const bool tickets = [] { const char* e = getenv("DSA_LPC_TICKETS"); return e && e[0] == '1'; }();   // A/B: the ticket counter
+            // ticket counter (the float64 kernel; the default kernel deals its items out statically and needs none): the first word of
+            // the caller's scratch, zeroed in stream order before the launch unless the caller says it is
+            unsigned* queue = (unsigned*)scratch;
+            if ((exact || tickets) && !scratch_clean && hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess)
+                return fail(DSA_ERR_LAUNCH, "frame_window_lpc: cannot reset the ticket counter%s");
             if (!exact && L <= 512) {
                 // three workgroups per CU need 4 (200 fpi + 4160) <= 53 KB: at most 47 frames per item, utterances split evenly.
                 // (Tried: frames per item chosen so that every one of the 3072 resident waves gets the same number of items -- 34
@@ -1177,7 +1205,7 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
         if (lds_m > 48 * 1024 && !ensure_dynamic_lds((const void*)frame_window_lpc24_mfma_kernel<NEV, LCV>, lds_m, attr_m))        \
             return fail(DSA_ERR_LAUNCH, "frame_window_lpc: cannot reserve LDS%s");                                                 \
         hipLaunchKernelGGL((frame_window_lpc24_mfma_kernel<NEV, LCV>), dim3((unsigned)wgs), dim3(256), lds_m, st, (const float*)x, \
-                           (long)T, (long)N, L, P, left, pad_mode, (const float*)w, eps, (float*)out, total_sc, sc_per_utt, queue, fpi); \
+                           (long)T, (long)N, L, P, left, pad_mode, (const float*)w, eps, (float*)out, total_sc, sc_per_utt, tickets ? queue : nullptr, fpi); \
     } while (0)
                 if (L == 400) DSA_LPC_MFMA(8, 400);   // the 25 ms window at 16 kHz
                 else DSA_LPC_MFMA(8, 0);

@@ -778,6 +778,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
     }
 #endif
     // the counters go back to zero with the last wave out (every draw of a wave precedes its own arrival here)
+#ifndef DSA_MCEP_NO_EXIT_ATOMIC   // (measurement builds: what the 2048 arrivals on one address cost at the end of the launch)
     if (lane == 0) {
         const unsigned arrived = atomicAdd(queue + 2, 1u);
         if (arrived == gridDim.x * WAVES - 1) {
@@ -786,6 +787,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             queue[2] = 0u;
         }
     }
+#endif
 }
 
 }  // namespace dsa

@@ -946,7 +946,7 @@ def _mcep_scratch(device):
     stream is current, possibly next to an eager call that uses the capture stream's counters, so a captured launch gets its
     own block and the library's reset (a captured memset node) instead."""
     with torch.cuda.device(device):
-        if torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_current_stream_capturing() or os.environ.get("DSA_CLEAN_SCRATCH", "1") == "0":   # (the variable: A/B runs)
             return _scratch(device), 0
         return _clean_scratch(device), _lib.ALGO_SCRATCH_IS_CLEAN
 
@@ -1462,8 +1462,10 @@ def frame_window_lpc(x, window, L, P, M, eps, center=True, mode="constant"):
     T = xc.size(-1)
     B = xc.numel() // T
     out = torch.empty(*xc.shape[:-1], num_frames(T, P), M + 1, device=x.device, dtype=x.dtype)
-    scratch = _scratch(x.device)
+    # the kept-zero per-(device, stream) counters of the persistent kernels (the kernel hands them back zeroed: no fill launch per call;
+    # under graph capture a private block and the library's own reset, see _mcep_scratch)
+    scratch, flag = _mcep_scratch(x.device)
     with torch.cuda.device(x.device):
-        _call("dsa_frame_window_lpc_fwd", _p(xc), B, T, L, P, _p(wc), int(center), pad_mode_code(mode), M,
+        _call("dsa_frame_window_lpc_fwd", _p(xc), B, T, L, P, _p(wc), int(center), pad_mode_code(mode) | flag, M,
               float(eps), _dtype_code(xc), _p(scratch), _p(out), _stream())
     return out

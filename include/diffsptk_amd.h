@@ -404,7 +404,10 @@ int dsa_lpc_bwd(const void* gout, const void* x, const void* out, int64_t F, int
                 double eps, int32_t dtype, void* gx, void* stream);
 /* Fused LPC branch of the README (README.md:198-201): LPC(Window(Frame(x))) in one kernel.
  * x:(B,T), w:(L) or NULL (a window of ones) -> out:(B,N,M+1).  scratch: see Conventions (the tuned kernel for
- * float32 / lpc_order 24 hands out 64-frame work items through a counter). */
+ * float32 / lpc_order 24 hands out work items through a counter: the first word, which the kernel leaves zeroed).  pad_mode may carry
+ * DSA_LPC_SCRATCH_IS_CLEAN: the caller guarantees that the scratch is zero on entry and used by one call at a time (a buffer per
+ * stream that only calls with this flag ever touch) -- the library then skips its fill launch, as DSA_ALGO_SCRATCH_IS_CLEAN does. */
+#define DSA_LPC_SCRATCH_IS_CLEAN 0x100
 int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P,
                              const void* w, int32_t center, int32_t pad_mode, int32_t M, double eps,
                              int32_t dtype, void* scratch, void* out, void* stream);
