@@ -665,6 +665,24 @@ def test_lpc_config4_batch1024_sampled():
     close(host(a_mod), host(a[:64]), 1e-6, 1e-6)
 
 
+@pytest.mark.parametrize("B,T,P,L", [(777, 12345, 80, 400), (3000, 2000, 80, 400), (5, 160000, 160, 400), (130, 9000, 100, 320),
+                                     (64, 16000, 80, 512), (2, 700, 80, 400)])
+def test_fused_lpc_ragged_batches_against_the_float64_kernel(B, T, P, L):
+    """The fused Frame + Window + LPC kernel deals its work items out statically (item = wave + k x number of waves) and works two
+    frames per round: batches whose item count is no multiple of the wave count, utterances of a few frames, odd frame counts per
+    item, hops other than 80, frame lengths up to the 512 samples an operand holds -- every output row against the float64 generic
+    kernels on the same input; rtol / atol 1e-4 as the other float32 LPC tests (white noise)."""
+    g = torch.Generator().manual_seed(B + T)
+    x = torch.randn(B, T, generator=g)
+    xd = x.to(DEV)
+    w = dsp.Window(L, device=DEV).window
+    a = ops.frame_window_lpc(xd, w, L, P, 24, 1e-5)
+    assert _lib.last_kernel() == "frame_window_lpc24_mfma_fwd"
+    assert torch.isfinite(a).all()
+    ref = ops.frame_window_lpc(xd.double(), w.double(), L, P, 24, 1e-5)
+    close(host(a), host(ref), 1e-4, 1e-4)
+
+
 def test_chunked_overlap_alternating_streams(monkeypatch):
     """dist.analyze_chunked_overlap on a GPU alternates chunks between two streams.  Only one GPU is
     available to this suite, so the collective is replaced by a stand-in that copies the local chunk
