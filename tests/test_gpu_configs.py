@@ -537,7 +537,7 @@ def test_hot_path_and_f_rows_replay_from_a_hip_graph():
 
 
 @pytest.mark.parametrize("F,K,N", [(300, 1025, 99), (1000, 50, 1025), (257, 513, 69), (64, 31, 17), (1, 1025, 121), (513, 1030, 260),
-                                   (130, 1027, 130), (70, 6, 5), (33, 3, 40), (40, 35, 2), (65, 4, 4)])
+                                   (130, 1027, 130), (70, 6, 5), (33, 3, 40), (40, 35, 2), (65, 4, 4), (100, 64, 40), (70, 96, 130), (257, 33, 4)])
 def test_rows_gemm_matrix_core_product_against_float64(F, K, N):
     """The general float32 row product (dsa_rows_gemm, csrc/rows_gemm.hip: what the 1025-bin products of the 48 kHz set-ups run
     on instead of a vendor GEMM): plain, transposed, with the log prologue and with the exp(aux - 2 .) epilogue of the untuned
@@ -574,7 +574,8 @@ def test_rows_gemm_matrix_core_product_against_float64(F, K, N):
         assert float((cg.grad.double().cpu() - gref).abs().max()) < 2e-6 * float(gref.abs().max()) + 1e-6
 
 
-@pytest.mark.parametrize("F,K,M1", [(300, 1025, 50), (1000, 513, 35), (65, 1025, 55), (1, 257, 3), (130, 1027, 25), (64, 100, 41)])
+@pytest.mark.parametrize("F,K,M1", [(300, 1025, 50), (1000, 513, 35), (65, 1025, 55), (1, 257, 3), (130, 1027, 25), (64, 100, 41), (70, 64, 30),
+                                    (33, 33, 5)])
 def test_newton_residual_in_one_launch_against_float64(F, K, M1):
     """dsa_mcep_newton_resid: rt = exp(log X - 2 mc D) E (mcep.py:210-215) with e formed in registers, against float64 and against
     the two-launch composition it replaces, on the warping matrices of a real configuration and on ragged sizes (K not a multiple of
