@@ -117,6 +117,8 @@ SIGNATURES = {
     "dsa_freqt_bwd": (C.c_int, [_P, _L, _I, _P, _I, _I, _P, _P]),
     "dsa_rows_gemm": (C.c_int, [_P, _L, _I, _P, _I, _I, _I, _P, _I, _I, _P, _I, _P]),
     "dsa_mcep_newton_update": (C.c_int, [_P, _L, _I, _P, _I, _P, _P, _P]),
+    "dsa_gnorm_fwd": (C.c_int, [_P, _L, _I, _D, _I, _I, _P, _P]),
+    "dsa_mgcep_gain": (C.c_int, [_P, _P, _P, _L, _I, _D, _I, _P, _P]),
     "dsa_mcep_newton_update_bwd": (C.c_int, [_P, _P, _P, _L, _I, _I, _P, _P, _P]),
     "dsa_mcep_newton_resid": (C.c_int, [_P, _L, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P]),
     "dsa_rows_ew": (C.c_int, [_I, _I, _P, _P, _P, _L, _I, _P, _P, _P]),

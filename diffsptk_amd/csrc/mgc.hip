@@ -1533,6 +1533,95 @@ DSA_EXPORT int dsa_thsolve_bwd(const void* gg, const void* p, const void* q, con
     return fail(DSA_ERR_UNSUPPORTED, "thsolve_bwd: unsupported dtype%s");
 }
 
+// ---- gain normalisation of generalized cepstra and its inverse as ONE launch each (gnorm.py:102-112, ignorm.py:99-109), forward only ----
+//   forward:  (K, x1 / z),  z = 1 + gamma x0,  K = z^(1/gamma)      (gamma = 0: (exp x0, x1))
+//   inverse:  ((z - 1) / gamma, y1 z),  z = K^gamma                   (gamma = 0: (log K, y1))
+// As stock tensor operations (split, multiply-add, pow, divide, cat) a call was five to six launches of ~5 us; the mel-generalized
+// analysis makes three such calls around its Newton steps.  (With a gradient wanted the modules keep the stock composition.)
+namespace dsa {
+template <typename T>
+__global__ __launch_bounds__(256) void gnorm_rows_kernel(const T* __restrict__ x, long F, int n, T gamma, int inverse, T* __restrict__ out)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= F * n) return;
+    const long f = i / n;
+    const int m = (int)(i - f * n);
+    const T x0 = x[f * n];
+    T scale, head;
+    if (!inverse) {
+        if (gamma == T(0)) {
+            head = dsa_exp(x0);
+            scale = T(1);
+        } else {
+            const T z = T(1) + gamma * x0;
+            head = dsa_pow(z, T(1) / gamma);
+            scale = T(1) / z;
+        }
+    } else {
+        if (gamma == T(0)) {
+            head = dsa_log(x0);
+            scale = T(1);
+        } else {
+            const T z = dsa_pow(x0, gamma);
+            head = (z - T(1)) / gamma;
+            scale = z;
+        }
+    }
+    out[i] = m == 0 ? head : (!inverse && gamma != T(0) ? x[i] / (T(1) + gamma * x0) : x[i] * scale);
+}
+// b = (sqrt(r_0 + gamma sum_m r_{m+1} b_eps_m), b_join): the gain of a Newton step of the mel-generalized analysis joined to its
+// coefficients (mgcep.py:213-215, 221, 231-233).  A row per wave (coalesced reads, the sum over the wave by DPP; one thread per row
+// read 25 scattered words per lane: 19 us per 51 200 rows); orders above 64 loop.
+template <typename T>
+__global__ __launch_bounds__(256) void mgcep_gain_kernel(const T* __restrict__ r, const T* __restrict__ b_eps, const T* __restrict__ b_join,
+                                                        long F, int M, T gamma, T* __restrict__ b)
+{
+    const int lane = threadIdx.x & 63;
+    const long f = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= F) return;
+    T acc = T(0);
+    for (int m = lane; m < M; m += 64) {
+        acc += r[f * (M + 1) + m + 1] * b_eps[f * M + m];
+        b[f * (M + 1) + m + 1] = b_join[f * M + m];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) b[f * (M + 1)] = sqrt(r[f * (M + 1)] + gamma * acc);
+}
+}  // namespace dsa
+
+DSA_EXPORT int dsa_gnorm_fwd(const void* x, int64_t F, int32_t n, double gamma, int32_t inverse, int32_t dtype, void* out, void* stream)
+{
+    DSA_REQUIRE(F >= 0 && n >= 1 && x && out, "gnorm: invalid arguments");
+    DSA_REQUIRE(gamma >= -1 && gamma <= 1, "gnorm: gamma must be in [-1, 1]");
+    if (F == 0) return DSA_OK;
+    const dim3 grid((unsigned)((F * n + 255) / 256));
+    if (dtype == DSA_F32)
+        hipLaunchKernelGGL(dsa::gnorm_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (long)F, (int)n,
+                           (float)gamma, (int)inverse, (float*)out);
+    else if (dtype == DSA_F64)
+        hipLaunchKernelGGL(dsa::gnorm_rows_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, (const double*)x, (long)F, (int)n, gamma,
+                           (int)inverse, (double*)out);
+    else return dsa::fail(DSA_ERR_UNSUPPORTED, "gnorm: unsupported dtype%s");
+    return dsa::check_launch(inverse ? "ignorm_fwd" : "gnorm_fwd");
+}
+
+DSA_EXPORT int dsa_mgcep_gain(const void* r, const void* b_eps, const void* b_join, int64_t F, int32_t M, double gamma, int32_t dtype,
+                              void* b, void* stream)
+{
+    DSA_REQUIRE(F >= 0 && M >= 1 && r && b_eps && b_join && b, "mgcep_gain: invalid arguments");
+    if (F == 0) return DSA_OK;
+    const dim3 grid((unsigned)((F + 3) / 4));
+    if (dtype == DSA_F32)
+        hipLaunchKernelGGL(dsa::mgcep_gain_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)r, (const float*)b_eps,
+                           (const float*)b_join, (long)F, (int)M, (float)gamma, (float*)b);
+    else if (dtype == DSA_F64)
+        hipLaunchKernelGGL(dsa::mgcep_gain_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, (const double*)r, (const double*)b_eps,
+                           (const double*)b_join, (long)F, (int)M, gamma, (double*)b);
+    else return dsa::fail(DSA_ERR_UNSUPPORTED, "mgcep_gain: unsupported dtype%s");
+    return dsa::check_launch("mgcep_gain");
+}
+
 DSA_EXPORT int dsa_mgcep_step(const void* x, const void* b1, int64_t F, int32_t fft_length, int32_t M, double gamma, const void* images,
                               int32_t dtype, void* pt, void* qt, void* r, void* stream)
 {

@@ -1,9 +1,10 @@
 """Gain normalisation of generalized cepstra and its inverse (reference: gnorm.py, ignorm.py) -- SURVEY.md 8(f), rows 3-4.
-Two element-wise device operations on (..., M+1) rows: no kernel of their own."""
+Element-wise on (..., M+1) rows: one launch each without a gradient (dsa_gnorm_fwd), the stock tensor operations with one."""
 from __future__ import annotations
 
 import torch
 
+from .. import ops
 from ..utils.private import check_size, filter_values
 from .base import BaseFunctionalModule, Precomputed
 
@@ -55,6 +56,8 @@ class GeneralizedCepstrumGainNormalization(BaseFunctionalModule):
 
     @staticmethod
     def _forward(x: torch.Tensor, *, gamma: float) -> torch.Tensor:
+        if ops.gnorm_applies(x):
+            return ops.gnorm(x, gamma)
         x0, x1 = torch.split(x, [1, x.size(-1) - 1], dim=-1)
         if gamma == 0:
             return torch.cat((torch.exp(x0), x1), dim=-1)
@@ -93,6 +96,8 @@ class GeneralizedCepstrumInverseGainNormalization(BaseFunctionalModule):
 
     @staticmethod
     def _forward(y: torch.Tensor, *, gamma: float) -> torch.Tensor:
+        if ops.gnorm_applies(y):
+            return ops.gnorm(y, gamma, inverse=True)
         K, y1 = torch.split(y, [1, y.size(-1) - 1], dim=-1)
         if gamma == 0:
             return torch.cat((torch.log(K), y1), dim=-1)

@@ -87,6 +87,7 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
             return r[..., 0] + gamma * (r[..., 1:] * b1).sum(-1)
 
         def newton(gamma, b1, need_gain=True):   # need_gain: b0 = sqrt(eps) is only read after the LAST step of a run
+            b1_old = b1
             if gamma == -1:                                        # mgcep.py:196-197, 213-215
                 pt = mm(x, self.Pr)
                 qt = None                                          # q (1 + gamma) = 0: no Hankel part
@@ -94,17 +95,14 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
             elif not (torch.is_grad_enabled() and (x.requires_grad or b1.requires_grad)) and self.step_images is not None \
                     and x.dtype == torch.float32 and self.step_images.device == x.device:
                 pt, qt, r = ops.mgcep_step(x, b1, self.step_images, gamma)   # mgcep.py:199-220 in one launch (forward only)
-                eps = epsilon(gamma, r, b1) if need_gain else None
             elif self.step_images is not None and x.dtype == torch.float32 and self.step_images.device == x.device:
                 # a graph is wanted: the same launch forward, its adjoint as one launch backward (ops.MgcepStepFn)
                 pt, qt, r = ops.MgcepStepFn.apply(x, b1, self.step_images, self.step_images_bwd, gamma)
-                eps = epsilon(gamma, r, b1) if need_gain else None
             elif not (torch.is_grad_enabled() and (x.requires_grad or b1.requires_grad)) and M <= 64:
                 S = ops.mgcep_spectra(x, b1, self.Cr, self.Ci, gamma)   # mgcep.py:199-209, one pass (forward only)
                 pt = mm(S[0], self.Pr)
                 qt = (mm(S[1], self.Qr) + mm(S[2], self.Qi)) * (1 + gamma)
                 r = mm(S[3], self.Rr) + mm(S[4], self.Ri)
-                eps = epsilon(gamma, r, b1) if need_gain else None
             else:
                 b = torch.cat((torch.zeros_like(b1[..., :1]), b1), dim=-1)
                 X = 1 + gamma * mm(b, self.Cr)                     # mgcep.py:199-209
@@ -116,23 +114,30 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
                 pt = mm(pp, self.Pr)
                 qt = (mm(qq * (XX - YY), self.Qr) + mm(qq * (2 * X * Y), self.Qi)) * (1 + gamma)
                 r = mm(pp * X, self.Rr) + mm(pp * Y, self.Ri)
-                eps = epsilon(gamma, r, b1) if need_gain else None
             if qt is None:
                 qt = torch.zeros(*pt.shape[:-1], 2 * M - 1, device=pt.device, dtype=pt.dtype)
             upd = None
             if not (torch.is_grad_enabled() and (pt.requires_grad or qt.requires_grad or r.requires_grad or b1.requires_grad)):
                 upd = ops.thsolve_update(pt, qt, r, b1)            # solve + update in one call, r read in place
             b1 = upd if upd is not None else b1 + ops.ThSolveFn.apply(pt, qt, r[..., 1:])      # mgcep.py:226-230
-            if gamma == -1:
-                eps = epsilon(gamma, r, b1)
-            return (torch.sqrt(eps).unsqueeze(-1) if eps is not None else None), b1
+            if not need_gain:
+                return None, b1, None
+            b_eps = b1 if gamma == -1 else b1_old     # mgcep.py:213-215 / 221: the gain uses the updated coefficients only at gamma = -1
+            if fused_gain and not (torch.is_grad_enabled() and (r.requires_grad or b1.requires_grad or b_eps.requires_grad)):
+                return None, b1, ops.mgcep_gain(r, b_eps, gamma, b1)   # (b0, b1) in one launch, already joined
+            return torch.sqrt(epsilon(gamma, r, b_eps)).unsqueeze(-1), b1, None
 
+        # without a gradient the gain and the joining of (b0, b1) are one launch (dsa_mgcep_gain) instead of six stock ones
+        fused_gain = x.is_cuda and x.dtype in (torch.float32, torch.float64)
         b1 = torch.zeros(*x.shape[:-1], M, device=x.device, dtype=x.dtype)
-        b0, b1 = newton(-1, b1)
+        b0, b1, b = newton(-1, b1)
         if self.gamma != -1:
-            b = torch.cat((b0, b1), dim=-1)
+            if b is None:
+                b = torch.cat((b0, b1), dim=-1)
             b = _Gnorm._forward(self.mc2b(self.gc2gc(self.b2mc(_Ignorm._forward(b, gamma=-1)))), gamma=self.gamma)   # b2b, :120-137
             b1 = b[..., 1:]
             for it in range(self.n_iter):
-                b0, b1 = newton(self.gamma, b1, need_gain=it == self.n_iter - 1)
-        return self.b2mc(_Ignorm._forward(torch.cat((b0, b1), dim=-1), gamma=self.gamma))                             # b2mc, :139-144
+                b0, b1, b = newton(self.gamma, b1, need_gain=it == self.n_iter - 1)
+        if b is None:
+            b = torch.cat((b0, b1), dim=-1)
+        return self.b2mc(_Ignorm._forward(b, gamma=self.gamma))                                                       # b2mc, :139-144

@@ -862,6 +862,33 @@ def mcep_newton_update(rt, av, mc):
     return out
 
 
+def gnorm(x, gamma, inverse=False):
+    """Gain normalisation (gnorm.py:102-112) / its inverse (ignorm.py:99-109) of (..., M + 1) rows in one launch (dsa_gnorm_fwd);
+    forward only -- the modules keep the stock composition when a gradient is wanted."""
+    xc = x.contiguous()
+    n = xc.size(-1)
+    out = torch.empty_like(xc)
+    with torch.cuda.device(x.device):
+        _call("dsa_gnorm_fwd", _p(xc), xc.numel() // n, n, float(gamma), int(bool(inverse)), _dtype_code(xc), _p(out), _stream())
+    return out
+
+
+def gnorm_applies(x) -> bool:
+    """dsa_gnorm_fwd takes this call: a device tensor in float32 / float64 and no gradient wanted."""
+    return x.is_cuda and x.dtype in (torch.float32, torch.float64) and not (torch.is_grad_enabled() and x.requires_grad) and x.numel() > 0
+
+
+def mgcep_gain(r, b_eps, gamma, b_join):
+    """(sqrt(r_0 + gamma sum_m r_{m+1} b_eps_m), b_join) as one (..., M + 1) tensor (mgcep.py:213-215, 221, 231-233; dsa_mgcep_gain),
+    forward only."""
+    rc, bc, jc = r.contiguous(), b_eps.contiguous(), b_join.contiguous()
+    M = bc.size(-1)
+    out = torch.empty(*bc.shape[:-1], M + 1, device=bc.device, dtype=bc.dtype)
+    with torch.cuda.device(bc.device):
+        _call("dsa_mgcep_gain", _p(rc), _p(bc), _p(jc), bc.numel() // M, M, float(gamma), _dtype_code(bc), _p(out), _stream())
+    return out
+
+
 class McepNewtonUpdateFn(torch.autograd.Function):
     """mc + solve(T(rt[:, :n]) + H(rt), rt[:, :n] - av) with a gradient (mcep.py:216-222): forward = the batched solve (the solution is
     kept), backward = the same solve on the cotangent and one launch of diagonal sums (dsa_mcep_newton_update_bwd).  As a slice, a

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 122 /* 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
+#define DSA_VERSION 123 /* 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
@@ -246,6 +246,15 @@ int dsa_mcep_prepare(const void* G, const void* D, const void* E, int32_t nfft, 
 int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, int32_t n_iter, const void* G,
                  const void* D, const void* E, const void* alpha_vec, int32_t dtype, int32_t algo,
                  const void* images, void* scratch, void* mc, void* mc_hist, void* stream);
+/* Gain normalisation of generalized cepstra (gnorm.py:102-112) and its inverse (ignorm.py:99-109), forward, one launch each:
+ *   inverse = 0:  x:(F,n) -> (K, x1 / (1 + gamma x0)),  K = (1 + gamma x0)^(1/gamma)   (gamma = 0: (exp x0, x1))
+ *   inverse = 1:  y:(F,n) -> ((K^gamma - 1) / gamma, y1 K^gamma)                          (gamma = 0: (log K, y1)) */
+int dsa_gnorm_fwd(const void* x, int64_t F, int32_t n, double gamma, int32_t inverse, int32_t dtype, void* out, void* stream);
+/* The gain of a Newton step of the mel-generalized analysis joined to its coefficients (mgcep.py:213-215, 221, 231-233):
+ * b:(F, M+1) = (sqrt(r_0 + gamma sum_m r_{m+1} b_eps_m), b_join),  r:(F, M+1), b_eps, b_join:(F, M) (the same rows at gamma = -1,
+ * the coefficients before / after the step's update otherwise). */
+int dsa_mgcep_gain(const void* r, const void* b_eps, const void* b_join, int64_t F, int32_t M, double gamma, int32_t dtype, void* b,
+                   void* stream);
 /* The solve-and-update of a Newton step of MelCepstralAnalysis (mcep.py:216-222) at a geometry without a tuned kernel:
  * mc_out:(F,n) = mc_in + solve(T(rt[:, :n]) + H(rt), rt[:, :n] - alpha_vec), rt:(F, 2n-1), n = cep_order + 1 in [2, 55], float32.
  * 16 systems per wave on the float32 matrix instruction, no pivoting; a system that meets a non-positive pivot is re-solved with

@@ -668,3 +668,23 @@ def test_thsolve_quad_layout_solver_for_general_orders(n, F):
         for got_g, ref_g, name in ((pg.grad, p6.grad, "p"), (qg.grad, q6.grad, "q"), (rg.grad, r6.grad, "r")):
             e = float((got_g.double().cpu() - ref_g).abs().max() / ref_g.abs().max())
             assert e < 5e-6 * float(cond) ** 0.5 + 5e-5, (name, e, float(cond))
+
+
+@pytest.mark.parametrize("gamma", [0.0, -0.5, -1.0, 0.5, 1.0])
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_gain_normalisation_kernels_against_the_stock_composition(gamma, dt):
+    """dsa_gnorm_fwd (one launch, no gradient) against the stock tensor operations the modules keep for the differentiable case
+    (gnorm.py:102-112, ignorm.py:99-109), both directions, ragged leading shapes; float32 2e-6, float64 1e-13 relative."""
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(3, 77, 9, generator=g, dtype=torch.float64) * 0.4 + 0.1).to(dt).to(DEV)    # 1 + gamma x0 stays positive
+    tol = 2e-6 if dt == torch.float32 else 1e-13
+    y = F.gnorm(x, gamma)
+    assert _lib.last_kernel() == "gnorm_fwd"
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.gnorm(xr, gamma)                      # a gradient is wanted: the composition
+    assert float(((y - y_ref.detach()) / y_ref.detach()).abs().max()) < tol
+    z = F.ignorm(y, gamma)
+    assert _lib.last_kernel() == "ignorm_fwd"
+    z_ref = F.ignorm(y.clone().requires_grad_(True), gamma)
+    assert float(((z - z_ref.detach()) / z_ref.detach().abs().clamp_min(1e-3)).abs().max()) < tol * 10
+    assert float((z - x).abs().max()) < (2e-6 if dt == torch.float32 else 1e-12)      # the round trip
