@@ -7,7 +7,7 @@ from diffsptk_amd import ops
 
 dev = "cuda"
 for n in (50, 35, 25):
-    F = 12800
+    F = int(os.environ.get('F', '12800'))
     g = torch.Generator().manual_seed(0)
     rt = torch.randn(F, 2 * n - 1, generator=g).to(dev) * 0.01
     rt[:, 0] += 4.0
