@@ -264,9 +264,18 @@ __global__ __launch_bounds__(256, 4) DSA_PK_TARGET void stft512_bwd_pk_kernel(
         const long g0 = (long)c.p * kFPW * P - left;
         const float* xs = x + c.b * Tlen + g0;
         if (g0 >= 0 && g0 + SPAN <= Tlen && (((size_t)xs) & 15) == 0) {
-            const v4f* src4 = reinterpret_cast<const v4f*>(xs);
+            // 32-bit byte offsets from an opaque copy of the lane index, formed here: as a 64-bit index the clamped offset of the last
+            // piece was hoisted out of the pass loop, spilled (the kernel sits at 128 registers), and its reload -- a
+            // `s_waitcnt vmcnt(0)` in the middle of this fetch -- made every pass wait for the first piece's trip to memory and for the
+            // stores issued before it
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const char* src = reinterpret_cast<const char*>(xs);
 #pragma unroll
-            for (int q = 0; q < NPRE; ++q) pre[q] = src4[lane + 64 * q < n4 ? lane + 64 * q : n4 - 1];
+            for (int q = 0; q < NPRE; ++q) {
+                const unsigned idx = (unsigned)(ln + 64 * q < n4 ? ln + 64 * q : n4 - 1);
+                pre[q] = *reinterpret_cast<const v4f*>(src + idx * 16u);
+            }
             return true;
         }
         return false;
