@@ -534,6 +534,8 @@ def compact_line(res: dict, detail_path: str = DETAIL_FILE) -> str:
         r = res.get(name)
         if r:
             line[name] = {k: r.get(k) for k in _ROOF_KEYS}
+            if r.get("measured_in"):
+                line[name]["measured_in"] = r["measured_in"]
     cb = res.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
@@ -575,9 +577,10 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="STRONG scaling: the whole job's utterances, split evenly over the N ranks (BASELINE configs[4] as written is "
                          "--global-batch 8192: N = 1 runs all 8192 utterances on one GPU, N = 8 runs 1024 each); 0 = weak scaling with --batch per GPU")
-    ap.add_argument("--path", choices=["two-kernel", "fused"], default="two-kernel",
-                    help="the step: fused STFT kernel + mel-cepstral kernel (default: measured faster, profiles/r04_fused_vs_two_kernels_*.txt) "
-                         "or the ONE-launch STFT -> mel-cepstrum kernel (diffsptk_amd.fuse; 420 B/frame of memory traffic instead of 2476)")
+    ap.add_argument("--path", choices=["two-kernel", "fused"], default="fused",
+                    help="the step: the ONE-launch STFT -> mel-cepstrum kernel (diffsptk_amd.fuse; 420 B/frame of memory traffic instead of "
+                         "2476; the default since it measures faster: profiles/r04_fused_vs_two_kernels_v2.txt) or the fused STFT kernel "
+                         "followed by the mel-cepstral kernel")
     ap.add_argument("--chunks", type=int, default=1,
                     help="N > 1: utterance chunks per step.  1 (default): one in-place all-gather per step, deferred "
                          "behind the next step's kernels; > 1: chunked gather/compute overlap inside the step")
@@ -752,6 +755,30 @@ def main():
     t_stft = statistics.mean(e[0].elapsed_time(e[1]) for e, _ in ev_log) * 1e-3
     t_mcep = statistics.mean(e[1].elapsed_time(e[2]) for e, _ in ev_log) * 1e-3
     frames_launch = statistics.mean(nb for _, nb in ev_log) * FRAMES_PER_UTT
+    stft_measured_in = "the timed region (HIP events around single launches)"
+    k_stft_ref = None
+    if args.path == "fused" and rank == 0:
+        # The timed step is ONE launch whose prologue is the frame + window + rFFT stage: there is no STFT launch to bracket.  The
+        # stage's own record (`roofline_stft`) comes from reference steps of the two-kernel path run AFTER the timed region,
+        # bracketed exactly as the two-kernel path brackets them inside it (event, STFT, event, mel-cepstral kernel, event).
+        ref_log = []
+        nref = int(frames_launch // FRAMES_PER_UTT)
+        with torch.no_grad():
+            for i in range(12):
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                e[0].record()
+                Xr = ops.StftFn.apply(x[:nref], stft.window, stft.twiddle, FL, FP, NFFT, True, False, "constant", 1e-9, None, 3, algo)
+                e[1].record()
+                k_stft_ref = _lib.last_kernel()
+                ops.McepFn.apply(Xr, mcep.G, mcep.D, mcep.E, mcep.alpha_vector, NFFT, M, N_ITER, algo)
+                e[2].record()
+                if i >= 2:
+                    ref_log.append(e)
+            torch.cuda.synchronize()
+        t_stft = statistics.mean(e[0].elapsed_time(e[1]) for e in ref_log) * 1e-3
+        t_mcep_two = statistics.mean(e[1].elapsed_time(e[2]) for e in ref_log) * 1e-3
+        stft_measured_in = ("reference steps of the two-kernel path after the timed region (event, STFT, event, mel-cepstral kernel, event): "
+                            "the timed step is ONE launch, this stage is its prologue and writes no spectrogram")
     if rank == 0:
         # the same two kernels back to back (no dispatch gap between an event and the launch): what a rocprofv3 kernel
         # trace reports as the kernels' own durations
@@ -762,7 +789,8 @@ def main():
                                                            1e-9, None, 3, algo), n=40) * 1e-3
             t_mcep_b2b = gpu_time(lambda: ops.McepFn.apply(Xl, mcep.G, mcep.D, mcep.E, mcep.alpha_vector, NFFT, M, N_ITER, algo),
                                   n=10) * 1e-3
-        pm_m, pm_s = pmc_static(kernels["mcep"]), pmc_static(kernels["stft"])
+        k_stft = k_stft_ref or kernels["stft"]   # (one-launch step: the stage's stand-alone kernel from the reference steps)
+        pm_m, pm_s = pmc_static(kernels["mcep"]), pmc_static(k_stft)
         ipf = pm_m["derived"]["valu_insts_per_frame"] if pm_m else None
         res = {
             "metric": "frames/sec STFT->mcep (fl=400 fp=80 nfft=512 M=24)",
@@ -816,21 +844,34 @@ def main():
                                   "1.99-2.09 GHz over a launch, so the nominal-clock peak above is not reachable"},
             })(datapath_roofline(isa_mix("mcep_mfma_fwd_kernel_hILi8ELb1" if args.path == "fused" else "mcep_mfma_fwd_kernel_hILi8ELb0"), N_ITER, frames_launch, t_mcep)),
             "roofline_stft": {
-                "kernel": kernels["stft"], "bound": "hbm",
+                "kernel": k_stft, "bound": "hbm",
                 "achieved": STFT_BYTES_PER_FRAME * frames_launch / t_stft / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": STFT_BYTES_PER_FRAME * frames_launch / t_stft / 1e9 / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(kernels["stft"], frames_launch), "avg_launch_ms": t_stft * 1e3,
+                "traffic": pmc_traffic(k_stft, frames_launch), "avg_launch_ms": t_stft * 1e3,
                 "back_to_back_ms": t_stft_b2b * 1e3,
                 "frac_back_to_back": STFT_BYTES_PER_FRAME * frames_launch / t_stft_b2b / 1e9 / HBM_PEAK_GBS,
                 "pmc": pm_s["derived"] if pm_s else None, "pmc_source": (pm_s["_source"] + " (static)") if pm_s else None,
                 "bytes_per_frame": STFT_BYTES_PER_FRAME,
-                "note": "avg_launch_ms: HIP events around single launches inside the timed region (what `frac` uses); "
-                        "back_to_back_ms: the same launch repeated between two events after the timed region (module API, "
-                        "no mel-cepstral kernel in between)",
+                "measured_in": stft_measured_in,
+                "note": "avg_launch_ms: HIP events around single launches (what `frac` uses), between two mel-cepstral launches; "
+                        "back_to_back_ms: the same launch repeated between two events (module API, no mel-cepstral kernel in between)",
             },
         }
-        if world == 1:
+        if world == 1 and args.path == "fused":
+            try:   # the other path of the same step, back to back (detail file only)
+                with torch.no_grad():
+                    t_two = gpu_time(lambda: mcep(stft(xl)), n=40) * 1e-3
+                    fused_mod = dsp.fuse(stft, mcep)
+                    t_fu = gpu_time(lambda: fused_mod(xl), n=40) * 1e-3
+                res["two_kernel_path"] = {
+                    "ms_per_step_back_to_back": t_two * 1e3, "frames/s": frames_launch / t_two, "fused_ms_back_to_back": t_fu * 1e3,
+                    "mcep_kernel_ms_in_reference_steps": t_mcep_two * 1e3, "stft_kernel_ms_in_reference_steps": t_stft * 1e3,
+                    "note": "bench.py --path two-kernel times this path as the step: `stft512_fwd` writes the (B, N, 257) power spectrogram, "
+                            "`mcep_mfma_fwd` reads it back (1348 + 1128 algorithmic bytes per frame instead of 420)"}
+            except Exception as e:
+                res["two_kernel_path"] = {"error": repr(e)}
+        if world == 1 and args.path != "fused":
             try:   # the other path of the same step, back to back (detail file only)
                 fused_mod = dsp.fuse(stft, mcep)
                 with torch.no_grad():
@@ -846,9 +887,8 @@ def main():
                                  "traffic": pmc_traffic("stft512_mcep_fused_fwd", frames_launch), "avg_launch_ms": t_fu * 1e3},
                     "note": "diffsptk_amd.fuse(stft, mcep): ONE launch, 320 + 100 algorithmic bytes per frame (SURVEY 8(d)) instead of 1348 + 1128; "
                             "the persistent mel-cepstral wave computes its tile's 16 spectra itself.  The kernel is bound by the float32 datapath, "
-                            "not by memory: removing the spectrogram's round trip buys no time, and the FFT must run on scalar vector "
-                            "instructions here (packed ones next to the other wave's 4x4x1 matrix products return stale results, "
-                            "profiles/r04_fused_pk_hazard_check_v1.txt), so the two-kernel step stays the default (--path)"}
+                            "not by memory, and its FFT runs on scalar vector instructions (packed ones next to the other wave's 4x4x1 matrix "
+                            "products return stale results, profiles/r04_fused_pk_hazard_check_v1.txt); it is the default step (--path)"}
             except Exception as e:
                 res["fused_path"] = {"error": repr(e)}
         if world == 1 and not args.no_configs:

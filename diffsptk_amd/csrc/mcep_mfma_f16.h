@@ -319,20 +319,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             const float* fu = lds + h_lds_floats(WAVES);
             v2f raw[FU_NR];
             auto fetch = [&](int p) __attribute__((always_inline)) {
-                long fr = tile * 16 + 4 * p + fl;
-                fr = fr < F ? fr : F - 1;
-                const unsigned ub = (unsigned)fr / (unsigned)sti.N;          // F < 2^31 (host-checked)
-                const long nf = fr - (long)ub * sti.N;
-                const long start = nf * sti.P - sti.left;
+                // 32-bit arithmetic from an opaque copy of the lane's frame slot, formed here (F, Tlen < 2^31, host-checked): as 64-bit
+                // values derived from `fl` these were hoisted out of the pass loop, spilled across the Newton iteration, and each
+                // reload was a `s_waitcnt vmcnt(0)` in front of the fetch it feeds
+                int flo = fl;
+                asm volatile("" : "+v"(flo));
+                int fr = (int)(tile * 16) + 4 * p + flo;
+                fr = fr < (int)F ? fr : (int)F - 1;
+                const unsigned ub = (unsigned)fr / (unsigned)sti.N;
+                const int nf = fr - (int)(ub * (unsigned)sti.N);
+                const int start = nf * sti.P - sti.left;
                 const float* xb = sti.x + (long)ub * sti.Tlen;
-                const bool interior = start >= 0 && start + 32 * FU_NR <= sti.Tlen;
+                const bool interior = start >= 0 && start + 32 * FU_NR <= (int)sti.Tlen;
                 if (__builtin_amdgcn_ballot_w64(!interior) == 0) {
                     const v2f_u4* src = reinterpret_cast<const v2f_u4*>(xb + start + 2 * j);
 #pragma unroll
                     for (int m1 = 0; m1 < FU_NR; ++m1) raw[m1] = src[16 * m1];
                 } else {   // frames that reach over an end of their utterance: zeros outside (F.pad, constant mode).  Branch-free:
                            // clamped addresses, the out-of-range values selected away (32-bit: Tlen < 2^31, host-checked)
-                    const int s00 = (int)start + 2 * j, tl = (int)sti.Tlen;
+                    const int s00 = start + 2 * j, tl = (int)sti.Tlen;
 #pragma unroll
                     for (int m1 = 0; m1 < FU_NR; ++m1) {
                         const int s0 = s00 + 32 * m1, s1 = s0 + 1;
@@ -416,9 +421,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                     }
                     // sp[0] = (bin 2l+1, bin 255-2l), sp[1] = (bin 2l+2, bin 254-2l)
                     if (sti.X_out && fr0 + q < F) {   // the spectrogram as a side product (a gradient will need it)
-                        float* yr = sti.X_out + (fr0 + q) * K;
-                        *reinterpret_cast<v2f_u4*>(yr + 2 * lane + 1) = v2f{sp[0].x, sp[1].x};
-                        *reinterpret_cast<v2f_u4*>(yr + 254 - 2 * lane) = v2f{sp[1].y, sp[0].y};
+                        float* yr = sti.X_out + (fr0 + q) * K;   // (uniform; the lane part below from the per-pass opaque copy l4)
+                        *reinterpret_cast<v2f_u4*>(yr + 2 * l4 + 1) = v2f{sp[0].x, sp[1].x};
+                        *reinterpret_cast<v2f_u4*>(yr + 254 - 2 * l4) = v2f{sp[1].y, sp[0].y};
                         if (lane == 0) {
                             yr[0] = se.x;
                             yr[256] = se.y;

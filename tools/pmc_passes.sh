@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # forward kernels: the headline command without its sub-benchmarks (every launch covers 204 800 frames);
 # backward kernels: a few forward + backward steps at the same size (2nd argument "bwd")
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --ramp-seconds 0 --no-cpu-baseline --no-configs"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --ramp-seconds 0 --no-cpu-baseline --no-configs --path two-kernel"
 if [ "${2:-fwd}" = "bwd" ]; then CMD="python $GRAFT_REPO_ROOT/tools/run_mcep_bwd_only.py"; fi
 if [ "${2:-fwd}" = "fused" ]; then CMD="python $GRAFT_REPO_ROOT/tools/run_fused_only.py"; fi
 if [ "${2:-fwd}" = "fusedmcep" ]; then CMD="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --ramp-seconds 0 --no-cpu-baseline --no-configs --path fused"; fi
