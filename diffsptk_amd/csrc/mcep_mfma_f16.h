@@ -99,6 +99,19 @@ static_assert(FU_TWS % 4 == 0 && H_WAVE % 4 == 0 && WAVE_FLOATS % 4 == 0, "16-by
 constexpr int h_lds_floats_fused(int waves) { return h_lds_floats(waves) + FU_FLOATS; }
 }  // namespace mh
 
+// The fused prologue's arithmetic, per stage on the packed (v_pk_*_f32) or the scalar forms of pk_math.h.  The product builds every
+// stage on the scalar forms (mask 0).  DSA_FUSED_PK_MASK re-creates the failing variants for the reduction of
+// tools/hazard_matrix.sh: bit 0 window multiply, 1 first 16-point FFT, 2 the W256 twiddles, 3 second 16-point FFT, 4 real-FFT split.
+#ifndef DSA_FUSED_PK_MASK
+#define DSA_FUSED_PK_MASK 0
+#endif
+#ifndef DSA_FUSED_DBG
+#define DSA_FUSED_DBG 0   // reduction builds: 1 no matrix chains, 2 no solve, 4 no back substitution, 8 self-check of the first FFT (log in `hist`)
+#endif
+template <bool PK> __device__ __forceinline__ v2f fu_mul(v2f a, v2f b) { if constexpr (PK) return pk_mul(a, b); else return sc_mul(a, b); }
+template <bool PK> __device__ __forceinline__ v2f fu_cmul(v2f a, v2f t) { if constexpr (PK) return pk_cmul(a, t); else return sc_cmul(a, t); }
+template <bool PK, bool ZT> __device__ __forceinline__ void fu_fft16(v2f (&v)[16]) { if constexpr (PK) pk_fft16<ZT>(v); else sc_fft16<ZT>(v); }
+
 __device__ __forceinline__ f32x4 mfma_h(f16x8 a, f16x8 b, f32x4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -312,6 +325,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             // log2 in the split's layout (every lane busy), staged as 4 x 257 floats and picked up by the 16 lanes (n, g) whose
             // frames these are, in the matrix-core layout the chains below consume.  The samples come straight from memory /
             // L2 per frame (neighbouring frames overlap there; a lane reads 13 pairs), requested one pass ahead.
+            constexpr int PKM = DSA_FUSED_PK_MASK;
             const int j = lane & 15, fl = lane >> 4;
             float* wreg = lds + H_WAVE + wave * WAVE_FLOATS;
             v2f* zbuf = reinterpret_cast<v2f*>(wreg);
@@ -363,21 +377,64 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                     // exact and non-finite neighbours stay out of frames that do not contain them
                     const bool in0 = 32 * m1 + 30 < FU_LC || 32 * m1 + 2 * j < FU_LC;
                     const bool in1 = 32 * m1 + 31 < FU_LC || 32 * m1 + 1 + 2 * j < FU_LC;
-                    v[m1] = sc_mul(v2f{in0 ? raw[m1].x : 0.f, in1 ? raw[m1].y : 0.f}, wtab[m1]);
+                    v[m1] = fu_mul<(PKM & 1) != 0>(v2f{in0 ? raw[m1].x : 0.f, in1 ? raw[m1].y : 0.f}, wtab[m1]);
                 }
 #pragma unroll
                 for (int m1 = FU_NR; m1 < 16; ++m1) v[m1] = v2f{0.f, 0.f};
                 if (p < 3) fetch(p + 1);
-                sc_fft16<true>(v);
+#if DSA_FUSED_DBG & 8
+                {   // reduction build: the packed transform against its scalar twin on the same inputs; mismatches logged with a re-run
+                    v2f vin[16], vs[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { vin[i] = v[i]; vs[i] = v[i]; }
+                    pk_fft16<true>(v);
+                    sc_fft16<true>(vs);
+                    int nbad = 0, first = -1;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const bool b = __builtin_bit_cast(unsigned, v[i].x) != __builtin_bit_cast(unsigned, vs[i].x) ||
+                                       __builtin_bit_cast(unsigned, v[i].y) != __builtin_bit_cast(unsigned, vs[i].y);
+                        if (b && first < 0) first = i;
+                        nbad += b ? 1 : 0;
+                    }
+                    if (nbad) {
+                        v2f vr[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) vr[i] = vin[i];
+                        pk_fft16<true>(vr);
+                        unsigned* lg = reinterpret_cast<unsigned*>(hist);
+                        const unsigned slot = atomicAdd(lg, 1u);
+                        if (slot < 4000) {
+                            unsigned hwid, xcc;
+                            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                            unsigned* r = lg + 16 + 16 * slot;
+                            float pkx = 0, pky = 0, scx = 0, scy = 0, rx = 0, ry = 0;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i)
+                                if (i == first) { pkx = v[i].x; pky = v[i].y; scx = vs[i].x; scy = vs[i].y; rx = vr[i].x; ry = vr[i].y; }
+                            r[0] = (unsigned)tile; r[1] = p; r[2] = lane; r[3] = first; r[4] = nbad;
+                            r[5] = __builtin_bit_cast(unsigned, pkx); r[6] = __builtin_bit_cast(unsigned, pky);
+                            r[7] = __builtin_bit_cast(unsigned, scx); r[8] = __builtin_bit_cast(unsigned, scy);
+                            r[9] = __builtin_bit_cast(unsigned, rx); r[10] = __builtin_bit_cast(unsigned, ry);
+                            r[11] = hwid; r[12] = xcc; r[13] = wave; r[14] = blockIdx.x; r[15] = 0xabcd0000u;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) v[i] = vs[i];   // carry on with the right values
+                    }
+                }
+#else
+                fu_fft16<(PKM & 2) != 0, true>(v);
+#endif
 #pragma unroll
                 for (int k1 = 0; k1 < 16; ++k1) {
-                    zf[k1 * 17 + j] = sc_cmul(v[FFT16_OUT(k1)], t256[k1 * 16]);
+                    zf[k1 * 17 + j] = fu_cmul<(PKM & 4) != 0>(v[FFT16_OUT(k1)], t256[k1 * 16]);
                 }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[i] = zf[j * 17 + i];
                 __builtin_amdgcn_wave_barrier();
-                sc_fft16<false>(v);
+                fu_fft16<(PKM & 8) != 0, false>(v);
 #pragma unroll
                 for (int k0 = 0; k0 < 16; ++k0) {
                     zf[j + 16 * k0 + (k0 < 8 ? 1 : 2)] = v[FFT16_OUT(k0)];   // Z[k] at k + 1 (k <= 128) / k + 2: 16-byte aligned pair reads
@@ -403,10 +460,27 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     // bins 0 and 256 from Z[0] alone: X[0] = 2 (re + im), X[256] = 2 (re - im) (Z arrives halved)
+                    v2f se, sp[2];
+                    if constexpr ((PKM & 16) != 0) {   // the packed form of csrc/stft_pk.h, instruction for instruction
+                        const v2f eps2 = v2f{sti.eps, sti.eps};
+                        v2f Ee;
+                        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(Ee) : "v"(z0[q]), "v"(z0[q]));
+                        const v2f E4 = pk_mul_s(Ee, v2f{4.f, 4.f});
+                        se = pk_fma_sc(E4, Ee, eps2);
+#pragma unroll
+                        for (int part = 0; part < 2; ++part) {
+                            const v2f S = pk_add_conj(pa[q][part], pb[q][part]);
+                            const v2f Dd = pk_sub_conj(pa[q][part], pb[q][part]);
+                            const v2f Pp = pk_cmul(Dd, part == 0 ? twA : twB);
+                            v2f R, I;
+                            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(R) : "v"(S), "v"(Pp));
+                            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(I) : "v"(S), "v"(Pp));
+                            sp[part] = pk_fma(I, I, pk_fma_sc(R, R, eps2));
+                        }
+                    } else {
                     const v2f Ee = v2f{sc_add1(z0[q].x, z0[q].y), sc_sub1(z0[q].x, z0[q].y)};
                     const v2f E4 = v2f{sc_mul1s(Ee.x, 4.f), sc_mul1s(Ee.y, 4.f)};
-                    const v2f se = v2f{sc_fma1sc(E4.x, Ee.x, sti.eps), sc_fma1sc(E4.y, Ee.y, sti.eps)};
-                    v2f sp[2];
+                    se = v2f{sc_fma1sc(E4.x, Ee.x, sti.eps), sc_fma1sc(E4.y, Ee.y, sti.eps)};
 #pragma unroll
                     for (int part = 0; part < 2; ++part) {
                         // S = a + conj(b), Dd = a - conj(b), Pp = W^k Dd; X[k] = (S.re + Pp.im, S.im - Pp.re),
@@ -418,6 +492,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                         const v2f I = v2f{sc_sub1(S.y, Pp.x), sc_nsub1(S.y, Pp.x)};
                         const v2f s0_ = v2f{sc_fma1sc(R.x, R.x, sti.eps), sc_fma1sc(R.y, R.y, sti.eps)};
                         sp[part] = v2f{sc_fma1(I.x, I.x, s0_.x), sc_fma1(I.y, I.y, s0_.y)};
+                    }
                     }
                     // sp[0] = (bin 2l+1, bin 255-2l), sp[1] = (bin 2l+2, bin 254-2l)
                     if (sti.X_out && fr0 + q < F) {   // the spectrogram as a side product (a gradient will need it)
@@ -496,7 +571,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             for (int i = 0; i < 8; ++i) mcv[i] = rt_lds[8 * g + i];  // coefficients >= 25 come out 0
             __builtin_amdgcn_wave_barrier();
         }
-        if (hist && f_ok) store_mc_row(hist + f * M1, g, mcv);
+        if (!(DSA_FUSED_DBG & 8) && hist && f_ok) store_mc_row(hist + f * M1, g, mcv);
 
         DSA_STAMP_T(18);
         // Ticket for this wave's next tile, drawn now: the atomic's round trip hides behind the iterations.
@@ -520,6 +595,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
         for (int iter = 0; iter < n_iter; ++iter) {
             DSA_STAMPS_DECL;
             DSA_STAMP(0);
+#if DSA_FUSED_DBG & 1   // reduction build: no matrix chains; a finite, diagonally dominant system from data at hand
+            f32x4 accB[3] = {logx[0], logx[1], logx[2]};
+            if (lane == (lane & 15)) accB[0][0] += 65536.f * 4096.f;
+            float rt48 = logx256;
+            const int back = 0;
+#else
             // ------------- first chain: t = log2 X - 2 log2(e) d,  d^T = D^T mc^T  (mcep.py:210-212) -----
             f16x8 bh, bl;
 #pragma unroll
@@ -687,6 +768,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
 #undef DSA_SB
             DSA_STAMP(9);
             rt48 = __builtin_ldexpf(rt48, back);
+#endif
 
             // ------------- rt and its reflection into this frame's LDS windows -------------
             DSA_STAMP(1);
@@ -720,6 +802,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             DSA_STAMP(2);
 
             // ------------- rows of R + Q, symmetric elimination, back substitution (as v2) -------------
+#if DSA_FUSED_DBG & 2   // reduction build: no system, no elimination
+            float xq[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#else
 #ifdef DSA_MCEP_SOLVE_VALU   // the column-cyclic v_fmac_f32_dpp elimination of rounds 1-2 (A/B builds; bit-identical results)
             float a[colm::TOTAL];
 #else
@@ -749,7 +834,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             float ninvs[M1];
             blk_elim_all(a, gq, ninvs, std::make_integer_sequence<int, M1>{});
             DSA_STAMP(4);
+#if !(DSA_FUSED_DBG & 4)
             blk_backsub_all(a, xq, gq, ninvs, std::make_integer_sequence<int, blk::NG>{});
+#else
+            xq[0] = ninvs[0] + a[0][0];
+#endif
+#endif
 #endif
             xq[6] = keep_if(gq.m[0], xq[6]);
 #pragma unroll
@@ -762,7 +852,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
             __builtin_amdgcn_wave_barrier();
             DSA_STAMP(5);
             DSA_STAMPS_FLUSH;
-            if (hist && f_ok) store_mc_row(hist + ((long)(iter + 1) * F + f) * M1, g, mcv);
+            if (!(DSA_FUSED_DBG & 8) && hist && f_ok) store_mc_row(hist + ((long)(iter + 1) * F + f) * M1, g, mcv);
         }
         DSA_STAMP_T(19);
         if (f_ok) store_mc_row(mc_out + f * M1, g, mcv);

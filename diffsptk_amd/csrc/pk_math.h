@@ -17,25 +17,75 @@ typedef float v2f_u4 __attribute__((ext_vector_type(2), aligned(4)));   // a pai
 __device__ __forceinline__ v2f pk_add(v2f a, v2f b)
 {
     v2f r;
+#if defined(DSA_PK_DBG) && (DSA_PK_DBG & 4)
+    asm("v_add_f32 %0, %1, %2" : "=v"(r.x) : "v"(a.x), "v"(b.x));
+    asm("v_add_f32 %0, %1, %2" : "=v"(r.y) : "v"(a.y), "v"(b.y));
+#else
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+#endif
     return r;
 }
 __device__ __forceinline__ v2f pk_sub(v2f a, v2f b)
 {
     v2f r;
+#if defined(DSA_PK_DBG) && (DSA_PK_DBG & 4)
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r.x) : "v"(a.x), "v"(b.x));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r.y) : "v"(a.y), "v"(b.y));
+#else
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+#endif
     return r;
 }
+// DSA_PK_DBG (reduction builds of tools/hazard/, never the product): 1 the +-i rotations on scalar instructions, 2 the scalar-register
+// twiddle products on scalar instructions, 4 plain packed add / sub on scalar instructions, 8 / 16 two wait states before / after
+// every +-i rotation, 32 the rotations as a plain packed add of a half-swapped copy (v_pk_mov-free: two v_mov), 64 volatile
+#ifndef DSA_PK_DBG
+#define DSA_PK_DBG 0
+#endif
+#if DSA_PK_DBG & 8
+#define DSA_PK_ROT_PRE "s_nop 1\n\t"
+#else
+#define DSA_PK_ROT_PRE ""
+#endif
+#if DSA_PK_DBG & 16
+#define DSA_PK_ROT_POST "\n\ts_nop 1"
+#else
+#define DSA_PK_ROT_POST ""
+#endif
 __device__ __forceinline__ v2f pk_add_negi(v2f a, v2f b)   // a - i b = (a.re + b.im, a.im - b.re)
 {
     v2f r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+#if DSA_PK_DBG & 1
+    float rx, ry;
+    asm("v_add_f32 %0, %1, %2" : "=v"(rx) : "v"(a.x), "v"(b.y));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(ry) : "v"(a.y), "v"(b.x));
+    r = v2f{rx, ry};
+#elif DSA_PK_DBG & 32
+    v2f bs;
+    asm("v_mov_b32 %0, %1" : "=v"(bs.x) : "v"(b.y));
+    asm("v_mov_b32 %0, %1" : "=v"(bs.y) : "v"(b.x));
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(bs));
+#else
+    asm(DSA_PK_ROT_PRE "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" DSA_PK_ROT_POST : "=v"(r) : "v"(a), "v"(b));
+#endif
     return r;
 }
 __device__ __forceinline__ v2f pk_add_posi(v2f a, v2f b)   // a + i b = (a.re - b.im, a.im + b.re)
 {
     v2f r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+#if DSA_PK_DBG & 1
+    float rx, ry;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(rx) : "v"(a.x), "v"(b.y));
+    asm("v_add_f32 %0, %1, %2" : "=v"(ry) : "v"(a.y), "v"(b.x));
+    r = v2f{rx, ry};
+#elif DSA_PK_DBG & 32
+    v2f bs;
+    asm("v_mov_b32 %0, %1" : "=v"(bs.x) : "v"(b.y));
+    asm("v_mov_b32 %0, %1" : "=v"(bs.y) : "v"(b.x));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(bs));
+#else
+    asm(DSA_PK_ROT_PRE "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" DSA_PK_ROT_POST : "=v"(r) : "v"(a), "v"(b));
+#endif
     return r;
 }
 __device__ __forceinline__ v2f pk_add_conj(v2f a, v2f b)   // a + conj(b) = (a.re + b.re, a.im - b.im)
@@ -86,6 +136,13 @@ __device__ __forceinline__ v2f pk_cmul(v2f a, v2f t)
 __device__ __forceinline__ v2f pk_cmul_s(v2f a, v2f t)
 {
     v2f t1, r;
+#if DSA_PK_DBG & 2
+    asm("v_mul_f32 %0, %2, %1" : "=v"(t1.x) : "v"(a.x), "s"(t.x));
+    asm("v_mul_f32 %0, %2, %1" : "=v"(t1.y) : "v"(a.y), "s"(t.x));
+    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(r.x) : "v"(a.y), "s"(t.y), "v"(t1.x));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r.y) : "v"(a.x), "s"(t.y), "v"(t1.y));
+    return r;
+#endif
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t1) : "v"(a), "s"(t));
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(t), "v"(t1));
     return r;

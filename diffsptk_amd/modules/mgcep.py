@@ -134,10 +134,16 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
         if self.gamma != -1:
             if b is None:
                 b = torch.cat((b0, b1), dim=-1)
+            if b0 is None:
+                b0 = b[..., :1]        # mgcep.py:240-249: with n_iter = 0 the gain of the gamma = -1 step is what is returned
             b = _Gnorm._forward(self.mc2b(self.gc2gc(self.b2mc(_Ignorm._forward(b, gamma=-1)))), gamma=self.gamma)   # b2b, :120-137
-            b1 = b[..., 1:]
+            b1 = b[..., 1:]            # mgcep.py:244: only b1 of b2b's output is kept
+            b = None
             for it in range(self.n_iter):
-                b0, b1, b = newton(self.gamma, b1, need_gain=it == self.n_iter - 1)
+                last = it == self.n_iter - 1
+                b0_it, b1, b_it = newton(self.gamma, b1, need_gain=last)
+                if last:
+                    b0, b = b0_it, b_it
         if b is None:
             b = torch.cat((b0, b1), dim=-1)
         return self.b2mc(_Ignorm._forward(b, gamma=self.gamma))                                                       # b2mc, :139-144

@@ -140,6 +140,28 @@ def test_mgcep_reference_grid(golden, gamma, n_iter):
     assert np.abs(host(X.grad) - ref).max() < 1e-6 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("M,alpha,gamma", [(4, 0.5, -0.3), (6, 0.42, -0.5), (4, 0.5, -1.0)])
+@pytest.mark.parametrize("n_iter", [0, 1])
+def test_mgcep_zero_iterations_keeps_the_gain_of_the_first_step(golden, M, alpha, gamma, n_iter):
+    """mgcep.py:240-249 of the reference: with n_iter = 0 (the reference default) and gamma not in {-1, 0} the zeroth coefficient is
+    the gain of the gamma = -1 Newton step, only b1 comes from b2b.  A small order with a strong alpha makes the difference 1.5e-3
+    (the reference's own grid, M = 8 / alpha = 0.1, hides it at 7.6e-11).  Both the path without a gradient (the gain and the
+    joining as one launch) and the differentiable path, outputs and gradients (tests/golden/make_golden_r5.py)."""
+    g = golden("r5")
+    ref = g[f"mgcep0_{M}_{alpha}_{gamma}_{n_iter}"]
+    for dt, tol in ((torch.float64, F64), (torch.float32, dict(rtol=2e-4, atol=2e-5))):
+        m = dsp.MelGeneralizedCepstralAnalysis(fft_length=32, cep_order=M, alpha=alpha, gamma=gamma, n_iter=n_iter, dtype=dt, device=DEV)
+        with torch.no_grad():
+            close(host(m(dev(g["mgcep0_X"], dt))), ref, **tol)
+        X = dev(g["mgcep0_X"], dt).requires_grad_(True)
+        y = m(X)
+        close(host(y), ref, **tol)
+        if dt == torch.float64:
+            (y * torch.linspace(-1, 1, M + 1, dtype=dt, device=DEV)).sum().backward()
+            gref = g[f"mgcep0_grad_{M}_{alpha}_{gamma}_{n_iter}"]
+            assert np.abs(host(X.grad) - gref).max() < 1e-6 * np.abs(gref).max()
+
+
 def test_mgcep_speech_512_and_gamma0_route(golden):
     g = golden("synth")
     X = dev(g["mgcep512_X"])
