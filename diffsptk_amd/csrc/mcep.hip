@@ -111,7 +111,7 @@ static bool matmul_rows_lds_launch(const void* c, int64_t F, int Lin, const void
                                    hipStream_t st)
 {
     const size_t lds = sizeof(T) * ((size_t)Lin * Lout + (size_t)kMrRows * (Lin + 1));
-    if (lds > 48 * 1024 || F < 4 * kMrRows) return false;
+    if (lds > 48 * 1024) return false;   // (the geometry alone decides: a row's result must not depend on how many rows share the call)
     long blocks = (long)((F + kMrRows - 1) / kMrRows);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL((matmul_rows_lds_kernel<T, TRANS>), dim3((unsigned)blocks), dim3(256), lds, st, (const T*)c, (long)F,
@@ -363,7 +363,8 @@ DSA_EXPORT int dsa_freqt_fwd(const void* c, int64_t F, int32_t L1, const void* A
         const char* e = getenv("DSA_FREQT_GENERIC");
         return e && atoi(e) != 0;
     }();
-    if (dtype == DSA_F32 && L1 > 48 && L1 <= 320 && L2 <= 192 && F >= 1024 && !no_mfma) {
+    // (chosen from the geometry alone: a row's result must not depend on how many rows share the call)
+    if (dtype == DSA_F32 && L1 > 48 && L1 <= 320 && L2 <= 192 && !no_mfma) {
         for (int c0 = 0; c0 < L2; c0 += 48) {
             const int cs = L2 - c0 < 48 ? L2 - c0 : 48;
             const int rc = fbank_mfma_launch_ex(c, F, L1, (const float*)A + c0, cs, L2, 1.0, 0.0, 1, 4, 1.0, (float*)out + c0, nullptr,

@@ -433,8 +433,8 @@ constexpr int kTq = 136;   // floats per system in LDS: q window [0, 52) | mirro
 // `r` rows are r_stride floats apart and start r_off floats in (the Newton step of mgcep hands over its (F, 25) vector with
 // the right-hand side in columns 1 .. 24); `add` (or NULL): g = add + solution (the step's update b <- b + solve(..)).
 __global__ __launch_bounds__(256) void thsolve_quad24_kernel(const float* __restrict__ p, const float* __restrict__ q,
-                                                             const float* __restrict__ r, long F, float* __restrict__ g,
-                                                             int r_stride, int r_off, const float* __restrict__ add)
+                                                             const float* __restrict__ r, long F, float* g,
+                                                             int r_stride, int r_off, const float* add)   // (g may be add)
 {
     using namespace mm;
     __shared__ __attribute__((aligned(16))) float lds[4 * 16 * kTq + 64];

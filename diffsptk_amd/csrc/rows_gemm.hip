@@ -290,7 +290,7 @@ static void rows_gemm_launch_t(const void* c, int64_t F, int K, const void* A, i
 // A operand of the second product as it stands, no LDS tile: 73.2 -> 76.2 us per workgroup; the exp then waits on the end of the
 // S chain instead of on an LDS read that the first matrix instructions of the product cover.)  Same staging discipline (loads a chunk ahead in registers, operands of step t + 1 read during step t).
 
-// exp(x) in five instructions, about 1.5 ulp for results in the normal range: x log2(e) = t + r with t the rounded product and r its
+// exp(x) in five instructions, about 2 ulp for results in the normal range: x log2(e) = t + r with t the rounded product and r its
 // exact remainder plus the low part of log2(e), exp2(t) on the transcendental unit (v_exp_f32, 1 ulp), times (1 + r ln 2).  No
 // scaling for results below 2^-126 (flushed): the operand here is exp(log X - 2 log of the model spectrum), a ratio near 1.  The
 // library routine's range handling tripled the count, and on this kernel every vector instruction is paid in full: the float32
@@ -301,7 +301,9 @@ __device__ __forceinline__ float exp_ratio(float x)
     float r = __builtin_fmaf(x, 0x1.715476p+0f, -t);
     r = __builtin_fmaf(x, 0x1.4ae0bep-26f, r);
     const float e = __builtin_amdgcn_exp2f(t);
-    return __builtin_fmaf(e, r * 0x1.62e430p-1f, e);
+    // e (1 + r ln 2) as a product: an overflowed e stays +inf (e + e c would be inf - inf = NaN for c < 0, where expf gives inf)
+    // and an underflowed one stays 0 -- the same five instructions; 1 + r ln 2 rounds the correction to half an ulp (2 ulp in all)
+    return e * __builtin_fmaf(r, 0x1.62e430p-1f, 1.0f);
 }
 
 #ifndef RG_ABL

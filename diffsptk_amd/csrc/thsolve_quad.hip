@@ -124,7 +124,7 @@ __device__ __forceinline__ void backsub_all(const f32x4 (&a)[Blk<NG>::N], float 
 template <int NG, int NMIN>
 __global__ __launch_bounds__(256, 1) void thsolve_quadn_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ q, int ldq,
                                                                const float* __restrict__ r, int ldr, const float* __restrict__ sub,
-                                                               const float* __restrict__ add, long F, int n, float* __restrict__ g)
+                                                               const float* add, long F, int n, float* g)   // (g may be add: dsa_mcep_newton_update in place)
 {
     using B = Blk<NG>;
     constexpr int CN = 4 * NG - 1;              // the right-hand side's column = the largest order
@@ -403,7 +403,7 @@ __device__ __forceinline__ void oct_backsub_all(const f32x4 (&a)[Oct<NG>::N], fl
 template <int NG, int NMIN>
 __global__ __launch_bounds__(256, 2) void thsolve_octn_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ q, int ldq,
                                                               const float* __restrict__ r, int ldr, const float* __restrict__ sub,
-                                                              const float* __restrict__ add, long F, int n, float* __restrict__ g)
+                                                              const float* add, long F, int n, float* g)   // (g may be add: dsa_mcep_newton_update in place)
 {
     using O = Oct<NG>;
     constexpr int NCP = O::NCP;

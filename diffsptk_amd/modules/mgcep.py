@@ -128,7 +128,7 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
             return torch.sqrt(epsilon(gamma, r, b_eps)).unsqueeze(-1), b1, None
 
         # without a gradient the gain and the joining of (b0, b1) are one launch (dsa_mgcep_gain) instead of six stock ones
-        fused_gain = x.is_cuda and x.dtype in (torch.float32, torch.float64)
+        fused_gain = x.is_cuda and x.dtype in (torch.float32, torch.float64) and M >= 1   # (dsa_mgcep_gain wants cep_order >= 1)
         b1 = torch.zeros(*x.shape[:-1], M, device=x.device, dtype=x.dtype)
         b0, b1, b = newton(-1, b1)
         if self.gamma != -1:

@@ -323,12 +323,13 @@ def rows_gemm(c, A, flags=0, aux=None):
     return out
 
 
-def _row_product_is_long(F, Lin, Lout, elt) -> bool:
+def _row_product_is_long(Lin, Lout, elt) -> bool:
     """True where the library's row-product entry (csrc/mcep.hip:dsa_freqt_fwd / _bwd) would fall to its one-workgroup-per-row
     kernel: the matrix does not fit the LDS-resident kernel's 48 KB and the shape is outside the 257-bin matrix-core kernel's
-    range -- the 1025-bin products of the 48 kHz set-ups.  Those run on the general matrix-core row product (rows_gemm); the
-    choice depends on the geometry and a minimum batch only, never on anything that changes from call to call."""
-    if os.environ.get("DSA_FREQT_GEMM", "1") == "0" or F < 256:
+    range -- the 1025-bin products of the 48 kHz set-ups.  Those run on the general matrix-core row product (rows_gemm).  The
+    choice is a function of the GEOMETRY only (never of the number of rows): a frame's result does not depend on how many frames
+    share its batch (tests/test_gpu_parity.py::test_row_products_are_batch_invariant)."""
+    if os.environ.get("DSA_FREQT_GEMM", "1") == "0":
         return False
     lds_fits = elt * (Lin * Lout + 64 * (Lin + 1)) <= 48 * 1024
     return not lds_fits and max(Lin, Lout) >= 512
@@ -345,8 +346,8 @@ class MatmulRowsFn(torch.autograd.Function):
         L1, L2 = Ac.shape
         F = cc.numel() // L1
         ctx.save_for_backward(Ac)
-        mfma = cc.dtype == torch.float32 and 48 < L1 <= 320 and L2 <= 192 and F >= 1024
-        if not mfma and cc.dtype == torch.float32 and _row_product_is_long(F, L1, L2, cc.element_size()):
+        mfma = cc.dtype == torch.float32 and 48 < L1 <= 320 and L2 <= 192   # (the library picks its 257-bin matrix-core kernel)
+        if not mfma and cc.dtype == torch.float32 and _row_product_is_long(L1, L2, cc.element_size()):
             return rows_gemm(cc, Ac)
         out = torch.empty(*cc.shape[:-1], L2, device=c.device, dtype=c.dtype)
         with torch.cuda.device(c.device):
@@ -360,7 +361,7 @@ class MatmulRowsFn(torch.autograd.Function):
         g = g.contiguous()
         L1, L2 = Ac.shape
         F = g.numel() // L2
-        if g.dtype == torch.float32 and _row_product_is_long(F, L2, L1, g.element_size()):
+        if g.dtype == torch.float32 and _row_product_is_long(L2, L1, g.element_size()):
             return rows_gemm(g, Ac, ROWS_TRANS), None
         gc = torch.empty(*g.shape[:-1], L1, device=g.device, dtype=g.dtype)
         with torch.cuda.device(g.device):
@@ -831,9 +832,11 @@ class MfccFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------- mcep
-def _mcep_composed_applies(Xc, M, F) -> bool:
-    """Geometries without a tuned kernel (48 kHz set-ups: fft_length 1024 / 2048, orders 34 .. 60)."""
-    return (Xc.dtype == torch.float32 and M + 1 <= 64 and M >= 1 and F >= 256
+def _mcep_composed_applies(Xc, M) -> bool:
+    """Geometries without a tuned kernel (48 kHz set-ups: fft_length 1024 / 2048, orders 34 .. 60).  A function of the geometry
+    and the dtype only -- never of the number of frames: a frame's mel-cepstrum does not depend on how many frames share its
+    batch.  Short spectra (fft_length < 256: the reference's own test grids) keep the generic kernel pair."""
+    return (Xc.dtype == torch.float32 and M + 1 <= 64 and M >= 1 and Xc.size(-1) >= 129
             and os.environ.get("DSA_MCEP_COMPOSED", "1") != "0")   # float64 keeps the generic kernel pair
 
 
@@ -841,12 +844,12 @@ def mcep_composed(X, G, D, E, av, fft_length, M, n_iter, algo):
     """The mel-cepstral analysis for a geometry without a tuned kernel, WITH a graph when one is wanted: the whole-batch
     launches of _mcep_composed_fwd are differentiable operations (GEMMs, element-wise, ThSolveFn), so autograd runs the
     backward as whole-batch launches too (the generic kernel pair keeps one workgroup per frame in both directions).
-    None: not applicable (a tuned kernel exists, the generic family was asked for, or the batch is tiny)."""
+    None: not applicable (a tuned kernel exists, the generic family was asked for, or the spectrum is short)."""
     if algo == _lib.ALGO_GENERIC or X.device.type != "cuda":
         return None
     K = fft_length // 2 + 1
     F = X.numel() // K
-    if not _mcep_composed_applies(X, M, F) or mcep_images(G, D, E, fft_length, M) is not None:
+    if not _mcep_composed_applies(X, M) or mcep_images(G, D, E, fft_length, M) is not None:
         return None
     _require_device(X, G, D, E, av)
     _same_dtype(X, G, D, E, av)
@@ -1058,7 +1061,7 @@ class McepFn(torch.autograd.Function):
         need_hist = ctx.needs_input_grad[0]
         hist = torch.empty(n_iter + 1, F, M + 1, device=X.device, dtype=X.dtype) if need_hist else None
         images = mcep_images(G, D, E, fft_length, M) if algo != _lib.ALGO_GENERIC else None
-        if images is None and not need_hist and algo != _lib.ALGO_GENERIC and _mcep_composed_applies(Xc, M, F):
+        if images is None and not need_hist and algo != _lib.ALGO_GENERIC and _mcep_composed_applies(Xc, M):
             return _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter)
         # the tile queue's counters: a per-(device, stream) scratch that the kernel leaves zeroed (no fill launch per call)
         scratch = None

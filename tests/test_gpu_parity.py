@@ -489,16 +489,19 @@ def test_mcep_tuned_dynamic_range(golden):
         close(y, ref, 1e-4, 1e-5)   # the one looser bound: c0 reaches +-60 at levels of 1e+-24, tilted frames lose bits
 
 
-def test_mcep_extreme_alpha_keeps_generic_kernel(golden):
+def test_mcep_extreme_alpha_keeps_off_the_tuned_kernel(golden):
     """|alpha| > 0.95 is outside the range the binary16 operand images of the tuned kernel are scaled
-    for: the module routes it to the generic kernel, and the result still matches float64."""
+    for: the module routes it to the float32 whole-batch composition (generic kernel when asked), and the
+    result still matches float64."""
     g = golden("datawav")
     X = torch.from_numpy(g["stft_power_f32"]).reshape(-1, 257)[:64].to(DEV)
     m32 = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.97, n_iter=2, device=DEV)
     y = host(m32(X))
-    assert _lib.last_kernel().startswith("mcep_generic_fwd")
+    assert not _lib.last_kernel().startswith("mcep_mfma")
     m64 = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.97, n_iter=2, device=DEV, dtype=torch.float64)
     close(y, host(m64(X.double())), 2e-3, 2e-3)   # alpha = 0.97 is ill-conditioned in float32 (reference alike)
+    close(host(ops.McepFn.apply(X, m32.G, m32.D, m32.E, m32.alpha_vector, 512, 24, 2, _lib.ALGO_GENERIC)), host(m64(X.double())), 2e-3, 2e-3)
+    assert _lib.last_kernel().startswith("mcep_generic_fwd")
     m = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.9, n_iter=2, device=DEV)
     m(X)
     assert _lib.last_kernel().startswith("mcep_mfma_fwd")
@@ -750,7 +753,7 @@ def test_fbank_mfcc_golden_forward_backward(golden, name, dt):
     mf = dsp.MFCC(fft_length=512, mfcc_order=12, n_channel=40, sample_rate=16000, lifter=22, out_format="ycE", device=DEV, dtype=dt)
     Xg = X.clone().requires_grad_(True)
     out = mf(Xg)
-    assert _lib.last_kernel() == ("fbank_dct_mfma_fwd" if dt == torch.float32 else "freqt_fwd")   # float32: one fused launch
+    assert _lib.last_kernel() == ("fbank_dct_mfma_fwd" if dt == torch.float32 else "freqt_lds_fwd")   # float32: one fused launch
     close(host(out), g[f"mfcc_ycE_{name}"], rt, 10 * at)
     (out * torch.linspace(-1, 1, out.size(-1), dtype=dt, device=DEV)).sum().backward()
     ref = g["grad_mfcc_wsum_f64"]
@@ -837,20 +840,21 @@ def test_fbank_matrix_core_forward_matches_float64(K, C, Fr, use_power, dense, m
 @pytest.mark.parametrize("L1,L2,Fr", [(40, 13, 1000), (25, 49, 257), (13, 40, 4096), (257, 8, 300), (40, 13, 100)])
 def test_small_matrix_rows_kernel(L1, L2, Fr):
     """c @ A for the small matrices of DCT / freqt / lifter (64-row tiles, A in LDS) and its transpose product
-    in the backward, float32 and float64, ragged row counts; short inputs keep the one-workgroup-per-row kernel, large
-    products whose operands do not fit LDS go to the vendor GEMM (ops._row_product_is_plain_gemm)."""
+    in the backward, float32 and float64, ragged row counts; products whose matrix + tile do not fit LDS keep the
+    one-workgroup-per-row kernel (or the matrix-core kernels where their geometry applies)."""
     gen = torch.Generator().manual_seed(L1 * 7 + L2)
     c = torch.randn(Fr, L1, dtype=torch.float64, generator=gen)
     A = torch.randn(L1, L2, dtype=torch.float64, generator=gen)
     g = torch.randn(Fr, L2, dtype=torch.float64, generator=gen)
     for dt, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
         cd = c.to(DEV, dt).requires_grad_(True)
-        ops.MatmulRowsFn.apply(c[:3].to(DEV, dt), A.to(DEV, dt))       # (a tiny call first: last_kernel() = "freqt_fwd")
-        out = ops.MatmulRowsFn.apply(cd, A.to(DEV, dt))
         fits = dt.itemsize * (L1 * L2 + 64 * (L1 + 1)) <= 48 * 1024   # matrix + a 64-row tile in LDS
-        # (rows of >= 512 values whose matrix + tile do not fit LDS are a plain GEMM for the vendor library; these shapes
-        # keep the one-workgroup-per-row kernel when they do not fit)
-        assert _lib.last_kernel() == ("freqt_lds_fwd" if Fr >= 256 and fits else "freqt_fwd")
+        mfma = dt == torch.float32 and 48 < L1 <= 320 and L2 <= 192   # the 257-bin float32 matrix-core kernel of csrc/fbank.hip
+        want = "freqt_mfma_fwd" if mfma else ("freqt_lds_fwd" if fits else "freqt_fwd")
+        ops.MatmulRowsFn.apply(c[:3].to(DEV, dt), A.to(DEV, dt))       # the kernel is chosen from the geometry: 3 rows or 4096
+        assert _lib.last_kernel() == want
+        out = ops.MatmulRowsFn.apply(cd, A.to(DEV, dt))
+        assert _lib.last_kernel() == want
         out.backward(g.to(DEV, dt))
         ref, gref = (c @ A).numpy(), (g @ A.T).numpy()
         assert np.abs(host(out) - ref).max() <= tol * np.abs(ref).max()
@@ -1083,3 +1087,25 @@ def test_tuned_kernels_are_bitwise_reproducible():
     third = run()
     for name, r, a2, a3 in zip(("stft", "mcep", "fbank", "lpc", "fftcep", "stft complex", "istft", "grad"), ref, again, third):
         assert torch.equal(r, a2) and torch.equal(r, a3), name
+
+
+@pytest.mark.parametrize("L1,L2", [(257, 25), (25, 257), (1025, 50), (50, 1025), (257, 49), (40, 13)])
+def test_row_products_are_batch_invariant(L1, L2):
+    """freqt.py:141-143 / mcep.py:286-288 as launches of the library: the kernel -- hence the float32 rounding -- is chosen from
+    (in_order, out_order, dtype) alone, so a row's product is bit-identical whether 1, 255, 256, 1023, 1024 or 4096 rows share
+    the call (round-4 review: the choice used to flip at 256 / 1024 rows); forward and the gradient."""
+    gen = torch.Generator().manual_seed(L1 * 7 + L2)
+    A = (torch.randn(L1, L2, generator=gen) / L1 ** 0.5).to(DEV)
+    c = torch.randn(4096, L1, generator=gen).to(DEV)
+    gy = torch.randn(4096, L2, generator=gen).to(DEV)
+    ref_y = ref_g = None
+    for F in (4096, 1, 255, 256, 1023, 1024):
+        cF = c[:F].clone().requires_grad_(True)
+        y = ops.MatmulRowsFn.apply(cF, A)
+        (y * gy[:F]).sum().backward()
+        if ref_y is None:
+            ref_y, ref_g = y.detach().clone(), cF.grad.clone()
+            ref64 = c.double() @ A.double()
+            assert float((ref_y.double() - ref64).abs().max()) < 2e-6 * float(ref64.abs().max()) + 1e-6
+        assert torch.equal(y.detach(), ref_y[:F]), F
+        assert torch.equal(cF.grad, ref_g[:F]), F

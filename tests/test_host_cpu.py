@@ -398,16 +398,17 @@ def test_round3_host_tables_and_dispatch_rules():
     want = np.where(row <= M, m["Cr"][np.minimum(row, M), 16 * 3 + 4 * lg + 2], 0.0).astype(np.float32)
     np.testing.assert_allclose(a3[0, 1, 2], want, rtol=0, atol=0)
     # dispatch rules
-    assert ops._row_product_is_long(12800, 50, 1025, 4) and ops._row_product_is_long(12800, 1025, 99, 4)
-    assert not ops._row_product_is_long(51200, 25, 200, 4)          # fits LDS
-    assert not ops._row_product_is_long(51200, 200, 25, 4)          # short rows keep the library's kernel
-    assert not ops._row_product_is_long(100, 50, 1025, 4)           # tiny batch
+    # (geometry only: the number of rows is not an argument -- a row's result must not depend on the batch it arrives in)
+    assert ops._row_product_is_long(50, 1025, 4) and ops._row_product_is_long(1025, 99, 4)
+    assert not ops._row_product_is_long(25, 200, 4)          # fits LDS
+    assert not ops._row_product_is_long(200, 25, 4)          # short rows keep the library's kernel
     x, b = torch.zeros(2, 160), torch.zeros(2, 2, 40)
     assert not ops.zerodf_taylor_shapes_ok(x, b, 80)                       # host tensors never take the fused launches
-    x32 = torch.zeros(1)
-    assert ops._mcep_composed_applies(x32, 49, 12800) and not ops._mcep_composed_applies(x32, 64, 12800)
-    assert not ops._mcep_composed_applies(x32, 49, 100)
-    assert not ops._mcep_composed_applies(x32.double(), 49, 12800)          # float64 keeps the generic kernel pair
+    x32 = torch.zeros(2, 1025)
+    assert ops._mcep_composed_applies(x32, 49) and not ops._mcep_composed_applies(x32, 64)
+    assert ops._mcep_composed_applies(x32[:1], 49)                           # one frame or 12 800: the same path
+    assert not ops._mcep_composed_applies(torch.zeros(2, 17), 8)             # short spectra (the reference's test grids): generic pair
+    assert not ops._mcep_composed_applies(x32.double(), 49)                  # float64 keeps the generic kernel pair
 
 
 def test_mlsa_learnable_constructs_on_the_host():
