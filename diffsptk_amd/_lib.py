@@ -32,6 +32,7 @@ F32, F64 = 0, 1
 SCRATCH_BYTES = 64   # DSA_SCRATCH_BYTES
 FBANK_PLAN_FLOATS = 2048   # DSA_FBANK_PLAN_FLOATS
 ERR_UNSUPPORTED = -2       # DSA_ERR_UNSUPPORTED
+LPC_EXACT_LAGSUMS = 0x200  # DSA_LPC_EXACT_LAGSUMS
 ALGO_AUTO, ALGO_GENERIC, ALGO_TUNED = 0, 1, 2
 ALGO_SCRATCH_IS_CLEAN = 0x100   # DSA_ALGO_SCRATCH_IS_CLEAN
 ALGO_SCRATCH_HAS_WORKSPACE = 0x200   # DSA_ALGO_SCRATCH_HAS_WORKSPACE
@@ -159,6 +160,7 @@ SIGNATURES = {
     "dsa_lpc_fwd": (C.c_int, [_P, _L, _I, _I, _D, _I, _P, _P, _P]),
     "dsa_lpc_bwd": (C.c_int, [_P, _P, _P, _L, _I, _I, _D, _I, _P, _P]),
     "dsa_frame_window_lpc_fwd": (C.c_int, [_P, _L, _L, _I, _I, _P, _I, _I, _I, _D, _I, _P, _P, _P]),
+    "dsa_frame_window_lpc_bwd": (C.c_int, [_P, _P, _L, _L, _I, _I, _P, _I, _I, _I, _D, _I, _P, _P]),
 }
 
 

@@ -965,6 +965,482 @@ __global__ __launch_bounds__(64, 1) void lpc24_bwd_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: backward of the fused Frame -> Window -> LPC launch in ONE launch (the adjoint of frame.py:120-141, window.py:185-193,
+// acorr.py:110-120 and levdur.py:113-127 composed; README.md:198-201 of the reference with a gradient).  The module chain ran it as
+// lpc24_bwd (0.71 ms per 204 800 frames: 1875 v_fma_f64 per four frames at one wave per SIMD behind synchronous stagings) + window
+// and frame backward over two materialised (F, 400) tensors.  Here a wave owns a run of Hc hops of one utterance -- the output
+// samples [h0 P, (h0 + Hc) P) -- and every frame that touches them (Hc + 4..5 frames at L = 400, P = 80: the halo is recomputed,
+// nothing is exchanged between waves, and every sample's sum runs over its frames in increasing order whatever the partition:
+// bit-identical for every Hc):
+//   A. lag sums of every frame as the forward kernel forms them (banded Gram product of binary16 splits on the matrix pipe, the
+//      16 entries of a lag added in float64) -> rbuf;
+//   B. one frame per LANE, float64, fully unrolled: the Levinson recursion re-run with a general right-hand side riding along
+//      (as lpc24_bwd_kernel) -> the cotangent of the lag sums rbar[0..24], left in the frame's row as float32 scaled by a power of
+//      two (its largest entry in [2^13, 2^14));
+//   C. the adjoint of the lag sums  xwbar[l] = sum_m rbar[m] (xw[l + m] + xw[l - m])  -- a 49-tap symmetric filter per frame -- as a
+//      banded matrix product on the binary16 matrix pipe: with u_c the c-th block of 16 windowed samples and E[q] = ext[q - 32]
+//      (ext[m] = rbar[|m|], doubled at 0), block c of xwbar is  sum_{s=-2..2} T_s u_{c+s},  (T_s)[i][j] = E[16 s + 32 + j - i]:
+//      A operand (16 x 96) = the Toeplitz band, row i = 8 consecutive taps from E[k - i] (a 16-byte LDS read at a 2-byte
+//      aligned address: gfx950 takes unaligned DS accesses), B operand (96 x 16) = column c = samples 16 c - 32 + k (aligned),
+//      3 k-steps x 2 column tiles x 3 split terms = 18 v_mfma_f32_16x16x32_f16 per frame instead of 1250 v_fma_f64 per 25
+//      samples and lane.  The result layout gives lane (c, g) the four consecutive samples 16 c + 4 g .. + 3: times the window,
+//      scale undone, added into the wave's overlap-add stretch in LDS (one 16-byte read-modify-write per tile and lane; frames in
+//      increasing order); the own range of the stretch goes to gx as whole rows at the end.
+// dynamic LDS per workgroup (one wave): rbuf[nfr_max][26] doubles | stretch[(nfr_max - 1) P + 512] floats |
+//   area shared by phase A (scatter rows dm[2][26][20] floats) and phase C (XH[640] XL[640] EH[128] EL[128] binary16)
+typedef _Float16 lp_h8u __attribute__((ext_vector_type(8), aligned(2)));
+typedef float lp_f4u __attribute__((ext_vector_type(4), aligned(4)));
+constexpr int kLbRow = 26;          // doubles per frame row of rbuf: 25 lag sums (then: 25 scaled taps as floats, their shift) | the samples' shift
+constexpr int kLbRing = 1024;       // floats of the overlap-add ring (frame_length + frame_period <= 1024)
+constexpr int kLbOps = 2 * 640 + 2 * 128;   // binary16 values of one operand set of phase C
+constexpr int kLbAreaBytes = 2 * kLbOps * 2 > 2 * 26 * 20 * 4 ? 2 * kLbOps * 2 : 2 * 26 * 20 * 4;
+__host__ __device__ inline long lb_floordiv(long a, long b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+template <int LC>
+__global__ __launch_bounds__(64, 2) void frame_window_lpc24_bwd_mfma_kernel(
+    const float* __restrict__ gout, const float* __restrict__ x, long Tlen, long N, int L_rt, int P, int left,
+    const float* __restrict__ w, double eps, float* __restrict__ gx, long total_items, int items_per_utt, int Hc, int nfr_max)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 lp_h8 __attribute__((ext_vector_type(8)));
+    typedef unsigned lp_u4 __attribute__((ext_vector_type(4)));
+    constexpr int DS = 20;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
+    const int L = LC ? LC : L_rt;
+    const int lane = threadIdx.x;
+    double* rbuf = reinterpret_cast<double*>(lb_smem);
+    float* ring = reinterpret_cast<float*>(rbuf + nfr_max * kLbRow);
+    float* dm = ring + kLbRing;
+    // phase C operand arrays, one set per frame of a round (u), over phase A's scatter rows: per set XH | XL [32 zeros | 512 samples |
+    // 96 zeros] and EH | EL (E[q] at q + 16, q in [-16, 112)), set stride kLbOps halves
+    _Float16* XH = reinterpret_cast<_Float16*>(dm);
+    _Float16* XL = XH + 640;
+    _Float16* EH = XL + 640;
+    _Float16* EL = EH + 128;
+    const int j = lane & 15, g = lane >> 4;
+    // ---- per-lane constants ----
+    float wa[8];    // phase A: element e of lane (j, g) is sample 128 g + 16 e + j
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int la = 128 * g + 16 * e + j;
+        wa[e] = la < L ? (w ? w[la] : 1.f) : 0.f;
+    }
+    float wc[8];    // phase C input: samples 8 lane .. 8 lane + 7
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int la = 8 * lane + e;
+        wc[e] = la < L ? (w ? w[la] : 1.f) : 0.f;
+    }
+    float wo[2][4]; // phase C output: samples 16 (16 nt + j) + 4 g + r
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int la = 16 * (16 * nt + j) + 4 * g + r;
+            wo[nt][r] = la < L ? (w ? w[la] : 1.f) : 0.f;
+        }
+    int addr[3][4];
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * g + r, lag = 16 * s_ + j - i;
+            addr[s_][r] = ((lag >= 0 && lag < kLpcM1) ? lag : kLpcM1) * DS + i;
+        }
+
+    for (int q = lane; q < kLbRing / 4; q += 64) reinterpret_cast<f4*>(ring)[q] = f4{0.f, 0.f, 0.f, 0.f};   // (every flush leaves its slots zero)
+    for (long item = blockIdx.x; item < total_items; item += gridDim.x) {
+        const long b = item / items_per_utt;
+        const long h0 = (item - b * items_per_utt) * Hc;
+        const long s0 = h0 * P;
+        long s1 = s0 + (long)Hc * P;
+        if (s1 > Tlen) s1 = Tlen;
+        if (s0 >= s1) continue;
+        long n_lo = lb_floordiv(s0 + left - L, P) + 1;
+        long n_hi = lb_floordiv(s1 - 1 + left, P);
+        if (n_lo < 0) n_lo = 0;
+        if (n_hi > N - 1) n_hi = N - 1;
+        const int nfr = (int)(n_hi - n_lo + 1);       // <= nfr_max (host); may be <= 0 when no frame reaches the range (L < P)
+        const float* xb = x + b * Tlen;
+        __builtin_amdgcn_wave_barrier();
+#ifndef LPB_ABL
+#define LPB_ABL 0   // measurement builds only: 1 no lag sums, 2 no recursion, 4 no filter / overlap-add
+#endif
+        // ================= A: lag sums (the forward kernel's rounds of two frames) =================
+        if (nfr > 0 && !(LPB_ABL & 1)) {
+            constexpr int U = 2;
+            float a[U][8];
+            const int soff = 128 * g + j;
+            auto fetch = [&](int u, int fi) __attribute__((always_inline)) {
+                const long start = (n_lo + fi) * P - left;
+                if (start >= 0 && start + 512 <= Tlen) {
+                    const float* src = xb + start + soff;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[u][e] = src[16 * e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const long si = start + soff + 16 * e;
+                        a[u][e] = (soff + 16 * e < L && si >= 0 && si < Tlen) ? xb[si] : 0.f;
+                    }
+                }
+            };
+            fetch(0, 0);
+            fetch(1, 1 < nfr ? 1 : 0);
+            for (int fi = 0; fi < nfr; fi += U) {
+                float va[U][8];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) va[u][e] = soff + 16 * e < L ? a[u][e] * wa[e] : 0.f;
+                if (fi + U < nfr) {
+                    fetch(0, fi + U);
+                    fetch(1, fi + U + 1 < nfr ? fi + U + 1 : fi + U);
+                }
+                float fmx[U];
+                int sh[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    fmx[u] = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) fmx[u] = __builtin_fmaxf(fmx[u], __builtin_fabsf(va[u][e]));
+                }
+#define DSA_LPC_MAX(CTRL, RM)                                                                                              \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) fmx[u] =                                                                 \
+        __builtin_fmaxf(fmx[u], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(fmx[u]), CTRL, RM, 0xf, false)))
+                DSA_LPC_MAX(0x111, 0xf); DSA_LPC_MAX(0x112, 0xf); DSA_LPC_MAX(0x114, 0xf); DSA_LPC_MAX(0x118, 0xf);
+                DSA_LPC_MAX(0x142, 0xa); DSA_LPC_MAX(0x143, 0xc);
+#undef DSA_LPC_MAX
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float fmax_all = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fmx[u]), 63));
+                    int fe = __builtin_amdgcn_frexp_expf(fmax_all);
+                    fe = fe < -100 ? -100 : (fe > 100 ? 100 : fe);
+                    sh[u] = 14 - fe;
+                }
+                lp_h8 ah[U], al[U], bh[U], bl[U], ch[U], cl[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    lp_u4 hr, lr;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        lp_h2 h, l;
+                        lp_split2(__builtin_ldexpf(va[u][e], sh[u]), __builtin_ldexpf(va[u][e + 1], sh[u]), h, l);
+                        hr[e >> 1] = __builtin_bit_cast(unsigned, h);
+                        lr[e >> 1] = __builtin_bit_cast(unsigned, l);
+                    }
+                    unsigned nh = (unsigned)__builtin_amdgcn_ds_bpermute(4 * ((lane + 16) & 63), (int)hr[0]);
+                    unsigned nl = (unsigned)__builtin_amdgcn_ds_bpermute(4 * ((lane + 16) & 63), (int)lr[0]);
+                    nh = g == 3 ? 0u : nh;
+                    nl = g == 3 ? 0u : nl;
+                    const lp_u4 bhr = {__builtin_amdgcn_alignbit(hr[1], hr[0], 16), __builtin_amdgcn_alignbit(hr[2], hr[1], 16),
+                                       __builtin_amdgcn_alignbit(hr[3], hr[2], 16), __builtin_amdgcn_alignbit(nh, hr[3], 16)};
+                    const lp_u4 blr = {__builtin_amdgcn_alignbit(lr[1], lr[0], 16), __builtin_amdgcn_alignbit(lr[2], lr[1], 16),
+                                       __builtin_amdgcn_alignbit(lr[3], lr[2], 16), __builtin_amdgcn_alignbit(nl, lr[3], 16)};
+                    const lp_u4 chr = {hr[1], hr[2], hr[3], nh}, clr = {lr[1], lr[2], lr[3], nl};
+                    ah[u] = __builtin_bit_cast(lp_h8, hr);
+                    al[u] = __builtin_bit_cast(lp_h8, lr);
+                    bh[u] = __builtin_bit_cast(lp_h8, bhr);
+                    bl[u] = __builtin_bit_cast(lp_h8, blr);
+                    ch[u] = __builtin_bit_cast(lp_h8, chr);
+                    cl[u] = __builtin_bit_cast(lp_h8, clr);
+                }
+                f4 c1[U], c2[U], c3[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) c1[u] = c2[u] = c3[u] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    c1[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], ah[u], c1[u], 0, 0, 0);
+                    c2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], bh[u], c2[u], 0, 0, 0);
+                    c3[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], ch[u], c3[u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    c1[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], al[u], c1[u], 0, 0, 0);
+                    c2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bl[u], c2[u], 0, 0, 0);
+                    c3[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], cl[u], c3[u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    c1[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], ah[u], c1[u], 0, 0, 0);
+                    c2[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bh[u], c2[u], 0, 0, 0);
+                    c3[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], ch[u], c3[u], 0, 0, 0);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dm[u * 26 * DS + addr[0][r]] = c1[u][r];
+                        dm[u * 26 * DS + addr[1][r]] = c2[u][r];
+                        dm[u * 26 * DS + addr[2][r]] = c3[u][r];
+                    }
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const int m_ = lane & 31, h_ = lane >> 5;
+                    double sm[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const f4* row = reinterpret_cast<const f4*>(dm + u * 26 * DS + (m_ < kLpcM1 ? m_ : kLpcM1) * DS + 8 * h_);
+                        const f4 q0 = row[0], q1 = row[1];
+                        sm[u] = ((double)q0[0] + (double)q0[1]) + ((double)q0[2] + (double)q0[3]);
+                        sm[u] += ((double)q1[0] + (double)q1[1]) + ((double)q1[2] + (double)q1[3]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int lo = __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), __double2loint(sm[u]));
+                        const int hi = __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), __double2hiint(sm[u]));
+                        const double other = __hiloint2double(hi, lo);
+                        const double tot = h_ == 0 ? sm[u] + other : other + sm[u];
+                        if (lane < kLpcM1 && fi + u < nfr) rbuf[(fi + u) * kLbRow + lane] = ldexp(tot, -2 * sh[u]);
+                        if (lane == kLpcM1 && fi + u < nfr) rbuf[(fi + u) * kLbRow + kLpcM1] = (double)sh[u];   // the samples' shift, for phase C
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ================= B: adjoint of the Yule-Walker solve, one frame per lane (as lpc24_bwd_kernel) =================
+        // (the lag sums stay in the frame's LDS row and are read where the recursion wants them: a, u in registers are 100 of them
+        //  instead of 150, and three waves share a SIMD)
+        if (lane < nfr && !(LPB_ABL & 2)) {
+            double a[kLpcM1], u[kLpcM1];
+            double* row = rbuf + (size_t)lane * kLbRow;
+            const float* go = gout + (b * N + n_lo + lane) * (long)kLpcM1;
+#pragma unroll
+            for (int m = 0; m < kLpcM1; ++m) {
+                a[m] = 0.0;
+                u[m] = 0.0;
+            }
+            const double r0 = row[0];
+            double Ecur = r0 + eps;
+#pragma unroll
+            for (int m = 1; m < kLpcM1; ++m) {
+                double d = (double)go[m];
+                double s = row[m];
+#pragma unroll
+                for (int q = 1; q < m; ++q) {
+                    const double rv = row[m - q];
+                    d = __builtin_fma(-rv, u[q], d);
+                    s = __builtin_fma(a[q], rv, s);
+                }
+                const double mu = d / Ecur;
+#pragma unroll
+                for (int q = 1; q < m; ++q) u[q] = __builtin_fma(mu, a[m - q], u[q]);
+                u[m] = mu;
+                const double kk = -s / Ecur;
+#pragma unroll
+                for (int q = 1; 2 * q <= m; ++q) {
+                    const double aq = a[q], amq = a[m - q];
+                    a[q] = __builtin_fma(kk, amq, aq);
+                    if (q != m - q) a[m - q] = __builtin_fma(kk, aq, amq);
+                }
+                a[m] = kk;
+                Ecur *= (1.0 - kk * kk);
+            }
+            double gsum = r0;
+#pragma unroll
+            for (int m = 1; m < kLpcM1; ++m) gsum = __builtin_fma(row[m], a[m], gsum);
+            const double sbar = (double)go[0] / (2.0 * sqrt(gsum));
+#pragma unroll
+            for (int m = 1; m < kLpcM1; ++m) u[m] = __builtin_fma(-sbar, a[m], u[m]);  // v
+            // the taps ext[m] = rbar[m] (doubled at 0: the lag-0 sum's adjoint is 2 rbar[0] xw[l]) over the dead lag sums, as float64
+            double mx = 0.0;
+#pragma unroll
+            for (int m = 0; m < kLpcM1; ++m) {
+                double acc = (m == 0) ? sbar : __builtin_fma(sbar, a[m], -u[m]);
+#pragma unroll
+                for (int i = 1; i + m < kLpcM1; ++i) {
+                    if (m < kLpcM1 - 1) {
+                        acc = __builtin_fma(-u[i], a[i + m], acc);
+                        if (m > 0) acc = __builtin_fma(-u[i + m], a[i], acc);
+                    }
+                }
+                if (m == 0) acc += acc;
+                row[m] = acc;
+                mx = fmax(mx, fabs(acc));
+            }
+            // ... then in place as float32 scaled by 2^she (largest in [2^13, 2^14)): float m lies inside doubles <= m / 2, all read by
+            // then.  A non-finite cotangent keeps the shift 0 and poisons its own frame only.
+            int fe = 0;
+            const bool okmx = mx > 0.0 && mx < 1e300;
+            if (okmx) (void)frexp(mx, &fe);
+            const int she = okmx ? 14 - fe : 0;
+            float* frow = reinterpret_cast<float*>(row);
+#pragma unroll
+            for (int m = 0; m < kLpcM1; ++m) {
+                const double tv = row[m];
+                asm volatile("" ::: "memory");
+                frow[m] = (float)ldexp(tv, she);
+            }
+            reinterpret_cast<int*>(frow)[kLpcM1] = she;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ================= C: the 49-tap filter of every frame on the matrix pipe, overlap-add in a ring in LDS =================
+        // Two frames per round (their chains share nothing and interleave).  The overlap-add runs in a ring of kLbRing floats:
+        // position q of the item's stretch (sample n_lo P - left + q) lives at q mod kLbRing; after frame fi's contribution the
+        // P positions [fi P, (fi + 1) P) are final -- no later frame reaches them -- and go to gx (own range only), their slots back to zero.
+        for (int q = lane; q < 2 * kLbOps * 2 / 16; q += 64) reinterpret_cast<f4*>(dm)[q] = f4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_wave_barrier();
+        {
+            const long base = n_lo * P - left;        // sample of stretch position 0
+            float* gxb = gx + b * Tlen;
+            const bool vec = (P & 3) == 0;
+            auto flush = [&](long q0, int cnt) __attribute__((always_inline)) {   // positions [q0, q0 + cnt) -> gx, slots zeroed
+                if (vec && (((size_t)(gxb + base + q0)) & 15) == 0 && (cnt & 3) == 0) {
+                    for (int t = 4 * lane; t < cnt; t += 256) {
+                        f4* slot = reinterpret_cast<f4*>(ring + ((q0 + t) & (kLbRing - 1)));
+                        const f4 v = *slot;
+                        *slot = f4{0.f, 0.f, 0.f, 0.f};
+                        const long sidx = base + q0 + t;
+                        if (sidx >= s0 && sidx + 3 < s1) *reinterpret_cast<f4*>(gxb + sidx) = v;
+                        else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (sidx + r >= s0 && sidx + r < s1) gxb[sidx + r] = v[r];
+                        }
+                    }
+                } else {
+                    for (int t = lane; t < cnt; t += 64) {
+                        float* slot = ring + ((q0 + t) & (kLbRing - 1));
+                        const float v = *slot;
+                        *slot = 0.f;
+                        const long sidx = base + q0 + t;
+                        if (sidx >= s0 && sidx < s1) gxb[sidx] = v;
+                    }
+                }
+            };
+            constexpr int U = 2;
+            float c8[U][8];
+            auto fetchc = [&](int u, int fi) __attribute__((always_inline)) {
+                const long start = (n_lo + fi) * P - left;
+                if (start >= 0 && start + 512 <= Tlen) {
+                    const lp_f4u* src = reinterpret_cast<const lp_f4u*>(xb + start + 8 * lane);
+                    const lp_f4u q0 = src[0], q1 = src[1];
+                    c8[u][0] = q0[0]; c8[u][1] = q0[1]; c8[u][2] = q0[2]; c8[u][3] = q0[3];
+                    c8[u][4] = q1[0]; c8[u][5] = q1[1]; c8[u][6] = q1[2]; c8[u][7] = q1[3];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const long si = start + 8 * lane + e;
+                        c8[u][e] = (8 * lane + e < L && si >= 0 && si < Tlen) ? xb[si] : 0.f;
+                    }
+                }
+            };
+            const int nfr_c = (LPB_ABL & 4) ? 0 : nfr;
+            if (nfr_c > 0) {
+                fetchc(0, 0);
+                fetchc(1, 1 < nfr_c ? 1 : 0);
+            }
+            for (int fi = 0; fi < nfr_c; fi += U) {
+                int back[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int fu = fi + u < nfr_c ? fi + u : fi;    // (an odd count: the round's second frame is its first again, never added)
+                    const double* row = rbuf + (size_t)fu * kLbRow;
+                    const float* frow = reinterpret_cast<const float*>(row);
+                    const int shx = (int)row[kLpcM1];
+                    const int she = reinterpret_cast<const int*>(frow)[kLpcM1];
+                    back[u] = -(shx + she);
+                    // windowed samples 8 lane .. 8 lane + 7, scaled and split, one 16-byte store per half
+                    lp_u4 hr, lr;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const float v0 = 8 * lane + e < L ? c8[u][e] * wc[e] : 0.f, v1 = 8 * lane + e + 1 < L ? c8[u][e + 1] * wc[e + 1] : 0.f;
+                        lp_h2 h, l;
+                        lp_split2(__builtin_ldexpf(v0, shx), __builtin_ldexpf(v1, shx), h, l);
+                        hr[e >> 1] = __builtin_bit_cast(unsigned, h);
+                        lr[e >> 1] = __builtin_bit_cast(unsigned, l);
+                    }
+                    *reinterpret_cast<lp_u4*>(XH + u * kLbOps + 32 + 8 * lane) = hr;
+                    *reinterpret_cast<lp_u4*>(XL + u * kLbOps + 32 + 8 * lane) = lr;
+                    // taps: E[q], q = 8 + lane (lanes 0 .. 48) = ext[lane - 24] = the row's entry |lane - 24|
+                    if (lane < 2 * kLpcM1 - 1) {
+                        const int m = lane < kLpcM1 - 1 ? kLpcM1 - 1 - lane : lane - (kLpcM1 - 1);
+                        const float tv = frow[m];
+                        const _Float16 th = (_Float16)tv;
+                        EH[u * kLbOps + 16 + 8 + lane] = th;
+                        EL[u * kLbOps + 16 + 8 + lane] = (_Float16)(tv - (float)th);
+                    }
+                }
+                if (fi + U < nfr_c) {
+                    fetchc(0, fi + U);
+                    fetchc(1, fi + U + 1 < nfr_c ? fi + U + 1 : fi + U);
+                }
+                __builtin_amdgcn_wave_barrier();
+                lp_h8 eh[U][3], el[U][3];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int off = u * kLbOps + 16 + 32 * t + 8 * g - j;
+                        eh[u][t] = *reinterpret_cast<const lp_h8u*>(EH + off);
+                        el[u][t] = *reinterpret_cast<const lp_h8u*>(EL + off);
+                    }
+                f4 acc[U][2];
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u][0] = acc[u][1] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    lp_h8 xh[U][2], xl[U][2];
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const int off = u * kLbOps + 16 * (16 * nt + j) + 32 * t + 8 * g;   // (+ 32 of padding, - 32 of the band's reach)
+                            xh[u][nt] = *reinterpret_cast<const lp_h8*>(XH + off);
+                            xl[u][nt] = *reinterpret_cast<const lp_h8*>(XL + off);
+                        }
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) acc[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(el[u][t], xh[u][nt], acc[u][nt], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) acc[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh[u][t], xl[u][nt], acc[u][nt], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) acc[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh[u][t], xh[u][nt], acc[u][nt], 0, 0, 0);
+                }
+                // lane (c, g): samples 16 c + 4 g + r of the frame; times the window (zero past the frame), scale undone; frames in order
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (fi + u < nfr_c) {
+                        const long q0 = (long)(fi + u) * P;
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const int l0 = 16 * (16 * nt + j) + 4 * g;
+                            if (vec) {
+                                f4* slot = reinterpret_cast<f4*>(ring + ((q0 + l0) & (kLbRing - 1)));
+                                f4 cur = *slot;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) cur[r] += __builtin_ldexpf(acc[u][nt][r], back[u]) * wo[nt][r];
+                                *slot = cur;
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) ring[(q0 + l0 + r) & (kLbRing - 1)] += __builtin_ldexpf(acc[u][nt][r], back[u]) * wo[nt][r];
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        flush(q0, P);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+            // what the last frame left beyond its first P positions (all zeros when there was no frame)
+            if (nfr_c > 0) flush((long)nfr_c * P, 512 > P ? 512 - P : 0);
+            // samples of the own range that no frame reaches (frame_period > frame_length, or no frame at all): zero gradient
+            {
+                const long covered_lo = nfr_c > 0 ? base : s1, covered_hi = nfr_c > 0 ? base + (long)(nfr_c - 1) * P + 512 : s1;
+                for (long sidx = s0 + lane; sidx < s1; sidx += 64)
+                    if (sidx < covered_lo || sidx >= covered_hi) gxb[sidx] = 0.f;
+            }
+        }
+    }
+}
+
 template <typename T>
 static int acorr_fwd_impl(const void* x, int64_t F, int L, int M, int fmt, void* r, hipStream_t st)
 {
@@ -1147,6 +1623,8 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
     DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0 && M >= 0 && M < L && eps >= 0, "frame_window_lpc: invalid sizes");
     const bool scratch_clean = (pad_mode & DSA_LPC_SCRATCH_IS_CLEAN) != 0;   // the caller's scratch is zero and private to this stream
     pad_mode &= ~DSA_LPC_SCRATCH_IS_CLEAN;
+    const bool exact_flag = (pad_mode & DSA_LPC_EXACT_LAGSUMS) != 0;   // exact float64 lag sums asked for by the caller
+    pad_mode &= ~DSA_LPC_EXACT_LAGSUMS;
     DSA_REQUIRE(pad_mode >= 0 && pad_mode <= 3, "frame_window_lpc: unknown pad mode");
     int64_t N = dsa_num_frames(T, P), F = B * N;
     if (F == 0) return DSA_OK;
@@ -1177,7 +1655,8 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
             long total_sc = (long)B * sc_per_utt;
             if (grid > total_sc) grid = total_sc;
             // lag sums: float32 matrix instruction (default) or the float64 vector unit (DSA_LPC_LAGSUMS=f64: exact sums)
-            static const bool exact = [] { const char* e = getenv("DSA_LPC_LAGSUMS"); return e && e[0] == 'f' && e[1] == '6'; }();
+            static const bool exact_env = [] { const char* e = getenv("DSA_LPC_LAGSUMS"); return e && e[0] == 'f' && e[1] == '6'; }();
+            const bool exact = exact_env || exact_flag;
             static const bool tickets = [] { const char* e = getenv("DSA_LPC_TICKETS"); return e && e[0] == '1'; }();   // A/B: the ticket counter
             // ticket counter (the float64 kernel; the default kernel deals its items out statically and needs none): the first word of
             // the caller's scratch, zeroed in stream order before the launch unless the caller says it is
@@ -1234,4 +1713,48 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
     else
         return fail(DSA_ERR_UNSUPPORTED, "frame_window_lpc: unsupported dtype%s");
     return check_launch("frame_window_lpc_fwd");
+}
+
+DSA_EXPORT int dsa_frame_window_lpc_bwd(const void* gout, const void* x, int64_t B, int64_t T, int32_t L, int32_t P, const void* w,
+                                        int32_t center, int32_t pad_mode, int32_t M, double eps, int32_t dtype, void* gx, void* stream)
+{
+    DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0 && M >= 0 && M < L && eps >= 0, "frame_window_lpc_bwd: invalid sizes");
+    DSA_REQUIRE(gout && x && gx, "frame_window_lpc_bwd: null pointer");
+    const int64_t N = dsa_num_frames(T, P);
+    if (B * N == 0) return DSA_OK;
+    if (!(dtype == DSA_F32 && M == 24 && L >= 25 && L <= 512 && pad_mode == DSA_PAD_CONSTANT))
+        return fail(DSA_ERR_UNSUPPORTED, "frame_window_lpc_bwd: the one-launch backward covers float32, lpc_order 24, 25 <= frame_length <= 512, constant padding%s");
+    const int left = center ? L / 2 : 0;
+    // frames that touch a run of Hc hops: Hc + halo, each a lane of phase B; the overlap-add ring holds frame_length + frame_period
+    if (L + P > kLbRing) return fail(DSA_ERR_UNSUPPORTED, "frame_window_lpc_bwd: frame_length + frame_period above 1024%s");
+    const long halo = lb_floordiv(left - 1, P) - lb_floordiv(left - L, P);
+    long Hc = 64 - halo;
+    if (Hc > N) Hc = N;
+    if (Hc < 1 || halo > 48)
+        return fail(DSA_ERR_UNSUPPORTED, "frame_window_lpc_bwd: this frame_length / frame_period pair does not fit the one-launch backward%s");
+    // runs of about 40 hops: LDS for nine waves per CU (the lag-sum rows are 208 bytes per frame) against 5 halo frames per run
+    if (Hc > 40 && halo <= 8) Hc = 40;
+    long ipu = (N + Hc - 1) / Hc;
+    Hc = (N + ipu - 1) / ipu;                      // equal runs per utterance
+    const int nfr_max = (int)(Hc + halo);
+    const size_t lds = (size_t)nfr_max * kLbRow * sizeof(double) + (size_t)kLbRing * 4 + kLbAreaBytes;
+    const long total = (long)B * ipu;
+    long per_cu = (long)(160 * 1024 / lds);
+    if (per_cu > 8) per_cu = 8;                    // two waves per SIMD (256 registers)
+    long grid = 256L * per_cu;
+    if (grid > total) grid = total;
+    hipStream_t st = (hipStream_t)stream;
+#define DSA_LPCB(LCV)                                                                                                                   \
+    do {                                                                                                                                \
+        static std::atomic<uint64_t> attr_b{0};                                                                                         \
+        if (lds > 48 * 1024 && !ensure_dynamic_lds((const void*)frame_window_lpc24_bwd_mfma_kernel<LCV>, (int)lds, attr_b))             \
+            return fail(DSA_ERR_LAUNCH, "frame_window_lpc_bwd: cannot reserve LDS%s");                                                  \
+        hipLaunchKernelGGL((frame_window_lpc24_bwd_mfma_kernel<LCV>), dim3((unsigned)grid), dim3(64), lds, st, (const float*)gout,      \
+                           (const float*)x, (long)T, (long)N, L, P, left, (const float*)w, eps, (float*)gx, total, (int)ipu, (int)Hc,   \
+                           nfr_max);                                                                                    \
+    } while (0)
+    if (L == 400) DSA_LPCB(400);
+    else DSA_LPCB(0);
+#undef DSA_LPCB
+    return check_launch("frame_window_lpc24_bwd_mfma");
 }

@@ -15,7 +15,7 @@ from .freqt import FrequencyTransform
 from .levdur import LevinsonDurbin
 from .lpc import LinearPredictiveCodingAnalysis
 from .lpc import LinearPredictiveCodingAnalysis as LPC
-from .fused import FusedSTFTFilterBank, FusedSTFTMelCepstralAnalysis, fuse
+from .fused import FusedFrameWindowLPC, FusedSTFTFilterBank, FusedSTFTMelCepstralAnalysis, fuse
 from .gnorm import GeneralizedCepstrumGainNormalization, GeneralizedCepstrumInverseGainNormalization
 from .mc2b import MelCepstrumToMLSADigitalFilterCoefficients, MLSADigitalFilterCoefficientsToMelCepstrum
 from .mcep import MelCepstralAnalysis
@@ -41,6 +41,6 @@ __all__ = [
     "MelCepstrumToMLSADigitalFilterCoefficients", "MLSADigitalFilterCoefficientsToMelCepstrum",
     "MelGeneralizedCepstrumToMelGeneralizedCepstrum", "MelGeneralizedCepstrumToSpectrum", "MelGeneralizedCepstralAnalysis",
     "PseudoMGLSADigitalFilter", "MLSA", "AllZeroDigitalFilter", "LinearInterpolation",
-    "FusedSTFTFilterBank", "FusedSTFTMelCepstralAnalysis", "fuse",
+    "FusedFrameWindowLPC", "FusedSTFTFilterBank", "FusedSTFTMelCepstralAnalysis", "fuse",
     "RealValuedFastFourierTransform", "STFT", "ShortTimeFourierTransform", "Spectrum", "Window",
 ]

@@ -14,9 +14,12 @@ from torch import nn
 
 from .. import ops
 from .fbank import MelFilterBankAnalysis
+from .frame import Frame
+from .lpc import LinearPredictiveCodingAnalysis
 from .mcep import MelCepstralAnalysis
 from .mfcc import MelFrequencyCepstralCoefficientsAnalysis
 from .stft import ShortTimeFourierTransform
+from .window import Window
 
 _SPEC_POWER, _FFT, _FRAME = 3, 512, 400
 
@@ -107,9 +110,63 @@ class FusedSTFTMelCepstralAnalysis(nn.Module):
                                     s.fft_length, s.center, s.eps, a.cep_order, a.n_iter)
 
 
-def fuse(stft: ShortTimeFourierTransform, analysis: nn.Module) -> nn.Module:
-    """``fuse(stft, analysis)(x) == analysis(stft(x))`` in one launch where a fused kernel applies: ``analysis`` a
-    MelCepstralAnalysis (the hot path), a MelFilterBankAnalysis or a MelFrequencyCepstralCoefficientsAnalysis."""
+class FusedFrameWindowLPC(nn.Module):
+    """``lpc(window(frame(x)))`` -- the LPC branch of the reference's README (README.md:198-201; BASELINE configs[3]) -- as ONE
+    launch forward and ONE launch backward (dsa_frame_window_lpc_fwd / _bwd, csrc/lpc.hip): the framed and windowed (B N, L) tensors
+    of the module chain (two of them forward, two more backward) never exist.  Same modules, same semantics; configurations the
+    launches do not cover (float64, other orders, learnable windows, a gradient through non-constant padding, frame lengths
+    above 512 ...) run the three modules unchanged.  ``exact_lag_sums``: float64 lag sums on the vector unit instead of binary16
+    splits on the matrix pipe (for near-singular frames).  ``last_path``: "fused" / "fused-forward" / "three-stage"."""
+
+    def __init__(self, frame: Frame, window: Window, lpc: LinearPredictiveCodingAnalysis, exact_lag_sums: bool = False) -> None:
+        super().__init__()
+        if not isinstance(frame, Frame):
+            raise ValueError("frame must be a Frame.")
+        if not isinstance(window, Window):
+            raise ValueError("window must be a Window.")
+        if not isinstance(lpc, LinearPredictiveCodingAnalysis):
+            raise ValueError("lpc must be a LinearPredictiveCodingAnalysis.")
+        if window.in_dim != frame.frame_length or (window.out_length or window.in_dim) != lpc.frame_length:
+            raise ValueError("frame, window and lpc disagree on frame_length.")
+        self.frame, self.window, self.lpc = frame, window, lpc
+        self.exact_lag_sums = bool(exact_lag_sums)
+        self.last_path = None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        f, wn, lp = self.frame, self.window, self.lpc
+        w = wn.window
+        L, P, M = f.frame_length, f.frame_period, lp.lpc_order
+        plain = (x.is_cuda and x.dim() >= 1 and x.size(-1) >= 1 and not f.zmean and (wn.out_length or wn.in_dim) == wn.in_dim
+                 and not isinstance(w, nn.Parameter) and w.dtype == x.dtype and w.device == x.device and M < L
+                 and x.dtype in (torch.float32, torch.float64))
+        want_grad = torch.is_grad_enabled() and x.requires_grad
+        if plain and not want_grad:
+            try:
+                y = ops.frame_window_lpc(x, w, L, P, M, lp.eps, f.center, f.mode, self.exact_lag_sums)
+                self.last_path = "fused-forward"
+                return y
+            except ops._lib.BackendError:      # a geometry the fused forward does not take (frame too long for LDS ...)
+                pass
+        if plain and want_grad and ops.frame_window_lpc_bwd_supported(x, L, P, M, f.center, f.mode):
+            self.last_path = "fused"
+            return ops.FrameWindowLpcFn.apply(x, w, L, P, M, lp.eps, f.center, self.exact_lag_sums)
+        self.last_path = "three-stage"
+        return lp(wn(f(x)))
+
+
+def fuse(first: nn.Module, *rest: nn.Module, **options) -> nn.Module:
+    """One launch where a fused kernel applies, the modules themselves elsewhere:
+
+    * ``fuse(stft, analysis)(x) == analysis(stft(x))`` for ``analysis`` a MelCepstralAnalysis (the hot path), a
+      MelFilterBankAnalysis or a MelFrequencyCepstralCoefficientsAnalysis;
+    * ``fuse(frame, window, lpc)(x) == lpc(window(frame(x)))`` -- the LPC branch, forward and backward."""
+    if isinstance(first, Frame):
+        if len(rest) != 2:
+            raise ValueError("fuse(frame, window, lpc) takes a Frame, a Window and a LinearPredictiveCodingAnalysis.")
+        return FusedFrameWindowLPC(first, rest[0], rest[1], **options)
+    if len(rest) != 1 or options:
+        raise ValueError("fuse(stft, analysis) takes a ShortTimeFourierTransform and one analysis module.")
+    analysis = rest[0]
     if isinstance(analysis, MelCepstralAnalysis):
-        return FusedSTFTMelCepstralAnalysis(stft, analysis)
-    return FusedSTFTFilterBank(stft, analysis)
+        return FusedSTFTMelCepstralAnalysis(first, analysis)
+    return FusedSTFTFilterBank(first, analysis)

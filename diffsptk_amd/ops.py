@@ -1484,8 +1484,9 @@ class LpcFn(torch.autograd.Function):
         return gx, None, None
 
 
-def frame_window_lpc(x, window, L, P, M, eps, center=True, mode="constant"):
-    """Fused LPC branch (forward only): LPC(Window(Frame(x))), README.md:198-201 of the reference."""
+def frame_window_lpc(x, window, L, P, M, eps, center=True, mode="constant", exact_lag_sums=False):
+    """Fused LPC branch, forward: LPC(Window(Frame(x))), README.md:198-201 of the reference.  exact_lag_sums: float64 lag sums on
+    the vector unit instead of binary16 splits on the matrix pipe (DSA_LPC_EXACT_LAGSUMS; for near-singular frames)."""
     _require_device(x, window)
     _same_dtype(x, window)
     xc, wc = x.contiguous(), window.contiguous()
@@ -1495,7 +1496,45 @@ def frame_window_lpc(x, window, L, P, M, eps, center=True, mode="constant"):
     # the kept-zero per-(device, stream) counters of the persistent kernels (the kernel hands them back zeroed: no fill launch per call;
     # under graph capture a private block and the library's own reset, see _mcep_scratch)
     scratch, flag = _mcep_scratch(x.device)
+    if exact_lag_sums:
+        flag |= _lib.LPC_EXACT_LAGSUMS
     with torch.cuda.device(x.device):
         _call("dsa_frame_window_lpc_fwd", _p(xc), B, T, L, P, _p(wc), int(center), pad_mode_code(mode) | flag, M,
               float(eps), _dtype_code(xc), _p(scratch), _p(out), _stream())
     return out
+
+
+def frame_window_lpc_bwd_supported(x, L, P, M, center, mode) -> bool:
+    """dsa_frame_window_lpc_bwd takes this configuration (the conditions of its launcher, csrc/lpc.hip): float32, lpc_order 24,
+    25 <= frame_length <= 512, constant padding, and a (frame_length, frame_period) pair whose overlap fits the wave's stretch."""
+    if not (x.is_cuda and x.dtype == torch.float32 and M == 24 and 25 <= L <= 512 and mode == "constant" and P >= 1 and x.size(-1) >= 1):
+        return False
+    left = L // 2 if center else 0
+    halo = (left - 1) // P - (left - L) // P          # (Python's floor division, as lb_floordiv)
+    return L + P <= 1024 and halo <= 48 and min(64 - halo, num_frames(x.size(-1), P)) >= 1
+
+
+class FrameWindowLpcFn(torch.autograd.Function):
+    """LPC(Window(Frame(x))) (README.md:198-201 of the reference; frame.py:120-141, window.py:185-193, lpc.py:137-139) as ONE launch
+    forward (dsa_frame_window_lpc_fwd) and ONE launch backward (dsa_frame_window_lpc_bwd): no (B N, L) tensor in memory either
+    way.  A fixed window; callers check frame_window_lpc_bwd_supported first."""
+
+    @staticmethod
+    def forward(ctx, x, window, L, P, M, eps, center, exact_lag_sums):
+        out = frame_window_lpc(x, window, L, P, M, eps, center, "constant", exact_lag_sums)
+        ctx.save_for_backward(x.contiguous(), window.contiguous())
+        ctx.cfg = (L, P, M, eps, center)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        xc, wc = ctx.saved_tensors
+        L, P, M, eps, center = ctx.cfg
+        gc = g.contiguous()
+        T = xc.size(-1)
+        gx = torch.empty_like(xc)
+        with torch.cuda.device(g.device):
+            _call("dsa_frame_window_lpc_bwd", _p(gc), _p(xc), xc.numel() // T, T, L, P, _p(wc), int(center), pad_mode_code("constant"),
+                  M, float(eps), _dtype_code(xc), _p(gx), _stream())
+        return gx, None, None, None, None, None, None, None

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 123 /* 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
+#define DSA_VERSION 124 /* 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
@@ -420,6 +420,19 @@ int dsa_lpc_bwd(const void* gout, const void* x, const void* out, int64_t F, int
 int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P,
                              const void* w, int32_t center, int32_t pad_mode, int32_t M, double eps,
                              int32_t dtype, void* scratch, void* out, void* stream);
+/* pad_mode may also carry DSA_LPC_EXACT_LAGSUMS: the tuned float32 kernel then forms its lag sums as exact float64 sums on the
+ * vector unit (the kernel of rounds 1-3; ~2.7 x the launch time) instead of 3-term binary16 splits on the matrix pipe (~1e-7 r[0]
+ * from the exact sums: what the reference's own float32 FFT route has).  For near-singular frames (a sinusoid plus tiny noise, small
+ * eps) whose Toeplitz system amplifies that error.  (The environment variable DSA_LPC_LAGSUMS=f64 still selects it process-wide.) */
+#define DSA_LPC_EXACT_LAGSUMS 0x200
+/* Its backward in ONE launch -- the adjoint of frame.py:120-141, window.py:185-193, acorr.py:110-120 and levdur.py:113-127
+ * composed (README.md:198-201 with a gradient): gout:(B,N,M+1), x:(B,T), w:(L) or NULL -> gx:(B,T), every element written; no
+ * (B N, L) tensor in memory either way.  Covers float32, lpc_order 24, 25 <= frame_length <= 512, constant padding and the
+ * (frame_length, frame_period) pairs whose overlap fits a wave's LDS stretch; anything else returns DSA_ERR_UNSUPPORTED and the
+ * caller composes dsa_lpc_bwd / dsa_window_bwd / dsa_frame_bwd.  A fixed (non-learnable) window: no window gradient. */
+int dsa_frame_window_lpc_bwd(const void* gout, const void* x, int64_t B, int64_t T, int32_t L, int32_t P,
+                             const void* w, int32_t center, int32_t pad_mode, int32_t M, double eps,
+                             int32_t dtype, void* gx, void* stream);
 
 #ifdef __cplusplus
 }
