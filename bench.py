@@ -335,20 +335,35 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
     w = dsp.Window(FL, device=dev).window
     B = 1024
     fr = B * FRAMES_PER_UTT
+    # (the entry timed is the drop-in one: fuse(frame, window, lpc) over the reference's own modules -- README.md:198-201 of the
+    #  reference -- one launch forward, one launch backward; the module chain beside it)
+    frm, wn, lpc = dsp.Frame(FL, FP), dsp.Window(FL, device=dev), dsp.LPC(FL, M, eps=1e-5, device=dev)
+    flpc = dsp.fuse(frm, wn, lpc)
     with torch.no_grad():
-        t_l = gpu_time(lambda: ops.frame_window_lpc(x1024, w, FL, FP, M, 1e-5), n=30) * 1e-3
+        t_l = gpu_time(lambda: flpc(x1024), n=30) * 1e-3
         k_lpc = _lib.last_kernel()
-        frm, wn, lpc = dsp.Frame(FL, FP), dsp.Window(FL, device=dev), dsp.LPC(FL, M, eps=1e-5, device=dev)
         t_chain = gpu_time(lambda: lpc(wn(frm(x1024))), n=10) * 1e-3
 
     def lpc_fb():
         xg = x1024.clone().requires_grad_(True)
         lpc(wn(frm(xg))).mean().backward()
 
+    def flpc_fb():
+        xg = x1024.clone().requires_grad_(True)
+        flpc(xg).mean().backward()
+
     t_lfb = gpu_time(lpc_fb, n=10) * 1e-3
+    t_ffb = gpu_time(flpc_fb, n=10) * 1e-3
+    gl_ = torch.randn(B, FRAMES_PER_UTT, M + 1, device=dev)
+    gxl_ = torch.empty_like(x1024)
+    t_lb = gpu_time(lambda: ops._call("dsa_frame_window_lpc_bwd", gl_.data_ptr(), x1024.data_ptr(), B, x1024.size(-1), FL, FP, w.data_ptr(), 1, 0, M,
+                                      1e-5, _lib.F32, gxl_.data_ptr(), ops._stream()), n=30) * 1e-3
+    del gl_, gxl_
     res["config4_lpc_batch1024"] = {
         "workload": f"BASELINE configs[3]: Frame+Window+acorr+levdur (M=24), {B} utterances x 1 s ({fr} frames), one wave per 64 frames",
-        "frames/s": fr / t_l, "ms_fused_fwd": t_l * 1e3, "ms_module_chain_fwd": t_chain * 1e3, "ms_module_chain_fwd_bwd": t_lfb * 1e3,
+        "frames/s": fr / t_l, "ms_fused_fwd": t_l * 1e3, "ms_fused_fwd_bwd": t_ffb * 1e3, "ms_fused_bwd_launch": t_lb * 1e3,
+        "entry": "diffsptk_amd.fuse(Frame, Window, LPC) (path: %s)" % flpc.last_path,
+        "ms_module_chain_fwd": t_chain * 1e3, "ms_module_chain_fwd_bwd": t_lfb * 1e3,
         "roofline": (lambda mm: {
                      "kernel": k_lpc, "bound": "valu_issue (binary16-split Gram products on the matrix pipe; float64 lag sums and Levinson on the vector ALU)" if mm
                      else "valu_issue (float64)",

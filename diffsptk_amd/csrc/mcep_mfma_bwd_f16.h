@@ -371,10 +371,12 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
                     for (int it = 0; it < 3; ++it) eah_n[it] = EH[(it * 8 + j) * 64];
                 }
                 auto prodE = [&](int i) __attribute__((always_inline)) {   // i = 3 term + it
+#ifndef DSA_BWD_ABL_NOCHAIN2
                     if (j > 0) {
                         const int it = i % 3, term = i / 3;
                         accB[it] = mfma_h(term == 0 ? eal[it] : eah[it], term == 1 ? el_p : eh_p, accB[it]);
                     }
+#endif
                 };
                 auto vecA = [&](int t_) __attribute__((always_inline)) {   // e = exp2(t + sh), kept for zbar = ebar * e
                     const int mt = (2 * j + t_) & 15;

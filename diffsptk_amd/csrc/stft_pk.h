@@ -60,8 +60,12 @@ template <int ABL, int LC, bool DIRECT = false, int FBM = 0, bool PF2 = false>  
 __global__ __launch_bounds__((FBM || PF2) ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
     const float* __restrict__ x, long Tlen, long N, int L, int P, int left, const float* __restrict__ w,
     const float* __restrict__ twiddle, float eps, float* __restrict__ y, long total_chunks, int chunks_per_utt,
-    const float* __restrict__ fbt, float fb_floor, float fb_gamma, int fbC)
+    const float* __restrict__ fbt, float fb_floor, float fb_gamma, int fbC, int run_len)
 {
+    // run_len > 1 (round 5): a wave takes RUNS of run_len consecutive passes instead of every (number of waves)-th pass.  Consecutive
+    // passes of an utterance share L - P of their 3 P + L samples; dealt round-robin those were fetched by two waves on two XCDs at
+    // two times -- 1.73 x the waveform's bytes from memory (FETCH_SIZE) -- while a wave that walks its own run finds them in its
+    // CU's cache a pass later.  Same passes, same arithmetic, same stores: only the order changes.
     constexpr bool FB = FBM != 0;
     static_assert(!FB || (DIRECT && LC > 0), "the filter-bank epilogue builds on the register-direct split");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -93,19 +97,38 @@ __global__ __launch_bounds__((FBM || PF2) ? 256 : 128, 4) DSA_PK_TARGET void stf
     const int j = lane & 15;   // lane within the frame group
     const int fl = lane >> 4;  // frame slot within the pass (0..3)
     PK_STAMP(0);
-    if (wid >= total_chunks) return;
+    // pass k of wave `wid` is chunk (wid + (k / R) nw) R + k % R (R = run_len; R <= 0: wid + k nw): runs of R consecutive chunks, the runs
+    // themselves dealt round-robin, so the passes in flight stay one compact window of the output
+    const int R = run_len > 0 ? run_len : 1;
+    const long jump = nw * R - (R - 1);                                       // from the last chunk of a run to the next run's first
+    const long c_first = wid * R;
+    const long c_end = total_chunks;
+    if (c_first >= c_end) return;
     constexpr int NR = LC ? (LC + 31) / 32 : 16;   // sample pairs a lane reads (the rest is zero padding)
     constexpr int K = 257;
     // (utterance, chunk) of a pass advance incrementally: one 64-bit division per wave
     // (32-bit: the wave count and the chunks of an utterance are far below 2^31; 64-bit divisions are ~150 instructions)
-    const long b_step = (long)((unsigned)nw / (unsigned)chunks_per_utt);
-    const int ci_step = (int)(nw - b_step * chunks_per_utt);
-    auto advance = [&](long& bb, int& cc) __attribute__((always_inline)) {
-        bb += b_step;
-        cc += ci_step;
-        if (cc >= chunks_per_utt) {
-            cc -= chunks_per_utt;
-            ++bb;
+    const long b_step = (long)((unsigned long)jump / (unsigned)chunks_per_utt);
+    const int ci_step = (int)(jump - b_step * chunks_per_utt);
+    // (kin: position of the pass inside its run; a step is +1 inside a run, `jump` at its end)
+    auto advance = [&](long& bb, int& cc, long& cq, int& kin) __attribute__((always_inline)) {
+        if (kin + 1 < R) {
+            ++kin;
+            ++cq;
+            ++cc;
+            if (cc >= chunks_per_utt) {
+                cc = 0;
+                ++bb;
+            }
+        } else {
+            kin = 0;
+            cq += jump;
+            bb += b_step;
+            cc += ci_step;
+            if (cc >= chunks_per_utt) {
+                cc -= chunks_per_utt;
+                ++bb;
+            }
         }
     };
     // the stretch of samples the (up to) four frames of pass (bb, cc) share, straight from memory into the tile
@@ -159,16 +182,18 @@ __global__ __launch_bounds__((FBM || PF2) ? 256 : 128, 4) DSA_PK_TARGET void stf
 
     // The first pass's stretch is fetched like every other one -- issued first, so that its round trip to memory
     // overlaps the table loads below instead of following them.
-    long b = (long)((unsigned)wid / (unsigned)chunks_per_utt);
-    int ci = (int)(wid - b * chunks_per_utt);
-    long c = wid;
+    long b = (long)((unsigned)c_first / (unsigned)chunks_per_utt);
+    int ci = (int)(c_first - b * chunks_per_utt);
+    long c = c_first;
     bool pre_ok = prefetch(b, ci);
     bool prb_ok = false;
     long bn1 = b;      // PF2: coordinates of the pass after this wave's first one
     int cin1 = ci;
+    long cn1 = c;
+    int kn1 = 0;
     if (PF2) {
-        advance(bn1, cin1);
-        prb_ok = (wid + nw < total_chunks) ? prefetch_into(bn1, cin1, prb0, prb1, prb2) : false;
+        advance(bn1, cin1, cn1, kn1);
+        prb_ok = (cn1 < c_end) ? prefetch_into(bn1, cin1, prb0, prb1, prb2) : false;
     }
     PK_STAMP(3);
 
@@ -276,13 +301,15 @@ __global__ __launch_bounds__((FBM || PF2) ? 256 : 128, 4) DSA_PK_TARGET void stf
     PK_STAMP(5);
     long b1 = b;
     int ci1 = ci;
-    advance(b1, ci1);
-    bool has1 = c + nw < total_chunks;
+    long c1 = c;
+    int k1n = 0;
+    advance(b1, ci1, c1, k1n);
+    bool has1 = c1 < c_end;
     if (PF2) {   // pass 1 is already on its way into the second register set; the first set now takes pass 2
-        long b2 = b1;
-        int ci2 = ci1;
-        advance(b2, ci2);
-        pre_ok = (c + 2 * nw < total_chunks) ? prefetch_into(b2, ci2, pre0, pre1, pre2) : false;
+        long b2 = b1, c2 = c1;
+        int ci2 = ci1, k2n = k1n;
+        advance(b2, ci2, c2, k2n);
+        pre_ok = (c2 < c_end) ? prefetch_into(b2, ci2, pre0, pre1, pre2) : false;
     } else {
         pre_ok = has1 ? prefetch(b1, ci1) : false;
     }
@@ -609,16 +636,16 @@ __global__ __launch_bounds__((FBM || PF2) ? 256 : 128, 4) DSA_PK_TARGET void stf
         } else {
             stage_sync(b1, ci1);
         }
-        c += nw;
+        c = c1;
         b = b1;
         ci = ci1;
-        advance(b1, ci1);
-        has1 = c + nw < total_chunks;
+        advance(b1, ci1, c1, k1n);
+        has1 = c1 < c_end;
         if (PF2) {   // the set just staged takes the stretch two passes ahead
-            long b2 = b1;
-            int ci2 = ci1;
-            advance(b2, ci2);
-            qok = (c + 2 * nw < total_chunks) ? prefetch_into(b2, ci2, q0, q1, q2) : false;
+            long b2 = b1, c2 = c1;
+            int ci2 = ci1, k2n = k1n;
+            advance(b2, ci2, c2, k2n);
+            qok = (c2 < c_end) ? prefetch_into(b2, ci2, q0, q1, q2) : false;
         } else {
             qok = has1 ? prefetch_into(b1, ci1, q0, q1, q2) : false;
         }

@@ -62,9 +62,11 @@ def test_fused_lpc_backward_against_the_float64_chain(L, P, T, B, center):
     (y * gy).sum().backward()
     assert _lib.last_kernel() in ("frame_window_lpc24_bwd_mfma", "frame_window_lpc24_mfma_fwd")
     y64, g64 = _chain64(x, L, P, center=center, gy=gy)
-    assert float((y.double() - y64).abs().max()) < 2e-4 * max(1.0, float(y64.abs().max()))
+    # (a frame of 25 samples carries an order-24 Toeplitz system that eps alone conditions: float32 lag sums move it by 1e-4)
+    tol = 5e-4 if L < 64 else 2e-5
+    assert float((y.detach().double() - y64).abs().max()) < tol * max(1.0, float(y64.abs().max()))
     scale = float(g64.abs().max())
-    assert float((xg.grad.double() - g64).abs().max()) < 2e-4 * scale, (float((xg.grad.double() - g64).abs().max()), scale)
+    assert float((xg.grad.double() - g64).abs().max()) < tol * scale, (float((xg.grad.double() - g64).abs().max()), scale)
     assert bool(torch.isfinite(xg.grad).all())
 
 
@@ -102,8 +104,9 @@ def test_fused_lpc_bench_size_properties():
     assert bool(torch.isfinite(xg.grad).all())
     idx = [0, 1, 511, 1023]
     y64, g64 = _chain64(x[idx], 400, 80, gy=gy[idx])
-    assert float((y[idx].double() - y64).abs().max()) < 1e-4
-    assert float((xg.grad[idx].double() - g64).abs().max()) < 1e-4 * float(g64.abs().max())
+    # measured (tools/measure_tolerances.py): outputs 2.1e-7, gradient 4.3e-7 of its maximum; bounds at three times that
+    assert float((y[idx].double() - y64).abs().max()) < 1e-6
+    assert float((xg.grad[idx].double() - g64).abs().max()) < 1.5e-6 * float(g64.abs().max())
     (g0,) = torch.autograd.grad((fl(xg) * 0.0).sum(), xg)
     assert float(g0.abs().max()) == 0.0
 

@@ -663,7 +663,9 @@ def test_lpc_config4_batch1024_sampled():
     a = ops.frame_window_lpc(xd, w, 400, 80, 24, 1e-5)
     assert a.shape == (1024, 200, 25) and torch.isfinite(a).all()
     sel = slice(0, 1024, 171)
-    close(host(a[sel]), O.frame_window_lpc(x[sel].double().numpy()), 1e-4, 1e-4)
+    # measured (tools/measure_tolerances.py, lag sums as 3-term binary16 splits on the matrix pipe): 2.1e-7 absolute, 1.6e-5 relative on
+    # coefficients above 1e-2 -- the bounds are three times that (round 4 held this test to 1e-4 / 1e-4)
+    close(host(a[sel]), O.frame_window_lpc(x[sel].double().numpy()), 5e-5, 1e-6)
     a_mod = dsp.LPC(400, 24, eps=1e-5, device=DEV)(dsp.Window(400, device=DEV)(dsp.Frame(400, 80)(xd[:64])))
     close(host(a_mod), host(a[:64]), 1e-6, 1e-6)
 

@@ -52,3 +52,24 @@ xs2 = torch.randn(8, 4000, generator=torch.Generator().manual_seed(0))
 X2 = stft(xs2.to(DEV))
 Xref = O.stft(xs2.double().numpy(), 400, 80, 512)
 print("smoke mcep: max |err|:", float(np.abs(mcep(X2).detach().cpu().numpy() - O.mcep(Xref, 24, 0.42, 10)).max()))
+# LPC branch, config 4 (tests/test_gpu_parity.py::test_lpc_config4_batch1024_sampled, tests/test_gpu_lpc_fused.py): the float32 kernels
+# against the float64 oracle on the same float32 samples -- lag sums as 3-term binary16 splits on the matrix pipe (default) and as
+# exact float64 sums (DSA_LPC_EXACT_LAGSUMS); and the one-launch gradient against the float64 module chain
+from diffsptk_amd import ops  # noqa: E402
+xl = torch.randn(1024, 16000, generator=torch.Generator().manual_seed(0))
+wl = dsp.Window(400, device=DEV).window
+sel = slice(0, 1024, 171)
+refl = O.frame_window_lpc(xl[sel].double().numpy())
+for name, exact in (("matrix-pipe lag sums (default)", False), ("exact float64 lag sums", True)):
+    a = ops.frame_window_lpc(xl.to(DEV), wl, 400, 80, 24, 1e-5, exact_lag_sums=exact)[sel].double().cpu().numpy()
+    print(f"LPC config 4, {name}: max |err| gain {np.abs(a[..., 0] - refl[..., 0]).max():.3e}  coefficients {np.abs(a[..., 1:] - refl[..., 1:]).max():.3e}"
+          f"  max rel (coefficients above 1e-2) {(np.abs(a - refl) / np.abs(refl))[np.abs(refl) > 1e-2].max():.3e}")
+frm, wn = dsp.Frame(400, 80), dsp.Window(400, device=DEV)
+fl = dsp.fuse(frm, wn, dsp.LPC(400, 24, eps=1e-5, device=DEV))
+xg = xl[:8].to(DEV).requires_grad_(True)
+gy = torch.randn(8, 200, 25, generator=torch.Generator().manual_seed(1)).to(DEV)
+(fl(xg) * gy).sum().backward()
+xg64 = xl[:8].double().to(DEV).requires_grad_(True)
+ch = dsp.LPC(400, 24, eps=1e-5, device=DEV, dtype=torch.float64)(dsp.Window(400, device=DEV, dtype=torch.float64)(frm(xg64)))
+(ch * gy.double()).sum().backward()
+print(f"LPC one-launch gradient vs float64 chain: max |err| / max |ref| {float((xg.grad.double() - xg64.grad).abs().max() / xg64.grad.abs().max()):.3e}")
