@@ -57,6 +57,15 @@ MCEP_FLOP_PER_FRAME = 2 * (K * M1 + N_ITER * (M1 * K + K * M2 + _SOLVE_MAC)) + (
 # sides, rtbar (Toeplitz + Hankel diagonals), ebar = E rtbar, mbar -= 2 D zbar; once: lbar += G mbar_0
 MCEP_BWD_FLOP_PER_FRAME = 2 * (N_ITER * (M1 * K + K * M2 + M1 ** 3 // 3 + 2 * M1 * M1 + 2 * M1 * M1 + K * M2 + K * M1) + K * M1) \
     + N_ITER * 3 * K
+# the binding pipe's ALGORITHMIC bound for the step (round-4 review): work that has to run on the float32 datapath -- the ten
+# eliminations, the exponentials, log and (one-launch step) the 512-point real FFT: ~2.5 n log2 n -- priced at the float32 peak; the
+# three matrix chains run as 3-term binary16 splits on the separate matrix pipe, priced at the dense binary16 peak.  The larger of
+# the two times over the measured launch time is `roofline.algorithmic_frac`: an efficiency (not the issued-instruction
+# utilisation that `frac` reports).
+MCEP_F32_FLOP_PER_FRAME = N_ITER * 2 * _SOLVE_MAC + (N_ITER + 1) * K
+STFT_F32_FLOP_PER_FRAME = int(2.5 * NFFT * 9)
+MCEP_F16_FLOP_PER_FRAME = 3 * 2 * (K * M1 + N_ITER * (M1 * K + K * M2))
+F16_MFMA_PEAK_TFLOPS = 2500.0   # dense binary16 matrix peak (MI355X_MICROARCH.md)
 LPC_FLOP_PER_FRAME = 2 * FL * M1 + 2 * M * M + 4 * M   # direct lag sums + Levinson recursion, float64
 LPC_BYTES_PER_FRAME = FP * 4 + M1 * 4
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
@@ -522,6 +531,7 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
 DETAIL_FILE = "bench_detail.json"
 LINE_LIMIT = 4096
 _ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms")
+_ROOF_OPTIONAL = ("algorithmic_frac", "back_to_back_ms", "frac_back_to_back")   # carried when the record has them
 
 
 def _round(v, digits=5):
@@ -549,6 +559,7 @@ def compact_line(res: dict, detail_path: str = DETAIL_FILE) -> str:
         r = res.get(name)
         if r:
             line[name] = {k: r.get(k) for k in _ROOF_KEYS}
+            line[name].update({k: r[k] for k in _ROOF_OPTIONAL if r.get(k) is not None})
             if r.get("measured_in"):
                 line[name]["measured_in"] = r["measured_in"]
     cb = res.get("cpu_baseline")
@@ -833,6 +844,8 @@ def main():
                 "achieved": dp["achieved"] if dp else None, "peak": F32_DATAPATH_PEAK_GCPS, "unit": "G datapath-cycles/s",
                 "frac": dp["frac"] if dp else None,
                 "traffic": pmc_traffic(kernels["mcep"], frames_launch), "avg_launch_ms": t_mcep * 1e3,
+                "algorithmic_frac": max((MCEP_F32_FLOP_PER_FRAME + (STFT_F32_FLOP_PER_FRAME if args.path == "fused" else 0)) / (FP32_PEAK_TFLOPS * 1e12),
+                                        MCEP_F16_FLOP_PER_FRAME / (F16_MFMA_PEAK_TFLOPS * 1e12)) * frames_launch / t_mcep,
                 "back_to_back_ms": t_mcep_b2b * 1e3, "frames_per_launch": frames_launch,
                 "datapath": dp,
                 "nominal_valu_issue": {"achieved": (ipf * frames_launch / t_mcep / 1e9) if ipf else None, "peak": VALU_ISSUE_PEAK_GIPS,
