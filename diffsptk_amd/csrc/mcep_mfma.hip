@@ -538,6 +538,9 @@ int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, v
 }  // namespace dsa
 #include "mcep_mfma_f16.h"
 #include "mcep_mfma_bwd_f16.h"
+#ifdef DSA_MCEP_BWD_PAIR_EXPERIMENT   // round 5: built, measured, not adopted (tools/experiments/mcep_mfma_bwd_pair.h)
+#include "../../tools/experiments/mcep_mfma_bwd_pair.h"
+#endif
 namespace dsa {
 
 int mcep_mfma_supported(int nfft, int M, int dtype) { return dtype == DSA_F32 && nfft == 512 && M == 24; }
@@ -618,6 +621,22 @@ int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, 
 int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* av,
                   const void* images, void* scratch, void* gX, hipStream_t st, bool has_workspace = false)
 {
+#ifdef DSA_MCEP_BWD_PAIR_EXPERIMENT
+    // round-5 experiment: pairs of waves that split the bins of a tile, two waves per SIMD (2.9 ms against 1.57: not adopted)
+    static const bool pair_on = [] { const char* e = getenv("DSA_MCEP_BWD_PAIR"); return !(e && e[0] == '0'); }();
+    if (pair_on) {
+        const int lds_p = mhp::P_LDS_FLOATS * 4;
+        static std::atomic<uint64_t> attr_p{0};
+        if (!ensure_dynamic_lds((const void*)mcep_mfma_bwd_pair_kernel, lds_p, attr_p))
+            return fail(DSA_ERR_LAUNCH, "mcep_mfma_bwd: cannot reserve the LDS operand images%s");
+        const long nt = (long)((F + 15) / 16);
+        long blocks_p = (nt + mhp::PAIRS - 1) / mhp::PAIRS;
+        if (blocks_p > 256) blocks_p = 256;
+        hipLaunchKernelGGL(mcep_mfma_bwd_pair_kernel, dim3((unsigned)blocks_p), dim3(512), lds_p, st, (const float*)gmc, (const float*)X,
+                           (const float*)hist, (long)F, n_iter, (const float*)av, (float*)gX, nt, (const _Float16*)images);
+        return check_launch("mcep_mfma_bwd_pair");
+    }
+#endif
     const int lds_bytes = mhb::B_LDS_FLOATS * 4;
     static std::atomic<uint64_t> attr_devices{0};
     if (!ensure_dynamic_lds((const void*)mcep_mfma_bwd_kernel_h, lds_bytes, attr_devices))
