@@ -12,6 +12,8 @@ compositions are the `learnable=` options (modules/_learnable.py, as SURVEY.md 8
 glue around kernels.  There is no CPU fallback.
 
     mc = diffsptk.fuse(stft, mcep)(x)   # the same in ONE launch (no spectrogram in memory)
+    a = diffsptk.fuse(diffsptk.Frame(400, 80), diffsptk.Window(400, device="cuda"), diffsptk.LPC(400, 24, device="cuda"))(x)
+                                        # lpc(window(frame(x))): one launch forward, one launch backward
 """
 from . import functional
 from .graph import Graphed

@@ -482,6 +482,14 @@ __device__ __forceinline__ void lp_split2(float x0, float x1, lp_h2& hi, lp_h2& 
     lo = __builtin_bit_cast(lp_h2, lb);
 }
 
+// The scatter area of a frame: lag rows kLsDS floats apart + a dump row.  kLsDS = 23: with lag = 16 s + j - (4 g + r) and slot
+// i = 4 g + r the 64 lanes of a store hit bank (23 j + 8 g + const) mod 32 -- two lanes per bank, the floor for 256 bytes -- where
+// the 16-byte aligned stride 20 of round 4 put (j + g) mod 8 classes, i.e. eight lanes, on one bank; entries whose lag is outside
+// [0, 24] go to a per-lane dump slot instead of all onto row 25's four addresses (sixteen lanes on one address).  Rows are read
+// back as 16-byte accesses at 4-byte alignment.  (round-4 review: lds_conflict_frac 0.49 in this kernel)
+constexpr int kLsDS = 23;
+constexpr int kLsArea = ((26 * kLsDS + 3) & ~3) + 64;   // floats per frame of a round: 26 rows (25 = never written, read by idle lanes) + dump
+typedef float lp_f4a4 __attribute__((ext_vector_type(4), aligned(4)));
 #ifndef LPC_ABL
 #define LPC_ABL 0   // measurement builds only (tools/gpu_abl_lpc.sh): 1 no recursion, 2 no scatter / sums, 4 no products, 8 no maximum / scale
 #endif
@@ -492,13 +500,13 @@ __global__ __launch_bounds__(256, 3) void frame_window_lpc24_mfma_kernel(
 {
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef _Float16 lp_h8 __attribute__((ext_vector_type(8)));
-    constexpr int DS = 20;                         // floats per lag row of the scatter area (16 slots, 16-byte aligned rows)
+    constexpr int DS = kLsDS;                      // floats per lag row of the scatter area (see kLsDS)
     // dynamic LDS, per wave: rbuf[fpi][25] doubles | dm[2][26][DS] floats (a scatter area per frame of a round)  (fpi = 40 at the bench
     // geometry: three workgroups per CU)
     extern __shared__ __attribute__((aligned(16))) unsigned char lpc_smem[];
     const int L = LC ? LC : L_rt;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int wave_bytes = fpi * kLpcM1 * (int)sizeof(double) + 2 * 26 * DS * (int)sizeof(float);
+    const int wave_bytes = fpi * kLpcM1 * (int)sizeof(double) + 2 * kLsArea * (int)sizeof(float);
     double* rbuf = reinterpret_cast<double*>(lpc_smem + (size_t)wave * wave_bytes);
     float* dm = reinterpret_cast<float*>(rbuf + fpi * kLpcM1);
     const int j = lane & 15, g = lane >> 4;
@@ -523,7 +531,7 @@ __global__ __launch_bounds__(256, 3) void frame_window_lpc24_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * g + r, lag = 16 * s_ + j - i;
-            addr[s_][r] = ((lag >= 0 && lag < kLpcM1) ? lag : kLpcM1) * DS + i;
+            addr[s_][r] = (lag >= 0 && lag < kLpcM1) ? lag * DS + i : kLsArea - 64 + lane;
         }
     // Items are dealt out statically, item = wave + k (number of waves), unless a counter is given (queue != NULL: tickets).  With
     // the ticket counter every item and every wave's exit was an atomic on ONE address -- 5120 + 3072 of them per launch at the
@@ -679,9 +687,9 @@ __global__ __launch_bounds__(256, 3) void frame_window_lpc24_mfma_kernel(
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    dm[u * 26 * DS + addr[0][r]] = c1[u][r];
-                    dm[u * 26 * DS + addr[1][r]] = c2[u][r];
-                    dm[u * 26 * DS + addr[2][r]] = c3[u][r];
+                    dm[u * kLsArea + addr[0][r]] = c1[u][r];
+                    dm[u * kLsArea + addr[1][r]] = c2[u][r];
+                    dm[u * kLsArea + addr[2][r]] = c3[u][r];
                 }
             __builtin_amdgcn_wave_barrier();
             {
@@ -691,7 +699,7 @@ __global__ __launch_bounds__(256, 3) void frame_window_lpc24_mfma_kernel(
                 double sm[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const f4* row = reinterpret_cast<const f4*>(dm + u * 26 * DS + (m_ < kLpcM1 ? m_ : kLpcM1) * DS + 8 * h_);
+                    const lp_f4a4* row = reinterpret_cast<const lp_f4a4*>(dm + u * kLsArea + (m_ < kLpcM1 ? m_ : kLpcM1) * DS + 8 * h_);
                     const f4 q0 = row[0], q1 = row[1];
                     sm[u] = ((double)q0[0] + (double)q0[1]) + ((double)q0[2] + (double)q0[3]);
                     sm[u] += ((double)q1[0] + (double)q1[1]) + ((double)q1[2] + (double)q1[3]);
@@ -994,7 +1002,7 @@ typedef float lp_f4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int kLbRow = 26;          // doubles per frame row of rbuf: 25 lag sums (then: 25 scaled taps as floats, their shift) | the samples' shift
 constexpr int kLbRing = 1024;       // floats of the overlap-add ring (frame_length + frame_period <= 1024)
 constexpr int kLbOps = 2 * 640 + 2 * 128;   // binary16 values of one operand set of phase C
-constexpr int kLbAreaBytes = 2 * kLbOps * 2 > 2 * 26 * 20 * 4 ? 2 * kLbOps * 2 : 2 * 26 * 20 * 4;
+constexpr int kLbAreaBytes = 2 * kLbOps * 2 > 2 * kLsArea * 4 ? 2 * kLbOps * 2 : 2 * kLsArea * 4;
 __host__ __device__ inline long lb_floordiv(long a, long b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
 template <int LC>
@@ -1005,7 +1013,7 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_bwd_mfma_kernel(
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef _Float16 lp_h8 __attribute__((ext_vector_type(8)));
     typedef unsigned lp_u4 __attribute__((ext_vector_type(4)));
-    constexpr int DS = 20;
+    constexpr int DS = kLsDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
     const int L = LC ? LC : L_rt;
     const int lane = threadIdx.x;
@@ -1046,7 +1054,7 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_bwd_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 4 * g + r, lag = 16 * s_ + j - i;
-            addr[s_][r] = ((lag >= 0 && lag < kLpcM1) ? lag : kLpcM1) * DS + i;
+            addr[s_][r] = (lag >= 0 && lag < kLpcM1) ? lag * DS + i : kLsArea - 64 + lane;
         }
 
     for (int q = lane; q < kLbRing / 4; q += 64) reinterpret_cast<f4*>(ring)[q] = f4{0.f, 0.f, 0.f, 0.f};   // (every flush leaves its slots zero)
@@ -1172,9 +1180,9 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_bwd_mfma_kernel(
                 for (int u = 0; u < U; ++u)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        dm[u * 26 * DS + addr[0][r]] = c1[u][r];
-                        dm[u * 26 * DS + addr[1][r]] = c2[u][r];
-                        dm[u * 26 * DS + addr[2][r]] = c3[u][r];
+                        dm[u * kLsArea + addr[0][r]] = c1[u][r];
+                        dm[u * kLsArea + addr[1][r]] = c2[u][r];
+                        dm[u * kLsArea + addr[2][r]] = c3[u][r];
                     }
                 __builtin_amdgcn_wave_barrier();
                 {
@@ -1182,7 +1190,7 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_bwd_mfma_kernel(
                     double sm[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const f4* row = reinterpret_cast<const f4*>(dm + u * 26 * DS + (m_ < kLpcM1 ? m_ : kLpcM1) * DS + 8 * h_);
+                        const lp_f4a4* row = reinterpret_cast<const lp_f4a4*>(dm + u * kLsArea + (m_ < kLpcM1 ? m_ : kLpcM1) * DS + 8 * h_);
                         const f4 q0 = row[0], q1 = row[1];
                         sm[u] = ((double)q0[0] + (double)q0[1]) + ((double)q0[2] + (double)q0[3]);
                         sm[u] += ((double)q1[0] + (double)q1[1]) + ((double)q1[2] + (double)q1[3]);
@@ -1664,18 +1672,18 @@ DSA_EXPORT int dsa_frame_window_lpc_fwd(const void* x, int64_t B, int64_t T, int
             if ((exact || tickets) && !scratch_clean && hipMemsetAsync(queue, 0, sizeof(unsigned), st) != hipSuccess)
                 return fail(DSA_ERR_LAUNCH, "frame_window_lpc: cannot reset the ticket counter%s");
             if (!exact && L <= 512) {
-                // three workgroups per CU need 4 (200 fpi + 4160) <= 53 KB: at most 47 frames per item, utterances split evenly.
+                // three workgroups per CU need 4 (200 fpi + 5312) <= 53 KB: at most 41 frames per item, utterances split evenly.
                 // (Tried: frames per item chosen so that every one of the 3072 resident waves gets the same number of items -- 34
                 // frames, 6144 items at the bench size instead of 40 / 5120: 0.135 -> 0.140 ms; more recursion phases on fewer lanes.)
-                if (fpi > 47) {
-                    const long cpu = (N + 46) / 47;
+                if (fpi > 41) {
+                    const long cpu = (N + 40) / 41;
                     long f = ((N + cpu - 1) / cpu + 3) & ~3L;
-                    if (f > 47) f = 44;
+                    if (f > 41) f = 40;
                     fpi = (int)f;
                     sc_per_utt = (int)((N + fpi - 1) / fpi);
                     total_sc = (long)B * sc_per_utt;
                 }
-                const int lds_m = 4 * (fpi * kLpcM1 * (int)sizeof(double) + 2 * 26 * 20 * (int)sizeof(float));
+                const int lds_m = 4 * (fpi * kLpcM1 * (int)sizeof(double) + 2 * kLsArea * (int)sizeof(float));
                 long wgs = (total_sc + 3) / 4;
                 const long wg_cap = 256L * (lds_m <= 53 * 1024 ? 3 : 2);   // workgroups of four waves per CU
                 if (wgs > wg_cap) wgs = wg_cap;

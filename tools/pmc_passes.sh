@@ -12,6 +12,7 @@ if [ "${2:-fwd}" = "bwd" ]; then CMD="python $GRAFT_REPO_ROOT/tools/run_mcep_bwd
 if [ "${2:-fwd}" = "fused" ]; then CMD="python $GRAFT_REPO_ROOT/tools/run_fused_only.py"; fi
 if [ "${2:-fwd}" = "fusedmcep" ]; then CMD="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --ramp-seconds 0 --no-cpu-baseline --no-configs --path fused"; fi
 if [ "${2:-fwd}" = "lpc" ]; then CMD="python $GRAFT_REPO_ROOT/tools/run_lpc_only.py"; fi
+if [ "${2:-fwd}" = "lpcbwd" ]; then CMD="python $GRAFT_REPO_ROOT/tools/run_lpc_bwd_only.py"; fi
 if [ "${2:-fwd}" = "mlsa" ]; then CMD="python $GRAFT_REPO_ROOT/tools/run_mlsa_multistage_only.py"; fi
 if [ "${2:-fwd}" = "stftbwd" ]; then CMD="env N=6 SMALL=0 python $GRAFT_REPO_ROOT/tools/run_stft_bwd_only.py"; fi
 i=0
