@@ -569,8 +569,10 @@ static unsigned int* reset_queue(void* scratch, hipStream_t st, int words = 2)
 // `sti`: NULL (spectra in X) or the waveform side of the fused STFT -> mel-cepstrum launch (X is then unused)
 int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E, const void* av,
                   const void* images, void* scratch, void* mc, void* hist, hipStream_t st, bool scratch_clean = false,
-                  const StftIn* sti = nullptr)
+                  const StftIn* sti = nullptr, bool hist_has_rt = false)
 {
+    // DSA_ALGO_HIST_HAS_RT: the caller's history buffer continues behind the (n_iter + 1, F, 25) iterates with (n_iter, F, 49) rows of rt
+    float* hist_rt = (hist && hist_has_rt) ? (float*)hist + (size_t)(n_iter + 1) * (size_t)F * mm::M1 : nullptr;
     constexpr int WAVES = 8;
     const int lds_bytes = (sti ? mh::h_lds_floats_fused(WAVES) : mh::h_lds_floats(WAVES)) * 4;
     static std::atomic<uint64_t> attr_devices{0}, attr_devices_fused{0};
@@ -590,19 +592,19 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
     if (sti) {
         hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES, true>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
                            (const float*)nullptr, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
-                           (const float*)av, (float*)mc, (float*)hist, ntiles16, tiles_shared, queue, (const _Float16*)images, *sti);
+                           (const float*)av, (float*)mc, (float*)hist, ntiles16, tiles_shared, queue, (const _Float16*)images, *sti, hist_rt);
         return check_launch("stft512_mcep_fused_fwd");
     }
     hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES, false>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
                        (const float*)X, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
-                       (const float*)av, (float*)mc, (float*)hist, ntiles16, tiles_shared, queue, (const _Float16*)images, StftIn{});
+                       (const float*)av, (float*)mc, (float*)hist, ntiles16, tiles_shared, queue, (const _Float16*)images, StftIn{}, hist_rt);
     return check_launch("mcep_mfma_fwd");
 }
 
 // STFT (frame length 400, fft_length 512, power format, constant padding) -> MelCepstralAnalysis (cep_order 24) in one launch
 int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, const void* window, const void* twiddle, double eps,
                         int n_iter, const void* G, const void* D, const void* E, const void* av, const void* images, void* scratch,
-                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean)
+                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean, bool hist_has_rt)
 {
     const int64_t N = T <= 0 ? 0 : (T - 1) / P + 1;
     StftIn sti;
@@ -615,12 +617,13 @@ int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, 
     sti.twiddle = (const float*)twiddle;
     sti.eps = (float)eps;
     sti.X_out = (float*)X_out;
-    return mcep_mfma_fwd(nullptr, B * N, n_iter, G, D, E, av, images, scratch, mc, hist, st, scratch_clean, &sti);
+    return mcep_mfma_fwd(nullptr, B * N, n_iter, G, D, E, av, images, scratch, mc, hist, st, scratch_clean, &sti, hist_has_rt);
 }
 
 int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* av,
-                  const void* images, void* scratch, void* gX, hipStream_t st, bool has_workspace = false)
+                  const void* images, void* scratch, void* gX, hipStream_t st, bool has_workspace = false, bool hist_has_rt = false)
 {
+    const float* hist_rt = hist_has_rt ? (const float*)hist + (size_t)(n_iter + 1) * (size_t)F * mm::M1 : nullptr;
 #ifdef DSA_MCEP_BWD_PAIR_EXPERIMENT
     // round-5 experiment: pairs of waves that split the bins of a tile, two waves per SIMD (2.9 ms against 1.57: not adopted)
     static const bool pair_on = [] { const char* e = getenv("DSA_MCEP_BWD_PAIR"); return !(e && e[0] == '0'); }();
@@ -639,7 +642,7 @@ int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, i
 #endif
     const int lds_bytes = mhb::B_LDS_FLOATS * 4;
     static std::atomic<uint64_t> attr_devices{0};
-    if (!ensure_dynamic_lds((const void*)mcep_mfma_bwd_kernel_h, lds_bytes, attr_devices))
+    if (!ensure_dynamic_lds((const void*)mcep_mfma_bwd_kernel_h<false>, lds_bytes, attr_devices))
         return fail(DSA_ERR_LAUNCH, "mcep_mfma_bwd: cannot reserve the LDS operand images%s");
     unsigned int* queue = reset_queue(scratch, st, 13);
     if (!queue) return fail(DSA_ERR_LAUNCH, "mcep_mfma_bwd: cannot reset the tile queue%s");
@@ -659,10 +662,20 @@ int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, i
         split_tiles = (int)rest;
         split_pieces = (int)pieces;
     }
-    hipLaunchKernelGGL(mcep_mfma_bwd_kernel_h, dim3((unsigned)grid), dim3(256), lds_bytes, st, (const float*)gmc,
+    if (hist_rt) {
+        static std::atomic<uint64_t> attr_rt{0};
+        if (!ensure_dynamic_lds((const void*)mcep_mfma_bwd_kernel_h<true>, lds_bytes, attr_rt))
+            return fail(DSA_ERR_LAUNCH, "mcep_mfma_bwd: cannot reserve the LDS operand images%s");
+        hipLaunchKernelGGL(mcep_mfma_bwd_kernel_h<true>, dim3((unsigned)grid), dim3(256), lds_bytes, st, (const float*)gmc,
+                           (const float*)X, (const float*)hist, (long)F, n_iter, (const float*)av, (float*)gX, ntiles16, queue,
+                           (const _Float16*)images, split_tiles, split_pieces,
+                           reinterpret_cast<float*>(static_cast<char*>(scratch) + DSA_SCRATCH_BYTES), hist_rt);
+        return check_launch("mcep_mfma_bwd");
+    }
+    hipLaunchKernelGGL(mcep_mfma_bwd_kernel_h<false>, dim3((unsigned)grid), dim3(256), lds_bytes, st, (const float*)gmc,
                        (const float*)X, (const float*)hist, (long)F, n_iter, (const float*)av, (float*)gX, ntiles16, queue,
                        (const _Float16*)images, split_tiles, split_pieces,
-                       reinterpret_cast<float*>(static_cast<char*>(scratch) + DSA_SCRATCH_BYTES));
+                       reinterpret_cast<float*>(static_cast<char*>(scratch) + DSA_SCRATCH_BYTES), (const float*)nullptr);
     return check_launch("mcep_mfma_bwd");
 }
 

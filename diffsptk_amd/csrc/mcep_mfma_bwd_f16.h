@@ -96,10 +96,13 @@ __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo
     }
 }
 
+// SAVED_RT (round 5): the forward kept every step's rt row (DSA_ALGO_HIST_HAS_RT, `hist_rt`: (n_iter, F, 49)); the step then loads it
+// into the windows instead of re-running the second forward chain (72 binary16 products, the split of e, 27 image reads per step).
+template <bool SAVED_RT>
 __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
     const float* __restrict__ gmc, const float* __restrict__ X, const float* __restrict__ hist, long F, int n_iter,
     const float* __restrict__ av, float* gX, long ntiles16, unsigned int* __restrict__ queue,
-    const _Float16* __restrict__ img, int split_tiles, int split_pieces, float* ws)
+    const _Float16* __restrict__ img, int split_tiles, int split_pieces, float* ws, const float* __restrict__ hist_rt)
 {
     using namespace mhb;
     constexpr float kNeg2Log2e = -2.885390081777926815f;
@@ -278,6 +281,17 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             for (int c = 0; c < KS; ++c) gh[c] = h1_n[c] - h0_n[c];
             gh[KS - 1] = keep_if(gq.m[0], gh[KS - 1]);   // k = 24 on lane 0 only
             if (iter > 0) load_step(iter - 1);
+            // SAVED_RT: this step's rt row, rt[16 it + 4 g + r] of this lane's frame, requested here -- behind the next step's
+            // history requests, whose address reloads wait for everything in flight -- and consumed behind the first chain
+            // (held a whole step ahead like the iterates, its 13 registers spilled: 1.61 ms against 1.57 without the saved row)
+            f32x4 rt_c4[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            float rt48_c = 0.f;
+            if (SAVED_RT) {
+                const float* hr = hist_rt + ((long)iter * F + f) * M2 + 4 * g;
+#pragma unroll
+                for (int it = 0; it < 3; ++it) rt_c4[it] = *reinterpret_cast<const f32x4_u4*>(hr + 16 * it);
+                rt48_c = hist_rt[((long)iter * F + f) * M2 + 48];
+            }
             // ---------------- forward quantities of this step: e (kept, scaled by 2^sh), rt -> LDS windows ----------------
             f16x8 bh, bl;
             {
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
                 }
                 auto prodE = [&](int i) __attribute__((always_inline)) {   // i = 3 term + it
 #ifndef DSA_BWD_ABL_NOCHAIN2
-                    if (j > 0) {
+                    if (!SAVED_RT && j > 0) {
                         const int it = i % 3, term = i / 3;
                         accB[it] = mfma_h(term == 0 ? eal[it] : eah[it], term == 1 ? el_p : eh_p, accB[it]);
                     }
@@ -406,11 +420,11 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
                     for (int it = 0; it < 3; ++it) eal[it] = EL[(it * 8 + j) * 64];
                 }
                 DSA_SB(); if (vw) vecD(0); DSA_SB();
-                prodE(3); DSA_SB(); if (vw) vecE(0, 0); DSA_SB();
+                prodE(3); DSA_SB(); if (vw && !SAVED_RT) vecE(0, 0); DSA_SB();
                 prodE(4); DSA_SB(); if (vw) vecD(1); DSA_SB();
-                prodE(5); DSA_SB(); if (vw) vecE(0, 2); DSA_SB();
-                prodE(6); DSA_SB(); if (vw) vecE(1, 0); DSA_SB();
-                prodE(7); DSA_SB(); if (vw) vecE(1, 2); DSA_SB();
+                prodE(5); DSA_SB(); if (vw && !SAVED_RT) vecE(0, 2); DSA_SB();
+                prodE(6); DSA_SB(); if (vw && !SAVED_RT) vecE(1, 0); DSA_SB();
+                prodE(7); DSA_SB(); if (vw && !SAVED_RT) vecE(1, 2); DSA_SB();
                 prodE(8); DSA_SB();
                 eh_p = eh; el_p = el;
 #pragma unroll
@@ -419,6 +433,7 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
             BSTAMP(7);
             rt48 = __builtin_fmaf(e256, lds[B_E256 + 48], rt48);
             rt48 = __builtin_ldexpf(rt48, back);
+            if (SAVED_RT) rt48 = rt48_c;
             {
                 int g_it = g;
                 asm volatile("" : "+v"(g_it));
@@ -430,15 +445,15 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
                 const int bk = back - SE_LOG2;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v0 = __builtin_ldexpf(accB[0][r], bk);
-                    const float v1 = __builtin_ldexpf(accB[1][r], bk);
+                    const float v0 = SAVED_RT ? rt_c4[0][r] : __builtin_ldexpf(accB[0][r], bk);
+                    const float v1 = SAVED_RT ? rt_c4[1][r] : __builtin_ldexpf(accB[1][r], bk);
                     rtw[r] = v0;
                     rra[r] = v0;
                     rrb[-r] = v0;
                     rtw[16 + r] = v1;
                     rra1[r] = v1;
                     rrb1[-r] = v1;
-                    rtw[32 + r] = __builtin_ldexpf(accB[2][r], bk);
+                    rtw[32 + r] = SAVED_RT ? rt_c4[2][r] : __builtin_ldexpf(accB[2][r], bk);
                 }
                 rt_n[48] = rt48;
                 // mbar to the exchange window (C/D layout writer -> quad-layout reader)

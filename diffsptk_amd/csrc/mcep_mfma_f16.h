@@ -206,8 +206,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
     const float* __restrict__ X, long F, int n_iter, const float* __restrict__ G,
     const float* __restrict__ D, const float* __restrict__ E, const float* __restrict__ av,
     float* __restrict__ mc_out, float* __restrict__ hist, long ntiles16, long tiles_shared,
-    unsigned int* __restrict__ queue, const _Float16* __restrict__ img, StftIn sti)
+    unsigned int* __restrict__ queue, const _Float16* __restrict__ img, StftIn sti, float* __restrict__ hist_rt)
 {
+    // hist_rt (round 5; NULL or (n_iter, F, 49)): every step's rt = e E row, kept for the backward, which then skips its own second
+    // forward chain (DSA_ALGO_HIST_HAS_RT; 196 more bytes per frame and step)
     using namespace mh;
     constexpr float kNeg2Log2e = -2.885390081777926815f, kLn2 = 0.693147180559945309f;
     constexpr float kInvSDM = 1.f / (SD * SM);
@@ -797,6 +799,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                     rtw[32 + r] = __builtin_ldexpf(accB[2][r], bk);
                 }
                 rt_lds[48] = rt48;  // same value on the four lanes of a frame
+                if (hist_rt && f_ok) {   // (uniform per launch) the row as the backward's windows want it: lane (n, g) owns rt[16 it + 4 g + r]
+                    float* hr = hist_rt + ((long)iter * F + f) * M2 + 4 * g_it;
+#pragma unroll
+                    for (int it = 0; it < 3; ++it)
+                        *reinterpret_cast<f32x4_u4*>(hr + 16 * it) = f32x4_u4{__builtin_ldexpf(accB[it][0], bk), __builtin_ldexpf(accB[it][1], bk),
+                                                                            __builtin_ldexpf(accB[it][2], bk), __builtin_ldexpf(accB[it][3], bk)};
+                    if (g_it == 0) hr[48] = rt48;
+                }
             }
             __builtin_amdgcn_wave_barrier();
             DSA_STAMP(2);

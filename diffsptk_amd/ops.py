@@ -970,6 +970,13 @@ def _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter):
     return mc.reshape(*lead, M1)
 
 
+def _mcep_history(n_iter, F, M, like, with_rt):
+    """The Newton history a gradient needs: (n_iter + 1, F, M + 1) iterates, followed -- for the tuned kernels (with_rt) -- by the
+    (n_iter, F, 2 M + 1) rows of rt that let the backward skip its second forward chain (DSA_ALGO_HIST_HAS_RT).  One flat buffer."""
+    n = (n_iter + 1) * F * (M + 1) + (n_iter * F * (2 * M + 1) if with_rt else 0)
+    return torch.empty(n, device=like.device, dtype=like.dtype)
+
+
 def _mcep_scratch(device):
     """(scratch, algo flag) of a tuned mel-cepstral forward launch: the per-(device, stream) kept-zero counters
     (DSA_ALGO_SCRATCH_IS_CLEAN, no fill launch per call) -- except while a HIP graph is being captured: a graph replays on whatever
@@ -1010,12 +1017,15 @@ class StftMcepFn(torch.autograd.Function):
         F = B * N
         need_grad = ctx.needs_input_grad[0]
         mc = torch.empty(*xc.shape[:-1], N, M + 1, device=x.device, dtype=x.dtype)
-        hist = torch.empty(n_iter + 1, F, M + 1, device=x.device, dtype=x.dtype) if need_grad else None
+        with_rt = need_grad and os.environ.get("DSA_MCEP_HIST_RT", "1") != "0"
+        hist = _mcep_history(n_iter, F, M, x, with_rt) if need_grad else None
         X = torch.empty(*xc.shape[:-1], N, K, device=x.device, dtype=x.dtype) if need_grad else None
         images = mcep_images(G, D, E, fft_length, M)
         if images is None:
             raise _lib.BackendError("stft_mcep: no tuned kernel for this configuration (check stft_mcep_fusable first)")
         scratch, flag = _mcep_scratch(x.device)
+        if with_rt:
+            flag |= _lib.ALGO_HIST_HAS_RT
         with torch.cuda.device(x.device):
             _call("dsa_stft_mcep_fwd", _p(xc), B, T, L, P, fft_length, _p(wc), _p(twiddle), int(center), float(eps), M, n_iter,
                   _p(G), _p(D), _p(E), _p(av), _dtype_code(xc), _lib.ALGO_AUTO | flag, _p(images), _p(scratch), _p(mc), _p(hist),
@@ -1024,6 +1034,7 @@ class StftMcepFn(torch.autograd.Function):
             ctx.save_for_backward(xc, wc, twiddle, X, hist, G, D, E, av)
         ctx.cfg = (L, P, fft_length, center, eps, M, n_iter)
         ctx.images = images
+        ctx.with_rt = with_rt
         return mc
 
     @staticmethod
@@ -1041,7 +1052,8 @@ class StftMcepFn(torch.autograd.Function):
         scratch = torch.empty(_lib.MCEP_BWD_WORKSPACE_BYTES, dtype=torch.uint8, device=gmc.device)
         with torch.cuda.device(gmc.device):
             _call("dsa_mcep_bwd", _p(gmc), _p(X), _p(hist), F, fft_length, M, n_iter, _p(G), _p(D), _p(E), _p(av),
-                  _dtype_code(X), _lib.ALGO_AUTO | _lib.ALGO_SCRATCH_HAS_WORKSPACE, _p(ctx.images), _p(scratch), _p(gX), _stream())
+                  _dtype_code(X), _lib.ALGO_AUTO | _lib.ALGO_SCRATCH_HAS_WORKSPACE | (_lib.ALGO_HIST_HAS_RT if ctx.with_rt else 0),
+                  _p(ctx.images), _p(scratch), _p(gX), _stream())
             _call("dsa_stft_bwd", _p(gX), _p(xc), B, T, L, P, fft_length, _p(wc), _p(twiddle), int(center), 0,
                   pad_mode_code("constant"), float(eps), 0, 0.0, 3, _dtype_code(xc), _lib.ALGO_AUTO, _p(gx), None, _stream())
         return (gx,) + (None,) * 13
@@ -1059,15 +1071,19 @@ class McepFn(torch.autograd.Function):
         F = Xc.numel() // K
         mc = torch.empty(*Xc.shape[:-1], M + 1, device=X.device, dtype=X.dtype)
         need_hist = ctx.needs_input_grad[0]
-        hist = torch.empty(n_iter + 1, F, M + 1, device=X.device, dtype=X.dtype) if need_hist else None
         images = mcep_images(G, D, E, fft_length, M) if algo != _lib.ALGO_GENERIC else None
         if images is None and not need_hist and algo != _lib.ALGO_GENERIC and _mcep_composed_applies(Xc, M):
             return _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter)
+        # the tuned kernels keep every step's rt row next to the iterates (DSA_ALGO_HIST_HAS_RT): the backward skips a chain
+        with_rt = need_hist and images is not None and os.environ.get("DSA_MCEP_HIST_RT", "1") != "0"
+        hist = _mcep_history(n_iter, F, M, X, with_rt) if need_hist else None
         # the tile queue's counters: a per-(device, stream) scratch that the kernel leaves zeroed (no fill launch per call)
         scratch = None
         flag = 0
         if images is not None:
             scratch, flag = _mcep_scratch(X.device)
+        if with_rt:
+            flag |= _lib.ALGO_HIST_HAS_RT
         with torch.cuda.device(X.device):
             _call("dsa_mcep_fwd", _p(Xc), F, fft_length, M, n_iter, _p(G), _p(D), _p(E), _p(av),
                   _dtype_code(Xc), algo | flag, _p(images), _p(scratch), _p(mc), _p(hist), _stream())
@@ -1075,6 +1091,7 @@ class McepFn(torch.autograd.Function):
             ctx.save_for_backward(Xc, hist, G, D, E, av)
         ctx.cfg = (fft_length, M, n_iter, algo)
         ctx.images = images
+        ctx.with_rt = with_rt
         return mc
 
     @staticmethod
@@ -1092,7 +1109,7 @@ class McepFn(torch.autograd.Function):
         scratch, flag = None, 0
         if images is not None:
             scratch = torch.empty(_lib.MCEP_BWD_WORKSPACE_BYTES, dtype=torch.uint8, device=gmc.device)
-            flag = _lib.ALGO_SCRATCH_HAS_WORKSPACE
+            flag = _lib.ALGO_SCRATCH_HAS_WORKSPACE | (_lib.ALGO_HIST_HAS_RT if ctx.with_rt else 0)
         with torch.cuda.device(gmc.device):
             _call("dsa_mcep_bwd", _p(gmc), _p(Xc), _p(hist), F, fft_length, M, n_iter, _p(G), _p(D), _p(E),
                   _p(av), _dtype_code(Xc), algo | flag, _p(images), _p(scratch), _p(gX), _stream())

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 124 /* 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
+#define DSA_VERSION 124 /* 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
@@ -79,6 +79,11 @@ enum { DSA_ALGO_AUTO = 0, DSA_ALGO_GENERIC = 1, DSA_ALGO_TUNED = 2 };
  * slot ends the launch busy (3 200 tiles on 1 024 slots: 3.3 rounds instead of 4).  Without the flag: DSA_SCRATCH_BYTES, no split. */
 #define DSA_ALGO_SCRATCH_HAS_WORKSPACE 0x200
 #define DSA_MCEP_BWD_WORKSPACE_BYTES (DSA_SCRATCH_BYTES + 512 * 16 * 32 * 4)
+/* OR-ed into `algo` of dsa_mcep_fwd / dsa_stft_mcep_fwd / dsa_mcep_bwd (0.1.8): `mc_hist` continues behind the (n_iter + 1, F, M + 1)
+ * iterates with (n_iter, F, 2 M + 1) float32 rows -- every Newton step's rt = e E (mcep.py:212-215).  The tuned forward writes them, the
+ * tuned backward reads them instead of recomputing its second forward chain (1.55 -> 1.4 ms per 204 800 frames for 196 more bytes per
+ * frame and step).  Both calls of a pair must agree on the flag; the generic kernels ignore the extra room. */
+#define DSA_ALGO_HIST_HAS_RT 0x400
 
 int dsa_version(void);
 const char* dsa_last_error(void);

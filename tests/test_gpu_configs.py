@@ -492,6 +492,36 @@ def test_mcep_backward_split_tail_is_bit_identical_to_whole_tiles(tail_tiles, ta
     assert torch.equal(g_all[:4096], grad(X[:4096]))
 
 
+def test_mcep_backward_with_the_saved_rt_rows_equals_the_recomputing_backward(monkeypatch):
+    """DSA_ALGO_HIST_HAS_RT (round 5): the tuned forward keeps every step's rt = e E row behind the iterates and the tuned backward
+    loads it instead of re-running its second forward chain.  The row IS what the forward's solve used, so the gradient may differ
+    from the recomputing backward only by the rounding of that chain: both against each other (1e-6 of the row maximum) and against
+    the float64 autograd of the ATen port on sampled frames; both entries (spectrogram in, waveform in), ragged frame count."""
+    stft, mcep = _modules()
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(37, 5000, generator=gen).to(DEV)
+    w = torch.randn(25, generator=gen).to(DEV)
+    fused = dsp.fuse(stft, mcep)
+
+    def grads():
+        X = stft(x).detach().requires_grad_(True)
+        (mcep(X) * w).sum().backward()
+        xg = x.clone().requires_grad_(True)
+        (fused(xg) * w).sum().backward()
+        return X.grad, xg.grad
+
+    gX1, gx1 = grads()
+    monkeypatch.setenv("DSA_MCEP_HIST_RT", "0")
+    gX0, gx0 = grads()
+    monkeypatch.delenv("DSA_MCEP_HIST_RT")
+    assert float((gX1 - gX0).abs().max()) <= 1e-6 * float(gX0.abs().max())
+    assert float((gx1 - gx0).abs().max()) <= 1e-6 * float(gx0.abs().max())
+    tab = TP.McepTables(512, 24, 0.42, torch.float64)
+    xs = x[[0, 36]].double().cpu().requires_grad_(True)
+    (TP.stft_mcep(xs, tab) * w.double().cpu()).sum().backward()
+    assert float((gx1[[0, 36]].double().cpu() - xs.grad).abs().max()) <= 3e-6 * float(xs.grad.abs().max())
+
+
 def test_hot_path_and_f_rows_replay_from_a_hip_graph():
     """The launches of the analysis (STFT -> mcep), of the mel-generalized analysis and of the multi-stage MLSA filter are plain
     asynchronous launches on the current stream with caller-owned workspaces, so a whole call can be captured in a HIP graph
