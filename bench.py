@@ -870,7 +870,7 @@ def main():
                           "source": "profiles/r03_power_probe.txt (static: tools/power_probe.sh, rocm-smi while the kernel loops)",
                           "note": "both headline kernels run at the socket's power cap; the kernel's cycle counter averages "
                                   "1.99-2.09 GHz over a launch, so the nominal-clock peak above is not reachable"},
-            })(datapath_roofline(isa_mix("mcep_mfma_fwd_kernel_hILi8ELb1" if args.path == "fused" else "mcep_mfma_fwd_kernel_hILi8ELb0"), N_ITER, frames_launch, t_mcep)),
+            })(datapath_roofline(isa_mix("mcep_mfma_fwd_kernel_hILi8ELb1ELb0" if args.path == "fused" else "mcep_mfma_fwd_kernel_hILi8ELb0ELb0"), N_ITER, frames_launch, t_mcep)),
             "roofline_stft": {
                 "kernel": k_stft, "bound": "hbm",
                 "achieved": STFT_BYTES_PER_FRAME * frames_launch / t_stft / 1e9,

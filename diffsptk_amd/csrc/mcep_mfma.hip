@@ -575,9 +575,11 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
     float* hist_rt = (hist && hist_has_rt) ? (float*)hist + (size_t)(n_iter + 1) * (size_t)F * mm::M1 : nullptr;
     constexpr int WAVES = 8;
     const int lds_bytes = (sti ? mh::h_lds_floats_fused(WAVES) : mh::h_lds_floats(WAVES)) * 4;
-    static std::atomic<uint64_t> attr_devices{0}, attr_devices_fused{0};
-    if (!(sti ? ensure_dynamic_lds((const void*)mcep_mfma_fwd_kernel_h<WAVES, true>, lds_bytes, attr_devices_fused)
-              : ensure_dynamic_lds((const void*)mcep_mfma_fwd_kernel_h<WAVES, false>, lds_bytes, attr_devices)))
+    static std::atomic<uint64_t> attr_devices{0}, attr_devices_fused{0}, attr_devices_rt{0}, attr_devices_fused_rt{0};
+    const bool rt = hist_rt != nullptr;
+    const void* kern = sti ? (rt ? (const void*)mcep_mfma_fwd_kernel_h<WAVES, true, true> : (const void*)mcep_mfma_fwd_kernel_h<WAVES, true, false>)
+                           : (rt ? (const void*)mcep_mfma_fwd_kernel_h<WAVES, false, true> : (const void*)mcep_mfma_fwd_kernel_h<WAVES, false, false>);
+    if (!ensure_dynamic_lds(kern, lds_bytes, sti ? (rt ? attr_devices_fused_rt : attr_devices_fused) : (rt ? attr_devices_rt : attr_devices)))
         return fail(DSA_ERR_LAUNCH, "mcep_mfma: cannot reserve the LDS operand images%s");
     long ntiles16 = (long)((F + 15) / 16);
     long blocks = (ntiles16 + WAVES - 1) / WAVES;
@@ -589,15 +591,18 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
     // see the ticket comment in the kernel: a short last round goes to one wave per SIMD pair
     const long slots = grid * WAVES, full = ntiles16 / slots * slots, rest = ntiles16 - full;
     const long tiles_shared = (full > 0 && rest > 0 && rest <= slots / 2) ? full : ntiles16;
+#define DSA_MCEP_FWD_LAUNCH(FU, RT, XPTR, STI)                                                                                       \
+    hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES, FU, RT>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st, (const float*)(XPTR), \
+                       (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E, (const float*)av, (float*)mc, (float*)hist,  \
+                       ntiles16, tiles_shared, queue, (const _Float16*)images, STI, hist_rt)
     if (sti) {
-        hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES, true>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
-                           (const float*)nullptr, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
-                           (const float*)av, (float*)mc, (float*)hist, ntiles16, tiles_shared, queue, (const _Float16*)images, *sti, hist_rt);
+        if (rt) DSA_MCEP_FWD_LAUNCH(true, true, nullptr, *sti);
+        else DSA_MCEP_FWD_LAUNCH(true, false, nullptr, *sti);
         return check_launch("stft512_mcep_fused_fwd");
     }
-    hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES, false>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st,
-                       (const float*)X, (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E,
-                       (const float*)av, (float*)mc, (float*)hist, ntiles16, tiles_shared, queue, (const _Float16*)images, StftIn{}, hist_rt);
+    if (rt) DSA_MCEP_FWD_LAUNCH(false, true, X, StftIn{});
+    else DSA_MCEP_FWD_LAUNCH(false, false, X, StftIn{});
+#undef DSA_MCEP_FWD_LAUNCH
     return check_launch("mcep_mfma_fwd");
 }
 

@@ -201,7 +201,8 @@ __device__ __forceinline__ void store_mc_row(float* row, int g, const float (&mc
     }
 }
 
-template <int WAVES, bool FUSED = false>
+template <int WAVES, bool FUSED = false, bool HIST_RT = false>   // HIST_RT: also keep every step's rt row (its own instantiation: the
+                                                                 // plain kernels' code and register allocation are untouched)
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
     const float* __restrict__ X, long F, int n_iter, const float* __restrict__ G,
     const float* __restrict__ D, const float* __restrict__ E, const float* __restrict__ av,
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                     rtw[32 + r] = __builtin_ldexpf(accB[2][r], bk);
                 }
                 rt_lds[48] = rt48;  // same value on the four lanes of a frame
-                if (hist_rt && f_ok) {   // (uniform per launch) the row as the backward's windows want it: lane (n, g) owns rt[16 it + 4 g + r]
+                if (HIST_RT && f_ok) {   // the row as the backward's windows want it: lane (n, g) owns rt[16 it + 4 g + r]
                     float* hr = hist_rt + ((long)iter * F + f) * M2 + 4 * g_it;
 #pragma unroll
                     for (int it = 0; it < 3; ++it)
