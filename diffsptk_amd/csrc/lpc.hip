@@ -1424,11 +1424,13 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_bwd_mfma_kernel(
                                 f4* slot = reinterpret_cast<f4*>(ring + ((q0 + l0) & (kLbRing - 1)));
                                 f4 cur = *slot;
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) cur[r] += __builtin_ldexpf(acc[u][nt][r], back[u]) * wo[nt][r];
+                                for (int r = 0; r < 4; ++r)   // (selected, not multiplied, past the frame: a non-finite frame stays inside its own samples)
+                                    cur[r] += wo[nt][r] != 0.f ? __builtin_ldexpf(acc[u][nt][r], back[u]) * wo[nt][r] : 0.f;
                                 *slot = cur;
                             } else {
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) ring[(q0 + l0 + r) & (kLbRing - 1)] += __builtin_ldexpf(acc[u][nt][r], back[u]) * wo[nt][r];
+                                for (int r = 0; r < 4; ++r)
+                                    ring[(q0 + l0 + r) & (kLbRing - 1)] += wo[nt][r] != 0.f ? __builtin_ldexpf(acc[u][nt][r], back[u]) * wo[nt][r] : 0.f;
                             }
                         }
                         __builtin_amdgcn_wave_barrier();
@@ -1727,9 +1729,9 @@ DSA_EXPORT int dsa_frame_window_lpc_bwd(const void* gout, const void* x, int64_t
                                         int32_t center, int32_t pad_mode, int32_t M, double eps, int32_t dtype, void* gx, void* stream)
 {
     DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0 && M >= 0 && M < L && eps >= 0, "frame_window_lpc_bwd: invalid sizes");
-    DSA_REQUIRE(gout && x && gx, "frame_window_lpc_bwd: null pointer");
     const int64_t N = dsa_num_frames(T, P);
     if (B * N == 0) return DSA_OK;
+    DSA_REQUIRE(gout && x && gx, "frame_window_lpc_bwd: null pointer");
     if (!(dtype == DSA_F32 && M == 24 && L >= 25 && L <= 512 && pad_mode == DSA_PAD_CONSTANT))
         return fail(DSA_ERR_UNSUPPORTED, "frame_window_lpc_bwd: the one-launch backward covers float32, lpc_order 24, 25 <= frame_length <= 512, constant padding%s");
     const int left = center ? L / 2 : 0;

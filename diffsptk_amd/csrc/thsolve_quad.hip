@@ -400,8 +400,11 @@ __device__ __forceinline__ void oct_backsub_all(const f32x4 (&a)[Oct<NG>::N], fl
 // LDS record of a system (floats): q window [0, QW), QW = 4 NG + 8 NCP - 1 (entry row + col, zeros from 2 n - 1 on) | p window
 // p[|d|] at PO + d, d in [-7, 8 NCP), PO = QW + 7 (slots below the diagonal are not built, but a block's views reach back 3) |
 // rhs at RO = PO + 8 NCP, 4 NG entries.  REC odd.
+#ifndef TQ_OCT_OCC
+#define TQ_OCT_OCC 2   // waves per SIMD of the octet kernel (A/B: 1 = 512 registers, no spills, half the residency)
+#endif
 template <int NG, int NMIN>
-__global__ __launch_bounds__(256, 2) void thsolve_octn_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ q, int ldq,
+__global__ __launch_bounds__(256, TQ_OCT_OCC) void thsolve_octn_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ q, int ldq,
                                                               const float* __restrict__ r, int ldr, const float* __restrict__ sub,
                                                               const float* add, long F, int n, float* g)   // (g may be add: dsa_mcep_newton_update in place)
 {

@@ -162,3 +162,39 @@ def test_exact_lag_sums_flag_on_a_near_singular_frame():
     ee = float((ye.double() - y64).abs().max())
     print(f"near-singular frames: matrix-pipe lag sums {ea:.3e}, exact lag sums {ee:.3e} from the float64 chain")
     assert ee <= ea + 1e-6 and ee < 5e-3
+
+
+def test_fused_lpc_nan_containment_and_empty_batch():
+    """a non-finite sample poisons the frames that contain it and the gradient of the samples those frames cover -- nothing else
+    (the per-frame power-of-two scales of the matrix-pipe products are taken with NaN-ignoring maxima); an empty batch is a no-op"""
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 8000, generator=gen).to(DEV)
+    gy = torch.randn(3, 100, 25, generator=gen).to(DEV)
+    fl = dsp.fuse(*_mods(400, 80))
+
+    def run(xs):
+        xg = xs.clone().requires_grad_(True)
+        y = fl(xg)
+        (y * gy).sum().backward()
+        return y.detach(), xg.grad
+
+    y0, g0 = run(x)
+    xb = x.clone()
+    xb[1, 4000] = float("nan")
+    y1, g1 = run(xb)
+    bad_frames = torch.isnan(y1).any(-1)
+    # frames n with 80 n - 200 <= 4000 < 80 n + 200: n = 48 .. 52 of utterance 1
+    assert bad_frames[1, 48:53].all() and int(bad_frames.sum()) == 5
+    ok = ~bad_frames
+    assert torch.equal(y1[ok], y0[ok])
+    bad_samples = torch.isnan(g1)
+    assert not bad_samples[0].any() and not bad_samples[2].any()
+    lo, hi = 48 * 80 - 200, 52 * 80 + 200
+    assert not bad_samples[1, :lo].any() and not bad_samples[1, hi:].any() and bad_samples[1, lo:hi].all()
+    assert torch.equal(g1[0], g0[0]) and torch.equal(g1[2], g0[2])
+    assert torch.equal(g1[1, :lo], g0[1, :lo]) and torch.equal(g1[1, hi:], g0[1, hi:])
+    xe = torch.zeros(0, 8000, device=DEV, requires_grad=True)
+    ye = fl(xe)
+    assert ye.shape == (0, 100, 25)
+    ye.sum().backward()
+    assert xe.grad.shape == (0, 8000)
