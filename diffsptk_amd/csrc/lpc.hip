@@ -1001,7 +1001,7 @@ typedef _Float16 lp_h8u __attribute__((ext_vector_type(8), aligned(2)));
 typedef float lp_f4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int kLbRow = 26;          // doubles per frame row of rbuf: 25 lag sums (then: 25 scaled taps as floats, their shift) | the samples' shift
 constexpr int kLbRing = 1024;       // floats of the overlap-add ring (frame_length + frame_period <= 1024)
-constexpr int kLbOps = 2 * 640 + 2 * 128;   // binary16 values of one operand set of phase C
+constexpr int kLbOps = 2 * 640 + 2 * 128;   // binary16 values of one operand set of phase C: XH | XL | EH | EL
 constexpr int kLbAreaBytes = 2 * kLbOps * 2 > 2 * kLsArea * 4 ? 2 * kLbOps * 2 : 2 * kLsArea * 4;
 __host__ __device__ inline long lb_floordiv(long a, long b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
@@ -1073,7 +1073,8 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_bwd_mfma_kernel(
         const float* xb = x + b * Tlen;
         __builtin_amdgcn_wave_barrier();
 #ifndef LPB_ABL
-#define LPB_ABL 0   // measurement builds only: 1 no lag sums, 2 no recursion, 4 no filter / overlap-add
+#define LPB_ABL 0   // measurement builds only: 1 no lag sums, 2 no recursion, 4 no filter / overlap-add, 8 taps read at an aligned address,
+                    // 16 no ring update / flush, 32 no matrix products
 #endif
         // ================= A: lag sums (the forward kernel's rounds of two frames) =================
         if (nfr > 0 && !(LPB_ABL & 1)) {
@@ -1320,6 +1321,11 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_bwd_mfma_kernel(
             };
             constexpr int U = 2;
             float c8[U][8];
+            // this lane's band offset into the taps (lane-constant), as the dword that holds its first tap + a funnel shift
+            typedef unsigned lp_u4a4 __attribute__((ext_vector_type(4), aligned(4)));
+            const int eoff = 16 + 8 * g - j;                 // >= 1
+            const unsigned* etap = reinterpret_cast<const unsigned*>(EH) + (eoff >> 1);
+            const unsigned esh = (eoff & 1) ? 16u : 0u;
             auto fetchc = [&](int u, int fi) __attribute__((always_inline)) {
                 const long start = (n_lo + fi) * P - left;
                 if (start >= 0 && start + 512 <= Tlen) {
@@ -1381,9 +1387,19 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_bwd_mfma_kernel(
                 for (int u = 0; u < U; ++u)
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
-                        const int off = u * kLbOps + 16 + 32 * t + 8 * g - j;
-                        eh[u][t] = *reinterpret_cast<const lp_h8u*>(EH + off);
-                        el[u][t] = *reinterpret_cast<const lp_h8u*>(EL + off);
+                        // eight taps from band offset 32 t + 8 g - j: read as FIVE aligned dwords from the dword that holds the first one
+                        // and funnel-shifted by 0 / 16 bits (lanes j, j + 1 then read the same dwords -- a broadcast -- where the
+                        // 2-byte aligned 16-byte read of the first version cost the launch 0.07 of 0.34 ms: ablations LPB_ABL 8 / 64 / 128)
+                        const unsigned* eph = etap + (u * kLbOps + 32 * t) / 2;
+                        const unsigned* epl = eph + 64;
+                        const lp_u4a4 hq = *reinterpret_cast<const lp_u4a4*>(eph), lq = *reinterpret_cast<const lp_u4a4*>(epl);
+                        const unsigned h4 = eph[4], l4 = epl[4];
+                        const lp_u4 hs = {__builtin_amdgcn_alignbit(hq[1], hq[0], esh), __builtin_amdgcn_alignbit(hq[2], hq[1], esh),
+                                          __builtin_amdgcn_alignbit(hq[3], hq[2], esh), __builtin_amdgcn_alignbit(h4, hq[3], esh)};
+                        const lp_u4 ls = {__builtin_amdgcn_alignbit(lq[1], lq[0], esh), __builtin_amdgcn_alignbit(lq[2], lq[1], esh),
+                                          __builtin_amdgcn_alignbit(lq[3], lq[2], esh), __builtin_amdgcn_alignbit(l4, lq[3], esh)};
+                        eh[u][t] = __builtin_bit_cast(lp_h8, hs);
+                        el[u][t] = __builtin_bit_cast(lp_h8, ls);
                     }
                 f4 acc[U][2];
 #pragma unroll
@@ -1415,7 +1431,7 @@ __global__ __launch_bounds__(64, 2) void frame_window_lpc24_bwd_mfma_kernel(
                 // lane (c, g): samples 16 c + 4 g + r of the frame; times the window (zero past the frame), scale undone; frames in order
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (fi + u < nfr_c) {
+                    if (fi + u < nfr_c && !(LPB_ABL & 16)) {
                         const long q0 = (long)(fi + u) * P;
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt) {

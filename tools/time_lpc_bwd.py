@@ -59,3 +59,7 @@ if hasattr(dsp.modules.fused, "FusedFrameWindowLPC"):
     xg = x.detach().requires_grad_(True)
     y = fl(xg)
     print("  backward launch alone: %.4f ms" % t(lambda: torch.autograd.grad(y, xg, gg, retain_graph=True)))
+gxd = torch.empty_like(x)
+gd = torch.randn(B, 200, 25, device=dev)
+print("  dsa_frame_window_lpc_bwd, direct calls: %.4f ms" % t(lambda: ops._call("dsa_frame_window_lpc_bwd", gd.data_ptr(), x.data_ptr(), B, 16000, 400, 80, wn.window.data_ptr(), 1, 0, 24,
+                                                                             1e-5, _lib.F32, gxd.data_ptr(), ops._stream()), n=30))
