@@ -787,6 +787,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                 float* rra1 = g_it < 3 ? rra + 16 : rr_lds + 55;
                 float* rrb1 = g_it < 3 ? rrb - 16 : rr_lds + 59;
                 const int bk = back - SE_LOG2;
+#ifdef DSA_MCEP_WIN_SCALAR   // (A/B: the 28 four-byte stores of rounds 1-4; lanes (n, g) of one store hit bank 4 (n + g) + r: eight to a bank)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v0 = __builtin_ldexpf(accB[0][r], bk);
@@ -799,6 +800,24 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                     rrb1[3 - r] = v1;
                     rtw[32 + r] = __builtin_ldexpf(accB[2][r], bk);
                 }
+#else
+                {   // the lane's four consecutive entries as ONE 16-byte store per window (7 stores instead of 28)
+                    f32x4 w0, w1, w2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        w0[r] = __builtin_ldexpf(accB[0][r], bk);
+                        w1[r] = __builtin_ldexpf(accB[1][r], bk);
+                        w2[r] = __builtin_ldexpf(accB[2][r], bk);
+                    }
+                    *reinterpret_cast<f32x4*>(rtw) = w0;
+                    *reinterpret_cast<f32x4_u4*>(rra) = w0;
+                    *reinterpret_cast<f32x4*>(rrb) = __builtin_shufflevector(w0, w0, 3, 2, 1, 0);
+                    *reinterpret_cast<f32x4*>(rtw + 16) = w1;
+                    *reinterpret_cast<f32x4_u4*>(rra1) = w1;
+                    *reinterpret_cast<f32x4_u4*>(rrb1) = __builtin_shufflevector(w1, w1, 3, 2, 1, 0);
+                    *reinterpret_cast<f32x4*>(rtw + 32) = w2;
+                }
+#endif
                 rt_lds[48] = rt48;  // same value on the four lanes of a frame
                 if (HIST_RT && f_ok) {   // the row as the backward's windows want it: lane (n, g) owns rt[16 it + 4 g + r]
                     float* hr = hist_rt + ((long)iter * F + f) * M2 + 4 * g_it;
