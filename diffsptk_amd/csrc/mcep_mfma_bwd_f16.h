@@ -439,28 +439,30 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
                 asm volatile("" : "+v"(g_it));
                 float* rtw = rt_n + 4 * g_it;
                 float* rra = rr_n + 27 + 4 * g_it;
-                float* rrb = rr_n + 27 - 4 * g_it;
+                float* rrb = rr_n + 24 - 4 * g_it;              // rr[27 - idx], idx = 4 g + r: the lane's four entries reversed
                 float* rra1 = g_it < 3 ? rra + 16 : rr_n + 55;
-                float* rrb1 = g_it < 3 ? rrb - 16 : rr_n + 62;
+                float* rrb1 = g_it < 3 ? rrb - 16 : rr_n + 59;
                 const int bk = back - SE_LOG2;
+                // the lane's four consecutive entries as ONE 16-byte store per window (as the forward)
+                f32x4 w0, w1, w2;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v0 = SAVED_RT ? rt_c4[0][r] : __builtin_ldexpf(accB[0][r], bk);
-                    const float v1 = SAVED_RT ? rt_c4[1][r] : __builtin_ldexpf(accB[1][r], bk);
-                    rtw[r] = v0;
-                    rra[r] = v0;
-                    rrb[-r] = v0;
-                    rtw[16 + r] = v1;
-                    rra1[r] = v1;
-                    rrb1[-r] = v1;
-                    rtw[32 + r] = SAVED_RT ? rt_c4[2][r] : __builtin_ldexpf(accB[2][r], bk);
+                    w0[r] = SAVED_RT ? rt_c4[0][r] : __builtin_ldexpf(accB[0][r], bk);
+                    w1[r] = SAVED_RT ? rt_c4[1][r] : __builtin_ldexpf(accB[1][r], bk);
+                    w2[r] = SAVED_RT ? rt_c4[2][r] : __builtin_ldexpf(accB[2][r], bk);
                 }
+                *reinterpret_cast<f32x4*>(rtw) = w0;
+                *reinterpret_cast<f32x4_u4*>(rra) = w0;
+                *reinterpret_cast<f32x4*>(rrb) = __builtin_shufflevector(w0, w0, 3, 2, 1, 0);
+                *reinterpret_cast<f32x4*>(rtw + 16) = w1;
+                *reinterpret_cast<f32x4_u4*>(rra1) = w1;
+                *reinterpret_cast<f32x4_u4*>(rrb1) = __builtin_shufflevector(w1, w1, 3, 2, 1, 0);
+                *reinterpret_cast<f32x4*>(rtw + 32) = w2;
                 rt_n[48] = rt48;
                 // mbar to the exchange window (C/D layout writer -> quad-layout reader)
 #pragma unroll
                 for (int it2 = 0; it2 < 2; ++it2)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) aux_n[it2 * 16 + 4 * g_it + r] = mbarC[it2][r];
+                    *reinterpret_cast<f32x4*>(aux_n + it2 * 16 + 4 * g_it) = f32x4{mbarC[it2][0], mbarC[it2][1], mbarC[it2][2], mbarC[it2][3]};
             }
             __builtin_amdgcn_wave_barrier();
 
