@@ -538,6 +538,7 @@ int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, v
 }  // namespace dsa
 #include "mcep_mfma_f16.h"
 #include "mcep_mfma_bwd_f16.h"
+#include "mcep_mfma_bwd2_f16.h"
 #ifdef DSA_MCEP_BWD_PAIR_EXPERIMENT   // round 5: built, measured, not adopted (tools/experiments/mcep_mfma_bwd_pair.h)
 #include "../../tools/experiments/mcep_mfma_bwd_pair.h"
 #endif
@@ -645,19 +646,23 @@ int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, i
         return check_launch("mcep_mfma_bwd_pair");
     }
 #endif
-    const int lds_bytes = mhb::B_LDS_FLOATS * 4;
+    // With the forward's rt rows at hand the sweep runs on the two-waves-per-SIMD kernel (mcep_mfma_bwd2_f16.h); DSA_MCEP_BWD2=0: A/B
+    static const bool bwd2_on = [] { const char* e = getenv("DSA_MCEP_BWD2"); return !(e && e[0] == '0'); }();
+    const bool two = hist_rt && bwd2_on;
+    const int waves = two ? mh2::WAVES_2 : mhb::WAVES_B;
+    const int lds_bytes = (two ? mh2::C_LDS_FLOATS : mhb::B_LDS_FLOATS) * 4;
     static std::atomic<uint64_t> attr_devices{0};
-    if (!ensure_dynamic_lds((const void*)mcep_mfma_bwd_kernel_h<false>, lds_bytes, attr_devices))
+    if (!two && !ensure_dynamic_lds((const void*)mcep_mfma_bwd_kernel_h<false>, lds_bytes, attr_devices))
         return fail(DSA_ERR_LAUNCH, "mcep_mfma_bwd: cannot reserve the LDS operand images%s");
     unsigned int* queue = reset_queue(scratch, st, 13);
     if (!queue) return fail(DSA_ERR_LAUNCH, "mcep_mfma_bwd: cannot reset the tile queue%s");
     long ntiles16 = (long)((F + 15) / 16);
-    long blocks = (ntiles16 + mhb::WAVES_B - 1) / mhb::WAVES_B;
+    long blocks = (ntiles16 + waves - 1) / waves;
     long grid = blocks < 256 ? blocks : 256;
     // A last round that fills at most half of the wave slots is cut into pieces of Newton steps (see the kernel) when the caller's
     // scratch carries the hand-over workspace behind the counters (DSA_ALGO_SCRATCH_HAS_WORKSPACE); DSA_MCEP_SPLIT=0: A/B
     static const bool split_on = [] { const char* e = getenv("DSA_MCEP_SPLIT"); return !(e && e[0] == '0'); }();
-    const long slots = grid * mhb::WAVES_B, rounds = ntiles16 / slots, rest = ntiles16 - rounds * slots;
+    const long slots = grid * waves, rounds = ntiles16 / slots, rest = ntiles16 - rounds * slots;
     int split_tiles = 0, split_pieces = 0;
     if (has_workspace && split_on && rounds >= 1 && rest > 0 && rest <= slots / 2 && rest <= 512 && n_iter >= 2) {
         long pieces = slots / rest;
@@ -666,6 +671,16 @@ int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, i
         if (pieces > 9) pieces = 9;   // one counter word of the scratch per piece level
         split_tiles = (int)rest;
         split_pieces = (int)pieces;
+    }
+    if (two) {
+        static std::atomic<uint64_t> attr_two{0};
+        if (!ensure_dynamic_lds((const void*)mcep_mfma_bwd2_kernel_h, lds_bytes, attr_two))
+            return fail(DSA_ERR_LAUNCH, "mcep_mfma_bwd: cannot reserve the LDS operand images%s");
+        hipLaunchKernelGGL(mcep_mfma_bwd2_kernel_h, dim3((unsigned)grid), dim3(waves * 64), lds_bytes, st, (const float*)gmc,
+                           (const float*)X, (const float*)hist, (long)F, n_iter, (const float*)av, (float*)gX, ntiles16, queue,
+                           (const _Float16*)images, split_tiles, split_pieces,
+                           reinterpret_cast<float*>(static_cast<char*>(scratch) + DSA_SCRATCH_BYTES), hist_rt);
+        return check_launch("mcep_mfma_bwd2");
     }
     if (hist_rt) {
         static std::atomic<uint64_t> attr_rt{0};

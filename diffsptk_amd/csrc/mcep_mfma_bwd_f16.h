@@ -324,7 +324,11 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (q < 3) ah_n[i] = DH[(4 * q + 4 + i) * 64];
+#ifdef DSA_BWD_ABL_NOCHAIN1   // (timing only: the bound of hiding the first chain's products in another phase)
+                        if (pm) c[i] = f32x4{mcv[0], mcv[1], mcv[2], mcv[3]} * (float)(4 * q + i);
+#else
                         if (pm) c[i] = mfma_h(al[i], bh, zero4);
+#endif
                         DSA_SB();
                         if (vw) {
                             const f32x2v ta = fma2(lo2(pc[i]), kInvSDM, lo2(logx[4 * q - 4 + i]));
@@ -335,7 +339,9 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
+#ifndef DSA_BWD_ABL_NOCHAIN1
                         if (pm) c[i] = mfma_h(ah[i], bl, c[i]);
+#endif
                         if (q < 3) al[i] = DL[(4 * q + 4 + i) * 64];
                         DSA_SB();
                         if (vw) {
@@ -347,7 +353,9 @@ __global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
+#ifndef DSA_BWD_ABL_NOCHAIN1
                         if (pm) c[i] = mfma_h(ah[i], bh, c[i]);
+#endif
                         DSA_SB();
                     }
 #pragma unroll

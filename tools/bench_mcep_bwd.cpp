@@ -33,7 +33,7 @@ int main(int argc, char** argv)
     float *X, *G, *D, *E, *av, *mc, *hist, *gmc, *gX;
     void *img, *scratch;
     hipMalloc(&X, hX.size() * 4); hipMalloc(&G, hG.size() * 4); hipMalloc(&D, hD.size() * 4);
-    hipMalloc(&E, hE.size() * 4); hipMalloc(&av, 128); hipMalloc(&mc, F * M1 * 4); hipMalloc(&hist, (size_t)(NIT + 1) * F * M1 * 4);
+    hipMalloc(&E, hE.size() * 4); hipMalloc(&av, 128); hipMalloc(&mc, F * M1 * 4); hipMalloc(&hist, (size_t)(NIT + 1) * F * M1 * 4 + (size_t)NIT * F * M2 * 4);
     hipMalloc(&gmc, F * M1 * 4); hipMalloc(&gX, hX.size() * 4);
     hipMalloc(&img, dsa::mcep_mfma_images_bytes()); hipMalloc(&scratch, 256);
     hipMemcpy(X, hX.data(), hX.size() * 4, hipMemcpyHostToDevice);
@@ -43,14 +43,15 @@ int main(int argc, char** argv)
     hipMemcpy(av, hav.data(), 100, hipMemcpyHostToDevice);
     hipMemcpy(gmc, hg.data(), hg.size() * 4, hipMemcpyHostToDevice);
     dsa::mcep_mfma_prepare(G, D, E, img, 0);
-    dsa::mcep_mfma_fwd(X, F, NIT, G, D, E, av, img, scratch, mc, hist, 0);
+    const bool rt = argc > 3 ? atoi(argv[3]) != 0 : true;   // the forward saves its rt rows (DSA_ALGO_HIST_HAS_RT), the product's default
+    dsa::mcep_mfma_fwd(X, F, NIT, G, D, E, av, img, scratch, mc, hist, 0, false, nullptr, rt);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0, best = 1e9;
     const int reps = argc > 2 ? atoi(argv[2]) : 20;
     for (int rep = 0; rep < reps; ++rep) {
         hipEventRecord(e0);
-        int rc = dsa::mcep_mfma_bwd(gmc, X, hist, F, NIT, av, img, scratch, gX, 0);
+        int rc = dsa::mcep_mfma_bwd(gmc, X, hist, F, NIT, av, img, scratch, gX, 0, false, rt);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
