@@ -420,6 +420,43 @@ __device__ __forceinline__ void blk_backsub_all(const f32x4 (&a)[blk::NBLK], flo
     (blk_backsub_group<blk::NG - 1 - Gs>(a, xq, gq, ninvs), ...);
 }
 
+// The same back substitution taking the pivots' reciprocals again instead of reading the 25 kept by the elimination (the
+// two-wave backward: 25 registers fewer across the elimination are worth 25 v_rcp_f32 per right-hand side there).
+template <int rg>
+__device__ __forceinline__ void blk_backsub_group_r(const f32x4 (&a)[blk::NBLK], float (&xq)[mm::KS], const GroupMask& gq)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f};
+#pragma unroll
+    for (int c = rg + 1; c < blk::NG; ++c) {
+        const f32x4 v = a[blk::at(rg, c)];
+        const f2 x = {xq[c], xq[c]};
+        p01 = __builtin_shufflevector(v, v, 0, 1) * x + p01;
+        if constexpr (4 * rg + 2 < mm::M1) p23 = __builtin_shufflevector(v, v, 2, 3) * x + p23;
+    }
+    const float part[4] = {p01[0], p01[1], p23[0], p23[1]};
+    const f32x4 d = a[blk::at(rg, rg)];
+    const float ninv[4] = {-__builtin_amdgcn_rcpf(quad_bcast<0>(d[0])), -__builtin_amdgcn_rcpf(quad_bcast<1>(d[1])),
+                           -__builtin_amdgcn_rcpf(quad_bcast<2>(d[2])), -__builtin_amdgcn_rcpf(quad_bcast<3>(d[3]))};
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+        const int k = 4 * rg + i;
+        if (k < mm::M1) {
+            float sl = __builtin_fmaf(d[i], xq[rg], part[i]);
+            sl += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sl), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+            sl += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(sl), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+            const float xk = sl * ninv[i];
+            xq[rg] = gq.m[i] ? xk : xq[rg];
+        }
+    }
+}
+template <int... Gs>
+__device__ __forceinline__ void blk_backsub_all_r(const f32x4 (&a)[blk::NBLK], float (&xq)[mm::KS], const GroupMask& gq,
+                                                  std::integer_sequence<int, Gs...>)
+{
+    (blk_backsub_group_r<blk::NG - 1 - Gs>(a, xq, gq), ...);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The same solve for the Toeplitz-plus-Hankel systems of the mel-generalized cepstral analysis (mgcep.py:226-229:
 // solve(symmetric_toeplitz(p) + hankel(q), r), n = 24 = the cepstral order): 16 systems per wave in the quad layout, no

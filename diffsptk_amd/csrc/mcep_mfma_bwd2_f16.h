@@ -33,7 +33,8 @@ static_assert(C_WAVE % 4 == 0 && C_LDS_FLOATS * 4 <= 160 * 1024, "the two-wave b
 }  // namespace mh2
 
 #ifndef BWD2_ABL
-#define BWD2_ABL 0   // measurement builds only: 1 no elimination, 2 no rtbar products, 4 no group chains, 8 X from one line
+#define BWD2_ABL 0   // measurement builds only: 1 no elimination, 2 no rtbar products, 4 no group chains, 8 X from one line,
+                     // 16 history / rt rows from one small region, 32 no back substitution, 64 no rtbar rotations
 #endif
 
 __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
     constexpr float kInvSDM = 1.f / (SD * SM);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform to the compiler: tile addresses in scalar registers)
     const __amdgpu_buffer_rsrc_t img_rsrc = image_rsrc(img, IMG_B_BYTES);   // the streamed E / G images (kernel argument: uniform)
     const int n = lane & 15, g = lane >> 4;
 
@@ -81,7 +82,6 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
     float* rt_q = wave_lds + nq * FS;
     float* rr_q = rt_q + 52;
     float* aux_q = rt_q + 116;
-    const GroupMask gq = make_group_mask(gs);
     int lane_a = lane, lane_c = lane + C_DB / 4;
     asm volatile("" : "+v"(lane_a), "+v"(lane_c));
     const f16x8* DH = reinterpret_cast<const f16x8*>(lds + DH_OFF) + lane_a;
@@ -118,15 +118,21 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
         } else {
             break;
         }
-        const long f_raw = tile * 16 + n;
-        const bool f_ok = f_raw < F;
-        const long f = f_ok ? f_raw : F - 1;
-        const float* xf = X + f * K;
-        const f32x4_u4* xrow = reinterpret_cast<const f32x4_u4*>((BWD2_ABL & 8) ? X + 4 * g : xf + 4 * g);   // tile mt: xrow[4 mt]
+        // The tile is uniform: every array is addressed as a scalar base of the tile's first row + a 32-bit lane offset (frames past F
+        // read the last row; 64-bit per-lane pointers cost registers and carry-chained vector additions)
+        const long t16 = tile * 16;
+        const int rows_here = (int)((F - t16 < 16) ? F - t16 : 16);
+        const bool f_ok = n < rows_here;
+        const int rn = f_ok ? n : rows_here - 1;                       // this lane's row of the tile, MFMA layout
+        const int rq = (lane >> 2) < rows_here ? (lane >> 2) : rows_here - 1;   // quad layout
+        const float* Xt = X + t16 * K;
+        float* gXt = gX + t16 * K;
+        const int xo = (BWD2_ABL & 8) ? 4 * g : rn * K + 4 * g;        // tile mt of the lane's row: Xt[xo + 16 mt ..]
+        auto xload = [&](int mt) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4_u4*>(Xt + xo + 16 * mt); };
         f32x4 lbar[16];
 #pragma unroll
         for (int mt = 0; mt < 16; ++mt) lbar[mt] = zero4;
-        const float logx256 = __log2f(xf[H]);
+        const float logx256 = __log2f(Xt[rn * K + H]);
         float lbar256 = 0.f;
         // mbar in the C/D layout of a 32-row product: tile it2, register r <-> coefficient 16 it2 + 4 g + r
         f32x4 mbarC[2];
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
                     __builtin_amdgcn_s_sleep(64);
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
-            const float* gxf = gX + f * K;
+            const float* gxf = gXt + rn * K;
 #pragma unroll
             for (int mt = 0; mt < 16; ++mt)
 #pragma unroll
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int c = it2 * 16 + 4 * g + r;
-                    mbarC[it2][r] = c < M1 ? gmc[f * M1 + c] : 0.f;
+                    mbarC[it2][r] = c < M1 ? (gmc + t16 * M1)[rn * M1 + c] : 0.f;
                 }
         }
         if (!is_piece) {   // (a piece leaves the ticket already held untouched)
@@ -164,88 +170,134 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
             if (lane == 0) nxt = atomicAdd(queue, 1u);
             tile_whole = wave_stride + (long)__builtin_amdgcn_readfirstlane((int)nxt);
         }
-        const long fq_raw = tile * 16 + nq;
-        const long fq = fq_raw < F ? fq_raw : F - 1;
+        // between the steps mbar lives in the frame's exchange window (aux [0, 32)), the step's rt row in the rt / rr windows
+#pragma unroll
+        for (int it2 = 0; it2 < 2; ++it2) *reinterpret_cast<f32x4*>(aux_n + it2 * 16 + 4 * g) = mbarC[it2];
+        int g_it = g;
+        asm volatile("" : "+v"(g_it));
+        // one saved rt row (lane (n, g): rt[16 it + 4 g + r] of its frame) requested / written into the windows
+        f32x4 rw0, rw1, rw2;
+        float rw48;
+        auto rt_row_request = [&](int it_) __attribute__((always_inline)) {
+            const float* hr = hist_rt + ((BWD2_ABL & 16) ? 0L : (long)it_ * F + t16) * M2 + rn * M2;
+            rw0 = *reinterpret_cast<const f32x4_u4*>(hr + 4 * g_it);
+            rw1 = *reinterpret_cast<const f32x4_u4*>(hr + 16 + 4 * g_it);
+            rw2 = *reinterpret_cast<const f32x4_u4*>(hr + 32 + 4 * g_it);
+            rw48 = hr[48];
+        };
+        auto rt_row_to_windows = [&]() __attribute__((always_inline)) {
+            float* rtw = rt_n + 4 * g_it;
+            float* rra = rr_n + 27 + 4 * g_it;
+            float* rrb = rr_n + 24 - 4 * g_it;              // rr[27 - idx], idx = 4 g + r: the lane's four entries reversed
+            float* rra1 = g_it < 3 ? rra + 16 : rr_n + 55;
+            float* rrb1 = g_it < 3 ? rrb - 16 : rr_n + 59;
+            *reinterpret_cast<f32x4*>(rtw) = rw0;
+            *reinterpret_cast<f32x4_u4*>(rra) = rw0;
+            *reinterpret_cast<f32x4*>(rrb) = __builtin_shufflevector(rw0, rw0, 3, 2, 1, 0);
+            *reinterpret_cast<f32x4*>(rtw + 16) = rw1;
+            *reinterpret_cast<f32x4_u4*>(rra1) = rw1;
+            *reinterpret_cast<f32x4_u4*>(rrb1) = __builtin_shufflevector(rw1, rw1, 3, 2, 1, 0);
+            *reinterpret_cast<f32x4*>(rtw + 32) = rw2;
+            rt_n[48] = rw48;
+        };
+        rt_row_request(it_hi - 1);
+        rt_row_to_windows();
+        // Touch loads: one dword per 128-byte line of the spectrum rows the groups read later in the step, issued behind the loads
+        // whose data is needed next (loads return in order) and a build + elimination ahead of the next request
+        auto touch_x = [&](int q) __attribute__((always_inline)) {   // bins 64 q .. 64 q + 63 of the tile's rows: lane (row, line)
+            const int r = (lane >> 2) < rows_here ? (lane >> 2) : rows_here - 1, j = lane & 3;
+            return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Xt + r * K + 64 * q) + (j < 2 ? 128 * j : 252));
+        };
+#define touch_done(v) asm volatile("" ::"v"(v))
+#ifndef BWD2_TOUCH_X
+#define BWD2_TOUCH_X 0   // (measured: 1.276 ms with the touches, 1.252 without)
+#endif
+#ifdef DSA_MCEP_TIMING   // phase stamps in scalar registers (pinned: nothing moves across), flushed at the end of the step
+#define B2STAMP(i) do { __builtin_amdgcn_sched_barrier(0); st2_[i] = (unsigned)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define B2STAMP(i)
+#endif
 
         for (int iter = it_hi - 1; iter >= it_lo; --iter) {
+#ifdef DSA_MCEP_TIMING
+            unsigned st2_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+            B2STAMP(0);
             const bool g_saved = iter + 1 < n_iter;
-            // ---------------- this step's saved rt row into the windows; mbar into the exchange window ----------------
+            // g = A^-1 (rt[:25] - alpha) as the difference of two SAVED iterates (mcep.py:224: mc <- mc + g): requested here, a build
+            // and an elimination ahead of its use
+            float h0r[KS], h1r[KS];
             {
-                const float* hr = hist_rt + ((long)iter * F + f) * M2;
-                int g_it = g;
-                asm volatile("" : "+v"(g_it));
-                const f32x4 w0 = *reinterpret_cast<const f32x4_u4*>(hr + 4 * g_it);
-                const f32x4 w1 = *reinterpret_cast<const f32x4_u4*>(hr + 16 + 4 * g_it);
-                const f32x4 w2 = *reinterpret_cast<const f32x4_u4*>(hr + 32 + 4 * g_it);
-                const float rt48 = hr[48];
-                float* rtw = rt_n + 4 * g_it;
-                float* rra = rr_n + 27 + 4 * g_it;
-                float* rrb = rr_n + 24 - 4 * g_it;              // rr[27 - idx], idx = 4 g + r: the lane's four entries reversed
-                float* rra1 = g_it < 3 ? rra + 16 : rr_n + 55;
-                float* rrb1 = g_it < 3 ? rrb - 16 : rr_n + 59;
-                *reinterpret_cast<f32x4*>(rtw) = w0;
-                *reinterpret_cast<f32x4_u4*>(rra) = w0;
-                *reinterpret_cast<f32x4*>(rrb) = __builtin_shufflevector(w0, w0, 3, 2, 1, 0);
-                *reinterpret_cast<f32x4*>(rtw + 16) = w1;
-                *reinterpret_cast<f32x4_u4*>(rra1) = w1;
-                *reinterpret_cast<f32x4_u4*>(rrb1) = __builtin_shufflevector(w1, w1, 3, 2, 1, 0);
-                *reinterpret_cast<f32x4*>(rtw + 32) = w2;
-                rt_n[48] = rt48;
-#pragma unroll
-                for (int it2 = 0; it2 < 2; ++it2) *reinterpret_cast<f32x4*>(aux_n + it2 * 16 + 4 * g_it) = mbarC[it2];
-            }
-            // g = A^-1 (rt[:25] - alpha) as the difference of two SAVED iterates (mcep.py:224: mc <- mc + g)
-            float gh[KS];
-            {
-                const float* h0 = hist + ((long)iter * F + fq) * M1;
+                const float* h0 = hist + ((BWD2_ABL & 16) ? 0L : (long)iter * F + t16) * M1 + rq * M1;
                 const float* h1 = g_saved ? h0 + F * M1 : h0;
 #pragma unroll
-                for (int c = 0; c < KS - 1; ++c) gh[c] = h1[gs + 4 * c] - h0[gs + 4 * c];
-                gh[KS - 1] = keep_if(gq.m[0], h1[M1 - 1] - h0[M1 - 1]);   // k = 24 on lane 0 only
+                for (int c = 0; c < KS - 1; ++c) { h0r[c] = h0[gs + 4 * c]; h1r[c] = h1[gs + 4 * c]; }
+                h0r[KS - 1] = h0[M1 - 1]; h1r[KS - 1] = h1[M1 - 1];
+            }
+            float t_x[4] = {0.f, 0.f, 0.f, 0.f};
+            if (BWD2_TOUCH_X) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t_x[q] = touch_x(q);
             }
             __builtin_amdgcn_wave_barrier();
+            B2STAMP(1);
 
             // ---------------- solve A [gv | uv] = [rt[:25] - alpha | mbar] in the quad layout ----------------
-            float xq1[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[1], -1.f)};
-            float xq2[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[2], -1.f)};
+            float xq1[KS], xq2[KS];
+            float mcv[8];
+            f32x4 xg[4];
             {
+                // the lane-group masks live for the solve only (8 registers)
+                int gsv = gs;
+                asm volatile("" : "+v"(gsv));
+                const GroupMask gq = make_group_mask(gsv);
+#pragma unroll
+                for (int c = 0; c < KS; ++c) { xq1[c] = 0.f; xq2[c] = 0.f; }
+                xq1[KS - 1] = keep_if(gq.m[1], -1.f);
+                xq2[KS - 1] = keep_if(gq.m[2], -1.f);
                 f32x4 a[blk::NBLK];
-                float ninvs[M1];
+                float ninvs[M1];   // (dead: the back substitutions take the pivots' reciprocals again, 25 registers fewer across the elimination)
                 {
-                    int gsv = gs;
-                    asm volatile("" : "+v"(gsv));
                     const float* zr = lds + C_ZERO;
                     const float* pa6 = gsv == 0 ? rt_q + 24 : (gsv == 1 ? rt_q : (gsv == 2 ? aux_q : zr));
                     const float* pb6 = gsv == 0 ? rr_q + 3 : (gsv == 1 ? lds + C_NAV : zr);
                     blk_build_rows<0>(a, rt_q, rr_q, pa6, pb6, gs);
                 }
                 __builtin_amdgcn_wave_barrier();
+                B2STAMP(2);
                 if (!(BWD2_ABL & 1)) blk_elim_all(a, gq, ninvs, std::make_integer_sequence<int, M1>{});
-                else {
+                B2STAMP(3);
+                if (BWD2_TOUCH_X) {
 #pragma unroll
-                    for (int k = 0; k < M1; ++k) ninvs[k] = a[k % blk::NBLK][0];
+                    for (int q = 0; q < 4; ++q) touch_done(t_x[q]);
                 }
                 if (g_saved) {
 #pragma unroll
-                    for (int c = 0; c < KS; ++c) xq1[c] = gh[c];
+                    for (int c = 0; c < KS; ++c) xq1[c] = h1r[c] - h0r[c];
+                    xq1[KS - 1] = keep_if(gq.m[0], xq1[KS - 1]);   // k = 24 on lane 0 only
                 } else {
-                    blk_backsub_all(a, xq1, gq, ninvs, std::make_integer_sequence<int, blk::NG>{});
+                    blk_backsub_all_r(a, xq1, gq, std::make_integer_sequence<int, blk::NG>{});
                     xq1[KS - 1] = keep_if(gq.m[0], xq1[KS - 1]);
                 }
-                blk_backsub_all(a, xq2, gq, ninvs, std::make_integer_sequence<int, blk::NG>{});
+                if (!(BWD2_ABL & 32)) blk_backsub_all_r(a, xq2, gq, std::make_integer_sequence<int, blk::NG>{});
+                else {
+#pragma unroll
+                    for (int c = 0; c < KS; ++c) xq2[c] = a[blk::at(c, c)][0] + a[blk::at(0, c)][1];
+                }
                 xq2[KS - 1] = keep_if(gq.m[0], xq2[KS - 1]);
             }
-            // this step's iterate for the first chain of the groups: requested here, a solve's back substitution ahead of its use
-            float mcv[8];
+            B2STAMP(4);
+            // requested here, rtbar and the exchange ahead of their use (the elimination's 112 registers are free again): this step's
+            // iterate, the first group's spectrum rows, the NEXT step's rt row
 #pragma unroll
-            for (int i = 0; i < 8; ++i) mcv[i] = (8 * g + i < M1) ? hist[((long)iter * F + f) * M1 + 8 * g + i] : 0.f;
-            // the first group's spectrum rows
-            f32x4 xg[4];
+            for (int i = 0; i < 8; ++i) mcv[i] = (8 * g + i < M1) ? (hist + ((BWD2_ABL & 16) ? 0L : (long)iter * F + t16) * M1)[rn * M1 + 8 * g + i] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xg[i] = xrow[4 * i];
+            for (int i = 0; i < 4; ++i) xg[i] = xload(i);
+            if (iter > it_lo) rt_row_request(iter - 1);
 
             // ---------------- rtbar (49 entries), scaled per frame to below 2^13, into the exchange window ----------------
-            // (as mcep_mfma_bwd_kernel_h: 2 x 49 4 x 4 x 1 outer-product blocks, quad rotations for the sums over equal m)
+            // (as mcep_mfma_bwd_kernel_h: 2 x 49 4 x 4 x 1 outer-product blocks, quad rotations for the sums over equal m; the
+            // exchange goes through the rr window, which is dead once the rows are built: aux keeps mbar)
             {
                 f32x4 DHk[13], DTk[13];
 #pragma unroll
@@ -277,6 +329,7 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
 #pragma unroll
                 for (int sl = 0; sl < 13; ++sl) {
                     float hs = DHk[sl][0];
+                    if (BWD2_ABL & 64) { rb[sl] = hs + DTk[sl][1]; continue; }
 #pragma unroll
                     for (int ip = 1; ip < 4; ++ip) {
                         const float prev = sl > 0 ? DHk[sl - 1][ip] : 0.f;
@@ -308,21 +361,22 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
                 amax = __builtin_fmaxf(amax, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(amax), 0x4E, 0xf, 0xf, true)));
                 const int s_r = VMAX_LOG2 - __builtin_amdgcn_frexp_expf(amax);
 #pragma unroll
-                for (int sl = 0; sl < 13; ++sl) aux_q[4 * sl + gs] = __builtin_ldexpf(rb[sl], s_r);
-                aux_q[52 + gs] = 0.f;
-                aux_q[56 + gs] = 0.f;
-                aux_q[60 + gs] = gs == 3 ? __int_as_float(s_r) : 0.f;
+                for (int sl = 0; sl < 13; ++sl) rr_q[4 * sl + gs] = __builtin_ldexpf(rb[sl], s_r);
+                rr_q[52 + gs] = 0.f;
+                rr_q[56 + gs] = 0.f;
+                rr_q[60 + gs] = gs == 3 ? __int_as_float(s_r) : 0.f;
             }
             __builtin_amdgcn_wave_barrier();
+            B2STAMP(5);
             f16x8 rbh[2], rbl[2];
             float eb256 = 0.f;
-            const int s_rn = __float_as_int(aux_n[63]);   // the scale of THIS lane's frame in the MFMA layout
+            const int s_rn = __float_as_int(rr_n[63]);   // the scale of THIS lane's frame in the MFMA layout
             {
                 float rv[16];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    rv[i] = aux_n[8 * g + i];
-                    rv[8 + i] = g < 3 ? aux_n[32 + 8 * g + i] : 0.f;     // slot 63 of group 3 holds the scale, not data
+                    rv[i] = rr_n[8 * g + i];
+                    rv[8 + i] = g < 3 ? rr_n[32 + 8 * g + i] : 0.f;     // slot 63 of group 3 holds the scale, not data
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -337,6 +391,8 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
             }
             __builtin_amdgcn_wave_barrier();
             eb256 = rows_sum4(eb256);
+            // the next step's rt row into the windows (their last reader, the exchange above, is done)
+            if (iter > it_lo) rt_row_to_windows();
 
             // ---------------- the bins, 64 at a time: e, ebar, zbar, lbar, this step's contribution to mbar ----------------
             f16x8 bh, bl;
@@ -352,16 +408,22 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
             }
             d256 = rows_sum4(d256);
             f32x4 macc[2] = {zero4, zero4};
+            B2STAMP(6);
             if (!(BWD2_ABL & 4)) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    // streamed E image of the group's first tile
-                    f16x8 ah[2], al[2];
+                    // streamed E image (L2): tiles 0, 1 of the group requested here, a first chain ahead of their products; tiles 2, 3
+                    // into the same registers as those are consumed
+                    f16x8 ah[2][2], al[2][2];
+                    auto req = [&](int slot, int i) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        ah[ks] = gload8(img_rsrc, lane16, 2 * (IMG_EBH + ((4 * q) * 2 + ks) * 512));
-                        al[ks] = gload8(img_rsrc, lane16, 2 * (IMG_EBL + ((4 * q) * 2 + ks) * 512));
-                    }
+                        for (int ks = 0; ks < 2; ++ks) {
+                            ah[slot][ks] = gload8(img_rsrc, lane16, 2 * (IMG_EBH + ((4 * q + i) * 2 + ks) * 512));
+                            al[slot][ks] = gload8(img_rsrc, lane16, 2 * (IMG_EBL + ((4 * q + i) * 2 + ks) * 512));
+                        }
+                    };
+                    req(0, 0);
+                    req(1, 1);
                     // first chain: t = log2 X + D^T mc on the group's four tiles
                     f32x4 c[4];
                     {
@@ -375,29 +437,17 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
 #pragma unroll
                         for (int i = 0; i < 4; ++i) c[i] = mfma_h(dh_[i], bh, c[i]);
                     }
-                    // ebar = E rtbar on the same tiles (independent of e): the image of the next tile requested a tile ahead
-                    f32x4 acc[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        f16x8 ah_n[2] = {ah[0], ah[1]}, al_n[2] = {al[0], al[1]};
-                        if (i < 3) {
-#pragma unroll
-                            for (int ks = 0; ks < 2; ++ks) {
-                                ah_n[ks] = gload8(img_rsrc, lane16, 2 * (IMG_EBH + ((4 * q + i + 1) * 2 + ks) * 512));
-                                al_n[ks] = gload8(img_rsrc, lane16, 2 * (IMG_EBL + ((4 * q + i + 1) * 2 + ks) * 512));
-                            }
-                        }
-                        f32x4 a_ = mfma_h(al[0], rbh[0], zero4);
-                        a_ = mfma_h(ah[0], rbl[0], a_);
-                        a_ = mfma_h(ah[0], rbh[0], a_);
-                        a_ = mfma_h(al[1], rbh[1], a_);
-                        a_ = mfma_h(ah[1], rbl[1], a_);
-                        a_ = mfma_h(ah[1], rbh[1], a_);
-                        acc[i] = a_;
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) { ah[ks] = ah_n[ks]; al[ks] = al_n[ks]; }
-                    }
-                    // t, the group's shift, e
+                    // ebar = E rtbar on one tile (independent of e)
+                    auto ebar = [&](int slot) __attribute__((always_inline)) {
+                        f32x4 a_ = mfma_h(al[slot][0], rbh[0], zero4);
+                        a_ = mfma_h(ah[slot][0], rbl[0], a_);
+                        a_ = mfma_h(ah[slot][0], rbh[0], a_);
+                        a_ = mfma_h(al[slot][1], rbh[1], a_);
+                        a_ = mfma_h(ah[slot][1], rbl[1], a_);
+                        a_ = mfma_h(ah[slot][1], rbh[1], a_);
+                        return a_;
+                    };
+                    // t, the group's shift
                     float gm = -3.0e38f;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -407,27 +457,42 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
                         gm = __builtin_fmaxf(__builtin_fmaxf(gm, ta[0]), ta[1]);
                         gm = __builtin_fmaxf(__builtin_fmaxf(gm, tb[0]), tb[1]);
                     }
-                    if (q < 3) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) xg[i] = xrow[4 * (4 * q + 4 + i)];
-                    }
                     gm = rows_max4(gm);
                     const float mi = __builtin_ceilf(gm);
                     const int kz = (int)mi - s_rn - SEB_LOG2;   // zbar = acc e' 2^kz, e = 2^mi e'
                     float zm = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    // e, zbar = ebar * e, lbar += zbar of one tile
+                    auto zbar = [&](int i, f32x4 acc) __attribute__((always_inline)) {
                         const f32x2v ta = lo2(c[i]) - f32x2v{mi, mi}, tb = hi2(c[i]) - f32x2v{mi, mi};
                         const f32x2v ea = {__builtin_amdgcn_exp2f(ta[0]), __builtin_amdgcn_exp2f(ta[1])};
                         const f32x2v eb = {__builtin_amdgcn_exp2f(tb[0]), __builtin_amdgcn_exp2f(tb[1])};
-                        const f32x2v ma = lo2(acc[i]) * ea, mb = hi2(acc[i]) * eb;
+                        const f32x2v ma = lo2(acc) * ea, mb = hi2(acc) * eb;
                         const f32x4 z = {__builtin_ldexpf(ma[0], kz), __builtin_ldexpf(ma[1], kz), __builtin_ldexpf(mb[0], kz),
                                          __builtin_ldexpf(mb[1], kz)};
                         c[i] = z;
                         lbar[4 * q + i] += z;
                         zm = __builtin_fmaxf(__builtin_fmaxf(zm, __builtin_fabsf(z[0])), __builtin_fabsf(z[1]));
                         zm = __builtin_fmaxf(__builtin_fmaxf(zm, __builtin_fabsf(z[2])), __builtin_fabsf(z[3]));
+                    };
+                    if (q == 1) B2STAMP(8);
+                    {
+                        const f32x4 a0 = ebar(0);
+                        req(0, 2);
+                        const f32x4 a1 = ebar(1);
+                        req(1, 3);
+                        // the next group's spectrum rows BEHIND this group's last image request (loads return in order)
+                        if (q < 3) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) xg[i] = xload(4 * q + 4 + i);
+                        }
+                        zbar(0, a0);
+                        zbar(1, a1);
+                        const f32x4 a2 = ebar(0);
+                        const f32x4 a3 = ebar(1);
+                        zbar(2, a2);
+                        zbar(3, a3);
                     }
+                    if (q == 1) B2STAMP(9);
                     // mbar contribution of the group with the group's own scale
                     zm = rows_max4(zm);
                     const int s_z = VMAX_LOG2 - __builtin_amdgcn_frexp_expf(zm);
@@ -457,28 +522,38 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
                     for (int it2 = 0; it2 < 2; ++it2)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) macc[it2][r] += __builtin_ldexpf(acc2[it2][r], -s_z - SDB_LOG2);
+                    if (q == 0) B2STAMP(7);
+                    if (q == 1) B2STAMP(10);
                 }
             }
-            // the Nyquist bin
+            // the Nyquist bin; mbar <- mbar + this step's contribution (in the exchange window)
             {
                 const float t256 = logx256 + d256;
                 const float m256 = __builtin_ceilf(t256);
                 const float zb256 = __builtin_ldexpf(eb256 * __builtin_amdgcn_exp2f(t256 - m256), (int)m256 - s_rn);
                 lbar256 += zb256;
 #pragma unroll
-                for (int it2 = 0; it2 < 2; ++it2)
+                for (int it2 = 0; it2 < 2; ++it2) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int c_ = it2 * 16 + 4 * g + r;   // < 32 (the table is 0 past c = 24)
-                        mbarC[it2][r] += __builtin_fmaf(zb256, lds[C_D256 + 32 + c_], macc[it2][r]);
+                        macc[it2][r] = __builtin_fmaf(zb256, lds[C_D256 + 32 + c_], macc[it2][r]);
                     }
+                    f32x4* mp = reinterpret_cast<f32x4*>(aux_n + it2 * 16 + 4 * g);
+                    *mp = *mp + macc[it2];
+                }
             }
+            B2STAMP(11);
+#ifdef DSA_MCEP_TIMING
+            if (blockIdx.x == 0 && threadIdx.x == 0 && tile == wave_id && iter == n_iter - 2)
+                for (int i_ = 0; i_ < 16; ++i_) g_mcep_stamps[40 + i_] = st2_[i_];
+#endif
         }
 
         if (it_lo > 0) {
             // hand over: lbar into the tile's rows of gX (the last piece overwrites them with gX), mbar into ws; written through
             // to device scope and acknowledged, then the level's counter
-            float* gxf = gX + f * K;
+            float* gxf = gXt + rn * K;
             float* wsf = ws + ((long)split_j * 16 + n) * 32;
             if (f_ok) {
 #pragma unroll
@@ -489,10 +564,12 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
                 if (g == 0) __hip_atomic_store(gxf + H, lbar256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
-            for (int it2 = 0; it2 < 2; ++it2)
+            for (int it2 = 0; it2 < 2; ++it2) {
+                const f32x4 mv = *reinterpret_cast<const f32x4*>(aux_n + it2 * 16 + 4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    __hip_atomic_store(wsf + it2 * 16 + 4 * g + r, mbarC[it2][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(wsf + it2 * 16 + 4 * g + r, mv[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) atomicAdd(queue + 3 + piece_mine, 1u);
@@ -501,8 +578,6 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
         }
         if (is_piece) piece_mine = -1;
         // ---------------- lbar += G mbar_0 (mcep.py:204-207 adjoint); gX = lbar / X ----------------
-#pragma unroll
-        for (int it2 = 0; it2 < 2; ++it2) *reinterpret_cast<f32x4*>(aux_n + it2 * 16 + 4 * g) = mbarC[it2];
         __builtin_amdgcn_wave_barrier();
         float m0[8];
         float mmax = 0.f;
@@ -528,20 +603,20 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
 #pragma unroll
             for (int mt = 0; mt < 16; ++mt) {
                 const f16x8 ah = gload8(img_rsrc, lane16, 2 * (IMG_GBH + mt * 512)), al = gload8(img_rsrc, lane16, 2 * (IMG_GBL + mt * 512));
-                const f32x4 xv = xrow[4 * mt];
+                const f32x4 xv = xload(mt);
                 f32x4 acc = {0, 0, 0, 0};
                 acc = mfma_h(al, mh8, acc);
                 acc = mfma_h(ah, ml8, acc);
                 acc = mfma_h(ah, mh8, acc);
                 if (f_ok) {
-                    float* dst = gX + f * K + mt * 16 + 4 * g;
+                    float* dst = gXt + rn * K + mt * 16 + 4 * g;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         dst[r] = (lbar[mt][r] + __builtin_ldexpf(acc[r], -s_m - SGB_LOG2)) * __builtin_amdgcn_exp2f(-__log2f(xv[r]));
                 }
             }
         }
-        if (f_ok && g == 0) gX[f * K + H] = lbar256 * __builtin_amdgcn_exp2f(-logx256);
+        if (f_ok && g == 0) gXt[rn * K + H] = lbar256 * __builtin_amdgcn_exp2f(-logx256);
     }
 #undef DSA_SB
 }

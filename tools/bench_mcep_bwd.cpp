@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace dsa {
@@ -66,6 +67,10 @@ int main(int argc, char** argv)
            best, reps - reps / 2, s[1] - s[0], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[5] - s[4], s[5] - s[0]);
     printf("   forward: first chain %u  reduction + second chain %u  windows %u | mbar: prologue %u  bodies %u  epilogue %u\n", s[6] - s[0], s[7] - s[6],
            s[1] - s[7], s[8] - s[4], s[9] - s[8], s[5] - s[9]);
+    if (rt && !(getenv("DSA_MCEP_BWD2") && getenv("DSA_MCEP_BWD2")[0] == '0'))
+        printf("   two-wave kernel (stamps as: windows %u  build %u  elimination %u  back substitution %u  rtbar %u  exchange %u | group 0 %u  group 1: products %u  e + zbar %u  mbar %u | groups 2, 3 + Nyquist %u | step %u)\n",
+               s[1] - s[0], s[2] - s[1], s[3] - s[2], s[4] - s[3], s[5] - s[4], s[6] - s[5], s[7] - s[6], s[8] - s[7], s[9] - s[8], s[10] - s[9],
+               s[11] - s[10], s[11] - s[0]);
     std::vector<float> h(4);
     hipMemcpy(h.data(), gX, 16, hipMemcpyDeviceToHost);
     printf("   gX[0..3] = %g %g %g %g\n", h[0], h[1], h[2], h[3]);
