@@ -410,20 +410,21 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
             f32x4 macc[2] = {zero4, zero4};
             B2STAMP(6);
             if (!(BWD2_ABL & 4)) {
+                // Streamed E image (L2), two tiles in flight.  Loads return in order, so the one slow request of a group -- the
+                // NEXT group's spectrum rows (memory) -- is made behind the next group's first two image tiles, when this group's
+                // products are through: nothing younger than it is needed before its own data is.
+                f16x8 ah[2][2], al[2][2];
+                auto req = [&](int slot, int mt) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        ah[slot][ks] = gload8(img_rsrc, lane16, 2 * (IMG_EBH + (mt * 2 + ks) * 512));
+                        al[slot][ks] = gload8(img_rsrc, lane16, 2 * (IMG_EBL + (mt * 2 + ks) * 512));
+                    }
+                };
+                req(0, 0);
+                req(1, 1);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    // streamed E image (L2): tiles 0, 1 of the group requested here, a first chain ahead of their products; tiles 2, 3
-                    // into the same registers as those are consumed
-                    f16x8 ah[2][2], al[2][2];
-                    auto req = [&](int slot, int i) __attribute__((always_inline)) {
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
-                            ah[slot][ks] = gload8(img_rsrc, lane16, 2 * (IMG_EBH + ((4 * q + i) * 2 + ks) * 512));
-                            al[slot][ks] = gload8(img_rsrc, lane16, 2 * (IMG_EBL + ((4 * q + i) * 2 + ks) * 512));
-                        }
-                    };
-                    req(0, 0);
-                    req(1, 1);
                     // first chain: t = log2 X + D^T mc on the group's four tiles
                     f32x4 c[4];
                     {
@@ -477,18 +478,19 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
                     if (q == 1) B2STAMP(8);
                     {
                         const f32x4 a0 = ebar(0);
-                        req(0, 2);
+                        req(0, 4 * q + 2);
                         const f32x4 a1 = ebar(1);
-                        req(1, 3);
-                        // the next group's spectrum rows BEHIND this group's last image request (loads return in order)
-                        if (q < 3) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) xg[i] = xload(4 * q + 4 + i);
-                        }
+                        req(1, 4 * q + 3);
                         zbar(0, a0);
                         zbar(1, a1);
                         const f32x4 a2 = ebar(0);
                         const f32x4 a3 = ebar(1);
+                        if (q < 3) {
+                            req(0, 4 * q + 4);
+                            req(1, 4 * q + 5);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) xg[i] = xload(4 * q + 4 + i);
+                        }
                         zbar(2, a2);
                         zbar(3, a3);
                     }
