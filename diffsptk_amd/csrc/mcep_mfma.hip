@@ -28,6 +28,7 @@
 namespace dsa {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_u4 __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte access at dword alignment
 
 namespace mm {
 constexpr int H = 256, K = 257;   // nfft = 512
@@ -320,15 +321,26 @@ __device__ __forceinline__ void blk_build_rows(f32x4 (&a)[blk::NBLK], const floa
     if constexpr (rg < blk::NG) {
         const float* rt_g = rt0 + gs;
         const float* rr_g = rr0 + 27 - gs;
+#ifndef DSA_BLK_BUILD_SCALAR   // the four rows of a block as ONE 16-byte read per window (dword-aligned) and two packed additions
+        // (round 5: half the LDS instructions of the build, the same sums; the forward kernels' last 28 bytes of scratch go with it)
+        if constexpr (4 * rg + 3 < M1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 4 * rg + i;
-            if (row < M1) {
+            for (int c = rg; c < 6; ++c)
+                a[blk::at(rg, c)] = *reinterpret_cast<const f32x4_u4*>(rt_g + 4 * rg + 4 * c) + *reinterpret_cast<const f32x4_u4*>(rr_g + 4 * rg - 4 * c);
+            a[blk::at(rg, 6)] = *reinterpret_cast<const f32x4_u4*>(pa6 + 4 * rg) + *reinterpret_cast<const f32x4_u4*>(pb6 + 4 * rg);
+        } else
+#endif
+        {
 #pragma unroll
-                for (int c = rg; c < 6; ++c) a[blk::at(rg, c)][i] = rt_g[row + 4 * c] + rr_g[row - 4 * c];
-                a[blk::at(rg, 6)][i] = pa6[row] + pb6[row];
-            } else {
-                a[blk::at(rg, 6)][i] = 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const int row = 4 * rg + i;
+                if (row < M1) {
+#pragma unroll
+                    for (int c = rg; c < 6; ++c) a[blk::at(rg, c)][i] = rt_g[row + 4 * c] + rr_g[row - 4 * c];
+                    a[blk::at(rg, 6)][i] = pa6[row] + pb6[row];
+                } else {
+                    a[blk::at(rg, 6)][i] = 0.f;
+                }
             }
         }
         blk_build_rows<rg + 1>(a, rt0, rr0, pa6, pb6, gs);

@@ -102,6 +102,11 @@ __global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
     long tile_whole = wave_id;   // the next whole tile of this wave (>= nwhole: none left)
     int whole_started = 0;
 #define DSA_SB() __builtin_amdgcn_sched_barrier(0x0004)
+#ifdef BWD2_PHASE_OFFSET   // (A/B: the second wave of every SIMD starts about half a step late, so that the two are not in the same phase)
+    if (wave >= 4) {
+        for (int i_ = 0; i_ < BWD2_PHASE_OFFSET; ++i_) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     for (;;) {
         // ---- this round's work item: a whole tile, or this wave's piece of a split tile (steps it_hi - 1 .. it_lo) ----
         long tile;

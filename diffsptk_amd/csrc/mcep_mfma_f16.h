@@ -190,7 +190,6 @@ __global__ __launch_bounds__(256) void mcep_h_prep_kernel(const float* __restric
 // A lane's eight consecutive coefficients mc[8 g .. 8 g + 7] of its frame (only mc[24] in lane group 3) as two 16-byte stores
 // (rows are 100 bytes apart: 4-byte aligned) instead of eight 4-byte ones: a quarter of the store instructions of the history
 // the backward needs (11 rows of 25 floats per frame: 225 MB per 204 800 frames).
-typedef float f32x4_u4 __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ void store_mc_row(float* row, int g, const float (&mcv)[8])
 {
     if (g < 3) {
