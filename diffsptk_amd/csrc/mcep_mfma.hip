@@ -696,7 +696,8 @@ int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, i
     }
 #endif
     // With the forward's rt rows at hand the sweep runs on the two-waves-per-SIMD kernel (mcep_mfma_bwd2_f16.h); DSA_MCEP_BWD2=0: A/B
-    static const bool bwd2_on = [] { const char* e = getenv("DSA_MCEP_BWD2"); return !(e && e[0] == '0'); }();
+    const char* e2 = getenv("DSA_MCEP_BWD2");   // (read per call: the tests switch it)
+    const bool bwd2_on = !(e2 && e2[0] == '0');
     const bool two = hist_rt && bwd2_on;
     const int waves = two ? mh2::WAVES_2 : mhb::WAVES_B;
     const int lds_bytes = (two ? mh2::C_LDS_FLOATS : mhb::B_LDS_FLOATS) * 4;

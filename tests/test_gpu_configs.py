@@ -15,6 +15,8 @@ its float64 run; its test criterion is rtol 1e-4 / atol 1e-6 for a float32 op ag
 tests/utils.py:66-72); gradients 3e-6 of the largest entry of the utterance's gradient (3 x the error measured by
 tools/measure_tolerances.py).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -520,6 +522,50 @@ def test_mcep_backward_with_the_saved_rt_rows_equals_the_recomputing_backward(mo
     xs = x[[0, 36]].double().cpu().requires_grad_(True)
     (TP.stft_mcep(xs, tab) * w.double().cpu()).sum().backward()
     assert float((gx1[[0, 36]].double().cpu() - xs.grad).abs().max()) <= 3e-6 * float(xs.grad.abs().max())
+
+
+def test_mcep_backward_two_waves_per_simd_against_the_one_wave_kernel_and_float64(monkeypatch):
+    """Round 5: with the saved rt rows the backward runs as mcep_mfma_bwd2_kernel_h (two waves per SIMD: only lbar resident, the bins
+    64 at a time with the group's own power-of-two scales, the forward's block elimination with the adjoint right-hand side riding
+    along).  Same mathematics, different rounding points: against the one-wave kernel on the same saved rows (DSA_MCEP_BWD2=0) within
+    the measured error of either (below), both against float64 autograd on sampled frames; repeated launches are bit-identical;
+    a launch on a prefix of the frames gives the same bits (whole tiles); ragged frame counts; n_iter in {1, 3, 10}."""
+    gen = torch.Generator().manual_seed(33)
+    stft, _ = _modules()
+    x = torch.randn(41, 4800, generator=gen).to(DEV)
+    X = stft(x).reshape(-1, 257)[:2449]   # 153 tiles + 1 frame
+    for n_iter in (1, 3, 10):
+        mcep = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=n_iter, device=DEV)
+        w = torch.randn(2449, 25, generator=gen).to(DEV)
+
+        def grad(Xin, wt):
+            Xg = Xin.detach().clone().requires_grad_(True)
+            (mcep(Xg) * wt).sum().backward()
+            return Xg.grad
+
+        g2 = grad(X, w)
+        assert torch.equal(g2, grad(X, w))
+        assert torch.equal(g2[:1600], grad(X[:1600], w[:1600]))
+        monkeypatch.setenv("DSA_MCEP_BWD2", "0")
+        g1 = grad(X, w)
+        monkeypatch.delenv("DSA_MCEP_BWD2")
+        assert torch.isfinite(g2).all()
+        assert not torch.equal(g1, g2)   # (two different kernels ran: the backward's name is recorded on autograd's thread)
+        # Both kernels against float64 autograd on ALL frames, per frame relative to the frame's largest gradient entry.  Measured
+        # (tools/check_mcep_bwd_kernels.py; two-wave / one-wave): whole-tensor 1.2e-6 / 1.2e-6, median frame 7e-7 / 7e-7, worst frame
+        # n_iter 1: 8.3e-5 / 4.1e-5, 3: 1.2e-4 / 4.0e-4, 10: 1.5e-6 / 3.4e-6 (unconverged iterates are ill-conditioned on a few frames,
+        # for either kernel).  Bounds: 3 x the larger of the two.
+        worst = {1: 2.5e-4, 3: 1.2e-3, 10: 1.1e-5}[n_iter]
+        tab = TP.McepTables(512, 24, 0.42, torch.float64)
+        Xs = X.double().cpu().requires_grad_(True)
+        (TP.mcep(Xs, tab, n_iter) * w.double().cpu()).sum().backward()
+        ref = Xs.grad
+        for gk in (g2, g1):
+            d = (gk.double().cpu() - ref).abs()
+            per = d.amax(1) / ref.abs().amax(1)
+            assert float(d.max() / ref.abs().max()) <= 3.5e-6
+            assert float(per.median()) <= 2.5e-6
+            assert float(per.max()) <= worst, (n_iter, float(per.max()))
 
 
 def test_hot_path_and_f_rows_replay_from_a_hip_graph():
