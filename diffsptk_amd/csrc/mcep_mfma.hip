@@ -714,11 +714,12 @@ int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, i
     static const bool split_on = [] { const char* e = getenv("DSA_MCEP_SPLIT"); return !(e && e[0] == '0'); }();
     const long slots = grid * waves, rounds = ntiles16 / slots, rest = ntiles16 - rounds * slots;
     int split_tiles = 0, split_pieces = 0;
-    if (has_workspace && split_on && rounds >= 1 && rest > 0 && rest <= slots / 2 && rest <= 512 && n_iter >= 2) {
+    if (!two && has_workspace && split_on && rounds >= 1 && rest > 0 && rest <= slots / 2 && rest <= 512 && n_iter >= 2) {
         long pieces = slots / rest;
         if (pieces > n_iter) pieces = n_iter;
         if (pieces > rounds + 1) pieces = rounds + 1;
         if (pieces > 9) pieces = 9;   // one counter word of the scratch per piece level
+        if (const char* ep = getenv("DSA_MCEP_SPLIT_PIECES")) { const long cap = atol(ep); if (cap >= 2 && pieces > cap) pieces = cap; }   // (A/B)
         split_tiles = (int)rest;
         split_pieces = (int)pieces;
     }
@@ -728,8 +729,7 @@ int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, i
             return fail(DSA_ERR_LAUNCH, "mcep_mfma_bwd: cannot reserve the LDS operand images%s");
         hipLaunchKernelGGL(mcep_mfma_bwd2_kernel_h, dim3((unsigned)grid), dim3(waves * 64), lds_bytes, st, (const float*)gmc,
                            (const float*)X, (const float*)hist, (long)F, n_iter, (const float*)av, (float*)gX, ntiles16, queue,
-                           (const _Float16*)images, split_tiles, split_pieces,
-                           reinterpret_cast<float*>(static_cast<char*>(scratch) + DSA_SCRATCH_BYTES), hist_rt);
+                           (const _Float16*)images, hist_rt);
         return check_launch("mcep_mfma_bwd2");
     }
     if (hist_rt) {

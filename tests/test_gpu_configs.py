@@ -469,12 +469,17 @@ def test_untuned_geometries_forward_as_whole_batch_launches(monkeypatch, fl, fp,
     assert err < 2e-4, err
 
 
+@pytest.mark.parametrize("two_wave", [False, True])
 @pytest.mark.parametrize("tail_tiles,tail_frames", [(8, 8 * 16 - 13), (512, 512 * 16), (37, 37 * 16 - 1)])
-def test_mcep_backward_split_tail_is_bit_identical_to_whole_tiles(tail_tiles, tail_frames):
-    """The tuned backward cuts a short last round of tiles into pieces of Newton steps that hand (lbar, mbar) over through
-    memory (csrc/mcep_mfma_bwd_f16.h, DSA_ALGO_SCRATCH_HAS_WORKSPACE).  Frames are independent and a piece repeats the whole
-    tile's arithmetic step by step, so the gradient of the tail frames must equal BIT FOR BIT what a launch of those frames
-    alone (fewer tiles than wave slots: no split) computes -- for 2 / 9 / 3 pieces, ragged last tiles included."""
+def test_mcep_backward_split_tail_is_bit_identical_to_whole_tiles(tail_tiles, tail_frames, two_wave, monkeypatch):
+    """The one-wave tuned backward (DSA_MCEP_BWD2=0, or a history without rt rows) cuts a short last round of tiles into pieces of
+    Newton steps that hand (lbar, mbar) over through memory (csrc/mcep_mfma_bwd_f16.h, DSA_ALGO_SCRATCH_HAS_WORKSPACE).  Frames are
+    independent and a piece repeats the whole tile's arithmetic step by step, so the gradient of the tail frames must equal BIT FOR
+    BIT what a launch of those frames alone (fewer tiles than wave slots: no split) computes -- for 2 / 9 / 3 pieces, ragged last
+    tiles included.  The two-wave kernel (the default) has no split tail; the same statement -- a frame's gradient does not depend on
+    the launch it is part of -- is checked for it too."""
+    if not two_wave:
+        monkeypatch.setenv("DSA_MCEP_BWD2", "0")
     _, mcep = _modules()
     gen = torch.Generator().manual_seed(tail_tiles)
     F = 2 * 1024 * 16 + tail_frames                      # two full rounds of the 1024 wave slots + the tail
