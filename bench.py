@@ -323,10 +323,10 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
                 "algorithmic": {"achieved": MCEP_BWD_FLOP_PER_FRAME * fr / t_mb / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": MCEP_BWD_FLOP_PER_FRAME * fr / t_mb / 1e12 / FP32_PEAK_TFLOPS,
                                 "flop_per_frame": MCEP_BWD_FLOP_PER_FRAME},
-                "datapath": datapath_roofline(isa_mix("mcep_mfma_bwd_kernel_h"), N_ITER, fr, t_mb),
+                "datapath": datapath_roofline(isa_mix("mcep_mfma_bwd2_kernel_h"), N_ITER, fr, t_mb),
                 "pmc": pm["derived"] if pm else None, "pmc_source": pm["_source"] if pm else None,
-                "arith": "five matrix chains as 3-term binary16 MFMA splits (fp32 accumulate), two-right-hand-side 25x25 "
-                         "elimination in unpacked fp32 VALU", "last_kernel": k_bwd,
+                "arith": "three matrix chains as 3-term binary16 MFMA splits (fp32 accumulate; the forward's rt rows are saved), "
+                         "two-right-hand-side 25x25 block elimination + the u g^T outer product on v_mfma_f32_4x4x1, two waves per SIMD", "last_kernel": k_bwd,
             },
             "roofline_stft_bwd": (lambda pmb: {
                 "kernel": k_sbwd, "bound": "hbm", "achieved": STFT_BWD_BYTES_PER_FRAME * fr / t_sb / 1e9,

@@ -12,12 +12,12 @@ from collections import defaultdict
 # <0, 400, true, 1|2> of the same template as the spectrum-out kernel <0, 400, true, 0>
 KERNELS = {"mcep_mfma_fwd": ("mcep_mfma_fwd_kernel_hILi8ELb0ELb0E", None), "stft512_fwd": ("stft512_fwd_pk_kernel<0, 400, true, 0,", None),
            "stft512_fbank_fwd": ("stft512_fwd_pk_kernel<0, 400, true, 1,", None),
-           "mcep_mfma_bwd": ("mcep_mfma_bwd_kernel_h", None), "stft512_bwd": ("stft512_bwd_pk_kernel<400, 80, false, false>", None),
+           "mcep_mfma_bwd": ("mcep_mfma_bwd2_kernel_h", None), "stft512_bwd": ("stft512_bwd_pk_kernel<400, 80, false, false>", None),
            "stft512_istft": ("stft512_bwd_pk_kernel<400, 80, true, false>", None),
            "frame_window_lpc24_fwd": ("frame_window_lpc24_kernel", None),
            "frame_window_lpc24_mfma_fwd": ("frame_window_lpc24_mfma_kernel", None),
            "frame_window_lpc24_bwd_mfma": ("frame_window_lpc24_bwd_mfma_kernel", None), "stft512_mcep_fused_fwd": ("mcep_mfma_fwd_kernel_hILi8ELb1ELb0E", None)}   # (these two arrive mangled)
-WAVES_PER_SIMD = {"mcep_mfma_fwd": 2, "stft512_fwd": 4, "stft512_fbank_fwd": 4, "mcep_mfma_bwd": 1, "stft512_bwd": 4, "stft512_istft": 4,
+WAVES_PER_SIMD = {"mcep_mfma_fwd": 2, "stft512_fwd": 4, "stft512_fbank_fwd": 4, "mcep_mfma_bwd": 2, "stft512_bwd": 4, "stft512_istft": 4,
                   "frame_window_lpc24_fwd": 2, "frame_window_lpc24_mfma_fwd": 3, "frame_window_lpc24_bwd_mfma": 2, "stft512_mcep_fused_fwd": 2}
 FRAMES = 204800
 

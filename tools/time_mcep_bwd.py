@@ -9,7 +9,7 @@ def timeit(fn, n=20):
     e0.record()
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n * 1e3
-x = torch.randn(1024, 16000, device=dev)
+x = torch.randn(int(os.environ.get("B", "1024")), 16000, device=dev)
 stft = dsp.STFT(400, 80, 512, device=dev)
 mcep = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, device=dev)
 with torch.no_grad():
