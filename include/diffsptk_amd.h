@@ -81,8 +81,8 @@ enum { DSA_ALGO_AUTO = 0, DSA_ALGO_GENERIC = 1, DSA_ALGO_TUNED = 2 };
 #define DSA_MCEP_BWD_WORKSPACE_BYTES (DSA_SCRATCH_BYTES + 512 * 16 * 32 * 4)
 /* OR-ed into `algo` of dsa_mcep_fwd / dsa_stft_mcep_fwd / dsa_mcep_bwd (0.1.8): `mc_hist` continues behind the (n_iter + 1, F, M + 1)
  * iterates with (n_iter, F, 2 M + 1) float32 rows -- every Newton step's rt = e E (mcep.py:212-215).  The tuned forward writes them, the
- * tuned backward reads them instead of recomputing its second forward chain (1.55 -> 1.4 ms per 204 800 frames for 196 more bytes per
- * frame and step).  Both calls of a pair must agree on the flag; the generic kernels ignore the extra room. */
+ * tuned backward reads them instead of recomputing its second forward chain -- and runs as the two-waves-per-SIMD kernel
+ * (csrc/mcep_mfma_bwd2_f16.h: 1.56 -> 1.1-1.2 ms per 204 800 frames for 196 more bytes per frame and step).  Both calls of a pair must agree on the flag; the generic kernels ignore the extra room. */
 #define DSA_ALGO_HIST_HAS_RT 0x400
 
 int dsa_version(void);
