@@ -59,6 +59,8 @@ inline bool ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64
 // 24 x 24 Toeplitz-plus-Hankel systems, float32, 16 per wave in the quad layout (csrc/mcep_mfma.hip)
 int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, void* g, hipStream_t st, int r_stride = 24,
                        int r_off = 0, const void* add = nullptr);
+// the whole Newton step of mgcep (gamma != 0, fft_length 512, cep_order 24, float32) in one launch: csrc/mgcep_step_f16.h
+int mgcep_step_solve_fwd(const void* x, const void* b1, int64_t F, double gamma, const void* images, void* b1_out, void* r_out, hipStream_t st);
 // orders 2 .. 55, float32, strided operands (csrc/thsolve_quad.hip)
 int thsolve_quadn_fwd(const void* p, int ldp, const void* q, int ldq, const void* r, int ldr, const void* sub, const void* add, int64_t F,
                       int n, void* g, hipStream_t st);

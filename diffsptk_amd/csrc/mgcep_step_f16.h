@@ -1,0 +1,272 @@
+// Round 5: one Newton step of the mel-generalized cepstral analysis (gamma != 0) in ONE launch, matrix chains as 3-term binary16
+// splits (included by mcep_mfma.hip: the block elimination, the split helpers and the quad-layout Toeplitz-plus-Hankel solve live
+// there).  mgcep.py:199-230 for fft_length 512, cep_order 24, float32:
+//   (re, im) = b1 (Cr, Ci);  X = 1 + g re, Y = g im, D = X^2 + Y^2, pp = x D^(-1/g - 1), qq = pp / D                 (:199-209)
+//   pt = pp Pr,  qt = (1 + g)(qq (X^2 - Y^2) Qr + qq 2XY Qi),  r = pp X Rr + pp Y Ri                                   (:212-220)
+//   b1 <- b1 + solve(toeplitz(pt) + hankel(qt), r[1:])                                                                 (:226-230)
+// Rounds 2-4 ran this as dsa_mgcep_step (60 float32 matrix instructions per 16 bins on the float32 datapath: 95 us per 51 200
+// frames) + dsa_thsolve (32 us) with (pt, qt, r) through memory.  Here one wave = 16 frames, eight waves per workgroup (two per
+// SIMD), the bins in nine STAGES of 32: the stage's operand images (32 KB, tables.mgcep_step_h_images) are staged through LDS for
+// the eight waves (double-buffered, one barrier per stage);
+//   first chain   2 tiles x (re, im) x 3 terms on v_mfma_f32_16x16x32_f16, b1 scaled per frame by a power of two;
+//   spectra       40 values per lane (5 spectra x 2 tiles x 4), scaled by the STAGE's own power of two (from their maximum over
+//                 the frame's 32 bins) and split into binary16 hi + lo: the C/D tiles of the first chain ARE the k-slots of the
+//                 second chain's B operands (as in the mel-cepstral kernels);
+//   second chain  12 (matrix tile, spectrum) x 3 terms, fresh accumulators per stage, added into float32 sums with the stage's scale;
+// then the 24 x 24 system of the wave's 16 frames in the quad layout (the 4 x 4 x 1 block elimination of thsolve_quad24_kernel,
+// with its pivoted re-solve for systems that are not positive definite) and the update of b1.  r is written out as well (the gain
+// of the last step, mgcep.py:221, reads it).
+#pragma once
+
+namespace dsa {
+
+namespace mgh {
+using namespace mm;
+constexpr int WAVES = 8;
+constexpr int STAGES = 9;
+constexpr int C1_HALVES = 2 * 2 * 2 * 512;      // [t][Cr | Ci][hi | lo][64 lane][8]
+constexpr int W2_HALVES = 12 * 2 * 512;         // [c][hi | lo][64 lane][8]
+constexpr int STAGE_HALVES = C1_HALVES + W2_HALVES;   // 16 384 halves = 32 KB
+constexpr int LOG2_SC = 12, LOG2_SW = 20;       // tables.MGCEP_STEP_H_LOG2_SC / _SW
+constexpr int VMAX_LOG2 = 13;                   // scaled B operands are below 2^13
+// LDS (floats): two stage buffers | per-wave solve records (16 x kTq) | constants [0, 28) zeros, [32, 57) e_24
+constexpr int L_STAGE = 0;
+constexpr int L_WAVE = 2 * STAGE_HALVES / 2;
+constexpr int L_CST = L_WAVE + WAVES * 16 * kTq;
+constexpr int LDS_FLOATS = L_CST + 64;
+static_assert(LDS_FLOATS * 4 <= 160 * 1024 && L_WAVE % 4 == 0, "the mgcep step's LDS carve-up");
+}  // namespace mgh
+
+__global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __restrict__ x, const float* b1, long F, float gamma,
+                                                             const _Float16* __restrict__ img, float* b1_out,   // (b1_out may be b1)
+                                                             float* __restrict__ r_out)
+{
+    using namespace mgh;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int nq = lane >> 2, gs = lane & 3;
+    if (tid < 64) lds[L_CST + tid] = tid == 32 + 24 ? 1.f : 0.f;
+    float* wl = lds + L_WAVE + wave * 16 * kTq;
+    const float* cst = lds + L_CST;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float ex = -1.f / gamma - 1.f;
+    const float og = 1.f + gamma;
+    const long ntiles = (F + 15) / 16;
+    const long nrounds = (ntiles + (long)gridDim.x * WAVES - 1) / ((long)gridDim.x * WAVES);
+    // staging: a stage = 2048 16-byte pieces, 4 per thread
+    const f32x4* img4 = reinterpret_cast<const f32x4*>(img);
+    f32x4 st[4];
+    auto fetch = [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st[q] = img4[(long)j * (STAGE_HALVES / 8) + tid + 512 * q];
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        f32x4* d = reinterpret_cast<f32x4*>(lds + L_STAGE) + buf * (STAGE_HALVES / 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[tid + 512 * q] = st[q];
+    };
+    for (long round = 0; round < nrounds; ++round) {
+        const long tile_raw = (round * gridDim.x + blockIdx.x) * WAVES + wave;   // uniform
+        const bool tile_ok = tile_raw < ntiles;
+        const long tile = tile_ok ? tile_raw : ntiles - 1;
+        const long t16 = tile * 16;
+        const int rows_here = (int)((F - t16 < 16) ? F - t16 : 16);
+        const bool f_ok = tile_ok && n < rows_here;
+        const int rn = n < rows_here ? n : rows_here - 1;
+        const float* xt = x + t16 * 257;
+        const float* bt = b1 + t16 * 24;
+        fetch(0);
+        // B operand of the first chain: b1[8 g + i] of this lane's frame, scaled per frame
+        float bv[8];
+        float bmax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bv[i] = g < 3 ? bt[rn * 24 + 8 * g + i] : 0.f;
+            bmax = __builtin_fmaxf(bmax, __builtin_fabsf(bv[i]));
+        }
+        bmax = rows_max4(bmax);
+        const int s_b = 12 - __builtin_amdgcn_frexp_expf(bmax);
+        f16x8 bh, bl;
+        {
+            float ms[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ms[i] = __builtin_ldexpf(bv[i], s_b);
+            split8(ms, bh, bl);
+        }
+        const int k1 = -s_b - LOG2_SC;      // (re, im) = 2^k1 x the first chain's accumulators
+        f32x4 acc[7];                       // pt 0-1 | qt 2-4 | r 5-6: C/D layout, lane (n, g) register r <-> column 16 t + 4 g + r
+#pragma unroll
+        for (int t = 0; t < 7; ++t) acc[t] = zero4;
+        stage(0);
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < STAGES; ++j) {
+            const int buf = j & 1;
+            if (j + 1 < STAGES) fetch(j + 1);
+            const f16x8* c1 = reinterpret_cast<const f16x8*>(lds + L_STAGE) + buf * (STAGE_HALVES / 8) + lane;
+            const f16x8* w2 = c1 + C1_HALVES / 8;
+            // the lane's spectrum values: bins 32 j + 16 t + 4 g + r (only bin 256 exists in the last stage)
+            f32x4 xv[2] = {zero4, zero4};
+            if (j < 8) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) xv[t] = *reinterpret_cast<const f32x4_u4*>(xt + rn * 257 + 32 * j + 16 * t + 4 * g);
+            } else if (g == 0) {
+                xv[0][0] = xt[rn * 257 + 256];
+            }
+            // first chain
+            f32x4 re[2], im[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f16x8 crh = c1[((t * 2 + 0) * 2 + 0) * 64], crl = c1[((t * 2 + 0) * 2 + 1) * 64];
+                const f16x8 cih = c1[((t * 2 + 1) * 2 + 0) * 64], cil = c1[((t * 2 + 1) * 2 + 1) * 64];
+                re[t] = mfma_h(crl, bh, zero4);
+                im[t] = mfma_h(cil, bh, zero4);
+                re[t] = mfma_h(crh, bl, re[t]);
+                im[t] = mfma_h(cih, bl, im[t]);
+                re[t] = mfma_h(crh, bh, re[t]);
+                im[t] = mfma_h(cih, bh, im[t]);
+            }
+            // the five spectra
+            float s[5][8];
+            float smax = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float X = __builtin_fmaf(gamma, __builtin_ldexpf(re[t][r], k1), 1.f), Y = gamma * __builtin_ldexpf(im[t][r], k1);
+                    const float XX = X * X, YY = Y * Y, D = XX + YY;
+                    const float dp = __builtin_amdgcn_exp2f(ex * __builtin_amdgcn_logf(D));   // D > 0; 1 ulp each (as dsa_mgcep_step)
+                    const float pp = xv[t][r] * dp;
+                    const float qq = pp * __builtin_amdgcn_rcpf(D);
+                    const int i = 4 * t + r;
+                    s[0][i] = pp;
+                    s[1][i] = qq * (XX - YY);
+                    s[2][i] = qq * (2.f * X * Y);
+                    s[3][i] = pp * X;
+                    s[4][i] = pp * Y;
+                    smax = __builtin_fmaxf(smax, __builtin_fmaxf(__builtin_fabsf(s[0][i]), __builtin_fabsf(s[1][i])));
+                    smax = __builtin_fmaxf(smax, __builtin_fmaxf(__builtin_fabsf(s[2][i]), __builtin_fabsf(s[3][i])));
+                    smax = __builtin_fmaxf(smax, __builtin_fabsf(s[4][i]));
+                }
+            smax = rows_max4(smax);
+            const int s_g = VMAX_LOG2 - __builtin_amdgcn_frexp_expf(smax);
+            // second chain: k-slot (g, i = 4 t + r) <-> bin 32 j + 16 t + 4 g + r: the scaled values above ARE the B operands
+            f32x4 ag[7];
+#pragma unroll
+            for (int t = 0; t < 7; ++t) ag[t] = zero4;
+#pragma unroll
+            for (int in = 0; in < 5; ++in) {
+                float ms[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ms[i] = __builtin_ldexpf(s[in][i], s_g);
+                f16x8 sh, sl;
+                split8(ms, sh, sl);
+                const int c0 = in == 0 ? 0 : (in == 1 ? 2 : (in == 2 ? 5 : (in == 3 ? 8 : 10)));
+                const int nt = (in == 1 || in == 2) ? 3 : 2;
+                const int t0 = in == 0 ? 0 : (in < 3 ? 2 : 5);
+#pragma unroll
+                for (int tc = 0; tc < nt; ++tc) {
+                    const f16x8 wh = w2[((c0 + tc) * 2 + 0) * 64], wlo = w2[((c0 + tc) * 2 + 1) * 64];
+                    ag[t0 + tc] = mfma_h(wlo, sh, ag[t0 + tc]);
+                    ag[t0 + tc] = mfma_h(wh, sl, ag[t0 + tc]);
+                    ag[t0 + tc] = mfma_h(wh, sh, ag[t0 + tc]);
+                }
+            }
+            const int k2 = -s_g - LOG2_SW;
+#pragma unroll
+            for (int t = 0; t < 7; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][r] += __builtin_ldexpf(ag[t][r], k2);
+            if (j + 1 < STAGES) stage(buf ^ 1);   // the other buffer: its readers finished before the barrier that ended stage j - 1
+            __syncthreads();
+        }
+        // ---------------- the wave's 16 systems: windows (q | mirrored p | r[1:]) in the quad-layout solve's record ----------------
+        for (int e = lane; e < 16 * kTq; e += 64) wl[e] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        {
+            float* rec = wl + n * kTq;
+            const bool row_ok = n < rows_here && tile_ok;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = 16 * t + 4 * g + r;
+                    // a missing system: the identity (p = e_0), right-hand side 0
+                    const float pv = row_ok ? acc[t][r] : (col == 0 ? 1.f : 0.f);
+                    if (col < 24) { rec[52 + 27 + col] = pv; rec[52 + 27 - col] = pv; }
+                    const float rv = row_ok ? acc[5 + t][r] : 0.f;
+                    if (col >= 1 && col < 25) rec[104 + col - 1] = rv;
+                    if (f_ok && col < 25) r_out[(t16 + n) * 25 + col] = rv;
+                }
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = 16 * t + 4 * g + r;
+                    if (col < 47) rec[col] = row_ok ? og * acc[2 + t][r] : 0.f;
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const GroupMask gq = make_group_mask(gs);
+            const float* rt_q = wl + nq * kTq;
+            const float* rr_q = rt_q + 52;
+            float xq[KS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, keep_if(gq.m[1], -1.f)};
+            bool bad = false;
+            {
+                f32x4 a[blk::NBLK];
+                float ninvs[M1];
+                int gsv = gs;
+                asm volatile("" : "+v"(gsv));
+                const float* zr = cst;
+                const float* pa6 = gsv == 0 ? cst + 32 : (gsv == 1 ? rt_q + 104 : zr);   // column 24: e_24 | right-hand side | 0
+                blk_build_rows<0>(a, rt_q, rr_q, pa6, zr, gs);
+                blk_elim_all(a, gq, ninvs, std::make_integer_sequence<int, M1>{});
+                blk_backsub_all(a, xq, gq, ninvs, std::make_integer_sequence<int, blk::NG>{});
+                // no pivoting: sound for the positive definite systems of the analysis; a pivot that is not positive marks the system
+                // for the pivoted re-solve below (as thsolve_quad24_kernel)
+#pragma unroll
+                for (int k = 0; k < M1 - 1; ++k) bad |= !(ninvs[k] < 0.f && ninvs[k] > -3.0e38f);
+            }
+            const long fq = t16 + nq;
+            const bool q_ok = tile_ok && nq < rows_here;
+            if (q_ok && !bad) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) b1_out[fq * 24 + gs + 4 * c] = b1[fq * 24 + gs + 4 * c] + xq[c];
+            }
+            unsigned long long marked = __ballot(bad && gs == 0 && q_ok);
+            while (marked) {   // uniform; normally empty
+                const int bl_ = __builtin_ctzll(marked);
+                marked &= marked - 1;
+                const int sy = bl_ >> 2;
+                const float* qs2 = wl + sy * kTq;               // q window
+                const float* ps2 = qs2 + 52 + 27;               // p[d] at the centre of the mirrored window
+                const float rhs = lane < 24 ? qs2[104 + lane] : 0.f;
+                int col;
+                float sol;
+                th_solve_reg<float, 24>(ps2, qs2, rhs, 24, lane, col, sol);
+                const long fs = t16 + sy;
+                if (lane < 24) b1_out[fs * 24 + col] = b1[fs * 24 + col] + sol;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int mgcep_step_solve_fwd(const void* x, const void* b1, int64_t F, double gamma, const void* images, void* b1_out, void* r_out, hipStream_t st)
+{
+    const int lds_bytes = mgh::LDS_FLOATS * 4;
+    static std::atomic<uint64_t> attr{0};
+    if (!ensure_dynamic_lds((const void*)mgcep_step_h_kernel, lds_bytes, attr))
+        return fail(DSA_ERR_LAUNCH, "mgcep_step_solve: cannot reserve the LDS stage buffers%s");
+    const long ntiles = (long)((F + 15) / 16);
+    long blocks = (ntiles + mgh::WAVES - 1) / mgh::WAVES;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(mgcep_step_h_kernel, dim3((unsigned)blocks), dim3(mgh::WAVES * 64), lds_bytes, st, (const float*)x, (const float*)b1,
+                       (long)F, (float)gamma, (const _Float16*)images, (float*)b1_out, (float*)r_out);
+    return check_launch("mgcep_step_solve");
+}
+
+}  // namespace dsa

@@ -8,6 +8,8 @@ Toeplitz-plus-Hankel solve kernel (csrc/mgc.hip).  Gradients: the kernels' own b
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -71,6 +73,13 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
         else:
             self.step_images = None
             self.step_images_bwd = None
+        # ... and at cep_order 24 the WHOLE step (chains as binary16 splits + the solve + the update) is one launch without a graph
+        # (dsa_mgcep_step_solve; DSA_MGCEP_STEP_SOLVE=0: the two launches of rounds 2-4, for A/B runs)
+        if self.step_images is not None and cep_order == 24 and -1 < gamma < 0:
+            self.register_buffer("step_images_h", torch.from_numpy(tables.mgcep_step_h_images(fft_length, cep_order, float(alpha))).to(device),
+                                 persistent=False)
+        else:
+            self.step_images_h = None
         self.b2mc = MLSADigitalFilterCoefficientsToMelCepstrum(M, alpha, device=device, dtype=dtype)
         self.mc2b = MelCepstrumToMLSADigitalFilterCoefficients(M, alpha, device=device, dtype=dtype)
         self.gc2gc = MelGeneralizedCepstrumToMelGeneralizedCepstrum(M, M, in_gamma=-1, out_gamma=gamma, device=device,
@@ -88,6 +97,14 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
 
         def newton(gamma, b1, need_gain=True):   # need_gain: b0 = sqrt(eps) is only read after the LAST step of a run
             b1_old = b1
+            if gamma != -1 and self.step_images_h is not None and x.dtype == torch.float32 and self.step_images_h.device == x.device \
+                    and not (torch.is_grad_enabled() and (x.requires_grad or b1.requires_grad)) and os.environ.get("DSA_MGCEP_STEP_SOLVE") != "0":
+                b1, r = ops.mgcep_step_solve(x, b1, self.step_images_h, gamma)     # mgcep.py:199-230 in ONE launch
+                if not need_gain:
+                    return None, b1, None
+                if fused_gain:
+                    return None, b1, ops.mgcep_gain(r, b1_old, gamma, b1)          # mgcep.py:221 (b_eps = the step's input coefficients)
+                return torch.sqrt(epsilon(gamma, r, b1_old)).unsqueeze(-1), b1, None
             if gamma == -1:                                        # mgcep.py:196-197, 213-215
                 pt = mm(x, self.Pr)
                 qt = None                                          # q (1 + gamma) = 0: no Hankel part

@@ -521,6 +521,63 @@ def mgcep_step_images(fft_length: int, cep_order: int, alpha: float) -> np.ndarr
     return out.astype(np.float32)
 
 
+MGCEP_STEP_H_LOG2_SC = 12   # scale of the (Cr, Ci) images of dsa_mgcep_step_solve (|C| <= 1.5)
+MGCEP_STEP_H_LOG2_SW = 20   # scale of the (Pr, Qr, Qi, Rr, Ri) images (|W| <= 0.008)
+
+
+def mgcep_step_h_images(fft_length: int, cep_order: int, alpha: float) -> np.ndarray:
+    """Binary16 hi / lo operand images of dsa_mgcep_step_solve (csrc/mgcep_step_f16.h), float16, shape (9, 16384): per STAGE of 32
+    bins (two 16-bin tiles t = 0, 1; bins 257 .. 287 of the ninth stage are zero rows)
+      [2 t][2 (Cr, Ci)][2 (hi, lo)][64 lane][8 i]   first chain, A operand of v_mfma_f32_16x16x32_f16: row = bin 32 j + 16 t + (lane & 15),
+                                                     k-slot (g = lane >> 4, i) <-> coefficient 1 + 8 g + i (zero past the order)
+      [12 c][2 (hi, lo)][64 lane][8 i]              second chain: row = column 16 tile_c + (lane & 15) of the chain's matrix,
+                                                     k-slot (g, i = 4 t + r) <-> bin 32 j + 16 t + 4 g + r
+    chains c as in mgcep_step_images: 0-1 Pr[:, :M] | 2-4 Qr[:, 2:] | 5-7 Qi[:, 2:] | 8-9 Rr | 10-11 Ri.  Each float32 entry v is stored as
+    hi = binary16(S v), lo = binary16(S v - hi) with S = 2^12 (C) / 2^20 (the others).  fft_length 512, cep_order 24."""
+    if fft_length != 512 or cep_order != 24:
+        raise ValueError("mgcep_step_h_images: fft_length 512 and cep_order 24 only")
+    M, K = cep_order, fft_length // 2 + 1
+    m = mgcep_matrices(fft_length, cep_order, float(alpha))
+    Cr, Ci = m["Cr"], m["Ci"]                                    # (M + 1, K)
+    mats = [(m["Pr"][:, :M], 2), (m["Qr"][:, 2:], 3), (m["Qi"][:, 2:], 3), (m["Rr"], 2), (m["Ri"], 2)]
+    lanes = np.arange(64)
+    li, lg = lanes & 15, lanes >> 4
+    sc, sw = float(2 ** MGCEP_STEP_H_LOG2_SC), float(2 ** MGCEP_STEP_H_LOG2_SW)
+    out = np.zeros((9, 16384), dtype=np.float16)
+
+    def hilo(v):
+        hi = v.astype(np.float16)
+        lo = (v - hi.astype(np.float64)).astype(np.float16)
+        return hi, lo
+
+    for j in range(9):
+        c1 = np.zeros((2, 2, 2, 64, 8), dtype=np.float16)
+        for t in range(2):
+            for ci_, C in enumerate((Cr, Ci)):
+                v = np.zeros((64, 8))
+                for i in range(8):
+                    row = 1 + 8 * lg + i
+                    col = 32 * j + 16 * t + li
+                    ok = (row <= M) & (col < K)
+                    v[ok, i] = sc * C[row[ok], col[ok]]
+                c1[t, ci_, 0], c1[t, ci_, 1] = hilo(v)
+        w2 = np.zeros((12, 2, 64, 8), dtype=np.float16)
+        c = 0
+        for W, ntile in mats:
+            for tc in range(ntile):
+                v = np.zeros((64, 8))
+                for i in range(8):
+                    b = 32 * j + 16 * (i >> 2) + 4 * lg + (i & 3)
+                    col = 16 * tc + li
+                    ok = (b < K) & (col < W.shape[1])
+                    v[ok, i] = sw * W[b[ok], col[ok]]
+                w2[c, 0], w2[c, 1] = hilo(v)
+                c += 1
+        out[j, :4096] = c1.reshape(-1)
+        out[j, 4096:] = w2.reshape(-1)
+    return out
+
+
 def mgcep_step_bwd_images(fft_length: int, cep_order: int, alpha: float) -> np.ndarray:
     """Operand images of dsa_mgcep_step_bwd (csrc/mgc.hip:mgcep_step_bwd_kernel): per 16-bin tile the forward's first-chain
     operands, the second-chain matrices TRANSPOSED (bin rows x column k-steps: Pr[:, :M] 6 | Qr[:, 2:] 12 | Qi[:, 2:] 12 | Rr 7 |

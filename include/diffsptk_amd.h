@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 124 /* 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
+#define DSA_VERSION 125 /* 0.1.9: + dsa_mgcep_step_solve; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
@@ -346,6 +346,14 @@ int dsa_thsolve_update_fwd(const void* p, const void* q, const void* r, int64_t 
  * caller once per configuration (layout: csrc/mgc.hip, mgcep_step_kernel; diffsptk_amd.utils.tables.mgcep_step_images).  Forward only. */
 int dsa_mgcep_step(const void* x, const void* b1, int64_t F, int32_t fft_length, int32_t M, double gamma, const void* images,
                    int32_t dtype, void* pt, void* qt, void* r, void* stream);
+/* (0.1.9) The WHOLE Newton step in one launch (mgcep.py:199-230; float32, fft_length 512, cep_order 24, gamma in (-1, 0)): the spectrum
+ * arithmetic, the five row products as 3-term binary16 splits on the matrix pipe, the 24 x 24 Toeplitz-plus-Hankel solve (block
+ * elimination, pivoted re-solve for systems that are not positive definite) and the update: x:(F,257), b1:(F,24) ->
+ * b1_out:(F,24) = b1 + solve(toeplitz(pt) + hankel(qt), r[1:]) (b1_out may be b1), r:(F,25) (what the gain of mgcep.py:221 reads).
+ * `images_h`: 9 x 16384 binary16, built by the caller once per configuration (diffsptk_amd.utils.tables.mgcep_step_h_images; layout:
+ * csrc/mgcep_step_f16.h).  Replaces dsa_mgcep_step + dsa_thsolve_update_fwd (95 + 32 us per 51 200 frames).  Forward only. */
+int dsa_mgcep_step_solve(const void* x, const void* b1, int64_t F, int32_t fft_length, int32_t M, double gamma, const void* images_h,
+                         int32_t dtype, void* b1_out, void* r, void* stream);
 /* Backward of dsa_mgcep_step in one launch: cotangents gpt:(F,M), gqt:(F,2M-1), gr:(F,M+1) -> gx:(F,L/2+1) (+ gx_in when not
  * NULL: the spectrum enters every Newton step, so the steps' contributions accumulate; gx_in may be gx) and gb1:(F,M).
  * `images_bwd`: 17 x 4608 float32 built by the caller (diffsptk_amd/utils/tables.py:mgcep_step_bwd_images). */
