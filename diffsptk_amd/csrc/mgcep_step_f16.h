@@ -37,6 +37,9 @@ constexpr int LDS_FLOATS = L_CST + 64;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024 && L_WAVE % 4 == 0, "the mgcep step's LDS carve-up");
 }  // namespace mgh
 
+#ifndef MGH_ABL
+#define MGH_ABL 0   // measurement builds only: 1 no staging after stage 0, 2 no barrier per stage (with 1), 4 no solve, 8 no second chain
+#endif
 __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __restrict__ x, const float* b1, long F, float gamma,
                                                              const _Float16* __restrict__ img, float* b1_out,   // (b1_out may be b1)
                                                              float* __restrict__ r_out)
@@ -68,7 +71,9 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
         for (int q = 0; q < 4; ++q) d[tid + 512 * q] = st[q];
     };
     for (long round = 0; round < nrounds; ++round) {
-        const long tile_raw = (round * gridDim.x + blockIdx.x) * WAVES + wave;   // uniform
+        // wave-major within a round: a partly filled last round gives every workgroup its share on its FIRST waves (one per SIMD),
+        // instead of filling some workgroups with two waves per SIMD and leaving the others idle
+        const long tile_raw = (round * WAVES + wave) * gridDim.x + blockIdx.x;   // uniform
         const bool tile_ok = tile_raw < ntiles;
         const long tile = tile_ok ? tile_raw : ntiles - 1;
         const long t16 = tile * 16;
@@ -99,22 +104,33 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
         f32x4 acc[7];                       // pt 0-1 | qt 2-4 | r 5-6: C/D layout, lane (n, g) register r <-> column 16 t + 4 g + r
 #pragma unroll
         for (int t = 0; t < 7; ++t) acc[t] = zero4;
+        // the lane's spectrum values of a stage: bins 32 j + 16 t + 4 g + r (only bin 256 exists in the last stage); requested a whole
+        // stage ahead (a request that goes to memory takes thousands of cycles, and loads return in order)
+        f32x4 xn[2] = {zero4, zero4};
+        auto xfetch = [&](int j) __attribute__((always_inline)) {
+            if (j < 8) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) xn[t] = *reinterpret_cast<const f32x4_u4*>(xt + rn * 257 + 32 * j + 16 * t + 4 * g);
+            } else {
+                xn[0] = zero4;
+                xn[1] = zero4;
+                if (g == 0) xn[0][0] = xt[rn * 257 + 256];
+            }
+        };
+        xfetch(0);
         stage(0);
         __syncthreads();
 #pragma unroll 1
         for (int j = 0; j < STAGES; ++j) {
-            const int buf = j & 1;
-            if (j + 1 < STAGES) fetch(j + 1);
+            const int buf = (MGH_ABL & 1) ? 0 : (j & 1);
+            const f32x4 xv[2] = {xn[0], xn[1]};
+            if (j + 1 < STAGES) {
+                xfetch(j + 1);
+                if (!(MGH_ABL & 1)) fetch(j + 1);
+            }
             const f16x8* c1 = reinterpret_cast<const f16x8*>(lds + L_STAGE) + buf * (STAGE_HALVES / 8) + lane;
             const f16x8* w2 = c1 + C1_HALVES / 8;
-            // the lane's spectrum values: bins 32 j + 16 t + 4 g + r (only bin 256 exists in the last stage)
-            f32x4 xv[2] = {zero4, zero4};
-            if (j < 8) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) xv[t] = *reinterpret_cast<const f32x4_u4*>(xt + rn * 257 + 32 * j + 16 * t + 4 * g);
-            } else if (g == 0) {
-                xv[0][0] = xt[rn * 257 + 256];
-            }
+            if (tile_ok) {
             // first chain
             f32x4 re[2], im[2];
 #pragma unroll
@@ -157,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
 #pragma unroll
             for (int t = 0; t < 7; ++t) ag[t] = zero4;
 #pragma unroll
-            for (int in = 0; in < 5; ++in) {
+            for (int in = 0; in < ((MGH_ABL & 8) ? 1 : 5); ++in) {
                 float ms[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ms[i] = __builtin_ldexpf(s[in][i], s_g);
@@ -179,9 +195,11 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
             for (int t = 0; t < 7; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[t][r] += __builtin_ldexpf(ag[t][r], k2);
-            if (j + 1 < STAGES) stage(buf ^ 1);   // the other buffer: its readers finished before the barrier that ended stage j - 1
-            __syncthreads();
+            }
+            if (j + 1 < STAGES && !(MGH_ABL & 1)) stage(buf ^ 1);   // the other buffer: its readers finished before the barrier that ended stage j - 1
+            if (!(MGH_ABL & 2)) __syncthreads();
         }
+        if (!tile_ok) continue;   // (no workgroup barrier below this point)
         // ---------------- the wave's 16 systems: windows (q | mirrored p | r[1:]) in the quad-layout solve's record ----------------
         for (int e = lane; e < 16 * kTq; e += 64) wl[e] = 0.f;
         __builtin_amdgcn_wave_barrier();
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
                 }
         }
         __builtin_amdgcn_wave_barrier();
-        {
+        if (!(MGH_ABL & 4)) {
             const GroupMask gq = make_group_mask(gs);
             const float* rt_q = wl + nq * kTq;
             const float* rr_q = rt_q + 52;

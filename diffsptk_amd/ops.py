@@ -1240,17 +1240,21 @@ def thsolve_update(pt, qt, r, b1):
     return out
 
 
-def mgcep_step_solve(x, b1, images_h, gamma):
+def mgcep_step_solve(x, b1, images_h, gamma, out=None):
     """(b1 + solve(toeplitz(pt) + hankel(qt), r[1:]), r) of one WHOLE Newton step of mgcep.py:199-230 in one launch
     (dsa_mgcep_step_solve: binary16-split matrix chains + the block elimination; float32 / fft_length 512 / cep_order 24 /
-    gamma in (-1, 0)); forward only.  `images_h`: tables.mgcep_step_h_images as a float16 tensor."""
+    gamma in (-1, 0)); forward only.  `images_h`: tables.mgcep_step_h_images as a float16 tensor; `out`: where the updated coefficients
+    go (may be `b1` itself when that is contiguous)."""
     _require_device(x, b1, images_h)
     _same_dtype(x, b1)
     xc, bc = x.contiguous(), b1.contiguous()
     K, M = xc.size(-1), bc.size(-1)
     F = xc.numel() // K
     lead = xc.shape[:-1]
-    out = torch.empty_like(bc)
+    if out is None:
+        out = torch.empty_like(bc)
+    elif not (out.is_contiguous() and out.shape == bc.shape and out.dtype == bc.dtype and out.device == bc.device):
+        raise ValueError("mgcep_step_solve: `out` must be a contiguous tensor like b1")
     r = torch.empty(*lead, M + 1, device=x.device, dtype=x.dtype)
     with torch.cuda.device(x.device):
         _call("dsa_mgcep_step_solve", _p(xc), _p(bc), F, 2 * (K - 1), M, float(gamma), _p(images_h), _dtype_code(xc), _p(out), _p(r), _stream())

@@ -335,6 +335,53 @@ def test_mgcep_fused_spectrum_arithmetic_equals_the_differentiable_chain(dt, tol
         assert np.abs(a.double().cpu().numpy() - ref).max() <= (1e-8 if dt == torch.float64 else 3e-6) * np.abs(ref).max()   # float32 measured 8.4e-7
 
 
+@pytest.mark.parametrize("F", [1, 15, 16, 33, 1595, 2049 * 16 + 5])
+def test_mgcep_whole_step_in_one_launch_against_the_two_launch_step_and_the_oracle(F, monkeypatch):
+    """dsa_mgcep_step_solve (round 5: mgcep.py:199-230 in ONE launch at cep_order 24 / float32 / fft_length 512 -- the matrix chains as
+    3-term binary16 splits with per-stage power-of-two scales, the 24 x 24 block elimination and the update behind them) against
+    dsa_mgcep_step + dsa_thsolve_update_fwd (float32 matrix instructions) on the same inputs: r within 2e-6 of its maximum, the updated
+    coefficients within 1e-5 (measured 6e-7 / 2.4e-6 by tools/check_mgcep_step_solve.py); ragged frame counts around the 16-frame tiles and
+    past one round of the 2 048 wave slots; repeated launches bit-identical; in place (b1_out = b1); the analysis through the module
+    against the float64 oracle at 3e-6 (measured 4e-7; the two-launch step 8e-7)."""
+    gen = torch.Generator().manual_seed(F)
+    X = (torch.randn(F, 257, generator=gen).square() * torch.rand(F, 1, generator=gen) + 1e-3).to(DEV)
+    b1 = (0.05 * torch.randn(F, 24, generator=gen)).to(DEV)
+    for gamma in (-0.5, -1 / 3):
+        mg = dsp.MelGeneralizedCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, gamma=gamma, n_iter=3, device=DEV)
+        pt, qt, r = ops.mgcep_step(X, b1, mg.step_images, gamma)
+        ref_b = ops.thsolve_update(pt, qt, r, b1)
+        new_b, new_r = ops.mgcep_step_solve(X, b1, mg.step_images_h, gamma)
+        assert _lib.last_kernel() == "mgcep_step_solve"
+        assert torch.isfinite(new_b).all() and torch.isfinite(new_r).all()
+        assert float((new_r - r).abs().max()) <= 2e-6 * float(r.abs().max())
+        assert float((new_b - ref_b).abs().max()) <= 1e-5 * max(1.0, float(ref_b.abs().max()))
+        again_b, again_r = ops.mgcep_step_solve(X, b1, mg.step_images_h, gamma)
+        assert torch.equal(again_b, new_b) and torch.equal(again_r, new_r)
+        bi = b1.clone()
+        ops.mgcep_step_solve(X, bi, mg.step_images_h, gamma, out=bi)
+        assert torch.equal(bi, new_b)
+        if F >= 33:   # a frame's result does not depend on the launch it is part of
+            part_b, part_r = ops.mgcep_step_solve(X[:33], b1[:33], mg.step_images_h, gamma)
+            assert torch.equal(part_b[:32], new_b[:32]) and torch.equal(part_r[:32], new_r[:32])
+        with torch.no_grad():
+            y1 = mg(X)
+            monkeypatch.setenv("DSA_MGCEP_STEP_SOLVE", "0")
+            y0 = mg(X)
+            monkeypatch.delenv("DSA_MGCEP_STEP_SOLVE")
+        assert not torch.equal(y0, y1) or F < 16
+        if F <= 2048:
+            ref = O.mgcep(X.double().cpu().numpy(), 24, 0.42, gamma, 3)
+            for y in (y1, y0):
+                assert np.abs(y.double().cpu().numpy() - ref).max() <= 3e-6 * np.abs(ref).max()
+        else:
+            assert float((y1 - y0).abs().max()) <= 5e-6 * float(y0.abs().max())
+    # unsupported set-ups are refused, not approximated
+    with pytest.raises(Exception):
+        ops.mgcep_step_solve(X[:, :129].contiguous(), b1, mg.step_images_h, -0.5)
+    with pytest.raises(Exception):
+        ops.mgcep_step_solve(X, b1[:, :12].contiguous(), mg.step_images_h, -0.5)
+
+
 def test_mgcep_step_backward_kernel_against_float64_autograd():
     """With a gradient wanted the float32 / 512 / order <= 24 analysis runs the fused step forward AND its adjoint as one
     launch each (ops.MgcepStepFn: dsa_mgcep_step / dsa_mgcep_step_bwd), the order-24 solve's backward on the quad-layout
