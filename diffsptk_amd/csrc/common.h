@@ -61,6 +61,10 @@ int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, v
                        int r_off = 0, const void* add = nullptr);
 // the whole Newton step of mgcep (gamma != 0, fft_length 512, cep_order 24, float32) in one launch: csrc/mgcep_step_f16.h
 int mgcep_step_solve_fwd(const void* x, const void* b1, int64_t F, double gamma, const void* images, void* b1_out, void* r_out, hipStream_t st);
+// the spectral half of a Newton step of the untuned mel-cepstral analysis on binary16-split chains: csrc/mcep_resid_f16.h
+int64_t mcep_resid_h_images_bytes(int K, int M1);
+int mcep_resid_h_prepare(const void* D, int ldd, const void* E, int lde, int K, int M1, void* images, hipStream_t st);
+int mcep_resid_h_fwd(const void* logx, int64_t F, int K, const void* mc, int M1, const void* images, void* out, int ldo, hipStream_t st);
 // orders 2 .. 55, float32, strided operands (csrc/thsolve_quad.hip)
 int thsolve_quadn_fwd(const void* p, int ldp, const void* q, int ldq, const void* r, int ldr, const void* sub, const void* add, int64_t F,
                       int n, void* g, hipStream_t st);

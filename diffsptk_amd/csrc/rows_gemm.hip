@@ -634,3 +634,27 @@ DSA_EXPORT int dsa_mcep_newton_resid(const void* logx, int64_t F, int32_t K, con
     if (F == 0) return DSA_OK;
     return dsa::mcep_resid_mfma(logx, F, K, mc, n, D, ldd, E, lde, 2 * n - 1, rt, 2 * n - 1, (hipStream_t)stream);
 }
+
+DSA_EXPORT int64_t dsa_mcep_resid_images_bytes(int32_t K, int32_t n)
+{
+    if (K < 4 || n < 3 || n > 55) return 0;
+    return dsa::mcep_resid_h_images_bytes(K, n);
+}
+
+DSA_EXPORT int dsa_mcep_resid_prepare(const void* D, int32_t ldd, const void* E, int32_t lde, int32_t K, int32_t n, int32_t dtype, void* images,
+                                      void* stream)
+{
+    DSA_REQUIRE(K >= 4 && n >= 3 && ldd >= K && lde >= 2 * n - 1 && D && E && images, "mcep_resid_prepare: invalid arguments");
+    if (dtype != DSA_F32 || n > 55) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_resid_prepare: float32, orders up to 54%s");
+    return dsa::mcep_resid_h_prepare(D, ldd, E, lde, K, n, images, (hipStream_t)stream);
+}
+
+DSA_EXPORT int dsa_mcep_newton_resid_h(const void* logx, int64_t F, int32_t K, const void* mc, int32_t n, const void* images, int32_t dtype,
+                                       void* rt, void* stream)
+{
+    DSA_REQUIRE(F >= 0 && K >= 4 && n >= 3, "mcep_newton_resid_h: invalid sizes");
+    DSA_REQUIRE(logx && mc && images && rt, "mcep_newton_resid_h: null pointer");
+    if (dtype != DSA_F32 || n > 55) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_resid_h: float32, orders up to 54%s");
+    if (F == 0) return DSA_OK;
+    return dsa::mcep_resid_h_fwd(logx, F, K, mc, n, images, rt, 2 * n - 1, (hipStream_t)stream);
+}

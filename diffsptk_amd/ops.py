@@ -931,6 +931,40 @@ def mcep_newton_resid(logx, mc, D, E):
     return rt
 
 
+_RESID_IMAGES: dict = {}   # (D.data_ptr(), E.data_ptr(), D._version, E._version, shapes) -> (images, D, E): the binary16 operand images of dsa_mcep_newton_resid_h
+
+
+def mcep_resid_images(D, E):
+    """The binary16 hi / lo operand images dsa_mcep_newton_resid_h consumes (dsa_mcep_resid_prepare: one small launch), kept per pair
+    of tables (modules hold D and E as buffers for their lifetime; the cache keeps them alive with their images)."""
+    Dc, Ec = D.contiguous(), E.contiguous()
+    key = (Dc.data_ptr(), Ec.data_ptr(), Dc._version, Ec._version, tuple(Dc.shape), tuple(Ec.shape))
+    hit = _RESID_IMAGES.get(key)
+    if hit is not None:
+        return hit[0]
+    n, K = Dc.size(0), Dc.size(1)
+    nbytes = _lib.load().dsa_mcep_resid_images_bytes(K, n)
+    if nbytes <= 0:
+        return None
+    images = torch.empty(nbytes, dtype=torch.uint8, device=Dc.device)
+    with torch.cuda.device(Dc.device):
+        _call("dsa_mcep_resid_prepare", _p(Dc), Dc.size(1), _p(Ec), Ec.size(1), K, n, _dtype_code(Dc), _p(images), _stream())
+    if len(_RESID_IMAGES) > 16:
+        _RESID_IMAGES.clear()
+    _RESID_IMAGES[key] = (images, Dc, Ec)
+    return images
+
+
+def mcep_newton_resid_h(logx, mc, images):
+    """rt = exp(logx - 2 mc D) E (mcep.py:210-215) in one launch with both products as 3-term binary16 splits on the matrix pipe
+    (dsa_mcep_newton_resid_h: float32, 3 <= M + 1 <= 55); `images` from mcep_resid_images(D, E)."""
+    n, K = mc.size(-1), logx.size(-1)
+    rt = torch.empty(*mc.shape[:-1], 2 * n - 1, device=mc.device, dtype=mc.dtype)
+    with torch.cuda.device(mc.device):
+        _call("dsa_mcep_newton_resid_h", _p(logx), mc.numel() // n, K, _p(mc), n, _p(images), _dtype_code(mc), _p(rt), _stream())
+    return rt
+
+
 def _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter):
     """mcep.py:203-222 for the geometries the tuned kernel does not cover, as whole-batch launches of the library's own kernels
     instead of the one-workgroup-per-frame generic kernel: per Newton step the two row products (F, M+1) x (M+1, K) and
@@ -951,10 +985,17 @@ def _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter):
         logx = RowsLogFn.apply(X2)                                        # kept: every step's epilogue reads it
         mc = rows_gemm(logx, G)
     one_launch_resid = os.environ.get("DSA_MCEP_RESID", "1") != "0" and Xc.size(-1) >= 4
+    # round 5: the step's two products as binary16 splits (DSA_MCEP_RESID_H=0: the float32 matrix instructions of round 4, for A/B runs)
+    images_h = None
+    if not want_grad and 3 <= M1 <= 55 and one_launch_resid and os.environ.get("DSA_MCEP_RESID_H", "1") != "0" \
+            and D.dtype == torch.float32 and E.dtype == torch.float32:
+        images_h = mcep_resid_images(D, E)
     for _ in range(n_iter):
         if want_grad:
             e = RowsExpSubFn.apply(logx, MatmulRowsFn.apply(mc, D))       # :210-212
             rt = MatmulRowsFn.apply(e, E)                                 # :214-215
+        elif images_h is not None:
+            rt = mcep_newton_resid_h(logx, mc.contiguous(), images_h)     # :210-215 in one launch on the binary16 matrix pipe
         elif 3 <= M1 <= 55 and one_launch_resid:
             rt = mcep_newton_resid(logx, mc, D, E)                        # :210-215 in one launch, e never stored
         else:

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 125 /* 0.1.9: + dsa_mgcep_step_solve; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
+#define DSA_VERSION 125 /* 0.1.9: + dsa_mgcep_step_solve, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
@@ -277,6 +277,15 @@ int dsa_mcep_newton_update_bwd(const void* gs, const void* rt, const void* sol, 
  * product (v_mfma_f32_16x16x4_f32 for both) and never reaches memory (csrc/rows_gemm.hip:mcep_resid_mfma_kernel). */
 int dsa_mcep_newton_resid(const void* logx, int64_t F, int32_t K, const void* mc, int32_t n, const void* D, int32_t ldd,
                           const void* E, int32_t lde, int32_t dtype, void* rt, void* stream);
+/* (0.1.9) The same launch with both products as 3-term binary16 splits on the matrix pipe (csrc/mcep_resid_f16.h: 12 + 21 binary16
+ * products per 32 bins and 16 frames at order 49 instead of 82 float32 ones): `images` = dsa_mcep_resid_images_bytes(K, n) bytes of
+ * caller-owned device memory filled ONCE per configuration by dsa_mcep_resid_prepare from D (n x K) and E (K x 2n - 1); logx holds
+ * natural logarithms as for dsa_mcep_newton_resid. */
+int64_t dsa_mcep_resid_images_bytes(int32_t K, int32_t n);
+int dsa_mcep_resid_prepare(const void* D, int32_t ldd, const void* E, int32_t lde, int32_t K, int32_t n, int32_t dtype, void* images,
+                           void* stream);
+int dsa_mcep_newton_resid_h(const void* logx, int64_t F, int32_t K, const void* mc, int32_t n, const void* images, int32_t dtype,
+                            void* rt, void* stream);
 /* General float32 row product on the matrix instruction, for shapes the kernels behind dsa_freqt_fwd / _bwd do not cover (rows
  * of 512 values and more: the 1025-bin products of the 48 kHz set-ups of utils/public.py:22-104) and for the Newton step of
  * MelCepstralAnalysis (mcep.py:203-215) at geometries without a tuned kernel:
