@@ -725,6 +725,34 @@ def test_newton_residual_in_one_launch_against_float64(F, K, M1):
     assert float((rt - two).abs().max()) < 3e-6 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("F,K,M1", [(300, 1025, 50), (1000, 513, 35), (65, 1025, 55), (1, 257, 3), (130, 1027, 25), (64, 100, 41), (70, 64, 30),
+                                    (33, 33, 5), (17, 2049, 33), (129, 129, 32)])
+def test_newton_residual_on_binary16_splits_against_float64(F, K, M1):
+    """dsa_mcep_newton_resid_h (round 5): the same rt = exp(log X - 2 mc D) E with both products as 3-term binary16 splits on the matrix
+    pipe (operand images prepared once by dsa_mcep_resid_prepare, a stage's e scaled by its own power of two): against float64 (2e-6
+    of the largest entry; measured 4-6e-7, the float32 matrix instruction's 0.8-1.4e-6) and the float32 launch, on ragged sizes (K not
+    a multiple of 32, rows not a multiple of 64, orders at both ends of the one- and two-k-step instantiations), with spectra whose
+    level moves by 2^40 along a row (the per-stage scale) and rows that differ by 2^60 (the per-frame scale of mc); repeated launches
+    bit-identical; a prefix of the rows gives the same bits."""
+    g = torch.Generator().manual_seed(F + K + M1)
+    N = 2 * M1 - 1
+    logx = (torch.randn(F, K, generator=g) * 0.5 + torch.linspace(-14, 14, K)[None, :]).to(DEV)
+    mc = (torch.randn(F, M1, generator=g) * 0.05 * (2.0 ** torch.randint(-30, 3, (F, 1), generator=g).float())).to(DEV)
+    D = (torch.randn(M1, K, generator=g) / M1 ** 0.5).to(DEV)
+    E = (torch.randn(K, N, generator=g) / K).to(DEV)
+    img = ops.mcep_resid_images(D, E)
+    assert img is not None and img.numel() == ((K + 31) // 32) * (4 * ((M1 + 31) // 32) + 2 * ((N + 15) // 16)) * 512 * 2
+    rt = ops.mcep_newton_resid_h(logx, mc, img)
+    assert _lib.last_kernel() == "mcep_resid_h"
+    ref = torch.exp(logx.double() - 2 * mc.double() @ D.double()) @ E.double()
+    assert torch.isfinite(rt).all()
+    assert float((rt.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max())
+    assert float((rt - ops.mcep_newton_resid(logx, mc, D, E)).abs().max()) < 4e-6 * float(ref.abs().max())
+    assert torch.equal(rt, ops.mcep_newton_resid_h(logx, mc, img))
+    if F > 16:
+        assert torch.equal(rt[:16], ops.mcep_newton_resid_h(logx[:16].contiguous(), mc[:16].contiguous(), img))
+
+
 def test_untuned_analysis_runs_on_the_library_s_own_kernels_only():
     """No stock operator carries data in the untuned mel-cepstral analysis: the kernel names of a forward and of a forward +
     backward call at a 48 kHz set-up are all the library's (dsa_last_kernel after every launch is not observable from here, so
