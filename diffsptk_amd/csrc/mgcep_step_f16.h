@@ -42,7 +42,7 @@ static_assert(LDS_FLOATS * 4 <= 160 * 1024 && L_WAVE % 4 == 0, "the mgcep step's
 #endif
 __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __restrict__ x, const float* b1, long F, float gamma,
                                                              const _Float16* __restrict__ img, float* b1_out,   // (b1_out may be b1)
-                                                             float* __restrict__ r_out)
+                                                             float* __restrict__ r_out, float* __restrict__ pt_out, float* __restrict__ qt_out)   // pt / qt: NULL, or where a graph keeps the system
 {
     using namespace mgh;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -214,6 +214,7 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
                     // a missing system: the identity (p = e_0), right-hand side 0
                     const float pv = row_ok ? acc[t][r] : (col == 0 ? 1.f : 0.f);
                     if (col < 24) { rec[52 + 27 + col] = pv; rec[52 + 27 - col] = pv; }
+                    if (pt_out && f_ok && col < 24) pt_out[(t16 + n) * 24 + col] = pv;
                     const float rv = row_ok ? acc[5 + t][r] : 0.f;
                     if (col >= 1 && col < 25) rec[104 + col - 1] = rv;
                     if (f_ok && col < 25) r_out[(t16 + n) * 25 + col] = rv;
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
                 for (int r = 0; r < 4; ++r) {
                     const int col = 16 * t + 4 * g + r;
                     if (col < 47) rec[col] = row_ok ? og * acc[2 + t][r] : 0.f;
+                    if (qt_out && f_ok && col < 47) qt_out[(t16 + n) * 47 + col] = og * acc[2 + t][r];
                 }
         }
         __builtin_amdgcn_wave_barrier();
@@ -273,7 +275,8 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
     }
 }
 
-int mgcep_step_solve_fwd(const void* x, const void* b1, int64_t F, double gamma, const void* images, void* b1_out, void* r_out, hipStream_t st)
+int mgcep_step_solve_fwd(const void* x, const void* b1, int64_t F, double gamma, const void* images, void* b1_out, void* r_out, hipStream_t st,
+                         void* pt_out, void* qt_out)
 {
     const int lds_bytes = mgh::LDS_FLOATS * 4;
     static std::atomic<uint64_t> attr{0};
@@ -283,7 +286,7 @@ int mgcep_step_solve_fwd(const void* x, const void* b1, int64_t F, double gamma,
     long blocks = (ntiles + mgh::WAVES - 1) / mgh::WAVES;
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(mgcep_step_h_kernel, dim3((unsigned)blocks), dim3(mgh::WAVES * 64), lds_bytes, st, (const float*)x, (const float*)b1,
-                       (long)F, (float)gamma, (const _Float16*)images, (float*)b1_out, (float*)r_out);
+                       (long)F, (float)gamma, (const _Float16*)images, (float*)b1_out, (float*)r_out, (float*)pt_out, (float*)qt_out);
     return check_launch("mgcep_step_solve");
 }
 

@@ -98,12 +98,19 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
         def newton(gamma, b1, need_gain=True):   # need_gain: b0 = sqrt(eps) is only read after the LAST step of a run
             b1_old = b1
             if gamma != -1 and self.step_images_h is not None and x.dtype == torch.float32 and self.step_images_h.device == x.device \
-                    and not (torch.is_grad_enabled() and (x.requires_grad or b1.requires_grad)) and os.environ.get("DSA_MGCEP_STEP_SOLVE") != "0":
-                b1, r = ops.mgcep_step_solve(x, b1, self.step_images_h, gamma)     # mgcep.py:199-230 in ONE launch
+                    and os.environ.get("DSA_MGCEP_STEP_SOLVE") != "0":
+                # mgcep.py:199-230 in ONE launch; with a graph wanted the same launch keeps (pt, qt) and the backward is the adjoint
+                # solve + the step's adjoint (ops.MgcepStepSolveFn)
+                if torch.is_grad_enabled() and (x.requires_grad or b1.requires_grad):
+                    b1, r = ops.MgcepStepSolveFn.apply(x, b1, self.step_images_h, self.step_images_bwd, gamma)
+                    if not need_gain:
+                        return None, b1, None
+                    return torch.sqrt(epsilon(gamma, r, b1_old)).unsqueeze(-1), b1, None   # mgcep.py:221 (b_eps = the step's input coefficients)
+                b1, r = ops.mgcep_step_solve(x, b1, self.step_images_h, gamma)
                 if not need_gain:
                     return None, b1, None
                 if fused_gain:
-                    return None, b1, ops.mgcep_gain(r, b1_old, gamma, b1)          # mgcep.py:221 (b_eps = the step's input coefficients)
+                    return None, b1, ops.mgcep_gain(r, b1_old, gamma, b1)
                 return torch.sqrt(epsilon(gamma, r, b1_old)).unsqueeze(-1), b1, None
             if gamma == -1:                                        # mgcep.py:196-197, 213-215
                 pt = mm(x, self.Pr)

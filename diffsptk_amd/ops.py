@@ -1298,8 +1298,53 @@ def mgcep_step_solve(x, b1, images_h, gamma, out=None):
         raise ValueError("mgcep_step_solve: `out` must be a contiguous tensor like b1")
     r = torch.empty(*lead, M + 1, device=x.device, dtype=x.dtype)
     with torch.cuda.device(x.device):
-        _call("dsa_mgcep_step_solve", _p(xc), _p(bc), F, 2 * (K - 1), M, float(gamma), _p(images_h), _dtype_code(xc), _p(out), _p(r), _stream())
+        _call("dsa_mgcep_step_solve", _p(xc), _p(bc), F, 2 * (K - 1), M, float(gamma), _p(images_h), _dtype_code(xc), _p(out), _p(r), None, None,
+              _stream())
     return out, r
+
+
+class MgcepStepSolveFn(torch.autograd.Function):
+    """(b1 + solve(toeplitz(pt) + hankel(qt), r[1:]), r) of one Newton step of mgcep.py:199-230 with a graph: forward ONE launch
+    (dsa_mgcep_step_solve, which also leaves pt and qt behind), backward the adjoint solve (dsa_thsolve_bwd on the kept system and
+    the step's solution) followed by the step's adjoint (dsa_mgcep_step_bwd) -- what autograd composes from MgcepStepFn, ThSolveFn
+    and the additions around them, without their intermediate tensors.  float32 / fft_length 512 / cep_order 24."""
+
+    @staticmethod
+    def forward(ctx, x, b1, images_h, images_bwd, gamma):
+        _require_device(x, b1, images_h)
+        _same_dtype(x, b1)
+        xc, bc = x.contiguous(), b1.contiguous()
+        K, M = xc.size(-1), bc.size(-1)
+        F = xc.numel() // K
+        lead = xc.shape[:-1]
+        out = torch.empty_like(bc)
+        r = torch.empty(*lead, M + 1, device=x.device, dtype=x.dtype)
+        pt = torch.empty(*lead, M, device=x.device, dtype=x.dtype)
+        qt = torch.empty(*lead, 2 * M - 1, device=x.device, dtype=x.dtype)
+        with torch.cuda.device(x.device):
+            _call("dsa_mgcep_step_solve", _p(xc), _p(bc), F, 2 * (K - 1), M, float(gamma), _p(images_h), _dtype_code(xc), _p(out), _p(r), _p(pt),
+                  _p(qt), _stream())
+        ctx.save_for_backward(xc, bc, out, pt, qt, images_bwd)
+        ctx.gamma = float(gamma)
+        return out, r
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout, gr):
+        xc, bc, out, pt, qt, images_bwd = ctx.saved_tensors
+        K, M = xc.size(-1), bc.size(-1)
+        F = xc.numel() // K
+        gout = torch.zeros_like(out) if gout is None else gout.contiguous()
+        sol = out - bc
+        gp, gq, grhs = torch.empty_like(pt), torch.empty_like(qt), torch.empty_like(sol)
+        grf = torch.zeros(*xc.shape[:-1], M + 1, device=xc.device, dtype=xc.dtype) if gr is None else gr.contiguous().clone()
+        gx, gb1 = torch.empty_like(xc), torch.empty_like(bc)
+        with torch.cuda.device(xc.device):
+            _call("dsa_thsolve_bwd", _p(gout), _p(pt), _p(qt), _p(sol), F, M, _dtype_code(pt), _p(gp), _p(gq), _p(grhs), _stream())
+            grf[..., 1:] += grhs                                         # the right-hand side is r[1:]
+            _call("dsa_mgcep_step_bwd", _p(xc), _p(bc), _p(gp), _p(gq), _p(grf), F, 2 * (K - 1), M, ctx.gamma, _p(images_bwd), _dtype_code(xc),
+                  None, _p(gx), _p(gb1), _stream())
+        return gx, gb1 + gout, None, None, None
 
 
 def mgcep_spectra(x, b1, Cr, Ci, gamma):

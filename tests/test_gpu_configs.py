@@ -375,6 +375,20 @@ def test_mgcep_whole_step_in_one_launch_against_the_two_launch_step_and_the_orac
                 assert np.abs(y.double().cpu().numpy() - ref).max() <= 3e-6 * np.abs(ref).max()
         else:
             assert float((y1 - y0).abs().max()) <= 5e-6 * float(y0.abs().max())
+    # with a graph: the same launch forward (it keeps pt, qt), the adjoint solve + the step's adjoint backward -- against the graph
+    # autograd composes from the two-launch step (MgcepStepFn, ThSolveFn and the additions around them)
+    if F <= 2048:
+        w = torch.randn(24, generator=gen).to(DEV)
+        wr = torch.randn(25, generator=gen).to(DEV)
+        xa, ba = X.clone().requires_grad_(True), b1.clone().requires_grad_(True)
+        o1, r1 = ops.MgcepStepSolveFn.apply(xa, ba, mg.step_images_h, mg.step_images_bwd, gamma)
+        ((o1 * w).sum() + (r1 * wr).sum()).backward()
+        xb, bb = X.clone().requires_grad_(True), b1.clone().requires_grad_(True)
+        pt2, qt2, r2 = ops.MgcepStepFn.apply(xb, bb, mg.step_images, mg.step_images_bwd, gamma)
+        o2 = bb + ops.ThSolveFn.apply(pt2, qt2, r2[..., 1:])
+        ((o2 * w).sum() + (r2 * wr).sum()).backward()
+        assert float((xa.grad - xb.grad).abs().max()) <= 2e-5 * float(xb.grad.abs().max())
+        assert float((ba.grad - bb.grad).abs().max()) <= 2e-5 * float(bb.grad.abs().max())
     # unsupported set-ups are refused, not approximated
     with pytest.raises(Exception):
         ops.mgcep_step_solve(X[:, :129].contiguous(), b1, mg.step_images_h, -0.5)
