@@ -133,6 +133,22 @@ __device__ __forceinline__ void split2(float x0, float x1, f16x2& hi, f16x2& lo)
         : "=&v"(lb) : "v"(hb), "v"(x0), "v"(x1));
     lo = __builtin_bit_cast(f16x2, lb);
 }
+// four values at a time: the two pairs' half-register writes interleaved, so that the wait state between the low-half write and
+// the high half's read-modify-write of one destination is the other pair's instruction (3 of 4 s_nop fewer per four values)
+__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, f16x2& hiA, f16x2& hiB, f16x2& loA, f16x2& loB)
+{
+    hiA = __builtin_convertvector(f32x2v{x0, x1}, f16x2);
+    hiB = __builtin_convertvector(f32x2v{x2, x3}, f16x2);
+    const unsigned ha = __builtin_bit_cast(unsigned, hiA), hb = __builtin_bit_cast(unsigned, hiB);
+    unsigned la, lb;
+    asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 0"
+        : "=&v"(la), "=&v"(lb) : "v"(ha), "v"(hb), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+    loA = __builtin_bit_cast(f16x2, la);
+    loB = __builtin_bit_cast(f16x2, lb);
+}
 // c * s + b on both halves of a register pair: v_pk_fma_f32 (two flops per lane and issue slot)
 #ifdef DSA_MCEP_NOPK
 __device__ __forceinline__ f32x2v fma2(f32x2v c, float s, f32x2v b)
@@ -757,11 +773,28 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                     for (int it = 0; it < 3; ++it) eal[it] = EL[(it * 8 + j) * 64];
                 }
                 DSA_SB(); if (vw) { vecD(0); vecB(1); } DSA_SB();
-                prodE(3); DSA_SB(); if (vw) vecE(0, 0); DSA_SB();
-                prodE(4); DSA_SB(); if (vw) { vecC(1); vecD(1); } DSA_SB();
-                prodE(5); DSA_SB(); if (vw) vecE(0, 2); DSA_SB();
-                prodE(6); DSA_SB(); if (vw) vecE(1, 0); DSA_SB();
-                prodE(7); DSA_SB(); if (vw) vecE(1, 2); DSA_SB();
+                // the binary16 split of e: in the one-launch kernel a tile's four values go in ONE slot with the half-register writes of
+                // the two pairs interleaved (split4: 3 of 4 wait states gone; fused step 0.5927 -> 0.5882 ms); in the spectrogram-in
+                // kernel the four separate slots measure faster (0.5223 against 0.5280 ms), so each keeps its own schedule
+                auto vecE4 = [&](int t_) __attribute__((always_inline)) {
+                    f16x2 h0, h1, l0, l1;
+                    split4(e[t_][0], e[t_][1], e[t_][2], e[t_][3], h0, h1, l0, l1);
+                    eh[4 * t_] = h0[0]; eh[4 * t_ + 1] = h0[1]; eh[4 * t_ + 2] = h1[0]; eh[4 * t_ + 3] = h1[1];
+                    el[4 * t_] = l0[0]; el[4 * t_ + 1] = l0[1]; el[4 * t_ + 2] = l1[0]; el[4 * t_ + 3] = l1[1];
+                };
+                if constexpr (FUSED) {
+                    prodE(3); DSA_SB(); if (vw) vecE4(0); DSA_SB();
+                    prodE(4); DSA_SB(); if (vw) { vecC(1); vecD(1); } DSA_SB();
+                    prodE(5); DSA_SB();
+                    prodE(6); DSA_SB(); if (vw) vecE4(1); DSA_SB();
+                    prodE(7); DSA_SB();
+                } else {
+                    prodE(3); DSA_SB(); if (vw) vecE(0, 0); DSA_SB();
+                    prodE(4); DSA_SB(); if (vw) { vecC(1); vecD(1); } DSA_SB();
+                    prodE(5); DSA_SB(); if (vw) vecE(0, 2); DSA_SB();
+                    prodE(6); DSA_SB(); if (vw) vecE(1, 0); DSA_SB();
+                    prodE(7); DSA_SB(); if (vw) vecE(1, 2); DSA_SB();
+                }
                 prodE(8); DSA_SB();
                 eh_p = eh; el_p = el;
 #pragma unroll
