@@ -1636,14 +1636,15 @@ DSA_EXPORT int dsa_mgcep_step(const void* x, const void* b1, int64_t F, int32_t 
 }
 
 DSA_EXPORT int dsa_mgcep_step_solve(const void* x, const void* b1, int64_t F, int32_t fft_length, int32_t M, double gamma,
-                                    const void* images_h, int32_t dtype, void* b1_out, void* r, void* pt, void* qt, void* stream)
+                                    const void* images_h, int32_t dtype, void* b1_out, void* r, void* pt, void* qt, int32_t n_steps,
+                                    void* b1_prev, void* stream)
 {
-    DSA_REQUIRE(F >= 0, "mgcep_step_solve: sizes must be positive");
+    DSA_REQUIRE(F >= 0 && n_steps >= 1, "mgcep_step_solve: sizes must be positive");
     DSA_REQUIRE(gamma != 0.0 && gamma > -1.0 && gamma < 0.0, "mgcep_step_solve: gamma must be in (-1, 0)");
     if (dtype != DSA_F32 || fft_length != 512 || M != 24)
         return fail(DSA_ERR_UNSUPPORTED, "mgcep_step_solve: needs float32, fft_length 512, cep_order 24%s");
     if (F == 0) return DSA_OK;
-    return mgcep_step_solve_fwd(x, b1, F, gamma, images_h, b1_out, r, (hipStream_t)stream, pt, qt);
+    return mgcep_step_solve_fwd(x, b1, F, gamma, images_h, b1_out, r, (hipStream_t)stream, pt, qt, n_steps, b1_prev);
 }
 
 DSA_EXPORT int dsa_mgcep_step_bwd(const void* x, const void* b1, const void* gpt, const void* gqt, const void* gr, int64_t F,

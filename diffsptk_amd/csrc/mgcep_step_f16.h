@@ -32,7 +32,8 @@ constexpr int VMAX_LOG2 = 13;                   // scaled B operands are below 2
 // LDS (floats): two stage buffers | per-wave solve records (16 x kTq) | constants [0, 28) zeros, [32, 57) e_24
 constexpr int L_STAGE = 0;
 constexpr int L_WAVE = 2 * STAGE_HALVES / 2;
-constexpr int L_CST = L_WAVE + WAVES * 16 * kTq;
+constexpr int L_B = L_WAVE + WAVES * 16 * kTq;        // per wave: the 16 frames' coefficients b1 (16 x 24), carried from step to step
+constexpr int L_CST = L_B + WAVES * 16 * 24;
 constexpr int LDS_FLOATS = L_CST + 64;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024 && L_WAVE % 4 == 0, "the mgcep step's LDS carve-up");
 }  // namespace mgh
@@ -42,7 +43,8 @@ static_assert(LDS_FLOATS * 4 <= 160 * 1024 && L_WAVE % 4 == 0, "the mgcep step's
 #endif
 __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __restrict__ x, const float* b1, long F, float gamma,
                                                              const _Float16* __restrict__ img, float* b1_out,   // (b1_out may be b1)
-                                                             float* __restrict__ r_out, float* __restrict__ pt_out, float* __restrict__ qt_out)   // pt / qt: NULL, or where a graph keeps the system
+                                                             float* __restrict__ r_out, float* __restrict__ pt_out, float* __restrict__ qt_out,   // pt / qt: NULL, or where a graph keeps the system
+                                                             int n_steps, float* __restrict__ b1_prev_out)   // n_steps Newton steps per launch; b1_prev: NULL, or the LAST step's input
 {
     using namespace mgh;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -52,6 +54,7 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
     const int nq = lane >> 2, gs = lane & 3;
     if (tid < 64) lds[L_CST + tid] = tid == 32 + 24 ? 1.f : 0.f;
     float* wl = lds + L_WAVE + wave * 16 * kTq;
+    float* bsl = lds + L_B + wave * 16 * 24;
     const float* cst = lds + L_CST;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const float ex = -1.f / gamma - 1.f;
@@ -82,14 +85,27 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
         const int rn = n < rows_here ? n : rows_here - 1;
         const float* xt = x + t16 * 257;
         const float* bt = b1 + t16 * 24;
+        // the tile's coefficients into the wave's LDS slots (rows past the end: the last row again; their systems are identities)
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int idx = lane + 64 * it, fr = idx / 24, k = idx - fr * 24;
+            bsl[idx] = bt[(fr < rows_here ? fr : rows_here - 1) * 24 + k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int step = 0; step < n_steps; ++step) {
+        const bool last = step + 1 == n_steps;
         fetch(0);
         // B operand of the first chain: b1[8 g + i] of this lane's frame, scaled per frame
         float bv[8];
         float bmax = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            bv[i] = g < 3 ? bt[rn * 24 + 8 * g + i] : 0.f;
+            bv[i] = g < 3 ? bsl[n * 24 + 8 * g + i] : 0.f;
             bmax = __builtin_fmaxf(bmax, __builtin_fabsf(bv[i]));
+        }
+        if (last && b1_prev_out && f_ok && g < 3) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) b1_prev_out[(t16 + n) * 24 + 8 * g + i] = bv[i];
         }
         bmax = rows_max4(bmax);
         const int s_b = 12 - __builtin_amdgcn_frexp_expf(bmax);
@@ -199,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
             if (j + 1 < STAGES && !(MGH_ABL & 1)) stage(buf ^ 1);   // the other buffer: its readers finished before the barrier that ended stage j - 1
             if (!(MGH_ABL & 2)) __syncthreads();
         }
-        if (!tile_ok) continue;   // (no workgroup barrier below this point)
+        if (tile_ok) {
         // ---------------- the wave's 16 systems: windows (q | mirrored p | r[1:]) in the quad-layout solve's record ----------------
         for (int e = lane; e < 16 * kTq; e += 64) wl[e] = 0.f;
         __builtin_amdgcn_wave_barrier();
@@ -214,10 +230,10 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
                     // a missing system: the identity (p = e_0), right-hand side 0
                     const float pv = row_ok ? acc[t][r] : (col == 0 ? 1.f : 0.f);
                     if (col < 24) { rec[52 + 27 + col] = pv; rec[52 + 27 - col] = pv; }
-                    if (pt_out && f_ok && col < 24) pt_out[(t16 + n) * 24 + col] = pv;
+                    if (last && pt_out && f_ok && col < 24) pt_out[(t16 + n) * 24 + col] = pv;
                     const float rv = row_ok ? acc[5 + t][r] : 0.f;
                     if (col >= 1 && col < 25) rec[104 + col - 1] = rv;
-                    if (f_ok && col < 25) r_out[(t16 + n) * 25 + col] = rv;
+                    if (last && f_ok && col < 25) r_out[(t16 + n) * 25 + col] = rv;
                 }
 #pragma unroll
             for (int t = 0; t < 3; ++t)
@@ -225,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
                 for (int r = 0; r < 4; ++r) {
                     const int col = 16 * t + 4 * g + r;
                     if (col < 47) rec[col] = row_ok ? og * acc[2 + t][r] : 0.f;
-                    if (qt_out && f_ok && col < 47) qt_out[(t16 + n) * 47 + col] = og * acc[2 + t][r];
+                    if (last && qt_out && f_ok && col < 47) qt_out[(t16 + n) * 47 + col] = og * acc[2 + t][r];
                 }
         }
         __builtin_amdgcn_wave_barrier();
@@ -252,9 +268,13 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
             }
             const long fq = t16 + nq;
             const bool q_ok = tile_ok && nq < rows_here;
-            if (q_ok && !bad) {
+            if (!bad) {   // (rows past the end: identities, xq = 0)
 #pragma unroll
-                for (int c = 0; c < 6; ++c) b1_out[fq * 24 + gs + 4 * c] = b1[fq * 24 + gs + 4 * c] + xq[c];
+                for (int c = 0; c < 6; ++c) {
+                    const float bn = bsl[nq * 24 + gs + 4 * c] + xq[c];
+                    bsl[nq * 24 + gs + 4 * c] = bn;
+                    if (last && q_ok) b1_out[fq * 24 + gs + 4 * c] = bn;
+                }
             }
             unsigned long long marked = __ballot(bad && gs == 0 && q_ok);
             while (marked) {   // uniform; normally empty
@@ -268,15 +288,21 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
                 float sol;
                 th_solve_reg<float, 24>(ps2, qs2, rhs, 24, lane, col, sol);
                 const long fs = t16 + sy;
-                if (lane < 24) b1_out[fs * 24 + col] = b1[fs * 24 + col] + sol;
+                if (lane < 24) {
+                    const float bn = bsl[sy * 24 + col] + sol;
+                    bsl[sy * 24 + col] = bn;
+                    if (last) b1_out[fs * 24 + col] = bn;
+                }
             }
         }
+        }
         __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
 int mgcep_step_solve_fwd(const void* x, const void* b1, int64_t F, double gamma, const void* images, void* b1_out, void* r_out, hipStream_t st,
-                         void* pt_out, void* qt_out)
+                         void* pt_out, void* qt_out, int n_steps, void* b1_prev_out)
 {
     const int lds_bytes = mgh::LDS_FLOATS * 4;
     static std::atomic<uint64_t> attr{0};
@@ -286,7 +312,7 @@ int mgcep_step_solve_fwd(const void* x, const void* b1, int64_t F, double gamma,
     long blocks = (ntiles + mgh::WAVES - 1) / mgh::WAVES;
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(mgcep_step_h_kernel, dim3((unsigned)blocks), dim3(mgh::WAVES * 64), lds_bytes, st, (const float*)x, (const float*)b1,
-                       (long)F, (float)gamma, (const _Float16*)images, (float*)b1_out, (float*)r_out, (float*)pt_out, (float*)qt_out);
+                       (long)F, (float)gamma, (const _Float16*)images, (float*)b1_out, (float*)r_out, (float*)pt_out, (float*)qt_out, n_steps, (float*)b1_prev_out);
     return check_launch("mgcep_step_solve");
 }
 

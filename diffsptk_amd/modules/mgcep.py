@@ -163,7 +163,17 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
             b = _Gnorm._forward(self.mc2b(self.gc2gc(self.b2mc(_Ignorm._forward(b, gamma=-1)))), gamma=self.gamma)   # b2b, :120-137
             b1 = b[..., 1:]            # mgcep.py:244: only b1 of b2b's output is kept
             b = None
-            for it in range(self.n_iter):
+            one_launch = self.n_iter >= 1 and self.step_images_h is not None and x.dtype == torch.float32 and self.step_images_h.device == x.device \
+                and not (torch.is_grad_enabled() and (x.requires_grad or b1.requires_grad)) and os.environ.get("DSA_MGCEP_STEP_SOLVE") != "0" \
+                and os.environ.get("DSA_MGCEP_ALL_STEPS") != "0"
+            if one_launch:
+                # no graph wanted: ALL n_iter Newton steps in one launch (a frame's iteration depends on the frame alone), then the gain
+                b1, r, b1_prev = ops.mgcep_step_solve(x, b1, self.step_images_h, self.gamma, n_steps=self.n_iter, want_prev=True)
+                if fused_gain:
+                    b = ops.mgcep_gain(r, b1_prev, self.gamma, b1)
+                else:
+                    b0 = torch.sqrt(epsilon(self.gamma, r, b1_prev)).unsqueeze(-1)
+            for it in range(0 if one_launch else self.n_iter):
                 last = it == self.n_iter - 1
                 b0_it, b1, b_it = newton(self.gamma, b1, need_gain=last)
                 if last:

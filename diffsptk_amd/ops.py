@@ -1281,11 +1281,12 @@ def thsolve_update(pt, qt, r, b1):
     return out
 
 
-def mgcep_step_solve(x, b1, images_h, gamma, out=None):
+def mgcep_step_solve(x, b1, images_h, gamma, out=None, n_steps=1, want_prev=False):
     """(b1 + solve(toeplitz(pt) + hankel(qt), r[1:]), r) of one WHOLE Newton step of mgcep.py:199-230 in one launch
     (dsa_mgcep_step_solve: binary16-split matrix chains + the block elimination; float32 / fft_length 512 / cep_order 24 /
     gamma in (-1, 0)); forward only.  `images_h`: tables.mgcep_step_h_images as a float16 tensor; `out`: where the updated coefficients
-    go (may be `b1` itself when that is contiguous)."""
+    go (may be `b1` itself when that is contiguous); `n_steps` Newton steps in the one launch (r is the last step's); `want_prev`: also
+    return the last step's input coefficients (what the gain of mgcep.py:221 multiplies r with)."""
     _require_device(x, b1, images_h)
     _same_dtype(x, b1)
     xc, bc = x.contiguous(), b1.contiguous()
@@ -1297,10 +1298,11 @@ def mgcep_step_solve(x, b1, images_h, gamma, out=None):
     elif not (out.is_contiguous() and out.shape == bc.shape and out.dtype == bc.dtype and out.device == bc.device):
         raise ValueError("mgcep_step_solve: `out` must be a contiguous tensor like b1")
     r = torch.empty(*lead, M + 1, device=x.device, dtype=x.dtype)
+    prev = torch.empty_like(bc) if want_prev else None
     with torch.cuda.device(x.device):
         _call("dsa_mgcep_step_solve", _p(xc), _p(bc), F, 2 * (K - 1), M, float(gamma), _p(images_h), _dtype_code(xc), _p(out), _p(r), None, None,
-              _stream())
-    return out, r
+              int(n_steps), _p(prev), _stream())
+    return (out, r, prev) if want_prev else (out, r)
 
 
 class MgcepStepSolveFn(torch.autograd.Function):
@@ -1323,7 +1325,7 @@ class MgcepStepSolveFn(torch.autograd.Function):
         qt = torch.empty(*lead, 2 * M - 1, device=x.device, dtype=x.dtype)
         with torch.cuda.device(x.device):
             _call("dsa_mgcep_step_solve", _p(xc), _p(bc), F, 2 * (K - 1), M, float(gamma), _p(images_h), _dtype_code(xc), _p(out), _p(r), _p(pt),
-                  _p(qt), _stream())
+                  _p(qt), 1, None, _stream())
         ctx.save_for_backward(xc, bc, out, pt, qt, images_bwd)
         ctx.gamma = float(gamma)
         return out, r

@@ -362,9 +362,10 @@ int dsa_mgcep_step(const void* x, const void* b1, int64_t F, int32_t fft_length,
  * `images_h`: 9 x 16384 binary16, built by the caller once per configuration (diffsptk_amd.utils.tables.mgcep_step_h_images; layout:
  * csrc/mgcep_step_f16.h).  `pt`:(F,24), `qt`:(F,47): NULL, or where the system's two generators are kept for a graph (the backward is
  * dsa_thsolve_bwd on (pt, qt, b1_out - b1) followed by dsa_mgcep_step_bwd).  Replaces dsa_mgcep_step + dsa_thsolve_update_fwd (95 + 32 us
- * per 51 200 frames: 80). */
+ * per 51 200 frames: 80).  `n_steps` >= 1 Newton steps run in the ONE launch (a frame's iteration depends on the frame alone: the
+ * coefficients stay in LDS between the steps); r, pt, qt are the LAST step's, `b1_prev`:(F,24) (or NULL) the last step's input. */
 int dsa_mgcep_step_solve(const void* x, const void* b1, int64_t F, int32_t fft_length, int32_t M, double gamma, const void* images_h,
-                         int32_t dtype, void* b1_out, void* r, void* pt, void* qt, void* stream);
+                         int32_t dtype, void* b1_out, void* r, void* pt, void* qt, int32_t n_steps, void* b1_prev, void* stream);
 /* Backward of dsa_mgcep_step in one launch: cotangents gpt:(F,M), gqt:(F,2M-1), gr:(F,M+1) -> gx:(F,L/2+1) (+ gx_in when not
  * NULL: the spectrum enters every Newton step, so the steps' contributions accumulate; gx_in may be gx) and gb1:(F,M).
  * `images_bwd`: 17 x 4608 float32 built by the caller (diffsptk_amd/utils/tables.py:mgcep_step_bwd_images). */

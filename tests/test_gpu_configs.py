@@ -360,6 +360,11 @@ def test_mgcep_whole_step_in_one_launch_against_the_two_launch_step_and_the_orac
         bi = b1.clone()
         ops.mgcep_step_solve(X, bi, mg.step_images_h, gamma, out=bi)
         assert torch.equal(bi, new_b)
+        # three steps in ONE launch (the coefficients stay in LDS between them) = three launches, bit for bit; r and the last step's input too
+        b3, r3, p3 = ops.mgcep_step_solve(X, b1, mg.step_images_h, gamma, n_steps=3, want_prev=True)
+        s1, _ = ops.mgcep_step_solve(X, new_b, mg.step_images_h, gamma)
+        s2, rr2 = ops.mgcep_step_solve(X, s1, mg.step_images_h, gamma)
+        assert torch.equal(b3, s2) and torch.equal(r3, rr2) and torch.equal(p3, s1)
         if F >= 33:   # a frame's result does not depend on the launch it is part of
             part_b, part_r = ops.mgcep_step_solve(X[:33], b1[:33], mg.step_images_h, gamma)
             assert torch.equal(part_b[:32], new_b[:32]) and torch.equal(part_r[:32], new_r[:32])
