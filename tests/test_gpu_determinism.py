@@ -67,3 +67,44 @@ def test_backward_kernels_repeat_bit_for_bit(wave):
 
     _repeat(lambda: grads(lambda v: mcep(stft(v))))
     _repeat(lambda: grads(fl))
+
+
+def test_non_finite_frames_stay_in_their_rows_in_the_round_5_kernels():
+    """A frame is a column of every matrix product and a quad of the solves: a non-finite input frame must not reach any other
+    frame's result -- two-wave mel-cepstral backward (gradient w.r.t. the spectrogram), the one-launch mgcep step, the binary16
+    residual of the 48 kHz set-ups.  The clean frames' results are bit-identical to a launch without the poisoned frame's data."""
+    g = torch.Generator().manual_seed(7)
+    X = (torch.randn(700, 257, generator=g).square() + 0.05).to(DEV)
+    bad = [3, 16, 47, 333, 699]
+    Xb = X.clone()
+    Xb[bad[0], 5] = float("nan")
+    Xb[bad[1], 100] = float("inf")
+    Xb[bad[2], :] = float("nan")
+    Xb[bad[3], 256] = float("nan")
+    Xb[bad[4], 0] = float("inf")
+    clean = torch.ones(700, dtype=torch.bool)
+    clean[bad] = False
+    mcep = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=10, device=DEV)
+    w = torch.randn(25, generator=g).to(DEV)
+
+    def grad(Xin):
+        Xg = Xin.clone().requires_grad_(True)
+        (mcep(Xg) * w).sum().backward()
+        return Xg.grad
+
+    g0, g1 = grad(X), grad(Xb)
+    assert torch.isfinite(g1[clean]).all() and torch.equal(g1[clean], g0[clean])
+    mg = dsp.MelGeneralizedCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, gamma=-0.5, n_iter=3, device=DEV)
+    with torch.no_grad():
+        y0, y1 = mg(X), mg(Xb)
+    assert torch.isfinite(y1[clean]).all() and torch.equal(y1[clean], y0[clean])
+    m48 = dsp.MelCepstralAnalysis(fft_length=1024, cep_order=34, alpha=0.55, n_iter=4, device=DEV)
+    X48 = (torch.randn(300, 513, generator=g).square() + 0.05).to(DEV)
+    X48b = X48.clone()
+    X48b[17, 3] = float("nan")
+    X48b[64, :] = float("inf")
+    c48 = torch.ones(300, dtype=torch.bool)
+    c48[[17, 64]] = False
+    with torch.no_grad():
+        z0, z1 = m48(X48), m48(X48b)
+    assert torch.isfinite(z1[c48]).all() and torch.equal(z1[c48], z0[c48])
