@@ -149,6 +149,7 @@ SIGNATURES = {
     "dsa_thsolve_fwd": (C.c_int, [_P, _P, _P, _L, _I, _I, _P, _P]),
     "dsa_mgcep_step": (C.c_int, [_P, _P, _L, _I, _I, _D, _P, _I, _P, _P, _P, _P]),
     "dsa_mgcep_step_solve": (C.c_int, [_P, _P, _L, _I, _I, _D, _P, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "dsa_mgcep_step_bwd_h": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _D, _P, _I, _P, _P, _P, _P]),
     "dsa_mgcep_step_bwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _D, _P, _I, _P, _P, _P, _P]),
     "dsa_gc2gc_fwd": (C.c_int, [_P, _L, _I, _I, _D, _D, _I, _P, _I, _I, _P, _P]),
     "dsa_gc2gc_bwd": (C.c_int, [_P, _P, _L, _I, _I, _D, _D, _I, _P, _I, _P, _P]),

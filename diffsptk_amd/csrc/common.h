@@ -62,6 +62,8 @@ int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, v
 // the whole Newton step of mgcep (gamma != 0, fft_length 512, cep_order 24, float32) in one launch: csrc/mgcep_step_f16.h
 int mgcep_step_solve_fwd(const void* x, const void* b1, int64_t F, double gamma, const void* images, void* b1_out, void* r_out, hipStream_t st,
                          void* pt_out = nullptr, void* qt_out = nullptr, int n_steps = 1, void* b1_prev_out = nullptr);
+int mgcep_step_bwd_h(const void* x, const void* b1, const void* gpt, const void* gqt, const void* gr, int64_t F, double gamma,
+                     const void* images, const void* gx_in, void* gx, void* gb1, hipStream_t st);
 // the spectral half of a Newton step of the untuned mel-cepstral analysis on binary16-split chains: csrc/mcep_resid_f16.h
 int64_t mcep_resid_h_images_bytes(int K, int M1);
 int mcep_resid_h_prepare(const void* D, int ldd, const void* E, int lde, int K, int M1, void* images, hipStream_t st);

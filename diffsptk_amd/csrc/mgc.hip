@@ -1635,6 +1635,18 @@ DSA_EXPORT int dsa_mgcep_step(const void* x, const void* b1, int64_t F, int32_t 
     return check_launch("mgcep_step");
 }
 
+DSA_EXPORT int dsa_mgcep_step_bwd_h(const void* x, const void* b1, const void* gpt, const void* gqt, const void* gr, int64_t F,
+                                    int32_t fft_length, int32_t M, double gamma, const void* images_bwd_h, int32_t dtype, const void* gx_in,
+                                    void* gx, void* gb1, void* stream)
+{
+    DSA_REQUIRE(F >= 0, "mgcep_step_bwd_h: sizes must be positive");
+    DSA_REQUIRE(gamma != 0.0 && gamma >= -1.0 && gamma < 0.0, "mgcep_step_bwd_h: gamma must be in [-1, 0)");
+    if (dtype != DSA_F32 || fft_length != 512 || M != 24)
+        return fail(DSA_ERR_UNSUPPORTED, "mgcep_step_bwd_h: needs float32, fft_length 512, cep_order 24%s");
+    if (F == 0) return DSA_OK;
+    return mgcep_step_bwd_h(x, b1, gpt, gqt, gr, F, gamma, images_bwd_h, gx_in, gx, gb1, (hipStream_t)stream);
+}
+
 DSA_EXPORT int dsa_mgcep_step_solve(const void* x, const void* b1, int64_t F, int32_t fft_length, int32_t M, double gamma,
                                     const void* images_h, int32_t dtype, void* b1_out, void* r, void* pt, void* qt, int32_t n_steps,
                                     void* b1_prev, void* stream)

@@ -301,6 +301,250 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Backward of (pt, qt, r) = mgcep_step(x, b1) (mgcep.py:199-220) in ONE launch on the binary16 matrix pipe -- the counterpart of
+// mgcep_step_bwd_kernel (csrc/mgc.hip: 144 float32 matrix instructions per 32 bins and 16 frames; here 66 binary16 ones).  Same
+// tiling as the forward above: a wave = 16 frames, nine stages of 32 bins, the stage's images (44 KB, tables.mgcep_step_bwd_h_images)
+// staged through LDS for the workgroup's eight waves.  Per stage: (re, im) recomputed (first chain), the cotangents of the five
+// spectra at the stage's bins as products of the bin-row matrices with the cotangent vectors (gpt | (1 + gamma) gqt | gr: the B
+// operands, scaled per frame and split once per launch), the element-wise chain rule (as mgcep_step_bwd_kernel), gx written, and
+// the cotangent of (re, im) -- scaled by the STAGE's own power of two and split -- accumulated into gb1 = gamma (gX Cr^T + gY Ci^T).
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace mgh {
+constexpr int BW_WT = C1_HALVES;                       // [2 t][7 ks][hi | lo][64][8]
+constexpr int BW_CT = BW_WT + 2 * 7 * 2 * 512;         // [Cr | Ci][2 tc][hi | lo][64][8]
+constexpr int BW_STAGE_HALVES = BW_CT + 2 * 2 * 2 * 512;   // 22 528 halves = 44 KB
+static_assert(2 * BW_STAGE_HALVES * 2 <= 160 * 1024, "the mgcep step backward's two stage buffers");
+}  // namespace mgh
+
+__global__ __launch_bounds__(512, 2) void mgcep_step_bwd_h_kernel(const float* __restrict__ x, const float* __restrict__ b1,
+                                                                 const float* __restrict__ gpt, const float* __restrict__ gqt,
+                                                                 const float* __restrict__ grr, long F, float gamma,
+                                                                 const _Float16* __restrict__ img, const float* __restrict__ gx_in,
+                                                                 float* __restrict__ gx, float* __restrict__ gb1)
+{
+    using namespace mgh;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PIECES = BW_STAGE_HALVES / 8;            // 2816 16-byte pieces per stage
+    constexpr int PER = (PIECES + 511) / 512;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float ex = -1.f / gamma - 1.f;
+    const float og = 1.f + gamma;
+    const long ntiles = (F + 15) / 16;
+    const long nrounds = (ntiles + (long)gridDim.x * WAVES - 1) / ((long)gridDim.x * WAVES);
+    const f32x4* img4 = reinterpret_cast<const f32x4*>(img);
+    f32x4 st[PER];
+    auto fetch = [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int p = tid + 512 * q;
+            if (p < PIECES) st[q] = img4[(long)j * PIECES + p];
+        }
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        f32x4* d = reinterpret_cast<f32x4*>(lds) + buf * PIECES;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int p = tid + 512 * q;
+            if (p < PIECES) d[p] = st[q];
+        }
+    };
+    // eight values of one row as a scaled binary16 pair: returns the scale's exponent (value = 2^-s x operand)
+    auto operand = [&](const float (&v)[8], f16x8& hi, f16x8& lo) __attribute__((always_inline)) {
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m = __builtin_fmaxf(m, __builtin_fabsf(v[i]));
+        m = rows_max4(m);
+        const int sx = 12 - __builtin_amdgcn_frexp_expf(m);
+        float ms[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ms[i] = __builtin_ldexpf(v[i], sx);
+        split8(ms, hi, lo);
+        return sx;
+    };
+    for (long round = 0; round < nrounds; ++round) {
+        const long tile_raw = (round * WAVES + wave) * gridDim.x + blockIdx.x;   // uniform; wave-major within a round (see the forward)
+        const bool tile_ok = tile_raw < ntiles;
+        const long tile = tile_ok ? tile_raw : ntiles - 1;
+        const long t16 = tile * 16;
+        const int rows_here = (int)((F - t16 < 16) ? F - t16 : 16);
+        const bool f_ok = tile_ok && n < rows_here;
+        const int rn = n < rows_here ? n : rows_here - 1;
+        const float* xt = x + t16 * 257 + rn * 257;
+        fetch(0);
+        // B operands held for the whole tile: lane (n, g) holds entries 8 g + i of its frame's vectors
+        f16x8 bh, bl, ph, pl, qh[2], ql[2], rh, rl;
+        int k1, kp, kq, kr;
+        {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = g < 3 ? b1[(t16 + rn) * 24 + 8 * g + i] : 0.f;
+            k1 = -operand(v, bh, bl) - LOG2_SC;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = g < 3 ? gpt[(t16 + rn) * 24 + 8 * g + i] : 0.f;
+            kp = -operand(v, ph, pl) - LOG2_SW;
+            float w0[8], w1[8];
+            float m = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                w0[i] = og * gqt[(t16 + rn) * 47 + 8 * g + i];
+                w1[i] = 32 + 8 * g + i < 47 ? og * gqt[(t16 + rn) * 47 + 32 + 8 * g + i] : 0.f;
+                m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(w0[i]), __builtin_fabsf(w1[i])));
+            }
+            m = rows_max4(m);
+            const int sq = 12 - __builtin_amdgcn_frexp_expf(m);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { w0[i] = __builtin_ldexpf(w0[i], sq); w1[i] = __builtin_ldexpf(w1[i], sq); }
+            split8(w0, qh[0], ql[0]);
+            split8(w1, qh[1], ql[1]);
+            kq = -sq - LOG2_SW;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = 8 * g + i < 25 ? grr[(t16 + rn) * 25 + 8 * g + i] : 0.f;
+            kr = -operand(v, rh, rl) - LOG2_SW;
+        }
+        f32x4 accb[2] = {zero4, zero4};   // gb1: C/D layout, lane (n, g) register r <-> coefficient 16 tc + 4 g + r
+        f32x4 xn[2] = {zero4, zero4};
+        auto xfetch = [&](int j) __attribute__((always_inline)) {
+            if (j < 8) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) xn[t] = *reinterpret_cast<const f32x4_u4*>(xt + 32 * j + 16 * t + 4 * g);
+            } else {
+                xn[0] = zero4;
+                xn[1] = zero4;
+                if (g == 0) xn[0][0] = xt[256];
+            }
+        };
+        xfetch(0);
+        stage(0);
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < STAGES; ++j) {
+            const int buf = j & 1;
+            const f32x4 xv[2] = {xn[0], xn[1]};
+            if (j + 1 < STAGES) {
+                xfetch(j + 1);
+                fetch(j + 1);
+            }
+            if (tile_ok) {
+                const f16x8* c1 = reinterpret_cast<const f16x8*>(lds) + buf * PIECES + lane;
+                const f16x8* wt = c1 + BW_WT / 8;
+                const f16x8* ct = c1 + BW_CT / 8;
+                float gre[8], gim[8];
+                float gmax = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    // (re, im) of the tile
+                    const f16x8 crh = c1[((t * 2 + 0) * 2 + 0) * 64], crl = c1[((t * 2 + 0) * 2 + 1) * 64];
+                    const f16x8 cih = c1[((t * 2 + 1) * 2 + 0) * 64], cil = c1[((t * 2 + 1) * 2 + 1) * 64];
+                    f32x4 re = mfma_h(crl, bh, zero4), im = mfma_h(cil, bh, zero4);
+                    re = mfma_h(crh, bl, re);
+                    im = mfma_h(cih, bl, im);
+                    re = mfma_h(crh, bh, re);
+                    im = mfma_h(cih, bh, im);
+                    // cotangents of the five spectra at the tile's bins
+                    auto prod = [&](int ks, const f16x8& vh, const f16x8& vl, f32x4 a_) __attribute__((always_inline)) {
+                        const f16x8 wh = wt[((t * 7 + ks) * 2 + 0) * 64], wlo = wt[((t * 7 + ks) * 2 + 1) * 64];
+                        a_ = mfma_h(wlo, vh, a_);
+                        a_ = mfma_h(wh, vl, a_);
+                        return mfma_h(wh, vh, a_);
+                    };
+                    const f32x4 g0 = prod(0, ph, pl, zero4);
+                    const f32x4 g1 = prod(2, qh[1], ql[1], prod(1, qh[0], ql[0], zero4));
+                    const f32x4 g2 = prod(4, qh[1], ql[1], prod(3, qh[0], ql[0], zero4));
+                    const f32x4 g3 = prod(5, rh, rl, zero4);
+                    const f32x4 g4 = prod(6, rh, rl, zero4);
+                    f32x4 gxo;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float gs0 = __builtin_ldexpf(g0[r], kp), gs1 = __builtin_ldexpf(g1[r], kq), gs2 = __builtin_ldexpf(g2[r], kq);
+                        const float gs3 = __builtin_ldexpf(g3[r], kr), gs4 = __builtin_ldexpf(g4[r], kr);
+                        const float X = __builtin_fmaf(gamma, __builtin_ldexpf(re[r], k1), 1.f), Y = gamma * __builtin_ldexpf(im[r], k1);
+                        const float XX = X * X, YY = Y * Y, D = XX + YY;
+                        const float dp = __builtin_amdgcn_exp2f(ex * __builtin_amdgcn_logf(D));
+                        const float pp = xv[t][r] * dp;
+                        const float rD = __builtin_amdgcn_rcpf(D);
+                        const float qq = pp * rD;
+                        const float g_qq = gs1 * (XX - YY) + gs2 * (2.f * X * Y);
+                        const float g_pp = gs0 + gs3 * X + gs4 * Y + g_qq * rD;
+                        const float g_D = (g_pp * ex * pp - g_qq * qq) * rD;
+                        const float gX = 2.f * qq * (gs1 * X + gs2 * Y) + gs3 * pp + 2.f * X * g_D;
+                        const float gY = 2.f * qq * (gs2 * X - gs1 * Y) + gs4 * pp + 2.f * Y * g_D;
+                        const bool live = j < 8 || (t == 0 && r == 0 && g == 0);   // (the last stage holds bin 256 only)
+                        gre[4 * t + r] = live ? gamma * gX : 0.f;
+                        gim[4 * t + r] = live ? gamma * gY : 0.f;
+                        gxo[r] = g_pp * dp;
+                        gmax = __builtin_fmaxf(gmax, __builtin_fmaxf(__builtin_fabsf(gre[4 * t + r]), __builtin_fabsf(gim[4 * t + r])));
+                    }
+                    if (f_ok) {
+                        if (j < 8) {
+                            float* dst = gx + (t16 + n) * 257 + 32 * j + 16 * t + 4 * g;
+                            if (gx_in) gxo += *reinterpret_cast<const f32x4_u4*>(gx_in + (t16 + n) * 257 + 32 * j + 16 * t + 4 * g);
+                            *reinterpret_cast<f32x4_u4*>(dst) = gxo;
+                        } else if (t == 0 && g == 0) {
+                            gx[(t16 + n) * 257 + 256] = gxo[0] + (gx_in ? gx_in[(t16 + n) * 257 + 256] : 0.f);
+                        }
+                    }
+                }
+                // gb1 += (Cr | Ci) with coefficients as rows x the stage's (gre | gim), scaled by the stage's power of two
+                gmax = rows_max4(gmax);
+                const int s_g = VMAX_LOG2 - __builtin_amdgcn_frexp_expf(gmax);
+                float ms[8];
+                f16x8 reh, rel, imh, iml;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ms[i] = __builtin_ldexpf(gre[i], s_g);
+                split8(ms, reh, rel);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ms[i] = __builtin_ldexpf(gim[i], s_g);
+                split8(ms, imh, iml);
+                const int k3 = -s_g - LOG2_SC;
+#pragma unroll
+                for (int tc = 0; tc < 2; ++tc) {
+                    const f16x8 ah = ct[((0 * 2 + tc) * 2 + 0) * 64], al = ct[((0 * 2 + tc) * 2 + 1) * 64];
+                    const f16x8 dh = ct[((1 * 2 + tc) * 2 + 0) * 64], dl = ct[((1 * 2 + tc) * 2 + 1) * 64];
+                    f32x4 a_ = mfma_h(al, reh, zero4);
+                    a_ = mfma_h(ah, rel, a_);
+                    a_ = mfma_h(ah, reh, a_);
+                    a_ = mfma_h(dl, imh, a_);
+                    a_ = mfma_h(dh, iml, a_);
+                    a_ = mfma_h(dh, imh, a_);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accb[tc][r] += __builtin_ldexpf(a_[r], k3);
+                }
+            }
+            if (j + 1 < STAGES) stage(buf ^ 1);
+            __syncthreads();
+        }
+        if (f_ok) {
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = 16 * tc + 4 * g + r;
+                    if (col < 24) gb1[(t16 + n) * 24 + col] = accb[tc][r];
+                }
+        }
+    }
+}
+
+int mgcep_step_bwd_h(const void* x, const void* b1, const void* gpt, const void* gqt, const void* gr, int64_t F, double gamma,
+                     const void* images, const void* gx_in, void* gx, void* gb1, hipStream_t st)
+{
+    const int lds_bytes = 2 * mgh::BW_STAGE_HALVES * 2;
+    static std::atomic<uint64_t> attr{0};
+    if (!ensure_dynamic_lds((const void*)mgcep_step_bwd_h_kernel, lds_bytes, attr))
+        return fail(DSA_ERR_LAUNCH, "mgcep_step_bwd_h: cannot reserve the LDS stage buffers%s");
+    const long ntiles = (long)((F + 15) / 16);
+    long blocks = (ntiles + mgh::WAVES - 1) / mgh::WAVES;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(mgcep_step_bwd_h_kernel, dim3((unsigned)blocks), dim3(mgh::WAVES * 64), lds_bytes, st, (const float*)x, (const float*)b1,
+                       (const float*)gpt, (const float*)gqt, (const float*)gr, (long)F, (float)gamma, (const _Float16*)images,
+                       (const float*)gx_in, (float*)gx, (float*)gb1);
+    return check_launch("mgcep_step_bwd_h");
+}
+
 int mgcep_step_solve_fwd(const void* x, const void* b1, int64_t F, double gamma, const void* images, void* b1_out, void* r_out, hipStream_t st,
                          void* pt_out, void* qt_out, int n_steps, void* b1_prev_out)
 {

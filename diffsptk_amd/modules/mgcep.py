@@ -78,6 +78,10 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
         if self.step_images is not None and cep_order == 24 and -1 < gamma < 0:
             self.register_buffer("step_images_h", torch.from_numpy(tables.mgcep_step_h_images(fft_length, cep_order, float(alpha))).to(device),
                                  persistent=False)
+            # ... and the step's adjoint on the binary16 matrix pipe too (DSA_MGCEP_STEP_BWD_H=0: the float32 kernel, for A/B runs)
+            if os.environ.get("DSA_MGCEP_STEP_BWD_H") != "0":
+                self.register_buffer("step_images_bwd", torch.from_numpy(tables.mgcep_step_bwd_h_images(fft_length, cep_order, float(alpha)))
+                                     .to(device), persistent=False)
         else:
             self.step_images_h = None
         self.b2mc = MLSADigitalFilterCoefficientsToMelCepstrum(M, alpha, device=device, dtype=dtype)

@@ -1229,6 +1229,11 @@ def mgcep_step(x, b1, images, gamma):
     return pt, qt, r
 
 
+def _step_bwd_entry(images_bwd):
+    """The step's adjoint: float16 images (tables.mgcep_step_bwd_h_images) select the binary16 kernel, float32 ones the round-3 kernel."""
+    return "dsa_mgcep_step_bwd_h" if images_bwd.dtype == torch.float16 else "dsa_mgcep_step_bwd"
+
+
 class MgcepStepFn(torch.autograd.Function):
     """(pt, qt, r) of one Newton step of mgcep.py:199-220 with a graph: forward dsa_mgcep_step, backward dsa_mgcep_step_bwd (one
     launch each; float32 / fft_length 512 / cep_order <= 24).  x:(..., 257), b1:(..., M)."""
@@ -1256,7 +1261,7 @@ class MgcepStepFn(torch.autograd.Function):
         gx = torch.empty_like(xc)
         gb = torch.empty_like(bc)
         with torch.cuda.device(xc.device):
-            _call("dsa_mgcep_step_bwd", _p(xc), _p(bc), _p(gpt), _p(gqt), _p(gr), F, 2 * (K - 1), M, ctx.gamma, _p(images_bwd),
+            _call(_step_bwd_entry(images_bwd), _p(xc), _p(bc), _p(gpt), _p(gqt), _p(gr), F, 2 * (K - 1), M, ctx.gamma, _p(images_bwd),
                   _dtype_code(xc), None, _p(gx), _p(gb), _stream())
         return gx, gb, None, None, None
 
@@ -1344,7 +1349,7 @@ class MgcepStepSolveFn(torch.autograd.Function):
         with torch.cuda.device(xc.device):
             _call("dsa_thsolve_bwd", _p(gout), _p(pt), _p(qt), _p(sol), F, M, _dtype_code(pt), _p(gp), _p(gq), _p(grhs), _stream())
             grf[..., 1:] += grhs                                         # the right-hand side is r[1:]
-            _call("dsa_mgcep_step_bwd", _p(xc), _p(bc), _p(gp), _p(gq), _p(grf), F, 2 * (K - 1), M, ctx.gamma, _p(images_bwd), _dtype_code(xc),
+            _call(_step_bwd_entry(images_bwd), _p(xc), _p(bc), _p(gp), _p(gq), _p(grf), F, 2 * (K - 1), M, ctx.gamma, _p(images_bwd), _dtype_code(xc),
                   None, _p(gx), _p(gb1), _stream())
         return gx, gb1 + gout, None, None, None
 

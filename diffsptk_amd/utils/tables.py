@@ -578,6 +578,66 @@ def mgcep_step_h_images(fft_length: int, cep_order: int, alpha: float) -> np.nda
     return out
 
 
+def mgcep_step_bwd_h_images(fft_length: int, cep_order: int, alpha: float) -> np.ndarray:
+    """Binary16 hi / lo operand images of dsa_mgcep_step_bwd_h (csrc/mgcep_step_f16.h), float16, shape (9, 22528): per STAGE of 32 bins
+      [2 t][2 (Cr, Ci)][2 (hi, lo)][64 lane][8 i]   the forward's first chain (re, im recomputed), as in mgcep_step_h_images
+      [2 t][7 ks][2 (hi, lo)][64 lane][8 i]          the second-chain matrices with BINS as rows: row = bin 32 j + 16 t + (lane & 15),
+                                                     k-slot (g, i) <-> column 8 g + i of the k-step's segment: ks 0 Pr[:, :24] | 1, 2 Qr[:, 2:]
+                                                     columns 0 .. 31, 32 .. 63 | 3, 4 Qi[:, 2:] | 5 Rr | 6 Ri (zero past the matrix)
+      [2 (Cr, Ci)][2 tc][2 (hi, lo)][64 lane][8 i]   (Cr, Ci) with COEFFICIENTS as rows: row = coefficient 1 + 16 tc + (lane & 15),
+                                                     k-slot (g, i = 4 t + r) <-> bin 32 j + 16 t + 4 g + r
+    Scales as in mgcep_step_h_images (2^12 for C, 2^20 for the others).  fft_length 512, cep_order 24."""
+    if fft_length != 512 or cep_order != 24:
+        raise ValueError("mgcep_step_bwd_h_images: fft_length 512 and cep_order 24 only")
+    M, K = cep_order, fft_length // 2 + 1
+    m = mgcep_matrices(fft_length, cep_order, float(alpha))
+    Cr, Ci = m["Cr"], m["Ci"]
+    segs = [(m["Pr"][:, :M], 0), (m["Qr"][:, 2:], 0), (m["Qr"][:, 2:], 32), (m["Qi"][:, 2:], 0), (m["Qi"][:, 2:], 32), (m["Rr"], 0), (m["Ri"], 0)]
+    lanes = np.arange(64)
+    li, lg = lanes & 15, lanes >> 4
+    sc, sw = float(2 ** MGCEP_STEP_H_LOG2_SC), float(2 ** MGCEP_STEP_H_LOG2_SW)
+    out = np.zeros((9, 22528), dtype=np.float16)
+
+    def hilo(v):
+        hi = v.astype(np.float16)
+        lo = (v - hi.astype(np.float64)).astype(np.float16)
+        return hi, lo
+
+    for j in range(9):
+        c1 = np.zeros((2, 2, 2, 64, 8), dtype=np.float16)
+        wt = np.zeros((2, 7, 2, 64, 8), dtype=np.float16)
+        ct = np.zeros((2, 2, 2, 64, 8), dtype=np.float16)
+        for t in range(2):
+            binrow = 32 * j + 16 * t + li
+            for ci_, C in enumerate((Cr, Ci)):
+                v = np.zeros((64, 8))
+                for i in range(8):
+                    row = 1 + 8 * lg + i
+                    ok = (row <= M) & (binrow < K)
+                    v[ok, i] = sc * C[row[ok], binrow[ok]]
+                c1[t, ci_, 0], c1[t, ci_, 1] = hilo(v)
+            for ks, (W, c0) in enumerate(segs):
+                v = np.zeros((64, 8))
+                for i in range(8):
+                    col = c0 + 8 * lg + i
+                    ok = (binrow < K) & (col < W.shape[1])
+                    v[ok, i] = sw * W[binrow[ok], col[ok]]
+                wt[t, ks, 0], wt[t, ks, 1] = hilo(v)
+        for ci_, C in enumerate((Cr, Ci)):
+            for tc in range(2):
+                v = np.zeros((64, 8))
+                for i in range(8):
+                    b = 32 * j + 16 * (i >> 2) + 4 * lg + (i & 3)
+                    row = 1 + 16 * tc + li
+                    ok = (b < K) & (row <= M)
+                    v[ok, i] = sc * C[row[ok], b[ok]]
+                ct[ci_, tc, 0], ct[ci_, tc, 1] = hilo(v)
+        out[j, :4096] = c1.reshape(-1)
+        out[j, 4096:4096 + 14336] = wt.reshape(-1)
+        out[j, 4096 + 14336:] = ct.reshape(-1)
+    return out
+
+
 def mgcep_step_bwd_images(fft_length: int, cep_order: int, alpha: float) -> np.ndarray:
     """Operand images of dsa_mgcep_step_bwd (csrc/mgc.hip:mgcep_step_bwd_kernel): per 16-bin tile the forward's first-chain
     operands, the second-chain matrices TRANSPOSED (bin rows x column k-steps: Pr[:, :M] 6 | Qr[:, 2:] 12 | Qi[:, 2:] 12 | Rr 7 |

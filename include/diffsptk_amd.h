@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 125 /* 0.1.9: + dsa_mgcep_step_solve, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
+#define DSA_VERSION 125 /* 0.1.9: + dsa_mgcep_step_solve, dsa_mgcep_step_bwd_h, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
@@ -355,6 +355,12 @@ int dsa_thsolve_update_fwd(const void* p, const void* q, const void* r, int64_t 
  * caller once per configuration (layout: csrc/mgc.hip, mgcep_step_kernel; diffsptk_amd.utils.tables.mgcep_step_images).  Forward only. */
 int dsa_mgcep_step(const void* x, const void* b1, int64_t F, int32_t fft_length, int32_t M, double gamma, const void* images,
                    int32_t dtype, void* pt, void* qt, void* r, void* stream);
+/* (0.1.9) dsa_mgcep_step_bwd on the binary16 matrix pipe (cep_order 24 / fft_length 512 / float32; csrc/mgcep_step_f16.h): same
+ * arguments, `images_bwd_h`: 9 x 22528 binary16 (diffsptk_amd.utils.tables.mgcep_step_bwd_h_images).  66 binary16 products per 32 bins and
+ * 16 frames instead of 144 float32 ones. */
+int dsa_mgcep_step_bwd_h(const void* x, const void* b1, const void* gpt, const void* gqt, const void* gr, int64_t F,
+                         int32_t fft_length, int32_t M, double gamma, const void* images_bwd_h, int32_t dtype, const void* gx_in,
+                         void* gx, void* gb1, void* stream);
 /* (0.1.9) The WHOLE Newton step in one launch (mgcep.py:199-230; float32, fft_length 512, cep_order 24, gamma in (-1, 0)): the spectrum
  * arithmetic, the five row products as 3-term binary16 splits on the matrix pipe, the 24 x 24 Toeplitz-plus-Hankel solve (block
  * elimination, pivoted re-solve for systems that are not positive definite) and the update: x:(F,257), b1:(F,24) ->

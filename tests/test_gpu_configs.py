@@ -401,6 +401,41 @@ def test_mgcep_whole_step_in_one_launch_against_the_two_launch_step_and_the_orac
         ops.mgcep_step_solve(X, b1[:, :12].contiguous(), mg.step_images_h, -0.5)
 
 
+@pytest.mark.parametrize("F", [1, 17, 2050])
+def test_mgcep_step_adjoint_on_binary16_splits_against_the_float32_kernel(F):
+    """dsa_mgcep_step_bwd_h (round 5: the step's adjoint with its 66 products per 32 bins as 3-term binary16 splits; cotangent vectors
+    scaled per frame, the cotangent of (re, im) per stage) against dsa_mgcep_step_bwd (float32 matrix instructions) on the same inputs:
+    3e-6 of the largest entry of each output (the two differ by both kernels' rounding; against float64 through the module the new one
+    measures 3.4e-7, the old 6.5e-7: tools/time_mgcep_grad.py); ragged frame counts; repeated launches bit-identical; cotangents of
+    very different levels per frame (the per-frame scales)."""
+    gen = torch.Generator().manual_seed(100 + F)
+    X = (torch.randn(F, 257, generator=gen).square() + 0.05).to(DEV)
+    b1 = (0.05 * torch.randn(F, 24, generator=gen)).to(DEV)
+    lvl = 2.0 ** torch.randint(-20, 20, (F, 1), generator=gen).float()
+    gpt = (torch.randn(F, 24, generator=gen) * lvl).to(DEV)
+    gqt = (torch.randn(F, 47, generator=gen) * lvl * 8).to(DEV)
+    gr = (torch.randn(F, 25, generator=gen) * lvl / 8).to(DEV)
+    mg = dsp.MelGeneralizedCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, gamma=-0.5, n_iter=1, device=DEV)
+    assert mg.step_images_bwd.dtype == torch.float16
+    img32 = torch.from_numpy(__import__("diffsptk_amd").utils.tables.mgcep_step_bwd_images(512, 24, 0.42)).to(DEV)
+
+    def run(images):
+        gx, gb = torch.empty_like(X), torch.empty_like(b1)
+        ops._call(ops._step_bwd_entry(images), X.data_ptr(), b1.data_ptr(), gpt.data_ptr(), gqt.data_ptr(), gr.data_ptr(), F, 512, 24, -0.5,
+                  images.data_ptr(), _lib.F32, None, gx.data_ptr(), gb.data_ptr(), ops._stream())
+        return gx, gb
+
+    gx_h, gb_h = run(mg.step_images_bwd)
+    assert _lib.last_kernel() == "mgcep_step_bwd_h"
+    gx_f, gb_f = run(img32)
+    assert torch.isfinite(gx_h).all() and torch.isfinite(gb_h).all()
+    for a, b in ((gx_h, gx_f), (gb_h, gb_f)):
+        per = (a - b).abs().amax(1) / b.abs().amax(1).clamp_min(1e-30)
+        assert float(per.max()) <= 3e-6, float(per.max())
+    gx2, gb2 = run(mg.step_images_bwd)
+    assert torch.equal(gx2, gx_h) and torch.equal(gb2, gb_h)
+
+
 def test_mgcep_step_backward_kernel_against_float64_autograd():
     """With a gradient wanted the float32 / 512 / order <= 24 analysis runs the fused step forward AND its adjoint as one
     launch each (ops.MgcepStepFn: dsa_mgcep_step / dsa_mgcep_step_bwd), the order-24 solve's backward on the quad-layout
