@@ -84,6 +84,7 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
                                      .to(device), persistent=False)
         else:
             self.step_images_h = None
+        self._zero_q = None   # (see forward: the Hankel generator of the gamma = -1 step)
         self.b2mc = MLSADigitalFilterCoefficientsToMelCepstrum(M, alpha, device=device, dtype=dtype)
         self.mc2b = MelCepstrumToMLSADigitalFilterCoefficients(M, alpha, device=device, dtype=dtype)
         self.gc2gc = MelGeneralizedCepstrumToMelGeneralizedCepstrum(M, M, in_gamma=-1, out_gamma=gamma, device=device,
@@ -143,7 +144,16 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
                 qt = (mm(qq * (XX - YY), self.Qr) + mm(qq * (2 * X * Y), self.Qi)) * (1 + gamma)
                 r = mm(pp * X, self.Rr) + mm(pp * Y, self.Ri)
             if qt is None:
-                qt = torch.zeros(*pt.shape[:-1], 2 * M - 1, device=pt.device, dtype=pt.dtype)
+                # q (1 + gamma) = 0 at gamma = -1: a block of zeros the solve only reads -- kept from call to call (no fill launch) unless
+                # a graph or a stream capture could make it outlive this call's view of it
+                shape = (*pt.shape[:-1], 2 * M - 1)
+                zq = self._zero_q
+                if torch.is_grad_enabled() or zq is None or zq.shape != shape or zq.device != pt.device or zq.dtype != pt.dtype \
+                        or torch.cuda.is_current_stream_capturing():
+                    zq = torch.zeros(shape, device=pt.device, dtype=pt.dtype)
+                    if not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
+                        self._zero_q = zq
+                qt = zq
             upd = None
             if not (torch.is_grad_enabled() and (pt.requires_grad or qt.requires_grad or r.requires_grad or b1.requires_grad)):
                 upd = ops.thsolve_update(pt, qt, r, b1)            # solve + update in one call, r read in place
