@@ -9,7 +9,7 @@ def timeit(fn, n=30):
     e0.record()
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n * 1e3
-x = torch.randn(1024, 16000, device=dev)
+x = torch.randn(int(os.environ.get("B", "1024")), 16000, device=dev)
 st = dsp.STFT(400, 80, 512, device=dev)
 xg = x.clone().requires_grad_(True); y = st(xg); g = torch.randn_like(y)
 t_b = timeit(lambda: torch.autograd.grad(y, xg, g, retain_graph=True))
