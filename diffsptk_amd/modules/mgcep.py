@@ -85,6 +85,7 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
         else:
             self.step_images_h = None
         self._zero_q = None   # (see forward: the Hankel generator of the gamma = -1 step)
+        self._zero_q_ready = None
         self.b2mc = MLSADigitalFilterCoefficientsToMelCepstrum(M, alpha, device=device, dtype=dtype)
         self.mc2b = MelCepstrumToMLSADigitalFilterCoefficients(M, alpha, device=device, dtype=dtype)
         self.gc2gc = MelGeneralizedCepstrumToMelGeneralizedCepstrum(M, M, in_gamma=-1, out_gamma=gamma, device=device,
@@ -153,6 +154,10 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
                     zq = torch.zeros(shape, device=pt.device, dtype=pt.dtype)
                     if not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
                         self._zero_q = zq
+                        self._zero_q_ready = torch.cuda.Event()
+                        self._zero_q_ready.record()
+                elif not self._zero_q_ready.query():   # filled on another stream and possibly not done yet
+                    torch.cuda.current_stream().wait_event(self._zero_q_ready)
                 qt = zq
             upd = None
             if not (torch.is_grad_enabled() and (pt.requires_grad or qt.requires_grad or r.requires_grad or b1.requires_grad)):

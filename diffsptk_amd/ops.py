@@ -931,27 +931,35 @@ def mcep_newton_resid(logx, mc, D, E):
     return rt
 
 
-_RESID_IMAGES: dict = {}   # (D.data_ptr(), E.data_ptr(), D._version, E._version, shapes) -> (images, D, E): the binary16 operand images of dsa_mcep_newton_resid_h
+_RESID_IMAGES: dict = {}   # id(D) -> (weakref to D, versions, images, ready event): the binary16 operand images of dsa_mcep_newton_resid_h
 
 
 def mcep_resid_images(D, E):
-    """The binary16 hi / lo operand images dsa_mcep_newton_resid_h consumes (dsa_mcep_resid_prepare: one small launch), kept per pair
-    of tables (modules hold D and E as buffers for their lifetime; the cache keeps them alive with their images)."""
-    Dc, Ec = D.contiguous(), E.contiguous()
-    key = (Dc.data_ptr(), Ec.data_ptr(), Dc._version, Ec._version, tuple(Dc.shape), tuple(Ec.shape))
-    hit = _RESID_IMAGES.get(key)
-    if hit is not None:
-        return hit[0]
-    n, K = Dc.size(0), Dc.size(1)
+    """The binary16 hi / lo operand images dsa_mcep_newton_resid_h consumes (dsa_mcep_resid_prepare: one small launch), made once per
+    pair of tables and kept as long as the tables live (keyed like mcep_images: weakly by the tensors and their version counters; a call
+    from another stream waits for the preparation's event on ITS stream)."""
+    if D.device.type != "cuda" or D.dtype != torch.float32 or E.dtype != torch.float32:
+        return None
+    n, K = D.size(0), D.size(1)
     nbytes = _lib.load().dsa_mcep_resid_images_bytes(K, n)
     if nbytes <= 0:
         return None
-    images = torch.empty(nbytes, dtype=torch.uint8, device=Dc.device)
-    with torch.cuda.device(Dc.device):
+    ver = (D._version, E._version, D.data_ptr(), E.data_ptr(), tuple(D.shape), tuple(E.shape))
+    hit = _RESID_IMAGES.get(id(D))
+    if hit is not None and hit[0]() is D and hit[1] == ver:
+        if not hit[3].query():
+            with torch.cuda.device(D.device):
+                torch.cuda.current_stream().wait_event(hit[3])
+        return hit[2]
+    Dc, Ec = D.contiguous(), E.contiguous()
+    images = torch.empty(nbytes, dtype=torch.uint8, device=D.device)
+    with torch.cuda.device(D.device):
         _call("dsa_mcep_resid_prepare", _p(Dc), Dc.size(1), _p(Ec), Ec.size(1), K, n, _dtype_code(Dc), _p(images), _stream())
-    if len(_RESID_IMAGES) > 16:
-        _RESID_IMAGES.clear()
-    _RESID_IMAGES[key] = (images, Dc, Ec)
+        ready = torch.cuda.Event()
+        ready.record()
+    if hit is None or hit[0]() is not D:
+        weakref.finalize(D, _RESID_IMAGES.pop, id(D), None)
+    _RESID_IMAGES[id(D)] = (weakref.ref(D), ver, images, ready)
     return images
 
 
