@@ -1640,6 +1640,7 @@ DSA_EXPORT int dsa_mgcep_step_bwd_h(const void* x, const void* b1, const void* g
                                     void* gx, void* gb1, void* stream)
 {
     DSA_REQUIRE(F >= 0, "mgcep_step_bwd_h: sizes must be positive");
+    DSA_REQUIRE(F == 0 || (x && b1 && gpt && gqt && gr && images_bwd_h && gx && gb1), "mgcep_step_bwd_h: null pointer");
     DSA_REQUIRE(gamma != 0.0 && gamma >= -1.0 && gamma < 0.0, "mgcep_step_bwd_h: gamma must be in [-1, 0)");
     if (dtype != DSA_F32 || fft_length != 512 || M != 24)
         return fail(DSA_ERR_UNSUPPORTED, "mgcep_step_bwd_h: needs float32, fft_length 512, cep_order 24%s");
@@ -1652,6 +1653,7 @@ DSA_EXPORT int dsa_mgcep_step_solve(const void* x, const void* b1, int64_t F, in
                                     void* b1_prev, void* stream)
 {
     DSA_REQUIRE(F >= 0 && n_steps >= 1, "mgcep_step_solve: sizes must be positive");
+    DSA_REQUIRE(F == 0 || (x && b1 && images_h && b1_out && r), "mgcep_step_solve: null pointer");
     DSA_REQUIRE(gamma != 0.0 && gamma > -1.0 && gamma < 0.0, "mgcep_step_solve: gamma must be in (-1, 0)");
     if (dtype != DSA_F32 || fft_length != 512 || M != 24)
         return fail(DSA_ERR_UNSUPPORTED, "mgcep_step_solve: needs float32, fft_length 512, cep_order 24%s");
