@@ -23,7 +23,9 @@ namespace dsa {
 namespace mgh {
 using namespace mm;
 constexpr int WAVES = 8;
-constexpr int STAGES = 9;
+constexpr int STAGES = 9;                       // stages of the images (the backward walks all nine)
+constexpr int FSTAGES = 8;                      // the forward's loop: bins 0 .. 255; bin 256 is a handful of float32 multiply-adds (below)
+constexpr int NYQ_FLOATS = 240;                 // behind the images: Cr | Ci at bin 256 [24 + 24], rows 256 of Pr [32] Qr [48] Qi [48] Rr [32] Ri [32]
 constexpr int C1_HALVES = 2 * 2 * 2 * 512;      // [t][Cr | Ci][hi | lo][64 lane][8]
 constexpr int W2_HALVES = 12 * 2 * 512;         // [c][hi | lo][64 lane][8]
 constexpr int STAGE_HALVES = C1_HALVES + W2_HALVES;   // 16 384 halves = 32 KB
@@ -34,7 +36,8 @@ constexpr int L_STAGE = 0;
 constexpr int L_WAVE = 2 * STAGE_HALVES / 2;
 constexpr int L_B = L_WAVE + WAVES * 16 * kTq;        // per wave: the 16 frames' coefficients b1 (16 x 24), carried from step to step
 constexpr int L_CST = L_B + WAVES * 16 * 24;
-constexpr int LDS_FLOATS = L_CST + 64;
+constexpr int L_NYQ = L_CST + 64;
+constexpr int LDS_FLOATS = L_NYQ + NYQ_FLOATS;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024 && L_WAVE % 4 == 0, "the mgcep step's LDS carve-up");
 }  // namespace mgh
 
@@ -53,6 +56,8 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
     const int n = lane & 15, g = lane >> 4;
     const int nq = lane >> 2, gs = lane & 3;
     if (tid < 64) lds[L_CST + tid] = tid == 32 + 24 ? 1.f : 0.f;
+    if (tid < NYQ_FLOATS) lds[L_NYQ + tid] = reinterpret_cast<const float*>(img + STAGES * STAGE_HALVES)[tid];
+    const float* nyq = lds + L_NYQ;
     float* wl = lds + L_WAVE + wave * 16 * kTq;
     float* bsl = lds + L_B + wave * 16 * 24;
     const float* cst = lds + L_CST;
@@ -124,23 +129,18 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
         // stage ahead (a request that goes to memory takes thousands of cycles, and loads return in order)
         f32x4 xn[2] = {zero4, zero4};
         auto xfetch = [&](int j) __attribute__((always_inline)) {
-            if (j < 8) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) xn[t] = *reinterpret_cast<const f32x4_u4*>(xt + rn * 257 + 32 * j + 16 * t + 4 * g);
-            } else {
-                xn[0] = zero4;
-                xn[1] = zero4;
-                if (g == 0) xn[0][0] = xt[rn * 257 + 256];
-            }
+            for (int t = 0; t < 2; ++t) xn[t] = *reinterpret_cast<const f32x4_u4*>(xt + rn * 257 + 32 * j + 16 * t + 4 * g);
         };
         xfetch(0);
+        const float x256 = xt[rn * 257 + 256];
         stage(0);
         __syncthreads();
 #pragma unroll 1
-        for (int j = 0; j < STAGES; ++j) {
+        for (int j = 0; j < FSTAGES; ++j) {
             const int buf = (MGH_ABL & 1) ? 0 : (j & 1);
             const f32x4 xv[2] = {xn[0], xn[1]};
-            if (j + 1 < STAGES) {
+            if (j + 1 < FSTAGES) {
                 xfetch(j + 1);
                 if (!(MGH_ABL & 1)) fetch(j + 1);
             }
@@ -212,10 +212,40 @@ __global__ __launch_bounds__(512, 2) void mgcep_step_h_kernel(const float* __res
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[t][r] += __builtin_ldexpf(ag[t][r], k2);
             }
-            if (j + 1 < STAGES && !(MGH_ABL & 1)) stage(buf ^ 1);   // the other buffer: its readers finished before the barrier that ended stage j - 1
+            if (j + 1 < FSTAGES && !(MGH_ABL & 1)) stage(buf ^ 1);   // the other buffer: its readers finished before the barrier that ended stage j - 1
             if (!(MGH_ABL & 2)) __syncthreads();
         }
         if (tile_ok) {
+        // ---------------- bin 256 (a ninth stage of 32 bins for one bin cost a ninth of the loop): float32 multiply-adds ----------------
+        {
+            float re = 0.f, im = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = g < 3 ? 8 * g + i : 0;
+                const float bc = g < 3 ? bsl[n * 24 + c] : 0.f;   // (re-read from the wave's slots: eight registers less across the stages)
+                re = __builtin_fmaf(bc, nyq[c], re);
+                im = __builtin_fmaf(bc, nyq[24 + c], im);
+            }
+            re = rows_sum4(re);
+            im = rows_sum4(im);
+            const float X = __builtin_fmaf(gamma, re, 1.f), Y = gamma * im;
+            const float XX = X * X, YY = Y * Y, D = XX + YY;
+            const float dp = __builtin_amdgcn_exp2f(ex * __builtin_amdgcn_logf(D));
+            const float pp = x256 * dp;
+            const float qq = pp * __builtin_amdgcn_rcpf(D);
+            const float s1 = qq * (XX - YY), s2 = qq * (2.f * X * Y), s3 = pp * X, s4 = pp * Y;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = 16 * t + 4 * g + r;   // < 48
+                    if (t < 2) {
+                        acc[t][r] = __builtin_fmaf(pp, nyq[48 + col], acc[t][r]);
+                        acc[5 + t][r] = __builtin_fmaf(s3, nyq[176 + col], __builtin_fmaf(s4, nyq[208 + col], acc[5 + t][r]));
+                    }
+                    acc[2 + t][r] = __builtin_fmaf(s1, nyq[80 + col], __builtin_fmaf(s2, nyq[128 + col], acc[2 + t][r]));
+                }
+        }
         // ---------------- the wave's 16 systems: windows (q | mirrored p | r[1:]) in the quad-layout solve's record ----------------
         for (int e = lane; e < 16 * kTq; e += 64) wl[e] = 0.f;
         __builtin_amdgcn_wave_barrier();

@@ -76,7 +76,7 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
         # ... and at cep_order 24 the WHOLE step (chains as binary16 splits + the solve + the update) is one launch without a graph
         # (dsa_mgcep_step_solve; DSA_MGCEP_STEP_SOLVE=0: the two launches of rounds 2-4, for A/B runs)
         if self.step_images is not None and cep_order == 24 and -1 < gamma < 0:
-            self.register_buffer("step_images_h", torch.from_numpy(tables.mgcep_step_h_images(fft_length, cep_order, float(alpha))).to(device),
+            self.register_buffer("step_images_h", torch.from_numpy(tables.mgcep_step_h_buffer(fft_length, cep_order, float(alpha))).to(device),
                                  persistent=False)
             # ... and the step's adjoint on the binary16 matrix pipe too (DSA_MGCEP_STEP_BWD_H=0: the float32 kernel, for A/B runs)
             if os.environ.get("DSA_MGCEP_STEP_BWD_H") != "0":

@@ -1297,7 +1297,7 @@ def thsolve_update(pt, qt, r, b1):
 def mgcep_step_solve(x, b1, images_h, gamma, out=None, n_steps=1, want_prev=False):
     """(b1 + solve(toeplitz(pt) + hankel(qt), r[1:]), r) of one WHOLE Newton step of mgcep.py:199-230 in one launch
     (dsa_mgcep_step_solve: binary16-split matrix chains + the block elimination; float32 / fft_length 512 / cep_order 24 /
-    gamma in (-1, 0)); forward only.  `images_h`: tables.mgcep_step_h_images as a float16 tensor; `out`: where the updated coefficients
+    gamma in (-1, 0)); forward only.  `images_h`: tables.mgcep_step_h_buffer as a byte tensor; `out`: where the updated coefficients
     go (may be `b1` itself when that is contiguous); `n_steps` Newton steps in the one launch (r is the last step's); `want_prev`: also
     return the last step's input coefficients (what the gain of mgcep.py:221 multiplies r with)."""
     _require_device(x, b1, images_h)

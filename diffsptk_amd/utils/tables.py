@@ -578,6 +578,24 @@ def mgcep_step_h_images(fft_length: int, cep_order: int, alpha: float) -> np.nda
     return out
 
 
+def mgcep_step_h_buffer(fft_length: int, cep_order: int, alpha: float) -> np.ndarray:
+    """What dsa_mgcep_step_solve takes as `images_h`, as bytes: mgcep_step_h_images (9 x 16384 binary16) followed by 240 float32 -- the
+    matrices at the Nyquist bin, which the kernel applies with float32 multiply-adds instead of a ninth stage of 32 bins:
+    Cr[1:25, 256] | Ci[1:25, 256] | rows 256 of Pr[:, :24] (32, zero-padded) | Qr[:, 2:] (48) | Qi[:, 2:] (48) | Rr (32) | Ri (32)."""
+    img = mgcep_step_h_images(fft_length, cep_order, alpha)
+    M, H = cep_order, fft_length // 2
+    m = mgcep_matrices(fft_length, cep_order, float(alpha))
+    t = np.zeros(240, dtype=np.float32)
+    t[0:24] = m["Cr"][1:M + 1, H]
+    t[24:48] = m["Ci"][1:M + 1, H]
+    t[48:48 + M] = m["Pr"][H, :M]
+    t[80:80 + 2 * M - 1] = m["Qr"][H, 2:]
+    t[128:128 + 2 * M - 1] = m["Qi"][H, 2:]
+    t[176:176 + M + 1] = m["Rr"][H, :]
+    t[208:208 + M + 1] = m["Ri"][H, :]
+    return np.concatenate([np.ascontiguousarray(img).view(np.uint8).reshape(-1), t.view(np.uint8)])
+
+
 def mgcep_step_bwd_h_images(fft_length: int, cep_order: int, alpha: float) -> np.ndarray:
     """Binary16 hi / lo operand images of dsa_mgcep_step_bwd_h (csrc/mgcep_step_f16.h), float16, shape (9, 22528): per STAGE of 32 bins
       [2 t][2 (Cr, Ci)][2 (hi, lo)][64 lane][8 i]   the forward's first chain (re, im recomputed), as in mgcep_step_h_images

@@ -365,8 +365,8 @@ int dsa_mgcep_step_bwd_h(const void* x, const void* b1, const void* gpt, const v
  * arithmetic, the five row products as 3-term binary16 splits on the matrix pipe, the 24 x 24 Toeplitz-plus-Hankel solve (block
  * elimination, pivoted re-solve for systems that are not positive definite) and the update: x:(F,257), b1:(F,24) ->
  * b1_out:(F,24) = b1 + solve(toeplitz(pt) + hankel(qt), r[1:]) (b1_out may be b1), r:(F,25) (what the gain of mgcep.py:221 reads).
- * `images_h`: 9 x 16384 binary16, built by the caller once per configuration (diffsptk_amd.utils.tables.mgcep_step_h_images; layout:
- * csrc/mgcep_step_f16.h).  `pt`:(F,24), `qt`:(F,47): NULL, or where the system's two generators are kept for a graph (the backward is
+ * `images_h`: 9 x 16384 binary16 followed by 240 float32 (the matrices at the Nyquist bin), built by the caller once per configuration
+ * (diffsptk_amd.utils.tables.mgcep_step_h_buffer; layout: csrc/mgcep_step_f16.h).  `pt`:(F,24), `qt`:(F,47): NULL, or where the system's two generators are kept for a graph (the backward is
  * dsa_thsolve_bwd on (pt, qt, b1_out - b1) followed by dsa_mgcep_step_bwd).  Replaces dsa_mgcep_step + dsa_thsolve_update_fwd (95 + 32 us
  * per 51 200 frames: 80).  `n_steps` >= 1 Newton steps run in the ONE launch (a frame's iteration depends on the frame alone: the
  * coefficients stay in LDS between the steps); r, pt, qt are the LAST step's, `b1_prev`:(F,24) (or NULL) the last step's input. */
