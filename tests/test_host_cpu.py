@@ -423,3 +423,58 @@ def test_mlsa_learnable_constructs_on_the_host():
     assert dsp.MLSA(24, 80, alpha=0.42, mode="multi-stage").a is None
     with pytest.raises(ValueError):
         dsp.MLSA(24, 80, mode="multi-stage", taylor_order=-1)
+
+
+def test_round5_binary16_operand_images_reconstruct_their_matrices():
+    """The hi / lo binary16 operand images of the one-launch mgcep step, of its adjoint and the Nyquist tail (utils/tables.py): every
+    (lane, k-slot) entry, hi + lo, is the scaled matrix entry the kernel's lane order names -- to 2^-21 of the entry (a 3-term split
+    carries 22 bits) -- and everything outside the matrices is zero.  (The 48 kHz residual's images are built on the device.)"""
+    from diffsptk_amd.utils import tables
+
+    m = tables.mgcep_matrices(512, 24, 0.42)
+    img = tables.mgcep_step_h_images(512, 24, 0.42).astype(np.float64)
+    assert img.shape == (9, 16384)
+    sc, sw = 2.0 ** tables.MGCEP_STEP_H_LOG2_SC, 2.0 ** tables.MGCEP_STEP_H_LOG2_SW
+    lanes = np.arange(64)
+    li, lg = lanes & 15, lanes >> 4
+    for j in (0, 3, 8):
+        c1 = img[j, :4096].reshape(2, 2, 2, 64, 8)
+        w2 = img[j, 4096:].reshape(12, 2, 64, 8)
+        for t in range(2):
+            for ci_, C in enumerate((m["Cr"], m["Ci"])):
+                for i in range(8):
+                    row, col = 1 + 8 * lg + i, 32 * j + 16 * t + li
+                    ok = (row <= 24) & (col < 257)
+                    want = np.where(ok, sc * C[np.minimum(row, 24), np.minimum(col, 256)], 0.0)
+                    got = c1[t, ci_, 0, :, i] + c1[t, ci_, 1, :, i]
+                    assert np.all(np.abs(got - want) <= 2.0 ** -21 * np.abs(want) + 2.0 ** -24)   # (+ the binary16 subnormal quantum)
+        mats = [(m["Pr"][:, :24], 2), (m["Qr"][:, 2:], 3), (m["Qi"][:, 2:], 3), (m["Rr"], 2), (m["Ri"], 2)]
+        c = 0
+        for W, ntile in mats:
+            for tc in range(ntile):
+                for i in range(8):
+                    b, col = 32 * j + 16 * (i >> 2) + 4 * lg + (i & 3), 16 * tc + li
+                    ok = (b < 257) & (col < W.shape[1])
+                    want = np.where(ok, sw * W[np.minimum(b, 256), np.minimum(col, W.shape[1] - 1)], 0.0)
+                    got = w2[c, 0, :, i] + w2[c, 1, :, i]
+                    # entries below 2^-14 / 2^11 of the scale keep fewer bits of their low piece (binary16 subnormals): absolute bound
+                    assert np.all(np.abs(got - want) <= 2.0 ** -21 * np.abs(want) + 2.0 ** -24)
+                c += 1
+    buf = tables.mgcep_step_h_buffer(512, 24, 0.42)
+    assert buf.dtype == np.uint8 and buf.size == 9 * 16384 * 2 + 240 * 4
+    tail = buf[9 * 16384 * 2:].view(np.float32)
+    assert np.array_equal(tail[0:24], m["Cr"][1:25, 256].astype(np.float32)) and np.array_equal(tail[24:48], m["Ci"][1:25, 256].astype(np.float32))
+    assert np.array_equal(tail[48:72], m["Pr"][256, :24].astype(np.float32)) and not tail[72:80].any()
+    assert np.array_equal(tail[80:127], m["Qr"][256, 2:].astype(np.float32)) and np.array_equal(tail[208:233], m["Ri"][256].astype(np.float32))
+    bw = tables.mgcep_step_bwd_h_images(512, 24, 0.42).astype(np.float64)
+    assert bw.shape == (9, 22528)
+    assert np.array_equal(bw[:, :4096], img[:, :4096])                      # the forward's first chain, verbatim
+    ct = bw[2, 4096 + 14336:].reshape(2, 2, 2, 64, 8)                       # (Cr, Ci) with coefficients as rows
+    for ci_, C in enumerate((m["Cr"], m["Ci"])):
+        for tc in range(2):
+            for i in range(8):
+                b, row = 32 * 2 + 16 * (i >> 2) + 4 * lg + (i & 3), 1 + 16 * tc + li
+                ok = row <= 24
+                want = np.where(ok, sc * C[np.minimum(row, 24), b], 0.0)
+                got = ct[ci_, tc, 0, :, i] + ct[ci_, tc, 1, :, i]
+                assert np.all(np.abs(got - want) <= 2.0 ** -21 * np.abs(want) + 2.0 ** -24)
