@@ -31,6 +31,7 @@ pass cannot be taken from inside the process being timed); every other number is
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -249,17 +250,27 @@ def gpu_time(fn, n=30, groups=3):
     """ms per call of fn(): `groups` groups of n back-to-back calls between two HIP events on the current stream,
     median over the groups (the launches of a group pipeline through the command processor: kernel time, not
     kernel + dispatch gap)."""
+    # no cyclic garbage collection inside a timed group (as the standard library's timeit): a generation-2 pass of this process
+    # takes 18 - 80 ms of host time and, landing between two launches, reads as a slow kernel (profiles/r05_measured_tolerances_final.txt).
+    # Only disabled, never forced here: a forced collection idles the chip for tens of milliseconds right in front of the groups, and the
+    # clock it costs showed in every figure (config 3's forward 0.61 -> 0.69 ms).
+    gc_was = gc.isenabled()
+    gc.disable()
     fn()
     torch.cuda.synchronize()
     out = []
-    for _ in range(groups):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        out.append(e0.elapsed_time(e1) / n)
+    try:
+        for _ in range(groups):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            out.append(e0.elapsed_time(e1) / n)
+    finally:
+        if gc_was:
+            gc.enable()
     return statistics.median(out)
 
 
@@ -748,6 +759,7 @@ def main():
         while in_flight:
             in_flight.pop(0)[1].wait()
 
+    gc.collect()   # (here, in front of the ramp: a collection right before the timed region would idle the chip and cost the clock)
     with torch.no_grad():
         if args.ramp_seconds > 0:   # clock ramp: untimed, same workload; a fixed count when N > 1 (collectives must match)
             t_ramp = time.perf_counter()
@@ -764,6 +776,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        gc.disable()   # (as timeit does: no generation-2 collection -- tens of milliseconds of host time -- between two launches of the timed region)
         t0 = time.perf_counter()
         for i in range(args.steps):
             # HIP events bracket the two launches of every fourth step of the timed region only (the per-kernel
@@ -774,6 +787,7 @@ def main():
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        gc.enable()
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
