@@ -13,6 +13,8 @@ if [ "${2:-fwd}" = "fused" ]; then CMD="python $GRAFT_REPO_ROOT/tools/run_fused_
 if [ "${2:-fwd}" = "fusedmcep" ]; then CMD="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --ramp-seconds 0 --no-cpu-baseline --no-configs --path fused"; fi
 if [ "${2:-fwd}" = "lpc" ]; then CMD="python $GRAFT_REPO_ROOT/tools/run_lpc_only.py"; fi
 if [ "${2:-fwd}" = "lpcbwd" ]; then CMD="python $GRAFT_REPO_ROOT/tools/run_lpc_bwd_only.py"; fi
+if [ "${2:-fwd}" = "mgcep" ]; then CMD="python $GRAFT_REPO_ROOT/tools/run_mgcep_only.py"; fi
+if [ "${2:-fwd}" = "k48" ]; then CMD="env B=512 N=3 python $GRAFT_REPO_ROOT/tools/run_48k_only.py"; fi
 if [ "${2:-fwd}" = "mlsa" ]; then CMD="python $GRAFT_REPO_ROOT/tools/run_mlsa_multistage_only.py"; fi
 if [ "${2:-fwd}" = "stftbwd" ]; then CMD="env N=6 SMALL=0 python $GRAFT_REPO_ROOT/tools/run_stft_bwd_only.py"; fi
 i=0
