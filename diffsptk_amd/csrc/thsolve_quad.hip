@@ -414,7 +414,14 @@ __global__ __launch_bounds__(256, TQ_OCT_OCC) void thsolve_octn_kernel(const flo
     constexpr int QW = 4 * NG + 8 * NCP - 1;
     constexpr int PO = QW + 7;
     constexpr int RO = PO + 8 * NCP;
+#ifdef TQ_OCT_REC_ODD   // (A/B: rounds 3-4)
     constexpr int REC = (RO + 4 * NG) | 1;
+#else
+    // record stride = 8 (mod 32): the eight lanes of a system read eight consecutive banks (column offset 4 h + gs), and the four
+    // systems of a 32-lane half then cover the 32 banks exactly once (an odd stride overlapped the systems' bank ranges: PMC
+    // lds_conflict_frac 0.67)
+    constexpr int REC = ((RO + 4 * NG - 8 + 31) / 32) * 32 + 8;
+#endif
     constexpr int CPN = (NG - 1) >> 1, HN = (NG - 1) & 1;   // where column CN lives
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -560,7 +567,11 @@ template <int NG, int NMIN>
 static int thsolve_octn_launch(const void* p, int ldp, const void* q, int ldq, const void* r, int ldr, const void* sub, const void* add,
                                int64_t F, int n, void* g, hipStream_t st)
 {
+#ifdef TQ_OCT_REC_ODD
     constexpr int NCP = (NG + 1) / 2, REC = ((4 * NG + 8 * NCP - 1) + 7 + 8 * NCP + 4 * NG) | 1;
+#else
+    constexpr int NCP = (NG + 1) / 2, REC = ((((4 * NG + 8 * NCP - 1) + 7 + 8 * NCP + 4 * NG) - 8 + 31) / 32) * 32 + 8;   // as in the kernel
+#endif
     const int lds_bytes = 4 * 8 * REC * (int)sizeof(float);
     long blocks = ((F + 7) / 8 + 3) / 4;
     if (blocks > 512) blocks = 512;   // two workgroups per CU
