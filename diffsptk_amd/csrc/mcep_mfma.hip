@@ -478,7 +478,8 @@ __device__ __forceinline__ void blk_backsub_all_r(const f32x4 (&a)[blk::NBLK], f
 // rows comes through the slot-6 pointers as zeros, so it never couples.  One system per wave with a pivot search
 // (th_solve_reg, csrc/mgc.hip) took 0.2 ms per 51 200 systems; this takes 0.02 ms.
 // ---------------------------------------------------------------------------------------------
-constexpr int kTq = 136;   // floats per system in LDS: q window [0, 52) | mirrored p window [52, 104) | r [104, 132) (136 % 32 = 8)
+constexpr int kTq = 132;   // floats per system in LDS: q window [0, 52) | mirrored p window [52, 104) | r [104, 132); 132 % 32 = 4: the four lanes of a
+                           // system read four consecutive banks and the eight systems of a 32-lane half cover the 32 banks once (136: two systems per bank range)
 // `r` rows are r_stride floats apart and start r_off floats in (the Newton step of mgcep hands over its (F, 25) vector with
 // the right-hand side in columns 1 .. 24); `add` (or NULL): g = add + solution (the step's update b <- b + solve(..)).
 __global__ __launch_bounds__(256) void thsolve_quad24_kernel(const float* __restrict__ p, const float* __restrict__ q,

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void thsolve_quadn_kernel(const float* __re
     constexpr int QW = 8 * NG - 1;
     constexpr int PO = QW + 3;                  // p[0]
     constexpr int RO = QW + 4 * NG + 3;         // rhs[0]
-    constexpr int REC = 16 * NG + 3;
+    constexpr int REC = ((16 * NG + 3 - 4 + 31) / 32) * 32 + 4;   // >= 16 NG + 3 and = 4 (mod 32): see the octet kernel (rounds 3-4: 16 NG + 3, odd)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float* wl = lds + wave * 16 * REC;
@@ -551,7 +551,7 @@ template <int NG, int NMIN>
 static int thsolve_quadn_launch(const void* p, int ldp, const void* q, int ldq, const void* r, int ldr, const void* sub, const void* add,
                                 int64_t F, int n, void* g, hipStream_t st)
 {
-    constexpr int REC = 16 * NG + 3;
+    constexpr int REC = ((16 * NG + 3 - 4 + 31) / 32) * 32 + 4;   // >= 16 NG + 3 and = 4 (mod 32): see the octet kernel (rounds 3-4: 16 NG + 3, odd)
     const int lds_bytes = 4 * 16 * REC * (int)sizeof(float);
     static std::atomic<uint64_t> attr{0};
     if (lds_bytes > 48 * 1024 && !ensure_dynamic_lds((const void*)tq::thsolve_quadn_kernel<NG, NMIN>, lds_bytes, attr))
