@@ -24,8 +24,16 @@ HIPCC_FLAGS = (
 # Per-source additions.  stft.hip: the compiler's automatic v_pk_*_f32 selection costs the register-FFT kernels
 # more in register-pairing moves than it saves (forward 88 -> 82 us per 204 800 frames without it; the packed
 # kernels of stft_pk.h / stft_bwd_pk.h switch the feature back on for themselves and place v_pk_* by hand).
+# Round 6: the same for every unit whose compiler-made packed code contained forms with a set op_sel bit (a low result half
+# reading a high source half: the instruction class of DESIGN.md 4, which no shipped kernel may execute --
+# tests/test_host_cpu.py::test_no_crossed_packed_float32); kernels with hand-placed packed instructions carry DSA_PK_TARGET.
+_NO_PK = ("-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops")
 SOURCE_FLAGS = {
-    "stft.hip": ("-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"),
+    "stft.hip": _NO_PK,
+    "fbank.hip": _NO_PK,
+    "mgc.hip": _NO_PK,
+    "thsolve_quad.hip": _NO_PK,
+    "mcep_mfma.hip": _NO_PK,   # (its kernels carry DSA_PK_TARGET -- measured faster with the compiler's pairing -- except mgcep_step_h)
 }
 
 F32, F64 = 0, 1

@@ -1,5 +1,17 @@
 // Shared host/device helpers for the diffsptk_amd HIP library (gfx950 only).
 #pragma once
+
+// Translation units are built with the compiler's packed-float32 selection switched OFF (_lib.py: SOURCE_FLAGS): its own
+// v_pk_*_f32 code pairs registers with extra moves, and it freely emits the forms with a set op_sel bit (a LOW result half
+// reading a HIGH source half) -- the instruction class of every transient wrong result DESIGN.md 4 recorded, which no shipped
+// kernel may execute (tests/test_host_cpu.py::test_no_crossed_packed_float32).  Switching the feature off also makes the
+// assembler reject v_pk_*_f32 in inline assembly: a kernel that places packed instructions by hand carries this attribute,
+// which switches the feature back on for that function only.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DSA_PK_TARGET __attribute__((target("packed-fp32-ops")))
+#else
+#define DSA_PK_TARGET
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -482,7 +482,7 @@ constexpr int kTq = 132;   // floats per system in LDS: q window [0, 52) | mirro
                            // system read four consecutive banks and the eight systems of a 32-lane half cover the 32 banks once (136: two systems per bank range)
 // `r` rows are r_stride floats apart and start r_off floats in (the Newton step of mgcep hands over its (F, 25) vector with
 // the right-hand side in columns 1 .. 24); `add` (or NULL): g = add + solution (the step's update b <- b + solve(..)).
-__global__ __launch_bounds__(256) void thsolve_quad24_kernel(const float* __restrict__ p, const float* __restrict__ q,
+__global__ __launch_bounds__(256) DSA_PK_TARGET void thsolve_quad24_kernel(const float* __restrict__ p, const float* __restrict__ q,
                                                              const float* __restrict__ r, long F, float* g,
                                                              int r_stride, int r_off, const float* add)   // (g may be add)
 {

@@ -38,7 +38,7 @@ static_assert(C_WAVE % 4 == 0 && C_LDS_FLOATS * 4 <= 160 * 1024, "the two-wave b
                      // 16 history / rt rows from one small region, 32 no back substitution, 64 no rtbar rotations
 #endif
 
-__global__ __launch_bounds__(512, 2) void mcep_mfma_bwd2_kernel_h(
+__global__ __launch_bounds__(512, 2) DSA_PK_TARGET void mcep_mfma_bwd2_kernel_h(
     const float* __restrict__ gmc, const float* __restrict__ X, const float* __restrict__ hist, long F, int n_iter,
     const float* __restrict__ av, float* gX, long ntiles16, unsigned int* __restrict__ queue,
     const _Float16* __restrict__ img, const float* __restrict__ hist_rt)

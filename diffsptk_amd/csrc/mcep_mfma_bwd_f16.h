@@ -99,7 +99,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo
 // SAVED_RT (round 5): the forward kept every step's rt row (DSA_ALGO_HIST_HAS_RT, `hist_rt`: (n_iter, F, 49)); the step then loads it
 // into the windows instead of re-running the second forward chain (72 binary16 products, the split of e, 27 image reads per step).
 template <bool SAVED_RT>
-__global__ __launch_bounds__(256, 1) void mcep_mfma_bwd_kernel_h(
+__global__ __launch_bounds__(256, 1) DSA_PK_TARGET void mcep_mfma_bwd_kernel_h(
     const float* __restrict__ gmc, const float* __restrict__ X, const float* __restrict__ hist, long F, int n_iter,
     const float* __restrict__ av, float* gX, long ntiles16, unsigned int* __restrict__ queue,
     const _Float16* __restrict__ img, int split_tiles, int split_pieces, float* ws, const float* __restrict__ hist_rt)

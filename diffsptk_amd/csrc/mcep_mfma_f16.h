@@ -218,7 +218,7 @@ __device__ __forceinline__ void store_mc_row(float* row, int g, const float (&mc
 
 template <int WAVES, bool FUSED = false, bool HIST_RT = false>   // HIST_RT: also keep every step's rt row (its own instantiation: the
                                                                  // plain kernels' code and register allocation are untouched)
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) DSA_PK_TARGET void mcep_mfma_fwd_kernel_h(
     const float* __restrict__ X, long F, int n_iter, const float* __restrict__ G,
     const float* __restrict__ D, const float* __restrict__ E, const float* __restrict__ av,
     float* __restrict__ mc_out, float* __restrict__ hist, long ntiles16, long tiles_shared,
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                     if constexpr ((PKM & 16) != 0) {   // the packed form of csrc/stft_pk.h, instruction for instruction
                         const v2f eps2 = v2f{sti.eps, sti.eps};
                         v2f Ee;
-                        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(Ee) : "v"(z0[q]), "v"(z0[q]));
+                        Ee = pk_lo_pm_hi(z0[q], z0[q]);
                         const v2f E4 = pk_mul_s(Ee, v2f{4.f, 4.f});
                         se = pk_fma_sc(E4, Ee, eps2);
 #pragma unroll
@@ -491,8 +491,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mcep_mfma_fwd_kernel_h(
                             const v2f Dd = pk_sub_conj(pa[q][part], pb[q][part]);
                             const v2f Pp = pk_cmul(Dd, part == 0 ? twA : twB);
                             v2f R, I;
-                            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(R) : "v"(S), "v"(Pp));
-                            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(I) : "v"(S), "v"(Pp));
+                            R = pk_lo_pm_hi(S, Pp);
+                            I = pk_hi_mp_lo(S, Pp);
                             sp[part] = pk_fma(I, I, pk_fma_sc(R, R, eps2));
                         }
                     } else {

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void mcep_resid_h_prep_kernel(const float* __r
 }
 
 template <int KS1, int NT>
-__global__ __launch_bounds__(256, 2) void mcep_resid_h_kernel(const float* __restrict__ logx, long F, int K, const float* __restrict__ mc, int M1,
+__global__ __launch_bounds__(256, 2) DSA_PK_TARGET void mcep_resid_h_kernel(const float* __restrict__ logx, long F, int K, const float* __restrict__ mc, int M1,
                                                              const _Float16* __restrict__ img, int N, float* __restrict__ out, int ldo)
 {
     using namespace mrh;

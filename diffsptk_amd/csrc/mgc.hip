@@ -529,7 +529,11 @@ __device__ __forceinline__ void zd_fma_lo(zd_v2f& acc, zd_v2f c, zd_v2f w)   // 
 }
 __device__ __forceinline__ void zd_fma_hi(zd_v2f& acc, zd_v2f c, zd_v2f w)   // acc += c * w.y (both halves)
 {
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(c), "v"(w));
+    // the odd sample as the LOW half of its own pair (a move the compiler shares between the uses of a ring slot), then the
+    // low-half broadcast of zd_fma_lo: the one-instruction form "op_sel:[0,1,0] op_sel_hi:[1,1,1]" has a set op_sel bit -- its
+    // low result reads a high source half -- and no shipped kernel executes that class (pk_math.h, DSA_PK_CROSSED)
+    const zd_v2f wh = __builtin_shufflevector(w, w, 1, 1);
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(c), "v"(wh));
 }
 // two adjacent pairs from a 16-byte aligned LDS address (float: one ds_read_b128); `both` false: only the first is wanted
 __device__ __forceinline__ void zd_load2(const zd_v2f* p, zd_v2f& a, zd_v2f& b, bool both)
@@ -556,7 +560,7 @@ __device__ __forceinline__ void zd_fma_lo(zd_v2d& acc, zd_v2d c, zd_v2d w) { acc
 __device__ __forceinline__ void zd_fma_hi(zd_v2d& acc, zd_v2d c, zd_v2d w) { acc += c * w.y; }
 
 template <typename T, int S>
-__global__ __launch_bounds__(256) void zerodf_fwd_rows_kernel(const T* __restrict__ x, const T* __restrict__ b, long Tlen, long N,
+__global__ __launch_bounds__(256) DSA_PK_TARGET void zerodf_fwd_rows_kernel(const T* __restrict__ x, const T* __restrict__ b, long Tlen, long N,
                                                               int M, int P, int z0, int ignore_gain, int nf, int G, T scale,
                                                               const T* acc, T* __restrict__ y, T* ysum)
 {
@@ -774,7 +778,7 @@ static int zerodf_launch_fwd(const void* x, const void* b, int64_t B, int64_t Tl
 // different m, so the window is re-read every block (the kernel is bound by LDS reads, ~1.4 x the multiply-adds).
 // The old kernel: a thread per sample over all taps with two row reads from memory per tap.
 template <typename T, int S>
-__global__ __launch_bounds__(256) void zerodf_bwd_x_rows_kernel(const T* __restrict__ gy, const T* __restrict__ b, long Tlen, long N,
+__global__ __launch_bounds__(256) DSA_PK_TARGET void zerodf_bwd_x_rows_kernel(const T* __restrict__ gy, const T* __restrict__ b, long Tlen, long N,
                                                                 int M, int P, int z0, int nf, int nrows, int ldb, int accumulate,
                                                                 T scale, const T* add, T* gx)
 {
@@ -1430,8 +1434,9 @@ DSA_EXPORT int dsa_thsolve_fwd(const void* p, const void* q, const void* r, int6
         return !e || atoi(e) != 0;
     }();
     if (dtype == DSA_F32 && n == 24 && quad && F > 0) return thsolve_quad24_fwd(p, q, r, F, g, (hipStream_t)stream);
-    // other orders up to 55, float32, a batch that fills waves of 16 systems: the same scheme as a template over the size
-    if (dtype == DSA_F32 && n >= 2 && n <= 55 && quad && F >= 64)
+    // other orders up to 55, float32: the same scheme as a template over the size -- chosen from (n, dtype) ALONE, like
+    // dsa_mcep_newton_update: a frame's rounding must not depend on how many frames travel with it (round 6: the F >= 64 test is gone)
+    if (dtype == DSA_F32 && n >= 2 && n <= 55 && quad && F > 0)
         return thsolve_quadn_fwd(p, n, q, 2 * n - 1, r, n, nullptr, nullptr, F, n, g, (hipStream_t)stream);
     if (dtype == DSA_F32) return th_launch<float>(false, nullptr, p, q, r, F, n, g, nullptr, nullptr, (hipStream_t)stream);
     if (dtype == DSA_F64) return th_launch<double>(false, nullptr, p, q, r, F, n, g, nullptr, nullptr, (hipStream_t)stream);
@@ -1522,7 +1527,7 @@ DSA_EXPORT int dsa_thsolve_bwd(const void* gg, const void* p, const void* q, con
     // the other orders the batched forward covers (csrc/thsolve_quad.hip: 2 .. 55, batches from 64 systems): the same two launches.
     // (The one-wave-per-system backward -- a second pivoted elimination per system -- took 220 us per 12 800 systems of order 50,
     // 37 % of a forward + backward of the 48 kHz analysis; this takes 39 + 7.)
-    if (dtype == DSA_F32 && n >= 2 && n <= 55 && n != 24 && F >= 64 && quad && gp && gq && gr) {
+    if (dtype == DSA_F32 && n >= 2 && n <= 55 && n != 24 && F > 0 && quad && gp && gq && gr) {
         if (int rc = thsolve_quadn_fwd(p, n, q, 2 * n - 1, gg, n, nullptr, nullptr, F, n, gr, (hipStream_t)stream)) return rc;
         hipLaunchKernelGGL(th_bwd_sums_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)gr,
                            (const float*)g, (long)F, (int)n, (float*)gp, (float*)gq);

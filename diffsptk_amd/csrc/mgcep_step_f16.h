@@ -347,7 +347,7 @@ constexpr int BW_STAGE_HALVES = BW_CT + 2 * 2 * 2 * 512;   // 22 528 halves = 44
 static_assert(2 * BW_STAGE_HALVES * 2 <= 160 * 1024, "the mgcep step backward's two stage buffers");
 }  // namespace mgh
 
-__global__ __launch_bounds__(512, 2) void mgcep_step_bwd_h_kernel(const float* __restrict__ x, const float* __restrict__ b1,
+__global__ __launch_bounds__(512, 2) DSA_PK_TARGET void mgcep_step_bwd_h_kernel(const float* __restrict__ x, const float* __restrict__ b1,
                                                                  const float* __restrict__ gpt, const float* __restrict__ gqt,
                                                                  const float* __restrict__ grr, long F, float gamma,
                                                                  const _Float16* __restrict__ img, const float* __restrict__ gx_in,

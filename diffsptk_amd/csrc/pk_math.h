@@ -42,6 +42,15 @@ __device__ __forceinline__ v2f pk_sub(v2f a, v2f b)
 #ifndef DSA_PK_DBG
 #define DSA_PK_DBG 0
 #endif
+// DSA_PK_CROSSED (A/B and tools/hazard/ builds only, 0 in the product): 1 restores the one-instruction forms whose LOW result half
+// reads a HIGH source half (a set op_sel bit: the +-i rotation, the second instruction of a complex product, the split's sums).
+// That is the instruction class of every transient wrong result DESIGN.md 4 recorded, and its trigger is not understood, so NO
+// shipped kernel executes it: the same roundings come from two one-component instructions (an addition / subtraction costs 2
+// datapath cycles against 4 for the packed pair: no loss; a multiply-add 4 against 4 for the pair: the complex product pays 4
+// cycles).  tests/test_host_cpu.py::test_no_crossed_packed_float32 disassembles the built library and enforces it.
+#ifndef DSA_PK_CROSSED
+#define DSA_PK_CROSSED 0
+#endif
 #if DSA_PK_DBG & 8
 #define DSA_PK_ROT_PRE "s_nop 1\n\t"
 #else
@@ -55,7 +64,7 @@ __device__ __forceinline__ v2f pk_sub(v2f a, v2f b)
 __device__ __forceinline__ v2f pk_add_negi(v2f a, v2f b)   // a - i b = (a.re + b.im, a.im - b.re)
 {
     v2f r;
-#if DSA_PK_DBG & 1
+#if (DSA_PK_DBG & 1) || !DSA_PK_CROSSED
     float rx, ry;
     asm("v_add_f32 %0, %1, %2" : "=v"(rx) : "v"(a.x), "v"(b.y));
     asm("v_sub_f32 %0, %1, %2" : "=v"(ry) : "v"(a.y), "v"(b.x));
@@ -73,7 +82,7 @@ __device__ __forceinline__ v2f pk_add_negi(v2f a, v2f b)   // a - i b = (a.re + 
 __device__ __forceinline__ v2f pk_add_posi(v2f a, v2f b)   // a + i b = (a.re - b.im, a.im + b.re)
 {
     v2f r;
-#if DSA_PK_DBG & 1
+#if (DSA_PK_DBG & 1) || !DSA_PK_CROSSED
     float rx, ry;
     asm("v_sub_f32 %0, %1, %2" : "=v"(rx) : "v"(a.x), "v"(b.y));
     asm("v_add_f32 %0, %1, %2" : "=v"(ry) : "v"(a.y), "v"(b.x));
@@ -98,6 +107,30 @@ __device__ __forceinline__ v2f pk_sub_conj(v2f a, v2f b)   // a - conj(b) = (a.r
 {
     v2f r;
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (a.lo + b.hi, a.lo - b.hi): the real-FFT split's sums (a, b may be the same pair)
+__device__ __forceinline__ v2f pk_lo_pm_hi(v2f a, v2f b)
+{
+    v2f r;
+#if DSA_PK_CROSSED
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+#else
+    asm("v_add_f32 %0, %1, %2" : "=v"(r.x) : "v"(a.x), "v"(b.y));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r.y) : "v"(a.x), "v"(b.y));
+#endif
+    return r;
+}
+// (a.hi - b.lo, -a.hi - b.lo)
+__device__ __forceinline__ v2f pk_hi_mp_lo(v2f a, v2f b)
+{
+    v2f r;
+#if DSA_PK_CROSSED
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+#else
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r.x) : "v"(a.y), "v"(b.x));
+    asm("v_sub_f32 %0, -%1, %2" : "=v"(r.y) : "v"(a.y), "v"(b.x));
+#endif
     return r;
 }
 __device__ __forceinline__ v2f pk_mul(v2f a, v2f b)
@@ -129,7 +162,12 @@ __device__ __forceinline__ v2f pk_cmul(v2f a, v2f t)
 {
     v2f t1, r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t1) : "v"(a), "v"(t));
+#if DSA_PK_CROSSED
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(t), "v"(t1));
+#else
+    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(r.x) : "v"(a.y), "v"(t.y), "v"(t1.x));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r.y) : "v"(a.x), "v"(t.y), "v"(t1.y));
+#endif
     return r;
 }
 // the same with the constant t in a SCALAR register pair (the radix-16 twiddles: uniform, 10 scalar registers)
@@ -144,7 +182,12 @@ __device__ __forceinline__ v2f pk_cmul_s(v2f a, v2f t)
     return r;
 #endif
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t1) : "v"(a), "s"(t));
+#if DSA_PK_CROSSED
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(t), "v"(t1));
+#else
+    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(r.x) : "v"(a.y), "s"(t.y), "v"(t1.x));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r.y) : "v"(a.x), "s"(t.y), "v"(t1.y));
+#endif
     return r;
 }
 

@@ -28,7 +28,12 @@ namespace dsa {
 __device__ __forceinline__ v2f pk_add_posi_conj(v2f ab, v2f q)   // conj(ab - i q) = (ab.re + q.im, q.re - ab.im)
 {
     v2f r;
+#if DSA_PK_CROSSED
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(ab), "v"(q));
+#else   // no packed float32 instruction whose low half reads a high source half (pk_math.h, DSA_PK_CROSSED)
+    asm("v_add_f32 %0, %1, %2" : "=v"(r.x) : "v"(ab.x), "v"(q.y));
+    asm("v_sub_f32 %0, %2, %1" : "=v"(r.y) : "v"(ab.y), "v"(q.x));
+#endif
     return r;
 }
 // conj(t) * a, t = (c, s) in vector registers: (a.re c + a.im s, a.im c - a.re s)
@@ -36,14 +41,24 @@ __device__ __forceinline__ v2f pk_cmul_conj(v2f a, v2f t)
 {
     v2f t1, r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t1) : "v"(a), "v"(t));
+#if DSA_PK_CROSSED
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(t), "v"(t1));
+#else
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r.x) : "v"(a.y), "v"(t.y), "v"(t1.x));
+    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(r.y) : "v"(a.x), "v"(t.y), "v"(t1.y));
+#endif
     return r;
 }
 __device__ __forceinline__ v2f pk_cmul_conj_s(v2f a, v2f t)   // the same, t uniform in a scalar register pair
 {
     v2f t1, r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t1) : "v"(a), "s"(t));
+#if DSA_PK_CROSSED
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "s"(t), "v"(t1));
+#else
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r.x) : "v"(a.y), "s"(t.y), "v"(t1.x));
+    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(r.y) : "v"(a.x), "s"(t.y), "v"(t1.y));
+#endif
     return r;
 }
 __device__ __forceinline__ v2f pk_mul_lo(v2f a, v2f g)   // a * g.x
@@ -55,7 +70,12 @@ __device__ __forceinline__ v2f pk_mul_lo(v2f a, v2f g)   // a * g.x
 __device__ __forceinline__ v2f pk_mul_hi(v2f a, v2f g)   // a * g.y
 {
     v2f r;
+#if DSA_PK_CROSSED
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(g));
+#else
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r.x) : "v"(a.x), "v"(g.y));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r.y) : "v"(a.y), "v"(g.y));
+#endif
     return r;
 }
 

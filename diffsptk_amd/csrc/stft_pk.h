@@ -37,11 +37,7 @@ __device__ unsigned long long g_stft_pk_stamps[64];
 // stft512_fwd_kernel<0, false, true, LC> (see there); P must be even (8-byte aligned sample pairs in LDS).
 // (stft.hip is built with the compiler's packed-float32 selection switched off, which also makes the assembler
 // reject v_pk_*_f32 in inline assembly: the target attribute switches the feature back on for this kernel only)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define DSA_PK_TARGET __attribute__((target("packed-fp32-ops")))
-#else
-#define DSA_PK_TARGET
-#endif
+// (DSA_PK_TARGET: common.h)
 // DIRECT: the power values leave the split's registers as 4-byte stores (lane = bin: every store instruction writes 64
 // consecutive floats of one row) instead of being staged in LDS for 16-byte stores: the kernel is bound by LDS
 // cycles, and the staged tile costs 18 four-byte LDS writes + 5 sixteen-byte reads per pass (a fifth of them).
@@ -55,6 +51,12 @@ __device__ unsigned long long g_stft_pk_stamps[64];
 // (v_fmac_f32_dpp with a 0/1 mask per lane and step: no transposition through LDS, no matrix operand images --
 // neither would fit beside four waves per SIMD).  Four-wave workgroups: the window moves from registers to a
 // shared LDS table to make room for the plan.
+// The filter-bank epilogue's rare branches (a floor below 1e-30, gamma != 0) call the library's logf / powf.  Inlined into a
+// kernel that carries DSA_PK_TARGET the compiler packs their polynomial code, with crossed forms (a low result half reading a
+// high source half: the class no shipped kernel executes, common.h) -- so they stay calls to functions built without the feature.
+__device__ __attribute__((noinline)) float fb_slow_log(float v) { return dsa_log(v); }
+__device__ __attribute__((noinline)) float fb_slow_glog(float v, float gamma) { return (dsa_pow(v, gamma) - 1.f) / gamma; }
+
 template <int ABL, int LC, bool DIRECT = false, int FBM = 0, bool PF2 = false>   // FBM: 0 spectrum out, 1 filter bank of the power values, 2 of the amplitudes;
                                                                             // PF2: the stretch fetched TWO passes ahead (two register sets, window from LDS)
 __global__ __launch_bounds__((FBM || PF2) ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
@@ -442,7 +444,7 @@ __global__ __launch_bounds__((FBM || PF2) ? 256 : 128, 4) DSA_PK_TARGET void stf
         for (int f = 0; f < kFPW; ++f) {
             // the two real-valued end bins from Z[0] alone: X[0] = 2 (re + im), X[256] = 2 (re - im)
             v2f E;
-            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(E) : "v"(z0[f]), "v"(z0[f]));
+            E = pk_lo_pm_hi(z0[f], z0[f]);
             const v2f E4 = pk_mul_s(E, v2f{4.f, 4.f});
             const v2f se = pk_fma_sc(E4, E, eps2);
             ends[f] = se;
@@ -460,8 +462,8 @@ __global__ __launch_bounds__((FBM || PF2) ? 256 : 128, 4) DSA_PK_TARGET void stf
                 const v2f Dd = pk_sub_conj(pa[f][part], pb[f][part]);
                 const v2f Pp = pk_cmul(Dd, part == 0 ? twA : twB);
                 v2f R, I, s;
-                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(R) : "v"(S), "v"(Pp));
-                asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(I) : "v"(S), "v"(Pp));
+                R = pk_lo_pm_hi(S, Pp);
+                I = pk_hi_mp_lo(S, Pp);
                 s = pk_fma_sc(R, R, eps2);
                 s = pk_fma(I, I, s);
                 sp[part] = s;
@@ -571,7 +573,7 @@ __global__ __launch_bounds__((FBM || PF2) ? 256 : 128, 4) DSA_PK_TARGET void stf
                     for (int f = 0; f < kFPW; ++f) {
                         float v = sums[0];
                         v = f == 1 ? sums[1] : v, v = f == 2 ? sums[2] : v, v = f == 3 ? sums[3] : v;
-                        v = dsa_log(v);
+                        v = fb_slow_log(v);
                         sums[0] = f == 0 ? v : sums[0], sums[1] = f == 1 ? v : sums[1];
                         sums[2] = f == 2 ? v : sums[2], sums[3] = f == 3 ? v : sums[3];
                     }
@@ -580,7 +582,7 @@ __global__ __launch_bounds__((FBM || PF2) ? 256 : 128, 4) DSA_PK_TARGET void stf
                     for (int f = 0; f < kFPW; ++f) {
                         float v = sums[0];
                         v = f == 1 ? sums[1] : v, v = f == 2 ? sums[2] : v, v = f == 3 ? sums[3] : v;
-                        v = (dsa_pow(v, fb_gamma) - 1.f) / fb_gamma;
+                        v = fb_slow_glog(v, fb_gamma);
                         sums[0] = f == 0 ? v : sums[0], sums[1] = f == 1 ? v : sums[1];
                         sums[2] = f == 2 ? v : sums[2], sums[3] = f == 3 ? v : sums[3];
                     }

@@ -80,8 +80,10 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
                                  persistent=False)
             # ... and the step's adjoint on the binary16 matrix pipe too (DSA_MGCEP_STEP_BWD_H=0: the float32 kernel, for A/B runs)
             if os.environ.get("DSA_MGCEP_STEP_BWD_H") != "0":
-                self.register_buffer("step_images_bwd", torch.from_numpy(tables.mgcep_step_bwd_h_images(fft_length, cep_order, float(alpha)))
-                                     .to(device), persistent=False)
+                # (stored as int16 bit patterns like step_images_h's bytes: nn.Module.float() / .to(dtype) cast every FLOATING buffer, and
+                #  a binary16 image silently cast to float32 would be read by the float32 kernel in the wrong layout)
+                self.register_buffer("step_images_bwd", torch.from_numpy(tables.mgcep_step_bwd_h_images(fft_length, cep_order, float(alpha))
+                                                                         .view("int16")).to(device), persistent=False)
         else:
             self.step_images_h = None
         self._zero_q = None   # (see forward: the Hankel generator of the gamma = -1 step)
@@ -149,15 +151,22 @@ class MelGeneralizedCepstralAnalysis(nn.Module):
                 # a graph or a stream capture could make it outlive this call's view of it
                 shape = (*pt.shape[:-1], 2 * M - 1)
                 zq = self._zero_q
-                if torch.is_grad_enabled() or zq is None or zq.shape != shape or zq.device != pt.device or zq.dtype != pt.dtype \
-                        or torch.cuda.is_current_stream_capturing():
-                    zq = torch.zeros(shape, device=pt.device, dtype=pt.dtype)
-                    if not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
-                        self._zero_q = zq
-                        self._zero_q_ready = torch.cuda.Event()
-                        self._zero_q_ready.record()
-                elif not self._zero_q_ready.query():   # filled on another stream and possibly not done yet
-                    torch.cuda.current_stream().wait_event(self._zero_q_ready)
+                with torch.cuda.device(pt.device):   # events and streams below belong to the INPUT's device, not the current one
+                    cur = torch.cuda.current_stream()
+                    nbytes = pt.element_size() * (pt.numel() // max(M, 1)) * (2 * M - 1)
+                    cacheable = not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing() and nbytes <= (16 << 20)
+                    if not cacheable or zq is None or zq.shape != shape or zq.device != pt.device or zq.dtype != pt.dtype:
+                        if zq is not None and zq.is_cuda and zq.device == pt.device:
+                            zq.record_stream(cur)   # the block being dropped may still be read by launches queued on this stream
+                        zq = torch.zeros(shape, device=pt.device, dtype=pt.dtype)
+                        if cacheable:               # (blocks above 16 MB are not kept for the module's lifetime)
+                            self._zero_q = zq
+                            self._zero_q_ready = torch.cuda.Event()
+                            self._zero_q_ready.record(cur)
+                    else:
+                        if not self._zero_q_ready.query():   # filled on another stream and possibly not done yet
+                            cur.wait_event(self._zero_q_ready)
+                        zq.record_stream(cur)                # read on this stream: the allocator must not recycle it under us
                 qt = zq
             upd = None
             if not (torch.is_grad_enabled() and (pt.requires_grad or qt.requires_grad or r.requires_grad or b1.requires_grad)):

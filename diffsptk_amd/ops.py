@@ -1019,6 +1019,20 @@ def _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter):
     return mc.reshape(*lead, M1)
 
 
+# The tuned mel-cepstral forward can keep every Newton step's (2 M + 1)-entry row of rt behind the iterates a gradient needs anyway:
+# the backward then skips its second forward chain (1.56 -> 1.09-1.18 ms per 204 800 frames).  Cost: n_iter F (2 M + 1) floats on top
+# of the (n_iter + 1) F (M + 1) of the iterates -- at 204 800 frames and 10 steps 401 MB on top of 225 MB, alive from the forward to
+# the backward.  Above this many EXTRA bytes per call the rows are not kept and the backward recomputes them (same gradient to
+# rounding; slower); set it to 0 to never keep them, or DSA_MCEP_HIST_RT=0 in the environment.
+MCEP_HIST_RT_MAX_BYTES = 4 << 30
+
+
+def _keep_rt_rows(n_iter, F, M, like):
+    if os.environ.get("DSA_MCEP_HIST_RT", "1") == "0":
+        return False
+    return n_iter * F * (2 * M + 1) * like.element_size() <= MCEP_HIST_RT_MAX_BYTES
+
+
 def _mcep_history(n_iter, F, M, like, with_rt):
     """The Newton history a gradient needs: (n_iter + 1, F, M + 1) iterates, followed -- for the tuned kernels (with_rt) -- by the
     (n_iter, F, 2 M + 1) rows of rt that let the backward skip its second forward chain (DSA_ALGO_HIST_HAS_RT).  One flat buffer."""
@@ -1066,7 +1080,7 @@ class StftMcepFn(torch.autograd.Function):
         F = B * N
         need_grad = ctx.needs_input_grad[0]
         mc = torch.empty(*xc.shape[:-1], N, M + 1, device=x.device, dtype=x.dtype)
-        with_rt = need_grad and os.environ.get("DSA_MCEP_HIST_RT", "1") != "0"
+        with_rt = need_grad and _keep_rt_rows(n_iter, F, M, xc)
         hist = _mcep_history(n_iter, F, M, x, with_rt) if need_grad else None
         X = torch.empty(*xc.shape[:-1], N, K, device=x.device, dtype=x.dtype) if need_grad else None
         images = mcep_images(G, D, E, fft_length, M)
@@ -1124,7 +1138,7 @@ class McepFn(torch.autograd.Function):
         if images is None and not need_hist and algo != _lib.ALGO_GENERIC and _mcep_composed_applies(Xc, M):
             return _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter)
         # the tuned kernels keep every step's rt row next to the iterates (DSA_ALGO_HIST_HAS_RT): the backward skips a chain
-        with_rt = need_hist and images is not None and os.environ.get("DSA_MCEP_HIST_RT", "1") != "0"
+        with_rt = need_hist and images is not None and _keep_rt_rows(n_iter, F, M, Xc)
         hist = _mcep_history(n_iter, F, M, X, with_rt) if need_hist else None
         # the tile queue's counters: a per-(device, stream) scratch that the kernel leaves zeroed (no fill launch per call)
         scratch = None
@@ -1238,8 +1252,15 @@ def mgcep_step(x, b1, images, gamma):
 
 
 def _step_bwd_entry(images_bwd):
-    """The step's adjoint: float16 images (tables.mgcep_step_bwd_h_images) select the binary16 kernel, float32 ones the round-3 kernel."""
-    return "dsa_mgcep_step_bwd_h" if images_bwd.dtype == torch.float16 else "dsa_mgcep_step_bwd"
+    """The step's adjoint: binary16 images (tables.mgcep_step_bwd_h_images, kept as int16 bit patterns so that Module.float() cannot
+    cast them; float16 accepted too) select the binary16 kernel, float32 ones the round-3 kernel.  Anything else is a cast image."""
+    if images_bwd.dtype in (torch.int16, torch.float16):
+        if images_bwd.numel() != 9 * 22528:
+            raise ValueError("mgcep step adjoint: the binary16 operand images must have 9 x 22528 entries")
+        return "dsa_mgcep_step_bwd_h"
+    if images_bwd.dtype != torch.float32:
+        raise ValueError(f"mgcep step adjoint: operand images of dtype {images_bwd.dtype} (expected int16 / float16 or float32)")
+    return "dsa_mgcep_step_bwd"
 
 
 class MgcepStepFn(torch.autograd.Function):

@@ -416,7 +416,7 @@ def test_mgcep_step_adjoint_on_binary16_splits_against_the_float32_kernel(F):
     gqt = (torch.randn(F, 47, generator=gen) * lvl * 8).to(DEV)
     gr = (torch.randn(F, 25, generator=gen) * lvl / 8).to(DEV)
     mg = dsp.MelGeneralizedCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, gamma=-0.5, n_iter=1, device=DEV)
-    assert mg.step_images_bwd.dtype == torch.float16
+    assert mg.step_images_bwd.dtype == torch.int16   # binary16 bit patterns: Module.float() must not cast them
     img32 = torch.from_numpy(__import__("diffsptk_amd").utils.tables.mgcep_step_bwd_images(512, 24, 0.42)).to(DEV)
 
     def run(images):
@@ -475,6 +475,32 @@ def test_mgcep_step_backward_kernel_against_float64_autograd():
         outs[dt] = (pp.grad.double(), qq.grad.double(), rr.grad.double())
     for a, b in zip(outs[torch.float32], outs[torch.float64]):
         assert float((a - b).abs().max()) < 2e-3 * float(b.abs().max())   # float32 solves of systems with condition ~1e3
+
+
+def test_mgcep_gradient_survives_module_float_and_to():
+    """nn.Module.float() / .to(dtype) cast every floating-point buffer: the binary16 operand images of the step's adjoint are kept
+    as int16 bit patterns (like the forward's bytes), so the same kernel reads the same image afterwards (round-5 advisor finding:
+    as a float16 buffer the image became float32 and the float32 kernel read it in the wrong layout -- finite, wrong gradients)."""
+    g = torch.Generator().manual_seed(33)
+    X = (torch.randn(2, 90, 257, generator=g).square() + 0.1).to(DEV)
+    w = torch.randn(25, generator=g).to(DEV)
+    mg = dsp.MelGeneralizedCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, gamma=-0.5, n_iter=3, device=DEV)
+
+    def grad(m):
+        xs = X.clone().requires_grad_(True)
+        (m(xs) * w).sum().backward()
+        return xs.grad
+
+    g0 = grad(mg)
+    assert _lib.last_kernel() is not None
+    bits = mg.step_images_bwd.clone()
+    for cast in (lambda m: m.float(), lambda m: m.to(torch.float32), lambda m: m.to(DEV, torch.float32), lambda m: m.double().float()):
+        mg = cast(mg)
+        assert mg.step_images_bwd.dtype == torch.int16 and torch.equal(mg.step_images_bwd, bits)
+        assert mg.step_images_h.dtype == torch.uint8
+        assert torch.equal(grad(mg), g0)
+    with pytest.raises(ValueError, match="operand images"):
+        ops._step_bwd_entry(bits.double())
 
 
 def test_bench_two_ranks_on_one_device():

@@ -1111,3 +1111,25 @@ def test_row_products_are_batch_invariant(L1, L2):
             assert float((ref_y.double() - ref64).abs().max()) < 2e-6 * float(ref64.abs().max()) + 1e-6
         assert torch.equal(y.detach(), ref_y[:F]), F
         assert torch.equal(cF.grad, ref_g[:F]), F
+
+
+@pytest.mark.parametrize("M", [17, 30])
+def test_mgcep_at_other_orders_is_batch_invariant(M):
+    """mgcep.py:226-230 at an order without the one-launch step: dsa_thsolve_fwd / _bwd choose their kernel from (order, dtype)
+    alone (round-5 advisor finding: they used to switch between the quad-layout and the one-wave-per-system solver at 64 frames,
+    so a frame's rounding depended on how many frames travelled with it); forward and the gradient, bit for bit."""
+    gen = torch.Generator().manual_seed(M)
+    X = (torch.randn(200, 257, generator=gen).square() + 0.1).to(DEV)
+    w = torch.randn(M + 1, generator=gen).to(DEV)
+    mg = dsp.MelGeneralizedCepstralAnalysis(fft_length=512, cep_order=M, alpha=0.42, gamma=-0.5, n_iter=2, device=DEV)
+    ref_y = ref_g = None
+    for F in (200, 1, 16, 63, 64, 65):
+        xs = X[:F].clone().requires_grad_(True)
+        y = mg(xs)
+        (y * w).sum().backward()
+        if ref_y is None:
+            ref_y, ref_g = y.detach().clone(), xs.grad.clone()
+        assert torch.equal(y.detach(), ref_y[:F]), F
+        assert torch.equal(xs.grad, ref_g[:F]), F
+        with torch.no_grad():
+            assert torch.equal(mg(X[:F]), mg(X[:200])[:F]), F

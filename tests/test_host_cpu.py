@@ -273,6 +273,37 @@ def test_build_recipe_is_consistent():
         assert hasattr(lib, name), name
 
 
+def test_no_crossed_packed_float32():
+    """The mechanical form of DESIGN.md 4's invariant: NO kernel of the built library contains a packed float32 instruction
+    with a set op_sel bit (a low result half reading a high source half) -- the instruction class of every transient wrong
+    result recorded there.  No allow-list: a kernel that "runs alone" can meet another instruction stream on its SIMD through
+    a second HIP stream.  The gfx950 code objects of the library on disk are disassembled (llvm-objdump, a private copy)."""
+    import sys
+
+    from diffsptk_amd import _lib
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    try:
+        import isa_mix
+    finally:
+        sys.path.pop(0)
+    if not os.path.exists(isa_mix.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    kernels = isa_mix.disassemble(_lib.build())
+    assert len(kernels) > 200   # the whole library was read, not one code object
+    n_packed = sum(1 for ins in kernels.values() for _, op, _t in ins if re.match(r"v_pk_\w+_f32", op))
+    assert n_packed > 1000      # ... and the pattern below sees packed instructions at all
+    bad = isa_mix.crossed_packed_f32(kernels)
+    assert not bad, {k: (len(v), v[:2]) for k, v in bad.items()}
+    # the detector itself: the two forms round 5's audit missed in mgcep_step_h_kernel, and forms that are fine
+    fake = {"k": [(0, "v_pk_mul_f32", "v[4:5], v[34:35], v[36:37] op_sel:[0,1] op_sel_hi:[1,0]"),
+                  (4, "v_pk_fma_f32", "v[0:1], v[2:3], v[4:5], v[0:1] op_sel_hi:[1,0,1]"),
+                  (8, "v_pk_add_f32", "v[0:1], v[2:3], v[4:5] neg_lo:[0,1] neg_hi:[0,1]"),
+                  (12, "v_pk_fma_f32", "v[0:1], v[2:3], v[4:5], v[0:1] op_sel:[0,1,0] op_sel_hi:[1,1,1]"),
+                  (16, "v_pk_mul_f16", "v0, v1, v2 op_sel:[1,0]")]}
+    assert [t.split()[0] for t in isa_mix.crossed_packed_f32(fake)["k"]] == ["v_pk_mul_f32", "v_pk_fma_f32"]
+
+
 def test_learnable_fallback_operators_match_the_transforms():
     """modules/_learnable.py (the torch-operator fallbacks behind ``learnable=``) against numpy / the oracle: at
     initialisation a learnable basis must reproduce the fixed transform it replaces (fftr.py:123-129,

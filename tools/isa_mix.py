@@ -76,6 +76,21 @@ def disassemble(lib):
     return kernels
 
 
+def crossed_packed_f32(kernels):
+    """{kernel: [instruction text]} of every packed float32 instruction with a SET op_sel bit -- a LOW result half that reads a
+    HIGH source half -- in `kernels` (the output of disassemble()).  That is the instruction class of every transient wrong
+    result DESIGN.md 4 recorded; the product must contain none (tests/test_host_cpu.py::test_no_crossed_packed_float32).
+    `python tools/isa_mix.py --audit [lib.so]` prints the per-kernel counts."""
+    bad = {}
+    for name, ins in kernels.items():
+        for _, op, txt in ins:
+            if re.match(r"v_pk_\w+_f32", op):
+                m = re.search(r"op_sel:\[([01,]+)\]", txt)
+                if m and "1" in m.group(1):
+                    bad.setdefault(name, []).append(op + " " + txt)
+    return bad
+
+
 def innermost_last_loop(ins):
     """(start, end) indices of the last backward branch's span that contains no other backward branch target span."""
     addr = {a: i for i, (a, _, _) in enumerate(ins)}
@@ -144,5 +159,14 @@ def main():
     print(json.dumps(res, indent=1))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--audit" in sys.argv:
+    args = [a for a in sys.argv[1:] if a != "--audit"]
+    ks = disassemble(args[0] if args else os.path.join(ROOT, "diffsptk_amd", "lib", "libdiffsptk_amd.so"))
+    bad = crossed_packed_f32(ks)
+    npk = sum(1 for ins in ks.values() for _, op, _t in ins if re.match(r"v_pk_\w+_f32", op))
+    for k_, v_ in sorted(bad.items()):
+        print("%5d  %s" % (len(v_), k_))
+    print("%d kernels, %d packed float32 instructions, %d with a set op_sel bit in %d kernels" % (len(ks), npk, sum(map(len, bad.values())), len(bad)))
+    sys.exit(1 if bad else 0)
+elif __name__ == "__main__":
     main()
