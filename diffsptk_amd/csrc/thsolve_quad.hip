@@ -586,22 +586,17 @@ int thsolve_quadn_fwd(const void* p, int ldp, const void* q, int ldq, const void
                       int n, void* g, hipStream_t st)
 {
     if (n < 2) return fail(DSA_ERR_UNSUPPORTED, "thsolve_quad: order below 2%s");
-    // orders from `oct_min` on: eight systems per wave (an octet each); below: sixteen (a quad each).  DSA_THSOLVE_OCT_MIN moves the
-    // border upwards for A/B runs (99: quads for every order)
-    static const int oct_min = [] {
-        const char* e = getenv("DSA_THSOLVE_OCT_MIN");
-        return e ? atoi(e) : 36;
-    }();
-    if (n >= oct_min && n >= 36) {   // (below 36 the octets measured slower: 19.9 against 17.2 us at order 35, 15.7 against 13.4 at 25)
+    // orders from 36 on: eight systems per wave (an octet each); below: sixteen (a quad each) -- below 36 the octets measured slower
+    // (19.9 against 17.2 us at order 35, 15.7 against 13.4 at 25), from 36 on the quads spill (57 / 271 / 419 registers at
+    // <11,36> / <13,44> / <14,52>: those instantiations left the build in round 6 together with their A/B switch).  The choice
+    // depends on the order alone: a system's rounding never depends on how many systems travel with it.
+    if (n >= 36) {
         if (n <= 43) return thsolve_octn_launch<11, 36>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
         if (n <= 51) return thsolve_octn_launch<13, 44>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
         if (n <= 55) return thsolve_octn_launch<14, 52>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
     }
     if (n <= 27) return thsolve_quadn_launch<7, 2>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
     if (n <= 35) return thsolve_quadn_launch<9, 28>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
-    if (n <= 43) return thsolve_quadn_launch<11, 36>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
-    if (n <= 51) return thsolve_quadn_launch<13, 44>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
-    if (n <= 55) return thsolve_quadn_launch<14, 52>(p, ldp, q, ldq, r, ldr, sub, add, F, n, g, st);
     return fail(DSA_ERR_UNSUPPORTED, "thsolve_quad: order above 55%s");
 }
 

@@ -34,7 +34,7 @@ def _canned(bench):
         "roofline": roof,
         "roofline_stft": dict(roof, kernel="stft512_fwd", bound="hbm", unit="GB/s", peak=8000.0, achieved=3516.2, frac=0.4395),
         "configs": {"big": [note] * 12},
-        "cpu_baseline": {"value": 40912.3, "unit": "frames/s", "cores": 8, "kind": "port", "sample": "64 utterances x 1 s " + "s" * 300,
+        "cpu_baseline": {"value": 40912.3, "unit": "frames/s", "cores": 128, "threads_best": 8, "kind": "port", "sample": "64 utterances x 1 s " + "s" * 300,
                          "by_threads": {str(i): {"value": 1.0 * i, "note": note} for i in (1, 8, 32, 128)}, "host": {"cpu": note}},
         "gpu_over_cpu": 7971.2, "cpu_baseline_c_oracle": {"value": 1.0, "note": note},
     }
@@ -55,7 +55,7 @@ def test_bench_line_is_compact_parseable_and_starts_with_metric(tmp_path, monkey
     for r in ("roofline", "roofline_stft"):
         assert set(d[r]) == {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms"}
         assert d[r]["frac"] == pytest.approx(d[r]["achieved"] / d[r]["peak"], rel=1e-3)
-    assert set(d["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] in ("port", "reference")
+    assert set(d["cpu_baseline"]) == {"value", "unit", "cores", "threads_best", "kind", "sample"} and d["cpu_baseline"]["kind"] in ("port", "reference")
     assert "workload" in d["config"] and "model" not in d["config"]
     # emit(): the full record goes to the side file, stdout gets the compact line only
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
