@@ -564,7 +564,7 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
 DETAIL_FILE = "bench_detail.json"
 LINE_LIMIT = 4096
 _ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms")
-_ROOF_OPTIONAL = ("algorithmic_frac", "back_to_back_ms", "frac_back_to_back")   # carried when the record has them
+_ROOF_OPTIONAL = ("algorithmic_frac", "back_to_back_ms", "frac_back_to_back", "step_period_ms", "frac_of_step_period")   # carried when the record has them
 
 
 def speech_like_batch(B, dev):
@@ -600,7 +600,7 @@ def compact_line(res: dict, detail_path: str = DETAIL_FILE) -> str:
                                 "scaling", "vs_baseline", "dtype", "data") if k in res}
     cfg = res.get("config", {})
     line["config"] = {k: cfg[k] for k in ("workload", "utterances_per_gpu", "global_batch", "frames_per_step", "parallelism",
-                                          "rccl_world_size", "collective_backend", "kernels", "path", "launches_per_step") if k in cfg}
+                                          "rccl_world_size", "collective_backend", "kernels", "path", "launches_per_step", "streams") if k in cfg}
     for name in ("roofline", "roofline_stft", "roofline_mcep"):
         r = res.get(name)
         if r:
@@ -613,7 +613,7 @@ def compact_line(res: dict, detail_path: str = DETAIL_FILE) -> str:
         line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "threads_best", "kind", "sample")}
         if "gpu_over_cpu" in res:
             line["gpu_over_cpu"] = res["gpu_over_cpu"]
-    for name in ("module_api", "speech_like"):   # the drop-in call mcep(stft(x)) beside the fused step; the speech-like input
+    for name in ("single_stream", "module_api", "speech_like"):   # the drop-in call mcep(stft(x)) beside the fused step; the speech-like input
         if res.get(name):
             line[name] = {k: v for k, v in res[name].items() if k != "note"}
     line["detail"] = detail_path
@@ -660,11 +660,12 @@ def main():
     ap.add_argument("--chunks", type=int, default=1,
                     help="N > 1: utterance chunks per step.  1 (default): one in-place all-gather per step, deferred "
                          "behind the next step's kernels; > 1: chunked gather/compute overlap inside the step")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="N = 1: with 2, consecutive steps alternate between two streams, so the next step's STFT can fill the "
-                         "tail of the persistent mel-cepstral kernel (steps are independent batches).  Round 2: +2.5 %% frames/s; "
-                         "with the round-3 kernel (shorter tail, power-limited clock) it costs 3 %% (tools/ab_streams.sh: 3.28e8 vs "
-                         "3.19e8), so the default stays 1 -- which also keeps the per-kernel timings of the roofline objects clean")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="consecutive steps (independent batches) alternate between this many streams.  2 (default since round 6): every "
+                         "launch carries DSA_ALGO_OVERLAPPED_LAUNCHES -- its short last round of tiles (204 800 frames = 6.25 rounds of the "
+                         "2 048 wave slots) is packed onto 64 workgroups and the other 192 CUs go to the next step's launch, which waits on "
+                         "the other stream: 6.25 rounds per step in the steady state instead of 6.8.  1: every launch runs alone (the "
+                         "figures of rounds 1-5; `single_stream` in the line is this mode measured after the timed region)")
     ap.add_argument("--record-every", type=int, default=4,
                     help="HIP events bracket the two launches of every n-th step of the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -757,31 +758,22 @@ def main():
 
     in_flight = []   # N > 1: (features, handle) of the previous step, whose all-gather overlaps this step
 
-    # N = 1: steps are independent batches; alternating them between streams lets step k+1's STFT run on the CUs the
-    # persistent mel-cepstral kernel of step k has already left (its last round of tiles fills a quarter of the
-    # machine).  The instrumented steps run alone on the main stream so that the per-kernel times stay clean.
-    n_streams = max(1, args.streams) if world == 1 else 1
+    # Steps are independent batches.  With --streams 2 they alternate between two side streams and every launch carries
+    # DSA_ALGO_OVERLAPPED_LAUNCHES (ops.overlapped_launches): a launch's short last round is packed onto a quarter of the CUs and
+    # the rest of the chip starts the next step's launch, which waits on the other stream.  Nothing is fenced inside the timed
+    # region; the HIP events of a recorded step sit on that step's own stream, so a launch's duration includes the time it
+    # shares the chip with its neighbours (what a rocprofv3 kernel trace of the same command reports too).
+    n_streams = max(1, args.streams)
     main_stream = torch.cuda.current_stream()
     side_streams = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else []
     for s_ in side_streams:
         s_.wait_stream(main_stream)   # x was produced on the main stream
     step_no = [0]
 
-    def step(record=False):
+    def step_body(record):
         # N > 1: the features are all-gathered (RCCL, one in-place all_gather_into_tensor) and the collective is left in
         # flight and completed one step later (a streaming consumer reads batch k while batch k+1 is computed), so it
         # hides behind the next step's kernels instead of ending every step
-        if world == 1 and side_streams:
-            step_no[0] += 1
-            if record:
-                for s_ in side_streams:
-                    main_stream.wait_stream(s_)
-                out_ = compute(x, True)
-                for s_ in side_streams:
-                    s_.wait_stream(main_stream)
-                return out_
-            with torch.cuda.stream(side_streams[step_no[0] % n_streams]):
-                return compute(x, False)
         if world == 1:
             return analyze_chunked_overlap(x, lambda xc: compute(xc, record), n_chunks)
         out, handle = analyze_chunked_overlap(x, lambda xc: compute(xc, record), n_chunks, defer=True)
@@ -789,6 +781,13 @@ def main():
         while len(in_flight) > 1:
             in_flight.pop(0)[1].wait()
         return out
+
+    def step(record=False):
+        if not side_streams:
+            return step_body(record)
+        step_no[0] += 1
+        with torch.cuda.stream(side_streams[step_no[0] % n_streams]), ops.overlapped_launches():
+            return step_body(record)
 
     def drain():
         while in_flight:
@@ -953,6 +952,29 @@ def main():
                             "`mcep_mfma_fwd` reads it back (1348 + 1128 algorithmic bytes per frame instead of 420)"}
             except Exception as e:
                 res["two_kernel_path"] = {"error": repr(e)}
+        if world == 1 and n_streams > 1:
+            # the same K steps WITHOUT the overlap: one stream, every launch alone on the chip (the timed region of rounds 1-5)
+            with torch.no_grad():
+                for _ in range(5):
+                    compute(x)
+                torch.cuda.synchronize()
+                gc.disable()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    compute(x)
+                torch.cuda.synchronize()
+                el1 = time.perf_counter() - t1
+                gc.enable()
+            res["single_stream"] = {"ms_per_step": el1 / args.steps * 1e3, "value": frames_rank * args.steps / el1, "unit": "frames/s",
+                                    "steps": args.steps,
+                                    "note": "--streams 1: each launch alone on the chip, its short last round (0.25 of 2 048 wave slots) one wave "
+                                            "per SIMD; measured after the timed region, same process, same input"}
+            r_ = res["roofline"]
+            if r_.get("frac") is not None:
+                # `frac` divides by the launch's own duration, which under the overlap includes the time it shares the chip with its
+                # neighbours; the chip-level figure divides the same cycles by the step period
+                r_["step_period_ms"] = res["ms_per_step"]
+                r_["frac_of_step_period"] = r_["frac"] * r_["avg_launch_ms"] / res["ms_per_step"]
         if world == 1 and args.path == "fused" and "error" not in res.get("two_kernel_path", {}):
             # what a user of the reference's own call sequence gets: mcep(stft(x)) through the modules = two launches
             res["module_api"] = {"call": "mcep(stft(x))", "launches_per_step": 2, "ms_per_step": t_two * 1e3,

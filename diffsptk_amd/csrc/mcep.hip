@@ -340,10 +340,10 @@ int mcep_mfma_prepare(const void* G, const void* D, const void* E, void* images,
 struct StftIn;
 int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E, const void* av,
                   const void* images, void* scratch, void* mc, void* hist, hipStream_t st, bool scratch_clean = false,
-                  const StftIn* sti = nullptr, bool hist_has_rt = false);
+                  const StftIn* sti = nullptr, bool hist_has_rt = false, bool overlapped = false);
 int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, const void* window, const void* twiddle, double eps,
                         int n_iter, const void* G, const void* D, const void* E, const void* av, const void* images, void* scratch,
-                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean, bool hist_has_rt);
+                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean, bool hist_has_rt, bool overlapped);
 int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* av,
                   const void* images, void* scratch, void* gX, hipStream_t st, bool has_workspace = false, bool hist_has_rt = false);
 
@@ -433,14 +433,15 @@ DSA_EXPORT int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, i
     hipStream_t st = (hipStream_t)stream;
     const bool scratch_clean = (algo & DSA_ALGO_SCRATCH_IS_CLEAN) != 0;
     const bool hist_has_rt = (algo & DSA_ALGO_HIST_HAS_RT) != 0;
-    algo &= ~(DSA_ALGO_SCRATCH_IS_CLEAN | DSA_ALGO_HIST_HAS_RT);
+    const bool overlapped = (algo & DSA_ALGO_OVERLAPPED_LAUNCHES) != 0;
+    algo &= ~(DSA_ALGO_SCRATCH_IS_CLEAN | DSA_ALGO_HIST_HAS_RT | DSA_ALGO_OVERLAPPED_LAUNCHES);
     bool tuned_ok = mcep_mfma_supported(nfft, M, dtype) != 0;
     if (algo == DSA_ALGO_TUNED && !tuned_ok)
         return fail(DSA_ERR_UNSUPPORTED, "mcep: tuned kernel needs float32, fft_length 512, cep_order 24%s");
     if (algo == DSA_ALGO_TUNED && !(images && scratch))
         return fail(DSA_ERR_INVALID_ARGUMENT, "mcep: the tuned kernel needs the prepared images (dsa_mcep_prepare) and a scratch buffer%s");
     if (tuned_ok && algo != DSA_ALGO_GENERIC && images && scratch)
-        return mcep_mfma_fwd(X, F, n_iter, G, D, E, alpha_vec, images, scratch, mc, mc_hist, st, scratch_clean, nullptr, hist_has_rt);
+        return mcep_mfma_fwd(X, F, n_iter, G, D, E, alpha_vec, images, scratch, mc, mc_hist, st, scratch_clean, nullptr, hist_has_rt, overlapped);
     if (dtype == DSA_F32) return mcep_generic_fwd<float>(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);
     if (dtype == DSA_F64) return mcep_generic_fwd<double>(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);
     return fail(DSA_ERR_UNSUPPORTED, "mcep: unsupported dtype%s");
@@ -454,6 +455,7 @@ DSA_EXPORT int dsa_stft_mcep_fwd(const void* x, int64_t B, int64_t T, int32_t L,
     DSA_REQUIRE(B >= 0 && T >= 0 && P >= 1 && L >= 1 && n_iter >= 0, "stft_mcep: invalid sizes");
     const bool scratch_clean = (algo & DSA_ALGO_SCRATCH_IS_CLEAN) != 0;
     const bool hist_has_rt = (algo & DSA_ALGO_HIST_HAS_RT) != 0;
+    const bool overlapped = (algo & DSA_ALGO_OVERLAPPED_LAUNCHES) != 0;
     const int64_t N = T <= 0 ? 0 : (T - 1) / P + 1;
     if (!(mcep_mfma_supported(nfft, M, dtype) && L == 400 && B * N < (int64_t(1) << 31) && T < (int64_t(1) << 31)))
         return fail(DSA_ERR_UNSUPPORTED, "stft_mcep: the fused launch covers float32, frame_length 400, fft_length 512, cep_order 24%s");
@@ -461,7 +463,7 @@ DSA_EXPORT int dsa_stft_mcep_fwd(const void* x, int64_t B, int64_t T, int32_t L,
     DSA_REQUIRE(x && window && twiddle && G && D && E && alpha_vec && mc, "stft_mcep: null pointer");
     if (B * N == 0) return DSA_OK;
     return stft_mcep_fused_fwd(x, B, T, P, center, window, twiddle, eps, n_iter, G, D, E, alpha_vec, images, scratch, mc, mc_hist,
-                               X_out, (hipStream_t)stream, scratch_clean, hist_has_rt);
+                               X_out, (hipStream_t)stream, scratch_clean, hist_has_rt, overlapped);
 }
 
 DSA_EXPORT int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist, int64_t F, int32_t nfft,

@@ -622,7 +622,7 @@ static unsigned int* reset_queue(void* scratch, hipStream_t st, int words = 2)
 // `sti`: NULL (spectra in X) or the waveform side of the fused STFT -> mel-cepstrum launch (X is then unused)
 int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E, const void* av,
                   const void* images, void* scratch, void* mc, void* hist, hipStream_t st, bool scratch_clean = false,
-                  const StftIn* sti = nullptr, bool hist_has_rt = false)
+                  const StftIn* sti = nullptr, bool hist_has_rt = false, bool overlapped = false)
 {
     // DSA_ALGO_HIST_HAS_RT: the caller's history buffer continues behind the (n_iter + 1, F, 25) iterates with (n_iter, F, 49) rows of rt
     float* hist_rt = (hist && hist_has_rt) ? (float*)hist + (size_t)(n_iter + 1) * (size_t)F * mm::M1 : nullptr;
@@ -643,11 +643,18 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
     if (!queue) return fail(DSA_ERR_LAUNCH, "mcep_mfma: cannot reset the tile queue%s");
     // see the ticket comment in the kernel: a short last round goes to one wave per SIMD pair
     const long slots = grid * WAVES, full = ntiles16 / slots * slots, rest = ntiles16 - full;
-    const long tiles_shared = (full > 0 && rest > 0 && rest <= slots / 2) ? full : ntiles16;
+    long tiles_shared = (full > 0 && rest > 0 && rest <= slots / 2) ? full : ntiles16;
+    // DSA_ALGO_OVERLAPPED_LAUNCHES: the short round packed onto the first tail_wgs workgroups at two waves per SIMD; everyone else
+    // exits and leaves its CU to the next launch on the caller's other stream (include/diffsptk_amd.h)
+    int tail_wgs = 0;
+    if (overlapped && full > 0 && rest > 0 && grid == 256) {
+        tiles_shared = full;
+        tail_wgs = (int)((rest + WAVES - 1) / WAVES);
+    }
 #define DSA_MCEP_FWD_LAUNCH(FU, RT, XPTR, STI)                                                                                       \
     hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES, FU, RT>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st, (const float*)(XPTR), \
                        (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E, (const float*)av, (float*)mc, (float*)hist,  \
-                       ntiles16, tiles_shared, queue, (const _Float16*)images, STI, hist_rt)
+                       ntiles16, tiles_shared, queue, (const _Float16*)images, STI, hist_rt, tail_wgs)
     if (sti) {
         if (rt) DSA_MCEP_FWD_LAUNCH(true, true, nullptr, *sti);
         else DSA_MCEP_FWD_LAUNCH(true, false, nullptr, *sti);
@@ -662,7 +669,7 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
 // STFT (frame length 400, fft_length 512, power format, constant padding) -> MelCepstralAnalysis (cep_order 24) in one launch
 int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, const void* window, const void* twiddle, double eps,
                         int n_iter, const void* G, const void* D, const void* E, const void* av, const void* images, void* scratch,
-                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean, bool hist_has_rt)
+                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean, bool hist_has_rt, bool overlapped)
 {
     const int64_t N = T <= 0 ? 0 : (T - 1) / P + 1;
     StftIn sti;
@@ -675,7 +682,7 @@ int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, 
     sti.twiddle = (const float*)twiddle;
     sti.eps = (float)eps;
     sti.X_out = (float*)X_out;
-    return mcep_mfma_fwd(nullptr, B * N, n_iter, G, D, E, av, images, scratch, mc, hist, st, scratch_clean, &sti, hist_has_rt);
+    return mcep_mfma_fwd(nullptr, B * N, n_iter, G, D, E, av, images, scratch, mc, hist, st, scratch_clean, &sti, hist_has_rt, overlapped);
 }
 
 int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* av,

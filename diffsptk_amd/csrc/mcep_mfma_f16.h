@@ -222,7 +222,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) DSA_PK_TARGET void mcep_mfma
     const float* __restrict__ X, long F, int n_iter, const float* __restrict__ G,
     const float* __restrict__ D, const float* __restrict__ E, const float* __restrict__ av,
     float* __restrict__ mc_out, float* __restrict__ hist, long ntiles16, long tiles_shared,
-    unsigned int* __restrict__ queue, const _Float16* __restrict__ img, StftIn sti, float* __restrict__ hist_rt)
+    unsigned int* __restrict__ queue, const _Float16* __restrict__ img, StftIn sti, float* __restrict__ hist_rt, int tail_wgs)
 {
     // hist_rt (round 5; NULL or (n_iter, F, 49)): every step's rt = e E row, kept for the backward, which then skips its own second
     // forward chain (DSA_ALGO_HIST_HAS_RT; 196 more bytes per frame and step)
@@ -604,7 +604,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) DSA_PK_TARGET void mcep_mfma
             tile_next = wave_stride + (long)__builtin_amdgcn_readfirstlane((int)nxt);
             if (tile_next >= tiles_shared) {
                 tile_next = ntiles16;
-                if (wave < WAVES / 2 && tiles_shared < ntiles16) {
+                // (tail_wgs > 0, DSA_ALGO_OVERLAPPED_LAUNCHES: the short round on ALL waves of the first tail_wgs workgroups instead --
+                //  the other workgroups exit and the next launch, queued on the caller's second stream, takes their CUs.  Measured,
+                //  204 800 frames, 200 steps on two streams: 0.5945 -> 0.5685 ms per step; dealing ALL tiles statically by whole
+                //  workgroups -- so that a workgroup's eight waves end together -- was tried and is worse, 0.589: the shared queue's
+                //  balancing of uneven CUs is worth more than the clean exit)
+                if ((tail_wgs > 0 ? (int)blockIdx.x < tail_wgs : wave < WAVES / 2) && tiles_shared < ntiles16) {
                     if (lane == 0) nxt = atomicAdd(queue + 1, 1u);
                     tile_next = tiles_shared + (long)__builtin_amdgcn_readfirstlane((int)nxt);
                 }

@@ -1084,6 +1084,7 @@ __global__ __launch_bounds__(128, 4) void stft512_fwd_kernel(
 }  // namespace dsa
 #include "stft_pk.h"
 #include "stft_bwd_pk.h"
+#include "stft_pk_big.h"
 namespace dsa {
 
 // ------------------------------------------------------------------ host-side dispatch helpers
@@ -2101,6 +2102,34 @@ DSA_EXPORT int dsa_stft_fwd(const void* x, int64_t B, int64_t T, int32_t L, int3
                           pad_mode, (const float*)w, (const float*)twiddle, (float)eps, use_floor, floor_lin,
                           out_format, (float*)y, total_chunks, chunks_per_utt, in_floats);
         return check_launch("stft512_fwd");
+    }
+    // fft_length 1024 / 2048 (the 44.1 / 48 kHz set-ups of utils/public.py:61-104), power format, constant padding, no zmean, no
+    // relative floor: the packed kernel of stft_pk_big.h (round 6; DSA_STFT_BIG=0: the generic kernel, for A/B runs)
+    static const bool big_on = [] { const char* e = getenv("DSA_STFT_BIG"); return !(e && e[0] == '0'); }();
+    if (big_on && dtype == DSA_F32 && algo != DSA_ALGO_GENERIC && (nfft == 1024 || nfft == 2048) && !zmean && !use_floor &&
+        out_format == DSA_SPEC_POWER && pad_mode == DSA_PAD_CONSTANT && L <= nfft && (L & 1) == 0 && (P & 1) == 0 && (left & 1) == 0 &&
+        (T & 1) == 0 && (((size_t)x) & 7) == 0 && B * N < (int64_t(1) << 31)) {
+        const int S = nfft / 512, FPP = 4 / S;
+        const int need = (L + 32 * S - 1) / (32 * S);   // sample pairs per lane
+        const int chunks_per_utt = (int)((N + FPP - 1) / FPP);
+        const long total_chunks = (long)B * chunks_per_utt;
+        const int lds_big = 4 * 4 * kZS * 8 + 256 * 8;
+        long wgs = (total_chunks + 3) / 4;
+        if (wgs > 256L * 3) wgs = 256L * 3;   // persistent: three four-wave workgroups per CU (126 .. 167 registers: 3 .. 4 waves per SIMD)
+#define DSA_BIG_LAUNCH(SV, NRV)                                                                                                   \
+    hipLaunchKernelGGL((stft_big_fwd_pk_kernel<SV, NRV>), dim3((unsigned)wgs), dim3(256), lds_big, st, (const float*)x, (long)T, (long)N, \
+                       L, P, left, (const float*)w, (const float*)twiddle, (float)eps, (float*)y, total_chunks, chunks_per_utt)
+        if (S == 2) {
+            if (need <= 10) DSA_BIG_LAUNCH(2, 10);
+            else if (need <= 13) DSA_BIG_LAUNCH(2, 13);
+            else DSA_BIG_LAUNCH(2, 16);
+        } else {
+            if (need <= 10) DSA_BIG_LAUNCH(4, 10);
+            else if (need <= 13) DSA_BIG_LAUNCH(4, 13);
+            else DSA_BIG_LAUNCH(4, 16);
+        }
+#undef DSA_BIG_LAUNCH
+        return check_launch(S == 2 ? "stft1024_fwd" : "stft2048_fwd");
     }
     if (dtype == DSA_F32)
         return launch_row_dft<float>(x, B, T, N, L, P, left, pad_mode, zmean, w, nfft, twiddle, 1, out_format,

@@ -1040,6 +1040,29 @@ def _mcep_history(n_iter, F, M, like, with_rt):
     return torch.empty(n, device=like.device, dtype=like.dtype)
 
 
+_overlapped = [False]
+
+
+class overlapped_launches:
+    """``with ops.overlapped_launches():`` -- the caller alternates consecutive, independent analysis calls between two streams
+    (bench.py --streams 2, dist.analyze_chunked_overlap(alternate_streams=True)).  The tuned mel-cepstral forward launches then pack
+    their short last round of tiles onto a few workgroups and release every other CU to the next launch, which waits on the other
+    stream (DSA_ALGO_OVERLAPPED_LAUNCHES, include/diffsptk_amd.h): 6.25 rounds per 204 800 frames in the steady state instead of
+    6.8.  Results are bit-identical either way; a lone launch is slower with it, so it is never the default."""
+
+    def __init__(self, on: bool = True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _overlapped[0]
+        _overlapped[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _overlapped[0] = self.prev
+        return False
+
+
 def _mcep_scratch(device):
     """(scratch, algo flag) of a tuned mel-cepstral forward launch: the per-(device, stream) kept-zero counters
     (DSA_ALGO_SCRATCH_IS_CLEAN, no fill launch per call) -- except while a HIP graph is being captured: a graph replays on whatever
@@ -1048,7 +1071,7 @@ def _mcep_scratch(device):
     with torch.cuda.device(device):
         if torch.cuda.is_current_stream_capturing() or os.environ.get("DSA_CLEAN_SCRATCH", "1") == "0":   # (the variable: A/B runs)
             return _scratch(device), 0
-        return _clean_scratch(device), _lib.ALGO_SCRATCH_IS_CLEAN
+        return _clean_scratch(device), _lib.ALGO_SCRATCH_IS_CLEAN | (_lib.ALGO_OVERLAPPED_LAUNCHES if _overlapped[0] else 0)
 
 
 def stft_mcep_fusable(x, window, G, L, P, fft_length, M) -> bool:

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 125 /* 0.1.9: + dsa_mgcep_step_solve, dsa_mgcep_step_bwd_h, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
+#define DSA_VERSION 126 /* 0.2.0: + DSA_ALGO_OVERLAPPED_LAUNCHES; 0.1.9: + dsa_mgcep_step_solve, dsa_mgcep_step_bwd_h, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
@@ -84,6 +84,15 @@ enum { DSA_ALGO_AUTO = 0, DSA_ALGO_GENERIC = 1, DSA_ALGO_TUNED = 2 };
  * tuned backward reads them instead of recomputing its second forward chain -- and runs as the two-waves-per-SIMD kernel
  * (csrc/mcep_mfma_bwd2_f16.h: 1.56 -> 1.1-1.2 ms per 204 800 frames for 196 more bytes per frame and step).  Both calls of a pair must agree on the flag; the generic kernels ignore the extra room. */
 #define DSA_ALGO_HIST_HAS_RT 0x400
+/* OR-ed into `algo` of dsa_mcep_fwd / dsa_stft_mcep_fwd (0.2.0): the caller alternates consecutive, independent launches between TWO
+ * streams (each with its own `scratch`).  A launch whose tiles do not fill a whole number of rounds of the chip's 2 048 wave slots
+ * (204 800 frames = 12 800 tiles = 6.25 rounds) ends in a short round.  Without the flag that round runs one wave per SIMD on every
+ * CU (the fastest way to finish ONE launch: 0.8 of a full round's time, the rest of the chip idle).  With it the short round is
+ * packed onto the first ceil(rest / 8) workgroups at two waves per SIMD and every other workgroup EXITS when the shared tiles run
+ * out, so that the next launch's workgroups -- waiting on the other stream for LDS -- start on the freed CUs (measured: 0.5945 ->
+ * 0.5685 ms per 204 800 frames over 200 steps; the ideal is 6.25 rounds per launch instead of 6.8).  Same tiles, same arithmetic,
+ * same results bit for bit; a lone launch gets 0.2 of a round slower. */
+#define DSA_ALGO_OVERLAPPED_LAUNCHES 0x800
 
 int dsa_version(void);
 const char* dsa_last_error(void);

@@ -100,6 +100,33 @@ def test_packed_stft_against_the_one_launch_mgcep_step_and_the_48khz_solver(setu
         _cross(lambda: stft(x), 2, lambda: (fb(x), fl(x)), rounds=25)
 
 
+def test_overlapped_launches_flag_changes_the_tile_dealing_only(setup):
+    """DSA_ALGO_OVERLAPPED_LAUNCHES (ops.overlapped_launches, bench.py --streams 2): the short last round of a launch is packed onto a
+    few workgroups so that the next launch -- on the caller's other stream -- takes the freed CUs.  Which wave computes a tile never
+    changes the tile's arithmetic: alone, and alternating on two streams, every launch is bit-identical to the plain launch; batches
+    with a short round below and above half the wave slots, one that is a whole number of rounds, and one below one round."""
+    from diffsptk_amd import ops
+
+    x, stft, mcep, S = setup
+    fused = dsp.fuse(stft, mcep)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.no_grad():
+        for B in (1024, 900, 512 + 128 + 16, 100):   # 12 800 / 11 250 / 8 200 / 1 250 tiles on 2 048 slots
+            xb = x[:B]
+            ref, ref2 = fused(xb), mcep(S[:B])
+            with ops.overlapped_launches():
+                assert torch.equal(fused(xb), ref) and torch.equal(mcep(S[:B]), ref2)
+                torch.cuda.synchronize()
+                outs = []
+                for it in range(30):
+                    with torch.cuda.stream(sa if it % 2 == 0 else sb):
+                        outs.append(fused(xb) if it % 3 else mcep(S[:B]))
+                torch.cuda.synchronize()
+                for it, o in enumerate(outs):
+                    assert torch.equal(o, ref if it % 3 else ref2), (B, it)
+            assert torch.equal(fused(xb), ref)   # the switch is off again outside the context
+
+
 def test_chunked_overlap_on_alternating_streams_at_full_load(setup, monkeypatch):
     """dist.analyze_chunked_overlap(alternate_streams=True) itself at a size that fills the chip (the older test of that path runs
     600 frames): chunk c + 1's packed STFT on a side stream while chunk c's mel-cepstral kernel is in its Newton phase.  One GPU
