@@ -518,10 +518,11 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
     with torch.no_grad():
         for B48 in (64, 512):   # 64 utterances: one workgroup per CU, latency-bound; 512: the chip filled (round-4 review: report both)
             x48 = torch.randn(B48, 48000, device=dev)
-            for (fl, fp, nfft, m, a) in ((1200, 240, 2048, 49, 0.55), (1024, 256, 1024, 34, 0.55)):
+            for (fl, fp, nfft, m, a) in ((1200, 240, 2048, 49, 0.55), (1024, 256, 1024, 34, 0.55), (800, 200, 1024, 34, 0.55)):
                 st48 = dsp.STFT(fl, fp, nfft, device=dev)
                 mc48 = dsp.MelCepstralAnalysis(fft_length=nfft, cep_order=m, alpha=a, n_iter=N_ITER, device=dev)
                 X48 = st48(x48)
+                k48s = _lib.last_kernel()
                 mc48(X48)
                 k48 = _lib.last_kernel()
                 fr48 = X48.shape[0] * X48.shape[1]
@@ -529,16 +530,20 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
                 # per frame: mc0 = log X G, then per step S = mc D, rt = e E (float32 matrix products), the order-(M+1) elimination
                 flop48 = 2 * k_ * m1_ + N_ITER * (2 * k_ * m1_ + 2 * k_ * (2 * m + 1) + 2 * (m1_ ** 3) // 3)
                 t_s, t_m = gpu_time(lambda: st48(x48), n=5) * 1e-3, gpu_time(lambda: mc48(X48), n=5) * 1e-3
-                rows48[f"fft {nfft} order {m}" + ("" if B48 == 64 else f" ({B48} utterances)")] = {
+                by48 = 4 * fp + 4 * k_   # algorithmic bytes per frame of the STFT: frame_period new samples in, fft_length / 2 + 1 power values out
+                rows48[f"fft {nfft} order {m}" + ("" if fl != 800 else " frame 800/200") + ("" if B48 == 64 else f" ({B48} utterances)")] = {
                     "utterances": B48, "frames": fr48, "stft_ms": t_s * 1e3, "mcep_ms": t_m * 1e3, "mcep_us_per_1000_frames": t_m * 1e9 / fr48,
-                    "last_kernel": k48, "frames_per_s": fr48 / (t_s + t_m),
+                    "last_kernel": k48, "stft_kernel": k48s, "frames_per_s": fr48 / (t_s + t_m),
+                    "roofline_stft": {"kernel": k48s, "bound": "hbm", "bytes_per_frame": by48, "achieved": by48 * fr48 / t_s / 1e9,
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by48 * fr48 / t_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                      "avg_launch_ms": t_s * 1e3},
                     "roofline": {"bound": "f32 arithmetic (matrix / packed-vector peak)", "flop_per_frame": flop48,
                                  "achieved": flop48 * fr48 / t_m / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": flop48 * fr48 / t_m / 1e12 / FP32_PEAK_TFLOPS}}
                 del X48
             del x48
-    res["untuned_48khz"] = {"workload": "MelCepstralAnalysis at the 48 kHz set-ups, 64 and 512 utterances x 1 s, float32, forward, n_iter=10; "
-                                        "one workgroup per CU at 64 utterances (docs/DESIGN_LOG.md 3.41)", "rows": rows48,
+    res["untuned_48khz"] = {"workload": "STFT (csrc/stft_pk_big.h since round 6) + MelCepstralAnalysis at the 48 kHz set-ups, 64 and 512 utterances x 1 s, "
+                                        "float32, forward, n_iter=10; one workgroup per CU at 64 utterances (docs/DESIGN_LOG.md 3.41)", "rows": rows48,
                             "timing": "back-to-back calls (gpu_time)"}
     # ---- BASELINE configs[4] AS WRITTEN on one GPU: all 8 192 utterances through the one-launch step (what `--global-batch 8192`
     # times as the step at N = 1) ----

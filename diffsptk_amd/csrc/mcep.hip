@@ -343,7 +343,7 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
                   const StftIn* sti = nullptr, bool hist_has_rt = false, bool overlapped = false);
 int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, const void* window, const void* twiddle, double eps,
                         int n_iter, const void* G, const void* D, const void* E, const void* av, const void* images, void* scratch,
-                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean, bool hist_has_rt, bool overlapped);
+                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean, bool hist_has_rt, bool overlapped, int pad_mode);
 int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* av,
                   const void* images, void* scratch, void* gX, hipStream_t st, bool has_workspace = false, bool hist_has_rt = false);
 
@@ -456,6 +456,8 @@ DSA_EXPORT int dsa_stft_mcep_fwd(const void* x, int64_t B, int64_t T, int32_t L,
     const bool scratch_clean = (algo & DSA_ALGO_SCRATCH_IS_CLEAN) != 0;
     const bool hist_has_rt = (algo & DSA_ALGO_HIST_HAS_RT) != 0;
     const bool overlapped = (algo & DSA_ALGO_OVERLAPPED_LAUNCHES) != 0;
+    const int pad_mode = (algo >> 12) & 3;   // DSA_ALGO_PAD_MODE(m)
+    DSA_REQUIRE(pad_mode != DSA_PAD_REFLECT || (center ? L / 2 : L - 1) < T || L == 1, "stft_mcep: reflect padding needs pad < input length");
     const int64_t N = T <= 0 ? 0 : (T - 1) / P + 1;
     if (!(mcep_mfma_supported(nfft, M, dtype) && L == 400 && B * N < (int64_t(1) << 31) && T < (int64_t(1) << 31)))
         return fail(DSA_ERR_UNSUPPORTED, "stft_mcep: the fused launch covers float32, frame_length 400, fft_length 512, cep_order 24%s");
@@ -463,7 +465,7 @@ DSA_EXPORT int dsa_stft_mcep_fwd(const void* x, int64_t B, int64_t T, int32_t L,
     DSA_REQUIRE(x && window && twiddle && G && D && E && alpha_vec && mc, "stft_mcep: null pointer");
     if (B * N == 0) return DSA_OK;
     return stft_mcep_fused_fwd(x, B, T, P, center, window, twiddle, eps, n_iter, G, D, E, alpha_vec, images, scratch, mc, mc_hist,
-                               X_out, (hipStream_t)stream, scratch_clean, hist_has_rt, overlapped);
+                               X_out, (hipStream_t)stream, scratch_clean, hist_has_rt, overlapped, pad_mode);
 }
 
 DSA_EXPORT int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist, int64_t F, int32_t nfft,

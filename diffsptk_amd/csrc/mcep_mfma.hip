@@ -630,9 +630,13 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
     const int lds_bytes = (sti ? mh::h_lds_floats_fused(WAVES) : mh::h_lds_floats(WAVES)) * 4;
     static std::atomic<uint64_t> attr_devices{0}, attr_devices_fused{0}, attr_devices_rt{0}, attr_devices_fused_rt{0};
     const bool rt = hist_rt != nullptr;
-    const void* kern = sti ? (rt ? (const void*)mcep_mfma_fwd_kernel_h<WAVES, true, true> : (const void*)mcep_mfma_fwd_kernel_h<WAVES, true, false>)
-                           : (rt ? (const void*)mcep_mfma_fwd_kernel_h<WAVES, false, true> : (const void*)mcep_mfma_fwd_kernel_h<WAVES, false, false>);
-    if (!ensure_dynamic_lds(kern, lds_bytes, sti ? (rt ? attr_devices_fused_rt : attr_devices_fused) : (rt ? attr_devices_rt : attr_devices)))
+    const bool padm = sti && sti->pad_mode != (int)DSA_PAD_CONSTANT;   // reflect / replicate / circular: instantiations of their own
+    static std::atomic<uint64_t> attr_devices_padm{0}, attr_devices_padm_rt{0};
+    const void* kern = padm ? (rt ? (const void*)mcep_mfma_fwd_kernel_h<WAVES, true, true, true> : (const void*)mcep_mfma_fwd_kernel_h<WAVES, true, false, true>)
+                     : sti  ? (rt ? (const void*)mcep_mfma_fwd_kernel_h<WAVES, true, true> : (const void*)mcep_mfma_fwd_kernel_h<WAVES, true, false>)
+                            : (rt ? (const void*)mcep_mfma_fwd_kernel_h<WAVES, false, true> : (const void*)mcep_mfma_fwd_kernel_h<WAVES, false, false>);
+    if (!ensure_dynamic_lds(kern, lds_bytes, padm ? (rt ? attr_devices_padm_rt : attr_devices_padm)
+                                             : sti ? (rt ? attr_devices_fused_rt : attr_devices_fused) : (rt ? attr_devices_rt : attr_devices)))
         return fail(DSA_ERR_LAUNCH, "mcep_mfma: cannot reserve the LDS operand images%s");
     long ntiles16 = (long)((F + 15) / 16);
     long blocks = (ntiles16 + WAVES - 1) / WAVES;
@@ -655,6 +659,15 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
     hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES, FU, RT>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st, (const float*)(XPTR), \
                        (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E, (const float*)av, (float*)mc, (float*)hist,  \
                        ntiles16, tiles_shared, queue, (const _Float16*)images, STI, hist_rt, tail_wgs)
+    if (padm) {
+        if (rt) hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES, true, true, true>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st, (const float*)nullptr,
+                                   (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E, (const float*)av, (float*)mc, (float*)hist,
+                                   ntiles16, tiles_shared, queue, (const _Float16*)images, *sti, hist_rt, tail_wgs);
+        else hipLaunchKernelGGL((mcep_mfma_fwd_kernel_h<WAVES, true, false, true>), dim3((unsigned)grid), dim3(WAVES * 64), lds_bytes, st, (const float*)nullptr,
+                                (long)F, n_iter, (const float*)G, (const float*)D, (const float*)E, (const float*)av, (float*)mc, (float*)hist,
+                                ntiles16, tiles_shared, queue, (const _Float16*)images, *sti, hist_rt, tail_wgs);
+        return check_launch("stft512_mcep_fused_fwd");
+    }
     if (sti) {
         if (rt) DSA_MCEP_FWD_LAUNCH(true, true, nullptr, *sti);
         else DSA_MCEP_FWD_LAUNCH(true, false, nullptr, *sti);
@@ -669,7 +682,7 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
 // STFT (frame length 400, fft_length 512, power format, constant padding) -> MelCepstralAnalysis (cep_order 24) in one launch
 int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, const void* window, const void* twiddle, double eps,
                         int n_iter, const void* G, const void* D, const void* E, const void* av, const void* images, void* scratch,
-                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean, bool hist_has_rt, bool overlapped)
+                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean, bool hist_has_rt, bool overlapped, int pad_mode)
 {
     const int64_t N = T <= 0 ? 0 : (T - 1) / P + 1;
     StftIn sti;
@@ -682,6 +695,7 @@ int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, 
     sti.twiddle = (const float*)twiddle;
     sti.eps = (float)eps;
     sti.X_out = (float*)X_out;
+    sti.pad_mode = pad_mode;
     return mcep_mfma_fwd(nullptr, B * N, n_iter, G, D, E, av, images, scratch, mc, hist, st, scratch_clean, &sti, hist_has_rt, overlapped);
 }
 

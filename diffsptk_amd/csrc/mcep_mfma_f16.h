@@ -33,6 +33,7 @@ struct StftIn {
     const float* twiddle;  // (512, 2) = (cos, -sin)(2 pi m / 512)
     float eps;             // spec.py:173
     float* X_out;          // NULL, or (B N, 257): the power spectrogram as a side product (kept for the backward)
+    int pad_mode;          // frame.py:130-137 (DSA_PAD_*): what positions outside the utterance read
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -216,8 +217,9 @@ __device__ __forceinline__ void store_mc_row(float* row, int g, const float (&mc
     }
 }
 
-template <int WAVES, bool FUSED = false, bool HIST_RT = false>   // HIST_RT: also keep every step's rt row (its own instantiation: the
-                                                                 // plain kernels' code and register allocation are untouched)
+template <int WAVES, bool FUSED = false, bool HIST_RT = false, bool PADM = false>   // HIST_RT: also keep every step's rt row (its own
+                                                                 // instantiation: the plain kernels' code and register allocation are
+                                                                 // untouched); PADM: reflect / replicate / circular padding (likewise)
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) DSA_PK_TARGET void mcep_mfma_fwd_kernel_h(
     const float* __restrict__ X, long F, int n_iter, const float* __restrict__ G,
     const float* __restrict__ D, const float* __restrict__ E, const float* __restrict__ av,
@@ -367,7 +369,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) DSA_PK_TARGET void mcep_mfma
                     const v2f_u4* src = reinterpret_cast<const v2f_u4*>(xb + start + 2 * j);
 #pragma unroll
                     for (int m1 = 0; m1 < FU_NR; ++m1) raw[m1] = src[16 * m1];
-                } else {   // frames that reach over an end of their utterance: zeros outside (F.pad, constant mode).  Branch-free:
+                } else if (!PADM || sti.pad_mode == (int)DSA_PAD_CONSTANT) {
+                           // frames that reach over an end of their utterance: zeros outside (F.pad, constant mode).  Branch-free:
                            // clamped addresses, the out-of-range values selected away (32-bit: Tlen < 2^31, host-checked)
                     const int s00 = start + 2 * j, tl = (int)sti.Tlen;
 #pragma unroll
@@ -376,6 +379,28 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) DSA_PK_TARGET void mcep_mfma
                         const bool ok0 = (unsigned)s0 < (unsigned)tl, ok1 = (unsigned)s1 < (unsigned)tl;
                         const float a0 = xb[ok0 ? s0 : 0], a1 = xb[ok1 ? s1 : 0];
                         raw[m1] = v2f{ok0 ? a0 : 0.f, ok1 ? a1 : 0.f};
+                    }
+                } else {   // reflect / replicate / circular (round 6): the position outside reads the sample F.pad would have put there
+                    // (32-bit pad_src_index: Tlen < 2^31 and |position| < Tlen + 512, host-checked; positions past the frame's 400
+                    //  samples are selected away below, their addresses stay inside the row)
+                    const int s00 = start + 2 * j, tl = (int)sti.Tlen, md = sti.pad_mode;
+                    auto src = [&](int i) __attribute__((always_inline)) -> int {
+                        if ((unsigned)i < (unsigned)tl) return i;
+                        if (md == (int)DSA_PAD_REPLICATE) return i < 0 ? 0 : tl - 1;
+                        if (md == (int)DSA_PAD_CIRCULAR) {
+                            int q = i % tl;
+                            return q < 0 ? q + tl : q;
+                        }
+                        if (tl == 1) return 0;                       // reflect (frame.py:134-137 through F.pad)
+                        const int period = 2 * (tl - 1);
+                        int q = i % period;
+                        q = q < 0 ? q + period : q;
+                        return q < tl ? q : period - q;
+                    };
+#pragma unroll
+                    for (int m1 = 0; m1 < FU_NR; ++m1) {
+                        const int s0 = s00 + 32 * m1;
+                        raw[m1] = v2f{xb[src(s0)], xb[src(s0 + 1)]};
                     }
                 }
             };
@@ -606,9 +631,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) DSA_PK_TARGET void mcep_mfma
                 tile_next = ntiles16;
                 // (tail_wgs > 0, DSA_ALGO_OVERLAPPED_LAUNCHES: the short round on ALL waves of the first tail_wgs workgroups instead --
                 //  the other workgroups exit and the next launch, queued on the caller's second stream, takes their CUs.  Measured,
-                //  204 800 frames, 200 steps on two streams: 0.5945 -> 0.5685 ms per step; dealing ALL tiles statically by whole
-                //  workgroups -- so that a workgroup's eight waves end together -- was tried and is worse, 0.589: the shared queue's
-                //  balancing of uneven CUs is worth more than the clean exit)
+                //  204 800 frames, 200 steps on two streams: 0.5945 -> 0.5685 ms per step.  Two cleaner-looking dealings were built
+                //  and measured too, and neither gains anything (profiles/r06_overlapped_launches_ab.txt): ALL tiles dealt statically
+                //  by whole workgroups, 0.589; shared-queue tickets per workgroup ROUND of eight tiles -- claimed in LDS by the first
+                //  wave to need one, published one step into its tile -- so that a workgroup's waves leave together, 0.594)
                 if ((tail_wgs > 0 ? (int)blockIdx.x < tail_wgs : wave < WAVES / 2) && tiles_shared < ntiles16) {
                     if (lane == 0) nxt = atomicAdd(queue + 1, 1u);
                     tile_next = tiles_shared + (long)__builtin_amdgcn_readfirstlane((int)nxt);

@@ -1704,29 +1704,47 @@ static void stft512_launch(bool zmean, dim3 grid, int lds, hipStream_t st, const
         const char* e = getenv("DSA_STFT_PK");
         return e ? atoi(e) : 2;
     }();
-    if (use_pk && ABL == 0 && plain && !zmean && L == 400 && (P & 1) == 0 && 3 * P + 512 <= kFPW * kZS * 2) {
+    // (round 6: every pad mode -- the mode only changes what the passes that reach over an utterance's end read)
+    const bool plain_any_pad = !use_floor && fmt == DSA_SPEC_POWER;
+    if (use_pk && ABL == 0 && plain_any_pad && !zmean && L == 400 && (P & 1) == 0 && 3 * P + 512 <= kFPW * kZS * 2) {
         // a wave walks a RUN of consecutive passes (their shared samples come from its CU's cache, not from memory twice);
         // DSA_STFT_RUN=0: the round-robin order of rounds 1-4 (A/B)
         static const int run_env = [] { const char* e = getenv("DSA_STFT_RUN"); return e ? atoi(e) : 0; }();
         const int run_len = run_env;
         if (use_pk == 1)   // staged 16-byte stores (A/B)
             hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, false>), g2, dim3(128), lds2, st, x, T, N, L, P, left, w, tw, eps, y,
-                               total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0, run_len);
+                               total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0, run_len, mode);
 #define DSA_PK_XCD(ABLV)                                                                                              \
     hipLaunchKernelGGL((stft512_fwd_pk_kernel<ABLV, 400, true>), g2, dim3(128), lds2, st, x, T, N, L, P, left, w, tw, eps, y, \
-                       total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0, 0)
+                       total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0, 0, mode)
         else if (use_pk == 3) DSA_PK_XCD(1024);   // experiments (A/B): XCD-chunked workgroup order, C = 4 / 8 / 2, XCD-contiguous
         else if (use_pk == 4) DSA_PK_XCD(4096);
         else if (use_pk == 5) DSA_PK_XCD(2048);
         else if (use_pk == 6) DSA_PK_XCD(256);
-        else if (use_pk == 7)   // the stretch fetched two passes ahead (two register sets, window table in LDS, four-wave workgroups)
+        else if (use_pk == 8)   // four-wave workgroups: four adjacent passes per workgroup
+            hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, true, 0, false, 4>), dim3((grid.x + 3) / 4), dim3(256),
+                               4 * kFPW * kZS * 8 + 256 * 8 + 64, st, x, T, N, L, P, left, w, tw, eps, y, total_chunks,
+                               chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0, run_len, mode);
+        else if (use_pk == 9) {   // eight-wave workgroups
+            static std::atomic<uint64_t> a9{0};
+            ensure_dynamic_lds(reinterpret_cast<const void*>(&stft512_fwd_pk_kernel<0, 400, true, 0, false, 8>), 8 * kFPW * kZS * 8 + 256 * 8 + 64, a9);
+            hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, true, 0, false, 8>), dim3((grid.x + 7) / 8), dim3(512),
+                               8 * kFPW * kZS * 8 + 256 * 8 + 64, st, x, T, N, L, P, left, w, tw, eps, y, total_chunks,
+                               chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0, run_len, mode);
+        } else if (use_pk == 10) {   // sixteen-wave workgroups: a CU's whole complement of waves on sixteen adjacent passes
+            static std::atomic<uint64_t> a10{0};
+            ensure_dynamic_lds(reinterpret_cast<const void*>(&stft512_fwd_pk_kernel<0, 400, true, 0, false, 16>), 16 * kFPW * kZS * 8 + 256 * 8 + 64, a10);
+            hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, true, 0, false, 16>), dim3((grid.x + 15) / 16), dim3(1024),
+                               16 * kFPW * kZS * 8 + 256 * 8 + 64, st, x, T, N, L, P, left, w, tw, eps, y, total_chunks,
+                               chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0, run_len, mode);
+        } else if (use_pk == 7)   // the stretch fetched two passes ahead (two register sets, window table in LDS, four-wave workgroups)
             hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, true, 0, true>), dim3((grid.x + 3) / 4), dim3(256),
                                4 * kFPW * kZS * 8 + 256 * 8 + 16 * 13 * 8 + 64, st, x, T, N, L, P, left, w, tw, eps, y, total_chunks,
-                               chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0, run_len);
+                               chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0, run_len, mode);
 #undef DSA_PK_XCD
         else               // 8-byte stores straight from the split's registers (default)
             hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, true>), g2, dim3(128), lds2, st, x, T, N, L, P, left, w, tw, eps, y,
-                               total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0, run_len);
+                               total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0, run_len, mode);
         return;
     }
 #define DSA_STFT_FWD_LAUNCH(ZM, PL, LCV)                                                                                 \
@@ -2248,7 +2266,7 @@ DSA_EXPORT int dsa_stft_fbank_fwd(const void* x, int64_t B, int64_t T, int32_t L
 #define DSA_FB_LAUNCH(MODE)                                                                                                  \
     hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, true, MODE>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, st,     \
                        (const float*)x, (long)T, (long)N, L, P, left, (const float*)w, (const float*)twiddle, (float)eps,      \
-                       (float*)y, total_chunks, chunks_per_utt, (const float*)plan, (float)floor, (float)gamma, C, 0)
+                       (float*)y, total_chunks, chunks_per_utt, (const float*)plan, (float)floor, (float)gamma, C, 0, (int)DSA_PAD_CONSTANT)
     if (use_power) DSA_FB_LAUNCH(1);
     else DSA_FB_LAUNCH(2);
 #undef DSA_FB_LAUNCH

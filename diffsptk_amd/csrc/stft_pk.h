@@ -57,13 +57,17 @@ __device__ unsigned long long g_stft_pk_stamps[64];
 __device__ __attribute__((noinline)) float fb_slow_log(float v) { return dsa_log(v); }
 __device__ __attribute__((noinline)) float fb_slow_glog(float v, float gamma) { return (dsa_pow(v, gamma) - 1.f) / gamma; }
 
-template <int ABL, int LC, bool DIRECT = false, int FBM = 0, bool PF2 = false>   // FBM: 0 spectrum out, 1 filter bank of the power values, 2 of the amplitudes;
+template <int ABL, int LC, bool DIRECT = false, int FBM = 0, bool PF2 = false, int WPBX = 0>   // FBM: 0 spectrum out, 1 filter bank of the power values, 2 of the amplitudes;
                                                                             // PF2: the stretch fetched TWO passes ahead (two register sets, window from LDS)
-__global__ __launch_bounds__((FBM || PF2) ? 256 : 128, 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
+                                                                            // WPBX: waves per workgroup (0: 2, or 4 with FBM / PF2) -- the waves of a workgroup take ADJACENT
+                                                                            // passes, which share L - P of their samples: on one CU the second fetch of those is a cache hit
+__global__ __launch_bounds__(WPBX ? WPBX * 64 : ((FBM || PF2) ? 256 : 128), WPBX ? 16 / WPBX : 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
     const float* __restrict__ x, long Tlen, long N, int L, int P, int left, const float* __restrict__ w,
     const float* __restrict__ twiddle, float eps, float* __restrict__ y, long total_chunks, int chunks_per_utt,
-    const float* __restrict__ fbt, float fb_floor, float fb_gamma, int fbC, int run_len)
+    const float* __restrict__ fbt, float fb_floor, float fb_gamma, int fbC, int run_len, int pad_mode)
 {
+    // pad_mode (round 6; frame.py:130-137): reflect / replicate / circular padding only changes which sample a position outside the
+    // utterance reads -- the passes that reach over an end (stage_sync's element-wise path); interior passes never see it
     // run_len > 1 (round 5): a wave takes RUNS of run_len consecutive passes instead of every (number of waves)-th pass.  Consecutive
     // passes of an utterance share L - P of their 3 P + L samples; dealt round-robin those were fetched by two waves on two XCDs at
     // two times -- 1.73 x the waveform's bytes from memory (FETCH_SIZE) -- while a wave that walks its own run finds them in its
@@ -73,7 +77,7 @@ __global__ __launch_bounds__((FBM || PF2) ? 256 : 128, 4) DSA_PK_TARGET void stf
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr bool WL = FB || PF2;    // window pairs from a shared LDS table instead of 26 registers per lane
     static_assert(!PF2 || (DIRECT && LC > 0 && !FB), "PF2 builds on the register-direct plain kernel");
-    constexpr int WPB = WL ? 4 : 2;   // waves per workgroup (they share the twiddle / window tables, nothing else)
+    constexpr int WPB = WPBX ? WPBX : (WL ? 4 : 2);   // waves per workgroup (they share the twiddle / window tables, nothing else)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     v2f* zbuf = reinterpret_cast<v2f*>(smem_raw) + wv * kFPW * kZS;
     float* io_buf = reinterpret_cast<float*>(zbuf);  // aliases zbuf: stretch -> tiles -> spectra -> staged output
@@ -153,7 +157,7 @@ __global__ __launch_bounds__((FBM || PF2) ? 256 : 128, 4) DSA_PK_TARGET void stf
             }
             for (int s = (n4 << 2) + lane; s < need; s += 64) io_buf[s] = xb[g0 + s];
         } else {
-            for (int s = lane; s < need; s += 64) io_buf[s] = load_padded(xb, g0 + s, Tlen, (int)DSA_PAD_CONSTANT);
+            for (int s = lane; s < need; s += 64) io_buf[s] = load_padded(xb, g0 + s, Tlen, pad_mode);
         }
     };
     // Software pipeline over passes.  At the END of pass n the stretch of pass n+1 -- fetched into registers during

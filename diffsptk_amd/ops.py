@@ -1092,7 +1092,7 @@ class StftMcepFn(torch.autograd.Function):
     and the Newton history behind, and the backward is the two stages' own (dsa_mcep_bwd, then dsa_stft_bwd)."""
 
     @staticmethod
-    def forward(ctx, x, window, twiddle, G, D, E, av, L, P, fft_length, center, eps, M, n_iter):
+    def forward(ctx, x, window, twiddle, G, D, E, av, L, P, fft_length, center, eps, M, n_iter, mode="constant"):
         _require_device(x, window, twiddle, G, D, E, av)
         _same_dtype(x, window, twiddle, G, D, E, av)
         xc, wc = x.contiguous(), window.contiguous()
@@ -1114,11 +1114,12 @@ class StftMcepFn(torch.autograd.Function):
             flag |= _lib.ALGO_HIST_HAS_RT
         with torch.cuda.device(x.device):
             _call("dsa_stft_mcep_fwd", _p(xc), B, T, L, P, fft_length, _p(wc), _p(twiddle), int(center), float(eps), M, n_iter,
-                  _p(G), _p(D), _p(E), _p(av), _dtype_code(xc), _lib.ALGO_AUTO | flag, _p(images), _p(scratch), _p(mc), _p(hist),
-                  _p(X), _stream())
+                  _p(G), _p(D), _p(E), _p(av), _dtype_code(xc), _lib.ALGO_AUTO | flag | (pad_mode_code(mode) << 12),   # DSA_ALGO_PAD_MODE
+                  _p(images), _p(scratch), _p(mc), _p(hist), _p(X), _stream())
         if need_grad:
             ctx.save_for_backward(xc, wc, twiddle, X, hist, G, D, E, av)
         ctx.cfg = (L, P, fft_length, center, eps, M, n_iter)
+        ctx.mode = mode
         ctx.images = images
         ctx.with_rt = with_rt
         return mc
@@ -1141,8 +1142,8 @@ class StftMcepFn(torch.autograd.Function):
                   _dtype_code(X), _lib.ALGO_AUTO | _lib.ALGO_SCRATCH_HAS_WORKSPACE | (_lib.ALGO_HIST_HAS_RT if ctx.with_rt else 0),
                   _p(ctx.images), _p(scratch), _p(gX), _stream())
             _call("dsa_stft_bwd", _p(gX), _p(xc), B, T, L, P, fft_length, _p(wc), _p(twiddle), int(center), 0,
-                  pad_mode_code("constant"), float(eps), 0, 0.0, 3, _dtype_code(xc), _lib.ALGO_AUTO, _p(gx), None, _stream())
-        return (gx,) + (None,) * 13
+                  pad_mode_code(ctx.mode), float(eps), 0, 0.0, 3, _dtype_code(xc), _lib.ALGO_AUTO, _p(gx), None, _stream())
+        return (gx,) + (None,) * 14
 
 
 class McepFn(torch.autograd.Function):

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 126 /* 0.2.0: + DSA_ALGO_OVERLAPPED_LAUNCHES; 0.1.9: + dsa_mgcep_step_solve, dsa_mgcep_step_bwd_h, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
+#define DSA_VERSION 126 /* 0.2.0: + DSA_ALGO_OVERLAPPED_LAUNCHES, DSA_ALGO_PAD_MODE, packed STFT kernels for fft_length 1024 / 2048 and for every pad mode at 512; 0.1.9: + dsa_mgcep_step_solve, dsa_mgcep_step_bwd_h, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
@@ -93,6 +93,9 @@ enum { DSA_ALGO_AUTO = 0, DSA_ALGO_GENERIC = 1, DSA_ALGO_TUNED = 2 };
  * 0.5685 ms per 204 800 frames over 200 steps; the ideal is 6.25 rounds per launch instead of 6.8).  Same tiles, same arithmetic,
  * same results bit for bit; a lone launch gets 0.2 of a round slower. */
 #define DSA_ALGO_OVERLAPPED_LAUNCHES 0x800
+/* OR-ed into `algo` of dsa_stft_mcep_fwd (0.2.0): the padding mode of Frame (frame.py:130-137; DSA_PAD_*, 0 = constant) for the
+ * samples a frame reads outside its utterance -- the one-launch step then covers ShortTimeFourierTransform(mode=...) too. */
+#define DSA_ALGO_PAD_MODE(m) (((m) & 3) << 12)
 
 int dsa_version(void);
 const char* dsa_last_error(void);

@@ -125,6 +125,48 @@ def test_config5_whole_batch_8192_on_one_gpu():
     np.testing.assert_allclose(host(mc1[sel]), ref, **MC32)
 
 
+def test_speech_like_batch_at_bench_size():
+    """"also run a speech-like input (data.wav tiled) because conditioning and Newton convergence differ".  The batch
+    bench.py times as `speech_like` (bench.speech_like_batch: the reference's test recording repeated end to end, utterance u
+    starting 997 u samples in -- 1 024 different alignments, frames of near-silence, onsets and voiced stretches at every tile
+    position) through the one-launch step and the two kernels at the BENCH size, against the C oracle in float64 on every eighth
+    utterance (25 600 frames), with the float32 tolerance of the goldens; Newton has converged (an eleventh step moves < 1e-4)."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        import bench
+    finally:
+        sys.path.pop(0)
+    B = 1024
+    xd = bench.speech_like_batch(B, torch.device(DEV))
+    assert xd.shape == (B, 16000) and float(xd.abs().max()) <= 1.0
+    stft, mcep = _modules()
+    fused = dsp.fuse(stft, mcep)
+    with torch.no_grad():
+        X = stft(xd)
+        mc2 = mcep(X)
+        mc1 = fused(xd)
+        assert fused.last_path == "fused" and _lib.last_kernel() == "stft512_mcep_fused_fwd"
+        assert bool(torch.isfinite(mc1).all()) and bool(torch.isfinite(mc2).all())
+        assert float((mc1 - mc2).abs().max()) <= 1e-6 * float(mc2.abs().max())
+        mc11 = F.mcep(X[:64], 24, 0.42, 11)
+        assert float((mc11 - mc2[:64]).abs().max()) < 1e-4
+    sel = list(range(0, B, 8))
+    x64 = xd[sel].double().cpu().numpy()
+    X_ref = O.stft(x64, 400, 80, 512)
+    err = np.abs(host(X)[sel] - X_ref) / X_ref.max(-1, keepdims=True)
+    assert err.max() < 2e-6, err.max()
+    ref = O.mcep(X_ref, 24, 0.42, 10)
+    np.testing.assert_allclose(host(mc1)[sel], ref, **MC32)
+    np.testing.assert_allclose(host(mc2)[sel], ref, **MC32)
+    # the dynamic range this input brings (what white noise does not): frame energies spread over > 50 dB
+    e = X.sum(-1)
+    assert float(10 * torch.log10(e.max() / e.min())) > 50
+
+
 def test_config5_eight_way_split_equals_whole_batch():
     """The 8-GPU run shards the batch contiguously (diffsptk_amd/dist.py:shard_bounds) and all-gathers the
     features; every rank's shard computed on its own must reproduce the rows of the whole-batch result bit for

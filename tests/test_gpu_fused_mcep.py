@@ -28,7 +28,7 @@ def _modules(P=80, center=True, n_iter=10, **kw):
     return stft, mcep, dsp.fuse(stft, mcep)
 
 
-def _fused_with_spectrogram(stft, mcep, x):
+def _fused_with_spectrogram(stft, mcep, x, pad_mode=0):
     """the raw launch with both side products (what the autograd Function keeps for the backward)"""
     T = x.size(-1)
     B = x.numel() // T
@@ -40,7 +40,7 @@ def _fused_with_spectrogram(stft, mcep, x):
     scratch = torch.zeros(_lib.SCRATCH_BYTES, dtype=torch.uint8, device=DEV)
     ops._call("dsa_stft_mcep_fwd", x.data_ptr(), B, T, 400, stft.frame_period, 512, stft.window.data_ptr(), stft.twiddle.data_ptr(),
               int(stft.center), float(stft.eps), 24, mcep.n_iter, mcep.G.data_ptr(), mcep.D.data_ptr(), mcep.E.data_ptr(),
-              mcep.alpha_vector.data_ptr(), _lib.F32, _lib.ALGO_AUTO, images.data_ptr(), scratch.data_ptr(), mc.data_ptr(),
+              mcep.alpha_vector.data_ptr(), _lib.F32, _lib.ALGO_AUTO | (pad_mode << 12), images.data_ptr(), scratch.data_ptr(), mc.data_ptr(),
               hist.data_ptr(), X.data_ptr(), ops._stream())
     assert _lib.last_kernel() == "stft512_mcep_fused_fwd"
     return mc, X, hist
@@ -108,6 +108,42 @@ def test_fused_gradient_equals_the_two_stage_gradient():
     assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * float(xb.grad.abs().max())
 
 
+@pytest.mark.parametrize("mode", ["reflect", "replicate", "circular"])
+@pytest.mark.parametrize("B,T,P,center", [(3, 16000, 80, True), (2, 15997, 80, True), (5, 1234, 80, True), (2, 4000, 160, True),
+                                          (3, 2000, 50, False), (4, 401, 80, True), (2, 640, 80, False)])
+def test_fused_pad_modes_equal_the_two_kernels_and_the_oracle(mode, B, T, P, center):
+    """ShortTimeFourierTransform(mode=...) (stft.py:86-104, frame.py:130-137) through the ONE launch (round 6; DSA_ALGO_PAD_MODE):
+    `last_path == "fused"`, the spectrogram side product bit-identical to the two-kernel path's -- which runs the packed kernel
+    for every pad mode now --, the mel-cepstra at 1e-6 of the two-kernel result and at the goldens' tolerance against the float64
+    oracle, and the gradient equal to the two-stage gradient."""
+    x = torch.randn(B, T, generator=torch.Generator().manual_seed(B * 11 + T)).to(DEV)
+    stft, mcep, fused = _modules(P, center, mode=mode)
+    with torch.no_grad():
+        X2 = stft(x)
+        k2 = _lib.last_kernel()
+        mc2 = mcep(X2)
+        mc1 = fused(x)
+    assert fused.last_path == "fused" and _lib.last_kernel() == "stft512_mcep_fused_fwd"
+    assert float((mc1 - mc2).abs().max()) <= 1e-6 * float(mc2.abs().max())
+    mcf, Xf, _ = _fused_with_spectrogram(stft, mcep, x, {"reflect": 1, "replicate": 2, "circular": 3}[mode])
+    assert torch.equal(mcf, mc1)
+    if P % 2 == 0:
+        assert k2 == "stft512_fwd" and torch.equal(Xf, X2)     # the packed kernel on both sides: bit for bit
+    else:
+        assert float(((Xf - X2).abs() / X2.amax(-1, keepdim=True)).max()) < 2e-6
+    X_ref = O.stft(host(x).astype(np.float64), 400, P, 512, center=center, mode=mode)
+    err = np.abs(host(X2) - X_ref) / X_ref.max(-1, keepdims=True)
+    assert err.max() < 2e-6, err.max()
+    np.testing.assert_allclose(host(mc1), O.mcep(X_ref, 24, 0.42, 10), **MC32)
+    w = torch.randn(mc1.shape, generator=torch.Generator().manual_seed(3)).to(DEV)
+    xa = x.clone().requires_grad_(True)
+    (fused(xa) * w).sum().backward()
+    assert fused.last_path == "fused"
+    xb = x.clone().requires_grad_(True)
+    (mcep(stft(xb)) * w).sum().backward()
+    assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * float(xb.grad.abs().max())
+
+
 def test_fused_contains_non_finite_samples_to_their_frames():
     x = torch.randn(2, 4000, generator=torch.Generator().manual_seed(9))
     x[0, 1000] = float("nan")
@@ -124,7 +160,7 @@ def test_fused_contains_non_finite_samples_to_their_frames():
 
 def test_fused_routes_other_configurations_to_the_two_modules():
     x = torch.randn(2, 4000, generator=torch.Generator().manual_seed(1)).to(DEV)
-    for kw in (dict(zmean=True), dict(mode="reflect"), dict(out_format="magnitude"), dict(relative_floor=-80.0)):
+    for kw in (dict(zmean=True), dict(out_format="magnitude"), dict(relative_floor=-80.0)):
         stft = dsp.STFT(400, 80, 512, device=DEV, **kw)
         mcep = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=2, device=DEV)
         f = dsp.fuse(stft, mcep)
