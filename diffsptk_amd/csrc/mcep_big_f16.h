@@ -1,0 +1,382 @@
+// Round 6: ALL Newton steps of MelCepstralAnalysis (mcep.py:208-222) at the 48 kHz set-ups (fft_length 2048 / order 49 and every
+// order 36 .. 55 the octet-layout solver covers) in ONE persistent launch (included by mcep_mfma.hip).
+//
+// Rounds 4-5 ran a step as two launches -- dsa_mcep_newton_resid_h (rt = exp(logx - 2 mc D) E on binary16 splits, mcep_resid_f16.h)
+// and dsa_mcep_newton_update (the batched Toeplitz-plus-Hankel solve, thsolve_tq.h) -- with rt:(F, 2 M + 1) and mc:(F, M + 1)
+// going through memory between them: 22 launches per analysis; at 12 800 frames (one workgroup per CU) the kernels take 37 + 35 us
+// of a 92 us step, the rest is the boundary between two dependent launches, twenty times.  A frame's iteration depends on the
+// frame alone, so here a wave keeps its 16 frames for all steps:
+//   * the step's products exactly as mcep_resid_h_kernel computes them (same images, same stages of 32 bins staged through LDS for
+//     the workgroup's four waves, same splits and scales: rt is bit-identical);
+//   * EIGHT waves per workgroup, 64 frames: waves w and w + 4 share 16 frames.  In the products they take alternate stages (the
+//     double-buffered staging holds two consecutive stages anyway) -- a lone wave's stage is a chain of dependent matrix products and
+//     an exp, so two waves halve the phase; the two partial sums meet in LDS (even stages + odd stages: a fixed order, but not the
+//     stage-by-stage order of mcep_resid_h_kernel -- rt differs from the two-launch step in the last bit);
+//   * each of the two then solves 8 of the 16 systems: rt rows -> the solver's LDS records (q window, p window, right-hand side
+//     rt[k] - alpha_vec[k]), the octet layout of thsolve_octn_kernel with its own elimination and back substitution templates, incl.
+//     the pivoted re-solve of a system whose elimination meets a bad pivot;
+//   * the update mc += x lands in the pair's LDS copy of mc, from which the next step's first-chain operands are split.
+// One workgroup per CU (two waves per SIMD, 256 registers: the solver's spills of the stand-alone kernel come with it), 105 KB of LDS
+// (the records and the parked rows alias the four staging buffers).
+// First cut of the round (four waves, each solving its 16 systems in two rounds): correct and bit-identical to the two-launch step,
+// but 1.68 ms per 12 800 frames against 0.93 -- a lone wave per SIMD ran the two eliminations one after the other.
+#pragma once
+
+#include "thsolve_tq.h"
+
+namespace dsa {
+
+namespace mbg {
+constexpr int PAIRS = 4;    // 16-frame groups per workgroup
+constexpr int WAVES = 8;    // two waves per group
+template <int NG>
+struct Geo {
+    using O = tq::Oct<NG>;
+    static constexpr int NCP = O::NCP;
+    static constexpr int CN = 4 * NG - 1;
+    static constexpr int QW = 4 * NG + 8 * NCP - 1;
+    static constexpr int PO = QW + 7;
+    static constexpr int RO = PO + 8 * NCP;
+    static constexpr int REC = ((RO + 4 * NG - 8 + 31) / 32) * 32 + 8;   // as thsolve_octn_kernel: stride 8 (mod 32)
+    static constexpr int MS = 4 * NG + 4;                                 // row stride of the LDS copy of mc (floats, 16-byte rows)
+};
+constexpr int rts(int nt) { return 16 * nt + 4; }   // row stride of the rt rows parked in LDS between the products and the solve (floats)
+// the region the four staging buffers (two stage pairs, SH halves per stage = 2 SH floats together) share with the parked rt rows of
+// the four groups and the eight waves' records -- all of them idle while the other is in use
+template <int KS1, int NT, int NG>
+constexpr int stage_floats()
+{
+    constexpr int sh = 2 * mrh::stage_halves(KS1, NT), solve = PAIRS * 16 * rts(NT) + WAVES * 8 * Geo<NG>::REC;
+    return sh > solve ? sh : solve;
+}
+template <int KS1, int NT, int NG>
+constexpr int lds_floats()
+{
+    return stage_floats<KS1, NT, NG>() + PAIRS * 16 * Geo<NG>::MS + 64;
+}
+}  // namespace mbg
+
+namespace mbg {
+typedef __attribute__((address_space(3))) float lds_f;
+}
+// Eight systems of the records `wl` solved in the octet layout (thsolve_octn_kernel's construction, elimination, back substitution
+// and pivoted re-solve), the solutions ADDED to the eight rows `mrow8` of the LDS copy of mc (mcep.py:222).
+template <int NG, int NMIN>
+__device__ __attribute__((noinline)) void big_solve8(mbg::lds_f* wl, mbg::lds_f* mrow8, int M1)
+{
+    using G = mbg::Geo<NG>;
+    using O = tq::Oct<NG>;
+    constexpr int NCP = G::NCP, CN = G::CN, PO = G::PO, RO = G::RO, REC = G::REC, MS = G::MS;
+    constexpr int CPN = (NG - 1) >> 1, HN = (NG - 1) & 1;   // where column CN (the right-hand side) lives
+    const int ln = threadIdx.x & 63;
+    const int sy = ln >> 3, h = (ln >> 2) & 1, gs = ln & 3;
+    const int view = sy * REC + 4 * h + gs;
+    const mbg::lds_f* rs = wl + sy * REC + RO;
+    f32x4 a[O::N];
+#pragma unroll
+    for (int rg = 0; rg < NG; ++rg) {
+        const mbg::lds_f* qs = wl + view;
+        const mbg::lds_f* pw = qs + PO;
+#pragma unroll
+        for (int cp = rg >> 1; cp < NCP; ++cp) {
+            const bool below = 2 * cp < rg;
+            const bool cin = 8 * cp + 7 < NMIN || 8 * cp + 4 * h + gs < M1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 4 * rg + i;
+                float v = pw[4 * (2 * cp - rg) - i] + qs[4 * (rg + 2 * cp) + i];
+                if (8 * cp + 7 >= NMIN) v = cin ? v : 0.f;
+                if (below) v = h == 1 ? v : 0.f;
+                if (2 * cp == rg || 2 * cp + 1 == rg) {
+                    if (row >= NMIN && row < CN) v = (h == (rg & 1) && gs == i && row >= M1) ? 1.f : v;
+                }
+                if (cp == CPN) v = (h == HN && gs == 3) ? rs[row] : v;
+                a[O::at(rg, cp)][i] = v;
+            }
+        }
+    }
+    bool bad = false;
+    tq::oct_elim_all<NG>(a, gs, bad, std::make_integer_sequence<int, CN>{});
+    float xq[NCP];
+#pragma unroll
+    for (int c = 0; c < NCP; ++c) xq[c] = (c == CPN && h == HN && gs == 3) ? -1.f : 0.f;
+    tq::oct_backsub_all<NG>(a, xq, gs, h, std::make_integer_sequence<int, NG>{});
+    mbg::lds_f* mrow = mrow8 + sy * MS;
+#pragma unroll
+    for (int c = 0; c < NCP; ++c) {
+        const int col = 8 * c + 4 * h + gs;
+        if (col < M1 && !bad) mrow[col] += xq[c];                                // mcep.py:222
+    }
+    unsigned long long marked = __ballot(bad && (ln & 7) == 0);
+    while (marked) {   // uniform; normally empty: the whole wave re-solves the system with row pivoting (th_solve_reg.h)
+        const int bl_ = __builtin_ctzll(marked);
+        marked &= marked - 1;
+        const int sb = bl_ >> 3;
+        const float* qs2 = (const float*)(wl + sb * REC);   // (flat view of the LDS record for the cold path)
+        const float* ps2 = qs2 + PO;
+        const float rhs = ln < M1 ? qs2[RO + ln] : 0.f;
+        int col;
+        float sol;
+        th_solve_reg<float, CN <= 48 ? 48 : 64>(ps2, qs2, rhs, M1, ln, col, sol);
+        if (ln < M1) mrow8[sb * MS + col] += sol;
+    }
+}
+
+template <int KS1, int NT, int NG, int NMIN>
+__global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __restrict__ logx, long F, int K, const float* __restrict__ mc_in,
+                                                                 int M1, const _Float16* __restrict__ img, const float* __restrict__ av,
+                                                                 int n_iter, float* __restrict__ mc_out)
+{
+    using namespace mrh;
+    using G = mbg::Geo<NG>;
+    using O = tq::Oct<NG>;
+    constexpr int NTH = mbg::WAVES * 64;
+    constexpr int SH = stage_halves(KS1, NT);
+    constexpr int PIECES = SH / 8;
+    constexpr int PER = (2 * PIECES + NTH - 1) / NTH;      // a stage PAIR per staging step
+    constexpr int NCP = G::NCP, CN = G::CN, PO = G::PO, RO = G::RO, REC = G::REC, MS = G::MS;
+    constexpr int CPN = (NG - 1) >> 1, HN = (NG - 1) & 1;   // where column CN (the right-hand side) lives
+    constexpr int RTS = mbg::rts(NT);
+    extern __shared__ __attribute__((aligned(16))) float smem_big[];
+    _Float16* sbuf0 = reinterpret_cast<_Float16*>(smem_big);   // [2 sets][2 stages of a pair][SH halves] = 2 SH floats
+    float* recs_all = smem_big + mbg::PAIRS * 16 * RTS;          // the records and the parked rt rows live INSIDE the staging buffers
+    float* mcs_all = smem_big + mbg::stage_floats<KS1, NT, NG>();
+    float* avs = mcs_all + mbg::PAIRS * 16 * MS;            // [64]: alpha_vec, zero-padded
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave & 3, hsel = wave >> 2;             // the 16-frame group; which half of its stages / systems this wave takes
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int nstage = (K + 31) / 32;
+    const int N = 2 * M1 - 1;
+    float* mcs = mcs_all + pair * 16 * MS;
+    float* wl = recs_all + wave * 8 * REC;                   // this wave's eight records
+    float* park = smem_big + pair * 16 * RTS;                // the group's rt rows (inside the staging buffers, idle during the solve)
+    const f32x4* img4 = reinterpret_cast<const f32x4*>(img);
+    if (tid < 64) avs[tid] = tid < M1 ? av[tid] : 0.f;
+    const long ntiles = (F + 63) / 64;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long t16 = (tile * mbg::PAIRS + pair) * 16;    // uniform
+        const bool tile_ok = t16 < F;
+        const long tb = tile_ok ? t16 : 0;
+        const int rows_here = (int)((F - tb < 16) ? F - tb : 16);
+        __syncthreads();   // the previous tile's result rows have left the LDS copy of mc
+        // ---- the group's 16 rows of mc into LDS, eight per wave (rows past the batch repeat the last one: finite, never stored) ----
+        for (int e = (tid & 63); e < 8 * MS; e += 64) {
+            const int row = 8 * hsel + e / MS, col = e % MS;
+            const int rr = row < rows_here ? row : rows_here - 1;
+            mcs[row * MS + col] = col < M1 ? mc_in[(tb + rr) * (long)M1 + col] : 0.f;
+        }
+#ifdef DSA_BIG_STAMPS   // (measurement builds: cycle stamps of wave 0 / wave 4 of workgroup 0 in step 2, returned in mc_out's first rows)
+        long long tsv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define BIG_STAMP(i) do { if (step == 2) tsv[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BIG_STAMP(i)
+#endif
+        for (int step = 0; step < n_iter; ++step) {
+            BIG_STAMP(0);
+            __syncthreads();   // every wave has left the previous step's solve: mc is updated, the staging buffers are free again
+            // everything derived from the lane index is derived again per step from an opaque copy: hoisted out of the step loop such
+            // values live across the elimination, go to scratch there and come back through scratch loads inside the stage loop
+            int tid_s = threadIdx.x;
+            asm volatile("" : "+v"(tid_s));
+            const int tid = tid_s, lane_s = tid_s & 63;
+            const int lane = lane_s, n = lane_s & 15, g = lane_s >> 4;
+            const int rn = n < rows_here ? n : rows_here - 1;
+            const float* xt = logx + tb * (long)K + (long)rn * K;
+            // ================= rt = exp(logx - 2 mc D) E: the stage body of mcep_resid_h_kernel, two stages per barrier =================
+            // A stage PAIR (2 i, 2 i + 1) is staged together (four buffers: the pair in use, the pair being written); between two
+            // barriers the group's first wave runs the even stage, its second wave the odd one -- concurrently.  (First 8-wave cut:
+            // one stage per barrier, the waves alternating -- a stage's arithmetic never overlapped the next one's: 1.05 ms.)
+            const int npair = (nstage + 1) / 2;
+            f32x4 st0[PER];   // ONE register set: a pair's images are requested one pair ahead (two sets ahead did not fit 256 registers
+                              // next to the hoisted image reads of a stage: the staged pieces went through scratch, 154 k cycles per step)
+            auto fetch = [&](int ip, f32x4 (&sv)[PER]) __attribute__((always_inline)) {   // stages 2 ip, 2 ip + 1: 2 PIECES pieces
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const int p = tid + NTH * q;
+                    // (unconditional, from a clamped index: a conditional element assignment kept the whole array in private memory)
+                    const long src = (long)(2 * ip) * PIECES + p, last = (long)nstage * PIECES - 1;
+                    sv[q] = img4[src < last ? src : last];
+                }
+            };
+            auto stage = [&](int set, const f32x4 (&sv)[PER]) __attribute__((always_inline)) {
+                f32x4* d = reinterpret_cast<f32x4*>(sbuf0 + set * 2 * SH);
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const int p = tid + NTH * q;
+                    if (p < 2 * PIECES) d[p] = sv[q];
+                }
+            };
+            fetch(0, st0);
+            f16x8 bh[KS1], bl[KS1];
+            int k1;
+            {
+                float bv[KS1][8];
+                float bmax = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int c = 32 * ks + 8 * g + i;
+                        bv[ks][i] = c < MS ? mcs[n * MS + (c < MS ? c : 0)] : 0.f;   // (columns M1 .. MS - 1 hold zeros)
+                        bmax = __builtin_fmaxf(bmax, __builtin_fabsf(bv[ks][i]));
+                    }
+                bmax = rows_max4(bmax);
+                const int s_b = 12 - __builtin_amdgcn_frexp_expf(bmax);
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) {
+                    float ms[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ms[i] = __builtin_ldexpf(bv[ks][i], s_b);
+                    split8(ms, bh[ks], bl[ks]);
+                }
+                k1 = -s_b - LOG2_SD;
+            }
+            f32x4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = zero4;
+            // the lane's log-spectrum values of ITS stage of a pair (2 ip + hsel), requested two pairs ahead
+            f32x4 x0[2], x1[2];
+            auto xfetch = [&](int ip, f32x4 (&xr)[2]) __attribute__((always_inline)) {
+                const int j = 2 * ip + hsel;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int b0 = 32 * j + 16 * t + 4 * g;
+                    if (b0 + 3 < K) {
+                        xr[t] = *reinterpret_cast<const f32x4_u4*>(xt + b0);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xr[t][r] = xt[b0 + r < K ? b0 + r : K - 1];
+                    }
+                }
+            };
+            xfetch(0, x0);
+            xfetch(npair > 1 ? 1 : 0, x1);
+            stage(0, st0);
+            __syncthreads();
+            BIG_STAMP(1);
+            // pair ip: the images of pair ip + 1 are requested at its head and staged at its end; `xr` holds this wave's rows
+            auto body = [&](int ip, f32x4 (&xr)[2]) __attribute__((always_inline)) {
+                const int set = ip & 1;
+                const int j = 2 * ip + hsel;
+                const f32x4 xv[2] = {xr[0], xr[1]};
+                if (ip + 1 < npair) fetch(ip + 1, st0);
+                if (ip + 2 < npair) xfetch(ip + 2, xr);
+                if (tile_ok && j < nstage) {
+                    const f16x8* c1 = reinterpret_cast<const f16x8*>(sbuf0 + (set * 2 + hsel) * SH) + lane;
+                    const f16x8* w2 = c1 + (4 * KS1 * 512) / 8;
+                    f32x4 s[2] = {zero4, zero4};
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const f16x8 dh = c1[((t * KS1 + ks) * 2 + 0) * 64], dl = c1[((t * KS1 + ks) * 2 + 1) * 64];
+                            s[t] = mfma_h(dl, bh[ks], s[t]);
+                            s[t] = mfma_h(dh, bl[ks], s[t]);
+                            s[t] = mfma_h(dh, bh[ks], s[t]);
+                        }
+                    float tv[8];
+                    float tmax = -3.0e38f;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool live = 32 * j + 16 * t + 4 * g + r < K;
+                            const float v = __builtin_fmaf(xv[t][r], 1.4426950408889634f, __builtin_ldexpf(s[t][r], k1));
+                            tv[4 * t + r] = live ? v : -3.0e38f;
+                            tmax = __builtin_fmaxf(tmax, tv[4 * t + r]);
+                        }
+                    tmax = rows_max4(tmax);
+                    const float mi = __builtin_ceilf(tmax);
+                    const float shf = (float)EMAX_LOG2 - mi;
+                    float ev[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ev[i] = __builtin_amdgcn_exp2f(tv[i] + shf);
+                    f16x8 eh, el;
+                    split8(ev, eh, el);
+                    const int k2 = (int)mi - EMAX_LOG2 - LOG2_SE;
+#pragma unroll
+                    for (int tc = 0; tc < NT; ++tc) {
+                        const f16x8 wh = w2[(tc * 2 + 0) * 64], wlo = w2[(tc * 2 + 1) * 64];
+                        f32x4 a_ = mfma_h(wlo, eh, zero4);
+                        a_ = mfma_h(wh, el, a_);
+                        a_ = mfma_h(wh, eh, a_);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[tc][r] += __builtin_ldexpf(a_[r], k2);
+                    }
+                }
+                if (ip + 1 < npair) stage(set ^ 1, st0);   // the other set: its readers finished before the barrier that ended pair ip - 1
+                __syncthreads();
+            };
+#pragma unroll 1
+            for (int ip = 0; ip < npair; ip += 2) {
+                body(ip, x0);
+                if (ip + 1 < npair) body(ip + 1, x1);
+            }
+            BIG_STAMP(2);
+            // (the barrier that ended the last stage: every wave is done with the staging buffers -- the rt rows may take them)
+            // ---- the two partial sums meet: odd stages' wave parks its rows, even stages' wave adds its own and parks the sums ----
+            // C/D layout: lane (n, g), register r of tile tc <-> rt[16 tc + 4 g + r] of frame n
+            if (hsel == 1) {
+#pragma unroll
+                for (int tc = 0; tc < NT; ++tc) *reinterpret_cast<f32x4*>(park + n * RTS + 16 * tc + 4 * g) = acc[tc];
+            }
+            __syncthreads();
+            if (hsel == 0) {
+#pragma unroll
+                for (int tc = 0; tc < NT; ++tc) {
+                    f32x4* p4 = reinterpret_cast<f32x4*>(park + n * RTS + 16 * tc + 4 * g);
+                    *p4 = acc[tc] + *p4;
+                }
+            }
+            __syncthreads();
+            BIG_STAMP(3);
+            // ================= mc += solve(T(rt[:n]) + H(rt), rt[:n] - alpha_vec): eight systems per wave =================
+            if (tile_ok) {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));   // (lane-derived values re-derived here: see thsolve_octn_kernel)
+                {
+                    f32x4* z4 = reinterpret_cast<f32x4*>(wl);
+                    for (int e = ln; e < 8 * REC / 4; e += 64) z4[e] = zero4;
+                }
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const int s0 = (ln >> 4) * 2;                                            // lane -> (two records, 16 columns apart)
+                    for (int s_ = s0; s_ < s0 + 2; ++s_) {
+                        float* rec = wl + s_ * REC;
+                        const float* prow = park + (8 * hsel + s_) * RTS;
+                        for (int col = ln & 15; col < N; col += 16) {
+                            const float v = prow[col];
+                            rec[col] = v;                                                    // q window: q[k] at k
+                            if (col < M1) {
+                                rec[PO + col] = v;                                           // p window: p[|d|] at PO + d
+                                if (col >= 1 && col <= 7) rec[PO - col] = v;
+                                rec[RO + col] = v - avs[col];                                // right-hand side
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                BIG_STAMP(4);
+                // the solve is a FUNCTION CALL: inlined, its 220-register matrix set the whole kernel's allocation and the stage loop's
+                // staged image pieces went through scratch (154 k cycles per step); behind a call boundary nothing of the stage loop
+                // is live here and nothing of the elimination is live there
+                big_solve8<NG, NMIN>((mbg::lds_f*)wl, (mbg::lds_f*)(mcs + 8 * hsel * MS), M1);
+            }
+        }
+        // ---- the result: the group's rows of mc, eight per wave ----
+        __syncthreads();
+        if (tile_ok) {
+            for (int e = (tid & 63); e < 8 * M1; e += 64) {
+                const int row = 8 * hsel + e / M1, col = e % M1;
+                if (row < rows_here) mc_out[(tb + row) * (long)M1 + col] = mcs[row * MS + col];
+            }
+        }
+#ifdef DSA_BIG_STAMPS
+        if (blockIdx.x == 0 && pair == 0 && (tid & 63) == 0 && tile == 0)
+            for (int i = 1; i < 8; ++i) mc_out[(8 * hsel) * (long)M1 + i] = (float)(tsv[i] - tsv[i - 1]);
+#endif
+    }
+}
+
+}  // namespace dsa

@@ -126,9 +126,17 @@ __global__ __launch_bounds__(256, 2) DSA_PK_TARGET void mcep_resid_h_kernel(cons
         }
         k1 = -s_b - LOG2_SD;     // the first chain's accumulators x 2^k1 = (-2 log2(e) D)^T mc
     }
-    f32x4 acc[NT];
+    // TWO sets of sums, the even and the odd stages': added once at the end.  The one-launch kernel of round 6 (mcep_big_f16.h) gives
+    // the stages of a tile to two waves alternately and adds their partial sums -- with the same order here, rt is bit-identical
+    // whichever of the two runs (the host chooses by batch size: a frame's bits must not depend on that choice).
+    // (only where that kernel has an instantiation -- orders 43 .. 50: KS1 = 2, NT = 6, 7; the second set costs 28 registers and
+    //  ~7 % of this kernel's time at large batches)
+    constexpr bool SPLIT = KS1 == 2 && NT >= 6;
+    f32x4 acc[NT], acc_odd[SPLIT ? NT : 1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = zero4;
+#pragma unroll
+    for (int t = 0; t < (SPLIT ? NT : 1); ++t) acc_odd[t] = zero4;
     // the lane's log-spectrum values of a stage: bins 32 j + 16 t + 4 g + r; bins past the end read the row's last value and are
     // masked below
     f32x4 x0[2], x1[2];
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(256, 2) DSA_PK_TARGET void mcep_resid_h_kernel(cons
     if (nstage > 1) fetch(1, st0);
     __syncthreads();
     // stage j: `sa` holds stage j + 1 (requested during stage j - 1), `sb` takes stage j + 2, `xr` holds the rows of stage j
-    auto body = [&](int j, f32x4 (&sa)[PER], f32x4 (&sb)[PER], f32x4 (&xr)[2]) __attribute__((always_inline)) {
+    auto body = [&](int j, f32x4 (&sa)[PER], f32x4 (&sb)[PER], f32x4 (&xr)[2], f32x4* accj) __attribute__((always_inline)) {
         const int buf = j & 1;
         const f32x4 xv[2] = {xr[0], xr[1]};
         if (j + 2 < nstage) {
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(256, 2) DSA_PK_TARGET void mcep_resid_h_kernel(cons
                 a_ = mfma_h(wh, el, a_);
                 a_ = mfma_h(wh, eh, a_);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[tc][r] += __builtin_ldexpf(a_[r], k2);
+                for (int r = 0; r < 4; ++r) accj[tc][r] += __builtin_ldexpf(a_[r], k2);
             }
         }
         if (j + 1 < nstage) stage(buf ^ 1, sa);   // the other buffer: its readers finished before the barrier that ended stage j - 1
@@ -208,8 +216,12 @@ __global__ __launch_bounds__(256, 2) DSA_PK_TARGET void mcep_resid_h_kernel(cons
     };
 #pragma unroll 1
     for (int j = 0; j < nstage; j += 2) {
-        body(j, st0, st1, x0);
-        if (j + 1 < nstage) body(j + 1, st1, st0, x1);
+        body(j, st0, st1, x0, acc);
+        if (j + 1 < nstage) body(j + 1, st1, st0, x1, SPLIT ? acc_odd : acc);
+    }
+    if (SPLIT) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] += acc_odd[t];
     }
     if (!tile_ok || n >= rows_here) return;
     // C/D layout: lane (n, g) register r of tile tc <-> column 16 tc + 4 g + r of frame n

@@ -649,6 +649,20 @@ DSA_EXPORT int dsa_mcep_resid_prepare(const void* D, int32_t ldd, const void* E,
     return dsa::mcep_resid_h_prepare(D, ldd, E, lde, K, n, images, (hipStream_t)stream);
 }
 
+// (0.2.0) mcep.py:208-222: ALL n_iter Newton steps in one persistent launch (csrc/mcep_big_f16.h); DSA_ERR_UNSUPPORTED where no
+// instantiation covers the order -- the caller then alternates dsa_mcep_newton_resid_h and dsa_mcep_newton_update
+DSA_EXPORT int dsa_mcep_newton_steps(const void* logx, int64_t F, int32_t K, const void* mc_in, int32_t n, const void* images,
+                                     const void* alpha_vec, int32_t n_iter, int32_t dtype, void* mc_out, void* stream)
+{
+    DSA_REQUIRE(F >= 0 && K >= 4 && n >= 3 && n_iter >= 0, "mcep_newton_steps: invalid sizes");
+    DSA_REQUIRE(logx && mc_in && images && alpha_vec && mc_out, "mcep_newton_steps: null pointer");
+    if (dtype != DSA_F32) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_steps: float32 only%s");
+    if (F == 0) return DSA_OK;
+    const int rc = dsa::mcep_big_newton(logx, F, K, mc_in, n, images, alpha_vec, n_iter, mc_out, (hipStream_t)stream);
+    if (rc == DSA_ERR_UNSUPPORTED) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_steps: no one-launch kernel for this order (43 .. 50)%s");
+    return rc;
+}
+
 DSA_EXPORT int dsa_mcep_newton_resid_h(const void* logx, int64_t F, int32_t K, const void* mc, int32_t n, const void* images, int32_t dtype,
                                        void* rt, void* stream)
 {

@@ -973,6 +973,28 @@ def mcep_newton_resid_h(logx, mc, images):
     return rt
 
 
+def mcep_newton_steps_applies(M1: int) -> bool:
+    """dsa_mcep_newton_steps has an instantiation for this order (43 .. 50: the 48 kHz set-up fft_length 2048 / order 49 and its
+    neighbours; DSA_MCEP_BIG=0: the two-launch step, for A/B runs)."""
+    return 44 <= M1 <= 51 and os.environ.get("DSA_MCEP_BIG", "1") != "0"
+
+
+def mcep_newton_steps(logx, mc0, images, av, n_iter):
+    """ALL n_iter Newton steps of mcep.py:208-222 in ONE persistent launch (dsa_mcep_newton_steps, csrc/mcep_big_f16.h): per step the
+    products of mcep_newton_resid_h and the solve-and-update of mcep_newton_update, rt and mc staying on chip; forward only.
+    None: the library has no instantiation for this order after all (the caller runs the two launches per step)."""
+    n, K = mc0.size(-1), logx.size(-1)
+    mcc = mc0.contiguous()
+    out = torch.empty_like(mcc)
+    with torch.cuda.device(mcc.device):
+        rc = getattr(_lib.load(), "dsa_mcep_newton_steps")(_p(logx), mcc.numel() // n, K, _p(mcc), n, _p(images), _p(av), int(n_iter),
+                                                            _dtype_code(mcc), _p(out), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "dsa_mcep_newton_steps")
+    return out
+
+
 def _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter):
     """mcep.py:203-222 for the geometries the tuned kernel does not cover, as whole-batch launches of the library's own kernels
     instead of the one-workgroup-per-frame generic kernel: per Newton step the two row products (F, M+1) x (M+1, K) and
@@ -998,6 +1020,11 @@ def _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter):
     if not want_grad and 3 <= M1 <= 55 and one_launch_resid and os.environ.get("DSA_MCEP_RESID_H", "1") != "0" \
             and D.dtype == torch.float32 and E.dtype == torch.float32:
         images_h = mcep_resid_images(D, E)
+    if images_h is not None and n_iter >= 1 and mcep_newton_steps_applies(M1) and av.dtype == torch.float32:
+        # round 6: every step in one persistent launch (22 launches -> 3 for the analysis)
+        out_ = mcep_newton_steps(logx, mc, images_h, av, n_iter)
+        if out_ is not None:
+            return out_.reshape(*lead, M1)
     for _ in range(n_iter):
         if want_grad:
             e = RowsExpSubFn.apply(logx, MatmulRowsFn.apply(mc, D))       # :210-212

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 126 /* 0.2.0: + DSA_ALGO_OVERLAPPED_LAUNCHES, DSA_ALGO_PAD_MODE, packed STFT kernels for fft_length 1024 / 2048 and for every pad mode at 512; 0.1.9: + dsa_mgcep_step_solve, dsa_mgcep_step_bwd_h, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
+#define DSA_VERSION 126 /* 0.2.0: + dsa_mcep_newton_steps, DSA_ALGO_OVERLAPPED_LAUNCHES, DSA_ALGO_PAD_MODE, packed STFT kernels for fft_length 1024 / 2048 and for every pad mode at 512; 0.1.9: + dsa_mgcep_step_solve, dsa_mgcep_step_bwd_h, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
@@ -296,6 +296,12 @@ int dsa_mcep_newton_resid(const void* logx, int64_t F, int32_t K, const void* mc
 int64_t dsa_mcep_resid_images_bytes(int32_t K, int32_t n);
 int dsa_mcep_resid_prepare(const void* D, int32_t ldd, const void* E, int32_t lde, int32_t K, int32_t n, int32_t dtype, void* images,
                            void* stream);
+/* (0.2.0) ALL n_iter Newton steps of mcep.py:208-222 in ONE persistent launch (csrc/mcep_big_f16.h): per step the two products of
+ * dsa_mcep_newton_resid_h (same images, bit-identical rt) and the solve-and-update of dsa_mcep_newton_update, rt and mc staying on
+ * chip; mc_in:(F, n) the start (mc0 = logx G), mc_out:(F, n) (may be mc_in).  Orders n - 1 in 43 .. 50 (the 48 kHz set-up fft_length
+ * 2048 / order 49); DSA_ERR_UNSUPPORTED otherwise -- alternate dsa_mcep_newton_resid_h and dsa_mcep_newton_update then. */
+int dsa_mcep_newton_steps(const void* logx, int64_t F, int32_t K, const void* mc_in, int32_t n, const void* images, const void* alpha_vec,
+                          int32_t n_iter, int32_t dtype, void* mc_out, void* stream);
 int dsa_mcep_newton_resid_h(const void* logx, int64_t F, int32_t K, const void* mc, int32_t n, const void* images, int32_t dtype,
                             void* rt, void* stream);
 /* General float32 row product on the matrix instruction, for shapes the kernels behind dsa_freqt_fwd / _bwd do not cover (rows

@@ -605,7 +605,9 @@ def test_untuned_geometries_forward_as_whole_batch_launches(monkeypatch, fl, fp,
         X = stft(x)
         assert X.shape[0] * X.shape[1] >= 256
         mc = mcep(X)
-        assert _lib.last_kernel() in ("th_solve_fwd", "th_solve_quad_fwd", "th_solve_quadn_fwd", "th_solve_octn_fwd"), _lib.last_kernel()
+        # (round 6: orders 43 .. 50 run all Newton steps in one persistent launch, csrc/mcep_big_f16.h)
+        assert _lib.last_kernel() in ("th_solve_fwd", "th_solve_quad_fwd", "th_solve_quadn_fwd", "th_solve_octn_fwd", "mcep_big_newton"), _lib.last_kernel()
+        assert (_lib.last_kernel() == "mcep_big_newton") == (43 <= M <= 50)
         monkeypatch.setenv("DSA_MCEP_COMPOSED", "0")
         mc_g = mcep(X)
         assert _lib.last_kernel() == "mcep_generic_fwd"
@@ -930,3 +932,47 @@ def test_newton_update_with_a_gradient_against_float64_autograd(n, F):
     assert float((out_d.detach().double().cpu() - out_r.detach()).abs().max() / out_r.detach().abs().max()) < tol
     assert float((rt_d.grad.double().cpu() - rt_r.grad).abs().max() / rt_r.grad.abs().max()) < tol
     assert torch.equal(mc_d.grad.cpu(), wgt.float())
+
+
+@pytest.mark.parametrize("M", [43, 49, 50])
+def test_48khz_newton_steps_in_one_launch_equal_the_two_launch_step_bit_for_bit(M, monkeypatch):
+    """dsa_mcep_newton_steps (round 6, csrc/mcep_big_f16.h: all Newton steps of mcep.py:208-222 at fft_length 2048 / orders 43 .. 50 in
+    one persistent launch -- 12 800 frames 0.92 -> 0.68 ms) against the two launches per step it replaces: the same bits at every
+    batch size, ragged tails and iteration counts, repeat launches identical, float64 at the tolerance of the goldens, non-finite
+    frames contained, and the kernel chosen by the order alone (1 frame or 102 400)."""
+    g = torch.Generator().manual_seed(M)
+    Xall = (torch.randn(3300, 1025, generator=g).square() + 0.05).to(DEV)
+    for F, n_iter in ((1, 3), (15, 1), (64, 10), (65, 2), (700, 10), (3217, 10)):
+        X = Xall[:F]
+        m = dsp.MelCepstralAnalysis(fft_length=2048, cep_order=M, alpha=0.55, n_iter=n_iter, device=DEV)
+        with torch.no_grad():
+            monkeypatch.setenv("DSA_MCEP_BIG", "0")
+            a = m(X)
+            assert _lib.last_kernel() != "mcep_big_newton"
+            monkeypatch.setenv("DSA_MCEP_BIG", "1")
+            b = m(X)
+            assert _lib.last_kernel() == "mcep_big_newton", (F, _lib.last_kernel())
+            assert torch.equal(a, b), (F, n_iter, float((a - b).abs().max()))
+            assert torch.equal(m(X), b)
+    m64 = dsp.MelCepstralAnalysis(fft_length=2048, cep_order=M, alpha=0.55, n_iter=10, device=DEV, dtype=torch.float64)
+    with torch.no_grad():
+        y64 = m64(Xall[:700].double())
+    np.testing.assert_allclose(host(b[:700]), host(y64), **MC32)
+    # a non-finite frame stays in its row: every other frame keeps its bits
+    Xb = Xall[:700].clone()
+    Xb[[3, 64, 699], 7] = float("nan")
+    m = dsp.MelCepstralAnalysis(fft_length=2048, cep_order=M, alpha=0.55, n_iter=10, device=DEV)
+    with torch.no_grad():
+        yb, y = m(Xb), m(Xall[:700])
+    keep = torch.ones(700, dtype=torch.bool, device=DEV)
+    keep[[3, 64, 699]] = False
+    assert torch.equal(yb[keep], y[keep]) and not torch.isfinite(yb[~keep]).all(-1).any()
+    # the same kernel, the same bits per frame, at 200 tiles of 64 frames (one round of the chip) and at 1 600 (6.25 rounds)
+    with torch.no_grad():
+        Xbig = Xall[:3200].repeat(4, 1)                                   # 12 800 frames
+        y1 = m(Xbig)
+        assert _lib.last_kernel() == "mcep_big_newton"
+        assert torch.equal(y1[:3200], y1[3200:6400]) and torch.equal(y1[:700], y)
+        y8 = m(Xbig.repeat(8, 1))                                        # 102 400 frames
+        assert _lib.last_kernel() == "mcep_big_newton"
+        assert torch.equal(y8[:12800], y1) and torch.equal(y8[-12800:], y1)
