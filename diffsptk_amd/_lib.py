@@ -155,6 +155,8 @@ SIGNATURES = {
     "dsa_mcep_prepare": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "dsa_mcep_fwd": (C.c_int, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "dsa_stft_mcep_fwd": (C.c_int, [_P, _L, _L, _I, _I, _I, _P, _P, _I, _D, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "dsa_stft_mcep_opts_fwd": (C.c_int, [_P, _L, _L, _I, _I, _I, _P, _P, _I, _I, _I, _D, _I, _D, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P,
+                                         _P, _P]),
     "dsa_mcep_bwd": (C.c_int, [_P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "dsa_thsolve_fwd": (C.c_int, [_P, _P, _P, _L, _I, _I, _P, _P]),
     "dsa_mgcep_step": (C.c_int, [_P, _P, _L, _I, _I, _D, _P, _I, _P, _P, _P, _P]),

@@ -343,7 +343,8 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
                   const StftIn* sti = nullptr, bool hist_has_rt = false, bool overlapped = false);
 int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, const void* window, const void* twiddle, double eps,
                         int n_iter, const void* G, const void* D, const void* E, const void* av, const void* images, void* scratch,
-                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean, bool hist_has_rt, bool overlapped, int pad_mode);
+                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean, bool hist_has_rt, bool overlapped, int pad_mode,
+                        int zmean, float floor_lin);
 int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* av,
                   const void* images, void* scratch, void* gX, hipStream_t st, bool has_workspace = false, bool hist_has_rt = false);
 
@@ -447,16 +448,19 @@ DSA_EXPORT int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, i
     return fail(DSA_ERR_UNSUPPORTED, "mcep: unsupported dtype%s");
 }
 
-DSA_EXPORT int dsa_stft_mcep_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft, const void* window,
-                                 const void* twiddle, int32_t center, double eps, int32_t M, int32_t n_iter, const void* G,
-                                 const void* D, const void* E, const void* alpha_vec, int32_t dtype, int32_t algo,
-                                 const void* images, void* scratch, void* mc, void* mc_hist, void* X_out, void* stream)
+// (0.2.0) dsa_stft_mcep_fwd with the framing / spectrum options of dsa_stft_fwd the one launch covers: zmean, the pad mode, the relative
+// floor (stft.py:86-104; power format only)
+DSA_EXPORT int dsa_stft_mcep_opts_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft, const void* window,
+                                      const void* twiddle, int32_t center, int32_t zmean, int32_t pad_mode, double eps, int32_t use_floor,
+                                      double relative_floor_db, int32_t M, int32_t n_iter, const void* G, const void* D, const void* E,
+                                      const void* alpha_vec, int32_t dtype, int32_t algo, const void* images, void* scratch, void* mc,
+                                      void* mc_hist, void* X_out, void* stream)
 {
     DSA_REQUIRE(B >= 0 && T >= 0 && P >= 1 && L >= 1 && n_iter >= 0, "stft_mcep: invalid sizes");
+    DSA_REQUIRE(pad_mode >= 0 && pad_mode <= 3, "stft_mcep: unknown pad mode");
     const bool scratch_clean = (algo & DSA_ALGO_SCRATCH_IS_CLEAN) != 0;
     const bool hist_has_rt = (algo & DSA_ALGO_HIST_HAS_RT) != 0;
     const bool overlapped = (algo & DSA_ALGO_OVERLAPPED_LAUNCHES) != 0;
-    const int pad_mode = (algo >> 12) & 3;   // DSA_ALGO_PAD_MODE(m)
     DSA_REQUIRE(pad_mode != DSA_PAD_REFLECT || (center ? L / 2 : L - 1) < T || L == 1, "stft_mcep: reflect padding needs pad < input length");
     const int64_t N = T <= 0 ? 0 : (T - 1) / P + 1;
     if (!(mcep_mfma_supported(nfft, M, dtype) && L == 400 && B * N < (int64_t(1) << 31) && T < (int64_t(1) << 31)))
@@ -464,8 +468,19 @@ DSA_EXPORT int dsa_stft_mcep_fwd(const void* x, int64_t B, int64_t T, int32_t L,
     DSA_REQUIRE(images && scratch, "stft_mcep: the prepared images (dsa_mcep_prepare) and a scratch buffer are required");
     DSA_REQUIRE(x && window && twiddle && G && D && E && alpha_vec && mc, "stft_mcep: null pointer");
     if (B * N == 0) return DSA_OK;
+    const float floor_lin = use_floor ? (float)pow(10.0, relative_floor_db / 10.0) : -1.f;
     return stft_mcep_fused_fwd(x, B, T, P, center, window, twiddle, eps, n_iter, G, D, E, alpha_vec, images, scratch, mc, mc_hist,
-                               X_out, (hipStream_t)stream, scratch_clean, hist_has_rt, overlapped, pad_mode);
+                               X_out, (hipStream_t)stream, scratch_clean, hist_has_rt, overlapped, pad_mode, zmean != 0, floor_lin);
+}
+
+DSA_EXPORT int dsa_stft_mcep_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft, const void* window,
+                                 const void* twiddle, int32_t center, double eps, int32_t M, int32_t n_iter, const void* G,
+                                 const void* D, const void* E, const void* alpha_vec, int32_t dtype, int32_t algo,
+                                 const void* images, void* scratch, void* mc, void* mc_hist, void* X_out, void* stream)
+{
+    // (the plain configuration; DSA_ALGO_PAD_MODE(m) in `algo` selects the pad mode)
+    return dsa_stft_mcep_opts_fwd(x, B, T, L, P, nfft, window, twiddle, center, 0, (algo >> 12) & 3, eps, 0, 0.0, M, n_iter, G, D, E, alpha_vec,
+                                  dtype, algo & ~(3 << 12), images, scratch, mc, mc_hist, X_out, stream);
 }
 
 DSA_EXPORT int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist, int64_t F, int32_t nfft,

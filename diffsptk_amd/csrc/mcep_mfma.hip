@@ -631,7 +631,8 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
     const int lds_bytes = (sti ? mh::h_lds_floats_fused(WAVES) : mh::h_lds_floats(WAVES)) * 4;
     static std::atomic<uint64_t> attr_devices{0}, attr_devices_fused{0}, attr_devices_rt{0}, attr_devices_fused_rt{0};
     const bool rt = hist_rt != nullptr;
-    const bool padm = sti && sti->pad_mode != (int)DSA_PAD_CONSTANT;   // reflect / replicate / circular: instantiations of their own
+    // reflect / replicate / circular padding, zmean, relative floor: instantiations of their own
+    const bool padm = sti && (sti->pad_mode != (int)DSA_PAD_CONSTANT || sti->zmean || sti->floor_lin >= 0.f);
     static std::atomic<uint64_t> attr_devices_padm{0}, attr_devices_padm_rt{0};
     const void* kern = padm ? (rt ? (const void*)mcep_mfma_fwd_kernel_h<WAVES, true, true, true> : (const void*)mcep_mfma_fwd_kernel_h<WAVES, true, false, true>)
                      : sti  ? (rt ? (const void*)mcep_mfma_fwd_kernel_h<WAVES, true, true> : (const void*)mcep_mfma_fwd_kernel_h<WAVES, true, false>)
@@ -683,7 +684,8 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
 // STFT (frame length 400, fft_length 512, power format, constant padding) -> MelCepstralAnalysis (cep_order 24) in one launch
 int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, const void* window, const void* twiddle, double eps,
                         int n_iter, const void* G, const void* D, const void* E, const void* av, const void* images, void* scratch,
-                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean, bool hist_has_rt, bool overlapped, int pad_mode)
+                        void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean, bool hist_has_rt, bool overlapped, int pad_mode,
+                        int zmean, float floor_lin)
 {
     const int64_t N = T <= 0 ? 0 : (T - 1) / P + 1;
     StftIn sti;
@@ -697,6 +699,8 @@ int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, 
     sti.eps = (float)eps;
     sti.X_out = (float*)X_out;
     sti.pad_mode = pad_mode;
+    sti.zmean = zmean;
+    sti.floor_lin = floor_lin;
     return mcep_mfma_fwd(nullptr, B * N, n_iter, G, D, E, av, images, scratch, mc, hist, st, scratch_clean, &sti, hist_has_rt, overlapped);
 }
 

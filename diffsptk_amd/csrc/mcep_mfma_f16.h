@@ -34,6 +34,8 @@ struct StftIn {
     float eps;             // spec.py:173
     float* X_out;          // NULL, or (B N, 257): the power spectrogram as a side product (kept for the backward)
     int pad_mode;          // frame.py:130-137 (DSA_PAD_*): what positions outside the utterance read
+    int zmean;             // frame.py:139-140: the frame's mean removed before the window
+    float floor_lin;       // spec.py:174-176: < 0 none, else every bin at least (the frame's largest value) x this (10^(dB / 10))
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -219,7 +221,8 @@ __device__ __forceinline__ void store_mc_row(float* row, int g, const float (&mc
 
 template <int WAVES, bool FUSED = false, bool HIST_RT = false, bool PADM = false>   // HIST_RT: also keep every step's rt row (its own
                                                                  // instantiation: the plain kernels' code and register allocation are
-                                                                 // untouched); PADM: reflect / replicate / circular padding (likewise)
+                                                                 // untouched); PADM: the options instantiation -- reflect / replicate /
+                                                                 // circular padding, zmean, relative floor (likewise)
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) DSA_PK_TARGET void mcep_mfma_fwd_kernel_h(
     const float* __restrict__ X, long F, int n_iter, const float* __restrict__ G,
     const float* __restrict__ D, const float* __restrict__ E, const float* __restrict__ av,
@@ -414,6 +417,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) DSA_PK_TARGET void mcep_mfma
                 const v2f* wtab = reinterpret_cast<const v2f*>(fu + FU_WTAB) + jo;
                 const v2f* t256 = reinterpret_cast<const v2f*>(fu + FU_T256) + j1;
                 v2f v[16];
+                if (PADM && sti.zmean) {   // frame.py:139-140, with the packed kernel's summation (pk_math.h: pk_zero_mean)
+                    bool in0[FU_NR], in1[FU_NR];
+#pragma unroll
+                    for (int m1 = 0; m1 < FU_NR; ++m1) {
+                        in0[m1] = 32 * m1 + 30 < FU_LC || 32 * m1 + 2 * j < FU_LC;
+                        in1[m1] = 32 * m1 + 31 < FU_LC || 32 * m1 + 1 + 2 * j < FU_LC;
+                        raw[m1] = v2f{in0[m1] ? raw[m1].x : 0.f, in1[m1] ? raw[m1].y : 0.f};
+                    }
+                    pk_zero_mean<FU_NR>(raw, in0, in1, FU_LC);
+                }
 #pragma unroll
                 for (int m1 = 0; m1 < FU_NR; ++m1) {
                     // element (m1, e) belongs to the frame iff 32 m1 + e + 2 j < L; selected, never multiplied: zero padding is
@@ -538,6 +551,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) DSA_PK_TARGET void mcep_mfma
                     }
                     }
                     // sp[0] = (bin 2l+1, bin 255-2l), sp[1] = (bin 2l+2, bin 254-2l)
+                    if (PADM && sti.floor_lin >= 0.f) {   // spec.py:174-176, as csrc/stft_pk.h applies it
+                        float m = sp[0].x > sp[0].y ? sp[0].x : sp[0].y;
+                        m = sp[1].x > m ? sp[1].x : m;
+                        m = sp[1].y > m ? sp[1].y : m;
+                        m = se.x > m ? se.x : m;
+                        m = se.y > m ? se.y : m;
+                        const float flv = wave64_max(m) * sti.floor_lin;
+                        sp[0] = v2f{sp[0].x > flv ? sp[0].x : flv, sp[0].y > flv ? sp[0].y : flv};
+                        sp[1] = v2f{sp[1].x > flv ? sp[1].x : flv, sp[1].y > flv ? sp[1].y : flv};
+                        se = v2f{se.x > flv ? se.x : flv, se.y > flv ? se.y : flv};
+                    }
                     if (sti.X_out && fr0 + q < F) {   // the spectrogram as a side product (a gradient will need it)
                         float* yr = sti.X_out + (fr0 + q) * K;   // (uniform; the lane part below from the per-pass opaque copy l4)
                         *reinterpret_cast<v2f_u4*>(yr + 2 * l4 + 1) = v2f{sp[0].x, sp[1].x};

@@ -191,6 +191,53 @@ __device__ __forceinline__ v2f pk_cmul_s(v2f a, v2f t)
     return r;
 }
 
+// ---- options of ShortTimeFourierTransform beyond the plain configuration (round 6), shared by the packed STFT kernel and the
+// prologue of the fused STFT -> mel-cepstrum kernel so that both round alike ----
+// sum over the 16 lanes of a frame group, the SAME bits in all 16: butterflies whose two partners add the same pair of values
+// (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror) -- a rotation scheme would associate differently per lane
+__device__ __forceinline__ float row16_sum(float s)
+{
+    s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0xB1, 0xf, 0xf, true));    // i ^ 1
+    s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0x4E, 0xf, 0xf, true));    // i ^ 2
+    s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0x141, 0xf, 0xf, true));   // row_half_mirror: i <-> 7 - i
+    s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s), 0x140, 0xf, 0xf, true));   // row_mirror: i <-> 15 - i
+    return s;
+}
+// frame.py:139-140 (zmean): the mean of the frame's L samples, 16 lanes x NR pairs each (lane j holds samples 2 j + 32 m1 (+ 1));
+// elements past the frame were selected to zero by the caller and are not touched (`in0` / `in1`: the element belongs to the frame).
+// Hand-placed instructions throughout: left to the compiler's pairing, this code came out with a crossed packed form
+// (tests/test_host_cpu.py::test_no_crossed_packed_float32 caught it).
+template <int NR>
+__device__ __forceinline__ void pk_zero_mean(v2f (&r)[NR], const bool (&in0)[NR], const bool (&in1)[NR], int L)
+{
+    float s = 0.f;
+#pragma unroll
+    for (int m1 = 0; m1 < NR; ++m1) {   // (zeros outside the frame)
+        float t;
+        asm("v_add_f32 %0, %1, %2" : "=v"(t) : "v"(r[m1].x), "v"(r[m1].y));
+        asm("v_add_f32 %0, %1, %2" : "=v"(s) : "v"(s), "v"(t));
+    }
+    const float mean = row16_sum(s) / (float)L;
+    v2f mm;
+    asm("v_mov_b32 %0, %1" : "=v"(mm.x) : "v"(mean));
+    asm("v_mov_b32 %0, %1" : "=v"(mm.y) : "v"(mean));
+#pragma unroll
+    for (int m1 = 0; m1 < NR; ++m1) {
+        const v2f d = pk_sub(r[m1], mm);
+        r[m1] = v2f{in0[m1] ? d.x : 0.f, in1[m1] ? d.y : 0.f};
+    }
+}
+// maximum over the wave, the same bits in all 64 lanes (spec.py:174-176: the relative floor's per-frame reference)
+__device__ __forceinline__ float wave64_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float u = __shfl_xor(v, o, 64);
+        v = u > v ? u : v;
+    }
+    return v;
+}
+
 // 4-point forward DFT in place (W4 = -i): 8 packed instructions
 __device__ __forceinline__ void pk_dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3)
 {

@@ -1704,9 +1704,14 @@ static void stft512_launch(bool zmean, dim3 grid, int lds, hipStream_t st, const
         const char* e = getenv("DSA_STFT_PK");
         return e ? atoi(e) : 2;
     }();
-    // (round 6: every pad mode -- the mode only changes what the passes that reach over an utterance's end read)
-    const bool plain_any_pad = !use_floor && fmt == DSA_SPEC_POWER;
-    if (use_pk && ABL == 0 && plain_any_pad && !zmean && L == 400 && (P & 1) == 0 && 3 * P + 512 <= kFPW * kZS * 2) {
+    // (round 6: every pad mode -- the mode only changes what the passes that reach over an utterance's end read -- and, as an
+    //  instantiation of its own, zmean and the relative floor)
+    if (use_pk && ABL == 0 && fmt == DSA_SPEC_POWER && L == 400 && (P & 1) == 0 && 3 * P + 512 <= kFPW * kZS * 2) {
+        if (zmean || use_floor) {
+            hipLaunchKernelGGL((stft512_fwd_pk_kernel<0, 400, true, 0, false, 0, true>), g2, dim3(128), lds2, st, x, T, N, L, P, left, w, tw, eps, y,
+                               total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0, 0, mode, (int)zmean, use_floor ? floor_lin : -1.f);
+            return;
+        }
         // a wave walks a RUN of consecutive passes (their shared samples come from its CU's cache, not from memory twice);
         // DSA_STFT_RUN=0: the round-robin order of rounds 1-4 (A/B)
         static const int run_env = [] { const char* e = getenv("DSA_STFT_RUN"); return e ? atoi(e) : 0; }();

@@ -57,15 +57,18 @@ __device__ unsigned long long g_stft_pk_stamps[64];
 __device__ __attribute__((noinline)) float fb_slow_log(float v) { return dsa_log(v); }
 __device__ __attribute__((noinline)) float fb_slow_glog(float v, float gamma) { return (dsa_pow(v, gamma) - 1.f) / gamma; }
 
-template <int ABL, int LC, bool DIRECT = false, int FBM = 0, bool PF2 = false, int WPBX = 0>   // FBM: 0 spectrum out, 1 filter bank of the power values, 2 of the amplitudes;
+// OPTS (round 6): zmean (frame.py:139-140) and the relative floor (spec.py:174-176) -- an instantiation of its own, the plain kernel's
+// code is untouched.  `opt_zmean`, `opt_floor` (< 0: none, else the linear factor 10^(dB / 10)) are its run-time switches.
+template <int ABL, int LC, bool DIRECT = false, int FBM = 0, bool PF2 = false, int WPBX = 0, bool OPTS = false>   // FBM: 0 spectrum out, 1 filter bank of the power values, 2 of the amplitudes;
                                                                             // PF2: the stretch fetched TWO passes ahead (two register sets, window from LDS)
                                                                             // WPBX: waves per workgroup (0: 2, or 4 with FBM / PF2) -- the waves of a workgroup take ADJACENT
                                                                             // passes, which share L - P of their samples: on one CU the second fetch of those is a cache hit
 __global__ __launch_bounds__(WPBX ? WPBX * 64 : ((FBM || PF2) ? 256 : 128), WPBX ? 16 / WPBX : 4) DSA_PK_TARGET void stft512_fwd_pk_kernel(
     const float* __restrict__ x, long Tlen, long N, int L, int P, int left, const float* __restrict__ w,
     const float* __restrict__ twiddle, float eps, float* __restrict__ y, long total_chunks, int chunks_per_utt,
-    const float* __restrict__ fbt, float fb_floor, float fb_gamma, int fbC, int run_len, int pad_mode)
+    const float* __restrict__ fbt, float fb_floor, float fb_gamma, int fbC, int run_len, int pad_mode, int opt_zmean = 0, float opt_floor = -1.f)
 {
+    static_assert(!OPTS || (DIRECT && LC > 0 && !FBM && !PF2), "zmean / relative floor build on the register-direct plain kernel");
     // pad_mode (round 6; frame.py:130-137): reflect / replicate / circular padding only changes which sample a position outside the
     // utterance reads -- the passes that reach over an end (stage_sync's element-wise path); interior passes never see it
     // run_len > 1 (round 5): a wave takes RUNS of run_len consecutive passes instead of every (number of waves)-th pass.  Consecutive
@@ -345,7 +348,20 @@ __global__ __launch_bounds__(WPBX ? WPBX * 64 : ((FBM || PF2) ? 256 : 128), WPBX
             for (int m1 = 0; m1 < NR; ++m1) raw[m1] = src[16 * m1];   // reads past the frame stay inside the tile
             // samples past the frame are selected away, never multiplied: zero padding is exact and non-finite
             // neighbours stay out of frames that do not contain them
-            if (LC) {
+            if (LC && OPTS) {
+                bool in0[NR], in1[NR];
+#pragma unroll
+                for (int m1 = 0; m1 < NR; ++m1) {
+                    in0[m1] = 32 * m1 + 30 < LC || 32 * m1 + 2 * j < LC;
+                    in1[m1] = 32 * m1 + 31 < LC || 32 * m1 + 1 + 2 * j < LC;
+                    raw[m1] = v2f{in0[m1] ? raw[m1].x : 0.f, in1[m1] ? raw[m1].y : 0.f};
+                }
+                if (opt_zmean) pk_zero_mean<NR>(raw, in0, in1, LC);
+#pragma unroll
+                for (int m1 = 0; m1 < NR; ++m1) v[m1] = pk_mul(raw[m1], WL ? wtab[j * NR + m1] : wreg[m1]);
+#pragma unroll
+                for (int m1 = NR; m1 < 16; ++m1) v[m1] = v2f{0.f, 0.f};
+            } else if (LC) {
 #pragma unroll
                 for (int m1 = 0; m1 < NR; ++m1) {
                     // element (m1, e) belongs to the frame iff 32 m1 + e + 2 j < LC; only the last pair can straddle
@@ -477,6 +493,18 @@ __global__ __launch_bounds__(WPBX ? WPBX * 64 : ((FBM || PF2) ? 256 : 128), WPBX
                     stage[f * K + k] = s.x;
                     stage[f * K + 256 - k] = s.y;
                 }
+            }
+            if (OPTS && opt_floor >= 0.f) {
+                // spec.py:174-176: every bin of the frame at least (the frame's largest value) x 10^(dB / 10)
+                float m = sp[0].x > sp[0].y ? sp[0].x : sp[0].y;
+                m = sp[1].x > m ? sp[1].x : m;
+                m = sp[1].y > m ? sp[1].y : m;
+                m = se.x > m ? se.x : m;
+                m = se.y > m ? se.y : m;
+                const float flv = wave64_max(m) * opt_floor;
+                sp[0] = v2f{sp[0].x > flv ? sp[0].x : flv, sp[0].y > flv ? sp[0].y : flv};
+                sp[1] = v2f{sp[1].x > flv ? sp[1].x : flv, sp[1].y > flv ? sp[1].y : flv};
+                ends[f] = v2f{se.x > flv ? se.x : flv, se.y > flv ? se.y : flv};
             }
             if (FB) {
                 // ---- filter bank: the lane's four values of this frame, weighted, summed over the lanes of each interval ----

@@ -94,8 +94,9 @@ class FusedSTFTMelCepstralAnalysis(nn.Module):
         s, a = self.stft, self.analysis
         if any(isinstance(getattr(s, n, None), nn.Parameter) for n in ("window", "W")) or getattr(s, "W", None) is not None:
             return False
-        # (round 6: every pad mode of Frame -- frame.py:130-137 -- runs in the one launch; zmean and the relative floor keep two stages)
-        if not (s.fmt == _SPEC_POWER and s.mode in ("constant", "reflect", "replicate", "circular") and not s.zmean and s.relative_floor is None):
+        # (round 6: every pad mode of Frame -- frame.py:130-137 --, zmean -- frame.py:139-140 -- and the relative floor -- spec.py:174-176 --
+        #  run in the one launch: own instantiations of the kernel; the other output formats keep two stages)
+        if not (s.fmt == _SPEC_POWER and s.mode in ("constant", "reflect", "replicate", "circular")):
             return False
         if s.mode == "reflect" and not ((s.frame_length // 2 if s.center else s.frame_length - 1) < x.size(-1) or s.frame_length == 1):
             return False   # (F.pad rejects it: let the stage raise its own error)
@@ -110,7 +111,7 @@ class FusedSTFTMelCepstralAnalysis(nn.Module):
             return a(s(x))
         self.last_path = "fused"
         return ops.StftMcepFn.apply(x, s.window, s.twiddle, a.G, a.D, a.E, a.alpha_vector, s.frame_length, s.frame_period,
-                                    s.fft_length, s.center, s.eps, a.cep_order, a.n_iter, s.mode)
+                                    s.fft_length, s.center, s.eps, a.cep_order, a.n_iter, s.mode, s.zmean, s.relative_floor)
 
 
 class FusedFrameWindowLPC(nn.Module):

@@ -1119,7 +1119,8 @@ class StftMcepFn(torch.autograd.Function):
     and the Newton history behind, and the backward is the two stages' own (dsa_mcep_bwd, then dsa_stft_bwd)."""
 
     @staticmethod
-    def forward(ctx, x, window, twiddle, G, D, E, av, L, P, fft_length, center, eps, M, n_iter, mode="constant"):
+    def forward(ctx, x, window, twiddle, G, D, E, av, L, P, fft_length, center, eps, M, n_iter, mode="constant", zmean=False,
+                relative_floor_db=None):
         _require_device(x, window, twiddle, G, D, E, av)
         _same_dtype(x, window, twiddle, G, D, E, av)
         xc, wc = x.contiguous(), window.contiguous()
@@ -1140,13 +1141,16 @@ class StftMcepFn(torch.autograd.Function):
         if with_rt:
             flag |= _lib.ALGO_HIST_HAS_RT
         with torch.cuda.device(x.device):
-            _call("dsa_stft_mcep_fwd", _p(xc), B, T, L, P, fft_length, _p(wc), _p(twiddle), int(center), float(eps), M, n_iter,
-                  _p(G), _p(D), _p(E), _p(av), _dtype_code(xc), _lib.ALGO_AUTO | flag | (pad_mode_code(mode) << 12),   # DSA_ALGO_PAD_MODE
-                  _p(images), _p(scratch), _p(mc), _p(hist), _p(X), _stream())
+            _call("dsa_stft_mcep_opts_fwd", _p(xc), B, T, L, P, fft_length, _p(wc), _p(twiddle), int(center), int(bool(zmean)),
+                  pad_mode_code(mode), float(eps), int(relative_floor_db is not None),
+                  0.0 if relative_floor_db is None else float(relative_floor_db), M, n_iter, _p(G), _p(D), _p(E), _p(av), _dtype_code(xc),
+                  _lib.ALGO_AUTO | flag, _p(images), _p(scratch), _p(mc), _p(hist), _p(X), _stream())
         if need_grad:
             ctx.save_for_backward(xc, wc, twiddle, X, hist, G, D, E, av)
         ctx.cfg = (L, P, fft_length, center, eps, M, n_iter)
         ctx.mode = mode
+        ctx.zmean = bool(zmean)
+        ctx.floor_db = relative_floor_db
         ctx.images = images
         ctx.with_rt = with_rt
         return mc
@@ -1168,9 +1172,10 @@ class StftMcepFn(torch.autograd.Function):
             _call("dsa_mcep_bwd", _p(gmc), _p(X), _p(hist), F, fft_length, M, n_iter, _p(G), _p(D), _p(E), _p(av),
                   _dtype_code(X), _lib.ALGO_AUTO | _lib.ALGO_SCRATCH_HAS_WORKSPACE | (_lib.ALGO_HIST_HAS_RT if ctx.with_rt else 0),
                   _p(ctx.images), _p(scratch), _p(gX), _stream())
-            _call("dsa_stft_bwd", _p(gX), _p(xc), B, T, L, P, fft_length, _p(wc), _p(twiddle), int(center), 0,
-                  pad_mode_code(ctx.mode), float(eps), 0, 0.0, 3, _dtype_code(xc), _lib.ALGO_AUTO, _p(gx), None, _stream())
-        return (gx,) + (None,) * 14
+            _call("dsa_stft_bwd", _p(gX), _p(xc), B, T, L, P, fft_length, _p(wc), _p(twiddle), int(center), int(ctx.zmean),
+                  pad_mode_code(ctx.mode), float(eps), int(ctx.floor_db is not None), 0.0 if ctx.floor_db is None else float(ctx.floor_db), 3,
+                  _dtype_code(xc), _lib.ALGO_AUTO, _p(gx), None, _stream())
+        return (gx,) + (None,) * 16
 
 
 class McepFn(torch.autograd.Function):

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 126 /* 0.2.0: + dsa_mcep_newton_steps, DSA_ALGO_OVERLAPPED_LAUNCHES, DSA_ALGO_PAD_MODE, packed STFT kernels for fft_length 1024 / 2048 and for every pad mode at 512; 0.1.9: + dsa_mgcep_step_solve, dsa_mgcep_step_bwd_h, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
+#define DSA_VERSION 126 /* 0.2.0: + dsa_mcep_newton_steps, dsa_stft_mcep_opts_fwd, DSA_ALGO_OVERLAPPED_LAUNCHES, DSA_ALGO_PAD_MODE, packed STFT kernels for fft_length 1024 / 2048 and for every pad mode at 512; 0.1.9: + dsa_mgcep_step_solve, dsa_mgcep_step_bwd_h, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
@@ -330,6 +330,14 @@ int dsa_rows_ew(int32_t op, int32_t backward, const void* a, const void* b, cons
  * (else DSA_ERR_UNSUPPORTED: call dsa_stft_fwd and dsa_mcep_fwd).  window:(L), twiddle:(nfft,2), G/D/E/alpha_vec/images/
  * scratch/algo flags as dsa_mcep_fwd; mc_hist: NULL or (n_iter+1, B N, M+1); X_out: NULL or (B N, nfft/2+1) receiving the
  * power spectrogram as a side product (what dsa_mcep_bwd needs when a gradient is wanted). */
+/* (0.2.0) The same launch with the options of ShortTimeFourierTransform it covers beyond the plain configuration (stft.py:86-104):
+ * zmean (frame.py:139-140), pad_mode (DSA_PAD_*, frame.py:130-137), the relative floor in dB (spec.py:174-176); power format only.
+ * Options run own instantiations of the kernel: the plain configuration's code is untouched. */
+int dsa_stft_mcep_opts_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft, const void* window,
+                           const void* twiddle, int32_t center, int32_t zmean, int32_t pad_mode, double eps, int32_t use_floor,
+                           double relative_floor_db, int32_t M, int32_t n_iter, const void* G, const void* D, const void* E,
+                           const void* alpha_vec, int32_t dtype, int32_t algo, const void* images, void* scratch, void* mc,
+                           void* mc_hist, void* X_out, void* stream);
 int dsa_stft_mcep_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft, const void* window,
                       const void* twiddle, int32_t center, double eps, int32_t M, int32_t n_iter, const void* G,
                       const void* D, const void* E, const void* alpha_vec, int32_t dtype, int32_t algo,

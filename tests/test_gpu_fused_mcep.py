@@ -144,6 +144,54 @@ def test_fused_pad_modes_equal_the_two_kernels_and_the_oracle(mode, B, T, P, cen
     assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * float(xb.grad.abs().max())
 
 
+@pytest.mark.parametrize("kw", [dict(zmean=True), dict(relative_floor=-40.0), dict(zmean=True, relative_floor=-25.0, mode="reflect"),
+                                dict(zmean=True, mode="circular"), dict(relative_floor=-60.0, mode="replicate")])
+@pytest.mark.parametrize("B,T,P,center", [(3, 16000, 80, True), (2, 15997, 80, True), (5, 1234, 160, True), (3, 2000, 80, False)])
+def test_fused_zmean_and_relative_floor_equal_the_two_kernels_and_the_oracle(kw, B, T, P, center):
+    """zmean (frame.py:139-140) and relative_floor (spec.py:174-176) -- with any pad mode -- through the ONE launch (round 6;
+    dsa_stft_mcep_opts_fwd): `last_path == "fused"`, the spectrogram side product bit-identical to the two-kernel path's (the packed
+    kernel serves these options now, with the same summation for the mean), mel-cepstra against the two kernels and the float64 oracle,
+    the gradient against the two-stage gradient."""
+    x = torch.randn(B, T, generator=torch.Generator().manual_seed(B * 13 + T)).to(DEV)
+    x[0, : min(T, 500)] *= 1e-3                                   # a quiet stretch: the floor bites there
+    # (no offset on top: a frame of 400 standard normal samples has a mean of ~0.05, which zmean removes; a large common offset is
+    #  removed in float32 with an error that shows at the DC bins against a float64 reference -- in the reference's own float32 too)
+    stft, mcep, fused = _modules(P, center, **kw)
+    with torch.no_grad():
+        X2 = stft(x)
+        assert _lib.last_kernel() == "stft512_fwd"
+        mc2 = mcep(X2)
+        mc1 = fused(x)
+    assert fused.last_path == "fused" and _lib.last_kernel() == "stft512_mcep_fused_fwd"
+    assert float((mc1 - mc2).abs().max()) <= 1e-6 * float(mc2.abs().max())
+    T_ = x.size(-1)
+    N = ops.num_frames(T_, P)
+    mcf = torch.empty(B, N, 25, device=DEV)
+    Xf = torch.full((B, N, 257), float("nan"), device=DEV)
+    images = ops.mcep_images(mcep.G, mcep.D, mcep.E, 512, 24)
+    scratch = torch.zeros(_lib.SCRATCH_BYTES, dtype=torch.uint8, device=DEV)
+    rf = kw.get("relative_floor")
+    ops._call("dsa_stft_mcep_opts_fwd", x.data_ptr(), B, T_, 400, P, 512, stft.window.data_ptr(), stft.twiddle.data_ptr(), int(center),
+              int(kw.get("zmean", False)), ops.pad_mode_code(kw.get("mode", "constant")), float(stft.eps), int(rf is not None),
+              float(rf or 0.0), 24, mcep.n_iter, mcep.G.data_ptr(), mcep.D.data_ptr(), mcep.E.data_ptr(), mcep.alpha_vector.data_ptr(),
+              _lib.F32, _lib.ALGO_AUTO, images.data_ptr(), scratch.data_ptr(), mcf.data_ptr(), None, Xf.data_ptr(), ops._stream())
+    assert torch.equal(Xf, X2) and torch.equal(mcf, mc1)
+    X_ref = O.stft(host(x).astype(np.float64), 400, P, 512, center=center, zmean=kw.get("zmean", False), mode=kw.get("mode", "constant"),
+                   relative_floor=rf)
+    err = np.abs(host(X2) - X_ref) / X_ref.max(-1, keepdims=True)
+    # (2e-6 of the row maximum as everywhere; with zmean 6e-6: the float32 mean of 400 samples carries ~1e-7 of their size, which
+    #  shows at the DC bins -- measured 3.1e-6)
+    assert err.max() < (6e-6 if kw.get("zmean") else 2e-6), err.max()
+    np.testing.assert_allclose(host(mc1), O.mcep(X_ref, 24, 0.42, 10), **MC32)
+    w = torch.randn(mc1.shape, generator=torch.Generator().manual_seed(3)).to(DEV)
+    xa = x.clone().requires_grad_(True)
+    (fused(xa) * w).sum().backward()
+    assert fused.last_path == "fused"
+    xb = x.clone().requires_grad_(True)
+    (mcep(stft(xb)) * w).sum().backward()
+    assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * float(xb.grad.abs().max())
+
+
 def test_fused_contains_non_finite_samples_to_their_frames():
     x = torch.randn(2, 4000, generator=torch.Generator().manual_seed(9))
     x[0, 1000] = float("nan")
@@ -160,7 +208,7 @@ def test_fused_contains_non_finite_samples_to_their_frames():
 
 def test_fused_routes_other_configurations_to_the_two_modules():
     x = torch.randn(2, 4000, generator=torch.Generator().manual_seed(1)).to(DEV)
-    for kw in (dict(zmean=True), dict(out_format="magnitude"), dict(relative_floor=-80.0)):
+    for kw in (dict(out_format="magnitude"),):
         stft = dsp.STFT(400, 80, 512, device=DEV, **kw)
         mcep = dsp.MelCepstralAnalysis(fft_length=512, cep_order=24, alpha=0.42, n_iter=2, device=DEV)
         f = dsp.fuse(stft, mcep)
