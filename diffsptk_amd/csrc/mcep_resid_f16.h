@@ -129,9 +129,9 @@ __global__ __launch_bounds__(256, 2) DSA_PK_TARGET void mcep_resid_h_kernel(cons
     // TWO sets of sums, the even and the odd stages': added once at the end.  The one-launch kernel of round 6 (mcep_big_f16.h) gives
     // the stages of a tile to two waves alternately and adds their partial sums -- with the same order here, rt is bit-identical
     // whichever of the two runs (the host chooses by batch size: a frame's bits must not depend on that choice).
-    // (only where that kernel has an instantiation -- orders 43 .. 50: KS1 = 2, NT = 6, 7; the second set costs 28 registers and
+    // (only where that kernel has instantiations -- orders 35 .. 54: KS1 = 2, NT = 5 .. 7; the second set costs 4 NT registers and
     //  ~7 % of this kernel's time at large batches)
-    constexpr bool SPLIT = KS1 == 2 && NT >= 6;
+    constexpr bool SPLIT = KS1 == 2 && NT >= 5;
     f32x4 acc[NT], acc_odd[SPLIT ? NT : 1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = zero4;
