@@ -618,7 +618,7 @@ def compact_line(res: dict, detail_path: str = DETAIL_FILE) -> str:
         line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "threads_best", "kind", "sample")}
         if "gpu_over_cpu" in res:
             line["gpu_over_cpu"] = res["gpu_over_cpu"]
-    for name in ("single_stream", "module_api", "speech_like"):   # the drop-in call mcep(stft(x)) beside the fused step; the speech-like input
+    for name in ("two_streams", "single_stream", "module_api", "speech_like"):   # the drop-in call mcep(stft(x)) beside the fused step; the speech-like input
         if res.get(name):
             line[name] = {k: v for k, v in res[name].items() if k != "note"}
     line["detail"] = detail_path
@@ -665,12 +665,14 @@ def main():
     ap.add_argument("--chunks", type=int, default=1,
                     help="N > 1: utterance chunks per step.  1 (default): one in-place all-gather per step, deferred "
                          "behind the next step's kernels; > 1: chunked gather/compute overlap inside the step")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="consecutive steps (independent batches) alternate between this many streams.  2 (default since round 6): every "
-                         "launch carries DSA_ALGO_OVERLAPPED_LAUNCHES -- its short last round of tiles (204 800 frames = 6.25 rounds of the "
-                         "2 048 wave slots) is packed onto 64 workgroups and the other 192 CUs go to the next step's launch, which waits on "
-                         "the other stream: 6.25 rounds per step in the steady state instead of 6.8.  1: every launch runs alone (the "
-                         "figures of rounds 1-5; `single_stream` in the line is this mode measured after the timed region)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="consecutive steps (independent batches) alternate between this many streams.  1 (default): every launch runs "
+                         "alone on the chip -- the timed region of rounds 1-5, and the one whose per-launch HIP events are a kernel's own "
+                         "duration (what the roofline objects divide by).  2: every launch carries DSA_ALGO_OVERLAPPED_LAUNCHES -- its "
+                         "short last round of tiles (204 800 frames = 6.25 rounds of the 2 048 wave slots) is packed onto 64 workgroups and "
+                         "the other 192 CUs go to the next step's launch, which waits on the other stream (round 6: 0.5945 -> 0.5685 ms per "
+                         "step at 200 steps, -2 % at 20).  At N = 1 the default run measures this mode too, AFTER the timed region, and "
+                         "carries it in the line as `two_streams`")
     ap.add_argument("--record-every", type=int, default=4,
                     help="HIP events bracket the two launches of every n-th step of the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -928,7 +930,7 @@ def main():
                           "source": "profiles/r03_power_probe.txt (static: tools/power_probe.sh, rocm-smi while the kernel loops)",
                           "note": "both headline kernels run at the socket's power cap; the kernel's cycle counter averages "
                                   "1.99-2.09 GHz over a launch, so the nominal-clock peak above is not reachable"},
-            })(datapath_roofline(isa_mix("mcep_mfma_fwd_kernel_hILi8ELb1ELb0" if args.path == "fused" else "mcep_mfma_fwd_kernel_hILi8ELb0ELb0"), N_ITER, frames_launch, t_mcep)),
+            })(datapath_roofline(isa_mix("mcep_mfma_fwd_kernel_hILi8ELb1ELb0ELb0E" if args.path == "fused" else "mcep_mfma_fwd_kernel_hILi8ELb0ELb0ELb0E"), N_ITER, frames_launch, t_mcep)),
             "roofline_stft": {
                 "kernel": k_stft, "bound": "hbm",
                 "achieved": STFT_BYTES_PER_FRAME * frames_launch / t_stft / 1e9,
@@ -957,6 +959,34 @@ def main():
                             "`mcep_mfma_fwd` reads it back (1348 + 1128 algorithmic bytes per frame instead of 420)"}
             except Exception as e:
                 res["two_kernel_path"] = {"error": repr(e)}
+        if world == 1 and n_streams == 1 and args.path == "fused":
+            # the same K steps alternating between TWO streams with DSA_ALGO_OVERLAPPED_LAUNCHES (bench.py --streams 2 times this as the
+            # step): consecutive launches overlap at their ends -- more frames per second, while a launch's own [start, end] no longer
+            # is its duration on the chip, which is why the timed region above (and `value`) stay single-stream
+            try:
+                s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+                for s_ in s2:
+                    s_.wait_stream(main_stream)
+                with torch.no_grad():
+                    def ov(i):
+                        with torch.cuda.stream(s2[i % 2]), ops.overlapped_launches():
+                            return compute(x)
+                    for i in range(40):   # (the two new streams' first launches carry one-off costs -- per-stream scratch, queue set-up:
+                        ov(i)             #  with 6 warm-up steps a 20-step region measured 0.65 ms per step, 0.58 with the region run first)
+                    torch.cuda.synchronize()
+                    gc.disable()
+                    t2 = time.perf_counter()
+                    for i in range(args.steps):
+                        ov(i)
+                    torch.cuda.synchronize()
+                    el2 = time.perf_counter() - t2
+                    gc.enable()
+                res["two_streams"] = {"ms_per_step": el2 / args.steps * 1e3, "value": frames_rank * args.steps / el2, "unit": "frames/s",
+                                      "steps": args.steps,
+                                      "note": "--streams 2: consecutive steps on alternating streams, DSA_ALGO_OVERLAPPED_LAUNCHES (a launch's short "
+                                              "last round on 64 workgroups, the other CUs to the next launch); measured after the timed region"}
+            except Exception as e:
+                res["two_streams"] = {"error": repr(e)}
         if world == 1 and n_streams > 1:
             # the same K steps WITHOUT the overlap: one stream, every launch alone on the chip (the timed region of rounds 1-5)
             with torch.no_grad():

@@ -1,6 +1,6 @@
-# default bench (as the driver runs it) + kernel trace + PMC passes; outputs under gpurun_out/$1; ROUND (default r05) names the
+# default bench (as the driver runs it) + kernel trace + PMC passes; outputs under gpurun_out/$1; ROUND (default r06) names the
 # profile files the traffic record points at (copy gpurun_out/$1/pmc_<what>.txt to profiles/${ROUND}_pmc_<what>_$1.txt)
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 OUT=gpurun_out/$1
 mkdir -p $OUT
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err
@@ -19,6 +19,8 @@ bash tools/pmc_passes.sh $1/pmc_sbwd stftbwd
 bash tools/pmc_passes.sh $1/pmc_lpc lpc
 bash tools/pmc_passes.sh $1/pmc_lpcbwd lpcbwd
 bash tools/pmc_passes.sh $1/pmc_fusedmcep fusedmcep
+bash tools/pmc_passes.sh $1/pmc_k48 k48
+python tools/pmc_summary.py $OUT/pmc_k48 > $OUT/pmc_k48.txt 2>&1
 bash tools/gpu_trace.sh tools/run_stft_bwd_only.py $1/sbwd_trace > /dev/null 2>&1
 python tools/pmc_summary.py $OUT/pmc_fwd > $OUT/pmc_fwd.txt 2>&1
 python tools/pmc_summary.py $OUT/pmc_bwd > $OUT/pmc_bwd.txt 2>&1
