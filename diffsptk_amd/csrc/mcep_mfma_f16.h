@@ -102,11 +102,16 @@ static_assert(FU_TWS % 4 == 0 && H_WAVE % 4 == 0 && WAVE_FLOATS % 4 == 0, "16-by
 constexpr int h_lds_floats_fused(int waves) { return h_lds_floats(waves) + FU_FLOATS; }
 }  // namespace mh
 
-// The fused prologue's arithmetic, per stage on the packed (v_pk_*_f32) or the scalar forms of pk_math.h.  The product builds every
-// stage on the scalar forms (mask 0).  DSA_FUSED_PK_MASK re-creates the failing variants for the reduction of
-// tools/hazard_matrix.sh: bit 0 window multiply, 1 first 16-point FFT, 2 the W256 twiddles, 3 second 16-point FFT, 4 real-FFT split.
+// The fused prologue's arithmetic, per stage on the packed (v_pk_*_f32) or the scalar forms of pk_math.h: bit 0 window multiply,
+// 1 first 16-point FFT, 2 the W256 twiddles, 3 second 16-point FFT, 4 real-FFT split.
+// Rounds 4-5 shipped every stage on the scalar forms (mask 0): with the packed helpers of those rounds ~58-170 of 204 800 frames per
+// launch came out wrong.  Round 6 found the cause stand-alone (tools/hazard/repro_min.cpp): a packed float32 form with a
+// SET op_sel bit fails next to the 16-bit-input matrix products of the SIMD's other wave; forms without one never do.  The helpers
+// no longer contain such a form (DSA_PK_CROSSED = 0: the rotations, the complex product's second instruction and the split's sums are
+// one-component instructions), so the packed stages are back: mask 31, 0.5891 -> 0.5811 ms per 204 800 frames, 0 wrong frames in 300
+// launches of tools/hazard/hazard_check.py (profiles/r06_fused_prologue_packed_again.txt); bit-identical to mask 0 by construction.
 #ifndef DSA_FUSED_PK_MASK
-#define DSA_FUSED_PK_MASK 0
+#define DSA_FUSED_PK_MASK 31
 #endif
 #ifndef DSA_FUSED_DBG
 #define DSA_FUSED_DBG 0   // reduction builds: 1 no matrix chains, 2 no solve, 4 no back substitution, 8 self-check of the first FFT (log in `hist`)
