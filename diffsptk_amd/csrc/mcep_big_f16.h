@@ -188,8 +188,9 @@ __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __
             // barriers the group's first wave runs the even stage, its second wave the odd one -- concurrently.  (First 8-wave cut:
             // one stage per barrier, the waves alternating -- a stage's arithmetic never overlapped the next one's: 1.05 ms.)
             const int npair = (nstage + 1) / 2;
-            f32x4 st0[PER];   // ONE register set: a pair's images are requested one pair ahead (two sets ahead did not fit 256 registers
-                              // next to the hoisted image reads of a stage: the staged pieces went through scratch, 154 k cycles per step)
+            f32x4 st0[PER];   // ONE register set: a pair's images are requested one pair ahead.  (Two sets, two pairs ahead, do not fit
+                              // 256 registers next to the hoisted image reads of a stage: 62 scratch accesses inside the loop.  Stamps of a
+                              // step, cycles: head 4-19 k, this loop 67 k (17 pairs), rows + records 6 k, the solve 50-62 k.)
             auto fetch = [&](int ip, f32x4 (&sv)[PER]) __attribute__((always_inline)) {   // stages 2 ip, 2 ip + 1: 2 PIECES pieces
 #pragma unroll
                 for (int q = 0; q < PER; ++q) {
@@ -362,6 +363,7 @@ __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __
                 // staged image pieces went through scratch (154 k cycles per step); behind a call boundary nothing of the stage loop
                 // is live here and nothing of the elimination is live there
                 big_solve8<NG, NMIN>((mbg::lds_f*)wl, (mbg::lds_f*)(mcs + 8 * hsel * MS), M1);
+                BIG_STAMP(5);
             }
         }
         // ---- the result: the group's rows of mc, eight per wave ----
