@@ -29,30 +29,35 @@ namespace dsa {
 namespace mbg {
 constexpr int PAIRS = 4;    // 16-frame groups per workgroup
 constexpr int WAVES = 8;    // two waves per group
-template <int NG>
+// the solver's LDS record of a system: octet layout (orders 35 .. 54: thsolve_octn_kernel, 8 systems per wave) or -- QUAD -- the quad
+// layout (orders up to 34: thsolve_quadn_kernel, 16 systems per wave)
+template <int NG, bool QUAD = false>
 struct Geo {
     using O = tq::Oct<NG>;
     static constexpr int NCP = O::NCP;
     static constexpr int CN = 4 * NG - 1;
-    static constexpr int QW = 4 * NG + 8 * NCP - 1;
-    static constexpr int PO = QW + 7;
-    static constexpr int RO = PO + 8 * NCP;
-    static constexpr int REC = ((RO + 4 * NG - 8 + 31) / 32) * 32 + 8;   // as thsolve_octn_kernel: stride 8 (mod 32)
+    static constexpr int QW = QUAD ? 8 * NG - 1 : 4 * NG + 8 * NCP - 1;
+    static constexpr int BACK = QUAD ? 3 : 7;                             // how far a block's views reach below the diagonal
+    static constexpr int PO = QW + BACK;
+    static constexpr int RO = QUAD ? QW + 4 * NG + 3 : PO + 8 * NCP;
+    static constexpr int REC = QUAD ? ((16 * NG + 3 - 4 + 31) / 32) * 32 + 4     // as thsolve_quadn_kernel: stride 4 (mod 32)
+                                    : ((RO + 4 * NG - 8 + 31) / 32) * 32 + 8;    // as thsolve_octn_kernel: stride 8 (mod 32)
+    static constexpr int SYS = QUAD ? 16 : 8;                             // systems a solving wave takes
     static constexpr int MS = 4 * NG + 4;                                 // row stride of the LDS copy of mc (floats, 16-byte rows)
 };
 constexpr int rts(int nt) { return 16 * nt + 4; }   // row stride of the rt rows parked in LDS between the products and the solve (floats)
 // the region the four staging buffers (two stage pairs, SH halves per stage = 2 SH floats together) share with the parked rt rows of
 // the four groups and the eight waves' records -- all of them idle while the other is in use
-template <int KS1, int NT, int NG>
+template <int KS1, int NT, int NG, bool QUAD = false>
 constexpr int stage_floats()
 {
-    constexpr int sh = 2 * mrh::stage_halves(KS1, NT), solve = PAIRS * 16 * rts(NT) + WAVES * 8 * Geo<NG>::REC;
+    constexpr int sh = 2 * mrh::stage_halves(KS1, NT), solve = PAIRS * 16 * rts(NT) + PAIRS * 16 * Geo<NG, QUAD>::REC;   // 64 records either way
     return sh > solve ? sh : solve;
 }
-template <int KS1, int NT, int NG>
+template <int KS1, int NT, int NG, bool QUAD = false>
 constexpr int lds_floats()
 {
-    return stage_floats<KS1, NT, NG>() + PAIRS * 16 * Geo<NG>::MS + 64;
+    return stage_floats<KS1, NT, NG, QUAD>() + PAIRS * 16 * Geo<NG, QUAD>::MS + 64;
 }
 }  // namespace mbg
 
@@ -122,25 +127,80 @@ __device__ __attribute__((noinline)) void big_solve8(mbg::lds_f* wl, mbg::lds_f*
     }
 }
 
-template <int KS1, int NT, int NG, int NMIN>
+// Sixteen systems of the records `wl` solved in the QUAD layout (thsolve_quadn_kernel's construction, elimination, back substitution and
+// pivoted re-solve; orders up to 34), the solutions ADDED to the sixteen rows `mrow16` of the LDS copy of mc.
+template <int NG, int NMIN>
+__device__ __attribute__((noinline)) void big_solve16q(mbg::lds_f* wl, mbg::lds_f* mrow16, int M1)
+{
+    using G = mbg::Geo<NG, true>;
+    using B = tq::Blk<NG>;
+    constexpr int CN = G::CN, PO = G::PO, RO = G::RO, REC = G::REC, MS = G::MS;
+    const int ln = threadIdx.x & 63;
+    const int nq = ln >> 2, gs = ln & 3;
+    const mbg::lds_f* qs = wl + nq * REC + gs;        // this lane's views: column offset gs folded in
+    const mbg::lds_f* pw = qs + PO;
+    const mbg::lds_f* rs = wl + nq * REC + RO;
+    f32x4 a[B::N];
+#pragma unroll
+    for (int rg = 0; rg < NG; ++rg) {
+#pragma unroll
+        for (int cg = rg; cg < NG; ++cg) {
+            const bool cin = 4 * cg + 3 < NMIN || 4 * cg + gs < M1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 4 * rg + i;
+                float v = pw[4 * (cg - rg) - i] + qs[4 * (rg + cg) + i];
+                if (4 * cg + 3 >= NMIN) v = cin ? v : 0.f;
+                if (cg == rg && row >= NMIN && row < CN) v = (gs == i && row >= M1) ? 1.f : v;
+                if (cg == NG - 1) v = gs == 3 ? rs[row] : v;
+                a[B::at(rg, cg)][i] = v;
+            }
+        }
+    }
+    bool bad = false;
+    tq::elim_all<NG>(a, gs, bad, std::make_integer_sequence<int, CN>{});
+    float xq[NG];
+#pragma unroll
+    for (int c = 0; c < NG; ++c) xq[c] = (4 * c + gs == CN) ? -1.f : 0.f;
+    tq::backsub_all<NG>(a, xq, gs, std::make_integer_sequence<int, NG>{});
+    mbg::lds_f* mrow = mrow16 + nq * MS;
+#pragma unroll
+    for (int c = 0; c < NG; ++c) {
+        const int col = 4 * c + gs;
+        if (col < M1 && !bad) mrow[col] += xq[c];                                // mcep.py:222
+    }
+    unsigned long long marked = __ballot(bad && gs == 0);
+    while (marked) {   // uniform; normally empty: the whole wave re-solves the system with row pivoting (th_solve_reg.h)
+        const int bl_ = __builtin_ctzll(marked);
+        marked &= marked - 1;
+        const int sb = bl_ >> 2;
+        const float* qs2 = (const float*)(wl + sb * REC);   // (flat view of the LDS record for the cold path)
+        const float* ps2 = qs2 + PO;
+        const float rhs = ln < M1 ? qs2[RO + ln] : 0.f;
+        int col;
+        float sol;
+        th_solve_reg<float, CN <= 32 ? 32 : (CN <= 48 ? 48 : 64)>(ps2, qs2, rhs, M1, ln, col, sol);
+        if (ln < M1) mrow16[sb * MS + col] += sol;
+    }
+}
+
+template <int KS1, int NT, int NG, int NMIN, bool QUAD = false>   // QUAD: orders up to 34 -- the group's first wave solves all 16 systems
 __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __restrict__ logx, long F, int K, const float* __restrict__ mc_in,
                                                                  int M1, const _Float16* __restrict__ img, const float* __restrict__ av,
                                                                  int n_iter, float* __restrict__ mc_out)
 {
     using namespace mrh;
-    using G = mbg::Geo<NG>;
-    using O = tq::Oct<NG>;
+    using G = mbg::Geo<NG, QUAD>;
     constexpr int NTH = mbg::WAVES * 64;
     constexpr int SH = stage_halves(KS1, NT);
     constexpr int PIECES = SH / 8;
     constexpr int PER = (2 * PIECES + NTH - 1) / NTH;      // a stage PAIR per staging step
-    constexpr int NCP = G::NCP, CN = G::CN, PO = G::PO, RO = G::RO, REC = G::REC, MS = G::MS;
-    constexpr int CPN = (NG - 1) >> 1, HN = (NG - 1) & 1;   // where column CN (the right-hand side) lives
+    constexpr int PO = G::PO, RO = G::RO, REC = G::REC, MS = G::MS, SYS = G::SYS, BACK = G::BACK;
     constexpr int RTS = mbg::rts(NT);
     extern __shared__ __attribute__((aligned(16))) float smem_big[];
     _Float16* sbuf0 = reinterpret_cast<_Float16*>(smem_big);   // [2 sets][2 stages of a pair][SH halves] = 2 SH floats
     float* recs_all = smem_big + mbg::PAIRS * 16 * RTS;          // the records and the parked rt rows live INSIDE the staging buffers
-    float* mcs_all = smem_big + mbg::stage_floats<KS1, NT, NG>();
+    float* mcs_all = smem_big + mbg::stage_floats<KS1, NT, NG, QUAD>();
     float* avs = mcs_all + mbg::PAIRS * 16 * MS;            // [64]: alpha_vec, zero-padded
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,7 +209,7 @@ __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __
     const int nstage = (K + 31) / 32;
     const int N = 2 * M1 - 1;
     float* mcs = mcs_all + pair * 16 * MS;
-    float* wl = recs_all + wave * 8 * REC;                   // this wave's eight records
+    float* wl = recs_all + (QUAD ? pair * 16 : wave * 8) * REC;   // this wave's records (QUAD: the group's 16, solved by its first wave)
     float* park = smem_big + pair * 16 * RTS;                // the group's rt rows (inside the staging buffers, idle during the solve)
     const f32x4* img4 = reinterpret_cast<const f32x4*>(img);
     if (tid < 64) avs[tid] = tid < M1 ? av[tid] : 0.f;
@@ -333,25 +393,25 @@ __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __
             __syncthreads();
             BIG_STAMP(3);
             // ================= mc += solve(T(rt[:n]) + H(rt), rt[:n] - alpha_vec): eight systems per wave =================
-            if (tile_ok) {
+            if (tile_ok && (!QUAD || hsel == 0)) {
                 int ln = lane;
                 asm volatile("" : "+v"(ln));   // (lane-derived values re-derived here: see thsolve_octn_kernel)
                 {
                     f32x4* z4 = reinterpret_cast<f32x4*>(wl);
-                    for (int e = ln; e < 8 * REC / 4; e += 64) z4[e] = zero4;
+                    for (int e = ln; e < SYS * REC / 4; e += 64) z4[e] = zero4;
                 }
                 __builtin_amdgcn_wave_barrier();
                 {
-                    const int s0 = (ln >> 4) * 2;                                            // lane -> (two records, 16 columns apart)
-                    for (int s_ = s0; s_ < s0 + 2; ++s_) {
+                    const int s0 = (ln >> 4) * (SYS / 4);                                    // lane -> (SYS / 4 records, 16 columns apart)
+                    for (int s_ = s0; s_ < s0 + SYS / 4; ++s_) {
                         float* rec = wl + s_ * REC;
-                        const float* prow = park + (8 * hsel + s_) * RTS;
+                        const float* prow = park + ((QUAD ? 0 : 8 * hsel) + s_) * RTS;
                         for (int col = ln & 15; col < N; col += 16) {
                             const float v = prow[col];
                             rec[col] = v;                                                    // q window: q[k] at k
                             if (col < M1) {
                                 rec[PO + col] = v;                                           // p window: p[|d|] at PO + d
-                                if (col >= 1 && col <= 7) rec[PO - col] = v;
+                                if (col >= 1 && col <= BACK) rec[PO - col] = v;
                                 rec[RO + col] = v - avs[col];                                // right-hand side
                             }
                         }
@@ -362,7 +422,8 @@ __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __
                 // the solve is a FUNCTION CALL: inlined, its 220-register matrix set the whole kernel's allocation and the stage loop's
                 // staged image pieces went through scratch (154 k cycles per step); behind a call boundary nothing of the stage loop
                 // is live here and nothing of the elimination is live there
-                big_solve8<NG, NMIN>((mbg::lds_f*)wl, (mbg::lds_f*)(mcs + 8 * hsel * MS), M1);
+                if constexpr (QUAD) big_solve16q<NG, NMIN>((mbg::lds_f*)wl, (mbg::lds_f*)mcs, M1);
+                else big_solve8<NG, NMIN>((mbg::lds_f*)wl, (mbg::lds_f*)(mcs + 8 * hsel * MS), M1);
                 BIG_STAMP(5);
             }
         }

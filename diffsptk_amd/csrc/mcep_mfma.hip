@@ -704,14 +704,15 @@ int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, 
     return mcep_mfma_fwd(nullptr, B * N, n_iter, G, D, E, av, images, scratch, mc, hist, st, scratch_clean, &sti, hist_has_rt, overlapped);
 }
 
-// mcep.py:208-222, all n_iter steps in one persistent launch, for the orders the octet-layout solver covers (35 .. 54: the 48 kHz
-// set-up fft_length 2048 / order 49 and its neighbours); DSA_ERR_UNSUPPORTED (no error text) otherwise --
+// mcep.py:208-222, all n_iter steps in one persistent launch, for orders 32 .. 54 (the 48 kHz set-ups fft_length 2048 / order 49 and
+// 1024 / order 34 among them); DSA_ERR_UNSUPPORTED (no error text) otherwise --
 // the caller then runs the step as two launches.  `images`: dsa_mcep_resid_prepare's.
 int mcep_big_newton(const void* logx, int64_t F, int K, const void* mc_in, int M1, const void* images, const void* av, int n_iter,
                     void* mc_out, hipStream_t st)
 {
     const int ks1 = (M1 + 31) / 32, nt = (2 * M1 - 1 + 15) / 16;
-    if (!(ks1 == 2 && M1 >= 36 && M1 <= 55 && K >= 4)) return DSA_ERR_UNSUPPORTED;   // the orders of the octet-layout solver: 35 .. 54
+    // the orders of the octet-layout solver, 35 .. 54, and -- quad layout -- 32 .. 34 (the 48 kHz set-up fft_length 1024 / order 34)
+    if (!(ks1 == 2 && M1 >= 33 && M1 <= 55 && K >= 4)) return DSA_ERR_UNSUPPORTED;
     static const bool off = [] { const char* e = getenv("DSA_MCEP_BIG"); return e && e[0] == '0'; }();   // A/B: the two-launch step
     if (off) return DSA_ERR_UNSUPPORTED;
     const long tiles = (long)((F + 63) / 64);
@@ -729,8 +730,16 @@ int mcep_big_newton(const void* logx, int64_t F, int K, const void* mc_in, int M
         hipLaunchKernelGGL((mcep_big_newton_kernel<2, NTV, NGV, NMINV>), dim3((unsigned)grid), dim3(512), lds_b, st, (const float*)logx, \
                            (long)F, K, (const float*)mc_in, M1, (const _Float16*)images, (const float*)av, n_iter, (float*)mc_out);      \
     } while (0)
-    // (M1 = order + 1; the solver's instantiations as thsolve_quadn_fwd picks them: <11,36> up to 43, <13,44> up to 51, <14,52>)
-    if (M1 <= 43) {
+    // (M1 = order + 1; the solver's instantiations as thsolve_quadn_fwd picks them: quad <9,28> up to 35, <11,36> up to 43, <13,44> up to
+    //  51, <14,52>)
+    if (M1 <= 35) {
+        constexpr int lds_q = mbg::lds_floats<2, 5, 9, true>() * 4;
+        static std::atomic<uint64_t> attr_q{0};
+        if (!ensure_dynamic_lds((const void*)mcep_big_newton_kernel<2, 5, 9, 28, true>, lds_q, attr_q))
+            return fail(DSA_ERR_LAUNCH, "mcep_big_newton: cannot reserve LDS%s");
+        hipLaunchKernelGGL((mcep_big_newton_kernel<2, 5, 9, 28, true>), dim3((unsigned)grid), dim3(512), lds_q, st, (const float*)logx, (long)F, K,
+                           (const float*)mc_in, M1, (const _Float16*)images, (const float*)av, n_iter, (float*)mc_out);
+    } else if (M1 <= 43) {
         if (nt == 5) DSA_BIG_NEWTON(5, 11, 36);
         else DSA_BIG_NEWTON(6, 11, 36);
     } else if (M1 <= 51) {

@@ -659,7 +659,7 @@ DSA_EXPORT int dsa_mcep_newton_steps(const void* logx, int64_t F, int32_t K, con
     if (dtype != DSA_F32) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_steps: float32 only%s");
     if (F == 0) return DSA_OK;
     const int rc = dsa::mcep_big_newton(logx, F, K, mc_in, n, images, alpha_vec, n_iter, mc_out, (hipStream_t)stream);
-    if (rc == DSA_ERR_UNSUPPORTED) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_steps: no one-launch kernel for this order (35 .. 54)%s");
+    if (rc == DSA_ERR_UNSUPPORTED) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_steps: no one-launch kernel for this order (32 .. 54)%s");
     return rc;
 }
 

@@ -974,9 +974,9 @@ def mcep_newton_resid_h(logx, mc, images):
 
 
 def mcep_newton_steps_applies(M1: int) -> bool:
-    """dsa_mcep_newton_steps has an instantiation for this order (35 .. 54: the orders of the octet-layout solver, among them the
-    48 kHz set-up fft_length 2048 / order 49; DSA_MCEP_BIG=0: the two-launch step, for A/B runs)."""
-    return 36 <= M1 <= 55 and os.environ.get("DSA_MCEP_BIG", "1") != "0"
+    """dsa_mcep_newton_steps has an instantiation for this order (32 .. 54, among them the 48 kHz set-ups fft_length 2048 / order 49
+    and 1024 / order 34; DSA_MCEP_BIG=0: the two-launch step, for A/B runs)."""
+    return 33 <= M1 <= 55 and os.environ.get("DSA_MCEP_BIG", "1") != "0"
 
 
 def mcep_newton_steps(logx, mc0, images, av, n_iter):

@@ -298,8 +298,8 @@ int dsa_mcep_resid_prepare(const void* D, int32_t ldd, const void* E, int32_t ld
                            void* stream);
 /* (0.2.0) ALL n_iter Newton steps of mcep.py:208-222 in ONE persistent launch (csrc/mcep_big_f16.h): per step the two products of
  * dsa_mcep_newton_resid_h (same images, bit-identical rt) and the solve-and-update of dsa_mcep_newton_update, rt and mc staying on
- * chip; mc_in:(F, n) the start (mc0 = logx G), mc_out:(F, n) (may be mc_in).  Orders n - 1 in 35 .. 54 (the 48 kHz set-up fft_length
- * 2048 / order 49 among them); DSA_ERR_UNSUPPORTED otherwise -- alternate dsa_mcep_newton_resid_h and dsa_mcep_newton_update then. */
+ * chip; mc_in:(F, n) the start (mc0 = logx G), mc_out:(F, n) (may be mc_in).  Orders n - 1 in 32 .. 54 (the 48 kHz set-ups fft_length
+ * 2048 / order 49 and 1024 / order 34 among them); DSA_ERR_UNSUPPORTED otherwise -- alternate dsa_mcep_newton_resid_h and dsa_mcep_newton_update then. */
 int dsa_mcep_newton_steps(const void* logx, int64_t F, int32_t K, const void* mc_in, int32_t n, const void* images, const void* alpha_vec,
                           int32_t n_iter, int32_t dtype, void* mc_out, void* stream);
 int dsa_mcep_newton_resid_h(const void* logx, int64_t F, int32_t K, const void* mc, int32_t n, const void* images, int32_t dtype,

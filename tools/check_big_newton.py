@@ -13,7 +13,7 @@ def timeit(fn, n=10):
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n * 1e3
 g = torch.Generator().manual_seed(0)
 bad = 0
-for M in (49, 43, 46, 50):
+for M in (49, 34, 32, 46):
     for F in (1, 15, 64, 65, 3217, 12800):
         X = (torch.randn(F, 1025, generator=g).square() + 0.05).to(dev)
         for n_iter in (1, 2, 10):
@@ -37,7 +37,16 @@ with torch.no_grad():
         y = m32(X)
         print(f"DSA_MCEP_BIG={flag}: {_lib.last_kernel()} max |f32 - f64| = {float((y.double() - y64).abs().max()):.3e}")
 os.environ["DSA_MCEP_BIG"] = "2"
-for B in (1, 4, 16, 64, 100, 128, 200, 512):
+m34 = dsp.MelCepstralAnalysis(fft_length=1024, cep_order=34, alpha=0.55, n_iter=10, device=dev)
+for B in (64, 512):
+    x = torch.randn(B, 48000, generator=g).to(dev)
+    with torch.no_grad():
+        X = dsp.STFT(800, 200, 1024, device=dev)(x)
+        for flag in ("0", "2", "0", "2"):
+            os.environ["DSA_MCEP_BIG"] = flag
+            t = timeit(lambda: m34(X), 5)
+            print(f"1024 / 34: B={B} ({X.shape[0] * X.shape[1]} frames) DSA_MCEP_BIG={flag}: {t:.1f} us per analysis ({_lib.last_kernel()})")
+for B in (64, 512):
     x = torch.randn(B, 48000, generator=g).to(dev)
     with torch.no_grad():
         X = dsp.STFT(1200, 240, 2048, device=dev)(x)
