@@ -48,16 +48,20 @@ struct Geo {
 constexpr int rts(int nt) { return 16 * nt + 4; }   // row stride of the rt rows parked in LDS between the products and the solve (floats)
 // the region the four staging buffers (two stage pairs, SH halves per stage = 2 SH floats together) share with the parked rt rows of
 // the four groups and the eight waves' records -- all of them idle while the other is in use
-template <int KS1, int NT, int NG, bool QUAD = false>
+// WIDE (see the kernel): EIGHT 16-frame groups per workgroup, one per wave.  The parked rows are then 128; the records stay 64 in the
+// octet layout (a wave solves its 16 systems in two rounds of 8) and become 128 in the quad layout (16 per wave at once).
+constexpr int groups(bool wide) { return wide ? WAVES : PAIRS; }
+template <int KS1, int NT, int NG, bool QUAD = false, bool WIDE = false>
 constexpr int stage_floats()
 {
-    constexpr int sh = 2 * mrh::stage_halves(KS1, NT), solve = PAIRS * 16 * rts(NT) + PAIRS * 16 * Geo<NG, QUAD>::REC;   // 64 records either way
+    constexpr int sh = 2 * mrh::stage_halves(KS1, NT);
+    constexpr int solve = groups(WIDE) * 16 * rts(NT) + (QUAD ? groups(WIDE) * 16 : WAVES * 8) * Geo<NG, QUAD>::REC;
     return sh > solve ? sh : solve;
 }
-template <int KS1, int NT, int NG, bool QUAD = false>
+template <int KS1, int NT, int NG, bool QUAD = false, bool WIDE = false>
 constexpr int lds_floats()
 {
-    return stage_floats<KS1, NT, NG, QUAD>() + PAIRS * 16 * Geo<NG, QUAD>::MS + 64;
+    return stage_floats<KS1, NT, NG, QUAD, WIDE>() + groups(WIDE) * 16 * Geo<NG, QUAD>::MS + 64;
 }
 }  // namespace mbg
 
@@ -184,7 +188,14 @@ __device__ __attribute__((noinline)) void big_solve16q(mbg::lds_f* wl, mbg::lds_
     }
 }
 
-template <int KS1, int NT, int NG, int NMIN, bool QUAD = false>   // QUAD: orders up to 34 -- the group's first wave solves all 16 systems
+// WIDE (second cut of the round): EIGHT 16-frame groups per workgroup -- every wave keeps its OWN 16 frames and runs BOTH stages of a
+// staged pair (two accumulator sets, even and odd stages, added at the end: the same sums in the same order as the two waves of a
+// narrow group, the same bits), then solves its 16 systems itself (octet layout: two rounds of 8).  The narrow kernel is a LATENCY
+// design (a tile's step as short as possible: small batches are one round of tiles); at more than one round of tiles what counts is
+// frames per staged image byte and per barrier -- the same 17 stage pairs, barriers and LDS staging now serve 128 frames, nothing is
+// exchanged between waves, and in the quad layout (orders up to 34) no wave idles through the solve.  Chosen by the batch size
+// (mcep_big_newton); both give the same bits (tests/test_gpu_configs.py).
+template <int KS1, int NT, int NG, int NMIN, bool QUAD = false, bool WIDE = false>   // QUAD: orders up to 34 -- narrow: the group's first wave solves all 16 systems
 __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __restrict__ logx, long F, int K, const float* __restrict__ mc_in,
                                                                  int M1, const _Float16* __restrict__ img, const float* __restrict__ av,
                                                                  int n_iter, float* __restrict__ mc_out)
@@ -192,45 +203,51 @@ __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __
     using namespace mrh;
     using G = mbg::Geo<NG, QUAD>;
     constexpr int NTH = mbg::WAVES * 64;
+    constexpr int GROUPS = mbg::groups(WIDE);              // 16-frame groups per workgroup
+    constexpr int NSTG = WIDE ? 2 : 1;                     // stages of a pair a wave runs
+    constexpr int RPW = WIDE ? 16 : 8;                     // rows of mc a wave moves in / out
     constexpr int SH = stage_halves(KS1, NT);
     constexpr int PIECES = SH / 8;
     constexpr int PER = (2 * PIECES + NTH - 1) / NTH;      // a stage PAIR per staging step
     constexpr int PO = G::PO, RO = G::RO, REC = G::REC, MS = G::MS, SYS = G::SYS, BACK = G::BACK;
     constexpr int RTS = mbg::rts(NT);
+    constexpr int ROUNDS = (WIDE && !QUAD) ? 2 : 1;        // solves per wave and step
     extern __shared__ __attribute__((aligned(16))) float smem_big[];
     _Float16* sbuf0 = reinterpret_cast<_Float16*>(smem_big);   // [2 sets][2 stages of a pair][SH halves] = 2 SH floats
-    float* recs_all = smem_big + mbg::PAIRS * 16 * RTS;          // the records and the parked rt rows live INSIDE the staging buffers
-    float* mcs_all = smem_big + mbg::stage_floats<KS1, NT, NG, QUAD>();
-    float* avs = mcs_all + mbg::PAIRS * 16 * MS;            // [64]: alpha_vec, zero-padded
+    float* recs_all = smem_big + GROUPS * 16 * RTS;          // the records and the parked rt rows live INSIDE the staging buffers
+    float* mcs_all = smem_big + mbg::stage_floats<KS1, NT, NG, QUAD, WIDE>();
+    float* avs = mcs_all + GROUPS * 16 * MS;                // [64]: alpha_vec, zero-padded
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pair = wave & 3, hsel = wave >> 2;             // the 16-frame group; which half of its stages / systems this wave takes
+    const int pair = WIDE ? wave : (wave & 3), hsel = WIDE ? 0 : (wave >> 2);   // the 16-frame group; narrow: which half of its stages / systems this wave takes
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int nstage = (K + 31) / 32;
     const int N = 2 * M1 - 1;
     float* mcs = mcs_all + pair * 16 * MS;
-    float* wl = recs_all + (QUAD ? pair * 16 : wave * 8) * REC;   // this wave's records (QUAD: the group's 16, solved by its first wave)
+    float* wl = recs_all + ((QUAD ? pair * 16 : wave * 8)) * REC;   // this wave's records (narrow QUAD: the group's 16, solved by its first wave)
     float* park = smem_big + pair * 16 * RTS;                // the group's rt rows (inside the staging buffers, idle during the solve)
     const f32x4* img4 = reinterpret_cast<const f32x4*>(img);
     if (tid < 64) avs[tid] = tid < M1 ? av[tid] : 0.f;
-    const long ntiles = (F + 63) / 64;
+    const long ntiles = (F + 16 * GROUPS - 1) / (16 * GROUPS);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long t16 = (tile * mbg::PAIRS + pair) * 16;    // uniform
+        const long t16 = (tile * GROUPS + pair) * 16;    // uniform
         const bool tile_ok = t16 < F;
         const long tb = tile_ok ? t16 : 0;
         const int rows_here = (int)((F - tb < 16) ? F - tb : 16);
         __syncthreads();   // the previous tile's result rows have left the LDS copy of mc
-        // ---- the group's 16 rows of mc into LDS, eight per wave (rows past the batch repeat the last one: finite, never stored) ----
-        for (int e = (tid & 63); e < 8 * MS; e += 64) {
+        // ---- the group's 16 rows of mc into LDS, RPW per wave (rows past the batch repeat the last one: finite, never stored) ----
+        for (int e = (tid & 63); e < RPW * MS; e += 64) {
             const int row = 8 * hsel + e / MS, col = e % MS;
             const int rr = row < rows_here ? row : rows_here - 1;
             mcs[row * MS + col] = col < M1 ? mc_in[(tb + rr) * (long)M1 + col] : 0.f;
         }
 #ifdef DSA_BIG_STAMPS   // (measurement builds: cycle stamps of wave 0 / wave 4 of workgroup 0 in step 2, returned in mc_out's first rows)
-        long long tsv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        long long tsv[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define BIG_STAMP(i) do { if (step == 2) tsv[i] = __builtin_readcyclecounter(); } while (0)
+#define BIG_STAMP_P(i) do { if (step == 2 && ip == 4) tsv[i] = __builtin_readcyclecounter(); } while (0)   // inside pair 4
 #else
 #define BIG_STAMP(i)
+#define BIG_STAMP_P(i)
 #endif
         for (int step = 0; step < n_iter; ++step) {
             BIG_STAMP(0);
@@ -245,8 +262,9 @@ __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __
             const float* xt = logx + tb * (long)K + (long)rn * K;
             // ================= rt = exp(logx - 2 mc D) E: the stage body of mcep_resid_h_kernel, two stages per barrier =================
             // A stage PAIR (2 i, 2 i + 1) is staged together (four buffers: the pair in use, the pair being written); between two
-            // barriers the group's first wave runs the even stage, its second wave the odd one -- concurrently.  (First 8-wave cut:
-            // one stage per barrier, the waves alternating -- a stage's arithmetic never overlapped the next one's: 1.05 ms.)
+            // barriers the group's first wave runs the even stage, its second wave the odd one -- concurrently (WIDE: the group's one
+            // wave runs both).  (First 8-wave cut: one stage per barrier, the waves alternating -- a stage's arithmetic never
+            // overlapped the next one's: 1.05 ms.)
             const int npair = (nstage + 1) / 2;
             f32x4 st0[PER];   // ONE register set: a pair's images are requested one pair ahead.  (Two sets, two pairs ahead, do not fit
                               // 256 registers next to the hoisted image reads of a stage: 62 scratch accesses inside the loop.  Stamps of a
@@ -293,21 +311,26 @@ __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __
                 }
                 k1 = -s_b - LOG2_SD;
             }
-            f32x4 acc[NT];
+            f32x4 acc[NSTG][NT];   // (WIDE: [0] the even stages' sums, [1] the odd stages')
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = zero4;
-            // the lane's log-spectrum values of ITS stage of a pair (2 ip + hsel), requested two pairs ahead
-            f32x4 x0[2], x1[2];
-            auto xfetch = [&](int ip, f32x4 (&xr)[2]) __attribute__((always_inline)) {
-                const int j = 2 * ip + hsel;
+            for (int hs = 0; hs < NSTG; ++hs)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int b0 = 32 * j + 16 * t + 4 * g;
-                    if (b0 + 3 < K) {
-                        xr[t] = *reinterpret_cast<const f32x4_u4*>(xt + b0);
-                    } else {
+                for (int t = 0; t < NT; ++t) acc[hs][t] = zero4;
+            // the lane's log-spectrum values of ITS stage(s) of a pair (narrow: 2 ip + hsel), requested two pairs ahead
+            f32x4 x0[NSTG][2], x1[NSTG][2];
+            auto xfetch = [&](int ip, f32x4 (&xr)[NSTG][2]) __attribute__((always_inline)) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) xr[t][r] = xt[b0 + r < K ? b0 + r : K - 1];
+                for (int hs = 0; hs < NSTG; ++hs) {
+                    const int j = 2 * ip + (WIDE ? hs : hsel);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int b0 = 32 * j + 16 * t + 4 * g;
+                        if (b0 + 3 < K) {
+                            xr[hs][t] = *reinterpret_cast<const f32x4_u4*>(xt + b0);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) xr[hs][t][r] = xt[b0 + r < K ? b0 + r : K - 1];
+                        }
                     }
                 }
             };
@@ -316,58 +339,77 @@ __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __
             stage(0, st0);
             __syncthreads();
             BIG_STAMP(1);
-            // pair ip: the images of pair ip + 1 are requested at its head and staged at its end; `xr` holds this wave's rows
-            auto body = [&](int ip, f32x4 (&xr)[2]) __attribute__((always_inline)) {
+            // pair ip: the images of pair ip + 1 are requested at its head and staged at its end; `xr` holds this wave's rows.
+            // (Measured and NOT adopted, profiles/r06_mcep_big_wide.txt: every load of the loop unconditional from clamped indices and the
+            // body straight-line -- the compiler's wait-counter analysis then counts exactly, where this form waits `vmcnt(0)` behind the
+            // image fetch it has just issued, 0.9-2.1 k cycles of a pair's 4.1 k by the stamps -- together with the two stages of a
+            // wide wave run phase by phase interleaved: the stamped wave's phases got shorter and its wait at the barrier longer by as
+            // much, 672 -> 718 us per 12 800 frames: the pair's time is set by the YOUNGER wave of each SIMD.)
+            auto body = [&](int ip, f32x4 (&xr)[NSTG][2]) __attribute__((always_inline)) {
                 const int set = ip & 1;
-                const int j = 2 * ip + hsel;
-                const f32x4 xv[2] = {xr[0], xr[1]};
+                f32x4 xv[NSTG][2];
+#pragma unroll
+                for (int hs = 0; hs < NSTG; ++hs) { xv[hs][0] = xr[hs][0]; xv[hs][1] = xr[hs][1]; }
+                BIG_STAMP_P(8);
                 if (ip + 1 < npair) fetch(ip + 1, st0);
                 if (ip + 2 < npair) xfetch(ip + 2, xr);
-                if (tile_ok && j < nstage) {
-                    const f16x8* c1 = reinterpret_cast<const f16x8*>(sbuf0 + (set * 2 + hsel) * SH) + lane;
-                    const f16x8* w2 = c1 + (4 * KS1 * 512) / 8;
-                    f32x4 s[2] = {zero4, zero4};
+                BIG_STAMP_P(9);
 #pragma unroll
-                    for (int ks = 0; ks < KS1; ++ks)
+                for (int hs = 0; hs < NSTG; ++hs) {
+                    const int hsx = WIDE ? hs : hsel;
+                    const int j = 2 * ip + hsx;
+                    if (tile_ok && j < nstage) {
+                        const f16x8* c1 = reinterpret_cast<const f16x8*>(sbuf0 + (set * 2 + hsx) * SH) + lane;
+                        const f16x8* w2 = c1 + (4 * KS1 * 512) / 8;
+                        f32x4 s[2] = {zero4, zero4};
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            const f16x8 dh = c1[((t * KS1 + ks) * 2 + 0) * 64], dl = c1[((t * KS1 + ks) * 2 + 1) * 64];
-                            s[t] = mfma_h(dl, bh[ks], s[t]);
-                            s[t] = mfma_h(dh, bl[ks], s[t]);
-                            s[t] = mfma_h(dh, bh[ks], s[t]);
+                        for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) {
+                                const f16x8 dh = c1[((t * KS1 + ks) * 2 + 0) * 64], dl = c1[((t * KS1 + ks) * 2 + 1) * 64];
+                                s[t] = mfma_h(dl, bh[ks], s[t]);
+                                s[t] = mfma_h(dh, bl[ks], s[t]);
+                                s[t] = mfma_h(dh, bh[ks], s[t]);
+                            }
+                        if (hs == 0) BIG_STAMP_P(10);
+                        float tv[8];
+                        float tmax = -3.0e38f;
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const bool live = 32 * j + 16 * t + 4 * g + r < K;
+                                const float v = __builtin_fmaf(xv[hs][t][r], 1.4426950408889634f, __builtin_ldexpf(s[t][r], k1));
+                                tv[4 * t + r] = live ? v : -3.0e38f;
+                                tmax = __builtin_fmaxf(tmax, tv[4 * t + r]);
+                            }
+                        tmax = rows_max4(tmax);
+                        const float mi = __builtin_ceilf(tmax);
+                        const float shf = (float)EMAX_LOG2 - mi;
+                        float ev[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) ev[i] = __builtin_amdgcn_exp2f(tv[i] + shf);
+                        f16x8 eh, el;
+                        split8(ev, eh, el);
+                        if (hs == 0) BIG_STAMP_P(11);
+                        const int k2 = (int)mi - EMAX_LOG2 - LOG2_SE;
+#pragma unroll
+                        for (int tc = 0; tc < NT; ++tc) {
+                            const f16x8 wh = w2[(tc * 2 + 0) * 64], wlo = w2[(tc * 2 + 1) * 64];
+                            f32x4 a_ = mfma_h(wlo, eh, zero4);
+                            a_ = mfma_h(wh, el, a_);
+                            a_ = mfma_h(wh, eh, a_);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[hs][tc][r] += __builtin_ldexpf(a_[r], k2);
                         }
-                    float tv[8];
-                    float tmax = -3.0e38f;
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const bool live = 32 * j + 16 * t + 4 * g + r < K;
-                            const float v = __builtin_fmaf(xv[t][r], 1.4426950408889634f, __builtin_ldexpf(s[t][r], k1));
-                            tv[4 * t + r] = live ? v : -3.0e38f;
-                            tmax = __builtin_fmaxf(tmax, tv[4 * t + r]);
-                        }
-                    tmax = rows_max4(tmax);
-                    const float mi = __builtin_ceilf(tmax);
-                    const float shf = (float)EMAX_LOG2 - mi;
-                    float ev[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) ev[i] = __builtin_amdgcn_exp2f(tv[i] + shf);
-                    f16x8 eh, el;
-                    split8(ev, eh, el);
-                    const int k2 = (int)mi - EMAX_LOG2 - LOG2_SE;
-#pragma unroll
-                    for (int tc = 0; tc < NT; ++tc) {
-                        const f16x8 wh = w2[(tc * 2 + 0) * 64], wlo = w2[(tc * 2 + 1) * 64];
-                        f32x4 a_ = mfma_h(wlo, eh, zero4);
-                        a_ = mfma_h(wh, el, a_);
-                        a_ = mfma_h(wh, eh, a_);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[tc][r] += __builtin_ldexpf(a_[r], k2);
+                        if (hs == 0) BIG_STAMP_P(12);
                     }
                 }
+                BIG_STAMP_P(13);
                 if (ip + 1 < npair) stage(set ^ 1, st0);   // the other set: its readers finished before the barrier that ended pair ip - 1
+                BIG_STAMP_P(14);
                 __syncthreads();
+                BIG_STAMP_P(15);
             };
 #pragma unroll 1
             for (int ip = 0; ip < npair; ip += 2) {
@@ -376,68 +418,80 @@ __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __
             }
             BIG_STAMP(2);
             // (the barrier that ended the last stage: every wave is done with the staging buffers -- the rt rows may take them)
-            // ---- the two partial sums meet: odd stages' wave parks its rows, even stages' wave adds its own and parks the sums ----
             // C/D layout: lane (n, g), register r of tile tc <-> rt[16 tc + 4 g + r] of frame n
-            if (hsel == 1) {
+            if constexpr (WIDE) {
+                // ---- the even and the odd stages' sums, added in the order the two waves of a narrow group add them ----
 #pragma unroll
-                for (int tc = 0; tc < NT; ++tc) *reinterpret_cast<f32x4*>(park + n * RTS + 16 * tc + 4 * g) = acc[tc];
-            }
-            __syncthreads();
-            if (hsel == 0) {
-#pragma unroll
-                for (int tc = 0; tc < NT; ++tc) {
-                    f32x4* p4 = reinterpret_cast<f32x4*>(park + n * RTS + 16 * tc + 4 * g);
-                    *p4 = acc[tc] + *p4;
-                }
-            }
-            __syncthreads();
-            BIG_STAMP(3);
-            // ================= mc += solve(T(rt[:n]) + H(rt), rt[:n] - alpha_vec): eight systems per wave =================
-            if (tile_ok && (!QUAD || hsel == 0)) {
-                int ln = lane;
-                asm volatile("" : "+v"(ln));   // (lane-derived values re-derived here: see thsolve_octn_kernel)
-                {
-                    f32x4* z4 = reinterpret_cast<f32x4*>(wl);
-                    for (int e = ln; e < SYS * REC / 4; e += 64) z4[e] = zero4;
-                }
+                for (int tc = 0; tc < NT; ++tc) *reinterpret_cast<f32x4*>(park + n * RTS + 16 * tc + 4 * g) = acc[0][tc] + acc[NSTG - 1][tc];
                 __builtin_amdgcn_wave_barrier();
-                {
-                    const int s0 = (ln >> 4) * (SYS / 4);                                    // lane -> (SYS / 4 records, 16 columns apart)
-                    for (int s_ = s0; s_ < s0 + SYS / 4; ++s_) {
-                        float* rec = wl + s_ * REC;
-                        const float* prow = park + ((QUAD ? 0 : 8 * hsel) + s_) * RTS;
-                        for (int col = ln & 15; col < N; col += 16) {
-                            const float v = prow[col];
-                            rec[col] = v;                                                    // q window: q[k] at k
-                            if (col < M1) {
-                                rec[PO + col] = v;                                           // p window: p[|d|] at PO + d
-                                if (col >= 1 && col <= BACK) rec[PO - col] = v;
-                                rec[RO + col] = v - avs[col];                                // right-hand side
+            } else {
+                // ---- the two partial sums meet: odd stages' wave parks its rows, even stages' wave adds its own and parks the sums ----
+                if (hsel == 1) {
+#pragma unroll
+                    for (int tc = 0; tc < NT; ++tc) *reinterpret_cast<f32x4*>(park + n * RTS + 16 * tc + 4 * g) = acc[0][tc];
+                }
+                __syncthreads();
+                if (hsel == 0) {
+#pragma unroll
+                    for (int tc = 0; tc < NT; ++tc) {
+                        f32x4* p4 = reinterpret_cast<f32x4*>(park + n * RTS + 16 * tc + 4 * g);
+                        *p4 = acc[0][tc] + *p4;
+                    }
+                }
+                __syncthreads();
+            }
+            BIG_STAMP(3);
+            // ================= mc += solve(T(rt[:n]) + H(rt), rt[:n] - alpha_vec): eight systems per wave and round =================
+            if (tile_ok && (WIDE || !QUAD || hsel == 0)) {
+#pragma unroll 1
+                for (int rnd = 0; rnd < ROUNDS; ++rnd) {
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));   // (lane-derived values re-derived here: see thsolve_octn_kernel)
+                    const int row0 = WIDE ? 8 * rnd : (QUAD ? 0 : 8 * hsel);   // the group's rows this solve takes (QUAD: all 16)
+                    {
+                        f32x4* z4 = reinterpret_cast<f32x4*>(wl);
+                        for (int e = ln; e < SYS * REC / 4; e += 64) z4[e] = zero4;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    {
+                        const int s0 = (ln >> 4) * (SYS / 4);                                    // lane -> (SYS / 4 records, 16 columns apart)
+                        for (int s_ = s0; s_ < s0 + SYS / 4; ++s_) {
+                            float* rec = wl + s_ * REC;
+                            const float* prow = park + (row0 + s_) * RTS;
+                            for (int col = ln & 15; col < N; col += 16) {
+                                const float v = prow[col];
+                                rec[col] = v;                                                    // q window: q[k] at k
+                                if (col < M1) {
+                                    rec[PO + col] = v;                                           // p window: p[|d|] at PO + d
+                                    if (col >= 1 && col <= BACK) rec[PO - col] = v;
+                                    rec[RO + col] = v - avs[col];                                // right-hand side
+                                }
                             }
                         }
                     }
+                    __builtin_amdgcn_wave_barrier();
+                    BIG_STAMP(4 + 2 * rnd);
+                    // the solve is a FUNCTION CALL: inlined, its 220-register matrix set the whole kernel's allocation and the stage loop's
+                    // staged image pieces went through scratch (154 k cycles per step); behind a call boundary nothing of the stage loop
+                    // is live here and nothing of the elimination is live there
+                    if constexpr (QUAD) big_solve16q<NG, NMIN>((mbg::lds_f*)wl, (mbg::lds_f*)mcs, M1);
+                    else big_solve8<NG, NMIN>((mbg::lds_f*)wl, (mbg::lds_f*)(mcs + row0 * MS), M1);
+                    BIG_STAMP(5 + 2 * rnd);
+                    __builtin_amdgcn_wave_barrier();   // (WIDE: the records are rebuilt for the second round)
                 }
-                __builtin_amdgcn_wave_barrier();
-                BIG_STAMP(4);
-                // the solve is a FUNCTION CALL: inlined, its 220-register matrix set the whole kernel's allocation and the stage loop's
-                // staged image pieces went through scratch (154 k cycles per step); behind a call boundary nothing of the stage loop
-                // is live here and nothing of the elimination is live there
-                if constexpr (QUAD) big_solve16q<NG, NMIN>((mbg::lds_f*)wl, (mbg::lds_f*)mcs, M1);
-                else big_solve8<NG, NMIN>((mbg::lds_f*)wl, (mbg::lds_f*)(mcs + 8 * hsel * MS), M1);
-                BIG_STAMP(5);
             }
         }
-        // ---- the result: the group's rows of mc, eight per wave ----
+        // ---- the result: the group's rows of mc, RPW per wave ----
         __syncthreads();
         if (tile_ok) {
-            for (int e = (tid & 63); e < 8 * M1; e += 64) {
+            for (int e = (tid & 63); e < RPW * M1; e += 64) {
                 const int row = 8 * hsel + e / M1, col = e % M1;
                 if (row < rows_here) mc_out[(tb + row) * (long)M1 + col] = mcs[row * MS + col];
             }
         }
 #ifdef DSA_BIG_STAMPS
         if (blockIdx.x == 0 && pair == 0 && (tid & 63) == 0 && tile == 0)
-            for (int i = 1; i < 8; ++i) mc_out[(8 * hsel) * (long)M1 + i] = (float)(tsv[i] - tsv[i - 1]);
+            for (int i = 1; i < 16; ++i) mc_out[(8 * hsel) * (long)M1 + i] = (float)(tsv[i] - tsv[i - 1]);
 #endif
     }
 }

@@ -715,40 +715,70 @@ int mcep_big_newton(const void* logx, int64_t F, int K, const void* mc_in, int M
     if (!(ks1 == 2 && M1 >= 33 && M1 <= 55 && K >= 4)) return DSA_ERR_UNSUPPORTED;
     static const bool off = [] { const char* e = getenv("DSA_MCEP_BIG"); return e && e[0] == '0'; }();   // A/B: the two-launch step
     if (off) return DSA_ERR_UNSUPPORTED;
-    const long tiles = (long)((F + 63) / 64);
-    // Chosen by the ORDER alone, whatever the batch: measured against the two launches per step (us per analysis, fft_length 2048 /
-    // order 49, 10 steps; profiles/r06_mcep_big_newton.txt): 200 frames 696 -> 593, 3 200 724 -> 630, 12 800 920 -> 672, 20 000
-    // (1.22 rounds of 256 tiles) 1 250 -> 1 300, 25 600 1 370 -> 1 330, 40 000 2 027 -> 2 008, 102 400 4 813 -> 4 720.  (Both paths
-    // give the same bits: mcep_resid_f16.h sums the even and the odd stages separately, as the two waves of a tile do here.)
-    const long grid = tiles < 256 ? tiles : 256;   // persistent: one eight-wave workgroup per CU (105 KB of LDS, 256 registers)
-#define DSA_BIG_NEWTON(NTV, NGV, NMINV)                                                                                                 \
+    // The kernel's INSTANTIATION is chosen by the order alone; its tile shape by the batch.  A persistent launch is rounds of 256 tiles
+    // (one eight-wave workgroup per CU) and a round takes a tile's time however few tiles it has.  Narrow tiles (64 frames, two
+    // waves per 16-frame group: the shortest step) for up to one round; beyond it a PLAN: W rounds of wide tiles (128 frames, a wave per
+    // group: 1.6 x a narrow round's time for twice the frames) over the first W x 32 768 frames, narrow rounds over the rest -- the W
+    // that minimises the sum, two launches on the caller's stream over disjoint frames.  Both shapes -- and the two launches per
+    // step -- give the same bits (mcep_resid_f16.h sums the even and the odd stages separately, as the two waves of a narrow group /
+    // the one wave of a wide group do), so a frame's result does not depend on the plan (tests/test_gpu_configs.py).
+    // Measured, us per analysis, fft_length 2048 / order 49, 10 steps (profiles/r06_mcep_big_newton.txt, two launches per step ->
+    // narrow): 200 frames 696 -> 593, 3 200 724 -> 630, 12 800 920 -> 672, 20 000 1 250 -> 1 300, 40 000 2 027 -> 2 008, 102 400
+    // 4 813 -> 4 720; with the plan: profiles/r06_mcep_big_wide.txt.
+    const char* wide_e = getenv("DSA_MCEP_BIG_WIDE");   // A/B and tests: 0 never, 1 always (read per call: the tests switch it in-process)
+    const int wide_env = wide_e ? atoi(wide_e) : -1;
+    const bool quad = M1 <= 35;
+    const long FN = 256L * 64, FW = 256L * 128;          // frames a full round of narrow / wide tiles takes
+    long wide_rounds = 0;
+    if (wide_env > 0) {
+        wide_rounds = (long)((F + FW - 1) / FW);
+    } else if (wide_env < 0 && F > FN) {
+        // a wide round's time in units of a narrow round's (measured: 1.09 / 0.67 ms at 2048 / 49, 0.48 / 0.34 ms at 1024 / 34)
+        const double tw = quad ? 1.42 : 1.63;
+        double best = (double)((F + FN - 1) / FN);
+        for (long w = 1; w <= (long)((F + FW - 1) / FW); ++w) {
+            const long rest = F - w * FW;
+            const double c = w * tw + (rest > 0 ? (double)((rest + FN - 1) / FN) : 0.0);
+            if (c < best - 1e-9) {
+                best = c;
+                wide_rounds = w;
+            }
+        }
+    }
+    const long F_wide = wide_rounds * FW < F ? wide_rounds * FW : (wide_rounds > 0 ? (long)F : 0);
+#define DSA_BIG_NEWTON_1(NTV, NGV, NMINV, QUADV, WIDEV, F0, FC)                                                                         \
     do {                                                                                                                                \
-        constexpr int lds_b = mbg::lds_floats<2, NTV, NGV>() * 4;                                                                       \
+        constexpr int lds_b = mbg::lds_floats<2, NTV, NGV, QUADV, WIDEV>() * 4;                                                         \
+        static_assert(lds_b <= 160 * 1024, "mcep_big_newton: LDS");                                                                     \
         static std::atomic<uint64_t> attr{0};                                                                                           \
-        if (!ensure_dynamic_lds((const void*)mcep_big_newton_kernel<2, NTV, NGV, NMINV>, lds_b, attr))                                  \
+        if (!ensure_dynamic_lds((const void*)mcep_big_newton_kernel<2, NTV, NGV, NMINV, QUADV, WIDEV>, lds_b, attr))                    \
             return fail(DSA_ERR_LAUNCH, "mcep_big_newton: cannot reserve LDS%s");                                                       \
-        hipLaunchKernelGGL((mcep_big_newton_kernel<2, NTV, NGV, NMINV>), dim3((unsigned)grid), dim3(512), lds_b, st, (const float*)logx, \
-                           (long)F, K, (const float*)mc_in, M1, (const _Float16*)images, (const float*)av, n_iter, (float*)mc_out);      \
+        const long tiles_ = ((FC) + (WIDEV ? 127 : 63)) / (WIDEV ? 128 : 64);                                                           \
+        const long grid_ = tiles_ < 256 ? tiles_ : 256;   /* persistent: one eight-wave workgroup per CU (105 / 148 KB of LDS) */        \
+        hipLaunchKernelGGL((mcep_big_newton_kernel<2, NTV, NGV, NMINV, QUADV, WIDEV>), dim3((unsigned)grid_), dim3(512), lds_b, st,     \
+                           (const float*)logx + (F0) * (long)K, (long)(FC), K, (const float*)mc_in + (F0) * (long)M1, M1,               \
+                           (const _Float16*)images, (const float*)av, n_iter, (float*)mc_out + (F0) * (long)M1);                        \
+    } while (0)
+#define DSA_BIG_NEWTON(NTV, NGV, NMINV, QUADV)                                                                                          \
+    do {                                                                                                                                \
+        if (F_wide > 0) DSA_BIG_NEWTON_1(NTV, NGV, NMINV, QUADV, true, 0L, F_wide);                                                     \
+        if (F_wide < (long)F) DSA_BIG_NEWTON_1(NTV, NGV, NMINV, QUADV, false, F_wide, (long)F - F_wide);                                \
     } while (0)
     // (M1 = order + 1; the solver's instantiations as thsolve_quadn_fwd picks them: quad <9,28> up to 35, <11,36> up to 43, <13,44> up to
     //  51, <14,52>)
-    if (M1 <= 35) {
-        constexpr int lds_q = mbg::lds_floats<2, 5, 9, true>() * 4;
-        static std::atomic<uint64_t> attr_q{0};
-        if (!ensure_dynamic_lds((const void*)mcep_big_newton_kernel<2, 5, 9, 28, true>, lds_q, attr_q))
-            return fail(DSA_ERR_LAUNCH, "mcep_big_newton: cannot reserve LDS%s");
-        hipLaunchKernelGGL((mcep_big_newton_kernel<2, 5, 9, 28, true>), dim3((unsigned)grid), dim3(512), lds_q, st, (const float*)logx, (long)F, K,
-                           (const float*)mc_in, M1, (const _Float16*)images, (const float*)av, n_iter, (float*)mc_out);
+    if (quad) {
+        DSA_BIG_NEWTON(5, 9, 28, true);
     } else if (M1 <= 43) {
-        if (nt == 5) DSA_BIG_NEWTON(5, 11, 36);
-        else DSA_BIG_NEWTON(6, 11, 36);
+        if (nt == 5) DSA_BIG_NEWTON(5, 11, 36, false);
+        else DSA_BIG_NEWTON(6, 11, 36, false);
     } else if (M1 <= 51) {
-        if (nt == 6) DSA_BIG_NEWTON(6, 13, 44);
-        else DSA_BIG_NEWTON(7, 13, 44);
+        if (nt == 6) DSA_BIG_NEWTON(6, 13, 44, false);
+        else DSA_BIG_NEWTON(7, 13, 44, false);
     } else {
-        DSA_BIG_NEWTON(7, 14, 52);
+        DSA_BIG_NEWTON(7, 14, 52, false);
     }
 #undef DSA_BIG_NEWTON
+#undef DSA_BIG_NEWTON_1
     return check_launch("mcep_big_newton");
 }
 

@@ -976,3 +976,43 @@ def test_48khz_newton_steps_in_one_launch_equal_the_two_launch_step_bit_for_bit(
         y8 = m(Xbig.repeat(8, 1))                                        # 102 400 frames
         assert _lib.last_kernel() == "mcep_big_newton"
         assert torch.equal(y8[:12800], y1) and torch.equal(y8[-12800:], y1)
+
+
+@pytest.mark.parametrize("M,nfft", [(34, 1024), (32, 2048), (42, 2048), (49, 2048), (54, 2048)])
+def test_48khz_newton_steps_wide_tiles_and_plan_give_the_narrow_tiles_bits(M, nfft, monkeypatch):
+    """The wide tile shape of dsa_mcep_newton_steps (128 frames per workgroup, a wave per 16-frame group running both stages of a staged
+    pair and solving its 16 systems itself) and the plan that mixes rounds of wide tiles with narrow ones (csrc/mcep_mfma.hip:
+    mcep_big_newton) against the narrow tiles: the same bits per frame at ragged sizes, in every round of a multi-round launch and
+    across the plan's two launches; non-finite frames contained."""
+    K = nfft // 2 + 1
+    g = torch.Generator().manual_seed(100 + M)
+    Xall = (torch.randn(3300, K, generator=g).square() + 0.05).to(DEV)
+    m = dsp.MelCepstralAnalysis(fft_length=nfft, cep_order=M, alpha=0.55, n_iter=10, device=DEV)
+    for F, n_iter in ((1, 2), (15, 10), (127, 3), (129, 10), (700, 10), (3217, 1)):
+        mi = dsp.MelCepstralAnalysis(fft_length=nfft, cep_order=M, alpha=0.55, n_iter=n_iter, device=DEV)
+        with torch.no_grad():
+            monkeypatch.setenv("DSA_MCEP_BIG_WIDE", "0")
+            a = mi(Xall[:F])
+            monkeypatch.setenv("DSA_MCEP_BIG_WIDE", "1")
+            b = mi(Xall[:F])
+            assert _lib.last_kernel() == "mcep_big_newton"
+            assert torch.equal(a, b), (F, n_iter, float((a - b).abs().max()))
+            assert torch.equal(mi(Xall[:F]), b)
+    Xb = Xall[:700].clone()
+    Xb[[3, 64, 130, 699], 7] = float("nan")
+    with torch.no_grad():
+        monkeypatch.setenv("DSA_MCEP_BIG_WIDE", "1")
+        yb, y = m(Xb), m(Xall[:700])
+    keep = torch.ones(700, dtype=torch.bool, device=DEV)
+    keep[[3, 64, 130, 699]] = False
+    assert torch.equal(yb[keep], y[keep]) and not torch.isfinite(yb[~keep]).all(-1).any()
+    with torch.no_grad():
+        Xbig = Xall[:3200].repeat(13, 1)[:40000]                          # 40 000 frames: 1.2 rounds of wide tiles, 2.4 of narrow ones
+        monkeypatch.setenv("DSA_MCEP_BIG_WIDE", "0")
+        yn = m(Xbig)
+        monkeypatch.setenv("DSA_MCEP_BIG_WIDE", "1")
+        yw = m(Xbig)
+        monkeypatch.delenv("DSA_MCEP_BIG_WIDE")
+        yp = m(Xbig)                                                     # the plan: one round of wide tiles + narrow tiles for the rest
+        assert torch.equal(yn, yw) and torch.equal(yn, yp)
+        assert torch.equal(yp[:3200], yp[3200:6400]) and torch.equal(yp[:700], y) and torch.equal(yp[35200:38400], yp[:3200])
