@@ -80,6 +80,10 @@ int mgcep_step_bwd_h(const void* x, const void* b1, const void* gpt, const void*
 int64_t mcep_resid_h_images_bytes(int K, int M1);
 int mcep_resid_h_prepare(const void* D, int ldd, const void* E, int lde, int K, int M1, void* images, hipStream_t st);
 int mcep_resid_h_fwd(const void* logx, int64_t F, int K, const void* mc, int M1, const void* images, void* out, int ldo, hipStream_t st);
+int64_t mcep_resid_bwd_images_bytes(int K, int M1);
+int mcep_resid_bwd_prepare(const void* D, int ldd, const void* E, int lde, int K, int M1, void* images, hipStream_t st);
+int mcep_resid_bwd_h(const void* logx, int64_t F, int K, const void* mc, int M1, const void* grt, const void* images, void* glogx, void* gmc,
+                     hipStream_t st);
 int mcep_big_newton(const void* logx, int64_t F, int K, const void* mc_in, int M1, const void* images, const void* av, int n_iter,
                     void* mc_out, hipStream_t st);   // csrc/mcep_mfma.hip (mcep_big_f16.h)
 // orders 2 .. 55, float32, strided operands (csrc/thsolve_quad.hip)

@@ -591,6 +591,7 @@ int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, v
 #include "mcep_mfma_bwd2_f16.h"
 #include "mgcep_step_f16.h"
 #include "mcep_resid_f16.h"
+#include "mcep_resid_bwd_f16.h"
 #include "mcep_big_f16.h"
 #ifdef DSA_MCEP_BWD_PAIR_EXPERIMENT   // round 5: built, measured, not adopted (tools/experiments/mcep_mfma_bwd_pair.h)
 #include "../../tools/experiments/mcep_mfma_bwd_pair.h"

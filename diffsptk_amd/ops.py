@@ -963,6 +963,93 @@ def mcep_resid_images(D, E):
     return images
 
 
+_RESID_BWD_IMAGES: dict = {}   # id(D) -> (weakref to D, versions, images, ready event): the operand images of dsa_mcep_newton_resid_h_bwd
+
+
+def mcep_resid_bwd_images(D, E):
+    """The binary16 hi / lo operand images dsa_mcep_newton_resid_h_bwd consumes (dsa_mcep_resid_bwd_prepare), made once per pair of
+    tables and kept as long as the tables live (as mcep_resid_images); None where no kernel covers the order."""
+    if D.device.type != "cuda" or D.dtype != torch.float32 or E.dtype != torch.float32:
+        return None
+    n, K = D.size(0), D.size(1)
+    nbytes = _lib.load().dsa_mcep_resid_bwd_images_bytes(K, n)
+    if nbytes <= 0:
+        return None
+    ver = (D._version, E._version, D.data_ptr(), E.data_ptr(), tuple(D.shape), tuple(E.shape))
+    hit = _RESID_BWD_IMAGES.get(id(D))
+    if hit is not None and hit[0]() is D and hit[1] == ver:
+        if not hit[3].query():
+            with torch.cuda.device(D.device):
+                torch.cuda.current_stream().wait_event(hit[3])
+        return hit[2]
+    Dc, Ec = D.contiguous(), E.contiguous()
+    images = torch.empty(nbytes, dtype=torch.uint8, device=D.device)
+    with torch.cuda.device(D.device):
+        _call("dsa_mcep_resid_bwd_prepare", _p(Dc), Dc.size(1), _p(Ec), Ec.size(1), K, n, _dtype_code(Dc), _p(images), _stream())
+        ready = torch.cuda.Event()
+        ready.record()
+    if hit is None or hit[0]() is not D:
+        weakref.finalize(D, _RESID_BWD_IMAGES.pop, id(D), None)
+    _RESID_BWD_IMAGES[id(D)] = (weakref.ref(D), ver, images, ready)
+    return images
+
+
+class McepNewtonStepsHFn(torch.autograd.Function):
+    """mcep.py:208-222 at the 48 kHz set-ups (orders 32 .. 54) WITH a gradient, as one node (round 6): forward = per Newton step
+    dsa_mcep_newton_resid_h + dsa_mcep_newton_update, the iterates, rt rows and solutions kept ((3 n + ...) floats per frame and step
+    -- not e:(F, K)); backward = per step, in reverse, dsa_mcep_newton_update_bwd (the solve on the cotangent, the diagonal sums) and
+    dsa_mcep_newton_resid_h_bwd (e recomputed from the iterate; glogx accumulated in place).  Inputs: logx (natural logarithms of the
+    spectrum) and the start mc0 = logx G; the tables D, E, alpha_vec carry no gradient here (a learnable basis takes the composed
+    path).  Replaces, per step and 102 400 frames at 2048 / 49, 2.0 ms of differentiable pieces by 0.5 + 0.7 ms."""
+
+    @staticmethod
+    def forward(ctx, logx, mc0, D, E, av, n_iter):
+        images = mcep_resid_images(D, E)
+        F, n = mc0.numel() // mc0.size(-1), mc0.size(-1)
+        K = logx.size(-1)
+        lx = logx.contiguous()
+        mcs = torch.empty(n_iter + 1, F, n, device=mc0.device, dtype=mc0.dtype)   # the iterates
+        rts = torch.empty(n_iter, F, 2 * n - 1, device=mc0.device, dtype=mc0.dtype)
+        sols = torch.empty(n_iter, F, n, device=mc0.device, dtype=mc0.dtype)
+        mcs[0].copy_(mc0.reshape(F, n))
+        with torch.cuda.device(mc0.device):
+            for i in range(n_iter):
+                _call("dsa_mcep_newton_resid_h", _p(lx), F, K, _p(mcs[i]), n, _p(images), _dtype_code(lx), _p(rts[i]), _stream())
+                _call("dsa_mcep_newton_update", _p(rts[i]), F, n, _p(av), _dtype_code(lx), None, _p(sols[i]), _stream())
+                torch.add(mcs[i], sols[i], out=mcs[i + 1])
+        ctx.save_for_backward(lx, mcs, rts, sols, D, E)
+        ctx.n_iter = n_iter
+        return mcs[n_iter].reshape(mc0.shape).clone()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        lx, mcs, rts, sols, D, E = ctx.saved_tensors
+        n_iter = ctx.n_iter
+        F, n = mcs.size(1), mcs.size(2)
+        K = lx.size(-1)
+        images_b = mcep_resid_bwd_images(D, E)
+        gbar = g.reshape(F, n).contiguous().clone()
+        glogx = torch.zeros_like(lx)
+        u, grt, gmc = torch.empty_like(gbar), torch.empty_like(rts[0]), torch.empty_like(gbar)
+        with torch.cuda.device(g.device):
+            for i in range(n_iter - 1, -1, -1):
+                _call("dsa_mcep_newton_update_bwd", _p(gbar), _p(rts[i]), _p(sols[i]), F, n, _dtype_code(lx), _p(u), _p(grt), _stream())
+                _call("dsa_mcep_newton_resid_h_bwd", _p(lx), F, K, _p(mcs[i]), n, _p(grt), _p(images_b), _dtype_code(lx), _p(glogx), _p(gmc),
+                      _stream())
+                gbar.add_(gmc)
+        return glogx.reshape(lx.shape), gbar.reshape(g.shape), None, None, None, None
+
+
+def mcep_newton_steps_grad_applies(M1, D, E, av):
+    """McepNewtonStepsHFn takes the analysis: orders 32 .. 54 at K = 32 m (+ 1) bins, float32 tables without a gradient of their own
+    (DSA_MCEP_GRAD_H=0: the composed path, for A/B runs)."""
+    return (33 <= M1 <= 55 and os.environ.get("DSA_MCEP_GRAD_H", "1") != "0" and D.dtype == torch.float32 and E.dtype == torch.float32
+            and av.dtype == torch.float32 and not (D.requires_grad or E.requires_grad or av.requires_grad)
+            and D.device.type == "cuda" and _lib.load().dsa_mcep_resid_bwd_images_bytes(D.size(1), D.size(0)) > 0
+            and _lib.load().dsa_mcep_resid_images_bytes(D.size(1), D.size(0)) > 0)
+
+
 def mcep_newton_resid_h(logx, mc, images):
     """rt = exp(logx - 2 mc D) E (mcep.py:210-215) in one launch with both products as 3-term binary16 splits on the matrix pipe
     (dsa_mcep_newton_resid_h: float32, 3 <= M + 1 <= 55); `images` from mcep_resid_images(D, E)."""
@@ -1025,6 +1112,9 @@ def _mcep_composed_fwd(Xc, G, D, E, av, M, n_iter):
         out_ = mcep_newton_steps(logx, mc, images_h, av, n_iter)
         if out_ is not None:
             return out_.reshape(*lead, M1)
+    if want_grad and n_iter >= 1 and Xc.size(-1) >= 4 and mcep_newton_steps_grad_applies(M1, D, E, av):
+        # round 6: the steps as ONE node whose backward is two launches per step (dsa_mcep_newton_update_bwd, dsa_mcep_newton_resid_h_bwd)
+        return McepNewtonStepsHFn.apply(logx, mc, D, E, av, n_iter).reshape(*lead, M1)
     for _ in range(n_iter):
         if want_grad:
             e = RowsExpSubFn.apply(logx, MatmulRowsFn.apply(mc, D))       # :210-212

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 126 /* 0.2.0: + dsa_mcep_newton_steps, dsa_stft_mcep_opts_fwd, DSA_ALGO_OVERLAPPED_LAUNCHES, DSA_ALGO_PAD_MODE, packed STFT kernels for fft_length 1024 / 2048 and for every pad mode at 512; 0.1.9: + dsa_mgcep_step_solve, dsa_mgcep_step_bwd_h, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
+#define DSA_VERSION 127 /* 0.2.1: + dsa_mcep_resid_bwd_images_bytes / _prepare, dsa_mcep_newton_resid_h_bwd (the 48 kHz analysis with a gradient: the step's backward in two launches); wide tiles in dsa_mcep_newton_steps; 0.2.0: + dsa_mcep_newton_steps, dsa_stft_mcep_opts_fwd, DSA_ALGO_OVERLAPPED_LAUNCHES, DSA_ALGO_PAD_MODE, packed STFT kernels for fft_length 1024 / 2048 and for every pad mode at 512; 0.1.9: + dsa_mgcep_step_solve, dsa_mgcep_step_bwd_h, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
@@ -304,6 +304,20 @@ int dsa_mcep_newton_steps(const void* logx, int64_t F, int32_t K, const void* mc
                           int32_t n_iter, int32_t dtype, void* mc_out, void* stream);
 int dsa_mcep_newton_resid_h(const void* logx, int64_t F, int32_t K, const void* mc, int32_t n, const void* images, int32_t dtype,
                             void* rt, void* stream);
+/* (0.2.1) The ADJOINT of dsa_mcep_newton_resid_h -- what autograd derives from mcep.py:210-215 -- in one launch on the binary16 matrix
+ * pipe (csrc/mcep_resid_bwd_f16.h), orders n - 1 in 32 .. 54 and K = 32 m or 32 m + 1 bins (every power-of-two fft_length from 128;
+ * dsa_mcep_resid_bwd_images_bytes returns 0 otherwise: keep the composed gradient there): given grt:(F, 2n - 1), the cotangent of rt = exp(logx - 2 mc D) E,
+ *   glogx:(F, K) += ebar * e,   gmc:(F, n) = -2 (ebar * e) D^T,   ebar = grt E^T,  e = exp(logx - 2 mc D) recomputed from the iterate
+ * (glogx is read-modify-written: the caller zeroes it before the first step of the reverse sweep; gmc is overwritten).  `images` =
+ * dsa_mcep_resid_bwd_images_bytes(K, n) bytes of caller-owned device memory filled ONCE per configuration by
+ * dsa_mcep_resid_bwd_prepare from D (n x K) and E (K x 2n - 1).  With dsa_mcep_newton_update_bwd (the solve on the cotangent and
+ * the diagonal sums: grt) this is a Newton step's whole backward: two launches, no intermediate of the forward kept but the iterates,
+ * the rt rows and the solutions. */
+int64_t dsa_mcep_resid_bwd_images_bytes(int32_t K, int32_t n);
+int dsa_mcep_resid_bwd_prepare(const void* D, int32_t ldd, const void* E, int32_t lde, int32_t K, int32_t n, int32_t dtype, void* images,
+                               void* stream);
+int dsa_mcep_newton_resid_h_bwd(const void* logx, int64_t F, int32_t K, const void* mc, int32_t n, const void* grt, const void* images,
+                                int32_t dtype, void* glogx, void* gmc, void* stream);
 /* General float32 row product on the matrix instruction, for shapes the kernels behind dsa_freqt_fwd / _bwd do not cover (rows
  * of 512 values and more: the 1025-bin products of the 48 kHz set-ups of utils/public.py:22-104) and for the Newton step of
  * MelCepstralAnalysis (mcep.py:203-215) at geometries without a tuned kernel:

@@ -1,0 +1,122 @@
+"""The 48 kHz mel-cepstral analysis WITH a gradient (round 6): McepNewtonStepsHFn -- per Newton step dsa_mcep_newton_update_bwd and
+dsa_mcep_newton_resid_h_bwd (csrc/mcep_resid_bwd_f16.h) -- against float64 autograd of the ATen port of mcep.py:189-224
+(oracle/torch_port.py), against the composed differentiable pieces it replaces, and the raw entry against float64 autograd of its own
+formula.  Tolerances: gradients 2e-5 of the frame's largest entry (measured 0.7e-6 .. 6.2e-6; the composed path's own error is
+3e-6 .. 3.4e-5)."""
+import numpy as np
+import pytest
+import torch
+
+import diffsptk_amd as dsp
+from diffsptk_amd import _lib, ops
+from oracle import torch_port as TP
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rel_rows(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float(((a - b).abs().amax(-1) / b.abs().amax(-1).clamp_min(1e-300)).max())
+
+
+def _grads(m, X, w):
+    Xg = X.detach().clone().requires_grad_(True)
+    y = m(Xg)
+    (y * w).sum().backward()
+    return y.detach(), Xg.grad
+
+
+@pytest.mark.parametrize("nfft,M,alpha", [(2048, 49, 0.55), (1024, 34, 0.55), (2048, 40, 0.5), (2048, 54, 0.55), (2048, 32, 0.55), (2048, 48, 0.46)])
+def test_48khz_gradient_one_node_vs_float64_autograd_and_the_composed_pieces(nfft, M, alpha, monkeypatch):
+    K = nfft // 2 + 1
+    g = torch.Generator().manual_seed(1000 + M)
+    for F, n_iter in ((70, 2), (333, 10)):
+        X = (torch.randn(F, K, generator=g).square() + 0.05).to(DEV)
+        w = torch.randn(F, M + 1, generator=g).to(DEV)
+        m = dsp.MelCepstralAnalysis(fft_length=nfft, cep_order=M, alpha=alpha, n_iter=n_iter, device=DEV)
+        monkeypatch.setenv("DSA_MCEP_GRAD_H", "1")
+        assert ops.mcep_newton_steps_grad_applies(M + 1, m.D, m.E, m.alpha_vector)
+        y1, g1 = _grads(m, X, w)
+        monkeypatch.setenv("DSA_MCEP_GRAD_H", "0")
+        y0, g0 = _grads(m, X, w)
+        tab = TP.McepTables(nfft, M, alpha, torch.float64)
+        Xs = X.double().cpu().requires_grad_(True)
+        yr = TP.mcep(Xs, tab, n_iter)
+        (yr * w.double().cpu()).sum().backward()
+        assert torch.isfinite(g1).all()
+        np.testing.assert_allclose(y1.cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=5e-6)
+        np.testing.assert_allclose(y1.cpu().numpy(), y0.cpu().numpy(), rtol=1e-4, atol=5e-6)   # (the composed forward runs float32 matrix products)
+        assert _rel_rows(g1, Xs.grad) < 2e-5, (F, n_iter, _rel_rows(g1, Xs.grad))
+        assert _rel_rows(g1, g0) < 1e-4
+        # with a gradient wanted or not: the same values (the no-gradient path is the one persistent launch)
+        with torch.no_grad():
+            assert torch.equal(m(X), y1)
+
+
+@pytest.mark.parametrize("K,n", [(1025, 50), (513, 35), (1025, 33), (1025, 55), (1024, 48), (129, 40)])
+def test_resid_h_bwd_entry_vs_float64_autograd_of_its_formula(K, n):
+    """dsa_mcep_newton_resid_h_bwd alone: glogx += (grt E^T) * e, gmc = -2 ((grt E^T) * e) D^T with e = exp(logx - 2 mc D), ragged batch,
+    accumulation into a non-zero glogx, rows past the batch untouched."""
+    g = torch.Generator().manual_seed(K + n)
+    F = 150
+    D = (torch.randn(n, K, generator=g) * 0.3).to(DEV)
+    E = (torch.randn(K, 2 * n - 1, generator=g) * 0.01).to(DEV)
+    logx = torch.randn(F, K, generator=g).to(DEV)
+    mc = (torch.randn(F, n, generator=g) * 0.2).to(DEV)
+    grt = torch.randn(F, 2 * n - 1, generator=g).to(DEV)
+    grt[7] *= 1e6          # per-frame scales
+    grt[8] *= 1e-6
+    grt[9] = 0.0
+    glogx0 = torch.randn(F + 3, K, generator=g).to(DEV)
+    glogx0[:F] = 0.0       # (the sums start at zero, as the reverse sweep starts them; the rows past the batch keep their noise)
+    images = ops.mcep_resid_bwd_images(D, E)
+    assert images is not None
+    glogx = glogx0.clone()
+    gmc = torch.full((F + 3, n), 7.0, device=DEV)
+    ops._call("dsa_mcep_newton_resid_h_bwd", ops._p(logx), F, K, ops._p(mc), n, ops._p(grt), ops._p(images), ops._dtype_code(logx), ops._p(glogx),
+              ops._p(gmc), ops._stream())
+    assert _lib.last_kernel() == "mcep_resid_bwd_h"
+    lx, mcd = logx.double().requires_grad_(True), mc.double().requires_grad_(True)
+    rt = torch.exp(lx - 2.0 * mcd @ D.double()) @ E.double()
+    (rt * grt.double()).sum().backward()
+    assert torch.equal(glogx[F:], glogx0[F:]) and bool((gmc[F:] == 7.0).all())      # rows past the batch: untouched
+    assert _rel_rows(glogx[:F], lx.grad) < 5e-6, _rel_rows(glogx[:F], lx.grad)
+    assert _rel_rows(gmc[:F], mcd.grad) < 5e-6, _rel_rows(gmc[:F], mcd.grad)
+    # a second call ADDS into glogx (read-modify-write) and overwrites gmc
+    gmc_b = torch.empty(F, n, device=DEV)
+    glogx_b = glogx.clone()
+    ops._call("dsa_mcep_newton_resid_h_bwd", ops._p(logx), F, K, ops._p(mc), n, ops._p(grt), ops._p(images), ops._dtype_code(logx), ops._p(glogx_b),
+              ops._p(gmc_b), ops._stream())
+    assert torch.equal(glogx_b[:F], glogx[:F] + glogx[:F]) and torch.equal(gmc_b, gmc[:F]) and torch.equal(glogx_b[F:], glogx0[F:])
+    # every frame's arithmetic depends on the frame alone: a slice gives the same bits
+    gl2 = torch.zeros(40, K, device=DEV)
+    gm2 = torch.empty(40, n, device=DEV)
+    ops._call("dsa_mcep_newton_resid_h_bwd", ops._p(logx[60:100].contiguous()), 40, K, ops._p(mc[60:100].contiguous()), n, ops._p(grt[60:100].contiguous()),
+              ops._p(images), ops._dtype_code(logx), ops._p(gl2), ops._p(gm2), ops._stream())
+    assert torch.equal(gm2, gmc[60:100]) and torch.equal(gl2, glogx[60:100])
+    # a non-finite frame stays in its rows
+    lx_bad = logx.clone()
+    lx_bad[5, 3] = float("nan")
+    gl3, gm3 = glogx0.clone(), torch.empty(F, n, device=DEV)
+    ops._call("dsa_mcep_newton_resid_h_bwd", ops._p(lx_bad), F, K, ops._p(mc), n, ops._p(grt), ops._p(images), ops._dtype_code(logx), ops._p(gl3),
+              ops._p(gm3), ops._stream())
+    keep = torch.ones(F, dtype=torch.bool, device=DEV)
+    keep[5] = False
+    assert torch.equal(gm3[keep], gmc[:F][keep]) and torch.equal(gl3[:F][keep], glogx[:F][keep]) and not torch.isfinite(gm3[5]).all()
+
+
+def test_48khz_gradient_falls_back_where_the_kernel_does_not_apply(monkeypatch):
+    """K = fft_length / 2 + 1 with K % 32 > 1 (fft_length 1000), orders outside 32 .. 54, a learnable basis: the composed gradient, no error."""
+    g = torch.Generator().manual_seed(5)
+    m = dsp.MelCepstralAnalysis(fft_length=1000, cep_order=40, alpha=0.5, n_iter=3, device=DEV)
+    assert not ops.mcep_newton_steps_grad_applies(41, m.D, m.E, m.alpha_vector)
+    X = (torch.randn(50, 501, generator=g).square() + 0.05).to(DEV)
+    w = torch.randn(50, 41, generator=g).to(DEV)
+    _, g1 = _grads(m, X, w)
+    tab = TP.McepTables(1000, 40, 0.5, torch.float64)
+    Xs = X.double().cpu().requires_grad_(True)
+    (TP.mcep(Xs, tab, 3) * w.double().cpu()).sum().backward()
+    assert _rel_rows(g1, Xs.grad) < 1e-4
+    m2 = dsp.MelCepstralAnalysis(fft_length=2048, cep_order=30, alpha=0.5, n_iter=2, device=DEV)
+    assert not ops.mcep_newton_steps_grad_applies(31, m2.D, m2.E, m2.alpha_vector)
