@@ -540,6 +540,17 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
                     "roofline": {"bound": "f32 arithmetic (matrix / packed-vector peak)", "flop_per_frame": flop48,
                                  "achieved": flop48 * fr48 / t_m / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": flop48 * fr48 / t_m / 1e12 / FP32_PEAK_TFLOPS}}
+                # round 6: the analysis with a gradient back to the spectrogram (one autograd node: dsa_mcep_newton_update_bwd +
+                # dsa_mcep_newton_resid_h_bwd per step; wall clock around whole calls, the backward is a sequence of launches)
+                if fl != 1024:
+                    with torch.enable_grad():
+                        def fb48():
+                            Xg = X48.detach().requires_grad_(True)
+                            mc48(Xg).sum().backward()
+                        rows48[list(rows48)[-1]]["mcep_fwd_bwd_ms"] = gpu_time(fb48, n=3, groups=2)
+                        rows48[list(rows48)[-1]]["mcep_fwd_bwd_path"] = ("one autograd node (ops.McepNewtonStepsHFn)"
+                                                                         if ops.mcep_newton_steps_grad_applies(m1_, mc48.D, mc48.E, mc48.alpha_vector)
+                                                                         else "composed differentiable pieces")
                 del X48
             del x48
     res["untuned_48khz"] = {"workload": "STFT (csrc/stft_pk_big.h since round 6) + MelCepstralAnalysis at the 48 kHz set-ups, 64 and 512 utterances x 1 s, "
