@@ -1480,6 +1480,84 @@ __global__ __launch_bounds__(256) void newton_update_bwd_sums_kernel(const float
         grt[f * (2 * n - 1) + k] = acc;
     }
 }
+
+// Round 6: the same sums with ONE FRAME PER LANE, everything in registers.  The kernel above gives a wave to a frame and a lane one or two
+// of its 2 n - 1 sums, every multiply-add behind two LDS reads (143 us per 102 400 frames of order 49: a tenth of the 48 kHz analysis'
+// forward + backward).  Here a lane loads its frame's u and s rows (zero-padded to NMAX), runs the three sums fully unrolled at compile
+// time -- 2 NMAX^2 + NMAX multiply-adds, no memory access, no cross-lane operation -- and stores four results at a time.  The rows of a
+// wave's 64 consecutive frames are one contiguous block, so the per-lane 16-byte accesses use every byte of the lines they touch.
+// sums k = K4 .. K4 + 3 of a lane's frame, then the next group: a compile-time recursion (as a loop of 28 x 450 instructions the unroller
+// gives up and the arrays live in private memory)
+template <int NMAX, int K4>
+__device__ __forceinline__ void sums_lane_groups(const float (&uu)[NMAX], const float (&sv)[NMAX], float* orow, int nout)
+{
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    if constexpr (K4 < 2 * NMAX - 1) {
+        if (K4 < nout) {   // (uniform)
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = K4 + e;
+                float acc = 0.f;
+                if (k < 2 * NMAX - 1) {
+                    // Hankel: sum_{i + j = k} u_i s_j (zero padding makes the sum over the padded range the sum over the order's)
+#pragma unroll
+                    for (int i = (k - (NMAX - 1) > 0 ? k - (NMAX - 1) : 0); i <= (k < NMAX - 1 ? k : NMAX - 1); ++i) acc = __builtin_fmaf(-uu[i], sv[k - i], acc);
+                    if (k < NMAX) {
+                        // Toeplitz: sum_{|i - j| = k} u_i s_j, and the right-hand side's u_k (u_k = 0 from the order on)
+#pragma unroll
+                        for (int i = 0; i + k < NMAX; ++i) {
+                            acc = __builtin_fmaf(-uu[i], sv[i + k], acc);
+                            if (k > 0) acc = __builtin_fmaf(-uu[i + k], sv[i], acc);
+                        }
+                        acc += uu[k];
+                    }
+                }
+                o[e] = acc;
+            }
+            if (K4 + 3 < nout) {
+                *reinterpret_cast<f4u*>(orow + K4) = f4u{o[0], o[1], o[2], o[3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (K4 + e < nout) orow[K4 + e] = o[e];
+            }
+            sums_lane_groups<NMAX, K4 + 4>(uu, sv, orow, nout);
+        }
+    }
+}
+
+template <int NMAX>
+__global__ __launch_bounds__(256) void newton_update_bwd_sums_lane_kernel(const float* __restrict__ u, const float* __restrict__ s, long F, int n,
+                                                                         float* __restrict__ grt)
+{
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const long f = (long)blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    const float* ur = u + f * n;
+    const float* sr = s + f * n;
+    float uu[NMAX], sv[NMAX];
+#pragma unroll
+    for (int i4 = 0; i4 < NMAX; i4 += 4) {
+        // (the group's values first, the array elements assigned unconditionally afterwards: element assignments on conditional paths keep
+        //  the arrays in private memory)
+        f4u a, b;
+        if (i4 + 3 < n) {   // (uniform)
+            a = *reinterpret_cast<const f4u*>(ur + i4);
+            b = *reinterpret_cast<const f4u*>(sr + i4);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = i4 + e < n ? ur[i4 + e] : 0.f;
+                b[e] = i4 + e < n ? sr[i4 + e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { uu[i4 + e] = a[e]; sv[i4 + e] = b[e]; }
+    }
+    float* orow = grt + f * (2 * n - 1);
+    sums_lane_groups<NMAX, 0>(uu, sv, orow, 2 * n - 1);
+}
 }  // namespace dsa
 
 DSA_EXPORT int dsa_mcep_newton_update_bwd(const void* gs, const void* rt, const void* sol, int64_t F, int32_t n, int32_t dtype, void* u,
@@ -1490,6 +1568,18 @@ DSA_EXPORT int dsa_mcep_newton_update_bwd(const void* gs, const void* rt, const 
     if (dtype != DSA_F32) return fail(DSA_ERR_UNSUPPORTED, "mcep_newton_update_bwd: float32 only%s");
     if (F == 0) return DSA_OK;
     if (int rc = thsolve_quadn_fwd(rt, 2 * n - 1, rt, 2 * n - 1, gs, n, nullptr, nullptr, F, n, u, (hipStream_t)stream)) return rc;
+    // one frame per lane (round 6) from 64 frames on; DSA_SUMS_LANE=0: the wave-per-frame kernel (A/B; it also takes tiny batches)
+    static const bool lane_on = [] { const char* e = getenv("DSA_SUMS_LANE"); return !(e && e[0] == '0'); }();
+    if (lane_on && F >= 64) {
+        const dim3 g((unsigned)((F + 255) / 256));
+        if (n <= 36)
+            hipLaunchKernelGGL((dsa::newton_update_bwd_sums_lane_kernel<36>), g, dim3(256), 0, (hipStream_t)stream, (const float*)u, (const float*)sol,
+                               (long)F, (int)n, (float*)grt);
+        else
+            hipLaunchKernelGGL((dsa::newton_update_bwd_sums_lane_kernel<56>), g, dim3(256), 0, (hipStream_t)stream, (const float*)u, (const float*)sol,
+                               (long)F, (int)n, (float*)grt);
+        return dsa::check_launch("mcep_newton_update_bwd");
+    }
     hipLaunchKernelGGL(dsa::newton_update_bwd_sums_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)u,
                        (const float*)sol, (long)F, (int)n, (float*)grt);
     return dsa::check_launch("mcep_newton_update_bwd");
