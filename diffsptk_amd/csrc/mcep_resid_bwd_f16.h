@@ -104,24 +104,13 @@ __global__ __launch_bounds__(256, 2) DSA_PK_TARGET void mcep_resid_bwd_h_kernel(
     const int rn = n < rows_here ? n : rows_here - 1;
     const bool row_ok = tile_ok && n < rows_here;
     const float* xt = logx + tb * (long)K + (long)rn * K;
-    const float* gxt = glogx + tb * (long)K + (long)rn * K;
+    float* gxt = glogx + tb * (long)K + (long)rn * K;
     const f32x4* img4 = reinterpret_cast<const f32x4*>(img);
-    // EVERY vector-memory operation of the stage loop is unconditional and the loop body straight-line code: with loads or stores on
-    // conditional paths the compiler's wait-counter analysis stops counting and drains the queue (`s_waitcnt vmcnt(0)`) in front of the
-    // next use of a prefetched register -- here that would be a wait for the previous stage's STORES to be acknowledged by memory,
-    // every stage (profiles/r06_mcep_big_wide.txt has the forward's version of the effect).  So: loads from clamped addresses; the
-    // gradient sums leave as raw-buffer stores over the tile's own rows whose offset is pushed out of range where nothing is to be
-    // written (rows past the batch, bins past K, waves past the last tile: the hardware drops the store); the one bin of a partial last
-    // stage (K % 32 == 1: every power-of-two fft_length) travels in registers of its own.
-    // (the descriptor's pieces through v_readfirstlane: derived from the wave index they ARE uniform, but the compiler does not see it and
-    //  wraps every store in a loop over the distinct descriptors of the wave)
-    const unsigned long long gb_ = (unsigned long long)(glogx + tb * (long)K);
-    const unsigned gb_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gb_), gb_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(gb_ >> 32));
-    float* gbase = reinterpret_cast<float*>(((unsigned long long)gb_hi << 32) | gb_lo);
-    const __amdgpu_buffer_rsrc_t grs =
-        __builtin_amdgcn_make_buffer_rsrc(gbase, 0, __builtin_amdgcn_readfirstlane(tile_ok ? rows_here * K * 4 : 0), 0x00020000);
-    const unsigned row_off = (unsigned)rn * (unsigned)K * 4u;
-    constexpr unsigned OOB = 0xfffffff0u;
+    // (Measured and not kept, profiles/r06_48khz_gradient_one_node.txt: every load and store of the stage loop unconditional -- clamped
+    // addresses, raw-buffer stores pushed out of range where nothing is to be written, the partial last stage's bin in registers of its
+    // own -- so that the compiler's wait counts stay exact instead of `vmcnt(0)`: 2-5 % faster at 12 800 frames, 9 % SLOWER per launch at
+    // 102 400 (539 against 495 us: the launch is bound by its 1.26 GB, and the always-issued extra store costs more than the drained
+    // waits), and only for K = 32 m (+ 1) bins.)
     f32x4 st0[PER];   // one stage ahead in registers, the stage in use in the other LDS buffer
     auto fetch = [&](int j, f32x4 (&sv)[PER]) __attribute__((always_inline)) {
 #pragma unroll
@@ -185,38 +174,41 @@ __global__ __launch_bounds__(256, 2) DSA_PK_TARGET void mcep_resid_bwd_h_kernel(
     f32x4 acc[NT3];
 #pragma unroll
     for (int t = 0; t < NT3; ++t) acc[t] = zero4;
-    // the partial last stage's one bin (K - 1 = 32 jpart; absent when K % 32 == 0): its log-spectrum value and gradient sum
-    const int jpart = K >> 5;
-    const bool has_part = (K & 31) != 0;
-    const float xlast = xt[K - 1], glast = gxt[K - 1];
-    // the lane's log-spectrum values and gradient sums of a stage: bins 32 j + 16 t + 4 g .. + 3 from min(bin, K - 4) -- a full stage's
-    // loads are where they belong; the partial stage and the stages past the end read valid addresses and are not used
+    // the lane's log-spectrum values and gradient sums of a stage: bins 32 j + 16 t + 4 g + r; bins past the end read the row's last
+    // value, are masked to e = 0 below and never stored
     f32x4 x0[2], x1[2], a0[2], a1[2];
     auto xfetch = [&](int j, f32x4 (&xr)[2], f32x4 (&ar)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int b0 = 32 * j + 16 * t + 4 * g, bc = b0 < K - 4 ? b0 : K - 4;
-            xr[t] = *reinterpret_cast<const f32x4_u4*>(xt + bc);
-            ar[t] = *reinterpret_cast<const f32x4_u4*>(gxt + bc);
+            const int b0 = 32 * j + 16 * t + 4 * g;
+            if (b0 + 3 < K) {
+                xr[t] = *reinterpret_cast<const f32x4_u4*>(xt + b0);
+                ar[t] = *reinterpret_cast<const f32x4_u4*>(gxt + b0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    xr[t][r] = xt[b0 + r < K ? b0 + r : K - 1];
+                    ar[t][r] = gxt[b0 + r < K ? b0 + r : K - 1];
+                }
+            }
         }
     };
     xfetch(0, x0, a0);
-    xfetch(1, x1, a1);
+    xfetch(nstage > 1 ? 1 : 0, x1, a1);
     stage(0, st0);
-    fetch(1, st0);
+    if (nstage > 1) fetch(1, st0);
     __syncthreads();
     // stage j: `sv` holds stage j + 1 (requested during stage j - 1) and takes stage j + 2 once staged; (xr, ar) hold the rows of stage j
     auto body = [&](int j, f32x4 (&sv)[PER], f32x4 (&xr)[2], f32x4 (&ar)[2]) __attribute__((always_inline)) {
         const int buf = j & 1;
-        const bool part = has_part && j == jpart;   // uniform
-        f32x4 xv[2] = {xr[0], xr[1]};
-        f32x4 av_[2] = {ar[0], ar[1]};
-        xv[0][0] = part ? xlast : xv[0][0];
-        av_[0][0] = part ? glast : av_[0][0];
-        stage(buf ^ 1, sv);   // the other buffer: its readers finished before the barrier that ended stage j - 1
-        xfetch(j + 2, xr, ar);
-        fetch(j + 2, sv);
-        {
+        const f32x4 xv[2] = {xr[0], xr[1]};
+        const f32x4 av_[2] = {ar[0], ar[1]};
+        if (j + 1 < nstage) stage(buf ^ 1, sv);   // the other buffer: its readers finished before the barrier that ended stage j - 1
+        if (j + 2 < nstage) {
+            xfetch(j + 2, xr, ar);
+            fetch(j + 2, sv);
+        }
+        if (tile_ok) {
             const f16x8* c1 = reinterpret_cast<const f16x8*>(sbuf_b + buf * SH) + lane;
             const f16x8* c2 = c1 + OFF2;
             const f16x8* c3 = c1 + OFF3;
@@ -255,12 +247,15 @@ __global__ __launch_bounds__(256, 2) DSA_PK_TARGET void mcep_resid_bwd_h_kernel(
                     zm = __builtin_fmaxf(zm, __builtin_fabsf(z));
                     o[r] += z;
                 }
-                const int b0 = 32 * j + 16 * t + 4 * g;
-                const unsigned off4 = (row_ok && b0 + 3 < K) ? row_off + 4u * (unsigned)b0 : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4v, o), grs, (int)off4, 0, 0);
-                if (t == 0) {   // the partial stage's one bin: a 4-byte store of its own, out of range everywhere else
-                    const unsigned off1 = (row_ok && part && g == 0) ? row_off + 4u * (unsigned)b0 : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, o[0]), grs, (int)off1, 0, 0);
+                if (row_ok) {
+                    const int b0 = 32 * j + 16 * t + 4 * g;
+                    if (b0 + 3 < K) {
+                        *reinterpret_cast<f32x4_u4*>(gxt + b0) = o;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (b0 + r < K) gxt[b0 + r] = o[r];
+                    }
                 }
             }
             // third chain: gmc += (-2 D) z with the stage's own scale
@@ -287,7 +282,7 @@ __global__ __launch_bounds__(256, 2) DSA_PK_TARGET void mcep_resid_bwd_h_kernel(
 #pragma unroll 1
     for (int j = 0; j < nstage; j += 2) {
         body(j, st0, x0, a0);
-        body(j + 1, st0, x1, a1);   // (past the last stage: every bin dead -- nothing added, nothing stored; one barrier more)
+        if (j + 1 < nstage) body(j + 1, st0, x1, a1);
     }
     if (!row_ok) return;
     // C/D layout: lane (n, g) register r of tile tc <-> coefficient 16 tc + 4 g + r of frame n
@@ -321,8 +316,7 @@ int mcep_resid_bwd_h(const void* logx, int64_t F, int K, const void* mc, int M1,
                      hipStream_t st)
 {
     const int ks1 = (M1 + 31) / 32, kse = mrb::kse_of(M1), nt3 = mrb::nt3_of(M1), N = 2 * M1 - 1;
-    // (K % 32 <= 1: every power-of-two fft_length -- the partial last stage is ONE bin, carried in registers of its own)
-    if (!(ks1 == 2 && M1 >= 33 && M1 <= 55 && K >= 36 && (K & 31) <= 1)) return DSA_ERR_UNSUPPORTED;
+    if (!(ks1 == 2 && M1 >= 33 && M1 <= 55 && K >= 4)) return DSA_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)((F + 63) / 64));
 #define DSA_RESID_BWD(KSEV, NT3V)                                                                                                         \
     do {                                                                                                                                  \

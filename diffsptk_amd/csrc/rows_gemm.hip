@@ -666,7 +666,7 @@ DSA_EXPORT int dsa_mcep_newton_steps(const void* logx, int64_t F, int32_t K, con
 // (0.2.1) the adjoint of dsa_mcep_newton_resid_h (csrc/mcep_resid_bwd_f16.h): images of their own
 DSA_EXPORT int64_t dsa_mcep_resid_bwd_images_bytes(int32_t K, int32_t n)
 {
-    if (K < 36 || (K & 31) > 1 || n < 33 || n > 55) return 0;   // what dsa_mcep_newton_resid_h_bwd covers (0: keep the composed gradient)
+    if (K < 4 || n < 33 || n > 55) return 0;   // what dsa_mcep_newton_resid_h_bwd covers (0: keep the composed gradient)
     return dsa::mcep_resid_bwd_images_bytes(K, n);
 }
 
@@ -674,8 +674,7 @@ DSA_EXPORT int dsa_mcep_resid_bwd_prepare(const void* D, int32_t ldd, const void
                                           void* stream)
 {
     DSA_REQUIRE(K >= 4 && n >= 3 && ldd >= K && lde >= 2 * n - 1 && D && E && images, "mcep_resid_bwd_prepare: invalid arguments");
-    if (dtype != DSA_F32 || n < 33 || n > 55 || K < 36 || (K & 31) > 1)
-        return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_resid_bwd_prepare: float32, orders 32 .. 54, K = 32 m or 32 m + 1 bins%s");
+    if (dtype != DSA_F32 || n < 33 || n > 55) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_resid_bwd_prepare: float32, orders 32 .. 54%s");
     return dsa::mcep_resid_bwd_prepare(D, ldd, E, lde, K, n, images, (hipStream_t)stream);
 }
 
@@ -687,7 +686,7 @@ DSA_EXPORT int dsa_mcep_newton_resid_h_bwd(const void* logx, int64_t F, int32_t 
     if (dtype != DSA_F32) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_resid_h_bwd: float32 only%s");
     if (F == 0) return DSA_OK;
     const int rc = dsa::mcep_resid_bwd_h(logx, F, K, mc, n, grt, images, glogx, gmc, (hipStream_t)stream);
-    if (rc == DSA_ERR_UNSUPPORTED) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_resid_h_bwd: orders 32 .. 54, K = 32 m or 32 m + 1 bins%s");
+    if (rc == DSA_ERR_UNSUPPORTED) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_resid_h_bwd: orders 32 .. 54%s");
     return rc;
 }
 

@@ -1042,7 +1042,7 @@ class McepNewtonStepsHFn(torch.autograd.Function):
 
 
 def mcep_newton_steps_grad_applies(M1, D, E, av):
-    """McepNewtonStepsHFn takes the analysis: orders 32 .. 54 at K = 32 m (+ 1) bins, float32 tables without a gradient of their own
+    """McepNewtonStepsHFn takes the analysis: orders 32 .. 54, float32 tables without a gradient of their own
     (DSA_MCEP_GRAD_H=0: the composed path, for A/B runs)."""
     return (33 <= M1 <= 55 and os.environ.get("DSA_MCEP_GRAD_H", "1") != "0" and D.dtype == torch.float32 and E.dtype == torch.float32
             and av.dtype == torch.float32 and not (D.requires_grad or E.requires_grad or av.requires_grad)

@@ -305,8 +305,8 @@ int dsa_mcep_newton_steps(const void* logx, int64_t F, int32_t K, const void* mc
 int dsa_mcep_newton_resid_h(const void* logx, int64_t F, int32_t K, const void* mc, int32_t n, const void* images, int32_t dtype,
                             void* rt, void* stream);
 /* (0.2.1) The ADJOINT of dsa_mcep_newton_resid_h -- what autograd derives from mcep.py:210-215 -- in one launch on the binary16 matrix
- * pipe (csrc/mcep_resid_bwd_f16.h), orders n - 1 in 32 .. 54 and K = 32 m or 32 m + 1 bins (every power-of-two fft_length from 128;
- * dsa_mcep_resid_bwd_images_bytes returns 0 otherwise: keep the composed gradient there): given grt:(F, 2n - 1), the cotangent of rt = exp(logx - 2 mc D) E,
+ * pipe (csrc/mcep_resid_bwd_f16.h), orders n - 1 in 32 .. 54 (dsa_mcep_resid_bwd_images_bytes returns 0 otherwise: keep the composed
+ * gradient there): given grt:(F, 2n - 1), the cotangent of rt = exp(logx - 2 mc D) E,
  *   glogx:(F, K) += ebar * e,   gmc:(F, n) = -2 (ebar * e) D^T,   ebar = grt E^T,  e = exp(logx - 2 mc D) recomputed from the iterate
  * (glogx is read-modify-written: the caller zeroes it before the first step of the reverse sweep; gmc is overwritten).  `images` =
  * dsa_mcep_resid_bwd_images_bytes(K, n) bytes of caller-owned device memory filled ONCE per configuration by
