@@ -354,6 +354,94 @@ __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __
                 if (ip + 1 < npair) fetch(ip + 1, st0);
                 if (ip + 2 < npair) xfetch(ip + 2, xr);
                 BIG_STAMP_P(9);
+#ifndef DSA_BIG_WIDE_INTERLEAVE
+#define DSA_BIG_WIDE_INTERLEAVE 1   // (0: the wide wave's two stages one after the other, for A/B builds)
+#endif
+                bool done_ = false;
+                if constexpr (WIDE && !QUAD && DSA_BIG_WIDE_INTERLEAVE) {   // (measured, profiles/r06_mcep_big_wide.txt: 2048 / 49 -1 .. -4 %; the quad-layout orders +3 .. +6 %: off there)
+                    if (tile_ok && 2 * ip + 1 < nstage) {
+                        // Both stages of the pair, software-pipelined INSIDE the wave: the matrix pipe and the vector unit are separate
+                        // pipes, and a stage alone uses them one after the other (stamps: first chain, t / max / exp / split, second chain
+                        // ~0.45 / 0.6 / 0.7 k cycles, each at its own pipe's rate when both waves of a SIMD are in the same phase).  Here the
+                        // second stage's first chain issues between the first stage's exponentials, the first stage's second chain between
+                        // the second stage's: [c1 a] [c1 b | exp a] [c2 a | exp b] [c2 b].  Same instructions, same operands, same order
+                        // of every sum: the same bits.
+                        done_ = true;
+                        const f16x8* c1a = reinterpret_cast<const f16x8*>(sbuf0 + (set * 2 + 0) * SH) + lane;
+                        const f16x8* c1b = c1a + SH / 8;
+                        auto chain1 = [&](const f16x8* c1, f32x4 (&s2)[2]) __attribute__((always_inline)) {
+#pragma unroll
+                            for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+                                for (int t = 0; t < 2; ++t) {
+                                    const f16x8 dh = c1[((t * KS1 + ks) * 2 + 0) * 64], dl = c1[((t * KS1 + ks) * 2 + 1) * 64];
+                                    s2[t] = mfma_h(dl, bh[ks], s2[t]);
+                                    s2[t] = mfma_h(dh, bl[ks], s2[t]);
+                                    s2[t] = mfma_h(dh, bh[ks], s2[t]);
+                                }
+                        };
+                        auto expsplit = [&](int j, const f32x4 (&xq)[2], const f32x4 (&s2)[2], f16x8& eh, f16x8& el, int& k2) __attribute__((always_inline)) {
+                            float tv[8];
+                            float tmax = -3.0e38f;
+#pragma unroll
+                            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const bool live = 32 * j + 16 * t + 4 * g + r < K;
+                                    const float v = __builtin_fmaf(xq[t][r], 1.4426950408889634f, __builtin_ldexpf(s2[t][r], k1));
+                                    tv[4 * t + r] = live ? v : -3.0e38f;
+                                    tmax = __builtin_fmaxf(tmax, tv[4 * t + r]);
+                                }
+                            tmax = rows_max4(tmax);
+                            const float mi = __builtin_ceilf(tmax);
+                            const float shf = (float)EMAX_LOG2 - mi;
+                            float ev[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) ev[i] = __builtin_amdgcn_exp2f(tv[i] + shf);
+                            split8(ev, eh, el);
+                            k2 = (int)mi - EMAX_LOG2 - LOG2_SE;
+                        };
+                        auto chain2 = [&](const f16x8* w2, const f16x8& eh, const f16x8& el, int k2, f32x4 (&ac)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+                            for (int tc = 0; tc < NT; ++tc) {
+                                const f16x8 wh = w2[(tc * 2 + 0) * 64], wlo = w2[(tc * 2 + 1) * 64];
+                                f32x4 a_ = mfma_h(wlo, eh, zero4);
+                                a_ = mfma_h(wh, el, a_);
+                                a_ = mfma_h(wh, eh, a_);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) ac[tc][r] += __builtin_ldexpf(a_[r], k2);
+                            }
+                        };
+                        f32x4 sa[2] = {zero4, zero4}, sb[2] = {zero4, zero4};
+                        f16x8 eha, ela, ehb, elb;
+                        int k2a, k2b;
+                        __builtin_amdgcn_sched_barrier(0);
+                        chain1(c1a, sa);
+                        __builtin_amdgcn_sched_barrier(0);
+                        BIG_STAMP_P(10);
+                        chain1(c1b, sb);
+                        expsplit(2 * ip, xv[0], sa, eha, ela, k2a);
+#pragma unroll
+                        for (int i_ = 0; i_ < 6 * KS1; ++i_) {   // one product, then a handful of the exponentials' vector instructions
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        BIG_STAMP_P(11);
+                        chain2(c1a + (4 * KS1 * 512) / 8, eha, ela, k2a, acc[0]);
+                        expsplit(2 * ip + 1, xv[NSTG - 1], sb, ehb, elb, k2b);
+#pragma unroll
+                        for (int i_ = 0; i_ < 3 * NT; ++i_) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        BIG_STAMP_P(12);
+                        chain2(c1b + (4 * KS1 * 512) / 8, ehb, elb, k2b, acc[NSTG - 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (!done_) {
 #pragma unroll
                 for (int hs = 0; hs < NSTG; ++hs) {
                     const int hsx = WIDE ? hs : hsel;
@@ -404,6 +492,7 @@ __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __
                         }
                         if (hs == 0) BIG_STAMP_P(12);
                     }
+                }
                 }
                 BIG_STAMP_P(13);
                 if (ip + 1 < npair) stage(set ^ 1, st0);   // the other set: its readers finished before the barrier that ended pair ip - 1
