@@ -1568,9 +1568,10 @@ DSA_EXPORT int dsa_mcep_newton_update_bwd(const void* gs, const void* rt, const 
     if (dtype != DSA_F32) return fail(DSA_ERR_UNSUPPORTED, "mcep_newton_update_bwd: float32 only%s");
     if (F == 0) return DSA_OK;
     if (int rc = thsolve_quadn_fwd(rt, 2 * n - 1, rt, 2 * n - 1, gs, n, nullptr, nullptr, F, n, u, (hipStream_t)stream)) return rc;
-    // one frame per lane (round 6) from 64 frames on; DSA_SUMS_LANE=0: the wave-per-frame kernel (A/B; it also takes tiny batches)
+    // one frame per lane (round 6), whatever the batch: the two kernels sum in different orders, and a frame's bits must not depend on
+    // how many frames travel with it; DSA_SUMS_LANE=0: the wave-per-frame kernel (A/B)
     static const bool lane_on = [] { const char* e = getenv("DSA_SUMS_LANE"); return !(e && e[0] == '0'); }();
-    if (lane_on && F >= 64) {
+    if (lane_on) {
         const dim3 g((unsigned)((F + 255) / 256));
         if (n <= 36)
             hipLaunchKernelGGL((dsa::newton_update_bwd_sums_lane_kernel<36>), g, dim3(256), 0, (hipStream_t)stream, (const float*)u, (const float*)sol,

@@ -121,3 +121,18 @@ def test_48khz_gradient_any_bin_count_and_the_fallback_outside_the_orders(monkey
     assert _rel_rows(g1, Xs.grad) < 2e-5
     m2 = dsp.MelCepstralAnalysis(fft_length=2048, cep_order=30, alpha=0.5, n_iter=2, device=DEV)
     assert not ops.mcep_newton_steps_grad_applies(31, m2.D, m2.E, m2.alpha_vector)
+
+
+@pytest.mark.parametrize("nfft,M", [(2048, 49), (1024, 34)])
+def test_48khz_gradient_is_batch_invariant(nfft, M):
+    """A frame's value and gradient depend on the frame alone: the same bits alone, in a batch of 3, of 70 and of 20 000 frames (every kernel of the
+    node is chosen by the order, none by the batch size; above 16 384 frames the NO-gradient path plans wide tiles -- not this path)."""
+    K = nfft // 2 + 1
+    g = torch.Generator().manual_seed(77 + M)
+    X = (torch.randn(20000, K, generator=g).square() + 0.05).to(DEV)
+    w = torch.randn(20000, M + 1, generator=g).to(DEV)
+    m = dsp.MelCepstralAnalysis(fft_length=nfft, cep_order=M, alpha=0.55, n_iter=4, device=DEV)
+    yb, gb = _grads(m, X, w)
+    for lo, hi in ((0, 1), (5, 8), (100, 170), (19990, 20000)):
+        ys, gs = _grads(m, X[lo:hi], w[lo:hi])
+        assert torch.equal(ys, yb[lo:hi]) and torch.equal(gs, gb[lo:hi]), (lo, hi)
