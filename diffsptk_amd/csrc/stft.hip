@@ -1085,6 +1085,7 @@ __global__ __launch_bounds__(128, 4) void stft512_fwd_kernel(
 #include "stft_pk.h"
 #include "stft_bwd_pk.h"
 #include "stft_pk_big.h"
+#include "stft_bwd_pk_big.h"
 namespace dsa {
 
 // ------------------------------------------------------------------ host-side dispatch helpers
@@ -2408,6 +2409,49 @@ static int stft_bwd_impl(const void* gy, const void* x, int64_t B, int64_t T, in
     DSA_REQUIRE(out_format >= 0 && out_format <= 5, "stft_bwd: unknown out_format");
     if (B == 0) return DSA_OK;
     hipStream_t st = (hipStream_t)stream;
+    {
+        // fft_length 1024 / 2048 (the 44.1 / 48 kHz set-ups), power format, constant padding, no zmean, no relative floor, fixed window:
+        // the packed kernel of stft_bwd_pk_big.h (round 6; DSA_STFT_BIG_BWD=0: the generic backward, for A/B runs)
+        const char* bigb_e = getenv("DSA_STFT_BIG_BWD");   // (read per call: the tests switch it in-process)
+        const bool bigb_on = !(bigb_e && bigb_e[0] == '0');
+        const int64_t Nb = dsa_num_frames(T, P);
+        const int leftb = center ? L / 2 : 0;
+        if (bigb_on && dtype == DSA_F32 && algo != DSA_ALGO_GENERIC && (nfft == 1024 || nfft == 2048) && !zmean && !use_floor && !gw && !div &&
+            out_format == DSA_SPEC_POWER && pad_mode == DSA_PAD_CONSTANT && L <= nfft && (L & 1) == 0 && (P & 1) == 0 && (leftb & 1) == 0 &&
+            (T & 1) == 0 && (((size_t)x) & 7) == 0 && B * Nb < (int64_t(1) << 31) && x && gy && gx) {
+            const int S = nfft / 512, FPP = 4 / S;
+            const int need = (L + 32 * S - 1) / (32 * S);   // sample pairs per lane
+            const int ppu = (int)((Nb + FPP - 1) / FPP);    // passes per utterance
+            const int warm = ((L + P - 1) / P - 1 + FPP - 1) / FPP;   // passes whose tails a run inherits
+            const long waves = 256L * 2 * 4;                 // two four-wave workgroups per CU
+            long want = (waves + B - 1) / B;                 // runs per utterance that fill the chip ...
+            const long longest = ppu / (4 * (warm > 0 ? warm : 1)) > 0 ? ppu / (4 * (warm > 0 ? warm : 1)) : 1;   // ... but no run shorter than four warm-ups
+            const int runs = (int)(want < longest ? want : longest);
+            const long items = (long)B * runs;
+            const long wv = items < waves ? items : waves;
+            const dim3 g2((unsigned)((wv + 3) / 4));
+            const int lds_bb = 4 * 4 * kZS * 8 + 256 * 8 + 4 * (2 * 256 * S) * 4;
+#define DSA_BIGB_LAUNCH(SV, NRV)                                                                                                        \
+    do {                                                                                                                                \
+        static std::atomic<uint64_t> abb{0};                                                                                            \
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(&stft_big_bwd_pk_kernel<SV, NRV>), lds_bb, abb))                          \
+            return fail(DSA_ERR_LAUNCH, "stft_bwd: cannot reserve LDS%s");                                                              \
+        hipLaunchKernelGGL((stft_big_bwd_pk_kernel<SV, NRV>), g2, dim3(256), lds_bb, st, (const float*)x, (const float*)gy, (long)T,    \
+                           (long)Nb, L, P, leftb, (const float*)w, (const float*)twiddle, (float*)gx, items, runs, ppu, warm);          \
+    } while (0)
+            if (S == 2) {
+                if (need <= 10) DSA_BIGB_LAUNCH(2, 10);
+                else if (need <= 13) DSA_BIGB_LAUNCH(2, 13);
+                else DSA_BIGB_LAUNCH(2, 16);
+            } else {
+                if (need <= 10) DSA_BIGB_LAUNCH(4, 10);
+                else if (need <= 13) DSA_BIGB_LAUNCH(4, 13);
+                else DSA_BIGB_LAUNCH(4, 16);
+            }
+#undef DSA_BIGB_LAUNCH
+            return check_launch(S == 2 ? "stft1024_bwd" : "stft2048_bwd");
+        }
+    }
     {
         int io_floats = 0;
         int lds = stft512_lds_bytes(L, P, &io_floats);

@@ -96,7 +96,7 @@ def test_non_finite_samples_stay_in_their_frames():
 
 @pytest.mark.parametrize("fl,fp,nfft", [(1200, 240, 2048), (800, 200, 1024)])
 def test_gradient_against_float64_autograd(fl, fp, nfft):
-    """The backward of these geometries stays on the generic kernels; the forward that feeds it is the packed one."""
+    """The packed backward of stft_bwd_pk_big.h behind the packed forward (see the tests below for the kernel against the generic one)."""
     g = torch.Generator().manual_seed(9)
     x = torch.randn(2, 6000, generator=g)
     cot = torch.randn(2, (6000 - 1) // fp + 1, nfft // 2 + 1, generator=g)
@@ -109,3 +109,60 @@ def test_gradient_against_float64_autograd(fl, fp, nfft):
     (yd * cot.double().to(DEV)).sum().backward()
     err = float((xs.grad.double() - xd.grad).abs().max() / xd.grad.abs().max())
     assert err < 3e-6, err
+
+
+def _grad(st, x, cot):
+    xs = x.detach().clone().requires_grad_(True)
+    (st(xs) * cot).sum().backward()
+    return xs.grad
+
+
+BWD_GEOMETRIES = [(1200, 240, 2048), (800, 200, 1024), (1024, 256, 1024), (2048, 512, 2048), (1600, 400, 2048), (600, 150, 1024),
+                  (600, 150, 2048), (64, 16, 1024), (1200, 1300, 2048)]
+
+
+@pytest.mark.parametrize("fl,fp,nfft", BWD_GEOMETRIES)
+@pytest.mark.parametrize("center", [True, False])
+def test_packed_backward_against_float64_autograd_and_the_generic_backward(fl, fp, nfft, center, monkeypatch):
+    """stft_big_bwd_pk_kernel (round 6): every (S, NR) instantiation, frame_length = fft_length, a period longer than the frame
+    (samples no frame reaches: zero gradient), ragged utterances (several runs per utterance, one-frame utterances), against float64 autograd of
+    the generic float64 kernels and the generic float32 backward."""
+    g = torch.Generator().manual_seed(fl + nfft + 7 * center)
+    for B, T in ((3, 12 * nfft), (2, 2 * fl + 2 * fp + 2), (70, 3 * nfft), (1, max(fl // 2 * 2, 2))):
+        x = torch.randn(B, T, generator=g).to(DEV)
+        st = dsp.STFT(fl, fp, nfft, center=center, device=DEV)
+        st64 = dsp.STFT(fl, fp, nfft, center=center, device=DEV, dtype=torch.float64)
+        N = (T - 1) // fp + 1
+        cot = torch.randn(B, N, nfft // 2 + 1, generator=g).to(DEV)
+        monkeypatch.setenv("DSA_STFT_BIG_BWD", "1")
+        gp = _grad(st, x, cot)
+        monkeypatch.setenv("DSA_STFT_BIG_BWD", "0")
+        gg = _grad(st, x, cot)
+        g64 = _grad(st64, x.double(), cot.double())
+        scale = float(g64.abs().max())
+        assert torch.isfinite(gp).all()
+        assert float((gp.double() - g64).abs().max()) < 3e-6 * scale, (B, T, float((gp.double() - g64).abs().max()) / scale)
+        assert float((gp - gg).abs().max()) < 3e-6 * scale
+
+
+def test_packed_backward_bench_size_partition_invariance_and_non_finite_containment(monkeypatch):
+    """512 utterances x 1 s @ 48 kHz: an utterance's gradient is the same bits alone or in the batch and however the chip cuts it into runs
+    (1 utterance: many runs; 512: four), repeat launches identical; a non-finite sample touches only the samples of the frames that contain it."""
+    g = torch.Generator().manual_seed(11)
+    fl, fp, nfft = 1200, 240, 2048
+    x = torch.randn(512, 48000, generator=g).to(DEV)
+    st = dsp.STFT(fl, fp, nfft, device=DEV)
+    cot = torch.randn(512, (48000 - 1) // fp + 1, 1025, generator=g).to(DEV)
+    gb = _grad(st, x, cot)
+    assert torch.equal(gb, _grad(st, x, cot))
+    for u in (0, 17, 511):
+        assert torch.equal(_grad(st, x[u:u + 1], cot[u:u + 1])[0], gb[u])
+    assert torch.equal(_grad(st, x[100:103], cot[100:103]), gb[100:103])
+    xb = x[:4].clone()
+    xb[1, 7000] = float("nan")
+    gn = _grad(st, xb, cot[:4])
+    t = torch.arange(48000, device=DEV)
+    n_lo, n_hi = (7000 + fl // 2 - fl) // fp + 1, (7000 + fl // 2) // fp          # frames that contain sample 7000
+    touched = (t >= n_lo * fp - fl // 2) & (t < n_hi * fp - fl // 2 + fl)
+    assert torch.equal(gn[[0, 2, 3]], gb[[0, 2, 3]])
+    assert torch.equal(gn[1][~touched], gb[1][~touched]) and not torch.isfinite(gn[1][touched]).all()
