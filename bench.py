@@ -548,6 +548,10 @@ def other_configs(dsp, ops, _lib, dev, stft, mcep, x1024):
                             Xg = X48.detach().requires_grad_(True)
                             mc48(Xg).sum().backward()
                         rows48[list(rows48)[-1]]["mcep_fwd_bwd_ms"] = gpu_time(fb48, n=3, groups=2)
+                        def sb48():
+                            xg = x48.detach().requires_grad_(True)
+                            torch.autograd.grad(st48(xg), xg, X48)
+                        rows48[list(rows48)[-1]]["stft_fwd_bwd_ms"] = gpu_time(sb48, n=3, groups=2)   # (backward: csrc/stft_bwd_pk_big.h)
                         rows48[list(rows48)[-1]]["mcep_fwd_bwd_path"] = ("one autograd node (ops.McepNewtonStepsHFn)"
                                                                          if ops.mcep_newton_steps_grad_applies(m1_, mc48.D, mc48.E, mc48.alpha_vector)
                                                                          else "composed differentiable pieces")
