@@ -2418,7 +2418,7 @@ static int stft_bwd_impl(const void* gy, const void* x, int64_t B, int64_t T, in
         const int leftb = center ? L / 2 : 0;
         if (bigb_on && dtype == DSA_F32 && algo != DSA_ALGO_GENERIC && (nfft == 1024 || nfft == 2048) && !zmean && !use_floor && !gw && !div &&
             out_format == DSA_SPEC_POWER && pad_mode == DSA_PAD_CONSTANT && L <= nfft && (L & 1) == 0 && (P & 1) == 0 && (leftb & 1) == 0 &&
-            (T & 1) == 0 && (((size_t)x) & 7) == 0 && B * Nb < (int64_t(1) << 31) && x && gy && gx) {
+            (T & 1) == 0 && (((size_t)x) & 7) == 0 && (((size_t)gx) & 7) == 0 && B * Nb < (int64_t(1) << 31) && x && gy && gx) {
             const int S = nfft / 512, FPP = 4 / S;
             const int need = (L + 32 * S - 1) / (32 * S);   // sample pairs per lane
             const int ppu = (int)((Nb + FPP - 1) / FPP);    // passes per utterance

@@ -284,17 +284,24 @@ __global__ __launch_bounds__(256, 2) DSA_PK_TARGET void stft_big_bwd_pk_kernel(
             for (int f = 0; f < FPP; ++f) {
                 const long n = (long)p * FPP + f;
                 const float* gf = reinterpret_cast<const float*>(zbuf + f * S * kZS);
+                // (sample PAIRS: L, P, left and Tlen are even -- the host checks -- so `base`, every frame start and every run of complete
+                //  samples are even: 8-byte LDS accesses and stores, half the instructions)
+                v2f* ring2 = reinterpret_cast<v2f*>(ring);
+                const v2f* gf2 = reinterpret_cast<const v2f*>(gf);
                 if (n < N) {
-                    for (int l = lane; l < L; l += 64) ring[(base + l) & (RING - 1)] += gf[l];
+                    for (int l = 2 * lane; l < L; l += 128) {
+                        const int pos = ((base + l) & (RING - 1)) >> 1;
+                        ring2[pos] = ring2[pos] + gf2[l >> 1];
+                    }
                 }
                 DSA_WAVE_SYNC();
                 const long t0s = n * P - left;
-                for (int s = lane; s < P; s += 64) {
-                    const int pos = (base + s) & (RING - 1);
-                    const float val = ring[pos];
-                    ring[pos] = 0.f;
+                for (int s = 2 * lane; s < P; s += 128) {
+                    const int pos = ((base + s) & (RING - 1)) >> 1;
+                    const v2f val = ring2[pos];
+                    ring2[pos] = v2f{0.f, 0.f};
                     const long t = t0s + s;
-                    if (store_ok && t >= 0 && t < Tlen) gxb[t] = val;
+                    if (store_ok && t >= 0 && t < Tlen) *reinterpret_cast<v2f*>(gxb + t) = val;
                 }
                 base = (base + P) & (RING - 1);
                 DSA_WAVE_SYNC();
