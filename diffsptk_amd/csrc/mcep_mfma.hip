@@ -593,6 +593,7 @@ int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, v
 #include "mcep_resid_f16.h"
 #include "mcep_resid_bwd_f16.h"
 #include "mcep_big_f16.h"
+#include "mcep_big4_f16.h"
 #ifdef DSA_MCEP_BWD_PAIR_EXPERIMENT   // round 5: built, measured, not adopted (tools/experiments/mcep_mfma_bwd_pair.h)
 #include "../../tools/experiments/mcep_mfma_bwd_pair.h"
 #endif
@@ -729,9 +730,17 @@ int mcep_big_newton(const void* logx, int64_t F, int K, const void* mc_in, int M
     const char* wide_e = getenv("DSA_MCEP_BIG_WIDE");   // A/B and tests: 0 never, 1 always (read per call: the tests switch it in-process)
     const int wide_env = wide_e ? atoi(wide_e) : -1;
     const bool quad = M1 <= 35;
-    const long FN = 256L * 64, FW = 256L * 128;          // frames a full round of narrow / wide tiles takes
+    // Quad-layout orders: the rounds of 32 768 frames run as TWIN workgroups (mcep_big4_f16.h: two four-wave workgroups per CU, the
+    // second half a step late: 1024 / 34 at 122 880 frames 2.15 -> 1.99 ms, profiles/r06_mcep_big_twin.txt) instead of eight-wave wide
+    // tiles (DSA_MCEP_BIG_TWIN=0, A/B); the same bits either way.  At the octet-layout orders the twin shape measured no faster than
+    // the plan (each workgroup streams the images itself: twice the bytes from L2 per frame) and is not instantiated.
+    const char* twin_e = getenv("DSA_MCEP_BIG_TWIN");
+    const bool twin = quad && !(twin_e && twin_e[0] == '0');
+    const long FN = 256L * 64, FW = 256L * 128;          // frames a full round of narrow / wide (or twin) tiles takes
     long wide_rounds = 0;
-    if (wide_env > 0) {
+    if (wide_env > 0 || (wide_env < 0 && twin && F > FN)) {
+        // (twin workgroups take 64-frame tiles like the narrow shape: beyond one narrow round every frame goes to them -- measured
+        //  against twin rounds + narrow rounds for the rest, 1024 / 34: 79 200 frames 1.28 / 1.34 ms, 245 760 3.62 / 3.88)
         wide_rounds = (long)((F + FW - 1) / FW);
     } else if (wide_env < 0 && F > FN) {
         // a wide round's time in units of a narrow round's (measured: 1.09 / 0.67 ms at 2048 / 49, 0.48 / 0.34 ms at 1024 / 34)
@@ -747,6 +756,10 @@ int mcep_big_newton(const void* logx, int64_t F, int K, const void* mc_in, int M
         }
     }
     const long F_wide = wide_rounds * FW < F ? wide_rounds * FW : (wide_rounds > 0 ? (long)F : 0);
+    const char* stag_e = getenv("DSA_MCEP_BIG_STAGGER");
+    const int stagger = stag_e ? atoi(stag_e) : 5;                // x ~8 k cycles (measured 4 .. 6 best: profiles/r06_mcep_big_twin.txt)
+    const char* abl_e = getenv("DSA_MCEP_BIG_ABL");                  // measurement only: 1 no solve, 2 no products
+    const int abl = abl_e ? atoi(abl_e) : 0;
 #define DSA_BIG_NEWTON_1(NTV, NGV, NMINV, QUADV, WIDEV, F0, FC)                                                                         \
     do {                                                                                                                                \
         constexpr int lds_b = mbg::lds_floats<2, NTV, NGV, QUADV, WIDEV>() * 4;                                                         \
@@ -760,6 +773,25 @@ int mcep_big_newton(const void* logx, int64_t F, int K, const void* mc_in, int M
                            (const float*)logx + (F0) * (long)K, (long)(FC), K, (const float*)mc_in + (F0) * (long)M1, M1,               \
                            (const _Float16*)images, (const float*)av, n_iter, (float*)mc_out + (F0) * (long)M1);                        \
     } while (0)
+#define DSA_BIG_NEWTON4_1(NTV, NGV, NMINV, QUADV, F0, FC)                                                                               \
+    do {                                                                                                                                \
+        constexpr int lds_b = mbg4::lds_floats<2, NTV, NGV, QUADV>() * 4;                                                               \
+        static_assert(lds_b <= 80 * 1024, "mcep_big_newton: two workgroups per CU");                                                    \
+        static std::atomic<uint64_t> attr{0};                                                                                           \
+        if (!ensure_dynamic_lds((const void*)mcep_big_newton4_kernel<2, NTV, NGV, NMINV, QUADV>, lds_b, attr))                          \
+            return fail(DSA_ERR_LAUNCH, "mcep_big_newton: cannot reserve LDS%s");                                                       \
+        const long tiles_ = ((FC) + 63) / 64;                                                                                           \
+        const long grid_ = tiles_ < 512 ? tiles_ : 512;   /* persistent: two four-wave workgroups per CU */                             \
+        hipLaunchKernelGGL((mcep_big_newton4_kernel<2, NTV, NGV, NMINV, QUADV>), dim3((unsigned)grid_), dim3(256), lds_b, st,           \
+                           (const float*)logx + (F0) * (long)K, (long)(FC), K, (const float*)mc_in + (F0) * (long)M1, M1,               \
+                           (const _Float16*)images, (const float*)av, n_iter, (float*)mc_out + (F0) * (long)M1, stagger, abl);               \
+    } while (0)
+#define DSA_BIG_NEWTON_Q(NTV, NGV, NMINV)                                                                                               \
+    do {                                                                                                                                \
+        if (F_wide > 0 && twin) DSA_BIG_NEWTON4_1(NTV, NGV, NMINV, true, 0L, F_wide);                                                   \
+        else if (F_wide > 0) DSA_BIG_NEWTON_1(NTV, NGV, NMINV, true, true, 0L, F_wide);                                                 \
+        if (F_wide < (long)F) DSA_BIG_NEWTON_1(NTV, NGV, NMINV, true, false, F_wide, (long)F - F_wide);                                 \
+    } while (0)
 #define DSA_BIG_NEWTON(NTV, NGV, NMINV, QUADV)                                                                                          \
     do {                                                                                                                                \
         if (F_wide > 0) DSA_BIG_NEWTON_1(NTV, NGV, NMINV, QUADV, true, 0L, F_wide);                                                     \
@@ -768,7 +800,7 @@ int mcep_big_newton(const void* logx, int64_t F, int K, const void* mc_in, int M
     // (M1 = order + 1; the solver's instantiations as thsolve_quadn_fwd picks them: quad <9,28> up to 35, <11,36> up to 43, <13,44> up to
     //  51, <14,52>)
     if (quad) {
-        DSA_BIG_NEWTON(5, 9, 28, true);
+        DSA_BIG_NEWTON_Q(5, 9, 28);
     } else if (M1 <= 43) {
         if (nt == 5) DSA_BIG_NEWTON(5, 11, 36, false);
         else DSA_BIG_NEWTON(6, 11, 36, false);
@@ -779,7 +811,9 @@ int mcep_big_newton(const void* logx, int64_t F, int K, const void* mc_in, int M
         DSA_BIG_NEWTON(7, 14, 52, false);
     }
 #undef DSA_BIG_NEWTON
+#undef DSA_BIG_NEWTON_Q
 #undef DSA_BIG_NEWTON_1
+#undef DSA_BIG_NEWTON4_1
     return check_launch("mcep_big_newton");
 }
 

@@ -1016,3 +1016,50 @@ def test_48khz_newton_steps_wide_tiles_and_plan_give_the_narrow_tiles_bits(M, nf
         yp = m(Xbig)                                                     # the plan: one round of wide tiles + narrow tiles for the rest
         assert torch.equal(yn, yw) and torch.equal(yn, yp)
         assert torch.equal(yp[:3200], yp[3200:6400]) and torch.equal(yp[:700], y) and torch.equal(yp[35200:38400], yp[:3200])
+
+
+@pytest.mark.parametrize("M,nfft", [(34, 1024), (32, 2048), (33, 512)])
+def test_48khz_newton_steps_twin_workgroups_give_the_same_bits(M, nfft, monkeypatch):
+    """The TWIN-workgroup shape of dsa_mcep_newton_steps at the quad-layout orders (csrc/mcep_big4_f16.h: two four-wave workgroups per CU,
+    the second half a step late) against the eight-wave wide tiles, the narrow tiles and the two launches per step: the same bits per
+    frame at ragged sizes, over several rounds, whatever the stagger; non-finite frames contained."""
+    K = nfft // 2 + 1
+    g = torch.Generator().manual_seed(300 + M)
+    Xall = (torch.randn(3300, K, generator=g).square() + 0.05).to(DEV)
+
+    def run(mod, X, wide, twin, stagger=None, big="2"):
+        monkeypatch.setenv("DSA_MCEP_BIG", big)
+        monkeypatch.setenv("DSA_MCEP_BIG_WIDE", wide)
+        monkeypatch.setenv("DSA_MCEP_BIG_TWIN", twin)
+        if stagger is None:
+            monkeypatch.delenv("DSA_MCEP_BIG_STAGGER", raising=False)
+        else:
+            monkeypatch.setenv("DSA_MCEP_BIG_STAGGER", stagger)
+        with torch.no_grad():
+            return mod(X)
+
+    for F, n_iter in ((1, 2), (15, 10), (64, 0), (65, 3), (129, 10), (700, 10), (3217, 1)):
+        mi = dsp.MelCepstralAnalysis(fft_length=nfft, cep_order=M, alpha=0.55, n_iter=n_iter, device=DEV)
+        t = run(mi, Xall[:F], "1", "1")
+        assert n_iter == 0 or _lib.last_kernel() == "mcep_big_newton"
+        assert torch.equal(t, run(mi, Xall[:F], "1", "0")), (F, n_iter)         # eight-wave wide tiles
+        assert torch.equal(t, run(mi, Xall[:F], "0", "0")), (F, n_iter)         # narrow tiles
+        assert torch.equal(t, run(mi, Xall[:F], "1", "1", "0")), (F, n_iter)    # no stagger
+        assert torch.equal(t, run(mi, Xall[:F], "1", "1", "11")), (F, n_iter)
+    m = dsp.MelCepstralAnalysis(fft_length=nfft, cep_order=M, alpha=0.55, n_iter=10, device=DEV)
+    y = run(m, Xall[:700], "1", "1")
+    assert torch.equal(y, run(m, Xall[:700], "0", "0", big="0"))                # two launches per step
+    Xb = Xall[:700].clone()
+    Xb[[3, 64, 130, 699], 7] = float("nan")
+    yb = run(m, Xb, "1", "1")
+    keep = torch.ones(700, dtype=torch.bool, device=DEV)
+    keep[[3, 64, 130, 699]] = False
+    assert torch.equal(yb[keep], y[keep]) and not torch.isfinite(yb[~keep]).all(-1).any()
+    Xbig = Xall[:3200].repeat(23, 1)[:70001]                                    # 2.1 rounds of 512 twin workgroups, ragged end
+    yt = run(m, Xbig, "1", "1")
+    assert torch.equal(yt, run(m, Xbig, "1", "0"))
+    monkeypatch.delenv("DSA_MCEP_BIG_WIDE")
+    with torch.no_grad():
+        yp = m(Xbig)                                                            # the plan: twin rounds + narrow tiles for the rest
+    assert torch.equal(yp, yt)
+    assert torch.equal(yt[:3200], yt[3200:6400]) and torch.equal(yt[:700], y) and torch.equal(yt[64000:67200], yt[:3200])
