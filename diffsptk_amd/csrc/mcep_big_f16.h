@@ -24,6 +24,10 @@
 
 #include "thsolve_tq.h"
 
+#ifndef DSA_BIG_ABL
+#define DSA_BIG_ABL 0   // measurement builds only: 1 no solve, 2 no products (tools/build_variant.sh ... -DDSA_BIG_ABL=3)
+#endif
+
 namespace dsa {
 
 namespace mbg {
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __
 #endif
                 bool done_ = false;
                 if constexpr (WIDE && !QUAD && DSA_BIG_WIDE_INTERLEAVE) {   // (measured, profiles/r06_mcep_big_wide.txt: 2048 / 49 -1 .. -4 %; the quad-layout orders +3 .. +6 %: off there)
-                    if (tile_ok && 2 * ip + 1 < nstage) {
+                    if (tile_ok && 2 * ip + 1 < nstage && !(DSA_BIG_ABL & 2)) {
                         // Both stages of the pair, software-pipelined INSIDE the wave: the matrix pipe and the vector unit are separate
                         // pipes, and a stage alone uses them one after the other (stamps: first chain, t / max / exp / split, second chain
                         // ~0.45 / 0.6 / 0.7 k cycles, each at its own pipe's rate when both waves of a SIMD are in the same phase).  Here the
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __
                 for (int hs = 0; hs < NSTG; ++hs) {
                     const int hsx = WIDE ? hs : hsel;
                     const int j = 2 * ip + hsx;
-                    if (tile_ok && j < nstage) {
+                    if (tile_ok && j < nstage && !(DSA_BIG_ABL & 2)) {
                         const f16x8* c1 = reinterpret_cast<const f16x8*>(sbuf0 + (set * 2 + hsx) * SH) + lane;
                         const f16x8* w2 = c1 + (4 * KS1 * 512) / 8;
                         f32x4 s[2] = {zero4, zero4};
@@ -531,7 +535,7 @@ __global__ __launch_bounds__(512, 1) void mcep_big_newton_kernel(const float* __
             }
             BIG_STAMP(3);
             // ================= mc += solve(T(rt[:n]) + H(rt), rt[:n] - alpha_vec): eight systems per wave and round =================
-            if (tile_ok && (WIDE || !QUAD || hsel == 0)) {
+            if (tile_ok && (WIDE || !QUAD || hsel == 0) && !(DSA_BIG_ABL & 1)) {
 #pragma unroll 1
                 for (int rnd = 0; rnd < ROUNDS; ++rnd) {
                     int ln = lane;
