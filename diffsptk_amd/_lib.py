@@ -138,6 +138,7 @@ SIGNATURES = {
     "dsa_mcep_resid_bwd_images_bytes": (C.c_int64, [_I, _I]),
     "dsa_mcep_resid_bwd_prepare": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "dsa_mcep_newton_resid_h_bwd": (C.c_int, [_P, _L, _I, _P, _I, _P, _P, _I, _P, _P, _P]),
+    "dsa_mcep_newton_glogx_h": (C.c_int, [_P, _L, _I, _P, _I, _P, _I, _P, _I, _P, _P]),
     "dsa_mcep_newton_steps": (C.c_int, [_P, _L, _I, _P, _I, _P, _P, _I, _I, _P, _P]),
     "dsa_rows_ew": (C.c_int, [_I, _I, _P, _P, _P, _L, _I, _P, _P, _P]),
     "dsa_irfft_scale": (C.c_int, [_P, _L, _I, _I, _P, _P]),

@@ -82,6 +82,8 @@ int mcep_resid_h_prepare(const void* D, int ldd, const void* E, int lde, int K, 
 int mcep_resid_h_fwd(const void* logx, int64_t F, int K, const void* mc, int M1, const void* images, void* out, int ldo, hipStream_t st);
 int64_t mcep_resid_bwd_images_bytes(int K, int M1);
 int mcep_resid_bwd_prepare(const void* D, int ldd, const void* E, int lde, int K, int M1, void* images, hipStream_t st);
+int mcep_glogx_h(const void* logx, int64_t F, int K, const void* mcs, int M1, const void* grts, int n_iter, const void* images, void* glogx,
+                 hipStream_t st);
 int mcep_resid_bwd_h(const void* logx, int64_t F, int K, const void* mc, int M1, const void* grt, const void* images, void* glogx, void* gmc,
                      hipStream_t st);
 int mcep_big_newton(const void* logx, int64_t F, int K, const void* mc_in, int M1, const void* images, const void* av, int n_iter,

@@ -592,6 +592,7 @@ int thsolve_quad24_fwd(const void* p, const void* q, const void* r, int64_t F, v
 #include "mgcep_step_f16.h"
 #include "mcep_resid_f16.h"
 #include "mcep_resid_bwd_f16.h"
+#include "mcep_glogx_f16.h"
 #include "mcep_big_f16.h"
 #include "mcep_big4_f16.h"
 #ifdef DSA_MCEP_BWD_PAIR_EXPERIMENT   // round 5: built, measured, not adopted (tools/experiments/mcep_mfma_bwd_pair.h)

@@ -79,7 +79,10 @@ __global__ __launch_bounds__(256) void mcep_resid_bwd_prep_kernel(const float* _
     split1(v, img[base], img[base + 512]);
 }
 
-template <int KS1, int KSE, int NT3>
+// GX = false (0.2.2): glogx is NOT touched -- z = ebar e only feeds the third chain; the sum over the Newton steps is then formed in one
+// pass over the bins by mcep_glogx_h_kernel (mcep_glogx_f16.h) from the saved iterates and cotangents, and a step's launch moves 420 MB
+// instead of 1.26 GB per 102 400 frames at 1025 bins.
+template <int KS1, int KSE, int NT3, bool GX = true>
 __global__ __launch_bounds__(256, 2) DSA_PK_TARGET void mcep_resid_bwd_h_kernel(const float* __restrict__ logx, long F, int K, const float* __restrict__ mc,
                                                                                  int M1, const float* __restrict__ grt, int N,
                                                                                  const _Float16* __restrict__ img, float* glogx,
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256, 2) DSA_PK_TARGET void mcep_resid_bwd_h_kernel(
     const int rn = n < rows_here ? n : rows_here - 1;
     const bool row_ok = tile_ok && n < rows_here;
     const float* xt = logx + tb * (long)K + (long)rn * K;
-    float* gxt = glogx + tb * (long)K + (long)rn * K;
+    float* gxt = GX ? glogx + tb * (long)K + (long)rn * K : nullptr;
     const f32x4* img4 = reinterpret_cast<const f32x4*>(img);
     // (Measured and not kept, profiles/r06_48khz_gradient_one_node.txt: every load and store of the stage loop unconditional -- clamped
     // addresses, raw-buffer stores pushed out of range where nothing is to be written, the partial last stage's bin in registers of its
@@ -183,14 +186,15 @@ __global__ __launch_bounds__(256, 2) DSA_PK_TARGET void mcep_resid_bwd_h_kernel(
             const int b0 = 32 * j + 16 * t + 4 * g;
             if (b0 + 3 < K) {
                 xr[t] = *reinterpret_cast<const f32x4_u4*>(xt + b0);
-                ar[t] = *reinterpret_cast<const f32x4_u4*>(gxt + b0);
+                if constexpr (GX) ar[t] = *reinterpret_cast<const f32x4_u4*>(gxt + b0);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     xr[t][r] = xt[b0 + r < K ? b0 + r : K - 1];
-                    ar[t][r] = gxt[b0 + r < K ? b0 + r : K - 1];
+                    if constexpr (GX) ar[t][r] = gxt[b0 + r < K ? b0 + r : K - 1];
                 }
             }
+            if constexpr (!GX) ar[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     xfetch(0, x0, a0);
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(256, 2) DSA_PK_TARGET void mcep_resid_bwd_h_kernel(
                     zm = __builtin_fmaxf(zm, __builtin_fabsf(z));
                     o[r] += z;
                 }
-                if (row_ok) {
+                if (GX && row_ok) {
                     const int b0 = 32 * j + 16 * t + 4 * g;
                     if (b0 + 3 < K) {
                         *reinterpret_cast<f32x4_u4*>(gxt + b0) = o;
@@ -321,11 +325,18 @@ int mcep_resid_bwd_h(const void* logx, int64_t F, int K, const void* mc, int M1,
 #define DSA_RESID_BWD(KSEV, NT3V)                                                                                                         \
     do {                                                                                                                                  \
         constexpr int lds_b = 2 * mrb::stage_halves_b(2, KSEV, NT3V) * 2;                                                                 \
-        static std::atomic<uint64_t> attr{0};                                                                                             \
-        if (!ensure_dynamic_lds((const void*)mcep_resid_bwd_h_kernel<2, KSEV, NT3V>, lds_b, attr))                                        \
-            return fail(DSA_ERR_LAUNCH, "mcep_resid_bwd_h: cannot reserve LDS%s");                                                        \
-        hipLaunchKernelGGL((mcep_resid_bwd_h_kernel<2, KSEV, NT3V>), grid, dim3(256), lds_b, st, (const float*)logx, (long)F, K,          \
-                           (const float*)mc, M1, (const float*)grt, N, (const _Float16*)images, (float*)glogx, (float*)gmc);              \
+        static std::atomic<uint64_t> attr{0}, attr0{0};                                                                                   \
+        if (glogx) {                                                                                                                      \
+            if (!ensure_dynamic_lds((const void*)mcep_resid_bwd_h_kernel<2, KSEV, NT3V, true>, lds_b, attr))                              \
+                return fail(DSA_ERR_LAUNCH, "mcep_resid_bwd_h: cannot reserve LDS%s");                                                    \
+            hipLaunchKernelGGL((mcep_resid_bwd_h_kernel<2, KSEV, NT3V, true>), grid, dim3(256), lds_b, st, (const float*)logx, (long)F, K, \
+                               (const float*)mc, M1, (const float*)grt, N, (const _Float16*)images, (float*)glogx, (float*)gmc);          \
+        } else {                                                                                                                          \
+            if (!ensure_dynamic_lds((const void*)mcep_resid_bwd_h_kernel<2, KSEV, NT3V, false>, lds_b, attr0))                            \
+                return fail(DSA_ERR_LAUNCH, "mcep_resid_bwd_h: cannot reserve LDS%s");                                                    \
+            hipLaunchKernelGGL((mcep_resid_bwd_h_kernel<2, KSEV, NT3V, false>), grid, dim3(256), lds_b, st, (const float*)logx, (long)F, K, \
+                               (const float*)mc, M1, (const float*)grt, N, (const _Float16*)images, (float*)nullptr, (float*)gmc);        \
+        }                                                                                                                                 \
     } while (0)
     (void)nt3;
     if (kse == 3) DSA_RESID_BWD(3, 3);   // M1 33 .. 48: N = 2 M1 - 1 <= 95 columns of rt, three tiles of coefficients

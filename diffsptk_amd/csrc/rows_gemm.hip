@@ -682,12 +682,23 @@ DSA_EXPORT int dsa_mcep_newton_resid_h_bwd(const void* logx, int64_t F, int32_t 
                                            int32_t dtype, void* glogx, void* gmc, void* stream)
 {
     DSA_REQUIRE(F >= 0 && K >= 4 && n >= 3, "mcep_newton_resid_h_bwd: invalid sizes");
-    DSA_REQUIRE(logx && mc && grt && images && glogx && gmc, "mcep_newton_resid_h_bwd: null pointer");
+    DSA_REQUIRE(logx && mc && grt && images && gmc, "mcep_newton_resid_h_bwd: null pointer");   // (glogx may be NULL since 0.2.2: not accumulated)
     if (dtype != DSA_F32) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_resid_h_bwd: float32 only%s");
     if (F == 0) return DSA_OK;
     const int rc = dsa::mcep_resid_bwd_h(logx, F, K, mc, n, grt, images, glogx, gmc, (hipStream_t)stream);
     if (rc == DSA_ERR_UNSUPPORTED) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_resid_h_bwd: orders 32 .. 54%s");
     return rc;
+}
+
+// (0.2.2) glogx of the whole analysis in one pass over the bins (csrc/mcep_glogx_f16.h), after a sweep run with glogx = NULL
+DSA_EXPORT int dsa_mcep_newton_glogx_h(const void* logx, int64_t F, int32_t K, const void* mcs, int32_t n, const void* grts, int32_t n_iter,
+                                       const void* images, int32_t dtype, void* glogx, void* stream)
+{
+    DSA_REQUIRE(F >= 0 && K >= 4 && n >= 3 && n_iter >= 1, "mcep_newton_glogx_h: invalid sizes");
+    DSA_REQUIRE(logx && mcs && grts && images && glogx, "mcep_newton_glogx_h: null pointer");
+    if (dtype != DSA_F32) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_glogx_h: float32 only%s");
+    if (F == 0) return DSA_OK;
+    return dsa::mcep_glogx_h(logx, F, K, mcs, n, grts, n_iter, images, glogx, (hipStream_t)stream);   // DSA_ERR_UNSUPPORTED: no error text
 }
 
 DSA_EXPORT int dsa_mcep_newton_resid_h(const void* logx, int64_t F, int32_t K, const void* mc, int32_t n, const void* images, int32_t dtype,

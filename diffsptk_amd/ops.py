@@ -994,6 +994,10 @@ def mcep_resid_bwd_images(D, E):
     return images
 
 
+MCEP_GLOGX_ONE_PASS = True   # McepNewtonStepsHFn.backward: glogx in one pass after the sweep (dsa_mcep_newton_glogx_h)
+MCEP_GLOGX_MIN_FRAMES = 32768
+
+
 class McepNewtonStepsHFn(torch.autograd.Function):
     """mcep.py:208-222 at the 48 kHz set-ups (orders 32 .. 54) WITH a gradient, as one node (round 6): forward = per Newton step
     dsa_mcep_newton_resid_h + dsa_mcep_newton_update, the iterates, rt rows and solutions kept ((3 n + ...) floats per frame and step
@@ -1030,14 +1034,42 @@ class McepNewtonStepsHFn(torch.autograd.Function):
         K = lx.size(-1)
         images_b = mcep_resid_bwd_images(D, E)
         gbar = g.reshape(F, n).contiguous().clone()
-        glogx = torch.zeros_like(lx)
-        u, grt, gmc = torch.empty_like(gbar), torch.empty_like(rts[0]), torch.empty_like(gbar)
+        u, gmc = torch.empty_like(gbar), torch.empty_like(gbar)
+        # 0.2.2: the sum over the steps that lands in glogx is formed AFTER the sweep, in one pass over the bins from the iterates and the
+        # steps' cotangents grt (kept: 4 (2 n - 1) bytes per frame and step) -- dsa_mcep_newton_glogx_h; the sweep's launches then leave
+        # glogx alone (a step moves the (F, K) array once instead of three times).  Same values summed in the same order: the same bits
+        # as the in-place accumulation (DSA_MCEP_GLOGX_PASS=0, and n_iter beyond what the pass holds on chip).
+        # (from MCEP_GLOGX_MIN_FRAMES frames on: below, the pass's one-tile workgroups leave CUs idle -- 12 800 frames at 2048 / 49: 2.42 ms
+        #  accumulating, 2.48 with the pass; DSA_MCEP_GLOGX_PASS=1 forces it, =0 forbids it.  The bits do not depend on the choice.)
+        env = os.environ.get("DSA_MCEP_GLOGX_PASS", "")
+        one_pass = (MCEP_GLOGX_ONE_PASS and env != "0" and (F >= MCEP_GLOGX_MIN_FRAMES or env == "1")
+                    and n_iter * ((4 + 2 * ((2 * n - 1 + 31) // 32)) * 1024 + 128) <= 156 * 1024)
         with torch.cuda.device(g.device):
-            for i in range(n_iter - 1, -1, -1):
-                _call("dsa_mcep_newton_update_bwd", _p(gbar), _p(rts[i]), _p(sols[i]), F, n, _dtype_code(lx), _p(u), _p(grt), _stream())
-                _call("dsa_mcep_newton_resid_h_bwd", _p(lx), F, K, _p(mcs[i]), n, _p(grt), _p(images_b), _dtype_code(lx), _p(glogx), _p(gmc),
-                      _stream())
-                gbar.add_(gmc)
+            if one_pass:
+                grts = torch.empty_like(rts)
+                for i in range(n_iter - 1, -1, -1):
+                    _call("dsa_mcep_newton_update_bwd", _p(gbar), _p(rts[i]), _p(sols[i]), F, n, _dtype_code(lx), _p(u), _p(grts[i]), _stream())
+                    _call("dsa_mcep_newton_resid_h_bwd", _p(lx), F, K, _p(mcs[i]), n, _p(grts[i]), _p(images_b), _dtype_code(lx), None, _p(gmc),
+                          _stream())
+                    gbar.add_(gmc)
+                glogx = torch.empty_like(lx)
+                rc = getattr(_lib.load(), "dsa_mcep_newton_glogx_h")(_p(lx), F, K, _p(mcs), n, _p(grts), int(n_iter), _p(images_b),
+                                                                       _dtype_code(lx), _p(glogx), _stream())
+                if rc == _lib.ERR_UNSUPPORTED:   # (cannot happen for what mcep_newton_steps_grad_applies admits; kept as the contract says)
+                    glogx.zero_()
+                    for i in range(n_iter):
+                        _call("dsa_mcep_newton_resid_h_bwd", _p(lx), F, K, _p(mcs[i]), n, _p(grts[i]), _p(images_b), _dtype_code(lx), _p(glogx),
+                              _p(gmc), _stream())
+                else:
+                    _lib.check(rc, "dsa_mcep_newton_glogx_h")
+            else:
+                glogx = torch.zeros_like(lx)
+                grt = torch.empty_like(rts[0])
+                for i in range(n_iter - 1, -1, -1):
+                    _call("dsa_mcep_newton_update_bwd", _p(gbar), _p(rts[i]), _p(sols[i]), F, n, _dtype_code(lx), _p(u), _p(grt), _stream())
+                    _call("dsa_mcep_newton_resid_h_bwd", _p(lx), F, K, _p(mcs[i]), n, _p(grt), _p(images_b), _dtype_code(lx), _p(glogx), _p(gmc),
+                          _stream())
+                    gbar.add_(gmc)
         return glogx.reshape(lx.shape), gbar.reshape(g.shape), None, None, None, None
 
 

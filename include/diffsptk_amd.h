@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 127 /* 0.2.1: + dsa_mcep_resid_bwd_images_bytes / _prepare, dsa_mcep_newton_resid_h_bwd (the 48 kHz analysis with a gradient: the step's backward in two launches); wide tiles in dsa_mcep_newton_steps; 0.2.0: + dsa_mcep_newton_steps, dsa_stft_mcep_opts_fwd, DSA_ALGO_OVERLAPPED_LAUNCHES, DSA_ALGO_PAD_MODE, packed STFT kernels for fft_length 1024 / 2048 and for every pad mode at 512; 0.1.9: + dsa_mgcep_step_solve, dsa_mgcep_step_bwd_h, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
+#define DSA_VERSION 128 /* 0.2.2: + dsa_mcep_newton_glogx_h (glogx of the 48 kHz analysis in one pass after the sweep; dsa_mcep_newton_resid_h_bwd takes glogx = NULL); twin workgroups in dsa_mcep_newton_steps; 0.2.1: + dsa_mcep_resid_bwd_images_bytes / _prepare, dsa_mcep_newton_resid_h_bwd (the 48 kHz analysis with a gradient: the step's backward in two launches); wide tiles in dsa_mcep_newton_steps; 0.2.0: + dsa_mcep_newton_steps, dsa_stft_mcep_opts_fwd, DSA_ALGO_OVERLAPPED_LAUNCHES, DSA_ALGO_PAD_MODE, packed STFT kernels for fft_length 1024 / 2048 and for every pad mode at 512; 0.1.9: + dsa_mgcep_step_solve, dsa_mgcep_step_bwd_h, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
@@ -318,6 +318,17 @@ int dsa_mcep_resid_bwd_prepare(const void* D, int32_t ldd, const void* E, int32_
                                void* stream);
 int dsa_mcep_newton_resid_h_bwd(const void* logx, int64_t F, int32_t K, const void* mc, int32_t n, const void* grt, const void* images,
                                 int32_t dtype, void* glogx, void* gmc, void* stream);
+/* (0.2.2) The sum over the Newton steps that dsa_mcep_newton_resid_h_bwd accumulates into glogx, formed in ONE pass over the bins after
+ * the reverse sweep instead (autograd of mcep.py:210-215 summed over mcep.py:208-222's iterations):
+ *   glogx[f, k] = sum_s (sum_j grts[s][f][j] E[k][j]) * exp(logx[f][k] - 2 sum_c mcs[s][f][c] D[c][k])
+ * mcs:(n_iter, F, n) the iterates the steps started from, grts:(n_iter, F, 2n - 1) the cotangents of their rt rows
+ * (dsa_mcep_newton_update_bwd's `grt`, kept per step), images of dsa_mcep_resid_bwd_prepare; glogx:(F, K) is WRITTEN.  The sweep's
+ * launches then pass glogx = NULL to dsa_mcep_newton_resid_h_bwd (a step moves the (F, K) array once instead of three times).  The
+ * steps are summed in the sweep's order on the same values: bit-identical to the in-place accumulation.  DSA_ERR_UNSUPPORTED
+ * (no error text): orders outside 32 .. 54, or n_iter above what one workgroup's LDS holds (12 at orders >= 48, 15 below) -- the
+ * caller keeps the in-place accumulation. */
+int dsa_mcep_newton_glogx_h(const void* logx, int64_t F, int32_t K, const void* mcs, int32_t n, const void* grts, int32_t n_iter,
+                            const void* images, int32_t dtype, void* glogx, void* stream);
 /* General float32 row product on the matrix instruction, for shapes the kernels behind dsa_freqt_fwd / _bwd do not cover (rows
  * of 512 values and more: the 1025-bin products of the 48 kHz set-ups of utils/public.py:22-104) and for the Newton step of
  * MelCepstralAnalysis (mcep.py:203-215) at geometries without a tuned kernel:

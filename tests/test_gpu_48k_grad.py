@@ -136,3 +136,69 @@ def test_48khz_gradient_is_batch_invariant(nfft, M):
     for lo, hi in ((0, 1), (5, 8), (100, 170), (19990, 20000)):
         ys, gs = _grads(m, X[lo:hi], w[lo:hi])
         assert torch.equal(ys, yb[lo:hi]) and torch.equal(gs, gb[lo:hi]), (lo, hi)
+
+
+@pytest.mark.parametrize("nfft,M,n_iter", [(2048, 49, 10), (1024, 34, 10), (2048, 54, 12), (2048, 32, 3), (1000, 40, 1), (2048, 48, 15)])
+def test_48khz_glogx_in_one_pass_equals_the_in_place_accumulation_bit_for_bit(nfft, M, n_iter, monkeypatch):
+    """0.2.2: the spectrum's gradient formed AFTER the reverse sweep, in one pass over the bins from the saved iterates and the steps'
+    cotangents (dsa_mcep_newton_glogx_h; the sweep's launches pass glogx = NULL), against the sweep's in-place accumulation
+    (DSA_MCEP_GLOGX_PASS=0): the same values summed in the same order -- the same bits, at ragged batch sizes and bin counts; n_iter
+    beyond what the pass holds on chip (13 at orders >= 48) keeps the accumulation."""
+    K = nfft // 2 + 1
+    g = torch.Generator().manual_seed(2000 + M + n_iter)
+    m = dsp.MelCepstralAnalysis(fft_length=nfft, cep_order=M, alpha=0.5, n_iter=n_iter, device=DEV)
+    assert ops.mcep_newton_steps_grad_applies(M + 1, m.D, m.E, m.alpha_vector)
+    for F in (1, 17, 333):
+        X = (torch.randn(F, K, generator=g).square() + 0.05).to(DEV)
+        w = torch.randn(F, M + 1, generator=g).to(DEV)
+        monkeypatch.setenv("DSA_MCEP_GLOGX_PASS", "1")
+        y1, g1 = _grads(m, X, w)
+        k1 = _lib.last_kernel()
+        monkeypatch.setenv("DSA_MCEP_GLOGX_PASS", "0")
+        y0, g0 = _grads(m, X, w)
+        assert torch.equal(y1, y0) and torch.isfinite(g1).all()
+        assert torch.equal(g1, g0), (F, float((g1 - g0).abs().max()))
+    fits = n_iter * ((4 + 2 * ((2 * (M + 1) - 1 + 31) // 32)) * 1024 + 128) <= 156 * 1024
+    assert fits == (n_iter <= (12 if M + 1 >= 49 else 15))
+    # a non-finite frame stays in its own row
+    # by default the pass takes over from ops.MCEP_GLOGX_MIN_FRAMES frames on -- the same bits either side of the threshold
+    monkeypatch.delenv("DSA_MCEP_GLOGX_PASS")
+    monkeypatch.setattr(ops, "MCEP_GLOGX_MIN_FRAMES", 300)
+    assert torch.equal(_grads(m, X, w)[1], g1)
+    monkeypatch.setattr(ops, "MCEP_GLOGX_MIN_FRAMES", 400)
+    assert torch.equal(_grads(m, X, w)[1], g1)
+    Xb = X.clone()
+    Xb[5, 3] = float("nan")
+    monkeypatch.setenv("DSA_MCEP_GLOGX_PASS", "1")
+    _, gb = _grads(m, Xb, w)
+    keep = torch.ones(F, dtype=torch.bool, device=DEV)
+    keep[5] = False
+    assert torch.equal(gb[keep], g1[keep]) and not torch.isfinite(gb[5]).all()
+
+
+def test_glogx_entry_against_float64_of_its_formula_and_null_glogx_in_the_sweep():
+    """dsa_mcep_newton_glogx_h alone against float64 of  sum_s (grt_s E^T) * exp(logx - 2 mc_s D); dsa_mcep_newton_resid_h_bwd with
+    glogx = NULL returns the gmc of the accumulating call, bit for bit."""
+    K, n, n_iter, F = 1025, 50, 4, 37
+    g = torch.Generator().manual_seed(9)
+    m = dsp.MelCepstralAnalysis(fft_length=2 * (K - 1), cep_order=n - 1, alpha=0.55, n_iter=1, device=DEV)
+    images = ops.mcep_resid_bwd_images(m.D, m.E)
+    logx = (torch.randn(F, K, generator=g) * 0.7).to(DEV)
+    mcs = (torch.randn(n_iter, F, n, generator=g) * 0.02).to(DEV)
+    mcs[:, :, 0] += 0.3
+    grts = torch.randn(n_iter, F, 2 * n - 1, generator=g).to(DEV)
+    glogx = torch.empty(F, K, device=DEV)
+    ops._call("dsa_mcep_newton_glogx_h", ops._p(logx), F, K, ops._p(mcs), n, ops._p(grts), n_iter, ops._p(images), ops._dtype_code(logx),
+              ops._p(glogx), ops._stream())
+    D, E = m.D.double(), m.E.double()
+    ref = sum((grts[s].double() @ E.T) * torch.exp(logx.double() - 2 * mcs[s].double() @ D) for s in range(n_iter))
+    assert _rel_rows(glogx, ref) < 2e-6, _rel_rows(glogx, ref)
+    acc = torch.zeros(F, K, device=DEV)
+    gm_a, gm_n = torch.empty(F, n, device=DEV), torch.empty(F, n, device=DEV)
+    for s in range(n_iter - 1, -1, -1):
+        ops._call("dsa_mcep_newton_resid_h_bwd", ops._p(logx), F, K, ops._p(mcs[s]), n, ops._p(grts[s]), ops._p(images), ops._dtype_code(logx),
+                  ops._p(acc), ops._p(gm_a), ops._stream())
+        ops._call("dsa_mcep_newton_resid_h_bwd", ops._p(logx), F, K, ops._p(mcs[s]), n, ops._p(grts[s]), ops._p(images), ops._dtype_code(logx),
+                  None, ops._p(gm_n), ops._stream())
+        assert torch.equal(gm_a, gm_n), s
+    assert torch.equal(acc, glogx)
