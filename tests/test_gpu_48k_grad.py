@@ -176,11 +176,11 @@ def test_48khz_glogx_in_one_pass_equals_the_in_place_accumulation_bit_for_bit(nf
     assert torch.equal(gb[keep], g1[keep]) and not torch.isfinite(gb[5]).all()
 
 
-def test_glogx_entry_against_float64_of_its_formula_and_null_glogx_in_the_sweep():
+@pytest.mark.parametrize("K,n,n_iter,F", [(1025, 50, 4, 37), (513, 35, 10, 100), (37, 33, 3, 5), (129, 40, 1, 16), (501, 41, 7, 33), (1024, 55, 12, 3)])
+def test_glogx_entry_against_float64_of_its_formula_and_null_glogx_in_the_sweep(K, n, n_iter, F):
     """dsa_mcep_newton_glogx_h alone against float64 of  sum_s (grt_s E^T) * exp(logx - 2 mc_s D); dsa_mcep_newton_resid_h_bwd with
-    glogx = NULL returns the gmc of the accumulating call, bit for bit."""
-    K, n, n_iter, F = 1025, 50, 4, 37
-    g = torch.Generator().manual_seed(9)
+    glogx = NULL returns the gmc of the accumulating call, bit for bit; ragged bin counts (a last unit of 5, 1, 16 bins), one step."""
+    g = torch.Generator().manual_seed(9 + K)
     m = dsp.MelCepstralAnalysis(fft_length=2 * (K - 1), cep_order=n - 1, alpha=0.55, n_iter=1, device=DEV)
     images = ops.mcep_resid_bwd_images(m.D, m.E)
     logx = (torch.randn(F, K, generator=g) * 0.7).to(DEV)
