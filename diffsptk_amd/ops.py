@@ -995,7 +995,7 @@ def mcep_resid_bwd_images(D, E):
 
 
 MCEP_GLOGX_ONE_PASS = True   # McepNewtonStepsHFn.backward: glogx in one pass after the sweep (dsa_mcep_newton_glogx_h)
-MCEP_GLOGX_MIN_FRAMES = 32768
+MCEP_GLOGX_MIN_FRAMES = 20480   # (tools/sweep_glogx_threshold.py: 16 384 frames 2.55 against 2.53 ms accumulating, 24 576: 3.40 against 3.73)
 
 
 class McepNewtonStepsHFn(torch.autograd.Function):
