@@ -36,7 +36,7 @@ constexpr int lds_floats()
 template <int KS1, int NT, int NG, int NMIN, bool QUAD>
 __global__ __launch_bounds__(256, 2) void mcep_big_newton4_kernel(const float* __restrict__ logx, long F, int K, const float* __restrict__ mc_in,
                                                                   int M1, const _Float16* __restrict__ img, const float* __restrict__ av,
-                                                                  int n_iter, float* __restrict__ mc_out, int stagger, int abl)
+                                                                  int n_iter, float* __restrict__ mc_out, int stagger)
 {
     using namespace mrh;
     using G = mbg::Geo<NG, QUAD>;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void mcep_big_newton4_kernel(const float* _
                 const f32x4 xv[2] = {xr[0], xr[1]};
                 fetch(j + 1, st0);
                 xfetch(j + 2 < nstage ? j + 2 : nstage - 1, xr);
-                if (tile_ok && !(abl & 2)) {
+                if (tile_ok && !(DSA_BIG_ABL & 2)) {
                     const f16x8* c1 = reinterpret_cast<const f16x8*>(sbuf0 + buf * SH) + lane;
                     const f16x8* w2 = c1 + (4 * KS1 * 512) / 8;
                     f32x4 s[2] = {zero4, zero4};
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void mcep_big_newton4_kernel(const float* _
             for (int tc = 0; tc < NT; ++tc) *reinterpret_cast<f32x4*>(park + n * RTS + 16 * tc + 4 * g) = acc[0][tc] + acc[1][tc];
             __builtin_amdgcn_wave_barrier();
             // ================= mc += solve(T(rt[:n]) + H(rt), rt[:n] - alpha_vec) =================
-            if (tile_ok && !(abl & 1)) {
+            if (tile_ok && !(DSA_BIG_ABL & 1)) {
 #pragma unroll 1
                 for (int rnd = 0; rnd < ROUNDS; ++rnd) {
                     int ln = lane;

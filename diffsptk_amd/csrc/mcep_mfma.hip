@@ -759,8 +759,6 @@ int mcep_big_newton(const void* logx, int64_t F, int K, const void* mc_in, int M
     const long F_wide = wide_rounds * FW < F ? wide_rounds * FW : (wide_rounds > 0 ? (long)F : 0);
     const char* stag_e = getenv("DSA_MCEP_BIG_STAGGER");
     const int stagger = stag_e ? atoi(stag_e) : 5;                // x ~8 k cycles (measured 4 .. 6 best: profiles/r06_mcep_big_twin.txt)
-    const char* abl_e = getenv("DSA_MCEP_BIG_ABL");                  // measurement only: 1 no solve, 2 no products
-    const int abl = abl_e ? atoi(abl_e) : 0;
 #define DSA_BIG_NEWTON_1(NTV, NGV, NMINV, QUADV, WIDEV, F0, FC)                                                                         \
     do {                                                                                                                                \
         constexpr int lds_b = mbg::lds_floats<2, NTV, NGV, QUADV, WIDEV>() * 4;                                                         \
@@ -785,7 +783,7 @@ int mcep_big_newton(const void* logx, int64_t F, int K, const void* mc_in, int M
         const long grid_ = tiles_ < 512 ? tiles_ : 512;   /* persistent: two four-wave workgroups per CU */                             \
         hipLaunchKernelGGL((mcep_big_newton4_kernel<2, NTV, NGV, NMINV, QUADV>), dim3((unsigned)grid_), dim3(256), lds_b, st,           \
                            (const float*)logx + (F0) * (long)K, (long)(FC), K, (const float*)mc_in + (F0) * (long)M1, M1,               \
-                           (const _Float16*)images, (const float*)av, n_iter, (float*)mc_out + (F0) * (long)M1, stagger, abl);               \
+                           (const _Float16*)images, (const float*)av, n_iter, (float*)mc_out + (F0) * (long)M1, stagger);               \
     } while (0)
 #define DSA_BIG_NEWTON_Q(NTV, NGV, NMINV)                                                                                               \
     do {                                                                                                                                \

@@ -1,4 +1,6 @@
-"""Ablation timings of the twin-workgroup Newton kernel (DSA_MCEP_BIG_ABL: 1 no solve, 2 no products; results are garbage, times are not)."""
+"""Ablation timings of the twin-workgroup Newton kernel.  The ablations are COMPILE-TIME since the round's end (tools/build_variant.sh <out.so> mcep_mfma.hip
+-DDSA_BIG_ABL=1|2|3: 1 no solve, 2 no products; results are garbage, times are not): run this script under tools/ab_libs.sh with those builds -- the
+DSA_MCEP_BIG_ABL variable it sets is no longer read by the library (the numbers of profiles/r06_mcep_big_twin.txt were taken with the run-time switch)."""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import diffsptk_amd as dsp
