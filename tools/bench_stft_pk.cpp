@@ -27,10 +27,10 @@ static float run(int iters, int waves_per_cu)
         if (PF2)
             hipLaunchKernelGGL((dsa::stft512_fwd_pk_kernel<ABL, 400, true, 0, true>), dim3((unsigned)((grid + 3) / 4)), dim3(256),
                                4 * dsa::kFPW * dsa::kZS * 8 + 256 * 8 + 16 * 13 * 8 + 64, 0, gx, gT, gN, L, P, 200, gw, gtw, 1e-9f, gy,
-                               total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0);
+                               total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0, 0, 0);
         else
         hipLaunchKernelGGL((dsa::stft512_fwd_pk_kernel<ABL, 400, DIRECT>), dim3((unsigned)((grid + 1) / 2)), dim3(128), lds2, 0, gx, gT, gN, L,
-                           P, 200, gw, gtw, 1e-9f, gy, total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0);
+                           P, 200, gw, gtw, 1e-9f, gy, total_chunks, chunks_per_utt, (const float*)nullptr, 0.f, 0.f, 0, 0, 0);
     };
     for (int i = 0; i < 3; ++i) launch();
     hipEventRecord(e0);
@@ -75,6 +75,9 @@ int main(int argc, char** argv)
         printf("  DIRECT stores: full %.1f | no-store %.1f | no-load %.1f | no-fft %.1f | no load/store %.1f | wpc12 %.1f\n", run<0, true>(20, wpc), run<1, true>(20, wpc),
                run<4, true>(20, wpc), run<2, true>(20, wpc), run<5, true>(20, wpc), run<0, true>(20, 12));
     }
+    for (int rep = 0; rep < 3; ++rep)
+        printf("DIRECT, twiddle-table reads: base %.1f | no-twtab(8) %.1f | base %.1f | no-twtab(8) %.1f\n", run<0, true>(20, 16), run<8, true>(20, 16),
+               run<0, true>(20, 16), run<8, true>(20, 16));
     for (int rep = 0; rep < 2; ++rep)
         printf("DIRECT variants: base %.1f | xcd-contiguous %.1f | nontemporal %.1f | both %.1f | xcd, staged %.1f\n", run<0, true>(20, 16), run<256, true>(20, 16),
                run<512, true>(20, 16), run<768, true>(20, 16), run<256, false>(20, 16));
