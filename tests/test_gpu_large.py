@@ -1,0 +1,30 @@
+"""Tensors beyond 2^31 elements ("maximum sizes"; DESIGN.md 2: sizes are bounded by the grid, not by 32-bit element offsets).
+
+A batch whose spectrogram has more than 2^31 floats -- 42 000 utterances x 1 s at 16 kHz (8.4 M frames, 8 GiB), 10 600 at 48 kHz / fft 2048 --
+against the same utterances alone in a small batch: the utterances at the ends and on both sides of the 2^31-element boundary must come
+out BITWISE equal (every kernel of the path is batch-invariant), through the reference's module API: STFT, mcep(stft(x)), fuse(stft, mcep),
+fuse(frame, window, lpc), the 48 kHz STFT + one-launch Newton kernel; the gradient of mcep(stft(x)) within the gradient tolerance of the
+other tests (above ops.MCEP_HIST_RT_MAX_BYTES the backward recomputes the rt rows: another kernel) and exactly zero elsewhere.
+The checks themselves live in tools/check_large_sizes.py (also a command-line report).
+"""
+import importlib.util
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batches_beyond_2_31_elements_match_small_batches(capsys):
+    free, _total = torch.cuda.mem_get_info(0)
+    if free < 64 * 2 ** 30:
+        pytest.skip("needs 64 GiB of free device memory")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_large_sizes.py")
+    spec = importlib.util.spec_from_file_location("check_large_sizes", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = mod.run_all()
+    out = capsys.readouterr().out
+    assert bad == 0, out
+    assert out.count("bitwise equal to the small batch: True") >= 7, out

@@ -17,8 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import diffsptk_amd as dsp  # noqa: E402
 
 dev = torch.device("cuda", 0)
-B16 = int(sys.argv[1]) if len(sys.argv) > 1 else 42000
-B48 = int(sys.argv[2]) if len(sys.argv) > 2 else 10600
+B16, B48 = 42000, 10600
 bad = 0
 
 
@@ -75,6 +74,25 @@ def section_16k():
         torch.cuda.synchronize()
         same("fuse(frame, window, lpc)(x)", a[idx], fl(xs))
         del a
+        # ONE utterance of B16 x T samples (8.4 M frames): the frames around the 2^31-element boundary of its spectrogram against a
+        # 0.5 s cut of the waveform there (interior frames: the cut's zero padding reaches 200 samples in)
+        xl = x.reshape(1, B16 * T)
+        Nl = (B16 * T - 1) // FP + 1
+        m0 = ((2 ** 31) // 257 - 40) // 16 * 16
+        cut = xl[:, m0 * FP: m0 * FP + 8000].clone()
+        Xl = stft(xl)
+        torch.cuda.synchronize()
+        print(f"  one utterance of {B16 * T} samples: stft {tuple(Xl.shape)} ({dsp._lib.last_kernel()})", flush=True)
+        Xc = stft(cut)
+        same("STFT of the long utterance, frames around the boundary", Xl[0, m0 + 3: m0 + 96], Xc[0, 3:96])
+        same("STFT of the long utterance, last frames", Xl[0, Nl - 64:], stft(xl[:, (Nl - 96) * FP:].clone())[0, 32:])
+        del Xl
+        ml = fused(xl)
+        torch.cuda.synchronize()
+        same("fuse(stft, mcep) of the long utterance", ml[0, m0 + 3: m0 + 96], fused(cut)[0, 3:96])
+        al = fl(xl)
+        same("fuse(frame, window, lpc) of the long utterance", al[0, m0 + 3: m0 + 96], fl(cut)[0, 3:96])
+        del ml, al, xl
     # gradient of mcep(stft(x)) at the large size: a fixed random cotangent per utterance
     gsel = torch.randn(len(idx), N, M + 1, device=dev, generator=g)
     xg = x.requires_grad_(True)
@@ -128,7 +146,10 @@ def section_48k():
         same("mcep(stft(x)) at 2048 / 49", mc[idx], mcep(Xs))
 
 
-if __name__ == "__main__":
+def run_all(b16=42000, b48=10600):
+    """both sections; returns the number of mismatching / failing checks (tests/test_gpu_large.py calls this)"""
+    global B16, B48, bad
+    B16, B48, bad = b16, b48, 0
     for sec in (section_16k, section_48k):
         try:
             sec()
@@ -137,4 +158,8 @@ if __name__ == "__main__":
             print(f"  FAILED with {type(e).__name__}: {e}", flush=True)
         torch.cuda.empty_cache()
     print("mismatching / failing checks:", bad)
-    sys.exit(1 if bad else 0)
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run_all(*(int(a) for a in sys.argv[1:3])) else 0)
