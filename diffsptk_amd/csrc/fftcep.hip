@@ -398,7 +398,7 @@ DSA_EXPORT int dsa_fftcep_bwd(const void* gout, const void* x, int64_t F, int32_
 {
     DSA_REQUIRE(fft_length > 1 && fft_length % 2 == 0 && cep_order >= 0 && fft_length >= 2 * cep_order && F >= 0,
                 "fftcep_bwd: cep_order must be less than or equal to fft_length // 2");
-    DSA_REQUIRE(n_iter == 0 || masks, "fftcep_bwd: the clamp masks of the forward are required when n_iter > 0");
+    DSA_REQUIRE(F == 0 || n_iter == 0 || masks, "fftcep_bwd: the clamp masks of the forward are required when n_iter > 0");
     const int H = fft_length / 2 + 1, N = cep_order + 1;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DSA_F32) return fftcep_launch<float>(true, gout, x, F, H, N, A, accel, n_iter, nullptr, (void*)masks, gx, st);

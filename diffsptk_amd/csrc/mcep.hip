@@ -465,9 +465,9 @@ DSA_EXPORT int dsa_stft_mcep_opts_fwd(const void* x, int64_t B, int64_t T, int32
     const int64_t N = T <= 0 ? 0 : (T - 1) / P + 1;
     if (!(mcep_mfma_supported(nfft, M, dtype) && L == 400 && B * N < (int64_t(1) << 31) && T < (int64_t(1) << 31)))
         return fail(DSA_ERR_UNSUPPORTED, "stft_mcep: the fused launch covers float32, frame_length 400, fft_length 512, cep_order 24%s");
+    if (B * N == 0) return DSA_OK;   // an empty batch is a no-op (its tensors have no storage: checked before the pointers)
     DSA_REQUIRE(images && scratch, "stft_mcep: the prepared images (dsa_mcep_prepare) and a scratch buffer are required");
     DSA_REQUIRE(x && window && twiddle && G && D && E && alpha_vec && mc, "stft_mcep: null pointer");
-    if (B * N == 0) return DSA_OK;
     const float floor_lin = use_floor ? (float)pow(10.0, relative_floor_db / 10.0) : -1.f;
     return stft_mcep_fused_fwd(x, B, T, P, center, window, twiddle, eps, n_iter, G, D, E, alpha_vec, images, scratch, mc, mc_hist,
                                X_out, (hipStream_t)stream, scratch_clean, hist_has_rt, overlapped, pad_mode, zmean != 0, floor_lin);
@@ -490,8 +490,8 @@ DSA_EXPORT int dsa_mcep_bwd(const void* gmc, const void* X, const void* mc_hist,
 {
     DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "mcep_bwd: fft_length must be positive even");
     DSA_REQUIRE(M >= 0 && 2 * M <= nfft && n_iter >= 0 && F >= 0, "mcep_bwd: invalid sizes");
-    DSA_REQUIRE(mc_hist != nullptr, "mcep_bwd: the forward history is required");
     if (F == 0) return DSA_OK;
+    DSA_REQUIRE(mc_hist != nullptr, "mcep_bwd: the forward history is required");
     hipStream_t st = (hipStream_t)stream;
     const bool has_workspace = (algo & DSA_ALGO_SCRATCH_HAS_WORKSPACE) != 0;
     const bool hist_has_rt = (algo & DSA_ALGO_HIST_HAS_RT) != 0;

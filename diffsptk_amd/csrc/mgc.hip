@@ -1384,9 +1384,9 @@ DSA_EXPORT int dsa_zerodf_taylor_fwd(const void* x, const void* b, int64_t B, in
 {
     DSA_REQUIRE(M >= 0 && P > 0 && B >= 0 && T >= 0 && zeroth_index >= 0 && zeroth_index <= M, "zerodf_taylor: invalid sizes");
     DSA_REQUIRE(T % P == 0, "zerodf_taylor: the sequence length must be frames x frame_period");
+    if (B * T == 0) return DSA_OK;   // (an empty batch: its tensors have no storage)
     DSA_REQUIRE((acc != nullptr) == (ysum != nullptr), "zerodf_taylor: acc and ysum come together");
     DSA_REQUIRE(y != nullptr || ysum != nullptr, "zerodf_taylor: no output");
-    if (B * T == 0) return DSA_OK;
     const int64_t N = T / P;
     if (dtype == DSA_F32)
         return zerodf_launch_fwd<float>(x, b, B, T, N, M, P, zeroth_index, 0, y, (hipStream_t)stream, scale, acc, ysum);
@@ -1413,8 +1413,8 @@ DSA_EXPORT int dsa_zerodf_taylor_bwd(const void* G, const void* x, const void* b
                                      void* stream)
 {
     DSA_REQUIRE(M >= 0 && P > 0 && B >= 0 && T >= 0 && zeroth_index >= 0 && zeroth_index <= M && T % P == 0, "zerodf_taylor_bwd: invalid sizes");
-    DSA_REQUIRE(G_out != nullptr && G_out != G, "zerodf_taylor_bwd: G_out must be a buffer of its own");
     if (B * T == 0) return DSA_OK;
+    DSA_REQUIRE(G_out != nullptr && G_out != G, "zerodf_taylor_bwd: G_out must be a buffer of its own");
     const int64_t N = T / P;
     if (dtype == DSA_F32)
         return zerodf_launch_bwd<float>(G, x, b, nullptr, B, T, N, M, P, zeroth_index, 0, G_out, gb, (hipStream_t)stream, scale, gy, true);
@@ -1448,7 +1448,7 @@ DSA_EXPORT int dsa_mcep_newton_update(const void* rt, int64_t F, int32_t n, cons
                                       void* mc_out, void* stream)
 {
     DSA_REQUIRE(n >= 2 && n <= 55 && F >= 0, "mcep_newton_update: order must be in [2, 55]");
-    DSA_REQUIRE(rt && alpha_vec && mc_out, "mcep_newton_update: null pointer");   // mc_in = NULL: the solution alone
+    DSA_REQUIRE(F == 0 || (rt && alpha_vec && mc_out), "mcep_newton_update: null pointer");   // mc_in = NULL: the solution alone
     if (dtype != DSA_F32) return fail(DSA_ERR_UNSUPPORTED, "mcep_newton_update: float32 only%s");
     if (F == 0) return DSA_OK;
     return thsolve_quadn_fwd(rt, 2 * n - 1, rt, 2 * n - 1, rt, 2 * n - 1, alpha_vec, mc_in, F, n, mc_out, (hipStream_t)stream);
@@ -1564,7 +1564,7 @@ DSA_EXPORT int dsa_mcep_newton_update_bwd(const void* gs, const void* rt, const 
                                           void* grt, void* stream)
 {
     DSA_REQUIRE(n >= 2 && n <= 55 && F >= 0, "mcep_newton_update_bwd: order must be in [2, 55]");
-    DSA_REQUIRE(gs && rt && sol && u && grt, "mcep_newton_update_bwd: null pointer");
+    DSA_REQUIRE(F == 0 || (gs && rt && sol && u && grt), "mcep_newton_update_bwd: null pointer");
     if (dtype != DSA_F32) return fail(DSA_ERR_UNSUPPORTED, "mcep_newton_update_bwd: float32 only%s");
     if (F == 0) return DSA_OK;
     if (int rc = thsolve_quadn_fwd(rt, 2 * n - 1, rt, 2 * n - 1, gs, n, nullptr, nullptr, F, n, u, (hipStream_t)stream)) return rc;
@@ -1591,7 +1591,7 @@ DSA_EXPORT int dsa_thsolve_update_fwd(const void* p, const void* q, const void* 
 {
     DSA_REQUIRE(n >= 1 && n <= kThMax && F >= 0, "thsolve_update: order must be in [1, 64]");
     DSA_REQUIRE(r_offset >= 0 && r_stride >= r_offset + n, "thsolve_update: the right-hand side does not fit its row stride");
-    DSA_REQUIRE(b_in != nullptr && b_out != nullptr && b_in != b_out, "thsolve_update: b_in and b_out must be distinct buffers");
+    DSA_REQUIRE(F == 0 || (b_in != nullptr && b_out != nullptr && b_in != b_out), "thsolve_update: b_in and b_out must be distinct buffers");
     if (F == 0) return DSA_OK;
     if (dtype == DSA_F32 && n == 24)
         return thsolve_quad24_fwd(p, q, r, F, b_out, (hipStream_t)stream, (int)r_stride, (int)r_offset, b_in);
@@ -1689,7 +1689,7 @@ __global__ __launch_bounds__(256) void mgcep_gain_kernel(const T* __restrict__ r
 
 DSA_EXPORT int dsa_gnorm_fwd(const void* x, int64_t F, int32_t n, double gamma, int32_t inverse, int32_t dtype, void* out, void* stream)
 {
-    DSA_REQUIRE(F >= 0 && n >= 1 && x && out, "gnorm: invalid arguments");
+    DSA_REQUIRE(F >= 0 && n >= 1 && (F == 0 || (x && out)), "gnorm: invalid arguments");
     DSA_REQUIRE(gamma >= -1 && gamma <= 1, "gnorm: gamma must be in [-1, 1]");
     if (F == 0) return DSA_OK;
     const dim3 grid((unsigned)((F * n + 255) / 256));
@@ -1706,7 +1706,7 @@ DSA_EXPORT int dsa_gnorm_fwd(const void* x, int64_t F, int32_t n, double gamma, 
 DSA_EXPORT int dsa_mgcep_gain(const void* r, const void* b_eps, const void* b_join, int64_t F, int32_t M, double gamma, int32_t dtype,
                               void* b, void* stream)
 {
-    DSA_REQUIRE(F >= 0 && M >= 1 && r && b_eps && b_join && b, "mgcep_gain: invalid arguments");
+    DSA_REQUIRE(F >= 0 && M >= 1 && (F == 0 || (r && b_eps && b_join && b)), "mgcep_gain: invalid arguments");
     if (F == 0) return DSA_OK;
     const dim3 grid((unsigned)((F + 3) / 4));
     if (dtype == DSA_F32)

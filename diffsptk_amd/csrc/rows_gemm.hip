@@ -609,8 +609,8 @@ DSA_EXPORT int dsa_rows_gemm(const void* c, int64_t F, int32_t K, const void* A,
                              int32_t ldaux, int32_t dtype, void* out, int32_t ldo, void* stream)
 {
     DSA_REQUIRE(F >= 0 && K > 0 && N > 0 && lda > 0 && ldo >= N, "rows_gemm: invalid sizes");
-    DSA_REQUIRE(c && A && out, "rows_gemm: null pointer");
-    DSA_REQUIRE(!(flags & dsa::RG_EPI_EXPSUB) || (aux && ldaux >= N), "rows_gemm: the exp-sub epilogue needs aux");
+    DSA_REQUIRE(F == 0 || (c && A && out), "rows_gemm: null pointer");
+    DSA_REQUIRE(F == 0 || !(flags & dsa::RG_EPI_EXPSUB) || (aux && ldaux >= N), "rows_gemm: the exp-sub epilogue needs aux");
     if (dtype != DSA_F32) return dsa::fail(DSA_ERR_UNSUPPORTED, "rows_gemm: float32 only%s");
     if (F == 0) return DSA_OK;
     return dsa::rows_gemm_mfma(c, F, K, A, lda, N, flags, aux, ldaux, out, ldo, (hipStream_t)stream);
@@ -619,7 +619,7 @@ DSA_EXPORT int dsa_rows_gemm(const void* c, int64_t F, int32_t K, const void* A,
 DSA_EXPORT int dsa_rows_ew(int32_t op, int32_t backward, const void* a, const void* b, const void* gy, int64_t n, int32_t dtype,
                            void* o0, void* o1, void* stream)
 {
-    DSA_REQUIRE(n >= 0 && a && o0, "rows_ew: invalid arguments");
+    DSA_REQUIRE(n >= 0 && (n == 0 || (a && o0)), "rows_ew: invalid arguments");
     if (dtype != DSA_F32) return dsa::fail(DSA_ERR_UNSUPPORTED, "rows_ew: float32 only%s");
     if (n == 0) return DSA_OK;
     return dsa::rows_ew(op, backward, a, b, gy, n, o0, o1, (hipStream_t)stream);
@@ -629,7 +629,7 @@ DSA_EXPORT int dsa_mcep_newton_resid(const void* logx, int64_t F, int32_t K, con
                                      const void* E, int32_t lde, int32_t dtype, void* rt, void* stream)
 {
     DSA_REQUIRE(F >= 0 && K >= 4 && n >= 3 && ldd >= K && lde >= 2 * n - 1, "mcep_newton_resid: invalid sizes");
-    DSA_REQUIRE(logx && mc && D && E && rt, "mcep_newton_resid: null pointer");
+    DSA_REQUIRE(F == 0 || (logx && mc && D && E && rt), "mcep_newton_resid: null pointer");
     if (dtype != DSA_F32 || n > 55) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_resid: float32, orders up to 54%s");
     if (F == 0) return DSA_OK;
     return dsa::mcep_resid_mfma(logx, F, K, mc, n, D, ldd, E, lde, 2 * n - 1, rt, 2 * n - 1, (hipStream_t)stream);
@@ -655,7 +655,7 @@ DSA_EXPORT int dsa_mcep_newton_steps(const void* logx, int64_t F, int32_t K, con
                                      const void* alpha_vec, int32_t n_iter, int32_t dtype, void* mc_out, void* stream)
 {
     DSA_REQUIRE(F >= 0 && K >= 4 && n >= 3 && n_iter >= 0, "mcep_newton_steps: invalid sizes");
-    DSA_REQUIRE(logx && mc_in && images && alpha_vec && mc_out, "mcep_newton_steps: null pointer");
+    DSA_REQUIRE(F == 0 || (logx && mc_in && images && alpha_vec && mc_out), "mcep_newton_steps: null pointer");
     if (dtype != DSA_F32) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_steps: float32 only%s");
     if (F == 0) return DSA_OK;
     const int rc = dsa::mcep_big_newton(logx, F, K, mc_in, n, images, alpha_vec, n_iter, mc_out, (hipStream_t)stream);
@@ -682,7 +682,7 @@ DSA_EXPORT int dsa_mcep_newton_resid_h_bwd(const void* logx, int64_t F, int32_t 
                                            int32_t dtype, void* glogx, void* gmc, void* stream)
 {
     DSA_REQUIRE(F >= 0 && K >= 4 && n >= 3, "mcep_newton_resid_h_bwd: invalid sizes");
-    DSA_REQUIRE(logx && mc && grt && images && gmc, "mcep_newton_resid_h_bwd: null pointer");   // (glogx may be NULL since 0.2.2: not accumulated)
+    DSA_REQUIRE(F == 0 || (logx && mc && grt && images && gmc), "mcep_newton_resid_h_bwd: null pointer");   // (glogx may be NULL since 0.2.2: not accumulated)
     if (dtype != DSA_F32) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_resid_h_bwd: float32 only%s");
     if (F == 0) return DSA_OK;
     const int rc = dsa::mcep_resid_bwd_h(logx, F, K, mc, n, grt, images, glogx, gmc, (hipStream_t)stream);
@@ -695,7 +695,7 @@ DSA_EXPORT int dsa_mcep_newton_glogx_h(const void* logx, int64_t F, int32_t K, c
                                        const void* images, int32_t dtype, void* glogx, void* stream)
 {
     DSA_REQUIRE(F >= 0 && K >= 4 && n >= 3 && n_iter >= 1, "mcep_newton_glogx_h: invalid sizes");
-    DSA_REQUIRE(logx && mcs && grts && images && glogx, "mcep_newton_glogx_h: null pointer");
+    DSA_REQUIRE(F == 0 || (logx && mcs && grts && images && glogx), "mcep_newton_glogx_h: null pointer");
     if (dtype != DSA_F32) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_glogx_h: float32 only%s");
     if (F == 0) return DSA_OK;
     return dsa::mcep_glogx_h(logx, F, K, mcs, n, grts, n_iter, images, glogx, (hipStream_t)stream);   // DSA_ERR_UNSUPPORTED: no error text
@@ -705,7 +705,7 @@ DSA_EXPORT int dsa_mcep_newton_resid_h(const void* logx, int64_t F, int32_t K, c
                                        void* rt, void* stream)
 {
     DSA_REQUIRE(F >= 0 && K >= 4 && n >= 3, "mcep_newton_resid_h: invalid sizes");
-    DSA_REQUIRE(logx && mc && images && rt, "mcep_newton_resid_h: null pointer");
+    DSA_REQUIRE(F == 0 || (logx && mc && images && rt), "mcep_newton_resid_h: null pointer");
     if (dtype != DSA_F32 || n > 55) return dsa::fail(DSA_ERR_UNSUPPORTED, "mcep_newton_resid_h: float32, orders up to 54%s");
     if (F == 0) return DSA_OK;
     return dsa::mcep_resid_h_fwd(logx, F, K, mc, n, images, rt, 2 * n - 1, (hipStream_t)stream);

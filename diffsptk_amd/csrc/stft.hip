@@ -2076,7 +2076,7 @@ DSA_EXPORT int dsa_spec_fwd(const void* b, int32_t lb, const void* a, int32_t la
                             double eps, int32_t use_floor, double relative_floor_db, int32_t out_format,
                             const void* twiddle, int32_t dtype, void* y, void* stream)
 {
-    DSA_REQUIRE(b || a, "spec: either b or a must be specified");
+    DSA_REQUIRE(F == 0 || b || a, "spec: either b or a must be specified");
     DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "spec: fft_length must be positive even");
     DSA_REQUIRE(out_format >= 0 && out_format <= 3, "spec: unknown out_format");
     if (F == 0) return DSA_OK;
@@ -2254,7 +2254,7 @@ DSA_EXPORT int dsa_stft_fbank_fwd(const void* x, int64_t B, int64_t T, int32_t L
                                   double gamma, int32_t use_power, int32_t dtype, void* y, void* stream)
 {
     DSA_REQUIRE(L > 0 && P > 0 && T > 0 && B >= 0, "stft_fbank: sizes must be positive");
-    DSA_REQUIRE(x && w && twiddle && plan && y, "stft_fbank: null pointer");
+    DSA_REQUIRE(B == 0 || (x && w && twiddle && plan && y), "stft_fbank: null pointer");
     DSA_REQUIRE(floor > 0, "stft_fbank: floor must be positive");
     if (!(dtype == DSA_F32 && nfft == 512 && L == 400 && (P & 1) == 0 && 3 * P + 512 <= kFPW * kZS * 2 && C >= 1 && C <= 126))
         return fail(DSA_ERR_UNSUPPORTED,
@@ -2363,11 +2363,11 @@ DSA_EXPORT int dsa_spec_bwd(const void* gy, const void* b, int32_t lb, const voi
                             int32_t out_format, const void* twiddle, int32_t dtype, void* gb, void* ga,
                             void* stream)
 {
-    DSA_REQUIRE(b || a, "spec_bwd: either b or a must be specified");
+    DSA_REQUIRE(F == 0 || b || a, "spec_bwd: either b or a must be specified");
     DSA_REQUIRE(nfft > 1 && nfft % 2 == 0, "spec_bwd: fft_length must be positive even");
     hipStream_t st = (hipStream_t)stream;
     if (a) {
-        DSA_REQUIRE(ga != nullptr, "spec_bwd: ga is required when a is given");
+        DSA_REQUIRE(F == 0 || ga != nullptr, "spec_bwd: ga is required when a is given");
         if (F == 0) return DSA_OK;
         const int K = nfft / 2 + 1;
         const size_t esz = dtype == DSA_F32 ? 4 : 8;
@@ -2582,7 +2582,7 @@ DSA_EXPORT int dsa_stft_bwd(const void* gy, const void* x, int64_t B, int64_t T,
                             int32_t pad_mode, double eps, int32_t use_floor, double relative_floor_db,
                             int32_t out_format, int32_t dtype, int32_t algo, void* gx, void* gw, void* stream)
 {
-    DSA_REQUIRE(x != nullptr, "stft_bwd: the waveform is required");
+    DSA_REQUIRE(B == 0 || T == 0 || x != nullptr, "stft_bwd: the waveform is required");
     return stft_bwd_impl(gy, x, B, T, L, P, nfft, w, twiddle, center, zmean, pad_mode, eps, use_floor, relative_floor_db,
                          out_format, dtype, algo, gx, gw, stream, nullptr, 0.0);
 }

@@ -28,3 +28,18 @@ def test_batches_beyond_2_31_elements_match_small_batches(capsys):
     out = capsys.readouterr().out
     assert bad == 0, out
     assert out.count("bitwise equal to the small batch: True") >= 7, out
+
+
+def test_empty_batches_and_shortest_inputs(capsys):
+    """The reference's ATen ops accept a zero-size batch and any T >= 1: every module of the path (and its consumers, forward and
+    backward, fused or not, 16 kHz and 48 kHz set-ups) returns the reference's shape for batch 0 -- the C-ABI treats a zero count as a
+    no-op BEFORE it looks at the pointers (empty tensors have no storage) -- and T = 1, one period, one period + 1, frame_length - 1
+    give finite outputs and gradients, fuse(stft, mcep) equal to mcep(stft(x)) bit for bit (tools/check_empty_inputs.py)."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_empty_inputs.py")
+    spec = importlib.util.spec_from_file_location("check_empty_inputs", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = mod.run_all()
+    out = capsys.readouterr().out
+    assert bad == 0, out
+    assert "FAILED" not in out and "MISMATCH" not in out, out
