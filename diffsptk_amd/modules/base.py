@@ -43,6 +43,35 @@ class BaseFunctionalModule(ABC, nn.Module):
                 setattr(self, k, nn.Parameter(t))
             else:
                 self.register_buffer(k, t, persistent=False)  # state_dict stays empty (base.py:67)
+        self._install_reference_state_keys()
+
+    #: ``state_dict`` compatibility with the reference for COMPOSITE modules, whose learnable tensors live in sub-modules there
+    #: (e.g. ``window.window`` / ``spec.fftr.W`` of diffsptk.STFT, stft.py:186-235) and directly on the module here (one fused
+    #: launch, no sub-modules): {local name: (reference key, reference shape or None)}.  ``state_dict()`` writes the reference's
+    #: keys and shapes, ``load_state_dict()`` reads them (and still accepts the local names): checkpoints interchange.
+    _reference_state_keys: ClassVar[dict[str, tuple[str, tuple[int, ...] | None]]] = {}
+
+    def _install_reference_state_keys(self) -> None:
+        if not self._reference_state_keys:
+            return
+
+        def on_save(module, state, prefix, _meta):
+            for local, (ref_key, ref_shape) in module._reference_state_keys.items():
+                k = prefix + local
+                if k in state:
+                    t = state.pop(k)
+                    state[prefix + ref_key] = t.reshape(ref_shape) if ref_shape is not None else t
+
+        def on_load(module, state, prefix, *_rest):
+            for local, (ref_key, _ref_shape) in module._reference_state_keys.items():
+                k = prefix + ref_key
+                if k in state:
+                    t = state.pop(k)
+                    own = module._parameters.get(local)
+                    state[prefix + local] = t.reshape(own.shape) if own is not None and t.numel() == own.numel() else t
+
+        self._register_state_dict_hook(on_save)
+        self._register_load_state_dict_pre_hook(on_load, with_module=True)
 
     def _state(self) -> dict[str, Any]:
         st = {k: getattr(self, k) for k in self._value_names + self._layer_names}

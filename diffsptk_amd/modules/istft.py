@@ -16,6 +16,9 @@ class InverseShortTimeFourierTransform(BaseFunctionalModule):
     """y:(..., T/P, N/2+1) complex spectrogram -> x:(..., T) = unframe(irfft(y)[..., :L]) (istft.py:186-193),
     ONE fused launch: the complex-cotangent STFT backward kernel is windowed inverse FFT + overlap-add."""
 
+    # istft.py:157-181: the learnable inverse-DFT matrix lives in ifftr, the learnable synthesis window in unframe as (1, L, 1)
+    _reference_state_keys = {"W": ("ifftr.W", None), "window": ("unframe.window", (1, -1, 1))}
+
     def __init__(self, frame_length: int, frame_period: int, fft_length: int, *, center: bool = True,
                  window: str | int = "blackman", norm: str | int = "power", symmetric: bool = True,
                  learnable: bool | list[str] = False, device=None, dtype=None) -> None:

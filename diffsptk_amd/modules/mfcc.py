@@ -18,6 +18,9 @@ class MelFrequencyCepstralCoefficientsAnalysis(BaseFunctionalModule):
     amplitude-domain filter bank -> DCT-II -> first M+1 coefficients times the liftering vector.
     The DCT and the lifter are ONE (C, M+1) matrix here (composed in float64, then cast)."""
 
+    # mfcc.py:118-121: the reference keeps the learnable filter bank in its fbank layer
+    _reference_state_keys = {"H": ("fbank.H", None)}
+
     def __init__(self, *, fft_length: int, mfcc_order: int, n_channel: int, sample_rate: int, lifter: int = 1,
                  f_min: float = 0, f_max: float | None = None, floor: float = 1e-5, gamma: float = 0,
                  scale: str = "htk", erb_factor: float | None = None, out_format: str | int = "y",

@@ -73,6 +73,11 @@ class PseudoMGLSADigitalFilter(nn.Module):
                  ignore_gain: bool = False, phase: str = "minimum", mode: str = "multi-stage", device=None, dtype=None,
                  **kwargs) -> None:
         super().__init__()
+        # state_dict compatibility: the reference keeps the learnable Taylor coefficients in its inner filter (`mglsadf.a`, mglsadf.py:346)
+        self._register_state_dict_hook(lambda m, sd, prefix, _meta: sd.__setitem__(prefix + "mglsadf.a", sd.pop(prefix + "a")) if prefix + "a" in sd else None)
+        self._register_load_state_dict_pre_hook(
+            lambda m, sd, prefix, *_r: sd.__setitem__(prefix + "a", sd.pop(prefix + "mglsadf.a")) if prefix + "mglsadf.a" in sd else None,
+            with_module=True)
         if phase not in ("minimum", "maximum", "zero", "mixed"):
             raise ValueError(f"phase {phase} is not supported.")
         if phase != "mixed" and not isinstance(filter_order, int):
@@ -144,7 +149,7 @@ class PseudoMGLSADigitalFilter(nn.Module):
             learnable = bool(kwargs.pop("learnable", False))
             if self.taylor_order < 0:
                 raise ValueError("taylor_order must be non-negative.")
-            self.a = nn.Parameter(torch.ones(self.taylor_order + 1, device=device, dtype=dtype)) if learnable else None
+            self.a = nn.Parameter(torch.ones(self.taylor_order + 1, **kw)) if learnable else None
             if alpha == 0 and gamma == 0:                                    # mglsadf.py:281-282
                 co_max, co_min = N, M
             self.cep_orders = (co_max, co_min)

@@ -26,6 +26,9 @@ class ShortTimeFourierTransform(BaseFunctionalModule):
     windowing stay on the kernels, the transform runs on stock device operators, modules/_learnable.py).
     """
 
+    # stft.py:186-235: the reference keeps the learnable window in its Window layer and the learnable DFT matrix in spec.fftr
+    _reference_state_keys = {"window": ("window.window", None), "W": ("spec.fftr.W", None)}
+
     def __init__(self, frame_length: int, frame_period: int, fft_length: int, *, center: bool = True,
                  zmean: bool = False, mode: str = "constant", window: str | int = "blackman",
                  norm: str | int = "power", symmetric: bool = True, eps: float = 1e-9,

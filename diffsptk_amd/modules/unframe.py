@@ -16,6 +16,9 @@ class Unframe(BaseFunctionalModule):
 
     _takes_input_size = True
 
+    # unframe.py:155-157: the reference stores its (learnable) window as (1, L, 1)
+    _reference_state_keys = {"window": ("window", (1, -1, 1))}
+
     def __init__(self, frame_length: int, frame_period: int, *, center: bool = True, window: str | int = "rectangular",
                  norm: str | int = "none", symmetric: bool = True, learnable: bool = False, device=None,
                  dtype=None) -> None:

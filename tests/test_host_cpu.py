@@ -509,3 +509,36 @@ def test_round5_binary16_operand_images_reconstruct_their_matrices():
                 want = np.where(ok, sc * C[np.minimum(row, 24), b], 0.0)
                 got = ct[ci_, tc, 0, :, i] + ct[ci_, tc, 1, :, i]
                 assert np.all(np.abs(got - want) <= 2.0 ** -21 * np.abs(want) + 2.0 ** -24)
+
+
+def test_state_dict_keys_and_shapes_are_the_references():
+    """Checkpoints interchange with the reference (same names): for every module of the path, learnable or not, ``state_dict()``
+    has the reference's keys and shapes (tests/golden/state_keys.json, generated by importing the reference:
+    tests/golden/make_golden_state_keys.py) -- the composite modules keep their learnable tensors on the module itself here (one
+    fused launch) and translate (`BaseFunctionalModule._reference_state_keys`) -- a state dict with the reference's keys loads, and the
+    values come back unchanged; the local names are still accepted."""
+    import json
+
+    import diffsptk_amd as dsp
+
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_keys.json")))
+    assert len(cases) >= 38
+    n_learnable = 0
+    for c in cases:
+        args = [tuple(v) if isinstance(v, list) else v for v in c["args"]]
+        m = getattr(dsp, c["module"])(*args, **c["kwargs"])
+        sd = m.state_dict()
+        assert {k: list(v.shape) for k, v in sd.items()} == c["state"], (c["module"], c["kwargs"])
+        if not sd:
+            continue
+        n_learnable += 1
+        ref_like = {k: torch.randn(*shape, dtype=sd[k].dtype) for k, shape in c["state"].items()}
+        m.load_state_dict(ref_like)                       # strict: no missing / unexpected keys
+        back = m.state_dict()
+        for k, v in ref_like.items():
+            assert torch.equal(back[k], v), (c["module"], k)
+        local = {k: torch.randn_like(v) for k, v in m.named_parameters()}
+        m.load_state_dict(local)                          # the module's own parameter names still load
+        for k, v in m.named_parameters():
+            assert torch.equal(v, local[k]), (c["module"], k)
+    assert n_learnable >= 15
