@@ -82,7 +82,7 @@ def griffin(y: Tensor, *, out_length: int | None = None, frame_length: int = 400
                                alpha=alpha, beta=beta, gamma=gamma, init_phase=init_phase, verbose=verbose)
 
 
-def unframe(y: Tensor, *, out_length: int | None = None, frame_period: int = 80, center: bool = True,
+def unframe(y: Tensor, out_length: int | None = None, *, frame_period: int = 80, center: bool = True,
             window: str | int = "rectangular", norm: str | int = "none", symmetric: bool = True) -> Tensor:
     """Overlap-add framed waveforms y:(..., T/P, L) -> (..., T)."""
     return nn.Unframe._func(y, out_length, frame_period=frame_period, center=center, window=window, norm=norm,

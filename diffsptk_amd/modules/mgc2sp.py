@@ -21,7 +21,7 @@ class MelGeneralizedCepstrumToSpectrum(BaseFunctionalModule):
 
     _takes_input_size = True
 
-    def __init__(self, cep_order: int, fft_length: int, alpha: float = 0, gamma: float = 0, norm: bool = False,
+    def __init__(self, cep_order: int, fft_length: int, *, alpha: float = 0, gamma: float = 0, norm: bool = False,
                  mul: bool = False, n_fft: int = 512, out_format: str | int = "power", device=None, dtype=None) -> None:
         super().__init__()
         self.in_dim = cep_order + 1

@@ -40,11 +40,25 @@ def get_alpha(sample_rate: int, mode: str = "hts", n_freq: int = 10, n_alpha: in
     raise ValueError("Only hts and auto are supported.")
 
 
-def read(filename: str, device=None, dtype=None, channel_first: bool = True):
+def read(filename: str, device=None, dtype=None, channel_first: bool = True, **kwargs):
     """Read a PCM wav file into a float tensor in [-1, 1) (stdlib ``wave``; the reference uses
-    soundfile, public.py:152-156, which scales int16 by 1/32768 as done here)."""
+    soundfile, public.py:152-156, which scales int16 by 1/32768 as done here).  Of the keyword arguments the reference hands to
+    ``soundfile.read`` the ones that select samples are honoured -- ``start``, ``stop``, ``frames`` (negative values count from the
+    end, as there) and ``always_2d``; anything else raises ``TypeError``."""
+    start, stop, frames = kwargs.pop("start", 0), kwargs.pop("stop", None), kwargs.pop("frames", -1)
+    always_2d = bool(kwargs.pop("always_2d", False))
+    if kwargs:
+        raise TypeError(f"read() got unsupported soundfile arguments: {sorted(kwargs)}")
     with wave.open(filename, "rb") as w:
-        nch, width, sr, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+        nch, width, sr, total = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+        start = max(0, min(total, start + total if start < 0 else start))
+        if stop is not None and frames >= 0:
+            raise TypeError("Only one of {frames, stop} may be used")
+        end = total if stop is None else max(0, min(total, stop + total if stop < 0 else stop))
+        if frames >= 0:
+            end = min(total, start + frames)
+        n = max(0, end - start)
+        w.setpos(start) if start < total else None
         raw = w.readframes(n)
     if width == 2:
         x = np.frombuffer(raw, dtype="<i2").astype(np.float64) / 32768.0
@@ -55,7 +69,7 @@ def read(filename: str, device=None, dtype=None, channel_first: bool = True):
     else:
         raise ValueError(f"unsupported sample width: {width}")
     x = x.reshape(-1, nch)
-    x = x[:, 0] if nch == 1 else (x.T if channel_first else x)
+    x = x[:, 0] if (nch == 1 and not always_2d) else (x.T if channel_first else x)
     if dtype is None:
         dtype = torch.get_default_dtype()
     return torch.tensor(np.ascontiguousarray(x), device=device, dtype=dtype), sr

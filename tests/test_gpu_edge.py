@@ -43,3 +43,17 @@ def test_empty_batches_and_shortest_inputs(capsys):
     out = capsys.readouterr().out
     assert bad == 0, out
     assert "FAILED" not in out and "MISMATCH" not in out, out
+
+
+def test_input_forms_the_reference_accepts(capsys):
+    """Non-contiguous views (strided, transposed, expanded, offset), no / three leading dims, non-contiguous spectrograms and
+    cotangents: bit-identical to the contiguous copy; float64 modules; fftr with inputs shorter / longer than fft_length against
+    torch.fft.rfft(x, n) on the host (tools/check_input_forms.py)."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_input_forms.py")
+    spec = importlib.util.spec_from_file_location("check_input_forms", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = mod.run_all()
+    out = capsys.readouterr().out
+    assert bad == 0, out
+    assert "FAILED" not in out and "MISMATCH" not in out and out.count(": ok") >= 50, out

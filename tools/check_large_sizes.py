@@ -147,7 +147,7 @@ def section_48k():
 
 
 def run_all(b16=42000, b48=10600):
-    """both sections; returns the number of mismatching / failing checks (tests/test_gpu_large.py calls this)"""
+    """both sections; returns the number of mismatching / failing checks (tests/test_gpu_edge.py calls this)"""
     global B16, B48, bad
     B16, B48, bad = b16, b48, 0
     for sec in (section_16k, section_48k):
