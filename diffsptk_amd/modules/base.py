@@ -22,6 +22,23 @@ class Precomputed(NamedTuple):
     tensors: dict[str, torch.Tensor] = {}
 
 
+def _reference_keys_on_save(module, state, prefix, _meta):
+    for local, (ref_key, ref_shape) in module._reference_state_keys.items():
+        k = prefix + local
+        if k in state:
+            t = state.pop(k)
+            state[prefix + ref_key] = t.reshape(ref_shape) if ref_shape is not None else t
+
+
+def _reference_keys_on_load(module, state, prefix, *_rest):
+    for local, (ref_key, _ref_shape) in module._reference_state_keys.items():
+        k = prefix + ref_key
+        if k in state:
+            t = state.pop(k)
+            own = module._parameters.get(local)
+            state[prefix + local] = t.reshape(own.shape) if own is not None and t.numel() == own.numel() else t
+
+
 class BaseFunctionalModule(ABC, nn.Module):
     #: True when the first parameter of ``_precompute`` is inferred from the input on the
     #: functional path (base.py:42, utils/private.py:51-52 of the reference)
@@ -52,26 +69,10 @@ class BaseFunctionalModule(ABC, nn.Module):
     _reference_state_keys: ClassVar[dict[str, tuple[str, tuple[int, ...] | None]]] = {}
 
     def _install_reference_state_keys(self) -> None:
-        if not self._reference_state_keys:
-            return
-
-        def on_save(module, state, prefix, _meta):
-            for local, (ref_key, ref_shape) in module._reference_state_keys.items():
-                k = prefix + local
-                if k in state:
-                    t = state.pop(k)
-                    state[prefix + ref_key] = t.reshape(ref_shape) if ref_shape is not None else t
-
-        def on_load(module, state, prefix, *_rest):
-            for local, (ref_key, _ref_shape) in module._reference_state_keys.items():
-                k = prefix + ref_key
-                if k in state:
-                    t = state.pop(k)
-                    own = module._parameters.get(local)
-                    state[prefix + local] = t.reshape(own.shape) if own is not None and t.numel() == own.numel() else t
-
-        self._register_state_dict_hook(on_save)
-        self._register_load_state_dict_pre_hook(on_load, with_module=True)
+        if self._reference_state_keys:
+            # (module-level functions, not closures: a module with hooks must stay picklable -- torch.save(model))
+            self._register_state_dict_hook(_reference_keys_on_save)
+            self._register_load_state_dict_pre_hook(_reference_keys_on_load, with_module=True)
 
     def _state(self) -> dict[str, Any]:
         st = {k: getattr(self, k) for k in self._value_names + self._layer_names}

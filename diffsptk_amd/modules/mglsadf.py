@@ -66,6 +66,16 @@ def _taylor_stages(x: torch.Tensor, c: torch.Tensor, P: int, z0: int, order: int
         y = y + cur
     return y
 
+def _taylor_key_on_save(_module, state, prefix, _meta):   # (module-level: the module stays picklable)
+    if prefix + "a" in state:
+        state[prefix + "mglsadf.a"] = state.pop(prefix + "a")
+
+
+def _taylor_key_on_load(_module, state, prefix, *_rest):
+    if prefix + "mglsadf.a" in state:
+        state[prefix + "a"] = state.pop(prefix + "mglsadf.a")
+
+
 class PseudoMGLSADigitalFilter(nn.Module):
     """x:(..., T) excitation, mc:(..., T/P, M+1) mel-generalized cepstrum -> y:(..., T) (mglsadf.py:211-252)."""
 
@@ -74,10 +84,8 @@ class PseudoMGLSADigitalFilter(nn.Module):
                  **kwargs) -> None:
         super().__init__()
         # state_dict compatibility: the reference keeps the learnable Taylor coefficients in its inner filter (`mglsadf.a`, mglsadf.py:346)
-        self._register_state_dict_hook(lambda m, sd, prefix, _meta: sd.__setitem__(prefix + "mglsadf.a", sd.pop(prefix + "a")) if prefix + "a" in sd else None)
-        self._register_load_state_dict_pre_hook(
-            lambda m, sd, prefix, *_r: sd.__setitem__(prefix + "a", sd.pop(prefix + "mglsadf.a")) if prefix + "mglsadf.a" in sd else None,
-            with_module=True)
+        self._register_state_dict_hook(_taylor_key_on_save)
+        self._register_load_state_dict_pre_hook(_taylor_key_on_load, with_module=True)
         if phase not in ("minimum", "maximum", "zero", "mixed"):
             raise ValueError(f"phase {phase} is not supported.")
         if phase != "mixed" and not isinstance(filter_order, int):

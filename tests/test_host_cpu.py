@@ -542,3 +542,25 @@ def test_state_dict_keys_and_shapes_are_the_references():
         for k, v in m.named_parameters():
             assert torch.equal(v, local[k]), (c["module"], k)
     assert n_learnable >= 15
+
+
+def test_modules_deepcopy_and_pickle():
+    """copy.deepcopy (EMA copies) and pickle (torch.save(model)) of the path's modules: the reference's composite modules are
+    deep-copyable and, where they hold no lambda, picklable; here every module is both -- the state-dict translation hooks are
+    module-level functions -- and a copy keeps the reference's state-dict keys with parameters of its own."""
+    import copy
+    import pickle
+
+    import diffsptk_amd as dsp
+
+    for name, args, kw in (("STFT", (400, 80, 512), {"learnable": True}), ("ISTFT", (400, 80, 512), {"learnable": True}),
+                           ("MelCepstralAnalysis", (), {"fft_length": 512, "cep_order": 24, "alpha": 0.42}),
+                           ("LPC", (400, 24), {}), ("MFCC", (), {"fft_length": 512, "mfcc_order": 12, "n_channel": 40, "sample_rate": 16000, "learnable": True}),
+                           ("PseudoMGLSADigitalFilter", (24, 80), {"alpha": 0.42, "learnable": True}),
+                           ("MelGeneralizedCepstralAnalysis", (), {"fft_length": 512, "cep_order": 24, "alpha": 0.42, "gamma": -0.5})):
+        m = getattr(dsp, name)(*args, **kw)
+        for c in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+            assert list(c.state_dict()) == list(m.state_dict()), name
+            for (k, p), (_k2, q) in zip(m.named_parameters(), c.named_parameters()):
+                assert torch.equal(p, q) and p.data_ptr() != q.data_ptr(), (name, k)
+            c.load_state_dict(m.state_dict())
