@@ -40,6 +40,8 @@ class ShortTimeFourierTransform(BaseFunctionalModule):
         learn_basis = learnable is True or (not isinstance(learnable, bool) and "basis" in learnable)
         names = (("window",) if learn_window else ()) + (("W",) if learn_basis else ())
         self._register_precomputed(pre, names if names else False)
+        if out_format == "complex":   # stft.py:211-222: with complex output the reference's `spec` layer IS the transform
+            self._reference_state_keys = {"window": ("window.window", None), "W": ("spec.W", None)}
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._call_forward(x)

@@ -22,6 +22,7 @@ CASES = [
     ("STFT", [400, 80, 512], {"learnable": ["basis"]}),
     ("STFT", [400, 80, 512], {"learnable": ["window"]}),
     ("STFT", [1200, 240, 2048], {"learnable": True}),
+    ("STFT", [400, 80, 512], {"learnable": True, "out_format": "complex"}),
     ("Frame", [400, 80], {}),
     ("Window", [400, 512], {}),
     ("Window", [400, 512], {"learnable": True}),

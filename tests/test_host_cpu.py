@@ -522,7 +522,7 @@ def test_state_dict_keys_and_shapes_are_the_references():
     import diffsptk_amd as dsp
 
     cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_keys.json")))
-    assert len(cases) >= 38
+    assert len(cases) >= 39
     n_learnable = 0
     for c in cases:
         args = [tuple(v) if isinstance(v, list) else v for v in c["args"]]
