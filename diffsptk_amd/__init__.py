@@ -19,7 +19,7 @@ from . import functional
 from .graph import Graphed
 from .modules import *  # noqa: F401,F403
 from .modules import __all__ as _module_names
-from .utils.public import get_alpha, read
+from .utils.public import get_alpha, read, write
 
 __version__ = "0.1.0"
-__all__ = [*_module_names, "functional", "get_alpha", "read", "Graphed"]
+__all__ = [*_module_names, "functional", "get_alpha", "read", "write", "Graphed"]

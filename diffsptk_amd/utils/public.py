@@ -73,3 +73,33 @@ def read(filename: str, device=None, dtype=None, channel_first: bool = True, **k
     if dtype is None:
         dtype = torch.get_default_dtype()
     return torch.tensor(np.ascontiguousarray(x), device=device, dtype=dtype), sr
+
+
+def write(filename: str, x, sample_rate: int, channel_first: bool = True, **kwargs) -> None:
+    """Write a waveform (C, T) / (T, C) / (T,) to a PCM wav file (stdlib ``wave``; the reference hands the array to
+    ``soundfile.write``, public.py:160-198, whose default for .wav is 16-bit PCM with the float samples scaled by 32767 and
+    rounded to nearest-even -- done the same way here, saturating instead of wrapping).  ``subtype="PCM_16"`` (default) or
+    ``"PCM_32"``; other soundfile arguments raise ``TypeError``."""
+    subtype = kwargs.pop("subtype", None) or "PCM_16"
+    if kwargs:
+        raise TypeError(f"write() got unsupported soundfile arguments: {sorted(kwargs)}")
+    if subtype not in ("PCM_16", "PCM_32"):
+        raise ValueError(f"unsupported subtype: {subtype}")
+    a = x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+    a = a.astype(np.float64)
+    if a.ndim == 2:
+        a = a.T if channel_first else a            # (T, C): interleaved frames
+    elif a.ndim != 1:
+        raise ValueError("x must be (T,), (C, T) or (T, C)")
+    nch = 1 if a.ndim == 1 else a.shape[1]
+    if subtype == "PCM_16":
+        pcm = np.clip(np.rint(a * 32767.0), -32768, 32767).astype("<i2")
+        width = 2
+    else:
+        pcm = np.clip(np.rint(a * 2147483647.0), -2147483648, 2147483647).astype("<i4")
+        width = 4
+    with wave.open(filename, "wb") as w:
+        w.setnchannels(nch)
+        w.setsampwidth(width)
+        w.setframerate(int(sample_rate))
+        w.writeframes(np.ascontiguousarray(pcm).tobytes())

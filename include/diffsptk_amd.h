@@ -13,6 +13,8 @@
  *  - every pointer is a DEVICE pointer (HIP, same process / same HIP runtime as the caller)
  *    unless the name ends in `_host`; the caller (PyTorch) allocates all buffers;
  *  - tensors are dense row-major ("contiguous"); leading batch dims are flattened by the caller;
+ *  - a ZERO count (B, F, n = 0: an empty batch, which the reference's ATen ops accept) is a successful no-op: the sizes are
+ *    validated, the pointers are not looked at (an empty tensor has no storage; its data pointer is NULL);
  *  - `dtype`: DSA_F32 or DSA_F64 (the reference supports both; CI runs float64);
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous
  *    on that stream, re-entrant, and keep no mutable global state: the library keeps NO device memory (the only

@@ -564,3 +564,32 @@ def test_modules_deepcopy_and_pickle():
             for (k, p), (_k2, q) in zip(m.named_parameters(), c.named_parameters()):
                 assert torch.equal(p, q) and p.data_ptr() != q.data_ptr(), (name, k)
             c.load_state_dict(m.state_dict())
+
+
+def test_read_write_wav_round_trip(tmp_path):
+    """diffsptk.read / diffsptk.write (public.py:107-198) on the standard library's wave module: 16-bit PCM scaled by 1 / 32768 on the
+    way in and by 32767 (nearest-even, as libsndfile does for normalised floats) on the way out; (T,), (C, T), (T, C); the
+    sample-selecting keyword arguments of soundfile.read."""
+    import numpy as np
+
+    import diffsptk_amd as dsp
+
+    pcm = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "datawav.npz"))["pcm"]
+    x = torch.from_numpy(pcm.astype(np.float64) / 32768.0)
+    p = str(tmp_path / "a.wav")
+    dsp.write(p, x, 16000)
+    y, sr = dsp.read(p, dtype=torch.float64)
+    assert sr == 16000 and y.shape == x.shape
+    want = torch.from_numpy(np.clip(np.rint(x.numpy() * 32767.0), -32768, 32767) / 32768.0)
+    assert torch.equal(y, want)
+    assert dsp.read(p, start=100, stop=-100)[0].shape == (x.numel() - 200,)
+    assert dsp.read(p, frames=50, always_2d=True)[0].shape == (1, 50)
+    two = torch.stack([x, -x])
+    dsp.write(p, two, 8000)
+    z, sr = dsp.read(p, dtype=torch.float64)
+    assert sr == 8000 and z.shape == (2, x.numel()) and torch.equal(z[0], want)
+    dsp.write(p, two.T, 8000, channel_first=False, subtype="PCM_32")
+    z, _ = dsp.read(p, channel_first=False, dtype=torch.float64)
+    assert z.shape == (x.numel(), 2) and float((z[:, 0] - x).abs().max()) < 1e-9
+    with pytest.raises(TypeError):
+        dsp.write(p, x, 16000, endian="BIG")
