@@ -144,6 +144,29 @@ def section_48k():
         torch.cuda.synchronize()
         print(f"  mcep 2048 / 49: {tuple(mc.shape)} in {1e3 * (time.perf_counter() - t0):.1f} ms ({dsp._lib.last_kernel()})", flush=True)
         same("mcep(stft(x)) at 2048 / 49", mc[idx], mcep(Xs))
+        del X, mc
+    # the 48 kHz gradient (one autograd node per analysis: residual-adjoint sweep + the glogx pass) beyond 2^31 elements of (F, K)
+    gsel = torch.randn(len(idx), N, M + 1, device=dev, generator=g)
+    xg = x.requires_grad_(True)
+    mcg = mcep(stft(xg))
+    w = torch.zeros(B48, N, M + 1, device=dev)
+    w[idx] = gsel
+    (mcg * w).sum().backward()
+    torch.cuda.synchronize()
+    gx_big = xg.grad[idx].clone()
+    rest = xg.grad.clone()
+    rest[idx] = 0
+    others = float(rest.abs().max())
+    del rest, mcg, w
+    xsg = xs.clone().requires_grad_(True)
+    (mcep(stft(xsg)) * gsel).sum().backward()
+    eq = torch.equal(gx_big, xsg.grad)
+    err = float((gx_big - xsg.grad).abs().max() / xsg.grad.abs().max())
+    print(f"  d mcep(stft(x)) / dx at 2048 / 49: bitwise equal to the small batch: {eq}; max |difference| / max |gradient| = {err:.3e}; "
+          f"finite: {bool(torch.isfinite(gx_big).all())}; peak memory {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB", flush=True)
+    print(f"  largest gradient magnitude on the other utterances (must be 0): {others:.3e}", flush=True)
+    global bad
+    bad += (err > 3e-6) + (others != 0.0)
 
 
 def run_all(b16=42000, b48=10600):
