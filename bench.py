@@ -620,7 +620,7 @@ def compact_line(res: dict, detail_path: str = DETAIL_FILE) -> str:
                                 "scaling", "vs_baseline", "dtype", "data") if k in res}
     cfg = res.get("config", {})
     line["config"] = {k: cfg[k] for k in ("workload", "utterances_per_gpu", "global_batch", "frames_per_step", "parallelism",
-                                          "rccl_world_size", "collective_backend", "kernels", "path", "launches_per_step", "streams") if k in cfg}
+                                          "rccl_world_size", "collective_backend", "reserved_cus", "kernels", "path", "launches_per_step", "streams") if k in cfg}
     for name in ("roofline", "roofline_stft", "roofline_mcep"):
         r = res.get(name)
         if r:
@@ -732,7 +732,7 @@ def main():
 
     import diffsptk_amd as dsp
     from diffsptk_amd import _lib, ops
-    from diffsptk_amd.dist import analyze_chunked_overlap
+    from diffsptk_amd.dist import analyze_chunked_overlap, reserved_cus
 
     algo = {"auto": _lib.ALGO_AUTO, "generic": _lib.ALGO_GENERIC, "tuned": _lib.ALGO_TUNED}[args.algo]
     B = args.batch
@@ -910,6 +910,7 @@ def main():
                 "path": args.path, "launches_per_step": 1 if args.path == "fused" else 2,
                 "utterances_per_gpu": B, "global_batch": B * world, "frames_per_step": frames_rank * world,
                 "parallelism": f"dp{world}", "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
+                "reserved_cus": (reserved_cus() if world > 1 else 0),   # CUs the persistent launches leave to RCCL's kernel (dist.reserved_cus)
                 "collective_backend": (dist.get_backend() if world > 1 else None), "kernels": kernels, "chunks_per_step": n_chunks, "streams": n_streams,
                 "arith": "float32 in / out / accumulate; the matrix chains of the mel-cepstral kernel run as 3-term "
                          "binary16 MFMA splits (hi/lo, dropped lo*lo: ~22-bit products), the STFT in packed float32",

@@ -46,6 +46,11 @@ ALGO_SCRATCH_IS_CLEAN = 0x100   # DSA_ALGO_SCRATCH_IS_CLEAN
 ALGO_SCRATCH_HAS_WORKSPACE = 0x200   # DSA_ALGO_SCRATCH_HAS_WORKSPACE
 ALGO_HIST_HAS_RT = 0x400             # DSA_ALGO_HIST_HAS_RT
 ALGO_OVERLAPPED_LAUNCHES = 0x800     # DSA_ALGO_OVERLAPPED_LAUNCHES
+
+
+def algo_reserve_cus(n: int) -> int:
+    """DSA_ALGO_RESERVE_CUS(n)"""
+    return (int(n) & 63) << 16
 MCEP_BWD_WORKSPACE_BYTES = SCRATCH_BYTES + 512 * 16 * 32 * 4   # DSA_MCEP_BWD_WORKSPACE_BYTES
 
 _lib = None

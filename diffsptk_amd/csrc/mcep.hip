@@ -340,11 +340,11 @@ int mcep_mfma_prepare(const void* G, const void* D, const void* E, void* images,
 struct StftIn;
 int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E, const void* av,
                   const void* images, void* scratch, void* mc, void* hist, hipStream_t st, bool scratch_clean = false,
-                  const StftIn* sti = nullptr, bool hist_has_rt = false, bool overlapped = false);
+                  const StftIn* sti = nullptr, bool hist_has_rt = false, bool overlapped = false, int reserve_cus = 0);
 int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, const void* window, const void* twiddle, double eps,
                         int n_iter, const void* G, const void* D, const void* E, const void* av, const void* images, void* scratch,
                         void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean, bool hist_has_rt, bool overlapped, int pad_mode,
-                        int zmean, float floor_lin);
+                        int zmean, float floor_lin, int reserve_cus);
 int mcep_mfma_bwd(const void* gmc, const void* X, const void* hist, int64_t F, int n_iter, const void* av,
                   const void* images, void* scratch, void* gX, hipStream_t st, bool has_workspace = false, bool hist_has_rt = false);
 
@@ -435,14 +435,16 @@ DSA_EXPORT int dsa_mcep_fwd(const void* X, int64_t F, int32_t nfft, int32_t M, i
     const bool scratch_clean = (algo & DSA_ALGO_SCRATCH_IS_CLEAN) != 0;
     const bool hist_has_rt = (algo & DSA_ALGO_HIST_HAS_RT) != 0;
     const bool overlapped = (algo & DSA_ALGO_OVERLAPPED_LAUNCHES) != 0;
-    algo &= ~(DSA_ALGO_SCRATCH_IS_CLEAN | DSA_ALGO_HIST_HAS_RT | DSA_ALGO_OVERLAPPED_LAUNCHES);
+    const int reserve_cus = DSA_ALGO_RESERVED_CUS(algo);
+    algo &= ~(DSA_ALGO_SCRATCH_IS_CLEAN | DSA_ALGO_HIST_HAS_RT | DSA_ALGO_OVERLAPPED_LAUNCHES | DSA_ALGO_RESERVE_CUS(63));
     bool tuned_ok = mcep_mfma_supported(nfft, M, dtype) != 0;
     if (algo == DSA_ALGO_TUNED && !tuned_ok)
         return fail(DSA_ERR_UNSUPPORTED, "mcep: tuned kernel needs float32, fft_length 512, cep_order 24%s");
     if (algo == DSA_ALGO_TUNED && !(images && scratch))
         return fail(DSA_ERR_INVALID_ARGUMENT, "mcep: the tuned kernel needs the prepared images (dsa_mcep_prepare) and a scratch buffer%s");
     if (tuned_ok && algo != DSA_ALGO_GENERIC && images && scratch)
-        return mcep_mfma_fwd(X, F, n_iter, G, D, E, alpha_vec, images, scratch, mc, mc_hist, st, scratch_clean, nullptr, hist_has_rt, overlapped);
+        return mcep_mfma_fwd(X, F, n_iter, G, D, E, alpha_vec, images, scratch, mc, mc_hist, st, scratch_clean, nullptr, hist_has_rt, overlapped,
+                             reserve_cus);
     if (dtype == DSA_F32) return mcep_generic_fwd<float>(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);
     if (dtype == DSA_F64) return mcep_generic_fwd<double>(X, F, nfft, M, n_iter, G, D, E, alpha_vec, mc, mc_hist, st);
     return fail(DSA_ERR_UNSUPPORTED, "mcep: unsupported dtype%s");
@@ -470,7 +472,8 @@ DSA_EXPORT int dsa_stft_mcep_opts_fwd(const void* x, int64_t B, int64_t T, int32
     DSA_REQUIRE(x && window && twiddle && G && D && E && alpha_vec && mc, "stft_mcep: null pointer");
     const float floor_lin = use_floor ? (float)pow(10.0, relative_floor_db / 10.0) : -1.f;
     return stft_mcep_fused_fwd(x, B, T, P, center, window, twiddle, eps, n_iter, G, D, E, alpha_vec, images, scratch, mc, mc_hist,
-                               X_out, (hipStream_t)stream, scratch_clean, hist_has_rt, overlapped, pad_mode, zmean != 0, floor_lin);
+                               X_out, (hipStream_t)stream, scratch_clean, hist_has_rt, overlapped, pad_mode, zmean != 0, floor_lin,
+                               DSA_ALGO_RESERVED_CUS(algo));
 }
 
 DSA_EXPORT int dsa_stft_mcep_fwd(const void* x, int64_t B, int64_t T, int32_t L, int32_t P, int32_t nfft, const void* window,

@@ -626,7 +626,7 @@ static unsigned int* reset_queue(void* scratch, hipStream_t st, int words = 2)
 // `sti`: NULL (spectra in X) or the waveform side of the fused STFT -> mel-cepstrum launch (X is then unused)
 int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const void* D, const void* E, const void* av,
                   const void* images, void* scratch, void* mc, void* hist, hipStream_t st, bool scratch_clean = false,
-                  const StftIn* sti = nullptr, bool hist_has_rt = false, bool overlapped = false)
+                  const StftIn* sti = nullptr, bool hist_has_rt = false, bool overlapped = false, int reserve_cus = 0)
 {
     // DSA_ALGO_HIST_HAS_RT: the caller's history buffer continues behind the (n_iter + 1, F, 25) iterates with (n_iter, F, 49) rows of rt
     float* hist_rt = (hist && hist_has_rt) ? (float*)hist + (size_t)(n_iter + 1) * (size_t)F * mm::M1 : nullptr;
@@ -646,6 +646,9 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
     long ntiles16 = (long)((F + 15) / 16);
     long blocks = (ntiles16 + WAVES - 1) / WAVES;
     long grid = blocks < 256 ? blocks : 256;  // one persistent workgroup per CU
+    // DSA_ALGO_RESERVE_CUS(n): n CUs stay free for a kernel of ANOTHER stream that has to run beside this launch (a collective's: a
+    // persistent workgroup fills its CU's LDS and registers, so nothing else starts on a CU before the launch's tail)
+    if (reserve_cus > 0 && grid == 256 && !overlapped) grid = 256 - (reserve_cus < 128 ? reserve_cus : 128);
     // the kernel zeroes the counters again when its last wave retires: a caller that vouches for a clean scratch
     // (DSA_ALGO_SCRATCH_IS_CLEAN) saves the fill launch
     unsigned int* queue = scratch_clean ? (unsigned int*)scratch : reset_queue(scratch, st, 3);
@@ -688,7 +691,7 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
 int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, const void* window, const void* twiddle, double eps,
                         int n_iter, const void* G, const void* D, const void* E, const void* av, const void* images, void* scratch,
                         void* mc, void* hist, void* X_out, hipStream_t st, bool scratch_clean, bool hist_has_rt, bool overlapped, int pad_mode,
-                        int zmean, float floor_lin)
+                        int zmean, float floor_lin, int reserve_cus)
 {
     const int64_t N = T <= 0 ? 0 : (T - 1) / P + 1;
     StftIn sti;
@@ -704,7 +707,7 @@ int stft_mcep_fused_fwd(const void* x, int64_t B, int64_t T, int P, int center, 
     sti.pad_mode = pad_mode;
     sti.zmean = zmean;
     sti.floor_lin = floor_lin;
-    return mcep_mfma_fwd(nullptr, B * N, n_iter, G, D, E, av, images, scratch, mc, hist, st, scratch_clean, &sti, hist_has_rt, overlapped);
+    return mcep_mfma_fwd(nullptr, B * N, n_iter, G, D, E, av, images, scratch, mc, hist, st, scratch_clean, &sti, hist_has_rt, overlapped, reserve_cus);
 }
 
 // mcep.py:208-222, all n_iter steps in one persistent launch, for orders 32 .. 54 (the 48 kHz set-ups fft_length 2048 / order 49 and

@@ -8,10 +8,23 @@ has no distributed code at all.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable
 
 import torch
 import torch.distributed as dist
+
+
+def reserved_cus() -> int:
+    """CUs the persistent analysis launches leave to the collective's kernel while a gather is in flight (ops.reserve_cus,
+    DSA_ALGO_RESERVE_CUS): a persistent workgroup fills its CU, so without free CUs RCCL's kernel starts in the launch's tail and the
+    next launch queues behind it -- measured with a stand-in collective of 16 workgroups x 350 us on a second stream
+    (tools/ab_reserve_cus.py, profiles/r06_reserve_cus_ab.txt): 0.91 ms per step with none reserved (analysis + exchange in series),
+    0.69 ms with 16 (the analysis alone: 0.58 on 256 CUs, 0.63 on 240).  DSA_RESERVE_CUS overrides (0: none)."""
+    try:
+        return max(0, min(63, int(os.environ.get("DSA_RESERVE_CUS", "16"))))
+    except ValueError:
+        return 16
 
 
 def shard_bounds(total: int, world_size: int, rank: int) -> tuple[int, int]:
@@ -136,12 +149,18 @@ def analyze_chunked_overlap(x_local: torch.Tensor, compute: Callable[[torch.Tens
         side.wait_stream(main)  # the input was produced on the current stream
     buf = None
     pending = []
+    if x_local.is_cuda:
+        from . import ops
+
+        reserve = ops.reserve_cus(reserved_cus())   # the gathers run beside the next chunk's / the next batch's launches
+    else:
+        reserve = _NullContext()
     for c in range(n_chunks):
         on_side = use_side and c % 2 == 1
         if on_side and buf is not None:
             side.wait_stream(main)  # `buf` was allocated on the current stream
         ctx = torch.cuda.stream(side) if on_side else _NullContext()
-        with ctx:
+        with ctx, reserve:
             feat = compute(x_local[c * Bc:(c + 1) * Bc]).contiguous()
             if buf is None:
                 buf = feat.new_empty((n_chunks, world, Bc, *feat.shape[1:]))

@@ -1212,6 +1212,29 @@ class overlapped_launches:
         return False
 
 
+_reserved_cus = [0]
+
+
+class reserve_cus:
+    """``with ops.reserve_cus(n):`` -- the tuned mel-cepstral forward launches (STFT -> mel-cepstrum in one launch, mcep alone) leave
+    ``n`` of the 256 CUs free (DSA_ALGO_RESERVE_CUS, include/diffsptk_amd.h).  A persistent workgroup fills its CU, so a kernel of
+    another stream -- RCCL's all-gather of the previous batch's features -- otherwise starts only in the launch's tail and the next
+    launch queues behind it.  dist.analyze_chunked_overlap sets it in a world of more than one rank.  Same bits; the launch itself
+    takes 256 / (256 - n) as long."""
+
+    def __init__(self, n: int):
+        self.n = max(0, min(63, int(n)))
+
+    def __enter__(self):
+        self.prev = _reserved_cus[0]
+        _reserved_cus[0] = self.n
+        return self
+
+    def __exit__(self, *exc):
+        _reserved_cus[0] = self.prev
+        return False
+
+
 def _mcep_scratch(device):
     """(scratch, algo flag) of a tuned mel-cepstral forward launch: the per-(device, stream) kept-zero counters
     (DSA_ALGO_SCRATCH_IS_CLEAN, no fill launch per call) -- except while a HIP graph is being captured: a graph replays on whatever
@@ -1219,8 +1242,9 @@ def _mcep_scratch(device):
     own block and the library's reset (a captured memset node) instead."""
     with torch.cuda.device(device):
         if torch.cuda.is_current_stream_capturing() or os.environ.get("DSA_CLEAN_SCRATCH", "1") == "0":   # (the variable: A/B runs)
-            return _scratch(device), 0
-        return _clean_scratch(device), _lib.ALGO_SCRATCH_IS_CLEAN | (_lib.ALGO_OVERLAPPED_LAUNCHES if _overlapped[0] else 0)
+            return _scratch(device), _lib.algo_reserve_cus(_reserved_cus[0])
+        return _clean_scratch(device), (_lib.ALGO_SCRATCH_IS_CLEAN | (_lib.ALGO_OVERLAPPED_LAUNCHES if _overlapped[0] else 0)
+                                        | _lib.algo_reserve_cus(_reserved_cus[0]))
 
 
 def stft_mcep_fusable(x, window, G, L, P, fft_length, M) -> bool:

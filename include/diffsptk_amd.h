@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define DSA_VERSION 128 /* 0.2.2: + dsa_mcep_newton_glogx_h (glogx of the 48 kHz analysis in one pass after the sweep; dsa_mcep_newton_resid_h_bwd takes glogx = NULL); twin workgroups in dsa_mcep_newton_steps; 0.2.1: + dsa_mcep_resid_bwd_images_bytes / _prepare, dsa_mcep_newton_resid_h_bwd (the 48 kHz analysis with a gradient: the step's backward in two launches); wide tiles in dsa_mcep_newton_steps; 0.2.0: + dsa_mcep_newton_steps, dsa_stft_mcep_opts_fwd, DSA_ALGO_OVERLAPPED_LAUNCHES, DSA_ALGO_PAD_MODE, packed STFT kernels for fft_length 1024 / 2048 and for every pad mode at 512; 0.1.9: + dsa_mgcep_step_solve, dsa_mgcep_step_bwd_h, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
+#define DSA_VERSION 129 /* 0.2.3: + DSA_ALGO_RESERVE_CUS; a zero count is a no-op before any pointer check; 0.2.2: + dsa_mcep_newton_glogx_h (glogx of the 48 kHz analysis in one pass after the sweep; dsa_mcep_newton_resid_h_bwd takes glogx = NULL); twin workgroups in dsa_mcep_newton_steps; 0.2.1: + dsa_mcep_resid_bwd_images_bytes / _prepare, dsa_mcep_newton_resid_h_bwd (the 48 kHz analysis with a gradient: the step's backward in two launches); wide tiles in dsa_mcep_newton_steps; 0.2.0: + dsa_mcep_newton_steps, dsa_stft_mcep_opts_fwd, DSA_ALGO_OVERLAPPED_LAUNCHES, DSA_ALGO_PAD_MODE, packed STFT kernels for fft_length 1024 / 2048 and for every pad mode at 512; 0.1.9: + dsa_mgcep_step_solve, dsa_mgcep_step_bwd_h, dsa_mcep_resid_images_bytes / _prepare, dsa_mcep_newton_resid_h; 0.1.8: + dsa_frame_window_lpc_bwd, DSA_LPC_EXACT_LAGSUMS, DSA_ALGO_HIST_HAS_RT; 0.1.7: + dsa_gnorm_fwd, dsa_mgcep_gain, DSA_LPC_SCRATCH_IS_CLEAN; 0.1.6: + dsa_mcep_newton_update_bwd; 0.1.5: + dsa_mcep_newton_resid; 0.1.4: dsa_stft_mcep_fwd (STFT -> mel-cepstrum in one launch), dsa_rows_gemm, dsa_rows_ew, dsa_mcep_newton_update */
 
 typedef enum {
     DSA_OK = 0,
@@ -98,6 +98,13 @@ enum { DSA_ALGO_AUTO = 0, DSA_ALGO_GENERIC = 1, DSA_ALGO_TUNED = 2 };
 /* OR-ed into `algo` of dsa_stft_mcep_fwd (0.2.0): the padding mode of Frame (frame.py:130-137; DSA_PAD_*, 0 = constant) for the
  * samples a frame reads outside its utterance -- the one-launch step then covers ShortTimeFourierTransform(mode=...) too. */
 #define DSA_ALGO_PAD_MODE(m) (((m) & 3) << 12)
+/* OR-ed into `algo` of dsa_mcep_fwd / dsa_stft_mcep_fwd / dsa_stft_mcep_opts_fwd (0.2.3): the persistent launch leaves n (<= 63) of the
+ * 256 CUs free.  A persistent workgroup fills its CU's LDS and registers, so a kernel of ANOTHER stream that has to run beside the
+ * launch -- RCCL's all-gather of the previous batch's features -- could otherwise only start in the launch's tail and the
+ * next launch would queue behind it: the exchange would be serial with the analysis instead of hidden behind it.  Same tiles, same
+ * arithmetic, same bits; the launch itself takes 256 / (256 - n) as long.  dist.py / bench.py set it when the world has > 1 rank. */
+#define DSA_ALGO_RESERVE_CUS(n) (((n) & 63) << 16)
+#define DSA_ALGO_RESERVED_CUS(algo) (((algo) >> 16) & 63)
 
 int dsa_version(void);
 const char* dsa_last_error(void);
