@@ -726,6 +726,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("DSA_BENCH_BACKEND", "nccl")   # "gloo" only for the one-GPU functional test
         if backend == "nccl":
+            from diffsptk_amd.dist import configure_rccl_for_overlap
+
+            configure_rccl_for_overlap()   # RCCL's kernel gets at most as many workgroups as CUs are left free for it (NCCL_MAX_NCHANNELS)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -910,7 +913,7 @@ def main():
                 "path": args.path, "launches_per_step": 1 if args.path == "fused" else 2,
                 "utterances_per_gpu": B, "global_batch": B * world, "frames_per_step": frames_rank * world,
                 "parallelism": f"dp{world}", "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
-                "reserved_cus": (reserved_cus() if world > 1 else 0),   # CUs the persistent launches leave to RCCL's kernel (dist.reserved_cus)
+                "reserved_cus": (reserved_cus() if world > 1 else 0), "nccl_max_nchannels": (os.environ.get("NCCL_MAX_NCHANNELS") if world > 1 else None),   # CUs the persistent launches leave to RCCL's kernel (dist.reserved_cus)
                 "collective_backend": (dist.get_backend() if world > 1 else None), "kernels": kernels, "chunks_per_step": n_chunks, "streams": n_streams,
                 "arith": "float32 in / out / accumulate; the matrix chains of the mel-cepstral kernel run as 3-term "
                          "binary16 MFMA splits (hi/lo, dropped lo*lo: ~22-bit products), the STFT in packed float32",

@@ -27,6 +27,19 @@ def reserved_cus() -> int:
         return 16
 
 
+def configure_rccl_for_overlap() -> int:
+    """Call BEFORE ``init_process_group("nccl")``: caps RCCL's channel count (``NCCL_MAX_NCHANNELS``, one workgroup per channel) at
+    the number of CUs the analysis launches leave free (``reserved_cus()``), unless the variable is already set.  The stand-in sweep
+    (profiles/r06_reserve_cus_ab.txt) shows why: a side kernel of W workgroups runs beside the persistent launch only when W CUs
+    are free -- 8 / 16 / 32 workgroups need 8 / 16 / 32 reserved CUs, 64 do not fit in 32 -- otherwise it waits for the launch's tail
+    and the exchange is serial with the analysis.  16 channels carry the 20 MB per peer of a step with room to spare (35 GB/s per
+    xGMI link are needed to hide it behind 0.6 ms of analysis).  Returns the reserved-CU count."""
+    n = reserved_cus()
+    if n > 0:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
+    return n
+
+
 def shard_bounds(total: int, world_size: int, rank: int) -> tuple[int, int]:
     """Contiguous, balanced split of ``total`` utterances: the first ``total % world_size``
     ranks get one extra.  Returns [lo, hi)."""
