@@ -648,7 +648,19 @@ int mcep_mfma_fwd(const void* X, int64_t F, int n_iter, const void* G, const voi
     long grid = blocks < 256 ? blocks : 256;  // one persistent workgroup per CU
     // DSA_ALGO_RESERVE_CUS(n): n CUs stay free for a kernel of ANOTHER stream that has to run beside this launch (a collective's: a
     // persistent workgroup fills its CU's LDS and registers, so nothing else starts on a CU before the launch's tail)
-    if (reserve_cus > 0 && grid == 256 && !overlapped) grid = 256 - (reserve_cus < 128 ? reserve_cus : 128);
+    if (reserve_cus > 0 && grid == 256 && !overlapped) {
+        // at least reserve_cus, and up to twice as many where they cost no further round of tiles: a launch is rounds of (8 grid) tiles, a
+        // short last round (at most half full) goes to one wave per SIMD pair and takes 0.8 of a round (below).  A side kernel whose
+        // workgroup count EQUALS the free CUs was measured to start late now and then (profiles/r06_reserve_cus_ab.txt): slack is cheap
+        auto rounds = [&](long g) {
+            const long s = g * WAVES, full = ntiles16 / s, rest = ntiles16 - full * s;
+            return (double)full + (rest == 0 ? 0.0 : (full > 0 && rest <= s / 2) ? 0.8 : 1.0);
+        };
+        const long g_hi = 256 - (reserve_cus < 63 ? reserve_cus : 63), g_lo = 256 - 2 * (reserve_cus < 63 ? reserve_cus : 63) < 128 ? 128 : 256 - 2 * (reserve_cus < 63 ? reserve_cus : 63);
+        grid = g_hi;
+        for (long g = g_hi - 1; g >= g_lo; --g)
+            if (rounds(g) <= rounds(g_hi) + 1e-9) grid = g;
+    }
     // the kernel zeroes the counters again when its last wave retires: a caller that vouches for a clean scratch
     // (DSA_ALGO_SCRATCH_IS_CLEAN) saves the fill launch
     unsigned int* queue = scratch_clean ? (unsigned int*)scratch : reset_queue(scratch, st, 3);

@@ -23,6 +23,9 @@ D = float(sys.argv[2]) if len(sys.argv) > 2 else 350.0
 dev = torch.device("cuda", 0)
 occ = ctypes.CDLL(os.path.join(ROOT, "build", "liboccupy.so"))
 occ.occupy.argtypes = [ctypes.c_int, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p]
+occ.occupy_sleep.argtypes = [ctypes.c_int, ctypes.c_long, ctypes.c_void_p]
+MODE = os.environ.get("STANDIN", "ordered")   # ordered: after the step's kernel, completed one step later (bench.py's deferred gather) |
+                                               # free: launched on the second stream with no dependency either way | sleep: ordered, a kernel that only sleeps
 sink = torch.zeros(4, dtype=torch.int32, device=dev)
 x = torch.randn(1024, 16000, device=dev)
 stft = dsp.STFT(400, 80, 512, device=dev)
@@ -39,11 +42,16 @@ def run(n_reserve, with_standin, steps=200):
     with torch.no_grad(), ops.reserve_cus(n_reserve):
         def step():
             y = fused(x)
-            if with_standin:
+            if with_standin and MODE == "free":
+                occ.occupy(W, int(D * 1000), sink.data_ptr(), side.cuda_stream)
+            elif with_standin:
                 e = torch.cuda.Event()
                 e.record(main)
                 side.wait_event(e)
-                occ.occupy(W, int(D * 1000), sink.data_ptr(), side.cuda_stream)
+                if MODE == "sleep":
+                    occ.occupy_sleep(W, int(D * 1000), side.cuda_stream)
+                else:
+                    occ.occupy(W, int(D * 1000), sink.data_ptr(), side.cuda_stream)
                 g = torch.cuda.Event()
                 g.record(side)
                 pending.append(g)
@@ -65,8 +73,8 @@ def run(n_reserve, with_standin, steps=200):
 
 
 if __name__ == "__main__":
-    print(f"stand-in collective: {W} workgroups x {D:.0f} us on a second stream, completed one step later", flush=True)
-    for rep in range(2):
+    print(f"stand-in collective: {W} workgroups x {D:.0f} us on a second stream, mode {MODE}", flush=True)
+    for rep in range(int(os.environ.get("REPS", "2"))):
         base = run(0, False)
         print(f"  no collective, all 256 CUs: {base:.4f} ms per step", flush=True)
         for n in (0, 8, 16, 24, 32):

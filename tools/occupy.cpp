@@ -16,6 +16,18 @@ __global__ __launch_bounds__(256) void occupy_kernel(long ns, unsigned* sink)
     if (acc == 0xffffffffu) *sink = acc;
 }
 
+__global__ __launch_bounds__(256) void occupy_sleep_kernel(long ns)   // no LDS, no memory: sleeps only
+{
+    const unsigned long long t0 = wall_clock64();
+    while ((long)(wall_clock64() - t0) * 10 < ns) __builtin_amdgcn_s_sleep(127);
+}
+
+extern "C" int occupy_sleep(int wgs, long ns, void* stream)
+{
+    hipLaunchKernelGGL(occupy_sleep_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, ns);
+    return (int)hipGetLastError();
+}
+
 extern "C" int occupy(int wgs, long ns, void* sink, void* stream)
 {
     hipLaunchKernelGGL(occupy_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, ns, (unsigned*)sink);
