@@ -8,7 +8,7 @@ alpha=0.42, n_iter=10) on synthetic 16 kHz waveforms, one process per GPU.
 
 A "step" is one pass of the hot path over this rank's shard of utterances (inputs resident in
 HBM): fused STFT kernel -> mel-cepstral analysis kernel -> (N > 1) ONE in-place all-gather of the
-(B, 200, 25) features over RCCL, left in flight and completed one step later so that it runs behind the
+(B, 200, 25) features over RCCL, left in flight and completed two steps later (dist.GATHER_DEPTH) so that it runs behind the
 next step's kernels.  Weak scaling: 1024 utterances x 1 s per GPU, so N = 8 is BASELINE.json configs[4]
 (batch 8192 sharded 8x) and N = 1 is its per-GPU shard.
 
@@ -620,7 +620,7 @@ def compact_line(res: dict, detail_path: str = DETAIL_FILE) -> str:
                                 "scaling", "vs_baseline", "dtype", "data") if k in res}
     cfg = res.get("config", {})
     line["config"] = {k: cfg[k] for k in ("workload", "utterances_per_gpu", "global_batch", "frames_per_step", "parallelism",
-                                          "rccl_world_size", "collective_backend", "reserved_cus", "kernels", "path", "launches_per_step", "streams") if k in cfg}
+                                          "rccl_world_size", "collective_backend", "reserved_cus", "gather_depth", "kernels", "path", "launches_per_step", "streams") if k in cfg}
     for name in ("roofline", "roofline_stft", "roofline_mcep"):
         r = res.get(name)
         if r:
@@ -726,16 +726,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("DSA_BENCH_BACKEND", "nccl")   # "gloo" only for the one-GPU functional test
         if backend == "nccl":
-            from diffsptk_amd.dist import configure_rccl_for_overlap
-
-            configure_rccl_for_overlap()   # RCCL's kernel gets at most as many workgroups as CUs are left free for it (NCCL_MAX_NCHANNELS)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import diffsptk_amd as dsp
     from diffsptk_amd import _lib, ops
-    from diffsptk_amd.dist import analyze_chunked_overlap, reserved_cus
+    from diffsptk_amd.dist import GATHER_DEPTH, analyze_chunked_overlap, reserved_cus
 
     algo = {"auto": _lib.ALGO_AUTO, "generic": _lib.ALGO_GENERIC, "tuned": _lib.ALGO_TUNED}[args.algo]
     B = args.batch
@@ -781,7 +778,7 @@ def main():
             kernels["mcep"] = _lib.last_kernel()
         return mc
 
-    in_flight = []   # N > 1: (features, handle) of the previous step, whose all-gather overlaps this step
+    in_flight = []   # N > 1: (features, handle) of the last GATHER_DEPTH steps, whose all-gathers overlap this step
 
     # Steps are independent batches.  With --streams 2 they alternate between two side streams and every launch carries
     # DSA_ALGO_OVERLAPPED_LAUNCHES (ops.overlapped_launches): a launch's short last round is packed onto a quarter of the CUs and
@@ -797,14 +794,14 @@ def main():
 
     def step_body(record):
         # N > 1: the features are all-gathered (RCCL, one in-place all_gather_into_tensor) and the collective is left in
-        # flight and completed one step later (a streaming consumer reads batch k while batch k+1 is computed), so it
-        # hides behind the next step's kernels instead of ending every step
+        # flight and completed GATHER_DEPTH = 2 steps later (a streaming consumer reads batch k while batch k+2 is computed), so it
+        # hides behind the next steps' kernels instead of ending every step
         if world == 1:
             return analyze_chunked_overlap(x, lambda xc: compute(xc, record), n_chunks)
         out, handle = analyze_chunked_overlap(x, lambda xc: compute(xc, record), n_chunks, defer=True)
         in_flight.append((out, handle))
-        while len(in_flight) > 1:
-            in_flight.pop(0)[1].wait()
+        while len(in_flight) > GATHER_DEPTH:   # completed TWO steps later: a gather starts in its step's tail and runs into the next launch
+            in_flight.pop(0)[1].wait()     # (completed ONE step later the analysis and the exchange run in series: dist.reserved_cus)
         return out
 
     def step(record=False):
@@ -913,7 +910,7 @@ def main():
                 "path": args.path, "launches_per_step": 1 if args.path == "fused" else 2,
                 "utterances_per_gpu": B, "global_batch": B * world, "frames_per_step": frames_rank * world,
                 "parallelism": f"dp{world}", "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
-                "reserved_cus": (reserved_cus() if world > 1 else 0), "nccl_max_nchannels": (os.environ.get("NCCL_MAX_NCHANNELS") if world > 1 else None),   # CUs the persistent launches leave to RCCL's kernel (dist.reserved_cus)
+                "reserved_cus": (reserved_cus() if world > 1 else 0), "gather_depth": (GATHER_DEPTH if world > 1 else 0),   # CUs the persistent launches leave to RCCL's kernel (dist.reserved_cus)
                 "collective_backend": (dist.get_backend() if world > 1 else None), "kernels": kernels, "chunks_per_step": n_chunks, "streams": n_streams,
                 "arith": "float32 in / out / accumulate; the matrix chains of the mel-cepstral kernel run as 3-term "
                          "binary16 MFMA splits (hi/lo, dropped lo*lo: ~22-bit products), the STFT in packed float32",

@@ -16,28 +16,24 @@ import torch.distributed as dist
 
 
 def reserved_cus() -> int:
-    """CUs the persistent analysis launches leave to the collective's kernel while a gather is in flight (ops.reserve_cus,
-    DSA_ALGO_RESERVE_CUS): a persistent workgroup fills its CU, so without free CUs RCCL's kernel starts in the launch's tail and the
-    next launch queues behind it -- measured with a stand-in collective of 16 workgroups x 350 us on a second stream
-    (tools/ab_reserve_cus.py, profiles/r06_reserve_cus_ab.txt): 0.91 ms per step with none reserved (analysis + exchange in series),
-    0.69 ms with 16 (the analysis alone: 0.58 on 256 CUs, 0.63 on 240).  DSA_RESERVE_CUS overrides (0: none)."""
+    """CUs the persistent analysis launches leave free while gathers are in flight (ops.reserve_cus, DSA_ALGO_RESERVE_CUS;
+    DSA_RESERVE_CUS overrides, 0: none).  A persistent workgroup fills its CU, so the collective's kernel -- on RCCL's own stream --
+    starts in a launch's tail and keeps its CUs into the next launch.  What that costs depends on WHEN the analysis waits for it,
+    measured with a stand-in collective (W workgroups holding their CUs for 350 us on a second stream, ordered after the step's kernel;
+    tools/ab_reserve_cus.py, profiles/r06_reserve_cus_ab.txt; the analysis alone: 0.584 ms per step):
+      * completed ONE step later (the next step's launch waits for it):  0.86-0.92 ms with no CU reserved -- analysis and exchange in
+        series --, 0.69 with 16-27 reserved;
+      * completed TWO steps later (GATHER_DEPTH = 2, what bench.py does):  0.627 ms with none reserved, **0.618 with 8** (0.65 / 0.66 for
+        32 / 64 workgroups: any channel count fits); three steps: the same.
+    Hence 8 (the launcher rounds up to 9 where that costs no round of tiles: +1.2 % on the launch alone)."""
     try:
-        return max(0, min(63, int(os.environ.get("DSA_RESERVE_CUS", "16"))))
+        return max(0, min(63, int(os.environ.get("DSA_RESERVE_CUS", "8"))))
     except ValueError:
-        return 16
+        return 8
 
 
-def configure_rccl_for_overlap() -> int:
-    """Call BEFORE ``init_process_group("nccl")``: caps RCCL's channel count (``NCCL_MAX_NCHANNELS``, one workgroup per channel) at
-    the number of CUs the analysis launches leave free (``reserved_cus()``), unless the variable is already set.  The stand-in sweep
-    (profiles/r06_reserve_cus_ab.txt) shows why: a side kernel of W workgroups runs beside the persistent launch only when W CUs
-    are free -- 8 / 16 / 32 workgroups need 8 / 16 / 32 reserved CUs, 64 do not fit in 32 -- otherwise it waits for the launch's tail
-    and the exchange is serial with the analysis.  16 channels carry the 20 MB per peer of a step with room to spare (35 GB/s per
-    xGMI link are needed to hide it behind 0.6 ms of analysis).  Returns the reserved-CU count."""
-    n = reserved_cus()
-    if n > 0:
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
-    return n
+#: how many batches later a streaming caller should complete a deferred gather (PendingGather.wait()): see reserved_cus()
+GATHER_DEPTH = 2
 
 
 def shard_bounds(total: int, world_size: int, rank: int) -> tuple[int, int]:

@@ -55,7 +55,7 @@ def run(n_reserve, with_standin, steps=200):
                 g = torch.cuda.Event()
                 g.record(side)
                 pending.append(g)
-                while len(pending) > 1:
+                while len(pending) > (10 ** 9 if MODE == "nowait" else int(os.environ.get("DEPTH", "1"))):   # nowait: the analysis never waits for the stand-in
                     main.wait_event(pending.pop(0))
             return y
         for _ in range(30):
