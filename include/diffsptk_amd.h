@@ -102,7 +102,9 @@ enum { DSA_ALGO_AUTO = 0, DSA_ALGO_GENERIC = 1, DSA_ALGO_TUNED = 2 };
  * 256 CUs free.  A persistent workgroup fills its CU's LDS and registers, so a kernel of ANOTHER stream that has to run beside the
  * launch -- RCCL's all-gather of the previous batch's features -- could otherwise only start in the launch's tail and the
  * next launch would queue behind it: the exchange would be serial with the analysis instead of hidden behind it.  Same tiles, same
- * arithmetic, same bits; the launch itself takes 256 / (256 - n) as long.  dist.py / bench.py set it when the world has > 1 rank. */
+ * arithmetic, same bits.  The launcher leaves at least n and up to 2 n CUs where that costs no further round of tiles.  Measured with a stand-in
+ * collective (profiles/r06_reserve_cus_ab.txt): what matters most is WHEN the caller waits for the collective -- two batches later, 8 CUs
+ * suffice (0.618 ms per step against 0.584 alone); one batch later the two run in series whatever is reserved below 16.  dist.py sets it. */
 #define DSA_ALGO_RESERVE_CUS(n) (((n) & 63) << 16)
 #define DSA_ALGO_RESERVED_CUS(algo) (((algo) >> 16) & 63)
 
