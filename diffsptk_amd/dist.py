@@ -133,8 +133,9 @@ def analyze_chunked_overlap(x_local: torch.Tensor, compute: Callable[[torch.Tens
     1024 utterances; 4 chunks cost +20 %).
 
     ``defer=True`` returns ``(features, PendingGather)`` without waiting for the collectives: the LAST chunk's
-    all-gather has nothing of this call left to hide behind, but the caller's next batch can -- call
-    ``PendingGather.wait()`` before the features are read (a streaming caller does so one batch later).
+    all-gather has nothing of this call left to hide behind, but the caller's next batches can -- call
+    ``PendingGather.wait()`` before the features are read; a streaming caller does so ``GATHER_DEPTH`` = 2 batches later
+    (one batch later the next launch waits for a kernel that could only start in this launch's tail: reserved_cus()).
     ``force_collective`` runs the collectives even in a world of one (functional test of the RCCL path on one GPU).
     """
     if layout not in ("rank_major", "chunk_major"):
