@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """An OPTION GRID through the reference's modules of the path and its consumers: for every case the input (seeded), the reference's
-output (float64 -> stored as float32 to stay small) -- a crash / shape / value smoke of rarely used option paths.  Build container only
+output and the gradient of a seeded linear functional of it w.r.t. the input (float64) -- a crash / shape / value smoke of rarely used option paths.  Build container only
 (imports /root/reference); writes tests/golden/option_grid.npz + option_grid.json (the cases: module, args, kwargs, input recipe).
 """
 import json
@@ -98,8 +98,19 @@ def main():
         except TypeError:
             m = getattr(d, name)(*args, **kwargs)
         extra = {"out_length": 200} if name in ("ISTFT", "Unframe") else {}
-        y = m(x, **extra)
+        xg = x.clone().requires_grad_(True)
+        y = m(xg, **extra)
         ys = y if isinstance(y, (tuple, list)) else (y,)
+        # gradient of sum_j <w_j, y_j> w.r.t. the input, w_j seeded per case (complex outputs / inputs through their real views)
+        gw = torch.Generator().manual_seed(1000 + i)
+        loss = 0
+        for j, t in enumerate(ys):
+            tr = torch.view_as_real(t) if t.is_complex() else t
+            wj = torch.randn(tr.shape, generator=gw, dtype=f64)
+            out[f"w{i}_{j}"] = wj.numpy()
+            loss = loss + (tr * wj).sum()
+        (gx,) = torch.autograd.grad(loss, xg)
+        out[f"gx{i}"] = torch.view_as_real(gx).numpy() if gx.is_complex() else gx.numpy()
         out[f"x{i}"] = torch.view_as_real(x).numpy() if x.is_complex() else x.numpy()
         for j, t in enumerate(ys):
             t = torch.view_as_real(t) if t.is_complex() else t
