@@ -593,3 +593,38 @@ def test_read_write_wav_round_trip(tmp_path):
     assert z.shape == (x.numel(), 2) and float((z[:, 0] - x).abs().max()) < 1e-9
     with pytest.raises(TypeError):
         dsp.write(p, x, 16000, endian="BIG")
+
+
+def test_api_surface_is_the_references():
+    """SURVEY 8(b) mechanically: the constructor / forward signatures of the 35 exported classes, the 26 functionals and `read` / `write` /
+    `get_alpha` equal the reference's (names, kinds, defaults; this repo may add `device` / `dtype` where the reference has none), and 65
+    invalid option sets raise the reference's exception type with the reference's text (tests/golden/api_surface.json, generated by
+    importing the reference: tests/golden/make_golden_api_surface.py)."""
+    import json
+
+    import diffsptk_amd.functional as OF
+
+    surf = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "api_surface.json")))
+
+    def sig(f):
+        return [[p.name, p.kind.name, None if p.default is inspect._empty else repr(p.default)] for p in inspect.signature(f).parameters.values()]
+
+    def strip(s):
+        return [p for p in s if p[0] not in ("device", "dtype")]
+
+    assert len(surf["classes"]) >= 35 and len(surf["functional"]) >= 26 and len(surf["errors"]) >= 65
+    for name, want in surf["classes"].items():
+        cls = getattr(dsp, name)
+        assert strip(sig(cls.__init__)) == strip(want["init"]), (name, "__init__")
+        assert strip(sig(cls.forward)) == strip(want["forward"]), (name, "forward")
+    for name, want in surf["functions"].items():
+        assert sig(getattr(dsp, name)) == want, name
+    for name, want in surf["functional"].items():
+        assert sig(getattr(OF, name)) == want, ("functional", name)
+    for c in surf["errors"]:
+        try:
+            getattr(dsp, c["module"])(*c["args"], **c["kwargs"])
+            got = ["ok", ""]
+        except Exception as e:   # noqa: BLE001
+            got = [type(e).__name__, str(e)]
+        assert got == c["raises"], (c["module"], c["args"], c["kwargs"], got, c["raises"])
