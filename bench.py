@@ -756,7 +756,7 @@ def main():
             e[0].record()
         if args.path == "fused":   # one launch: the spectrogram never exists
             if record:
-                e[1].record()
+                e[1] = e[0]        # (one event in front of the launch: every record is a marker packet between two launches of the timed region)
             mc = ops.StftMcepFn.apply(xc, stft.window, stft.twiddle, mcep.G, mcep.D, mcep.E, mcep.alpha_vector, FL, FP, NFFT, True,
                                       1e-9, M, N_ITER)
             if record:
