@@ -72,7 +72,7 @@ def main():
         except Exception as e:   # noqa: BLE001
             res = [type(e).__name__, str(e)]
         out["errors"].append({"module": name, "args": args, "kwargs": kw, "raises": res})
-    json.dump(out, open(os.path.join(HERE, "api_surface.json"), "w"), indent=0)
+    json.dump(out, open(os.path.join(HERE, "api_surface.json"), "w"), separators=(",", ":"))
     print(len(out["classes"]), "classes,", len(out["functional"]), "functionals,", len(out["errors"]), "error cases")
 
 

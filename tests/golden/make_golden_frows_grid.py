@@ -62,7 +62,7 @@ def main():
             if phase == "minimum":
                 record(f"mlsa {mode} {phase}: d/dmc", lambda c, m=m: m(x, c), mc, {"kind": "mlsa", "mode": mode, "phase": phase, "kwargs": kw, "input": "mc", "wrt": "mc"})
     np.savez_compressed(os.path.join(HERE, "frows_grid.npz"), **out)
-    json.dump(meta, open(os.path.join(HERE, "frows_grid.json"), "w"), indent=0)
+    json.dump(meta, open(os.path.join(HERE, "frows_grid.json"), "w"), separators=(",", ":"))
     print("wrote", len(meta), "cases")
 
 

@@ -118,7 +118,7 @@ def main():
         meta.append({"module": name, "args": args, "kwargs": kwargs, "input": recipe, "complex_input": bool(x.is_complex()),
                      "n_out": len(ys), "extra": extra})
     np.savez_compressed(os.path.join(HERE, "option_grid.npz"), **out)
-    json.dump(meta, open(os.path.join(HERE, "option_grid.json"), "w"), indent=0)
+    json.dump(meta, open(os.path.join(HERE, "option_grid.json"), "w"), separators=(",", ":"))
     print(f"wrote {len(meta)} cases")
 
 

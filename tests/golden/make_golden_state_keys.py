@@ -67,7 +67,7 @@ def main():
         out.append({"module": name, "args": args, "kwargs": kwargs,
                     "state": {k: list(v.shape) for k, v in m.state_dict().items()}})
     with open(os.path.join(HERE, "state_keys.json"), "w") as f:
-        json.dump(out, f, indent=1)
+        json.dump(out, f, separators=(",", ":"))
     print(f"wrote {len(out)} cases")
 
 

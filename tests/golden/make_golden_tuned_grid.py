@@ -66,7 +66,7 @@ def main():
         lp = d.LPC(FL, M, eps=1e-5, dtype=f64)
         record(f"lpc(window(frame {o}))", lambda z, fr=fr, wi=wi, lp=lp: lp(wi(fr(z))), {"kind": "lpc", "frame": o})
     np.savez_compressed(os.path.join(HERE, "tuned_grid.npz"), **out)
-    json.dump(meta, open(os.path.join(HERE, "tuned_grid.json"), "w"), indent=0)
+    json.dump(meta, open(os.path.join(HERE, "tuned_grid.json"), "w"), separators=(",", ":"))
     print("wrote", len(meta), "cases")
 
 

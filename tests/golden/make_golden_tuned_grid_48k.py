@@ -48,7 +48,7 @@ def main():
             mc = d.MelCepstralAnalysis(fft_length=NFFT, cep_order=M, alpha=alpha, n_iter=10, dtype=f64)
             record(f"mcep {NFFT}/{M} (stft {o})", lambda z, st=st, mc=mc: mc(st(z)), {"kind": "mcep", "stft": o})
     np.savez_compressed(os.path.join(HERE, "tuned_grid_48k.npz"), **out)
-    json.dump(meta, open(os.path.join(HERE, "tuned_grid_48k.json"), "w"), indent=0)
+    json.dump(meta, open(os.path.join(HERE, "tuned_grid_48k.json"), "w"), separators=(",", ":"))
     print("wrote", len(meta), "cases")
 
 
